@@ -1,0 +1,148 @@
+"""Generate tests/golden/*.npz by IMPORTING the reference (LienM/recpack v0.3.6) from /root/reference.
+
+Run in the build container only (the reference does not travel to the GPU box):
+
+    python oracle/gen_golden.py
+
+Every file holds inputs (CSR arrays) and the outputs the reference computed for them:
+``ItemKNN(...).fit(X).similarity_matrix_``, ``EASE(...).fit(X).similarity_matrix_`` and ``predict``.
+The fixtures named ``ref_*`` re-create the reference's own test fixtures (values written out here as
+data; file:line given per case), the ``syn_*`` ones are seeded synthetic power-law matrices.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+
+if not hasattr(np, "product"):  # recpack/algorithms/ease.py:105 uses the alias removed in numpy 2
+    np.product = np.prod
+
+from recpack.algorithms import EASE, ItemKNN  # noqa: E402
+from recpack.util import get_top_K_values  # noqa: E402
+
+from recpack_amd.synth import powerlaw_csr  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+warnings.simplefilter("ignore")
+
+
+def csr_parts(prefix, M):
+    M = sp.csr_matrix(M)
+    return {
+        f"{prefix}_indptr": M.indptr.astype(np.int64),
+        f"{prefix}_indices": M.indices.astype(np.int32),
+        f"{prefix}_data": M.data.astype(np.float64),
+        f"{prefix}_shape": np.asarray(M.shape, dtype=np.int64),
+    }
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def cosine_full(X):
+    from recpack.algorithms.nearest_neighbour import compute_cosine_similarity
+    from recpack.matrix import to_csr_matrix
+
+    S = compute_cosine_similarity(to_csr_matrix(X, binary=True))
+    S = sp.csr_matrix(S)
+    S.sort_indices()
+    return S
+
+
+def itemknn_case(name, X, Ks, predict_in=None, **kw):
+    arrays = dict(csr_parts("X", X))
+    arrays["Ks"] = np.asarray(Ks, dtype=np.int64)
+    arrays.update(csr_parts("cos", cosine_full(X)))  # all candidates incl. explicit diagonal zeros
+    for K in Ks:
+        algo = ItemKNN(K=K, **kw).fit(X)
+        S = sp.csr_matrix(algo.similarity_matrix_)
+        S.sort_indices()
+        arrays.update(csr_parts(f"S{K}", S))
+        if predict_in is not None:
+            for n, P in enumerate(predict_in):
+                arrays.update(csr_parts(f"Pin{n}", P))
+                out = algo.predict(P)
+                out.sort_indices()
+                arrays.update(csr_parts(f"Pout{K}_{n}", out))
+    save(name, **arrays)
+
+
+def ease_case(name, X, params, predict_in=None):
+    arrays = dict(csr_parts("X", X))
+    arrays["l2"] = np.asarray([p[0] for p in params], dtype=np.float64)
+    arrays["alpha"] = np.asarray([p[1] for p in params], dtype=np.float64)
+    for n, (l2, alpha) in enumerate(params):
+        algo = EASE(l2=l2, alpha=alpha).fit(X)
+        arrays[f"B{n}"] = algo.similarity_matrix_.toarray()
+        if predict_in is not None:
+            arrays.update(csr_parts("Pin", predict_in))
+            arrays[f"Pout{n}"] = algo.predict(predict_in).toarray()
+    save(name, **arrays)
+
+
+def main():
+    # --- reference fixture: recpack/tests/test_algorithms/test_nearest_neighbour.py:24-31 (data), :61, :67 (predict inputs)
+    data = sp.csr_matrix(([1] * 7, ([0, 0, 1, 1, 2, 2, 2], [1, 2, 0, 2, 0, 1, 2])), shape=(4, 3))
+    p1 = sp.csr_matrix(([1, 1, 1], ([0, 1, 2], [0, 1, 2])), shape=(3, 3))
+    p2 = sp.csr_matrix(([1, 1], ([0, 0], [0, 1])), shape=(1, 3))
+    itemknn_case("ref_itemknn_data", data, [1, 2, 10], predict_in=[p1, p2])
+    # normalize_sim on the same data (test_nearest_neighbour.py:110-116)
+    itemknn_case("ref_itemknn_data_normsim", data, [2], normalize_sim=True)
+    # --- test_nearest_neighbour.py:34-41 (data_empty_col)
+    dec = sp.csr_matrix(([1] * 5, ([0, 0, 1, 1, 2], [1, 2, 2, 1, 2])))
+    itemknn_case("ref_itemknn_empty_col", dec, [2])
+    # --- recpack/tests/test_algorithms/conftest.py:24-34 (X_in, counts > 1) with column 4 emptied
+    # as in test_algorithms_base.py:49-67
+    x_in = sp.csr_matrix(([1, 2, 1, 1, 1, 1], ([0, 0, 0, 2, 2, 2], [0, 2, 3, 1, 3, 1])), shape=(10, 5))
+    itemknn_case("ref_itemknn_x_in", x_in, [2], predict_in=[x_in])
+    # --- recpack/tests/test_algorithms/conftest.py:42-58 (larger_matrix, seed 400; duplicates -> counts > 1)
+    np.random.seed(400)
+    us = [np.random.randint(0, 500) for _ in range(2000)]
+    it = [np.random.randint(0, 500) for _ in range(2000)]
+    larger = sp.csr_matrix(([1] * 2000, (us, it)), shape=(700, 500))
+    itemknn_case("ref_itemknn_larger_matrix", larger, [3, 200], predict_in=[larger[:50]])
+    ease_case("ref_ease_larger_matrix", larger, [(10.0, 0.0)], predict_in=larger[:20])
+    # --- recpack/tests/test_algorithms/test_ease.py:16-35 (data) + :44 predict input, alphas of :66-87
+    ed = sp.csr_matrix(([1] * 9, ([0, 0, 1, 1, 2, 2, 2, 3, 3], [0, 2, 0, 2, 0, 1, 2, 0, 2])), shape=(5, 3))
+    ease_case("ref_ease_data", ed, [(0.03, 0), (200.0, 0), (0.03, 1), (0.03, 2)], predict_in=p1)
+    # prune (test_ease.py:90-105): matrix before/after _prune at density 2/9
+    algo = EASE(l2=0.03, density=2 / 9)
+    algo.similarity_matrix_ = sp.csr_matrix(
+        ([0.9, 0.8, 0.7, 0.2, -0.9, -0.6], ([0, 0, 1, 1, 2, 2], [1, 2, 0, 2, 0, 1]))
+    )
+    before = algo.similarity_matrix_.toarray()
+    algo._prune()
+    save("ref_ease_prune", before=before, after=algo.similarity_matrix_.toarray(), density=np.asarray(2 / 9))
+    # --- recpack/tests/conftest.py:55-66 (data_knn) + recpack/tests/test_util.py:49-62
+    dk = sp.csr_matrix(([0.3, 0.2, 0.1, 0.23, 0.3, 0.5], ([0, 0, 0, 2, 2, 2], [0, 2, 3, 1, 3, 4])), shape=(10, 5))
+    save("ref_topk_data_knn", **csr_parts("X", dk), **csr_parts("top2", get_top_K_values(dk, 2)))
+
+    # --- seeded synthetic power-law matrices
+    m = powerlaw_csr(2000, 500, 0.02, seed=20260101).to_scipy()
+    # duplicate a few interactions (counts > 1 must binarise to the same result)
+    m_dup = m.copy().astype(np.int32)
+    m_dup.data[::7] = 3
+    itemknn_case("syn_itemknn_2000x500", m_dup, [10, 50, 600], predict_in=[m[:300]])
+    ease_case("syn_ease_2000x500", m_dup, [(200.0, 0.0), (5.0, 0.5)], predict_in=m[:100])
+    m2 = powerlaw_csr(10000, 2000, 0.004, seed=20260102).to_scipy()
+    algo = ItemKNN(K=100).fit(m2)
+    S = sp.csr_matrix(algo.similarity_matrix_)
+    S.sort_indices()
+    cosf = cosine_full(m2)
+    # per-row K'-th reference value (threshold of the tie-aware rule) instead of the full 2000^2 candidates
+    save("syn_itemknn_10000x2000", **csr_parts("X", m2), **csr_parts("S100", S), Ks=np.asarray([100]),
+         cos_row_nnz=np.diff(cosf.indptr).astype(np.int64))
+
+
+if __name__ == "__main__":
+    main()

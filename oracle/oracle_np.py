@@ -1,0 +1,215 @@
+"""CPU ORACLE (numpy/scipy) for the item-similarity hot path of LienM/recpack v0.3.6.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``recpack_amd/`` may import this module: it is the
+checker for ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py``.
+
+Parity status: PINNED.  ``oracle/gen_golden.py`` imports the reference from /root/reference in
+the build container, runs ``ItemKNN``/``EASE`` ``fit``/``predict`` on the reference's own test
+fixtures and on seeded synthetic matrices, and stores inputs + outputs under ``tests/golden``;
+``tests/test_oracle_golden.py`` checks every function here against those vectors.
+
+Each function restates one step of the reference (file:line relative to /root/reference):
+
+* ``binarize``            recpack/util.py:99-109 (``to_binary``) via recpack/matrix/util.py:27-48
+* ``item_degrees``        diag(X^T X); the l2 norms sklearn ``normalize`` uses inside
+                          ``cosine_similarity`` (recpack/algorithms/nearest_neighbour.py:80)
+* ``gram_counts``         X^T X as integer co-occurrence counts (nearest_neighbour.py:80, ease.py:81)
+* ``itemknn_fit``         compute_cosine_similarity + setdiag(0) + get_top_K_values
+                          (nearest_neighbour.py:69-84, :204-224; recpack/util.py:50-96)
+* ``predict_full``        ItemSimilarityMatrixAlgorithm._predict, ``X @ similarity_matrix_``
+                          (recpack/algorithms/base.py:237-255)
+* ``topk_rows``           per-row top-K as used on predictions by the metrics
+                          (recpack/util.py:50-77, recpack/metrics/base.py:189)
+* ``ease_fit``            EASE._fit (recpack/algorithms/ease.py:63-95)
+
+Deterministic ordering (the reference's own tie order is an artefact of numpy's introselect and of
+scipy's unsorted SpGEMM output): larger key first, then SMALLER column index.
+For ItemKNN the selection key of entry (i, j) is the IEEE double ``fl(c_ij*c_ij) * fl(1/c_j)``
+(monotone in cosine for a fixed row i, computed from integers only), the stored value is
+``c_ij / sqrt(c_i*c_j)`` in float64.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+
+
+# --------------------------------------------------------------------------------------
+# input handling
+# --------------------------------------------------------------------------------------
+def binarize(X: sp.csr_matrix) -> sp.csr_matrix:
+    """recpack/util.py:99-109: non-zero stored values -> 1 (explicit zeros are dropped)."""
+    X = sp.csr_matrix(X)
+    X = X.copy()
+    X.sum_duplicates()
+    X.eliminate_zeros()
+    X.sort_indices()
+    return sp.csr_matrix((np.ones(X.nnz, dtype=np.int64), X.indices, X.indptr), shape=X.shape)
+
+
+def item_degrees(Xb: sp.csr_matrix) -> np.ndarray:
+    return np.bincount(Xb.indices, minlength=Xb.shape[1]).astype(np.int64)
+
+
+def gram_counts(Xb: sp.csr_matrix, rows=None) -> sp.csr_matrix:
+    """Integer co-occurrence counts c_ij = |users(i) & users(j)|; ``rows`` restricts the item rows."""
+    Xt = Xb.T.tocsr()
+    if rows is not None:
+        Xt = Xt[rows]
+    G = (Xt @ Xb).tocsr()
+    G.sort_indices()
+    return G
+
+
+# --------------------------------------------------------------------------------------
+# top-K with the build's deterministic order
+# --------------------------------------------------------------------------------------
+def _segment_topk(indptr, cols, keys, K):
+    """Return (sel_positions sorted by row then rank, row_counts) for top-K per CSR row.
+
+    Order inside a row: key descending, then column ascending.
+    """
+    n_rows = indptr.shape[0] - 1
+    rows = np.repeat(np.arange(n_rows, dtype=np.int64), np.diff(indptr))
+    order = np.lexsort((cols, -keys, rows))  # last key is primary
+    # rank inside row
+    start = indptr[:-1][rows[order]]
+    rank = np.arange(order.shape[0], dtype=np.int64) - start
+    keep = rank < K
+    sel = order[keep]
+    cnt = np.minimum(np.diff(indptr), K).astype(np.int32)
+    return sel, cnt
+
+
+def itemknn_fit(X: sp.csr_matrix, K: int, rows=None):
+    """Cosine ItemKNN. Returns dict(idx int32[R,K] (-1 pad), val float64[R,K] (0 pad), nnz int32[R], deg int64[I]).
+
+    Rows of ``idx``/``val`` are in rank order (best neighbour first).
+    """
+    Xb = binarize(X)
+    n_items = Xb.shape[1]
+    c = item_degrees(Xb)
+    row_ids = np.arange(n_items, dtype=np.int64) if rows is None else np.asarray(rows, dtype=np.int64)
+    G = gram_counts(Xb, None if rows is None else row_ids)
+    R = row_ids.shape[0]
+    gi = np.repeat(row_ids, np.diff(G.indptr))
+    gj = G.indices.astype(np.int64)
+    gc = G.data.astype(np.int64)
+    off = gi != gj  # setdiag(0): the diagonal never survives get_top_K_values
+    # rebuild CSR without the diagonal
+    cnt = np.bincount(np.repeat(np.arange(R), np.diff(G.indptr))[off], minlength=R)
+    indptr = np.zeros(R + 1, dtype=np.int64)
+    np.cumsum(cnt, out=indptr[1:])
+    gi, gj, gc = gi[off], gj[off], gc[off]
+    with np.errstate(divide="ignore"):
+        inv = 1.0 / c.astype(np.float64)
+    key = (gc * gc).astype(np.float64) * inv[gj]
+    sel, nsel = _segment_topk(indptr, gj, key, K)
+    val = gc[sel].astype(np.float64) / np.sqrt(c[gi[sel]].astype(np.float64) * c[gj[sel]].astype(np.float64))
+    idx = np.full((R, K), -1, dtype=np.int32)
+    out = np.zeros((R, K), dtype=np.float64)
+    r = np.repeat(np.arange(R), nsel)
+    pos = np.arange(sel.shape[0]) - np.repeat(np.concatenate([[0], np.cumsum(nsel)[:-1]]), nsel)
+    idx[r, pos] = gj[sel]
+    out[r, pos] = val
+    return {"idx": idx, "val": out, "nnz": nsel.astype(np.int32), "deg": c, "rows": row_ids}
+
+
+def topk_to_csr(idx: np.ndarray, val: np.ndarray, nnz: np.ndarray, n_cols: int, normalize_l1: bool = False):
+    """(idx,val,nnz) -> canonical CSR float64; ``normalize_l1`` = Normalizer('l1') of nearest_neighbour.py:220-222."""
+    R, K = idx.shape
+    mask = np.arange(K)[None, :] < nnz[:, None]
+    v = val.astype(np.float64)
+    if normalize_l1:
+        s = np.where(mask, np.abs(v), 0).sum(axis=1, keepdims=True)
+        s[s == 0] = 1.0
+        v = v / s
+    indptr = np.zeros(R + 1, dtype=np.int64)
+    np.cumsum(nnz, out=indptr[1:])
+    S = sp.csr_matrix((v[mask], idx[mask], indptr), shape=(R, n_cols))
+    S.sort_indices()
+    return S
+
+
+def predict_full(X: sp.csr_matrix, S) -> sp.csr_matrix:
+    """base.py:237-255: scores = binarised X @ similarity, returned as CSR float64."""
+    Xb = binarize(X).astype(np.float64)
+    scores = Xb @ S
+    if not isinstance(scores, sp.csr_matrix):
+        scores = sp.csr_matrix(scores)
+    scores.sort_indices()
+    return scores
+
+
+def topk_rows(scores: sp.csr_matrix, K: int, exclude: sp.csr_matrix | None = None, drop_nonpositive: bool = False):
+    """Per-row top-K of stored scores (optionally with the history entries removed first,
+    recpack/pipelines/pipeline.py:174-175). Returns idx int32[U,K] (-1 pad), val float64[U,K], nnz int32[U]."""
+    scores = sp.csr_matrix(scores).copy()
+    scores.sort_indices()
+    U = scores.shape[0]
+    rows = np.repeat(np.arange(U, dtype=np.int64), np.diff(scores.indptr))
+    cols = scores.indices.astype(np.int64)
+    vals = scores.data.astype(np.float64)
+    keep = np.ones(vals.shape[0], dtype=bool)
+    if exclude is not None:
+        ex = binarize(exclude)
+        ekey = np.repeat(np.arange(U, dtype=np.int64), np.diff(ex.indptr)) * scores.shape[1] + ex.indices
+        keep &= ~np.isin(rows * scores.shape[1] + cols, ekey)
+    if drop_nonpositive:
+        keep &= vals > 0
+    rows, cols, vals = rows[keep], cols[keep], vals[keep]
+    cnt = np.bincount(rows, minlength=U)
+    indptr = np.zeros(U + 1, dtype=np.int64)
+    np.cumsum(cnt, out=indptr[1:])
+    sel, nsel = _segment_topk(indptr, cols, vals, K)
+    idx = np.full((U, K), -1, dtype=np.int32)
+    out = np.zeros((U, K), dtype=np.float64)
+    r = np.repeat(np.arange(U), nsel)
+    pos = np.arange(sel.shape[0]) - np.repeat(np.concatenate([[0], np.cumsum(nsel)[:-1]]), nsel)
+    idx[r, pos] = cols[sel]
+    out[r, pos] = vals[sel]
+    return idx, out, nsel.astype(np.int32)
+
+
+# --------------------------------------------------------------------------------------
+# EASE
+# --------------------------------------------------------------------------------------
+def ease_fit(X: sp.csr_matrix, l2: float, alpha: float = 0.0) -> np.ndarray:
+    """ease.py:78-90 in float64: B_ij = -P_ij / P_jj (i != j), B_ii = 0, optional column weights c_j^-alpha.
+
+    The two n^3 products with diagonal matrices of the reference (ease.py:85, :90) are column scalings.
+    Items never interacted with (c_j = 0) give 0/inf = NaN columns in the reference when alpha != 0;
+    here their (all-zero) columns stay zero - documented deviation.
+    """
+    Xb = binarize(X)
+    G = (Xb.T @ Xb).toarray().astype(np.float64)
+    n = G.shape[0]
+    # ease.py:82 builds l2 * np.identity(n, dtype=float32): lambda is ROUNDED TO float32 before the
+    # int32 + float32 -> float64 promotion (0.03 becomes 0.029999999329447746).
+    lam = float(np.float32(l2))
+    P = np.linalg.inv(G + lam * np.identity(n))
+    d = np.diag(P).copy()
+    B = -P / d[None, :]
+    B[np.diag_indices(n)] = 0.0
+    if alpha != 0:
+        c = np.diag(G)
+        w = np.zeros(n)
+        nz = c > 0
+        w[nz] = 1.0 / c[nz] ** alpha
+        B = B * w[None, :]
+    return B
+
+
+def ease_prune(B: np.ndarray, density: float) -> np.ndarray:
+    """ease.py:97-109 with np.prod for the removed np.product: keep the ``int(density*n*n)`` largest |B_ij|
+    among the stored (off-diagonal, non-zero) entries."""
+    n = B.shape[0]
+    S = sp.csr_matrix(B)
+    k = min(int(density * n * n), S.nnz)
+    out = B.copy()
+    if k < S.nnz:
+        a = np.abs(S.data)
+        drop = np.argpartition(a, -k)[: S.nnz - k] if k > 0 else np.arange(S.nnz)
+        r = np.repeat(np.arange(n), np.diff(S.indptr))
+        out[r[drop], S.indices[drop]] = 0.0
+    return out
