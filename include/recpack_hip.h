@@ -1,0 +1,175 @@
+/*
+ * recpack_hip.h - C ABI of librecpack_hip.so: the MI355X (gfx950) implementation of recpack's
+ * item-similarity hot path (ItemKNN cosine, EASE; fit + predict).
+ *
+ * The reference (LienM/recpack v0.3.6) is pure Python and has no FFI; its boundary for this path is the
+ * class protocol Algorithm.fit(X)/predict(X) (recpack/algorithms/base.py:165-217).  The entry points
+ * below are what a binding for that protocol needs; each cites the reference code it replaces
+ * (paths relative to the reference root).  The ctypes binding that a recpack maintainer would add is in
+ * INTEGRATION.md; the one this repo ships is recpack_amd/_lib.py.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative RPHIP_E* code; rphip_last_error() gives the
+ *    thread-local message of the last failure;
+ *  - plain pointers and sizes only; "host" pointers are caller-owned host memory, "dev" pointers are
+ *    device memory on the context's GPU (e.g. a torch tensor's data_ptr());
+ *  - indices are int32, row pointers int32 or int64 (flag); nnz must be < 2^31;
+ *  - a context is bound to one GPU and one HIP stream; it must not be used from two threads at once;
+ *    host-output calls are synchronous on return, *_dev calls are ordered on the context's stream;
+ *  - objects (ctx, csr, model) are opaque and freed by their *_destroy.
+ */
+#ifndef RECPACK_HIP_H
+#define RECPACK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPHIP_VERSION 100 /* 0.1.0 */
+
+/* error codes */
+#define RPHIP_OK 0
+#define RPHIP_EINVAL (-1)     /* bad argument */
+#define RPHIP_EHIP (-2)       /* HIP runtime failure (message has the hipError string) */
+#define RPHIP_ENOMEM (-3)     /* device allocation failed */
+#define RPHIP_ENODEV (-4)     /* no usable GPU */
+#define RPHIP_EUNSORTED (-5)  /* column indices of a row are not strictly increasing */
+#define RPHIP_ELIMIT (-6)     /* size outside what this build supports (see message) */
+#define RPHIP_ESTATE (-7)     /* object in the wrong state for the call */
+#define RPHIP_ENUMERIC (-8)   /* factorisation broke down (matrix not positive definite) */
+
+typedef struct rphip_ctx rphip_ctx;
+typedef struct rphip_csr rphip_csr;
+typedef struct rphip_model rphip_model;
+
+/* model kinds */
+#define RPHIP_MODEL_TOPK 1  /* I x K neighbour lists (ItemKNN) */
+#define RPHIP_MODEL_DENSE 2 /* dense I x I fp32 item-item matrix (EASE) */
+
+/* timing slots of rphip_get_timings (milliseconds, HIP events on the context's stream) */
+enum {
+  RPHIP_T_CSR_TRANSPOSE = 0, /* K0: degree histogram + scan + scatter (X -> X^T) */
+  RPHIP_T_FIT_PLAN = 1,      /* row costs, task list */
+  RPHIP_T_GRAM_TOPK = 2,     /* K1-K3: row-blocked Gram + cosine key + per-row top-K (the SpGEMM) */
+  RPHIP_T_TOPK_MERGE = 3,    /* merge of per-column-tile candidates (only when I > one LDS tile) */
+  RPHIP_T_PREDICT = 4,       /* K8 / K9 */
+  RPHIP_T_GRAM_DENSE = 5,    /* K4 */
+  RPHIP_T_CHOLESKY = 6,      /* K5 */
+  RPHIP_T_INVERSE = 7,       /* K6 */
+  RPHIP_T_EASE_SCALE = 8,    /* K7 */
+  RPHIP_T_H2D = 9,
+  RPHIP_T_D2H = 10,
+  RPHIP_T_COUNT = 16
+};
+
+typedef struct rphip_timings {
+  double ms[RPHIP_T_COUNT];       /* accumulated since the last rphip_reset_timings */
+  int64_t launches[RPHIP_T_COUNT];
+  double work[RPHIP_T_COUNT];     /* algorithmic bytes (HBM-bound slots) or flops (MFMA slots), same period */
+} rphip_timings;
+
+/* ---- library / context ------------------------------------------------------------------------- */
+int rphip_version(void);
+const char* rphip_last_error(void);
+int rphip_device_count(int* n_out);
+
+/* device: HIP ordinal.  stream: a hipStream_t to run on (e.g. torch's current stream) or NULL to
+ * create a private one. */
+int rphip_ctx_create(int device, void* stream, rphip_ctx** out);
+int rphip_ctx_destroy(rphip_ctx* ctx);
+int rphip_ctx_sync(rphip_ctx* ctx);
+int rphip_get_timings(rphip_ctx* ctx, rphip_timings* out);
+int rphip_reset_timings(rphip_ctx* ctx);
+/* number of CUs, bytes of HBM, gfx arch string (into buf) */
+int rphip_device_info(rphip_ctx* ctx, int* n_cu, int64_t* hbm_bytes, char* arch_buf, int arch_buf_len);
+
+/* ---- interaction matrix --------------------------------------------------------------------------
+ * Replaces InteractionMatrix.values -> to_csr_matrix(binary=True)
+ * (recpack/matrix/interaction_matrix.py:202-217, recpack/matrix/util.py:27-48, recpack/util.py:99-109):
+ * only the sparsity pattern is taken (binary), `data` is never shipped.
+ * Builds X^T (the CSC view) on the device (K0) and the item degrees c = diag(X^T X).
+ * indices inside a row may be in any order unless n_items exceeds one LDS tile (then they must be
+ * increasing: RPHIP_EUNSORTED otherwise; scipy's canonical CSR satisfies this).
+ */
+int rphip_csr_from_host(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_t nnz,
+                        const void* indptr_host, int indptr_is_int64, const int32_t* indices_host,
+                        rphip_csr** out);
+/* same, from device arrays that are already resident (indptr int32[n_users+1], indices int32[nnz]);
+ * the arrays are NOT copied and must outlive the object. */
+int rphip_csr_from_device(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_t nnz,
+                          const int32_t* indptr_dev, const int32_t* indices_dev, rphip_csr** out);
+int rphip_csr_destroy(rphip_csr* m);
+int rphip_csr_shape(const rphip_csr* m, int64_t* n_users, int64_t* n_items, int64_t* nnz);
+/* item degrees c_j (int32[n_items]) to host; sum_u d_u^2 (the number of scalar products P) */
+int rphip_csr_item_degrees(rphip_ctx* ctx, const rphip_csr* m, int32_t* deg_host);
+int rphip_csr_num_products(rphip_ctx* ctx, const rphip_csr* m, int64_t* p_out);
+
+/* ---- ItemKNN fit ----------------------------------------------------------------------------------
+ * Replaces ItemKNN._fit for similarity="cosine" (recpack/algorithms/nearest_neighbour.py:204-224):
+ * compute_cosine_similarity (:69-84, sklearn cosine_similarity + setdiag(0)) and get_top_K_values
+ * (recpack/util.py:50-96), fused: the I x I similarity matrix is never materialised.
+ * Computes the neighbour lists of item rows [row_begin, row_end) (the shard of this GPU; the whole
+ * matrix is 0..n_items).  Result: per row min(K, #co-occurring items) neighbours, sorted by column,
+ * value c_ij / sqrt(c_i c_j) in float64.  Ties at the K-th position: larger similarity first, then
+ * the SMALLER column index.
+ */
+int rphip_itemknn_fit(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K,
+                      rphip_model** out);
+/* neighbour lists to host: idx int32[rows*K] (-1 padded), val float64[rows*K] (0 padded), nnz int32[rows] */
+int rphip_model_topk_download(rphip_ctx* ctx, const rphip_model* m, int32_t* idx_host, double* val_host,
+                              int32_t* nnz_host);
+/* device pointers of the same arrays (for collectives on them): idx int32, val float64, nnz int32 */
+int rphip_model_topk_device(const rphip_model* m, void** idx_dev, void** val_dev, void** nnz_dev,
+                            int64_t* rows, int32_t* K);
+/* build a predict-ready model from assembled neighbour lists (all n_items rows) in host / device memory;
+ * the arrays are copied. */
+int rphip_model_from_topk_host(rphip_ctx* ctx, int64_t n_items, int32_t K, const int32_t* idx_host,
+                               const double* val_host, const int32_t* nnz_host, rphip_model** out);
+int rphip_model_from_topk_device(rphip_ctx* ctx, int64_t n_items, int32_t K, const int32_t* idx_dev,
+                                 const double* val_dev, const int32_t* nnz_dev, rphip_model** out);
+int rphip_model_destroy(rphip_model* m);
+int rphip_model_info(const rphip_model* m, int32_t* kind, int64_t* n_items, int64_t* row_begin,
+                     int64_t* row_end, int32_t* K);
+
+/* ---- predict --------------------------------------------------------------------------------------
+ * Replaces ItemSimilarityMatrixAlgorithm._predict, scores = X @ similarity_matrix_
+ * (recpack/algorithms/base.py:237-255) for users [user_begin, user_end) of Xpred.
+ *
+ * rphip_predict_topk fuses the per-user top-Kp that the reference applies later in
+ * MetricTopK.calculate (recpack/metrics/base.py:189, recpack/util.py:50-77) and, when
+ * exclude_history != 0, the history removal of Pipeline (recpack/pipelines/pipeline.py:174-175).
+ * Outputs (host): idx int32[n*Kp] (-1 padded), val float32[n*Kp], nnz int32[n]; entries of a row are
+ * sorted by column.  Ties: larger score first, then smaller column.
+ */
+int rphip_predict_topk(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin,
+                       int64_t user_end, int32_t Kp, int32_t exclude_history, int32_t* idx_host,
+                       float* val_host, int32_t* nnz_host);
+int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred,
+                           int64_t user_begin, int64_t user_end, int32_t Kp, int32_t exclude_history,
+                           int32_t* idx_dev, float* val_dev, int32_t* nnz_dev);
+/* exact reference semantics (every non-zero score): two phases.  _count fills row_nnz_host
+ * (int64[n]) and returns the total; _fill writes CSR indices/data (float64) given the caller's
+ * indptr (exclusive scan of row_nnz). */
+int rphip_predict_full_count(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred,
+                             int64_t user_begin, int64_t user_end, int64_t* row_nnz_host, int64_t* total_out);
+int rphip_predict_full_fill(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred,
+                            int64_t user_begin, int64_t user_end, const int64_t* indptr_host,
+                            int32_t* indices_host, double* data_host);
+
+/* ---- EASE fit -------------------------------------------------------------------------------------
+ * Replaces EASE._fit (recpack/algorithms/ease.py:63-95): G = X^T X (dense), P = (G + l2 I)^-1 by
+ * blocked Cholesky on MFMA tiles instead of np.linalg.inv (:82), B_ij = -P_ij / P_jj, B_ii = 0 (:85-86),
+ * optional column weights c_j^-alpha (:88-90).  l2 is rounded to float32 first, as the reference does
+ * (l2 * np.identity(dtype=float32), :82).  B stays on the device (fp32).
+ */
+int rphip_ease_fit(rphip_ctx* ctx, const rphip_csr* X, double l2, double alpha, rphip_model** out);
+/* dense B (row-major float32[n_items*n_items]) to host - the lazy similarity_matrix_ (ease.py:92) */
+int rphip_model_dense_download(rphip_ctx* ctx, const rphip_model* m, float* B_host);
+int rphip_model_dense_device(const rphip_model* m, void** B_dev, int64_t* n_items, int64_t* ld);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECPACK_HIP_H */

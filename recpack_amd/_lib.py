@@ -1,0 +1,310 @@
+"""ctypes binding of librecpack_hip.so (C ABI: include/recpack_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or no MI355X is visible,
+calls raise :class:`RecpackHipError`.  Build the library with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C recpack_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librecpack_hip.so")
+
+RPHIP_T_NAMES = [
+    "csr_transpose", "fit_plan", "gram_topk", "topk_merge", "predict", "gram_dense", "cholesky", "inverse",
+    "ease_scale", "h2d", "d2h",
+]
+RPHIP_T_COUNT = 16
+RPHIP_MODEL_TOPK = 1
+RPHIP_MODEL_DENSE = 2
+
+
+class RecpackHipError(RuntimeError):
+    """Raised for every failure of the HIP library (message from rphip_last_error)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"librecpack_hip error {code}: {message}")
+        self.code = code
+
+
+class Timings(C.Structure):
+    _fields_ = [
+        ("ms", C.c_double * RPHIP_T_COUNT),
+        ("launches", C.c_int64 * RPHIP_T_COUNT),
+        ("work", C.c_double * RPHIP_T_COUNT),
+    ]
+
+    def as_dict(self):
+        return {
+            n: {"ms": self.ms[i], "launches": self.launches[i], "work": self.work[i]}
+            for i, n in enumerate(RPHIP_T_NAMES)
+        }
+
+
+_p = C.c_void_p
+_i32, _i64, _f64 = C.c_int32, C.c_int64, C.c_double
+_pp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); mirrors include/recpack_hip.h one to one
+PROTOTYPES = {
+    "rphip_version": (C.c_int, []),
+    "rphip_last_error": (C.c_char_p, []),
+    "rphip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "rphip_ctx_create": (C.c_int, [C.c_int, _p, _pp]),
+    "rphip_ctx_destroy": (C.c_int, [_p]),
+    "rphip_ctx_sync": (C.c_int, [_p]),
+    "rphip_get_timings": (C.c_int, [_p, C.POINTER(Timings)]),
+    "rphip_reset_timings": (C.c_int, [_p]),
+    "rphip_device_info": (C.c_int, [_p, C.POINTER(C.c_int), C.POINTER(_i64), C.c_char_p, C.c_int]),
+    "rphip_csr_from_host": (C.c_int, [_p, _i64, _i64, _i64, _p, C.c_int, _p, _pp]),
+    "rphip_csr_from_device": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _pp]),
+    "rphip_csr_destroy": (C.c_int, [_p]),
+    "rphip_csr_shape": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "rphip_csr_item_degrees": (C.c_int, [_p, _p, _p]),
+    "rphip_csr_num_products": (C.c_int, [_p, _p, C.POINTER(_i64)]),
+    "rphip_itemknn_fit": (C.c_int, [_p, _p, _i64, _i64, _i32, _pp]),
+    "rphip_model_topk_download": (C.c_int, [_p, _p, _p, _p, _p]),
+    "rphip_model_topk_device": (C.c_int, [_p, _pp, _pp, _pp, C.POINTER(_i64), C.POINTER(_i32)]),
+    "rphip_model_from_topk_host": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _pp]),
+    "rphip_model_from_topk_device": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _pp]),
+    "rphip_model_destroy": (C.c_int, [_p]),
+    "rphip_model_info": (C.c_int, [_p, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]),
+    "rphip_predict_topk": (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _p]),
+    "rphip_predict_topk_dev": (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _p]),
+    "rphip_predict_full_count": (C.c_int, [_p, _p, _p, _i64, _i64, _p, C.POINTER(_i64)]),
+    "rphip_predict_full_fill": (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p, _p]),
+    "rphip_ease_fit": (C.c_int, [_p, _p, _f64, _f64, _pp]),
+    "rphip_model_dense_download": (C.c_int, [_p, _p, _p]),
+    "rphip_model_dense_device": (C.c_int, [_p, _pp, C.POINTER(_i64), C.POINTER(_i64)]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """dlopen the library and attach prototypes. Raises RecpackHipError if it is not built."""
+    global _lib
+    with _lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise RecpackHipError(-100, f"{p} not found - build it first (make -C recpack_amd/csrc); there is no CPU fallback")
+        try:
+            # torch bundles its own libamdhip64.so.7: import it first so that both share ONE HIP runtime
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for single-GPU host-array use
+            pass
+        lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError => the .so is older than the header
+            fn.restype = res
+            fn.argtypes = args
+        if path is None:
+            _lib = lib
+        return lib
+
+
+def check(code: int):
+    if code != 0:
+        msg = load_library().rphip_last_error()
+        raise RecpackHipError(code, msg.decode("utf-8", "replace") if msg else "")
+
+
+def _np_ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One GPU + one stream (rphip_ctx)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = load_library()
+        h = C.c_void_p()
+        check(self.lib.rphip_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.rphip_ctx_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def sync(self):
+        check(self.lib.rphip_ctx_sync(self.handle))
+
+    def timings(self) -> dict:
+        t = Timings()
+        check(self.lib.rphip_get_timings(self.handle, C.byref(t)))
+        return t.as_dict()
+
+    def reset_timings(self):
+        check(self.lib.rphip_reset_timings(self.handle))
+
+    def device_info(self) -> dict:
+        ncu, hbm = C.c_int(), C.c_int64()
+        buf = C.create_string_buffer(64)
+        check(self.lib.rphip_device_info(self.handle, C.byref(ncu), C.byref(hbm), buf, 64))
+        return {"n_cu": ncu.value, "hbm_bytes": hbm.value, "arch": buf.value.decode()}
+
+
+class DeviceCSR:
+    """Device-resident binary interaction matrix (rphip_csr): X, X^T, item degrees."""
+
+    def __init__(self, ctx: Context, handle, keepalive=None):
+        self.ctx, self.handle, self._keep = ctx, handle, keepalive
+        nu, ni, nz = C.c_int64(), C.c_int64(), C.c_int64()
+        check(ctx.lib.rphip_csr_shape(handle, C.byref(nu), C.byref(ni), C.byref(nz)))
+        self.shape = (nu.value, ni.value)
+        self.nnz = nz.value
+
+    @classmethod
+    def from_host(cls, ctx: Context, indptr: np.ndarray, indices: np.ndarray, shape):
+        indptr = np.ascontiguousarray(indptr)
+        if indptr.dtype not in (np.int32, np.int64):
+            indptr = indptr.astype(np.int64)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        h = C.c_void_p()
+        check(ctx.lib.rphip_csr_from_host(ctx.handle, int(shape[0]), int(shape[1]), int(indices.shape[0]), _np_ptr(indptr),
+                                          1 if indptr.dtype == np.int64 else 0, _np_ptr(indices), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_device(cls, ctx: Context, indptr_t, indices_t, shape):
+        """indptr_t / indices_t: torch int32 CUDA tensors (kept alive by this object)."""
+        h = C.c_void_p()
+        check(ctx.lib.rphip_csr_from_device(ctx.handle, int(shape[0]), int(shape[1]), int(indices_t.numel()),
+                                            C.c_void_p(indptr_t.data_ptr()), C.c_void_p(indices_t.data_ptr()), C.byref(h)))
+        return cls(ctx, h, keepalive=(indptr_t, indices_t))
+
+    def item_degrees(self) -> np.ndarray:
+        out = np.empty(self.shape[1], dtype=np.int32)
+        check(self.ctx.lib.rphip_csr_item_degrees(self.ctx.handle, self.handle, _np_ptr(out)))
+        return out
+
+    def num_products(self) -> int:
+        p = C.c_int64()
+        check(self.ctx.lib.rphip_csr_num_products(self.ctx.handle, self.handle, C.byref(p)))
+        return p.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.lib.rphip_csr_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+
+class Model:
+    """Fitted similarity on the device (rphip_model)."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx, self.handle = ctx, handle
+        kind, K = C.c_int32(), C.c_int32()
+        ni, r0, r1 = C.c_int64(), C.c_int64(), C.c_int64()
+        check(ctx.lib.rphip_model_info(handle, C.byref(kind), C.byref(ni), C.byref(r0), C.byref(r1), C.byref(K)))
+        self.kind, self.n_items, self.row_begin, self.row_end, self.K = kind.value, ni.value, r0.value, r1.value, K.value
+
+    @property
+    def n_rows(self):
+        return self.row_end - self.row_begin
+
+    def topk_download(self):
+        idx = np.empty((self.n_rows, self.K), dtype=np.int32)
+        val = np.empty((self.n_rows, self.K), dtype=np.float64)
+        nnz = np.empty(self.n_rows, dtype=np.int32)
+        check(self.ctx.lib.rphip_model_topk_download(self.ctx.handle, self.handle, _np_ptr(idx), _np_ptr(val), _np_ptr(nnz)))
+        return idx, val, nnz
+
+    def topk_device_ptrs(self):
+        pi, pv, pn = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        rows, K = C.c_int64(), C.c_int32()
+        check(self.ctx.lib.rphip_model_topk_device(self.handle, C.byref(pi), C.byref(pv), C.byref(pn), C.byref(rows), C.byref(K)))
+        return pi.value, pv.value, pn.value, rows.value, K.value
+
+    @classmethod
+    def from_topk_host(cls, ctx: Context, idx: np.ndarray, val: np.ndarray, nnz: np.ndarray):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        nnz = np.ascontiguousarray(nnz, dtype=np.int32)
+        h = C.c_void_p()
+        check(ctx.lib.rphip_model_from_topk_host(ctx.handle, idx.shape[0], idx.shape[1], _np_ptr(idx), _np_ptr(val), _np_ptr(nnz), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_topk_device(cls, ctx: Context, idx_t, val_t, nnz_t):
+        """torch CUDA tensors: idx int32[I,K], val float64[I,K], nnz int32[I] (copied)."""
+        h = C.c_void_p()
+        check(ctx.lib.rphip_model_from_topk_device(ctx.handle, int(idx_t.shape[0]), int(idx_t.shape[1]), C.c_void_p(idx_t.data_ptr()),
+                                                   C.c_void_p(val_t.data_ptr()), C.c_void_p(nnz_t.data_ptr()), C.byref(h)))
+        return cls(ctx, h)
+
+    def dense_download(self) -> np.ndarray:
+        out = np.empty((self.n_items, self.n_items), dtype=np.float32)
+        check(self.ctx.lib.rphip_model_dense_download(self.ctx.handle, self.handle, _np_ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.lib.rphip_model_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+
+def itemknn_fit(ctx: Context, X: DeviceCSR, K: int, row_begin: int = 0, row_end: int | None = None) -> Model:
+    h = C.c_void_p()
+    row_end = X.shape[1] if row_end is None else row_end
+    check(ctx.lib.rphip_itemknn_fit(ctx.handle, X.handle, int(row_begin), int(row_end), int(K), C.byref(h)))
+    return Model(ctx, h)
+
+
+def ease_fit(ctx: Context, X: DeviceCSR, l2: float, alpha: float = 0.0) -> Model:
+    h = C.c_void_p()
+    check(ctx.lib.rphip_ease_fit(ctx.handle, X.handle, float(l2), float(alpha), C.byref(h)))
+    return Model(ctx, h)
+
+
+def predict_topk(ctx: Context, model: Model, X: DeviceCSR, Kp: int, exclude_history: bool = False, user_begin: int = 0,
+                 user_end: int | None = None):
+    user_end = X.shape[0] if user_end is None else user_end
+    n = user_end - user_begin
+    idx = np.empty((n, Kp), dtype=np.int32)
+    val = np.empty((n, Kp), dtype=np.float32)
+    nnz = np.empty(n, dtype=np.int32)
+    check(ctx.lib.rphip_predict_topk(ctx.handle, model.handle, X.handle, int(user_begin), int(user_end), int(Kp),
+                                     1 if exclude_history else 0, _np_ptr(idx), _np_ptr(val), _np_ptr(nnz)))
+    return idx, val, nnz
+
+
+def predict_topk_dev(ctx: Context, model: Model, X: DeviceCSR, Kp: int, idx_t, val_t, nnz_t, exclude_history: bool = False,
+                     user_begin: int = 0, user_end: int | None = None):
+    """Outputs into torch CUDA tensors idx int32[n,Kp], val float32[n,Kp], nnz int32[n]; asynchronous."""
+    user_end = X.shape[0] if user_end is None else user_end
+    check(ctx.lib.rphip_predict_topk_dev(ctx.handle, model.handle, X.handle, int(user_begin), int(user_end), int(Kp),
+                                         1 if exclude_history else 0, C.c_void_p(idx_t.data_ptr()), C.c_void_p(val_t.data_ptr()),
+                                         C.c_void_p(nnz_t.data_ptr())))
+
+
+def predict_full(ctx: Context, model: Model, X: DeviceCSR, user_begin: int = 0, user_end: int | None = None):
+    """Every non-zero score as CSR arrays (indptr int64, indices int32, data float64)."""
+    user_end = X.shape[0] if user_end is None else user_end
+    n = user_end - user_begin
+    row_nnz = np.zeros(n, dtype=np.int64)
+    total = C.c_int64()
+    check(ctx.lib.rphip_predict_full_count(ctx.handle, model.handle, X.handle, int(user_begin), int(user_end), _np_ptr(row_nnz), C.byref(total)))
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(row_nnz, out=indptr[1:])
+    indices = np.empty(total.value, dtype=np.int32)
+    data = np.empty(total.value, dtype=np.float64)
+    check(ctx.lib.rphip_predict_full_fill(ctx.handle, model.handle, X.handle, int(user_begin), int(user_end), _np_ptr(indptr),
+                                          _np_ptr(indices), _np_ptr(data)))
+    return indptr, indices, data

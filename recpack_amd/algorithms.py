@@ -1,0 +1,273 @@
+"""Drop-in ``ItemKNN`` and ``EASE`` with recpack's ``Algorithm.fit()/predict()`` surface, computed on MI355X.
+
+Host-side mirror of the reference interface for the hot path (paths relative to /root/reference):
+
+* ``Algorithm``            recpack/algorithms/base.py:33-217   (name, identifier, fit/predict wrappers, post-conditions)
+* ``ItemSimilarityMatrixAlgorithm`` / ``TopKItemSimilarityMatrixAlgorithm``   base.py:220-304
+* ``ItemKNN``              recpack/algorithms/nearest_neighbour.py:114-224
+* ``EASE``                 recpack/algorithms/ease.py:19-109
+
+Same constructor arguments (stored under the same attribute names so that sklearn's ``get_params`` and
+recpack's ``identifier`` work), same exceptions and warning texts.  All arithmetic happens in
+``librecpack_hip.so`` through :mod:`recpack_amd._lib`; there is no CPU fallback.
+
+Extensions (not in the reference): ``predict_topk(X, K, exclude_history)`` returns only the K best
+scores per user, fused on the device (what ``Pipeline`` + ``MetricTopK`` compute from the full matrix).
+"""
+from __future__ import annotations
+
+import logging
+import os
+import time
+import warnings
+from typing import Optional
+
+import numpy as np
+import scipy.sparse as sp
+from sklearn.base import BaseEstimator
+from sklearn.utils.validation import check_is_fitted
+
+from recpack_amd import _lib
+
+logger = logging.getLogger("recpack")
+
+_contexts: dict = {}
+
+
+def get_context(device: Optional[int] = None) -> "_lib.Context":
+    """Process-wide context per GPU (device defaults to LOCAL_RANK or 0)."""
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    ctx = _contexts.get(device)
+    if ctx is None:
+        ctx = _contexts[device] = _lib.Context(device)
+    return ctx
+
+
+class UnsupportedTypeError(Exception):
+    """recpack/matrix/util.py:64-80."""
+
+    def __init__(self, X):
+        super().__init__(
+            "Recpack only supports matrix types InteractionMatrix, csr_matrix. Received {}.".format(type(X).__name__)
+        )
+
+
+def to_binary_csr(X) -> sp.csr_matrix:
+    """``to_csr_matrix(X, binary=True)`` (recpack/matrix/util.py:27-48, recpack/util.py:99-109).
+
+    Accepts a scipy ``csr_matrix`` or anything with recpack's ``InteractionMatrix.values`` property.
+    Only the sparsity pattern matters downstream: explicit zeros are dropped, duplicates merged, indices sorted.
+    """
+    if isinstance(X, sp.csr_matrix):
+        M = X
+    else:
+        M = getattr(X, "values", None)  # InteractionMatrix.values rebuilds the CSR on every access: read once
+        if not isinstance(M, sp.csr_matrix):
+            raise UnsupportedTypeError(X)
+    if not M.has_canonical_format or (M.nnz and not np.all(M.data)):
+        M = M.copy()
+        M.sum_duplicates()
+        M.eliminate_zeros()
+        M.sort_indices()
+    return M
+
+
+class Algorithm(BaseEstimator):
+    """recpack/algorithms/base.py:33-217."""
+
+    def __init__(self):
+        super().__init__()
+
+    @property
+    def name(self):
+        return self.__class__.__name__
+
+    @property
+    def identifier(self):
+        paramstring = ",".join((f"{k}={v}" for k, v in self.get_params().items()))
+        return self.name + "(" + paramstring + ")"
+
+    def __str__(self):
+        return self.name
+
+    def set_params(self, **params):
+        super().set_params(**params)
+
+    def _fit(self, X):
+        raise NotImplementedError("Please implement _fit")
+
+    def _predict(self, X):
+        raise NotImplementedError("Please implement _predict")
+
+    def _check_fit_complete(self):
+        check_is_fitted(self)
+
+    def _check_prediction(self, X_pred: sp.csr_matrix, X: sp.csr_matrix) -> None:
+        # base.py:108-127, without materialising two Python sets of user ids
+        has_hist = np.diff(X.indptr) > 0
+        has_pred = np.diff(X_pred.indptr) > 0
+        if X_pred.nnz and not np.all(X_pred.data):
+            has_pred = np.asarray((X_pred != 0).sum(axis=1)).ravel() > 0
+        missing = int(np.count_nonzero(has_hist & ~has_pred))
+        if missing > 0:
+            warnings.warn(f"{self.name} failed to recommend any items " f"for {missing} users")
+
+    def _transform_fit_input(self, X):
+        return to_binary_csr(X)
+
+    def _transform_predict_input(self, X):
+        return to_binary_csr(X)
+
+    def fit(self, X) -> "Algorithm":
+        start = time.time()
+        X = self._transform_fit_input(X)
+        self._fit(X)
+        self._check_fit_complete()
+        end = time.time()
+        logger.info(f"Fitting {self.name} complete - Took {end - start :.3}s")
+        return self
+
+    def predict(self, X) -> sp.csr_matrix:
+        self._check_fit_complete()
+        X = self._transform_predict_input(X)
+        X_pred = self._predict(X)
+        self._check_prediction(X_pred, X)
+        return X_pred
+
+
+class ItemSimilarityMatrixAlgorithm(Algorithm):
+    """base.py:220-279; the model lives on the GPU, ``similarity_matrix_`` is its host view."""
+
+    _model = None          # _lib.Model
+    _empty_rows_ = None    # rows of the similarity matrix without any stored value (set by _fit)
+
+    def _upload(self, X: sp.csr_matrix):
+        ctx = get_context()
+        return ctx, _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
+
+    def _predict(self, X: sp.csr_matrix) -> sp.csr_matrix:
+        ctx, dX = self._upload(X)
+        try:
+            indptr, indices, data = _lib.predict_full(ctx, self._model, dX)
+        finally:
+            dX.close()
+        return sp.csr_matrix((data, indices, indptr), shape=X.shape)
+
+    def predict_topk(self, X, K: int, exclude_history: bool = False) -> sp.csr_matrix:
+        """Top-K scores per user (column-sorted CSR rows, float32 scores widened to float64)."""
+        self._check_fit_complete()
+        X = self._transform_predict_input(X)
+        ctx, dX = self._upload(X)
+        try:
+            idx, val, nnz = _lib.predict_topk(ctx, self._model, dX, min(int(K), max(1, X.shape[1])), exclude_history)
+        finally:
+            dX.close()
+        mask = np.arange(idx.shape[1])[None, :] < nnz[:, None]
+        indptr = np.zeros(X.shape[0] + 1, dtype=np.int64)
+        np.cumsum(nnz, out=indptr[1:])
+        return sp.csr_matrix((val[mask].astype(np.float64), idx[mask], indptr), shape=X.shape)
+
+    def _check_fit_complete(self):
+        super()._check_fit_complete()
+        assert hasattr(self, "similarity_matrix_")
+        if self._empty_rows_ is not None:
+            missing = int(self._empty_rows_)
+        else:  # a similarity matrix set from outside: the reference's own check (base.py:272-279)
+            items_with_score = set(self.similarity_matrix_.nonzero()[0])
+            missing = self.similarity_matrix_.shape[0] - len(items_with_score)
+        if missing > 0:
+            warnings.warn(f"{self.name} missing similar items for {missing} items.")
+
+
+class TopKItemSimilarityMatrixAlgorithm(ItemSimilarityMatrixAlgorithm):
+    """base.py:282-304."""
+
+    def __init__(self, K):
+        super().__init__()
+        self.K = K
+
+
+def topk_arrays_to_csr(idx: np.ndarray, val: np.ndarray, nnz: np.ndarray, n_cols: int) -> sp.csr_matrix:
+    mask = np.arange(idx.shape[1])[None, :] < nnz[:, None]
+    indptr = np.zeros(idx.shape[0] + 1, dtype=np.int64)
+    np.cumsum(nnz, out=indptr[1:])
+    return sp.csr_matrix((val[mask], idx[mask], indptr), shape=(idx.shape[0], n_cols))
+
+
+class ItemKNN(TopKItemSimilarityMatrixAlgorithm):
+    """Item K Nearest Neighbours (recpack/algorithms/nearest_neighbour.py:114-224) on MI355X.
+
+    ``similarity="cosine"`` with binary input is the accelerated path.  ``normalize_sim`` is a host
+    epilogue on the I x K result.  ``normalize_X`` and ``similarity="conditional_probability"`` are the
+    weighted-Gram variants of SURVEY.md §8(f) and raise ``NotImplementedError`` until they land.
+    """
+
+    SUPPORTED_SIMILARITIES = ["cosine", "conditional_probability"]
+
+    def __init__(self, K=200, similarity: str = "cosine", pop_discount: Optional[float] = None, normalize_X: bool = False,
+                 normalize_sim: bool = False):
+        super().__init__(K)
+        if similarity not in self.SUPPORTED_SIMILARITIES:
+            raise ValueError(f"similarity {similarity} not supported")
+        self.similarity = similarity
+        if self.similarity != "conditional_probability" and pop_discount:
+            warnings.warn(
+                "Argument pop_discount is incompatible with all similarity \
+                functions except conditional probability. \
+                This argument will be ignored, \
+                popularity discounting won't be applied.",
+                UserWarning,
+            )
+        if type(pop_discount) == float and (pop_discount < 0 or pop_discount > 1):
+            raise ValueError("Invalid value for pop_discount. Value should be between 0 and 1.")
+        self.pop_discount = pop_discount
+        self.normalize_X = normalize_X
+        self.normalize_sim = normalize_sim
+
+    def _fit(self, X: sp.csr_matrix) -> None:
+        if self.similarity != "cosine" or self.normalize_X:
+            raise NotImplementedError(
+                "recpack_amd.ItemKNN: only similarity='cosine' with normalize_X=False runs on the GPU in this build"
+            )
+        ctx, dX = self._upload(X)
+        try:
+            model = _lib.itemknn_fit(ctx, dX, int(self.K))
+            idx, val, nnz = model.topk_download()
+        finally:
+            dX.close()
+        self._set_topk(ctx, model, idx, val, nnz, X.shape[1])
+
+    def _set_topk(self, ctx, model, idx, val, nnz, n_items):
+        if self.normalize_sim:
+            # Normalizer(norm="l1") on the rows of the top-K matrix (nearest_neighbour.py:220-222)
+            mask = np.arange(idx.shape[1])[None, :] < nnz[:, None]
+            s = np.where(mask, np.abs(val), 0.0).sum(axis=1, keepdims=True)
+            s[s == 0] = 1.0
+            val = val / s
+            model = _lib.Model.from_topk_host(ctx, idx, val, nnz)
+        self._model = model
+        self._empty_rows_ = int(np.count_nonzero(nnz == 0))
+        self.similarity_matrix_ = topk_arrays_to_csr(idx, val, nnz, n_items)
+
+
+class EASE(ItemSimilarityMatrixAlgorithm):
+    """EASE (recpack/algorithms/ease.py:19-109) on MI355X: dense B stays on the device."""
+
+    def __init__(self, l2=1e3, alpha=0, density=None):
+        super().__init__()
+        self.l2 = l2
+        self.alpha = alpha
+        self.density = density
+
+    def _fit(self, X: sp.csr_matrix):
+        ctx, dX = self._upload(X)
+        try:
+            self._model = _lib.ease_fit(ctx, dX, float(self.l2), float(self.alpha))
+        finally:
+            dX.close()
+        B = self._model.dense_download().astype(np.float64)
+        self.similarity_matrix_ = sp.csr_matrix(B)
+        self._empty_rows_ = int(np.count_nonzero(np.diff(self.similarity_matrix_.indptr) == 0))
+        if self.density:
+            raise NotImplementedError("recpack_amd.EASE: density pruning is not part of this build yet")

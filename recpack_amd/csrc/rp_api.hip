@@ -1,0 +1,265 @@
+// Context, errors, timing and small device utilities of librecpack_hip.so.
+#include "rp_common.h"
+
+#include <string.h>
+
+static thread_local char g_err[1024] = "";
+
+void rp_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int rphip_version(void) { return RPHIP_VERSION; }
+extern "C" const char* rphip_last_error(void) { return g_err; }
+
+extern "C" int rphip_device_count(int* n_out) {
+  if (!n_out) RP_FAIL(RPHIP_EINVAL, "n_out is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *n_out = 0;
+    RP_FAIL(RPHIP_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *n_out = n;
+  return RPHIP_OK;
+}
+
+int rp_set_device(const rphip_ctx* ctx) {
+  RP_HIP(hipSetDevice(ctx->device));
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_ctx_create(int device, void* stream, rphip_ctx** out) {
+  if (!out) RP_FAIL(RPHIP_EINVAL, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) RP_FAIL(RPHIP_ENODEV, "no HIP device visible");
+  if (device < 0 || device >= n) RP_FAIL(RPHIP_EINVAL, "device %d out of range (0..%d)", device, n - 1);
+  RP_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  RP_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    RP_FAIL(RPHIP_ENODEV, "device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+  rphip_ctx* c = new rphip_ctx();
+  c->device = device;
+  c->n_cu = prop.multiProcessorCount;
+  c->hbm_bytes = prop.totalGlobalMem;
+  strncpy(c->arch, prop.gcnArchName, sizeof(c->arch) - 1);
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete c;
+      RP_FAIL(RPHIP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    c->own_stream = true;
+  }
+  memset(&c->tm, 0, sizeof(c->tm));
+  *out = c;
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_ctx_destroy(rphip_ctx* ctx) {
+  if (!ctx) return RPHIP_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  for (auto& p : ctx->pending) {
+    hipEventDestroy(p.a);
+    hipEventDestroy(p.b);
+  }
+  for (auto e : ctx->ev_pool) hipEventDestroy(e);
+  for (auto& b : ctx->scratch)
+    if (b.p) hipFree(b.p);
+  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_ctx_sync(rphip_ctx* ctx) {
+  if (!ctx) RP_FAIL(RPHIP_EINVAL, "ctx is NULL");
+  RP_TRY(rp_set_device(ctx));
+  RP_HIP(hipStreamSynchronize(ctx->stream));
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_device_info(rphip_ctx* ctx, int* n_cu, int64_t* hbm_bytes, char* arch_buf, int arch_buf_len) {
+  if (!ctx) RP_FAIL(RPHIP_EINVAL, "ctx is NULL");
+  if (n_cu) *n_cu = ctx->n_cu;
+  if (hbm_bytes) *hbm_bytes = (int64_t)ctx->hbm_bytes;
+  if (arch_buf && arch_buf_len > 0) {
+    strncpy(arch_buf, ctx->arch, arch_buf_len - 1);
+    arch_buf[arch_buf_len - 1] = 0;
+  }
+  return RPHIP_OK;
+}
+
+int rp_scratch(rphip_ctx* ctx, int slot, size_t bytes, void** out) {
+  rp_buf& b = ctx->scratch[slot];
+  if (bytes > b.cap) {
+    if (b.p) {
+      RP_HIP(hipStreamSynchronize(ctx->stream));
+      RP_HIP(hipFree(b.p));
+      b.p = nullptr;
+      b.cap = 0;
+    }
+    size_t cap = (bytes + (size_t)4095) & ~(size_t)4095;
+    RP_HIP(hipMalloc(&b.p, cap));
+    b.cap = cap;
+  }
+  *out = b.p;
+  return RPHIP_OK;
+}
+
+// ---- timing ----------------------------------------------------------------------------------------
+static hipEvent_t rp_get_event(rphip_ctx* ctx) {
+  if (!ctx->ev_pool.empty()) {
+    hipEvent_t e = ctx->ev_pool.back();
+    ctx->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  hipEventCreate(&e);
+  return e;
+}
+
+void rp_time_begin(rphip_ctx* ctx, hipEvent_t* a) {
+  *a = rp_get_event(ctx);
+  hipEventRecord(*a, ctx->stream);
+}
+
+void rp_time_end(rphip_ctx* ctx, hipEvent_t a, int slot, double work) {
+  hipEvent_t b = rp_get_event(ctx);
+  hipEventRecord(b, ctx->stream);
+  ctx->pending.push_back({a, b, slot});
+  ctx->tm.launches[slot] += 1;
+  ctx->tm.work[slot] += work;
+  if (ctx->pending.size() > 4096) rp_resolve_timings(ctx);
+}
+
+int rp_resolve_timings(rphip_ctx* ctx) {
+  if (ctx->pending.empty()) return RPHIP_OK;
+  RP_HIP(hipStreamSynchronize(ctx->stream));
+  for (auto& p : ctx->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) ctx->tm.ms[p.slot] += ms;
+    ctx->ev_pool.push_back(p.a);
+    ctx->ev_pool.push_back(p.b);
+  }
+  ctx->pending.clear();
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_get_timings(rphip_ctx* ctx, rphip_timings* out) {
+  if (!ctx || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  RP_TRY(rp_set_device(ctx));
+  RP_TRY(rp_resolve_timings(ctx));
+  *out = ctx->tm;
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_reset_timings(rphip_ctx* ctx) {
+  if (!ctx) RP_FAIL(RPHIP_EINVAL, "ctx is NULL");
+  RP_TRY(rp_set_device(ctx));
+  RP_TRY(rp_resolve_timings(ctx));
+  memset(&ctx->tm, 0, sizeof(ctx->tm));
+  return RPHIP_OK;
+}
+
+// ---- exclusive scan (int32) ------------------------------------------------------------------------
+constexpr int SCAN_T = 1024;
+constexpr int SCAN_E = 4;                 // elements per thread
+constexpr int SCAN_B = SCAN_T * SCAN_E;   // elements per block
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// block-wide exclusive scan of one value per thread; returns exclusive prefix, *total = block sum
+__device__ __forceinline__ int block_excl_scan(int v, int* total, int* smem /* >= 17 ints */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = wave_incl_scan(v);
+  if (lane == 63) smem[wave] = inc;
+  __syncthreads();
+  if (wave == 0) {
+    int w = (lane < (int)(blockDim.x >> 6)) ? smem[lane] : 0;
+    int wi = wave_incl_scan(w);
+    if (lane < 16) smem[lane] = wi - w;
+    if (lane == 15 || lane == (int)(blockDim.x >> 6) - 1) smem[16] = wi;
+  }
+  __syncthreads();
+  int res = inc - v + smem[wave];
+  *total = smem[16];
+  __syncthreads();
+  return res;
+}
+
+__global__ void __launch_bounds__(SCAN_T) k_scan_block_sums(const int32_t* __restrict__ in, int32_t* __restrict__ bsum, int64_t n) {
+  __shared__ int sm[32];
+  int64_t base = (int64_t)blockIdx.x * SCAN_B + (int64_t)threadIdx.x * SCAN_E;
+  int s = 0;
+#pragma unroll
+  for (int e = 0; e < SCAN_E; ++e)
+    if (base + e < n) s += in[base + e];
+  int tot;
+  block_excl_scan(s, &tot, sm);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(SCAN_T) k_scan_sums(int32_t* __restrict__ bsum, int64_t nb, int32_t* __restrict__ total_out) {
+  __shared__ int sm[32];
+  int carry = 0;
+  for (int64_t b0 = 0; b0 < nb; b0 += SCAN_T) {
+    int64_t i = b0 + threadIdx.x;
+    int v = (i < nb) ? bsum[i] : 0;
+    int tot;
+    int ex = block_excl_scan(v, &tot, sm);
+    if (i < nb) bsum[i] = ex + carry;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ void __launch_bounds__(SCAN_T) k_scan_final(const int32_t* __restrict__ in, const int32_t* __restrict__ bsum,
+                                                     int32_t* __restrict__ out, int64_t n) {
+  __shared__ int sm[32];
+  int64_t base = (int64_t)blockIdx.x * SCAN_B + (int64_t)threadIdx.x * SCAN_E;
+  int v[SCAN_E];
+  int s = 0;
+#pragma unroll
+  for (int e = 0; e < SCAN_E; ++e) {
+    v[e] = (base + e < n) ? in[base + e] : 0;
+    s += v[e];
+  }
+  int tot;
+  int ex = block_excl_scan(s, &tot, sm) + bsum[blockIdx.x];
+#pragma unroll
+  for (int e = 0; e < SCAN_E; ++e) {
+    if (base + e < n) out[base + e] = ex;
+    ex += v[e];
+  }
+}
+
+int rp_exclusive_scan_i32(rphip_ctx* ctx, const int32_t* in, int32_t* out, int64_t n) {
+  if (n <= 0) {
+    RP_HIP(hipMemsetAsync(out, 0, sizeof(int32_t), ctx->stream));
+    return RPHIP_OK;
+  }
+  int64_t nb = rp_cdiv(n, SCAN_B);
+  int32_t* bsum = nullptr;
+  RP_TRY(rp_scratch(ctx, 7, (size_t)nb * sizeof(int32_t), (void**)&bsum));
+  hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb), dim3(SCAN_T), 0, ctx->stream, in, bsum, n);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_T), 0, ctx->stream, bsum, nb, out + n);
+  hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_T), 0, ctx->stream, in, bsum, out, n);
+  RP_HIP(hipGetLastError());
+  return RPHIP_OK;
+}

@@ -1,0 +1,116 @@
+// Internal definitions shared by the translation units of librecpack_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/recpack_hip.h"
+
+// ---- errors --------------------------------------------------------------------------------------
+void rp_set_error(const char* fmt, ...);
+
+#define RP_FAIL(code, ...)      \
+  do {                          \
+    rp_set_error(__VA_ARGS__);  \
+    return (code);              \
+  } while (0)
+
+#define RP_HIP(expr)                                                                           \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      rp_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return (_e == hipErrorOutOfMemory) ? RPHIP_ENOMEM : RPHIP_EHIP;                          \
+    }                                                                                          \
+  } while (0)
+
+#define RP_TRY(expr)        \
+  do {                      \
+    int _r = (expr);        \
+    if (_r != RPHIP_OK) return _r; \
+  } while (0)
+
+// ---- geometry ------------------------------------------------------------------------------------
+constexpr int RP_WAVE = 64;
+constexpr int RP_FIT_THREADS = 1024;      // 16 waves, one workgroup per CU (LDS-bound)
+constexpr int RP_TILE_MAX = 30720;        // accumulator columns per LDS tile (120 KiB of u32/f32)
+constexpr int RP_SORT_CAP = 2048;         // entries of the in-LDS exact sort (32 KiB)
+constexpr int RP_HIST_BINS = 4096;        // radix-select digit: 12 bits (overlays the sort buffer)
+constexpr int RP_K_MAX = RP_SORT_CAP;     // largest effective K / Kp of one call
+
+// ---- objects -------------------------------------------------------------------------------------
+struct rp_buf {  // grow-only device scratch
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct rphip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int n_cu = 0;
+  size_t hbm_bytes = 0;
+  char arch[64] = {0};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  rphip_timings tm;
+  rp_buf scratch[8];
+  // pending event pairs are resolved lazily (no sync inside *_dev calls)
+  struct pending_t { hipEvent_t a, b; int slot; };
+  std::vector<pending_t> pending;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+struct rphip_csr {
+  rphip_ctx* ctx = nullptr;
+  int64_t n_users = 0, n_items = 0, nnz = 0;
+  bool owns_x = false;
+  const int32_t* x_ptr = nullptr;  // [U+1]
+  const int32_t* x_idx = nullptr;  // [nnz]
+  int32_t* xt_ptr = nullptr;       // [I+1]
+  int32_t* xt_idx = nullptr;       // [nnz] users of each item (any order inside a row)
+  int32_t* deg = nullptr;          // [I] item degrees
+  double* inv_deg = nullptr;       // [I] fl(1/c_j) (0 for empty items)
+  int64_t* row_cost = nullptr;     // [I] w_i = sum_{u in i} d_u
+  int64_t n_products = -1;         // P = sum_u d_u^2
+  // column tiling (n_items > RP_TILE_MAX): tile_ptr[u*(T+1)+t] = first position of row u with col >= t*W
+  int n_tiles = 1;
+  int tile_w = 0;
+  int32_t* tile_ptr = nullptr;
+  bool sorted_rows = false;
+};
+
+struct rphip_model {
+  rphip_ctx* ctx = nullptr;
+  int kind = 0;
+  int64_t n_items = 0;
+  int64_t row_begin = 0, row_end = 0;
+  int32_t K = 0;
+  // TOPK
+  int32_t* idx = nullptr;   // [rows*K]
+  double* val = nullptr;    // [rows*K]
+  float* val32 = nullptr;   // [rows*K] (predict operand)
+  int32_t* nnz = nullptr;   // [rows]
+  // DENSE
+  float* B = nullptr;       // [n_items * ld]
+  int64_t ld = 0;
+};
+
+// ---- helpers (rp_api.hip) ------------------------------------------------------------------------
+int rp_scratch(rphip_ctx* ctx, int slot, size_t bytes, void** out);
+void rp_time_begin(rphip_ctx* ctx, hipEvent_t* a);
+void rp_time_end(rphip_ctx* ctx, hipEvent_t a, int slot, double work);
+int rp_resolve_timings(rphip_ctx* ctx);
+int rp_set_device(const rphip_ctx* ctx);
+
+// device-wide exclusive scan of int32 (n < 2^31, total < 2^31): out[i] = sum_{k<i} in[k], out[n] = total
+int rp_exclusive_scan_i32(rphip_ctx* ctx, const int32_t* in, int32_t* out, int64_t n);
+
+// rp_csr.hip
+int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m);
+
+static inline int64_t rp_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,269 @@
+// K0: the device-resident interaction matrix: X (CSR by user), X^T (CSR by item), item degrees, column tiles.
+//
+// Replaces InteractionMatrix.values + to_csr_matrix(binary=True) (recpack/matrix/interaction_matrix.py:202-217,
+// recpack/matrix/util.py:27-48) as far as the hot path needs them: only the pattern (indptr, indices) is used.
+// X^T is what scipy builds implicitly for `X.T @ X` (nearest_neighbour.py:80 via sklearn, ease.py:81).
+//
+//   k_rank_hist   rank[k] = atomicAdd(deg[idx[k]], 1)     one pass over nnz: degrees AND the position of
+//                                                          every entry inside its item row
+//   scan          xt_ptr = exclusive_scan(deg)
+//   k_scatter     xt_idx[xt_ptr[j] + rank[k]] = u          8 lanes per user row, coalesced 32-B segments
+//   k_inv_deg     inv_deg[j] = fl(1/c_j)
+//   k_tile_ptr    (n_items > one LDS tile) per user the first position with column >= t*W, checks order
+#include <algorithm>
+
+#include "rp_common.h"
+
+__global__ void k_rank_hist(const int32_t* __restrict__ idx, int64_t nnz, int n_items, int32_t* __restrict__ deg,
+                            int32_t* __restrict__ rank, int32_t* __restrict__ err) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
+    const int j = idx[k];
+    if ((unsigned)j >= (unsigned)n_items) {
+      *err = 1;
+      continue;
+    }
+    rank[k] = atomicAdd(&deg[j], 1);
+  }
+}
+
+__global__ void k_scatter(const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ x_idx, int n_users,
+                          const int32_t* __restrict__ xt_ptr, const int32_t* __restrict__ rank, int32_t* __restrict__ xt_idx,
+                          unsigned long long* __restrict__ p_sum, int n_items) {
+  const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, sub = threadIdx.x & 7;
+  const int ng = (gridDim.x * blockDim.x) >> 3;
+  unsigned long long local = 0;
+  for (int u = g; u < n_users; u += ng) {
+    const int s = x_ptr[u], e = x_ptr[u + 1];
+    if (sub == 0) local += (unsigned long long)(e - s) * (unsigned long long)(e - s);
+    for (int k = s + sub; k < e; k += 8) {
+      const int j = x_idx[k];
+      if ((unsigned)j < (unsigned)n_items) xt_idx[xt_ptr[j] + rank[k]] = u;
+    }
+  }
+  // P = sum_u d_u^2
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) local += __shfl_xor(local, d);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(p_sum, local);
+}
+
+__global__ void k_inv_deg(const int32_t* __restrict__ deg, double* __restrict__ inv, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int d = deg[i];
+    inv[i] = d > 0 ? 1.0 / (double)d : 0.0;
+  }
+}
+
+__global__ void k_check_ptr(const int32_t* __restrict__ x_ptr, int n_users, int64_t nnz, int32_t* __restrict__ err) {
+  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u <= n_users; u += gridDim.x * blockDim.x) {
+    const int a = x_ptr[u];
+    if (u == 0 && a != 0) *err = 2;
+    if (u == n_users && a != (int)nnz) *err = 2;
+    if (u < n_users && x_ptr[u + 1] < a) *err = 2;
+  }
+}
+
+// one thread per user: tile boundaries by a linear merge (rows are short), and the order check
+__global__ void k_tile_ptr(const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ x_idx, int n_users, int n_tiles,
+                           int tile_w, int32_t* __restrict__ tile_ptr, int32_t* __restrict__ err) {
+  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n_users; u += gridDim.x * blockDim.x) {
+    const int s = x_ptr[u], e = x_ptr[u + 1];
+    int32_t* tp = tile_ptr + (int64_t)u * (n_tiles + 1);
+    int t = 0;
+    int prev = -1;
+    tp[0] = s;
+    for (int k = s; k < e; ++k) {
+      const int j = x_idx[k];
+      if (j <= prev) *err = 3;
+      prev = j;
+      const int tj = j / tile_w;
+      while (t < tj) tp[++t] = k;
+    }
+    while (t < n_tiles) tp[++t] = e;
+  }
+}
+
+int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
+  hipStream_t st = ctx->stream;
+  const int64_t U = m->n_users, I = m->n_items, nnz = m->nnz;
+  m->n_tiles = (int)std::max<int64_t>(1, rp_cdiv(I, RP_TILE_MAX));
+  m->tile_w = (int)(rp_cdiv(rp_cdiv(std::max<int64_t>(I, 1), m->n_tiles), 64) * 64);
+  RP_HIP(hipMalloc((void**)&m->xt_ptr, (size_t)(I + 1) * sizeof(int32_t)));
+  RP_HIP(hipMalloc((void**)&m->xt_idx, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t)));
+  RP_HIP(hipMalloc((void**)&m->deg, (size_t)std::max<int64_t>(I, 1) * sizeof(int32_t)));
+  RP_HIP(hipMalloc((void**)&m->inv_deg, (size_t)std::max<int64_t>(I, 1) * sizeof(double)));
+  char* sc = nullptr;
+  const size_t rank_bytes = ((size_t)std::max<int64_t>(nnz, 1) * 4 + 15) & ~(size_t)15;  // keeps p_sum 8-B aligned
+  RP_TRY(rp_scratch(ctx, 0, rank_bytes + 64, (void**)&sc));
+  int32_t* rank = (int32_t*)sc;
+  int32_t* err = (int32_t*)(sc + rank_bytes);
+  unsigned long long* p_sum = (unsigned long long*)(err + 2);
+  hipEvent_t ev;
+  rp_time_begin(ctx, &ev);
+  RP_HIP(hipMemsetAsync(m->deg, 0, (size_t)std::max<int64_t>(I, 1) * sizeof(int32_t), st));
+  RP_HIP(hipMemsetAsync(err, 0, 64, st));
+  const int bt = 256;
+  const int grid_nnz = (int)std::min<int64_t>((int64_t)ctx->n_cu * 16, std::max<int64_t>(1, rp_cdiv(nnz, bt)));
+  const int grid_u = (int)std::min<int64_t>((int64_t)ctx->n_cu * 16, std::max<int64_t>(1, rp_cdiv(U + 1, bt)));
+  hipLaunchKernelGGL(k_check_ptr, dim3(grid_u), dim3(bt), 0, st, m->x_ptr, (int)U, nnz, err);
+  int32_t h_err = 0;
+  RP_HIP(hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, st));
+  RP_HIP(hipStreamSynchronize(st));
+  if (h_err) RP_FAIL(RPHIP_EINVAL, "indptr is not a valid row pointer array (not monotone, or indptr[0] != 0, or indptr[-1] != nnz)");
+  if (nnz > 0) hipLaunchKernelGGL(k_rank_hist, dim3(grid_nnz), dim3(bt), 0, st, m->x_idx, nnz, (int)I, m->deg, rank, err);
+  RP_TRY(rp_exclusive_scan_i32(ctx, m->deg, m->xt_ptr, I));
+  if (nnz > 0) {
+    const int grid_s = (int)std::min<int64_t>((int64_t)ctx->n_cu * 16, std::max<int64_t>(1, rp_cdiv(U * 8, bt)));
+    hipLaunchKernelGGL(k_scatter, dim3(grid_s), dim3(bt), 0, st, m->x_ptr, m->x_idx, (int)U, m->xt_ptr, rank, m->xt_idx, p_sum,
+                       (int)I);
+  }
+  hipLaunchKernelGGL(k_inv_deg, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, rp_cdiv(I, bt)))), dim3(bt), 0, st,
+                     m->deg, m->inv_deg, (int)I);
+  if (m->n_tiles > 1) {
+    RP_HIP(hipMalloc((void**)&m->tile_ptr, (size_t)U * (m->n_tiles + 1) * sizeof(int32_t)));
+    hipLaunchKernelGGL(k_tile_ptr, dim3(grid_u), dim3(bt), 0, st, m->x_ptr, m->x_idx, (int)U, m->n_tiles, m->tile_w, m->tile_ptr,
+                       err);
+  }
+  RP_HIP(hipGetLastError());
+  rp_time_end(ctx, ev, RPHIP_T_CSR_TRANSPOSE, 12.0 * (double)nnz + 4.0 * (double)(U + I + 2) + 4.0 * (double)(I + 1));
+  struct {
+    int32_t err[2];
+    unsigned long long p;
+  } h;
+  RP_HIP(hipMemcpyAsync(&h, err, sizeof(h), hipMemcpyDeviceToHost, st));
+  RP_HIP(hipStreamSynchronize(st));
+  if (h.err[0] == 1) RP_FAIL(RPHIP_EINVAL, "a column index is outside [0, n_items)");
+  if (h.err[0] == 3)
+    RP_FAIL(RPHIP_EUNSORTED, "n_items=%lld needs %d column tiles: column indices of every row must be strictly increasing",
+            (long long)I, m->n_tiles);
+  m->n_products = (int64_t)h.p;
+  m->sorted_rows = m->n_tiles > 1;
+  return RPHIP_OK;
+}
+
+static int rp_csr_check_shape(int64_t U, int64_t I, int64_t nnz) {
+  if (U < 0 || I < 0 || nnz < 0) RP_FAIL(RPHIP_EINVAL, "negative shape");
+  if (U >= (1ll << 31) - 1 || I >= (1ll << 31) - 1 || nnz >= (1ll << 31) - 1)
+    RP_FAIL(RPHIP_ELIMIT, "n_users, n_items and nnz must be below 2^31-1 (got %lld, %lld, %lld)", (long long)U, (long long)I,
+            (long long)nnz);
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_csr_from_host(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_t nnz, const void* indptr_host,
+                                   int indptr_is_int64, const int32_t* indices_host, rphip_csr** out) {
+  if (!ctx || !out || !indptr_host || (nnz > 0 && !indices_host)) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  RP_TRY(rp_csr_check_shape(n_users, n_items, nnz));
+  RP_TRY(rp_set_device(ctx));
+  rphip_csr* m = new rphip_csr();
+  m->ctx = ctx;
+  m->n_users = n_users;
+  m->n_items = n_items;
+  m->nnz = nnz;
+  m->owns_x = true;
+  int32_t* dp = nullptr;
+  int32_t* di = nullptr;
+  std::vector<int32_t> tmp;
+  const int32_t* hp = (const int32_t*)indptr_host;
+  if (indptr_is_int64) {
+    const int64_t* p64 = (const int64_t*)indptr_host;
+    tmp.resize((size_t)n_users + 1);
+    for (int64_t i = 0; i <= n_users; ++i) {
+      if (p64[i] < 0 || p64[i] > nnz) {
+        delete m;
+        RP_FAIL(RPHIP_EINVAL, "indptr[%lld]=%lld outside [0, nnz]", (long long)i, (long long)p64[i]);
+      }
+      tmp[(size_t)i] = (int32_t)p64[i];
+    }
+    hp = tmp.data();
+  }
+  hipError_t e1 = hipMalloc((void**)&dp, (size_t)(n_users + 1) * sizeof(int32_t));
+  hipError_t e2 = hipMalloc((void**)&di, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t));
+  m->x_ptr = dp;
+  m->x_idx = di;
+  if (e1 != hipSuccess || e2 != hipSuccess) {
+    rphip_csr_destroy(m);
+    RP_FAIL(RPHIP_ENOMEM, "hipMalloc of the CSR arrays failed");
+  }
+  hipEvent_t ev;
+  rp_time_begin(ctx, &ev);
+  e1 = hipMemcpyAsync(dp, hp, (size_t)(n_users + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+  e2 = nnz > 0 ? hipMemcpyAsync(di, indices_host, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
+  rp_time_end(ctx, ev, RPHIP_T_H2D, 4.0 * (double)(n_users + 1 + nnz));
+  hipError_t e3 = hipStreamSynchronize(ctx->stream);  // tmp may go out of scope
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+    rphip_csr_destroy(m);
+    RP_FAIL(RPHIP_EHIP, "host to device copy of the CSR arrays failed");
+  }
+  int r = rp_csr_prepare(ctx, m);
+  if (r != RPHIP_OK) {
+    rphip_csr_destroy(m);
+    return r;
+  }
+  *out = m;
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_csr_from_device(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_t nnz, const int32_t* indptr_dev,
+                                     const int32_t* indices_dev, rphip_csr** out) {
+  if (!ctx || !out || !indptr_dev || (nnz > 0 && !indices_dev)) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  RP_TRY(rp_csr_check_shape(n_users, n_items, nnz));
+  RP_TRY(rp_set_device(ctx));
+  rphip_csr* m = new rphip_csr();
+  m->ctx = ctx;
+  m->n_users = n_users;
+  m->n_items = n_items;
+  m->nnz = nnz;
+  m->owns_x = false;
+  m->x_ptr = indptr_dev;
+  m->x_idx = indices_dev;
+  int r = rp_csr_prepare(ctx, m);
+  if (r != RPHIP_OK) {
+    rphip_csr_destroy(m);
+    return r;
+  }
+  *out = m;
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_csr_destroy(rphip_csr* m) {
+  if (!m) return RPHIP_OK;
+  if (m->ctx) {
+    hipSetDevice(m->ctx->device);
+    hipStreamSynchronize(m->ctx->stream);
+  }
+  if (m->owns_x) {
+    if (m->x_ptr) hipFree((void*)m->x_ptr);
+    if (m->x_idx) hipFree((void*)m->x_idx);
+  }
+  if (m->xt_ptr) hipFree(m->xt_ptr);
+  if (m->xt_idx) hipFree(m->xt_idx);
+  if (m->deg) hipFree(m->deg);
+  if (m->inv_deg) hipFree(m->inv_deg);
+  if (m->tile_ptr) hipFree(m->tile_ptr);
+  if (m->row_cost) hipFree(m->row_cost);
+  delete m;
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_csr_shape(const rphip_csr* m, int64_t* n_users, int64_t* n_items, int64_t* nnz) {
+  if (!m) RP_FAIL(RPHIP_EINVAL, "matrix is NULL");
+  if (n_users) *n_users = m->n_users;
+  if (n_items) *n_items = m->n_items;
+  if (nnz) *nnz = m->nnz;
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_csr_item_degrees(rphip_ctx* ctx, const rphip_csr* m, int32_t* deg_host) {
+  if (!ctx || !m || !deg_host) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  RP_TRY(rp_set_device(ctx));
+  if (m->n_items > 0) RP_HIP(hipMemcpyAsync(deg_host, m->deg, (size_t)m->n_items * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  RP_HIP(hipStreamSynchronize(ctx->stream));
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_csr_num_products(rphip_ctx* ctx, const rphip_csr* m, int64_t* p_out) {
+  if (!ctx || !m || !p_out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *p_out = m->n_products;
+  return RPHIP_OK;
+}

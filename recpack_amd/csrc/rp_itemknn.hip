@@ -1,0 +1,633 @@
+// K1-K3: row-blocked Gram X^T X + cosine key + per-row top-K, fused (ItemKNN cosine fit).
+//
+// Replaces compute_cosine_similarity (recpack/algorithms/nearest_neighbour.py:69-84: sklearn
+// cosine_similarity(X.T) -> scipy csr_matmat, then setdiag(0)) and get_top_K_values (recpack/util.py:50-96,
+// called at nearest_neighbour.py:217).  The I x I similarity matrix is never materialised:
+//
+//   task = (item row i, column tile t, slice of the users of i)
+//   accumulate  c_ij = |users(i) & users(j)| for j in tile t into a dense u32 tile in LDS
+//               (one LDS atomic per scalar product; indices of X rows are gathered coalesced, 16 lanes
+//               per user row, 4 user rows per wave-step, 16 waves per workgroup)
+//   select      exact top-K of key(i,j) = fl(c_ij^2) * fl(1/c_j)  (monotone in cosine for fixed i), ties by
+//               smaller j (rp_select.h); emit (j, c_ij / sqrt(c_i c_j)) in column order
+//
+// Rows whose user list is long are cut into slices (partial tiles summed by a second launch), rows are
+// handed out heaviest first through a ticket counter to persistent workgroups (one per CU).
+#include <algorithm>
+
+#include "rp_common.h"
+#include "rp_select.h"
+
+struct rp_task {
+  int32_t row;      // item row
+  int32_t tile;     // column tile
+  int32_t p_begin;  // slice of xt_idx (mode 0/1)  |  first partial slot (mode 2)
+  int32_t p_end;    //                              |  one past the last partial slot
+  int32_t slot;     // mode 1: partial slot to write
+  int32_t mode;     // 0 = whole row: accumulate + select; 1 = slice: accumulate + dump; 2 = sum partials + select
+};
+
+struct rp_fit_params {
+  const int32_t* x_ptr;
+  const int32_t* x_idx;
+  const int32_t* xt_ptr;
+  const int32_t* xt_idx;
+  const int32_t* deg;
+  const double* inv_deg;
+  const int32_t* tile_ptr;
+  int n_items, n_tiles, tile_w, K, row_begin;
+  const rp_task* tasks;
+  const int32_t* n_tasks;
+  int32_t* ticket;
+  int32_t* out_idx;   // n_tiles == 1: final [rows*K]; else per-tile candidates [rows*T*K]
+  double* out_val;    // n_tiles == 1 only
+  uint32_t* out_cnt;  // n_tiles > 1: candidate counts c_ij
+  int32_t* out_nnz;   // [rows] or [rows*T]
+  uint32_t* part;     // partial tiles [slot][tile_w]
+};
+
+__device__ __forceinline__ uint64_t rp_fit_key(uint32_t c, double inv) {
+  // k = fl(c*c) * inv in [2^-31, 2^32): the exponent offset from 992 fits 6 bits; shift the 58
+  // significant bits to the top so that the first radix level already resolves 6 mantissa bits.
+  double k = (double)((uint64_t)c * (uint64_t)c) * inv;
+  uint64_t b = (uint64_t)__double_as_longlong(k);
+  return (b - (992ull << 52)) << 6;
+}
+
+struct rp_dense_src {
+  const uint32_t* acc;
+  const double* inv_deg;
+  int t0, row, n_cols;
+  __device__ __forceinline__ bool valid(int w) const { return acc[w] != 0u && (t0 + w) != row; }
+  __device__ __forceinline__ uint64_t key(int w) const { return rp_fit_key(acc[w], inv_deg[t0 + w]); }
+  __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)(t0 + w); }
+};
+
+__global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit(rp_fit_params P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t* acc = reinterpret_cast<uint32_t*>(smem);
+  rp_select_smem sel = rp_select_carve(smem + (size_t)P.tile_w * 4, P.tile_w);
+  int* s_task = &sel.misc[RPS_USER];  // all LDS lives in the dynamic region (keeps its base 16-B aligned)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = RP_FIT_THREADS / 64;
+  const int W = P.tile_w;
+  const int T = P.n_tiles;
+
+  for (int w = tid; w < W; w += RP_FIT_THREADS) acc[w] = 0u;
+  const int n_tasks = *P.n_tasks;
+
+  while (true) {
+    __syncthreads();
+    if (tid == 0) *s_task = atomicAdd(P.ticket, 1);
+    __syncthreads();
+    const int ti = *s_task;
+    if (ti >= n_tasks) break;
+    const rp_task tk = P.tasks[ti];
+    const int row = tk.row, tile = tk.tile;
+    const int t0 = tile * W;
+    const int n_cols = min(W, P.n_items - t0);
+
+    if (tk.mode != 2) {
+      // ---- accumulate: users p in [p_begin, p_end) of item `row`
+      for (int base = tk.p_begin + wave * 64; base < tk.p_end; base += NW * 64) {
+        const int p = base + lane;
+        int s = 0, len = 0;
+        if (p < tk.p_end) {
+          const int u = P.xt_idx[p];
+          int e;
+          if (T == 1) {
+            s = P.x_ptr[u];
+            e = P.x_ptr[u + 1];
+          } else {
+            const int32_t* tp = P.tile_ptr + (int64_t)u * (T + 1) + tile;
+            s = tp[0];
+            e = tp[1];
+          }
+          len = e - s;
+        }
+        const int n_user = min(64, tk.p_end - base);
+        for (int r = 0; r * 4 < n_user; ++r) {
+          const int srcl = r * 4 + (lane >> 4);
+          const int ss = __shfl(s, srcl);
+          const int ll = __shfl(len, srcl);
+          for (int k = lane & 15; k < ll; k += 16) {
+            const int j = P.x_idx[ss + k];
+            atomicAdd(&acc[j - t0], 1u);
+          }
+        }
+      }
+      __syncthreads();
+      if (tk.mode == 1) {
+        uint32_t* dst = P.part + (int64_t)tk.slot * W;
+        for (int w = tid; w < W; w += RP_FIT_THREADS) {
+          dst[w] = acc[w];
+          acc[w] = 0u;
+        }
+        continue;
+      }
+    } else {
+      for (int w = tid; w < W; w += RP_FIT_THREADS) {
+        uint32_t sum = 0;
+        for (int sl = tk.p_begin; sl < tk.p_end; ++sl) sum += P.part[(int64_t)sl * W + w];
+        acc[w] = sum;
+      }
+      __syncthreads();
+    }
+
+    // ---- select
+    rp_dense_src src{acc, P.inv_deg, t0, row, n_cols};
+    const int kp = rp_select_topk<RP_FIT_THREADS>(src, n_cols, P.K, sel);
+    const int rl = row - P.row_begin;
+    if (T == 1) {
+      int32_t* oi = P.out_idx + (int64_t)rl * P.K;
+      double* ov = P.out_val + (int64_t)rl * P.K;
+      const double ci = (double)P.deg[row];
+      rp_select_emit(n_cols, sel, [&](int pos, int w) {
+        const int j = t0 + w;
+        oi[pos] = j;
+        ov[pos] = (double)acc[w] / sqrt(ci * (double)P.deg[j]);
+      });
+      if (tid == 0) P.out_nnz[rl] = kp;
+    } else {
+      const int64_t o = ((int64_t)rl * T + tile) * P.K;
+      rp_select_emit(n_cols, sel, [&](int pos, int w) {
+        P.out_idx[o + pos] = t0 + w;
+        P.out_cnt[o + pos] = acc[w];
+      });
+      if (tid == 0) P.out_nnz[(int64_t)rl * T + tile] = kp;
+    }
+    __syncthreads();
+    for (int w = tid; w < W; w += RP_FIT_THREADS) acc[w] = 0u;
+  }
+}
+
+// ---- merge of per-tile candidates (n_tiles > 1) ---------------------------------------------------
+struct rp_list_src {
+  const int32_t* col_;
+  const uint32_t* cnt_;
+  const double* inv_deg;
+  int n;
+  __device__ __forceinline__ bool valid(int w) const { return w < n; }
+  __device__ __forceinline__ uint64_t key(int w) const { return rp_fit_key(cnt_[w], inv_deg[col_[w]]); }
+  __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)col_[w]; }
+};
+
+struct rp_merge_params {
+  const int32_t* cand_idx;
+  const uint32_t* cand_cnt;
+  const int32_t* cand_nnz;
+  const int32_t* deg;
+  const double* inv_deg;
+  int n_tiles, K, row_begin, n_rows;
+  int32_t* out_idx;
+  double* out_val;
+  int32_t* out_nnz;
+};
+
+__global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_merge(rp_merge_params P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = P.n_tiles, K = P.K;
+  const int cap = T * K;
+  int32_t* lcol = reinterpret_cast<int32_t*>(smem);
+  uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 4);
+  rp_select_smem sel = rp_select_carve(smem + (size_t)cap * 8, cap);
+  int* s_off = &sel.misc[RPS_USER];  // n_tiles + 1 <= 16 entries
+  const int tid = threadIdx.x;
+  for (int rl = blockIdx.x; rl < P.n_rows; rl += gridDim.x) {
+    __syncthreads();
+    if (tid == 0) {
+      int o = 0;
+      for (int t = 0; t < T; ++t) {
+        s_off[t] = o;
+        o += P.cand_nnz[(int64_t)rl * T + t];
+      }
+      s_off[T] = o;
+    }
+    __syncthreads();
+    const int n = s_off[T];
+    for (int t = 0; t < T; ++t) {
+      const int cn = s_off[t + 1] - s_off[t];
+      const int64_t src = ((int64_t)rl * T + t) * K;
+      for (int k = tid; k < cn; k += RP_FIT_THREADS) {
+        lcol[s_off[t] + k] = P.cand_idx[src + k];
+        lcnt[s_off[t] + k] = P.cand_cnt[src + k];
+      }
+    }
+    __syncthreads();
+    rp_list_src src{lcol, lcnt, P.inv_deg, n};
+    const int kp = rp_select_topk<RP_FIT_THREADS>(src, n, K, sel);
+    int32_t* oi = P.out_idx + (int64_t)rl * K;
+    double* ov = P.out_val + (int64_t)rl * K;
+    const double ci = (double)P.deg[P.row_begin + rl];
+    rp_select_emit(n, sel, [&](int pos, int w) {
+      const int j = lcol[w];
+      oi[pos] = j;
+      ov[pos] = (double)lcnt[w] / sqrt(ci * (double)P.deg[j]);
+    });
+    if (tid == 0) P.out_nnz[rl] = kp;
+  }
+}
+
+// ---- planning: order rows by degree (descending, coarse buckets), cut long rows into slices -------
+constexpr int PLAN_BUCKETS = 264;  // 0, then 8 per octave
+
+__device__ __forceinline__ int rp_deg_bucket(int d) {
+  if (d <= 0) return 0;
+  if (d < 8) return d;  // 1..7
+  const int lg = 31 - __clz(d);           // >= 3
+  return 8 * (lg - 2) + ((d >> (lg - 3)) & 7);  // 8.. ; monotone in d
+}
+
+__global__ void k_plan_hist(const int32_t* __restrict__ deg, int row_begin, int n_rows, int32_t* __restrict__ bucket_cnt) {
+  __shared__ int h[PLAN_BUCKETS];
+  for (int i = threadIdx.x; i < PLAN_BUCKETS; i += blockDim.x) h[i] = 0;
+  __syncthreads();
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += gridDim.x * blockDim.x)
+    atomicAdd(&h[rp_deg_bucket(deg[row_begin + r])], 1);
+  __syncthreads();
+  for (int i = threadIdx.x; i < PLAN_BUCKETS; i += blockDim.x)
+    if (h[i]) atomicAdd(&bucket_cnt[i], h[i]);
+}
+
+// bucket_cnt -> start offsets in DESCENDING bucket order (in place)
+__global__ void k_plan_offsets(int32_t* __restrict__ bucket_cnt) {
+  if (threadIdx.x == 0) {
+    int off = 0;
+    for (int b = PLAN_BUCKETS - 1; b >= 0; --b) {
+      int c = bucket_cnt[b];
+      bucket_cnt[b] = off;
+      off += c;
+    }
+  }
+}
+
+__global__ void k_plan_scatter(const int32_t* __restrict__ deg, int row_begin, int n_rows, int32_t* __restrict__ bucket_off,
+                               int32_t* __restrict__ order) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += gridDim.x * blockDim.x) {
+    const int row = row_begin + r;
+    const int pos = atomicAdd(&bucket_off[rp_deg_bucket(deg[row])], 1);
+    order[pos] = row;
+  }
+}
+
+// per ordered row: number of accumulate tasks, finalize tasks and partial slots
+__global__ void k_plan_count(const int32_t* __restrict__ deg, const int32_t* __restrict__ order, int n_rows, int n_tiles,
+                             int slice_users, int heavy_thr, int32_t* __restrict__ n_acc, int32_t* __restrict__ n_fin,
+                             int32_t* __restrict__ n_slot) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_rows; k += gridDim.x * blockDim.x) {
+    const int d = deg[order[k]];
+    int a = 0, f = 0, s = 0;
+    if (d > 0) {
+      if (d > heavy_thr) {
+        const int ns = (d + slice_users - 1) / slice_users;
+        a = ns * n_tiles;
+        f = n_tiles;
+        s = ns * n_tiles;
+      } else {
+        a = n_tiles;
+      }
+    }
+    n_acc[k] = a;
+    n_fin[k] = f;
+    n_slot[k] = s;
+  }
+}
+
+__global__ void k_plan_write(const int32_t* __restrict__ deg, const int32_t* __restrict__ xt_ptr, const int32_t* __restrict__ order,
+                             int n_rows, int n_tiles, int slice_users, int heavy_thr, const int32_t* __restrict__ off_acc,
+                             const int32_t* __restrict__ off_fin, const int32_t* __restrict__ off_slot,
+                             rp_task* __restrict__ acc_tasks, rp_task* __restrict__ fin_tasks) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_rows; k += gridDim.x * blockDim.x) {
+    const int row = order[k];
+    const int d = deg[row];
+    if (d <= 0) continue;
+    const int p0 = xt_ptr[row];
+    int oa = off_acc[k];
+    if (d > heavy_thr) {
+      const int ns = (d + slice_users - 1) / slice_users;
+      int of = off_fin[k];
+      int os = off_slot[k];
+      for (int t = 0; t < n_tiles; ++t) {
+        for (int s = 0; s < ns; ++s) {
+          rp_task tk;
+          tk.row = row;
+          tk.tile = t;
+          tk.p_begin = p0 + s * slice_users;
+          tk.p_end = p0 + min(d, (s + 1) * slice_users);
+          tk.slot = os + t * ns + s;
+          tk.mode = 1;
+          acc_tasks[oa++] = tk;
+        }
+        rp_task fk;
+        fk.row = row;
+        fk.tile = t;
+        fk.p_begin = os + t * ns;
+        fk.p_end = os + (t + 1) * ns;
+        fk.slot = -1;
+        fk.mode = 2;
+        fin_tasks[of++] = fk;
+      }
+    } else {
+      for (int t = 0; t < n_tiles; ++t) {
+        rp_task tk;
+        tk.row = row;
+        tk.tile = t;
+        tk.p_begin = p0;
+        tk.p_end = p0 + d;
+        tk.slot = -1;
+        tk.mode = 0;
+        acc_tasks[oa++] = tk;
+      }
+    }
+  }
+}
+
+__global__ void k_f64_to_f32(const double* __restrict__ in, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (float)in[i];
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+static int rp_model_alloc_topk(rphip_ctx* ctx, int64_t n_items, int64_t r0, int64_t r1, int32_t K, rphip_model** out) {
+  rphip_model* m = new rphip_model();
+  m->ctx = ctx;
+  m->kind = RPHIP_MODEL_TOPK;
+  m->n_items = n_items;
+  m->row_begin = r0;
+  m->row_end = r1;
+  m->K = K;
+  const size_t n = (size_t)std::max<int64_t>(1, (r1 - r0) * (int64_t)K);
+  hipError_t e1 = hipMalloc((void**)&m->idx, n * sizeof(int32_t));
+  hipError_t e2 = hipMalloc((void**)&m->val, n * sizeof(double));
+  hipError_t e3 = hipMalloc((void**)&m->val32, n * sizeof(float));
+  hipError_t e4 = hipMalloc((void**)&m->nnz, (size_t)std::max<int64_t>(1, r1 - r0) * sizeof(int32_t));
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+    rphip_model_destroy(m);
+    RP_FAIL(RPHIP_ENOMEM, "hipMalloc of the neighbour lists failed (%lld rows x K=%d)", (long long)(r1 - r0), K);
+  }
+  *out = m;
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_model_destroy(rphip_model* m) {
+  if (!m) return RPHIP_OK;
+  if (m->ctx) hipSetDevice(m->ctx->device);
+  if (m->idx) hipFree(m->idx);
+  if (m->val) hipFree(m->val);
+  if (m->val32) hipFree(m->val32);
+  if (m->nnz) hipFree(m->nnz);
+  if (m->B) hipFree(m->B);
+  delete m;
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_model_info(const rphip_model* m, int32_t* kind, int64_t* n_items, int64_t* row_begin, int64_t* row_end,
+                                int32_t* K) {
+  if (!m) RP_FAIL(RPHIP_EINVAL, "model is NULL");
+  if (kind) *kind = m->kind;
+  if (n_items) *n_items = m->n_items;
+  if (row_begin) *row_begin = m->row_begin;
+  if (row_end) *row_end = m->row_end;
+  if (K) *K = m->K;
+  return RPHIP_OK;
+}
+
+static size_t rp_fit_lds_bytes(int tile_w) { return (size_t)tile_w * 4 + rp_select_smem_bytes(tile_w); }
+
+extern "C" int rphip_itemknn_fit(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K,
+                                 rphip_model** out) {
+  if (!ctx || !X || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (row_begin < 0 || row_end > X->n_items || row_begin > row_end)
+    RP_FAIL(RPHIP_EINVAL, "row range [%lld,%lld) outside 0..%lld", (long long)row_begin, (long long)row_end, (long long)X->n_items);
+  if (K < 1) RP_FAIL(RPHIP_EINVAL, "K must be >= 1 (got %d)", K);
+  RP_TRY(rp_set_device(ctx));
+  // a row has at most n_items-1 neighbours
+  const int32_t Keff = (int32_t)std::min<int64_t>(K, std::max<int64_t>(1, X->n_items - 1));
+  if (Keff > RP_K_MAX) RP_FAIL(RPHIP_ELIMIT, "effective K=%d exceeds the supported maximum %d", Keff, RP_K_MAX);
+  const int n_rows = (int)(row_end - row_begin);
+  const int T = X->n_tiles, W = X->tile_w;
+
+  K = Keff;  // the model's row stride; rphip_model_info reports it
+  if (T > 15) RP_FAIL(RPHIP_ELIMIT, "%d column tiles (n_items=%lld) exceed the supported 15", T, (long long)X->n_items);
+  rphip_model* m = nullptr;
+  RP_TRY(rp_model_alloc_topk(ctx, X->n_items, row_begin, row_end, K, &m));
+  hipStream_t st = ctx->stream;
+  const size_t nk = (size_t)std::max<int64_t>(1, (int64_t)n_rows * K);
+  hipMemsetAsync(m->idx, 0xFF, nk * sizeof(int32_t), st);
+  hipMemsetAsync(m->val, 0, nk * sizeof(double), st);
+  hipMemsetAsync(m->nnz, 0, (size_t)std::max(1, n_rows) * sizeof(int32_t), st);
+  if (n_rows == 0 || X->nnz == 0) {
+    hipMemsetAsync(m->val32, 0, nk * sizeof(float), st);
+    *out = m;
+    return RPHIP_OK;
+  }
+
+  // ---- plan
+  hipEvent_t ev;
+  rp_time_begin(ctx, &ev);
+  const int slice_users = (int)std::min<int64_t>(1 << 20, std::max<int64_t>(1024, X->nnz / ((int64_t)ctx->n_cu * 8)));
+  const int heavy_thr = 2 * slice_users;
+  // upper bounds: every row n_tiles tasks, plus slices
+  const int64_t max_slices = (X->nnz / slice_users + X->nnz / heavy_thr + 2) * T;
+  const int64_t max_acc = (int64_t)n_rows * T + max_slices;
+  const int64_t max_fin = std::min<int64_t>((int64_t)n_rows, X->nnz / heavy_thr + 1) * T;
+  char* sc = nullptr;
+  const size_t plan_bytes = (size_t)PLAN_BUCKETS * 4 + (size_t)n_rows * 4 * 4 + (size_t)(n_rows + 1) * 4 * 3 + 64 +
+                            (size_t)(max_acc + max_fin) * sizeof(rp_task) + 256;
+  RP_TRY(rp_scratch(ctx, 0, plan_bytes, (void**)&sc));
+  size_t o = 0;
+  auto carve = [&](size_t bytes) {
+    char* p = sc + o;
+    o += (bytes + 15) & ~(size_t)15;
+    return p;
+  };
+  int32_t* bucket = (int32_t*)carve(PLAN_BUCKETS * 4);
+  int32_t* order = (int32_t*)carve((size_t)n_rows * 4);
+  int32_t* n_acc = (int32_t*)carve((size_t)n_rows * 4);
+  int32_t* n_fin = (int32_t*)carve((size_t)n_rows * 4);
+  int32_t* n_slot = (int32_t*)carve((size_t)n_rows * 4);
+  int32_t* off_acc = (int32_t*)carve((size_t)(n_rows + 1) * 4);
+  int32_t* off_fin = (int32_t*)carve((size_t)(n_rows + 1) * 4);
+  int32_t* off_slot = (int32_t*)carve((size_t)(n_rows + 1) * 4);
+  int32_t* tickets = (int32_t*)carve(16);
+  rp_task* acc_tasks = (rp_task*)carve((size_t)max_acc * sizeof(rp_task));
+  rp_task* fin_tasks = (rp_task*)carve((size_t)max_fin * sizeof(rp_task));
+  hipMemsetAsync(bucket, 0, PLAN_BUCKETS * 4, st);
+  hipMemsetAsync(tickets, 0, 16, st);
+  const int pb = 256, pg = (int)std::min<int64_t>(1024, rp_cdiv(n_rows, pb));
+  hipLaunchKernelGGL(k_plan_hist, dim3(pg), dim3(pb), 0, st, X->deg, (int)row_begin, n_rows, bucket);
+  hipLaunchKernelGGL(k_plan_offsets, dim3(1), dim3(64), 0, st, bucket);
+  hipLaunchKernelGGL(k_plan_scatter, dim3(pg), dim3(pb), 0, st, X->deg, (int)row_begin, n_rows, bucket, order);
+  hipLaunchKernelGGL(k_plan_count, dim3(pg), dim3(pb), 0, st, X->deg, order, n_rows, T, slice_users, heavy_thr, n_acc, n_fin,
+                     n_slot);
+  RP_TRY(rp_exclusive_scan_i32(ctx, n_acc, off_acc, n_rows));
+  RP_TRY(rp_exclusive_scan_i32(ctx, n_fin, off_fin, n_rows));
+  RP_TRY(rp_exclusive_scan_i32(ctx, n_slot, off_slot, n_rows));
+  hipLaunchKernelGGL(k_plan_write, dim3(pg), dim3(pb), 0, st, X->deg, X->xt_ptr, order, n_rows, T, slice_users, heavy_thr,
+                     off_acc, off_fin, off_slot, acc_tasks, fin_tasks);
+  RP_HIP(hipGetLastError());
+  rp_time_end(ctx, ev, RPHIP_T_FIT_PLAN, 0.0);
+
+  // ---- partial tiles and per-tile candidates
+  uint32_t* part = nullptr;
+  RP_TRY(rp_scratch(ctx, 1, (size_t)std::max<int64_t>(1, max_slices) * W * 4, (void**)&part));
+  int32_t* cand_idx = nullptr;
+  uint32_t* cand_cnt = nullptr;
+  int32_t* cand_nnz = nullptr;
+  if (T > 1) {
+    char* cb = nullptr;
+    const size_t n_c = (size_t)n_rows * T * Keff;
+    RP_TRY(rp_scratch(ctx, 2, n_c * 8 + (size_t)n_rows * T * 4 + 64, (void**)&cb));
+    cand_idx = (int32_t*)cb;
+    cand_cnt = (uint32_t*)(cb + n_c * 4);
+    cand_nnz = (int32_t*)(cb + n_c * 8);
+    hipMemsetAsync(cand_nnz, 0, (size_t)n_rows * T * 4, st);
+  }
+
+  rp_fit_params P;
+  P.x_ptr = X->x_ptr;
+  P.x_idx = X->x_idx;
+  P.xt_ptr = X->xt_ptr;
+  P.xt_idx = X->xt_idx;
+  P.deg = X->deg;
+  P.inv_deg = X->inv_deg;
+  P.tile_ptr = X->tile_ptr;
+  P.n_items = (int)X->n_items;
+  P.n_tiles = T;
+  P.tile_w = W;
+  P.K = K;
+  P.row_begin = (int)row_begin;
+  P.part = part;
+  if (T == 1) {
+    P.out_idx = m->idx;
+    P.out_val = m->val;
+    P.out_cnt = nullptr;
+    P.out_nnz = m->nnz;
+  } else {
+    P.out_idx = cand_idx;
+    P.out_val = nullptr;
+    P.out_cnt = cand_cnt;
+    P.out_nnz = cand_nnz;
+  }
+  const size_t lds = rp_fit_lds_bytes(W);
+  RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_fit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int grid = ctx->n_cu;
+
+  rp_time_begin(ctx, &ev);
+  P.tasks = acc_tasks;
+  P.n_tasks = off_acc + n_rows;
+  P.ticket = tickets;
+  hipLaunchKernelGGL(k_itemknn_fit, dim3(grid), dim3(RP_FIT_THREADS), lds, st, P);
+  P.tasks = fin_tasks;
+  P.n_tasks = off_fin + n_rows;
+  P.ticket = tickets + 1;
+  hipLaunchKernelGGL(k_itemknn_fit, dim3(grid), dim3(RP_FIT_THREADS), lds, st, P);
+  RP_HIP(hipGetLastError());
+  // algorithmic bytes of the SpGEMM: 4*P_shard + 8*nnz + 4*(U+I+2) + 8*rows*K; the
+  // caller scales P by the shard's share, here the full-matrix figure is attributed when rows cover all.
+  double work = 8.0 * (double)X->nnz + 4.0 * (double)(X->n_users + X->n_items + 2) + 12.0 * (double)n_rows * K;
+  if (X->n_products >= 0) work += 4.0 * (double)X->n_products * ((double)n_rows / (double)X->n_items);
+  rp_time_end(ctx, ev, RPHIP_T_GRAM_TOPK, work);
+
+  if (T > 1) {
+    rp_time_begin(ctx, &ev);
+    rp_merge_params M;
+    M.cand_idx = cand_idx;
+    M.cand_cnt = cand_cnt;
+    M.cand_nnz = cand_nnz;
+    M.deg = X->deg;
+    M.inv_deg = X->inv_deg;
+    M.n_tiles = T;
+    M.K = Keff;
+    M.row_begin = (int)row_begin;
+    M.n_rows = n_rows;
+    M.out_idx = m->idx;
+    M.out_val = m->val;
+    M.out_nnz = m->nnz;
+    const size_t mlds = (size_t)T * Keff * 8 + rp_select_smem_bytes(T * Keff);
+    if (mlds > 160 * 1024) {
+      rphip_model_destroy(m);
+      RP_FAIL(RPHIP_ELIMIT, "K=%d with %d column tiles needs %zu bytes of LDS for the merge", K, T, mlds);
+    }
+    RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+    const int mg = (int)std::min<int64_t>(n_rows, (int64_t)ctx->n_cu * 2);
+    hipLaunchKernelGGL(k_itemknn_merge, dim3(mg), dim3(RP_FIT_THREADS), mlds, st, M);
+    RP_HIP(hipGetLastError());
+    rp_time_end(ctx, ev, RPHIP_T_TOPK_MERGE, 16.0 * (double)n_rows * T * Keff);
+  }
+  hipLaunchKernelGGL(k_f64_to_f32, dim3((unsigned)std::min<int64_t>(2048, rp_cdiv((int64_t)nk, 256))), dim3(256), 0, st, m->val,
+                     m->val32, (int64_t)nk);
+  RP_HIP(hipGetLastError());
+  *out = m;
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_model_topk_download(rphip_ctx* ctx, const rphip_model* m, int32_t* idx_host, double* val_host,
+                                         int32_t* nnz_host) {
+  if (!ctx || !m) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if (m->kind != RPHIP_MODEL_TOPK) RP_FAIL(RPHIP_ESTATE, "model is not a neighbour-list model");
+  RP_TRY(rp_set_device(ctx));
+  const int64_t rows = m->row_end - m->row_begin;
+  hipEvent_t ev;
+  rp_time_begin(ctx, &ev);
+  if (rows > 0) {
+    if (idx_host) RP_HIP(hipMemcpyAsync(idx_host, m->idx, (size_t)rows * m->K * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (val_host) RP_HIP(hipMemcpyAsync(val_host, m->val, (size_t)rows * m->K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (nnz_host) RP_HIP(hipMemcpyAsync(nnz_host, m->nnz, (size_t)rows * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  rp_time_end(ctx, ev, RPHIP_T_D2H, (double)rows * m->K * 12.0);
+  RP_HIP(hipStreamSynchronize(ctx->stream));
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_model_topk_device(const rphip_model* m, void** idx_dev, void** val_dev, void** nnz_dev, int64_t* rows,
+                                       int32_t* K) {
+  if (!m) RP_FAIL(RPHIP_EINVAL, "model is NULL");
+  if (m->kind != RPHIP_MODEL_TOPK) RP_FAIL(RPHIP_ESTATE, "model is not a neighbour-list model");
+  if (idx_dev) *idx_dev = m->idx;
+  if (val_dev) *val_dev = m->val;
+  if (nnz_dev) *nnz_dev = m->nnz;
+  if (rows) *rows = m->row_end - m->row_begin;
+  if (K) *K = m->K;
+  return RPHIP_OK;
+}
+
+static int rp_model_from_topk(rphip_ctx* ctx, int64_t n_items, int32_t K, const int32_t* idx, const double* val,
+                              const int32_t* nnz, hipMemcpyKind kind, rphip_model** out) {
+  if (!ctx || !idx || !val || !nnz || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if (n_items < 0 || K < 1) RP_FAIL(RPHIP_EINVAL, "bad shape (%lld x %d)", (long long)n_items, K);
+  RP_TRY(rp_set_device(ctx));
+  rphip_model* m = nullptr;
+  RP_TRY(rp_model_alloc_topk(ctx, n_items, 0, n_items, K, &m));
+  const size_t nk = (size_t)n_items * K;
+  if (nk) {
+    hipEvent_t ev;
+    rp_time_begin(ctx, &ev);
+    hipError_t e1 = hipMemcpyAsync(m->idx, idx, nk * sizeof(int32_t), kind, ctx->stream);
+    hipError_t e2 = hipMemcpyAsync(m->val, val, nk * sizeof(double), kind, ctx->stream);
+    hipError_t e3 = hipMemcpyAsync(m->nnz, nnz, (size_t)n_items * sizeof(int32_t), kind, ctx->stream);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+      rphip_model_destroy(m);
+      RP_FAIL(RPHIP_EHIP, "copy of the neighbour lists failed");
+    }
+    if (kind == hipMemcpyHostToDevice) rp_time_end(ctx, ev, RPHIP_T_H2D, (double)nk * 12.0);
+    else ctx->ev_pool.push_back(ev);
+    hipLaunchKernelGGL(k_f64_to_f32, dim3((unsigned)std::min<int64_t>(2048, rp_cdiv((int64_t)nk, 256))), dim3(256), 0, ctx->stream,
+                       m->val, m->val32, (int64_t)nk);
+    if (kind == hipMemcpyHostToDevice) RP_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  *out = m;
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_model_from_topk_host(rphip_ctx* ctx, int64_t n_items, int32_t K, const int32_t* idx_host,
+                                          const double* val_host, const int32_t* nnz_host, rphip_model** out) {
+  return rp_model_from_topk(ctx, n_items, K, idx_host, val_host, nnz_host, hipMemcpyHostToDevice, out);
+}
+
+extern "C" int rphip_model_from_topk_device(rphip_ctx* ctx, int64_t n_items, int32_t K, const int32_t* idx_dev,
+                                            const double* val_dev, const int32_t* nnz_dev, rphip_model** out) {
+  return rp_model_from_topk(ctx, n_items, K, idx_dev, val_dev, nnz_dev, hipMemcpyDeviceToDevice, out);
+}

@@ -1,0 +1,372 @@
+// K8: predict for neighbour-list models: scores = X @ S with a fused per-user top-Kp.
+//
+// Replaces ItemSimilarityMatrixAlgorithm._predict (recpack/algorithms/base.py:237-255, `X @ similarity_matrix_`,
+// scipy csr_matmat on one thread).  With Kp the kernel also applies what the reference does to the scores
+// afterwards: optional history removal (recpack/pipelines/pipeline.py:174-175) and the per-user top-K of
+// MetricTopK (recpack/metrics/base.py:189 -> recpack/util.py:50-77).  The U x I score matrix is never stored.
+//
+//   task = (user u, column tile t)
+//   accumulate  for every history item i of u: the <= K (j, s_ij) pairs of S row i (contiguous, coalesced)
+//               are added into a dense f32 tile in LDS with LDS float atomics; one wave per history item
+//   select      exact top-Kp by (score desc, column asc)  (rp_select.h), emitted in column order
+//
+// The "full" variants return every non-zero score (the reference's CSR result) in two phases: count, fill.
+#include <algorithm>
+
+#include "rp_common.h"
+#include "rp_select.h"
+
+constexpr int RP_PRED_THREADS = 1024;
+
+struct rp_pred_params {
+  const int32_t* x_ptr;   // prediction input (binary CSR)
+  const int32_t* x_idx;
+  const int32_t* s_idx;   // model: [I*K]
+  const float* s_val;
+  const int32_t* s_nnz;
+  int n_items, n_tiles, tile_w, K, Kp, exclude_history;
+  int user_begin, n_users;
+  int mode;               // 0 = top-Kp, 1 = count, 2 = fill
+  int32_t* out_idx;       // mode 0, T==1: [n*Kp]; T>1: candidates [n*T*Kp]
+  float* out_val;
+  int32_t* out_nnz;       // [n] or [n*T]
+  long long* row_nnz;     // mode 1: [n]
+  const long long* indptr;  // mode 2: [n+1]
+  int32_t* full_idx;      // mode 2
+  double* full_val;
+};
+
+struct rp_score_src {
+  const float* acc;
+  int t0;
+  __device__ __forceinline__ bool valid(int w) const { return acc[w] != 0.0f; }
+  __device__ __forceinline__ uint64_t key(int w) const {
+    // order-preserving map of a float (any sign) to u32, placed in the high half
+    uint32_t b = __float_as_uint(acc[w]);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return (uint64_t)b << 32;
+  }
+  __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)(t0 + w); }
+};
+
+__global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_sparse(rp_pred_params P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* acc = reinterpret_cast<float*>(smem);
+  rp_select_smem sel = rp_select_carve(smem + (size_t)P.tile_w * 4, P.tile_w);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = RP_PRED_THREADS / 64;
+  const int W = P.tile_w, T = P.n_tiles, K = P.K;
+
+  for (int w = tid; w < W; w += RP_PRED_THREADS) acc[w] = 0.0f;
+  __syncthreads();
+
+  // modes 1/2 walk the tiles of a user inside the workgroup (output offsets are sequential);
+  // mode 0 treats (user, tile) as independent tasks.
+  const long long n_tasks = (P.mode == 0) ? (long long)P.n_users * T : (long long)P.n_users;
+  for (long long task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+    const int ul = (P.mode == 0) ? (int)(task / T) : (int)task;
+    const int u = P.user_begin + ul;
+    const int hs = P.x_ptr[u], he = P.x_ptr[u + 1];
+    long long off = (P.mode == 2) ? P.indptr[ul] : 0;
+    long long total = 0;
+    const int t_first = (P.mode == 0) ? (int)(task % T) : 0;
+    const int t_last = (P.mode == 0) ? t_first + 1 : T;
+    for (int tile = t_first; tile < t_last; ++tile) {
+      const int t0 = tile * W;
+      const int n_cols = min(W, P.n_items - t0);
+      // ---- accumulate
+      for (int h = hs + wave; h < he; h += NW) {
+        const int i = P.x_idx[h];
+        const int nn = P.s_nnz[i];
+        const int32_t* si = P.s_idx + (int64_t)i * K;
+        const float* sv = P.s_val + (int64_t)i * K;
+        for (int k = lane; k < nn; k += 64) {
+          const int j = si[k] - t0;
+          if ((unsigned)j < (unsigned)n_cols) atomicAdd(&acc[j], sv[k]);
+        }
+      }
+      __syncthreads();
+      if (P.exclude_history) {
+        for (int h = hs + tid; h < he; h += RP_PRED_THREADS) {
+          const int j = P.x_idx[h] - t0;
+          if ((unsigned)j < (unsigned)n_cols) acc[j] = 0.0f;
+        }
+        __syncthreads();
+      }
+      // ---- select
+      rp_score_src src{acc, t0};
+      const int kk = (P.mode == 0) ? P.Kp : 0x7fffffff;
+      const int kp = rp_select_topk<RP_PRED_THREADS>(src, n_cols, kk, sel);
+      if (P.mode == 0) {
+        const int64_t o = (T == 1) ? (int64_t)ul * P.Kp : ((int64_t)ul * T + tile) * P.Kp;
+        rp_select_emit(n_cols, sel, [&](int pos, int w) {
+          P.out_idx[o + pos] = t0 + w;
+          P.out_val[o + pos] = acc[w];
+        });
+        if (tid == 0) P.out_nnz[(T == 1) ? ul : ul * T + tile] = kp;
+      } else if (P.mode == 2) {
+        rp_select_emit(n_cols, sel, [&](int pos, int w) {
+          P.full_idx[off + pos] = t0 + w;
+          P.full_val[off + pos] = (double)acc[w];
+        });
+        off += kp;
+      }
+      total += kp;
+      __syncthreads();
+      for (int w = tid; w < W; w += RP_PRED_THREADS) acc[w] = 0.0f;
+      __syncthreads();
+    }
+    if (P.mode == 1 && tid == 0) P.row_nnz[ul] = total;
+  }
+}
+
+// ---- merge of per-tile top-Kp candidates -----------------------------------------------------------
+struct rp_flist_src {
+  const int32_t* col_;
+  const float* val_;
+  int n;
+  __device__ __forceinline__ bool valid(int w) const { return w < n; }
+  __device__ __forceinline__ uint64_t key(int w) const {
+    uint32_t b = __float_as_uint(val_[w]);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return (uint64_t)b << 32;
+  }
+  __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)col_[w]; }
+};
+
+__global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_merge(const int32_t* __restrict__ cand_idx, const float* __restrict__ cand_val,
+                                                                  const int32_t* __restrict__ cand_nnz, int n_tiles, int Kp, int n_users,
+                                                                  int32_t* __restrict__ out_idx, float* __restrict__ out_val,
+                                                                  int32_t* __restrict__ out_nnz) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = n_tiles, cap = T * Kp;
+  int32_t* lcol = reinterpret_cast<int32_t*>(smem);
+  float* lval = reinterpret_cast<float*>(smem + (size_t)cap * 4);
+  rp_select_smem sel = rp_select_carve(smem + (size_t)cap * 8, cap);
+  int* s_off = &sel.misc[RPS_USER];
+  const int tid = threadIdx.x;
+  for (int ul = blockIdx.x; ul < n_users; ul += gridDim.x) {
+    __syncthreads();
+    if (tid == 0) {
+      int o = 0;
+      for (int t = 0; t < T; ++t) {
+        s_off[t] = o;
+        o += cand_nnz[(int64_t)ul * T + t];
+      }
+      s_off[T] = o;
+    }
+    __syncthreads();
+    const int n = s_off[T];
+    for (int t = 0; t < T; ++t) {
+      const int cn = s_off[t + 1] - s_off[t];
+      const int64_t so = ((int64_t)ul * T + t) * Kp;
+      for (int k = tid; k < cn; k += RP_PRED_THREADS) {
+        lcol[s_off[t] + k] = cand_idx[so + k];
+        lval[s_off[t] + k] = cand_val[so + k];
+      }
+    }
+    __syncthreads();
+    rp_flist_src src{lcol, lval, n};
+    const int kp = rp_select_topk<RP_PRED_THREADS>(src, n, Kp, sel);
+    rp_select_emit(n, sel, [&](int pos, int w) {
+      out_idx[(int64_t)ul * Kp + pos] = lcol[w];
+      out_val[(int64_t)ul * Kp + pos] = lval[w];
+    });
+    if (tid == 0) out_nnz[ul] = kp;
+  }
+}
+
+// ---- host ------------------------------------------------------------------------------------------
+static int rp_pred_check(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* X, int64_t ub, int64_t ue) {
+  if (!ctx || !model || !X) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if (model->kind != RPHIP_MODEL_TOPK) RP_FAIL(RPHIP_ESTATE, "rp_predict_sparse needs a neighbour-list model");
+  if (model->row_begin != 0 || model->row_end != model->n_items)
+    RP_FAIL(RPHIP_ESTATE, "the model holds rows [%lld,%lld) of %lld: assemble all rows before predict", (long long)model->row_begin,
+            (long long)model->row_end, (long long)model->n_items);
+  if (X->n_items != model->n_items)
+    RP_FAIL(RPHIP_EINVAL, "prediction matrix has %lld items, the model %lld", (long long)X->n_items, (long long)model->n_items);
+  if (ub < 0 || ue > X->n_users || ub > ue) RP_FAIL(RPHIP_EINVAL, "user range [%lld,%lld) outside 0..%lld", (long long)ub, (long long)ue, (long long)X->n_users);
+  return RPHIP_OK;
+}
+
+static void rp_pred_fill(rp_pred_params& P, const rphip_model* m, const rphip_csr* X, int64_t ub, int64_t ue) {
+  P.x_ptr = X->x_ptr;
+  P.x_idx = X->x_idx;
+  P.s_idx = m->idx;
+  P.s_val = m->val32;
+  P.s_nnz = m->nnz;
+  P.n_items = (int)X->n_items;
+  P.n_tiles = X->n_tiles;
+  P.tile_w = X->tile_w;
+  P.K = m->K;
+  P.Kp = 0;
+  P.exclude_history = 0;
+  P.user_begin = (int)ub;
+  P.n_users = (int)(ue - ub);
+  P.mode = 0;
+  P.out_idx = nullptr;
+  P.out_val = nullptr;
+  P.out_nnz = nullptr;
+  P.row_nnz = nullptr;
+  P.indptr = nullptr;
+  P.full_idx = nullptr;
+  P.full_val = nullptr;
+}
+
+static size_t rp_pred_lds(int tile_w) { return (size_t)tile_w * 4 + rp_select_smem_bytes(tile_w); }
+
+// algorithmic bytes of K8: 8*K*nnz_pred + 4*(nnz_pred+U) + 8*U*Kp
+static double rp_pred_work(const rphip_csr* X, const rphip_model* m, int64_t n_users, int Kp) {
+  const double share = X->n_users > 0 ? (double)n_users / (double)X->n_users : 0.0;
+  return 8.0 * m->K * (double)X->nnz * share + 4.0 * ((double)X->nnz * share + (double)n_users) + 8.0 * (double)n_users * Kp;
+}
+
+extern "C" int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin,
+                                      int64_t user_end, int32_t Kp, int32_t exclude_history, int32_t* idx_dev, float* val_dev,
+                                      int32_t* nnz_dev) {
+  RP_TRY(rp_pred_check(ctx, model, Xpred, user_begin, user_end));
+  if (!idx_dev || !val_dev || !nnz_dev) RP_FAIL(RPHIP_EINVAL, "NULL output");
+  if (Kp < 1 || Kp > RP_K_MAX) RP_FAIL(RPHIP_ELIMIT, "Kp=%d outside 1..%d", Kp, RP_K_MAX);
+  RP_TRY(rp_set_device(ctx));
+  const int64_t n = user_end - user_begin;
+  if (n == 0) return RPHIP_OK;
+  hipStream_t st = ctx->stream;
+  const int T = Xpred->n_tiles;
+  hipMemsetAsync(idx_dev, 0xFF, (size_t)n * Kp * 4, st);
+  hipMemsetAsync(val_dev, 0, (size_t)n * Kp * 4, st);
+  hipMemsetAsync(nnz_dev, 0, (size_t)n * 4, st);
+  rp_pred_params P;
+  rp_pred_fill(P, model, Xpred, user_begin, user_end);
+  P.Kp = Kp;
+  P.exclude_history = exclude_history;
+  P.mode = 0;
+  int32_t* cand_idx = nullptr;
+  float* cand_val = nullptr;
+  int32_t* cand_nnz = nullptr;
+  if (T == 1) {
+    P.out_idx = idx_dev;
+    P.out_val = val_dev;
+    P.out_nnz = nnz_dev;
+  } else {
+    if (T > 15) RP_FAIL(RPHIP_ELIMIT, "%d column tiles exceed the supported 15", T);
+    char* cb = nullptr;
+    const size_t nc = (size_t)n * T * Kp;
+    RP_TRY(rp_scratch(ctx, 2, nc * 8 + (size_t)n * T * 4 + 64, (void**)&cb));
+    cand_idx = (int32_t*)cb;
+    cand_val = (float*)(cb + nc * 4);
+    cand_nnz = (int32_t*)(cb + nc * 8);
+    hipMemsetAsync(cand_nnz, 0, (size_t)n * T * 4, st);
+    P.out_idx = cand_idx;
+    P.out_val = cand_val;
+    P.out_nnz = cand_nnz;
+  }
+  const size_t lds = rp_pred_lds(Xpred->tile_w);
+  RP_HIP(hipFuncSetAttribute((const void*)k_predict_sparse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int grid = (int)std::min<int64_t>(n * T, (int64_t)ctx->n_cu * 8);
+  hipEvent_t ev;
+  rp_time_begin(ctx, &ev);
+  hipLaunchKernelGGL(k_predict_sparse, dim3(grid), dim3(RP_PRED_THREADS), lds, st, P);
+  if (T > 1) {
+    const size_t mlds = (size_t)T * Kp * 8 + rp_select_smem_bytes(T * Kp);
+    if (mlds > 160 * 1024) RP_FAIL(RPHIP_ELIMIT, "Kp=%d with %d column tiles needs %zu bytes of LDS for the merge", Kp, T, mlds);
+    RP_HIP(hipFuncSetAttribute((const void*)k_predict_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+    const int mg = (int)std::min<int64_t>(n, (int64_t)ctx->n_cu * 8);
+    hipLaunchKernelGGL(k_predict_merge, dim3(mg), dim3(RP_PRED_THREADS), mlds, st, cand_idx, cand_val, cand_nnz, T, Kp, (int)n, idx_dev,
+                       val_dev, nnz_dev);
+  }
+  RP_HIP(hipGetLastError());
+  rp_time_end(ctx, ev, RPHIP_T_PREDICT, rp_pred_work(Xpred, model, n, Kp));
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_predict_topk(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin,
+                                  int64_t user_end, int32_t Kp, int32_t exclude_history, int32_t* idx_host, float* val_host,
+                                  int32_t* nnz_host) {
+  RP_TRY(rp_pred_check(ctx, model, Xpred, user_begin, user_end));
+  if (!idx_host || !val_host || !nnz_host) RP_FAIL(RPHIP_EINVAL, "NULL output");
+  if (Kp < 1 || Kp > RP_K_MAX) RP_FAIL(RPHIP_ELIMIT, "Kp=%d outside 1..%d", Kp, RP_K_MAX);
+  RP_TRY(rp_set_device(ctx));
+  const int64_t n = user_end - user_begin;
+  if (n == 0) return RPHIP_OK;
+  char* ob = nullptr;
+  RP_TRY(rp_scratch(ctx, 3, (size_t)n * Kp * 8 + (size_t)n * 4 + 64, (void**)&ob));
+  int32_t* di = (int32_t*)ob;
+  float* dv = (float*)(ob + (size_t)n * Kp * 4);
+  int32_t* dn = (int32_t*)(ob + (size_t)n * Kp * 8);
+  RP_TRY(rphip_predict_topk_dev(ctx, model, Xpred, user_begin, user_end, Kp, exclude_history, di, dv, dn));
+  hipEvent_t ev;
+  rp_time_begin(ctx, &ev);
+  RP_HIP(hipMemcpyAsync(idx_host, di, (size_t)n * Kp * 4, hipMemcpyDeviceToHost, ctx->stream));
+  RP_HIP(hipMemcpyAsync(val_host, dv, (size_t)n * Kp * 4, hipMemcpyDeviceToHost, ctx->stream));
+  RP_HIP(hipMemcpyAsync(nnz_host, dn, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  rp_time_end(ctx, ev, RPHIP_T_D2H, (double)n * Kp * 8.0);
+  RP_HIP(hipStreamSynchronize(ctx->stream));
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_predict_full_count(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin,
+                                        int64_t user_end, int64_t* row_nnz_host, int64_t* total_out) {
+  RP_TRY(rp_pred_check(ctx, model, Xpred, user_begin, user_end));
+  if (!row_nnz_host || !total_out) RP_FAIL(RPHIP_EINVAL, "NULL output");
+  RP_TRY(rp_set_device(ctx));
+  const int64_t n = user_end - user_begin;
+  *total_out = 0;
+  if (n == 0) return RPHIP_OK;
+  long long* dn = nullptr;
+  RP_TRY(rp_scratch(ctx, 3, (size_t)n * 8, (void**)&dn));
+  rp_pred_params P;
+  rp_pred_fill(P, model, Xpred, user_begin, user_end);
+  P.mode = 1;
+  P.row_nnz = dn;
+  const size_t lds = rp_pred_lds(Xpred->tile_w);
+  RP_HIP(hipFuncSetAttribute((const void*)k_predict_sparse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int grid = (int)std::min<int64_t>(n, (int64_t)ctx->n_cu * 8);
+  hipEvent_t ev;
+  rp_time_begin(ctx, &ev);
+  hipLaunchKernelGGL(k_predict_sparse, dim3(grid), dim3(RP_PRED_THREADS), lds, ctx->stream, P);
+  RP_HIP(hipGetLastError());
+  rp_time_end(ctx, ev, RPHIP_T_PREDICT, rp_pred_work(Xpred, model, n, 0));
+  RP_HIP(hipMemcpyAsync(row_nnz_host, dn, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  RP_HIP(hipStreamSynchronize(ctx->stream));
+  int64_t tot = 0;
+  for (int64_t i = 0; i < n; ++i) tot += row_nnz_host[i];
+  *total_out = tot;
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_predict_full_fill(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin,
+                                       int64_t user_end, const int64_t* indptr_host, int32_t* indices_host, double* data_host) {
+  RP_TRY(rp_pred_check(ctx, model, Xpred, user_begin, user_end));
+  if (!indptr_host) RP_FAIL(RPHIP_EINVAL, "indptr is NULL");
+  RP_TRY(rp_set_device(ctx));
+  const int64_t n = user_end - user_begin;
+  if (n == 0) return RPHIP_OK;
+  const int64_t total = indptr_host[n];
+  if (total < 0) RP_FAIL(RPHIP_EINVAL, "indptr[n] is negative");
+  if (total == 0) return RPHIP_OK;
+  if (!indices_host || !data_host) RP_FAIL(RPHIP_EINVAL, "NULL output");
+  char* ob = nullptr;
+  RP_TRY(rp_scratch(ctx, 3, (size_t)total * 12 + (size_t)(n + 1) * 8 + 64, (void**)&ob));
+  double* dv = (double*)ob;
+  long long* dp = (long long*)(ob + (size_t)total * 8);
+  int32_t* di = (int32_t*)(ob + (size_t)total * 8 + (size_t)(n + 1) * 8);
+  RP_HIP(hipMemcpyAsync(dp, indptr_host, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  rp_pred_params P;
+  rp_pred_fill(P, model, Xpred, user_begin, user_end);
+  P.mode = 2;
+  P.indptr = dp;
+  P.full_idx = di;
+  P.full_val = dv;
+  const size_t lds = rp_pred_lds(Xpred->tile_w);
+  RP_HIP(hipFuncSetAttribute((const void*)k_predict_sparse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int grid = (int)std::min<int64_t>(n, (int64_t)ctx->n_cu * 8);
+  hipEvent_t ev;
+  rp_time_begin(ctx, &ev);
+  hipLaunchKernelGGL(k_predict_sparse, dim3(grid), dim3(RP_PRED_THREADS), lds, ctx->stream, P);
+  RP_HIP(hipGetLastError());
+  rp_time_end(ctx, ev, RPHIP_T_PREDICT, rp_pred_work(Xpred, model, n, 0) + 12.0 * (double)total);
+  RP_HIP(hipMemcpyAsync(indices_host, di, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+  RP_HIP(hipMemcpyAsync(data_host, dv, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));
+  RP_HIP(hipStreamSynchronize(ctx->stream));
+  return RPHIP_OK;
+}

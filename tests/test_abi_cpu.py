@@ -1,0 +1,104 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every declared symbol; host logic."""
+import os
+import re
+import warnings
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "recpack_hip.h")).read()
+    return sorted(set(re.findall(r"\b(rphip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from recpack_amd import _lib
+
+    lib = _lib.load_library()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/recpack_hip.h but not exported"
+    assert set(declared) == set(_lib.PROTOTYPES), set(declared) ^ set(_lib.PROTOTYPES)
+    assert lib.rphip_version() == 100
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a GPU the product path must fail loudly, not compute on the host."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from recpack_amd import ItemKNN
+    from recpack_amd._lib import RecpackHipError
+
+    X = sp.csr_matrix(([1] * 7, ([0, 0, 1, 1, 2, 2, 2], [1, 2, 0, 2, 0, 1, 2])), shape=(4, 3))
+    with pytest.raises(RecpackHipError):
+        ItemKNN(K=2).fit(X)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "recpack_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no CPU fallback", ""), f"{f} mentions the oracle"
+
+
+def test_itemknn_params_identifier_and_validation():
+    # recpack/algorithms/base.py:45-61, nearest_neighbour.py:172-202
+    from recpack_amd import EASE, ItemKNN
+
+    a = ItemKNN(K=10, normalize_sim=True)
+    assert a.name == "ItemKNN"
+    assert a.identifier == "ItemKNN(K=10,normalize_X=False,normalize_sim=True,pop_discount=None,similarity=cosine)"
+    assert a.get_params() == {"K": 10, "normalize_X": False, "normalize_sim": True, "pop_discount": None, "similarity": "cosine"}
+    assert EASE(l2=200).identifier == "EASE(alpha=0,density=None,l2=200)"
+    with pytest.raises(ValueError):
+        ItemKNN(similarity="jaccard")
+    with pytest.raises(ValueError):
+        ItemKNN(similarity="conditional_probability", pop_discount=1.5)
+    with pytest.warns(UserWarning, match="pop_discount"):
+        ItemKNN(similarity="cosine", pop_discount=0.5)
+    a.set_params(K=3)
+    assert a.K == 3
+
+
+def test_to_binary_csr_semantics():
+    from recpack_amd.algorithms import UnsupportedTypeError, to_binary_csr
+
+    X = sp.csr_matrix(([1, 2, 0, 1], ([0, 0, 1, 2], [0, 2, 1, 1])), shape=(3, 3))
+    B = to_binary_csr(X)
+    assert B.nnz == 3 and B.has_sorted_indices
+    # duplicates merged
+    M = sp.csr_matrix((np.array([1, 1, 1]), np.array([2, 2, 0]), np.array([0, 3])), shape=(1, 3))
+    assert to_binary_csr(M).nnz == 2
+
+    class FakeIM:  # recpack InteractionMatrix exposes .values (interaction_matrix.py:202-217)
+        values = X
+
+    assert to_binary_csr(FakeIM()).nnz == 3
+    with pytest.raises(UnsupportedTypeError):
+        to_binary_csr(np.zeros((2, 2)))
+
+
+def test_post_condition_warnings():
+    # recpack/tests/test_algorithms/test_algorithms_base.py:33-47
+    from recpack_amd.algorithms import Algorithm
+
+    a = np.ones(5)
+    b = a.copy()
+    b[2] = 0
+    X_pred = sp.diags(b).tocsr()
+    X = sp.diags(a).tocsr()
+    alg = Algorithm()
+    with pytest.warns(UserWarning, match="1 users"):
+        alg._check_prediction(X_pred, X)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        alg._check_prediction(X, X)

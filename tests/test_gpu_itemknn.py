@@ -1,0 +1,277 @@
+"""GPU parity: ItemKNN cosine fit + predict through the C ABI against the golden vectors and the oracle.
+
+Bars: neighbour index sets bit-exact against the oracle (integer work, same documented tie order) and
+tie-aware identical against the reference's goldens (eps = 1e-9); similarity values
+rtol 1e-12 (float64, closed form c_ij/sqrt(c_i c_j)); predicted scores rtol 2e-6 (fp32 accumulation).
+"""
+import warnings
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import csr_from, load_golden
+from oracle import oracle_np as onp
+from parity import tie_aware_topk, topk_vals_close
+
+pytestmark = pytest.mark.gpu
+
+VAL_RTOL = 1e-12
+PRED_RTOL = 2e-6
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from recpack_amd import _lib, get_context
+
+    ctx = get_context(0)
+    return _lib, ctx
+
+
+def fit_arrays(hip, X, K, rows=None):
+    _lib, ctx = hip
+    X = sp.csr_matrix(X)
+    dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
+    r0, r1 = (0, X.shape[1]) if rows is None else rows
+    m = _lib.itemknn_fit(ctx, dX, K, r0, r1)
+    idx, val, nnz = m.topk_download()
+    return dX, m, idx, val, nnz
+
+
+def assert_same_as_oracle(idx, val, nnz, ref):
+    k = min(idx.shape[1], ref["idx"].shape[1])
+    np.testing.assert_array_equal(nnz, ref["nnz"])
+    # the device emits a row in column order, the oracle in rank order
+    for r in range(idx.shape[0]):
+        n = nnz[r]
+        o = np.argsort(ref["idx"][r, :n])
+        np.testing.assert_array_equal(idx[r, :n], ref["idx"][r, :n][o], err_msg=f"row {r}")
+        np.testing.assert_allclose(val[r, :n], ref["val"][r, :n][o], rtol=VAL_RTOL)
+        assert (idx[r, n:] == -1).all() and (val[r, n:] == 0).all()
+
+
+@pytest.mark.parametrize("name", ["ref_itemknn_data", "ref_itemknn_empty_col", "ref_itemknn_x_in", "ref_itemknn_larger_matrix",
+                                  "syn_itemknn_2000x500"])
+def test_fit_golden(hip, name):
+    from recpack_amd.algorithms import to_binary_csr
+
+    g = load_golden(name)
+    X = to_binary_csr(csr_from(g, "X"))
+    cand = csr_from(g, "cos")
+    for K in g["Ks"]:
+        K = int(K)
+        _, m, idx, val, nnz = fit_arrays(hip, X, K)
+        ref = csr_from(g, f"S{K}")
+        bad, exact = tie_aware_topk(cand, ref, idx, nnz, eps=1e-9)
+        assert not bad, (name, K, bad[:5])
+        topk_vals_close(ref, idx, val, nnz, rtol=1e-11)
+        assert_same_as_oracle(idx, val, nnz, onp.itemknn_fit(X, m.K))
+
+
+def test_fit_golden_thresholds_10000x2000(hip):
+    g = load_golden("syn_itemknn_10000x2000")
+    X = csr_from(g, "X")
+    _, m, idx, val, nnz = fit_arrays(hip, X, 100)
+    ref = csr_from(g, "S100")
+    assert (np.diff(ref.indptr) == nnz).all()
+    topk_vals_close(ref, idx, val, nnz, rtol=1e-11)
+    assert_same_as_oracle(idx, val, nnz, onp.itemknn_fit(X, 100))
+
+
+def test_dropin_class_matches_reference_values(hip):
+    # recpack/tests/test_algorithms/test_nearest_neighbour.py:44-70
+    from recpack_amd import ItemKNN
+
+    g = load_golden("ref_itemknn_data")
+    algo = ItemKNN(K=2).fit(csr_from(g, "X"))
+    e = 2 / np.sqrt(6)
+    expected = np.array([[0, 0.5, e], [0.5, 0, e], [e, e, 0]])
+    np.testing.assert_almost_equal(algo.similarity_matrix_.toarray(), expected)
+    _in = sp.csr_matrix(([1, 1, 1], ([0, 1, 2], [0, 1, 2])), shape=(3, 3))
+    np.testing.assert_almost_equal(algo.predict(_in).toarray(), expected, decimal=6)
+    _in = sp.csr_matrix(([1, 1], ([0, 0], [0, 1])), shape=(1, 3))
+    np.testing.assert_almost_equal(algo.predict(_in).toarray(), [[0.5, 0.5, 2 * e]], decimal=6)
+
+
+def test_dropin_normalize_sim_and_warnings(hip):
+    from recpack_amd import ItemKNN
+
+    g = load_golden("ref_itemknn_data_normsim")
+    algo = ItemKNN(K=2, normalize_sim=True).fit(csr_from(g, "X"))
+    np.testing.assert_allclose(algo.similarity_matrix_.toarray(), csr_from(g, "S2").toarray(), rtol=1e-12)
+    np.testing.assert_array_almost_equal(algo.similarity_matrix_.sum(axis=1), 1)
+    # recpack/tests/test_algorithms/test_algorithms_base.py:49-67: an item without neighbours warns
+    x_in = sp.csr_matrix(([1, 2, 1, 1, 1, 1], ([0, 0, 0, 2, 2, 2], [0, 2, 3, 1, 3, 1])), shape=(10, 5))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ItemKNN(2).fit(x_in)
+        assert len(w) >= 1 and "1 items" in str(w[-1].message)
+
+
+@pytest.mark.parametrize("shape,density,K,seed", [
+    ((20000, 2000, 0.004), None, 200, 11),     # one LDS tile
+    ((3000, 40000, 0.0008), None, 50, 12),     # two column tiles + merge
+    ((150000, 300, 0.02), None, 20, 13),       # long user lists: rows cut into slices + partial sums
+    ((500, 64, 0.5), None, 1000, 14),          # K >= n_items, dense rows
+])
+def test_fit_synthetic_vs_oracle(hip, shape, density, K, seed):
+    from recpack_amd.synth import powerlaw_csr
+
+    X = powerlaw_csr(shape[0], shape[1], shape[2], seed=seed).to_scipy()
+    _, m, idx, val, nnz = fit_arrays(hip, X, K)
+    assert_same_as_oracle(idx, val, nnz, onp.itemknn_fit(X, m.K))
+
+
+def test_fit_tie_heavy(hip):
+    """Many exact ties at the K boundary (all users have the same two-item baskets): smaller column wins."""
+    rng = np.random.default_rng(5)
+    n_items = 3000
+    pairs = rng.integers(0, n_items, size=(20000, 2))
+    rows = np.repeat(np.arange(20000), 2)
+    X = sp.csr_matrix((np.ones(40000), (rows, pairs.ravel())), shape=(20000, n_items))
+    X.sum_duplicates()
+    X.data[:] = 1
+    _, m, idx, val, nnz = fit_arrays(hip, X, 5)
+    assert_same_as_oracle(idx, val, nnz, onp.itemknn_fit(X, 5))
+    # one hub item co-occurring exactly once with thousands of degree-1 items: > RP_SORT_CAP exact ties
+    n = 6000
+    rows = np.repeat(np.arange(n - 1), 2)
+    cols = np.stack([np.zeros(n - 1, dtype=np.int64), np.arange(1, n)], axis=1).ravel()
+    H = sp.csr_matrix((np.ones(2 * (n - 1)), (rows, cols)), shape=(n - 1, n))
+    _, m, idx, val, nnz = fit_arrays(hip, H, 7)
+    assert nnz[0] == 7 and (idx[0, :7] == np.arange(1, 8)).all()
+    assert_same_as_oracle(idx, val, nnz, onp.itemknn_fit(H, 7))
+
+
+def test_fit_edge_cases(hip):
+    _lib, ctx = hip
+    # empty matrix, empty rows / columns
+    E = sp.csr_matrix((5, 7))
+    _, m, idx, val, nnz = fit_arrays(hip, E, 3)
+    assert (nnz == 0).all() and (idx == -1).all()
+    X = sp.csr_matrix(([1, 1, 1], ([0, 0, 3], [1, 5, 5])), shape=(6, 8))
+    _, m, idx, val, nnz = fit_arrays(hip, X, 3)
+    assert_same_as_oracle(idx, val, nnz, onp.itemknn_fit(X, 3))
+    # unsorted column indices are fine within one tile; int64 indptr accepted
+    Xu = sp.csr_matrix((np.ones(4), np.array([5, 1, 5, 2], dtype=np.int32), np.array([0, 2, 2, 4], dtype=np.int64)), shape=(3, 8))
+    dX = _lib.DeviceCSR.from_host(ctx, Xu.indptr.astype(np.int64), Xu.indices, Xu.shape)
+    m = _lib.itemknn_fit(ctx, dX, 2)
+    idx, val, nnz = m.topk_download()
+    Xs = Xu.copy()
+    Xs.sort_indices()
+    assert_same_as_oracle(idx, val, nnz, onp.itemknn_fit(Xs, 2))
+    # row shards give the same rows as the full fit
+    from recpack_amd.synth import powerlaw_csr
+
+    Y = powerlaw_csr(4000, 900, 0.01, seed=3).to_scipy()
+    _, _, idx_f, val_f, nnz_f = fit_arrays(hip, Y, 30)
+    _, _, idx_s, val_s, nnz_s = fit_arrays(hip, Y, 30, rows=(300, 711))
+    np.testing.assert_array_equal(idx_s, idx_f[300:711])
+    np.testing.assert_array_equal(val_s, val_f[300:711])
+    # bad input -> error code, not a crash
+    with pytest.raises(_lib.RecpackHipError):
+        _lib.DeviceCSR.from_host(ctx, np.array([0, 2, 1], dtype=np.int32), np.array([0, 1], dtype=np.int32), (2, 3))
+    with pytest.raises(_lib.RecpackHipError):
+        _lib.DeviceCSR.from_host(ctx, np.array([0, 1], dtype=np.int32), np.array([9], dtype=np.int32), (1, 3))
+    with pytest.raises(_lib.RecpackHipError):
+        _lib.itemknn_fit(ctx, dX, 0)
+
+
+# ---------------------------------------------------------------------------------------------------
+def check_topk_scores(scores_ref: sp.csr_matrix, idx, val, nnz, Kp, exclude=None, eps=2e-5):
+    """Tie-aware check of a fused top-Kp against float64 oracle scores (fp32 accumulation => eps 2e-5)."""
+    ridx, rval, rnnz = onp.topk_rows(scores_ref, Kp, exclude=exclude)
+    cand = scores_ref
+    if exclude is not None:
+        cand = scores_ref - scores_ref.multiply(onp.binarize(exclude))
+        cand.eliminate_zeros()
+    ref_sel = onp.topk_to_csr(ridx, rval, rnnz, scores_ref.shape[1])
+    bad, exact = tie_aware_topk(sp.csr_matrix(cand), ref_sel, idx, nnz, eps=eps)
+    assert not bad, bad[:5]
+    lut = sp.csr_matrix(cand)
+    for r in range(0, idx.shape[0], max(1, idx.shape[0] // 200)):
+        n = nnz[r]
+        assert (np.diff(idx[r, :n]) > 0).all()
+        got = val[r, :n]
+        want = np.asarray(lut[r, idx[r, :n]].todense()).ravel()
+        np.testing.assert_allclose(got, want, rtol=PRED_RTOL)
+    return exact
+
+
+@pytest.mark.parametrize("name", ["ref_itemknn_data", "ref_itemknn_x_in", "ref_itemknn_larger_matrix", "syn_itemknn_2000x500"])
+def test_predict_full_golden(hip, name):
+    """predict() from the reference's own similarity matrix reproduces the reference's scores."""
+    _lib, ctx = hip
+    g = load_golden(name)
+    n_items = int(g["X_shape"][1])
+    for K in g["Ks"]:
+        K = int(K)
+        S = csr_from(g, f"S{K}")
+        Kst = max(1, int(np.diff(S.indptr).max()))
+        idx = np.full((n_items, Kst), -1, dtype=np.int32)
+        val = np.zeros((n_items, Kst))
+        nnz = np.diff(S.indptr).astype(np.int32)
+        for r in range(n_items):
+            idx[r, : nnz[r]] = S.indices[S.indptr[r]: S.indptr[r + 1]]
+            val[r, : nnz[r]] = S.data[S.indptr[r]: S.indptr[r + 1]]
+        model = _lib.Model.from_topk_host(ctx, idx, val, nnz)
+        n = 0
+        while f"Pin{n}_indptr" in g:
+            from recpack_amd.algorithms import to_binary_csr
+
+            Pin = to_binary_csr(csr_from(g, f"Pin{n}"))
+            dP = _lib.DeviceCSR.from_host(ctx, Pin.indptr, Pin.indices, Pin.shape)
+            indptr, indices, data = _lib.predict_full(ctx, model, dP)
+            out = sp.csr_matrix((data, indices, indptr), shape=Pin.shape)
+            ref = csr_from(g, f"Pout{K}_{n}")
+            ref.eliminate_zeros()
+            assert (out.indptr == ref.indptr).all() and (out.indices == ref.indices).all()
+            np.testing.assert_allclose(out.data, ref.data, rtol=PRED_RTOL)
+            n += 1
+
+
+@pytest.mark.parametrize("shape,K,Kp,seed", [((6000, 1500, 0.006), 100, 50, 21), ((2500, 33000, 0.001), 40, 20, 22)])
+def test_predict_topk_vs_oracle(hip, shape, K, Kp, seed):
+    from recpack_amd.synth import powerlaw_csr
+
+    _lib, ctx = hip
+    X = powerlaw_csr(shape[0], shape[1], shape[2], seed=seed).to_scipy()
+    dX, m, idx, val, nnz = fit_arrays(hip, X, K)
+    S = onp.topk_to_csr(idx, val, nnz, X.shape[1])
+    users = slice(0, 1200)
+    scores = onp.predict_full(X[users], S)
+    # full scores
+    ip, ind, dat = _lib.predict_full(ctx, m, dX, 0, 1200)
+    out = sp.csr_matrix((dat, ind, ip), shape=scores.shape)
+    assert (out.indptr == scores.indptr).all() and (out.indices == scores.indices).all()
+    np.testing.assert_allclose(out.data, scores.data, rtol=PRED_RTOL)
+    # fused top-Kp, with and without history removal
+    for excl in (False, True):
+        pi, pv, pn = _lib.predict_topk(ctx, m, dX, Kp, exclude_history=excl, user_begin=0, user_end=1200)
+        check_topk_scores(scores, pi, pv, pn, Kp, exclude=X[users] if excl else None)
+    # a user range in the middle equals the same rows of the full call
+    pi2, pv2, pn2 = _lib.predict_topk(ctx, m, dX, Kp, user_begin=100, user_end=300)
+    pi, pv, pn = _lib.predict_topk(ctx, m, dX, Kp, user_begin=0, user_end=1200)
+    np.testing.assert_array_equal(pi2, pi[100:300])
+    np.testing.assert_array_equal(pn2, pn[100:300])
+
+
+def test_predict_edge_cases(hip):
+    from recpack_amd import ItemKNN
+
+    g = load_golden("ref_itemknn_data")
+    algo = ItemKNN(K=2).fit(csr_from(g, "X"))
+    # users without history get empty rows; a user whose only item has no neighbours warns
+    P = sp.csr_matrix((4, 3))
+    out = algo.predict(P)
+    assert out.shape == (4, 3) and out.nnz == 0
+    ec = load_golden("ref_itemknn_empty_col")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a2 = ItemKNN(K=2).fit(csr_from(ec, "X"))
+    with pytest.warns(UserWarning, match="failed to recommend any items for 1 users"):
+        a2.predict(sp.csr_matrix(([1], ([0], [0])), shape=(2, 3)))
+    top = algo.predict_topk(sp.csr_matrix(([1, 1], ([0, 0], [0, 1])), shape=(1, 3)), 1)
+    assert top.nnz == 1 and top.indices[0] == 2
+    top = algo.predict_topk(sp.csr_matrix(([1, 1], ([0, 0], [0, 2])), shape=(1, 3)), 3, exclude_history=True)
+    assert top.indices.tolist() == [1]
