@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ItemKNN cosine fit + predict wall-seconds on synthetic power-law data (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C4]
+
+A step is ONE pass of the hot path over one synthetic interaction matrix that is already resident in HBM:
+K0 (X -> X^T, degrees) + K1-K3 (Gram + cosine + top-K, K=200) [+ all-gather of the neighbour lists when N > 1]
++ K8 (predict with fused top-100 for every user).  Default workload: C4 = 1M users x 100K items, 50M
+interactions - the shape BASELINE.json's metric is quoted on; it fits one MI355X.  With N > 1 the same
+matrix is sharded (item rows for fit, users for predict): strong scaling.
+
+Prints one JSON line (rank 0).  `roofline` prices the dominant kernel (k_itemknn_fit<false>, the SpGEMM)
+with the 4*P byte model of SURVEY.md §8(d) against 8 TB/s; `cpu_baseline` times the numpy/scipy oracle
+(a port of the reference's scipy path, 1 thread) on a bounded sample and scales it to the full workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="C4", choices=["C1", "C2", "C3", "C4", "C5"])
+    ap.add_argument("--K", type=int, default=200)
+    ap.add_argument("--Kp", type=int, default=100)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="0 disables the CPU leg")
+    return ap.parse_args()
+
+
+def cpu_baseline(indptr, indices, shape, K, Kp, S_csr, budget_s, P_total):
+    """Time the oracle (port of the reference's scipy path) on a bounded sample; scale to the full workload."""
+    import scipy.sparse as sp
+
+    from oracle import oracle_np as onp
+
+    U, I = shape
+    nnz = indices.shape[0]
+    X = sp.csr_matrix((np.ones(nnz, dtype=np.int32), indices, indptr), shape=shape)
+    rng = np.random.default_rng(1)
+    d = np.diff(indptr).astype(np.int64)
+    w = np.bincount(indices, weights=np.repeat(d, d), minlength=I)  # w_i = sum_{u in i} d_u
+    # --- fit: binarise + transpose at full size, Gram rows + top-K on a row sample
+    t0 = time.perf_counter()
+    Xb = onp.binarize(X)
+    _ = Xb.T.tocsr()
+    t_prep = time.perf_counter() - t0
+    # ~3e7 scalar products per second for scipy's csr_matmat on one core
+    target_p = max(1.0, 0.5 * budget_s * 2.5e7)
+    order = rng.permutation(I)
+    cw = np.cumsum(w[order])
+    n_rows = int(min(I, max(8, np.searchsorted(cw, target_p) + 1)))
+    rows = np.sort(order[:n_rows])
+    t0 = time.perf_counter()
+    onp.itemknn_fit(X, K, rows=rows)
+    t_rows = max(1e-9, time.perf_counter() - t0 - t_prep)
+    p_sample = float(w[rows].sum())
+    fit_full = t_prep + t_rows * (P_total / max(1.0, p_sample))
+    # --- predict: X[users] @ S + per-user top-Kp on a user sample
+    n_users = int(min(U, max(64, 0.5 * budget_s * 4.0e4 * 200.0 / max(1, K) / max(1.0, nnz / U))))
+    users = np.sort(rng.choice(U, size=n_users, replace=False))
+    Xs = X[users]
+    t0 = time.perf_counter()
+    scores = onp.predict_full(Xs, S_csr)
+    onp.topk_rows(scores, Kp)
+    t_pred = time.perf_counter() - t0
+    pred_full = t_pred * (nnz / max(1, Xs.nnz))
+    return {
+        "value": round(fit_full + pred_full, 3),
+        "unit": "s",
+        "cores": 1,
+        "kind": "port",
+        "sample": (f"oracle/oracle_np.py (scipy csr_matmat + vectorised top-K, 1 thread): binarise+transpose at full size "
+                   f"{t_prep:.2f}s; Gram+top-K of {n_rows} random item rows ({p_sample / P_total:.3%} of P) {t_rows:.2f}s; "
+                   f"predict+top-{Kp} of {n_users} random users ({Xs.nnz / nnz:.3%} of nnz) {t_pred:.2f}s; "
+                   f"scaled by P and nnz to fit {fit_full:.1f}s + predict {pred_full:.1f}s"),
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from recpack_amd import _lib, dist as rdist
+    from recpack_amd.synth import CONFIG_SEED_BASE, CONFIGS, powerlaw_csr
+
+    U, I, dens = CONFIGS[args.config]
+    seed = CONFIG_SEED_BASE + int(args.config[1:])
+    t_gen = time.perf_counter()
+    indptr_t, indices_t = powerlaw_csr(U, I, dens, seed, device=device)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+    nnz = int(indices_t.numel())
+
+    stream = torch.cuda.Stream(device)
+    torch.cuda.set_stream(stream)
+    ctx = _lib.Context(local_rank, stream.cuda_stream)
+    info = ctx.device_info()
+
+    # static plan (data dependent only through the degrees): item-row ranges and user ranges per rank
+    dX0 = _lib.DeviceCSR.from_device(ctx, indptr_t, indices_t, (U, I))
+    P_total = dX0.num_products()
+    deg = dX0.item_degrees()
+    row_parts = rdist.partition_by_cost(rdist.item_row_cost(deg, nnz, P_total), world)
+    user_parts = rdist.partition_users(indptr_t.cpu().numpy(), world)
+    dX0.close()
+    ub, ue = user_parts[rank]
+    Kp = min(args.Kp, I)
+    out_idx = torch.empty((ue - ub, Kp), dtype=torch.int32, device=device)
+    out_val = torch.empty((ue - ub, Kp), dtype=torch.float32, device=device)
+    out_nnz = torch.empty((ue - ub,), dtype=torch.int32, device=device)
+
+    keep = {}
+
+    def step():
+        dX = _lib.DeviceCSR.from_device(ctx, indptr_t, indices_t, (U, I))  # K0
+        if world == 1:
+            model = _lib.itemknn_fit(ctx, dX, args.K)  # K1-K3
+        else:
+            model = rdist.fit_itemknn_sharded(ctx, dX, args.K, row_parts, device)  # K1-K3 + all-gather
+        _lib.predict_topk_dev(ctx, model, dX, Kp, out_idx, out_val, out_nnz, user_begin=ub, user_end=ue)  # K8
+        keep["model"], keep["dX"] = model, dX
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.reset_timings()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tm = ctx.timings()
+
+    if rank == 0:
+        sec_per_step = elapsed / args.steps
+        g = tm["gram_topk"]
+        launches = max(1, g["launches"])
+        avg_ms = g["ms"] / launches
+        rows0 = row_parts[0][1] - row_parts[0][0]
+        # 4*P + 8*nnz + 4*(U+I+2) + 8*I*K per launch (P and I*K are this rank's share)
+        algo_bytes = 4.0 * P_total / world + 8.0 * nnz + 4.0 * (U + I + 2) + 8.0 * rows0 * args.K
+        achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        phases = {k: round(v["ms"] / args.steps, 4) for k, v in tm.items() if v["launches"]}
+        result = {
+            "metric": "fit+predict wall-sec (ItemKNN cosine) on synthetic power-law implicit feedback",
+            "value": round(sec_per_step, 6),
+            "unit": "s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(sec_per_step * 1e3, 3),
+            "higher_is_better": False,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "int32 counts, f64 similarity, f32 scores",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.config}: ItemKNN cosine K={args.K}, {U} users x {I} items, nnz {nnz} "
+                            f"(P={P_total} scalar products), predict + top-{Kp} for all users",
+                "parallelism": f"item-row shards x{world} (fit) + user shards x{world} (predict)" if world > 1 else "1 GPU",
+                "generate_s": round(t_gen, 2),
+                "device": info,
+            },
+            "phases_ms_per_step": phases,
+            "throughput": {
+                "interactions_per_s": round(nnz / sec_per_step, 1),
+                "gram_products_per_s": round(P_total / world / (avg_ms * 1e-3), 1) if avg_ms > 0 else None,
+            },
+            "roofline": {
+                "kernel": "k_itemknn_fit<false> (K1-K3: Gram + cosine key + top-K)",
+                "bound": "hbm",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "avg_launch_ms": round(avg_ms, 4),
+            },
+        }
+        if world == 1 and args.cpu_baseline_seconds > 0:
+            idx, val, nnz_rows = keep["model"].topk_download()
+            from recpack_amd.algorithms import topk_arrays_to_csr
+
+            S = topk_arrays_to_csr(idx, val, nnz_rows, I)
+            result["cpu_baseline"] = cpu_baseline(indptr_t.cpu().numpy(), indices_t.cpu().numpy(), (U, I), args.K, Kp, S,
+                                                  args.cpu_baseline_seconds, P_total)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

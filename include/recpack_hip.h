@@ -61,6 +61,7 @@ enum {
   RPHIP_T_EASE_SCALE = 8,    /* K7 */
   RPHIP_T_H2D = 9,
   RPHIP_T_D2H = 10,
+  RPHIP_T_GRAM_FINALIZE = 11, /* second launch of K1-K3: sum of the partial tiles of sliced rows + top-K */
   RPHIP_T_COUNT = 16
 };
 

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "librecpack_hip.so")
 
 RPHIP_T_NAMES = [
     "csr_transpose", "fit_plan", "gram_topk", "topk_merge", "predict", "gram_dense", "cholesky", "inverse",
-    "ease_scale", "h2d", "d2h",
+    "ease_scale", "h2d", "d2h", "gram_finalize",
 ]
 RPHIP_T_COUNT = 16
 RPHIP_MODEL_TOPK = 1

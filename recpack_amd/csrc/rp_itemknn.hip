@@ -63,6 +63,8 @@ struct rp_dense_src {
   __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)(t0 + w); }
 };
 
+// FINALIZE only gives the second launch (sum of partial tiles + select) its own name in profiles
+template <bool FINALIZE>
 __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit(rp_fit_params P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint32_t* acc = reinterpret_cast<uint32_t*>(smem);
@@ -512,24 +514,28 @@ extern "C" int rphip_itemknn_fit(rphip_ctx* ctx, const rphip_csr* X, int64_t row
     P.out_nnz = cand_nnz;
   }
   const size_t lds = rp_fit_lds_bytes(W);
-  RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_fit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_fit<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_fit<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = ctx->n_cu;
 
   rp_time_begin(ctx, &ev);
   P.tasks = acc_tasks;
   P.n_tasks = off_acc + n_rows;
   P.ticket = tickets;
-  hipLaunchKernelGGL(k_itemknn_fit, dim3(grid), dim3(RP_FIT_THREADS), lds, st, P);
-  P.tasks = fin_tasks;
-  P.n_tasks = off_fin + n_rows;
-  P.ticket = tickets + 1;
-  hipLaunchKernelGGL(k_itemknn_fit, dim3(grid), dim3(RP_FIT_THREADS), lds, st, P);
+  hipLaunchKernelGGL(k_itemknn_fit<false>, dim3(grid), dim3(RP_FIT_THREADS), lds, st, P);
   RP_HIP(hipGetLastError());
   // algorithmic bytes of the SpGEMM: 4*P_shard + 8*nnz + 4*(U+I+2) + 8*rows*K; the
   // caller scales P by the shard's share, here the full-matrix figure is attributed when rows cover all.
-  double work = 8.0 * (double)X->nnz + 4.0 * (double)(X->n_users + X->n_items + 2) + 12.0 * (double)n_rows * K;
+  double work = 8.0 * (double)X->nnz + 4.0 * (double)(X->n_users + X->n_items + 2) + 8.0 * (double)n_rows * K;
   if (X->n_products >= 0) work += 4.0 * (double)X->n_products * ((double)n_rows / (double)X->n_items);
   rp_time_end(ctx, ev, RPHIP_T_GRAM_TOPK, work);
+  rp_time_begin(ctx, &ev);
+  P.tasks = fin_tasks;
+  P.n_tasks = off_fin + n_rows;
+  P.ticket = tickets + 1;
+  hipLaunchKernelGGL(k_itemknn_fit<true>, dim3(grid), dim3(RP_FIT_THREADS), lds, st, P);
+  RP_HIP(hipGetLastError());
+  rp_time_end(ctx, ev, RPHIP_T_GRAM_FINALIZE, 0.0);
 
   if (T > 1) {
     rp_time_begin(ctx, &ev);

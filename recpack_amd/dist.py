@@ -1,0 +1,116 @@
+"""Sharding of the item-similarity path over the GPUs of one node (one process per GPU, torch.distributed).
+
+SURVEY.md §8(e): the rows of the similarity matrix are independent, so ItemKNN fit shards by ITEM ROWS
+(X and X^T replicated, contiguous row ranges balanced by cost) and needs one exchange: an all-gather of the
+per-shard neighbour lists (I*K*12 bytes in total) so that every GPU holds S for predict.  Predict shards by
+USERS with no collective.  The reference has no distributed code at all (recpack/algorithms/base.py:454-455
+leaves multi-GPU as a TODO); backend "nccl" is RCCL over xGMI on MI355X, "gloo" is used by the CPU tests.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Sequence, Tuple
+
+import numpy as np
+
+
+def partition_by_cost(cost: np.ndarray, n_parts: int) -> List[Tuple[int, int]]:
+    """Contiguous ranges [b, e) of near-equal total cost; every part is a valid (possibly empty) range."""
+    n = int(cost.shape[0])
+    if n_parts <= 1:
+        return [(0, n)]
+    c = np.cumsum(cost.astype(np.float64))
+    total = float(c[-1]) if n else 0.0
+    bounds = [0]
+    for p in range(1, n_parts):
+        b = int(np.searchsorted(c, total * p / n_parts, side="left")) + 1 if total > 0 else (n * p) // n_parts
+        bounds.append(min(max(b, bounds[-1]), n))
+    bounds.append(n)
+    return [(bounds[i], bounds[i + 1]) for i in range(n_parts)]
+
+
+def item_row_cost(item_deg: np.ndarray, nnz: int, n_products: int) -> np.ndarray:
+    """Cost model of one Gram row: c_i * (P / nnz) scalar products plus a fixed per-row share for the top-K."""
+    n_items = max(1, item_deg.shape[0])
+    per_user = (n_products / nnz) if nnz else 1.0
+    return item_deg.astype(np.float64) * per_user + 0.5 * (n_products / n_items if n_products else 1.0)
+
+
+def partition_users(indptr_or_deg: np.ndarray, n_parts: int, is_indptr: bool = True) -> List[Tuple[int, int]]:
+    """User ranges balanced by history length (the predict cost is K * d_u)."""
+    d = np.diff(indptr_or_deg) if is_indptr else indptr_or_deg
+    return partition_by_cost(d.astype(np.float64) + 1.0, n_parts)
+
+
+def allgather_topk(idx_local, val_local, nnz_local, parts: Sequence[Tuple[int, int]], group=None):
+    """All-gather the neighbour lists of every rank's row range into full [I, K] tensors (any torch device).
+
+    ``idx_local`` int32[rows, K], ``val_local`` float64[rows, K], ``nnz_local`` int32[rows] hold this rank's
+    rows ``parts[rank]``.  Shards are padded to the longest range so that ONE all_gather per array suffices
+    (direct all-gather: every GPU talks to all peers at once over xGMI; no ring of broadcasts).
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    assert len(parts) == world
+    K = int(idx_local.shape[1])
+    n_items = parts[-1][1]
+    max_rows = max(e - b for b, e in parts)
+    b, e = parts[rank]
+    assert idx_local.shape[0] == e - b
+
+    def padded(t, fill):
+        out = torch.full((max_rows,) + tuple(t.shape[1:]), fill, dtype=t.dtype, device=t.device)
+        out[: t.shape[0]] = t
+        return out
+
+    outs = []
+    for t, fill in ((idx_local, -1), (val_local, 0), (nnz_local, 0)):
+        p = padded(t, fill)
+        g = torch.empty((world,) + tuple(p.shape), dtype=p.dtype, device=p.device)
+        dist.all_gather_into_tensor(g, p, group=group)
+        full = torch.empty((n_items,) + tuple(p.shape[1:]), dtype=p.dtype, device=p.device)
+        for r, (rb, re) in enumerate(parts):
+            full[rb:re] = g[r, : re - rb]
+        outs.append(full)
+    return tuple(outs)
+
+
+class _DevPtr:
+    """Zero-copy view of library-owned device memory for torch (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr: int, shape, typestr: str, owner=None):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+        self._owner = owner
+
+
+def model_topk_tensors(model, device):
+    """torch views (no copy) of a neighbour-list model's device arrays: idx, val (float64), nnz."""
+    import torch
+
+    pi, pv, pn, rows, K = model.topk_device_ptrs()
+    if rows == 0:
+        return (torch.empty((0, K), dtype=torch.int32, device=device), torch.empty((0, K), dtype=torch.float64, device=device),
+                torch.empty((0,), dtype=torch.int32, device=device))
+    idx = torch.as_tensor(_DevPtr(pi, (rows, K), "<i4", model), device=device)
+    val = torch.as_tensor(_DevPtr(pv, (rows, K), "<f8", model), device=device)
+    nnz = torch.as_tensor(_DevPtr(pn, (rows,), "<i4", model), device=device)
+    return idx, val, nnz
+
+
+def fit_itemknn_sharded(ctx, dX, K: int, parts: Sequence[Tuple[int, int]], device, group=None):
+    """Fit this rank's item rows on its GPU, all-gather, return a predict-ready full model (replicated)."""
+    import torch
+    import torch.distributed as dist
+
+    from recpack_amd import _lib
+
+    rank = dist.get_rank(group)
+    b, e = parts[rank]
+    local = _lib.itemknn_fit(ctx, dX, K, b, e)
+    idx, val, nnz = model_topk_tensors(local, device)
+    ctx.sync()  # the collective runs on torch's stream: order it after the library's stream
+    idx_f, val_f, nnz_f = allgather_topk(idx, val, nnz, parts, group)
+    torch.cuda.current_stream(device).synchronize()
+    return _lib.Model.from_topk_device(ctx, idx_f, val_f, nnz_f)
