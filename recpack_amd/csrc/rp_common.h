@@ -38,10 +38,10 @@ void rp_set_error(const char* fmt, ...);
 // ---- geometry ------------------------------------------------------------------------------------
 constexpr int RP_WAVE = 64;
 constexpr int RP_FIT_THREADS = 1024;      // 16 waves, one workgroup per CU (LDS-bound)
-constexpr int RP_TILE_MAX = 30720;        // accumulator columns per LDS tile (120 KiB of u32/f32)
-constexpr int RP_SORT_CAP = 2048;         // entries of the in-LDS exact sort (32 KiB)
-constexpr int RP_HIST_BINS = 4096;        // radix-select digit: 12 bits (overlays the sort buffer)
-constexpr int RP_K_MAX = RP_SORT_CAP;     // largest effective K / Kp of one call
+constexpr int RP_TILE_MAX = 25600;        // accumulator columns per LDS tile (100 KiB of u32/f32 + 50 KiB candidate list)
+constexpr int RP_SORT_CAP = 512;          // entries of the in-LDS exact sort (6 KiB, overlays the histogram)
+constexpr int RP_HIST_BINS = 2048;        // radix-select digit: 11 bits
+constexpr int RP_K_MAX = 2048;            // largest effective K / Kp of one call
 
 // ---- objects -------------------------------------------------------------------------------------
 struct rp_buf {  // grow-only device scratch

@@ -44,7 +44,21 @@ struct rp_fit_params {
   uint32_t* out_cnt;  // n_tiles > 1: candidate counts c_ij
   int32_t* out_nnz;   // [rows] or [rows*T]
   uint32_t* part;     // partial tiles [slot][tile_w]
+  unsigned long long* stamps;  // diagnostic build only (-DRP_STAMPS): cycles per phase, summed over tasks
 };
+
+#ifdef RP_STAMPS
+#define RP_STAMP(ph)                                                        \
+  do {                                                                      \
+    if (tid == 0) {                                                         \
+      unsigned long long _t = __builtin_amdgcn_s_memtime();                 \
+      atomicAdd(&P.stamps[ph], _t - t_last);                                \
+      t_last = _t;                                                          \
+    }                                                                       \
+  } while (0)
+#else
+#define RP_STAMP(ph) do { } while (0)
+#endif
 
 __device__ __forceinline__ uint64_t rp_fit_key(uint32_t c, double inv) {
   // k = fl(c*c) * inv in [2^-31, 2^32): the exponent offset from 992 fits 6 bits; shift the 58
@@ -70,6 +84,9 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit(rp_fit_params P)
   uint32_t* acc = reinterpret_cast<uint32_t*>(smem);
   rp_select_smem sel = rp_select_carve(smem + (size_t)P.tile_w * 4, P.tile_w);
   int* s_task = &sel.misc[RPS_USER];  // all LDS lives in the dynamic region (keeps its base 16-B aligned)
+#ifdef RP_STAMPS
+  sel.stamps = P.stamps;
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NW = RP_FIT_THREADS / 64;
@@ -78,20 +95,56 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit(rp_fit_params P)
 
   for (int w = tid; w < W; w += RP_FIT_THREADS) acc[w] = 0u;
   const int n_tasks = *P.n_tasks;
+#ifdef RP_STAMPS
+  unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
+
+  // Tasks come from a ticket counter (heaviest first).  The NEXT task is fetched by one lane of the last
+  // wave while the current one is processed (two LDS slots), so the ticket atomic and the descriptor load
+  // never sit on the critical path.
+  auto fetch_task = [&](int q) {
+    int* d = s_task + q * 8;
+    const int ti = atomicAdd(P.ticket, 1);
+    if (ti < n_tasks) {
+      const rp_task t = P.tasks[ti];
+      d[0] = t.row;
+      d[1] = t.tile;
+      d[2] = t.p_begin;
+      d[3] = t.p_end;
+      d[4] = t.slot;
+      d[5] = t.mode;
+      d[6] = 1;
+    } else {
+      d[6] = 0;
+    }
+  };
+  if (tid == RP_FIT_THREADS - 64) fetch_task(0);
+  int par = 0;
 
   while (true) {
     __syncthreads();
-    if (tid == 0) *s_task = atomicAdd(P.ticket, 1);
-    __syncthreads();
-    const int ti = *s_task;
-    if (ti >= n_tasks) break;
-    const rp_task tk = P.tasks[ti];
+    const int* cur = s_task + par * 8;
+    if (!cur[6]) break;
+    rp_task tk;
+    tk.row = cur[0];
+    tk.tile = cur[1];
+    tk.p_begin = cur[2];
+    tk.p_end = cur[3];
+    tk.slot = cur[4];
+    tk.mode = cur[5];
+    par ^= 1;
+    if (tid == RP_FIT_THREADS - 64) fetch_task(par);
+    RP_STAMP(0);
     const int row = tk.row, tile = tk.tile;
     const int t0 = tile * W;
     const int n_cols = min(W, P.n_items - t0);
 
     if (tk.mode != 2) {
-      // ---- accumulate: users p in [p_begin, p_end) of item `row`
+      // ---- accumulate: users p in [p_begin, p_end) of item `row`.
+      // A wave takes 64 users (one per lane: row pointer pair), cuts their index segments into chunks of
+      // CH entries, and hands chunk c to lane c % 64: every lane then issues CH independent index loads
+      // before the first LDS atomic, instead of one dependent load per user per round.
+      constexpr int CH = 8;
       for (int base = tk.p_begin + wave * 64; base < tk.p_end; base += NW * 64) {
         const int p = base + lane;
         int s = 0, len = 0;
@@ -108,24 +161,44 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit(rp_fit_params P)
           }
           len = e - s;
         }
-        const int n_user = min(64, tk.p_end - base);
-        for (int r = 0; r * 4 < n_user; ++r) {
-          const int srcl = r * 4 + (lane >> 4);
-          const int ss = __shfl(s, srcl);
-          const int ll = __shfl(len, srcl);
-          for (int k = lane & 15; k < ll; k += 16) {
-            const int j = P.x_idx[ss + k];
-            atomicAdd(&acc[j - t0], 1u);
+        const int nch = (len + CH - 1) / CH;
+        int inc = nch;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int t = __shfl_up(inc, d);
+          if (lane >= d) inc += t;
+        }
+        const int choff = inc - nch;       // first chunk of this lane's user
+        const int n_chunks = __shfl(inc, 63);
+        for (int c0 = 0; c0 < n_chunks; c0 += 64) {
+          const int c = c0 + lane;
+          int lo = 0;                        // owner = largest lane l with choff[l] <= c
+#pragma unroll
+          for (int step = 32; step > 0; step >>= 1) {
+            const int v = __shfl(choff, lo + step);
+            if (v <= c) lo += step;
           }
+          const int us = __shfl(s, lo), ul = __shfl(len, lo), co = __shfl(choff, lo);
+          const int k0 = (c - co) * CH;
+          const int n = (c < n_chunks) ? min(CH, ul - k0) : 0;
+          const int32_t* src = P.x_idx + us + k0;
+          int jv[CH];
+#pragma unroll
+          for (int e = 0; e < CH; ++e) jv[e] = (e < n) ? src[e] : -1;
+#pragma unroll
+          for (int e = 0; e < CH; ++e)
+            if (jv[e] >= 0) atomicAdd(&acc[jv[e] - t0], 1u);
         }
       }
       __syncthreads();
+      RP_STAMP(1);
       if (tk.mode == 1) {
         uint32_t* dst = P.part + (int64_t)tk.slot * W;
         for (int w = tid; w < W; w += RP_FIT_THREADS) {
           dst[w] = acc[w];
           acc[w] = 0u;
         }
+        RP_STAMP(2);
         continue;
       }
     } else {
@@ -140,12 +213,13 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit(rp_fit_params P)
     // ---- select
     rp_dense_src src{acc, P.inv_deg, t0, row, n_cols};
     const int kp = rp_select_topk<RP_FIT_THREADS>(src, n_cols, P.K, sel);
+    RP_STAMP(3);
     const int rl = row - P.row_begin;
     if (T == 1) {
       int32_t* oi = P.out_idx + (int64_t)rl * P.K;
       double* ov = P.out_val + (int64_t)rl * P.K;
       const double ci = (double)P.deg[row];
-      rp_select_emit(n_cols, sel, [&](int pos, int w) {
+      rp_select_emit<RP_FIT_THREADS>(n_cols, sel, [&](int pos, int w) {
         const int j = t0 + w;
         oi[pos] = j;
         ov[pos] = (double)acc[w] / sqrt(ci * (double)P.deg[j]);
@@ -153,14 +227,16 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit(rp_fit_params P)
       if (tid == 0) P.out_nnz[rl] = kp;
     } else {
       const int64_t o = ((int64_t)rl * T + tile) * P.K;
-      rp_select_emit(n_cols, sel, [&](int pos, int w) {
+      rp_select_emit<RP_FIT_THREADS>(n_cols, sel, [&](int pos, int w) {
         P.out_idx[o + pos] = t0 + w;
         P.out_cnt[o + pos] = acc[w];
       });
       if (tid == 0) P.out_nnz[(int64_t)rl * T + tile] = kp;
     }
-    __syncthreads();
-    for (int w = tid; w < W; w += RP_FIT_THREADS) acc[w] = 0u;
+    // clear only what was touched: the candidates (every wave its own list segment) and the diagonal
+    rp_select_foreach<RP_FIT_THREADS>(n_cols, sel, [&](int w) { acc[w] = 0u; });
+    if (tid == 0 && (unsigned)(row - t0) < (unsigned)n_cols) acc[row - t0] = 0u;
+    RP_STAMP(4);
   }
 }
 
@@ -222,7 +298,7 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_merge(rp_merge_param
     int32_t* oi = P.out_idx + (int64_t)rl * K;
     double* ov = P.out_val + (int64_t)rl * K;
     const double ci = (double)P.deg[P.row_begin + rl];
-    rp_select_emit(n, sel, [&](int pos, int w) {
+    rp_select_emit<RP_FIT_THREADS>(n, sel, [&](int pos, int w) {
       const int j = lcol[w];
       oi[pos] = j;
       ov[pos] = (double)lcnt[w] / sqrt(ci * (double)P.deg[j]);
@@ -502,6 +578,15 @@ extern "C" int rphip_itemknn_fit(rphip_ctx* ctx, const rphip_csr* X, int64_t row
   P.K = K;
   P.row_begin = (int)row_begin;
   P.part = part;
+  P.stamps = nullptr;
+#ifdef RP_STAMPS
+  {
+    void* sp = nullptr;
+    RP_TRY(rp_scratch(ctx, 6, 64 * 8, &sp));
+    P.stamps = (unsigned long long*)sp;
+    hipMemsetAsync(sp, 0, 64 * 8, st);
+  }
+#endif
   if (T == 1) {
     P.out_idx = m->idx;
     P.out_val = m->val;
@@ -536,6 +621,15 @@ extern "C" int rphip_itemknn_fit(rphip_ctx* ctx, const rphip_csr* X, int64_t row
   hipLaunchKernelGGL(k_itemknn_fit<true>, dim3(grid), dim3(RP_FIT_THREADS), lds, st, P);
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, RPHIP_T_GRAM_FINALIZE, 0.0);
+#ifdef RP_STAMPS
+  {
+    unsigned long long h[16];
+    hipMemcpyAsync(h, P.stamps, sizeof(h), hipMemcpyDeviceToHost, st);
+    hipStreamSynchronize(st);
+    fprintf(stderr, "[stamps] cycles/1e6: ticket %.1f accumulate %.1f dump %.1f select %.1f emit+clear %.1f | sel: compact %.1f levels %.1f sort %.1f pred %.1f\n",
+            h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, h[8] / 1e6, h[9] / 1e6, h[10] / 1e6, h[11] / 1e6);
+  }
+#endif
 
   if (T > 1) {
     rp_time_begin(ctx, &ev);
@@ -553,7 +647,7 @@ extern "C" int rphip_itemknn_fit(rphip_ctx* ctx, const rphip_csr* X, int64_t row
     M.out_val = m->val;
     M.out_nnz = m->nnz;
     const size_t mlds = (size_t)T * Keff * 8 + rp_select_smem_bytes(T * Keff);
-    if (mlds > 160 * 1024) {
+    if (mlds > 160 * 1024 || T * Keff >= RPS_FLAG) {
       rphip_model_destroy(m);
       RP_FAIL(RPHIP_ELIMIT, "K=%d with %d column tiles needs %zu bytes of LDS for the merge", K, T, mlds);
     }

@@ -99,21 +99,20 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_sparse(rp_pred_para
       const int kp = rp_select_topk<RP_PRED_THREADS>(src, n_cols, kk, sel);
       if (P.mode == 0) {
         const int64_t o = (T == 1) ? (int64_t)ul * P.Kp : ((int64_t)ul * T + tile) * P.Kp;
-        rp_select_emit(n_cols, sel, [&](int pos, int w) {
+        rp_select_emit<RP_PRED_THREADS>(n_cols, sel, [&](int pos, int w) {
           P.out_idx[o + pos] = t0 + w;
           P.out_val[o + pos] = acc[w];
         });
         if (tid == 0) P.out_nnz[(T == 1) ? ul : ul * T + tile] = kp;
       } else if (P.mode == 2) {
-        rp_select_emit(n_cols, sel, [&](int pos, int w) {
+        rp_select_emit<RP_PRED_THREADS>(n_cols, sel, [&](int pos, int w) {
           P.full_idx[off + pos] = t0 + w;
           P.full_val[off + pos] = (double)acc[w];
         });
         off += kp;
       }
       total += kp;
-      __syncthreads();
-      for (int w = tid; w < W; w += RP_PRED_THREADS) acc[w] = 0.0f;
+      rp_select_foreach<RP_PRED_THREADS>(n_cols, sel, [&](int w) { acc[w] = 0.0f; });  // clear what was touched
       __syncthreads();
     }
     if (P.mode == 1 && tid == 0) P.row_nnz[ul] = total;
@@ -168,7 +167,7 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_merge(const int32_t
     __syncthreads();
     rp_flist_src src{lcol, lval, n};
     const int kp = rp_select_topk<RP_PRED_THREADS>(src, n, Kp, sel);
-    rp_select_emit(n, sel, [&](int pos, int w) {
+    rp_select_emit<RP_PRED_THREADS>(n, sel, [&](int pos, int w) {
       out_idx[(int64_t)ul * Kp + pos] = lcol[w];
       out_val[(int64_t)ul * Kp + pos] = lval[w];
     });
@@ -268,7 +267,8 @@ extern "C" int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, 
   hipLaunchKernelGGL(k_predict_sparse, dim3(grid), dim3(RP_PRED_THREADS), lds, st, P);
   if (T > 1) {
     const size_t mlds = (size_t)T * Kp * 8 + rp_select_smem_bytes(T * Kp);
-    if (mlds > 160 * 1024) RP_FAIL(RPHIP_ELIMIT, "Kp=%d with %d column tiles needs %zu bytes of LDS for the merge", Kp, T, mlds);
+    if (mlds > 160 * 1024 || T * Kp >= RPS_FLAG)
+      RP_FAIL(RPHIP_ELIMIT, "Kp=%d with %d column tiles needs %zu bytes of LDS for the merge", Kp, T, mlds);
     RP_HIP(hipFuncSetAttribute((const void*)k_predict_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
     const int mg = (int)std::min<int64_t>(n, (int64_t)ctx->n_cu * 8);
     hipLaunchKernelGGL(k_predict_merge, dim3(mg), dim3(RP_PRED_THREADS), mlds, st, cand_idx, cand_val, cand_nnz, T, Kp, (int)n, idx_dev,

@@ -10,58 +10,89 @@
 // Slots must be in increasing column order; the selected entries are emitted in slot (= column) order,
 // so the output rows are canonical CSR rows.
 //
-// Method: MSD radix select on the composite (key, ~col), 12 bits per level, histogram in LDS; as soon as
-// the undecided group fits RP_SORT_CAP entries it is sorted exactly (bitonic) to read off the threshold.
-// Then one predicate pass builds a 64-slot bitmask per wave-step, a 16-entry scan orders the waves and a
-// last pass emits.  Every candidate is classified exactly - no sampling, no tolerance.
+// Method
+//   1. compaction: every wave scans its contiguous share of the slots ONCE and writes the valid slot ids
+//      (u16) to its segment of an LDS list - all later passes touch candidates only (rows are ~5-10 % dense);
+//   2. MSD radix select on the composite (key, ~col), 11 bits per level, histogram in LDS; as soon as the
+//      undecided group fits RP_SORT_CAP entries it is sorted exactly (bitonic) to read off the threshold;
+//   3. predicate pass flags the selected list entries (bit 15), a 16-entry scan orders the waves, emit.
+// Every candidate is classified exactly - no sampling, no tolerance.
 #pragma once
 
 #include "rp_common.h"
 
 struct rp_select_smem {
-  uint32_t* hist;    // RP_HIST_BINS u32, overlays skey/scol
-  uint64_t* skey;    // RP_SORT_CAP
-  uint32_t* scol;    // RP_SORT_CAP
-  uint64_t* mask;    // ceil(n_slots / 64)
-  int* misc;         // 64 ints
+  uint32_t* hist;  // RP_HIST_BINS u32, overlays skey/scol
+  uint64_t* skey;  // RP_SORT_CAP
+  uint32_t* scol;  // RP_SORT_CAP
+  uint16_t* list;  // rp_list_cap(n_slots) entries: wave w owns [w*per_wave, (w+1)*per_wave)
+  int* misc;       // RPS_MISC_INTS ints
+#ifdef RP_STAMPS
+  unsigned long long* stamps;  // diagnostic build: [8]=compaction [9]=radix levels [10]=sort [11]=predicate
+#endif
 };
 
-// bytes of LDS the selection needs besides the tile itself
-__host__ __device__ constexpr size_t rp_select_smem_bytes(int n_slots) {
-  return (size_t)RP_SORT_CAP * 12 + (size_t)((n_slots + 63) / 64) * 8 + 64 * 4;
+#ifdef RP_STAMPS
+#define RPS_STAMP(ph)                                         \
+  do {                                                        \
+    if (threadIdx.x == 0 && s.stamps) {                       \
+      unsigned long long _t = __builtin_amdgcn_s_memtime();   \
+      atomicAdd(&s.stamps[ph], _t - ts_last);                 \
+      ts_last = _t;                                           \
+    }                                                         \
+  } while (0)
+#else
+#define RPS_STAMP(ph) do { } while (0)
+#endif
+
+constexpr int RPS_MISC_INTS = 96;
+constexpr int RPS_FLAG = 0x8000;
+
+__host__ __device__ constexpr int rp_per_wave(int n_slots, int nwaves) {
+  return ((n_slots + nwaves * 64 - 1) / (nwaves * 64)) * 64;
+}
+__host__ __device__ constexpr int rp_list_cap(int n_slots, int nwaves) { return rp_per_wave(n_slots, nwaves) * nwaves; }
+
+// bytes of LDS the selection needs besides the tile itself (nwaves = threads / 64)
+__host__ __device__ constexpr size_t rp_select_smem_bytes(int n_slots, int nwaves = 16) {
+  return (size_t)RP_HIST_BINS * 4 + (size_t)rp_list_cap(n_slots, nwaves) * 2 + RPS_MISC_INTS * 4;
 }
 
-__device__ __forceinline__ rp_select_smem rp_select_carve(char* base, int n_slots) {
+__device__ __forceinline__ rp_select_smem rp_select_carve(char* base, int n_slots, int nwaves = 16) {
+  static_assert(RP_SORT_CAP * 12 <= RP_HIST_BINS * 4, "sort buffers overlay the histogram");
   rp_select_smem s;
+  s.hist = reinterpret_cast<uint32_t*>(base);
   s.skey = reinterpret_cast<uint64_t*>(base);
   s.scol = reinterpret_cast<uint32_t*>(base + (size_t)RP_SORT_CAP * 8);
-  s.hist = reinterpret_cast<uint32_t*>(base);  // 16 KiB <= 24 KiB
-  s.mask = reinterpret_cast<uint64_t*>(base + (size_t)RP_SORT_CAP * 12);
-  s.misc = reinterpret_cast<int*>(base + (size_t)RP_SORT_CAP * 12 + (size_t)((n_slots + 63) / 64) * 8);
+  s.list = reinterpret_cast<uint16_t*>(base + (size_t)RP_HIST_BINS * 4);
+  s.misc = reinterpret_cast<int*>(base + (size_t)RP_HIST_BINS * 4 + (size_t)rp_list_cap(n_slots, nwaves) * 2);
+#ifdef RP_STAMPS
+  s.stamps = nullptr;
+#endif
   return s;
 }
 
-// level table: 6 levels over the key (12,12,12,12,12,4 bits from the top), 3 over ~col (12,12,8)
+// level table: 6 levels over the key (11,11,11,11,11,9 bits from the top), 3 over ~col (11,11,10)
 __device__ __forceinline__ void rp_level(int level, int* shift, int* width, bool* is_col) {
   if (level < 5) {
-    *shift = 52 - 12 * level;
-    *width = 12;
+    *shift = 53 - 11 * level;
+    *width = 11;
     *is_col = false;
   } else if (level == 5) {
     *shift = 0;
-    *width = 4;
+    *width = 9;
     *is_col = false;
   } else if (level == 6) {
-    *shift = 20;
-    *width = 12;
+    *shift = 21;
+    *width = 11;
     *is_col = true;
   } else if (level == 7) {
-    *shift = 8;
-    *width = 12;
+    *shift = 10;
+    *width = 11;
     *is_col = true;
   } else {
     *shift = 0;
-    *width = 8;
+    *width = 10;
     *is_col = true;
   }
 }
@@ -72,38 +103,59 @@ __device__ __forceinline__ int rp_wave_sum(int v) {
   return v;
 }
 
-// misc layout
-enum { RPS_NVALID = 0, RPS_BIN = 1, RPS_ABOVE = 2, RPS_CNT = 3, RPS_GROUP = 4, RPS_WCNT = 16 /* 16..31 */, RPS_RED = 32 /* 32..47 */, RPS_USER = 48 /* 48..63: caller's */ };
+// misc layout (ints)
+enum {
+  RPS_NSEL = 0,
+  RPS_BIN = 1,
+  RPS_ABOVE = 2,
+  RPS_CNT = 3,
+  RPS_GROUP = 4,
+  RPS_WOFF = 16,  // 16..31: exclusive offset of wave w's selected entries
+  RPS_RED = 32,   // 32..47: scratch for reductions over waves
+  RPS_LCNT = 48,  // 48..63: candidates in wave w's list segment
+  RPS_USER = 64   // 64..95: the caller's
+};
 
-// Returns K' (number of selected entries).  After the call, s.mask holds one bit per slot (1 = selected)
-// and s.misc[RPS_WCNT + w] the exclusive offset of wave w's first slot.  Wave w owns the slots
-// [w*per_wave, (w+1)*per_wave), per_wave = ceil(n_slots / nwaves / 64) * 64.
+// Returns K' (number of selected entries).  Afterwards the list holds the candidates of every wave segment
+// (RPS_LCNT + w entries), selected ones flagged with RPS_FLAG; use rp_select_emit / rp_select_foreach.
 template <int NTHR, class Src>
 __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem s) {
   static_assert(RP_HIST_BINS % NTHR == 0, "bins must divide over the threads");
   constexpr int BPT = RP_HIST_BINS / NTHR;  // histogram bins owned by one thread
-  const int tid = threadIdx.x, nthr = NTHR;
-  const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
-  const int per_wave = ((n_slots + nwaves * 64 - 1) / (nwaves * 64)) * 64;
+  constexpr int NW = NTHR / 64;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int per_wave = rp_per_wave(n_slots, NW);
   const int w_begin = wave * per_wave;
   const int w_end = min(n_slots, w_begin + per_wave);
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  uint16_t* mylist = s.list + w_begin;
 
-  // ---- count candidates
+#ifdef RP_STAMPS
+  unsigned long long ts_last = __builtin_amdgcn_s_memtime();
+#endif
+  // ---- 1. compaction
   int cnt = 0;
   for (int b = w_begin; b < w_end; b += 64) {
-    int slot = b + lane;
-    bool v = (slot < w_end) && src.valid(slot);
-    cnt += v ? 1 : 0;
+    const int slot = b + lane;
+    const bool v = (slot < w_end) && src.valid(slot);
+    const uint64_t m = __ballot(v);
+    if (v) mylist[cnt + __popcll(m & lt_mask)] = (uint16_t)slot;
+    cnt += __popcll(m);
   }
-  cnt = rp_wave_sum(cnt);
-  if (lane == 0) s.misc[RPS_RED + wave] = cnt;
+  if (lane == 0) {
+    s.misc[RPS_RED + wave] = cnt;
+    s.misc[RPS_LCNT + wave] = cnt;
+  }
   __syncthreads();
   int n_valid = 0;
-  for (int w = 0; w < nwaves; ++w) n_valid += s.misc[RPS_RED + w];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) n_valid += s.misc[RPS_RED + w];
   const int kprime = min(K, n_valid);
   __syncthreads();
+  RPS_STAMP(8);
 
-  uint64_t tkey = 0;   // threshold composite: selected <=> (key, ~col) >= (tkey, tcol)
+  uint64_t tkey = 0;  // threshold composite: selected <=> (key, ~col) >= (tkey, tcol)
   uint32_t tcol = 0;
   if (kprime < n_valid) {
     uint64_t pkey = 0;  // decided prefix
@@ -114,47 +166,44 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
       bool is_col;
       rp_level(level, &shift, &width, &is_col);
       const int nb = 1 << width;
-      for (int i = tid; i < RP_HIST_BINS; i += nthr) s.hist[i] = 0;
+      for (int i = tid; i < RP_HIST_BINS; i += NTHR) s.hist[i] = 0;
       if (tid == 0) {
         s.misc[RPS_BIN] = -1;
         s.misc[RPS_CNT] = 0;
       }
       __syncthreads();
       // histogram of this level's digit over the undecided group
-      for (int b = w_begin; b < w_end; b += 64) {
-        int slot = b + lane;
-        if (slot < w_end && src.valid(slot)) {
-          uint64_t k = src.key(slot);
-          uint32_t ic = ~src.col(slot);
-          bool in_group;
-          uint32_t d;
-          if (!is_col) {
-            in_group = (level == 0) || ((k >> (shift + width)) == (pkey >> (shift + width)));
-            d = (uint32_t)(k >> shift) & (nb - 1);
-          } else {
-            in_group = (k == pkey) && ((level == 6) || ((ic >> (shift + width)) == (pcol >> (shift + width))));
-            d = (ic >> shift) & (nb - 1);
-          }
-          if (in_group) atomicAdd(&s.hist[d], 1u);
+      for (int e = lane; e < cnt; e += 64) {
+        const int slot = mylist[e];
+        const uint64_t k = src.key(slot);
+        const uint32_t ic = ~src.col(slot);
+        bool in_group;
+        uint32_t d;
+        if (!is_col) {
+          in_group = (level == 0) || ((k >> (shift + width)) == (pkey >> (shift + width)));
+          d = (uint32_t)(k >> shift) & (nb - 1);
+        } else {
+          in_group = (k == pkey) && ((level == 6) || ((ic >> (shift + width)) == (pcol >> (shift + width))));
+          d = (ic >> shift) & (nb - 1);
         }
+        if (in_group) atomicAdd(&s.hist[d], 1u);
       }
       __syncthreads();
       // find the bin where the count from the top reaches `need`: thread t owns BPT bins, descending
       {
-        int d_hi = RP_HIST_BINS - 1 - BPT * tid;
+        const int d_hi = RP_HIST_BINS - 1 - BPT * tid;
         int h[BPT];
         int sum = 0;
 #pragma unroll
         for (int e = 0; e < BPT; ++e) {
-          int d = d_hi - e;
+          const int d = d_hi - e;
           h[e] = (d < nb) ? (int)s.hist[d] : 0;
           sum += h[e];
         }
-        // exclusive prefix over threads (= entries in higher bins)
-        int inc = sum;
+        int inc = sum;  // inclusive prefix over the wave (= entries in this and higher bins)
 #pragma unroll
         for (int dd = 1; dd < 64; dd <<= 1) {
-          int t = __shfl_up(inc, dd);
+          const int t = __shfl_up(inc, dd);
           if (lane >= dd) inc += t;
         }
         if (lane == 63) s.misc[RPS_RED + wave] = inc;
@@ -189,40 +238,39 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
       if (group <= RP_SORT_CAP) {
         // exact: gather the group, sort descending, read the need-th
         __syncthreads();  // hist is dead from here (skey overlays it)
-        for (int b = w_begin; b < w_end; b += 64) {
-          int slot = b + lane;
-          if (slot < w_end && src.valid(slot)) {
-            uint64_t k = src.key(slot);
-            uint32_t ic = ~src.col(slot);
-            bool in_group;
-            if (!is_col)
-              in_group = (k >> shift) == (pkey >> shift);
-            else
-              in_group = (k == pkey) && ((ic >> shift) == (pcol >> shift));
-            if (in_group) {
-              int p = atomicAdd(&s.misc[RPS_CNT], 1);
-              s.skey[p] = k;
-              s.scol[p] = ic;
-            }
+        RPS_STAMP(9);
+        for (int e = lane; e < cnt; e += 64) {
+          const int slot = mylist[e];
+          const uint64_t k = src.key(slot);
+          const uint32_t ic = ~src.col(slot);
+          bool in_group;
+          if (!is_col)
+            in_group = (k >> shift) == (pkey >> shift);
+          else
+            in_group = (k == pkey) && ((ic >> shift) == (pcol >> shift));
+          if (in_group) {
+            const int p = atomicAdd(&s.misc[RPS_CNT], 1);
+            s.skey[p] = k;
+            s.scol[p] = ic;
           }
         }
         __syncthreads();
         int n2 = 1;
         while (n2 < group) n2 <<= 1;
-        for (int i = group + tid; i < n2; i += nthr) {
+        for (int i = group + tid; i < n2; i += NTHR) {
           s.skey[i] = 0;
           s.scol[i] = 0;
         }
         __syncthreads();
         for (int k2 = 2; k2 <= n2; k2 <<= 1) {
           for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < n2; i += nthr) {
-              int ixj = i ^ j;
+            for (int i = tid; i < n2; i += NTHR) {
+              const int ixj = i ^ j;
               if (ixj > i) {
-                uint64_t ka = s.skey[i], kb = s.skey[ixj];
-                uint32_t ca = s.scol[i], cb = s.scol[ixj];
-                bool a_lt_b = (ka < kb) || (ka == kb && ca < cb);
-                bool desc = ((i & k2) == 0);  // descending in the first half
+                const uint64_t ka = s.skey[i], kb = s.skey[ixj];
+                const uint32_t ca = s.scol[i], cb = s.scol[ixj];
+                const bool a_lt_b = (ka < kb) || (ka == kb && ca < cb);
+                const bool desc = ((i & k2) == 0);  // descending in the first half
                 if (desc ? a_lt_b : !a_lt_b) {
                   s.skey[i] = kb;
                   s.skey[ixj] = ka;
@@ -237,58 +285,71 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
         tkey = s.skey[need - 1];
         tcol = s.scol[need - 1];
         __syncthreads();
+        RPS_STAMP(10);
         break;
       }
       __syncthreads();
     }
   }
 
-  // ---- predicate pass: bitmask + per-wave counts
+  RPS_STAMP(9);
+  // ---- 3. predicate pass: flag the selected entries, per-wave counts
   int wc = 0;
-  for (int b = w_begin; b < w_begin + per_wave; b += 64) {
-    int slot = b + lane;
+  for (int e0 = 0; e0 < cnt; e0 += 64) {
+    const int e = e0 + lane;
     bool sel = false;
-    if (slot < w_end && src.valid(slot)) {
+    if (e < cnt) {
+      const int slot = mylist[e];
       if (kprime == n_valid) {
         sel = true;
       } else {
-        uint64_t k = src.key(slot);
-        uint32_t ic = ~src.col(slot);
+        const uint64_t k = src.key(slot);
+        const uint32_t ic = ~src.col(slot);
         sel = (k > tkey) || (k == tkey && ic >= tcol);
       }
+      if (sel) mylist[e] = (uint16_t)(slot | RPS_FLAG);
     }
-    uint64_t m = __ballot(sel);
-    if (b < n_slots && lane == 0) s.mask[b >> 6] = m;
-    wc += __popcll(m);
+    wc += __popcll(__ballot(sel));
   }
   if (lane == 0) s.misc[RPS_RED + wave] = wc;
   __syncthreads();
   if (tid == 0) {
     int off = 0;
-    for (int w = 0; w < nwaves; ++w) {
-      s.misc[RPS_WCNT + w] = off;
+    for (int w = 0; w < NW; ++w) {
+      s.misc[RPS_WOFF + w] = off;
       off += s.misc[RPS_RED + w];
     }
-    s.misc[RPS_NVALID] = off;
+    s.misc[RPS_NSEL] = off;
   }
   __syncthreads();
+  RPS_STAMP(11);
   return kprime;
 }
 
 // Emit the selected slots in column order: emit(pos, slot).
-template <class Emit>
+template <int NTHR, class Emit>
 __device__ __forceinline__ void rp_select_emit(int n_slots, rp_select_smem s, Emit emit) {
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
-  const int per_wave = ((n_slots + nwaves * 64 - 1) / (nwaves * 64)) * 64;
-  const int w_begin = wave * per_wave;
-  int off = s.misc[RPS_WCNT + wave];
-  for (int b = w_begin; b < w_begin + per_wave && b < n_slots; b += 64) {
-    uint64_t m = s.mask[b >> 6];
-    if ((m >> lane) & 1ull) {
-      int pos = off + __popcll(m & ((1ull << lane) - 1ull));
-      emit(pos, b + lane);
-    }
+  constexpr int NW = NTHR / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint16_t* mylist = s.list + wave * rp_per_wave(n_slots, NW);
+  const int cnt = s.misc[RPS_LCNT + wave];
+  int off = s.misc[RPS_WOFF + wave];
+  for (int e0 = 0; e0 < cnt; e0 += 64) {
+    const int e = e0 + lane;
+    const int v = (e < cnt) ? (int)mylist[e] : 0;
+    const bool sel = (v & RPS_FLAG) != 0;
+    const uint64_t m = __ballot(sel);
+    if (sel) emit(off + __popcll(m & ((1ull << lane) - 1ull)), v & (RPS_FLAG - 1));
     off += __popcll(m);
   }
+}
+
+// Visit every candidate slot (selected or not): f(slot).  Used to clear the touched accumulators.
+template <int NTHR, class F>
+__device__ __forceinline__ void rp_select_foreach(int n_slots, rp_select_smem s, F f) {
+  constexpr int NW = NTHR / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint16_t* mylist = s.list + wave * rp_per_wave(n_slots, NW);
+  const int cnt = s.misc[RPS_LCNT + wave];
+  for (int e = lane; e < cnt; e += 64) f((int)(mylist[e] & (RPS_FLAG - 1)));
 }
