@@ -94,7 +94,9 @@ struct rphip_model {
   int32_t* idx = nullptr;   // [rows*K]
   double* val = nullptr;    // [rows*K]
   float* val32 = nullptr;   // [rows*K] (predict operand)
+  int2* pairs = nullptr;    // [rows*K] {column, float bits}: what the wave-per-user predict kernel streams
   int32_t* nnz = nullptr;   // [rows]
+  bool cols_sorted = false; // every row's columns strictly increasing (checked when the model is finalised)
   // DENSE
   float* B = nullptr;       // [n_items * ld]
   int64_t ld = 0;
@@ -112,5 +114,8 @@ int rp_exclusive_scan_i32(rphip_ctx* ctx, const int32_t* in, int32_t* out, int64
 
 // rp_csr.hip
 int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m);
+
+// rp_predict.hip: val (f64) -> val32 + pairs, column-order check; call once the lists are complete
+int rp_model_finalize_topk(rphip_ctx* ctx, rphip_model* m);
 
 static inline int64_t rp_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

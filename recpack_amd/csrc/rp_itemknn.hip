@@ -421,11 +421,6 @@ __global__ void k_plan_write(const int32_t* __restrict__ deg, const int32_t* __r
   }
 }
 
-__global__ void k_f64_to_f32(const double* __restrict__ in, float* __restrict__ out, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    out[i] = (float)in[i];
-}
-
 // ---- host side -------------------------------------------------------------------------------------
 static int rp_model_alloc_topk(rphip_ctx* ctx, int64_t n_items, int64_t r0, int64_t r1, int32_t K, rphip_model** out) {
   rphip_model* m = new rphip_model();
@@ -439,6 +434,7 @@ static int rp_model_alloc_topk(rphip_ctx* ctx, int64_t n_items, int64_t r0, int6
   hipError_t e1 = hipMalloc((void**)&m->idx, n * sizeof(int32_t));
   hipError_t e2 = hipMalloc((void**)&m->val, n * sizeof(double));
   hipError_t e3 = hipMalloc((void**)&m->val32, n * sizeof(float));
+  if (e3 == hipSuccess) e3 = hipMalloc((void**)&m->pairs, n * sizeof(int2));
   hipError_t e4 = hipMalloc((void**)&m->nnz, (size_t)std::max<int64_t>(1, r1 - r0) * sizeof(int32_t));
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
     rphip_model_destroy(m);
@@ -454,6 +450,7 @@ extern "C" int rphip_model_destroy(rphip_model* m) {
   if (m->idx) hipFree(m->idx);
   if (m->val) hipFree(m->val);
   if (m->val32) hipFree(m->val32);
+  if (m->pairs) hipFree(m->pairs);
   if (m->nnz) hipFree(m->nnz);
   if (m->B) hipFree(m->B);
   delete m;
@@ -497,7 +494,11 @@ extern "C" int rphip_itemknn_fit(rphip_ctx* ctx, const rphip_csr* X, int64_t row
   hipMemsetAsync(m->val, 0, nk * sizeof(double), st);
   hipMemsetAsync(m->nnz, 0, (size_t)std::max(1, n_rows) * sizeof(int32_t), st);
   if (n_rows == 0 || X->nnz == 0) {
-    hipMemsetAsync(m->val32, 0, nk * sizeof(float), st);
+    int r = rp_model_finalize_topk(ctx, m);
+    if (r != RPHIP_OK) {
+      rphip_model_destroy(m);
+      return r;
+    }
     *out = m;
     return RPHIP_OK;
   }
@@ -657,9 +658,13 @@ extern "C" int rphip_itemknn_fit(rphip_ctx* ctx, const rphip_csr* X, int64_t row
     RP_HIP(hipGetLastError());
     rp_time_end(ctx, ev, RPHIP_T_TOPK_MERGE, 16.0 * (double)n_rows * T * Keff);
   }
-  hipLaunchKernelGGL(k_f64_to_f32, dim3((unsigned)std::min<int64_t>(2048, rp_cdiv((int64_t)nk, 256))), dim3(256), 0, st, m->val,
-                     m->val32, (int64_t)nk);
-  RP_HIP(hipGetLastError());
+  {
+    int r = rp_model_finalize_topk(ctx, m);
+    if (r != RPHIP_OK) {
+      rphip_model_destroy(m);
+      return r;
+    }
+  }
   *out = m;
   return RPHIP_OK;
 }
@@ -714,8 +719,11 @@ static int rp_model_from_topk(rphip_ctx* ctx, int64_t n_items, int32_t K, const 
     }
     if (kind == hipMemcpyHostToDevice) rp_time_end(ctx, ev, RPHIP_T_H2D, (double)nk * 12.0);
     else ctx->ev_pool.push_back(ev);
-    hipLaunchKernelGGL(k_f64_to_f32, dim3((unsigned)std::min<int64_t>(2048, rp_cdiv((int64_t)nk, 256))), dim3(256), 0, ctx->stream,
-                       m->val, m->val32, (int64_t)nk);
+    int r = rp_model_finalize_topk(ctx, m);
+    if (r != RPHIP_OK) {
+      rphip_model_destroy(m);
+      return r;
+    }
     if (kind == hipMemcpyHostToDevice) RP_HIP(hipStreamSynchronize(ctx->stream));
   }
   *out = m;
