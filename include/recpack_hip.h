@@ -169,6 +169,19 @@ int rphip_ease_fit(rphip_ctx* ctx, const rphip_csr* X, double l2, double alpha, 
 /* dense B (row-major float32[n_items*n_items]) to host - the lazy similarity_matrix_ (ease.py:92) */
 int rphip_model_dense_download(rphip_ctx* ctx, const rphip_model* m, float* B_host);
 int rphip_model_dense_device(const rphip_model* m, void** B_dev, int64_t* n_items, int64_t* ld);
+/* a dense model from a host matrix (row-major float32[n_items*n_items], copied): used after host-side edits of B
+ * such as EASE's density pruning (ease.py:97-109) */
+int rphip_model_from_dense_host(rphip_ctx* ctx, int64_t n_items, const float* B_host, rphip_model** out);
+/* number of similarity rows without any stored value (dense models; -1 if not counted): what
+ * ItemSimilarityMatrixAlgorithm._check_fit_complete warns about (recpack/algorithms/base.py:257-279) */
+int rphip_model_empty_rows(rphip_ctx* ctx, const rphip_model* m, int64_t* out);
+
+/* The building block of K5/K6: C = alpha * A * B^T + beta * C in fp32 on MFMA tiles (v_mfma_f32_32x32x2_f32,
+ * exact fp32 FMA chains).  A is M x K, B is N x K, C is M x N, all row-major device memory; M and N must be
+ * multiples of 128, K of 16, lda/ldb of 4.  Stands where the reference relies on LAPACK/BLAS inside
+ * np.linalg.inv (recpack/algorithms/ease.py:82); exported for tests and roofline measurements. */
+int rphip_gemm_nt_f32(rphip_ctx* ctx, int64_t M, int64_t N, int64_t K, float alpha, const float* A_dev, int64_t lda,
+                      const float* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc);
 
 #ifdef __cplusplus
 }

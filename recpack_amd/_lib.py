@@ -81,6 +81,9 @@ PROTOTYPES = {
     "rphip_ease_fit": (C.c_int, [_p, _p, _f64, _f64, _pp]),
     "rphip_model_dense_download": (C.c_int, [_p, _p, _p]),
     "rphip_model_dense_device": (C.c_int, [_p, _pp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "rphip_model_from_dense_host": (C.c_int, [_p, _i64, _p, _pp]),
+    "rphip_model_empty_rows": (C.c_int, [_p, _p, C.POINTER(_i64)]),
+    "rphip_gemm_nt_f32": (C.c_int, [_p, _i64, _i64, _i64, C.c_float, _p, _i64, _p, _i64, C.c_float, _p, _i64]),
 }
 
 _lock = threading.Lock()
@@ -247,6 +250,19 @@ class Model:
                                                    C.c_void_p(val_t.data_ptr()), C.c_void_p(nnz_t.data_ptr()), C.byref(h)))
         return cls(ctx, h)
 
+    @classmethod
+    def from_dense_host(cls, ctx: Context, B: np.ndarray):
+        B = np.ascontiguousarray(B, dtype=np.float32)
+        assert B.ndim == 2 and B.shape[0] == B.shape[1]
+        h = C.c_void_p()
+        check(ctx.lib.rphip_model_from_dense_host(ctx.handle, B.shape[0], _np_ptr(B), C.byref(h)))
+        return cls(ctx, h)
+
+    def empty_rows(self) -> int:
+        v = C.c_int64()
+        check(self.ctx.lib.rphip_model_empty_rows(self.ctx.handle, self.handle, C.byref(v)))
+        return v.value
+
     def dense_download(self) -> np.ndarray:
         out = np.empty((self.n_items, self.n_items), dtype=np.float32)
         check(self.ctx.lib.rphip_model_dense_download(self.ctx.handle, self.handle, _np_ptr(out)))
@@ -271,6 +287,14 @@ def ease_fit(ctx: Context, X: DeviceCSR, l2: float, alpha: float = 0.0) -> Model
     h = C.c_void_p()
     check(ctx.lib.rphip_ease_fit(ctx.handle, X.handle, float(l2), float(alpha), C.byref(h)))
     return Model(ctx, h)
+
+
+def gemm_nt(ctx: Context, A_t, B_t, C_t, alpha: float = 1.0, beta: float = 0.0):
+    """C = alpha * A @ B.T + beta * C on torch float32 CUDA tensors (row-major, sizes multiples of 128 / 16)."""
+    M, K = A_t.shape
+    N = B_t.shape[0]
+    check(ctx.lib.rphip_gemm_nt_f32(ctx.handle, M, N, K, float(alpha), C.c_void_p(A_t.data_ptr()), A_t.stride(0),
+                                    C.c_void_p(B_t.data_ptr()), B_t.stride(0), float(beta), C.c_void_p(C_t.data_ptr()), C_t.stride(0)))
 
 
 def predict_topk(ctx: Context, model: Model, X: DeviceCSR, Kp: int, exclude_history: bool = False, user_begin: int = 0,

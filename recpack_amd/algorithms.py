@@ -252,7 +252,13 @@ class ItemKNN(TopKItemSimilarityMatrixAlgorithm):
 
 
 class EASE(ItemSimilarityMatrixAlgorithm):
-    """EASE (recpack/algorithms/ease.py:19-109) on MI355X: dense B stays on the device."""
+    """EASE (recpack/algorithms/ease.py:19-109) on MI355X.
+
+    The dense item-item matrix B stays on the device in float32; ``similarity_matrix_`` is materialised on the
+    host (float64 CSR, as the reference stores it, ease.py:92) only when it is read - for 50K items that is a
+    20 GB download plus a CSR conversion, so predict() never touches it.
+    ``density`` (ease.py:97-109) prunes on the host with the reference's rule and re-uploads the result.
+    """
 
     def __init__(self, l2=1e3, alpha=0, density=None):
         super().__init__()
@@ -266,8 +272,45 @@ class EASE(ItemSimilarityMatrixAlgorithm):
             self._model = _lib.ease_fit(ctx, dX, float(self.l2), float(self.alpha))
         finally:
             dX.close()
-        B = self._model.dense_download().astype(np.float64)
-        self.similarity_matrix_ = sp.csr_matrix(B)
-        self._empty_rows_ = int(np.count_nonzero(np.diff(self.similarity_matrix_.indptr) == 0))
+        self._sim_cache = None
+        self.n_items_ = X.shape[1]
         if self.density:
-            raise NotImplementedError("recpack_amd.EASE: density pruning is not part of this build yet")
+            self._prune()
+        self._empty_rows_ = self._model.empty_rows()
+
+    def _prune(self):
+        """ease.py:97-109: keep the ``int(density * n * n)`` largest |B_ij| (np.prod for the removed np.product)."""
+        B = self._model.dense_download()
+        n = B.shape[0]
+        nnz = int(np.count_nonzero(B))
+        k = min(int(self.density * n * n), nnz)
+        if k < nnz:
+            flat = np.abs(B).ravel()
+            if k > 0:
+                thr_idx = np.argpartition(flat, -k)[:-k]
+            else:
+                thr_idx = np.arange(flat.shape[0])
+            B.ravel()[thr_idx] = 0.0
+            self._model = _lib.Model.from_dense_host(get_context(), B)
+        self._sim_cache = None
+
+    @property
+    def similarity_matrix_(self) -> sp.csr_matrix:
+        if getattr(self, "_model", None) is None:
+            raise AttributeError("similarity_matrix_")
+        if self._sim_cache is None:
+            self._sim_cache = sp.csr_matrix(self._model.dense_download().astype(np.float64))
+        return self._sim_cache
+
+    @similarity_matrix_.setter
+    def similarity_matrix_(self, value):  # an externally supplied matrix (reference tests do this before _prune)
+        value = sp.csr_matrix(value)
+        self._model = _lib.Model.from_dense_host(get_context(), value.toarray().astype(np.float32))
+        self._sim_cache = value
+        self.n_items_ = value.shape[0]
+        self._empty_rows_ = self._model.empty_rows()
+
+    def _check_fit_complete(self):
+        check_is_fitted(self)
+        if self._empty_rows_ is not None and self._empty_rows_ > 0:
+            warnings.warn(f"{self.name} missing similar items for {self._empty_rows_} items.")

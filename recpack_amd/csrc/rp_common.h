@@ -100,6 +100,7 @@ struct rphip_model {
   // DENSE
   float* B = nullptr;       // [n_items * ld]
   int64_t ld = 0;
+  int64_t empty_rows = -1;  // rows without any stored similarity (-1: not counted)
 };
 
 // ---- helpers (rp_api.hip) ------------------------------------------------------------------------
@@ -114,6 +115,10 @@ int rp_exclusive_scan_i32(rphip_ctx* ctx, const int32_t* in, int32_t* out, int64
 
 // rp_csr.hip
 int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m);
+
+// rp_itemknn.hip: K4, dense f32 Gram rows [row_begin,row_end) of X^T X into G (row-major, leading dimension ld),
+// diag_add on the diagonal; rows of items nobody interacted with are left untouched
+int rp_gram_dense(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, float* G, int64_t ld, float diag_add);
 
 // rp_predict.hip: val (f64) -> val32 + pairs, column-order check; call once the lists are complete
 int rp_model_finalize_topk(rphip_ctx* ctx, rphip_model* m);

@@ -1,18 +1,535 @@
-// EASE (K4-K7, K9) - placeholder translation unit until the dense path lands.
+// EASE fit (K4-K7): dense Gram, blocked Cholesky + triangular inverse + product on fp32 MFMA tiles, scaling.
+//
+// Replaces EASE._fit (recpack/algorithms/ease.py:63-95):
+//   XTX = (X.T @ X).toarray()                         -> K4  rp_gram_dense (rp_itemknn.hip), lambda fused on the diagonal
+//   P = np.linalg.inv(XTX + l2 * I)  (LU, float64)     -> K5  G + lambda I = L L^T   (left-looking blocked Cholesky)
+//                                                         K6  N = L^-T (blocked triangular inverse), P = N N^T
+//   B = I - P @ diag(1/diag P); B[diag] = 0; B @ diag(w) -> K7  one elementwise pass B_ij = -P_ij / P_jj * w_j
+// The matrix is SPD (lambda > 0), so Cholesky replaces the reference's general LU at half the flops.
+//
+// Every O(n^3) step is the same kernel: C = alpha * A * B^T + beta * C on 128x128 tiles with
+// v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit-exact fp32 FMA chains, no reduced precision), both
+// operands K-contiguous ("NT"), K ranges clipped per tile for the triangular factors.  The 128x128 diagonal
+// blocks are factorised and inverted by one workgroup in float64 in LDS.
+//
+//   Cholesky, panel k : A[k:,k] -= L[k:,0:k] L[k,0:k]^T ; L_kk, W_k = chol(A_kk), L_kk^-1 ; L[k+1:,k] = A[k+1:,k] W_k^T
+//   inverse, column i : N_ii = W_i^T ; T = N[0:i,0:i] L[i,0:i]^T (K from the row's first non-zero) ; N[0:i,i] = -T W_i^T
+//   product           : P = N N^T, K from max(row tile, column tile)
+#include <algorithm>
+
 #include "rp_common.h"
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static int rp_dense_count_empty(rphip_ctx* ctx, rphip_model* m);
+
+constexpr int GT = 128;   // tile (and diagonal block) size
+constexpr int GBK = 16;   // K step
+constexpr int GLD = 20;   // LDS row stride in floats (16 + 4 pad: conflict-free ds_read_b128 over 16 rows)
+
+struct rp_gemm_args {
+  const float* A;
+  long long lda;
+  const float* B;
+  long long ldb;
+  float* C;
+  long long ldc;
+  int M, N;          // multiples of 128
+  int k0, k1;        // K range, multiples of 16
+  int kb_m, kb_n;    // k_begin = max(k0, kb_m * (m_off + m0), kb_n * (n_off + n0))
+  int m_off, n_off;
+  int tri;           // 0: all tiles; 1: only tiles with n_off + n0 <= m_off + m0
+  float alpha, beta;
+};
+
+__global__ void __launch_bounds__(256) k_gemm_nt(rp_gemm_args g) {
+  __shared__ __attribute__((aligned(16))) float As[2][GT * GLD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][GT * GLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  if (g.tri == 1 && g.n_off + n0 > g.m_off + m0) return;
+  int kb = g.k0;
+  if (g.kb_m) kb = max(kb, g.m_off + m0);
+  if (g.kb_n) kb = max(kb, g.n_off + n0);
+  kb &= ~(GBK - 1);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  if (kb < g.k1) {
+    const int lr = tid >> 2, lk = (tid & 3) * 4;
+    const float* Ap = g.A + (long long)(m0 + lr) * g.lda + lk;
+    const float* Bp = g.B + (long long)(n0 + lr) * g.ldb + lk;
+    float4 ra0, ra1, rb0, rb1;
+    auto gload = [&](int k) {
+      ra0 = *reinterpret_cast<const float4*>(Ap + k);
+      ra1 = *reinterpret_cast<const float4*>(Ap + 64 * g.lda + k);
+      rb0 = *reinterpret_cast<const float4*>(Bp + k);
+      rb1 = *reinterpret_cast<const float4*>(Bp + 64 * g.ldb + k);
+    };
+    auto lstore = [&](int buf) {
+      *reinterpret_cast<float4*>(&As[buf][lr * GLD + lk]) = ra0;
+      *reinterpret_cast<float4*>(&As[buf][(lr + 64) * GLD + lk]) = ra1;
+      *reinterpret_cast<float4*>(&Bs[buf][lr * GLD + lk]) = rb0;
+      *reinterpret_cast<float4*>(&Bs[buf][(lr + 64) * GLD + lk]) = rb1;
+    };
+    gload(kb);
+    lstore(0);
+    __syncthreads();
+    const int arow = (wr * 64 + (lane & 31)) * GLD + (lane >> 5) * 4;
+    const int brow = (wc * 64 + (lane & 31)) * GLD + (lane >> 5) * 4;
+    int cur = 0;
+    for (int k = kb; k < g.k1; k += GBK) {
+      const bool more = (k + GBK) < g.k1;
+      if (more) gload(k + GBK);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        // lanes 0-31 take k = 8j..8j+3, lanes 32-63 k = 8j+4..8j+7: one 16-byte read feeds four MFMA k-steps
+        const float4 a0 = *reinterpret_cast<const float4*>(&As[cur][arow + j * 8]);
+        const float4 a1 = *reinterpret_cast<const float4*>(&As[cur][arow + 32 * GLD + j * 8]);
+        const float4 b0 = *reinterpret_cast<const float4*>(&Bs[cur][brow + j * 8]);
+        const float4 b1 = *reinterpret_cast<const float4*>(&Bs[cur][brow + 32 * GLD + j * 8]);
+        const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+        const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv0[s], acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv1[s], acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv0[s], acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv1[s], acc[1][1], 0, 0, 0);
+        }
+      }
+      if (more) lstore(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wc * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float* cp = g.C + (long long)row * g.ldc + col;
+        float v = g.alpha * acc[i][j][r];
+        if (g.beta != 0.0f) v += g.beta * (*cp);
+        *cp = v;
+      }
+    }
+}
+
+// ---- diagonal block: Cholesky + inverse of a 128x128 block, float64 in LDS --------------------------------
+constexpr int DS = GT + 1;  // LDS row stride in doubles
+
+__global__ void __launch_bounds__(1024) k_potrf_trtri(float* __restrict__ A, long long lda, float* __restrict__ W, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* a = reinterpret_cast<double*>(smem_raw);
+  const int tid = threadIdx.x;
+  for (int e = tid; e < GT * GT; e += 1024) {
+    const int i = e / GT, k = e % GT;
+    a[i * DS + k] = (k <= i) ? (double)A[(long long)i * lda + k] : 0.0;
+  }
+  __syncthreads();
+  // right-looking unblocked Cholesky
+  for (int j = 0; j < GT; ++j) {
+    if (tid == 0) {
+      const double d = a[j * DS + j];
+      if (!(d > 0.0)) atomicExch(info, j + 1);
+      a[j * DS + j] = sqrt(d > 0.0 ? d : 1.0);
+    }
+    __syncthreads();
+    const double djj = a[j * DS + j];
+    for (int i = j + 1 + tid; i < GT; i += 1024) a[i * DS + j] /= djj;
+    __syncthreads();
+    // a[i][k] -= a[i][j] * a[k][j] for j < k <= i
+    const int m = GT - 1 - j;  // trailing size
+    for (int e = tid; e < m * m; e += 1024) {
+      const int ii = e / m, kk = e % m;
+      if (kk <= ii) {
+        const int i = j + 1 + ii, k = j + 1 + kk;
+        a[i * DS + k] -= a[i * DS + j] * a[k * DS + j];
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < GT * GT; e += 1024) {
+    const int i = e / GT, k = e % GT;
+    A[(long long)i * lda + k] = (k <= i) ? (float)a[i * DS + k] : 0.0f;
+  }
+  __syncthreads();
+  // in-place inverse of the lower-triangular factor (columns from last to first)
+  for (int j = GT - 1; j >= 0; --j) {
+    const double ajj = 1.0 / a[j * DS + j];
+    double t = 0.0;
+    const int i = j + 1 + tid;
+    if (i < GT) {
+      for (int k = j + 1; k <= i; ++k) t += a[i * DS + k] * a[k * DS + j];
+    }
+    __syncthreads();
+    if (i < GT) a[i * DS + j] = -t * ajj;
+    if (tid == 0) a[j * DS + j] = ajj;
+    __syncthreads();
+  }
+  for (int e = tid; e < GT * GT; e += 1024) {
+    const int i = e / GT, k = e % GT;
+    W[i * GT + k] = (k <= i) ? (float)a[i * DS + k] : 0.0f;
+  }
+}
+
+// ---- small helpers -------------------------------------------------------------------------------------------
+// G = 0 everywhere, diag = lambda (real items) or 1 (padding)
+__global__ void k_ease_init(float* __restrict__ G, long long ld, int n, int n_pad, float lam) {
+  const long long total = (long long)n_pad * ld;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long i = e / ld, j = e % ld;
+    G[e] = (i == j) ? (i < n ? lam : 1.0f) : 0.0f;
+  }
+}
+
+__global__ void k_zero_f32(float* __restrict__ p, long long n) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) p[e] = 0.0f;
+}
+
+// dst block (ld) = src^T, src is a 128x128 block with leading dimension 128
+__global__ void __launch_bounds__(256) k_transpose_128(const float* __restrict__ src, float* __restrict__ dst, long long ld) {
+  __shared__ float t[GT][GT + 1];
+  for (int e = threadIdx.x; e < GT * GT; e += 256) t[e / GT][e % GT] = src[e];
+  __syncthreads();
+  for (int e = threadIdx.x; e < GT * GT; e += 256) {
+    const int i = e / GT, k = e % GT;
+    dst[(long long)i * ld + k] = t[k][i];
+  }
+}
+
+__global__ void k_ease_diag(const float* __restrict__ P, long long ld, int n, const int32_t* __restrict__ deg, float alpha,
+                            float* __restrict__ colscale) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const float d = P[(long long)j * ld + j];
+    float w = 1.0f;
+    if (alpha != 0.0f) w = deg[j] > 0 ? powf((float)deg[j], -alpha) : 0.0f;
+    colscale[j] = -w / d;
+  }
+}
+
+// K7: B_ij = P_ij * colscale_j (= -P_ij / P_jj * w_j), B_ii = 0; in place
+__global__ void k_ease_scale(float* __restrict__ P, long long ld, int n, const float* __restrict__ colscale) {
+  const long long total = (long long)n * ld;
+  for (long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; e < total; e += (long long)gridDim.x * blockDim.x * 4) {
+    const long long i = e / ld;
+    const int j = (int)(e % ld);  // ld is a multiple of 4
+    float4 v = *reinterpret_cast<float4*>(P + e);
+    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int jj = j + c;
+      o[c] = (jj < n && jj != (int)i) ? o[c] * colscale[jj] : 0.0f;
+    }
+    *reinterpret_cast<float4*>(P + e) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ---- host ------------------------------------------------------------------------------------------------------
+static int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g) {
+  if (g.M <= 0 || g.N <= 0) return RPHIP_OK;
+  if ((g.M % GT) || (g.N % GT) || (g.k0 % GBK) || (g.k1 % GBK)) RP_FAIL(RPHIP_EINVAL, "gemm_nt: sizes must be tile multiples");
+  hipLaunchKernelGGL(k_gemm_nt, dim3(g.N / GT, g.M / GT), dim3(256), 0, ctx->stream, g);
+  RP_HIP(hipGetLastError());
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_gemm_nt_f32(rphip_ctx* ctx, int64_t M, int64_t N, int64_t K, float alpha, const float* A_dev, int64_t lda,
+                                 const float* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc) {
+  if (!ctx || !A_dev || !B_dev || !C_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if ((M % GT) || (N % GT) || (K % GBK) || (lda % 4) || (ldb % 4)) RP_FAIL(RPHIP_EINVAL, "M, N must be multiples of 128, K of 16, lda/ldb of 4");
+  RP_TRY(rp_set_device(ctx));
+  rp_gemm_args g{};
+  g.A = A_dev;
+  g.lda = lda;
+  g.B = B_dev;
+  g.ldb = ldb;
+  g.C = C_dev;
+  g.ldc = ldc;
+  g.M = (int)M;
+  g.N = (int)N;
+  g.k0 = 0;
+  g.k1 = (int)K;
+  g.alpha = alpha;
+  g.beta = beta;
+  hipEvent_t ev;
+  rp_time_begin(ctx, &ev);
+  RP_TRY(rp_gemm_nt(ctx, g));
+  rp_time_end(ctx, ev, RPHIP_T_CHOLESKY, 2.0 * (double)M * (double)N * (double)K);
+  return RPHIP_OK;
+}
+
+// in-place inverse of the SPD matrix A (n_pad x n_pad, ld) using the workspace Nb (same size); result in A (full)
+static int rp_spd_inverse(rphip_ctx* ctx, float* A, float* Nb, int n_pad, long long ld) {
+  hipStream_t st = ctx->stream;
+  const int nb = n_pad / GT;
+  char* wsb = nullptr;
+  RP_TRY(rp_scratch(ctx, 5, (size_t)nb * GT * GT * 4 + (size_t)n_pad * GT * 4 + 256, (void**)&wsb));
+  int* info = (int*)wsb;
+  float* W = (float*)(wsb + 256);                 // [nb][128][128]
+  float* T = W + (size_t)nb * GT * GT;            // [n_pad][128]
+  RP_HIP(hipMemsetAsync(info, 0, 4, st));
+  const size_t diag_lds = (size_t)GT * DS * sizeof(double);
+  RP_HIP(hipFuncSetAttribute((const void*)k_potrf_trtri, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
+  const double n3 = (double)n_pad * n_pad * n_pad;
+  hipEvent_t ev;
+  // ---- K5: left-looking blocked Cholesky
+  rp_time_begin(ctx, &ev);
+  for (int k = 0; k < nb; ++k) {
+    const int r0 = k * GT;
+    if (k > 0) {
+      rp_gemm_args g{};
+      g.A = A + (long long)r0 * ld;
+      g.lda = ld;
+      g.B = A + (long long)r0 * ld;
+      g.ldb = ld;
+      g.C = A + (long long)r0 * ld + r0;
+      g.ldc = ld;
+      g.M = n_pad - r0;
+      g.N = GT;
+      g.k0 = 0;
+      g.k1 = r0;
+      g.alpha = -1.0f;
+      g.beta = 1.0f;
+      RP_TRY(rp_gemm_nt(ctx, g));
+    }
+    hipLaunchKernelGGL(k_potrf_trtri, dim3(1), dim3(1024), diag_lds, st, A + (long long)r0 * ld + r0, ld, W + (size_t)k * GT * GT, info);
+    if (r0 + GT < n_pad) {
+      rp_gemm_args g{};
+      g.A = A + (long long)(r0 + GT) * ld + r0;
+      g.lda = ld;
+      g.B = W + (size_t)k * GT * GT;
+      g.ldb = GT;
+      g.C = A + (long long)(r0 + GT) * ld + r0;
+      g.ldc = ld;
+      g.M = n_pad - r0 - GT;
+      g.N = GT;
+      g.k0 = 0;
+      g.k1 = GT;
+      g.alpha = 1.0f;
+      g.beta = 0.0f;
+      RP_TRY(rp_gemm_nt(ctx, g));
+    }
+  }
+  RP_HIP(hipGetLastError());
+  rp_time_end(ctx, ev, RPHIP_T_CHOLESKY, n3 / 3.0);
+  // ---- K6a: N = L^-T (upper triangular), block column by block column
+  rp_time_begin(ctx, &ev);
+  hipLaunchKernelGGL(k_zero_f32, dim3(2048), dim3(256), 0, st, Nb, (long long)n_pad * ld);
+  for (int i = 0; i < nb; ++i) {
+    const int c0 = i * GT;
+    const float* Wi = W + (size_t)i * GT * GT;
+    hipLaunchKernelGGL(k_transpose_128, dim3(1), dim3(256), 0, st, Wi, Nb + (long long)c0 * ld + c0, ld);
+    if (i > 0) {
+      rp_gemm_args g{};
+      g.A = Nb;
+      g.lda = ld;
+      g.B = A + (long long)c0 * ld;
+      g.ldb = ld;
+      g.C = T;
+      g.ldc = GT;
+      g.M = c0;
+      g.N = GT;
+      g.k0 = 0;
+      g.k1 = c0;
+      g.kb_m = 1;  // row block r of N starts at column r
+      g.alpha = 1.0f;
+      g.beta = 0.0f;
+      RP_TRY(rp_gemm_nt(ctx, g));
+      rp_gemm_args h{};
+      h.A = T;
+      h.lda = GT;
+      h.B = Wi;
+      h.ldb = GT;
+      h.C = Nb + c0;
+      h.ldc = ld;
+      h.M = c0;
+      h.N = GT;
+      h.k0 = 0;
+      h.k1 = GT;
+      h.alpha = -1.0f;
+      h.beta = 0.0f;
+      RP_TRY(rp_gemm_nt(ctx, h));
+    }
+  }
+  // ---- K6b: P = N N^T (every tile, K from max(row, column))
+  {
+    rp_gemm_args g{};
+    g.A = Nb;
+    g.lda = ld;
+    g.B = Nb;
+    g.ldb = ld;
+    g.C = A;
+    g.ldc = ld;
+    g.M = n_pad;
+    g.N = n_pad;
+    g.k0 = 0;
+    g.k1 = n_pad;
+    g.kb_m = 1;
+    g.kb_n = 1;
+    g.alpha = 1.0f;
+    g.beta = 0.0f;
+    RP_TRY(rp_gemm_nt(ctx, g));
+  }
+  RP_HIP(hipGetLastError());
+  rp_time_end(ctx, ev, RPHIP_T_INVERSE, n3);  // n^3/3 (N) + 2n^3/3 (full P)
+  int h_info = 0;
+  RP_HIP(hipMemcpyAsync(&h_info, info, 4, hipMemcpyDeviceToHost, st));
+  RP_HIP(hipStreamSynchronize(st));
+  if (h_info) RP_FAIL(RPHIP_ENUMERIC, "Cholesky broke down (non-positive pivot %d in a diagonal block): G + l2*I is not positive definite", h_info);
+  return RPHIP_OK;
+}
+
 extern "C" int rphip_ease_fit(rphip_ctx* ctx, const rphip_csr* X, double l2, double alpha, rphip_model** out) {
-  (void)ctx; (void)X; (void)l2; (void)alpha;
-  if (out) *out = nullptr;
-  RP_FAIL(RPHIP_ESTATE, "rphip_ease_fit: the dense EASE path is not part of this build yet");
+  if (!ctx || !X || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (!(l2 > 0.0)) RP_FAIL(RPHIP_EINVAL, "l2 must be > 0 (got %g): G + l2*I has to be positive definite", l2);
+  RP_TRY(rp_set_device(ctx));
+  const int n = (int)X->n_items;
+  if (n <= 0) RP_FAIL(RPHIP_EINVAL, "no items");
+  const int n_pad = (int)(rp_cdiv(n, GT) * GT);
+  const long long ld = n_pad;
+  const size_t bytes = (size_t)n_pad * ld * sizeof(float);
+  size_t free_b = 0, total_b = 0;
+  hipMemGetInfo(&free_b, &total_b);
+  if (2 * bytes + (1ull << 30) > free_b)
+    RP_FAIL(RPHIP_ENOMEM, "EASE with %d items needs %.1f GB of HBM (two %d x %d f32 matrices), %.1f GB free", n, 2 * bytes / 1e9, n_pad, n_pad,
+            free_b / 1e9);
+  hipStream_t st = ctx->stream;
+  rphip_model* m = new rphip_model();
+  m->ctx = ctx;
+  m->kind = RPHIP_MODEL_DENSE;
+  m->n_items = n;
+  m->row_begin = 0;
+  m->row_end = n;
+  m->K = 0;
+  m->ld = ld;
+  float* Nb = nullptr;
+  if (hipMalloc((void**)&m->B, bytes) != hipSuccess || hipMalloc((void**)&Nb, bytes) != hipSuccess) {
+    if (Nb) hipFree(Nb);
+    rphip_model_destroy(m);
+    RP_FAIL(RPHIP_ENOMEM, "hipMalloc of the dense matrices failed");
+  }
+  // lambda is rounded to float32 exactly as the reference does (l2 * np.identity(dtype=float32), ease.py:82)
+  const float lam = (float)l2;
+  hipLaunchKernelGGL(k_ease_init, dim3(4096), dim3(256), 0, st, m->B, ld, n, n_pad, lam);
+  int r = rp_gram_dense(ctx, X, 0, n, m->B, ld, lam);
+  if (r == RPHIP_OK) r = rp_spd_inverse(ctx, m->B, Nb, n_pad, ld);
+  hipStreamSynchronize(st);
+  hipFree(Nb);
+  if (r != RPHIP_OK) {
+    rphip_model_destroy(m);
+    return r;
+  }
+  // ---- K7
+  hipEvent_t ev;
+  rp_time_begin(ctx, &ev);
+  float* colscale = nullptr;
+  RP_TRY(rp_scratch(ctx, 5, (size_t)n_pad * 4, (void**)&colscale));
+  hipLaunchKernelGGL(k_ease_diag, dim3((unsigned)rp_cdiv(n, 256)), dim3(256), 0, st, m->B, ld, n, X->deg, (float)alpha, colscale);
+  hipLaunchKernelGGL(k_ease_scale, dim3(4096), dim3(256), 0, st, m->B, ld, n, colscale);
+  RP_HIP(hipGetLastError());
+  rp_time_end(ctx, ev, RPHIP_T_EASE_SCALE, 8.0 * (double)n * (double)n);
+  RP_HIP(hipStreamSynchronize(st));
+  r = rp_dense_count_empty(ctx, m);
+  if (r != RPHIP_OK) {
+    rphip_model_destroy(m);
+    return r;
+  }
+  *out = m;
+  return RPHIP_OK;
+}
+
+// rows of B without any non-zero entry (items that co-occur with nothing): feeds the reference's
+// "missing similar items" warning (recpack/algorithms/base.py:272-279) without a host-side nonzero()
+__global__ void __launch_bounds__(256) k_count_empty_rows(const float* __restrict__ B, long long ld, int n, int* __restrict__ cnt) {
+  __shared__ int any_nz;
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    if (threadIdx.x == 0) any_nz = 0;
+    __syncthreads();
+    int nz = 0;
+    for (int j = threadIdx.x; j < n; j += 256) nz |= (B[(long long)i * ld + j] != 0.0f);
+    if (nz) any_nz = 1;
+    __syncthreads();
+    if (threadIdx.x == 0 && !any_nz) atomicAdd(cnt, 1);
+    __syncthreads();
+  }
+}
+
+static int rp_dense_count_empty(rphip_ctx* ctx, rphip_model* m) {
+  int* cnt = nullptr;
+  RP_TRY(rp_scratch(ctx, 5, 64, (void**)&cnt));
+  RP_HIP(hipMemsetAsync(cnt, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(k_count_empty_rows, dim3((unsigned)std::min<int64_t>(m->n_items, 4096)), dim3(256), 0, ctx->stream, m->B, m->ld,
+                     (int)m->n_items, cnt);
+  int h = 0;
+  RP_HIP(hipMemcpyAsync(&h, cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+  RP_HIP(hipStreamSynchronize(ctx->stream));
+  m->empty_rows = h;
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_model_from_dense_host(rphip_ctx* ctx, int64_t n_items, const float* B_host, rphip_model** out) {
+  if (!ctx || !B_host || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (n_items <= 0) RP_FAIL(RPHIP_EINVAL, "no items");
+  RP_TRY(rp_set_device(ctx));
+  rphip_model* m = new rphip_model();
+  m->ctx = ctx;
+  m->kind = RPHIP_MODEL_DENSE;
+  m->n_items = n_items;
+  m->row_end = n_items;
+  m->ld = rp_cdiv(n_items, 4) * 4;
+  if (hipMalloc((void**)&m->B, (size_t)n_items * m->ld * sizeof(float)) != hipSuccess) {
+    rphip_model_destroy(m);
+    RP_FAIL(RPHIP_ENOMEM, "hipMalloc of the dense matrix failed");
+  }
+  hipError_t e = hipMemcpy2DAsync(m->B, (size_t)m->ld * 4, B_host, (size_t)n_items * 4, (size_t)n_items * 4, (size_t)n_items,
+                                  hipMemcpyHostToDevice, ctx->stream);
+  if (e != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    rphip_model_destroy(m);
+    RP_FAIL(RPHIP_EHIP, "upload of the dense matrix failed");
+  }
+  int r = rp_dense_count_empty(ctx, m);
+  if (r != RPHIP_OK) {
+    rphip_model_destroy(m);
+    return r;
+  }
+  *out = m;
+  return RPHIP_OK;
 }
 
 extern "C" int rphip_model_dense_download(rphip_ctx* ctx, const rphip_model* m, float* B_host) {
-  (void)ctx; (void)m; (void)B_host;
-  RP_FAIL(RPHIP_ESTATE, "rphip_model_dense_download: the dense EASE path is not part of this build yet");
+  if (!ctx || !m || !B_host) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if (m->kind != RPHIP_MODEL_DENSE) RP_FAIL(RPHIP_ESTATE, "model is not dense");
+  RP_TRY(rp_set_device(ctx));
+  const size_t n = (size_t)m->n_items;
+  hipEvent_t ev;
+  rp_time_begin(ctx, &ev);
+  RP_HIP(hipMemcpy2DAsync(B_host, n * sizeof(float), m->B, (size_t)m->ld * sizeof(float), n * sizeof(float), n, hipMemcpyDeviceToHost,
+                          ctx->stream));
+  rp_time_end(ctx, ev, RPHIP_T_D2H, 4.0 * (double)n * (double)n);
+  RP_HIP(hipStreamSynchronize(ctx->stream));
+  return RPHIP_OK;
 }
 
 extern "C" int rphip_model_dense_device(const rphip_model* m, void** B_dev, int64_t* n_items, int64_t* ld) {
-  (void)m; (void)B_dev; (void)n_items; (void)ld;
-  RP_FAIL(RPHIP_ESTATE, "rphip_model_dense_device: the dense EASE path is not part of this build yet");
+  if (!m) RP_FAIL(RPHIP_EINVAL, "model is NULL");
+  if (m->kind != RPHIP_MODEL_DENSE) RP_FAIL(RPHIP_ESTATE, "model is not dense");
+  if (B_dev) *B_dev = m->B;
+  if (n_items) *n_items = m->n_items;
+  if (ld) *ld = m->ld;
+  return RPHIP_OK;
 }

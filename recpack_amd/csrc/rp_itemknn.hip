@@ -44,6 +44,9 @@ struct rp_fit_params {
   uint32_t* out_cnt;  // n_tiles > 1: candidate counts c_ij
   int32_t* out_nnz;   // [rows] or [rows*T]
   uint32_t* part;     // partial tiles [slot][tile_w]
+  float* dense;       // K4 (EASE): write the Gram row tile as f32 into dense[row*dense_ld + col] instead of selecting
+  long long dense_ld;
+  float diag_add;     // lambda, added on the diagonal of the dense Gram
   unsigned long long* stamps;  // diagnostic build only (-DRP_STAMPS): cycles per phase, summed over tasks
 };
 
@@ -210,6 +213,15 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit(rp_fit_params P)
       __syncthreads();
     }
 
+    if (P.dense) {
+      // ---- K4: dense Gram row (ease.py:81 `(X.T @ X).toarray()`), lambda fused on the diagonal
+      float* g = P.dense + (long long)row * P.dense_ld + t0;
+      for (int w = tid; w < n_cols; w += RP_FIT_THREADS) {
+        g[w] = (float)acc[w] + ((t0 + w == row) ? P.diag_add : 0.0f);
+        acc[w] = 0u;
+      }
+      continue;
+    }
     // ---- select
     rp_dense_src src{acc, P.inv_deg, t0, row, n_cols};
     const int kp = rp_select_topk<RP_FIT_THREADS>(src, n_cols, P.K, sel);
@@ -457,6 +469,12 @@ extern "C" int rphip_model_destroy(rphip_model* m) {
   return RPHIP_OK;
 }
 
+extern "C" int rphip_model_empty_rows(rphip_ctx* ctx, const rphip_model* m, int64_t* out) {
+  if (!ctx || !m || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *out = m->empty_rows;
+  return RPHIP_OK;
+}
+
 extern "C" int rphip_model_info(const rphip_model* m, int32_t* kind, int64_t* n_items, int64_t* row_begin, int64_t* row_end,
                                 int32_t* K) {
   if (!m) RP_FAIL(RPHIP_EINVAL, "model is NULL");
@@ -470,10 +488,11 @@ extern "C" int rphip_model_info(const rphip_model* m, int32_t* kind, int64_t* n_
 
 static size_t rp_fit_lds_bytes(int tile_w) { return (size_t)tile_w * 4 + rp_select_smem_bytes(tile_w); }
 
-extern "C" int rphip_itemknn_fit(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K,
-                                 rphip_model** out) {
-  if (!ctx || !X || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
-  *out = nullptr;
+// Shared driver of K1-K3 (out != NULL: neighbour lists) and K4 (dense != NULL: dense f32 Gram rows + lambda).
+static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K, rphip_model** out,
+                        float* dense, int64_t dense_ld, float diag_add) {
+  if (!ctx || !X || (!out && !dense)) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if (out) *out = nullptr;
   if (row_begin < 0 || row_end > X->n_items || row_begin > row_end)
     RP_FAIL(RPHIP_EINVAL, "row range [%lld,%lld) outside 0..%lld", (long long)row_begin, (long long)row_end, (long long)X->n_items);
   if (K < 1) RP_FAIL(RPHIP_EINVAL, "K must be >= 1 (got %d)", K);
@@ -487,13 +506,16 @@ extern "C" int rphip_itemknn_fit(rphip_ctx* ctx, const rphip_csr* X, int64_t row
   K = Keff;  // the model's row stride; rphip_model_info reports it
   if (T > 15) RP_FAIL(RPHIP_ELIMIT, "%d column tiles (n_items=%lld) exceed the supported 15", T, (long long)X->n_items);
   rphip_model* m = nullptr;
-  RP_TRY(rp_model_alloc_topk(ctx, X->n_items, row_begin, row_end, K, &m));
   hipStream_t st = ctx->stream;
-  const size_t nk = (size_t)std::max<int64_t>(1, (int64_t)n_rows * K);
-  hipMemsetAsync(m->idx, 0xFF, nk * sizeof(int32_t), st);
-  hipMemsetAsync(m->val, 0, nk * sizeof(double), st);
-  hipMemsetAsync(m->nnz, 0, (size_t)std::max(1, n_rows) * sizeof(int32_t), st);
+  if (!dense) {
+    RP_TRY(rp_model_alloc_topk(ctx, X->n_items, row_begin, row_end, K, &m));
+    const size_t nk = (size_t)std::max<int64_t>(1, (int64_t)n_rows * K);
+    hipMemsetAsync(m->idx, 0xFF, nk * sizeof(int32_t), st);
+    hipMemsetAsync(m->val, 0, nk * sizeof(double), st);
+    hipMemsetAsync(m->nnz, 0, (size_t)std::max(1, n_rows) * sizeof(int32_t), st);
+  }
   if (n_rows == 0 || X->nnz == 0) {
+    if (dense) return RPHIP_OK;  // rows without users keep what the caller initialised (zeros + lambda)
     int r = rp_model_finalize_topk(ctx, m);
     if (r != RPHIP_OK) {
       rphip_model_destroy(m);
@@ -555,7 +577,7 @@ extern "C" int rphip_itemknn_fit(rphip_ctx* ctx, const rphip_csr* X, int64_t row
   int32_t* cand_idx = nullptr;
   uint32_t* cand_cnt = nullptr;
   int32_t* cand_nnz = nullptr;
-  if (T > 1) {
+  if (T > 1 && !dense) {
     char* cb = nullptr;
     const size_t n_c = (size_t)n_rows * T * Keff;
     RP_TRY(rp_scratch(ctx, 2, n_c * 8 + (size_t)n_rows * T * 4 + 64, (void**)&cb));
@@ -579,6 +601,9 @@ extern "C" int rphip_itemknn_fit(rphip_ctx* ctx, const rphip_csr* X, int64_t row
   P.K = K;
   P.row_begin = (int)row_begin;
   P.part = part;
+  P.dense = dense;
+  P.dense_ld = dense_ld;
+  P.diag_add = diag_add;
   P.stamps = nullptr;
 #ifdef RP_STAMPS
   {
@@ -588,7 +613,12 @@ extern "C" int rphip_itemknn_fit(rphip_ctx* ctx, const rphip_csr* X, int64_t row
     hipMemsetAsync(sp, 0, 64 * 8, st);
   }
 #endif
-  if (T == 1) {
+  if (dense) {
+    P.out_idx = nullptr;
+    P.out_val = nullptr;
+    P.out_cnt = nullptr;
+    P.out_nnz = nullptr;
+  } else if (T == 1) {
     P.out_idx = m->idx;
     P.out_val = m->val;
     P.out_cnt = nullptr;
@@ -614,14 +644,15 @@ extern "C" int rphip_itemknn_fit(rphip_ctx* ctx, const rphip_csr* X, int64_t row
   // caller scales P by the shard's share, here the full-matrix figure is attributed when rows cover all.
   double work = 8.0 * (double)X->nnz + 4.0 * (double)(X->n_users + X->n_items + 2) + 8.0 * (double)n_rows * K;
   if (X->n_products >= 0) work += 4.0 * (double)X->n_products * ((double)n_rows / (double)X->n_items);
-  rp_time_end(ctx, ev, RPHIP_T_GRAM_TOPK, work);
+  if (dense) work = 2.0 * (double)(X->n_products >= 0 ? X->n_products : 0) * ((double)n_rows / (double)X->n_items) + 4.0 * (double)n_rows * (double)X->n_items;
+  rp_time_end(ctx, ev, dense ? RPHIP_T_GRAM_DENSE : RPHIP_T_GRAM_TOPK, work);
   rp_time_begin(ctx, &ev);
   P.tasks = fin_tasks;
   P.n_tasks = off_fin + n_rows;
   P.ticket = tickets + 1;
   hipLaunchKernelGGL(k_itemknn_fit<true>, dim3(grid), dim3(RP_FIT_THREADS), lds, st, P);
   RP_HIP(hipGetLastError());
-  rp_time_end(ctx, ev, RPHIP_T_GRAM_FINALIZE, 0.0);
+  rp_time_end(ctx, ev, dense ? RPHIP_T_GRAM_DENSE : RPHIP_T_GRAM_FINALIZE, 0.0);
 #ifdef RP_STAMPS
   {
     unsigned long long h[16];
@@ -632,6 +663,7 @@ extern "C" int rphip_itemknn_fit(rphip_ctx* ctx, const rphip_csr* X, int64_t row
   }
 #endif
 
+  if (dense) return RPHIP_OK;
   if (T > 1) {
     rp_time_begin(ctx, &ev);
     rp_merge_params M;
@@ -667,6 +699,17 @@ extern "C" int rphip_itemknn_fit(rphip_ctx* ctx, const rphip_csr* X, int64_t row
   }
   *out = m;
   return RPHIP_OK;
+}
+
+extern "C" int rphip_itemknn_fit(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K,
+                                 rphip_model** out) {
+  if (!out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  return rp_gram_core(ctx, X, row_begin, row_end, K, out, nullptr, 0, 0.0f);
+}
+
+int rp_gram_dense(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, float* G, int64_t ld, float diag_add) {
+  if (!G) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  return rp_gram_core(ctx, X, row_begin, row_end, 1, nullptr, G, ld, diag_add);
 }
 
 extern "C" int rphip_model_topk_download(rphip_ctx* ctx, const rphip_model* m, int32_t* idx_host, double* val_host,

@@ -24,6 +24,8 @@ struct rp_pred_params {
   const int32_t* s_idx;   // model: [I*K]
   const float* s_val;
   const int32_t* s_nnz;
+  const float* dense_B;   // K9: dense model (EASE), row-major with leading dimension dense_ld; NULL for neighbour lists
+  long long dense_ld;
   int n_items, n_tiles, tile_w, K, Kp, exclude_history;
   int user_begin, n_users;
   const int32_t* user_list;  // optional: local user ids to process (mode 0); count in *n_list
@@ -79,14 +81,36 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_sparse(rp_pred_para
       const int t0 = tile * W;
       const int n_cols = min(W, P.n_items - t0);
       // ---- accumulate
-      for (int h = hs + wave; h < he; h += NW) {
-        const int i = P.x_idx[h];
-        const int nn = P.s_nnz[i];
-        const int32_t* si = P.s_idx + (int64_t)i * K;
-        const float* sv = P.s_val + (int64_t)i * K;
-        for (int k = lane; k < nn; k += 64) {
-          const int j = si[k] - t0;
-          if ((unsigned)j < (unsigned)n_cols) atomicAdd(&acc[j], sv[k]);
+      if (P.dense_B) {
+        // K9: score[u, t0:t0+n_cols] = sum of the history items' rows of B; every thread owns CPT columns
+        // (registers, no atomics), rows are streamed coalesced
+        constexpr int CPT = (RP_TILE_MAX + RP_PRED_THREADS - 1) / RP_PRED_THREADS;
+        float r[CPT];
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) r[c] = 0.0f;
+        for (int h = hs; h < he; ++h) {
+          const float* Bi = P.dense_B + (long long)P.x_idx[h] * P.dense_ld + t0;
+#pragma unroll
+          for (int c = 0; c < CPT; ++c) {
+            const int w = tid + c * RP_PRED_THREADS;
+            if (w < n_cols) r[c] += Bi[w];
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+          const int w = tid + c * RP_PRED_THREADS;
+          if (w < n_cols) acc[w] = r[c];
+        }
+      } else {
+        for (int h = hs + wave; h < he; h += NW) {
+          const int i = P.x_idx[h];
+          const int nn = P.s_nnz[i];
+          const int32_t* si = P.s_idx + (int64_t)i * K;
+          const float* sv = P.s_val + (int64_t)i * K;
+          for (int k = lane; k < nn; k += 64) {
+            const int j = si[k] - t0;
+            if ((unsigned)j < (unsigned)n_cols) atomicAdd(&acc[j], sv[k]);
+          }
         }
       }
       __syncthreads();
@@ -414,7 +438,7 @@ int rp_model_finalize_topk(rphip_ctx* ctx, rphip_model* m) {
 // ---- host ------------------------------------------------------------------------------------------
 static int rp_pred_check(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* X, int64_t ub, int64_t ue) {
   if (!ctx || !model || !X) RP_FAIL(RPHIP_EINVAL, "NULL argument");
-  if (model->kind != RPHIP_MODEL_TOPK) RP_FAIL(RPHIP_ESTATE, "rp_predict_sparse needs a neighbour-list model");
+  if (model->kind != RPHIP_MODEL_TOPK && model->kind != RPHIP_MODEL_DENSE) RP_FAIL(RPHIP_ESTATE, "unknown model kind");
   if (model->row_begin != 0 || model->row_end != model->n_items)
     RP_FAIL(RPHIP_ESTATE, "the model holds rows [%lld,%lld) of %lld: assemble all rows before predict", (long long)model->row_begin,
             (long long)model->row_end, (long long)model->n_items);
@@ -430,6 +454,8 @@ static void rp_pred_fill(rp_pred_params& P, const rphip_model* m, const rphip_cs
   P.s_idx = m->idx;
   P.s_val = m->val32;
   P.s_nnz = m->nnz;
+  P.dense_B = (m->kind == RPHIP_MODEL_DENSE) ? m->B : nullptr;
+  P.dense_ld = m->ld;
   P.n_items = (int)X->n_items;
   P.n_tiles = X->n_tiles;
   P.tile_w = X->tile_w;
@@ -455,6 +481,8 @@ static size_t rp_pred_lds(int tile_w) { return (size_t)tile_w * 4 + rp_select_sm
 // algorithmic bytes of K8: 8*K*nnz_pred + 4*(nnz_pred+U) + 8*U*Kp
 static double rp_pred_work(const rphip_csr* X, const rphip_model* m, int64_t n_users, int Kp) {
   const double share = X->n_users > 0 ? (double)n_users / (double)X->n_users : 0.0;
+  if (m->kind == RPHIP_MODEL_DENSE)  // K9: 4*I*nnz_pred (rows of B streamed) + 8*U*Kp
+    return 4.0 * (double)m->n_items * (double)X->nnz * share + 8.0 * (double)n_users * Kp;
   return 8.0 * m->K * (double)X->nnz * share + 4.0 * ((double)X->nnz * share + (double)n_users) + 8.0 * (double)n_users * Kp;
 }
 
@@ -480,7 +508,7 @@ extern "C" int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, 
   // light users (history <= 64*PW_NB items) go to the wave-per-user kernel, the rest to the workgroup kernel
   // (measured: with one column tile the workgroup kernel is still faster - 8.0 vs 11.8 ms at 100K x 20K -, with
   // several tiles the wave kernel wins - 187 vs 347 ms at 1M x 100K)
-  const bool use_wave = T > 1 && model->cols_sorted && Kp <= PW_KP_MAX && (int64_t)model->n_items * model->K < (1ll << 31);
+  const bool use_wave = model->kind == RPHIP_MODEL_TOPK && T > 1 && model->cols_sorted && Kp <= PW_KP_MAX && (int64_t)model->n_items * model->K < (1ll << 31);
   int32_t* heavy_list = nullptr;
   int32_t* heavy_cnt = nullptr;
   hipEvent_t ev;

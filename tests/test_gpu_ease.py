@@ -1,0 +1,182 @@
+"""GPU parity: EASE fit (dense Gram, MFMA Cholesky/inverse, scaling) and dense predict through the C ABI.
+
+Bar (BASELINE.json north_star): EASE scores within 1e-4 relative in fp32.  Written here as
+  max|B - B_ref| <= 1e-4 * max|B_ref|   and   max|scores - scores_ref| <= 1e-4 * max|scores_ref|
+against the reference's float64 goldens and, at sizes without goldens, the float64 oracle.
+The fp32 MFMA GEMM itself is checked against float64 numpy at rtol 2e-5 (K = 512 fp32 accumulations).
+"""
+import warnings
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import csr_from, load_golden
+from oracle import oracle_np as onp
+from parity import tie_aware_topk
+
+pytestmark = pytest.mark.gpu
+
+EASE_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from recpack_amd import _lib, get_context
+
+    return _lib, get_context(0)
+
+
+def rel_max(a, b):
+    return float(np.abs(a - b).max() / max(1e-300, np.abs(b).max()))
+
+
+def test_gemm_nt_mfma(hip):
+    import torch
+
+    _lib, ctx = hip
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for (M, N, K) in [(128, 128, 16), (256, 384, 512), (128, 256, 2048)]:
+        A = torch.rand((M, K), generator=g) * 2 - 1
+        B = torch.rand((N, K), generator=g) * 2 - 1  # asymmetric operands
+        C0 = torch.rand((M, N), generator=g)
+        Ad, Bd, Cd = A.cuda(), B.cuda(), C0.clone().cuda()
+        _lib.gemm_nt(ctx, Ad, Bd, Cd, alpha=1.0, beta=0.0)
+        ctx.sync()
+        ref = A.double().numpy() @ B.double().numpy().T
+        np.testing.assert_allclose(Cd.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+        Cd = C0.clone().cuda()
+        _lib.gemm_nt(ctx, Ad, Bd, Cd, alpha=-0.5, beta=2.0)
+        ctx.sync()
+        ref2 = -0.5 * ref + 2.0 * C0.double().numpy()
+        np.testing.assert_allclose(Cd.cpu().numpy(), ref2, rtol=2e-5, atol=2e-5 * np.abs(ref2).max())
+    # A = I picks rows of an asymmetric B: catches a transposed C write
+    I = torch.eye(128).cuda()
+    Bd = (torch.arange(128 * 128, dtype=torch.float32).reshape(128, 128) / 1000).cuda()
+    Cd = torch.zeros((128, 128)).cuda()
+    _lib.gemm_nt(ctx, I, Bd, Cd)
+    ctx.sync()
+    np.testing.assert_array_equal(Cd.cpu().numpy(), Bd.cpu().numpy().T)
+
+
+def ease_B(hip, X, l2, alpha=0.0):
+    _lib, ctx = hip
+    from recpack_amd.algorithms import to_binary_csr
+
+    X = to_binary_csr(sp.csr_matrix(X))
+    dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
+    m = _lib.ease_fit(ctx, dX, l2, alpha)
+    return dX, m, m.dense_download()
+
+
+@pytest.mark.parametrize("name", ["ref_ease_data", "ref_ease_larger_matrix", "syn_ease_2000x500"])
+def test_ease_fit_golden(hip, name):
+    _lib, ctx = hip
+    g = load_golden(name)
+    X = csr_from(g, "X")
+    for n, (l2, alpha) in enumerate(zip(g["l2"], g["alpha"])):
+        dX, m, B = ease_B(hip, X, float(l2), float(alpha))
+        ref = g[f"B{n}"]
+        assert rel_max(B, ref) <= EASE_TOL, (name, l2, alpha, rel_max(B, ref))
+        assert (np.diag(B) == 0).all()
+        if "Pin_indptr" in g:
+            from recpack_amd.algorithms import to_binary_csr
+
+            Pin = to_binary_csr(csr_from(g, "Pin"))
+            dP = _lib.DeviceCSR.from_host(ctx, Pin.indptr, Pin.indices, Pin.shape)
+            ip, ind, dat = _lib.predict_full(ctx, m, dP)
+            out = sp.csr_matrix((dat, ind, ip), shape=Pin.shape).toarray()
+            assert rel_max(out, g[f"Pout{n}"]) <= EASE_TOL
+
+
+def test_ease_reference_test_cases(hip):
+    """recpack/tests/test_algorithms/test_ease.py:38-52, :66-87 through the drop-in class."""
+    from recpack_amd import EASE
+
+    g = load_golden("ref_ease_data")
+    data = csr_from(g, "X")
+    algo = EASE(l2=0.03).fit(data)
+    _in = sp.csr_matrix(([1, 1, 1], ([0, 1, 2], [0, 1, 2])), shape=(3, 3))
+    result = algo.predict(_in)
+    np.testing.assert_almost_equal(result[2, 0], 1, decimal=1)
+    np.testing.assert_almost_equal(result[0, 2], 1, decimal=1)
+    a1, a2, a3 = EASE(l2=0.03, alpha=1).fit(data), EASE(l2=0.03, alpha=0).fit(data), EASE(l2=0.03, alpha=2).fit(data)
+    np.testing.assert_almost_equal(a1.similarity_matrix_[1, 0], a2.similarity_matrix_[1, 0] / 4, decimal=6)
+    np.testing.assert_almost_equal(a1.similarity_matrix_[2, 1], a2.similarity_matrix_[2, 1], decimal=6)
+    np.testing.assert_almost_equal(a1.similarity_matrix_[1, 0] / 4, a3.similarity_matrix_[1, 0], decimal=6)
+    # known values of SURVEY.md §8(c)
+    np.testing.assert_allclose(algo.similarity_matrix_.toarray()[0], [0, 0.12453300125572914, 0.9901932783260373], rtol=1e-4)
+
+
+def test_ease_prune_dropin(hip):
+    # recpack/tests/test_algorithms/test_ease.py:90-105
+    from recpack_amd import EASE
+
+    g = load_golden("ref_ease_prune")
+    algo = EASE(l2=0.03, density=float(g["density"]))
+    algo.similarity_matrix_ = sp.csr_matrix(g["before"])
+    algo._prune()
+    np.testing.assert_allclose(algo.similarity_matrix_.toarray(), g["after"], rtol=1e-6)
+    S = algo.similarity_matrix_
+    np.testing.assert_almost_equal(S.nnz / (S.shape[0] * S.shape[1]), 2 / 9)
+
+
+@pytest.mark.parametrize("shape,l2,alpha,seed", [((20000, 3000, 0.004), 200.0, 0.0, 31), ((8000, 1100, 0.01), 5.0, 0.5, 32),
+                                                 ((4000, 700, 0.02), 0.5, 1.0, 33)])
+def test_ease_fit_synthetic_vs_oracle(hip, shape, l2, alpha, seed):
+    from recpack_amd.synth import powerlaw_csr
+
+    _lib, ctx = hip
+    X = powerlaw_csr(shape[0], shape[1], shape[2], seed=seed).to_scipy()
+    dX, m, B = ease_B(hip, X, l2, alpha)
+    ref = onp.ease_fit(X, l2, alpha)
+    err = rel_max(B, ref)
+    assert err <= EASE_TOL, err
+    # fused top-Kp on the dense model vs float64 scores (tie-aware, fp32 eps)
+    users = slice(0, 500)
+    scores = sp.csr_matrix(onp.predict_full(X[users], ref))
+    for excl in (False, True):
+        pi, pv, pn = _lib.predict_topk(ctx, m, dX, 50, exclude_history=excl, user_begin=0, user_end=500)
+        ridx, rval, rnnz = onp.topk_rows(scores, 50, exclude=X[users] if excl else None)
+        cand = scores
+        if excl:
+            cand = scores - scores.multiply(onp.binarize(X[users]))
+            cand.eliminate_zeros()
+        ref_sel = onp.topk_to_csr(ridx, rval, rnnz, X.shape[1])
+        smax = np.abs(scores.data).max()
+        # values: absolute 1e-4 of the largest score
+        lut = sp.csr_matrix(cand)
+        for r in range(0, 500, 25):
+            n = pn[r]
+            want = np.asarray(lut[r, pi[r, :n]].todense()).ravel()
+            assert np.abs(pv[r, :n] - want).max() <= EASE_TOL * smax
+        # sets: every selected score is within tolerance of the reference's K-th score or above it
+        for r in range(500):
+            n = pn[r]
+            assert n == rnnz[r]
+            if n == 0:
+                continue
+            t = rval[r, : rnnz[r]].min()
+            got = np.asarray(lut[r, pi[r, :n]].todense()).ravel()
+            assert (got >= t - 2 * EASE_TOL * smax).all()
+
+
+def test_ease_edge_cases(hip):
+    _lib, ctx = hip
+    from recpack_amd import EASE
+
+    # an item nobody interacted with: its row and column of B stay zero, a warning names it
+    X = sp.csr_matrix(([1, 1, 1, 1], ([0, 0, 1, 1], [0, 1, 0, 1])), shape=(3, 3))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        algo = EASE(l2=1.0).fit(X)
+        assert any("missing similar items for 1 items" in str(x.message) for x in w)
+    B = algo.similarity_matrix_.toarray()
+    assert (B[2] == 0).all() and (B[:, 2] == 0).all()
+    ref = onp.ease_fit(X, 1.0)
+    assert rel_max(B, ref) <= EASE_TOL
+    with pytest.raises(_lib.RecpackHipError):
+        EASE(l2=0.0).fit(X)
+    # users without history predict nothing
+    out = algo.predict(sp.csr_matrix((2, 3)))
+    assert out.nnz == 0
