@@ -134,31 +134,28 @@ __global__ void __launch_bounds__(1024) k_potrf_trtri(float* __restrict__ A, lon
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* a = reinterpret_cast<double*>(smem_raw);
   const int tid = threadIdx.x;
+  const int row = tid >> 3, part = tid & 7;  // 8 threads share one row's dot product
   for (int e = tid; e < GT * GT; e += 1024) {
     const int i = e / GT, k = e % GT;
     a[i * DS + k] = (k <= i) ? (double)A[(long long)i * lda + k] : 0.0;
   }
   __syncthreads();
-  // right-looking unblocked Cholesky
+  // left-looking column Cholesky: column j needs dot(a[i][0:j], a[j][0:j]) for every row i >= j
   for (int j = 0; j < GT; ++j) {
-    if (tid == 0) {
-      const double d = a[j * DS + j];
-      if (!(d > 0.0)) atomicExch(info, j + 1);
-      a[j * DS + j] = sqrt(d > 0.0 ? d : 1.0);
-    }
+    double t = 0.0;
+    if (row >= j)
+      for (int k = part; k < j; k += 8) t += a[row * DS + k] * a[j * DS + k];
+    t += __shfl_xor(t, 1);
+    t += __shfl_xor(t, 2);
+    t += __shfl_xor(t, 4);
     __syncthreads();
-    const double djj = a[j * DS + j];
-    for (int i = j + 1 + tid; i < GT; i += 1024) a[i * DS + j] /= djj;
+    if (part == 0 && row >= j) a[row * DS + j] -= t;
     __syncthreads();
-    // a[i][k] -= a[i][j] * a[k][j] for j < k <= i
-    const int m = GT - 1 - j;  // trailing size
-    for (int e = tid; e < m * m; e += 1024) {
-      const int ii = e / m, kk = e % m;
-      if (kk <= ii) {
-        const int i = j + 1 + ii, k = j + 1 + kk;
-        a[i * DS + k] -= a[i * DS + j] * a[k * DS + j];
-      }
-    }
+    const double d = a[j * DS + j];
+    if (tid == 0 && !(d > 0.0)) atomicExch(info, j + 1);
+    const double djj = sqrt(d > 0.0 ? d : 1.0);
+    __syncthreads();
+    if (part == 0 && row >= j) a[row * DS + j] = (row == j) ? djj : a[row * DS + j] / djj;
     __syncthreads();
   }
   for (int e = tid; e < GT * GT; e += 1024) {
@@ -166,22 +163,41 @@ __global__ void __launch_bounds__(1024) k_potrf_trtri(float* __restrict__ A, lon
     A[(long long)i * lda + k] = (k <= i) ? (float)a[i * DS + k] : 0.0f;
   }
   __syncthreads();
-  // in-place inverse of the lower-triangular factor (columns from last to first)
+  // in-place inverse of the lower-triangular factor, columns from last to first:
+  // x_ij = -(sum_{k=j+1..i} X_ik l_kj) / l_jj with X the already inverted trailing block
   for (int j = GT - 1; j >= 0; --j) {
     const double ajj = 1.0 / a[j * DS + j];
     double t = 0.0;
-    const int i = j + 1 + tid;
-    if (i < GT) {
-      for (int k = j + 1; k <= i; ++k) t += a[i * DS + k] * a[k * DS + j];
-    }
+    if (row > j)
+      for (int k = j + 1 + part; k <= row; k += 8) t += a[row * DS + k] * a[k * DS + j];
+    t += __shfl_xor(t, 1);
+    t += __shfl_xor(t, 2);
+    t += __shfl_xor(t, 4);
     __syncthreads();
-    if (i < GT) a[i * DS + j] = -t * ajj;
-    if (tid == 0) a[j * DS + j] = ajj;
+    if (part == 0) {
+      if (row > j) a[row * DS + j] = -t * ajj;
+      if (row == j) a[j * DS + j] = ajj;
+    }
     __syncthreads();
   }
   for (int e = tid; e < GT * GT; e += 1024) {
     const int i = e / GT, k = e % GT;
     W[i * GT + k] = (k <= i) ? (float)a[i * DS + k] : 0.0f;
+  }
+}
+
+// upper triangle of a symmetric matrix from its lower triangle, tile pair by tile pair
+__global__ void __launch_bounds__(256) k_mirror_lower(float* __restrict__ P, long long ld, int nb) {
+  __shared__ float t[32][33];
+  // 32x32 sub-tiles; blockIdx.x enumerates (bi, bj) with bj <= bi over a (nb32 x nb32) grid
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj > bi) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) t[r][tx] = P[(long long)(bi * 32 + r) * ld + bj * 32 + tx];
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bj * 32 + r, j = bi * 32 + tx;  // element (i, j) = P[j][i]
+    if (j > i) P[(long long)i * ld + j] = t[tx][r];
   }
 }
 
@@ -364,7 +380,7 @@ static int rp_spd_inverse(rphip_ctx* ctx, float* A, float* Nb, int n_pad, long l
       RP_TRY(rp_gemm_nt(ctx, h));
     }
   }
-  // ---- K6b: P = N N^T (every tile, K from max(row, column))
+  // ---- K6b: P = N N^T (lower tiles, K from max(row, column) = row), mirrored into the upper half
   {
     rp_gemm_args g{};
     g.A = Nb;
@@ -379,12 +395,14 @@ static int rp_spd_inverse(rphip_ctx* ctx, float* A, float* Nb, int n_pad, long l
     g.k1 = n_pad;
     g.kb_m = 1;
     g.kb_n = 1;
+    g.tri = 1;  // P is symmetric: lower tiles only, then mirrored
     g.alpha = 1.0f;
     g.beta = 0.0f;
     RP_TRY(rp_gemm_nt(ctx, g));
+    hipLaunchKernelGGL(k_mirror_lower, dim3(n_pad / 32, n_pad / 32), dim3(256), 0, st, A, ld, n_pad / 32);
   }
   RP_HIP(hipGetLastError());
-  rp_time_end(ctx, ev, RPHIP_T_INVERSE, n3);  // n^3/3 (N) + 2n^3/3 (full P)
+  rp_time_end(ctx, ev, RPHIP_T_INVERSE, 2.0 * n3 / 3.0);  // n^3/3 (N = L^-T) + n^3/3 (lower half of N N^T)
   int h_info = 0;
   RP_HIP(hipMemcpyAsync(&h_info, info, 4, hipMemcpyDeviceToHost, st));
   RP_HIP(hipStreamSynchronize(st));

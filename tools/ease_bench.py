@@ -1,0 +1,29 @@
+"""Time EASE fit (K4-K7) on a synthetic matrix: python tools/ease_bench.py <users> <items> <density> [l2]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.getcwd())
+import torch  # noqa: E402
+
+from recpack_amd import _lib  # noqa: E402
+from recpack_amd.synth import powerlaw_csr  # noqa: E402
+
+U, I, dens = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])
+l2 = float(sys.argv[4]) if len(sys.argv) > 4 else 200.0
+dev = torch.device("cuda", 0)
+ip, ix = powerlaw_csr(U, I, dens, seed=20260003, device=dev)
+ctx = _lib.Context(0)
+dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
+for it in range(2):
+    ctx.reset_timings()
+    t0 = time.perf_counter()
+    m = _lib.ease_fit(ctx, dX, l2, 0.0)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    tm = ctx.timings()
+    n_pad = (I + 127) // 128 * 128
+    chol, inv = tm["cholesky"], tm["inverse"]
+    print(f"I={I} nnz={ix.numel()} fit {dt*1e3:.1f} ms | gram_dense {tm['gram_dense']['ms']:.1f} ms | cholesky {chol['ms']:.1f} ms "
+          f"({chol['work']/chol['ms']/1e9:.1f} TF/s) | inverse {inv['ms']:.1f} ms ({inv['work']/inv['ms']/1e9:.1f} TF/s) | scale {tm['ease_scale']['ms']:.1f} ms | n^3 model {n_pad**3/((chol['ms']+inv['ms'])*1e9):.1f} TF/s")
+    del m
