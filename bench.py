@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--K", type=int, default=200)
     ap.add_argument("--Kp", type=int, default=100)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="0 disables the CPU leg")
+    ap.add_argument("--ease-config", default="C3", help="config of the EASE leg (N=1 only); 'none' disables it")
+    ap.add_argument("--l2", type=float, default=200.0)
     return ap.parse_args()
 
 
@@ -86,6 +88,63 @@ def cpu_baseline(indptr, indices, shape, K, Kp, S_csr, budget_s, P_total):
                    f"predict+top-{Kp} of {n_users} random users ({Xs.nnz / nnz:.3%} of nnz) {t_pred:.2f}s; "
                    f"scaled by P and nnz to fit {fit_full:.1f}s + predict {pred_full:.1f}s"),
         "host_cpus": os.cpu_count(),
+    }
+
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+
+
+def ease_leg(args, ctx, device, Kp):
+    """EASE fit + predict on its own config (BASELINE.json configs[2]: 200K x 50K, lambda = 200); the solve is
+    priced with the n^3 flop model of SURVEY.md §8(d) against the dense fp32 MFMA peak."""
+    import torch
+
+    from recpack_amd import _lib
+    from recpack_amd.synth import CONFIG_SEED_BASE, CONFIGS, powerlaw_csr
+
+    U, I, dens = CONFIGS[args.ease_config]
+    ip, ix = powerlaw_csr(U, I, dens, CONFIG_SEED_BASE + int(args.ease_config[1:]), device=device)
+    dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
+    out_idx = torch.empty((U, Kp), dtype=torch.int32, device=device)
+    out_val = torch.empty((U, Kp), dtype=torch.float32, device=device)
+    out_nnz = torch.empty((U,), dtype=torch.int32, device=device)
+    best = None
+    for it in range(2):
+        ctx.reset_timings()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model = _lib.ease_fit(ctx, dX, args.l2, 0.0)
+        torch.cuda.synchronize()
+        t_fit = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        _lib.predict_topk_dev(ctx, model, dX, Kp, out_idx, out_val, out_nnz)
+        torch.cuda.synchronize()
+        t_pred = time.perf_counter() - t0
+        tm = ctx.timings()
+        if best is None or t_fit + t_pred < best[0] + best[1]:
+            best = (t_fit, t_pred, tm)
+        del model
+    t_fit, t_pred, tm = best
+    n_pad = (I + 127) // 128 * 128
+    solve_ms = tm["cholesky"]["ms"] + tm["inverse"]["ms"]
+    tf = n_pad ** 3 / (solve_ms * 1e-3) / 1e12
+    return {
+        "workload": f"{args.ease_config}: EASE l2={args.l2}, {U} users x {I} items, nnz {int(ix.numel())}, predict + top-{Kp} for all users",
+        "fit_s": round(t_fit, 4),
+        "predict_s": round(t_pred, 4),
+        "fit_plus_predict_s": round(t_fit + t_pred, 4),
+        "phases_ms": {k: round(v["ms"], 3) for k, v in tm.items() if v["launches"]},
+        "roofline": {
+            "kernel": "k_gemm_nt (K5 Cholesky + K6 inverse, v_mfma_f32_32x32x2_f32)",
+            "bound": "mfma",
+            "achieved": round(tf, 2),
+            "peak": MFMA_F32_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+            "flops_model": "n^3 (Cholesky n^3/3 + inverse 2n^3/3), n padded to 128",
+            "solve_ms": round(solve_ms, 2),
+        },
+        "dtype": "f32 (MFMA f32 in / f32 accumulate), float64 diagonal blocks",
     }
 
 
@@ -222,6 +281,9 @@ def main():
             S = topk_arrays_to_csr(idx, val, nnz_rows, I)
             result["cpu_baseline"] = cpu_baseline(indptr_t.cpu().numpy(), indices_t.cpu().numpy(), (U, I), args.K, Kp, S,
                                                   args.cpu_baseline_seconds, P_total)
+        if world == 1 and args.ease_config.lower() != "none":
+            keep.clear()
+            result["ease"] = ease_leg(args, ctx, device, Kp)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -68,8 +68,9 @@ def allgather_topk(idx_local, val_local, nnz_local, parts: Sequence[Tuple[int, i
     outs = []
     for t, fill in ((idx_local, -1), (val_local, 0), (nnz_local, 0)):
         p = padded(t, fill)
-        g = torch.empty((world,) + tuple(p.shape), dtype=p.dtype, device=p.device)
-        dist.all_gather_into_tensor(g, p, group=group)
+        g = torch.empty((world * max_rows,) + tuple(p.shape[1:]), dtype=p.dtype, device=p.device)
+        dist.all_gather_into_tensor(g, p, group=group)  # concatenation along dim 0 (works for nccl and gloo)
+        g = g.view((world, max_rows) + tuple(p.shape[1:]))
         full = torch.empty((n_items,) + tuple(p.shape[1:]), dtype=p.dtype, device=p.device)
         for r, (rb, re) in enumerate(parts):
             full[rb:re] = g[r, : re - rb]

@@ -275,3 +275,41 @@ def test_predict_edge_cases(hip):
     assert top.nnz == 1 and top.indices[0] == 2
     top = algo.predict_topk(sp.csr_matrix(([1, 1], ([0, 0], [0, 2])), shape=(1, 3)), 3, exclude_history=True)
     assert top.indices.tolist() == [1]
+
+
+def test_sharded_fit_nccl_world1(hip):
+    """The N > 1 code path (torch views of the library's arrays, RCCL all-gather, model from device arrays) on one GPU."""
+    import torch
+    import torch.distributed as dist
+
+    from recpack_amd import dist as rdist
+    from recpack_amd.synth import powerlaw_csr
+
+    _lib, ctx = hip
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29571", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        X = powerlaw_csr(5000, 1200, 0.008, seed=77).to_scipy()
+        dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
+        parts = rdist.partition_by_cost(rdist.item_row_cost(dX.item_degrees(), X.nnz, dX.num_products()), 1)
+        full = rdist.fit_itemknn_sharded(ctx, dX, 40, parts, torch.device("cuda", 0))
+        idx, val, nnz = full.topk_download()
+        assert_same_as_oracle(idx, val, nnz, onp.itemknn_fit(X, 40))
+        pi, pv, pn = _lib.predict_topk(ctx, full, dX, 10, user_begin=0, user_end=200)
+        m2 = _lib.itemknn_fit(ctx, dX, 40)
+        qi, qv, qn = _lib.predict_topk(ctx, m2, dX, 10, user_begin=0, user_end=200)
+        np.testing.assert_array_equal(pi, qi)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gpu_generator_matches_numpy():
+    """bench.py builds its matrices with the torch backend on the GPU: same bits as the numpy generator."""
+    import torch
+
+    from recpack_amd.synth import powerlaw_csr
+
+    ref = powerlaw_csr(20000, 3000, 0.003, seed=5)
+    ip, ix = powerlaw_csr(20000, 3000, 0.003, seed=5, device=torch.device("cuda", 0))
+    np.testing.assert_array_equal(ip.cpu().numpy(), ref.indptr)
+    np.testing.assert_array_equal(ix.cpu().numpy(), ref.indices)
