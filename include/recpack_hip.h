@@ -62,6 +62,7 @@ enum {
   RPHIP_T_H2D = 9,
   RPHIP_T_D2H = 10,
   RPHIP_T_GRAM_FINALIZE = 11, /* second launch of K1-K3: sum of the partial tiles of sliced rows + top-K */
+  RPHIP_T_GRAM_TOPK_WAVE = 12, /* K1-K3 for rows with <= 255 users: 256-thread workgroups, byte counters */
   RPHIP_T_COUNT = 16
 };
 
@@ -83,6 +84,9 @@ int rphip_ctx_destroy(rphip_ctx* ctx);
 int rphip_ctx_sync(rphip_ctx* ctx);
 int rphip_get_timings(rphip_ctx* ctx, rphip_timings* out);
 int rphip_reset_timings(rphip_ctx* ctx);
+/* counters of the last rphip_itemknn_fit (int64[8]): [0] scalar products done by the light-row kernel,
+ * [1] its tasks (row, tile); the rest is reserved.  Used to split the SpGEMM's algorithmic bytes between its two kernels. */
+int rphip_get_counters(rphip_ctx* ctx, int64_t* out8);
 /* number of CUs, bytes of HBM, gfx arch string (into buf) */
 int rphip_device_info(rphip_ctx* ctx, int* n_cu, int64_t* hbm_bytes, char* arch_buf, int arch_buf_len);
 

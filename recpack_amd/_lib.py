@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "librecpack_hip.so")
 
 RPHIP_T_NAMES = [
     "csr_transpose", "fit_plan", "gram_topk", "topk_merge", "predict", "gram_dense", "cholesky", "inverse",
-    "ease_scale", "h2d", "d2h", "gram_finalize",
+    "ease_scale", "h2d", "d2h", "gram_finalize", "gram_topk_wave",
 ]
 RPHIP_T_COUNT = 16
 RPHIP_MODEL_TOPK = 1
@@ -60,6 +60,7 @@ PROTOTYPES = {
     "rphip_ctx_sync": (C.c_int, [_p]),
     "rphip_get_timings": (C.c_int, [_p, C.POINTER(Timings)]),
     "rphip_reset_timings": (C.c_int, [_p]),
+    "rphip_get_counters": (C.c_int, [_p, _p]),
     "rphip_device_info": (C.c_int, [_p, C.POINTER(C.c_int), C.POINTER(_i64), C.c_char_p, C.c_int]),
     "rphip_csr_from_host": (C.c_int, [_p, _i64, _i64, _i64, _p, C.c_int, _p, _pp]),
     "rphip_csr_from_device": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _pp]),
@@ -148,6 +149,11 @@ class Context:
         t = Timings()
         check(self.lib.rphip_get_timings(self.handle, C.byref(t)))
         return t.as_dict()
+
+    def counters(self) -> np.ndarray:
+        out = np.zeros(8, dtype=np.int64)
+        check(self.lib.rphip_get_counters(self.handle, _np_ptr(out)))
+        return out
 
     def reset_timings(self):
         check(self.lib.rphip_reset_timings(self.handle))

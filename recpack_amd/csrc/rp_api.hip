@@ -59,6 +59,10 @@ extern "C" int rphip_ctx_create(int device, void* stream, rphip_ctx** out) {
     c->own_stream = true;
   }
   memset(&c->tm, 0, sizeof(c->tm));
+  if (hipMalloc((void**)&c->dev_counters, 64) != hipSuccess || hipMemset(c->dev_counters, 0, 64) != hipSuccess) {
+    delete c;
+    RP_FAIL(RPHIP_ENOMEM, "hipMalloc of the counter block failed");
+  }
   *out = c;
   return RPHIP_OK;
 }
@@ -74,6 +78,7 @@ extern "C" int rphip_ctx_destroy(rphip_ctx* ctx) {
   for (auto e : ctx->ev_pool) hipEventDestroy(e);
   for (auto& b : ctx->scratch)
     if (b.p) hipFree(b.p);
+  if (ctx->dev_counters) hipFree(ctx->dev_counters);
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return RPHIP_OK;
@@ -158,6 +163,14 @@ extern "C" int rphip_get_timings(rphip_ctx* ctx, rphip_timings* out) {
   RP_TRY(rp_set_device(ctx));
   RP_TRY(rp_resolve_timings(ctx));
   *out = ctx->tm;
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_get_counters(rphip_ctx* ctx, int64_t* out8) {
+  if (!ctx || !out8) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  RP_TRY(rp_set_device(ctx));
+  RP_HIP(hipMemcpyAsync(out8, ctx->dev_counters, 64, hipMemcpyDeviceToHost, ctx->stream));
+  RP_HIP(hipStreamSynchronize(ctx->stream));
   return RPHIP_OK;
 }
 

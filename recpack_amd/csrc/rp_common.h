@@ -59,6 +59,7 @@ struct rphip_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   rphip_timings tm;
   rp_buf scratch[8];
+  unsigned long long* dev_counters = nullptr;  // 8 x u64 on the device: [0] products done by the wave fit kernel, [1] its rows
   // pending event pairs are resolved lazily (no sync inside *_dev calls)
   struct pending_t { hipEvent_t a, b; int slot; };
   std::vector<pending_t> pending;

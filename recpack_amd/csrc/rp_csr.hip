@@ -82,6 +82,17 @@ __global__ void k_tile_ptr(const int32_t* __restrict__ x_ptr, const int32_t* __r
   }
 }
 
+// 8 lanes per user: are the column indices of every row strictly increasing?
+__global__ void k_check_sorted(const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ x_idx, int n_users, int32_t* __restrict__ flag) {
+  const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, sub = threadIdx.x & 7;
+  const int ng = (gridDim.x * blockDim.x) >> 3;
+  for (int u = g; u < n_users; u += ng) {
+    const int s = x_ptr[u], e = x_ptr[u + 1];
+    for (int k = s + 1 + sub; k < e; k += 8)
+      if (x_idx[k] <= x_idx[k - 1]) *flag = 1;
+  }
+}
+
 int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
   hipStream_t st = ctx->stream;
   const int64_t U = m->n_users, I = m->n_items, nnz = m->nnz;
@@ -122,6 +133,9 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
     RP_HIP(hipMalloc((void**)&m->tile_ptr, (size_t)U * (m->n_tiles + 1) * sizeof(int32_t)));
     hipLaunchKernelGGL(k_tile_ptr, dim3(grid_u), dim3(bt), 0, st, m->x_ptr, m->x_idx, (int)U, m->n_tiles, m->tile_w, m->tile_ptr,
                        err);
+  } else if (nnz > 0) {
+    const int grid_c = (int)std::min<int64_t>((int64_t)ctx->n_cu * 16, std::max<int64_t>(1, rp_cdiv(U * 8, bt)));
+    hipLaunchKernelGGL(k_check_sorted, dim3(grid_c), dim3(bt), 0, st, m->x_ptr, m->x_idx, (int)U, err + 1);
   }
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, RPHIP_T_CSR_TRANSPOSE, 12.0 * (double)nnz + 4.0 * (double)(U + I + 2) + 4.0 * (double)(I + 1));
@@ -136,7 +150,7 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
     RP_FAIL(RPHIP_EUNSORTED, "n_items=%lld needs %d column tiles: column indices of every row must be strictly increasing",
             (long long)I, m->n_tiles);
   m->n_products = (int64_t)h.p;
-  m->sorted_rows = m->n_tiles > 1;
+  m->sorted_rows = (m->n_tiles > 1) || (h.err[1] == 0);  // several tiles: enforced above; one tile: checked
   return RPHIP_OK;
 }
 

@@ -44,6 +44,9 @@ struct rp_fit_params {
   uint32_t* out_cnt;  // n_tiles > 1: candidate counts c_ij
   int32_t* out_nnz;   // [rows] or [rows*T]
   uint32_t* part;     // partial tiles [slot][tile_w]
+  rp_task* spill_tasks;          // light kernel: tasks whose candidate list overflowed are appended here ...
+  int32_t* spill_count;          // ... (= the heavy kernel's task array and task count)
+  unsigned long long* n_products;  // light kernel: += scalar products (roofline split); may be NULL
   float* dense;       // K4 (EASE): write the Gram row tile as f32 into dense[row*dense_ld + col] instead of selecting
   long long dense_ld;
   float diag_add;     // lambda, added on the diagonal of the dense Gram
@@ -71,32 +74,49 @@ __device__ __forceinline__ uint64_t rp_fit_key(uint32_t c, double inv) {
   return (b - (992ull << 52)) << 6;
 }
 
+// accumulator tile: u32 counters (any row) or four byte counters per word (rows with <= 255 users: c_ij <= c_i)
+template <bool BYTES>
 struct rp_dense_src {
+  static constexpr bool PACK4 = BYTES;
   const uint32_t* acc;
   const double* inv_deg;
   int t0, row, n_cols;
-  __device__ __forceinline__ bool valid(int w) const { return acc[w] != 0u && (t0 + w) != row; }
-  __device__ __forceinline__ uint64_t key(int w) const { return rp_fit_key(acc[w], inv_deg[t0 + w]); }
+  __device__ __forceinline__ uint32_t word(int wi) const { return acc[wi]; }
+  __device__ __forceinline__ int excluded_slot() const { return row - t0; }
+  __device__ __forceinline__ uint32_t count(int w) const {
+    if (BYTES) return (acc[w >> 2] >> (8 * (w & 3))) & 255u;
+    return acc[w];
+  }
+  __device__ __forceinline__ bool valid(int w) const { return count(w) != 0u && (t0 + w) != row; }
+  __device__ __forceinline__ uint64_t key(int w) const { return rp_fit_key(count(w), inv_deg[t0 + w]); }
   __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)(t0 + w); }
 };
 
-// FINALIZE only gives the second launch (sum of partial tiles + select) its own name in profiles
-template <bool FINALIZE>
-__global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit(rp_fit_params P) {
+constexpr int RP_LIGHT_THREADS = 256;   // light rows: 4-wave workgroups, several per CU
+constexpr int RP_LIGHT_SEG = 1024;      // candidate-list entries per wave (4096 per task); overflow -> heavy kernel
+constexpr int RP_LIGHT_MAX_DEG = 255;   // byte counters
+
+// FINALIZE only gives the second launch (sum of partial tiles + select) its own name in profiles.
+// NTHR/BYTES: 1024 threads + u32 counters (one workgroup per CU) for heavy rows, 256 threads + byte counters
+// (three to four workgroups per CU) for rows with at most 255 users.
+template <bool FINALIZE, int NTHR, bool BYTES>
+__global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = NTHR / 64;
+  constexpr int SEG = BYTES ? RP_LIGHT_SEG : 0;
   uint32_t* acc = reinterpret_cast<uint32_t*>(smem);
-  rp_select_smem sel = rp_select_carve(smem + (size_t)P.tile_w * 4, P.tile_w);
+  const int W = P.tile_w;
+  const int acc_words = BYTES ? (W + 3) / 4 : W;
+  rp_select_smem sel = rp_select_carve(smem + (((size_t)acc_words * 4 + 15) & ~(size_t)15), W, NW, SEG);
   int* s_task = &sel.misc[RPS_USER];  // all LDS lives in the dynamic region (keeps its base 16-B aligned)
 #ifdef RP_STAMPS
   sel.stamps = P.stamps;
 #endif
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int NW = RP_FIT_THREADS / 64;
-  const int W = P.tile_w;
   const int T = P.n_tiles;
 
-  for (int w = tid; w < W; w += RP_FIT_THREADS) acc[w] = 0u;
+  for (int w = tid; w < acc_words; w += NTHR) acc[w] = 0u;
   const int n_tasks = *P.n_tasks;
 #ifdef RP_STAMPS
   unsigned long long t_last = __builtin_amdgcn_s_memtime();
@@ -121,7 +141,7 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit(rp_fit_params P)
       d[6] = 0;
     }
   };
-  if (tid == RP_FIT_THREADS - 64) fetch_task(0);
+  if (tid == NTHR - 64) fetch_task(0);
   int par = 0;
 
   while (true) {
@@ -136,7 +156,7 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit(rp_fit_params P)
     tk.slot = cur[4];
     tk.mode = cur[5];
     par ^= 1;
-    if (tid == RP_FIT_THREADS - 64) fetch_task(par);
+    if (tid == NTHR - 64) fetch_task(par);
     RP_STAMP(0);
     const int row = tk.row, tile = tk.tile;
     const int t0 = tile * W;
@@ -148,6 +168,7 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit(rp_fit_params P)
       // CH entries, and hands chunk c to lane c % 64: every lane then issues CH independent index loads
       // before the first LDS atomic, instead of one dependent load per user per round.
       constexpr int CH = 8;
+      int n_prod = 0;
       for (int base = tk.p_begin + wave * 64; base < tk.p_end; base += NW * 64) {
         const int p = base + lane;
         int s = 0, len = 0;
@@ -164,6 +185,7 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit(rp_fit_params P)
           }
           len = e - s;
         }
+        n_prod += len;
         const int nch = (len + CH - 1) / CH;
         int inc = nch;
 #pragma unroll
@@ -190,22 +212,32 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit(rp_fit_params P)
           for (int e = 0; e < CH; ++e) jv[e] = (e < n) ? src[e] : -1;
 #pragma unroll
           for (int e = 0; e < CH; ++e)
-            if (jv[e] >= 0) atomicAdd(&acc[jv[e] - t0], 1u);
+            if (jv[e] >= 0) {
+              const int j = jv[e] - t0;
+              if (BYTES)
+                atomicAdd(&acc[j >> 2], 1u << (8 * (j & 3)));
+              else
+                atomicAdd(&acc[j], 1u);
+            }
         }
+      }
+      if (BYTES && P.n_products) {  // products done by the light kernel (roofline split between the two kernels)
+        n_prod = rp_wave_sum(n_prod);
+        if (lane == 0 && n_prod) atomicAdd(P.n_products, (unsigned long long)n_prod);
       }
       __syncthreads();
       RP_STAMP(1);
-      if (tk.mode == 1) {
+      if (!BYTES && tk.mode == 1) {
         uint32_t* dst = P.part + (int64_t)tk.slot * W;
-        for (int w = tid; w < W; w += RP_FIT_THREADS) {
+        for (int w = tid; w < W; w += NTHR) {
           dst[w] = acc[w];
           acc[w] = 0u;
         }
         RP_STAMP(2);
         continue;
       }
-    } else {
-      for (int w = tid; w < W; w += RP_FIT_THREADS) {
+    } else if (!BYTES) {
+      for (int w = tid; w < W; w += NTHR) {
         uint32_t sum = 0;
         for (int sl = tk.p_begin; sl < tk.p_end; ++sl) sum += P.part[(int64_t)sl * W + w];
         acc[w] = sum;
@@ -213,47 +245,62 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit(rp_fit_params P)
       __syncthreads();
     }
 
-    if (P.dense) {
+    if (!BYTES && P.dense) {
       // ---- K4: dense Gram row (ease.py:81 `(X.T @ X).toarray()`), lambda fused on the diagonal
       float* g = P.dense + (long long)row * P.dense_ld + t0;
-      for (int w = tid; w < n_cols; w += RP_FIT_THREADS) {
+      for (int w = tid; w < n_cols; w += NTHR) {
         g[w] = (float)acc[w] + ((t0 + w == row) ? P.diag_add : 0.0f);
         acc[w] = 0u;
       }
       continue;
     }
     // ---- select
-    rp_dense_src src{acc, P.inv_deg, t0, row, n_cols};
-    const int kp = rp_select_topk<RP_FIT_THREADS>(src, n_cols, P.K, sel);
+    rp_dense_src<BYTES> src{acc, P.inv_deg, t0, row, n_cols};
+    const int kp = rp_select_topk<NTHR>(src, n_cols, P.K, sel, SEG);
     RP_STAMP(3);
+    if (BYTES && kp < 0) {
+      // more candidates than the list holds: hand the task to the heavy kernel (it runs after this one)
+      if (tid == 0) {
+        const int pos = atomicAdd(P.spill_count, 1);
+        rp_task t2 = tk;
+        t2.mode = 0;
+        P.spill_tasks[pos] = t2;
+      }
+      __syncthreads();
+      for (int w = tid; w < acc_words; w += NTHR) acc[w] = 0u;
+      continue;
+    }
     const int rl = row - P.row_begin;
     if (T == 1) {
       int32_t* oi = P.out_idx + (int64_t)rl * P.K;
       double* ov = P.out_val + (int64_t)rl * P.K;
       const double ci = (double)P.deg[row];
-      rp_select_emit<RP_FIT_THREADS>(n_cols, sel, [&](int pos, int w) {
+      rp_select_emit<NTHR>(n_cols, sel, [&](int pos, int w) {
         const int j = t0 + w;
         oi[pos] = j;
-        ov[pos] = (double)acc[w] / sqrt(ci * (double)P.deg[j]);
-      });
+        ov[pos] = (double)src.count(w) / sqrt(ci * (double)P.deg[j]);
+      }, SEG);
       if (tid == 0) P.out_nnz[rl] = kp;
     } else {
       const int64_t o = ((int64_t)rl * T + tile) * P.K;
-      rp_select_emit<RP_FIT_THREADS>(n_cols, sel, [&](int pos, int w) {
+      rp_select_emit<NTHR>(n_cols, sel, [&](int pos, int w) {
         P.out_idx[o + pos] = t0 + w;
-        P.out_cnt[o + pos] = acc[w];
-      });
+        P.out_cnt[o + pos] = src.count(w);
+      }, SEG);
       if (tid == 0) P.out_nnz[(int64_t)rl * T + tile] = kp;
     }
-    // clear only what was touched: the candidates (every wave its own list segment) and the diagonal
-    rp_select_foreach<RP_FIT_THREADS>(n_cols, sel, [&](int w) { acc[w] = 0u; });
-    if (tid == 0 && (unsigned)(row - t0) < (unsigned)n_cols) acc[row - t0] = 0u;
+    // clear only what was touched: the candidates (every wave its own list segment) and the diagonal.
+    // Byte tiles: the emit above still reads neighbouring bytes of a word, so clear after a barrier.
+    if (BYTES) __syncthreads();
+    rp_select_foreach<NTHR>(n_cols, sel, [&](int w) { acc[BYTES ? (w >> 2) : w] = 0u; }, SEG);
+    if (tid == 0 && (unsigned)(row - t0) < (unsigned)n_cols) acc[BYTES ? ((row - t0) >> 2) : (row - t0)] = 0u;
     RP_STAMP(4);
   }
 }
 
 // ---- merge of per-tile candidates (n_tiles > 1) ---------------------------------------------------
 struct rp_list_src {
+  static constexpr bool PACK4 = false;
   const int32_t* col_;
   const uint32_t* cnt_;
   const double* inv_deg;
@@ -363,13 +410,15 @@ __global__ void k_plan_scatter(const int32_t* __restrict__ deg, int row_begin, i
 
 // per ordered row: number of accumulate tasks, finalize tasks and partial slots
 __global__ void k_plan_count(const int32_t* __restrict__ deg, const int32_t* __restrict__ order, int n_rows, int n_tiles,
-                             int slice_users, int heavy_thr, int32_t* __restrict__ n_acc, int32_t* __restrict__ n_fin,
-                             int32_t* __restrict__ n_slot) {
+                             int slice_users, int heavy_thr, int light_max, int32_t* __restrict__ n_acc, int32_t* __restrict__ n_fin,
+                             int32_t* __restrict__ n_slot, int32_t* __restrict__ n_light) {
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_rows; k += gridDim.x * blockDim.x) {
     const int d = deg[order[k]];
-    int a = 0, f = 0, s = 0;
+    int a = 0, f = 0, s = 0, l = 0;
     if (d > 0) {
-      if (d > heavy_thr) {
+      if (d <= light_max) {
+        l = n_tiles;  // light kernel: one task per column tile
+      } else if (d > heavy_thr) {
         const int ns = (d + slice_users - 1) / slice_users;
         a = ns * n_tiles;
         f = n_tiles;
@@ -381,17 +430,33 @@ __global__ void k_plan_count(const int32_t* __restrict__ deg, const int32_t* __r
     n_acc[k] = a;
     n_fin[k] = f;
     n_slot[k] = s;
+    n_light[k] = l;
   }
 }
 
 __global__ void k_plan_write(const int32_t* __restrict__ deg, const int32_t* __restrict__ xt_ptr, const int32_t* __restrict__ order,
-                             int n_rows, int n_tiles, int slice_users, int heavy_thr, const int32_t* __restrict__ off_acc,
-                             const int32_t* __restrict__ off_fin, const int32_t* __restrict__ off_slot,
-                             rp_task* __restrict__ acc_tasks, rp_task* __restrict__ fin_tasks) {
+                             int n_rows, int n_tiles, int slice_users, int heavy_thr, int light_max,
+                             const int32_t* __restrict__ off_acc, const int32_t* __restrict__ off_fin,
+                             const int32_t* __restrict__ off_slot, const int32_t* __restrict__ off_light,
+                             rp_task* __restrict__ acc_tasks, rp_task* __restrict__ fin_tasks, rp_task* __restrict__ light_tasks) {
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_rows; k += gridDim.x * blockDim.x) {
     const int row = order[k];
     const int d = deg[row];
     if (d <= 0) continue;
+    if (d <= light_max) {
+      int ol = off_light[k];
+      for (int t = 0; t < n_tiles; ++t) {
+        rp_task tk;
+        tk.row = row;
+        tk.tile = t;
+        tk.p_begin = xt_ptr[row];
+        tk.p_end = xt_ptr[row] + d;
+        tk.slot = -1;
+        tk.mode = 0;
+        light_tasks[ol++] = tk;
+      }
+      continue;
+    }
     const int p0 = xt_ptr[row];
     int oa = off_acc[k];
     if (d > heavy_thr) {
@@ -535,8 +600,13 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   const int64_t max_acc = (int64_t)n_rows * T + max_slices;
   const int64_t max_fin = std::min<int64_t>((int64_t)n_rows, X->nnz / heavy_thr + 1) * T;
   char* sc = nullptr;
-  const size_t plan_bytes = (size_t)PLAN_BUCKETS * 4 + (size_t)n_rows * 4 * 4 + (size_t)(n_rows + 1) * 4 * 3 + 64 +
-                            (size_t)(max_acc + max_fin) * sizeof(rp_task) + 256;
+  // light rows (<= 255 users): 256-thread workgroups with byte counters, several per CU; a task whose candidate
+  // list overflows is appended to the heavy kernel's task array, which therefore has room for all of them
+  const bool use_light = !dense;
+  const int light_max = use_light ? RP_LIGHT_MAX_DEG : 0;
+  const int64_t max_light = use_light ? (int64_t)n_rows * T : 0;
+  const size_t plan_bytes = (size_t)PLAN_BUCKETS * 4 + (size_t)n_rows * 4 * 5 + (size_t)(n_rows + 1) * 4 * 4 + 64 +
+                            (size_t)(max_acc + max_light + max_fin + max_light) * sizeof(rp_task) + 512;
   RP_TRY(rp_scratch(ctx, 0, plan_bytes, (void**)&sc));
   size_t o = 0;
   auto carve = [&](size_t bytes) {
@@ -552,22 +622,26 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   int32_t* off_acc = (int32_t*)carve((size_t)(n_rows + 1) * 4);
   int32_t* off_fin = (int32_t*)carve((size_t)(n_rows + 1) * 4);
   int32_t* off_slot = (int32_t*)carve((size_t)(n_rows + 1) * 4);
+  int32_t* n_light = (int32_t*)carve((size_t)n_rows * 4);
+  int32_t* off_light = (int32_t*)carve((size_t)(n_rows + 1) * 4);
   int32_t* tickets = (int32_t*)carve(16);
-  rp_task* acc_tasks = (rp_task*)carve((size_t)max_acc * sizeof(rp_task));
+  rp_task* acc_tasks = (rp_task*)carve((size_t)(max_acc + max_light) * sizeof(rp_task));
   rp_task* fin_tasks = (rp_task*)carve((size_t)max_fin * sizeof(rp_task));
+  rp_task* light_tasks = (rp_task*)carve((size_t)std::max<int64_t>(1, max_light) * sizeof(rp_task));
   hipMemsetAsync(bucket, 0, PLAN_BUCKETS * 4, st);
   hipMemsetAsync(tickets, 0, 16, st);
   const int pb = 256, pg = (int)std::min<int64_t>(1024, rp_cdiv(n_rows, pb));
   hipLaunchKernelGGL(k_plan_hist, dim3(pg), dim3(pb), 0, st, X->deg, (int)row_begin, n_rows, bucket);
   hipLaunchKernelGGL(k_plan_offsets, dim3(1), dim3(64), 0, st, bucket);
   hipLaunchKernelGGL(k_plan_scatter, dim3(pg), dim3(pb), 0, st, X->deg, (int)row_begin, n_rows, bucket, order);
-  hipLaunchKernelGGL(k_plan_count, dim3(pg), dim3(pb), 0, st, X->deg, order, n_rows, T, slice_users, heavy_thr, n_acc, n_fin,
-                     n_slot);
+  hipLaunchKernelGGL(k_plan_count, dim3(pg), dim3(pb), 0, st, X->deg, order, n_rows, T, slice_users, heavy_thr, light_max, n_acc,
+                     n_fin, n_slot, n_light);
   RP_TRY(rp_exclusive_scan_i32(ctx, n_acc, off_acc, n_rows));
   RP_TRY(rp_exclusive_scan_i32(ctx, n_fin, off_fin, n_rows));
   RP_TRY(rp_exclusive_scan_i32(ctx, n_slot, off_slot, n_rows));
-  hipLaunchKernelGGL(k_plan_write, dim3(pg), dim3(pb), 0, st, X->deg, X->xt_ptr, order, n_rows, T, slice_users, heavy_thr,
-                     off_acc, off_fin, off_slot, acc_tasks, fin_tasks);
+  RP_TRY(rp_exclusive_scan_i32(ctx, n_light, off_light, n_rows));
+  hipLaunchKernelGGL(k_plan_write, dim3(pg), dim3(pb), 0, st, X->deg, X->xt_ptr, order, n_rows, T, slice_users, heavy_thr, light_max,
+                     off_acc, off_fin, off_slot, off_light, acc_tasks, fin_tasks, light_tasks);
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, RPHIP_T_FIT_PLAN, 0.0);
 
@@ -629,16 +703,47 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
     P.out_cnt = cand_cnt;
     P.out_nnz = cand_nnz;
   }
+  P.spill_tasks = acc_tasks;
+  P.spill_count = off_acc + n_rows;
+  P.n_products = nullptr;
   const size_t lds = rp_fit_lds_bytes(W);
-  RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_fit<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_fit<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_fit<false, RP_FIT_THREADS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_fit<true, RP_FIT_THREADS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = ctx->n_cu;
+
+  if (use_light) {
+    // ---- light rows first: their overflow tasks join the heavy kernel's list
+    const size_t llds = (((size_t)W + 15) & ~(size_t)15) + rp_select_smem_bytes(W, RP_LIGHT_THREADS / 64, RP_LIGHT_SEG);
+    RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_fit<false, RP_LIGHT_THREADS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
+    const int per_cu = std::max<int>(1, std::min<int>(8, (int)((160 * 1024) / llds)));
+    RP_HIP(hipMemsetAsync(ctx->dev_counters, 0, 64, st));
+    RP_HIP(hipMemcpyAsync(ctx->dev_counters + 1, off_light + n_rows, 4, hipMemcpyDeviceToDevice, st));
+    rp_fit_params L = P;
+    L.tasks = light_tasks;
+    L.n_tasks = off_light + n_rows;
+    L.ticket = tickets + 2;
+    L.n_products = ctx->dev_counters;
+    rp_time_begin(ctx, &ev);
+    hipLaunchKernelGGL((k_itemknn_fit<false, RP_LIGHT_THREADS, true>), dim3(ctx->n_cu * per_cu), dim3(RP_LIGHT_THREADS), llds, st, L);
+    RP_HIP(hipGetLastError());
+    rp_time_end(ctx, ev, RPHIP_T_GRAM_TOPK_WAVE, 0.0);
+#ifdef RP_STAMPS
+    {
+      unsigned long long h[16];
+      hipMemcpyAsync(h, P.stamps, sizeof(h), hipMemcpyDeviceToHost, st);
+      hipStreamSynchronize(st);
+      fprintf(stderr, "[stamps light] cycles/1e6: ticket %.1f accumulate %.1f select %.1f emit+clear %.1f | sel: compact %.1f levels %.1f sort %.1f pred %.1f\n",
+              h[0] / 1e6, h[1] / 1e6, h[3] / 1e6, h[4] / 1e6, h[8] / 1e6, h[9] / 1e6, h[10] / 1e6, h[11] / 1e6);
+      hipMemsetAsync(P.stamps, 0, 64 * 8, st);
+    }
+#endif
+  }
 
   rp_time_begin(ctx, &ev);
   P.tasks = acc_tasks;
   P.n_tasks = off_acc + n_rows;
   P.ticket = tickets;
-  hipLaunchKernelGGL(k_itemknn_fit<false>, dim3(grid), dim3(RP_FIT_THREADS), lds, st, P);
+  hipLaunchKernelGGL((k_itemknn_fit<false, RP_FIT_THREADS, false>), dim3(grid), dim3(RP_FIT_THREADS), lds, st, P);
   RP_HIP(hipGetLastError());
   // algorithmic bytes of the SpGEMM: 4*P_shard + 8*nnz + 4*(U+I+2) + 8*rows*K; the
   // caller scales P by the shard's share, here the full-matrix figure is attributed when rows cover all.
@@ -650,7 +755,7 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   P.tasks = fin_tasks;
   P.n_tasks = off_fin + n_rows;
   P.ticket = tickets + 1;
-  hipLaunchKernelGGL(k_itemknn_fit<true>, dim3(grid), dim3(RP_FIT_THREADS), lds, st, P);
+  hipLaunchKernelGGL((k_itemknn_fit<true, RP_FIT_THREADS, false>), dim3(grid), dim3(RP_FIT_THREADS), lds, st, P);
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, dense ? RPHIP_T_GRAM_DENSE : RPHIP_T_GRAM_FINALIZE, 0.0);
 #ifdef RP_STAMPS

@@ -41,6 +41,7 @@ struct rp_pred_params {
 };
 
 struct rp_score_src {
+  static constexpr bool PACK4 = false;
   const float* acc;
   int t0;
   __device__ __forceinline__ bool valid(int w) const { return acc[w] != 0.0f; }
@@ -149,6 +150,7 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_sparse(rp_pred_para
 
 // ---- merge of per-tile top-Kp candidates -----------------------------------------------------------
 struct rp_flist_src {
+  static constexpr bool PACK4 = false;
   const int32_t* col_;
   const float* val_;
   int n;

@@ -53,19 +53,21 @@ __host__ __device__ constexpr int rp_per_wave(int n_slots, int nwaves) {
 }
 __host__ __device__ constexpr int rp_list_cap(int n_slots, int nwaves) { return rp_per_wave(n_slots, nwaves) * nwaves; }
 
-// bytes of LDS the selection needs besides the tile itself (nwaves = threads / 64)
-__host__ __device__ constexpr size_t rp_select_smem_bytes(int n_slots, int nwaves = 16) {
-  return (size_t)RP_HIST_BINS * 4 + (size_t)rp_list_cap(n_slots, nwaves) * 2 + RPS_MISC_INTS * 4;
+// bytes of LDS the selection needs besides the tile itself (nwaves = threads / 64).  seg_cap = list entries per
+// wave; 0 = enough for every slot of the wave's share (no overflow possible).
+__host__ __device__ constexpr size_t rp_select_smem_bytes(int n_slots, int nwaves = 16, int seg_cap = 0) {
+  return (size_t)RP_HIST_BINS * 4 + (size_t)(seg_cap ? seg_cap * nwaves : rp_list_cap(n_slots, nwaves)) * 2 + RPS_MISC_INTS * 4;
 }
 
-__device__ __forceinline__ rp_select_smem rp_select_carve(char* base, int n_slots, int nwaves = 16) {
+__device__ __forceinline__ rp_select_smem rp_select_carve(char* base, int n_slots, int nwaves = 16, int seg_cap = 0) {
   static_assert(RP_SORT_CAP * 12 <= RP_HIST_BINS * 4, "sort buffers overlay the histogram");
+  const size_t list_entries = seg_cap ? (size_t)seg_cap * nwaves : (size_t)rp_list_cap(n_slots, nwaves);
   rp_select_smem s;
   s.hist = reinterpret_cast<uint32_t*>(base);
   s.skey = reinterpret_cast<uint64_t*>(base);
   s.scol = reinterpret_cast<uint32_t*>(base + (size_t)RP_SORT_CAP * 8);
   s.list = reinterpret_cast<uint16_t*>(base + (size_t)RP_HIST_BINS * 4);
-  s.misc = reinterpret_cast<int*>(base + (size_t)RP_HIST_BINS * 4 + (size_t)rp_list_cap(n_slots, nwaves) * 2);
+  s.misc = reinterpret_cast<int*>(base + (size_t)RP_HIST_BINS * 4 + list_entries * 2);
 #ifdef RP_STAMPS
   s.stamps = nullptr;
 #endif
@@ -110,16 +112,19 @@ enum {
   RPS_ABOVE = 2,
   RPS_CNT = 3,
   RPS_GROUP = 4,
+  RPS_TK = 8,     // 8..10: threshold handed from the ranking wave to the workgroup
   RPS_WOFF = 16,  // 16..31: exclusive offset of wave w's selected entries
   RPS_RED = 32,   // 32..47: scratch for reductions over waves
   RPS_LCNT = 48,  // 48..63: candidates in wave w's list segment
   RPS_USER = 64   // 64..95: the caller's
 };
 
-// Returns K' (number of selected entries).  Afterwards the list holds the candidates of every wave segment
-// (RPS_LCNT + w entries), selected ones flagged with RPS_FLAG; use rp_select_emit / rp_select_foreach.
+// Returns K' (number of selected entries), or -1 when a wave found more candidates than its list segment holds
+// (seg_cap > 0 only; nothing is selected then and the caller must clear the tile densely).  Afterwards the list
+// holds the candidates of every wave segment (RPS_LCNT + w entries), selected ones flagged with RPS_FLAG; use
+// rp_select_emit / rp_select_foreach with the same seg_cap.
 template <int NTHR, class Src>
-__device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem s) {
+__device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem s, int seg_cap = 0) {
   static_assert(RP_HIST_BINS % NTHR == 0, "bins must divide over the threads");
   constexpr int BPT = RP_HIST_BINS / NTHR;  // histogram bins owned by one thread
   constexpr int NW = NTHR / 64;
@@ -129,28 +134,75 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
   const int w_begin = wave * per_wave;
   const int w_end = min(n_slots, w_begin + per_wave);
   const uint64_t lt_mask = (1ull << lane) - 1ull;
-  uint16_t* mylist = s.list + w_begin;
+  const int seg = seg_cap ? seg_cap : per_wave;
+  uint16_t* mylist = s.list + wave * seg;
 
 #ifdef RP_STAMPS
   unsigned long long ts_last = __builtin_amdgcn_s_memtime();
 #endif
   // ---- 1. compaction
   int cnt = 0;
-  for (int b = w_begin; b < w_end; b += 64) {
-    const int slot = b + lane;
-    const bool v = (slot < w_end) && src.valid(slot);
-    const uint64_t m = __ballot(v);
-    if (v) mylist[cnt + __popcll(m & lt_mask)] = (uint16_t)slot;
-    cnt += __popcll(m);
+  bool over = false;
+  if constexpr (Src::PACK4) {
+    // byte tiles: one u32 word (four slots) per lane and step; positions keep the column order
+    // (lane-major, byte-minor) from four ballots - no prefix scan
+    const int excl = src.excluded_slot();
+    for (int wb = w_begin >> 2; wb * 4 < w_end; wb += 64) {
+      const int wi = wb + lane;
+      const int s0 = wi * 4;
+      const uint32_t w = (s0 < w_end) ? src.word(wi) : 0u;
+      bool v[4];
+      uint64_t m[4];
+      int add = 0, below = 0, own = 0;
+#pragma unroll
+      for (int by = 0; by < 4; ++by) {
+        v[by] = ((w >> (8 * by)) & 255u) != 0u && (s0 + by) < w_end && (s0 + by) != excl;
+        m[by] = __ballot(v[by]);
+        add += __popcll(m[by]);
+        below += __popcll(m[by] & lt_mask);
+      }
+      if (cnt + add > seg) {
+        over = true;
+        break;
+      }
+#pragma unroll
+      for (int by = 0; by < 4; ++by) {
+        if (v[by]) mylist[cnt + below + own] = (uint16_t)(s0 + by);
+        own += v[by] ? 1 : 0;
+      }
+      cnt += add;
+    }
+  } else {
+    for (int b = w_begin; b < w_end; b += 64) {
+      const int slot = b + lane;
+      const bool v = (slot < w_end) && src.valid(slot);
+      const uint64_t m = __ballot(v);
+      const int add = __popcll(m);
+      if (cnt + add > seg) {
+        over = true;
+        break;
+      }
+      if (v) mylist[cnt + __popcll(m & lt_mask)] = (uint16_t)slot;
+      cnt += add;
+    }
   }
   if (lane == 0) {
-    s.misc[RPS_RED + wave] = cnt;
-    s.misc[RPS_LCNT + wave] = cnt;
+    s.misc[RPS_RED + wave] = over ? -1 : cnt;
+    s.misc[RPS_LCNT + wave] = over ? 0 : cnt;
   }
   __syncthreads();
   int n_valid = 0;
+  bool any_over = false;
 #pragma unroll
-  for (int w = 0; w < NW; ++w) n_valid += s.misc[RPS_RED + w];
+  for (int w = 0; w < NW; ++w) {
+    const int c = s.misc[RPS_RED + w];
+    any_over |= (c < 0);
+    n_valid += c;
+  }
+  if (any_over) {
+    __syncthreads();
+    return -1;
+  }
   const int kprime = min(K, n_valid);
   __syncthreads();
   RPS_STAMP(8);
@@ -172,21 +224,36 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
         s.misc[RPS_CNT] = 0;
       }
       __syncthreads();
-      // histogram of this level's digit over the undecided group
-      for (int e = lane; e < cnt; e += 64) {
-        const int slot = mylist[e];
-        const uint64_t k = src.key(slot);
-        const uint32_t ic = ~src.col(slot);
-        bool in_group;
-        uint32_t d;
-        if (!is_col) {
-          in_group = (level == 0) || ((k >> (shift + width)) == (pkey >> (shift + width)));
-          d = (uint32_t)(k >> shift) & (nb - 1);
-        } else {
-          in_group = (k == pkey) && ((level == 6) || ((ic >> (shift + width)) == (pcol >> (shift + width))));
-          d = (ic >> shift) & (nb - 1);
+      // histogram of this level's digit over the undecided group (4 candidates per lane in flight:
+      // the key needs a global gather)
+      for (int e0 = 0; e0 < cnt; e0 += 256) {
+        int sl[4];
+        bool ok[4];
+        uint64_t kk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + u * 64 + lane;
+          ok[u] = e < cnt;
+          sl[u] = ok[u] ? (int)mylist[e] : 0;
         }
-        if (in_group) atomicAdd(&s.hist[d], 1u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kk[u] = ok[u] ? src.key(sl[u]) : 0ull;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (!ok[u]) continue;
+          const uint64_t k = kk[u];
+          const uint32_t ic = ~src.col(sl[u]);
+          bool in_group;
+          uint32_t d;
+          if (!is_col) {
+            in_group = (level == 0) || ((k >> (shift + width)) == (pkey >> (shift + width)));
+            d = (uint32_t)(k >> shift) & (nb - 1);
+          } else {
+            in_group = (k == pkey) && ((level == 6) || ((ic >> (shift + width)) == (pcol >> (shift + width))));
+            d = (ic >> shift) & (nb - 1);
+          }
+          if (in_group) atomicAdd(&s.hist[d], 1u);
+        }
       }
       __syncthreads();
       // find the bin where the count from the top reaches `need`: thread t owns BPT bins, descending
@@ -239,22 +306,66 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
         // exact: gather the group, sort descending, read the need-th
         __syncthreads();  // hist is dead from here (skey overlays it)
         RPS_STAMP(9);
-        for (int e = lane; e < cnt; e += 64) {
-          const int slot = mylist[e];
-          const uint64_t k = src.key(slot);
-          const uint32_t ic = ~src.col(slot);
-          bool in_group;
-          if (!is_col)
-            in_group = (k >> shift) == (pkey >> shift);
-          else
-            in_group = (k == pkey) && ((ic >> shift) == (pcol >> shift));
-          if (in_group) {
-            const int p = atomicAdd(&s.misc[RPS_CNT], 1);
-            s.skey[p] = k;
-            s.scol[p] = ic;
+        for (int e0 = 0; e0 < cnt; e0 += 256) {
+          int sl[4];
+          bool ok[4];
+          uint64_t kk[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * 64 + lane;
+            ok[u] = e < cnt;
+            sl[u] = ok[u] ? (int)mylist[e] : 0;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) kk[u] = ok[u] ? src.key(sl[u]) : 0ull;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (!ok[u]) continue;
+            const uint64_t k = kk[u];
+            const uint32_t ic = ~src.col(sl[u]);
+            bool in_group;
+            if (!is_col)
+              in_group = (k >> shift) == (pkey >> shift);
+            else
+              in_group = (k == pkey) && ((ic >> shift) == (pcol >> shift));
+            if (in_group) {
+              const int p = atomicAdd(&s.misc[RPS_CNT], 1);
+              s.skey[p] = k;
+              s.scol[p] = ic;
+            }
           }
         }
         __syncthreads();
+        if (group <= 64) {
+          // one wave ranks the group in registers: the member with need-1 better members is the threshold
+          if (wave == 0) {
+            uint64_t mk = 0;
+            uint32_t mic = 0;
+            if (lane < group) {
+              mk = s.skey[lane];
+              mic = s.scol[lane];
+            }
+            int rank = 0;
+            for (int m2 = 0; m2 < group; ++m2) {
+              const uint32_t olo = (uint32_t)__shfl((int)(uint32_t)mk, m2);
+              const uint32_t ohi = (uint32_t)__shfl((int)(uint32_t)(mk >> 32), m2);
+              const uint32_t oic = (uint32_t)__shfl((int)mic, m2);
+              const uint64_t ok2 = ((uint64_t)ohi << 32) | olo;
+              rank += ((ok2 > mk) || (ok2 == mk && oic > mic)) ? 1 : 0;
+            }
+            if (lane < group && rank == need - 1) {
+              s.misc[RPS_TK] = (int)(uint32_t)mk;
+              s.misc[RPS_TK + 1] = (int)(uint32_t)(mk >> 32);
+              s.misc[RPS_TK + 2] = (int)mic;
+            }
+          }
+          __syncthreads();
+          tkey = ((uint64_t)(uint32_t)s.misc[RPS_TK + 1] << 32) | (uint32_t)s.misc[RPS_TK];
+          tcol = (uint32_t)s.misc[RPS_TK + 2];
+          __syncthreads();
+          RPS_STAMP(10);
+          break;
+        }
         int n2 = 1;
         while (n2 < group) n2 <<= 1;
         for (int i = group + tid; i < n2; i += NTHR) {
@@ -295,21 +406,34 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
   RPS_STAMP(9);
   // ---- 3. predicate pass: flag the selected entries, per-wave counts
   int wc = 0;
-  for (int e0 = 0; e0 < cnt; e0 += 64) {
-    const int e = e0 + lane;
-    bool sel = false;
-    if (e < cnt) {
-      const int slot = mylist[e];
-      if (kprime == n_valid) {
-        sel = true;
-      } else {
-        const uint64_t k = src.key(slot);
-        const uint32_t ic = ~src.col(slot);
-        sel = (k > tkey) || (k == tkey && ic >= tcol);
-      }
-      if (sel) mylist[e] = (uint16_t)(slot | RPS_FLAG);
+  for (int e0 = 0; e0 < cnt; e0 += 256) {
+    int sl[4];
+    bool ok[4];
+    uint64_t kk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * 64 + lane;
+      ok[u] = e < cnt;
+      sl[u] = ok[u] ? (int)mylist[e] : 0;
     }
-    wc += __popcll(__ballot(sel));
+    if (kprime != n_valid) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kk[u] = ok[u] ? src.key(sl[u]) : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bool sel = false;
+      if (ok[u]) {
+        if (kprime == n_valid) {
+          sel = true;
+        } else {
+          const uint32_t ic = ~src.col(sl[u]);
+          sel = (kk[u] > tkey) || (kk[u] == tkey && ic >= tcol);
+        }
+        if (sel) mylist[e0 + u * 64 + lane] = (uint16_t)(sl[u] | RPS_FLAG);
+      }
+      wc += __popcll(__ballot(sel));
+    }
   }
   if (lane == 0) s.misc[RPS_RED + wave] = wc;
   __syncthreads();
@@ -328,10 +452,10 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
 
 // Emit the selected slots in column order: emit(pos, slot).
 template <int NTHR, class Emit>
-__device__ __forceinline__ void rp_select_emit(int n_slots, rp_select_smem s, Emit emit) {
+__device__ __forceinline__ void rp_select_emit(int n_slots, rp_select_smem s, Emit emit, int seg_cap = 0) {
   constexpr int NW = NTHR / 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint16_t* mylist = s.list + wave * rp_per_wave(n_slots, NW);
+  const uint16_t* mylist = s.list + wave * (seg_cap ? seg_cap : rp_per_wave(n_slots, NW));
   const int cnt = s.misc[RPS_LCNT + wave];
   int off = s.misc[RPS_WOFF + wave];
   for (int e0 = 0; e0 < cnt; e0 += 64) {
@@ -346,10 +470,10 @@ __device__ __forceinline__ void rp_select_emit(int n_slots, rp_select_smem s, Em
 
 // Visit every candidate slot (selected or not): f(slot).  Used to clear the touched accumulators.
 template <int NTHR, class F>
-__device__ __forceinline__ void rp_select_foreach(int n_slots, rp_select_smem s, F f) {
+__device__ __forceinline__ void rp_select_foreach(int n_slots, rp_select_smem s, F f, int seg_cap = 0) {
   constexpr int NW = NTHR / 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint16_t* mylist = s.list + wave * rp_per_wave(n_slots, NW);
+  const uint16_t* mylist = s.list + wave * (seg_cap ? seg_cap : rp_per_wave(n_slots, NW));
   const int cnt = s.misc[RPS_LCNT + wave];
   for (int e = lane; e < cnt; e += 64) f((int)(mylist[e] & (RPS_FLAG - 1)));
 }

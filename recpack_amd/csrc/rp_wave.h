@@ -1,0 +1,205 @@
+// Wave-private running top-K pool (no workgroup barriers): the selection machinery of the wave-per-row fit
+// kernel and the wave-per-user predict kernel.
+//
+// A wave streams candidates (key, column) in ASCENDING column order.  Candidates whose key beats the current
+// threshold are appended to an LDS pool; when the pool is full it is cut to the K best by an exact wave-level
+// radix select (8-bit digits, 256-bin LDS histogram, boundary group of <= 64 resolved by ranking in registers).
+// After a cut the threshold is the K-th key, and a later candidate must be STRICTLY larger to enter: it has a
+// larger column than everything in the pool, so on equal keys it loses - which is exactly the order
+// "larger key first, then smaller column" of recpack/util.py:50-96 as restated by the oracle.
+#pragma once
+
+#include "rp_common.h"
+
+template <typename KeyT>
+struct rp_wpool {
+  KeyT* key;        // [CAP]
+  uint32_t* pay;    // [CAP] payload; the column is pay >> col_shift
+  uint32_t* hist;   // [256]
+  uint16_t* gidx;   // [64]
+  int n;            // entries in the pool (wave-uniform)
+  KeyT tau;         // admission threshold: key must be > tau (0 = everything positive)
+};
+
+template <typename KeyT>
+__device__ __forceinline__ KeyT rp_shfl_key(KeyT v, int src);
+template <>
+__device__ __forceinline__ uint32_t rp_shfl_key<uint32_t>(uint32_t v, int src) {
+  return (uint32_t)__shfl((int)v, src);
+}
+template <>
+__device__ __forceinline__ uint64_t rp_shfl_key<uint64_t>(uint64_t v, int src) {
+  const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src);
+  const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ int rp_wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// Cut the pool to its K best entries by (key desc, column asc); requires pool.n > K.  Sets pool.tau.
+template <typename KeyT, int COL_SHIFT>
+__device__ void rp_wpool_cut(rp_wpool<KeyT>& P, int K, int lane) {
+  constexpr int KEY_LEVELS = sizeof(KeyT);  // 8-bit digits
+  const int n = P.n;
+  volatile KeyT* key = P.key;
+  volatile uint32_t* pay = P.pay;
+  volatile uint32_t* hist = P.hist;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  KeyT pkey = 0;
+  uint32_t pic = 0;  // decided prefix of ~column
+  int need = K;
+  KeyT tkey = 0;
+  uint32_t tcol = 0xffffffffu;  // selected <=> key > tkey || (key == tkey && col <= tcol)
+  bool done = false;
+  for (int level = 0; level < KEY_LEVELS + 4 && !done; ++level) {
+    const bool is_col = level >= KEY_LEVELS;
+    const int shift = is_col ? 8 * (3 - (level - KEY_LEVELS)) : 8 * (KEY_LEVELS - 1 - level);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) hist[lane * 4 + b] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < n; e += 64) {
+      const KeyT k = key[e];
+      const uint32_t ic = ~(pay[e] >> COL_SHIFT);
+      bool in_group;
+      uint32_t d;
+      if (!is_col) {
+        in_group = (level == 0) || ((k >> shift) >> 8) == ((pkey >> shift) >> 8);
+        d = (uint32_t)(k >> shift) & 255u;
+      } else {
+        in_group = (k == pkey) && ((level == KEY_LEVELS) || ((ic >> shift) >> 8) == ((pic >> shift) >> 8));
+        d = (ic >> shift) & 255u;
+      }
+      if (in_group) atomicAdd((uint32_t*)&P.hist[d], 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // lane owns bins 255-4*lane .. 252-4*lane (descending)
+    int h[4];
+    int sum = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      h[b] = (int)hist[255 - 4 * lane - b];
+      sum += h[b];
+    }
+    int above = rp_wave_incl_scan(sum, lane) - sum;
+    int fbin = -1, fabove = 0, fgroup = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (above < need && need <= above + h[b]) {
+        fbin = 255 - 4 * lane - b;
+        fabove = above;
+        fgroup = h[b];
+      }
+      above += h[b];
+    }
+    const uint64_t fm = __ballot(fbin >= 0);
+    const int src = __ffsll((unsigned long long)fm) - 1;
+    const int bin = __shfl(fbin, src);
+    const int group = __shfl(fgroup, src);
+    need -= __shfl(fabove, src);
+    if (!is_col)
+      pkey |= (KeyT)bin << shift;
+    else
+      pic |= (uint32_t)bin << shift;
+    if (group == need) {  // the whole boundary group is selected
+      if (!is_col) {
+        tkey = pkey;
+        tcol = 0xffffffffu;
+      } else {
+        tkey = pkey;
+        tcol = ~pic;  // ~col >= pic  <=>  col <= ~pic
+      }
+      done = true;
+    } else if (group <= 64) {
+      // exact: gather the group (one member per lane), rank it, the member of rank need-1 is the threshold
+      int base = 0;
+      for (int e0 = 0; e0 < n; e0 += 64) {
+        const int e = e0 + lane;
+        bool mem = false;
+        if (e < n) {
+          const KeyT k = key[e];
+          const uint32_t ic = ~(pay[e] >> COL_SHIFT);
+          if (!is_col)
+            mem = (k >> shift) == (pkey >> shift);
+          else
+            mem = (k == pkey) && ((ic >> shift) == (pic >> shift));
+        }
+        const uint64_t m = __ballot(mem);
+        if (mem) ((volatile uint16_t*)P.gidx)[base + __popcll(m & lt_mask)] = (uint16_t)e;
+        base += __popcll(m);
+      }
+      __builtin_amdgcn_wave_barrier();
+      KeyT mk = 0;
+      uint32_t mic = 0;
+      if (lane < group) {
+        const int e = ((volatile uint16_t*)P.gidx)[lane];
+        mk = key[e];
+        mic = ~(pay[e] >> COL_SHIFT);
+      }
+      int rank = 0;
+      for (int m = 0; m < group; ++m) {
+        const KeyT ok = rp_shfl_key<KeyT>(mk, m);
+        const uint32_t oic = (uint32_t)__shfl((int)mic, m);
+        rank += ((ok > mk) || (ok == mk && oic > mic)) ? 1 : 0;
+      }
+      const uint64_t tm = __ballot(lane < group && rank == need - 1);
+      const int tsrc = __ffsll((unsigned long long)tm) - 1;
+      tkey = rp_shfl_key<KeyT>(mk, tsrc);
+      tcol = ~(uint32_t)__shfl((int)mic, tsrc);
+      done = true;
+    }
+  }
+  // rebuild the pool in place: all reads first (n <= 512 => at most 8 rounds), then ordered writes
+  constexpr int MAXR = 8;
+  KeyT rk[MAXR];
+  uint32_t rp[MAXR];
+#pragma unroll
+  for (int r = 0; r < MAXR; ++r) {
+    const int e = r * 64 + lane;
+    rk[r] = (e < n) ? key[e] : (KeyT)0;
+    rp[r] = (e < n) ? pay[e] : 0u;
+  }
+  __builtin_amdgcn_wave_barrier();
+  int out = 0;
+#pragma unroll
+  for (int r = 0; r < MAXR; ++r) {
+    const int e = r * 64 + lane;
+    const uint32_t c = rp[r] >> COL_SHIFT;
+    const bool sel = (e < n) && ((rk[r] > tkey) || (rk[r] == tkey && c <= tcol));
+    const uint64_t m = __ballot(sel);
+    if (sel) {
+      const int pos = out + __popcll(m & lt_mask);
+      key[pos] = rk[r];
+      pay[pos] = rp[r];
+    }
+    out += __popcll(m);
+  }
+  __builtin_amdgcn_wave_barrier();
+  P.n = out;  // == K
+  P.tau = tkey;
+}
+
+// Append the lanes' candidates (keep == true) to the pool; cuts first when fewer than 64 slots are free.
+template <typename KeyT, int COL_SHIFT>
+__device__ __forceinline__ void rp_wpool_push(rp_wpool<KeyT>& P, int K, int cap, bool keep, KeyT k, uint32_t pay, int lane) {
+  uint64_t m = __ballot(keep);
+  if (m == 0) return;
+  if (P.n + 64 > cap && P.n > K) {  // cap >= K + 64
+    rp_wpool_cut<KeyT, COL_SHIFT>(P, K, lane);
+    keep = keep && (k > P.tau);
+    m = __ballot(keep);
+    if (m == 0) return;
+  }
+  if (keep) {
+    const int pos = P.n + __popcll(m & ((1ull << lane) - 1ull));
+    ((volatile KeyT*)P.key)[pos] = k;
+    ((volatile uint32_t*)P.pay)[pos] = pay;
+  }
+  P.n += __popcll(m);
+}
