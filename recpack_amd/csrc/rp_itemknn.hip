@@ -511,7 +511,7 @@ static int rp_model_alloc_topk(rphip_ctx* ctx, int64_t n_items, int64_t r0, int6
   hipError_t e1 = hipMalloc((void**)&m->idx, n * sizeof(int32_t));
   hipError_t e2 = hipMalloc((void**)&m->val, n * sizeof(double));
   hipError_t e3 = hipMalloc((void**)&m->val32, n * sizeof(float));
-  if (e3 == hipSuccess) e3 = hipMalloc((void**)&m->pairs, n * sizeof(int2));
+  if (e3 == hipSuccess) e3 = hipMalloc((void**)&m->pairs, (n + 8) * sizeof(int2));  // +8: aligned 4-entry chunk loads may overrun
   hipError_t e4 = hipMalloc((void**)&m->nnz, (size_t)std::max<int64_t>(1, r1 - r0) * sizeof(int32_t));
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
     rphip_model_destroy(m);

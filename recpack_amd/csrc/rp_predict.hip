@@ -15,6 +15,7 @@
 
 #include "rp_common.h"
 #include "rp_select.h"
+#include "rp_wave.h"
 
 constexpr int RP_PRED_THREADS = 1024;
 
@@ -212,22 +213,24 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_merge(const int32_t
 // ---- K8, wave-per-user form ------------------------------------------------------------------------
 // One WAVE owns one user: no workgroup barriers, PW_WAVES independent users per workgroup and ~12 per CU.
 //   * lane l holds a cursor into the (column-sorted) neighbour list of the user's l-th history item
-//     (PW_NB registers sets => up to 64*PW_NB history items; heavier users take the workgroup kernel);
+//     (PW_NB register sets => up to 64*PW_NB history items; heavier users take the workgroup kernel);
 //   * the item axis is walked in tiles of PW_WT columns; each lane adds its row's entries that fall into the
-//     tile to the wave's private f32 LDS tile (LDS float atomics; entries are prefetched PW_D ahead);
-//   * the tile is then scanned once (16 B per lane), cleared, and every score above the current threshold
-//     goes to a per-wave pool; when the pool is full it is sorted (wave-synchronous bitonic in LDS), cut
-//     to Kp and the threshold becomes the Kp-th score - exact, because tiles arrive in column order and ties
-//     are resolved towards the smaller column;
-//   * at the end the pool is cut to Kp, re-sorted by column and written out.
+//     tile to the wave's private f32 LDS tile (LDS float atomics; entries are prefetched two ahead);
+//   * the tile is then scanned once (16 B per lane) and cleared; a lane first compares the maximum of its four
+//     scores with the running threshold, so after warm-up almost every step is a read, a clear and one compare;
+//     scores above the threshold enter the wave's pool in column order (rp_wave.h), which cuts itself to the
+//     Kp best with an exact radix select when it is full;
+//   * at the end the pool is cut to Kp, ranked by column and written out.
 constexpr int PW_WT = 2048;
-constexpr int PW_CAP = 512;
-constexpr int PW_NB = 4;
+constexpr int PW_NB = 4;        // 64*PW_NB history items per user at most (cursors live in registers)
 constexpr int PW_WAVES = 4;
-constexpr int PW_UCH = 4;  // users per ticket
-constexpr size_t PW_WAVE_BYTES = (size_t)PW_WT * 4 + (size_t)PW_CAP * 8;
-constexpr int PW_KP_MAX = PW_CAP - 256;  // a scan step appends at most 256 entries
-constexpr int PW_SENT = 0x7fffffff;
+constexpr int PW_UCH = 4;       // users per ticket
+constexpr int PW_KP_MAX = 384;  // pool capacity = Kp rounded up + 128 <= 512
+
+__host__ __device__ constexpr int rp_pw_cap(int Kp) { return ((Kp + 63) / 64) * 64 + 128; }
+__host__ __device__ constexpr size_t rp_pw_wave_bytes(int Kp) {
+  return (size_t)PW_WT * 4 + (size_t)rp_pw_cap(Kp) * 8 + 1024 + 128;
+}
 
 struct rp_pw_params {
   const int32_t* x_ptr;
@@ -239,45 +242,42 @@ struct rp_pw_params {
   int32_t* out_idx;
   float* out_val;
   int32_t* out_nnz;
+  unsigned long long* stamps;  // -DRP_STAMPS only
 };
 
-// wave-synchronous bitonic sort of n2 (power of two) LDS entries; by_col = false: (key desc, col asc); true: col asc
-__device__ __forceinline__ void pw_sort(volatile float* pkey, volatile int* pcol, int n2, bool by_col, int lane) {
-  for (int k2 = 2; k2 <= n2; k2 <<= 1) {
-    for (int j = k2 >> 1; j > 0; j >>= 1) {
-      for (int i = lane; i < n2; i += 64) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const float ka = pkey[i], kb = pkey[ixj];
-          const int ca = pcol[i], cb = pcol[ixj];
-          // "a should come after b" in the final order
-          const bool a_after_b = by_col ? (ca > cb) : ((ka < kb) || (ka == kb && ca > cb));
-          const bool up = ((i & k2) == 0);
-          if (up ? a_after_b : !a_after_b) {
-            pkey[i] = kb;
-            pkey[ixj] = ka;
-            pcol[i] = cb;
-            pcol[ixj] = ca;
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-}
+#ifdef RP_STAMPS
+#define PW_STAMP(ph)                                                   \
+  do {                                                                 \
+    if (lane == 0) {                                                   \
+      unsigned long long _t = __builtin_amdgcn_s_memtime();            \
+      atomicAdd(&P.stamps[ph], _t - t_last);                           \
+      t_last = _t;                                                     \
+    }                                                                  \
+  } while (0)
+#else
+#define PW_STAMP(ph) do { } while (0)
+#endif
 
 __global__ void __launch_bounds__(PW_WAVES * 64) k_predict_wave(rp_pw_params P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* acc = reinterpret_cast<float*>(smem + (size_t)wave * PW_WAVE_BYTES);
-  float* pkey = acc + PW_WT;
-  int* pcol = reinterpret_cast<int*>(pkey + PW_CAP);
-  float4* acc4 = reinterpret_cast<float4*>(acc);
   const int K = P.K, Kp = P.Kp;
+  const int cap = rp_pw_cap(Kp);
+  char* base = smem + (size_t)wave * rp_pw_wave_bytes(Kp);
+  float* acc = reinterpret_cast<float*>(base);
+  float4* acc4 = reinterpret_cast<float4*>(acc);
+  rp_wpool<uint32_t> pool;
+  pool.key = reinterpret_cast<uint32_t*>(base + (size_t)PW_WT * 4);
+  pool.pay = pool.key + cap;
+  pool.hist = pool.pay + cap;
+  pool.gidx = reinterpret_cast<uint16_t*>(pool.hist + 256);
   const uint64_t lt_mask = (1ull << lane) - 1ull;
-  const int2 SENT = make_int2(PW_SENT, 0);
+  const int2 SENT = make_int2(0x7fffffff, 0);
 
   for (int i = lane; i < PW_WT / 4; i += 64) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef RP_STAMPS
+  unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
 
   while (true) {
     int ubase = 0;
@@ -290,41 +290,26 @@ __global__ void __launch_bounds__(PW_WAVES * 64) k_predict_wave(rp_pw_params P) 
       const int hs = P.x_ptr[u], he = P.x_ptr[u + 1];
       const int d = he - hs;
       if (d <= 0 || d > 64 * PW_NB) continue;  // heavy users: workgroup kernel
-
-      int cur[PW_NB], end[PW_NB], item[PW_NB];
+      // per-lane cursors into the neighbour lists of history items lane, lane+64, ... ; entries prefetched two ahead
+      int cur[PW_NB], end[PW_NB];
       int2 e0[PW_NB], e1[PW_NB], e2[PW_NB];
 #pragma unroll
       for (int b = 0; b < PW_NB; ++b) {
         const int h = hs + b * 64 + lane;
-        item[b] = -1;
         cur[b] = 0;
         end[b] = 0;
         if (h < he) {
-          item[b] = P.x_idx[h];
-          cur[b] = item[b] * K;
-          end[b] = cur[b] + P.s_nnz[item[b]];
+          const int it = P.x_idx[h];
+          cur[b] = it * K;
+          end[b] = cur[b] + P.s_nnz[it];
         }
         e0[b] = (cur[b] < end[b]) ? P.pairs[cur[b]] : SENT;
         e1[b] = (cur[b] + 1 < end[b]) ? P.pairs[cur[b] + 1] : SENT;
         e2[b] = (cur[b] + 2 < end[b]) ? P.pairs[cur[b] + 2] : SENT;
       }
-      int pool_n = 0;
-      float tau = 0.0f;  // scores are positive; strict '>' also drops untouched (zero) slots
-
-      auto compact = [&]() {
-        int n2 = 64;
-        while (n2 < pool_n) n2 <<= 1;
-        for (int i = pool_n + lane; i < n2; i += 64) {
-          pkey[i] = -1.0f;
-          pcol[i] = PW_SENT;
-        }
-        __builtin_amdgcn_wave_barrier();
-        pw_sort(pkey, pcol, n2, false, lane);
-        if (pool_n >= Kp) {
-          pool_n = Kp;
-          tau = ((volatile float*)pkey)[Kp - 1];
-        }
-      };
+      pool.n = 0;
+      pool.tau = 0;  // scores are positive: bits of a positive float order like the float
+      PW_STAMP(0);
 
       for (int t0 = 0; t0 < P.n_items; t0 += PW_WT) {
         const int t_end = min(t0 + PW_WT, P.n_items);
@@ -343,56 +328,91 @@ __global__ void __launch_bounds__(PW_WAVES * 64) k_predict_wave(rp_pw_params P) 
             touched = true;
           }
         }
+        PW_STAMP(1);
         if (!touched) continue;
         if (P.exclude_history) {
-#pragma unroll
-          for (int b = 0; b < PW_NB; ++b)
-            if (item[b] >= t0 && item[b] < t_end) acc[item[b] - t0] = 0.0f;
+          for (int h = hs + lane; h < he; h += 64) {
+            const int it = P.x_idx[h];
+            if (it >= t0 && it < t_end) acc[it - t0] = 0.0f;
+          }
         }
         __builtin_amdgcn_wave_barrier();
         for (int it = 0; it < PW_WT / 256; ++it) {
           const int q = it * 64 + lane;
-          const float4 v = acc4[q];
-          const bool any_nz = (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
-          if (any_nz) acc4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (!__any(any_nz)) continue;
+          typedef float f32x4_t __attribute__((ext_vector_type(4)));
+          volatile f32x4_t* accv = reinterpret_cast<volatile f32x4_t*>(acc);
+          const f32x4_t v = accv[q];
+          const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+          if (mx != 0.0f) accv[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          const float tau_f = __uint_as_float(pool.tau);
+          if (!__any(mx > tau_f)) continue;
+          // column order inside the step is lane-major, component-minor: push the four components of all lanes
+          // as ONE ordered batch (positions from four ballots) so that the pool's strict threshold stays exact
           const float vv[4] = {v.x, v.y, v.z, v.w};
+          bool keep[4];
+          uint64_t m[4];
+          int add = 0;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            bool keep = vv[c] > tau;
-            uint64_t m = __ballot(keep);
-            if (m == 0) continue;
-            if (pool_n + __popcll(m) > PW_CAP) {
-              compact();
-              keep = vv[c] > tau;
-              m = __ballot(keep);
-            }
-            if (keep) {
-              const int pos = pool_n + __popcll(m & lt_mask);
-              pkey[pos] = vv[c];
-              pcol[pos] = t0 + q * 4 + c;
-            }
-            pool_n += __popcll(m);
+            keep[c] = vv[c] > tau_f;
+            m[c] = __ballot(keep[c]);
+            add += __popcll(m[c]);
           }
+          if (pool.n + add > cap && pool.n > Kp) {
+            rp_wpool_cut<uint32_t, 0>(pool, Kp, lane);
+            const float t2 = __uint_as_float(pool.tau);
+            add = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              keep[c] = vv[c] > t2;
+              m[c] = __ballot(keep[c]);
+              add += __popcll(m[c]);
+            }
+          }
+          if (pool.n + add > cap) {
+            // more admissible scores in one step than the pool has room for: push the four components as separate
+            // batches.  Their order is not the column order, so admission is non-strict here and ties are
+            // resolved exactly by the next cut.
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const bool k2 = vv[c] >= __uint_as_float(pool.tau) && vv[c] > 0.0f;
+              rp_wpool_push<uint32_t, 0>(pool, Kp, cap, k2, __float_as_uint(vv[c]), (uint32_t)(t0 + q * 4 + c), lane);
+            }
+            continue;
+          }
+          int below = 0;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) below += __popcll(m[c] & lt_mask);
+          int own = 0;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (keep[c]) {
+              const int pos = pool.n + below + own;
+              ((volatile uint32_t*)pool.key)[pos] = __float_as_uint(vv[c]);
+              ((volatile uint32_t*)pool.pay)[pos] = (uint32_t)(t0 + q * 4 + c);
+            }
+            own += keep[c] ? 1 : 0;
+          }
+          pool.n += add;
         }
+        PW_STAMP(2);
       }
       // ---- final: best Kp by (score desc, column asc), then column order for the output row
       __builtin_amdgcn_wave_barrier();
-      compact();
-      const int n_out = min(pool_n, Kp);
-      int n2 = 64;
-      while (n2 < n_out) n2 <<= 1;
-      for (int i = n_out + lane; i < n2; i += 64) {
-        pkey[i] = 0.0f;
-        pcol[i] = PW_SENT;
-      }
-      __builtin_amdgcn_wave_barrier();
-      pw_sort(pkey, pcol, n2, true, lane);
-      for (int i = lane; i < n_out; i += 64) {
-        P.out_idx[(int64_t)ul * Kp + i] = ((volatile int*)pcol)[i];
-        P.out_val[(int64_t)ul * Kp + i] = ((volatile float*)pkey)[i];
+      if (pool.n > Kp) rp_wpool_cut<uint32_t, 0>(pool, Kp, lane);
+      const int n_out = pool.n;
+      volatile uint32_t* pk = pool.key;
+      volatile uint32_t* pp = pool.pay;
+      for (int e = lane; e < n_out; e += 64) {
+        const uint32_t col = pp[e];
+        int rank = 0;
+        for (int o = 0; o < n_out; ++o) rank += (pp[o] < col) ? 1 : 0;
+        P.out_idx[(int64_t)ul * Kp + rank] = (int)col;
+        P.out_val[(int64_t)ul * Kp + rank] = __uint_as_float(pk[e]);
       }
       if (lane == 0) P.out_nnz[ul] = n_out;
+      __builtin_amdgcn_wave_barrier();
+      PW_STAMP(3);
     }
   }
 }
@@ -538,11 +558,29 @@ extern "C" int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, 
     W.out_idx = idx_dev;
     W.out_val = val_dev;
     W.out_nnz = nnz_dev;
-    const size_t wl = PW_WAVE_BYTES * PW_WAVES;
+    W.stamps = nullptr;
+#ifdef RP_STAMPS
+    {
+      void* sp = nullptr;
+      RP_TRY(rp_scratch(ctx, 6, 64 * 8, &sp));
+      W.stamps = (unsigned long long*)sp;
+      hipMemsetAsync(sp, 0, 64 * 8, st);
+    }
+#endif
+    const size_t wl = rp_pw_wave_bytes(Kp) * PW_WAVES;
     RP_HIP(hipFuncSetAttribute((const void*)k_predict_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl));
     const int wpc = std::max<int>(1, (int)((160 * 1024) / wl));
     const int wg = (int)std::min<int64_t>(rp_cdiv(n, PW_UCH * PW_WAVES), (int64_t)ctx->n_cu * wpc);
     hipLaunchKernelGGL(k_predict_wave, dim3(wg), dim3(PW_WAVES * 64), wl, st, W);
+#ifdef RP_STAMPS
+    {
+      unsigned long long h[8];
+      hipMemcpyAsync(h, W.stamps, sizeof(h), hipMemcpyDeviceToHost, st);
+      hipStreamSynchronize(st);
+      fprintf(stderr, "[stamps predict_wave] cycles/1e6: setup %.1f accumulate %.1f scan+pool %.1f final %.1f\n", h[0] / 1e6, h[1] / 1e6,
+              h[2] / 1e6, h[3] / 1e6);
+    }
+#endif
     P.user_list = heavy_list;
     P.n_list = heavy_cnt;
   }

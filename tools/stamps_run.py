@@ -14,3 +14,10 @@ for it in range(2):
     m = _lib.itemknn_fit(ctx, dX, 200)
     ctx.sync()
 print(ctx.timings()["gram_topk"])
+if len(sys.argv) > 2:
+    n = int(sys.argv[2])
+    oi = torch.empty((n, 100), dtype=torch.int32, device=dev); ov = torch.empty((n, 100), dtype=torch.float32, device=dev); on = torch.empty((n,), dtype=torch.int32, device=dev)
+    ctx.reset_timings()
+    _lib.predict_topk_dev(ctx, m, dX, 100, oi, ov, on, user_begin=0, user_end=n)
+    ctx.sync()
+    print("predict", ctx.timings()["predict"])
