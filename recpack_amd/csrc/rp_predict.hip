@@ -530,7 +530,7 @@ extern "C" int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, 
   // light users (history <= 64*PW_NB items) go to the wave-per-user kernel, the rest to the workgroup kernel
   // (measured: with one column tile the workgroup kernel is still faster - 8.0 vs 11.8 ms at 100K x 20K -, with
   // several tiles the wave kernel wins - 187 vs 347 ms at 1M x 100K)
-  const bool use_wave = model->kind == RPHIP_MODEL_TOPK && T > 1 && model->cols_sorted && Kp <= PW_KP_MAX && (int64_t)model->n_items * model->K < (1ll << 31);
+  const bool use_wave = model->kind == RPHIP_MODEL_TOPK && model->cols_sorted && Kp <= PW_KP_MAX && (int64_t)model->n_items * model->K < (1ll << 31);
   int32_t* heavy_list = nullptr;
   int32_t* heavy_cnt = nullptr;
   hipEvent_t ev;
