@@ -36,6 +36,7 @@ struct rp_fit_params {
   const double* inv_deg;
   const int32_t* tile_ptr;
   int n_items, n_tiles, tile_w, K, row_begin;
+  int nnz;
   const rp_task* tasks;
   const int32_t* n_tasks;
   int32_t* ticket;
@@ -169,12 +170,17 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
       // before the first LDS atomic, instead of one dependent load per user per round.
       constexpr int CH = 8;
       int n_prod = 0;
-      for (int base = tk.p_begin + wave * 64; base < tk.p_end; base += NW * 64) {
-        const int p = base + lane;
-        int s = 0, len = 0;
-        if (p < tk.p_end) {
-          const int u = P.xt_idx[p];
-          int e;
+      const int stride = NW * 64;
+      // software pipeline over the wave's batches of 64 users: the user ids of batch n+2 and the row pointers of
+      // batch n+1 are in flight while batch n is expanded into chunks
+      auto load_user = [&](int bs) -> int {
+        const int p = bs + lane;
+        return (p < tk.p_end) ? P.xt_idx[p] : -1;
+      };
+      auto load_seg = [&](int u, int& s, int& e) {
+        s = 0;
+        e = 0;
+        if (u >= 0) {
           if (T == 1) {
             s = P.x_ptr[u];
             e = P.x_ptr[u + 1];
@@ -183,8 +189,16 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
             s = tp[0];
             e = tp[1];
           }
-          len = e - s;
         }
+      };
+      int base = tk.p_begin + wave * 64;
+      int u_next = load_user(base + stride);
+      int s_cur, e_cur;
+      load_seg(load_user(base), s_cur, e_cur);
+      for (; base < tk.p_end; base += stride) {
+        const int s = s_cur, len = e_cur - s_cur;
+        load_seg(u_next, s_cur, e_cur);           // batch n+1
+        u_next = load_user(base + 2 * stride);    // batch n+2
         n_prod += len;
         const int nch = (len + CH - 1) / CH;
         int inc = nch;
@@ -195,7 +209,8 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
         }
         const int choff = inc - nch;       // first chunk of this lane's user
         const int n_chunks = __shfl(inc, 63);
-        for (int c0 = 0; c0 < n_chunks; c0 += 64) {
+        // chunk c goes to lane c % 64; the index loads of step c0+64 are issued before the atomics of step c0
+        auto fetch = [&](int c0, int (&jv)[CH]) {
           const int c = c0 + lane;
           int lo = 0;                        // owner = largest lane l with choff[l] <= c
 #pragma unroll
@@ -207,9 +222,24 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
           const int k0 = (c - co) * CH;
           const int n = (c < n_chunks) ? min(CH, ul - k0) : 0;
           const int32_t* src = P.x_idx + us + k0;
-          int jv[CH];
+          if (n > 0) {
+            if (us + k0 + CH <= P.nnz) {
+              // two 16-byte loads (dword-aligned is enough for global_load_dwordx4) instead of eight dword loads:
+              // the address path processes a quarter of the instructions; entries past n are read but ignored
+              typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));
+              const v4i_a4 a = *reinterpret_cast<const v4i_a4*>(src);
+              const v4i_a4 b = *reinterpret_cast<const v4i_a4*>(src + 4);
+              jv[0] = a.x; jv[1] = a.y; jv[2] = a.z; jv[3] = a.w;
+              jv[4] = b.x; jv[5] = b.y; jv[6] = b.z; jv[7] = b.w;
+            } else {  // the last few entries of the matrix
 #pragma unroll
-          for (int e = 0; e < CH; ++e) jv[e] = (e < n) ? src[e] : -1;
+              for (int e = 0; e < CH; ++e) jv[e] = (e < n) ? src[e] : -1;
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < CH; ++e) jv[e] = (e < n) ? jv[e] : -1;
+        };
+        auto apply = [&](const int (&jv)[CH]) {
 #pragma unroll
           for (int e = 0; e < CH; ++e)
             if (jv[e] >= 0) {
@@ -219,6 +249,16 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
               else
                 atomicAdd(&acc[j], 1u);
             }
+        };
+        int ja[CH], jb[CH];
+        if (n_chunks > 0) fetch(0, ja);
+        for (int c0 = 0; c0 < n_chunks; c0 += 128) {
+          if (c0 + 64 < n_chunks) fetch(c0 + 64, jb);
+          apply(ja);
+          if (c0 + 64 < n_chunks) {
+            if (c0 + 128 < n_chunks) fetch(c0 + 128, ja);
+            apply(jb);
+          }
         }
       }
       if (BYTES && P.n_products) {  // products done by the light kernel (roofline split between the two kernels)
@@ -322,13 +362,15 @@ struct rp_merge_params {
   int32_t* out_nnz;
 };
 
-__global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_merge(rp_merge_params P) {
+constexpr int RP_MERGE_THREADS = 256;  // a row's T*K candidates are few: small workgroups, many per CU
+
+__global__ void __launch_bounds__(RP_MERGE_THREADS) k_itemknn_merge(rp_merge_params P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int T = P.n_tiles, K = P.K;
   const int cap = T * K;
   int32_t* lcol = reinterpret_cast<int32_t*>(smem);
   uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 4);
-  rp_select_smem sel = rp_select_carve(smem + (size_t)cap * 8, cap);
+  rp_select_smem sel = rp_select_carve(smem + (size_t)cap * 8, cap, RP_MERGE_THREADS / 64);
   int* s_off = &sel.misc[RPS_USER];  // n_tiles + 1 <= 16 entries
   const int tid = threadIdx.x;
   for (int rl = blockIdx.x; rl < P.n_rows; rl += gridDim.x) {
@@ -346,18 +388,18 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_merge(rp_merge_param
     for (int t = 0; t < T; ++t) {
       const int cn = s_off[t + 1] - s_off[t];
       const int64_t src = ((int64_t)rl * T + t) * K;
-      for (int k = tid; k < cn; k += RP_FIT_THREADS) {
+      for (int k = tid; k < cn; k += RP_MERGE_THREADS) {
         lcol[s_off[t] + k] = P.cand_idx[src + k];
         lcnt[s_off[t] + k] = P.cand_cnt[src + k];
       }
     }
     __syncthreads();
     rp_list_src src{lcol, lcnt, P.inv_deg, n};
-    const int kp = rp_select_topk<RP_FIT_THREADS>(src, n, K, sel);
+    const int kp = rp_select_topk<RP_MERGE_THREADS>(src, n, K, sel);
     int32_t* oi = P.out_idx + (int64_t)rl * K;
     double* ov = P.out_val + (int64_t)rl * K;
     const double ci = (double)P.deg[P.row_begin + rl];
-    rp_select_emit<RP_FIT_THREADS>(n, sel, [&](int pos, int w) {
+    rp_select_emit<RP_MERGE_THREADS>(n, sel, [&](int pos, int w) {
       const int j = lcol[w];
       oi[pos] = j;
       ov[pos] = (double)lcnt[w] / sqrt(ci * (double)P.deg[j]);
@@ -670,6 +712,7 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   P.inv_deg = X->inv_deg;
   P.tile_ptr = X->tile_ptr;
   P.n_items = (int)X->n_items;
+  P.nnz = (int)X->nnz;
   P.n_tiles = T;
   P.tile_w = W;
   P.K = K;
@@ -784,14 +827,15 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
     M.out_idx = m->idx;
     M.out_val = m->val;
     M.out_nnz = m->nnz;
-    const size_t mlds = (size_t)T * Keff * 8 + rp_select_smem_bytes(T * Keff);
+    const size_t mlds = (size_t)T * Keff * 8 + rp_select_smem_bytes(T * Keff, RP_MERGE_THREADS / 64);
     if (mlds > 160 * 1024 || T * Keff >= RPS_FLAG) {
       rphip_model_destroy(m);
       RP_FAIL(RPHIP_ELIMIT, "K=%d with %d column tiles needs %zu bytes of LDS for the merge", K, T, mlds);
     }
     RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
-    const int mg = (int)std::min<int64_t>(n_rows, (int64_t)ctx->n_cu * 2);
-    hipLaunchKernelGGL(k_itemknn_merge, dim3(mg), dim3(RP_FIT_THREADS), mlds, st, M);
+    const int mper = std::max<int>(1, std::min<int>(8, (int)((160 * 1024) / mlds)));
+    const int mg = (int)std::min<int64_t>(n_rows, (int64_t)ctx->n_cu * mper);
+    hipLaunchKernelGGL(k_itemknn_merge, dim3(mg), dim3(RP_MERGE_THREADS), mlds, st, M);
     RP_HIP(hipGetLastError());
     rp_time_end(ctx, ev, RPHIP_T_TOPK_MERGE, 16.0 * (double)n_rows * T * Keff);
   }
