@@ -59,10 +59,23 @@ def cosine_full(X):
     return S
 
 
+def condprob_full(X, pop_discount):
+    from recpack.algorithms.nearest_neighbour import compute_conditional_probability
+    from recpack.matrix import to_csr_matrix
+
+    S = sp.csr_matrix(compute_conditional_probability(to_csr_matrix(X, binary=True), pop_discount or 0))
+    S.sort_indices()
+    return S
+
+
 def itemknn_case(name, X, Ks, predict_in=None, **kw):
     arrays = dict(csr_parts("X", X))
     arrays["Ks"] = np.asarray(Ks, dtype=np.int64)
-    arrays.update(csr_parts("cos", cosine_full(X)))  # all candidates incl. explicit diagonal zeros
+    if kw.get("similarity") == "conditional_probability":
+        arrays.update(csr_parts("cos", condprob_full(X, kw.get("pop_discount"))))  # all candidates of this similarity
+        arrays["pop_discount"] = np.asarray(kw.get("pop_discount") or 0.0)
+    else:
+        arrays.update(csr_parts("cos", cosine_full(X)))  # all candidates incl. explicit diagonal zeros
     for K in Ks:
         algo = ItemKNN(K=K, **kw).fit(X)
         S = sp.csr_matrix(algo.similarity_matrix_)
@@ -98,6 +111,10 @@ def main():
     itemknn_case("ref_itemknn_data", data, [1, 2, 10], predict_in=[p1, p2])
     # normalize_sim on the same data (test_nearest_neighbour.py:110-116)
     itemknn_case("ref_itemknn_data_normsim", data, [2], normalize_sim=True)
+    # conditional probability with and without pop_discount (test_nearest_neighbour.py:127-181)
+    itemknn_case("ref_itemknn_data_condprob", data, [2], similarity="conditional_probability")
+    for pd in (1.0, 0.2, 0.5):
+        itemknn_case(f"ref_itemknn_data_condprob_pd{pd}", data, [2], similarity="conditional_probability", pop_discount=pd)
     # --- test_nearest_neighbour.py:34-41 (data_empty_col)
     dec = sp.csr_matrix(([1] * 5, ([0, 0, 1, 1, 2], [1, 2, 2, 1, 2])))
     itemknn_case("ref_itemknn_empty_col", dec, [2])
@@ -134,6 +151,8 @@ def main():
     m_dup.data[::7] = 3
     itemknn_case("syn_itemknn_2000x500", m_dup, [10, 50, 600], predict_in=[m[:300]])
     ease_case("syn_ease_2000x500", m_dup, [(200.0, 0.0), (5.0, 0.5)], predict_in=m[:100])
+    itemknn_case("syn_itemknn_condprob_2000x500", m_dup, [20], similarity="conditional_probability", pop_discount=0.5)
+    itemknn_case("syn_itemknn_condprob0_2000x500", m_dup, [20], similarity="conditional_probability")
     m2 = powerlaw_csr(10000, 2000, 0.004, seed=20260102).to_scipy()
     algo = ItemKNN(K=100).fit(m2)
     S = sp.csr_matrix(algo.similarity_matrix_)

@@ -81,10 +81,12 @@ def _segment_topk(indptr, cols, keys, K):
     return sel, cnt
 
 
-def itemknn_fit(X: sp.csr_matrix, K: int, rows=None):
-    """Cosine ItemKNN. Returns dict(idx int32[R,K] (-1 pad), val float64[R,K] (0 pad), nnz int32[R], deg int64[I]).
+def itemknn_fit(X: sp.csr_matrix, K: int, rows=None, similarity: str = "cosine", pop_discount=None):
+    """ItemKNN (cosine, or conditional probability nearest_neighbour.py:22-66 on the binarised matrix).
+    Returns dict(idx int32[R,K] (-1 pad), val float64[R,K] (0 pad), nnz int32[R], deg int64[I]).
 
-    Rows of ``idx``/``val`` are in rank order (best neighbour first).
+    Rows of ``idx``/``val`` are in rank order (best neighbour first).  Conditional probability:
+    sim(i,j) = c_ij / (c_i * c_j^alpha), alpha = pop_discount or 0; key = fl(c_ij) * c_j^-alpha, value = key / c_i.
     """
     Xb = binarize(X)
     n_items = Xb.shape[1]
@@ -101,11 +103,23 @@ def itemknn_fit(X: sp.csr_matrix, K: int, rows=None):
     indptr = np.zeros(R + 1, dtype=np.int64)
     np.cumsum(cnt, out=indptr[1:])
     gi, gj, gc = gi[off], gj[off], gc[off]
-    with np.errstate(divide="ignore"):
-        inv = 1.0 / c.astype(np.float64)
-    key = (gc * gc).astype(np.float64) * inv[gj]
+    if similarity == "cosine":
+        with np.errstate(divide="ignore"):
+            inv = 1.0 / c.astype(np.float64)
+        key = (gc * gc).astype(np.float64) * inv[gj]
+    elif similarity == "conditional_probability":
+        alpha = float(pop_discount or 0.0)
+        colw = np.zeros(n_items)
+        nz = c > 0
+        colw[nz] = 1.0 if alpha == 0.0 else np.power(c[nz].astype(np.float64), -alpha)
+        key = gc.astype(np.float64) * colw[gj]
+    else:
+        raise ValueError(similarity)
     sel, nsel = _segment_topk(indptr, gj, key, K)
-    val = gc[sel].astype(np.float64) / np.sqrt(c[gi[sel]].astype(np.float64) * c[gj[sel]].astype(np.float64))
+    if similarity == "cosine":
+        val = gc[sel].astype(np.float64) / np.sqrt(c[gi[sel]].astype(np.float64) * c[gj[sel]].astype(np.float64))
+    else:
+        val = key[sel] / c[gi[sel]].astype(np.float64)
     idx = np.full((R, K), -1, dtype=np.int32)
     out = np.zeros((R, K), dtype=np.float64)
     r = np.repeat(np.arange(R), nsel)

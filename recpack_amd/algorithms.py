@@ -198,9 +198,9 @@ def topk_arrays_to_csr(idx: np.ndarray, val: np.ndarray, nnz: np.ndarray, n_cols
 class ItemKNN(TopKItemSimilarityMatrixAlgorithm):
     """Item K Nearest Neighbours (recpack/algorithms/nearest_neighbour.py:114-224) on MI355X.
 
-    ``similarity="cosine"`` with binary input is the accelerated path.  ``normalize_sim`` is a host
-    epilogue on the I x K result.  ``normalize_X`` and ``similarity="conditional_probability"`` are the
-    weighted-Gram variants of SURVEY.md §8(f) and raise ``NotImplementedError`` until they land.
+    ``similarity="cosine"`` and ``"conditional_probability"`` (with ``pop_discount``) run on the GPU from the same
+    integer Gram.  ``normalize_sim`` is a host epilogue on the I x K result.  ``normalize_X`` (a weighted Gram,
+    SURVEY.md §8(f)) raises ``NotImplementedError`` until it lands.
     """
 
     SUPPORTED_SIMILARITIES = ["cosine", "conditional_probability"]
@@ -226,13 +226,15 @@ class ItemKNN(TopKItemSimilarityMatrixAlgorithm):
         self.normalize_sim = normalize_sim
 
     def _fit(self, X: sp.csr_matrix) -> None:
-        if self.similarity != "cosine" or self.normalize_X:
-            raise NotImplementedError(
-                "recpack_amd.ItemKNN: only similarity='cosine' with normalize_X=False runs on the GPU in this build"
-            )
+        if self.normalize_X:
+            raise NotImplementedError("recpack_amd.ItemKNN: normalize_X=True is not part of this build yet")
         ctx, dX = self._upload(X)
         try:
-            model = _lib.itemknn_fit(ctx, dX, int(self.K))
+            if self.similarity == "cosine":
+                model = _lib.itemknn_fit(ctx, dX, int(self.K))
+            else:  # nearest_neighbour.py:213-215: `if pop_discount:` - None and 0 mean no discount
+                model = _lib.itemknn_fit(ctx, dX, int(self.K), similarity=_lib.SIM_CONDITIONAL_PROBABILITY,
+                                         pop_discount=float(self.pop_discount or 0.0))
             idx, val, nnz = model.topk_download()
         finally:
             dX.close()

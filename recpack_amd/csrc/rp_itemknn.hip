@@ -13,6 +13,8 @@
 //
 // Rows whose user list is long are cut into slices (partial tiles summed by a second launch), rows are
 // handed out heaviest first through a ticket counter to persistent workgroups (one per CU).
+#include <math.h>
+
 #include <algorithm>
 
 #include "rp_common.h"
@@ -33,10 +35,11 @@ struct rp_fit_params {
   const int32_t* xt_ptr;
   const int32_t* xt_idx;
   const int32_t* deg;
-  const double* inv_deg;
+  const double* inv_deg;   // column weight of the key: 1/c_j (cosine) or c_j^-alpha (conditional probability)
   const int32_t* tile_ptr;
   int n_items, n_tiles, tile_w, K, row_begin;
   int nnz;
+  int key_pow;             // 2 = cosine, 1 = conditional probability
   const rp_task* tasks;
   const int32_t* n_tasks;
   int32_t* ticket;
@@ -67,10 +70,13 @@ struct rp_fit_params {
 #define RP_STAMP(ph) do { } while (0)
 #endif
 
-__device__ __forceinline__ uint64_t rp_fit_key(uint32_t c, double inv) {
-  // k = fl(c*c) * inv in [2^-31, 2^32): the exponent offset from 992 fits 6 bits; shift the 58
+// Selection key of entry (i, j), monotone in the similarity for a fixed row i:
+//   cosine (pw = 2):                 fl(c*c) * fl(1/c_j)        (nearest_neighbour.py:69-84)
+//   conditional probability (pw = 1): fl(c) * c_j^-alpha         (nearest_neighbour.py:22-66; alpha = pop_discount)
+__device__ __forceinline__ uint64_t rp_fit_key(uint32_t c, double colw, int pw = 2) {
+  // k in [2^-31, 2^32): the exponent offset from 992 fits 6 bits; shift the 58
   // significant bits to the top so that the first radix level already resolves 6 mantissa bits.
-  double k = (double)((uint64_t)c * (uint64_t)c) * inv;
+  double k = (double)((uint64_t)c * (uint64_t)(pw == 2 ? c : 1u)) * colw;
   uint64_t b = (uint64_t)__double_as_longlong(k);
   return (b - (992ull << 52)) << 6;
 }
@@ -81,7 +87,7 @@ struct rp_dense_src {
   static constexpr bool PACK4 = BYTES;
   const uint32_t* acc;
   const double* inv_deg;
-  int t0, row, n_cols;
+  int t0, row, n_cols, key_pow;
   __device__ __forceinline__ uint32_t word(int wi) const { return acc[wi]; }
   __device__ __forceinline__ int excluded_slot() const { return row - t0; }
   __device__ __forceinline__ uint32_t count(int w) const {
@@ -89,7 +95,7 @@ struct rp_dense_src {
     return acc[w];
   }
   __device__ __forceinline__ bool valid(int w) const { return count(w) != 0u && (t0 + w) != row; }
-  __device__ __forceinline__ uint64_t key(int w) const { return rp_fit_key(count(w), inv_deg[t0 + w]); }
+  __device__ __forceinline__ uint64_t key(int w) const { return rp_fit_key(count(w), inv_deg[t0 + w], key_pow); }
   __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)(t0 + w); }
 };
 
@@ -295,7 +301,7 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
       continue;
     }
     // ---- select
-    rp_dense_src<BYTES> src{acc, P.inv_deg, t0, row, n_cols};
+    rp_dense_src<BYTES> src{acc, P.inv_deg, t0, row, n_cols, P.key_pow};
     const int kp = rp_select_topk<NTHR>(src, n_cols, P.K, sel, SEG);
     RP_STAMP(3);
     if (BYTES && kp < 0) {
@@ -318,7 +324,8 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
       rp_select_emit<NTHR>(n_cols, sel, [&](int pos, int w) {
         const int j = t0 + w;
         oi[pos] = j;
-        ov[pos] = (double)src.count(w) / sqrt(ci * (double)P.deg[j]);
+        ov[pos] = (P.key_pow == 2) ? (double)src.count(w) / sqrt(ci * (double)P.deg[j])
+                                   : ((double)src.count(w) * P.inv_deg[j]) / ci;
       }, SEG);
       if (tid == 0) P.out_nnz[rl] = kp;
     } else {
@@ -344,9 +351,9 @@ struct rp_list_src {
   const int32_t* col_;
   const uint32_t* cnt_;
   const double* inv_deg;
-  int n;
+  int n, key_pow;
   __device__ __forceinline__ bool valid(int w) const { return w < n; }
-  __device__ __forceinline__ uint64_t key(int w) const { return rp_fit_key(cnt_[w], inv_deg[col_[w]]); }
+  __device__ __forceinline__ uint64_t key(int w) const { return rp_fit_key(cnt_[w], inv_deg[col_[w]], key_pow); }
   __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)col_[w]; }
 };
 
@@ -356,7 +363,7 @@ struct rp_merge_params {
   const int32_t* cand_nnz;
   const int32_t* deg;
   const double* inv_deg;
-  int n_tiles, K, row_begin, n_rows;
+  int n_tiles, K, row_begin, n_rows, key_pow;
   int32_t* out_idx;
   double* out_val;
   int32_t* out_nnz;
@@ -394,7 +401,7 @@ __global__ void __launch_bounds__(RP_MERGE_THREADS) k_itemknn_merge(rp_merge_par
       }
     }
     __syncthreads();
-    rp_list_src src{lcol, lcnt, P.inv_deg, n};
+    rp_list_src src{lcol, lcnt, P.inv_deg, n, P.key_pow};
     const int kp = rp_select_topk<RP_MERGE_THREADS>(src, n, K, sel);
     int32_t* oi = P.out_idx + (int64_t)rl * K;
     double* ov = P.out_val + (int64_t)rl * K;
@@ -402,7 +409,7 @@ __global__ void __launch_bounds__(RP_MERGE_THREADS) k_itemknn_merge(rp_merge_par
     rp_select_emit<RP_MERGE_THREADS>(n, sel, [&](int pos, int w) {
       const int j = lcol[w];
       oi[pos] = j;
-      ov[pos] = (double)lcnt[w] / sqrt(ci * (double)P.deg[j]);
+      ov[pos] = (P.key_pow == 2) ? (double)lcnt[w] / sqrt(ci * (double)P.deg[j]) : ((double)lcnt[w] * P.inv_deg[j]) / ci;
     });
     if (tid == 0) P.out_nnz[rl] = kp;
   }
@@ -597,7 +604,7 @@ static size_t rp_fit_lds_bytes(int tile_w) { return (size_t)tile_w * 4 + rp_sele
 
 // Shared driver of K1-K3 (out != NULL: neighbour lists) and K4 (dense != NULL: dense f32 Gram rows + lambda).
 static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K, rphip_model** out,
-                        float* dense, int64_t dense_ld, float diag_add) {
+                        float* dense, int64_t dense_ld, float diag_add, const double* colw = nullptr, int key_pow = 2) {
   if (!ctx || !X || (!out && !dense)) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (out) *out = nullptr;
   if (row_begin < 0 || row_end > X->n_items || row_begin > row_end)
@@ -709,7 +716,8 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   P.xt_ptr = X->xt_ptr;
   P.xt_idx = X->xt_idx;
   P.deg = X->deg;
-  P.inv_deg = X->inv_deg;
+  P.inv_deg = colw ? colw : X->inv_deg;
+  P.key_pow = key_pow;
   P.tile_ptr = X->tile_ptr;
   P.n_items = (int)X->n_items;
   P.nnz = (int)X->nnz;
@@ -819,7 +827,8 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
     M.cand_cnt = cand_cnt;
     M.cand_nnz = cand_nnz;
     M.deg = X->deg;
-    M.inv_deg = X->inv_deg;
+    M.inv_deg = colw ? colw : X->inv_deg;
+    M.key_pow = key_pow;
     M.n_tiles = T;
     M.K = Keff;
     M.row_begin = (int)row_begin;
@@ -854,6 +863,29 @@ extern "C" int rphip_itemknn_fit(rphip_ctx* ctx, const rphip_csr* X, int64_t row
                                  rphip_model** out) {
   if (!out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   return rp_gram_core(ctx, X, row_begin, row_end, K, out, nullptr, 0, 0.0f);
+}
+
+extern "C" int rphip_itemknn_fit_ex(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K,
+                                    int32_t similarity, double pop_discount, rphip_model** out) {
+  if (!ctx || !X || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if (similarity == RPHIP_SIM_COSINE) return rp_gram_core(ctx, X, row_begin, row_end, K, out, nullptr, 0, 0.0f);
+  if (similarity != RPHIP_SIM_CONDITIONAL_PROBABILITY) RP_FAIL(RPHIP_EINVAL, "unknown similarity %d", similarity);
+  if (!(pop_discount >= 0.0 && pop_discount <= 1.0)) RP_FAIL(RPHIP_EINVAL, "pop_discount must be in [0, 1] (got %g)", pop_discount);
+  RP_TRY(rp_set_device(ctx));
+  // column weights c_j^-alpha on the HOST with the C library's pow - the same function numpy calls, so that the
+  // selection keys are bit-identical to the restated reference (a device pow could differ in the last bit)
+  const int64_t n = X->n_items;
+  std::vector<int32_t> deg((size_t)std::max<int64_t>(n, 1));
+  std::vector<double> w((size_t)std::max<int64_t>(n, 1));
+  if (n > 0) RP_HIP(hipMemcpyAsync(deg.data(), X->deg, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  RP_HIP(hipStreamSynchronize(ctx->stream));
+  for (int64_t j = 0; j < n; ++j)
+    w[(size_t)j] = deg[(size_t)j] > 0 ? (pop_discount == 0.0 ? 1.0 : pow((double)deg[(size_t)j], -pop_discount)) : 0.0;
+  double* dw = nullptr;
+  RP_TRY(rp_scratch(ctx, 6, (size_t)std::max<int64_t>(n, 1) * 8, (void**)&dw));
+  if (n > 0) RP_HIP(hipMemcpyAsync(dw, w.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  RP_HIP(hipStreamSynchronize(ctx->stream));
+  return rp_gram_core(ctx, X, row_begin, row_end, K, out, nullptr, 0, 0.0f, dw, 1);
 }
 
 int rp_gram_dense(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, float* G, int64_t ld, float diag_add) {

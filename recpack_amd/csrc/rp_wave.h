@@ -6,7 +6,7 @@
 // radix select (8-bit digits, 256-bin LDS histogram, boundary group of <= 64 resolved by ranking in registers).
 // After a cut the threshold is the K-th key, and a later candidate must be STRICTLY larger to enter: it has a
 // larger column than everything in the pool, so on equal keys it loses - which is exactly the order
-// "larger key first, then smaller column" of recpack/util.py:50-96 as restated by the oracle.
+// "larger key first, then smaller column" of recpack/util.py:50-96 as DESIGN.md restates it.
 #pragma once
 
 #include "rp_common.h"

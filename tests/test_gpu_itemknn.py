@@ -313,3 +313,48 @@ def test_gpu_generator_matches_numpy():
     ip, ix = powerlaw_csr(20000, 3000, 0.003, seed=5, device=torch.device("cuda", 0))
     np.testing.assert_array_equal(ip.cpu().numpy(), ref.indptr)
     np.testing.assert_array_equal(ix.cpu().numpy(), ref.indices)
+
+
+@pytest.mark.parametrize("name", ["ref_itemknn_data_condprob", "ref_itemknn_data_condprob_pd1.0", "ref_itemknn_data_condprob_pd0.2",
+                                  "ref_itemknn_data_condprob_pd0.5", "syn_itemknn_condprob_2000x500", "syn_itemknn_condprob0_2000x500"])
+def test_fit_conditional_probability_golden(hip, name):
+    from recpack_amd.algorithms import to_binary_csr
+
+    _lib, ctx = hip
+    g = load_golden(name)
+    X = to_binary_csr(csr_from(g, "X"))
+    cand = csr_from(g, "cos")
+    pd = float(g["pop_discount"])
+    dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
+    for K in g["Ks"]:
+        K = int(K)
+        m = _lib.itemknn_fit(ctx, dX, K, similarity=_lib.SIM_CONDITIONAL_PROBABILITY, pop_discount=pd)
+        idx, val, nnz = m.topk_download()
+        ref = csr_from(g, f"S{K}")
+        bad, exact = tie_aware_topk(cand, ref, idx, nnz, eps=1e-9)
+        assert not bad, (name, K, bad[:5])
+        topk_vals_close(ref, idx, val, nnz, rtol=1e-11)
+        assert_same_as_oracle(idx, val, nnz, onp.itemknn_fit(X, m.K, similarity="conditional_probability", pop_discount=pd))
+
+
+def test_conditional_probability_dropin_and_big(hip):
+    # recpack/tests/test_algorithms/test_nearest_neighbour.py:127-181 through the drop-in class
+    from recpack_amd import ItemKNN
+    from recpack_amd.synth import powerlaw_csr
+
+    _lib, ctx = hip
+    g = load_golden("ref_itemknn_data")
+    data = csr_from(g, "X")
+    algo = ItemKNN(K=2, similarity="conditional_probability").fit(data)
+    np.testing.assert_almost_equal(algo.similarity_matrix_.toarray(), [[0, 1 / 2, 2 / 2], [1 / 2, 0, 2 / 2], [2 / 3, 2 / 3, 0]])
+    for pd in (1, 0.2, 0.5):
+        algo = ItemKNN(K=2, similarity="conditional_probability", pop_discount=pd).fit(data)
+        expected = np.array([[0, 1 / (2 * 2**pd), 2 / (2 * 3**pd)], [1 / (2 * 2**pd), 0, 2 / (2 * 3**pd)],
+                             [2 / (3 * 2**pd), 2 / (3 * 2**pd), 0]])
+        np.testing.assert_almost_equal(algo.similarity_matrix_.toarray(), expected)
+    # several column tiles, sliced rows, light and heavy rows
+    X = powerlaw_csr(30000, 30000, 0.001, seed=41).to_scipy()
+    dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
+    m = _lib.itemknn_fit(ctx, dX, 30, similarity=_lib.SIM_CONDITIONAL_PROBABILITY, pop_discount=0.3)
+    idx, val, nnz = m.topk_download()
+    assert_same_as_oracle(idx, val, nnz, onp.itemknn_fit(X, 30, similarity="conditional_probability", pop_discount=0.3))

@@ -127,3 +127,31 @@ def test_ease_prune():
     g = load_golden("ref_ease_prune")
     out = onp.ease_prune(g["before"], float(g["density"]))
     np.testing.assert_array_equal(out, g["after"])
+
+
+CONDPROB_CASES = ["ref_itemknn_data_condprob", "ref_itemknn_data_condprob_pd1.0", "ref_itemknn_data_condprob_pd0.2",
+                  "ref_itemknn_data_condprob_pd0.5", "syn_itemknn_condprob_2000x500", "syn_itemknn_condprob0_2000x500"]
+
+
+@pytest.mark.parametrize("name", CONDPROB_CASES)
+def test_itemknn_conditional_probability_matches_reference(name):
+    # recpack/algorithms/nearest_neighbour.py:22-66 through ItemKNN(similarity="conditional_probability")
+    g = load_golden(name)
+    X = csr_from(g, "X")
+    cand = csr_from(g, "cos")
+    pd = float(g["pop_discount"])
+    for K in g["Ks"]:
+        K = int(K)
+        ref = csr_from(g, f"S{K}")
+        out = onp.itemknn_fit(X, K, similarity="conditional_probability", pop_discount=pd)
+        bad, exact = tie_aware_topk(cand, ref, out["idx"], out["nnz"], eps=1e-9)
+        assert not bad, (name, K, bad[:5])
+        topk_vals_close(ref, out["idx"], out["val"], out["nnz"], rtol=1e-11)
+
+
+def test_conditional_probability_analytic():
+    # recpack/tests/test_algorithms/test_nearest_neighbour.py:127-152
+    g = load_golden("ref_itemknn_data_condprob")
+    out = onp.itemknn_fit(csr_from(g, "X"), 2, similarity="conditional_probability")
+    S = onp.topk_to_csr(out["idx"], out["val"], out["nnz"], 3).toarray()
+    np.testing.assert_almost_equal(S, [[0, 1 / 2, 2 / 2], [1 / 2, 0, 2 / 2], [2 / 3, 2 / 3, 0]])
