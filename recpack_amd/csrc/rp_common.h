@@ -96,6 +96,7 @@ struct rphip_model {
   double* val = nullptr;    // [rows*K]
   float* val32 = nullptr;   // [rows*K] (predict operand)
   int2* pairs = nullptr;    // [rows*K] {column, float bits}: what the wave-per-user predict kernel streams
+  uint16_t* toff = nullptr; // [n_items * (n_wt + 1)] per-row offsets of the predict column tiles (built on first use)
   int32_t* nnz = nullptr;   // [rows]
   bool cols_sorted = false; // every row's columns strictly increasing (checked when the model is finalised)
   // DENSE

@@ -577,6 +577,7 @@ extern "C" int rphip_model_destroy(rphip_model* m) {
   if (m->val) hipFree(m->val);
   if (m->val32) hipFree(m->val32);
   if (m->pairs) hipFree(m->pairs);
+  if (m->toff) hipFree(m->toff);
   if (m->nnz) hipFree(m->nnz);
   if (m->B) hipFree(m->B);
   delete m;

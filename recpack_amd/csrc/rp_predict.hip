@@ -211,33 +211,43 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_merge(const int32_t
 
 
 // ---- K8, wave-per-user form ------------------------------------------------------------------------
-// One WAVE owns one user: no workgroup barriers, PW_WAVES independent users per workgroup and ~12 per CU.
-//   * lane l holds a cursor into the (column-sorted) neighbour list of the user's l-th history item
-//     (PW_NB register sets => up to 64*PW_NB history items; heavier users take the workgroup kernel);
-//   * the item axis is walked in tiles of PW_WT columns; each lane adds its row's entries that fall into the
-//     tile to the wave's private f32 LDS tile (LDS float atomics; entries are prefetched two ahead);
-//   * the tile is then scanned once (16 B per lane) and cleared; a lane first compares the maximum of its four
-//     scores with the running threshold, so after warm-up almost every step is a read, a clear and one compare;
-//     scores above the threshold enter the wave's pool in column order (rp_wave.h), which cuts itself to the
-//     Kp best with an exact radix select when it is full;
-//   * at the end the pool is cut to Kp, ranked by column and written out.
+// One WAVE owns one user: no workgroup barriers, one user per 64-thread workgroup and ~7 in flight per CU.
+//   * the item axis is walked in tiles of PW_WT columns; toff[i][t] (built once per model) is the offset of the
+//     first entry of neighbour list i with column >= t*PW_WT, so for a tile lane l knows the slice of the l-th
+//     history item's (column-sorted) list that falls into it;
+//   * the slices of the 64 history items of a batch are cut into chunks of four entries and chunk c goes to lane
+//     c % 64 (two 16-byte loads per chunk): the loads are coalesced per list and every lane is busy whatever the
+//     history length; histories longer than 64 take several batches per tile;
+//   * scores are accumulated in 64-bit FIXED POINT (f32 similarity * 2^50, exact for every similarity >= 2^-27) with
+//     u64 LDS atomics: measured on MI355X an LDS f32 atomic add sustains 0.33 per clock per CU, u32/u64 integer adds
+//     4.4-4.8 (tools/lds_atomic_bench.hip).  The integer sum is exact and independent of the order of the adds, so
+//     predict is bit-reproducible;
+//   * a 2048-bit dirty map (one word per lane, LDS atomic OR) records the touched columns; after the tile's adds
+//     each lane walks the set bits of its word, reads and clears the sums and offers them to the wave's running
+//     top-Kp pool (rp_wave.h: exact radix-select cuts; admission is exact for any arrival order);
+//   * at the end the pool is cut to Kp, ranked by column and written out (score = (float)(sum * 2^-50)).
 constexpr int PW_WT = 2048;
-constexpr int PW_NB = 4;        // 64*PW_NB history items per user at most (cursors live in registers)
-constexpr int PW_WAVES = 4;
+constexpr int PW_CH = 4;        // entries per chunk (32 bytes)
 constexpr int PW_UCH = 4;       // users per ticket
 constexpr int PW_KP_MAX = 384;  // pool capacity = Kp rounded up + 128 <= 512
+constexpr int PW_FIX_SHIFT = 50;
 
 __host__ __device__ constexpr int rp_pw_cap(int Kp) { return ((Kp + 63) / 64) * 64 + 128; }
-__host__ __device__ constexpr size_t rp_pw_wave_bytes(int Kp) {
-  return (size_t)PW_WT * 4 + (size_t)rp_pw_cap(Kp) * 8 + 1024 + 128;
+__host__ __device__ constexpr size_t rp_pw_wave_bytes(int Kp) { return (size_t)PW_WT * 8 + 256 + (size_t)rp_pw_cap(Kp) * 12 + 1024 + 128; }
+
+// f32 bits (positive, normal) -> value * 2^50 as u64, by integer arithmetic (exact when the value is >= 2^-27)
+__device__ __forceinline__ unsigned long long rp_f32_to_fix(int bits) {
+  const unsigned long long m = (unsigned long long)((bits & 0x7fffff) | 0x800000);
+  const int sh = ((bits >> 23) & 0xff) - 127 - 23 + PW_FIX_SHIFT;
+  return sh >= 0 ? (m << sh) : (m >> (-sh));
 }
 
 struct rp_pw_params {
   const int32_t* x_ptr;
   const int32_t* x_idx;
   const int2* pairs;
-  const int32_t* s_nnz;
-  int n_items, K, Kp, exclude_history, user_begin, n_users;
+  const uint16_t* toff;  // [I * (n_wt + 1)]
+  int n_items, n_wt, K, Kp, exclude_history, user_begin, n_users;
   int32_t* ticket;
   int32_t* out_idx;
   float* out_val;
@@ -246,37 +256,33 @@ struct rp_pw_params {
 };
 
 #ifdef RP_STAMPS
-#define PW_STAMP(ph)                                                   \
-  do {                                                                 \
-    if (lane == 0) {                                                   \
-      unsigned long long _t = __builtin_amdgcn_s_memtime();            \
-      atomicAdd(&P.stamps[ph], _t - t_last);                           \
-      t_last = _t;                                                     \
-    }                                                                  \
-  } while (0)
+#define PW_STAMP(ph) do { unsigned long long _t = __builtin_amdgcn_s_memtime(); t_ph[ph] += _t - t_last; t_last = _t; } while (0)
+#define PW_FLUSH() do { if (lane == 0) { for (int _p = 0; _p < 4; ++_p) atomicAdd(&P.stamps[_p], t_ph[_p]); } t_ph[0] = t_ph[1] = t_ph[2] = t_ph[3] = 0; } while (0)
 #else
 #define PW_STAMP(ph) do { } while (0)
+#define PW_FLUSH() do { } while (0)
 #endif
 
-__global__ void __launch_bounds__(PW_WAVES * 64) k_predict_wave(rp_pw_params P) {
+__global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int K = P.K, Kp = P.Kp;
+  const int lane = threadIdx.x;
+  const int K = P.K, Kp = P.Kp, NT = P.n_wt;
   const int cap = rp_pw_cap(Kp);
-  char* base = smem + (size_t)wave * rp_pw_wave_bytes(Kp);
-  float* acc = reinterpret_cast<float*>(base);
-  float4* acc4 = reinterpret_cast<float4*>(acc);
-  rp_wpool<uint32_t> pool;
-  pool.key = reinterpret_cast<uint32_t*>(base + (size_t)PW_WT * 4);
-  pool.pay = pool.key + cap;
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem);
+  volatile uint32_t* dirty = reinterpret_cast<volatile uint32_t*>(smem + (size_t)PW_WT * 8);
+  rp_wpool<uint64_t> pool;
+  pool.key = reinterpret_cast<uint64_t*>(smem + (size_t)PW_WT * 8 + 256);
+  pool.pay = reinterpret_cast<uint32_t*>(pool.key + cap);
   pool.hist = pool.pay + cap;
   pool.gidx = reinterpret_cast<uint16_t*>(pool.hist + 256);
-  const uint64_t lt_mask = (1ull << lane) - 1ull;
-  const int2 SENT = make_int2(0x7fffffff, 0);
+  typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));
+  const int* pairs_i = reinterpret_cast<const int*>(P.pairs);
 
-  for (int i = lane; i < PW_WT / 4; i += 64) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = lane; i < PW_WT; i += 64) acc[i] = 0ull;
+  dirty[lane] = 0u;
 #ifdef RP_STAMPS
   unsigned long long t_last = __builtin_amdgcn_s_memtime();
+  unsigned long long t_ph[4] = {0, 0, 0, 0};
 #endif
 
   while (true) {
@@ -288,141 +294,189 @@ __global__ void __launch_bounds__(PW_WAVES * 64) k_predict_wave(rp_pw_params P) 
     for (int ul = ubase; ul < uend; ++ul) {
       const int u = P.user_begin + ul;
       const int hs = P.x_ptr[u], he = P.x_ptr[u + 1];
-      const int d = he - hs;
-      if (d <= 0 || d > 64 * PW_NB) continue;  // heavy users: workgroup kernel
-      // per-lane cursors into the neighbour lists of history items lane, lane+64, ... ; entries prefetched two ahead
-      int cur[PW_NB], end[PW_NB];
-      int2 e0[PW_NB], e1[PW_NB], e2[PW_NB];
-#pragma unroll
-      for (int b = 0; b < PW_NB; ++b) {
-        const int h = hs + b * 64 + lane;
-        cur[b] = 0;
-        end[b] = 0;
-        if (h < he) {
-          const int it = P.x_idx[h];
-          cur[b] = it * K;
-          end[b] = cur[b] + P.s_nnz[it];
-        }
-        e0[b] = (cur[b] < end[b]) ? P.pairs[cur[b]] : SENT;
-        e1[b] = (cur[b] + 1 < end[b]) ? P.pairs[cur[b] + 1] : SENT;
-        e2[b] = (cur[b] + 2 < end[b]) ? P.pairs[cur[b] + 2] : SENT;
-      }
+      if (he <= hs) continue;
       pool.n = 0;
-      pool.tau = 0;  // scores are positive: bits of a positive float order like the float
+      pool.tau = 0;
+      pool.tau_col = 0;
       PW_STAMP(0);
 
-      for (int t0 = 0; t0 < P.n_items; t0 += PW_WT) {
-        const int t_end = min(t0 + PW_WT, P.n_items);
-        bool touched = false;
+      // The first batch of 64 history items is software-pipelined over the tiles: its tile offsets are loaded two
+      // tiles ahead and the entries of tile t+1 are in flight while tile t is added, scanned and pooled.  Without
+      // this the three dependent loads (item id -> offsets -> entries) are paid once per tile.
+      const int it0 = (hs + lane < he) ? P.x_idx[hs + lane] : -1;
+      const uint16_t* to0 = P.toff + (long long)max(it0, 0) * (NT + 1);
+      int o_a = (it0 >= 0) ? (int)to0[0] : 0;              // offsets of tiles t+1, t+2, t+3 relative to the loop below
+      int o_b = (it0 >= 0) ? (int)to0[1] : 0;
+      int o_c = (it0 >= 0 && NT >= 2) ? (int)to0[2] : o_b;
+      // state of the prepared (next) tile's first chunk step
+      int p_s = 0, p_len = 0, p_choff = 0, p_nchunks = 0, p_n = 0;
+      v4i_a4 p_a = (v4i_a4){0, 0, 0, 0}, p_b = p_a;
+      auto prepare = [&](int oa, int ob) {
+        p_s = (it0 >= 0) ? it0 * K + oa : 0;
+        p_len = (it0 >= 0) ? ob - oa : 0;
+        const int nch = (p_len + PW_CH - 1) / PW_CH;
+        const int inc = rp_wave_incl_scan(nch, lane);
+        p_choff = inc - nch;
+        p_nchunks = __shfl(inc, 63);
+        int lo = 0;
 #pragma unroll
-        for (int b = 0; b < PW_NB; ++b) {
-          if (b * 64 >= d) break;
-          while (__any(e0[b].x < t_end)) {
-            if (e0[b].x < t_end) {
-              atomicAdd(&acc[e0[b].x - t0], __int_as_float(e0[b].y));
-              e0[b] = e1[b];
-              e1[b] = e2[b];
-              cur[b]++;
-              e2[b] = (cur[b] + 2 < end[b]) ? P.pairs[cur[b] + 2] : SENT;
+        for (int step = 32; step > 0; step >>= 1) {
+          const int v = __shfl(p_choff, lo + step);
+          if (v <= lane) lo += step;
+        }
+        const int us = __shfl(p_s, lo), ulen = __shfl(p_len, lo), co = __shfl(p_choff, lo);
+        const int k0 = (lane - co) * PW_CH;
+        p_n = (lane < p_nchunks) ? min(PW_CH, ulen - k0) : 0;
+        if (p_n > 0) {
+          const int* src = pairs_i + 2 * (long long)(us + k0);
+          p_a = *reinterpret_cast<const v4i_a4*>(src);
+          p_b = *reinterpret_cast<const v4i_a4*>(src + 4);
+        }
+      };
+      auto add_chunk = [&](int n, const v4i_a4& a, const v4i_a4& b, int t0) {
+        const int ec[4] = {a.x, a.z, b.x, b.z};
+        const int ev[4] = {a.y, a.w, b.y, b.w};
+#pragma unroll
+        for (int e = 0; e < PW_CH; ++e) {
+          if (e < n) {
+            const int j = ec[e] - t0;
+            atomicAdd(&acc[j], rp_f32_to_fix(ev[e]));
+            atomicOr((uint32_t*)&dirty[j >> 5], 1u << (j & 31));
+          }
+        }
+      };
+      prepare(o_a, o_b);  // tile 0
+
+      for (int t = 0; t < NT; ++t) {
+        const int t0 = t * PW_WT;
+        // current tile = what was prepared; then prepare tile t+1 and fetch the offset of tile t+3
+        const int c_s = p_s, c_len = p_len, c_choff = p_choff, c_nchunks = p_nchunks, c_n = p_n;
+        const v4i_a4 c_a = p_a, c_b = p_b;
+        o_a = o_b;
+        o_b = o_c;
+        if (t + 3 <= NT && it0 >= 0) o_c = (int)to0[t + 3];
+        if (t + 1 < NT) prepare(o_a, o_b);
+        bool touched = c_nchunks > 0;
+        // ---- first batch: the prefetched first step, then any further steps
+        add_chunk(c_n, c_a, c_b, t0);
+        for (int c0 = 64; c0 < c_nchunks; c0 += 64) {
+          const int c = c0 + lane;
+          int lo = 0;
+#pragma unroll
+          for (int step = 32; step > 0; step >>= 1) {
+            const int v = __shfl(c_choff, lo + step);
+            if (v <= c) lo += step;
+          }
+          const int us = __shfl(c_s, lo), ulen = __shfl(c_len, lo), co = __shfl(c_choff, lo);
+          const int k0 = (c - co) * PW_CH;
+          const int n = (c < c_nchunks) ? min(PW_CH, ulen - k0) : 0;
+          v4i_a4 a = (v4i_a4){0, 0, 0, 0}, b2 = a;
+          if (n > 0) {
+            const int* src = pairs_i + 2 * (long long)(us + k0);
+            a = *reinterpret_cast<const v4i_a4*>(src);
+            b2 = *reinterpret_cast<const v4i_a4*>(src + 4);
+          }
+          add_chunk(n, a, b2, t0);
+        }
+        // ---- histories longer than 64 items: the remaining batches, not pipelined
+        for (int hb = hs + 64; hb < he; hb += 64) {
+          const int h = hb + lane;
+          int s = 0, len = 0;
+          if (h < he) {
+            const int it = P.x_idx[h];
+            const uint16_t* to = P.toff + (long long)it * (NT + 1) + t;
+            const int o0 = to[0], o1 = to[1];
+            s = it * K + o0;
+            len = o1 - o0;
+          }
+          const int nch = (len + PW_CH - 1) / PW_CH;
+          const int inc = rp_wave_incl_scan(nch, lane);
+          const int choff = inc - nch;
+          const int n_chunks = __shfl(inc, 63);
+          if (n_chunks > 0) touched = true;
+          for (int c0 = 0; c0 < n_chunks; c0 += 64) {
+            const int c = c0 + lane;
+            int lo = 0;  // owner = largest lane l with choff[l] <= c
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1) {
+              const int v = __shfl(choff, lo + step);
+              if (v <= c) lo += step;
             }
-            touched = true;
+            const int us = __shfl(s, lo), ulen = __shfl(len, lo), co = __shfl(choff, lo);
+            const int k0 = (c - co) * PW_CH;
+            const int n = (c < n_chunks) ? min(PW_CH, ulen - k0) : 0;
+            v4i_a4 a = (v4i_a4){0, 0, 0, 0}, b2 = a;
+            if (n > 0) {
+              const int* src = pairs_i + 2 * (long long)(us + k0);
+              a = *reinterpret_cast<const v4i_a4*>(src);      // the pairs array is padded: reading past
+              b2 = *reinterpret_cast<const v4i_a4*>(src + 4);  // the slice's end is harmless
+            }
+            add_chunk(n, a, b2, t0);
           }
         }
         PW_STAMP(1);
         if (!touched) continue;
         if (P.exclude_history) {
           for (int h = hs + lane; h < he; h += 64) {
-            const int it = P.x_idx[h];
-            if (it >= t0 && it < t_end) acc[it - t0] = 0.0f;
+            const int j = P.x_idx[h] - t0;
+            if ((unsigned)j < (unsigned)PW_WT) acc[j] = 0ull;  // the dirty bit stays: a zero sum is skipped below
           }
         }
         __builtin_amdgcn_wave_barrier();
-        for (int it = 0; it < PW_WT / 256; ++it) {
-          const int q = it * 64 + lane;
-          typedef float f32x4_t __attribute__((ext_vector_type(4)));
-          volatile f32x4_t* accv = reinterpret_cast<volatile f32x4_t*>(acc);
-          const f32x4_t v = accv[q];
-          const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
-          if (mx != 0.0f) accv[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-          const float tau_f = __uint_as_float(pool.tau);
-          if (!__any(mx > tau_f)) continue;
-          // column order inside the step is lane-major, component-minor: push the four components of all lanes
-          // as ONE ordered batch (positions from four ballots) so that the pool's strict threshold stays exact
-          const float vv[4] = {v.x, v.y, v.z, v.w};
-          bool keep[4];
-          uint64_t m[4];
-          int add = 0;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            keep[c] = vv[c] > tau_f;
-            m[c] = __ballot(keep[c]);
-            add += __popcll(m[c]);
+        // ---- offer the touched columns to the pool: lane l walks the set bits of dirty word l
+        uint32_t w = dirty[lane];
+        dirty[lane] = 0u;
+        while (__any(w != 0u)) {
+          const bool has = w != 0u;
+          const int bpos = has ? (__ffs((int)w) - 1) : 0;
+          const int j = lane * 32 + bpos;
+          unsigned long long v = 0ull;
+          if (has) {
+            v = ((volatile unsigned long long*)acc)[j];
+            ((volatile unsigned long long*)acc)[j] = 0ull;
+            w &= w - 1u;
           }
-          if (pool.n + add > cap && pool.n > Kp) {
-            rp_wpool_cut<uint32_t, 0>(pool, Kp, lane);
-            const float t2 = __uint_as_float(pool.tau);
-            add = 0;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              keep[c] = vv[c] > t2;
-              m[c] = __ballot(keep[c]);
-              add += __popcll(m[c]);
-            }
-          }
-          if (pool.n + add > cap) {
-            // more admissible scores in one step than the pool has room for: push the four components as separate
-            // batches.  Their order is not the column order, so admission is non-strict here and ties are
-            // resolved exactly by the next cut.
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const bool k2 = vv[c] >= __uint_as_float(pool.tau) && vv[c] > 0.0f;
-              rp_wpool_push<uint32_t, 0>(pool, Kp, cap, k2, __float_as_uint(vv[c]), (uint32_t)(t0 + q * 4 + c), lane);
-            }
-            continue;
-          }
-          int below = 0;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) below += __popcll(m[c] & lt_mask);
-          int own = 0;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (keep[c]) {
-              const int pos = pool.n + below + own;
-              ((volatile uint32_t*)pool.key)[pos] = __float_as_uint(vv[c]);
-              ((volatile uint32_t*)pool.pay)[pos] = (uint32_t)(t0 + q * 4 + c);
-            }
-            own += keep[c] ? 1 : 0;
-          }
-          pool.n += add;
+          const uint32_t col = (uint32_t)(t0 + j);
+          const bool keep = has && v != 0ull && rp_wpool_admits<uint64_t, 0>(pool, v, col);
+          rp_wpool_push<uint64_t, 0>(pool, Kp, cap, keep, v, col, lane);
         }
         PW_STAMP(2);
       }
       // ---- final: best Kp by (score desc, column asc), then column order for the output row
       __builtin_amdgcn_wave_barrier();
-      if (pool.n > Kp) rp_wpool_cut<uint32_t, 0>(pool, Kp, lane);
+      if (pool.n > Kp) rp_wpool_cut<uint64_t, 0>(pool, Kp, lane);
       const int n_out = pool.n;
-      volatile uint32_t* pk = pool.key;
+      volatile uint64_t* pk = pool.key;
       volatile uint32_t* pp = pool.pay;
       for (int e = lane; e < n_out; e += 64) {
         const uint32_t col = pp[e];
         int rank = 0;
         for (int o = 0; o < n_out; ++o) rank += (pp[o] < col) ? 1 : 0;
         P.out_idx[(int64_t)ul * Kp + rank] = (int)col;
-        P.out_val[(int64_t)ul * Kp + rank] = __uint_as_float(pk[e]);
+        P.out_val[(int64_t)ul * Kp + rank] = (float)((double)pk[e] * 0x1p-50);
       }
       if (lane == 0) P.out_nnz[ul] = n_out;
       __builtin_amdgcn_wave_barrier();
       PW_STAMP(3);
+      PW_FLUSH();
     }
   }
 }
 
-// users whose history exceeds what k_predict_wave holds in registers
-__global__ void k_pred_split(const int32_t* __restrict__ x_ptr, int user_begin, int n_users, int thr, int32_t* __restrict__ list,
-                             int32_t* __restrict__ cnt) {
-  for (int ul = blockIdx.x * blockDim.x + threadIdx.x; ul < n_users; ul += gridDim.x * blockDim.x) {
-    const int d = x_ptr[user_begin + ul + 1] - x_ptr[user_begin + ul];
-    if (d > thr) list[atomicAdd(cnt, 1)] = ul;
+// toff[i][t] = number of entries of neighbour list i with column < t*PW_WT (lists are column-sorted)
+__global__ void k_build_toff(const int32_t* __restrict__ idx, const int32_t* __restrict__ nnz, int K, int n_items, int n_wt,
+                             uint16_t* __restrict__ toff) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += gridDim.x * blockDim.x) {
+    uint16_t* o = toff + (long long)i * (n_wt + 1);
+    const int32_t* row = idx + (long long)i * K;
+    const int n = nnz[i];
+    int t = 0;
+    o[0] = 0;
+    for (int k = 0; k < n; ++k) {
+      const int tj = row[k] / PW_WT;
+      while (t < tj) o[++t] = (uint16_t)k;
+    }
+    while (t < n_wt) o[++t] = (uint16_t)n;
   }
 }
 
@@ -527,34 +581,36 @@ extern "C" int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, 
   P.Kp = Kp;
   P.exclude_history = exclude_history;
   P.mode = 0;
-  // light users (history <= 64*PW_NB items) go to the wave-per-user kernel, the rest to the workgroup kernel
-  // (measured: with one column tile the workgroup kernel is still faster - 8.0 vs 11.8 ms at 100K x 20K -, with
-  // several tiles the wave kernel wins - 187 vs 347 ms at 1M x 100K)
-  const bool use_wave = model->kind == RPHIP_MODEL_TOPK && model->cols_sorted && Kp <= PW_KP_MAX && (int64_t)model->n_items * model->K < (1ll << 31);
-  int32_t* heavy_list = nullptr;
-  int32_t* heavy_cnt = nullptr;
+  // neighbour-list models with column-sorted rows: wave-per-user kernel (any history length); otherwise (dense
+  // models, unsorted lists, very large Kp) the workgroup kernel below
+  const bool use_wave = model->kind == RPHIP_MODEL_TOPK && model->cols_sorted && Kp <= PW_KP_MAX && model->K < 65536 &&
+                        (int64_t)model->n_items * model->K < (1ll << 30);
   hipEvent_t ev;
   rp_time_begin(ctx, &ev);
   if (use_wave) {
-    char* hb = nullptr;
-    RP_TRY(rp_scratch(ctx, 4, (size_t)n * 4 + 64, (void**)&hb));
-    heavy_cnt = (int32_t*)hb;          // [0] = count, [1] = ticket
-    heavy_list = (int32_t*)(hb + 64);
-    hipMemsetAsync(hb, 0, 64, st);
-    hipLaunchKernelGGL(k_pred_split, dim3((unsigned)std::min<int64_t>(1024, rp_cdiv(n, 256))), dim3(256), 0, st, Xpred->x_ptr,
-                       (int)user_begin, (int)n, 64 * PW_NB, heavy_list, heavy_cnt);
+    rphip_model* mm = const_cast<rphip_model*>(model);  // lazily built, cached acceleration structure
+    const int n_wt = (int)rp_cdiv(model->n_items, PW_WT);
+    if (!mm->toff) {
+      RP_HIP(hipMalloc((void**)&mm->toff, (size_t)model->n_items * (n_wt + 1) * sizeof(uint16_t)));
+      hipLaunchKernelGGL(k_build_toff, dim3((unsigned)std::min<int64_t>(4096, rp_cdiv(model->n_items, 256))), dim3(256), 0, st, model->idx,
+                         model->nnz, model->K, (int)model->n_items, n_wt, mm->toff);
+    }
+    int32_t* tk = nullptr;
+    RP_TRY(rp_scratch(ctx, 4, 64, (void**)&tk));
+    hipMemsetAsync(tk, 0, 64, st);
     rp_pw_params W;
     W.x_ptr = Xpred->x_ptr;
     W.x_idx = Xpred->x_idx;
     W.pairs = model->pairs;
-    W.s_nnz = model->nnz;
+    W.toff = mm->toff;
     W.n_items = (int)Xpred->n_items;
+    W.n_wt = n_wt;
     W.K = model->K;
     W.Kp = Kp;
     W.exclude_history = exclude_history;
     W.user_begin = (int)user_begin;
     W.n_users = (int)n;
-    W.ticket = heavy_cnt + 1;
+    W.ticket = tk;
     W.out_idx = idx_dev;
     W.out_val = val_dev;
     W.out_nnz = nnz_dev;
@@ -567,22 +623,23 @@ extern "C" int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, 
       hipMemsetAsync(sp, 0, 64 * 8, st);
     }
 #endif
-    const size_t wl = rp_pw_wave_bytes(Kp) * PW_WAVES;
+    const size_t wl = rp_pw_wave_bytes(Kp);
     RP_HIP(hipFuncSetAttribute((const void*)k_predict_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl));
-    const int wpc = std::max<int>(1, (int)((160 * 1024) / wl));
-    const int wg = (int)std::min<int64_t>(rp_cdiv(n, PW_UCH * PW_WAVES), (int64_t)ctx->n_cu * wpc);
-    hipLaunchKernelGGL(k_predict_wave, dim3(wg), dim3(PW_WAVES * 64), wl, st, W);
+    const int wpc = std::max<int>(1, std::min<int>(16, (int)((160 * 1024) / wl)));
+    const int wg = (int)std::min<int64_t>(rp_cdiv(n, PW_UCH), (int64_t)ctx->n_cu * wpc);
+    hipLaunchKernelGGL(k_predict_wave, dim3(wg), dim3(64), wl, st, W);
+    RP_HIP(hipGetLastError());
 #ifdef RP_STAMPS
     {
       unsigned long long h[8];
       hipMemcpyAsync(h, W.stamps, sizeof(h), hipMemcpyDeviceToHost, st);
       hipStreamSynchronize(st);
-      fprintf(stderr, "[stamps predict_wave] cycles/1e6: setup %.1f accumulate %.1f scan+pool %.1f final %.1f\n", h[0] / 1e6, h[1] / 1e6,
-              h[2] / 1e6, h[3] / 1e6);
+      fprintf(stderr, "[stamps predict_wave] cycles/1e6: setup %.1f accumulate %.1f scan+pool %.1f final %.1f (grid %d)\n", h[0] / 1e6, h[1] / 1e6,
+              h[2] / 1e6, h[3] / 1e6, wg);
     }
 #endif
-    P.user_list = heavy_list;
-    P.n_list = heavy_cnt;
+    rp_time_end(ctx, ev, RPHIP_T_PREDICT, rp_pred_work(Xpred, model, n, Kp));
+    return RPHIP_OK;
   }
   int32_t* cand_idx = nullptr;
   float* cand_val = nullptr;
@@ -606,7 +663,7 @@ extern "C" int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, 
   }
   const size_t lds = rp_pred_lds(Xpred->tile_w);
   RP_HIP(hipFuncSetAttribute((const void*)k_predict_sparse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int grid = (int)std::min<int64_t>(n * T, (int64_t)ctx->n_cu * (use_wave ? 1 : 8));
+  const int grid = (int)std::min<int64_t>(n * T, (int64_t)ctx->n_cu * 8);
   hipLaunchKernelGGL(k_predict_sparse, dim3(grid), dim3(RP_PRED_THREADS), lds, st, P);
   if (T > 1) {
     const size_t mlds = (size_t)T * Kp * 8 + rp_select_smem_bytes(T * Kp);
@@ -615,7 +672,7 @@ extern "C" int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, 
     RP_HIP(hipFuncSetAttribute((const void*)k_predict_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
     const int mg = (int)std::min<int64_t>(n, (int64_t)ctx->n_cu * 8);
     hipLaunchKernelGGL(k_predict_merge, dim3(mg), dim3(RP_PRED_THREADS), mlds, st, cand_idx, cand_val, cand_nnz, T, Kp, (int)n,
-                       use_wave ? heavy_list : nullptr, heavy_cnt, idx_dev, val_dev, nnz_dev);
+                       nullptr, nullptr, idx_dev, val_dev, nnz_dev);
   }
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, RPHIP_T_PREDICT, rp_pred_work(Xpred, model, n, Kp));

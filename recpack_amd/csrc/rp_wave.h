@@ -18,7 +18,8 @@ struct rp_wpool {
   uint32_t* hist;   // [256]
   uint16_t* gidx;   // [64]
   int n;            // entries in the pool (wave-uniform)
-  KeyT tau;         // admission threshold: key must be > tau (0 = everything positive)
+  KeyT tau;         // admission threshold: a candidate enters if key > tau, or key == tau and column < tau_col
+  uint32_t tau_col; // (0 / 0 = everything positive)
 };
 
 template <typename KeyT>
@@ -183,6 +184,14 @@ __device__ void rp_wpool_cut(rp_wpool<KeyT>& P, int K, int lane) {
   __builtin_amdgcn_wave_barrier();
   P.n = out;  // == K
   P.tau = tkey;
+  P.tau_col = tcol;
+}
+
+// Is a candidate still able to make the top K?  Exact for candidates arriving in ANY column order: ties with the
+// K-th key are admitted only when their column is smaller than the K-th entry's.
+template <typename KeyT, int COL_SHIFT>
+__device__ __forceinline__ bool rp_wpool_admits(const rp_wpool<KeyT>& P, KeyT k, uint32_t pay) {
+  return (k > P.tau) || (k == P.tau && k != 0 && (pay >> COL_SHIFT) < P.tau_col);
 }
 
 // Append the lanes' candidates (keep == true) to the pool; cuts first when fewer than 64 slots are free.
@@ -192,7 +201,7 @@ __device__ __forceinline__ void rp_wpool_push(rp_wpool<KeyT>& P, int K, int cap,
   if (m == 0) return;
   if (P.n + 64 > cap && P.n > K) {  // cap >= K + 64
     rp_wpool_cut<KeyT, COL_SHIFT>(P, K, lane);
-    keep = keep && (k > P.tau);
+    keep = keep && rp_wpool_admits<KeyT, COL_SHIFT>(P, k, pay);
     m = __ballot(keep);
     if (m == 0) return;
   }
