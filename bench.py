@@ -148,6 +148,23 @@ def ease_leg(args, ctx, device, Kp):
     }
 
 
+def pmc_traffic(config, kernel, world):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/pmc_traffic.sh: one rocprofv3 --pmc run per
+    counter on this same command).  FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B read
+    requests as 64 B (MI355X_MICROARCH.md, HBM section), so it is doubled.  None when no pass exists for the config."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_pmc_traffic_{config.lower()}.json")
+    if world != 1 or not os.path.exists(path):
+        return None, "no PMC pass committed for this configuration"
+    want = kernel.replace(" ", "")
+    for name, c in json.load(open(path)).items():
+        if want in name.replace(" ", "") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            f, w = c["FETCH_SIZE"]["avg_per_dispatch"], c["WRITE_SIZE"]["avg_per_dispatch"]
+            return (2.0 * f + w) * 1024.0, (f"profiles/{os.path.basename(path)}: (2 x FETCH_SIZE {f:.0f} KiB + WRITE_SIZE {w:.0f} KiB) "
+                                            "per launch; the x2 is the guide's gfx950 correction for wide reads and is an upper "
+                                            "bound for this kernel's 16-B gathers (uncalibrated width)")
+    return None, "kernel not in the PMC pass"
+
+
 def main():
     args = parse()
     import torch
@@ -252,6 +269,7 @@ def main():
         spgemm_ms = sum(tm[k]["ms"] for k in ("gram_topk", "gram_topk_wave", "gram_finalize", "topk_merge")) / args.steps
         spgemm_bytes = 4.0 * p_rank + other
         phases = {k: round(v["ms"] / args.steps, 4) for k, v in tm.items() if v["launches"]}
+        traffic, traffic_note = pmc_traffic(args.config, dom, world)
         result = {
             "metric": "fit+predict wall-sec (ItemKNN cosine) on synthetic power-law implicit feedback",
             "value": round(sec_per_step, 6),
@@ -284,7 +302,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": traffic_note,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "avg_launch_ms": round(avg_ms, 4),
                 "legs": {k: {"avg_launch_ms": round(v[0], 4), "algorithmic_bytes": v[1],

@@ -83,6 +83,7 @@ struct rphip_csr {
   int tile_w = 0;
   int32_t* tile_ptr = nullptr;
   bool sorted_rows = false;
+  int max_user_deg = 0;            // longest history (bounds |score| for predict's fixed-point scale)
 };
 
 struct rphip_model {
@@ -99,6 +100,7 @@ struct rphip_model {
   uint16_t* toff = nullptr; // [n_items * (n_wt + 1)] per-row offsets of the predict column tiles (built on first use)
   int32_t* nnz = nullptr;   // [rows]
   bool cols_sorted = false; // every row's columns strictly increasing (checked when the model is finalised)
+  float vmax_abs = 0.0f;    // largest |similarity| (f32): with the longest history it bounds |score|
   // DENSE
   float* B = nullptr;       // [n_items * ld]
   int64_t ld = 0;

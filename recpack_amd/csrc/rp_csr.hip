@@ -84,12 +84,20 @@ __global__ void k_inv_deg(const int32_t* __restrict__ deg, double* __restrict__ 
 }
 
 __global__ void k_check_ptr(const int32_t* __restrict__ x_ptr, int n_users, int64_t nnz, int32_t* __restrict__ err) {
+  int dmax = 0;
   for (int u = blockIdx.x * blockDim.x + threadIdx.x; u <= n_users; u += gridDim.x * blockDim.x) {
     const int a = x_ptr[u];
     if (u == 0 && a != 0) *err = 2;
     if (u == n_users && a != (int)nnz) *err = 2;
-    if (u < n_users && x_ptr[u + 1] < a) *err = 2;
+    if (u < n_users) {
+      const int d = x_ptr[u + 1] - a;
+      if (d < 0) *err = 2;
+      dmax = max(dmax, d);
+    }
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, __shfl_xor(dmax, o));
+  if ((threadIdx.x & 63) == 0 && dmax > 0) atomicMax(&err[4], dmax);  // longest history
 }
 
 // one thread per user: tile boundaries by a linear merge (rows are short), and the order check
@@ -146,9 +154,11 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
   const int grid_nnz = (int)std::min<int64_t>((int64_t)ctx->n_cu * 16, std::max<int64_t>(1, rp_cdiv(nnz, bt)));
   const int grid_u = (int)std::min<int64_t>((int64_t)ctx->n_cu * 16, std::max<int64_t>(1, rp_cdiv(U + 1, bt)));
   hipLaunchKernelGGL(k_check_ptr, dim3(grid_u), dim3(bt), 0, st, m->x_ptr, (int)U, nnz, err);
-  int32_t h_err = 0;
-  RP_HIP(hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, st));
+  int32_t h_chk[5] = {0, 0, 0, 0, 0};
+  RP_HIP(hipMemcpyAsync(h_chk, err, sizeof(h_chk), hipMemcpyDeviceToHost, st));
   RP_HIP(hipStreamSynchronize(st));
+  const int32_t h_err = h_chk[0];
+  m->max_user_deg = h_chk[4];
   if (h_err) RP_FAIL(RPHIP_EINVAL, "indptr is not a valid row pointer array (not monotone, or indptr[0] != 0, or indptr[-1] != nnz)");
   if (nnz > 0) {
     const int n_ranges = (int)rp_cdiv(I, 32768);

@@ -6,18 +6,59 @@
 // MetricTopK (recpack/metrics/base.py:189 -> recpack/util.py:50-77).  The U x I score matrix is never stored.
 //
 //   task = (user u, column tile t)
-//   accumulate  for every history item i of u: the <= K (j, s_ij) pairs of S row i (contiguous, coalesced)
-//               are added into a dense f32 tile in LDS with LDS float atomics; one wave per history item
+//   accumulate  neighbour lists: for every history item i of u the <= K (j, s_ij) pairs of S row i (contiguous,
+//               coalesced) are added into a dense tile of 64-bit FIXED-POINT sums in LDS with integer LDS atomics,
+//               one wave per history item; dense models (K9): rows of B streamed into per-thread f32 registers
 //   select      exact top-Kp by (score desc, column asc)  (rp_select.h), emitted in column order
+//
+// Fixed point: an LDS f32 atomic add sustains 0.33 per clock per CU on MI355X, u32/u64 integer adds 4.4-4.8
+// (tools/lds_atomic_bench.hip).  Scores of neighbour-list models are therefore summed as signed 64-bit integers,
+// value * 2^shift with shift chosen per call from the model's largest |similarity| and the longest history so that
+// no sum can overflow (rp_fix_shift).  The integer sum is exact and independent of the order of the adds: predict
+// is bit-reproducible, and the f32 similarities themselves are the only rounding before the final conversion.
 //
 // The "full" variants return every non-zero score (the reference's CSR result) in two phases: count, fill.
 #include <algorithm>
+#include <cmath>
+#include <cstring>
 
 #include "rp_common.h"
 #include "rp_select.h"
 #include "rp_wave.h"
 
 constexpr int RP_PRED_THREADS = 1024;
+constexpr int RP_PRED_FIX_TILE = 15360;  // columns of an 8-byte tile + selection buffers in 160 KB of LDS
+constexpr unsigned long long RP_KEY_FLIP = 0x8000000000000000ull;  // two's complement sum -> order-preserving u64 key
+
+// Scale of the sums.  |score| <= max_deg * vmax_abs < 2^(e + dl): shift <= 62 - e - dl keeps every sum inside 63 bits;
+// shift <= 50 - e keeps every single term below 2^50 units so that the conversion below is one f64 add.
+static int rp_fix_shift(float vmax_abs, int max_deg) {
+  int e = 0;
+  if (vmax_abs > 0.0f && std::isfinite(vmax_abs)) (void)std::frexp(vmax_abs, &e);  // vmax_abs < 2^e
+  int dl = 0;
+  while ((1ll << dl) < (long long)std::max(max_deg, 1)) ++dl;
+  return std::min(200, std::max(-100, std::min(62 - e - dl, 50 - e)));
+}
+
+// f32 -> round(value * 2^shift) as a two's complement 64-bit integer: adding 1.5 * 2^(52-shift) in f64 leaves the
+// integer in the low mantissa bits (|value| * 2^shift < 2^50 by the choice of shift; round to nearest even).
+struct rp_fix_scale {
+  double magic;
+  unsigned long long magic_bits;
+  int shift;
+};
+static rp_fix_scale rp_fix_make(int shift) {
+  rp_fix_scale f;
+  f.shift = shift;
+  f.magic = std::ldexp(1.5, 52 - shift);
+  std::memcpy(&f.magic_bits, &f.magic, 8);
+  return f;
+}
+__device__ __forceinline__ unsigned long long rp_f32_to_fix(int bits, const rp_fix_scale& f) {
+  const double r = (double)__int_as_float(bits) + f.magic;
+  return (unsigned long long)__double_as_longlong(r) - f.magic_bits;
+}
+__device__ __forceinline__ double rp_fix_to_f64(unsigned long long sum, int shift) { return ldexp((double)(long long)sum, -shift); }
 
 struct rp_pred_params {
   const int32_t* x_ptr;   // prediction input (binary CSR)
@@ -28,6 +69,7 @@ struct rp_pred_params {
   const float* dense_B;   // K9: dense model (EASE), row-major with leading dimension dense_ld; NULL for neighbour lists
   long long dense_ld;
   int n_items, n_tiles, tile_w, K, Kp, exclude_history;
+  rp_fix_scale fix;       // neighbour lists: scale of the fixed-point sums
   int user_begin, n_users;
   const int32_t* user_list;  // optional: local user ids to process (mode 0); count in *n_list
   const int32_t* n_list;
@@ -41,29 +83,46 @@ struct rp_pred_params {
   double* full_val;
 };
 
+// tile of f32 scores (dense models) or of fixed-point sums (neighbour lists)
+template <bool DENSE>
 struct rp_score_src {
   static constexpr bool PACK4 = false;
-  const float* acc;
+  const void* acc_;
   int t0;
-  __device__ __forceinline__ bool valid(int w) const { return acc[w] != 0.0f; }
+  __device__ __forceinline__ bool valid(int w) const {
+    if (DENSE) return ((const float*)acc_)[w] != 0.0f;
+    return ((const unsigned long long*)acc_)[w] != 0ull;
+  }
   __device__ __forceinline__ uint64_t key(int w) const {
-    // order-preserving map of a float (any sign) to u32, placed in the high half
-    uint32_t b = __float_as_uint(acc[w]);
-    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-    return (uint64_t)b << 32;
+    if (DENSE) {  // order-preserving map of a float (any sign) to u32, placed in the high half
+      uint32_t b = __float_as_uint(((const float*)acc_)[w]);
+      b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+      return (uint64_t)b << 32;
+    }
+    return ((const unsigned long long*)acc_)[w] ^ RP_KEY_FLIP;
   }
   __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)(t0 + w); }
 };
 
-__global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_sparse(rp_pred_params P) {
+template <bool DENSE>
+__global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_tile(rp_pred_params P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* acc = reinterpret_cast<float*>(smem);
-  rp_select_smem sel = rp_select_carve(smem + (size_t)P.tile_w * 4, P.tile_w);
+  constexpr int ACC_B = DENSE ? 4 : 8;
+  float* accf = reinterpret_cast<float*>(smem);
+  unsigned long long* accq = reinterpret_cast<unsigned long long*>(smem);
+  rp_select_smem sel = rp_select_carve(smem + (size_t)P.tile_w * ACC_B, P.tile_w);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NW = RP_PRED_THREADS / 64;
-  const int W = P.tile_w, T = P.n_tiles, K = P.K;
+  const int W = P.tile_w, T = P.n_tiles, K = P.K, shift = P.fix.shift;
+  auto clear = [&](int w) {
+    if (DENSE)
+      accf[w] = 0.0f;
+    else
+      accq[w] = 0ull;
+  };
+  auto score = [&](int w) -> double { return DENSE ? (double)accf[w] : rp_fix_to_f64(accq[w], shift); };
 
-  for (int w = tid; w < W; w += RP_PRED_THREADS) acc[w] = 0.0f;
+  for (int w = tid; w < W; w += RP_PRED_THREADS) clear(w);
   __syncthreads();
 
   // modes 1/2 walk the tiles of a user inside the workgroup (output offsets are sequential);
@@ -83,7 +142,7 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_sparse(rp_pred_para
       const int t0 = tile * W;
       const int n_cols = min(W, P.n_items - t0);
       // ---- accumulate
-      if (P.dense_B) {
+      if (DENSE) {
         // K9: score[u, t0:t0+n_cols] = sum of the history items' rows of B; every thread owns CPT columns
         // (registers, no atomics), rows are streamed coalesced
         constexpr int CPT = (RP_TILE_MAX + RP_PRED_THREADS - 1) / RP_PRED_THREADS;
@@ -101,7 +160,7 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_sparse(rp_pred_para
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
           const int w = tid + c * RP_PRED_THREADS;
-          if (w < n_cols) acc[w] = r[c];
+          if (w < n_cols) accf[w] = r[c];
         }
       } else {
         for (int h = hs + wave; h < he; h += NW) {
@@ -111,7 +170,7 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_sparse(rp_pred_para
           const float* sv = P.s_val + (int64_t)i * K;
           for (int k = lane; k < nn; k += 64) {
             const int j = si[k] - t0;
-            if ((unsigned)j < (unsigned)n_cols) atomicAdd(&acc[j], sv[k]);
+            if ((unsigned)j < (unsigned)n_cols) atomicAdd(&accq[j], rp_f32_to_fix(__float_as_int(sv[k]), P.fix));
           }
         }
       }
@@ -119,30 +178,30 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_sparse(rp_pred_para
       if (P.exclude_history) {
         for (int h = hs + tid; h < he; h += RP_PRED_THREADS) {
           const int j = P.x_idx[h] - t0;
-          if ((unsigned)j < (unsigned)n_cols) acc[j] = 0.0f;
+          if ((unsigned)j < (unsigned)n_cols) clear(j);
         }
         __syncthreads();
       }
       // ---- select
-      rp_score_src src{acc, t0};
+      rp_score_src<DENSE> src{smem, t0};
       const int kk = (P.mode == 0) ? P.Kp : 0x7fffffff;
       const int kp = rp_select_topk<RP_PRED_THREADS>(src, n_cols, kk, sel);
       if (P.mode == 0) {
         const int64_t o = (T == 1) ? (int64_t)ul * P.Kp : ((int64_t)ul * T + tile) * P.Kp;
         rp_select_emit<RP_PRED_THREADS>(n_cols, sel, [&](int pos, int w) {
           P.out_idx[o + pos] = t0 + w;
-          P.out_val[o + pos] = acc[w];
+          P.out_val[o + pos] = (float)score(w);
         });
         if (tid == 0) P.out_nnz[(T == 1) ? ul : ul * T + tile] = kp;
       } else if (P.mode == 2) {
         rp_select_emit<RP_PRED_THREADS>(n_cols, sel, [&](int pos, int w) {
           P.full_idx[off + pos] = t0 + w;
-          P.full_val[off + pos] = (double)acc[w];
+          P.full_val[off + pos] = score(w);
         });
         off += kp;
       }
       total += kp;
-      rp_select_foreach<RP_PRED_THREADS>(n_cols, sel, [&](int w) { acc[w] = 0.0f; });  // clear what was touched
+      rp_select_foreach<RP_PRED_THREADS>(n_cols, sel, [&](int w) { clear(w); });  // clear what was touched
       __syncthreads();
     }
     if (P.mode == 1 && tid == 0) P.row_nnz[ul] = total;
@@ -218,29 +277,22 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_merge(const int32_t
 //   * the slices of the 64 history items of a batch are cut into chunks of four entries and chunk c goes to lane
 //     c % 64 (two 16-byte loads per chunk): the loads are coalesced per list and every lane is busy whatever the
 //     history length; histories longer than 64 take several batches per tile;
-//   * scores are accumulated in 64-bit FIXED POINT (f32 similarity * 2^50, exact for every similarity >= 2^-27) with
-//     u64 LDS atomics: measured on MI355X an LDS f32 atomic add sustains 0.33 per clock per CU, u32/u64 integer adds
-//     4.4-4.8 (tools/lds_atomic_bench.hip).  The integer sum is exact and independent of the order of the adds, so
-//     predict is bit-reproducible;
+//   * scores are accumulated as 64-bit fixed-point sums with u64 LDS atomics (see the top of this file);
 //   * a 2048-bit dirty map (one word per lane, LDS atomic OR) records the touched columns; after the tile's adds
 //     each lane walks the set bits of its word, reads and clears the sums and offers them to the wave's running
 //     top-Kp pool (rp_wave.h: exact radix-select cuts; admission is exact for any arrival order);
-//   * at the end the pool is cut to Kp, ranked by column and written out (score = (float)(sum * 2^-50)).
+//   * at the end the pool is cut to Kp, ranked by column and written out (score = (float)(sum * 2^-shift)).
 constexpr int PW_WT = 2048;
 constexpr int PW_CH = 4;        // entries per chunk (32 bytes)
 constexpr int PW_UCH = 4;       // users per ticket
 constexpr int PW_KP_MAX = 384;  // pool capacity = Kp rounded up + 128 <= 512
-constexpr int PW_FIX_SHIFT = 50;
 
-__host__ __device__ constexpr int rp_pw_cap(int Kp) { return ((Kp + 63) / 64) * 64 + 128; }
-__host__ __device__ constexpr size_t rp_pw_wave_bytes(int Kp) { return (size_t)PW_WT * 8 + 256 + (size_t)rp_pw_cap(Kp) * 12 + 1024 + 128; }
-
-// f32 bits (positive, normal) -> value * 2^50 as u64, by integer arithmetic (exact when the value is >= 2^-27)
-__device__ __forceinline__ unsigned long long rp_f32_to_fix(int bits) {
-  const unsigned long long m = (unsigned long long)((bits & 0x7fffff) | 0x800000);
-  const int sh = ((bits >> 23) & 0xff) - 127 - 23 + PW_FIX_SHIFT;
-  return sh >= 0 ? (m << sh) : (m >> (-sh));
+// pool capacity (<= 512, the cut's limit): the more room above Kp, the fewer exact cuts per user
+__host__ __device__ constexpr int rp_pw_cap(int Kp) {
+  const int base = ((Kp + 63) / 64) * 64;
+  return base + 128;
 }
+__host__ __device__ constexpr size_t rp_pw_wave_bytes(int Kp) { return (size_t)PW_WT * 8 + 256 + (size_t)rp_pw_cap(Kp) * 12 + 1024 + 128; }
 
 struct rp_pw_params {
   const int32_t* x_ptr;
@@ -248,6 +300,7 @@ struct rp_pw_params {
   const int2* pairs;
   const uint16_t* toff;  // [I * (n_wt + 1)]
   int n_items, n_wt, K, Kp, exclude_history, user_begin, n_users;
+  rp_fix_scale fix;
   int32_t* ticket;
   int32_t* out_idx;
   float* out_val;
@@ -255,34 +308,276 @@ struct rp_pw_params {
   unsigned long long* stamps;  // -DRP_STAMPS only
 };
 
-#ifdef RP_STAMPS
-#define PW_STAMP(ph) do { unsigned long long _t = __builtin_amdgcn_s_memtime(); t_ph[ph] += _t - t_last; t_last = _t; } while (0)
-#define PW_FLUSH() do { if (lane == 0) { for (int _p = 0; _p < 4; ++_p) atomicAdd(&P.stamps[_p], t_ph[_p]); } t_ph[0] = t_ph[1] = t_ph[2] = t_ph[3] = 0; } while (0)
-#else
+#ifndef RP_STAMPS
 #define PW_STAMP(ph) do { } while (0)
-#define PW_FLUSH() do { } while (0)
+#define PW_COUNT(ph, n) do { } while (0)
 #endif
+
+typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+struct rp_pw_state {
+  RP_LDS unsigned long long* acc;
+  volatile RP_LDS uint32_t* dirty;
+  rp_wpool<uint64_t> pool;
+  const int* pairs_i;
+  int lane, cap;
+  rp_fix_scale fix;
+#ifdef RP_STAMPS
+  unsigned long long t_last, t_ph[8];
+#endif
+};
+
+#ifdef RP_STAMPS
+#define PW_STAMP(ph) do { unsigned long long _t = __builtin_amdgcn_s_memtime(); S.t_ph[ph] += _t - S.t_last; S.t_last = _t; } while (0)
+#define PW_COUNT(ph, n) do { S.t_ph[ph] += (n); } while (0)
+#endif
+
+__device__ __forceinline__ void rp_pw_add_chunk(rp_pw_state& S, int n, const v4i_a4& a, const v4i_a4& b, int t0) {
+  const int ec[4] = {a.x, a.z, b.x, b.z};
+  const int ev[4] = {a.y, a.w, b.y, b.w};
+#pragma unroll
+  for (int e = 0; e < PW_CH; ++e) {
+    if (e < n) {
+      const int j = ec[e] - t0;
+      atomicAdd((unsigned long long*)&S.acc[j], rp_f32_to_fix(ev[e], S.fix));
+      atomicOr((uint32_t*)&S.dirty[j & 63], 1u << (j >> 6));
+    }
+  }
+}
+
+// chunk c of a batch whose lanes hold (start, length, first chunk) of their slices: owner lane by binary search
+// over the exclusive chunk offsets, then the chunk's two 16-byte loads
+__device__ __forceinline__ int rp_pw_fetch_chunk(const rp_pw_state& S, int c, int n_chunks, int s, int len, int choff, v4i_a4* a,
+                                                 v4i_a4* b) {
+  int lo = 0;
+#pragma unroll
+  for (int step = 32; step > 0; step >>= 1) {
+    const int v = __shfl(choff, lo + step);
+    if (v <= c) lo += step;
+  }
+  const int us = __shfl(s, lo), ulen = __shfl(len, lo), co = __shfl(choff, lo);
+  const int k0 = (c - co) * PW_CH;
+  const int n = (c < n_chunks) ? min(PW_CH, ulen - k0) : 0;
+  if (n > 0) {
+    const int* src = S.pairs_i + 2 * (long long)(us + k0);  // the pairs array is padded: reading past the
+    *a = *reinterpret_cast<const v4i_a4*>(src);               // slice's end is harmless
+    *b = *reinterpret_cast<const v4i_a4*>(src + 4);
+  }
+  return n;
+}
+
+// The first 64 chunks of a batch (chunk = lane): every slice owner writes its lane id at its first chunk's slot of a
+// 64-word LDS scratch, a running maximum over the lanes (DPP) turns that into the owner of every chunk - two LDS
+// round trips where the binary search takes six.
+__device__ __forceinline__ int rp_pw_fetch_first(const rp_pw_state& S, int n_chunks, int nch, int s, int len, int choff, v4i_a4* a,
+                                                 v4i_a4* b) {
+  volatile RP_LDS uint32_t* sc = S.pool.hist;  // idle while a tile's entries are fetched and added
+  const int lane = S.lane;
+  sc[lane] = 0u;
+  if (nch > 0 && choff < 64) sc[choff] = (uint32_t)lane;
+  const int lo = rp_wave_incl_max((int)sc[lane]);
+  const int us = __shfl(s, lo), ulen = __shfl(len, lo), co = __shfl(choff, lo);
+  const int k0 = (lane - co) * PW_CH;
+  const int n = (lane < n_chunks) ? min(PW_CH, ulen - k0) : 0;
+  if (n > 0) {
+    const int* src = S.pairs_i + 2 * (long long)(us + k0);
+    *a = *reinterpret_cast<const v4i_a4*>(src);
+    *b = *reinterpret_cast<const v4i_a4*>(src + 4);
+  }
+  return n;
+}
+
+// All tiles of one user.  The first NB batches of 64 history items are software-pipelined over the tiles: item ids stay
+// in registers, tile offsets are loaded two tiles ahead and the entries of tile t+1 are in flight while tile t is
+// added, scanned and pooled.  Without this the three dependent loads (item id -> offsets -> entries) are paid once
+// per tile and batch; batches beyond NB (histories longer than 64*NB) still go that way.
+template <int NB>
+__device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_state& S, int ul, int hs, int he) {
+  const int lane = S.lane, K = P.K, Kp = P.Kp, NT = P.n_wt, cap = S.cap;
+  const int nb = min(NB, (he - hs + 63) >> 6);
+  int it[NB], o_a[NB], o_b[NB], o_c[NB];
+  const uint16_t* to[NB];
+  int p_s[NB], p_len[NB], p_choff[NB], p_nchunks[NB], p_n[NB];
+  v4i_a4 p_a[NB], p_b[NB];
+  auto prepare = [&](int b) {
+    p_s[b] = (it[b] >= 0) ? it[b] * K + o_a[b] : 0;
+    p_len[b] = (it[b] >= 0) ? o_b[b] - o_a[b] : 0;
+    const int nch = (p_len[b] + PW_CH - 1) / PW_CH;
+    const int inc = rp_wave_incl_scan(nch, lane);
+    p_choff[b] = inc - nch;
+    p_nchunks[b] = __builtin_amdgcn_readlane(inc, 63);
+    p_n[b] = rp_pw_fetch_first(S, p_nchunks[b], nch, p_s[b], p_len[b], p_choff[b], &p_a[b], &p_b[b]);
+  };
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    it[b] = -1;
+    to[b] = P.toff;
+    o_a[b] = o_b[b] = o_c[b] = 0;
+    p_s[b] = p_len[b] = p_choff[b] = p_nchunks[b] = p_n[b] = 0;
+    p_a[b] = p_b[b] = (v4i_a4){0, 0, 0, 0};
+    if (b < nb) {
+      const int h = hs + 64 * b + lane;
+      it[b] = (h < he) ? P.x_idx[h] : -1;
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (b < nb) {
+      to[b] = P.toff + (long long)max(it[b], 0) * (NT + 1);
+      o_a[b] = (it[b] >= 0) ? (int)to[b][0] : 0;
+      o_b[b] = (it[b] >= 0) ? (int)to[b][1] : 0;
+      o_c[b] = (it[b] >= 0 && NT >= 2) ? (int)to[b][2] : o_b[b];
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+    if (b < nb) prepare(b);  // tile 0
+
+  for (int t = 0; t < NT; ++t) {
+    const int t0 = t * PW_WT;
+    // current tile = what was prepared; then prepare tile t+1 and fetch the offset of tile t+3
+    int c_s[NB], c_len[NB], c_choff[NB], c_nchunks[NB], c_n[NB];
+    v4i_a4 c_a[NB], c_b[NB];
+    bool touched = false;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      c_s[b] = p_s[b];
+      c_len[b] = p_len[b];
+      c_choff[b] = p_choff[b];
+      c_nchunks[b] = p_nchunks[b];
+      c_n[b] = p_n[b];
+      c_a[b] = p_a[b];
+      c_b[b] = p_b[b];
+      touched |= c_nchunks[b] > 0;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b < nb) {
+        o_a[b] = o_b[b];
+        o_b[b] = o_c[b];
+        if (t + 3 <= NT && it[b] >= 0) o_c[b] = (int)to[b][t + 3];
+        if (t + 1 < NT) prepare(b);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b < nb) {
+        rp_pw_add_chunk(S, c_n[b], c_a[b], c_b[b], t0);  // the prefetched first step, then any further steps
+        for (int c0 = 64; c0 < c_nchunks[b]; c0 += 64) {
+          v4i_a4 a = (v4i_a4){0, 0, 0, 0}, b2 = a;
+          const int n = rp_pw_fetch_chunk(S, c0 + lane, c_nchunks[b], c_s[b], c_len[b], c_choff[b], &a, &b2);
+          rp_pw_add_chunk(S, n, a, b2, t0);
+        }
+      }
+    }
+    // ---- histories longer than 64*NB items: the remaining batches, not pipelined
+    for (int hb = hs + 64 * NB; hb < he; hb += 64) {
+      const int h = hb + lane;
+      int s = 0, len = 0;
+      if (h < he) {
+        const int itx = P.x_idx[h];
+        const uint16_t* tx = P.toff + (long long)itx * (NT + 1) + t;
+        const int o0 = tx[0], o1 = tx[1];
+        s = itx * K + o0;
+        len = o1 - o0;
+      }
+      const int nch = (len + PW_CH - 1) / PW_CH;
+      const int inc = rp_wave_incl_scan(nch, lane);
+      const int choff = inc - nch;
+      const int n_chunks = __builtin_amdgcn_readlane(inc, 63);
+      if (n_chunks > 0) touched = true;
+      for (int c0 = 0; c0 < n_chunks; c0 += 64) {
+        v4i_a4 a = (v4i_a4){0, 0, 0, 0}, b2 = a;
+        const int n = rp_pw_fetch_chunk(S, c0 + lane, n_chunks, s, len, choff, &a, &b2);
+        rp_pw_add_chunk(S, n, a, b2, t0);
+      }
+    }
+    PW_STAMP(1);
+    if (!touched) continue;
+    if (P.exclude_history) {  // the dirty bit stays: a zero sum is skipped below
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {  // item ids of the pipelined batches are in registers: no load to wait for here
+        const int j = it[b] - t0;
+        if (b < nb && (unsigned)j < (unsigned)PW_WT) S.acc[j] = 0ull;
+      }
+      for (int h = hs + 64 * NB + lane; h < he; h += 64) {
+        const int j = P.x_idx[h] - t0;
+        if ((unsigned)j < (unsigned)PW_WT) S.acc[j] = 0ull;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- offer the touched columns to the pool: lane l walks the set bits of dirty word l
+    // (word l covers columns l, l+64, ..: the lanes' reads of one round fall into different LDS banks), four set bits
+    // per lane and round so that the sums of a round are read with one wait
+    uint32_t w = S.dirty[lane];
+    S.dirty[lane] = 0u;
+    while (__any(w != 0u)) {
+      bool has[4];
+      int j[4];
+      unsigned long long v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        has[q] = w != 0u;
+        j[q] = lane + 64 * (has[q] ? (__ffs((int)w) - 1) : 0);
+        w &= w - 1u;  // 0 stays 0
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = has[q] ? ((volatile RP_LDS unsigned long long*)S.acc)[j[q]] : 0ull;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (has[q]) ((volatile RP_LDS unsigned long long*)S.acc)[j[q]] = 0ull;
+      // most sums lose against the pool's threshold once it is warm: one vote for the round, then only the
+      // surviving slots are pushed (rolled: one inlined copy of the pool cut; the values rotate through slot 0)
+      bool kq[4];
+      bool anyk = false;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[q] ^= RP_KEY_FLIP;  // signed sum -> unsigned order; a zero sum is no candidate
+        kq[q] = has[q] && v[q] != RP_KEY_FLIP && rp_wpool_admits<uint64_t, 0>(S.pool, v[q], (uint32_t)(t0 + j[q]));
+        anyk |= kq[q];
+      }
+      PW_COUNT(4, 1);
+      if (!__any(anyk)) continue;
+      PW_COUNT(5, 1);
+#pragma unroll 1
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t col = (uint32_t)(t0 + j[0]);
+        // the threshold may have moved since the vote (a cut inside an earlier push): ask again
+        const bool keep = kq[0] && rp_wpool_admits<uint64_t, 0>(S.pool, v[0], col);
+        rp_wpool_push<uint64_t, 0>(S.pool, Kp, cap, keep, v[0], col, lane);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          kq[r] = kq[r + 1];
+          j[r] = j[r + 1];
+          v[r] = v[r + 1];
+        }
+      }
+    }
+    PW_STAMP(2);
+  }
+}
 
 __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
-  const int K = P.K, Kp = P.Kp, NT = P.n_wt;
-  const int cap = rp_pw_cap(Kp);
-  unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem);
-  volatile uint32_t* dirty = reinterpret_cast<volatile uint32_t*>(smem + (size_t)PW_WT * 8);
-  rp_wpool<uint64_t> pool;
-  pool.key = reinterpret_cast<uint64_t*>(smem + (size_t)PW_WT * 8 + 256);
-  pool.pay = reinterpret_cast<uint32_t*>(pool.key + cap);
-  pool.hist = pool.pay + cap;
-  pool.gidx = reinterpret_cast<uint16_t*>(pool.hist + 256);
-  typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));
-  const int* pairs_i = reinterpret_cast<const int*>(P.pairs);
+  const int Kp = P.Kp;
+  rp_pw_state S;
+  S.lane = lane;
+  S.cap = rp_pw_cap(Kp);
+  S.fix = P.fix;
+  S.acc = (RP_LDS unsigned long long*)smem;
+  S.dirty = (volatile RP_LDS uint32_t*)(smem + (size_t)PW_WT * 8);
+  S.pool.key = (RP_LDS uint64_t*)(smem + (size_t)PW_WT * 8 + 256);
+  S.pool.pay = (RP_LDS uint32_t*)(S.pool.key + S.cap);
+  S.pool.hist = S.pool.pay + S.cap;
+  S.pool.gidx = (RP_LDS uint16_t*)(S.pool.hist + 256);
+  S.pairs_i = reinterpret_cast<const int*>(P.pairs);
 
-  for (int i = lane; i < PW_WT; i += 64) acc[i] = 0ull;
-  dirty[lane] = 0u;
+  for (int i = lane; i < PW_WT; i += 64) S.acc[i] = 0ull;
+  S.dirty[lane] = 0u;
 #ifdef RP_STAMPS
-  unsigned long long t_last = __builtin_amdgcn_s_memtime();
-  unsigned long long t_ph[4] = {0, 0, 0, 0};
+  S.t_last = __builtin_amdgcn_s_memtime();
+  for (int _p = 0; _p < 8; ++_p) S.t_ph[_p] = 0;
 #endif
 
   while (true) {
@@ -295,170 +590,44 @@ __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
       const int u = P.user_begin + ul;
       const int hs = P.x_ptr[u], he = P.x_ptr[u + 1];
       if (he <= hs) continue;
-      pool.n = 0;
-      pool.tau = 0;
-      pool.tau_col = 0;
+      S.pool.n = 0;
+      S.pool.tau = 0;
+      S.pool.tau_col = 0;
       PW_STAMP(0);
-
-      // The first batch of 64 history items is software-pipelined over the tiles: its tile offsets are loaded two
-      // tiles ahead and the entries of tile t+1 are in flight while tile t is added, scanned and pooled.  Without
-      // this the three dependent loads (item id -> offsets -> entries) are paid once per tile.
-      const int it0 = (hs + lane < he) ? P.x_idx[hs + lane] : -1;
-      const uint16_t* to0 = P.toff + (long long)max(it0, 0) * (NT + 1);
-      int o_a = (it0 >= 0) ? (int)to0[0] : 0;              // offsets of tiles t+1, t+2, t+3 relative to the loop below
-      int o_b = (it0 >= 0) ? (int)to0[1] : 0;
-      int o_c = (it0 >= 0 && NT >= 2) ? (int)to0[2] : o_b;
-      // state of the prepared (next) tile's first chunk step
-      int p_s = 0, p_len = 0, p_choff = 0, p_nchunks = 0, p_n = 0;
-      v4i_a4 p_a = (v4i_a4){0, 0, 0, 0}, p_b = p_a;
-      auto prepare = [&](int oa, int ob) {
-        p_s = (it0 >= 0) ? it0 * K + oa : 0;
-        p_len = (it0 >= 0) ? ob - oa : 0;
-        const int nch = (p_len + PW_CH - 1) / PW_CH;
-        const int inc = rp_wave_incl_scan(nch, lane);
-        p_choff = inc - nch;
-        p_nchunks = __shfl(inc, 63);
-        int lo = 0;
-#pragma unroll
-        for (int step = 32; step > 0; step >>= 1) {
-          const int v = __shfl(p_choff, lo + step);
-          if (v <= lane) lo += step;
-        }
-        const int us = __shfl(p_s, lo), ulen = __shfl(p_len, lo), co = __shfl(p_choff, lo);
-        const int k0 = (lane - co) * PW_CH;
-        p_n = (lane < p_nchunks) ? min(PW_CH, ulen - k0) : 0;
-        if (p_n > 0) {
-          const int* src = pairs_i + 2 * (long long)(us + k0);
-          p_a = *reinterpret_cast<const v4i_a4*>(src);
-          p_b = *reinterpret_cast<const v4i_a4*>(src + 4);
-        }
-      };
-      auto add_chunk = [&](int n, const v4i_a4& a, const v4i_a4& b, int t0) {
-        const int ec[4] = {a.x, a.z, b.x, b.z};
-        const int ev[4] = {a.y, a.w, b.y, b.w};
-#pragma unroll
-        for (int e = 0; e < PW_CH; ++e) {
-          if (e < n) {
-            const int j = ec[e] - t0;
-            atomicAdd(&acc[j], rp_f32_to_fix(ev[e]));
-            atomicOr((uint32_t*)&dirty[j >> 5], 1u << (j & 31));
-          }
-        }
-      };
-      prepare(o_a, o_b);  // tile 0
-
-      for (int t = 0; t < NT; ++t) {
-        const int t0 = t * PW_WT;
-        // current tile = what was prepared; then prepare tile t+1 and fetch the offset of tile t+3
-        const int c_s = p_s, c_len = p_len, c_choff = p_choff, c_nchunks = p_nchunks, c_n = p_n;
-        const v4i_a4 c_a = p_a, c_b = p_b;
-        o_a = o_b;
-        o_b = o_c;
-        if (t + 3 <= NT && it0 >= 0) o_c = (int)to0[t + 3];
-        if (t + 1 < NT) prepare(o_a, o_b);
-        bool touched = c_nchunks > 0;
-        // ---- first batch: the prefetched first step, then any further steps
-        add_chunk(c_n, c_a, c_b, t0);
-        for (int c0 = 64; c0 < c_nchunks; c0 += 64) {
-          const int c = c0 + lane;
-          int lo = 0;
-#pragma unroll
-          for (int step = 32; step > 0; step >>= 1) {
-            const int v = __shfl(c_choff, lo + step);
-            if (v <= c) lo += step;
-          }
-          const int us = __shfl(c_s, lo), ulen = __shfl(c_len, lo), co = __shfl(c_choff, lo);
-          const int k0 = (c - co) * PW_CH;
-          const int n = (c < c_nchunks) ? min(PW_CH, ulen - k0) : 0;
-          v4i_a4 a = (v4i_a4){0, 0, 0, 0}, b2 = a;
-          if (n > 0) {
-            const int* src = pairs_i + 2 * (long long)(us + k0);
-            a = *reinterpret_cast<const v4i_a4*>(src);
-            b2 = *reinterpret_cast<const v4i_a4*>(src + 4);
-          }
-          add_chunk(n, a, b2, t0);
-        }
-        // ---- histories longer than 64 items: the remaining batches, not pipelined
-        for (int hb = hs + 64; hb < he; hb += 64) {
-          const int h = hb + lane;
-          int s = 0, len = 0;
-          if (h < he) {
-            const int it = P.x_idx[h];
-            const uint16_t* to = P.toff + (long long)it * (NT + 1) + t;
-            const int o0 = to[0], o1 = to[1];
-            s = it * K + o0;
-            len = o1 - o0;
-          }
-          const int nch = (len + PW_CH - 1) / PW_CH;
-          const int inc = rp_wave_incl_scan(nch, lane);
-          const int choff = inc - nch;
-          const int n_chunks = __shfl(inc, 63);
-          if (n_chunks > 0) touched = true;
-          for (int c0 = 0; c0 < n_chunks; c0 += 64) {
-            const int c = c0 + lane;
-            int lo = 0;  // owner = largest lane l with choff[l] <= c
-#pragma unroll
-            for (int step = 32; step > 0; step >>= 1) {
-              const int v = __shfl(choff, lo + step);
-              if (v <= c) lo += step;
-            }
-            const int us = __shfl(s, lo), ulen = __shfl(len, lo), co = __shfl(choff, lo);
-            const int k0 = (c - co) * PW_CH;
-            const int n = (c < n_chunks) ? min(PW_CH, ulen - k0) : 0;
-            v4i_a4 a = (v4i_a4){0, 0, 0, 0}, b2 = a;
-            if (n > 0) {
-              const int* src = pairs_i + 2 * (long long)(us + k0);
-              a = *reinterpret_cast<const v4i_a4*>(src);      // the pairs array is padded: reading past
-              b2 = *reinterpret_cast<const v4i_a4*>(src + 4);  // the slice's end is harmless
-            }
-            add_chunk(n, a, b2, t0);
-          }
-        }
-        PW_STAMP(1);
-        if (!touched) continue;
-        if (P.exclude_history) {
-          for (int h = hs + lane; h < he; h += 64) {
-            const int j = P.x_idx[h] - t0;
-            if ((unsigned)j < (unsigned)PW_WT) acc[j] = 0ull;  // the dirty bit stays: a zero sum is skipped below
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---- offer the touched columns to the pool: lane l walks the set bits of dirty word l
-        uint32_t w = dirty[lane];
-        dirty[lane] = 0u;
-        while (__any(w != 0u)) {
-          const bool has = w != 0u;
-          const int bpos = has ? (__ffs((int)w) - 1) : 0;
-          const int j = lane * 32 + bpos;
-          unsigned long long v = 0ull;
-          if (has) {
-            v = ((volatile unsigned long long*)acc)[j];
-            ((volatile unsigned long long*)acc)[j] = 0ull;
-            w &= w - 1u;
-          }
-          const uint32_t col = (uint32_t)(t0 + j);
-          const bool keep = has && v != 0ull && rp_wpool_admits<uint64_t, 0>(pool, v, col);
-          rp_wpool_push<uint64_t, 0>(pool, Kp, cap, keep, v, col, lane);
-        }
-        PW_STAMP(2);
-      }
+      const int nbu = (he - hs + 63) >> 6;
+      if (nbu <= 1)
+        rp_pw_user_tiles<1>(P, S, ul, hs, he);
+      else if (nbu <= 2)
+        rp_pw_user_tiles<2>(P, S, ul, hs, he);
+      else
+        rp_pw_user_tiles<4>(P, S, ul, hs, he);
       // ---- final: best Kp by (score desc, column asc), then column order for the output row
       __builtin_amdgcn_wave_barrier();
-      if (pool.n > Kp) rp_wpool_cut<uint64_t, 0>(pool, Kp, lane);
-      const int n_out = pool.n;
-      volatile uint64_t* pk = pool.key;
-      volatile uint32_t* pp = pool.pay;
+      if (S.pool.n > Kp) rp_wpool_cut<uint64_t, 0>(S.pool, Kp, lane);
+      const int n_out = S.pool.n;
+      volatile RP_LDS uint64_t* pk = S.pool.key;
+      volatile RP_LDS uint32_t* pp = S.pool.pay;
+      if (lane < 4) pp[n_out + lane] = 0xffffffffu;  // pads the last group of four (n_out + 4 <= cap)
+      typedef uint32_t v4u __attribute__((ext_vector_type(4)));
       for (int e = lane; e < n_out; e += 64) {
         const uint32_t col = pp[e];
         int rank = 0;
-        for (int o = 0; o < n_out; ++o) rank += (pp[o] < col) ? 1 : 0;
+        for (int o = 0; o < n_out; o += 4) {
+          const v4u q = *reinterpret_cast<volatile RP_LDS v4u*>(&pp[o]);
+          rank += (q.x < col ? 1 : 0) + (q.y < col ? 1 : 0) + (q.z < col ? 1 : 0) + (q.w < col ? 1 : 0);
+        }
         P.out_idx[(int64_t)ul * Kp + rank] = (int)col;
-        P.out_val[(int64_t)ul * Kp + rank] = (float)((double)pk[e] * 0x1p-50);
+        P.out_val[(int64_t)ul * Kp + rank] = (float)rp_fix_to_f64(pk[e] ^ RP_KEY_FLIP, S.fix.shift);
       }
       if (lane == 0) P.out_nnz[ul] = n_out;
       __builtin_amdgcn_wave_barrier();
       PW_STAMP(3);
-      PW_FLUSH();
+#ifdef RP_STAMPS
+      if (lane == 0) {
+        for (int _p = 0; _p < 8; ++_p) atomicAdd(&P.stamps[_p], S.t_ph[_p]);
+      }
+      for (int _p = 0; _p < 8; ++_p) S.t_ph[_p] = 0;
+#endif
     }
   }
 }
@@ -490,6 +659,8 @@ __global__ void k_model_finalize(const int32_t* __restrict__ idx, const double* 
     pairs[i] = make_int2(idx[i], __float_as_int(v));
     const int k = (int)(i % K);
     if (k > 0 && k < nnz[i / K] && idx[i] <= idx[i - 1]) *unsorted = 1;
+    const int ab = __float_as_int(v) & 0x7fffffff;  // |v| as ordered bits
+    if (k < nnz[i / K] && ab > unsorted[1]) atomicMax(&unsorted[1], ab);
   }
 }
 
@@ -500,14 +671,15 @@ int rp_model_finalize_topk(rphip_ctx* ctx, rphip_model* m) {
   if (n <= 0) return RPHIP_OK;
   int32_t* flag = nullptr;
   RP_TRY(rp_scratch(ctx, 5, 64, (void**)&flag));
-  RP_HIP(hipMemsetAsync(flag, 0, 4, ctx->stream));
+  RP_HIP(hipMemsetAsync(flag, 0, 8, ctx->stream));
   hipLaunchKernelGGL(k_model_finalize, dim3((unsigned)std::min<int64_t>(4096, rp_cdiv(n, 256))), dim3(256), 0, ctx->stream, m->idx, m->val,
                      m->nnz, m->K, rows, m->val32, m->pairs, flag);
   RP_HIP(hipGetLastError());
-  int32_t h = 0;
-  RP_HIP(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+  int32_t h[2] = {0, 0};
+  RP_HIP(hipMemcpyAsync(h, flag, 8, hipMemcpyDeviceToHost, ctx->stream));
   RP_HIP(hipStreamSynchronize(ctx->stream));
-  m->cols_sorted = (h == 0);
+  m->cols_sorted = (h[0] == 0);
+  std::memcpy(&m->vmax_abs, &h[1], 4);
   return RPHIP_OK;
 }
 
@@ -533,8 +705,14 @@ static void rp_pred_fill(rp_pred_params& P, const rphip_model* m, const rphip_cs
   P.dense_B = (m->kind == RPHIP_MODEL_DENSE) ? m->B : nullptr;
   P.dense_ld = m->ld;
   P.n_items = (int)X->n_items;
-  P.n_tiles = X->n_tiles;
-  P.tile_w = X->tile_w;
+  if (m->kind == RPHIP_MODEL_DENSE) {
+    P.n_tiles = X->n_tiles;
+    P.tile_w = X->tile_w;
+  } else {  // 8-byte sums: narrower tiles than K0's plan
+    P.n_tiles = (int)std::max<int64_t>(1, rp_cdiv(X->n_items, RP_PRED_FIX_TILE));
+    P.tile_w = (int)(rp_cdiv(rp_cdiv(std::max<int64_t>(X->n_items, 1), P.n_tiles), 64) * 64);
+  }
+  P.fix = rp_fix_make(rp_fix_shift(m->vmax_abs, X->max_user_deg));
   P.K = m->K;
   P.Kp = 0;
   P.exclude_history = 0;
@@ -552,7 +730,20 @@ static void rp_pred_fill(rp_pred_params& P, const rphip_model* m, const rphip_cs
   P.full_val = nullptr;
 }
 
-static size_t rp_pred_lds(int tile_w) { return (size_t)tile_w * 4 + rp_select_smem_bytes(tile_w); }
+static size_t rp_pred_lds(const rp_pred_params& P) { return (size_t)P.tile_w * (P.dense_B ? 4 : 8) + rp_select_smem_bytes(P.tile_w); }
+
+static int rp_pred_launch(rphip_ctx* ctx, const rp_pred_params& P, int grid) {
+  const size_t lds = rp_pred_lds(P);
+  if (P.dense_B) {
+    RP_HIP(hipFuncSetAttribute((const void*)k_predict_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_predict_tile<true>, dim3(grid), dim3(RP_PRED_THREADS), lds, ctx->stream, P);
+  } else {
+    RP_HIP(hipFuncSetAttribute((const void*)k_predict_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_predict_tile<false>, dim3(grid), dim3(RP_PRED_THREADS), lds, ctx->stream, P);
+  }
+  RP_HIP(hipGetLastError());
+  return RPHIP_OK;
+}
 
 // algorithmic bytes of K8: 8*K*nnz_pred + 4*(nnz_pred+U) + 8*U*Kp
 static double rp_pred_work(const rphip_csr* X, const rphip_model* m, int64_t n_users, int Kp) {
@@ -572,7 +763,6 @@ extern "C" int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, 
   const int64_t n = user_end - user_begin;
   if (n == 0) return RPHIP_OK;
   hipStream_t st = ctx->stream;
-  const int T = Xpred->n_tiles;
   hipMemsetAsync(idx_dev, 0xFF, (size_t)n * Kp * 4, st);
   hipMemsetAsync(val_dev, 0, (size_t)n * Kp * 4, st);
   hipMemsetAsync(nnz_dev, 0, (size_t)n * 4, st);
@@ -581,6 +771,7 @@ extern "C" int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, 
   P.Kp = Kp;
   P.exclude_history = exclude_history;
   P.mode = 0;
+  const int T = P.n_tiles;
   // neighbour-list models with column-sorted rows: wave-per-user kernel (any history length); otherwise (dense
   // models, unsorted lists, very large Kp) the workgroup kernel below
   const bool use_wave = model->kind == RPHIP_MODEL_TOPK && model->cols_sorted && Kp <= PW_KP_MAX && model->K < 65536 &&
@@ -610,6 +801,7 @@ extern "C" int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, 
     W.exclude_history = exclude_history;
     W.user_begin = (int)user_begin;
     W.n_users = (int)n;
+    W.fix = P.fix;
     W.ticket = tk;
     W.out_idx = idx_dev;
     W.out_val = val_dev;
@@ -634,8 +826,8 @@ extern "C" int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, 
       unsigned long long h[8];
       hipMemcpyAsync(h, W.stamps, sizeof(h), hipMemcpyDeviceToHost, st);
       hipStreamSynchronize(st);
-      fprintf(stderr, "[stamps predict_wave] cycles/1e6: setup %.1f accumulate %.1f scan+pool %.1f final %.1f (grid %d)\n", h[0] / 1e6, h[1] / 1e6,
-              h[2] / 1e6, h[3] / 1e6, wg);
+      fprintf(stderr, "[stamps predict_wave] cycles/1e6: setup %.1f accumulate %.1f scan+pool %.1f final %.1f (grid %d); walk rounds %llu, with a push %llu\n",
+              h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, wg, h[4], h[5]);
     }
 #endif
     rp_time_end(ctx, ev, RPHIP_T_PREDICT, rp_pred_work(Xpred, model, n, Kp));
@@ -661,10 +853,7 @@ extern "C" int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, 
     P.out_val = cand_val;
     P.out_nnz = cand_nnz;
   }
-  const size_t lds = rp_pred_lds(Xpred->tile_w);
-  RP_HIP(hipFuncSetAttribute((const void*)k_predict_sparse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int grid = (int)std::min<int64_t>(n * T, (int64_t)ctx->n_cu * 8);
-  hipLaunchKernelGGL(k_predict_sparse, dim3(grid), dim3(RP_PRED_THREADS), lds, st, P);
+  RP_TRY(rp_pred_launch(ctx, P, (int)std::min<int64_t>(n * T, (int64_t)ctx->n_cu * 8)));
   if (T > 1) {
     const size_t mlds = (size_t)T * Kp * 8 + rp_select_smem_bytes(T * Kp);
     if (mlds > 160 * 1024 || T * Kp >= RPS_FLAG)
@@ -718,13 +907,10 @@ extern "C" int rphip_predict_full_count(rphip_ctx* ctx, const rphip_model* model
   rp_pred_fill(P, model, Xpred, user_begin, user_end);
   P.mode = 1;
   P.row_nnz = dn;
-  const size_t lds = rp_pred_lds(Xpred->tile_w);
-  RP_HIP(hipFuncSetAttribute((const void*)k_predict_sparse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = (int)std::min<int64_t>(n, (int64_t)ctx->n_cu * 8);
   hipEvent_t ev;
   rp_time_begin(ctx, &ev);
-  hipLaunchKernelGGL(k_predict_sparse, dim3(grid), dim3(RP_PRED_THREADS), lds, ctx->stream, P);
-  RP_HIP(hipGetLastError());
+  RP_TRY(rp_pred_launch(ctx, P, grid));
   rp_time_end(ctx, ev, RPHIP_T_PREDICT, rp_pred_work(Xpred, model, n, 0));
   RP_HIP(hipMemcpyAsync(row_nnz_host, dn, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
   RP_HIP(hipStreamSynchronize(ctx->stream));
@@ -757,13 +943,10 @@ extern "C" int rphip_predict_full_fill(rphip_ctx* ctx, const rphip_model* model,
   P.indptr = dp;
   P.full_idx = di;
   P.full_val = dv;
-  const size_t lds = rp_pred_lds(Xpred->tile_w);
-  RP_HIP(hipFuncSetAttribute((const void*)k_predict_sparse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = (int)std::min<int64_t>(n, (int64_t)ctx->n_cu * 8);
   hipEvent_t ev;
   rp_time_begin(ctx, &ev);
-  hipLaunchKernelGGL(k_predict_sparse, dim3(grid), dim3(RP_PRED_THREADS), lds, ctx->stream, P);
-  RP_HIP(hipGetLastError());
+  RP_TRY(rp_pred_launch(ctx, P, grid));
   rp_time_end(ctx, ev, RPHIP_T_PREDICT, rp_pred_work(Xpred, model, n, 0) + 12.0 * (double)total);
   RP_HIP(hipMemcpyAsync(indices_host, di, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
   RP_HIP(hipMemcpyAsync(data_host, dv, (size_t)total * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -11,12 +11,16 @@
 
 #include "rp_common.h"
 
+// LDS pointers carry their address space: a plain (generic) pointer kept in a struct or made volatile compiles to
+// FLAT loads/stores, which count on vmcnt AND lgkmcnt - every wait on one then also drains the global loads in flight.
+#define RP_LDS __attribute__((address_space(3)))
+
 template <typename KeyT>
 struct rp_wpool {
-  KeyT* key;        // [CAP]
-  uint32_t* pay;    // [CAP] payload; the column is pay >> col_shift
-  uint32_t* hist;   // [256]
-  uint16_t* gidx;   // [64]
+  RP_LDS KeyT* key;        // [CAP]
+  RP_LDS uint32_t* pay;    // [CAP] payload; the column is pay >> col_shift
+  RP_LDS uint32_t* hist;   // [256]
+  RP_LDS uint16_t* gidx;   // [64]
   int n;            // entries in the pool (wave-uniform)
   KeyT tau;         // admission threshold: a candidate enters if key > tau, or key == tau and column < tau_col
   uint32_t tau_col; // (0 / 0 = everything positive)
@@ -35,13 +39,40 @@ __device__ __forceinline__ uint64_t rp_shfl_key<uint64_t>(uint64_t v, int src) {
   return ((uint64_t)hi << 32) | lo;
 }
 
-__device__ __forceinline__ int rp_wave_incl_scan(int v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int t = __shfl_up(v, d);
-    if (lane >= d) v += t;
-  }
+// Wave-wide inclusive scans on the VALU (DPP row shifts + row broadcasts, gfx9 encodings): no LDS round trips, where
+// a __shfl_up ladder is six dependent ds_bpermute.  Out-of-row sources read 0 (old = 0, bound_ctrl off).
+#define RP_DPP_ROW_SHR(n) (0x110 + (n))
+#define RP_DPP_ROW_BCAST15 0x142
+#define RP_DPP_ROW_BCAST31 0x143
+__device__ __forceinline__ int rp_wave_incl_scan(int v, int /*lane*/) {
+  v += __builtin_amdgcn_update_dpp(0, v, RP_DPP_ROW_SHR(1), 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, RP_DPP_ROW_SHR(2), 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, RP_DPP_ROW_SHR(4), 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, RP_DPP_ROW_SHR(8), 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, RP_DPP_ROW_BCAST15, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, RP_DPP_ROW_BCAST31, 0xc, 0xf, false);
   return v;
+}
+// inclusive running maximum of non-negative values
+__device__ __forceinline__ int rp_wave_incl_max(int v) {
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, RP_DPP_ROW_SHR(1), 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, RP_DPP_ROW_SHR(2), 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, RP_DPP_ROW_SHR(4), 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, RP_DPP_ROW_SHR(8), 0xf, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, RP_DPP_ROW_BCAST15, 0xa, 0xf, false));
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, RP_DPP_ROW_BCAST31, 0xc, 0xf, false));
+  return v;
+}
+
+// OR over the wave (returned in every lane's SGPR-uniform result)
+__device__ __forceinline__ uint32_t rp_wave_or(uint32_t v) {
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RP_DPP_ROW_SHR(1), 0xf, 0xf, false);
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RP_DPP_ROW_SHR(2), 0xf, 0xf, false);
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RP_DPP_ROW_SHR(4), 0xf, 0xf, false);
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RP_DPP_ROW_SHR(8), 0xf, 0xf, false);
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RP_DPP_ROW_BCAST15, 0xa, 0xf, false);
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RP_DPP_ROW_BCAST31, 0xc, 0xf, false);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // Cut the pool to its K best entries by (key desc, column asc); requires pool.n > K.  Sets pool.tau.
@@ -49,9 +80,9 @@ template <typename KeyT, int COL_SHIFT>
 __device__ void rp_wpool_cut(rp_wpool<KeyT>& P, int K, int lane) {
   constexpr int KEY_LEVELS = sizeof(KeyT);  // 8-bit digits
   const int n = P.n;
-  volatile KeyT* key = P.key;
-  volatile uint32_t* pay = P.pay;
-  volatile uint32_t* hist = P.hist;
+  volatile RP_LDS KeyT* key = P.key;
+  volatile RP_LDS uint32_t* pay = P.pay;
+  volatile RP_LDS uint32_t* hist = P.hist;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   KeyT pkey = 0;
   uint32_t pic = 0;  // decided prefix of ~column
@@ -59,7 +90,20 @@ __device__ void rp_wpool_cut(rp_wpool<KeyT>& P, int K, int lane) {
   KeyT tkey = 0;
   uint32_t tcol = 0xffffffffu;  // selected <=> key > tkey || (key == tkey && col <= tcol)
   bool done = false;
-  for (int level = 0; level < KEY_LEVELS + 4 && !done; ++level) {
+  // Skip the digits every key shares (fixed-point sums are far below the overflow bound, so the top bytes agree):
+  // OR of key ^ key[0] over the pool, first differing byte = first level worth a pass.
+  int level0 = 0;
+  {
+    const KeyT k0 = key[0];
+    KeyT diff = 0;
+    for (int e = lane; e < n; e += 64) diff |= key[e] ^ k0;
+    uint32_t dlo = rp_wave_or((uint32_t)diff), dhi = 0;
+    if (sizeof(KeyT) == 8) dhi = rp_wave_or((uint32_t)((uint64_t)diff >> 32));
+    const uint64_t d64 = sizeof(KeyT) == 8 ? (((uint64_t)dhi << 32) | dlo) : ((uint64_t)dlo << 32);
+    level0 = d64 ? (__builtin_clzll(d64) >> 3) : KEY_LEVELS;  // all keys equal: straight to the column digits
+    if (level0 > 0) pkey = level0 >= KEY_LEVELS ? k0 : (KeyT)(k0 & ~((((KeyT)1) << (8 * (KEY_LEVELS - level0))) - 1));
+  }
+  for (int level = level0; level < KEY_LEVELS + 4 && !done; ++level) {
     const bool is_col = level >= KEY_LEVELS;
     const int shift = is_col ? 8 * (3 - (level - KEY_LEVELS)) : 8 * (KEY_LEVELS - 1 - level);
 #pragma unroll
@@ -71,7 +115,7 @@ __device__ void rp_wpool_cut(rp_wpool<KeyT>& P, int K, int lane) {
       bool in_group;
       uint32_t d;
       if (!is_col) {
-        in_group = (level == 0) || ((k >> shift) >> 8) == ((pkey >> shift) >> 8);
+        in_group = (level == 0) || ((k >> shift) >> 8) == ((pkey >> shift) >> 8);  // the skipped prefix is shared by all
         d = (uint32_t)(k >> shift) & 255u;
       } else {
         in_group = (k == pkey) && ((level == KEY_LEVELS) || ((ic >> shift) >> 8) == ((pic >> shift) >> 8));
@@ -132,21 +176,22 @@ __device__ void rp_wpool_cut(rp_wpool<KeyT>& P, int K, int lane) {
             mem = (k == pkey) && ((ic >> shift) == (pic >> shift));
         }
         const uint64_t m = __ballot(mem);
-        if (mem) ((volatile uint16_t*)P.gidx)[base + __popcll(m & lt_mask)] = (uint16_t)e;
+        if (mem) ((volatile RP_LDS uint16_t*)P.gidx)[base + __popcll(m & lt_mask)] = (uint16_t)e;
         base += __popcll(m);
       }
       __builtin_amdgcn_wave_barrier();
       KeyT mk = 0;
       uint32_t mic = 0;
       if (lane < group) {
-        const int e = ((volatile uint16_t*)P.gidx)[lane];
+        const int e = ((volatile RP_LDS uint16_t*)P.gidx)[lane];
         mk = key[e];
         mic = ~(pay[e] >> COL_SHIFT);
       }
       int rank = 0;
-      for (int m = 0; m < group; ++m) {
-        const KeyT ok = rp_shfl_key<KeyT>(mk, m);
-        const uint32_t oic = (uint32_t)__shfl((int)mic, m);
+      for (int m = 0; m < group; ++m) {  // v_readlane broadcasts (m is uniform): no LDS round trips
+        KeyT ok = (KeyT)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mk, m);
+        if (sizeof(KeyT) == 8) ok |= (KeyT)((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)mk >> 32), m) << 32);
+        const uint32_t oic = (uint32_t)__builtin_amdgcn_readlane((int)mic, m);
         rank += ((ok > mk) || (ok == mk && oic > mic)) ? 1 : 0;
       }
       const uint64_t tm = __ballot(lane < group && rank == need - 1);
@@ -207,8 +252,8 @@ __device__ __forceinline__ void rp_wpool_push(rp_wpool<KeyT>& P, int K, int cap,
   }
   if (keep) {
     const int pos = P.n + __popcll(m & ((1ull << lane) - 1ull));
-    ((volatile KeyT*)P.key)[pos] = k;
-    ((volatile uint32_t*)P.pay)[pos] = pay;
+    ((volatile RP_LDS KeyT*)P.key)[pos] = k;
+    ((volatile RP_LDS uint32_t*)P.pay)[pos] = pay;
   }
   P.n += __popcll(m);
 }
