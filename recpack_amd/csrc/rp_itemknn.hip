@@ -19,6 +19,7 @@
 
 #include "rp_common.h"
 #include "rp_select.h"
+#include "rp_wave.h"
 
 struct rp_task {
   int32_t row;      // item row
@@ -84,12 +85,9 @@ __device__ __forceinline__ uint64_t rp_fit_key(uint32_t c, double colw, int pw =
 // accumulator tile: u32 counters (any row) or four byte counters per word (rows with <= 255 users: c_ij <= c_i)
 template <bool BYTES>
 struct rp_dense_src {
-  static constexpr bool PACK4 = BYTES;
   const uint32_t* acc;
   const double* inv_deg;
   int t0, row, n_cols, key_pow;
-  __device__ __forceinline__ uint32_t word(int wi) const { return acc[wi]; }
-  __device__ __forceinline__ int excluded_slot() const { return row - t0; }
   __device__ __forceinline__ uint32_t count(int w) const {
     if (BYTES) return (acc[w >> 2] >> (8 * (w & 3))) & 255u;
     return acc[w];
@@ -124,6 +122,7 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
   const int T = P.n_tiles;
 
   for (int w = tid; w < acc_words; w += NTHR) acc[w] = 0u;
+  if (tid == 0) sel.misc[RPS_USER + 16] = 0;  // first-touch block counter (light rows)
   const int n_tasks = *P.n_tasks;
 #ifdef RP_STAMPS
   unsigned long long t_last = __builtin_amdgcn_s_memtime();
@@ -168,6 +167,11 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
     const int row = tk.row, tile = tk.tile;
     const int t0 = tile * W;
     const int n_cols = min(W, P.n_items - t0);
+    // light rows: first-touch candidate list = pool of NBLK blocks of 64 entries shared by the waves
+    constexpr int NBLK = (SEG * NW) / 64;
+    int* blk_cnt = &sel.misc[RPS_USER + 16];  // blocks handed out (reset at the end of every task)
+    int lcnt = 0;             // candidates this wave appended
+    int blk = NBLK, fill = 64;  // current block (none yet) and its fill
 
     if (tk.mode != 2) {
       // ---- accumulate: users p in [p_begin, p_end) of item `row`.
@@ -175,6 +179,10 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
       // CH entries, and hands chunk c to lane c % 64: every lane then issues CH independent index loads
       // before the first LDS atomic, instead of one dependent load per user per round.
       constexpr int CH = 8;
+      volatile RP_LDS uint32_t* own_sc = (volatile RP_LDS uint32_t*)sel.hist + wave * 64;  // the histogram is idle here
+      RP_LDS uint16_t* ft_list = (RP_LDS uint16_t*)sel.list;  // light rows: first-touch candidates
+      const uint64_t lt_mask = (1ull << lane) - 1ull;
+      const int diag = row - t0;
       int n_prod = 0;
       const int stride = NW * 64;
       // software pipeline over the wave's batches of 64 users: the user ids of batch n+2 and the row pointers of
@@ -207,23 +215,20 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
         u_next = load_user(base + 2 * stride);    // batch n+2
         n_prod += len;
         const int nch = (len + CH - 1) / CH;
-        int inc = nch;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const int t = __shfl_up(inc, d);
-          if (lane >= d) inc += t;
-        }
+        const int inc = rp_wave_incl_scan(nch, lane);  // DPP: no LDS round trips
         const int choff = inc - nch;       // first chunk of this lane's user
-        const int n_chunks = __shfl(inc, 63);
-        // chunk c goes to lane c % 64; the index loads of step c0+64 are issued before the atomics of step c0
+        const int n_chunks = __builtin_amdgcn_readlane(inc, 63);
+        // chunk c goes to lane c % 64; the index loads of step c0+64 are issued before the atomics of step c0.
+        // Owner of chunk c = largest lane l with choff[l] <= c: every owner whose first chunk falls into this step
+        // writes its lane id at that chunk's slot of a 64-word LDS scratch, a running maximum (DPP) fills the gaps;
+        // slot 0 starts from the owner of the previous step's last chunk.  Steps are fetched in increasing order.
+        int carry = 0;
         auto fetch = [&](int c0, int (&jv)[CH]) {
           const int c = c0 + lane;
-          int lo = 0;                        // owner = largest lane l with choff[l] <= c
-#pragma unroll
-          for (int step = 32; step > 0; step >>= 1) {
-            const int v = __shfl(choff, lo + step);
-            if (v <= c) lo += step;
-          }
+          own_sc[lane] = (lane == 0) ? (uint32_t)carry : 0u;
+          if (nch > 0 && (unsigned)(choff - c0) < 64u) own_sc[choff - c0] = (uint32_t)lane;
+          const int lo = rp_wave_incl_max((int)own_sc[lane]);
+          carry = __builtin_amdgcn_readlane(lo, 63);
           const int us = __shfl(s, lo), ul = __shfl(len, lo), co = __shfl(choff, lo);
           const int k0 = (c - co) * CH;
           const int n = (c < n_chunks) ? min(CH, ul - k0) : 0;
@@ -246,15 +251,49 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
           for (int e = 0; e < CH; ++e) jv[e] = (e < n) ? jv[e] : -1;
         };
         auto apply = [&](const int (&jv)[CH]) {
+          if constexpr (BYTES) {
+            // returning adds: the lane that finds its byte at zero is the column's first toucher and appends the
+            // slot to the candidate list - the selection then never scans the tile.  The list is a pool of 64-entry
+            // blocks; a wave takes a new block (one LDS atomic) when its current one is full.
+            uint32_t old[CH];
 #pragma unroll
-          for (int e = 0; e < CH; ++e)
-            if (jv[e] >= 0) {
+            for (int e = 0; e < CH; ++e) {
               const int j = jv[e] - t0;
-              if (BYTES)
-                atomicAdd(&acc[j >> 2], 1u << (8 * (j & 3)));
-              else
-                atomicAdd(&acc[j], 1u);
+              old[e] = (jv[e] >= 0) ? atomicAdd(&acc[j >> 2], 1u << (8 * (j & 3))) : 0xffffffffu;
             }
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+              const int j = jv[e] - t0;
+              const bool first = jv[e] >= 0 && ((old[e] >> (8 * (j & 3))) & 255u) == 0u && j != diag;
+              const uint64_t m = __ballot(first);
+              if (m) {
+                const int n_new = __popcll(m);
+                const int pos = fill + __popcll(m & lt_mask);
+                int blk_next = blk;
+                if (fill + n_new > 64) {  // wave-uniform
+                  int b = 0;
+                  if (lane == 0) b = atomicAdd(blk_cnt, 1);
+                  blk_next = __builtin_amdgcn_readfirstlane(b);
+                }
+                if (first) {
+                  const int bk = (pos < 64) ? blk : blk_next;
+                  if (bk < NBLK) ft_list[bk * 64 + (pos & 63)] = (uint16_t)j;
+                }
+                if (fill + n_new > 64) {
+                  // the rest of the old block is full by construction; the new one holds the overflow so far
+                  blk = blk_next;
+                  fill = fill + n_new - 64;
+                } else {
+                  fill += n_new;
+                }
+                lcnt += n_new;
+              }
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < CH; ++e)
+              if (jv[e] >= 0) atomicAdd(&acc[jv[e] - t0], 1u);
+          }
         };
         int ja[CH], jb[CH];
         if (n_chunks > 0) fetch(0, ja);
@@ -267,6 +306,7 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
           }
         }
       }
+      if (BYTES && blk < NBLK && lane >= fill) ft_list[blk * 64 + lane] = (uint16_t)RPS_EMPTY;  // rest of the last block
       if (BYTES && P.n_products) {  // products done by the light kernel (roofline split between the two kernels)
         n_prod = rp_wave_sum(n_prod);
         if (lane == 0 && n_prod) atomicAdd(P.n_products, (unsigned long long)n_prod);
@@ -302,7 +342,14 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
     }
     // ---- select
     rp_dense_src<BYTES> src{acc, P.inv_deg, t0, row, n_cols, P.key_pow};
-    const int kp = rp_select_topk<NTHR>(src, n_cols, P.K, sel, SEG);
+    int kp;
+    if constexpr (BYTES) {
+      const int handed = *blk_cnt;  // (the barrier after the accumulate phase has passed)
+      kp = rp_select_topk<NTHR, rp_dense_src<BYTES>, true>(src, n_cols, P.K, sel, SEG, lcnt, handed > NBLK, min(handed, NBLK));
+      if (tid == 0) *blk_cnt = 0;  // every wave has read it before the barriers inside the selection
+    } else {
+      kp = rp_select_topk<NTHR>(src, n_cols, P.K, sel, SEG);
+    }
     RP_STAMP(3);
     if (BYTES && kp < 0) {
       // more candidates than the list holds: hand the task to the heavy kernel (it runs after this one)
@@ -321,25 +368,36 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
       int32_t* oi = P.out_idx + (int64_t)rl * P.K;
       double* ov = P.out_val + (int64_t)rl * P.K;
       const double ci = (double)P.deg[row];
-      rp_select_emit<NTHR>(n_cols, sel, [&](int pos, int w) {
+      auto emit = [&](int pos, int w) {
         const int j = t0 + w;
         oi[pos] = j;
         ov[pos] = (P.key_pow == 2) ? (double)src.count(w) / sqrt(ci * (double)P.deg[j])
                                    : ((double)src.count(w) * P.inv_deg[j]) / ci;
-      }, SEG);
+      };
+      if (BYTES)
+        rp_select_emit_sorted<NTHR>(sel, emit);
+      else
+        rp_select_emit<NTHR>(n_cols, sel, emit, SEG);
       if (tid == 0) P.out_nnz[rl] = kp;
     } else {
       const int64_t o = ((int64_t)rl * T + tile) * P.K;
-      rp_select_emit<NTHR>(n_cols, sel, [&](int pos, int w) {
+      auto emit = [&](int pos, int w) {
         P.out_idx[o + pos] = t0 + w;
         P.out_cnt[o + pos] = src.count(w);
-      }, SEG);
+      };
+      if (BYTES)
+        rp_select_emit_sorted<NTHR>(sel, emit);
+      else
+        rp_select_emit<NTHR>(n_cols, sel, emit, SEG);
       if (tid == 0) P.out_nnz[(int64_t)rl * T + tile] = kp;
     }
     // clear only what was touched: the candidates (every wave its own list segment) and the diagonal.
     // Byte tiles: the emit above still reads neighbouring bytes of a word, so clear after a barrier.
     if (BYTES) __syncthreads();
-    rp_select_foreach<NTHR>(n_cols, sel, [&](int w) { acc[BYTES ? (w >> 2) : w] = 0u; }, SEG);
+    if (BYTES)
+      rp_select_foreach_pre<NTHR>(sel, [&](int w) { acc[w >> 2] = 0u; });
+    else
+      rp_select_foreach<NTHR>(n_cols, sel, [&](int w) { acc[w] = 0u; }, SEG);
     if (tid == 0 && (unsigned)(row - t0) < (unsigned)n_cols) acc[BYTES ? ((row - t0) >> 2) : (row - t0)] = 0u;
     RP_STAMP(4);
   }

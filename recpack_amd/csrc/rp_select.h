@@ -13,6 +13,8 @@
 // Method
 //   1. compaction: every wave scans its contiguous share of the slots ONCE and writes the valid slot ids
 //      (u16) to its segment of an LDS list - all later passes touch candidates only (rows are ~5-10 % dense);
+//      with PRE the caller has already filled the segments (first-touch lists built while accumulating, in any
+//      order) and the results are emitted through rp_select_emit_sorted, which restores the column order;
 //   2. MSD radix select on the composite (key, ~col), 11 bits per level, histogram in LDS; as soon as the
 //      undecided group fits RP_SORT_CAP entries it is sorted exactly (bitonic) to read off the threshold;
 //   3. predicate pass flags the selected list entries (bit 15), a 16-entry scan orders the waves, emit.
@@ -47,6 +49,15 @@ struct rp_select_smem {
 
 constexpr int RPS_MISC_INTS = 96;
 constexpr int RPS_FLAG = 0x8000;
+constexpr int RPS_EMPTY = 0x7fff;  // PRE lists: unused entry of a partly filled block (no slot is that large)
+
+// Position of a wave's e-th list entry.  Scan-built lists: wave w owns [w*seg, (w+1)*seg).  PRE (first-touch) lists
+// are a shared pool of 64-entry blocks handed out while accumulating; for the selection wave w takes blocks
+// w, w+NW, w+2NW, .. whoever filled them, so the passes stay balanced.
+template <int NW, bool PRE>
+__device__ __forceinline__ int rp_list_pos(int wave, int seg, int e) {
+  return PRE ? ((((e >> 6) * NW + wave) << 6) | (e & 63)) : wave * seg + e;
+}
 
 __host__ __device__ constexpr int rp_per_wave(int n_slots, int nwaves) {
   return ((n_slots + nwaves * 64 - 1) / (nwaves * 64)) * 64;
@@ -120,11 +131,14 @@ enum {
 };
 
 // Returns K' (number of selected entries), or -1 when a wave found more candidates than its list segment holds
-// (seg_cap > 0 only; nothing is selected then and the caller must clear the tile densely).  Afterwards the list
-// holds the candidates of every wave segment (RPS_LCNT + w entries), selected ones flagged with RPS_FLAG; use
-// rp_select_emit / rp_select_foreach with the same seg_cap.
-template <int NTHR, class Src>
-__device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem s, int seg_cap = 0) {
+// (seg_cap > 0 only; nothing is selected then and the caller must clear the tile densely).  PRE: the caller filled
+// `pre_blocks` 64-entry blocks of the list itself (unused entries = RPS_EMPTY) and passes the number of candidates
+// its wave appended (pre_cnt) and whether the pool overflowed (pre_over).  Afterwards the list holds the candidates
+// (RPS_LCNT + w entries to visit per wave), selected ones flagged with RPS_FLAG; use rp_select_emit /
+// rp_select_emit_sorted / rp_select_foreach with the same seg_cap.
+template <int NTHR, class Src, bool PRE = false>
+__device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem s, int seg_cap = 0, int pre_cnt = 0,
+                              bool pre_over = false, int pre_blocks = 0) {
   static_assert(RP_HIST_BINS % NTHR == 0, "bins must divide over the threads");
   constexpr int BPT = RP_HIST_BINS / NTHR;  // histogram bins owned by one thread
   constexpr int NW = NTHR / 64;
@@ -135,43 +149,19 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
   const int w_end = min(n_slots, w_begin + per_wave);
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   const int seg = seg_cap ? seg_cap : per_wave;
-  uint16_t* mylist = s.list + wave * seg;
+  auto lpos = [&](int e) { return rp_list_pos<NW, PRE>(wave, seg, e); };
 
 #ifdef RP_STAMPS
   unsigned long long ts_last = __builtin_amdgcn_s_memtime();
 #endif
   // ---- 1. compaction
-  int cnt = 0;
+  int cnt = 0;       // list entries this wave visits
+  int n_mine = 0;    // candidates among them
   bool over = false;
-  if constexpr (Src::PACK4) {
-    // byte tiles: one u32 word (four slots) per lane and step; positions keep the column order
-    // (lane-major, byte-minor) from four ballots - no prefix scan
-    const int excl = src.excluded_slot();
-    for (int wb = w_begin >> 2; wb * 4 < w_end; wb += 64) {
-      const int wi = wb + lane;
-      const int s0 = wi * 4;
-      const uint32_t w = (s0 < w_end) ? src.word(wi) : 0u;
-      bool v[4];
-      uint64_t m[4];
-      int add = 0, below = 0, own = 0;
-#pragma unroll
-      for (int by = 0; by < 4; ++by) {
-        v[by] = ((w >> (8 * by)) & 255u) != 0u && (s0 + by) < w_end && (s0 + by) != excl;
-        m[by] = __ballot(v[by]);
-        add += __popcll(m[by]);
-        below += __popcll(m[by] & lt_mask);
-      }
-      if (cnt + add > seg) {
-        over = true;
-        break;
-      }
-#pragma unroll
-      for (int by = 0; by < 4; ++by) {
-        if (v[by]) mylist[cnt + below + own] = (uint16_t)(s0 + by);
-        own += v[by] ? 1 : 0;
-      }
-      cnt += add;
-    }
+  if constexpr (PRE) {
+    cnt = ((pre_blocks - wave + NW - 1) / NW) * 64;
+    n_mine = pre_cnt;  // what this wave appended: the sum over the waves is what counts
+    over = pre_over;
   } else {
     for (int b = w_begin; b < w_end; b += 64) {
       const int slot = b + lane;
@@ -182,12 +172,13 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
         over = true;
         break;
       }
-      if (v) mylist[cnt + __popcll(m & lt_mask)] = (uint16_t)slot;
+      if (v) s.list[lpos(cnt + __popcll(m & lt_mask))] = (uint16_t)slot;
       cnt += add;
     }
+    n_mine = cnt;
   }
   if (lane == 0) {
-    s.misc[RPS_RED + wave] = over ? -1 : cnt;
+    s.misc[RPS_RED + wave] = over ? -1 : n_mine;
     s.misc[RPS_LCNT + wave] = over ? 0 : cnt;
   }
   __syncthreads();
@@ -233,8 +224,8 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int e = e0 + u * 64 + lane;
-          ok[u] = e < cnt;
-          sl[u] = ok[u] ? (int)mylist[e] : 0;
+          sl[u] = (e < cnt) ? (int)s.list[lpos(e)] : RPS_EMPTY;
+          ok[u] = PRE ? sl[u] != RPS_EMPTY : e < cnt;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) kk[u] = ok[u] ? src.key(sl[u]) : 0ull;
@@ -313,8 +304,8 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int e = e0 + u * 64 + lane;
-            ok[u] = e < cnt;
-            sl[u] = ok[u] ? (int)mylist[e] : 0;
+            sl[u] = (e < cnt) ? (int)s.list[lpos(e)] : RPS_EMPTY;
+            ok[u] = PRE ? sl[u] != RPS_EMPTY : e < cnt;
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) kk[u] = ok[u] ? src.key(sl[u]) : 0ull;
@@ -413,8 +404,8 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = e0 + u * 64 + lane;
-      ok[u] = e < cnt;
-      sl[u] = ok[u] ? (int)mylist[e] : 0;
+      sl[u] = (e < cnt) ? (int)s.list[lpos(e)] : RPS_EMPTY;
+      ok[u] = PRE ? sl[u] != RPS_EMPTY : e < cnt;
     }
     if (kprime != n_valid) {
 #pragma unroll
@@ -430,7 +421,7 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
           const uint32_t ic = ~src.col(sl[u]);
           sel = (kk[u] > tkey) || (kk[u] == tkey && ic >= tcol);
         }
-        if (sel) mylist[e0 + u * 64 + lane] = (uint16_t)(sl[u] | RPS_FLAG);
+        if (sel) s.list[lpos(e0 + u * 64 + lane)] = (uint16_t)(sl[u] | RPS_FLAG);
       }
       wc += __popcll(__ballot(sel));
     }
@@ -465,6 +456,50 @@ __device__ __forceinline__ void rp_select_emit(int n_slots, rp_select_smem s, Em
     const uint64_t m = __ballot(sel);
     if (sel) emit(off + __popcll(m & ((1ull << lane) - 1ull)), v & (RPS_FLAG - 1));
     off += __popcll(m);
+  }
+}
+
+// Emit the selected slots in column order when the list segments are NOT column-ordered (first-touch lists):
+// the flagged slots are gathered into a small LDS array (over the dead histogram), every thread ranks its entries
+// by counting the smaller slots, emit(rank, slot).  Needs K <= RP_HIST_BINS * 2 selected entries.
+template <int NTHR, class Emit>
+__device__ __forceinline__ void rp_select_emit_sorted(rp_select_smem s, Emit emit) {
+  constexpr int NW = NTHR / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint16_t* buf = reinterpret_cast<uint16_t*>(s.hist);
+  const int cnt = s.misc[RPS_LCNT + wave];
+  int off = s.misc[RPS_WOFF + wave];
+  const int n_sel = s.misc[RPS_NSEL];
+  for (int e0 = 0; e0 < cnt; e0 += 64) {
+    const int v = (int)s.list[rp_list_pos<NW, true>(wave, 0, e0 + lane)];  // cnt is a multiple of 64
+    const bool sel = (v & RPS_FLAG) != 0;
+    const uint64_t m = __ballot(sel);
+    if (sel) buf[off + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(v & (RPS_FLAG - 1));
+    off += __popcll(m);
+  }
+  if (tid < 4) buf[n_sel + tid] = 0xffffu;  // pads the last group of four (written by nobody else)
+  __syncthreads();
+  const uint2* buf4 = reinterpret_cast<const uint2*>(s.hist);
+  for (int e = tid; e < n_sel; e += NTHR) {
+    const uint32_t slot = buf[e];
+    int rank = 0;
+    for (int o = 0; o < n_sel; o += 4) {
+      const uint2 q = buf4[o >> 2];
+      rank += ((q.x & 0xffffu) < slot ? 1 : 0) + ((q.x >> 16) < slot ? 1 : 0) + ((q.y & 0xffffu) < slot ? 1 : 0) + ((q.y >> 16) < slot ? 1 : 0);
+    }
+    emit(rank, (int)slot);
+  }
+}
+
+// PRE lists: visit every candidate slot (selected or not).
+template <int NTHR, class F>
+__device__ __forceinline__ void rp_select_foreach_pre(rp_select_smem s, F f) {
+  constexpr int NW = NTHR / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cnt = s.misc[RPS_LCNT + wave];
+  for (int e = lane; e < cnt; e += 64) {
+    const int v = (int)s.list[rp_list_pos<NW, true>(wave, 0, e)] & (RPS_FLAG - 1);
+    if (v != RPS_EMPTY) f(v);
   }
 }
 
