@@ -15,9 +15,11 @@
 //      (u16) to its segment of an LDS list - all later passes touch candidates only (rows are ~5-10 % dense);
 //      with PRE the caller has already filled the segments (first-touch lists built while accumulating, in any
 //      order) and the results are emitted through rp_select_emit_sorted, which restores the column order;
-//   2. MSD radix select on the composite (key, ~col), 11 bits per level, histogram in LDS; as soon as the
-//      undecided group fits RP_SORT_CAP entries it is sorted exactly (bitonic) to read off the threshold;
-//   3. predicate pass flags the selected list entries (bit 15), a 16-entry scan orders the waves, emit.
+//   2. MSD radix select on the composite (key, ~col), 11 bits per level, histogram in LDS, until the boundary bin
+//      holds at most RP_SORT_CAP candidates (or is selected as a whole);
+//   3. ONE classification pass: candidates above the boundary bin are flagged (bit 15 of the list entry), members
+//      of the bin are gathered with their list positions and ordered exactly (ranking in registers for <= 64,
+//      bitonic sort otherwise): the best of them are flagged too; a scan over the waves' counts orders the emit.
 // Every candidate is classified exactly - no sampling, no tolerance.
 #pragma once
 
@@ -71,7 +73,7 @@ __host__ __device__ constexpr size_t rp_select_smem_bytes(int n_slots, int nwave
 }
 
 __device__ __forceinline__ rp_select_smem rp_select_carve(char* base, int n_slots, int nwaves = 16, int seg_cap = 0) {
-  static_assert(RP_SORT_CAP * 12 <= RP_HIST_BINS * 4, "sort buffers overlay the histogram");
+  static_assert(RP_SORT_CAP * 14 <= RP_HIST_BINS * 4, "sort buffers (key, ~col, list position) overlay the histogram");
   const size_t list_entries = seg_cap ? (size_t)seg_cap * nwaves : (size_t)rp_list_cap(n_slots, nwaves);
   rp_select_smem s;
   s.hist = reinterpret_cast<uint32_t*>(base);
@@ -198,8 +200,12 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
   __syncthreads();
   RPS_STAMP(8);
 
-  uint64_t tkey = 0;  // threshold composite: selected <=> (key, ~col) >= (tkey, tcol)
-  uint32_t tcol = 0;
+  // outcome of the radix levels: the boundary bin (prefix fin_pkey/fin_pcol down to fin_shift) holds fin_group
+  // candidates of which fin_need are selected
+  bool have_fin = false, fin_is_col = false, fin_all = false;
+  int fin_shift = 0, fin_group = 0, fin_need = 0;
+  uint64_t fin_pkey = 0;
+  uint32_t fin_pcol = 0;
   if (kprime < n_valid) {
     uint64_t pkey = 0;  // decided prefix
     uint32_t pcol = 0;
@@ -288,106 +294,18 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
         pkey |= (uint64_t)bin << shift;
       else
         pcol |= (uint32_t)bin << shift;
-      if (group == need) {  // the whole group is selected: threshold = smallest composite with this prefix
-        tkey = pkey;
-        tcol = pcol;
-        break;
-      }
-      if (group <= RP_SORT_CAP) {
-        // exact: gather the group, sort descending, read the need-th
-        __syncthreads();  // hist is dead from here (skey overlays it)
-        RPS_STAMP(9);
-        for (int e0 = 0; e0 < cnt; e0 += 256) {
-          int sl[4];
-          bool ok[4];
-          uint64_t kk[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u * 64 + lane;
-            sl[u] = (e < cnt) ? (int)s.list[lpos(e)] : RPS_EMPTY;
-            ok[u] = PRE ? sl[u] != RPS_EMPTY : e < cnt;
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) kk[u] = ok[u] ? src.key(sl[u]) : 0ull;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (!ok[u]) continue;
-            const uint64_t k = kk[u];
-            const uint32_t ic = ~src.col(sl[u]);
-            bool in_group;
-            if (!is_col)
-              in_group = (k >> shift) == (pkey >> shift);
-            else
-              in_group = (k == pkey) && ((ic >> shift) == (pcol >> shift));
-            if (in_group) {
-              const int p = atomicAdd(&s.misc[RPS_CNT], 1);
-              s.skey[p] = k;
-              s.scol[p] = ic;
-            }
-          }
-        }
-        __syncthreads();
-        if (group <= 64) {
-          // one wave ranks the group in registers: the member with need-1 better members is the threshold
-          if (wave == 0) {
-            uint64_t mk = 0;
-            uint32_t mic = 0;
-            if (lane < group) {
-              mk = s.skey[lane];
-              mic = s.scol[lane];
-            }
-            int rank = 0;
-            for (int m2 = 0; m2 < group; ++m2) {
-              const uint32_t olo = (uint32_t)__shfl((int)(uint32_t)mk, m2);
-              const uint32_t ohi = (uint32_t)__shfl((int)(uint32_t)(mk >> 32), m2);
-              const uint32_t oic = (uint32_t)__shfl((int)mic, m2);
-              const uint64_t ok2 = ((uint64_t)ohi << 32) | olo;
-              rank += ((ok2 > mk) || (ok2 == mk && oic > mic)) ? 1 : 0;
-            }
-            if (lane < group && rank == need - 1) {
-              s.misc[RPS_TK] = (int)(uint32_t)mk;
-              s.misc[RPS_TK + 1] = (int)(uint32_t)(mk >> 32);
-              s.misc[RPS_TK + 2] = (int)mic;
-            }
-          }
-          __syncthreads();
-          tkey = ((uint64_t)(uint32_t)s.misc[RPS_TK + 1] << 32) | (uint32_t)s.misc[RPS_TK];
-          tcol = (uint32_t)s.misc[RPS_TK + 2];
-          __syncthreads();
-          RPS_STAMP(10);
-          break;
-        }
-        int n2 = 1;
-        while (n2 < group) n2 <<= 1;
-        for (int i = group + tid; i < n2; i += NTHR) {
-          s.skey[i] = 0;
-          s.scol[i] = 0;
-        }
-        __syncthreads();
-        for (int k2 = 2; k2 <= n2; k2 <<= 1) {
-          for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < n2; i += NTHR) {
-              const int ixj = i ^ j;
-              if (ixj > i) {
-                const uint64_t ka = s.skey[i], kb = s.skey[ixj];
-                const uint32_t ca = s.scol[i], cb = s.scol[ixj];
-                const bool a_lt_b = (ka < kb) || (ka == kb && ca < cb);
-                const bool desc = ((i & k2) == 0);  // descending in the first half
-                if (desc ? a_lt_b : !a_lt_b) {
-                  s.skey[i] = kb;
-                  s.skey[ixj] = ka;
-                  s.scol[i] = cb;
-                  s.scol[ixj] = ca;
-                }
-              }
-            }
-            __syncthreads();
-          }
-        }
-        tkey = s.skey[need - 1];
-        tcol = s.scol[need - 1];
-        __syncthreads();
-        RPS_STAMP(10);
+      if (group == need || group <= RP_SORT_CAP) {
+        // decided: everything above the boundary bin is selected; the bin itself entirely (group == need) or after an
+        // exact ordering of its members (fused pass below)
+        fin_shift = shift;
+        fin_is_col = is_col;
+        fin_all = (group == need);
+        fin_group = group;
+        fin_need = need;
+        fin_pkey = pkey;
+        fin_pcol = pcol;
+        have_fin = true;
+        __syncthreads();  // hist is dead from here (the sort buffers overlay it)
         break;
       }
       __syncthreads();
@@ -395,8 +313,10 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
   }
 
   RPS_STAMP(9);
-  // ---- 3. predicate pass: flag the selected entries, per-wave counts
+  // ---- 3. fused classification pass: one key evaluation per candidate.  Above the boundary bin -> flagged now;
+  // members of the bin -> flagged (whole bin selected) or gathered with their list position for the exact step.
   int wc = 0;
+  uint16_t* spos = reinterpret_cast<uint16_t*>(s.scol + RP_SORT_CAP);  // [RP_SORT_CAP] list positions of the members
   for (int e0 = 0; e0 < cnt; e0 += 256) {
     int sl[4];
     bool ok[4];
@@ -407,7 +327,7 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
       sl[u] = (e < cnt) ? (int)s.list[lpos(e)] : RPS_EMPTY;
       ok[u] = PRE ? sl[u] != RPS_EMPTY : e < cnt;
     }
-    if (kprime != n_valid) {
+    if (have_fin) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) kk[u] = ok[u] ? src.key(sl[u]) : 0ull;
     }
@@ -415,11 +335,26 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
     for (int u = 0; u < 4; ++u) {
       bool sel = false;
       if (ok[u]) {
-        if (kprime == n_valid) {
-          sel = true;
+        if (!have_fin) {
+          sel = true;  // fewer candidates than K: all of them
         } else {
+          const uint64_t k = kk[u];
           const uint32_t ic = ~src.col(sl[u]);
-          sel = (kk[u] > tkey) || (kk[u] == tkey && ic >= tcol);
+          bool above, member;
+          if (!fin_is_col) {
+            above = (k >> fin_shift) > (fin_pkey >> fin_shift);
+            member = (k >> fin_shift) == (fin_pkey >> fin_shift);
+          } else {
+            above = (k > fin_pkey) || (k == fin_pkey && (ic >> fin_shift) > (fin_pcol >> fin_shift));
+            member = (k == fin_pkey) && ((ic >> fin_shift) == (fin_pcol >> fin_shift));
+          }
+          sel = above || (member && fin_all);
+          if (member && !fin_all) {
+            const int p = atomicAdd(&s.misc[RPS_CNT], 1);
+            s.skey[p] = k;
+            s.scol[p] = ic;
+            spos[p] = (uint16_t)lpos(e0 + u * 64 + lane);
+          }
         }
         if (sel) s.list[lpos(e0 + u * 64 + lane)] = (uint16_t)(sl[u] | RPS_FLAG);
       }
@@ -428,6 +363,74 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
   }
   if (lane == 0) s.misc[RPS_RED + wave] = wc;
   __syncthreads();
+  RPS_STAMP(11);
+  if (have_fin && !fin_all) {
+    // ---- 4. exact order of the boundary bin's members: the fin_need best of them are selected too
+    const int group = fin_group, need = fin_need;
+    auto owner = [&](int pos) { return PRE ? ((pos >> 6) % NW) : (pos / seg); };
+    if (group <= 64) {
+      if (wave == 0) {  // one wave ranks the members in registers
+        uint64_t mk = 0;
+        uint32_t mic = 0;
+        if (lane < group) {
+          mk = s.skey[lane];
+          mic = s.scol[lane];
+        }
+        int rank = 0;
+        for (int m2 = 0; m2 < group; ++m2) {
+          const uint32_t olo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mk, m2);
+          const uint32_t ohi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mk >> 32), m2);
+          const uint32_t oic = (uint32_t)__builtin_amdgcn_readlane((int)mic, m2);
+          const uint64_t ok2 = ((uint64_t)ohi << 32) | olo;
+          rank += ((ok2 > mk) || (ok2 == mk && oic > mic)) ? 1 : 0;
+        }
+        if (lane < group && rank < need) {
+          const int pos = spos[lane];
+          s.list[pos] = (uint16_t)(s.list[pos] | RPS_FLAG);
+          atomicAdd(&s.misc[RPS_RED + owner(pos)], 1);
+        }
+      }
+    } else {
+      int n2 = 1;
+      while (n2 < group) n2 <<= 1;
+      for (int i = group + tid; i < n2; i += NTHR) {
+        s.skey[i] = 0;
+        s.scol[i] = 0;
+        spos[i] = 0;
+      }
+      __syncthreads();
+      for (int k2 = 2; k2 <= n2; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+          for (int i = tid; i < n2; i += NTHR) {
+            const int ixj = i ^ j;
+            if (ixj > i) {
+              const uint64_t ka = s.skey[i], kb = s.skey[ixj];
+              const uint32_t ca = s.scol[i], cb = s.scol[ixj];
+              const bool a_lt_b = (ka < kb) || (ka == kb && ca < cb);
+              const bool desc = ((i & k2) == 0);  // descending in the first half
+              if (desc ? a_lt_b : !a_lt_b) {
+                const uint16_t pa = spos[i], pb = spos[ixj];
+                s.skey[i] = kb;
+                s.skey[ixj] = ka;
+                s.scol[i] = cb;
+                s.scol[ixj] = ca;
+                spos[i] = pb;
+                spos[ixj] = pa;
+              }
+            }
+          }
+          __syncthreads();
+        }
+      }
+      for (int i = tid; i < need; i += NTHR) {
+        const int pos = spos[i];
+        s.list[pos] = (uint16_t)(s.list[pos] | RPS_FLAG);
+        atomicAdd(&s.misc[RPS_RED + owner(pos)], 1);
+      }
+    }
+    __syncthreads();
+    RPS_STAMP(10);
+  }
   if (tid == 0) {
     int off = 0;
     for (int w = 0; w < NW; ++w) {
