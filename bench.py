@@ -263,6 +263,17 @@ def main():
                 avg = t["ms"] / t["launches"]
                 by = 4.0 * p_share + other * (p_share / p_rank if p_rank else 0.0)
                 legs[name] = (avg, by)
+        # K8 (the longest phase of the step) priced with its own byte model: 8*K*nnz + 4*(nnz+U) + 8*U*Kp per rank share
+        tp = tm["predict"]
+        predict_leg = None
+        if tp["launches"]:
+            u_rank = user_parts[0][1] - user_parts[0][0]
+            share = u_rank / U
+            p_bytes = 8.0 * args.K * nnz * share + 4.0 * (nnz * share + u_rank) + 8.0 * u_rank * Kp
+            p_ms = tp["ms"] / tp["launches"]
+            predict_leg = {"kernel": "k_predict_wave (K8: scores + fused top-Kp)", "avg_launch_ms": round(p_ms, 4), "algorithmic_bytes": p_bytes,
+                           "GBps": round(p_bytes / (p_ms * 1e-3) / 1e9, 1), "frac": round(p_bytes / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "note": "bound by LDS-atomic and instruction issue, not HBM: the model (240 MB) stays in L2/MALL"}
         dom = max(legs, key=lambda k: legs[k][0])
         avg_ms, algo_bytes = legs[dom]
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -308,6 +319,7 @@ def main():
                 "avg_launch_ms": round(avg_ms, 4),
                 "legs": {k: {"avg_launch_ms": round(v[0], 4), "algorithmic_bytes": v[1],
                              "GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None} for k, v in legs.items()},
+                "predict": predict_leg,
                 "spgemm_all_kernels": {"ms": round(spgemm_ms, 4), "algorithmic_bytes": spgemm_bytes,
                                        "GBps": round(spgemm_bytes / (spgemm_ms * 1e-3) / 1e9, 1) if spgemm_ms > 0 else None,
                                        "frac": round(spgemm_bytes / (spgemm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if spgemm_ms > 0 else None},
