@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+LDS_ATOMIC_PEAK = 2.7e12  # measured: tools/lds_atomic_bench.hip, non-returning u32 LDS adds, all 256 CUs
 
 
 def parse():
@@ -319,6 +320,13 @@ def main():
                 "avg_launch_ms": round(avg_ms, 4),
                 "legs": {k: {"avg_launch_ms": round(v[0], 4), "algorithmic_bytes": v[1],
                              "GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None} for k, v in legs.items()},
+                # the three numbers of the SpGEMM - (i) the 4*P model above, (ii) bytes the PMC
+                # counters saw / time, (iii) accumulator updates per second against the LDS-atomic peak measured with
+                # tools/lds_atomic_bench.hip on MI355X (u32 adds, no return: 4.8 per clock per CU, 2.7e12/s chip-wide)
+                "measured_fabric_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic else None,
+                "accumulator_updates": {"per_s": round(p_rank / (spgemm_ms * 1e-3), 1) if spgemm_ms > 0 else None,
+                                        "lds_atomic_peak_per_s": LDS_ATOMIC_PEAK,
+                                        "frac": round(p_rank / (spgemm_ms * 1e-3) / LDS_ATOMIC_PEAK, 4) if spgemm_ms > 0 else None},
                 "predict": predict_leg,
                 "spgemm_all_kernels": {"ms": round(spgemm_ms, 4), "algorithmic_bytes": spgemm_bytes,
                                        "GBps": round(spgemm_bytes / (spgemm_ms * 1e-3) / 1e9, 1) if spgemm_ms > 0 else None,

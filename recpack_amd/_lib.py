@@ -116,6 +116,14 @@ def load_library(path: str | None = None):
         return lib
 
 
+def _torch_inputs_ready():
+    """The library runs on its own HIP stream: tensors a caller has just produced on torch's current stream must be
+    complete before the library reads them."""
+    import torch
+
+    torch.cuda.current_stream().synchronize()
+
+
 def check(code: int):
     if code != 0:
         msg = load_library().rphip_last_error()
@@ -190,6 +198,7 @@ class DeviceCSR:
     @classmethod
     def from_device(cls, ctx: Context, indptr_t, indices_t, shape):
         """indptr_t / indices_t: torch int32 CUDA tensors (kept alive by this object)."""
+        _torch_inputs_ready()
         h = C.c_void_p()
         check(ctx.lib.rphip_csr_from_device(ctx.handle, int(shape[0]), int(shape[1]), int(indices_t.numel()),
                                             C.c_void_p(indptr_t.data_ptr()), C.c_void_p(indices_t.data_ptr()), C.byref(h)))
@@ -252,6 +261,7 @@ class Model:
     @classmethod
     def from_topk_device(cls, ctx: Context, idx_t, val_t, nnz_t):
         """torch CUDA tensors: idx int32[I,K], val float64[I,K], nnz int32[I] (copied)."""
+        _torch_inputs_ready()
         h = C.c_void_p()
         check(ctx.lib.rphip_model_from_topk_device(ctx.handle, int(idx_t.shape[0]), int(idx_t.shape[1]), C.c_void_p(idx_t.data_ptr()),
                                                    C.c_void_p(val_t.data_ptr()), C.c_void_p(nnz_t.data_ptr()), C.byref(h)))
@@ -269,6 +279,12 @@ class Model:
         v = C.c_int64()
         check(self.ctx.lib.rphip_model_empty_rows(self.ctx.handle, self.handle, C.byref(v)))
         return v.value
+
+    def dense_device_ptr(self):
+        """(device pointer of B, n_items, leading dimension in floats) of a dense model."""
+        ptr, n, ld = C.c_void_p(), C.c_int64(), C.c_int64()
+        check(self.ctx.lib.rphip_model_dense_device(self.handle, C.byref(ptr), C.byref(n), C.byref(ld)))
+        return ptr.value, n.value, ld.value
 
     def dense_download(self) -> np.ndarray:
         out = np.empty((self.n_items, self.n_items), dtype=np.float32)
@@ -306,6 +322,7 @@ def ease_fit(ctx: Context, X: DeviceCSR, l2: float, alpha: float = 0.0) -> Model
 
 def gemm_nt(ctx: Context, A_t, B_t, C_t, alpha: float = 1.0, beta: float = 0.0):
     """C = alpha * A @ B.T + beta * C on torch float32 CUDA tensors (row-major, sizes multiples of 128 / 16)."""
+    _torch_inputs_ready()
     M, K = A_t.shape
     N = B_t.shape[0]
     check(ctx.lib.rphip_gemm_nt_f32(ctx.handle, M, N, K, float(alpha), C.c_void_p(A_t.data_ptr()), A_t.stride(0),

@@ -100,6 +100,15 @@ def model_topk_tensors(model, device):
     return idx, val, nnz
 
 
+def model_dense_tensor(model, device):
+    """torch view (no copy) of a dense model's B: float32 [n_items, n_items] with the library's row stride."""
+    import torch
+
+    ptr, n, ld = model.dense_device_ptr()
+    full = torch.as_tensor(_DevPtr(ptr, (n, ld), "<f4", model), device=device)
+    return full[:, :n]
+
+
 def fit_itemknn_sharded(ctx, dX, K: int, parts: Sequence[Tuple[int, int]], device, group=None):
     """Fit this rank's item rows on its GPU, all-gather, return a predict-ready full model (replicated)."""
     import torch
