@@ -40,6 +40,10 @@ struct rp_gemm_args {
   int m_off, n_off;
   int tri;           // 0: all tiles; 1: only tiles with n_off + n0 <= m_off + m0
   float alpha, beta;
+  // split-K (skinny products with few tiles and a long K): blockIdx.z = s handles K chunk s and writes its partial
+  // tile to part[s][M][N] (alpha = 1, beta = 0); k_splitk_reduce applies alpha / beta to C afterwards
+  float* part;
+  int k_chunk;
 };
 
 __global__ void __launch_bounds__(256) k_gemm_nt(rp_gemm_args g) {
@@ -47,9 +51,17 @@ __global__ void __launch_bounds__(256) k_gemm_nt(rp_gemm_args g) {
   __shared__ __attribute__((aligned(16))) float Bs[2][GT * GLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  // Tiles in plain row-major order: with the clipped K ranges of the triangular factors the top tile rows carry the
+  // longest K loops, so dispatch order = longest first.  (An XCD-contiguous regrouping for L2 reuse was measured and
+  // lost 50 % on P = N N^T: it hands all long rows to one XCD.)
+  const int tm = blockIdx.y, tn = blockIdx.x;
+  const int m0 = tm * GT, n0 = tn * GT;
   if (g.tri == 1 && g.n_off + n0 > g.m_off + m0) return;
-  int kb = g.k0;
+  int kb = g.k0, ke = g.k1;
+  if (g.part) {
+    kb = g.k0 + (int)blockIdx.z * g.k_chunk;
+    ke = min(g.k1, kb + g.k_chunk);
+  }
   if (g.kb_m) kb = max(kb, g.m_off + m0);
   if (g.kb_n) kb = max(kb, g.n_off + n0);
   kb &= ~(GBK - 1);
@@ -62,7 +74,7 @@ __global__ void __launch_bounds__(256) k_gemm_nt(rp_gemm_args g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  if (kb < g.k1) {
+  if (kb < ke) {
     const int lr = tid >> 2, lk = (tid & 3) * 4;
     const float* Ap = g.A + (long long)(m0 + lr) * g.lda + lk;
     const float* Bp = g.B + (long long)(n0 + lr) * g.ldb + lk;
@@ -85,8 +97,8 @@ __global__ void __launch_bounds__(256) k_gemm_nt(rp_gemm_args g) {
     const int arow = (wr * 64 + (lane & 31)) * GLD + (lane >> 5) * 4;
     const int brow = (wc * 64 + (lane & 31)) * GLD + (lane >> 5) * 4;
     int cur = 0;
-    for (int k = kb; k < g.k1; k += GBK) {
-      const bool more = (k + GBK) < g.k1;
+    for (int k = kb; k < ke; k += GBK) {
+      const bool more = (k + GBK) < ke;
       if (more) gload(k + GBK);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -119,12 +131,44 @@ __global__ void __launch_bounds__(256) k_gemm_nt(rp_gemm_args g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        float* cp = g.C + (long long)row * g.ldc + col;
-        float v = g.alpha * acc[i][j][r];
-        if (g.beta != 0.0f) v += g.beta * (*cp);
-        *cp = v;
+        if (g.part) {
+          g.part[((long long)blockIdx.z * g.M + row) * g.N + col] = acc[i][j][r];
+        } else {
+          float* cp = g.C + (long long)row * g.ldc + col;
+          float v = g.alpha * acc[i][j][r];
+          if (g.beta != 0.0f) v += g.beta * (*cp);
+          *cp = v;
+        }
       }
     }
+}
+
+// C = beta * C + alpha * sum_s part[s]  (fixed order of the partial sums: deterministic)
+__global__ void k_splitk_reduce(const float* __restrict__ part, int S, int M, int N, float alpha, float beta, float* __restrict__ C,
+                                long long ldc) {
+  const long long total = (long long)M * N / 4;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long row = (e * 4) / N;
+    const int col = (int)((e * 4) % N);
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s2 = 0; s2 < S; ++s2) {
+      const float4 v = *reinterpret_cast<const float4*>(part + ((long long)s2 * M + row) * N + col);
+      sum.x += v.x;
+      sum.y += v.y;
+      sum.z += v.z;
+      sum.w += v.w;
+    }
+    float4* cp = reinterpret_cast<float4*>(C + row * ldc + col);
+    float4 o = make_float4(alpha * sum.x, alpha * sum.y, alpha * sum.z, alpha * sum.w);
+    if (beta != 0.0f) {
+      const float4 c = *cp;
+      o.x += beta * c.x;
+      o.y += beta * c.y;
+      o.z += beta * c.z;
+      o.w += beta * c.w;
+    }
+    *cp = o;
+  }
 }
 
 // ---- diagonal block: Cholesky + inverse of a 128x128 block, float64 in LDS --------------------------------
@@ -257,7 +301,29 @@ __global__ void k_ease_scale(float* __restrict__ P, long long ld, int n, const f
 static int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g) {
   if (g.M <= 0 || g.N <= 0) return RPHIP_OK;
   if ((g.M % GT) || (g.N % GT) || (g.k0 % GBK) || (g.k1 % GBK)) RP_FAIL(RPHIP_EINVAL, "gemm_nt: sizes must be tile multiples");
-  hipLaunchKernelGGL(k_gemm_nt, dim3(g.N / GT, g.M / GT), dim3(256), 0, ctx->stream, g);
+  const long long tiles = (long long)(g.M / GT) * (g.N / GT);
+  const int klen = g.k1 - g.k0;
+  // few tiles and a long K: split K so that the launch fills the chip (partials in scratch, fixed-order reduce)
+  int S = 1;
+  if (!g.tri && tiles < 2LL * ctx->n_cu && klen >= 4096 && (g.ldc % 4) == 0) {
+    S = (int)std::min<long long>(8, std::min<long long>(klen / 2048, rp_cdiv(3LL * ctx->n_cu, tiles)));
+    if (S < 2) S = 1;
+  }
+  if (S == 1) {
+    hipLaunchKernelGGL(k_gemm_nt, dim3(g.N / GT, g.M / GT), dim3(256), 0, ctx->stream, g);
+    RP_HIP(hipGetLastError());
+    return RPHIP_OK;
+  }
+  rp_gemm_args h = g;
+  float* part = nullptr;
+  RP_TRY(rp_scratch(ctx, 7, (size_t)S * g.M * g.N * sizeof(float), (void**)&part));
+  h.part = part;
+  h.k_chunk = (int)(rp_cdiv(rp_cdiv(klen, S), GBK) * GBK);
+  hipLaunchKernelGGL(k_gemm_nt, dim3(g.N / GT, g.M / GT, S), dim3(256), 0, ctx->stream, h);
+  RP_HIP(hipGetLastError());
+  const long long quads = (long long)g.M * g.N / 4;
+  hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)std::min<long long>(4096, rp_cdiv(quads, 256))), dim3(256), 0, ctx->stream, part, S, g.M,
+                     g.N, g.alpha, g.beta, g.C, g.ldc);
   RP_HIP(hipGetLastError());
   return RPHIP_OK;
 }
@@ -296,6 +362,10 @@ static int rp_spd_inverse(rphip_ctx* ctx, float* A, float* Nb, int n_pad, long l
   int* info = (int*)wsb;
   float* W = (float*)(wsb + 256);                 // [nb][128][128]
   float* T = W + (size_t)nb * GT * GT;            // [n_pad][128]
+  {
+    void* pre = nullptr;  // the split-K partials of the skinny products: sized once for the tallest of them
+    RP_TRY(rp_scratch(ctx, 7, (size_t)8 * n_pad * GT * sizeof(float), &pre));
+  }
   RP_HIP(hipMemsetAsync(info, 0, 4, st));
   const size_t diag_lds = (size_t)GT * DS * sizeof(double);
   RP_HIP(hipFuncSetAttribute((const void*)k_potrf_trtri, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
