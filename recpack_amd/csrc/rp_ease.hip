@@ -298,31 +298,35 @@ __global__ void k_ease_scale(float* __restrict__ P, long long ld, int n, const f
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------
-static int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g) {
+// `st` = stream to launch on (the context's by default); `part_at` = where this product's split-K partials go
+// (two products that run concurrently on different streams must not share them)
+static int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st = nullptr, float* part_at = nullptr) {
+  if (!st) st = ctx->stream;
   if (g.M <= 0 || g.N <= 0) return RPHIP_OK;
   if ((g.M % GT) || (g.N % GT) || (g.k0 % GBK) || (g.k1 % GBK)) RP_FAIL(RPHIP_EINVAL, "gemm_nt: sizes must be tile multiples");
   const long long tiles = (long long)(g.M / GT) * (g.N / GT);
   const int klen = g.k1 - g.k0;
   // few tiles and a long K: split K so that the launch fills the chip (partials in scratch, fixed-order reduce)
   int S = 1;
+  // (thresholds 2-4 x CUs, targets 3-6 x CUs and minimum chunks of 512-2048 measured within noise of each other)
   if (!g.tri && tiles < 2LL * ctx->n_cu && klen >= 4096 && (g.ldc % 4) == 0) {
     S = (int)std::min<long long>(8, std::min<long long>(klen / 2048, rp_cdiv(3LL * ctx->n_cu, tiles)));
     if (S < 2) S = 1;
   }
   if (S == 1) {
-    hipLaunchKernelGGL(k_gemm_nt, dim3(g.N / GT, g.M / GT), dim3(256), 0, ctx->stream, g);
+    hipLaunchKernelGGL(k_gemm_nt, dim3(g.N / GT, g.M / GT), dim3(256), 0, st, g);
     RP_HIP(hipGetLastError());
     return RPHIP_OK;
   }
   rp_gemm_args h = g;
-  float* part = nullptr;
-  RP_TRY(rp_scratch(ctx, 7, (size_t)S * g.M * g.N * sizeof(float), (void**)&part));
+  float* part = part_at;
+  if (!part) RP_TRY(rp_scratch(ctx, 7, (size_t)S * g.M * g.N * sizeof(float), (void**)&part));
   h.part = part;
   h.k_chunk = (int)(rp_cdiv(rp_cdiv(klen, S), GBK) * GBK);
-  hipLaunchKernelGGL(k_gemm_nt, dim3(g.N / GT, g.M / GT, S), dim3(256), 0, ctx->stream, h);
+  hipLaunchKernelGGL(k_gemm_nt, dim3(g.N / GT, g.M / GT, S), dim3(256), 0, st, h);
   RP_HIP(hipGetLastError());
   const long long quads = (long long)g.M * g.N / 4;
-  hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)std::min<long long>(4096, rp_cdiv(quads, 256))), dim3(256), 0, ctx->stream, part, S, g.M,
+  hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)std::min<long long>(4096, rp_cdiv(quads, 256))), dim3(256), 0, st, part, S, g.M,
                      g.N, g.alpha, g.beta, g.C, g.ldc);
   RP_HIP(hipGetLastError());
   return RPHIP_OK;
@@ -362,53 +366,78 @@ static int rp_spd_inverse(rphip_ctx* ctx, float* A, float* Nb, int n_pad, long l
   int* info = (int*)wsb;
   float* W = (float*)(wsb + 256);                 // [nb][128][128]
   float* T = W + (size_t)nb * GT * GT;            // [n_pad][128]
-  {
-    void* pre = nullptr;  // the split-K partials of the skinny products: sized once for the tallest of them
-    RP_TRY(rp_scratch(ctx, 7, (size_t)8 * n_pad * GT * sizeof(float), &pre));
-  }
+  float* part_all = nullptr;  // the split-K partials of the skinny products: sized once for the tallest of them
+  RP_TRY(rp_scratch(ctx, 7, (size_t)8 * n_pad * GT * sizeof(float), (void**)&part_all));
   RP_HIP(hipMemsetAsync(info, 0, 4, st));
   const size_t diag_lds = (size_t)GT * DS * sizeof(double);
   RP_HIP(hipFuncSetAttribute((const void*)k_potrf_trtri, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
   const double n3 = (double)n_pad * n_pad * n_pad;
   hipEvent_t ev;
-  // ---- K5: left-looking blocked Cholesky
+  // ---- K5: left-looking blocked Cholesky.  The 128x128 diagonal block (its update and its float64 factorisation, one
+  // workgroup for 0.26 ms) runs on a side stream while the rest of the panel is updated on the main stream.
+  hipStream_t s2 = nullptr;
+  hipEvent_t e_panel = nullptr, e_diag = nullptr;
+  RP_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+  RP_HIP(hipEventCreateWithFlags(&e_panel, hipEventDisableTiming));
+  RP_HIP(hipEventCreateWithFlags(&e_diag, hipEventDisableTiming));
+  float* part_diag = part_all + (size_t)8 * (n_pad - GT) * GT;  // the side stream's own split-K partials
   rp_time_begin(ctx, &ev);
-  for (int k = 0; k < nb; ++k) {
+  int rc = RPHIP_OK;
+  for (int k = 0; k < nb && rc == RPHIP_OK; ++k) {
     const int r0 = k * GT;
-    if (k > 0) {
-      rp_gemm_args g{};
-      g.A = A + (long long)r0 * ld;
-      g.lda = ld;
-      g.B = A + (long long)r0 * ld;
-      g.ldb = ld;
-      g.C = A + (long long)r0 * ld + r0;
-      g.ldc = ld;
-      g.M = n_pad - r0;
-      g.N = GT;
-      g.k0 = 0;
-      g.k1 = r0;
-      g.alpha = -1.0f;
-      g.beta = 1.0f;
-      RP_TRY(rp_gemm_nt(ctx, g));
+    RP_HIP(hipEventRecord(e_panel, st));  // panel k-1 (and everything before) is complete
+    RP_HIP(hipStreamWaitEvent(s2, e_panel, 0));
+    rp_gemm_args g{};
+    g.A = A + (long long)r0 * ld;
+    g.lda = ld;
+    g.B = A + (long long)r0 * ld;
+    g.ldb = ld;
+    g.C = A + (long long)r0 * ld + r0;
+    g.ldc = ld;
+    g.N = GT;
+    g.k0 = 0;
+    g.k1 = r0;
+    g.alpha = -1.0f;
+    g.beta = 1.0f;
+    if (k > 0) {  // A[k,k] -= L[k,0:k] L[k,0:k]^T on the side stream
+      g.M = GT;
+      rc = rp_gemm_nt(ctx, g, s2, part_diag);
+      if (rc != RPHIP_OK) break;
     }
-    hipLaunchKernelGGL(k_potrf_trtri, dim3(1), dim3(1024), diag_lds, st, A + (long long)r0 * ld + r0, ld, W + (size_t)k * GT * GT, info);
+    hipLaunchKernelGGL(k_potrf_trtri, dim3(1), dim3(1024), diag_lds, s2, A + (long long)r0 * ld + r0, ld, W + (size_t)k * GT * GT, info);
+    RP_HIP(hipEventRecord(e_diag, s2));
     if (r0 + GT < n_pad) {
-      rp_gemm_args g{};
-      g.A = A + (long long)(r0 + GT) * ld + r0;
-      g.lda = ld;
-      g.B = W + (size_t)k * GT * GT;
-      g.ldb = GT;
-      g.C = A + (long long)(r0 + GT) * ld + r0;
-      g.ldc = ld;
-      g.M = n_pad - r0 - GT;
-      g.N = GT;
-      g.k0 = 0;
-      g.k1 = GT;
-      g.alpha = 1.0f;
-      g.beta = 0.0f;
-      RP_TRY(rp_gemm_nt(ctx, g));
+      if (k > 0) {  // A[k+1:,k] -= L[k+1:,0:k] L[k,0:k]^T
+        g.A = A + (long long)(r0 + GT) * ld;
+        g.C = A + (long long)(r0 + GT) * ld + r0;
+        g.M = n_pad - r0 - GT;
+        rc = rp_gemm_nt(ctx, g, st, part_all);
+        if (rc != RPHIP_OK) break;
+      }
+      RP_HIP(hipStreamWaitEvent(st, e_diag, 0));
+      rp_gemm_args h{};  // L[k+1:,k] = A[k+1:,k] W_k^T
+      h.A = A + (long long)(r0 + GT) * ld + r0;
+      h.lda = ld;
+      h.B = W + (size_t)k * GT * GT;
+      h.ldb = GT;
+      h.C = A + (long long)(r0 + GT) * ld + r0;
+      h.ldc = ld;
+      h.M = n_pad - r0 - GT;
+      h.N = GT;
+      h.k0 = 0;
+      h.k1 = GT;
+      h.alpha = 1.0f;
+      h.beta = 0.0f;
+      rc = rp_gemm_nt(ctx, h);
+    } else {
+      RP_HIP(hipStreamWaitEvent(st, e_diag, 0));
     }
   }
+  hipStreamSynchronize(s2);
+  hipEventDestroy(e_panel);
+  hipEventDestroy(e_diag);
+  hipStreamDestroy(s2);
+  if (rc != RPHIP_OK) return rc;
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, RPHIP_T_CHOLESKY, n3 / 3.0);
   // ---- K6a: N = L^-T (upper triangular), block column by block column
