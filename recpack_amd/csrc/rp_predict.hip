@@ -143,24 +143,60 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_tile(rp_pred_params
       const int n_cols = min(W, P.n_items - t0);
       // ---- accumulate
       if (DENSE) {
-        // K9: score[u, t0:t0+n_cols] = sum of the history items' rows of B; every thread owns CPT columns
-        // (registers, no atomics), rows are streamed coalesced
-        constexpr int CPT = (RP_TILE_MAX + RP_PRED_THREADS - 1) / RP_PRED_THREADS;
-        float r[CPT];
+        // K9: score[u, t0:t0+n_cols] = sum of the history items' rows of B.  Every thread owns groups of four
+        // consecutive columns (registers, no atomics); a row is streamed with one 16-byte load per group, two rows in
+        // flight (row stride and tile offsets are multiples of 64 floats, the rows are padded to 128)
+        constexpr int C4 = (RP_TILE_MAX + 4 * RP_PRED_THREADS - 1) / (4 * RP_PRED_THREADS);
+        float4 r[C4];
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) r[c] = 0.0f;
-        for (int h = hs; h < he; ++h) {
-          const float* Bi = P.dense_B + (long long)P.x_idx[h] * P.dense_ld + t0;
+        for (int c = 0; c < C4; ++c) r[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int w4 = (n_cols + 3) >> 2;  // groups in this tile (reads past n_cols stay inside the padded row)
+        auto add_row = [&](const float* Bi) {
 #pragma unroll
-          for (int c = 0; c < CPT; ++c) {
-            const int w = tid + c * RP_PRED_THREADS;
-            if (w < n_cols) r[c] += Bi[w];
+          for (int c = 0; c < C4; ++c) {
+            const int gq = tid + c * RP_PRED_THREADS;
+            if (gq < w4) {
+              const float4 v = *reinterpret_cast<const float4*>(Bi + 4 * gq);
+              r[c].x += v.x;
+              r[c].y += v.y;
+              r[c].z += v.z;
+              r[c].w += v.w;
+            }
+          }
+        };
+        int h = hs;
+        for (; h + 1 < he; h += 2) {
+          const float* B0 = P.dense_B + (long long)P.x_idx[h] * P.dense_ld + t0;
+          const float* B1 = P.dense_B + (long long)P.x_idx[h + 1] * P.dense_ld + t0;
+          float4 v0[C4], v1[C4];
+#pragma unroll
+          for (int c = 0; c < C4; ++c) {
+            const int gq = tid + c * RP_PRED_THREADS;
+            v0[c] = v1[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gq < w4) {
+              v0[c] = *reinterpret_cast<const float4*>(B0 + 4 * gq);
+              v1[c] = *reinterpret_cast<const float4*>(B1 + 4 * gq);
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < C4; ++c) {  // same order as the one-row form: row h, then row h+1
+            r[c].x = (r[c].x + v0[c].x) + v1[c].x;
+            r[c].y = (r[c].y + v0[c].y) + v1[c].y;
+            r[c].z = (r[c].z + v0[c].z) + v1[c].z;
+            r[c].w = (r[c].w + v0[c].w) + v1[c].w;
           }
         }
+        if (h < he) add_row(P.dense_B + (long long)P.x_idx[h] * P.dense_ld + t0);
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-          const int w = tid + c * RP_PRED_THREADS;
-          if (w < n_cols) accf[w] = r[c];
+        for (int c = 0; c < C4; ++c) {
+          const int gq = tid + c * RP_PRED_THREADS;
+          if (gq < w4) {
+            const int w = 4 * gq;
+            accf[w] = r[c].x;
+            if (w + 1 < n_cols) accf[w + 1] = r[c].y;
+            if (w + 2 < n_cols) accf[w + 2] = r[c].z;
+            if (w + 3 < n_cols) accf[w + 3] = r[c].w;
+          }
         }
       } else {
         for (int h = hs + wave; h < he; h += NW) {
