@@ -162,6 +162,16 @@ int rphip_predict_topk(rphip_ctx* ctx, const rphip_model* model, const rphip_csr
 int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred,
                            int64_t user_begin, int64_t user_end, int32_t Kp, int32_t exclude_history,
                            int32_t* idx_dev, float* val_dev, int32_t* nnz_dev);
+/* The same with an item filter applied to the scores before the top-Kp: only items with item_keep[j] != 0
+ * (n_items bytes; NULL = every item) can be recommended.  This is ExcludeItems / SelectItems
+ * (recpack/postprocessing/filters.py:58-101: X_pred.multiply(mask)) fused into the kernel, the step Pipeline runs
+ * between predict and the metrics (recpack/pipelines/pipeline.py:170-180). */
+int rphip_predict_topk_filtered(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin,
+                                int64_t user_end, int32_t Kp, int32_t exclude_history, const uint8_t* item_keep_host,
+                                int32_t* idx_host, float* val_host, int32_t* nnz_host);
+int rphip_predict_topk_filtered_dev(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred,
+                                    int64_t user_begin, int64_t user_end, int32_t Kp, int32_t exclude_history,
+                                    const uint8_t* item_keep_dev, int32_t* idx_dev, float* val_dev, int32_t* nnz_dev);
 /* exact reference semantics (every non-zero score): two phases.  _count fills row_nnz_host
  * (int64[n]) and returns the total; _fill writes CSR indices/data (float64) given the caller's
  * indptr (exclusive scan of row_nnz). */

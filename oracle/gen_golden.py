@@ -163,5 +163,57 @@ def main():
          cos_row_nnz=np.diff(cosf.indptr).astype(np.int64))
 
 
+def pipeline_case():
+    """C1 (BASELINE.json configs[0]): the MovieLens-100K sample that ships with the reference's tests
+    (recpack/tests/test_datasets/datasets/ml-100k_sample.data, default filters -> 373 x 390, 4620 interactions),
+    WeakGeneralization(0.75, seed=42), ItemKNN(K=50) and EASE(l2=20), history removal as in
+    pipelines/pipeline.py:174-175, NDCGK / RecallK / CalibratedRecallK / CoverageK at K=10.  Stored: the split's CSR
+    arrays, the reference's score matrices and metric values (data, not the sample file)."""
+    import logging
+
+    logging.disable(logging.CRITICAL)
+    from recpack.datasets import MovieLens100K
+    from recpack.metrics import NDCGK, CalibratedRecallK, CoverageK, RecallK
+    from recpack.postprocessing.filters import ExcludeItems
+    from recpack.scenarios import WeakGeneralization
+
+    d = MovieLens100K(path="/root/reference/recpack/tests/test_datasets/datasets", filename="ml-100k_sample.data")
+    im = d.load()
+    sc = WeakGeneralization(0.75, seed=42, validation=False)
+    sc.split(im)
+    tr, tin, tout = sc.full_training_data, sc.test_data_in, sc.test_data_out
+    arrays = {}
+    arrays.update(csr_parts("train", tr.values))
+    arrays.update(csr_parts("test_in", tin.values))
+    arrays.update(csr_parts("test_out", tout.values))
+    # a post-filter as Pipeline would apply it: the 20 most popular training items are not to be recommended
+    pop = np.argsort(-np.asarray(tr.binary_values.sum(axis=0)).ravel(), kind="stable")[:20]
+    arrays["excluded_items"] = pop.astype(np.int64)
+    names = []
+    for algo in (ItemKNN(K=50), EASE(l2=20)):
+        algo.fit(tr)
+        Xp = algo.predict(tin)
+        Xp = Xp - Xp.multiply(tin.binary_values)
+        Xp = sp.csr_matrix(Xp)
+        Xp.eliminate_zeros()
+        Xp.sort_indices()
+        arrays.update(csr_parts(f"scores_{algo.name}", Xp))
+        Xf = ExcludeItems(pop).apply(Xp)
+        for tag, M in (("", Xp), ("_filtered", Xf)):
+            vals = []
+            for metric in (NDCGK(10), RecallK(10), CalibratedRecallK(10), CoverageK(10)):
+                metric.calculate(tout.binary_values, M)
+                vals.append(float(metric.value))
+            arrays[f"metrics_{algo.name}{tag}"] = np.asarray(vals)
+            print(algo.name + tag, vals)
+        names.append(algo.name)
+    arrays["metric_names"] = np.asarray(["NDCGK_10", "RecallK_10", "CalibratedRecallK_10", "CoverageK_10"])
+    save("c1_pipeline_ml100k", **arrays)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "pipeline":
+        pipeline_case()
+    else:
+        main()
+        pipeline_case()

@@ -227,3 +227,42 @@ def ease_prune(B: np.ndarray, density: float) -> np.ndarray:
         r = np.repeat(np.arange(n), np.diff(S.indptr))
         out[r[drop], S.indices[drop]] = 0.0
     return out
+
+
+def pipeline_scores(scores: sp.csr_matrix, history: sp.csr_matrix | None = None, item_keep: np.ndarray | None = None) -> sp.csr_matrix:
+    """What Pipeline does to the predicted scores before the metrics (pipelines/pipeline.py:170-180): history removal
+    ``X_pred - X_pred.multiply(data_in.binary_values)`` and the post-filters ``X_pred.multiply(mask)``
+    (postprocessing/filters.py:58-101)."""
+    out = sp.csr_matrix(scores, dtype=np.float64)
+    if history is not None:
+        out = (out - out.multiply(binarize(sp.csr_matrix(history)))).tocsr()
+    if item_keep is not None:
+        out = out.multiply(np.asarray(item_keep, dtype=bool)).tocsr()
+    out.eliminate_zeros()
+    return out
+
+
+def metrics_topk(y_true: sp.csr_matrix, scores: sp.csr_matrix, K: int) -> dict:
+    """NDCGK / RecallK / CalibratedRecallK / CoverageK of the reference (metrics/dcg.py:98-137, recall.py:34-44, 75-85,
+    coverage.py:30-36, user elimination metrics/base.py:97-118) from a FULL score matrix, per-user loop, with the
+    deterministic rank order (score desc, item id asc) inside the top-K."""
+    y_true = binarize(sp.csr_matrix(y_true))
+    scores = sp.csr_matrix(scores)
+    discount = 1.0 / np.log2(np.arange(2, K + 2))
+    idcg = np.concatenate([[1.0], np.cumsum(discount)])
+    ndcg, rec, crec = [], [], []
+    covered = set()
+    for u in np.nonzero(np.diff(y_true.indptr) > 0)[0]:
+        cols = scores.indices[scores.indptr[u]:scores.indptr[u + 1]]
+        vals = scores.data[scores.indptr[u]:scores.indptr[u + 1]]
+        nz = vals != 0
+        cols, vals = cols[nz], vals[nz]
+        top = cols[np.lexsort((cols, -vals))[:K]]
+        covered.update(top.tolist())
+        true = y_true.indices[y_true.indptr[u]:y_true.indptr[u + 1]]
+        hit = np.isin(top, true).astype(np.float64)
+        ndcg.append(float((hit * discount[: len(top)]).sum()) / idcg[min(K, len(true))])
+        rec.append(hit.sum() / len(true))
+        crec.append(hit.sum() / min(K, len(true)))
+    return {"ndcg": float(np.mean(ndcg)), "recall": float(np.mean(rec)), "calibrated_recall": float(np.mean(crec)),
+            "coverage": len(covered) / scores.shape[1]}

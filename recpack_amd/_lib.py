@@ -78,6 +78,8 @@ PROTOTYPES = {
     "rphip_model_info": (C.c_int, [_p, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]),
     "rphip_predict_topk": (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _p]),
     "rphip_predict_topk_dev": (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _p]),
+    "rphip_predict_topk_filtered": (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _p]),
+    "rphip_predict_topk_filtered_dev": (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _p]),
     "rphip_predict_full_count": (C.c_int, [_p, _p, _p, _i64, _i64, _p, C.POINTER(_i64)]),
     "rphip_predict_full_fill": (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p, _p]),
     "rphip_ease_fit": (C.c_int, [_p, _p, _f64, _f64, _pp]),
@@ -330,24 +332,36 @@ def gemm_nt(ctx: Context, A_t, B_t, C_t, alpha: float = 1.0, beta: float = 0.0):
 
 
 def predict_topk(ctx: Context, model: Model, X: DeviceCSR, Kp: int, exclude_history: bool = False, user_begin: int = 0,
-                 user_end: int | None = None):
+                 user_end: int | None = None, item_keep: np.ndarray | None = None):
+    """item_keep: optional bool/uint8[n_items]; only items with a non-zero entry can be recommended
+    (ExcludeItems / SelectItems of recpack/postprocessing/filters.py:58-101, fused)."""
     user_end = X.shape[0] if user_end is None else user_end
     n = user_end - user_begin
     idx = np.empty((n, Kp), dtype=np.int32)
     val = np.empty((n, Kp), dtype=np.float32)
     nnz = np.empty(n, dtype=np.int32)
-    check(ctx.lib.rphip_predict_topk(ctx.handle, model.handle, X.handle, int(user_begin), int(user_end), int(Kp),
-                                     1 if exclude_history else 0, _np_ptr(idx), _np_ptr(val), _np_ptr(nnz)))
+    keep_p = None
+    if item_keep is not None:
+        item_keep = np.ascontiguousarray(np.asarray(item_keep) != 0, dtype=np.uint8)
+        if item_keep.shape != (X.shape[1],):
+            raise ValueError(f"item_keep has shape {item_keep.shape}, expected ({X.shape[1]},)")
+        keep_p = _np_ptr(item_keep)
+    check(ctx.lib.rphip_predict_topk_filtered(ctx.handle, model.handle, X.handle, int(user_begin), int(user_end), int(Kp),
+                                              1 if exclude_history else 0, keep_p, _np_ptr(idx), _np_ptr(val), _np_ptr(nnz)))
     return idx, val, nnz
 
 
 def predict_topk_dev(ctx: Context, model: Model, X: DeviceCSR, Kp: int, idx_t, val_t, nnz_t, exclude_history: bool = False,
-                     user_begin: int = 0, user_end: int | None = None):
-    """Outputs into torch CUDA tensors idx int32[n,Kp], val float32[n,Kp], nnz int32[n]; asynchronous."""
+                     user_begin: int = 0, user_end: int | None = None, item_keep_t=None):
+    """Outputs into torch CUDA tensors idx int32[n,Kp], val float32[n,Kp], nnz int32[n]; asynchronous.
+    item_keep_t: optional torch uint8 CUDA tensor [n_items]."""
     user_end = X.shape[0] if user_end is None else user_end
-    check(ctx.lib.rphip_predict_topk_dev(ctx.handle, model.handle, X.handle, int(user_begin), int(user_end), int(Kp),
-                                         1 if exclude_history else 0, C.c_void_p(idx_t.data_ptr()), C.c_void_p(val_t.data_ptr()),
-                                         C.c_void_p(nnz_t.data_ptr())))
+    if item_keep_t is not None:
+        _torch_inputs_ready()
+    check(ctx.lib.rphip_predict_topk_filtered_dev(ctx.handle, model.handle, X.handle, int(user_begin), int(user_end), int(Kp),
+                                                  1 if exclude_history else 0,
+                                                  C.c_void_p(item_keep_t.data_ptr()) if item_keep_t is not None else None,
+                                                  C.c_void_p(idx_t.data_ptr()), C.c_void_p(val_t.data_ptr()), C.c_void_p(nnz_t.data_ptr())))
 
 
 def predict_full(ctx: Context, model: Model, X: DeviceCSR, user_begin: int = 0, user_end: int | None = None):

@@ -154,13 +154,29 @@ class ItemSimilarityMatrixAlgorithm(Algorithm):
             dX.close()
         return sp.csr_matrix((data, indices, indptr), shape=X.shape)
 
-    def predict_topk(self, X, K: int, exclude_history: bool = False) -> sp.csr_matrix:
-        """Top-K scores per user (column-sorted CSR rows, float32 scores widened to float64)."""
+    def predict_topk(self, X, K: int, exclude_history: bool = False, exclude_items=None, select_items=None) -> sp.csr_matrix:
+        """Top-K scores per user (column-sorted CSR rows, float32 scores widened to float64).
+
+        The steps recpack's Pipeline applies between predict and the metrics, fused into the kernel:
+        ``exclude_history`` (pipelines/pipeline.py:174-175), ``exclude_items`` / ``select_items`` = the
+        ExcludeItems / SelectItems post-filters (postprocessing/filters.py:58-101, same argument checks), and the
+        per-user top-K of MetricTopK (metrics/base.py:189)."""
         self._check_fit_complete()
         X = self._transform_predict_input(X)
+        n_items = X.shape[1]
+        keep = None
+        for items, select in ((exclude_items, False), (select_items, True)):
+            if items is None:
+                continue
+            items = np.asarray(items)
+            if len(items) == 0 or np.amax(items) > n_items:  # filters.py:69-70, 91-92
+                raise ValueError(f"{X.shape} and {items.shape}")
+            m = np.zeros(n_items, dtype=bool) if select else np.ones(n_items, dtype=bool)
+            m[items] = select
+            keep = m if keep is None else (keep & m)
         ctx, dX = self._upload(X)
         try:
-            idx, val, nnz = _lib.predict_topk(ctx, self._model, dX, min(int(K), max(1, X.shape[1])), exclude_history)
+            idx, val, nnz = _lib.predict_topk(ctx, self._model, dX, min(int(K), max(1, n_items)), exclude_history, item_keep=keep)
         finally:
             dX.close()
         mask = np.arange(idx.shape[1])[None, :] < nnz[:, None]

@@ -68,6 +68,7 @@ struct rp_pred_params {
   const int32_t* s_nnz;
   const float* dense_B;   // K9: dense model (EASE), row-major with leading dimension dense_ld; NULL for neighbour lists
   long long dense_ld;
+  const uint8_t* keep;    // optional item filter (mode 0): only items with keep[j] != 0 are candidates
   int n_items, n_tiles, tile_w, K, Kp, exclude_history;
   rp_fix_scale fix;       // neighbour lists: scale of the fixed-point sums
   int user_begin, n_users;
@@ -89,9 +90,10 @@ struct rp_score_src {
   static constexpr bool PACK4 = false;
   const void* acc_;
   int t0;
+  const uint8_t* keep;
   __device__ __forceinline__ bool valid(int w) const {
-    if (DENSE) return ((const float*)acc_)[w] != 0.0f;
-    return ((const unsigned long long*)acc_)[w] != 0ull;
+    const bool nz = DENSE ? ((const float*)acc_)[w] != 0.0f : ((const unsigned long long*)acc_)[w] != 0ull;
+    return nz && (!keep || keep[t0 + w] != 0);
   }
   __device__ __forceinline__ uint64_t key(int w) const {
     if (DENSE) {  // order-preserving map of a float (any sign) to u32, placed in the high half
@@ -219,7 +221,7 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_tile(rp_pred_params
         __syncthreads();
       }
       // ---- select
-      rp_score_src<DENSE> src{smem, t0};
+      rp_score_src<DENSE> src{smem, t0, P.mode == 0 ? P.keep : nullptr};
       const int kk = (P.mode == 0) ? P.Kp : 0x7fffffff;
       const int kp = rp_select_topk<RP_PRED_THREADS>(src, n_cols, kk, sel);
       if (P.mode == 0) {
@@ -237,7 +239,12 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_tile(rp_pred_params
         off += kp;
       }
       total += kp;
-      rp_select_foreach<RP_PRED_THREADS>(n_cols, sel, [&](int w) { clear(w); });  // clear what was touched
+      if (P.keep && P.mode == 0) {  // filtered-out columns are not in the candidate list: clear the whole tile
+        __syncthreads();
+        for (int w = tid; w < n_cols; w += RP_PRED_THREADS) clear(w);
+      } else {
+        rp_select_foreach<RP_PRED_THREADS>(n_cols, sel, [&](int w) { clear(w); });  // clear what was touched
+      }
       __syncthreads();
     }
     if (P.mode == 1 && tid == 0) P.row_nnz[ul] = total;
@@ -335,6 +342,7 @@ struct rp_pw_params {
   const int32_t* x_idx;
   const int2* pairs;
   const uint16_t* toff;  // [I * (n_wt + 1)]
+  const uint8_t* keep;   // optional item filter: only items with keep[j] != 0 are candidates
   int n_items, n_wt, K, Kp, exclude_history, user_begin, n_users;
   rp_fix_scale fix;
   int32_t* ticket;
@@ -570,6 +578,7 @@ __device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_st
       for (int q = 0; q < 4; ++q) {
         v[q] ^= RP_KEY_FLIP;  // signed sum -> unsigned order; a zero sum is no candidate
         kq[q] = has[q] && v[q] != RP_KEY_FLIP && rp_wpool_admits<uint64_t, 0>(S.pool, v[q], (uint32_t)(t0 + j[q]));
+        if (P.keep && kq[q]) kq[q] = P.keep[t0 + j[q]] != 0;  // only sums that would enter the pool pay the lookup
         anyk |= kq[q];
       }
       PW_COUNT(4, 1);
@@ -740,6 +749,7 @@ static void rp_pred_fill(rp_pred_params& P, const rphip_model* m, const rphip_cs
   P.s_nnz = m->nnz;
   P.dense_B = (m->kind == RPHIP_MODEL_DENSE) ? m->B : nullptr;
   P.dense_ld = m->ld;
+  P.keep = nullptr;
   P.n_items = (int)X->n_items;
   if (m->kind == RPHIP_MODEL_DENSE) {
     P.n_tiles = X->n_tiles;
@@ -789,9 +799,9 @@ static double rp_pred_work(const rphip_csr* X, const rphip_model* m, int64_t n_u
   return 8.0 * m->K * (double)X->nnz * share + 4.0 * ((double)X->nnz * share + (double)n_users) + 8.0 * (double)n_users * Kp;
 }
 
-extern "C" int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin,
-                                      int64_t user_end, int32_t Kp, int32_t exclude_history, int32_t* idx_dev, float* val_dev,
-                                      int32_t* nnz_dev) {
+static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin,
+                                int64_t user_end, int32_t Kp, int32_t exclude_history, const uint8_t* keep_dev, int32_t* idx_dev,
+                                float* val_dev, int32_t* nnz_dev) {
   RP_TRY(rp_pred_check(ctx, model, Xpred, user_begin, user_end));
   if (!idx_dev || !val_dev || !nnz_dev) RP_FAIL(RPHIP_EINVAL, "NULL output");
   if (Kp < 1 || Kp > RP_K_MAX) RP_FAIL(RPHIP_ELIMIT, "Kp=%d outside 1..%d", Kp, RP_K_MAX);
@@ -807,6 +817,7 @@ extern "C" int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, 
   P.Kp = Kp;
   P.exclude_history = exclude_history;
   P.mode = 0;
+  P.keep = keep_dev;
   const int T = P.n_tiles;
   // neighbour-list models with column-sorted rows: wave-per-user kernel (any history length); otherwise (dense
   // models, unsorted lists, very large Kp) the workgroup kernel below
@@ -830,6 +841,7 @@ extern "C" int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, 
     W.x_idx = Xpred->x_idx;
     W.pairs = model->pairs;
     W.toff = mm->toff;
+    W.keep = keep_dev;
     W.n_items = (int)Xpred->n_items;
     W.n_wt = n_wt;
     W.K = model->K;
@@ -904,9 +916,27 @@ extern "C" int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, 
   return RPHIP_OK;
 }
 
+extern "C" int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin,
+                                      int64_t user_end, int32_t Kp, int32_t exclude_history, int32_t* idx_dev, float* val_dev,
+                                      int32_t* nnz_dev) {
+  return rp_predict_topk_impl(ctx, model, Xpred, user_begin, user_end, Kp, exclude_history, nullptr, idx_dev, val_dev, nnz_dev);
+}
+
+extern "C" int rphip_predict_topk_filtered_dev(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin,
+                                               int64_t user_end, int32_t Kp, int32_t exclude_history, const uint8_t* item_keep_dev,
+                                               int32_t* idx_dev, float* val_dev, int32_t* nnz_dev) {
+  return rp_predict_topk_impl(ctx, model, Xpred, user_begin, user_end, Kp, exclude_history, item_keep_dev, idx_dev, val_dev, nnz_dev);
+}
+
 extern "C" int rphip_predict_topk(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin,
                                   int64_t user_end, int32_t Kp, int32_t exclude_history, int32_t* idx_host, float* val_host,
                                   int32_t* nnz_host) {
+  return rphip_predict_topk_filtered(ctx, model, Xpred, user_begin, user_end, Kp, exclude_history, nullptr, idx_host, val_host, nnz_host);
+}
+
+extern "C" int rphip_predict_topk_filtered(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin,
+                                           int64_t user_end, int32_t Kp, int32_t exclude_history, const uint8_t* item_keep_host,
+                                           int32_t* idx_host, float* val_host, int32_t* nnz_host) {
   RP_TRY(rp_pred_check(ctx, model, Xpred, user_begin, user_end));
   if (!idx_host || !val_host || !nnz_host) RP_FAIL(RPHIP_EINVAL, "NULL output");
   if (Kp < 1 || Kp > RP_K_MAX) RP_FAIL(RPHIP_ELIMIT, "Kp=%d outside 1..%d", Kp, RP_K_MAX);
@@ -918,7 +948,12 @@ extern "C" int rphip_predict_topk(rphip_ctx* ctx, const rphip_model* model, cons
   int32_t* di = (int32_t*)ob;
   float* dv = (float*)(ob + (size_t)n * Kp * 4);
   int32_t* dn = (int32_t*)(ob + (size_t)n * Kp * 8);
-  RP_TRY(rphip_predict_topk_dev(ctx, model, Xpred, user_begin, user_end, Kp, exclude_history, di, dv, dn));
+  uint8_t* keep_dev = nullptr;
+  if (item_keep_host) {
+    RP_TRY(rp_scratch(ctx, 1, (size_t)model->n_items, (void**)&keep_dev));
+    RP_HIP(hipMemcpyAsync(keep_dev, item_keep_host, (size_t)model->n_items, hipMemcpyHostToDevice, ctx->stream));
+  }
+  RP_TRY(rp_predict_topk_impl(ctx, model, Xpred, user_begin, user_end, Kp, exclude_history, keep_dev, di, dv, dn));
   hipEvent_t ev;
   rp_time_begin(ctx, &ev);
   RP_HIP(hipMemcpyAsync(idx_host, di, (size_t)n * Kp * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -249,6 +249,12 @@ def test_predict_topk_vs_oracle(hip, shape, K, Kp, seed):
     for excl in (False, True):
         pi, pv, pn = _lib.predict_topk(ctx, m, dX, Kp, exclude_history=excl, user_begin=0, user_end=1200)
         check_topk_scores(scores, pi, pv, pn, Kp, exclude=X[users] if excl else None)
+    # item filter (ExcludeItems / SelectItems fused into the kernel), with and without history removal
+    keep = np.random.default_rng(seed).random(X.shape[1]) < 0.7
+    for excl in (False, True):
+        pi, pv, pn = _lib.predict_topk(ctx, m, dX, Kp, exclude_history=excl, user_begin=0, user_end=1200, item_keep=keep)
+        assert keep[pi[pi >= 0]].all()
+        check_topk_scores(onp.pipeline_scores(scores, item_keep=keep), pi, pv, pn, Kp, exclude=X[users] if excl else None)
     # a user range in the middle equals the same rows of the full call
     pi2, pv2, pn2 = _lib.predict_topk(ctx, m, dX, Kp, user_begin=100, user_end=300)
     pi, pv, pn = _lib.predict_topk(ctx, m, dX, Kp, user_begin=0, user_end=1200)
