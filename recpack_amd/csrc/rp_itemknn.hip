@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
       // CH entries, and hands chunk c to lane c % 64: every lane then issues CH independent index loads
       // before the first LDS atomic, instead of one dependent load per user per round.
       constexpr int CH = 8;
-      volatile RP_LDS uint32_t* own_sc = (volatile RP_LDS uint32_t*)sel.hist + wave * 64;  // the histogram is idle here
+      RP_LDS uint32_t* own_sc = (RP_LDS uint32_t*)sel.hist + wave * 64;  // the histogram is idle here
       RP_LDS uint16_t* ft_list = (RP_LDS uint16_t*)sel.list;  // light rows: first-touch candidates
       const uint64_t lt_mask = (1ull << lane) - 1ull;
       const int diag = row - t0;
@@ -226,7 +226,9 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
         auto fetch = [&](int c0, int (&jv)[CH]) {
           const int c = c0 + lane;
           own_sc[lane] = (lane == 0) ? (uint32_t)carry : 0u;
+          RP_WAVE_FENCE();
           if (nch > 0 && (unsigned)(choff - c0) < 64u) own_sc[choff - c0] = (uint32_t)lane;
+          RP_WAVE_FENCE();
           const int lo = rp_wave_incl_max((int)own_sc[lane]);
           carry = __builtin_amdgcn_readlane(lo, 63);
           const int us = __shfl(s, lo), ul = __shfl(len, lo), co = __shfl(choff, lo);

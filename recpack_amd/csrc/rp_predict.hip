@@ -361,7 +361,7 @@ typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 struct rp_pw_state {
   RP_LDS unsigned long long* acc;
-  volatile RP_LDS uint32_t* dirty;
+  RP_LDS uint32_t* dirty;
   rp_wpool<uint64_t> pool;
   const int* pairs_i;
   int lane, cap;
@@ -415,10 +415,12 @@ __device__ __forceinline__ int rp_pw_fetch_chunk(const rp_pw_state& S, int c, in
 // round trips where the binary search takes six.
 __device__ __forceinline__ int rp_pw_fetch_first(const rp_pw_state& S, int n_chunks, int nch, int s, int len, int choff, v4i_a4* a,
                                                  v4i_a4* b) {
-  volatile RP_LDS uint32_t* sc = S.pool.hist;  // idle while a tile's entries are fetched and added
+  RP_LDS uint32_t* sc = S.pool.hist;  // idle while a tile's entries are fetched and added
   const int lane = S.lane;
   sc[lane] = 0u;
+  RP_WAVE_FENCE();
   if (nch > 0 && choff < 64) sc[choff] = (uint32_t)lane;
+  RP_WAVE_FENCE();
   const int lo = rp_wave_incl_max((int)sc[lane]);
   const int us = __shfl(s, lo), ulen = __shfl(len, lo), co = __shfl(choff, lo);
   const int k0 = (lane - co) * PW_CH;
@@ -431,34 +433,120 @@ __device__ __forceinline__ int rp_pw_fetch_first(const rp_pw_state& S, int n_chu
   return n;
 }
 
+// ---- the rare paths of a tile, kept OUT OF LINE on purpose.  Both load and immediately consume global data; inlined,
+// their temporaries made the compiler put conservative s_waitcnt vmcnt(..) into the common path, which then waited for
+// the prefetched entries of the next tile in the middle of the current one.  As calls they cost nothing unless taken.
+//
+// Further chunk steps of one pipelined batch (more than 64 chunks of the batch fall into the tile).
+__device__ __attribute__((noinline)) void rp_pw_extra_steps(RP_LDS unsigned long long* acc, RP_LDS uint32_t* dirty, const int* pairs_i,
+                                                            rp_fix_scale fix, int lane, int s, int len, int choff, int nchunks, int t0) {
+  rp_pw_state S;
+  S.acc = acc;
+  S.dirty = dirty;
+  S.pairs_i = pairs_i;
+  S.fix = fix;
+  S.lane = lane;
+  for (int c0 = 64; c0 < nchunks; c0 += 64) {
+    v4i_a4 a = (v4i_a4){0, 0, 0, 0}, b2 = a;
+    const int n = rp_pw_fetch_chunk(S, c0 + lane, nchunks, s, len, choff, &a, &b2);
+    rp_pw_add_chunk(S, n, a, b2, t0);
+  }
+}
+
+// History batches beyond the pipelined ones (items [h_from, he)): offsets and entries fetched on the spot.
+// Returns whether anything was added.
+__device__ __attribute__((noinline)) bool rp_pw_slow_batches(RP_LDS unsigned long long* acc, RP_LDS uint32_t* dirty, const int* pairs_i,
+                                                             rp_fix_scale fix, int lane, const int32_t* x_idx, const uint16_t* toff,
+                                                             int K, int NT, int t, int h_from, int he) {
+  rp_pw_state S;
+  S.acc = acc;
+  S.dirty = dirty;
+  S.pairs_i = pairs_i;
+  S.fix = fix;
+  S.lane = lane;
+  const int t0 = t * PW_WT;
+  bool touched = false;
+  for (int hb = h_from; hb < he; hb += 64) {
+    const int h = hb + lane;
+    int s = 0, len = 0;
+    if (h < he) {
+      const int itx = x_idx[h];
+      const uint16_t* tx = toff + (long long)itx * (NT + 1) + t;
+      const int o0 = tx[0], o1 = tx[1];
+      s = itx * K + o0;
+      len = o1 - o0;
+    }
+    const int nch = (len + PW_CH - 1) / PW_CH;
+    const int inc = rp_wave_incl_scan(nch, lane);
+    const int choff = inc - nch;
+    const int n_chunks = __builtin_amdgcn_readlane(inc, 63);
+    if (n_chunks > 0) touched = true;
+    for (int c0 = 0; c0 < n_chunks; c0 += 64) {
+      v4i_a4 a = (v4i_a4){0, 0, 0, 0}, b2 = a;
+      const int n = rp_pw_fetch_chunk(S, c0 + lane, n_chunks, s, len, choff, &a, &b2);
+      rp_pw_add_chunk(S, n, a, b2, t0);
+    }
+  }
+  return touched;
+}
+
+// history removal for the items of those batches
+__device__ __attribute__((noinline)) void rp_pw_slow_exclude(RP_LDS unsigned long long* acc, int lane, const int32_t* x_idx, int t0,
+                                                             int h_from, int he) {
+  for (int h = h_from + lane; h < he; h += 64) {
+    const int j = x_idx[h] - t0;
+    if ((unsigned)j < (unsigned)PW_WT) acc[j] = 0ull;
+  }
+}
+
+// the item filter for the four slots of a walk round (only lanes whose sum would enter the pool look the item up)
+__device__ __attribute__((noinline)) uint32_t rp_pw_keep_lookup(const uint8_t* keep, int c0, int c1, int c2, int c3, uint32_t want) {
+  uint32_t ok = 0;
+  if ((want & 1u) && keep[c0] != 0) ok |= 1u;
+  if ((want & 2u) && keep[c1] != 0) ok |= 2u;
+  if ((want & 4u) && keep[c2] != 0) ok |= 4u;
+  if ((want & 8u) && keep[c3] != 0) ok |= 8u;
+  return ok;
+}
+
 // All tiles of one user.  The first NB batches of 64 history items are software-pipelined over the tiles: item ids stay
 // in registers, tile offsets are loaded two tiles ahead and the entries of tile t+1 are in flight while tile t is
 // added, scanned and pooled.  Without this the three dependent loads (item id -> offsets -> entries) are paid once
 // per tile and batch; batches beyond NB (histories longer than 64*NB) still go that way.
+// prepared first chunk step of one tile for the NB pipelined batches
+template <int NB>
+struct rp_pw_set {
+  int s[NB], len[NB], choff[NB], nchunks[NB], n[NB];
+  v4i_a4 a[NB], b[NB];
+};
+
 template <int NB>
 __device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_state& S, int ul, int hs, int he) {
   const int lane = S.lane, K = P.K, Kp = P.Kp, NT = P.n_wt, cap = S.cap;
   const int nb = min(NB, (he - hs + 63) >> 6);
   int it[NB], o_a[NB], o_b[NB], o_c[NB];
   const uint16_t* to[NB];
-  int p_s[NB], p_len[NB], p_choff[NB], p_nchunks[NB], p_n[NB];
-  v4i_a4 p_a[NB], p_b[NB];
-  auto prepare = [&](int b) {
-    p_s[b] = (it[b] >= 0) ? it[b] * K + o_a[b] : 0;
-    p_len[b] = (it[b] >= 0) ? o_b[b] - o_a[b] : 0;
-    const int nch = (p_len[b] + PW_CH - 1) / PW_CH;
+  // two register sets, used alternately as "current tile" and "tile being prefetched": the entries of tile t+1 are
+  // loaded straight into the set tile t+1 will read, a whole tile period before they are needed (copying a prepared
+  // set into a current one made the compiler wait for the loads at the end of every tile)
+  rp_pw_set<NB> set0, set1;
+  auto prepare = [&](int b, rp_pw_set<NB>& D) __attribute__((always_inline)) {
+    D.s[b] = (it[b] >= 0) ? it[b] * K + o_a[b] : 0;
+    D.len[b] = (it[b] >= 0) ? o_b[b] - o_a[b] : 0;
+    const int nch = (D.len[b] + PW_CH - 1) / PW_CH;
     const int inc = rp_wave_incl_scan(nch, lane);
-    p_choff[b] = inc - nch;
-    p_nchunks[b] = __builtin_amdgcn_readlane(inc, 63);
-    p_n[b] = rp_pw_fetch_first(S, p_nchunks[b], nch, p_s[b], p_len[b], p_choff[b], &p_a[b], &p_b[b]);
+    D.choff[b] = inc - nch;
+    D.nchunks[b] = __builtin_amdgcn_readlane(inc, 63);
+    D.n[b] = rp_pw_fetch_first(S, D.nchunks[b], nch, D.s[b], D.len[b], D.choff[b], &D.a[b], &D.b[b]);
   };
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     it[b] = -1;
     to[b] = P.toff;
     o_a[b] = o_b[b] = o_c[b] = 0;
-    p_s[b] = p_len[b] = p_choff[b] = p_nchunks[b] = p_n[b] = 0;
-    p_a[b] = p_b[b] = (v4i_a4){0, 0, 0, 0};
+    set0.s[b] = set0.len[b] = set0.choff[b] = set0.nchunks[b] = set0.n[b] = 0;
+    set1.s[b] = set1.len[b] = set1.choff[b] = set1.nchunks[b] = set1.n[b] = 0;
+    set0.a[b] = set0.b[b] = set1.a[b] = set1.b[b] = (v4i_a4){0, 0, 0, 0};
     if (b < nb) {
       const int h = hs + 64 * b + lane;
       it[b] = (h < he) ? P.x_idx[h] : -1;
@@ -475,81 +563,44 @@ __device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_st
   }
 #pragma unroll
   for (int b = 0; b < NB; ++b)
-    if (b < nb) prepare(b);  // tile 0
+    if (b < nb) prepare(b, set0);  // tile 0
 
-  for (int t = 0; t < NT; ++t) {
+  // one tile: C = the set prepared for it, N = the set to prepare for tile t+1
+  auto tile = [&](int t, rp_pw_set<NB>& C, rp_pw_set<NB>& N) __attribute__((always_inline)) {
     const int t0 = t * PW_WT;
-    // current tile = what was prepared; then prepare tile t+1 and fetch the offset of tile t+3
-    int c_s[NB], c_len[NB], c_choff[NB], c_nchunks[NB], c_n[NB];
-    v4i_a4 c_a[NB], c_b[NB];
     bool touched = false;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      c_s[b] = p_s[b];
-      c_len[b] = p_len[b];
-      c_choff[b] = p_choff[b];
-      c_nchunks[b] = p_nchunks[b];
-      c_n[b] = p_n[b];
-      c_a[b] = p_a[b];
-      c_b[b] = p_b[b];
-      touched |= c_nchunks[b] > 0;
-    }
+    for (int b = 0; b < NB; ++b) touched |= C.nchunks[b] > 0;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (b < nb) {
         o_a[b] = o_b[b];
         o_b[b] = o_c[b];
         if (t + 3 <= NT && it[b] >= 0) o_c[b] = (int)to[b][t + 3];
-        if (t + 1 < NT) prepare(b);
+        if (t + 1 < NT) prepare(b, N);
       }
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (b < nb) {
-        rp_pw_add_chunk(S, c_n[b], c_a[b], c_b[b], t0);  // the prefetched first step, then any further steps
-        for (int c0 = 64; c0 < c_nchunks[b]; c0 += 64) {
-          v4i_a4 a = (v4i_a4){0, 0, 0, 0}, b2 = a;
-          const int n = rp_pw_fetch_chunk(S, c0 + lane, c_nchunks[b], c_s[b], c_len[b], c_choff[b], &a, &b2);
-          rp_pw_add_chunk(S, n, a, b2, t0);
-        }
+        rp_pw_add_chunk(S, C.n[b], C.a[b], C.b[b], t0);  // the prefetched first step, then (rarely) further steps
+        if (C.nchunks[b] > 64) rp_pw_extra_steps(S.acc, S.dirty, S.pairs_i, S.fix, lane, C.s[b], C.len[b], C.choff[b], C.nchunks[b], t0);
       }
     }
     // ---- histories longer than 64*NB items: the remaining batches, not pipelined
-    for (int hb = hs + 64 * NB; hb < he; hb += 64) {
-      const int h = hb + lane;
-      int s = 0, len = 0;
-      if (h < he) {
-        const int itx = P.x_idx[h];
-        const uint16_t* tx = P.toff + (long long)itx * (NT + 1) + t;
-        const int o0 = tx[0], o1 = tx[1];
-        s = itx * K + o0;
-        len = o1 - o0;
-      }
-      const int nch = (len + PW_CH - 1) / PW_CH;
-      const int inc = rp_wave_incl_scan(nch, lane);
-      const int choff = inc - nch;
-      const int n_chunks = __builtin_amdgcn_readlane(inc, 63);
-      if (n_chunks > 0) touched = true;
-      for (int c0 = 0; c0 < n_chunks; c0 += 64) {
-        v4i_a4 a = (v4i_a4){0, 0, 0, 0}, b2 = a;
-        const int n = rp_pw_fetch_chunk(S, c0 + lane, n_chunks, s, len, choff, &a, &b2);
-        rp_pw_add_chunk(S, n, a, b2, t0);
-      }
-    }
+    if (hs + 64 * NB < he)
+      touched |= rp_pw_slow_batches(S.acc, S.dirty, S.pairs_i, S.fix, lane, P.x_idx, P.toff, K, NT, t, hs + 64 * NB, he);
     PW_STAMP(1);
-    if (!touched) continue;
+    if (!touched) return;
     if (P.exclude_history) {  // the dirty bit stays: a zero sum is skipped below
 #pragma unroll
       for (int b = 0; b < NB; ++b) {  // item ids of the pipelined batches are in registers: no load to wait for here
         const int j = it[b] - t0;
         if (b < nb && (unsigned)j < (unsigned)PW_WT) S.acc[j] = 0ull;
       }
-      for (int h = hs + 64 * NB + lane; h < he; h += 64) {
-        const int j = P.x_idx[h] - t0;
-        if ((unsigned)j < (unsigned)PW_WT) S.acc[j] = 0ull;
-      }
+      if (hs + 64 * NB < he) rp_pw_slow_exclude(S.acc, lane, P.x_idx, t0, hs + 64 * NB, he);
     }
-    __builtin_amdgcn_wave_barrier();
+    RP_WAVE_FENCE();
     // ---- offer the touched columns to the pool: lane l walks the set bits of dirty word l
     // (word l covers columns l, l+64, ..: the lanes' reads of one round fall into different LDS banks), four set bits
     // per lane and round so that the sums of a round are read with one wait
@@ -566,30 +617,40 @@ __device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_st
         w &= w - 1u;  // 0 stays 0
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = has[q] ? ((volatile RP_LDS unsigned long long*)S.acc)[j[q]] : 0ull;
+      for (int q = 0; q < 4; ++q) v[q] = has[q] ? S.acc[j[q]] : 0ull;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        if (has[q]) ((volatile RP_LDS unsigned long long*)S.acc)[j[q]] = 0ull;
-      // most sums lose against the pool's threshold once it is warm: one vote for the round, then only the
-      // surviving slots are pushed (rolled: one inlined copy of the pool cut; the values rotate through slot 0)
+        if (has[q]) S.acc[j[q]] = 0ull;
+      // most sums lose against the pool's threshold once it is warm: the slots of the round are voted on first and only
+      // slots with a surviving lane are pushed (rolled loop: one inlined copy of the pool cut; values rotate through 0)
       bool kq[4];
-      bool anyk = false;
+      uint32_t live = 0;  // bit q: some lane keeps its slot q
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         v[q] ^= RP_KEY_FLIP;  // signed sum -> unsigned order; a zero sum is no candidate
         kq[q] = has[q] && v[q] != RP_KEY_FLIP && rp_wpool_admits<uint64_t, 0>(S.pool, v[q], (uint32_t)(t0 + j[q]));
-        if (P.keep && kq[q]) kq[q] = P.keep[t0 + j[q]] != 0;  // only sums that would enter the pool pay the lookup
-        anyk |= kq[q];
       }
+      if (P.keep) {  // item filter: only sums that would enter the pool pay the lookup
+        const uint32_t want = (kq[0] ? 1u : 0u) | (kq[1] ? 2u : 0u) | (kq[2] ? 4u : 0u) | (kq[3] ? 8u : 0u);
+        if (__any(want != 0u)) {
+          const uint32_t ok = rp_pw_keep_lookup(P.keep, t0 + j[0], t0 + j[1], t0 + j[2], t0 + j[3], want);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) kq[q] = (ok >> q) & 1u;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) live |= __any(kq[q]) ? (1u << q) : 0u;
       PW_COUNT(4, 1);
-      if (!__any(anyk)) continue;
+      if (!live) continue;
       PW_COUNT(5, 1);
 #pragma unroll 1
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t col = (uint32_t)(t0 + j[0]);
-        // the threshold may have moved since the vote (a cut inside an earlier push): ask again
-        const bool keep = kq[0] && rp_wpool_admits<uint64_t, 0>(S.pool, v[0], col);
-        rp_wpool_push<uint64_t, 0>(S.pool, Kp, cap, keep, v[0], col, lane);
+      for (int q = 0; q < 4 && live; ++q, live >>= 1) {
+        if (live & 1u) {
+          const uint32_t col = (uint32_t)(t0 + j[0]);
+          // the threshold may have moved since the vote (a cut inside an earlier push): ask again
+          const bool keep = kq[0] && rp_wpool_admits<uint64_t, 0>(S.pool, v[0], col);
+          rp_wpool_push<uint64_t, 0>(S.pool, Kp, cap, keep, v[0], col, lane);
+        }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
           kq[r] = kq[r + 1];
@@ -599,6 +660,10 @@ __device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_st
       }
     }
     PW_STAMP(2);
+  };
+  for (int t = 0; t < NT; t += 2) {
+    tile(t, set0, set1);
+    if (t + 1 < NT) tile(t + 1, set1, set0);
   }
 }
 
@@ -611,7 +676,7 @@ __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
   S.cap = rp_pw_cap(Kp);
   S.fix = P.fix;
   S.acc = (RP_LDS unsigned long long*)smem;
-  S.dirty = (volatile RP_LDS uint32_t*)(smem + (size_t)PW_WT * 8);
+  S.dirty = (RP_LDS uint32_t*)(smem + (size_t)PW_WT * 8);
   S.pool.key = (RP_LDS uint64_t*)(smem + (size_t)PW_WT * 8 + 256);
   S.pool.pay = (RP_LDS uint32_t*)(S.pool.key + S.cap);
   S.pool.hist = S.pool.pay + S.cap;
@@ -647,25 +712,25 @@ __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
       else
         rp_pw_user_tiles<4>(P, S, ul, hs, he);
       // ---- final: best Kp by (score desc, column asc), then column order for the output row
-      __builtin_amdgcn_wave_barrier();
+      RP_WAVE_FENCE();
       if (S.pool.n > Kp) rp_wpool_cut<uint64_t, 0>(S.pool, Kp, lane);
       const int n_out = S.pool.n;
-      volatile RP_LDS uint64_t* pk = S.pool.key;
-      volatile RP_LDS uint32_t* pp = S.pool.pay;
+      RP_LDS uint64_t* pk = S.pool.key;
+      RP_LDS uint32_t* pp = S.pool.pay;
       if (lane < 4) pp[n_out + lane] = 0xffffffffu;  // pads the last group of four (n_out + 4 <= cap)
       typedef uint32_t v4u __attribute__((ext_vector_type(4)));
       for (int e = lane; e < n_out; e += 64) {
         const uint32_t col = pp[e];
         int rank = 0;
         for (int o = 0; o < n_out; o += 4) {
-          const v4u q = *reinterpret_cast<volatile RP_LDS v4u*>(&pp[o]);
+          const v4u q = *reinterpret_cast<RP_LDS v4u*>(&pp[o]);
           rank += (q.x < col ? 1 : 0) + (q.y < col ? 1 : 0) + (q.z < col ? 1 : 0) + (q.w < col ? 1 : 0);
         }
         P.out_idx[(int64_t)ul * Kp + rank] = (int)col;
         P.out_val[(int64_t)ul * Kp + rank] = (float)rp_fix_to_f64(pk[e] ^ RP_KEY_FLIP, S.fix.shift);
       }
       if (lane == 0) P.out_nnz[ul] = n_out;
-      __builtin_amdgcn_wave_barrier();
+      RP_WAVE_FENCE();
       PW_STAMP(3);
 #ifdef RP_STAMPS
       if (lane == 0) {

@@ -14,6 +14,11 @@
 // LDS pointers carry their address space: a plain (generic) pointer kept in a struct or made volatile compiles to
 // FLAT loads/stores, which count on vmcnt AND lgkmcnt - every wait on one then also drains the global loads in flight.
 #define RP_LDS __attribute__((address_space(3)))
+// LDS accesses of one wave execute in program order, so wave-synchronous code (lane A writes, lane B reads, no
+// barrier) only needs the COMPILER to keep the order.  `volatile` does that too, but the memory legalizer then puts an
+// s_waitcnt vmcnt(0) behind every such access, which drains the global loads a kernel has in flight; a wavefront-scope
+// fence orders the accesses at no cost.
+#define RP_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
 
 template <typename KeyT>
 struct rp_wpool {
@@ -75,14 +80,22 @@ __device__ __forceinline__ uint32_t rp_wave_or(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// Cut the pool to its K best entries by (key desc, column asc); requires pool.n > K.  Sets pool.tau.
+template <typename KeyT>
+struct rp_wcut {
+  KeyT tau;
+  uint32_t tau_col;
+  int n;
+};
+
+// The work of a cut on plain values (pointers and sizes in, threshold out): if the compiler keeps this large function
+// out of line, the pool struct itself is never address-taken and stays in registers in the callers' hot loops.
 template <typename KeyT, int COL_SHIFT>
-__device__ void rp_wpool_cut(rp_wpool<KeyT>& P, int K, int lane) {
+__device__ rp_wcut<KeyT> rp_wpool_cut_impl(RP_LDS KeyT* pkey_, RP_LDS uint32_t* ppay_, RP_LDS uint32_t* phist_, RP_LDS uint16_t* pgidx_,
+                                           int n, int K, int lane) {
   constexpr int KEY_LEVELS = sizeof(KeyT);  // 8-bit digits
-  const int n = P.n;
-  volatile RP_LDS KeyT* key = P.key;
-  volatile RP_LDS uint32_t* pay = P.pay;
-  volatile RP_LDS uint32_t* hist = P.hist;
+  RP_LDS KeyT* key = pkey_;
+  RP_LDS uint32_t* pay = ppay_;
+  RP_LDS uint32_t* hist = phist_;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   KeyT pkey = 0;
   uint32_t pic = 0;  // decided prefix of ~column
@@ -108,7 +121,7 @@ __device__ void rp_wpool_cut(rp_wpool<KeyT>& P, int K, int lane) {
     const int shift = is_col ? 8 * (3 - (level - KEY_LEVELS)) : 8 * (KEY_LEVELS - 1 - level);
 #pragma unroll
     for (int b = 0; b < 4; ++b) hist[lane * 4 + b] = 0;
-    __builtin_amdgcn_wave_barrier();
+    RP_WAVE_FENCE();
     for (int e = lane; e < n; e += 64) {
       const KeyT k = key[e];
       const uint32_t ic = ~(pay[e] >> COL_SHIFT);
@@ -121,9 +134,9 @@ __device__ void rp_wpool_cut(rp_wpool<KeyT>& P, int K, int lane) {
         in_group = (k == pkey) && ((level == KEY_LEVELS) || ((ic >> shift) >> 8) == ((pic >> shift) >> 8));
         d = (ic >> shift) & 255u;
       }
-      if (in_group) atomicAdd((uint32_t*)&P.hist[d], 1u);
+      if (in_group) atomicAdd((uint32_t*)&phist_[d], 1u);
     }
-    __builtin_amdgcn_wave_barrier();
+    RP_WAVE_FENCE();
     // lane owns bins 255-4*lane .. 252-4*lane (descending)
     int h[4];
     int sum = 0;
@@ -176,14 +189,14 @@ __device__ void rp_wpool_cut(rp_wpool<KeyT>& P, int K, int lane) {
             mem = (k == pkey) && ((ic >> shift) == (pic >> shift));
         }
         const uint64_t m = __ballot(mem);
-        if (mem) ((volatile RP_LDS uint16_t*)P.gidx)[base + __popcll(m & lt_mask)] = (uint16_t)e;
+        if (mem) pgidx_[base + __popcll(m & lt_mask)] = (uint16_t)e;
         base += __popcll(m);
       }
-      __builtin_amdgcn_wave_barrier();
+      RP_WAVE_FENCE();
       KeyT mk = 0;
       uint32_t mic = 0;
       if (lane < group) {
-        const int e = ((volatile RP_LDS uint16_t*)P.gidx)[lane];
+        const int e = pgidx_[lane];
         mk = key[e];
         mic = ~(pay[e] >> COL_SHIFT);
       }
@@ -201,35 +214,38 @@ __device__ void rp_wpool_cut(rp_wpool<KeyT>& P, int K, int lane) {
       done = true;
     }
   }
-  // rebuild the pool in place: all reads first (n <= 512 => at most 8 rounds), then ordered writes
-  constexpr int MAXR = 8;
-  KeyT rk[MAXR];
-  uint32_t rp[MAXR];
-#pragma unroll
-  for (int r = 0; r < MAXR; ++r) {
-    const int e = r * 64 + lane;
-    rk[r] = (e < n) ? key[e] : (KeyT)0;
-    rp[r] = (e < n) ? pay[e] : 0u;
-  }
-  __builtin_amdgcn_wave_barrier();
+  // rebuild the pool in place, 64 entries per round: round r writes at most 64 selected entries at positions
+  // <= 64 r + 63, all of which this or an earlier round has already read (one wave: LDS accesses are in order)
   int out = 0;
-#pragma unroll
-  for (int r = 0; r < MAXR; ++r) {
-    const int e = r * 64 + lane;
-    const uint32_t c = rp[r] >> COL_SHIFT;
-    const bool sel = (e < n) && ((rk[r] > tkey) || (rk[r] == tkey && c <= tcol));
+  for (int e0 = 0; e0 < n; e0 += 64) {
+    const int e = e0 + lane;
+    const KeyT rk = (e < n) ? key[e] : (KeyT)0;
+    const uint32_t rp = (e < n) ? pay[e] : 0u;
+    const uint32_t c = rp >> COL_SHIFT;
+    const bool sel = (e < n) && ((rk > tkey) || (rk == tkey && c <= tcol));
     const uint64_t m = __ballot(sel);
     if (sel) {
       const int pos = out + __popcll(m & lt_mask);
-      key[pos] = rk[r];
-      pay[pos] = rp[r];
+      key[pos] = rk;
+      pay[pos] = rp;
     }
     out += __popcll(m);
   }
-  __builtin_amdgcn_wave_barrier();
-  P.n = out;  // == K
-  P.tau = tkey;
-  P.tau_col = tcol;
+  RP_WAVE_FENCE();
+  rp_wcut<KeyT> r;
+  r.n = out;  // == K
+  r.tau = tkey;
+  r.tau_col = tcol;
+  return r;
+}
+
+// Cut the pool to its K best entries by (key desc, column asc); requires pool.n > K.  Sets pool.tau / tau_col.
+template <typename KeyT, int COL_SHIFT>
+__device__ __forceinline__ void rp_wpool_cut(rp_wpool<KeyT>& P, int K, int lane) {
+  const rp_wcut<KeyT> r = rp_wpool_cut_impl<KeyT, COL_SHIFT>(P.key, P.pay, P.hist, P.gidx, P.n, K, lane);
+  P.n = r.n;
+  P.tau = r.tau;
+  P.tau_col = r.tau_col;
 }
 
 // Is a candidate still able to make the top K?  Exact for candidates arriving in ANY column order: ties with the
@@ -252,8 +268,8 @@ __device__ __forceinline__ void rp_wpool_push(rp_wpool<KeyT>& P, int K, int cap,
   }
   if (keep) {
     const int pos = P.n + __popcll(m & ((1ull << lane) - 1ull));
-    ((volatile RP_LDS KeyT*)P.key)[pos] = k;
-    ((volatile RP_LDS uint32_t*)P.pay)[pos] = pay;
+    P.key[pos] = k;
+    P.pay[pos] = pay;
   }
   P.n += __popcll(m);
 }
