@@ -125,11 +125,15 @@ int rphip_itemknn_fit(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int
 /* Same with the similarity of ItemKNN's constructor (nearest_neighbour.py:172-202):
  *   RPHIP_SIM_COSINE                   as above;
  *   RPHIP_SIM_CONDITIONAL_PROBABILITY  sim(i,j) = c_ij / (c_i * c_j^pop_discount), compute_conditional_probability
- *                                      (nearest_neighbour.py:22-66) on the binarised matrix; pop_discount in [0,1]. */
+ *                                      (nearest_neighbour.py:22-66) on the binarised matrix; pop_discount in [0,1].
+ * normalize_X != 0 (nearest_neighbour.py:207-210): the binarised rows are l1-normalised first, X[u,i] = 1/d_u; the
+ * Gram then is a float64 sum over the common users (cosine: sum 1/d_u^2 over sqrt(G_ii G_jj); conditional
+ * probability: sum 1/d_u over c_i c_j^pop_discount).  Values agree with the reference to 1e-11 relative; the last
+ * bits depend on the order of the adds, as they do in scipy. */
 #define RPHIP_SIM_COSINE 0
 #define RPHIP_SIM_CONDITIONAL_PROBABILITY 1
 int rphip_itemknn_fit_ex(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K,
-                         int32_t similarity, double pop_discount, rphip_model** out);
+                         int32_t similarity, double pop_discount, int32_t normalize_X, rphip_model** out);
 /* neighbour lists to host: idx int32[rows*K] (-1 padded), val float64[rows*K] (0 padded), nnz int32[rows] */
 int rphip_model_topk_download(rphip_ctx* ctx, const rphip_model* m, int32_t* idx_host, double* val_host,
                               int32_t* nnz_host);

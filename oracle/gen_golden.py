@@ -163,6 +163,49 @@ def main():
          cos_row_nnz=np.diff(cosf.indptr).astype(np.int64))
 
 
+def normalized_cases():
+    """normalize_X=True (nearest_neighbour.py:207-210): the reference's own fixture (test_nearest_neighbour.py:73-107)
+    and seeded synthetic matrices, cosine and conditional probability.  ``full_*`` holds every candidate of the
+    similarity (before the top-K) for the tie-aware rule."""
+    from sklearn.preprocessing import Normalizer
+
+    from recpack.algorithms.nearest_neighbour import compute_conditional_probability, compute_cosine_similarity
+    from recpack.matrix import to_csr_matrix
+
+    def full(X, similarity, pd):
+        Xn = Normalizer(norm="l1", copy=True).transform(to_csr_matrix(X, binary=True))
+        S = compute_cosine_similarity(Xn) if similarity == "cosine" else compute_conditional_probability(Xn, pd or 0)
+        S = sp.csr_matrix(S)
+        S.sort_indices()
+        return S
+
+    data = sp.csr_matrix(([1] * 7, ([0, 0, 1, 1, 2, 2, 2], [1, 2, 0, 2, 0, 1, 2])), shape=(4, 3))
+    m = powerlaw_csr(2000, 500, 0.02, seed=20260101).to_scipy()
+    m_dup = m.copy().astype(np.int32)
+    m_dup.data[::7] = 3
+    m3 = powerlaw_csr(6000, 14000, 0.0015, seed=20260105).to_scipy()  # two weighted column tiles
+    cases = [("ref_itemknn_data_normX", data, [2], "cosine", None), ("syn_itemknn_normX_2000x500", m_dup, [10, 50], "cosine", None),
+             ("syn_itemknn_normX_condprob_2000x500", m_dup, [20], "conditional_probability", 0.5),
+             ("syn_itemknn_normX_6000x14000", m3, [10], "cosine", None)]
+    for name, X, Ks, sim, pd in cases:
+        arrays = dict(csr_parts("X", X))
+        arrays["Ks"] = np.asarray(Ks, dtype=np.int64)
+        arrays["pop_discount"] = np.asarray(pd or 0.0)
+        arrays["similarity"] = np.asarray(sim)
+        if X.shape[1] <= 1000:
+            arrays.update(csr_parts("cos", full(X, sim, pd)))
+        else:
+            arrays["cos_row_nnz"] = np.diff(full(X, sim, pd).indptr).astype(np.int64)
+        for K in Ks:
+            kw = {"similarity": sim, "normalize_X": True}
+            if pd is not None:
+                kw["pop_discount"] = pd
+            S = sp.csr_matrix(ItemKNN(K=K, **kw).fit(X).similarity_matrix_)
+            S.sort_indices()
+            arrays.update(csr_parts(f"S{K}", S))
+        save(name, **arrays)
+
+
 def pipeline_case():
     """C1 (BASELINE.json configs[0]): the MovieLens-100K sample that ships with the reference's tests
     (recpack/tests/test_datasets/datasets/ml-100k_sample.data, default filters -> 373 x 390, 4620 interactions),
@@ -214,6 +257,9 @@ def pipeline_case():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "pipeline":
         pipeline_case()
+    elif len(sys.argv) > 1 and sys.argv[1] == "normalized":
+        normalized_cases()
     else:
         main()
+        normalized_cases()
         pipeline_case()

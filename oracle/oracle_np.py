@@ -81,6 +81,59 @@ def _segment_topk(indptr, cols, keys, K):
     return sel, cnt
 
 
+def itemknn_fit_normalized(X: sp.csr_matrix, K: int, similarity: str = "cosine", pop_discount=None):
+    """ItemKNN with ``normalize_X=True`` (nearest_neighbour.py:207-210): the binarised rows are l1-normalised first,
+    X[u, i] = w_u = 1/d_u.  Cosine (:69-84) then is G_ij / (n_i n_j) with G_ij = sum_{u in i&j} w_u^2 and n_i = sqrt(G_ii);
+    conditional probability (:22-66: ``to_binary(X).T @ X``, binary frequencies) is G'_ij / (c_i c_j^alpha) with
+    G'_ij = sum_{u in i&j} w_u.  Same return layout and rank order as ``itemknn_fit``.  Sums are float64 in scipy's
+    order; the kernels add the same float64 terms in another order (last-bit differences).  ``K=None`` returns every
+    candidate of the similarity as a CSR matrix instead."""
+    Xb = binarize(X)
+    n_items = Xb.shape[1]
+    c = item_degrees(Xb)
+    d = np.diff(Xb.indptr).astype(np.float64)
+    with np.errstate(divide="ignore"):
+        w = np.where(d > 0, 1.0 / d, 0.0)
+    q = w * w if similarity == "cosine" else w
+    Xq = sp.csr_matrix((np.repeat(q, np.diff(Xb.indptr)), Xb.indices, Xb.indptr), shape=Xb.shape)
+    G = (Xb.T.tocsr() @ Xq).tocsr()
+    G.sort_indices()
+    gi = np.repeat(np.arange(n_items, dtype=np.int64), np.diff(G.indptr))
+    gj = G.indices.astype(np.int64)
+    gv = G.data.astype(np.float64)
+    if similarity == "cosine":
+        n2 = np.asarray(Xq.sum(axis=0)).ravel()  # G_ii
+        with np.errstate(divide="ignore"):
+            colw = np.where(n2 > 0, 1.0 / np.sqrt(n2), 0.0)
+        roww = colw
+    elif similarity == "conditional_probability":
+        alpha = float(pop_discount or 0.0)
+        colw = np.zeros(n_items)
+        nz = c > 0
+        colw[nz] = 1.0 if alpha == 0.0 else np.power(c[nz].astype(np.float64), -alpha)
+        with np.errstate(divide="ignore"):
+            roww = np.where(c > 0, 1.0 / c.astype(np.float64), 0.0)
+    else:
+        raise ValueError(similarity)
+    off = (gi != gj) & (gv != 0)
+    cnt = np.bincount(gi[off], minlength=n_items)
+    indptr = np.zeros(n_items + 1, dtype=np.int64)
+    np.cumsum(cnt, out=indptr[1:])
+    gi, gj, gv = gi[off], gj[off], gv[off]
+    key = gv * colw[gj]
+    if K is None:  # every candidate of the similarity, as CSR
+        return sp.csr_matrix((key * roww[gi], gj, indptr), shape=(n_items, n_items))
+    sel, nsel = _segment_topk(indptr, gj, key, K)
+    val = key[sel] * roww[gi[sel]]
+    idx = np.full((n_items, K), -1, dtype=np.int32)
+    out = np.zeros((n_items, K), dtype=np.float64)
+    r = np.repeat(np.arange(n_items), nsel)
+    pos = np.arange(sel.shape[0]) - np.repeat(np.concatenate([[0], np.cumsum(nsel)[:-1]]), nsel)
+    idx[r, pos] = gj[sel]
+    out[r, pos] = val
+    return {"idx": idx, "val": out, "nnz": nsel.astype(np.int32), "deg": c, "rows": np.arange(n_items, dtype=np.int64)}
+
+
 def itemknn_fit(X: sp.csr_matrix, K: int, rows=None, similarity: str = "cosine", pop_discount=None):
     """ItemKNN (cosine, or conditional probability nearest_neighbour.py:22-66 on the binarised matrix).
     Returns dict(idx int32[R,K] (-1 pad), val float64[R,K] (0 pad), nnz int32[R], deg int64[I]).

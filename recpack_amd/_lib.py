@@ -69,7 +69,7 @@ PROTOTYPES = {
     "rphip_csr_item_degrees": (C.c_int, [_p, _p, _p]),
     "rphip_csr_num_products": (C.c_int, [_p, _p, C.POINTER(_i64)]),
     "rphip_itemknn_fit": (C.c_int, [_p, _p, _i64, _i64, _i32, _pp]),
-    "rphip_itemknn_fit_ex": (C.c_int, [_p, _p, _i64, _i64, _i32, _i32, _f64, _pp]),
+    "rphip_itemknn_fit_ex": (C.c_int, [_p, _p, _i64, _i64, _i32, _i32, _f64, _i32, _pp]),
     "rphip_model_topk_download": (C.c_int, [_p, _p, _p, _p, _p]),
     "rphip_model_topk_device": (C.c_int, [_p, _pp, _pp, _pp, C.POINTER(_i64), C.POINTER(_i32)]),
     "rphip_model_from_topk_host": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _pp]),
@@ -305,14 +305,14 @@ SIM_COSINE, SIM_CONDITIONAL_PROBABILITY = 0, 1
 
 
 def itemknn_fit(ctx: Context, X: DeviceCSR, K: int, row_begin: int = 0, row_end: int | None = None, similarity: int = SIM_COSINE,
-                pop_discount: float = 0.0) -> Model:
+                pop_discount: float = 0.0, normalize_X: bool = False) -> Model:
     h = C.c_void_p()
     row_end = X.shape[1] if row_end is None else row_end
-    if similarity == SIM_COSINE:
+    if similarity == SIM_COSINE and not normalize_X:
         check(ctx.lib.rphip_itemknn_fit(ctx.handle, X.handle, int(row_begin), int(row_end), int(K), C.byref(h)))
     else:
         check(ctx.lib.rphip_itemknn_fit_ex(ctx.handle, X.handle, int(row_begin), int(row_end), int(K), int(similarity),
-                                           float(pop_discount), C.byref(h)))
+                                           float(pop_discount), 1 if normalize_X else 0, C.byref(h)))
     return Model(ctx, h)
 
 

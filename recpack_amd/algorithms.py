@@ -215,8 +215,8 @@ class ItemKNN(TopKItemSimilarityMatrixAlgorithm):
     """Item K Nearest Neighbours (recpack/algorithms/nearest_neighbour.py:114-224) on MI355X.
 
     ``similarity="cosine"`` and ``"conditional_probability"`` (with ``pop_discount``) run on the GPU from the same
-    integer Gram.  ``normalize_sim`` is a host epilogue on the I x K result.  ``normalize_X`` (a weighted Gram,
-    SURVEY.md §8(f)) raises ``NotImplementedError`` until it lands.
+    integer Gram; ``normalize_X`` (rows l1-normalised first, nearest_neighbour.py:207-210) from a float64 weighted
+    Gram.  ``normalize_sim`` is a host epilogue on the I x K result.
     """
 
     SUPPORTED_SIMILARITIES = ["cosine", "conditional_probability"]
@@ -242,15 +242,13 @@ class ItemKNN(TopKItemSimilarityMatrixAlgorithm):
         self.normalize_sim = normalize_sim
 
     def _fit(self, X: sp.csr_matrix) -> None:
-        if self.normalize_X:
-            raise NotImplementedError("recpack_amd.ItemKNN: normalize_X=True is not part of this build yet")
         ctx, dX = self._upload(X)
         try:
             if self.similarity == "cosine":
-                model = _lib.itemknn_fit(ctx, dX, int(self.K))
+                model = _lib.itemknn_fit(ctx, dX, int(self.K), normalize_X=bool(self.normalize_X))
             else:  # nearest_neighbour.py:213-215: `if pop_discount:` - None and 0 mean no discount
                 model = _lib.itemknn_fit(ctx, dX, int(self.K), similarity=_lib.SIM_CONDITIONAL_PROBABILITY,
-                                         pop_discount=float(self.pop_discount or 0.0))
+                                         pop_discount=float(self.pop_discount or 0.0), normalize_X=bool(self.normalize_X))
             idx, val, nnz = model.topk_download()
         finally:
             dX.close()

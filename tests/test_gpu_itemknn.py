@@ -426,3 +426,71 @@ def test_conditional_probability_dropin_and_big(hip):
     m = _lib.itemknn_fit(ctx, dX, 30, similarity=_lib.SIM_CONDITIONAL_PROBABILITY, pop_discount=0.3)
     idx, val, nnz = m.topk_download()
     assert_same_as_oracle(idx, val, nnz, onp.itemknn_fit(X, 30, similarity="conditional_probability", pop_discount=0.3))
+
+
+@pytest.mark.parametrize("name", ["ref_itemknn_data_normX", "syn_itemknn_normX_2000x500", "syn_itemknn_normX_condprob_2000x500",
+                                  "syn_itemknn_normX_6000x14000"])
+def test_fit_normalize_X_golden(hip, name):
+    """normalize_X=True (nearest_neighbour.py:207-210): float64 weighted Gram; tie-aware sets (eps 1e-9) and values
+    (1e-11) against the reference's goldens, and against the oracle's closed form."""
+    from recpack_amd.algorithms import to_binary_csr
+
+    _lib, ctx = hip
+    g = load_golden(name)
+    X = to_binary_csr(csr_from(g, "X"))
+    sim_name, pd = str(g["similarity"]), float(g["pop_discount"])
+    sim = _lib.SIM_COSINE if sim_name == "cosine" else _lib.SIM_CONDITIONAL_PROBABILITY
+    cand = csr_from(g, "cos") if "cos_indptr" in g else onp.itemknn_fit_normalized(X, None, similarity=sim_name, pop_discount=pd)
+    dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
+    for K in g["Ks"]:
+        K = int(K)
+        m = _lib.itemknn_fit(ctx, dX, K, similarity=sim, pop_discount=pd, normalize_X=True)
+        idx, val, nnz = m.topk_download()
+        ref = csr_from(g, f"S{K}")
+        assert (np.diff(ref.indptr) == nnz).all()
+        live = np.arange(idx.shape[1])[None, :] < nnz[:, None]
+        assert ((idx[:, 1:] > idx[:, :-1]) | ~live[:, 1:]).all()  # canonical rows
+        bad, exact = tie_aware_topk(cand, ref, idx, nnz, eps=1e-9)
+        assert not bad, (name, K, bad[:5])
+        topk_vals_close(ref, idx, val, nnz, rtol=1e-11)
+        o = onp.itemknn_fit_normalized(X, m.K, similarity=sim_name, pop_discount=pd)
+        osel = onp.topk_to_csr(o["idx"], o["val"], o["nnz"], X.shape[1])
+        bad, exact = tie_aware_topk(cand, osel, idx, nnz, eps=1e-9)
+        assert not bad, ("oracle", name, K, bad[:5])
+        topk_vals_close(osel, idx, val, nnz, rtol=1e-11)
+        # the model predicts like any other neighbour-list model
+        ip, ind, dat = _lib.predict_full(ctx, m, dX, 0, min(200, X.shape[0]))
+        S_gpu = onp.topk_to_csr(idx, val, nnz, X.shape[1])
+        want = onp.predict_full(X[: min(200, X.shape[0])], S_gpu)
+        out = sp.csr_matrix((dat, ind, ip), shape=want.shape)
+        assert (out.indptr == want.indptr).all() and (out.indices == want.indices).all()
+        np.testing.assert_allclose(out.data, want.data, rtol=PRED_RTOL)
+
+
+def test_normalize_X_dropin(hip):
+    # recpack/tests/test_algorithms/test_nearest_neighbour.py:73-107 through the drop-in class
+    import math
+
+    from recpack_amd import ItemKNN
+
+    g = load_golden("ref_itemknn_data")
+    algo = ItemKNN(K=2, similarity="cosine", normalize_X=True).fit(csr_from(g, "X"))
+    a = 1 / (3 * 3)
+    b = 1 / (3 * 3) + 1 / (2 * 2)
+    d = math.sqrt((1 / 2) ** 2 + (1 / 3) ** 2)
+    f = math.sqrt(2 * (1 / 2) ** 2 + (1 / 3) ** 2)
+    expected = np.array([[0, a / (d * d), b / (d * f)], [a / (d * d), 0, b / (d * f)], [b / (d * f), b / (d * f), 0]])
+    np.testing.assert_almost_equal(algo.similarity_matrix_.toarray(), expected)
+    # with normalize_sim on top (nearest_neighbour.py:220-222) every row sums to one
+    algo = ItemKNN(K=2, normalize_X=True, normalize_sim=True).fit(csr_from(g, "X"))
+    np.testing.assert_array_almost_equal(np.asarray(algo.similarity_matrix_.sum(axis=1)).ravel(), 1)
+    # a shard of rows equals the same rows of the full fit
+    _lib, ctx = hip
+    from recpack_amd.synth import powerlaw_csr
+
+    X = powerlaw_csr(3000, 900, 0.01, seed=9).to_scipy()
+    dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
+    full = _lib.itemknn_fit(ctx, dX, 40, normalize_X=True).topk_download()
+    part = _lib.itemknn_fit(ctx, dX, 40, row_begin=300, row_end=700, normalize_X=True).topk_download()
+    np.testing.assert_array_equal(part[2], full[2][300:700])
+    np.testing.assert_allclose(part[1], full[1][300:700], rtol=1e-12)

@@ -155,3 +155,42 @@ def test_conditional_probability_analytic():
     out = onp.itemknn_fit(csr_from(g, "X"), 2, similarity="conditional_probability")
     S = onp.topk_to_csr(out["idx"], out["val"], out["nnz"], 3).toarray()
     np.testing.assert_almost_equal(S, [[0, 1 / 2, 2 / 2], [1 / 2, 0, 2 / 2], [2 / 3, 2 / 3, 0]])
+
+
+NORMX_CASES = ["ref_itemknn_data_normX", "syn_itemknn_normX_2000x500", "syn_itemknn_normX_condprob_2000x500"]
+
+
+def normx_candidates(X, similarity, pd):
+    """Every candidate of the normalize_X similarity from the oracle's closed form (for goldens without ``cos``)."""
+    return onp.itemknn_fit_normalized(X, None, similarity=similarity, pop_discount=pd)
+
+
+@pytest.mark.parametrize("name", NORMX_CASES + ["syn_itemknn_normX_6000x14000"])
+def test_itemknn_normalize_X_matches_reference(name):
+    # nearest_neighbour.py:207-210 (Normalizer l1 on the binarised rows) followed by :69-84 or :22-66
+    g = load_golden(name)
+    X = csr_from(g, "X")
+    sim, pd = str(g["similarity"]), float(g["pop_discount"])
+    cand = csr_from(g, "cos") if "cos_indptr" in g else normx_candidates(X, sim, pd)
+    for K in g["Ks"]:
+        K = int(K)
+        ref = csr_from(g, f"S{K}")
+        out = onp.itemknn_fit_normalized(X, K, similarity=sim, pop_discount=pd)
+        assert (np.diff(ref.indptr) == out["nnz"]).all()
+        bad, exact = tie_aware_topk(cand, ref, out["idx"], out["nnz"], eps=1e-9)
+        assert not bad, (name, K, bad[:5])
+        topk_vals_close(ref, out["idx"], out["val"], out["nnz"], rtol=1e-11)
+
+
+def test_itemknn_normalize_X_analytic():
+    # recpack/tests/test_algorithms/test_nearest_neighbour.py:73-107
+    import math
+
+    g = load_golden("ref_itemknn_data_normX")
+    out = onp.itemknn_fit_normalized(csr_from(g, "X"), 2)
+    S = onp.topk_to_csr(out["idx"], out["val"], out["nnz"], 3).toarray()
+    a = 1 / (3 * 3)
+    b = 1 / (3 * 3) + 1 / (2 * 2)
+    d = math.sqrt((1 / 2) ** 2 + (1 / 3) ** 2)
+    f = math.sqrt(2 * (1 / 2) ** 2 + (1 / 3) ** 2)
+    np.testing.assert_almost_equal(S, [[0, a / (d * d), b / (d * f)], [a / (d * d), 0, b / (d * f)], [b / (d * f), b / (d * f), 0]])
