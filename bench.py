@@ -180,10 +180,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # RECPACK_DIST_BACKEND=gloo lets N ranks share the GPUs that are there (functional test of the sharded path on a
+    # one-GPU box); the default is nccl = RCCL over xGMI, one rank per GPU
+    backend = os.environ.get("RECPACK_DIST_BACKEND", "nccl")
+    local_rank = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from recpack_amd import _lib, dist as rdist
     from recpack_amd.synth import CONFIG_SEED_BASE, CONFIGS, powerlaw_csr

@@ -118,12 +118,15 @@ def load_library(path: str | None = None):
         return lib
 
 
-def _torch_inputs_ready():
+def _torch_inputs_ready(ctx=None):
     """The library runs on its own HIP stream: tensors a caller has just produced on torch's current stream must be
-    complete before the library reads them."""
+    complete before the library reads them.  Nothing to do when the context was created on that very stream."""
     import torch
 
-    torch.cuda.current_stream().synchronize()
+    cur = torch.cuda.current_stream()
+    if ctx is not None and ctx.stream is not None and int(cur.cuda_stream) == ctx.stream:
+        return
+    cur.synchronize()
 
 
 def check(code: int):
@@ -145,6 +148,7 @@ class Context:
         check(self.lib.rphip_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
         self.handle = h
         self.device = int(device)
+        self.stream = int(stream) if stream else None  # the caller's HIP stream, if the context runs on one
 
     def close(self):
         if getattr(self, "handle", None):
@@ -200,7 +204,7 @@ class DeviceCSR:
     @classmethod
     def from_device(cls, ctx: Context, indptr_t, indices_t, shape):
         """indptr_t / indices_t: torch int32 CUDA tensors (kept alive by this object)."""
-        _torch_inputs_ready()
+        _torch_inputs_ready(ctx)
         h = C.c_void_p()
         check(ctx.lib.rphip_csr_from_device(ctx.handle, int(shape[0]), int(shape[1]), int(indices_t.numel()),
                                             C.c_void_p(indptr_t.data_ptr()), C.c_void_p(indices_t.data_ptr()), C.byref(h)))
@@ -263,7 +267,7 @@ class Model:
     @classmethod
     def from_topk_device(cls, ctx: Context, idx_t, val_t, nnz_t):
         """torch CUDA tensors: idx int32[I,K], val float64[I,K], nnz int32[I] (copied)."""
-        _torch_inputs_ready()
+        _torch_inputs_ready(ctx)
         h = C.c_void_p()
         check(ctx.lib.rphip_model_from_topk_device(ctx.handle, int(idx_t.shape[0]), int(idx_t.shape[1]), C.c_void_p(idx_t.data_ptr()),
                                                    C.c_void_p(val_t.data_ptr()), C.c_void_p(nnz_t.data_ptr()), C.byref(h)))
@@ -324,7 +328,7 @@ def ease_fit(ctx: Context, X: DeviceCSR, l2: float, alpha: float = 0.0) -> Model
 
 def gemm_nt(ctx: Context, A_t, B_t, C_t, alpha: float = 1.0, beta: float = 0.0):
     """C = alpha * A @ B.T + beta * C on torch float32 CUDA tensors (row-major, sizes multiples of 128 / 16)."""
-    _torch_inputs_ready()
+    _torch_inputs_ready(ctx)
     M, K = A_t.shape
     N = B_t.shape[0]
     check(ctx.lib.rphip_gemm_nt_f32(ctx.handle, M, N, K, float(alpha), C.c_void_p(A_t.data_ptr()), A_t.stride(0),
@@ -357,7 +361,7 @@ def predict_topk_dev(ctx: Context, model: Model, X: DeviceCSR, Kp: int, idx_t, v
     item_keep_t: optional torch uint8 CUDA tensor [n_items]."""
     user_end = X.shape[0] if user_end is None else user_end
     if item_keep_t is not None:
-        _torch_inputs_ready()
+        _torch_inputs_ready(ctx)
     check(ctx.lib.rphip_predict_topk_filtered_dev(ctx.handle, model.handle, X.handle, int(user_begin), int(user_end), int(Kp),
                                                   1 if exclude_history else 0,
                                                   C.c_void_p(item_keep_t.data_ptr()) if item_keep_t is not None else None,
