@@ -198,6 +198,10 @@ int rphip_model_dense_device(const rphip_model* m, void** B_dev, int64_t* n_item
 /* a dense model from a host matrix (row-major float32[n_items*n_items], copied): used after host-side edits of B
  * such as EASE's density pruning (ease.py:97-109) */
 int rphip_model_from_dense_host(rphip_ctx* ctx, int64_t n_items, const float* B_host, rphip_model** out);
+/* density pruning on the device (ease.py:97-109): keep the `keep` largest |B_ij| of a dense model, zero the rest
+ * (keep = min(int(density * n * n), nnz) in the reference).  Entries equal to the threshold are kept up to the exact
+ * count in no particular order, as np.argpartition does.  nnz_before / nnz_after may be NULL. */
+int rphip_model_dense_prune(rphip_ctx* ctx, rphip_model* m, int64_t keep, int64_t* nnz_before, int64_t* nnz_after);
 /* number of similarity rows without any stored value (dense models; -1 if not counted): what
  * ItemSimilarityMatrixAlgorithm._check_fit_complete warns about (recpack/algorithms/base.py:257-279) */
 int rphip_model_empty_rows(rphip_ctx* ctx, const rphip_model* m, int64_t* out);

@@ -85,6 +85,7 @@ PROTOTYPES = {
     "rphip_ease_fit": (C.c_int, [_p, _p, _f64, _f64, _pp]),
     "rphip_model_dense_download": (C.c_int, [_p, _p, _p]),
     "rphip_model_dense_device": (C.c_int, [_p, _pp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "rphip_model_dense_prune": (C.c_int, [_p, _p, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
     "rphip_model_from_dense_host": (C.c_int, [_p, _i64, _p, _pp]),
     "rphip_model_empty_rows": (C.c_int, [_p, _p, C.POINTER(_i64)]),
     "rphip_gemm_nt_f32": (C.c_int, [_p, _i64, _i64, _i64, C.c_float, _p, _i64, _p, _i64, C.c_float, _p, _i64]),
@@ -291,6 +292,12 @@ class Model:
         ptr, n, ld = C.c_void_p(), C.c_int64(), C.c_int64()
         check(self.ctx.lib.rphip_model_dense_device(self.handle, C.byref(ptr), C.byref(n), C.byref(ld)))
         return ptr.value, n.value, ld.value
+
+    def dense_prune(self, keep: int):
+        """Keep the ``keep`` largest |B_ij| on the device (ease.py:97-109); returns (nnz before, nnz after)."""
+        a, b = C.c_int64(), C.c_int64()
+        check(self.ctx.lib.rphip_model_dense_prune(self.ctx.handle, self.handle, int(keep), C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def dense_download(self) -> np.ndarray:
         out = np.empty((self.n_items, self.n_items), dtype=np.float32)

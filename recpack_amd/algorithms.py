@@ -273,7 +273,7 @@ class EASE(ItemSimilarityMatrixAlgorithm):
     The dense item-item matrix B stays on the device in float32; ``similarity_matrix_`` is materialised on the
     host (float64 CSR, as the reference stores it, ease.py:92) only when it is read - for 50K items that is a
     20 GB download plus a CSR conversion, so predict() never touches it.
-    ``density`` (ease.py:97-109) prunes on the host with the reference's rule and re-uploads the result.
+    ``density`` (ease.py:97-109) prunes on the device with the reference's rule.
     """
 
     def __init__(self, l2=1e3, alpha=0, density=None):
@@ -295,19 +295,10 @@ class EASE(ItemSimilarityMatrixAlgorithm):
         self._empty_rows_ = self._model.empty_rows()
 
     def _prune(self):
-        """ease.py:97-109: keep the ``int(density * n * n)`` largest |B_ij| (np.prod for the removed np.product)."""
-        B = self._model.dense_download()
-        n = B.shape[0]
-        nnz = int(np.count_nonzero(B))
-        k = min(int(self.density * n * n), nnz)
-        if k < nnz:
-            flat = np.abs(B).ravel()
-            if k > 0:
-                thr_idx = np.argpartition(flat, -k)[:-k]
-            else:
-                thr_idx = np.arange(flat.shape[0])
-            B.ravel()[thr_idx] = 0.0
-            self._model = _lib.Model.from_dense_host(get_context(), B)
+        """ease.py:97-109: keep the ``int(density * n * n)`` largest |B_ij| (np.prod for the removed np.product), on the
+        device: B never leaves HBM (an exact radix select over the magnitudes, then one zeroing pass)."""
+        n = int(self.n_items_)
+        self._model.dense_prune(int(self.density * n * n))
         self._sim_cache = None
 
     @property

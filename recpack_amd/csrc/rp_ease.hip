@@ -16,6 +16,7 @@
 //   inverse, column i : N_ii = W_i^T ; T = N[0:i,0:i] L[i,0:i]^T (K from the row's first non-zero) ; N[0:i,i] = -T W_i^T
 //   product           : P = N N^T, K from max(row tile, column tile)
 #include <algorithm>
+#include <vector>
 
 #include "rp_common.h"
 
@@ -596,6 +597,120 @@ static int rp_dense_count_empty(rphip_ctx* ctx, rphip_model* m) {
   RP_HIP(hipStreamSynchronize(ctx->stream));
   m->empty_rows = h;
   return RPHIP_OK;
+}
+
+
+// ---- density pruning on the device (ease.py:97-109) -----------------------------------------------------------------
+// Keep the `keep` largest |B_ij| of a dense model, zero the rest: an exact radix select over the 31 magnitude bits of
+// the floats (11 + 11 + 9 bits, one histogram pass over the matrix per digit), then one pass that zeroes everything
+// below the threshold.  Entries EQUAL to the threshold (rare for float32 values) are kept up to the exact count,
+// whichever come first to an atomic counter - the reference's np.argpartition leaves that choice open as well.
+constexpr int PR_BINS = 2048;
+
+__global__ void __launch_bounds__(256) k_prune_hist(const float* __restrict__ B, long long ld, int n, uint32_t prefix, int shift, int width,
+                                                    int hi_shift, unsigned long long* __restrict__ hist) {
+  __shared__ uint32_t h[PR_BINS];
+  for (int i = threadIdx.x; i < PR_BINS; i += 256) h[i] = 0u;
+  __syncthreads();
+  const int n4 = (n + 3) >> 2;
+  const long long total = (long long)n * n4;
+  const uint32_t mask = (1u << width) - 1u;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long i = e / n4;
+    const int j = (int)(e % n4) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(B + i * ld + j);  // ld is a multiple of 4
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint32_t a = __float_as_uint(x[c]) & 0x7fffffffu;
+      if (j + c < n && a != 0u && (hi_shift >= 32 || (a >> hi_shift) == prefix)) atomicAdd(&h[(a >> shift) & mask], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < PR_BINS; i += 256)
+    if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+
+__global__ void __launch_bounds__(256) k_prune_apply(float* __restrict__ B, long long ld, int n, uint32_t thr, unsigned long long tie_budget,
+                                                     unsigned long long* __restrict__ ties_taken) {
+  const int n4 = (n + 3) >> 2;
+  const long long total = (long long)n * n4;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long i = e / n4;
+    const int j = (int)(e % n4) * 4;
+    float4* p = reinterpret_cast<float4*>(B + i * ld + j);
+    float4 v = *p;
+    float x[4] = {v.x, v.y, v.z, v.w};
+    bool changed = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint32_t a = __float_as_uint(x[c]) & 0x7fffffffu;
+      if (j + c >= n || a == 0u) continue;
+      bool drop = a < thr;
+      if (a == thr) drop = atomicAdd(ties_taken, 1ull) >= tie_budget;
+      if (drop) {
+        x[c] = 0.0f;
+        changed = true;
+      }
+    }
+    if (changed) *p = make_float4(x[0], x[1], x[2], x[3]);
+  }
+}
+
+extern "C" int rphip_model_dense_prune(rphip_ctx* ctx, rphip_model* m, int64_t keep, int64_t* nnz_before, int64_t* nnz_after) {
+  if (!ctx || !m) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if (m->kind != RPHIP_MODEL_DENSE) RP_FAIL(RPHIP_ESTATE, "model is not a dense model");
+  if (keep < 0) RP_FAIL(RPHIP_EINVAL, "keep must be >= 0");
+  RP_TRY(rp_set_device(ctx));
+  hipStream_t st = ctx->stream;
+  const int n = (int)m->n_items;
+  unsigned long long* hist = nullptr;
+  RP_TRY(rp_scratch(ctx, 5, (size_t)(PR_BINS + 8) * 8, (void**)&hist));
+  unsigned long long* ties_taken = hist + PR_BINS;
+  std::vector<unsigned long long> h(PR_BINS);
+  const int grid = ctx->n_cu * 8;
+  // digits from the top of the 31 magnitude bits
+  const int shifts[3] = {20, 9, 0}, widths[3] = {11, 11, 9};
+  uint32_t prefix = 0;
+  unsigned long long need = (unsigned long long)keep, total_nz = 0, above = 0;
+  for (int lv = 0; lv < 3; ++lv) {
+    RP_HIP(hipMemsetAsync(hist, 0, (size_t)PR_BINS * 8, st));
+    const int hi_shift = shifts[lv] + widths[lv];  // bits above this digit must equal the prefix
+    hipLaunchKernelGGL(k_prune_hist, dim3(grid), dim3(256), 0, st, m->B, m->ld, n, prefix, shifts[lv], widths[lv], lv == 0 ? 32 : hi_shift, hist);
+    RP_HIP(hipGetLastError());
+    RP_HIP(hipMemcpyAsync(h.data(), hist, (size_t)PR_BINS * 8, hipMemcpyDeviceToHost, st));
+    RP_HIP(hipStreamSynchronize(st));
+    const int nb = 1 << widths[lv];
+    if (lv == 0) {
+      for (int b = 0; b < nb; ++b) total_nz += h[b];
+      if (nnz_before) *nnz_before = (int64_t)total_nz;
+      if ((unsigned long long)keep >= total_nz) {  // nothing to prune
+        if (nnz_after) *nnz_after = (int64_t)total_nz;
+        return RPHIP_OK;
+      }
+      if (keep == 0) break;
+    }
+    int b = nb - 1;
+    for (; b > 0; --b) {
+      if (h[b] >= need) break;
+      need -= h[b];
+      above += h[b];
+    }
+    // bin b holds the threshold: `need` of its members (from the top) are kept
+    prefix = (prefix << widths[lv]) | (uint32_t)b;
+  }
+  uint32_t thr = prefix;
+  unsigned long long budget = need;  // entries equal to the threshold that stay
+  if (keep == 0) {
+    thr = 0x7fffffffu;
+    budget = 0;
+  }
+  RP_HIP(hipMemsetAsync(ties_taken, 0, 8, st));
+  hipLaunchKernelGGL(k_prune_apply, dim3(grid), dim3(256), 0, st, m->B, m->ld, n, thr, budget, ties_taken);
+  RP_HIP(hipGetLastError());
+  if (nnz_after) *nnz_after = keep;
+  (void)above;
+  return rp_dense_count_empty(ctx, m);
 }
 
 extern "C" int rphip_model_from_dense_host(rphip_ctx* ctx, int64_t n_items, const float* B_host, rphip_model** out) {

@@ -180,3 +180,41 @@ def test_ease_edge_cases(hip):
     # users without history predict nothing
     out = algo.predict(sp.csr_matrix((2, 3)))
     assert out.nnz == 0
+
+
+def test_ease_prune_on_device(hip):
+    """ease.py:97-109 on the device: exact count, the same survivors as the oracle's rule when there are no ties, and with
+    ties exactly `keep` entries none of which is smaller than a dropped one."""
+    from recpack_amd import EASE
+    from recpack_amd.synth import powerlaw_csr
+
+    _lib, ctx = hip
+    X = powerlaw_csr(8000, 1100, 0.01, seed=32).to_scipy()
+    dX, m, B = ease_B(hip, X, 5.0, 0.5)
+    n = B.shape[0]
+    density = 0.03
+    want = onp.ease_prune(B.astype(np.float64), density)
+    before, after = m.dense_prune(int(density * n * n))
+    assert before == np.count_nonzero(B) and after == int(density * n * n)
+    got = m.dense_download()
+    assert np.count_nonzero(got) == after
+    np.testing.assert_array_equal(got != 0, want != 0)
+    np.testing.assert_array_equal(got[got != 0], B[got != 0])
+    # pruning to more than there is changes nothing; to zero clears the matrix
+    assert m.dense_prune(n * n) == (after, after)
+    # through the drop-in class, with the warning bookkeeping still working
+    algo = EASE(l2=5.0, alpha=0.5, density=density).fit(X)
+    S = algo.similarity_matrix_
+    assert S.nnz == after
+    assert (S.toarray().astype(np.float32) != 0).sum() == after
+    # ties: values from a tiny set
+    rng = np.random.default_rng(0)
+    T = rng.choice(np.array([0.0, 0.25, -0.25, 0.5, -0.5, 1.0], dtype=np.float32), size=(300, 300))
+    mt = _lib.Model.from_dense_host(ctx, T)
+    keep = int((np.abs(T) >= 0.5).sum()) + 1234  # all of the 0.5 and 1.0 entries plus 1234 of the 0.25 ones
+    b, a = mt.dense_prune(keep)
+    G = mt.dense_download()
+    assert b == np.count_nonzero(T) and a == keep and np.count_nonzero(G) == keep
+    assert (G[np.abs(T) >= 0.5] == T[np.abs(T) >= 0.5]).all()
+    assert (np.abs(G[G != 0]) >= 0.25).all()
+    assert mt.dense_prune(0)[1] == 0 and np.count_nonzero(mt.dense_download()) == 0
