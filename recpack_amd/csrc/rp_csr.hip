@@ -4,8 +4,8 @@
 // recpack/matrix/util.py:27-48) as far as the hot path needs them: only the pattern (indptr, indices) is used.
 // X^T is what scipy builds implicitly for `X.T @ X` (nearest_neighbour.py:80 via sklearn, ease.py:81).
 //
-//   k_rank_hist   rank[k] = atomicAdd(deg[idx[k]], 1)     one pass over nnz: degrees AND the position of
-//                                                          every entry inside its item row
+//   k_rank_hist_ranges   degrees AND the position of every entry inside its item row, one pass over nnz per item
+//                 range (LDS counters per block, one global atomic per (block, item))
 //   scan          xt_ptr = exclusive_scan(deg)
 //   k_scatter     xt_idx[xt_ptr[j] + rank[k]] = u          8 lanes per user row, coalesced 32-B segments
 //   k_inv_deg     inv_deg[j] = fl(1/c_j)
@@ -13,18 +13,6 @@
 #include <algorithm>
 
 #include "rp_common.h"
-
-__global__ void k_rank_hist(const int32_t* __restrict__ idx, int64_t nnz, int n_items, int32_t* __restrict__ deg,
-                            int32_t* __restrict__ rank, int32_t* __restrict__ err) {
-  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
-    const int j = idx[k];
-    if ((unsigned)j >= (unsigned)n_items) {
-      *err = 1;
-      continue;
-    }
-    rank[k] = atomicAdd(&deg[j], 1);
-  }
-}
 
 // Degrees and in-row ranks without hot global atomics: the item axis is cut into ranges that fit LDS, a block
 // (chunk of nnz, range) counts its entries with returning LDS atomics (= rank inside the block), reserves a
@@ -151,7 +139,6 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
   RP_HIP(hipMemsetAsync(m->deg, 0, (size_t)std::max<int64_t>(I, 1) * sizeof(int32_t), st));
   RP_HIP(hipMemsetAsync(err, 0, 64, st));
   const int bt = 256;
-  const int grid_nnz = (int)std::min<int64_t>((int64_t)ctx->n_cu * 16, std::max<int64_t>(1, rp_cdiv(nnz, bt)));
   const int grid_u = (int)std::min<int64_t>((int64_t)ctx->n_cu * 16, std::max<int64_t>(1, rp_cdiv(U + 1, bt)));
   hipLaunchKernelGGL(k_check_ptr, dim3(grid_u), dim3(bt), 0, st, m->x_ptr, (int)U, nnz, err);
   int32_t h_chk[5] = {0, 0, 0, 0, 0};
@@ -170,7 +157,6 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
     hipLaunchKernelGGL(k_rank_hist_ranges, dim3((unsigned)rp_cdiv(nnz, chunk), n_ranges), dim3(1024), hl, st, m->x_idx, (long long)nnz, chunk,
                        (int)I, range_w, m->deg, rank, err);
   }
-  (void)grid_nnz;
   RP_TRY(rp_exclusive_scan_i32(ctx, m->deg, m->xt_ptr, I));
   if (nnz > 0) {
     const int grid_s = (int)std::min<int64_t>((int64_t)ctx->n_cu * 16, std::max<int64_t>(1, rp_cdiv(U * 8, bt)));

@@ -407,7 +407,6 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
 
 // ---- merge of per-tile candidates (n_tiles > 1) ---------------------------------------------------
 struct rp_list_src {
-  static constexpr bool PACK4 = false;
   const int32_t* col_;
   const uint32_t* cnt_;
   const double* inv_deg;
@@ -947,7 +946,6 @@ struct rp_wfit_params {
 };
 
 struct rp_wdense_src {
-  static constexpr bool PACK4 = false;
   const double* acc;
   const double* colw;
   int t0, row;
@@ -1023,7 +1021,6 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_weighted(rp_wfit
 }
 
 struct rp_wlist_src {
-  static constexpr bool PACK4 = false;
   const int32_t* col_;
   const double* g_;
   const double* colw;

@@ -87,7 +87,6 @@ struct rp_pred_params {
 // tile of f32 scores (dense models) or of fixed-point sums (neighbour lists)
 template <bool DENSE>
 struct rp_score_src {
-  static constexpr bool PACK4 = false;
   const void* acc_;
   int t0;
   const uint8_t* keep;
@@ -253,7 +252,6 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_tile(rp_pred_params
 
 // ---- merge of per-tile top-Kp candidates -----------------------------------------------------------
 struct rp_flist_src {
-  static constexpr bool PACK4 = false;
   const int32_t* col_;
   const float* val_;
   int n;
