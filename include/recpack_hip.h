@@ -105,6 +105,16 @@ int rphip_csr_from_host(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_
  * the arrays are NOT copied and must outlive the object. */
 int rphip_csr_from_device(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_t nnz,
                           const int32_t* indptr_dev, const int32_t* indices_dev, rphip_csr** out);
+/* from raw (user id, item id) pairs, int64 as pandas holds them, in any order and with repeats: what
+ * InteractionMatrix.values builds from its DataFrame (recpack/matrix/interaction_matrix.py:202-217:
+ * csr_matrix((ones, (uid, iid)), shape), duplicates summed) before the path binarises it - here the DISTINCT pairs,
+ * rows sorted by item, built on the device (64-bit key sort + flagged compaction).  Ids outside the shape: RPHIP_EINVAL. */
+int rphip_csr_from_coo_host(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_t n_pairs, const int64_t* uid_host,
+                            const int64_t* iid_host, rphip_csr** out);
+int rphip_csr_from_coo_device(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_t n_pairs, const int64_t* uid_dev,
+                              const int64_t* iid_dev, rphip_csr** out);
+/* the CSR arrays of a device matrix to the host: indptr int32[n_users+1], indices int32[nnz] */
+int rphip_csr_download(rphip_ctx* ctx, const rphip_csr* m, int32_t* indptr_host, int32_t* indices_host);
 int rphip_csr_destroy(rphip_csr* m);
 int rphip_csr_shape(const rphip_csr* m, int64_t* n_users, int64_t* n_items, int64_t* nnz);
 /* item degrees c_j (int32[n_items]) to host; sum_u d_u^2 (the number of scalar products P) */

@@ -64,6 +64,9 @@ PROTOTYPES = {
     "rphip_device_info": (C.c_int, [_p, C.POINTER(C.c_int), C.POINTER(_i64), C.c_char_p, C.c_int]),
     "rphip_csr_from_host": (C.c_int, [_p, _i64, _i64, _i64, _p, C.c_int, _p, _pp]),
     "rphip_csr_from_device": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _pp]),
+    "rphip_csr_from_coo_host": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _pp]),
+    "rphip_csr_from_coo_device": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _pp]),
+    "rphip_csr_download": (C.c_int, [_p, _p, _p, _p]),
     "rphip_csr_destroy": (C.c_int, [_p]),
     "rphip_csr_shape": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "rphip_csr_item_degrees": (C.c_int, [_p, _p, _p]),
@@ -210,6 +213,37 @@ class DeviceCSR:
         check(ctx.lib.rphip_csr_from_device(ctx.handle, int(shape[0]), int(shape[1]), int(indices_t.numel()),
                                             C.c_void_p(indptr_t.data_ptr()), C.c_void_p(indices_t.data_ptr()), C.byref(h)))
         return cls(ctx, h, keepalive=(indptr_t, indices_t))
+
+    @classmethod
+    def from_coo(cls, ctx: Context, uid, iid, shape):
+        """From raw (user id, item id) pairs - numpy int arrays, or torch int64 CUDA tensors - in any order, repeats
+        allowed: the distinct pairs become the binary matrix (InteractionMatrix.values + to_binary, built on the GPU)."""
+        h = C.c_void_p()
+        if hasattr(uid, "data_ptr"):  # torch
+            import torch
+
+            if uid.dtype != torch.int64 or iid.dtype != torch.int64 or not uid.is_cuda or not iid.is_cuda:
+                raise TypeError("from_coo: torch inputs must be int64 CUDA tensors")
+            uid, iid = uid.contiguous(), iid.contiguous()
+            _torch_inputs_ready(ctx)
+            check(ctx.lib.rphip_csr_from_coo_device(ctx.handle, int(shape[0]), int(shape[1]), int(uid.numel()), C.c_void_p(uid.data_ptr()),
+                                                    C.c_void_p(iid.data_ptr()), C.byref(h)))
+            ctx.sync()  # the pairs may be freed by the caller right away
+        else:
+            uid = np.ascontiguousarray(uid, dtype=np.int64)
+            iid = np.ascontiguousarray(iid, dtype=np.int64)
+            if uid.shape != iid.shape or uid.ndim != 1:
+                raise ValueError("from_coo: uid and iid must be 1-d arrays of the same length")
+            check(ctx.lib.rphip_csr_from_coo_host(ctx.handle, int(shape[0]), int(shape[1]), int(uid.shape[0]), _np_ptr(uid), _np_ptr(iid),
+                                                  C.byref(h)))
+        return cls(ctx, h)
+
+    def download(self):
+        """(indptr int32[n_users+1], indices int32[nnz]) of X."""
+        indptr = np.empty(self.shape[0] + 1, dtype=np.int32)
+        indices = np.empty(max(self.nnz, 1), dtype=np.int32)
+        check(self.ctx.lib.rphip_csr_download(self.ctx.handle, self.handle, _np_ptr(indptr), _np_ptr(indices)))
+        return indptr, indices[: self.nnz]
 
     def item_degrees(self) -> np.ndarray:
         out = np.empty(self.shape[1], dtype=np.int32)

@@ -494,3 +494,39 @@ def test_normalize_X_dropin(hip):
     part = _lib.itemknn_fit(ctx, dX, 40, row_begin=300, row_end=700, normalize_X=True).topk_download()
     np.testing.assert_array_equal(part[2], full[2][300:700])
     np.testing.assert_allclose(part[1], full[1][300:700], rtol=1e-12)
+
+
+def test_csr_from_coo(hip):
+    """COO ingestion on the device equals scipy's csr_matrix((ones, (uid, iid))) binarised
+    (recpack/matrix/interaction_matrix.py:202-217 + recpack/util.py:99-109): any order, repeats, empty users."""
+    import torch
+
+    _lib, ctx = hip
+    rng = np.random.default_rng(4)
+    for (U, I, n) in [(50, 20, 300), (3000, 70000, 200000), (7, 5, 0), (1200, 900, 50000)]:
+        uid = rng.integers(0, max(1, U - 3), n)  # the last users stay empty
+        iid = (rng.zipf(1.3, n) - 1) % I if n else np.zeros(0, dtype=np.int64)
+        if n:
+            uid[: n // 10], iid[: n // 10] = uid[n // 2: n // 2 + n // 10], iid[n // 2: n // 2 + n // 10]  # repeats
+        ref = sp.csr_matrix((np.ones(n), (uid, iid)), shape=(U, I))
+        ref.data[:] = 1
+        ref.sort_indices()
+        for dev in (False, True):
+            if dev:
+                d = _lib.DeviceCSR.from_coo(ctx, torch.as_tensor(uid, dtype=torch.int64).cuda(), torch.as_tensor(iid, dtype=torch.int64).cuda(), (U, I))
+            else:
+                d = _lib.DeviceCSR.from_coo(ctx, uid, iid, (U, I))
+            ip, ix = d.download()
+            assert d.nnz == ref.nnz
+            np.testing.assert_array_equal(ip, ref.indptr)
+            np.testing.assert_array_equal(ix, ref.indices)
+            np.testing.assert_array_equal(d.item_degrees(), np.asarray(ref.sum(axis=0)).ravel().astype(np.int32))
+    # the fit on a COO-built matrix equals the fit on the host CSR
+    d2 = _lib.DeviceCSR.from_host(ctx, ref.indptr, ref.indices, ref.shape)
+    a, b = _lib.itemknn_fit(ctx, d, 30).topk_download(), _lib.itemknn_fit(ctx, d2, 30).topk_download()
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    with pytest.raises(_lib.RecpackHipError):
+        _lib.DeviceCSR.from_coo(ctx, np.array([0, 5]), np.array([1, 1]), (5, 3))
+    with pytest.raises(_lib.RecpackHipError):
+        _lib.DeviceCSR.from_coo(ctx, np.array([0, 1]), np.array([1, -1]), (5, 3))
