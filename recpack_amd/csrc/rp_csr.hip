@@ -7,9 +7,10 @@
 //   k_rank_hist_ranges   degrees AND the position of every entry inside its item row, one pass over nnz per item
 //                 range (LDS counters per block, one global atomic per (block, item))
 //   scan          xt_ptr = exclusive_scan(deg)
-//   k_scatter     xt_idx[xt_ptr[j] + rank[k]] = u          8 lanes per user row, coalesced 32-B segments
+//   k_scatter     xt_idx[xt_ptr[j] + rank[k]] = u          8 lanes per user row, coalesced 32-B segments; the same
+//                 pass checks the column order and (n_items > one LDS tile) writes per user the first position
+//                 with column >= t*W
 //   k_inv_deg     inv_deg[j] = fl(1/c_j)
-//   k_tile_ptr    (n_items > one LDS tile) per user the first position with column >= t*W, checks order
 #include <algorithm>
 
 #include "rp_common.h"
@@ -44,21 +45,51 @@ __global__ void __launch_bounds__(1024) k_rank_hist_ranges(const int32_t* __rest
   }
 }
 
+// One pass over X with 8 lanes per user row (coalesced 32-byte segments):
+//   * X^T: xt_idx[xt_ptr[j] + rank[k]] = u
+//   * are the column indices of every row strictly increasing?  (err[1] = 1 if not; with several column tiles err[0] = 3)
+//   * n_tiles > 1: tile_ptr[u][t] = first position of row u with column >= t * tile_w - an entry whose tile differs from
+//     its predecessor's opens the tiles in between; the row's first entry opens tiles 0.., its last closes the rest
+//   * P = sum_u d_u^2
 __global__ void k_scatter(const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ x_idx, int n_users,
                           const int32_t* __restrict__ xt_ptr, const int32_t* __restrict__ rank, int32_t* __restrict__ xt_idx,
-                          unsigned long long* __restrict__ p_sum, int n_items) {
+                          unsigned long long* __restrict__ p_sum, int n_items, int n_tiles, int tile_w, int32_t* __restrict__ tile_ptr,
+                          int32_t* __restrict__ err) {
   const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, sub = threadIdx.x & 7;
   const int ng = (gridDim.x * blockDim.x) >> 3;
+  const float inv_w = 1.0f / (float)tile_w;
+  auto tile_of = [&](int j) {
+    int t = (int)((float)j * inv_w);
+    while ((long long)(t + 1) * tile_w <= j) ++t;
+    while ((long long)t * tile_w > j) --t;
+    return t;
+  };
   unsigned long long local = 0;
   for (int u = g; u < n_users; u += ng) {
     const int s = x_ptr[u], e = x_ptr[u + 1];
-    if (sub == 0) local += (unsigned long long)(e - s) * (unsigned long long)(e - s);
+    int32_t* tp = (n_tiles > 1) ? tile_ptr + (int64_t)u * (n_tiles + 1) : nullptr;
+    if (sub == 0) {
+      local += (unsigned long long)(e - s) * (unsigned long long)(e - s);
+      if (tp && e == s)
+        for (int t = 0; t <= n_tiles; ++t) tp[t] = s;
+    }
     for (int k = s + sub; k < e; k += 8) {
       const int j = x_idx[k];
+      const int prev = (k > s) ? x_idx[k - 1] : -1;
       if ((unsigned)j < (unsigned)n_items) xt_idx[xt_ptr[j] + rank[k]] = u;
+      if (j <= prev) {
+        err[1] = 1;
+        if (tp) err[0] = 3;
+      }
+      if (tp && (unsigned)j < (unsigned)n_items) {
+        const int tj = tile_of(j);
+        const int tprev = (k > s && (unsigned)prev < (unsigned)n_items) ? tile_of(prev) : -1;
+        for (int t = tprev + 1; t <= tj; ++t) tp[t] = k;
+        if (k == e - 1)
+          for (int t = tj + 1; t <= n_tiles; ++t) tp[t] = e;
+      }
     }
   }
-  // P = sum_u d_u^2
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) local += __shfl_xor(local, d);
   if ((threadIdx.x & 63) == 0 && local) atomicAdd(p_sum, local);
@@ -86,37 +117,6 @@ __global__ void k_check_ptr(const int32_t* __restrict__ x_ptr, int n_users, int6
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, __shfl_xor(dmax, o));
   if ((threadIdx.x & 63) == 0 && dmax > 0) atomicMax(&err[4], dmax);  // longest history
-}
-
-// one thread per user: tile boundaries by a linear merge (rows are short), and the order check
-__global__ void k_tile_ptr(const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ x_idx, int n_users, int n_tiles,
-                           int tile_w, int32_t* __restrict__ tile_ptr, int32_t* __restrict__ err) {
-  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n_users; u += gridDim.x * blockDim.x) {
-    const int s = x_ptr[u], e = x_ptr[u + 1];
-    int32_t* tp = tile_ptr + (int64_t)u * (n_tiles + 1);
-    int t = 0;
-    int prev = -1;
-    tp[0] = s;
-    for (int k = s; k < e; ++k) {
-      const int j = x_idx[k];
-      if (j <= prev) *err = 3;
-      prev = j;
-      const int tj = j / tile_w;
-      while (t < tj) tp[++t] = k;
-    }
-    while (t < n_tiles) tp[++t] = e;
-  }
-}
-
-// 8 lanes per user: are the column indices of every row strictly increasing?
-__global__ void k_check_sorted(const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ x_idx, int n_users, int32_t* __restrict__ flag) {
-  const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, sub = threadIdx.x & 7;
-  const int ng = (gridDim.x * blockDim.x) >> 3;
-  for (int u = g; u < n_users; u += ng) {
-    const int s = x_ptr[u], e = x_ptr[u + 1];
-    for (int k = s + 1 + sub; k < e; k += 8)
-      if (x_idx[k] <= x_idx[k - 1]) *flag = 1;
-  }
 }
 
 int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
@@ -158,21 +158,14 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
                        (int)I, range_w, m->deg, rank, err);
   }
   RP_TRY(rp_exclusive_scan_i32(ctx, m->deg, m->xt_ptr, I));
-  if (nnz > 0) {
+  if (m->n_tiles > 1) RP_HIP(hipMalloc((void**)&m->tile_ptr, (size_t)U * (m->n_tiles + 1) * sizeof(int32_t)));
+  if (U > 0) {  // (rows without entries still need their tile pointers)
     const int grid_s = (int)std::min<int64_t>((int64_t)ctx->n_cu * 16, std::max<int64_t>(1, rp_cdiv(U * 8, bt)));
     hipLaunchKernelGGL(k_scatter, dim3(grid_s), dim3(bt), 0, st, m->x_ptr, m->x_idx, (int)U, m->xt_ptr, rank, m->xt_idx, p_sum,
-                       (int)I);
+                       (int)I, m->n_tiles, m->tile_w, m->tile_ptr, err);
   }
   hipLaunchKernelGGL(k_inv_deg, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, rp_cdiv(I, bt)))), dim3(bt), 0, st,
                      m->deg, m->inv_deg, (int)I);
-  if (m->n_tiles > 1) {
-    RP_HIP(hipMalloc((void**)&m->tile_ptr, (size_t)U * (m->n_tiles + 1) * sizeof(int32_t)));
-    hipLaunchKernelGGL(k_tile_ptr, dim3(grid_u), dim3(bt), 0, st, m->x_ptr, m->x_idx, (int)U, m->n_tiles, m->tile_w, m->tile_ptr,
-                       err);
-  } else if (nnz > 0) {
-    const int grid_c = (int)std::min<int64_t>((int64_t)ctx->n_cu * 16, std::max<int64_t>(1, rp_cdiv(U * 8, bt)));
-    hipLaunchKernelGGL(k_check_sorted, dim3(grid_c), dim3(bt), 0, st, m->x_ptr, m->x_idx, (int)U, err + 1);
-  }
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, RPHIP_T_CSR_TRANSPOSE, 12.0 * (double)nnz + 4.0 * (double)(U + I + 2) + 4.0 * (double)(I + 1));
   struct {
