@@ -254,9 +254,9 @@ def main():
 
     if rank == 0:
         sec_per_step = elapsed / args.steps
-        # The SpGEMM (K1-K3) runs as two instances of one kernel: k_itemknn_fit<false,1024,false> (rows with more than
-        # 255 users: u32 counters, one 1024-thread workgroup per CU) and k_itemknn_fit<false,256,true> (lighter rows:
-        # byte counters, 256-thread workgroups, three to four per CU).  Each is priced with its own share of the 4*P byte model
+        # The SpGEMM (K1-K3) runs as two instances of one kernel: k_itemknn_fit<false,512,16> (rows with more than 255
+        # users: u16 counter pairs, no candidate list, two 512-thread workgroups per CU) and k_itemknn_fit<false,256,8>
+        # (lighter rows: byte counters, first-touch lists, 256-thread workgroups, three per CU).  Each is priced with its own share of the 4*P byte model
         # (4*P + 8*nnz + 4*(U+I+2) + 8*I*K); `roofline` is the one that takes longer.
         cnt = ctx.counters()
         p_rank = P_total / world
@@ -265,7 +265,7 @@ def main():
         rows0 = row_parts[0][1] - row_parts[0][0]
         other = 8.0 * nnz + 4.0 * (U + I + 2) + 8.0 * rows0 * args.K
         legs = {}
-        for name, slot, p_share in (("k_itemknn_fit<false,1024,false>", "gram_topk", p_heavy), ("k_itemknn_fit<false,256,true>", "gram_topk_wave", p_light)):
+        for name, slot, p_share in (("k_itemknn_fit<false,512,16>", "gram_topk", p_heavy), ("k_itemknn_fit<false,256,8>", "gram_topk_wave", p_light)):
             t = tm[slot]
             if t["launches"]:
                 avg = t["ms"] / t["launches"]

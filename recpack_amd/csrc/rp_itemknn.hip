@@ -82,14 +82,16 @@ __device__ __forceinline__ uint64_t rp_fit_key(uint32_t c, double colw, int pw =
   return (b - (992ull << 52)) << 6;
 }
 
-// accumulator tile: u32 counters (any row) or four byte counters per word (rows with <= 255 users: c_ij <= c_i)
-template <bool BYTES>
+// accumulator tile: CB-bit counters, 32 / CB of them per LDS word: u32 (any row), u16 pairs (rows and slices with at most
+// 65 535 users: c_ij <= c_i) or bytes (at most 255 users)
+template <int CB>
 struct rp_dense_src {
   const uint32_t* acc;
   const double* inv_deg;
   int t0, row, n_cols, key_pow;
   __device__ __forceinline__ uint32_t count(int w) const {
-    if (BYTES) return (acc[w >> 2] >> (8 * (w & 3))) & 255u;
+    if (CB == 8) return (acc[w >> 2] >> (8 * (w & 3))) & 255u;
+    if (CB == 16) return (acc[w >> 1] >> (16 * (w & 1))) & 65535u;
     return acc[w];
   }
   __device__ __forceinline__ bool valid(int w) const { return count(w) != 0u && (t0 + w) != row; }
@@ -100,19 +102,39 @@ struct rp_dense_src {
 constexpr int RP_LIGHT_THREADS = 256;   // light rows: 4-wave workgroups, several per CU
 constexpr int RP_LIGHT_SEG = 1024;      // candidate-list entries per wave (4096 per task); overflow -> heavy kernel
 constexpr int RP_LIGHT_MAX_DEG = 255;   // byte counters
+constexpr int RP_PAIR_THREADS = 512;    // heavy rows: u16 counter pairs, no candidate list, two workgroups per CU
+constexpr int RP_PAIR_MAX_USERS = 65535;
 
 // FINALIZE only gives the second launch (sum of partial tiles + select) its own name in profiles.
-// NTHR/BYTES: 1024 threads + u32 counters (one workgroup per CU) for heavy rows, 256 threads + byte counters
-// (three to four workgroups per CU) for rows with at most 255 users.
-template <bool FINALIZE, int NTHR, bool BYTES>
+// NTHR / CB (counter bits), three instances of the accumulate + select kernel:
+//   <.,1024,32>  u32 counters, one workgroup per CU: the finalize launch (sums of partial tiles can exceed 65 535) and
+//                the dense Gram of EASE
+//   <., 512,16>  heavy rows: u16 counter pairs and NO candidate list (their tiles are mostly non-zero: the selection
+//                walks the tile itself, rp_select_tile) - 63 KB of LDS, so two workgroups share a CU and one row's
+//                selection (VALU/LDS) overlaps another row's accumulation (memory)
+//   <., 256, 8>  rows with at most 255 users: byte counters, first-touch candidate lists, three workgroups per CU
+template <bool FINALIZE, int NTHR, int CB>
 __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = NTHR / 64;
+  constexpr bool BYTES = (CB == 8), PAIRS = (CB == 16);
   constexpr int SEG = BYTES ? RP_LIGHT_SEG : 0;
   uint32_t* acc = reinterpret_cast<uint32_t*>(smem);
   const int W = P.tile_w;
-  const int acc_words = BYTES ? (W + 3) / 4 : W;
-  rp_select_smem sel = rp_select_carve(smem + (((size_t)acc_words * 4 + 15) & ~(size_t)15), W, NW, SEG);
+  const int acc_words = (W * CB + 31) / 32;
+  char* sel_base = smem + (((size_t)acc_words * 4 + 15) & ~(size_t)15);
+  rp_tsel_smem tsel = rp_tsel_carve(sel_base, W);
+  rp_select_smem sel;
+  if constexpr (PAIRS) {  // no list: only the histogram (scratch of the accumulate phase) and misc are shared
+    sel.hist = tsel.hist;
+    sel.skey = tsel.skey;
+    sel.scol = tsel.scol;
+    sel.list = nullptr;
+    sel.misc = tsel.misc;
+    for (int w = threadIdx.x; w < (W + 31) / 32 + 4; w += NTHR) tsel.bitmap[w] = 0u;
+  } else {
+    sel = rp_select_carve(sel_base, W, NW, SEG);
+  }
   int* s_task = &sel.misc[RPS_USER];  // all LDS lives in the dynamic region (keeps its base 16-B aligned)
 #ifdef RP_STAMPS
   sel.stamps = P.stamps;
@@ -291,6 +313,13 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
                 lcnt += n_new;
               }
             }
+          } else if constexpr (PAIRS) {
+#pragma unroll
+            for (int e = 0; e < CH; ++e)
+              if (jv[e] >= 0) {
+                const int j = jv[e] - t0;
+                atomicAdd(&acc[j >> 1], 1u << (16 * (j & 1)));
+              }
           } else {
 #pragma unroll
             for (int e = 0; e < CH; ++e)
@@ -317,14 +346,20 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
       RP_STAMP(1);
       if (!BYTES && tk.mode == 1) {
         uint32_t* dst = P.part + (int64_t)tk.slot * W;
-        for (int w = tid; w < W; w += NTHR) {
-          dst[w] = acc[w];
-          acc[w] = 0u;
+        if constexpr (PAIRS) {
+          for (int w = tid; w < W; w += NTHR) dst[w] = (acc[w >> 1] >> (16 * (w & 1))) & 65535u;
+          __syncthreads();
+          for (int w = tid; w < acc_words; w += NTHR) acc[w] = 0u;
+        } else {
+          for (int w = tid; w < W; w += NTHR) {
+            dst[w] = acc[w];
+            acc[w] = 0u;
+          }
         }
         RP_STAMP(2);
         continue;
       }
-    } else if (!BYTES) {
+    } else if constexpr (CB == 32) {
       for (int w = tid; w < W; w += NTHR) {
         uint32_t sum = 0;
         for (int sl = tk.p_begin; sl < tk.p_end; ++sl) sum += P.part[(int64_t)sl * W + w];
@@ -333,7 +368,7 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
       __syncthreads();
     }
 
-    if (!BYTES && P.dense) {
+    if (CB == 32 && P.dense) {
       // ---- K4: dense Gram row (ease.py:81 `(X.T @ X).toarray()`), lambda fused on the diagonal
       float* g = P.dense + (long long)row * P.dense_ld + t0;
       for (int w = tid; w < n_cols; w += NTHR) {
@@ -343,12 +378,14 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
       continue;
     }
     // ---- select
-    rp_dense_src<BYTES> src{acc, P.inv_deg, t0, row, n_cols, P.key_pow};
+    rp_dense_src<CB> src{acc, P.inv_deg, t0, row, n_cols, P.key_pow};
     int kp;
     if constexpr (BYTES) {
       const int handed = *blk_cnt;  // (the barrier after the accumulate phase has passed)
-      kp = rp_select_topk<NTHR, rp_dense_src<BYTES>, true>(src, n_cols, P.K, sel, SEG, lcnt, handed > NBLK, min(handed, NBLK));
+      kp = rp_select_topk<NTHR, rp_dense_src<CB>, true>(src, n_cols, P.K, sel, SEG, lcnt, handed > NBLK, min(handed, NBLK));
       if (tid == 0) *blk_cnt = 0;  // every wave has read it before the barriers inside the selection
+    } else if constexpr (PAIRS) {
+      kp = rp_select_tile<NTHR>(src, n_cols, P.K, tsel);
     } else {
       kp = rp_select_topk<NTHR>(src, n_cols, P.K, sel, SEG);
     }
@@ -376,8 +413,10 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
         ov[pos] = (P.key_pow == 2) ? (double)src.count(w) / sqrt(ci * (double)P.deg[j])
                                    : ((double)src.count(w) * P.inv_deg[j]) / ci;
       };
-      if (BYTES)
+      if constexpr (BYTES)
         rp_select_emit_sorted<NTHR>(sel, emit);
+      else if constexpr (PAIRS)
+        rp_select_tile_emit<NTHR>(n_cols, tsel, emit);
       else
         rp_select_emit<NTHR>(n_cols, sel, emit, SEG);
       if (tid == 0) P.out_nnz[rl] = kp;
@@ -387,20 +426,26 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
         P.out_idx[o + pos] = t0 + w;
         P.out_cnt[o + pos] = src.count(w);
       };
-      if (BYTES)
+      if constexpr (BYTES)
         rp_select_emit_sorted<NTHR>(sel, emit);
+      else if constexpr (PAIRS)
+        rp_select_tile_emit<NTHR>(n_cols, tsel, emit);
       else
         rp_select_emit<NTHR>(n_cols, sel, emit, SEG);
       if (tid == 0) P.out_nnz[(int64_t)rl * T + tile] = kp;
     }
-    // clear only what was touched: the candidates (every wave its own list segment) and the diagonal.
-    // Byte tiles: the emit above still reads neighbouring bytes of a word, so clear after a barrier.
-    if (BYTES) __syncthreads();
-    if (BYTES)
-      rp_select_foreach_pre<NTHR>(sel, [&](int w) { acc[w >> 2] = 0u; });
-    else
-      rp_select_foreach<NTHR>(n_cols, sel, [&](int w) { acc[w] = 0u; }, SEG);
-    if (tid == 0 && (unsigned)(row - t0) < (unsigned)n_cols) acc[BYTES ? ((row - t0) >> 2) : (row - t0)] = 0u;
+    // clear only what was touched: the candidates (every wave its own list segment) and the diagonal; without a list
+    // the whole tile.  Byte tiles: the emit above still reads neighbouring bytes of a word, so clear after a barrier.
+    if (BYTES || PAIRS) __syncthreads();
+    if constexpr (PAIRS) {
+      for (int w = tid; w < acc_words; w += NTHR) acc[w] = 0u;
+    } else {
+      if (BYTES)
+        rp_select_foreach_pre<NTHR>(sel, [&](int w) { acc[w >> 2] = 0u; });
+      else
+        rp_select_foreach<NTHR>(n_cols, sel, [&](int w) { acc[w] = 0u; }, SEG);
+      if (tid == 0 && (unsigned)(row - t0) < (unsigned)n_cols) acc[BYTES ? ((row - t0) >> 2) : (row - t0)] = 0u;
+    }
     RP_STAMP(4);
   }
 }
@@ -702,7 +747,9 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   // ---- plan
   hipEvent_t ev;
   rp_time_begin(ctx, &ev);
-  const int slice_users = (int)std::min<int64_t>(1 << 20, std::max<int64_t>(1024, X->nnz / ((int64_t)ctx->n_cu * 8)));
+  // (neighbour lists: a row or slice handled by the u16-pair kernel may have at most 65 535 users -> slices <= 32 767)
+  const int slice_users = (int)std::min<int64_t>(dense ? (1 << 20) : RP_PAIR_MAX_USERS / 2,
+                                                  std::max<int64_t>(1024, X->nnz / ((int64_t)ctx->n_cu * 8)));
   const int heavy_thr = 2 * slice_users;
   // upper bounds: every row n_tiles tasks, plus slices
   const int64_t max_slices = (X->nnz / slice_users + X->nnz / heavy_thr + 2) * T;
@@ -818,14 +865,18 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   P.spill_count = off_acc + n_rows;
   P.n_products = nullptr;
   const size_t lds = rp_fit_lds_bytes(W);
-  RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_fit<false, RP_FIT_THREADS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_fit<true, RP_FIT_THREADS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_fit<false, RP_FIT_THREADS, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_fit<true, RP_FIT_THREADS, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = ctx->n_cu;
+  // heavy rows of the neighbour-list path: u16 pairs, no list
+  const size_t plds = ((((size_t)W * 2 + 3) & ~(size_t)3) + 15 & ~(size_t)15) + rp_tsel_smem_bytes(W);
+  RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_fit<false, RP_PAIR_THREADS, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+  const int pair_per_cu = std::max<int>(1, std::min<int>(4, (int)((160 * 1024) / plds)));
 
   if (use_light) {
     // ---- light rows first: their overflow tasks join the heavy kernel's list
     const size_t llds = (((size_t)W + 15) & ~(size_t)15) + rp_select_smem_bytes(W, RP_LIGHT_THREADS / 64, RP_LIGHT_SEG);
-    RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_fit<false, RP_LIGHT_THREADS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
+    RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_fit<false, RP_LIGHT_THREADS, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
     const int per_cu = std::max<int>(1, std::min<int>(8, (int)((160 * 1024) / llds)));
     RP_HIP(hipMemsetAsync(ctx->dev_counters, 0, 64, st));
     RP_HIP(hipMemcpyAsync(ctx->dev_counters + 1, off_light + n_rows, 4, hipMemcpyDeviceToDevice, st));
@@ -835,7 +886,7 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
     L.ticket = tickets + 2;
     L.n_products = ctx->dev_counters;
     rp_time_begin(ctx, &ev);
-    hipLaunchKernelGGL((k_itemknn_fit<false, RP_LIGHT_THREADS, true>), dim3(ctx->n_cu * per_cu), dim3(RP_LIGHT_THREADS), llds, st, L);
+    hipLaunchKernelGGL((k_itemknn_fit<false, RP_LIGHT_THREADS, 8>), dim3(ctx->n_cu * per_cu), dim3(RP_LIGHT_THREADS), llds, st, L);
     RP_HIP(hipGetLastError());
     rp_time_end(ctx, ev, RPHIP_T_GRAM_TOPK_WAVE, 0.0);
 #ifdef RP_STAMPS
@@ -854,7 +905,10 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   P.tasks = acc_tasks;
   P.n_tasks = off_acc + n_rows;
   P.ticket = tickets;
-  hipLaunchKernelGGL((k_itemknn_fit<false, RP_FIT_THREADS, false>), dim3(grid), dim3(RP_FIT_THREADS), lds, st, P);
+  if (dense)
+    hipLaunchKernelGGL((k_itemknn_fit<false, RP_FIT_THREADS, 32>), dim3(grid), dim3(RP_FIT_THREADS), lds, st, P);
+  else
+    hipLaunchKernelGGL((k_itemknn_fit<false, RP_PAIR_THREADS, 16>), dim3(grid * pair_per_cu), dim3(RP_PAIR_THREADS), plds, st, P);
   RP_HIP(hipGetLastError());
   // algorithmic bytes of the SpGEMM: 4*P_shard + 8*nnz + 4*(U+I+2) + 8*rows*K; the
   // caller scales P by the shard's share, here the full-matrix figure is attributed when rows cover all.
@@ -866,7 +920,7 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   P.tasks = fin_tasks;
   P.n_tasks = off_fin + n_rows;
   P.ticket = tickets + 1;
-  hipLaunchKernelGGL((k_itemknn_fit<true, RP_FIT_THREADS, false>), dim3(grid), dim3(RP_FIT_THREADS), lds, st, P);
+  hipLaunchKernelGGL((k_itemknn_fit<true, RP_FIT_THREADS, 32>), dim3(grid), dim3(RP_FIT_THREADS), lds, st, P);
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, dense ? RPHIP_T_GRAM_DENSE : RPHIP_T_GRAM_FINALIZE, 0.0);
 #ifdef RP_STAMPS

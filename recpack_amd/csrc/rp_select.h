@@ -515,3 +515,278 @@ __device__ __forceinline__ void rp_select_foreach(int n_slots, rp_select_smem s,
   const int cnt = s.misc[RPS_LCNT + wave];
   for (int e = lane; e < cnt; e += 64) f((int)(mylist[e] & (RPS_FLAG - 1)));
 }
+
+// ---- selection straight from a dense tile (no candidate list) ---------------------------------------------------------
+// For rows whose tile is mostly non-zero (heavy item rows) a candidate list is as large as the tile itself and only
+// costs LDS.  Here every pass walks the slots (thread t takes slots t, t + NTHR, ..: the key's global operand, e.g.
+// 1/c_j, is then read coalesced), selected slots are recorded in a bitmap and emitted in slot (= column) order.
+// Same exact rule as rp_select_topk: larger key first, then smaller column.
+struct rp_tsel_smem {
+  uint32_t* hist;    // RP_HIST_BINS u32, overlays skey / scol / spos of the boundary bin
+  uint64_t* skey;
+  uint32_t* scol;
+  uint32_t* bitmap;  // (n_slots + 31) / 32 words
+  int* misc;         // RPS_MISC_INTS
+};
+
+__host__ __device__ constexpr size_t rp_tsel_smem_bytes(int n_slots) {
+  return (size_t)RP_HIST_BINS * 4 + (size_t)((n_slots + 31) / 32 + 4) * 4 + RPS_MISC_INTS * 4;
+}
+
+__device__ __forceinline__ rp_tsel_smem rp_tsel_carve(char* base, int n_slots) {
+  rp_tsel_smem s;
+  s.hist = reinterpret_cast<uint32_t*>(base);
+  s.skey = reinterpret_cast<uint64_t*>(base);
+  s.scol = reinterpret_cast<uint32_t*>(base + (size_t)RP_SORT_CAP * 8);
+  s.bitmap = reinterpret_cast<uint32_t*>(base + (size_t)RP_HIST_BINS * 4);
+  s.misc = reinterpret_cast<int*>(base + (size_t)RP_HIST_BINS * 4 + (size_t)((n_slots + 31) / 32 + 4) * 4);
+  return s;
+}
+
+// Returns K' and leaves the selected slots in s.bitmap (bit w of word w/32).  The bitmap must be all zero on entry;
+// rp_select_tile_emit clears it again.
+template <int NTHR, class Src>
+__device__ int rp_select_tile(const Src& src, int n_slots, int K, rp_tsel_smem s) {
+  static_assert(RP_HIST_BINS % NTHR == 0, "bins must divide over the threads");
+  constexpr int BPT = RP_HIST_BINS / NTHR;
+  constexpr int NW = NTHR / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint16_t* spos = reinterpret_cast<uint16_t*>(s.scol + RP_SORT_CAP);
+
+  bool have_fin = false, fin_is_col = false, fin_all = false;
+  int fin_shift = 0, fin_group = 0, fin_need = 0;
+  uint64_t fin_pkey = 0;
+  uint32_t fin_pcol = 0;
+  int n_valid = 0, kprime = 0;
+  {
+    uint64_t pkey = 0;
+    uint32_t pcol = 0;
+    int need = 0;
+    for (int level = 0; level < 9; ++level) {
+      int shift, width;
+      bool is_col;
+      rp_level(level, &shift, &width, &is_col);
+      const int nb = 1 << width;
+      for (int i = tid; i < RP_HIST_BINS; i += NTHR) s.hist[i] = 0;
+      if (tid == 0) {
+        s.misc[RPS_BIN] = -1;
+        s.misc[RPS_CNT] = 0;
+      }
+      __syncthreads();
+      int mine = 0;
+      for (int w = tid; w < n_slots; w += NTHR) {
+        if (!src.valid(w)) continue;
+        const uint64_t k = src.key(w);
+        const uint32_t ic = ~src.col(w);
+        bool in_group;
+        uint32_t d;
+        if (!is_col) {
+          in_group = (level == 0) || ((k >> (shift + width)) == (pkey >> (shift + width)));
+          d = (uint32_t)(k >> shift) & (nb - 1);
+        } else {
+          in_group = (k == pkey) && ((level == 6) || ((ic >> (shift + width)) == (pcol >> (shift + width))));
+          d = (ic >> shift) & (nb - 1);
+        }
+        if (in_group) {
+          atomicAdd(&s.hist[d], 1u);
+          ++mine;
+        }
+      }
+      if (level == 0) {  // the first pass also counts the candidates
+        mine = rp_wave_sum(mine);
+        if (lane == 0) s.misc[RPS_RED + wave] = mine;
+      }
+      __syncthreads();
+      if (level == 0) {
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) n_valid += s.misc[RPS_RED + w2];
+        kprime = min(K, n_valid);
+        need = kprime;
+        __syncthreads();
+        if (kprime == n_valid) break;  // fewer candidates than K: all of them
+      }
+      {
+        const int d_hi = RP_HIST_BINS - 1 - BPT * tid;
+        int h[BPT];
+        int sum = 0;
+#pragma unroll
+        for (int e = 0; e < BPT; ++e) {
+          const int d = d_hi - e;
+          h[e] = (d < nb) ? (int)s.hist[d] : 0;
+          sum += h[e];
+        }
+        int inc = sum;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+          const int t = __shfl_up(inc, dd);
+          if (lane >= dd) inc += t;
+        }
+        if (lane == 63) s.misc[RPS_RED + wave] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int w2 = 0; w2 < wave; ++w2) woff += s.misc[RPS_RED + w2];
+        int above = woff + inc - sum;
+#pragma unroll
+        for (int e = 0; e < BPT; ++e) {
+          if (above < need && need <= above + h[e]) {
+            s.misc[RPS_BIN] = d_hi - e;
+            s.misc[RPS_ABOVE] = above;
+            s.misc[RPS_GROUP] = h[e];
+          }
+          above += h[e];
+        }
+        __syncthreads();
+      }
+      const int bin = s.misc[RPS_BIN];
+      const int above = s.misc[RPS_ABOVE];
+      const int group = s.misc[RPS_GROUP];
+      need -= above;
+      if (!is_col)
+        pkey |= (uint64_t)bin << shift;
+      else
+        pcol |= (uint32_t)bin << shift;
+      if (group == need || group <= RP_SORT_CAP) {
+        fin_shift = shift;
+        fin_is_col = is_col;
+        fin_all = (group == need);
+        fin_group = group;
+        fin_need = need;
+        fin_pkey = pkey;
+        fin_pcol = pcol;
+        have_fin = true;
+        __syncthreads();  // hist is dead from here
+        break;
+      }
+      __syncthreads();
+    }
+  }
+  // classification pass
+  for (int w = tid; w < n_slots; w += NTHR) {
+    if (!src.valid(w)) continue;
+    bool sel = true;
+    if (have_fin) {
+      const uint64_t k = src.key(w);
+      const uint32_t ic = ~src.col(w);
+      bool above, member;
+      if (!fin_is_col) {
+        above = (k >> fin_shift) > (fin_pkey >> fin_shift);
+        member = (k >> fin_shift) == (fin_pkey >> fin_shift);
+      } else {
+        above = (k > fin_pkey) || (k == fin_pkey && (ic >> fin_shift) > (fin_pcol >> fin_shift));
+        member = (k == fin_pkey) && ((ic >> fin_shift) == (fin_pcol >> fin_shift));
+      }
+      sel = above || (member && fin_all);
+      if (member && !fin_all) {
+        const int p = atomicAdd(&s.misc[RPS_CNT], 1);
+        s.skey[p] = k;
+        s.scol[p] = ic;
+        spos[p] = (uint16_t)w;
+      }
+    }
+    if (sel) atomicOr(&s.bitmap[w >> 5], 1u << (w & 31));
+  }
+  __syncthreads();
+  if (have_fin && !fin_all) {
+    const int group = fin_group, need = fin_need;
+    if (group <= 64) {
+      if (wave == 0) {
+        uint64_t mk = 0;
+        uint32_t mic = 0;
+        if (lane < group) {
+          mk = s.skey[lane];
+          mic = s.scol[lane];
+        }
+        int rank = 0;
+        for (int m2 = 0; m2 < group; ++m2) {
+          const uint32_t olo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mk, m2);
+          const uint32_t ohi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mk >> 32), m2);
+          const uint32_t oic = (uint32_t)__builtin_amdgcn_readlane((int)mic, m2);
+          const uint64_t ok2 = ((uint64_t)ohi << 32) | olo;
+          rank += ((ok2 > mk) || (ok2 == mk && oic > mic)) ? 1 : 0;
+        }
+        if (lane < group && rank < need) {
+          const int w = spos[lane];
+          atomicOr(&s.bitmap[w >> 5], 1u << (w & 31));
+        }
+      }
+    } else {
+      int n2 = 1;
+      while (n2 < group) n2 <<= 1;
+      for (int i = group + tid; i < n2; i += NTHR) {
+        s.skey[i] = 0;
+        s.scol[i] = 0;
+        spos[i] = 0;
+      }
+      __syncthreads();
+      for (int k2 = 2; k2 <= n2; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+          for (int i = tid; i < n2; i += NTHR) {
+            const int ixj = i ^ j;
+            if (ixj > i) {
+              const uint64_t ka = s.skey[i], kb = s.skey[ixj];
+              const uint32_t ca = s.scol[i], cb = s.scol[ixj];
+              const bool a_lt_b = (ka < kb) || (ka == kb && ca < cb);
+              const bool desc = ((i & k2) == 0);
+              if (desc ? a_lt_b : !a_lt_b) {
+                const uint16_t pa = spos[i], pb = spos[ixj];
+                s.skey[i] = kb;
+                s.skey[ixj] = ka;
+                s.scol[i] = cb;
+                s.scol[ixj] = ca;
+                spos[i] = pb;
+                spos[ixj] = pa;
+              }
+            }
+          }
+          __syncthreads();
+        }
+      }
+      for (int i = tid; i < need; i += NTHR) {
+        const int w = spos[i];
+        atomicOr(&s.bitmap[w >> 5], 1u << (w & 31));
+      }
+    }
+    __syncthreads();
+  }
+  return kprime;
+}
+
+// emit(pos, slot) for every selected slot in slot order; clears the bitmap
+template <int NTHR, class Emit>
+__device__ __forceinline__ void rp_select_tile_emit(int n_slots, rp_tsel_smem s, Emit emit) {
+  constexpr int NW = NTHR / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_words = (n_slots + 31) >> 5;
+  const int per_wave = ((n_words + NW * 64 - 1) / (NW * 64)) * 64;  // words per wave, a multiple of 64
+  const int wb = wave * per_wave, we = min(n_words, wb + per_wave);
+  int cnt = 0;
+  for (int w0 = wb; w0 < we; w0 += 64) {
+    const int wi = w0 + lane;
+    cnt += (wi < we) ? __popc(s.bitmap[wi]) : 0;
+  }
+  cnt = rp_wave_sum(cnt);
+  if (lane == 0) s.misc[RPS_RED + wave] = cnt;
+  __syncthreads();
+  int off = 0;
+  for (int w2 = 0; w2 < wave; ++w2) off += s.misc[RPS_RED + w2];
+  for (int w0 = wb; w0 < we; w0 += 64) {
+    const int wi = w0 + lane;
+    uint32_t bits = (wi < we) ? s.bitmap[wi] : 0u;
+    const int c = __popc(bits);
+    int inc = c;  // inclusive prefix over the lanes
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+      const int t = __shfl_up(inc, dd);
+      if (lane >= dd) inc += t;
+    }
+    int pos = off + inc - c;
+    while (bits) {
+      const int b = __ffs((int)bits) - 1;
+      bits &= bits - 1u;
+      emit(pos++, wi * 32 + b);
+    }
+    off += __shfl(inc, 63);
+    if (wi < we) s.bitmap[wi] = 0u;
+  }
+  __syncthreads();
+}
