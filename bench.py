@@ -9,8 +9,9 @@ K0 (X -> X^T, degrees) + K1-K3 (Gram + cosine + top-K, K=200) [+ all-gather of t
 interactions - the shape BASELINE.json's metric is quoted on; it fits one MI355X.  With N > 1 the same
 matrix is sharded (item rows for fit, users for predict): strong scaling.
 
-Prints one JSON line (rank 0).  `roofline` prices the dominant kernel (k_itemknn_fit<false>, the SpGEMM)
-with the 4*P byte model of SURVEY.md §8(d) against 8 TB/s; `cpu_baseline` times the numpy/scipy oracle
+Prints one JSON line (rank 0).  `roofline` prices the kernel with the longest launch of the step with its algorithmic
+byte model (4*P-model for the SpGEMM instances, 8*K*nnz-model for predict) against 8 TB/s - `legs`
+holds all three kernels, `spgemm_all_kernels` the whole K1-K3 group; `cpu_baseline` times the numpy/scipy oracle
 (a port of the reference's scipy path, 1 thread) on a bounded sample and scales it to the full workload.
 """
 import argparse
@@ -254,8 +255,8 @@ def main():
 
     if rank == 0:
         sec_per_step = elapsed / args.steps
-        # The SpGEMM (K1-K3) runs as two instances of one kernel: k_itemknn_fit<false,512,16> (rows with more than 255
-        # users: u16 counter pairs, no candidate list, two 512-thread workgroups per CU) and k_itemknn_fit<false,256,8>
+        # The SpGEMM (K1-K3) runs as two instances of one kernel: k_itemknn_fit<false,1024,16> (rows with more than 255
+        # users: u16 counter pairs, no candidate list, two 1024-thread workgroups per CU) and k_itemknn_fit<false,256,8>
         # (lighter rows: byte counters, first-touch lists, 256-thread workgroups, three per CU).  Each is priced with its own share of the 4*P byte model
         # (4*P + 8*nnz + 4*(U+I+2) + 8*I*K); `roofline` is the one that takes longer.
         cnt = ctx.counters()
@@ -265,23 +266,24 @@ def main():
         rows0 = row_parts[0][1] - row_parts[0][0]
         other = 8.0 * nnz + 4.0 * (U + I + 2) + 8.0 * rows0 * args.K
         legs = {}
-        for name, slot, p_share in (("k_itemknn_fit<false,512,16>", "gram_topk", p_heavy), ("k_itemknn_fit<false,256,8>", "gram_topk_wave", p_light)):
+        for name, slot, p_share in (("k_itemknn_fit<false,1024,16>", "gram_topk", p_heavy), ("k_itemknn_fit<false,256,8>", "gram_topk_wave", p_light)):
             t = tm[slot]
             if t["launches"]:
                 avg = t["ms"] / t["launches"]
                 by = 4.0 * p_share + other * (p_share / p_rank if p_rank else 0.0)
                 legs[name] = (avg, by)
-        # K8 (the longest phase of the step) priced with its own byte model: 8*K*nnz + 4*(nnz+U) + 8*U*Kp per rank share
+        # K8 priced with its own byte model: 8*K*nnz + 4*(nnz+U) + 8*U*Kp per rank share
         tp = tm["predict"]
-        predict_leg = None
         if tp["launches"]:
             u_rank = user_parts[0][1] - user_parts[0][0]
             share = u_rank / U
             p_bytes = 8.0 * args.K * nnz * share + 4.0 * (nnz * share + u_rank) + 8.0 * u_rank * Kp
-            p_ms = tp["ms"] / tp["launches"]
-            predict_leg = {"kernel": "k_predict_wave (K8: scores + fused top-Kp)", "avg_launch_ms": round(p_ms, 4), "algorithmic_bytes": p_bytes,
-                           "GBps": round(p_bytes / (p_ms * 1e-3) / 1e9, 1), "frac": round(p_bytes / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                           "note": "bound by LDS-atomic and instruction issue, not HBM: the model (240 MB) stays in L2/MALL"}
+            legs["k_predict_wave"] = (tp["ms"] / tp["launches"], p_bytes)
+        leg_what = {"k_itemknn_fit<false,1024,16>": "K1-K3 heavy rows: Gram + similarity key + top-K",
+                    "k_itemknn_fit<false,256,8>": "K1-K3 light rows: Gram + similarity key + top-K",
+                    "k_predict_wave": "K8: scores X.S + fused top-Kp (bound by LDS atomics and instruction issue in practice: "
+                                      "the 400 MB model stays in L2/MALL)"}
+        # `roofline` = the kernel with the longest launch; all of them are under `legs`
         dom = max(legs, key=lambda k: legs[k][0])
         avg_ms, algo_bytes = legs[dom]
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -315,7 +317,7 @@ def main():
                 "gram_products_per_s": round(p_rank / (spgemm_ms * 1e-3), 1) if spgemm_ms > 0 else None,
             },
             "roofline": {
-                "kernel": dom + " (K1-K3: Gram + cosine key + top-K)",
+                "kernel": dom + " (" + leg_what[dom] + ")",
                 "bound": "hbm",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
@@ -325,8 +327,9 @@ def main():
                 "traffic_note": traffic_note,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "avg_launch_ms": round(avg_ms, 4),
-                "legs": {k: {"avg_launch_ms": round(v[0], 4), "algorithmic_bytes": v[1],
-                             "GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None} for k, v in legs.items()},
+                "legs": {k: {"what": leg_what[k], "avg_launch_ms": round(v[0], 4), "algorithmic_bytes": v[1],
+                             "GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None,
+                             "frac": round(v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v[0] > 0 else None} for k, v in legs.items()},
                 # the three numbers of the SpGEMM - (i) the 4*P model above, (ii) bytes the PMC
                 # counters saw / time, (iii) accumulator updates per second against the LDS-atomic peak measured with
                 # tools/lds_atomic_bench.hip on MI355X (u32 adds, no return: 4.8 per clock per CU, 2.7e12/s chip-wide)
@@ -334,7 +337,6 @@ def main():
                 "accumulator_updates": {"per_s": round(p_rank / (spgemm_ms * 1e-3), 1) if spgemm_ms > 0 else None,
                                         "lds_atomic_peak_per_s": LDS_ATOMIC_PEAK,
                                         "frac": round(p_rank / (spgemm_ms * 1e-3) / LDS_ATOMIC_PEAK, 4) if spgemm_ms > 0 else None},
-                "predict": predict_leg,
                 "spgemm_all_kernels": {"ms": round(spgemm_ms, 4), "algorithmic_bytes": spgemm_bytes,
                                        "GBps": round(spgemm_bytes / (spgemm_ms * 1e-3) / 1e9, 1) if spgemm_ms > 0 else None,
                                        "frac": round(spgemm_bytes / (spgemm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if spgemm_ms > 0 else None},

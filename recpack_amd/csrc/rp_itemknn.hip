@@ -102,7 +102,7 @@ struct rp_dense_src {
 constexpr int RP_LIGHT_THREADS = 256;   // light rows: 4-wave workgroups, several per CU
 constexpr int RP_LIGHT_SEG = 1024;      // candidate-list entries per wave (4096 per task); overflow -> heavy kernel
 constexpr int RP_LIGHT_MAX_DEG = 255;   // byte counters
-constexpr int RP_PAIR_THREADS = 512;    // heavy rows: u16 counter pairs, no candidate list, two workgroups per CU
+constexpr int RP_PAIR_THREADS = 1024;   // heavy rows: u16 counter pairs, no candidate list, two workgroups per CU
 constexpr int RP_PAIR_MAX_USERS = 65535;
 
 // FINALIZE only gives the second launch (sum of partial tiles + select) its own name in profiles.
@@ -114,7 +114,7 @@ constexpr int RP_PAIR_MAX_USERS = 65535;
 //                selection (VALU/LDS) overlaps another row's accumulation (memory)
 //   <., 256, 8>  rows with at most 255 users: byte counters, first-touch candidate lists, three workgroups per CU
 template <bool FINALIZE, int NTHR, int CB>
-__global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
+__global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit_params P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = NTHR / 64;
   constexpr bool BYTES = (CB == 8), PAIRS = (CB == 16);
@@ -326,14 +326,24 @@ __global__ void __launch_bounds__(NTHR) k_itemknn_fit(rp_fit_params P) {
               if (jv[e] >= 0) atomicAdd(&acc[jv[e] - t0], 1u);
           }
         };
-        int ja[CH], jb[CH];
-        if (n_chunks > 0) fetch(0, ja);
-        for (int c0 = 0; c0 < n_chunks; c0 += 128) {
-          if (c0 + 64 < n_chunks) fetch(c0 + 64, jb);
-          apply(ja);
-          if (c0 + 64 < n_chunks) {
-            if (c0 + 128 < n_chunks) fetch(c0 + 128, ja);
-            apply(jb);
+        if constexpr (PAIRS) {
+          // 32 waves per CU (two 1024-thread workgroups at 64 VGPRs) hide the load latency by themselves: one chunk
+          // step at a time keeps the register count down
+          int ja[CH];
+          for (int c0 = 0; c0 < n_chunks; c0 += 64) {
+            fetch(c0, ja);
+            apply(ja);
+          }
+        } else {
+          int ja[CH], jb[CH];
+          if (n_chunks > 0) fetch(0, ja);
+          for (int c0 = 0; c0 < n_chunks; c0 += 128) {
+            if (c0 + 64 < n_chunks) fetch(c0 + 64, jb);
+            apply(ja);
+            if (c0 + 64 < n_chunks) {
+              if (c0 + 128 < n_chunks) fetch(c0 + 128, ja);
+              apply(jb);
+            }
           }
         }
       }
