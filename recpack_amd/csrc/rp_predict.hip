@@ -331,7 +331,7 @@ constexpr int PW_KP_MAX = 384;  // pool capacity = Kp rounded up + 128 <= 512
 // pool capacity (<= 512, the cut's limit): the more room above Kp, the fewer exact cuts per user
 __host__ __device__ constexpr int rp_pw_cap(int Kp) {
   const int base = ((Kp + 63) / 64) * 64;
-  return base + 128;
+  return base + 96;
 }
 __host__ __device__ constexpr size_t rp_pw_wave_bytes(int Kp) { return (size_t)PW_WT * 8 + 256 + (size_t)rp_pw_cap(Kp) * 12 + 1024 + 128; }
 
