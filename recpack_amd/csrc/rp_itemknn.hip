@@ -102,6 +102,7 @@ struct rp_dense_src {
 constexpr int RP_LIGHT_THREADS = 256;   // light rows: 4-wave workgroups, several per CU
 constexpr int RP_LIGHT_SEG = 1024;      // candidate-list entries per wave (4096 per task); overflow -> heavy kernel
 constexpr int RP_LIGHT_MAX_DEG = 255;   // byte counters
+constexpr int RP_LIGHT_BITS = 10;       // 1024-bin histogram: 25.6 + 4 + 8 KB per workgroup, four of them per CU
 constexpr int RP_PAIR_THREADS = 1024;   // heavy rows: u16 counter pairs, no candidate list, two workgroups per CU
 constexpr int RP_PAIR_MAX_USERS = 65535;
 
@@ -119,6 +120,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
   constexpr int NW = NTHR / 64;
   constexpr bool BYTES = (CB == 8), PAIRS = (CB == 16);
   constexpr int SEG = BYTES ? RP_LIGHT_SEG : 0;
+  constexpr int SBITS = BYTES ? RP_LIGHT_BITS : 11;  // radix digit of the selection (light rows: 10 -> 4 KB histogram)
   uint32_t* acc = reinterpret_cast<uint32_t*>(smem);
   const int W = P.tile_w;
   const int acc_words = (W * CB + 31) / 32;
@@ -133,7 +135,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
     sel.misc = tsel.misc;
     for (int w = threadIdx.x; w < (W + 31) / 32 + 4; w += NTHR) tsel.bitmap[w] = 0u;
   } else {
-    sel = rp_select_carve(sel_base, W, NW, SEG);
+    sel = rp_select_carve(sel_base, W, NW, SEG, 1 << SBITS);
   }
   int* s_task = &sel.misc[RPS_USER];  // all LDS lives in the dynamic region (keeps its base 16-B aligned)
 #ifdef RP_STAMPS
@@ -392,7 +394,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
     int kp;
     if constexpr (BYTES) {
       const int handed = *blk_cnt;  // (the barrier after the accumulate phase has passed)
-      kp = rp_select_topk<NTHR, rp_dense_src<CB>, true>(src, n_cols, P.K, sel, SEG, lcnt, handed > NBLK, min(handed, NBLK));
+      kp = rp_select_topk<NTHR, rp_dense_src<CB>, true, SBITS>(src, n_cols, P.K, sel, SEG, lcnt, handed > NBLK, min(handed, NBLK));
       if (tid == 0) *blk_cnt = 0;  // every wave has read it before the barriers inside the selection
     } else if constexpr (PAIRS) {
       kp = rp_select_tile<NTHR>(src, n_cols, P.K, tsel);
@@ -885,7 +887,7 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
 
   if (use_light) {
     // ---- light rows first: their overflow tasks join the heavy kernel's list
-    const size_t llds = (((size_t)W + 15) & ~(size_t)15) + rp_select_smem_bytes(W, RP_LIGHT_THREADS / 64, RP_LIGHT_SEG);
+    const size_t llds = (((size_t)W + 15) & ~(size_t)15) + rp_select_smem_bytes(W, RP_LIGHT_THREADS / 64, RP_LIGHT_SEG, 1 << RP_LIGHT_BITS);
     RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_fit<false, RP_LIGHT_THREADS, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
     const int per_cu = std::max<int>(1, std::min<int>(8, (int)((160 * 1024) / llds)));
     RP_HIP(hipMemsetAsync(ctx->dev_counters, 0, 64, st));

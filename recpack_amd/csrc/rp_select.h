@@ -68,47 +68,41 @@ __host__ __device__ constexpr int rp_list_cap(int n_slots, int nwaves) { return 
 
 // bytes of LDS the selection needs besides the tile itself (nwaves = threads / 64).  seg_cap = list entries per
 // wave; 0 = enough for every slot of the wave's share (no overflow possible).
-__host__ __device__ constexpr size_t rp_select_smem_bytes(int n_slots, int nwaves = 16, int seg_cap = 0) {
-  return (size_t)RP_HIST_BINS * 4 + (size_t)(seg_cap ? seg_cap * nwaves : rp_list_cap(n_slots, nwaves)) * 2 + RPS_MISC_INTS * 4;
+__host__ __device__ constexpr size_t rp_select_smem_bytes(int n_slots, int nwaves = 16, int seg_cap = 0, int bins = RP_HIST_BINS) {
+  return (size_t)bins * 4 + (size_t)(seg_cap ? seg_cap * nwaves : rp_list_cap(n_slots, nwaves)) * 2 + RPS_MISC_INTS * 4;
 }
 
-__device__ __forceinline__ rp_select_smem rp_select_carve(char* base, int n_slots, int nwaves = 16, int seg_cap = 0) {
-  static_assert(RP_SORT_CAP * 14 <= RP_HIST_BINS * 4, "sort buffers (key, ~col, list position) overlay the histogram");
+// `bins` = histogram bins of the radix levels (rp_select_topk's 1 << BITS); the boundary bin is ordered exactly once it
+// holds at most bins / 4 candidates, whose (key, ~col, list position) overlay the histogram
+__device__ __forceinline__ rp_select_smem rp_select_carve(char* base, int n_slots, int nwaves = 16, int seg_cap = 0,
+                                                          int bins = RP_HIST_BINS) {
   const size_t list_entries = seg_cap ? (size_t)seg_cap * nwaves : (size_t)rp_list_cap(n_slots, nwaves);
   rp_select_smem s;
   s.hist = reinterpret_cast<uint32_t*>(base);
   s.skey = reinterpret_cast<uint64_t*>(base);
-  s.scol = reinterpret_cast<uint32_t*>(base + (size_t)RP_SORT_CAP * 8);
-  s.list = reinterpret_cast<uint16_t*>(base + (size_t)RP_HIST_BINS * 4);
-  s.misc = reinterpret_cast<int*>(base + (size_t)RP_HIST_BINS * 4 + list_entries * 2);
+  s.scol = reinterpret_cast<uint32_t*>(base + (size_t)(bins / 4) * 8);
+  s.list = reinterpret_cast<uint16_t*>(base + (size_t)bins * 4);
+  s.misc = reinterpret_cast<int*>(base + (size_t)bins * 4 + list_entries * 2);
 #ifdef RP_STAMPS
   s.stamps = nullptr;
 #endif
   return s;
 }
 
-// level table: 6 levels over the key (11,11,11,11,11,9 bits from the top), 3 over ~col (11,11,10)
+// level table for BITS-bit digits: ceil(64 / BITS) levels over the key from the top, then ceil(32 / BITS) over ~col
+// (BITS = 11: 11,11,11,11,11,9 and 11,11,10)
+template <int BITS = 11>
 __device__ __forceinline__ void rp_level(int level, int* shift, int* width, bool* is_col) {
-  if (level < 5) {
-    *shift = 53 - 11 * level;
-    *width = 11;
+  constexpr int NK = (64 + BITS - 1) / BITS, NC = (32 + BITS - 1) / BITS;
+  if (level < NK) {
     *is_col = false;
-  } else if (level == 5) {
-    *shift = 0;
-    *width = 9;
-    *is_col = false;
-  } else if (level == 6) {
-    *shift = 21;
-    *width = 11;
-    *is_col = true;
-  } else if (level == 7) {
-    *shift = 10;
-    *width = 11;
-    *is_col = true;
+    *shift = (level < NK - 1) ? 64 - BITS * (level + 1) : 0;
+    *width = (level < NK - 1) ? BITS : 64 - BITS * (NK - 1);
   } else {
-    *shift = 0;
-    *width = 10;
+    const int l = level - NK;
     *is_col = true;
+    *shift = (l < NC - 1) ? 32 - BITS * (l + 1) : 0;
+    *width = (l < NC - 1) ? BITS : 32 - BITS * (NC - 1);
   }
 }
 
@@ -138,11 +132,14 @@ enum {
 // its wave appended (pre_cnt) and whether the pool overflowed (pre_over).  Afterwards the list holds the candidates
 // (RPS_LCNT + w entries to visit per wave), selected ones flagged with RPS_FLAG; use rp_select_emit /
 // rp_select_emit_sorted / rp_select_foreach with the same seg_cap.
-template <int NTHR, class Src, bool PRE = false>
+template <int NTHR, class Src, bool PRE = false, int BITS = 11>
 __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem s, int seg_cap = 0, int pre_cnt = 0,
                               bool pre_over = false, int pre_blocks = 0) {
-  static_assert(RP_HIST_BINS % NTHR == 0, "bins must divide over the threads");
-  constexpr int BPT = RP_HIST_BINS / NTHR;  // histogram bins owned by one thread
+  constexpr int BINS = 1 << BITS, SCAP = BINS / 4;  // histogram bins; largest boundary bin that is ordered exactly
+  constexpr int NK = (64 + BITS - 1) / BITS, NLEV = NK + (32 + BITS - 1) / BITS;
+  static_assert(BINS % NTHR == 0, "bins must divide over the threads");
+  static_assert(SCAP * 14 <= BINS * 4, "sort buffers (key, ~col, list position) overlay the histogram");
+  constexpr int BPT = BINS / NTHR;  // histogram bins owned by one thread
   constexpr int NW = NTHR / 64;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -210,12 +207,12 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
     uint64_t pkey = 0;  // decided prefix
     uint32_t pcol = 0;
     int need = kprime;
-    for (int level = 0; level < 9; ++level) {
+    for (int level = 0; level < NLEV; ++level) {
       int shift, width;
       bool is_col;
-      rp_level(level, &shift, &width, &is_col);
+      rp_level<BITS>(level, &shift, &width, &is_col);
       const int nb = 1 << width;
-      for (int i = tid; i < RP_HIST_BINS; i += NTHR) s.hist[i] = 0;
+      for (int i = tid; i < BINS; i += NTHR) s.hist[i] = 0;
       if (tid == 0) {
         s.misc[RPS_BIN] = -1;
         s.misc[RPS_CNT] = 0;
@@ -246,7 +243,7 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
             in_group = (level == 0) || ((k >> (shift + width)) == (pkey >> (shift + width)));
             d = (uint32_t)(k >> shift) & (nb - 1);
           } else {
-            in_group = (k == pkey) && ((level == 6) || ((ic >> (shift + width)) == (pcol >> (shift + width))));
+            in_group = (k == pkey) && ((level == NK) || ((ic >> (shift + width)) == (pcol >> (shift + width))));
             d = (ic >> shift) & (nb - 1);
           }
           if (in_group) atomicAdd(&s.hist[d], 1u);
@@ -255,7 +252,7 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
       __syncthreads();
       // find the bin where the count from the top reaches `need`: thread t owns BPT bins, descending
       {
-        const int d_hi = RP_HIST_BINS - 1 - BPT * tid;
+        const int d_hi = BINS - 1 - BPT * tid;
         int h[BPT];
         int sum = 0;
 #pragma unroll
@@ -294,7 +291,7 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
         pkey |= (uint64_t)bin << shift;
       else
         pcol |= (uint32_t)bin << shift;
-      if (group == need || group <= RP_SORT_CAP) {
+      if (group == need || group <= SCAP) {
         // decided: everything above the boundary bin is selected; the bin itself entirely (group == need) or after an
         // exact ordering of its members (fused pass below)
         fin_shift = shift;
@@ -316,7 +313,7 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
   // ---- 3. fused classification pass: one key evaluation per candidate.  Above the boundary bin -> flagged now;
   // members of the bin -> flagged (whole bin selected) or gathered with their list position for the exact step.
   int wc = 0;
-  uint16_t* spos = reinterpret_cast<uint16_t*>(s.scol + RP_SORT_CAP);  // [RP_SORT_CAP] list positions of the members
+  uint16_t* spos = reinterpret_cast<uint16_t*>(s.scol + SCAP);  // [SCAP] list positions of the members
   for (int e0 = 0; e0 < cnt; e0 += 256) {
     int sl[4];
     bool ok[4];
@@ -464,7 +461,7 @@ __device__ __forceinline__ void rp_select_emit(int n_slots, rp_select_smem s, Em
 
 // Emit the selected slots in column order when the list segments are NOT column-ordered (first-touch lists):
 // the flagged slots are gathered into a small LDS array (over the dead histogram), every thread ranks its entries
-// by counting the smaller slots, emit(rank, slot).  Needs K <= RP_HIST_BINS * 2 selected entries.
+// by counting the smaller slots, emit(rank, slot).  Needs K <= 2 * bins selected entries (u16 each, over the histogram).
 template <int NTHR, class Emit>
 __device__ __forceinline__ void rp_select_emit_sorted(rp_select_smem s, Emit emit) {
   constexpr int NW = NTHR / 64;
@@ -480,15 +477,15 @@ __device__ __forceinline__ void rp_select_emit_sorted(rp_select_smem s, Emit emi
     if (sel) buf[off + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(v & (RPS_FLAG - 1));
     off += __popcll(m);
   }
-  if (tid < 4) buf[n_sel + tid] = 0xffffu;  // pads the last group of four (written by nobody else)
   __syncthreads();
   const uint2* buf4 = reinterpret_cast<const uint2*>(s.hist);
   for (int e = tid; e < n_sel; e += NTHR) {
     const uint32_t slot = buf[e];
     int rank = 0;
-    for (int o = 0; o < n_sel; o += 4) {
+    for (int o = 0; o < n_sel; o += 4) {  // (the words past n_sel hold stale bytes: masked by the index)
       const uint2 q = buf4[o >> 2];
-      rank += ((q.x & 0xffffu) < slot ? 1 : 0) + ((q.x >> 16) < slot ? 1 : 0) + ((q.y & 0xffffu) < slot ? 1 : 0) + ((q.y >> 16) < slot ? 1 : 0);
+      rank += ((q.x & 0xffffu) < slot ? 1 : 0) + ((q.x >> 16) < slot && o + 1 < n_sel ? 1 : 0) +
+              ((q.y & 0xffffu) < slot && o + 2 < n_sel ? 1 : 0) + ((q.y >> 16) < slot && o + 3 < n_sel ? 1 : 0);
     }
     emit(rank, (int)slot);
   }
