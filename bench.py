@@ -225,7 +225,7 @@ def main():
     keep = {}
 
     def step():
-        dX = _lib.DeviceCSR.from_device(ctx, indptr_t, indices_t, (U, I))  # K0
+        dX = _lib.DeviceCSR.from_device(ctx, indptr_t, indices_t, (U, I), fit_rows=row_parts[rank] if world > 1 else None)  # K0
         if world == 1:
             model = _lib.itemknn_fit(ctx, dX, args.K)  # K1-K3
         else:

@@ -105,6 +105,11 @@ int rphip_csr_from_host(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_
  * the arrays are NOT copied and must outlive the object. */
 int rphip_csr_from_device(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_t nnz,
                           const int32_t* indptr_dev, const int32_t* indices_dev, rphip_csr** out);
+/* same for one shard of a multi-GPU fit: X^T (the costly scattered writes of K0) is filled for the item rows
+ * [fit_row_begin, fit_row_end) only, which is all rphip_itemknn_fit(row range inside it) reads; degrees, tile pointers
+ * and predict are complete.  fit_row_end < 0 = all rows. */
+int rphip_csr_from_device_rows(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_t nnz, const int32_t* indptr_dev,
+                               const int32_t* indices_dev, int64_t fit_row_begin, int64_t fit_row_end, rphip_csr** out);
 /* from raw (user id, item id) pairs, int64 as pandas holds them, in any order and with repeats: what
  * InteractionMatrix.values builds from its DataFrame (recpack/matrix/interaction_matrix.py:202-217:
  * csr_matrix((ones, (uid, iid)), shape), duplicates summed) before the path binarises it - here the DISTINCT pairs,

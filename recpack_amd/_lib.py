@@ -64,6 +64,7 @@ PROTOTYPES = {
     "rphip_device_info": (C.c_int, [_p, C.POINTER(C.c_int), C.POINTER(_i64), C.c_char_p, C.c_int]),
     "rphip_csr_from_host": (C.c_int, [_p, _i64, _i64, _i64, _p, C.c_int, _p, _pp]),
     "rphip_csr_from_device": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _pp]),
+    "rphip_csr_from_device_rows": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _i64, _i64, _pp]),
     "rphip_csr_from_coo_host": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _pp]),
     "rphip_csr_from_coo_device": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _pp]),
     "rphip_csr_download": (C.c_int, [_p, _p, _p, _p]),
@@ -206,12 +207,14 @@ class DeviceCSR:
         return cls(ctx, h)
 
     @classmethod
-    def from_device(cls, ctx: Context, indptr_t, indices_t, shape):
-        """indptr_t / indices_t: torch int32 CUDA tensors (kept alive by this object)."""
+    def from_device(cls, ctx: Context, indptr_t, indices_t, shape, fit_rows=None):
+        """indptr_t / indices_t: torch int32 CUDA tensors (kept alive by this object).  ``fit_rows=(begin, end)``: this
+        rank only fits those item rows (multi-GPU shard): X^T is filled for them alone."""
         _torch_inputs_ready(ctx)
         h = C.c_void_p()
-        check(ctx.lib.rphip_csr_from_device(ctx.handle, int(shape[0]), int(shape[1]), int(indices_t.numel()),
-                                            C.c_void_p(indptr_t.data_ptr()), C.c_void_p(indices_t.data_ptr()), C.byref(h)))
+        b, e = (0, -1) if fit_rows is None else (int(fit_rows[0]), int(fit_rows[1]))
+        check(ctx.lib.rphip_csr_from_device_rows(ctx.handle, int(shape[0]), int(shape[1]), int(indices_t.numel()),
+                                                 C.c_void_p(indptr_t.data_ptr()), C.c_void_p(indices_t.data_ptr()), b, e, C.byref(h)))
         return cls(ctx, h, keepalive=(indptr_t, indices_t))
 
     @classmethod

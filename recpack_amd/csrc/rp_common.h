@@ -84,6 +84,7 @@ struct rphip_csr {
   int32_t* tile_ptr = nullptr;
   bool sorted_rows = false;
   int max_user_deg = 0;            // longest history (bounds |score| for predict's fixed-point scale)
+  int64_t xt_row_begin = 0, xt_row_end = -1;  // item rows of X^T that were filled (-1: all); fit is limited to them
 };
 
 struct rphip_model {

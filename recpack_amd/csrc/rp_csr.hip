@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(1024) k_rank_hist_ranges(const int32_t* __rest
 __global__ void k_scatter(const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ x_idx, int n_users,
                           const int32_t* __restrict__ xt_ptr, const int32_t* __restrict__ rank, int32_t* __restrict__ xt_idx,
                           unsigned long long* __restrict__ p_sum, int n_items, int n_tiles, int tile_w, int32_t* __restrict__ tile_ptr,
-                          int32_t* __restrict__ err) {
+                          int32_t* __restrict__ err, int xt_lo, int xt_hi) {
   const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, sub = threadIdx.x & 7;
   const int ng = (gridDim.x * blockDim.x) >> 3;
   const float inv_w = 1.0f / (float)tile_w;
@@ -76,7 +76,7 @@ __global__ void k_scatter(const int32_t* __restrict__ x_ptr, const int32_t* __re
     for (int k = s + sub; k < e; k += 8) {
       const int j = x_idx[k];
       const int prev = (k > s) ? x_idx[k - 1] : -1;
-      if ((unsigned)j < (unsigned)n_items) xt_idx[xt_ptr[j] + rank[k]] = u;
+      if (j >= xt_lo && j < xt_hi) xt_idx[xt_ptr[j] + rank[k]] = u;  // (a shard only fills the item rows it will fit)
       if (j <= prev) {
         err[1] = 1;
         if (tp) err[0] = 3;
@@ -162,7 +162,8 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
   if (U > 0) {  // (rows without entries still need their tile pointers)
     const int grid_s = (int)std::min<int64_t>((int64_t)ctx->n_cu * 16, std::max<int64_t>(1, rp_cdiv(U * 8, bt)));
     hipLaunchKernelGGL(k_scatter, dim3(grid_s), dim3(bt), 0, st, m->x_ptr, m->x_idx, (int)U, m->xt_ptr, rank, m->xt_idx, p_sum,
-                       (int)I, m->n_tiles, m->tile_w, m->tile_ptr, err);
+                       (int)I, m->n_tiles, m->tile_w, m->tile_ptr, err, (int)std::max<int64_t>(0, m->xt_row_begin),
+                       (int)(m->xt_row_end < 0 ? I : std::min<int64_t>(I, m->xt_row_end)));
   }
   hipLaunchKernelGGL(k_inv_deg, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, rp_cdiv(I, bt)))), dim3(bt), 0, st,
                      m->deg, m->inv_deg, (int)I);
@@ -248,11 +249,20 @@ extern "C" int rphip_csr_from_host(rphip_ctx* ctx, int64_t n_users, int64_t n_it
 
 extern "C" int rphip_csr_from_device(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_t nnz, const int32_t* indptr_dev,
                                      const int32_t* indices_dev, rphip_csr** out) {
+  return rphip_csr_from_device_rows(ctx, n_users, n_items, nnz, indptr_dev, indices_dev, 0, -1, out);
+}
+
+extern "C" int rphip_csr_from_device_rows(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_t nnz, const int32_t* indptr_dev,
+                                          const int32_t* indices_dev, int64_t fit_row_begin, int64_t fit_row_end, rphip_csr** out) {
   if (!ctx || !out || !indptr_dev || (nnz > 0 && !indices_dev)) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   RP_TRY(rp_csr_check_shape(n_users, n_items, nnz));
+  if (fit_row_end >= 0 && (fit_row_begin < 0 || fit_row_begin > fit_row_end || fit_row_end > n_items))
+    RP_FAIL(RPHIP_EINVAL, "fit row range [%lld,%lld) outside 0..%lld", (long long)fit_row_begin, (long long)fit_row_end, (long long)n_items);
   RP_TRY(rp_set_device(ctx));
   rphip_csr* m = new rphip_csr();
+  m->xt_row_begin = fit_row_end < 0 ? 0 : fit_row_begin;
+  m->xt_row_end = fit_row_end;
   m->ctx = ctx;
   m->n_users = n_users;
   m->n_items = n_items;

@@ -514,6 +514,7 @@ extern "C" int rphip_ease_fit(rphip_ctx* ctx, const rphip_csr* X, double l2, dou
   if (!ctx || !X || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   if (!(l2 > 0.0)) RP_FAIL(RPHIP_EINVAL, "l2 must be > 0 (got %g): G + l2*I has to be positive definite", l2);
+  if (X->xt_row_end >= 0) RP_FAIL(RPHIP_ESTATE, "EASE needs a matrix with all item rows of X^T (not rphip_csr_from_device_rows)");
   RP_TRY(rp_set_device(ctx));
   const int n = (int)X->n_items;
   if (n <= 0) RP_FAIL(RPHIP_EINVAL, "no items");

@@ -530,3 +530,35 @@ def test_csr_from_coo(hip):
         _lib.DeviceCSR.from_coo(ctx, np.array([0, 5]), np.array([1, 1]), (5, 3))
     with pytest.raises(_lib.RecpackHipError):
         _lib.DeviceCSR.from_coo(ctx, np.array([0, 1]), np.array([1, -1]), (5, 3))
+
+
+def test_csr_for_a_row_shard(hip):
+    """rphip_csr_from_device_rows: X^T filled for a rank's item rows only gives the same neighbour lists for those rows;
+    other rows, EASE and normalize_X are refused."""
+    import torch
+
+    from recpack_amd.synth import powerlaw_csr
+
+    _lib, ctx = hip
+    dev = torch.device("cuda", 0)
+    ip, ix = powerlaw_csr(9000, 30000, 0.002, seed=91, device=dev)  # two column tiles
+    full = _lib.DeviceCSR.from_device(ctx, ip, ix, (9000, 30000))
+    ref = _lib.itemknn_fit(ctx, full, 60).topk_download()
+    for b, e in ((0, 4000), (4000, 30000), (12345, 12346)):
+        part = _lib.DeviceCSR.from_device(ctx, ip, ix, (9000, 30000), fit_rows=(b, e))
+        np.testing.assert_array_equal(part.item_degrees(), full.item_degrees())
+        got = _lib.itemknn_fit(ctx, part, 60, row_begin=b, row_end=e).topk_download()
+        for x, y in zip(got, ref):
+            np.testing.assert_array_equal(x, y[b:e])
+        with pytest.raises(_lib.RecpackHipError):
+            _lib.itemknn_fit(ctx, part, 60)
+        with pytest.raises(_lib.RecpackHipError):
+            _lib.ease_fit(ctx, part, 10.0)
+        with pytest.raises(_lib.RecpackHipError):
+            _lib.itemknn_fit(ctx, part, 60, row_begin=b, row_end=e, normalize_X=True)
+    # predict is unaffected by the shard
+    m = _lib.itemknn_fit(ctx, full, 60)
+    a = _lib.predict_topk(ctx, m, part, 20, user_begin=0, user_end=500)
+    c = _lib.predict_topk(ctx, m, full, 20, user_begin=0, user_end=500)
+    for x, y in zip(a, c):
+        np.testing.assert_array_equal(x, y)
