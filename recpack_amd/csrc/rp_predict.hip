@@ -377,13 +377,21 @@ struct rp_pw_state {
 __device__ __forceinline__ void rp_pw_add_chunk(rp_pw_state& S, int n, const v4i_a4& a, const v4i_a4& b, int t0) {
   const int ec[4] = {a.x, a.z, b.x, b.z};
   const int ev[4] = {a.y, a.w, b.y, b.w};
+  // Straight-line code, no per-entry branch: an entry past the chunk's end adds 0 to a dummy word of the lane's own
+  // (the idle upper half of the pool histogram) and ORs 0 into the lane's dirty word.  With a branch per entry the
+  // compiler computed each entry's operands into the registers of the previous one behind an s_waitcnt lgkmcnt(0),
+  // i.e. one full LDS round trip per entry; now the eight atomics of a step go out back to back.
+  RP_LDS unsigned long long* dummy = reinterpret_cast<RP_LDS unsigned long long*>(S.pool.hist + 128) + S.lane;
 #pragma unroll
   for (int e = 0; e < PW_CH; ++e) {
-    if (e < n) {
-      const int j = ec[e] - t0;
-      atomicAdd((unsigned long long*)&S.acc[j], rp_f32_to_fix(ev[e], S.fix));
-      atomicOr((uint32_t*)&S.dirty[j & 63], 1u << (j >> 6));
-    }
+    const bool on = e < n;
+    const int j = ec[e] - t0;
+    RP_LDS unsigned long long* tgt = on ? &S.acc[j] : dummy;
+    const unsigned long long v = on ? rp_f32_to_fix(ev[e], S.fix) : 0ull;
+    RP_LDS uint32_t* dw = &S.dirty[on ? (j & 63) : S.lane];
+    const uint32_t bit = on ? (1u << ((j >> 6) & 31)) : 0u;
+    atomicAdd((unsigned long long*)tgt, v);
+    atomicOr((uint32_t*)dw, bit);
   }
 }
 
