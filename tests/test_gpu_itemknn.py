@@ -562,3 +562,34 @@ def test_csr_for_a_row_shard(hip):
     c = _lib.predict_topk(ctx, m, full, 20, user_begin=0, user_end=500)
     for x, y in zip(a, c):
         np.testing.assert_array_equal(x, y)
+
+
+def test_limits_and_dense_corners(hip):
+    """The corners of the supported range: K and Kp at their maxima, a column every user has, a user with every item,
+    more neighbours requested than items exist."""
+    _lib, ctx = hip
+    rng = np.random.default_rng(8)
+    U, I = 600, 2300
+    X = sp.random(U, I, density=0.01, format="csr", random_state=7)
+    X.data[:] = 1
+    X = X.tolil()
+    X[:, 5] = 1      # an item every user has
+    X[17, :] = 1     # a user with every item
+    X = sp.csr_matrix(X)
+    X.sort_indices()
+    dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
+    for K in (2048, 5000):  # RP_K_MAX, and a request beyond the number of items (clipped to I - 1)
+        if min(K, I - 1) > 2048:
+            with pytest.raises(_lib.RecpackHipError):
+                _lib.itemknn_fit(ctx, dX, K)
+            continue
+        m = _lib.itemknn_fit(ctx, dX, K)
+        idx, val, nnz = m.topk_download()
+        assert_same_as_oracle(idx, val, nnz, onp.itemknn_fit(X, m.K))
+        S = onp.topk_to_csr(idx, val, nnz, I)
+        scores = onp.predict_full(X[:100], S)
+        for Kp in (384, 385, 2048):  # wave kernel's largest pool, first value of the workgroup kernel, RP_K_MAX
+            pi, pv, pn = _lib.predict_topk(ctx, m, dX, Kp, exclude_history=True, user_begin=0, user_end=100)
+            check_topk_scores(scores, pi, pv, pn, Kp, exclude=X[:100])
+        with pytest.raises(_lib.RecpackHipError):
+            _lib.predict_topk(ctx, m, dX, 2049)
