@@ -38,7 +38,9 @@ def parse():
     ap.add_argument("--K", type=int, default=200)
     ap.add_argument("--Kp", type=int, default=100)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="0 disables the CPU leg")
-    ap.add_argument("--ease-config", default="C3", help="config of the EASE leg (N=1 only); 'none' disables it")
+    ap.add_argument("--ease-config", default="C4,C3",
+                    help="configs of the EASE legs (N=1 only), comma separated: the first goes to `ease`, others to `ease_<cfg>`; "
+                         "'none' disables them")
     ap.add_argument("--l2", type=float, default=200.0)
     return ap.parse_args()
 
@@ -96,22 +98,23 @@ def cpu_baseline(indptr, indices, shape, K, Kp, S_csr, budget_s, P_total):
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 
 
-def ease_leg(args, ctx, device, Kp):
-    """EASE fit + predict on its own config (BASELINE.json configs[2]: 200K x 50K, lambda = 200); the solve is
-    priced with the n^3 flop model of SURVEY.md §8(d) against the dense fp32 MFMA peak."""
+def ease_leg(args, ctx, device, Kp, config, repeats):
+    """EASE fit + predict on one config (C4 = the metric's 1M x 100K matrix, 40 GB of B; C3 = BASELINE.json configs[2],
+    200K x 50K; lambda = 200); the solve is priced with the n^3 flop model of SURVEY.md §8(d) against the dense fp32
+    MFMA peak."""
     import torch
 
     from recpack_amd import _lib
     from recpack_amd.synth import CONFIG_SEED_BASE, CONFIGS, powerlaw_csr
 
-    U, I, dens = CONFIGS[args.ease_config]
-    ip, ix = powerlaw_csr(U, I, dens, CONFIG_SEED_BASE + int(args.ease_config[1:]), device=device)
+    U, I, dens = CONFIGS[config]
+    ip, ix = powerlaw_csr(U, I, dens, CONFIG_SEED_BASE + int(config[1:]), device=device)
     dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
     out_idx = torch.empty((U, Kp), dtype=torch.int32, device=device)
     out_val = torch.empty((U, Kp), dtype=torch.float32, device=device)
     out_nnz = torch.empty((U,), dtype=torch.int32, device=device)
     best = None
-    for it in range(2):
+    for it in range(repeats):
         ctx.reset_timings()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -131,7 +134,7 @@ def ease_leg(args, ctx, device, Kp):
     solve_ms = tm["cholesky"]["ms"] + tm["inverse"]["ms"]
     tf = n_pad ** 3 / (solve_ms * 1e-3) / 1e12
     return {
-        "workload": f"{args.ease_config}: EASE l2={args.l2}, {U} users x {I} items, nnz {int(ix.numel())}, predict + top-{Kp} for all users",
+        "workload": f"{config}: EASE l2={args.l2}, {U} users x {I} items, nnz {int(ix.numel())}, predict + top-{Kp} for all users",
         "fit_s": round(t_fit, 4),
         "predict_s": round(t_pred, 4),
         "fit_plus_predict_s": round(t_fit + t_pred, 4),
@@ -351,7 +354,13 @@ def main():
                                                   args.cpu_baseline_seconds, P_total)
         if world == 1 and args.ease_config.lower() != "none":
             keep.clear()
-            result["ease"] = ease_leg(args, ctx, device, Kp)
+            del indptr_t, indices_t, out_idx, out_val, out_nnz
+            torch.cuda.empty_cache()
+            for n, cfg in enumerate(c.strip().upper() for c in args.ease_config.split(",")):
+                # (the 100K-item solve takes ~10 s: one timed run; smaller ones are repeated and the better run kept)
+                leg = ease_leg(args, ctx, device, Kp, cfg, 1 if CONFIGS[cfg][1] > 60000 else 2)
+                result["ease" if n == 0 else f"ease_{cfg.lower()}"] = leg
+                torch.cuda.empty_cache()
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
