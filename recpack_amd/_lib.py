@@ -99,6 +99,17 @@ _lock = threading.Lock()
 _lib = None
 
 
+def _build_in_tree():
+    """`make -C recpack_amd/csrc` when hipcc is there and the library has not been built yet (errors are left to the
+    loader's own message)."""
+    import shutil
+    import subprocess
+
+    src = os.path.dirname(LIB_PATH)
+    if shutil.which("make") and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        subprocess.run(["make", "-C", src, "-j", "6"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+
+
 def load_library(path: str | None = None):
     """dlopen the library and attach prototypes. Raises RecpackHipError if it is not built."""
     global _lib
@@ -106,6 +117,8 @@ def load_library(path: str | None = None):
         if _lib is not None and path is None:
             return _lib
         p = path or LIB_PATH
+        if not os.path.exists(p) and path is None:
+            _build_in_tree()  # a fresh checkout: the library is a build product (never a different code path)
         if not os.path.exists(p):
             raise RecpackHipError(-100, f"{p} not found - build it first (make -C recpack_amd/csrc); there is no CPU fallback")
         try:
