@@ -118,6 +118,13 @@ int rp_set_device(const rphip_ctx* ctx);
 // device-wide exclusive scan of int32 (n < 2^31, total < 2^31): out[i] = sum_{k<i} in[k], out[n] = total
 int rp_exclusive_scan_i32(rphip_ctx* ctx, const int32_t* in, int32_t* out, int64_t n);
 
+// rp_itemknn.hip / rp_itemknn_w.hip
+constexpr int RP_PLAN_BUCKETS = 264;  // degree buckets of the row ordering: 0, then 8 per octave
+int rp_model_alloc_topk(rphip_ctx* ctx, int64_t n_items, int64_t r0, int64_t r1, int32_t K, rphip_model** out);
+int rp_plan_row_order(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int n_rows, int32_t* bucket, int32_t* order);
+int rp_gram_weighted(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K, int32_t similarity,
+                     const double* cp_colw_host, rphip_model** out);
+
 // rp_csr.hip
 int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m);
 

@@ -376,11 +376,21 @@ static int rp_spd_inverse(rphip_ctx* ctx, float* A, float* Nb, int n_pad, long l
   hipEvent_t ev;
   // ---- K5: left-looking blocked Cholesky.  The 128x128 diagonal block (its update and its float64 factorisation, one
   // workgroup for 0.26 ms) runs on a side stream while the rest of the panel is updated on the main stream.
-  hipStream_t s2 = nullptr;
-  hipEvent_t e_panel = nullptr, e_diag = nullptr;
-  RP_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
-  RP_HIP(hipEventCreateWithFlags(&e_panel, hipEventDisableTiming));
-  RP_HIP(hipEventCreateWithFlags(&e_diag, hipEventDisableTiming));
+  struct side_stream {  // released on every way out of this function
+    hipStream_t s = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    ~side_stream() {
+      if (s) hipStreamSynchronize(s);
+      if (a) hipEventDestroy(a);
+      if (b) hipEventDestroy(b);
+      if (s) hipStreamDestroy(s);
+    }
+  } side;
+  RP_HIP(hipStreamCreateWithFlags(&side.s, hipStreamNonBlocking));
+  RP_HIP(hipEventCreateWithFlags(&side.a, hipEventDisableTiming));
+  RP_HIP(hipEventCreateWithFlags(&side.b, hipEventDisableTiming));
+  hipStream_t s2 = side.s;
+  hipEvent_t e_panel = side.a, e_diag = side.b;
   float* part_diag = part_all + (size_t)8 * (n_pad - GT) * GT;  // the side stream's own split-K partials
   rp_time_begin(ctx, &ev);
   int rc = RPHIP_OK;
@@ -435,9 +445,6 @@ static int rp_spd_inverse(rphip_ctx* ctx, float* A, float* Nb, int n_pad, long l
     }
   }
   hipStreamSynchronize(s2);
-  hipEventDestroy(e_panel);
-  hipEventDestroy(e_diag);
-  hipStreamDestroy(s2);
   if (rc != RPHIP_OK) return rc;
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, RPHIP_T_CHOLESKY, n3 / 3.0);

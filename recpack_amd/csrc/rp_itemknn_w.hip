@@ -1,0 +1,298 @@
+// ItemKNN with normalize_X = True: the weighted (float64) Gram variant of K1-K3.
+#include <algorithm>
+
+#include "rp_common.h"
+#include "rp_select.h"
+
+constexpr int RP_MERGE_THREADS = 256;
+
+// ---- normalize_X: weighted Gram (nearest_neighbour.py:207-210) ------------------------------------------------------
+// With normalize_X the binarised rows are l1-normalised first, X[u, i] = w_u = 1/d_u, so the Gram entry of (i, j) is a
+// float64 sum over the common users: G_ij = sum w_u^2 (cosine, :69-84: S_ij = G_ij / sqrt(G_ii G_jj)) or sum w_u
+// (conditional probability, :22-66: to_binary(X).T @ X, S_ij = G_ij / (c_i c_j^alpha) with the binary frequencies c).
+// The tile holds doubles (LDS f64 atomic adds, half the columns of the integer tile), there is no byte-counter or
+// slicing path: this variant is about coverage, not the roofline.  The float sums depend on the order of the adds in the
+// last bits (as they do in scipy); parity is the tie-aware rule with eps = 1e-9 and values at 1e-11.
+constexpr int RP_WTILE_MAX = 12288;
+
+struct rp_wfit_params {
+  const int32_t* x_ptr;
+  const int32_t* x_idx;
+  const int32_t* xt_ptr;
+  const int32_t* xt_idx;
+  const int32_t* order;    // rows by descending degree
+  const double* user_q;    // [U] what one common user adds
+  const double* colw;      // [I] key = G_ij * colw_j (monotone in S_ij for a fixed row)
+  const double* roww;      // [I] S_ij = key * roww_i
+  int n_items, n_rows, n_tiles, tile_w, K, row_begin;
+  int32_t* ticket;
+  int32_t* out_idx;        // T == 1: model rows; T > 1: per-tile candidates
+  double* out_val;         //         values        ;        G_ij of the candidates
+  int32_t* out_nnz;
+};
+
+struct rp_wdense_src {
+  const double* acc;
+  const double* colw;
+  int t0, row;
+  __device__ __forceinline__ bool valid(int w) const { return acc[w] != 0.0 && (t0 + w) != row; }
+  __device__ __forceinline__ uint64_t key(int w) const { return (uint64_t)__double_as_longlong(acc[w] * colw[t0 + w]); }  // > 0
+  __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)(t0 + w); }
+};
+
+__global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_weighted(rp_wfit_params P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NTHR = RP_FIT_THREADS, NW = NTHR / 64;
+  double* acc = reinterpret_cast<double*>(smem);
+  const int W = P.tile_w, T = P.n_tiles;
+  rp_select_smem sel = rp_select_carve(smem + (size_t)W * 8, W, NW);
+  int* s_task = &sel.misc[RPS_USER];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave * 4 + (lane >> 4), gl = lane & 15;  // 64 groups of 16 lanes: one user per group and round
+  for (int w = tid; w < W; w += NTHR) acc[w] = 0.0;
+  const long long n_tasks = (long long)P.n_rows * T;
+  while (true) {
+    __syncthreads();
+    if (tid == 0) s_task[0] = atomicAdd(P.ticket, 1);
+    __syncthreads();
+    const long long task = s_task[0];
+    if (task >= n_tasks) break;
+    const int row = P.order[task / T], tile = (int)(task % T);
+    const int t0 = tile * W, n_cols = min(W, P.n_items - t0);
+    // ---- accumulate
+    const int pe = P.xt_ptr[row + 1];
+    for (int p = P.xt_ptr[row] + grp; p < pe; p += 64) {
+      const int u = P.xt_idx[p];
+      const double q = P.user_q[u];
+      int s = P.x_ptr[u], e = P.x_ptr[u + 1];
+      if (T > 1) {  // the slice of the (column-sorted) row that falls into this tile
+        int lo = s, hi = e;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (P.x_idx[mid] < t0) lo = mid + 1; else hi = mid;
+        }
+        s = lo;
+        hi = e;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (P.x_idx[mid] < t0 + n_cols) lo = mid + 1; else hi = mid;
+        }
+        e = lo;
+      }
+      for (int k = s + gl; k < e; k += 16) atomicAdd(&acc[P.x_idx[k] - t0], q);
+    }
+    __syncthreads();
+    // ---- select
+    rp_wdense_src src{acc, P.colw, t0, row};
+    const int kp = rp_select_topk<NTHR>(src, n_cols, P.K, sel);
+    const int rl = row - P.row_begin;
+    if (T == 1) {
+      const double ri = P.roww[row];
+      rp_select_emit<NTHR>(n_cols, sel, [&](int pos, int w) {
+        P.out_idx[(int64_t)rl * P.K + pos] = t0 + w;
+        P.out_val[(int64_t)rl * P.K + pos] = (acc[w] * P.colw[t0 + w]) * ri;
+      });
+      if (tid == 0) P.out_nnz[rl] = kp;
+    } else {
+      const int64_t o = ((int64_t)rl * T + tile) * P.K;
+      rp_select_emit<NTHR>(n_cols, sel, [&](int pos, int w) {
+        P.out_idx[o + pos] = t0 + w;
+        P.out_val[o + pos] = acc[w];
+      });
+      if (tid == 0) P.out_nnz[(int64_t)rl * T + tile] = kp;
+    }
+    rp_select_foreach<NTHR>(n_cols, sel, [&](int w) { acc[w] = 0.0; });
+    if (tid == 0 && (unsigned)(row - t0) < (unsigned)n_cols) acc[row - t0] = 0.0;
+  }
+}
+
+struct rp_wlist_src {
+  const int32_t* col_;
+  const double* g_;
+  const double* colw;
+  int n;
+  __device__ __forceinline__ bool valid(int w) const { return w < n; }
+  __device__ __forceinline__ uint64_t key(int w) const { return (uint64_t)__double_as_longlong(g_[w] * colw[col_[w]]); }
+  __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)col_[w]; }
+};
+
+// top-K of the T per-tile candidate lists of a row (weighted variant of k_itemknn_merge)
+__global__ void __launch_bounds__(RP_MERGE_THREADS) k_itemknn_merge_weighted(const int32_t* __restrict__ cand_idx, const double* __restrict__ cand_g,
+                                                                            const int32_t* __restrict__ cand_nnz, const double* __restrict__ colw,
+                                                                            const double* __restrict__ roww, int n_tiles, int K, int n_rows,
+                                                                            int row_begin, int32_t* __restrict__ out_idx,
+                                                                            double* __restrict__ out_val, int32_t* __restrict__ out_nnz) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = n_tiles, cap = T * K;
+  double* lg = reinterpret_cast<double*>(smem);
+  int32_t* lcol = reinterpret_cast<int32_t*>(smem + (size_t)cap * 8);
+  rp_select_smem sel = rp_select_carve(smem + (size_t)cap * 12 + ((cap & 1) ? 4 : 0), cap, RP_MERGE_THREADS / 64);
+  int* s_off = &sel.misc[RPS_USER];
+  const int tid = threadIdx.x;
+  for (int rl = blockIdx.x; rl < n_rows; rl += gridDim.x) {
+    __syncthreads();
+    if (tid == 0) {
+      int o = 0;
+      for (int t = 0; t < T; ++t) {
+        s_off[t] = o;
+        o += cand_nnz[(int64_t)rl * T + t];
+      }
+      s_off[T] = o;
+    }
+    __syncthreads();
+    const int n = s_off[T];
+    for (int t = 0; t < T; ++t) {
+      const int cn = s_off[t + 1] - s_off[t];
+      const int64_t so = ((int64_t)rl * T + t) * K;
+      for (int k = tid; k < cn; k += RP_MERGE_THREADS) {
+        lcol[s_off[t] + k] = cand_idx[so + k];
+        lg[s_off[t] + k] = cand_g[so + k];
+      }
+    }
+    __syncthreads();
+    rp_wlist_src src{lcol, lg, colw, n};
+    const int kp = rp_select_topk<RP_MERGE_THREADS>(src, n, K, sel);
+    const double ri = roww[row_begin + rl];
+    rp_select_emit<RP_MERGE_THREADS>(n, sel, [&](int pos, int w) {
+      const int j = lcol[w];
+      out_idx[(int64_t)rl * K + pos] = j;
+      out_val[(int64_t)rl * K + pos] = (lg[w] * colw[j]) * ri;
+    });
+    if (tid == 0) out_nnz[rl] = kp;
+  }
+}
+
+// q_u = w_u^2 (cosine) or w_u (conditional probability), w_u = fl(1 / d_u)
+__global__ void k_user_weights(const int32_t* __restrict__ x_ptr, int n_users, int squared, double* __restrict__ q) {
+  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n_users; u += gridDim.x * blockDim.x) {
+    const int d = x_ptr[u + 1] - x_ptr[u];
+    const double w = d > 0 ? 1.0 / (double)d : 0.0;
+    q[u] = squared ? w * w : w;
+  }
+}
+
+// cosine: G_ii = sum of q_u over the item's users (one wave per item, fixed order), colw_i = 1 / sqrt(G_ii)
+__global__ void k_weighted_norms(const int32_t* __restrict__ xt_ptr, const int32_t* __restrict__ xt_idx, const double* __restrict__ q,
+                                 int n_items, double* __restrict__ colw) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  for (int i = blockIdx.x * wpb + (threadIdx.x >> 6); i < n_items; i += gridDim.x * wpb) {
+    double s = 0.0;
+    for (int p = xt_ptr[i] + lane; p < xt_ptr[i + 1]; p += 64) s += q[xt_idx[p]];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) colw[i] = s > 0.0 ? 1.0 / sqrt(s) : 0.0;
+  }
+}
+
+int rp_gram_weighted(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K, int32_t similarity,
+                            const double* cp_colw_host, rphip_model** out) {
+  if (row_begin < 0 || row_end > X->n_items || row_begin > row_end)
+    RP_FAIL(RPHIP_EINVAL, "row range [%lld,%lld) outside 0..%lld", (long long)row_begin, (long long)row_end, (long long)X->n_items);
+  if (K < 1) RP_FAIL(RPHIP_EINVAL, "K must be >= 1 (got %d)", K);
+  if (X->xt_row_end >= 0) RP_FAIL(RPHIP_ESTATE, "normalize_X needs a matrix with all item rows of X^T (not rphip_csr_from_device_rows)");
+  const int32_t Keff = (int32_t)std::min<int64_t>(K, std::max<int64_t>(1, X->n_items - 1));
+  if (Keff > RP_K_MAX) RP_FAIL(RPHIP_ELIMIT, "effective K=%d exceeds the supported maximum %d", Keff, RP_K_MAX);
+  K = Keff;
+  const int n_rows = (int)(row_end - row_begin);
+  const int64_t I = X->n_items, U = X->n_users;
+  const int T = (int)std::max<int64_t>(1, rp_cdiv(I, RP_WTILE_MAX));
+  const int W = (int)(rp_cdiv(rp_cdiv(std::max<int64_t>(I, 1), T), 64) * 64);
+  if (T > 15) RP_FAIL(RPHIP_ELIMIT, "%d weighted column tiles (n_items=%lld) exceed the supported 15", T, (long long)I);
+  if (T > 1 && !X->sorted_rows) RP_FAIL(RPHIP_EINVAL, "normalize_X with more than %d items needs column-sorted rows", RP_WTILE_MAX);
+  hipStream_t st = ctx->stream;
+  rphip_model* m = nullptr;
+  RP_TRY(rp_model_alloc_topk(ctx, I, row_begin, row_end, K, &m));
+  const size_t nk = (size_t)std::max<int64_t>(1, (int64_t)n_rows * K);
+  hipMemsetAsync(m->idx, 0xFF, nk * sizeof(int32_t), st);
+  hipMemsetAsync(m->val, 0, nk * sizeof(double), st);
+  hipMemsetAsync(m->nnz, 0, (size_t)std::max(1, n_rows) * sizeof(int32_t), st);
+  auto fail = [&](int rc) {
+    rphip_model_destroy(m);
+    return rc;
+  };
+  if (n_rows > 0 && X->nnz > 0) {
+    char* sc = nullptr;
+    const size_t cand_n = (T > 1) ? (size_t)n_rows * T * K : 0;
+    const size_t bytes = (size_t)U * 8 + (size_t)I * 8 + RP_PLAN_BUCKETS * 4 + (size_t)n_rows * 4 + 64 + cand_n * 12 + (size_t)n_rows * T * 4 + 256;
+    int rc = rp_scratch(ctx, 0, bytes, (void**)&sc);
+    if (rc != RPHIP_OK) return fail(rc);
+    size_t o = 0;
+    auto carve = [&](size_t b) {
+      char* p = sc + o;
+      o += (b + 15) & ~(size_t)15;
+      return p;
+    };
+    double* user_q = (double*)carve((size_t)U * 8);
+    double* colw = (double*)carve((size_t)I * 8);
+    int32_t* bucket = (int32_t*)carve(RP_PLAN_BUCKETS * 4);
+    int32_t* order = (int32_t*)carve((size_t)n_rows * 4);
+    int32_t* ticket = (int32_t*)carve(64);
+    double* cand_g = (double*)carve(cand_n * 8);
+    int32_t* cand_idx = (int32_t*)carve(cand_n * 4);
+    int32_t* cand_nnz = (int32_t*)carve((size_t)n_rows * T * 4);
+    hipEvent_t ev;
+    rp_time_begin(ctx, &ev);
+    hipMemsetAsync(ticket, 0, 64, st);
+    if (T > 1) hipMemsetAsync(cand_nnz, 0, (size_t)n_rows * T * 4, st);
+    rc = rp_plan_row_order(ctx, X, row_begin, n_rows, bucket, order);
+    if (rc != RPHIP_OK) return fail(rc);
+    hipLaunchKernelGGL(k_user_weights, dim3((unsigned)std::min<int64_t>(2048, rp_cdiv(U, 256))), dim3(256), 0, st, X->x_ptr, (int)U,
+                       similarity == RPHIP_SIM_COSINE ? 1 : 0, user_q);
+    const double* roww = nullptr;
+    if (similarity == RPHIP_SIM_COSINE) {
+      hipLaunchKernelGGL(k_weighted_norms, dim3((unsigned)std::min<int64_t>(4096, rp_cdiv(I, 4))), dim3(256), 0, st, X->xt_ptr, X->xt_idx, user_q,
+                         (int)I, colw);
+      roww = colw;
+    } else {
+      if (hipMemcpyAsync(colw, cp_colw_host, (size_t)I * 8, hipMemcpyHostToDevice, st) != hipSuccess) return fail(RPHIP_EHIP);
+      roww = X->inv_deg;
+    }
+    rp_time_end(ctx, ev, RPHIP_T_FIT_PLAN, 0.0);
+    rp_wfit_params P;
+    P.x_ptr = X->x_ptr;
+    P.x_idx = X->x_idx;
+    P.xt_ptr = X->xt_ptr;
+    P.xt_idx = X->xt_idx;
+    P.order = order;
+    P.user_q = user_q;
+    P.colw = colw;
+    P.roww = roww;
+    P.n_items = (int)I;
+    P.n_rows = n_rows;
+    P.n_tiles = T;
+    P.tile_w = W;
+    P.K = K;
+    P.row_begin = (int)row_begin;
+    P.ticket = ticket;
+    P.out_idx = (T == 1) ? m->idx : cand_idx;
+    P.out_val = (T == 1) ? m->val : cand_g;
+    P.out_nnz = (T == 1) ? m->nnz : cand_nnz;
+    const size_t lds = (size_t)W * 8 + rp_select_smem_bytes(W);
+    if (hipFuncSetAttribute((const void*)k_itemknn_fit_weighted, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(RPHIP_EHIP);
+    rp_time_begin(ctx, &ev);
+    hipLaunchKernelGGL(k_itemknn_fit_weighted, dim3(ctx->n_cu), dim3(RP_FIT_THREADS), lds, st, P);
+    rp_time_end(ctx, ev, RPHIP_T_GRAM_TOPK, 0.0);
+    if (T > 1) {
+      const size_t mlds = (size_t)T * K * 12 + 8 + rp_select_smem_bytes(T * K, RP_MERGE_THREADS / 64);
+      if (mlds > 160 * 1024 || T * K >= RPS_FLAG) {
+        rp_set_error("K=%d with %d column tiles needs %zu bytes of LDS for the merge", K, T, mlds);
+        return fail(RPHIP_ELIMIT);
+      }
+      if (hipFuncSetAttribute((const void*)k_itemknn_merge_weighted, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds) != hipSuccess)
+        return fail(RPHIP_EHIP);
+      const int mper = std::max<int>(1, std::min<int>(8, (int)((160 * 1024) / mlds)));
+      rp_time_begin(ctx, &ev);
+      hipLaunchKernelGGL(k_itemknn_merge_weighted, dim3((unsigned)std::min<int64_t>(n_rows, (int64_t)ctx->n_cu * mper)), dim3(RP_MERGE_THREADS),
+                         mlds, st, cand_idx, cand_g, cand_nnz, colw, roww, T, K, n_rows, (int)row_begin, m->idx, m->val, m->nnz);
+      rp_time_end(ctx, ev, RPHIP_T_TOPK_MERGE, 0.0);
+    }
+    if (hipGetLastError() != hipSuccess) return fail(RPHIP_EHIP);
+  }
+  int r = rp_model_finalize_topk(ctx, m);
+  if (r != RPHIP_OK) return fail(r);
+  *out = m;
+  return RPHIP_OK;
+}
+
