@@ -42,6 +42,9 @@ def parse():
                     help="configs of the EASE legs (N=1 only), comma separated: the first goes to `ease`, others to `ease_<cfg>`; "
                          "'none' disables them")
     ap.add_argument("--l2", type=float, default=200.0)
+    ap.add_argument("--ease-sharded", action="store_true",
+                    help="N > 1 only: also time the multi-GPU EASE fit (recpack_amd.dist.ease_fit_sharded) + user-sharded predict on the "
+                         "first config of --ease-config; off by default so that the scaling run of the ItemKNN metric cannot be held up")
     return ap.parse_args()
 
 
@@ -153,6 +156,43 @@ def ease_leg(args, ctx, device, Kp, config, repeats):
     }
 
 
+def ease_leg_sharded(args, ctx, device, Kp, config, world, rank):
+    """EASE over all ranks: panels of the Cholesky / inverse split by row tiles and all-gathered, P rows and the scaling
+    local, B all-gathered (recpack_amd/dist.py::ease_fit_sharded); predict + top-Kp for this rank's users.  Runs on EVERY rank."""
+    import torch
+    import torch.distributed as dist
+
+    from recpack_amd import _lib, dist as rdist
+    from recpack_amd.synth import CONFIG_SEED_BASE, CONFIGS, powerlaw_csr
+
+    U, I, dens = CONFIGS[config]
+    ip, ix = powerlaw_csr(U, I, dens, CONFIG_SEED_BASE + int(config[1:]), device=device)
+    dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
+    ub, ue = rdist.partition_users(ip.cpu().numpy(), world)[rank]
+    out_idx = torch.empty((ue - ub, Kp), dtype=torch.int32, device=device)
+    out_val = torch.empty((ue - ub, Kp), dtype=torch.float32, device=device)
+    out_nnz = torch.empty((ue - ub,), dtype=torch.int32, device=device)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model = rdist.ease_fit_sharded(ctx, dX, args.l2, 0.0, device)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t_fit = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    _lib.predict_topk_dev(ctx, model, dX, Kp, out_idx, out_val, out_nnz, user_begin=ub, user_end=ue)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t_pred = time.perf_counter() - t0
+    t = torch.tensor([t_fit, t_pred], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    n_pad = -(-I // (128 * world)) * 128 * world
+    return {"workload": f"{config}: EASE l2={args.l2}, {U} users x {I} items over {world} GPUs (row-tile split panels + all-gather), "
+                        f"predict + top-{Kp} user-sharded",
+            "fit_s": round(float(t[0]), 4), "predict_s": round(float(t[1]), 4), "fit_plus_predict_s": round(float(t[0] + t[1]), 4),
+            "n3_model_TFLOPs_aggregate": round(n_pad ** 3 / float(t[0]) / 1e12, 2)}
+
+
 def pmc_traffic(config, kernel, world):
     """HBM bytes per launch of `kernel` from the committed PMC passes (tools/pmc_traffic.sh: one rocprofv3 --pmc run per
     counter on this same command).  FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B read
@@ -255,6 +295,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tm = ctx.timings()
+    ease_multi = None
+    if world > 1 and args.ease_sharded and args.ease_config.lower() != "none":
+        keep.clear()
+        ease_multi = ease_leg_sharded(args, ctx, device, Kp, args.ease_config.split(",")[0].strip().upper(), world, rank)
 
     if rank == 0:
         sec_per_step = elapsed / args.steps
@@ -361,6 +405,8 @@ def main():
                 leg = ease_leg(args, ctx, device, Kp, cfg, 1 if CONFIGS[cfg][1] > 60000 else 2)
                 result["ease" if n == 0 else f"ease_{cfg.lower()}"] = leg
                 torch.cuda.empty_cache()
+        if ease_multi is not None:
+            result["ease"] = ease_multi
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

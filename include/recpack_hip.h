@@ -228,6 +228,24 @@ int rphip_model_empty_rows(rphip_ctx* ctx, const rphip_model* m, int64_t* out);
 int rphip_gemm_nt_f32(rphip_ctx* ctx, int64_t M, int64_t N, int64_t K, float alpha, const float* A_dev, int64_t lda,
                       const float* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc);
 
+/* ---- building blocks of the multi-GPU EASE solve ---------------------------------------------------------------
+ * One process per GPU holds the matrix in its own device memory; the collectives (RCCL through torch.distributed)
+ * run between these calls (recpack_amd/dist.py::ease_fit_sharded).
+ *
+ * rphip_ease_gram_rows: rows [row_begin, row_end) of G + l2*I (ease.py:78-82) into a row-major matrix with n_cols
+ * columns (n_cols >= n_items: rows/columns past n_items carry an identity block), leading dimension ld. */
+int rphip_ease_gram_rows(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int64_t n_cols, double l2,
+                         float* G_dev, int64_t ld);
+/* Cholesky factor (lower) of a 128 x 128 block in place and its inverse into W (ld 128), in float64 internally;
+ * *info_dev (device int32) receives pivot + 1 if the block is not positive definite. */
+int rphip_potrf_trtri_128(rphip_ctx* ctx, float* A_dev, int64_t lda, float* W_dev, int32_t* info_dev);
+/* rphip_gemm_nt_f32 with per-tile K clipping for triangular operands (see rp_ease.hip). */
+int rphip_gemm_nt_f32_ex(rphip_ctx* ctx, int64_t M, int64_t N, int64_t k_begin, int64_t k_end, float alpha, const float* A_dev,
+                         int64_t lda, const float* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc, int32_t k_from_row,
+                         int32_t k_from_col, int64_t m_off, int64_t n_off, int32_t lower_only);
+/* a dense model on caller-owned device memory (not copied; must outlive the model) */
+int rphip_model_from_dense_device(rphip_ctx* ctx, int64_t n_items, float* B_dev, int64_t ld, rphip_model** out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,10 @@ PROTOTYPES = {
     "rphip_model_from_dense_host": (C.c_int, [_p, _i64, _p, _pp]),
     "rphip_model_empty_rows": (C.c_int, [_p, _p, C.POINTER(_i64)]),
     "rphip_gemm_nt_f32": (C.c_int, [_p, _i64, _i64, _i64, C.c_float, _p, _i64, _p, _i64, C.c_float, _p, _i64]),
+    "rphip_ease_gram_rows": (C.c_int, [_p, _p, _i64, _i64, _i64, _f64, _p, _i64]),
+    "rphip_potrf_trtri_128": (C.c_int, [_p, _p, _i64, _p, _p]),
+    "rphip_gemm_nt_f32_ex": (C.c_int, [_p, _i64, _i64, _i64, _i64, C.c_float, _p, _i64, _p, _i64, C.c_float, _p, _i64, _i32, _i32, _i64, _i64, _i32]),
+    "rphip_model_from_dense_device": (C.c_int, [_p, _i64, _p, _i64, _pp]),
 }
 
 _lock = threading.Lock()
@@ -325,6 +329,16 @@ class Model:
         return cls(ctx, h)
 
     @classmethod
+    def from_dense_device(cls, ctx: Context, n_items: int, B_t):
+        """A dense model on a torch float32 CUDA matrix (not copied; kept alive by the model object)."""
+        _torch_inputs_ready(ctx)
+        h = C.c_void_p()
+        check(ctx.lib.rphip_model_from_dense_device(ctx.handle, int(n_items), C.c_void_p(B_t.data_ptr()), B_t.stride(0), C.byref(h)))
+        m = cls(ctx, h)
+        m._keep = B_t
+        return m
+
+    @classmethod
     def from_dense_host(cls, ctx: Context, B: np.ndarray):
         B = np.ascontiguousarray(B, dtype=np.float32)
         assert B.ndim == 2 and B.shape[0] == B.shape[1]
@@ -390,6 +404,32 @@ def gemm_nt(ctx: Context, A_t, B_t, C_t, alpha: float = 1.0, beta: float = 0.0):
     N = B_t.shape[0]
     check(ctx.lib.rphip_gemm_nt_f32(ctx.handle, M, N, K, float(alpha), C.c_void_p(A_t.data_ptr()), A_t.stride(0),
                                     C.c_void_p(B_t.data_ptr()), B_t.stride(0), float(beta), C.c_void_p(C_t.data_ptr()), C_t.stride(0)))
+
+
+def gemm_nt_ex(ctx: Context, A_t, B_t, C_t, k_begin: int, k_end: int, alpha: float = 1.0, beta: float = 0.0, k_from_row: bool = False,
+               k_from_col: bool = False, m_off: int = 0, n_off: int = 0, lower_only: bool = False):
+    """C (M x N) = alpha * A[:, k] @ B[:, k].T + beta * C over k in [k_begin, k_end), with per-tile K clipping for
+    triangular operands (rphip_gemm_nt_f32_ex); torch float32 CUDA tensors / views with unit inner stride."""
+    _torch_inputs_ready(ctx)
+    M, N = C_t.shape
+    check(ctx.lib.rphip_gemm_nt_f32_ex(ctx.handle, int(M), int(N), int(k_begin), int(k_end), float(alpha), C.c_void_p(A_t.data_ptr()),
+                                       A_t.stride(0), C.c_void_p(B_t.data_ptr()), B_t.stride(0), float(beta), C.c_void_p(C_t.data_ptr()),
+                                       C_t.stride(0), 1 if k_from_row else 0, 1 if k_from_col else 0, int(m_off), int(n_off),
+                                       1 if lower_only else 0))
+
+
+def potrf_trtri_128(ctx: Context, A_block_t, W_t, info_t):
+    """In-place Cholesky of a 128 x 128 block (a view with row stride lda) and its inverse into W_t (128 x 128 contiguous)."""
+    _torch_inputs_ready(ctx)
+    check(ctx.lib.rphip_potrf_trtri_128(ctx.handle, C.c_void_p(A_block_t.data_ptr()), A_block_t.stride(0), C.c_void_p(W_t.data_ptr()),
+                                        C.c_void_p(info_t.data_ptr())))
+
+
+def ease_gram_rows(ctx: Context, X: DeviceCSR, row_begin: int, row_end: int, l2: float, G_t):
+    """Rows [row_begin, row_end) of G + l2*I into the square torch matrix G_t (identity block on the padding)."""
+    _torch_inputs_ready(ctx)
+    check(ctx.lib.rphip_ease_gram_rows(ctx.handle, X.handle, int(row_begin), int(row_end), int(G_t.shape[1]), float(l2),
+                                       C.c_void_p(G_t.data_ptr()), G_t.stride(0)))
 
 
 def predict_topk(ctx: Context, model: Model, X: DeviceCSR, Kp: int, exclude_history: bool = False, user_begin: int = 0,

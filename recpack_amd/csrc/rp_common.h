@@ -104,6 +104,7 @@ struct rphip_model {
   float vmax_abs = 0.0f;    // largest |similarity| (f32): with the longest history it bounds |score|
   // DENSE
   float* B = nullptr;       // [n_items * ld]
+  bool borrows_B = false;   // B belongs to the caller (rphip_model_from_dense_device)
   int64_t ld = 0;
   int64_t empty_rows = -1;  // rows without any stored similarity (-1: not counted)
 };

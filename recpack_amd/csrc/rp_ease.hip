@@ -517,6 +517,109 @@ static int rp_spd_inverse(rphip_ctx* ctx, float* A, float* Nb, int n_pad, long l
   return RPHIP_OK;
 }
 
+
+// ---- building blocks of a multi-GPU solve (recpack_amd/dist.py::ease_fit_sharded drives them) --------------------------
+// The matrix lives in caller-owned device memory (a torch tensor per rank); collectives happen between these calls.
+
+// rows [row_begin, row_end) of G + lambda I, with the identity block on the padding (row >= n_items), into a row-major matrix
+__global__ void k_ease_init_rows(float* __restrict__ G, long long ld, int n, long long r0, long long r1, long long n_cols, float lam) {
+  const long long total = (r1 - r0) * n_cols;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long i = r0 + e / n_cols, j = e % n_cols;
+    G[i * ld + j] = (i == j) ? (i < n ? lam : 1.0f) : 0.0f;
+  }
+}
+
+extern "C" int rphip_ease_gram_rows(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int64_t n_cols, double l2,
+                                    float* G_dev, int64_t ld) {
+  if (!ctx || !X || !G_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if (row_begin < 0 || row_begin > row_end || row_end > n_cols || n_cols < X->n_items || ld < n_cols || (ld % 4))
+    RP_FAIL(RPHIP_EINVAL, "rows [%lld,%lld) of a %lld-column matrix with ld %lld", (long long)row_begin, (long long)row_end,
+            (long long)n_cols, (long long)ld);
+  if (!(l2 > 0.0)) RP_FAIL(RPHIP_EINVAL, "l2 must be > 0 (got %g)", l2);
+  if (X->xt_row_end >= 0 && (row_begin < X->xt_row_begin || std::min<int64_t>(row_end, X->n_items) > X->xt_row_end))
+    RP_FAIL(RPHIP_ESTATE, "the matrix was built for item rows [%lld,%lld) only", (long long)X->xt_row_begin, (long long)X->xt_row_end);
+  RP_TRY(rp_set_device(ctx));
+  const float lam = (float)l2;  // rounded to float32 as the reference does (ease.py:82)
+  if (row_end > row_begin)
+    hipLaunchKernelGGL(k_ease_init_rows, dim3(4096), dim3(256), 0, ctx->stream, G_dev, (long long)ld, (int)X->n_items, (long long)row_begin,
+                       (long long)row_end, (long long)n_cols, lam);
+  RP_HIP(hipGetLastError());
+  const int64_t r1 = std::min<int64_t>(row_end, X->n_items);
+  if (r1 > row_begin) RP_TRY(rp_gram_dense(ctx, X, row_begin, r1, G_dev, ld, lam));
+  return RPHIP_OK;
+}
+
+// A (128 x 128 block, leading dimension lda) := its Cholesky factor (lower, upper part zeroed), W (128 x 128, ld 128) := the
+// factor's inverse; *info_dev (device int) is set to the failing pivot + 1 when the block is not positive definite
+extern "C" int rphip_potrf_trtri_128(rphip_ctx* ctx, float* A_dev, int64_t lda, float* W_dev, int32_t* info_dev) {
+  if (!ctx || !A_dev || !W_dev || !info_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  RP_TRY(rp_set_device(ctx));
+  const size_t diag_lds = (size_t)GT * DS * sizeof(double);
+  RP_HIP(hipFuncSetAttribute((const void*)k_potrf_trtri, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
+  hipLaunchKernelGGL(k_potrf_trtri, dim3(1), dim3(1024), diag_lds, ctx->stream, A_dev, (long long)lda, W_dev, (int*)info_dev);
+  RP_HIP(hipGetLastError());
+  return RPHIP_OK;
+}
+
+// rphip_gemm_nt_f32 with the K clipping of the triangular factors: tile (m0, n0) starts its K loop at
+// max(k_begin, k_from_row ? m_off + m0 : 0, k_from_col ? n_off + n0 : 0); lower_only skips tiles with n_off + n0 > m_off + m0
+extern "C" int rphip_gemm_nt_f32_ex(rphip_ctx* ctx, int64_t M, int64_t N, int64_t k_begin, int64_t k_end, float alpha, const float* A_dev,
+                                    int64_t lda, const float* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc, int32_t k_from_row,
+                                    int32_t k_from_col, int64_t m_off, int64_t n_off, int32_t lower_only) {
+  if (!ctx || !A_dev || !B_dev || !C_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if ((M % GT) || (N % GT) || (k_begin % GBK) || (k_end % GBK) || (lda % 4) || (ldb % 4) || (m_off % GT) || (n_off % GT))
+    RP_FAIL(RPHIP_EINVAL, "M, N, m_off, n_off must be multiples of 128, the K range of 16, lda/ldb of 4");
+  RP_TRY(rp_set_device(ctx));
+  rp_gemm_args g{};
+  g.A = A_dev;
+  g.lda = lda;
+  g.B = B_dev;
+  g.ldb = ldb;
+  g.C = C_dev;
+  g.ldc = ldc;
+  g.M = (int)M;
+  g.N = (int)N;
+  g.k0 = (int)k_begin;
+  g.k1 = (int)k_end;
+  g.kb_m = k_from_row ? 1 : 0;
+  g.kb_n = k_from_col ? 1 : 0;
+  g.m_off = (int)m_off;
+  g.n_off = (int)n_off;
+  g.tri = lower_only ? 1 : 0;
+  g.alpha = alpha;
+  g.beta = beta;
+  hipEvent_t ev;
+  rp_time_begin(ctx, &ev);
+  RP_TRY(rp_gemm_nt(ctx, g));
+  rp_time_end(ctx, ev, RPHIP_T_CHOLESKY, 2.0 * (double)M * (double)N * (double)(k_end - k_begin));
+  return RPHIP_OK;
+}
+
+// a dense model on caller-owned device memory (row-major float32, leading dimension ld >= n_items, ld % 4 == 0): not copied,
+// must outlive the model
+extern "C" int rphip_model_from_dense_device(rphip_ctx* ctx, int64_t n_items, float* B_dev, int64_t ld, rphip_model** out) {
+  if (!ctx || !B_dev || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (n_items <= 0 || ld < n_items || (ld % 4)) RP_FAIL(RPHIP_EINVAL, "n_items %lld, ld %lld", (long long)n_items, (long long)ld);
+  RP_TRY(rp_set_device(ctx));
+  rphip_model* m = new rphip_model();
+  m->ctx = ctx;
+  m->kind = RPHIP_MODEL_DENSE;
+  m->n_items = n_items;
+  m->row_end = n_items;
+  m->ld = ld;
+  m->B = B_dev;
+  m->borrows_B = true;
+  int r = rp_dense_count_empty(ctx, m);
+  if (r != RPHIP_OK) {
+    rphip_model_destroy(m);
+    return r;
+  }
+  *out = m;
+  return RPHIP_OK;
+}
+
 extern "C" int rphip_ease_fit(rphip_ctx* ctx, const rphip_csr* X, double l2, double alpha, rphip_model** out) {
   if (!ctx || !X || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;

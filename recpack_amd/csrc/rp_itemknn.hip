@@ -695,7 +695,7 @@ extern "C" int rphip_model_destroy(rphip_model* m) {
   if (m->pairs) hipFree(m->pairs);
   if (m->toff) hipFree(m->toff);
   if (m->nnz) hipFree(m->nnz);
-  if (m->B) hipFree(m->B);
+  if (m->B && !m->borrows_B) hipFree(m->B);
   delete m;
   return RPHIP_OK;
 }

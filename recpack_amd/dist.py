@@ -125,3 +125,121 @@ def fit_itemknn_sharded(ctx, dX, K: int, parts: Sequence[Tuple[int, int]], devic
     idx_f, val_f, nnz_f = allgather_topk(idx, val, nnz, parts, group)
     torch.cuda.current_stream(device).synchronize()
     return _lib.Model.from_topk_device(ctx, idx_f, val_f, nnz_f)
+
+
+def ease_fit_sharded(ctx, dX, l2: float, alpha: float, device, group=None):
+    """EASE fit (recpack/algorithms/ease.py:63-95) on all ranks of ``group``, one GPU each.
+
+    Every rank keeps ONE n x n float32 matrix: first G + l2*I, then the Cholesky factor L below the diagonal and
+    N = L^-T on and above it (a diagonal block is only needed until its panel is done, then it holds N's block), finally B.
+    The O(n^3) work of every panel is split by row tiles over the ranks and the finished panel is all-gathered
+    (n^2/2 * 4 bytes in total per phase); P = N N^T and the scaling are computed for a rank's own rows and B is
+    all-gathered into the big matrix, so predict can shard by users as for ItemKNN.  Peak memory n^2 * 4 * (1 + 1/world)
+    bytes per GPU.  Returns a dense model on this rank's copy of B.
+    """
+    import torch
+    import torch.distributed as dist
+
+    from recpack_amd import _lib
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    T = 128
+    n = dX.shape[1]
+    n_pad = -(-n // (T * world)) * (T * world)  # rows split evenly in whole tiles
+    rows = n_pad // world
+    nb = n_pad // T
+    lib_stream_is_torchs = ctx.stream is not None and int(torch.cuda.current_stream().cuda_stream) == ctx.stream
+
+    def to_torch():  # library work -> visible to torch's stream
+        if not lib_stream_is_torchs:
+            ctx.sync()
+
+    def gather(out, inp):
+        to_torch()
+        if world > 1:
+            dist.all_gather_into_tensor(out, inp, group=group)
+        else:
+            out.view(-1)[: inp.numel()].copy_(inp.reshape(-1))
+
+    A = torch.empty((n_pad, n_pad), dtype=torch.float32, device=device)
+    W = torch.empty((nb, T, T), dtype=torch.float32, device=device)
+    info = torch.zeros((1,), dtype=torch.int32, device=device)
+    # ---- Gram rows of this rank, all-gathered
+    mine = torch.empty((rows, n_pad), dtype=torch.float32, device=device)
+    _lib.ease_gram_rows(ctx, dX, rank * rows, (rank + 1) * rows, l2, A)
+    to_torch()
+    mine.copy_(A[rank * rows:(rank + 1) * rows])
+    gather(A, mine)
+    max_per = -(-nb // world)
+    send = torch.empty((max_per * T, T), dtype=torch.float32, device=device)
+    recv = torch.empty((world * max_per * T, T), dtype=torch.float32, device=device)
+    tmp = torch.empty((max_per * T, T), dtype=torch.float32, device=device)
+
+    def split(first_tile, n_tiles):
+        """This rank's share [lo, hi) of the tiles first_tile .. first_tile + n_tiles, and the per-rank chunk size."""
+        per = -(-n_tiles // world)
+        lo = min(n_tiles, rank * per)
+        hi = min(n_tiles, (rank + 1) * per)
+        return first_tile + lo, first_tile + hi, per
+
+    # ---- K5: left-looking Cholesky, panel by panel
+    for k in range(nb):
+        r0 = k * T
+        diag = A[r0:r0 + T, r0:r0 + T]
+        if k > 0:  # every rank updates the diagonal tile itself (128 rows: negligible, and no broadcast)
+            _lib.gemm_nt_ex(ctx, A[r0:r0 + T], A[r0:r0 + T], diag, 0, r0, alpha=-1.0, beta=1.0)
+        _lib.potrf_trtri_128(ctx, diag, W[k], info)
+        lo, hi, per = split(k + 1, nb - k - 1)
+        if hi > lo:
+            R = slice(lo * T, hi * T)
+            if k > 0:
+                _lib.gemm_nt_ex(ctx, A[R], A[r0:r0 + T], A[R, r0:r0 + T], 0, r0, alpha=-1.0, beta=1.0)
+            _lib.gemm_nt_ex(ctx, A[R, r0:r0 + T], W[k], send[: (hi - lo) * T], 0, T)  # L[R, k] = A[R, k] W_k^T
+        if nb - k - 1 > 0:
+            gather(recv[: world * per * T], send[: per * T])
+            A[r0 + T:, r0:r0 + T].copy_(recv[: (nb - k - 1) * T])
+        else:
+            to_torch()
+        diag.copy_(W[k].t())  # from here on the block is N's diagonal block
+        if not lib_stream_is_torchs:
+            torch.cuda.current_stream().synchronize()
+    # ---- K6a: N = L^-T above the diagonal, block column by block column
+    for i in range(1, nb):
+        c0 = i * T
+        lo, hi, per = split(0, i)
+        if hi > lo:
+            R = slice(lo * T, hi * T)
+            _lib.gemm_nt_ex(ctx, A[R], A[c0:c0 + T], tmp[: (hi - lo) * T], 0, c0, k_from_row=True, m_off=lo * T)
+            _lib.gemm_nt_ex(ctx, tmp[: (hi - lo) * T], W[i], send[: (hi - lo) * T], 0, T, alpha=-1.0)
+        gather(recv[: world * per * T], send[: per * T])
+        A[:c0, c0:c0 + T].copy_(recv[: i * T])
+        if not lib_stream_is_torchs:
+            torch.cuda.current_stream().synchronize()
+    # ---- K6b: this rank's rows of P = N N^T, K7 scaling, B all-gathered into the big matrix
+    Rr = slice(rank * rows, (rank + 1) * rows)
+    P = torch.empty((rows, n_pad), dtype=torch.float32, device=device)
+    _lib.gemm_nt_ex(ctx, A[Rr], A, P, 0, n_pad, k_from_row=True, k_from_col=True, m_off=rank * rows)
+    to_torch()
+    d_mine = torch.diagonal(P[:, Rr]).contiguous()
+    d_all = torch.empty((n_pad,), dtype=torch.float32, device=device)
+    gather(d_all, d_mine)
+    w = torch.ones((n_pad,), dtype=torch.float32, device=device)
+    if alpha != 0.0:
+        deg = torch.as_tensor(dX.item_degrees(), device=device).to(torch.float32)
+        w[:n] = torch.where(deg > 0, deg.clamp(min=1).pow(-float(alpha)), torch.zeros_like(deg))
+    P.mul_((-w / d_all)[None, :])  # B_ij = -P_ij / P_jj * w_j (ease.py:85-90)
+    torch.diagonal(P[:, Rr]).zero_()
+    P[:, n:] = 0
+    if (rank + 1) * rows > n:
+        P[max(0, n - rank * rows):] = 0
+    if world > 1:
+        dist.barrier(group=group)  # every rank has finished reading N before it becomes B
+    gather(A, P)
+    del P
+    if not lib_stream_is_torchs:
+        torch.cuda.current_stream().synchronize()
+    bad = int(info.item())
+    if bad:
+        raise _lib.RecpackHipError(-7, f"Cholesky broke down (non-positive pivot {bad} in a diagonal block): G + l2*I is not positive definite")
+    return _lib.Model.from_dense_device(ctx, n, A)

@@ -1,0 +1,41 @@
+"""Time recpack_amd.dist.ease_fit_sharded (one rank per GPU; plain `python` = one rank):
+    python tools/ease_sharded_bench.py <users> <items> <density> [l2]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.getcwd())
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from recpack_amd import _lib  # noqa: E402
+from recpack_amd import dist as rdist  # noqa: E402
+from recpack_amd.synth import powerlaw_csr  # noqa: E402
+
+U, I, dens = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])
+l2 = float(sys.argv[4]) if len(sys.argv) > 4 else 200.0
+world = int(os.environ.get("WORLD_SIZE", "1"))
+rank = int(os.environ.get("RANK", "0"))
+backend = os.environ.get("RECPACK_DIST_BACKEND", "nccl")
+local = int(os.environ.get("LOCAL_RANK", "0"))
+if backend != "nccl":
+    local %= max(1, torch.cuda.device_count())
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
+if world > 1:
+    dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+stream = torch.cuda.Stream(dev)
+torch.cuda.set_stream(stream)
+ctx = _lib.Context(local, stream.cuda_stream)
+ip, ix = powerlaw_csr(U, I, dens, seed=20260003, device=dev)
+dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
+for it in range(2):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m = rdist.ease_fit_sharded(ctx, dX, l2, 0.0, dev)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        n_pad = -(-I // (128 * world)) * 128 * world
+        print(f"world {world}: I={I} sharded fit {dt*1e3:.1f} ms = {n_pad**3 / dt / 1e12:.1f} TF/s by the n^3 model", flush=True)
+    del m
