@@ -157,7 +157,7 @@ def ease_fit_sharded(ctx, dX, l2: float, alpha: float, device, group=None):
 
     def gather(out, inp):
         to_torch()
-        if world > 1:
+        if dist.is_initialized():
             dist.all_gather_into_tensor(out, inp, group=group)
         else:
             out.view(-1)[: inp.numel()].copy_(inp.reshape(-1))
@@ -233,7 +233,7 @@ def ease_fit_sharded(ctx, dX, l2: float, alpha: float, device, group=None):
     P[:, n:] = 0
     if (rank + 1) * rows > n:
         P[max(0, n - rank * rows):] = 0
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier(group=group)  # every rank has finished reading N before it becomes B
     gather(A, P)
     del P

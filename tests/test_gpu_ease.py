@@ -257,3 +257,17 @@ def test_ease_fit_sharded_one_rank(hip):
     assert rel_max(B, ref) <= EASE_TOL
     with pytest.raises(_lib.RecpackHipError):
         rdist.ease_fit_sharded(ctx, dX, 0.0, 0.0, torch.device("cuda", 0))
+
+
+def test_ease_fit_sharded_rccl_one_rank(hip):
+    """The same code with a one-rank NCCL (= RCCL) group: every collective call of the multi-GPU path runs through RCCL."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RECPACK_FORCE_PG="1", RECPACK_DIST_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT="29591", RANK="0",
+               WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dist_ease_check.py"), "3000", "600", "0.02"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
