@@ -207,6 +207,10 @@ int rphip_predict_full_fill(rphip_ctx* ctx, const rphip_model* model, const rphi
  * (l2 * np.identity(dtype=float32), :82).  B stays on the device (fp32).
  */
 int rphip_ease_fit(rphip_ctx* ctx, const rphip_csr* X, double l2, double alpha, rphip_model** out);
+/* EASE_XY (recpack/algorithms/experimental/ease_xy.py:61-96): reconstruct a second matrix y from X,
+ * B = P (X^T y) - P diag(diag(P X^T y) / diag(P)) with P = (X^T X + l2 I)^-1, columns scaled by c_j^-alpha;
+ * X and y are binary matrices of the same shape.  Three n x n float32 matrices during the fit. */
+int rphip_ease_xy_fit(rphip_ctx* ctx, const rphip_csr* X, const rphip_csr* Y, double l2, double alpha, rphip_model** out);
 /* dense B (row-major float32[n_items*n_items]) to host - the lazy similarity_matrix_ (ease.py:92) */
 int rphip_model_dense_download(rphip_ctx* ctx, const rphip_model* m, float* B_host);
 int rphip_model_dense_device(const rphip_model* m, void** B_dev, int64_t* n_items, int64_t* ld);

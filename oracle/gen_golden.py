@@ -206,6 +206,27 @@ def normalized_cases():
         save(name, **arrays)
 
 
+def ease_xy_cases():
+    """EASE_XY (experimental/ease_xy.py): the docstring example and a seeded synthetic pair (y = a later, overlapping draw)."""
+    from recpack.algorithms.experimental.ease_xy import EASE_XY
+
+    Xd = sp.csr_matrix(np.array([[1, 0, 1], [1, 0, 1], [1, 1, 1]]))
+    yd = sp.csr_matrix(np.array([[0, 0, 1], [0, 0, 1], [1, 0, 0]]))
+    m = powerlaw_csr(1500, 300, 0.03, seed=20260112).to_scipy()
+    m2 = powerlaw_csr(1500, 300, 0.02, seed=20260111).to_scipy()
+    for name, X, y, params in (("ref_ease_xy_doc", Xd, yd, [(1.0, 0.0), (1000.0, 0.0)]),
+                               ("syn_ease_xy_1500x300", m, m2, [(200.0, 0.0), (5.0, 0.5)])):
+        arrays = dict(csr_parts("X", X))
+        arrays.update(csr_parts("Y", y))
+        arrays["l2"] = np.asarray([p[0] for p in params], dtype=np.float64)
+        arrays["alpha"] = np.asarray([p[1] for p in params], dtype=np.float64)
+        for n, (l2, alpha) in enumerate(params):
+            algo = EASE_XY(l2=l2, alpha=alpha).fit(X, y)
+            arrays[f"B{n}"] = algo.similarity_matrix_.toarray()
+            arrays[f"Pout{n}"] = algo.predict(X[:50]).toarray()
+        save(name, **arrays)
+
+
 def pipeline_case():
     """C1 (BASELINE.json configs[0]): the MovieLens-100K sample that ships with the reference's tests
     (recpack/tests/test_datasets/datasets/ml-100k_sample.data, default filters -> 373 x 390, 4620 interactions),
@@ -259,7 +280,10 @@ if __name__ == "__main__":
         pipeline_case()
     elif len(sys.argv) > 1 and sys.argv[1] == "normalized":
         normalized_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ease_xy":
+        ease_xy_cases()
     else:
         main()
         normalized_cases()
+        ease_xy_cases()
         pipeline_case()

@@ -267,6 +267,25 @@ def ease_fit(X: sp.csr_matrix, l2: float, alpha: float = 0.0) -> np.ndarray:
     return B
 
 
+def ease_xy_fit(X: sp.csr_matrix, Y: sp.csr_matrix, l2: float, alpha: float = 0.0) -> np.ndarray:
+    """experimental/ease_xy.py:76-92 in float64: B = P (X^T y) - P diag(diag(P X^T y) / diag(P)), P = (X^T X + l2 I)^-1 (the
+    identity is float64 there: l2 is not rounded), optional column weights c_j^-alpha (0 for items nobody interacted with,
+    where the reference divides by zero)."""
+    Xb, Yb = binarize(X), binarize(Y)
+    n = Xb.shape[1]
+    XTX = (Xb.T @ Xb).toarray().astype(np.float64)
+    P = np.linalg.inv(XTX + float(l2) * np.identity(n))
+    B_rr = P @ (Xb.T @ Yb).toarray().astype(np.float64)
+    B = B_rr - P * (np.diag(B_rr) / np.diag(P))[None, :]
+    if alpha != 0:
+        c = np.diag(XTX)
+        w = np.zeros(n)
+        w[c > 0] = np.power(c[c > 0], -float(alpha))
+        B = B * w[None, :]
+    np.fill_diagonal(B, 0.0)  # (exactly zero up to rounding in the reference as well)
+    return B
+
+
 def ease_prune(B: np.ndarray, density: float) -> np.ndarray:
     """ease.py:97-109 with np.prod for the removed np.product: keep the ``int(density*n*n)`` largest |B_ij|
     among the stored (off-diagonal, non-zero) entries."""

@@ -321,3 +321,31 @@ class EASE(ItemSimilarityMatrixAlgorithm):
         check_is_fitted(self)
         if self._empty_rows_ is not None and self._empty_rows_ > 0:
             warnings.warn(f"{self.name} missing similar items for {self._empty_rows_} items.")
+
+
+class EASE_XY(EASE):
+    """EASE_XY (recpack/algorithms/experimental/ease_xy.py:20-96): EASE trained to reconstruct a second matrix ``y`` from ``X``
+    (``fit(X, y)``), B = P (X^T y) - P diag(diag(P X^T y) / diag(P)) with P = (X^T X + l2 I)^-1; predict as EASE."""
+
+    def fit(self, X, y) -> "EASE_XY":
+        start = time.time()
+        X, y = to_binary_csr(X), to_binary_csr(y)
+        if X.shape != y.shape:
+            raise ValueError(f"X {X.shape} and y {y.shape} must have the same shape")
+        ctx = get_context()
+        dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
+        dY = _lib.DeviceCSR.from_host(ctx, y.indptr, y.indices, y.shape)
+        try:
+            self._model = _lib.ease_xy_fit(ctx, dX, dY, float(self.l2), float(self.alpha))
+        finally:
+            dX.close()
+            dY.close()
+        self._sim_cache = None
+        self.n_items_ = X.shape[1]
+        if self.density:
+            self._prune()
+        self._empty_rows_ = self._model.empty_rows()
+        self._check_fit_complete()
+        logger.info(f"fitting {self.name} complete - Took {time.time() - start :.3}s")
+        return self
+

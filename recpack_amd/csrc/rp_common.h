@@ -131,7 +131,9 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m);
 
 // rp_itemknn.hip: K4, dense f32 Gram rows [row_begin,row_end) of X^T X into G (row-major, leading dimension ld),
 // diag_add on the diagonal; rows of items nobody interacted with are left untouched
-int rp_gram_dense(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, float* G, int64_t ld, float diag_add);
+// Xcols != NULL: rows of X^T Xcols (the user rows come from Xcols, a matrix of the same shape)
+int rp_gram_dense(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, float* G, int64_t ld, float diag_add,
+                  const rphip_csr* Xcols = nullptr);
 
 // rp_predict.hip: val (f64) -> val32 + pairs, column-order check; call once the lists are complete
 int rp_model_finalize_topk(rphip_ctx* ctx, rphip_model* m);

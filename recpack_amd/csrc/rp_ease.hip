@@ -620,6 +620,113 @@ extern "C" int rphip_model_from_dense_device(rphip_ctx* ctx, int64_t n_items, fl
   return RPHIP_OK;
 }
 
+
+// ---- EASE_XY (recpack/algorithms/experimental/ease_xy.py:61-96) --------------------------------------------------------
+// B = P (X^T Y) - P diag(diag(P X^T Y) / diag(P)), columns scaled by c_j^-alpha; P = (X^T X + l2 I)^-1 as for EASE.
+// X^T Y is needed with its K index contiguous for the NT product, i.e. as rows of Y^T X: the dense Gram kernel with the
+// item rows taken from Y and the user rows from X.
+__global__ void k_ease_xy_finish(float* __restrict__ Brr, const float* __restrict__ P, long long ld, int n, int n_pad,
+                                 const int32_t* __restrict__ deg, float alpha) {
+  const long long total = (long long)n_pad * ld;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long i = e / ld;
+    const int j = (int)(e % ld);
+    float v = 0.0f;
+    if (i < n && j < n && i != j) {
+      const long long dj = (long long)j * ld + j;
+      const float d = Brr[dj] / P[dj];
+      v = Brr[e] - P[e] * d;
+      if (alpha != 0.0f) v *= deg[j] > 0 ? powf((float)deg[j], -alpha) : 0.0f;
+    }
+    // the diagonal entries are read by every thread of their column: write them in a second pass
+    if (i != j || i >= n) Brr[e] = v;
+  }
+}
+
+__global__ void k_zero_diag(float* __restrict__ B, long long ld, int n) {
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) B[(long long)j * ld + j] = 0.0f;
+}
+
+extern "C" int rphip_ease_xy_fit(rphip_ctx* ctx, const rphip_csr* X, const rphip_csr* Y, double l2, double alpha, rphip_model** out) {
+  if (!ctx || !X || !Y || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (!(l2 > 0.0)) RP_FAIL(RPHIP_EINVAL, "l2 must be > 0 (got %g): G + l2*I has to be positive definite", l2);
+  if (X->n_users != Y->n_users || X->n_items != Y->n_items) RP_FAIL(RPHIP_EINVAL, "X and y must have the same shape");
+  if (X->xt_row_end >= 0 || Y->xt_row_end >= 0) RP_FAIL(RPHIP_ESTATE, "EASE_XY needs matrices with all item rows of X^T");
+  RP_TRY(rp_set_device(ctx));
+  const int n = (int)X->n_items;
+  if (n <= 0) RP_FAIL(RPHIP_EINVAL, "no items");
+  const int n_pad = (int)(rp_cdiv(n, GT) * GT);
+  const long long ld = n_pad;
+  const size_t bytes = (size_t)n_pad * ld * sizeof(float);
+  size_t free_b = 0, total_b = 0;
+  hipMemGetInfo(&free_b, &total_b);
+  if (3 * bytes + (1ull << 30) > free_b)
+    RP_FAIL(RPHIP_ENOMEM, "EASE_XY with %d items needs %.1f GB of HBM (three %d x %d f32 matrices), %.1f GB free", n, 3 * bytes / 1e9, n_pad,
+            n_pad, free_b / 1e9);
+  hipStream_t st = ctx->stream;
+  float *Pm = nullptr, *Gyx = nullptr;
+  rphip_model* m = new rphip_model();
+  m->ctx = ctx;
+  m->kind = RPHIP_MODEL_DENSE;
+  m->n_items = n;
+  m->row_end = n;
+  m->ld = ld;
+  auto fail = [&](int rc) {
+    hipStreamSynchronize(st);
+    if (Pm) hipFree(Pm);
+    if (Gyx) hipFree(Gyx);
+    rphip_model_destroy(m);
+    return rc;
+  };
+  if (hipMalloc((void**)&m->B, bytes) != hipSuccess || hipMalloc((void**)&Pm, bytes) != hipSuccess ||
+      hipMalloc((void**)&Gyx, bytes) != hipSuccess) {
+    rp_set_error("hipMalloc of the dense matrices failed");
+    return fail(RPHIP_ENOMEM);
+  }
+  // P = (X^T X + l2 I)^-1 (ease_xy.py:80-83: the identity is float64 there, l2 is used as given; it is float32 here)
+  const float lam = (float)l2;
+  hipLaunchKernelGGL(k_ease_init, dim3(4096), dim3(256), 0, st, Pm, ld, n, n_pad, lam);
+  int r = rp_gram_dense(ctx, X, 0, n, Pm, ld, lam);
+  if (r == RPHIP_OK) r = rp_spd_inverse(ctx, Pm, Gyx, n_pad, ld);  // (Gyx is the workspace of the inverse first)
+  if (r != RPHIP_OK) return fail(r);
+  // Y^T X rows, then B_rr = P (X^T Y) = P (Y^T X)^T as an NT product
+  hipLaunchKernelGGL(k_zero_f32, dim3(2048), dim3(256), 0, st, Gyx, (long long)n_pad * ld);
+  r = rp_gram_dense(ctx, Y, 0, n, Gyx, ld, 0.0f, X);
+  if (r != RPHIP_OK) return fail(r);
+  hipEvent_t ev;
+  rp_time_begin(ctx, &ev);
+  rp_gemm_args g{};
+  g.A = Pm;
+  g.lda = ld;
+  g.B = Gyx;
+  g.ldb = ld;
+  g.C = m->B;
+  g.ldc = ld;
+  g.M = n_pad;
+  g.N = n_pad;
+  g.k0 = 0;
+  g.k1 = n_pad;
+  g.alpha = 1.0f;
+  g.beta = 0.0f;
+  r = rp_gemm_nt(ctx, g);
+  if (r != RPHIP_OK) return fail(r);
+  rp_time_end(ctx, ev, RPHIP_T_INVERSE, 2.0 * (double)n_pad * n_pad * n_pad);
+  rp_time_begin(ctx, &ev);
+  hipLaunchKernelGGL(k_ease_xy_finish, dim3(4096), dim3(256), 0, st, m->B, Pm, ld, n, n_pad, X->deg, (float)alpha);
+  hipLaunchKernelGGL(k_zero_diag, dim3((unsigned)rp_cdiv(n, 256)), dim3(256), 0, st, m->B, ld, n);
+  if (hipGetLastError() != hipSuccess) return fail(RPHIP_EHIP);
+  rp_time_end(ctx, ev, RPHIP_T_EASE_SCALE, 12.0 * (double)n * (double)n);
+  hipStreamSynchronize(st);
+  hipFree(Pm);
+  hipFree(Gyx);
+  Pm = Gyx = nullptr;
+  r = rp_dense_count_empty(ctx, m);
+  if (r != RPHIP_OK) return fail(r);
+  *out = m;
+  return RPHIP_OK;
+}
+
 extern "C" int rphip_ease_fit(rphip_ctx* ctx, const rphip_csr* X, double l2, double alpha, rphip_model** out) {
   if (!ctx || !X || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;

@@ -732,10 +732,15 @@ int rp_plan_row_order(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int
 }
 
 // Shared driver of K1-K3 (out != NULL: neighbour lists) and K4 (dense != NULL: dense f32 Gram rows + lambda).
+// Xc (dense only): take the USER ROWS from another matrix of the same shape - rows of X^T Xc instead of X^T X
+// (EASE_XY's Y^T X); NULL = X itself.
 static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K, rphip_model** out,
-                        float* dense, int64_t dense_ld, float diag_add, const double* colw = nullptr, int key_pow = 2) {
+                        float* dense, int64_t dense_ld, float diag_add, const double* colw = nullptr, int key_pow = 2,
+                        const rphip_csr* Xc = nullptr) {
   if (!ctx || !X || (!out && !dense)) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (out) *out = nullptr;
+  if (!Xc) Xc = X;
+  if (Xc->n_users != X->n_users || Xc->n_items != X->n_items) RP_FAIL(RPHIP_EINVAL, "the two matrices must have the same shape");
   if (row_begin < 0 || row_end > X->n_items || row_begin > row_end)
     RP_FAIL(RPHIP_EINVAL, "row range [%lld,%lld) outside 0..%lld", (long long)row_begin, (long long)row_end, (long long)X->n_items);
   if (K < 1) RP_FAIL(RPHIP_EINVAL, "K must be >= 1 (got %d)", K);
@@ -760,7 +765,7 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
     hipMemsetAsync(m->val, 0, nk * sizeof(double), st);
     hipMemsetAsync(m->nnz, 0, (size_t)std::max(1, n_rows) * sizeof(int32_t), st);
   }
-  if (n_rows == 0 || X->nnz == 0) {
+  if (n_rows == 0 || X->nnz == 0 || Xc->nnz == 0) {
     if (dense) return RPHIP_OK;  // rows without users keep what the caller initialised (zeros + lambda)
     int r = rp_model_finalize_topk(ctx, m);
     if (r != RPHIP_OK) {
@@ -845,16 +850,16 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   }
 
   rp_fit_params P;
-  P.x_ptr = X->x_ptr;
-  P.x_idx = X->x_idx;
+  P.x_ptr = Xc->x_ptr;
+  P.x_idx = Xc->x_idx;
   P.xt_ptr = X->xt_ptr;
   P.xt_idx = X->xt_idx;
   P.deg = X->deg;
   P.inv_deg = colw ? colw : X->inv_deg;
   P.key_pow = key_pow;
-  P.tile_ptr = X->tile_ptr;
+  P.tile_ptr = Xc->tile_ptr;
   P.n_items = (int)X->n_items;
-  P.nnz = (int)X->nnz;
+  P.nnz = (int)Xc->nnz;
   P.n_tiles = T;
   P.tile_w = W;
   P.K = K;
@@ -1039,9 +1044,10 @@ extern "C" int rphip_itemknn_fit_ex(rphip_ctx* ctx, const rphip_csr* X, int64_t 
   return rp_gram_core(ctx, X, row_begin, row_end, K, out, nullptr, 0, 0.0f, dw, 1);
 }
 
-int rp_gram_dense(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, float* G, int64_t ld, float diag_add) {
+int rp_gram_dense(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, float* G, int64_t ld, float diag_add,
+                  const rphip_csr* Xcols) {
   if (!G) RP_FAIL(RPHIP_EINVAL, "NULL argument");
-  return rp_gram_core(ctx, X, row_begin, row_end, 1, nullptr, G, ld, diag_add);
+  return rp_gram_core(ctx, X, row_begin, row_end, 1, nullptr, G, ld, diag_add, nullptr, 2, Xcols);
 }
 
 extern "C" int rphip_model_topk_download(rphip_ctx* ctx, const rphip_model* m, int32_t* idx_host, double* val_host,

@@ -271,3 +271,39 @@ def test_ease_fit_sharded_rccl_one_rank(hip):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "dist_ease_check.py"), "3000", "600", "0.02"], cwd=root, env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("name", ["ref_ease_xy_doc", "syn_ease_xy_1500x300"])
+def test_ease_xy_golden(hip, name):
+    """EASE_XY (experimental/ease_xy.py:61-96): B and predict against the reference's goldens at the EASE tolerance."""
+    from recpack_amd import EASE_XY
+    from recpack_amd.algorithms import to_binary_csr
+
+    _lib, ctx = hip
+    g = load_golden(name)
+    X, Y = csr_from(g, "X"), csr_from(g, "Y")
+    for n, (l2, alpha) in enumerate(zip(g["l2"], g["alpha"])):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            algo = EASE_XY(l2=float(l2), alpha=float(alpha)).fit(X, Y)
+            B = algo.similarity_matrix_.toarray()
+            out = algo.predict(X[:50]).toarray()
+        assert rel_max(B, g[f"B{n}"]) <= EASE_TOL, (name, l2, alpha, rel_max(B, g[f"B{n}"]))
+        assert (np.diag(B) == 0).all()
+        assert rel_max(out, g[f"Pout{n}"]) <= EASE_TOL
+    with pytest.raises(ValueError):
+        EASE_XY(l2=1.0).fit(X, Y[:, :-1])
+
+
+def test_ease_xy_larger_vs_oracle(hip):
+    from recpack_amd.synth import powerlaw_csr
+
+    _lib, ctx = hip
+    X = powerlaw_csr(9000, 1300, 0.01, seed=51).to_scipy()
+    Y = powerlaw_csr(9000, 1300, 0.006, seed=52).to_scipy()
+    dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
+    dY = _lib.DeviceCSR.from_host(ctx, Y.indptr, Y.indices, Y.shape)
+    for l2, alpha in ((100.0, 0.0), (10.0, 0.3)):
+        B = _lib.ease_xy_fit(ctx, dX, dY, l2, alpha).dense_download()
+        ref = onp.ease_xy_fit(X, Y, l2, alpha)
+        assert rel_max(B, ref) <= EASE_TOL, rel_max(B, ref)

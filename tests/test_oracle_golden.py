@@ -194,3 +194,16 @@ def test_itemknn_normalize_X_analytic():
     d = math.sqrt((1 / 2) ** 2 + (1 / 3) ** 2)
     f = math.sqrt(2 * (1 / 2) ** 2 + (1 / 3) ** 2)
     np.testing.assert_almost_equal(S, [[0, a / (d * d), b / (d * f)], [a / (d * d), 0, b / (d * f)], [b / (d * f), b / (d * f), 0]])
+
+
+@pytest.mark.parametrize("name", ["ref_ease_xy_doc", "syn_ease_xy_1500x300"])
+def test_ease_xy_matches_reference(name):
+    # recpack/algorithms/experimental/ease_xy.py:61-96
+    g = load_golden(name)
+    X, Y = csr_from(g, "X"), csr_from(g, "Y")
+    for n, (l2, alpha) in enumerate(zip(g["l2"], g["alpha"])):
+        B = onp.ease_xy_fit(X, Y, float(l2), float(alpha))
+        ref = g[f"B{n}"]
+        assert np.abs(B - ref).max() <= 1e-10 * np.abs(ref).max()
+        out = onp.predict_full(X[:50], sp.csr_matrix(B)).toarray()
+        assert np.abs(out - g[f"Pout{n}"]).max() <= 1e-9 * max(1e-300, np.abs(g[f"Pout{n}"]).max())
