@@ -586,6 +586,7 @@ __device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_st
         if (t + 1 < NT) prepare(b, N);
       }
     }
+    PW_STAMP(4);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (b < nb) {
@@ -612,6 +613,7 @@ __device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_st
     // per lane and round so that the sums of a round are read with one wait
     uint32_t w = S.dirty[lane];
     S.dirty[lane] = 0u;
+    PW_STAMP(5);
     while (__any(w != 0u)) {
       bool has[4];
       int j[4];
@@ -646,16 +648,21 @@ __device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_st
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) live |= __any(kq[q]) ? (1u << q) : 0u;
-      PW_COUNT(4, 1);
       if (!live) continue;
-      PW_COUNT(5, 1);
+      PW_STAMP(2);
 #pragma unroll 1
       for (int q = 0; q < 4 && live; ++q, live >>= 1) {
         if (live & 1u) {
           const uint32_t col = (uint32_t)(t0 + j[0]);
           // the threshold may have moved since the vote (a cut inside an earlier push): ask again
           const bool keep = kq[0] && rp_wpool_admits<uint64_t, 0>(S.pool, v[0], col);
+#ifdef RP_STAMPS
+          const int n_before = S.pool.n;
+#endif
           rp_wpool_push<uint64_t, 0>(S.pool, Kp, cap, keep, v[0], col, lane);
+#ifdef RP_STAMPS
+          if (S.pool.n < n_before) PW_COUNT(6, 1);  // a cut happened
+#endif
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -664,6 +671,7 @@ __device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_st
           v[r] = v[r + 1];
         }
       }
+      PW_STAMP(7);
     }
     PW_STAMP(2);
   };
@@ -945,8 +953,9 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
       unsigned long long h[8];
       hipMemcpyAsync(h, W.stamps, sizeof(h), hipMemcpyDeviceToHost, st);
       hipStreamSynchronize(st);
-      fprintf(stderr, "[stamps predict_wave] cycles/1e6: setup %.1f accumulate %.1f scan+pool %.1f final %.1f (grid %d); walk rounds %llu, with a push %llu\n",
-              h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, wg, h[4], h[5]);
+      fprintf(stderr, "[stamps predict_wave] cycles/1e6: setup %.1f | per tile: prepare %.1f adds %.1f exclusion+dirty %.1f walk %.1f | final %.1f "
+                      "(grid %d); of the walk: push loops %.1f, pool cuts %llu\n",
+              h[0] / 1e6, h[4] / 1e6, h[1] / 1e6, h[5] / 1e6, (h[2] + h[7]) / 1e6, h[3] / 1e6, wg, h[7] / 1e6, h[6]);
     }
 #endif
     rp_time_end(ctx, ev, RPHIP_T_PREDICT, rp_pred_work(Xpred, model, n, Kp));
