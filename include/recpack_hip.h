@@ -207,6 +207,18 @@ int rphip_predict_full_fill(rphip_ctx* ctx, const rphip_model* model, const rphi
  * (l2 * np.identity(dtype=float32), :82).  B stays on the device (fp32).
  */
 int rphip_ease_fit(rphip_ctx* ctx, const rphip_csr* X, double l2, double alpha, rphip_model** out);
+
+/* Sweep over l2 with the Gram computed once (pipelines grid-search l2, e.g. [10, 100, 1000],
+ * recpack doc/source/guides.create_algorithm.rst:681; the reference recomputes X^T X in every EASE._fit,
+ * ease.py:81).  rphip_ease_gram_create keeps G = X^T X (float32, no shift) on the device behind a model
+ * handle that only rphip_ease_fit_gram, rphip_model_dense_device and rphip_model_destroy accept;
+ * rphip_ease_fit_gram(l2, alpha) copies it, adds l2 to the diagonal and runs the solve and the scaling of
+ * rphip_ease_fit: same result, bit for bit.  X must be the matrix the Gram was built from (its item
+ * degrees feed the alpha weights).
+ */
+int rphip_ease_gram_create(rphip_ctx* ctx, const rphip_csr* X, rphip_model** out);
+int rphip_ease_fit_gram(rphip_ctx* ctx, const rphip_csr* X, const rphip_model* gram, double l2, double alpha,
+                        rphip_model** out);
 /* EASE_XY (recpack/algorithms/experimental/ease_xy.py:61-96): reconstruct a second matrix y from X,
  * B = P (X^T y) - P diag(diag(P X^T y) / diag(P)) with P = (X^T X + l2 I)^-1, columns scaled by c_j^-alpha;
  * X and y are binary matrices of the same shape.  Three n x n float32 matrices during the fit. */

@@ -94,6 +94,8 @@ PROTOTYPES = {
     "rphip_model_empty_rows": (C.c_int, [_p, _p, C.POINTER(_i64)]),
     "rphip_gemm_nt_f32": (C.c_int, [_p, _i64, _i64, _i64, C.c_float, _p, _i64, _p, _i64, C.c_float, _p, _i64]),
     "rphip_ease_xy_fit": (C.c_int, [_p, _p, _p, _f64, _f64, _pp]),
+    "rphip_ease_gram_create": (C.c_int, [_p, _p, _pp]),
+    "rphip_ease_fit_gram": (C.c_int, [_p, _p, _p, _f64, _f64, _pp]),
     "rphip_ease_gram_rows": (C.c_int, [_p, _p, _i64, _i64, _i64, _f64, _p, _i64]),
     "rphip_potrf_trtri_128": (C.c_int, [_p, _p, _i64, _p, _p]),
     "rphip_gemm_nt_f32_ex": (C.c_int, [_p, _i64, _i64, _i64, _i64, C.c_float, _p, _i64, _p, _i64, C.c_float, _p, _i64, _i32, _i32, _i64, _i64, _i32]),
@@ -395,6 +397,19 @@ def itemknn_fit(ctx: Context, X: DeviceCSR, K: int, row_begin: int = 0, row_end:
 def ease_fit(ctx: Context, X: DeviceCSR, l2: float, alpha: float = 0.0) -> Model:
     h = C.c_void_p()
     check(ctx.lib.rphip_ease_fit(ctx.handle, X.handle, float(l2), float(alpha), C.byref(h)))
+    return Model(ctx, h)
+
+
+def ease_gram_create(ctx: Context, X: DeviceCSR) -> Model:
+    """G = X^T X kept on the device for a sweep over l2 (a handle for ease_fit_gram, not a model to predict with)."""
+    h = C.c_void_p()
+    check(ctx.lib.rphip_ease_gram_create(ctx.handle, X.handle, C.byref(h)))
+    return Model(ctx, h)
+
+
+def ease_fit_gram(ctx: Context, X: DeviceCSR, gram: Model, l2: float, alpha: float = 0.0) -> Model:
+    h = C.c_void_p()
+    check(ctx.lib.rphip_ease_fit_gram(ctx.handle, X.handle, gram.handle, float(l2), float(alpha), C.byref(h)))
     return Model(ctx, h)
 
 

@@ -323,6 +323,58 @@ class EASE(ItemSimilarityMatrixAlgorithm):
             warnings.warn(f"{self.name} missing similar items for {self._empty_rows_} items.")
 
 
+class EASEGram:
+    """The part of an EASE fit that does not depend on ``l2`` or ``alpha``, computed once: the device copy of X and its Gram.
+
+    recpack's pipelines grid-search ``l2`` (doc/source/guides.create_algorithm.rst:681, ``"l2": [10, 100, 1000]``) and the
+    reference recomputes X^T X in every ``_fit`` (ease.py:81).  Usage::
+
+        with EASEGram(X) as g:
+            for l2 in (10, 100, 1000):
+                algo = g.fit(EASE(l2=l2))      # == EASE(l2=l2).fit(X), bit for bit
+    """
+
+    def __init__(self, X):
+        X = to_binary_csr(X)
+        self.shape = X.shape
+        self._ctx = get_context()
+        self._dX = _lib.DeviceCSR.from_host(self._ctx, X.indptr, X.indices, X.shape)
+        try:
+            self._gram = _lib.ease_gram_create(self._ctx, self._dX)
+        except Exception:
+            self._dX.close()
+            raise
+
+    def fit(self, algo: "EASE") -> "EASE":
+        """Fit ``algo`` (an EASE with its own l2 / alpha / density) from the cached Gram; returns ``algo``."""
+        if self._gram is None:
+            raise RuntimeError("EASEGram is closed")
+        if type(algo) is not EASE:
+            raise TypeError("EASEGram.fit takes an EASE instance")
+        start = time.time()
+        algo._model = _lib.ease_fit_gram(self._ctx, self._dX, self._gram, float(algo.l2), float(algo.alpha))
+        algo._sim_cache = None
+        algo.n_items_ = self.shape[1]
+        if algo.density:
+            algo._prune()
+        algo._empty_rows_ = algo._model.empty_rows()
+        algo._check_fit_complete()
+        logger.info(f"fitting {algo.name} complete - Took {time.time() - start :.3}s")
+        return algo
+
+    def close(self):
+        if self._gram is not None:
+            self._gram.close()
+            self._dX.close()
+            self._gram = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 class EASE_XY(EASE):
     """EASE_XY (recpack/algorithms/experimental/ease_xy.py:20-96): EASE trained to reconstruct a second matrix ``y`` from ``X``
     (``fit(X, y)``), B = P (X^T y) - P diag(diag(P X^T y) / diag(P)) with P = (X^T X + l2 I)^-1; predict as EASE."""

@@ -727,23 +727,16 @@ extern "C" int rphip_ease_xy_fit(rphip_ctx* ctx, const rphip_csr* X, const rphip
   return RPHIP_OK;
 }
 
-extern "C" int rphip_ease_fit(rphip_ctx* ctx, const rphip_csr* X, double l2, double alpha, rphip_model** out) {
-  if (!ctx || !X || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
-  *out = nullptr;
-  if (!(l2 > 0.0)) RP_FAIL(RPHIP_EINVAL, "l2 must be > 0 (got %g): G + l2*I has to be positive definite", l2);
-  if (X->xt_row_end >= 0) RP_FAIL(RPHIP_ESTATE, "EASE needs a matrix with all item rows of X^T (not rphip_csr_from_device_rows)");
-  RP_TRY(rp_set_device(ctx));
-  const int n = (int)X->n_items;
-  if (n <= 0) RP_FAIL(RPHIP_EINVAL, "no items");
+// a dense n_pad x n_pad model (B) and, for a solve, the second matrix of the same size
+static int rp_ease_alloc(rphip_ctx* ctx, int n, int n_mats, rphip_model** mo, float** Nb) {
   const int n_pad = (int)(rp_cdiv(n, GT) * GT);
   const long long ld = n_pad;
   const size_t bytes = (size_t)n_pad * ld * sizeof(float);
   size_t free_b = 0, total_b = 0;
   hipMemGetInfo(&free_b, &total_b);
-  if (2 * bytes + (1ull << 30) > free_b)
-    RP_FAIL(RPHIP_ENOMEM, "EASE with %d items needs %.1f GB of HBM (two %d x %d f32 matrices), %.1f GB free", n, 2 * bytes / 1e9, n_pad, n_pad,
-            free_b / 1e9);
-  hipStream_t st = ctx->stream;
+  if (n_mats * bytes + (1ull << 30) > free_b)
+    RP_FAIL(RPHIP_ENOMEM, "EASE with %d items needs %.1f GB of HBM (%d %d x %d f32 matrices), %.1f GB free", n, n_mats * bytes / 1e9, n_mats,
+            n_pad, n_pad, free_b / 1e9);
   rphip_model* m = new rphip_model();
   m->ctx = ctx;
   m->kind = RPHIP_MODEL_DENSE;
@@ -752,34 +745,115 @@ extern "C" int rphip_ease_fit(rphip_ctx* ctx, const rphip_csr* X, double l2, dou
   m->row_end = n;
   m->K = 0;
   m->ld = ld;
-  float* Nb = nullptr;
-  if (hipMalloc((void**)&m->B, bytes) != hipSuccess || hipMalloc((void**)&Nb, bytes) != hipSuccess) {
-    if (Nb) hipFree(Nb);
+  *Nb = nullptr;
+  if (hipMalloc((void**)&m->B, bytes) != hipSuccess || (n_mats > 1 && hipMalloc((void**)Nb, bytes) != hipSuccess)) {
+    if (*Nb) hipFree(*Nb);
+    *Nb = nullptr;
     rphip_model_destroy(m);
     RP_FAIL(RPHIP_ENOMEM, "hipMalloc of the dense matrices failed");
   }
-  // lambda is rounded to float32 exactly as the reference does (l2 * np.identity(dtype=float32), ease.py:82)
-  const float lam = (float)l2;
-  hipLaunchKernelGGL(k_ease_init, dim3(4096), dim3(256), 0, st, m->B, ld, n, n_pad, lam);
-  int r = rp_gram_dense(ctx, X, 0, n, m->B, ld, lam);
-  if (r == RPHIP_OK) r = rp_spd_inverse(ctx, m->B, Nb, n_pad, ld);
+  *mo = m;
+  return RPHIP_OK;
+}
+
+// m->B holds G + lambda I (identity on the padding): P = its inverse (K5/K6, Nb = workspace, freed here), then K7
+static int rp_ease_solve_scale(rphip_ctx* ctx, const rphip_csr* X, rphip_model* m, float* Nb, double alpha) {
+  hipStream_t st = ctx->stream;
+  const int n = (int)m->n_items;
+  const int n_pad = (int)m->ld;
+  int r = rp_spd_inverse(ctx, m->B, Nb, n_pad, m->ld);
   hipStreamSynchronize(st);
   hipFree(Nb);
-  if (r != RPHIP_OK) {
-    rphip_model_destroy(m);
-    return r;
-  }
+  if (r != RPHIP_OK) return r;
   // ---- K7
   hipEvent_t ev;
   rp_time_begin(ctx, &ev);
   float* colscale = nullptr;
   RP_TRY(rp_scratch(ctx, 5, (size_t)n_pad * 4, (void**)&colscale));
-  hipLaunchKernelGGL(k_ease_diag, dim3((unsigned)rp_cdiv(n, 256)), dim3(256), 0, st, m->B, ld, n, X->deg, (float)alpha, colscale);
-  hipLaunchKernelGGL(k_ease_scale, dim3(4096), dim3(256), 0, st, m->B, ld, n, colscale);
+  hipLaunchKernelGGL(k_ease_diag, dim3((unsigned)rp_cdiv(n, 256)), dim3(256), 0, st, m->B, m->ld, n, X->deg, (float)alpha, colscale);
+  hipLaunchKernelGGL(k_ease_scale, dim3(4096), dim3(256), 0, st, m->B, m->ld, n, colscale);
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, RPHIP_T_EASE_SCALE, 8.0 * (double)n * (double)n);
   RP_HIP(hipStreamSynchronize(st));
-  r = rp_dense_count_empty(ctx, m);
+  return rp_dense_count_empty(ctx, m);
+}
+
+extern "C" int rphip_ease_fit(rphip_ctx* ctx, const rphip_csr* X, double l2, double alpha, rphip_model** out) {
+  if (!ctx || !X || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (!(l2 > 0.0)) RP_FAIL(RPHIP_EINVAL, "l2 must be > 0 (got %g): G + l2*I has to be positive definite", l2);
+  if (X->xt_row_end >= 0) RP_FAIL(RPHIP_ESTATE, "EASE needs a matrix with all item rows of X^T (not rphip_csr_from_device_rows)");
+  RP_TRY(rp_set_device(ctx));
+  const int n = (int)X->n_items;
+  if (n <= 0) RP_FAIL(RPHIP_EINVAL, "no items");
+  rphip_model* m = nullptr;
+  float* Nb = nullptr;
+  RP_TRY(rp_ease_alloc(ctx, n, 2, &m, &Nb));
+  // lambda is rounded to float32 exactly as the reference does (l2 * np.identity(dtype=float32), ease.py:82)
+  const float lam = (float)l2;
+  hipLaunchKernelGGL(k_ease_init, dim3(4096), dim3(256), 0, ctx->stream, m->B, m->ld, n, (int)m->ld, lam);
+  int r = rp_gram_dense(ctx, X, 0, n, m->B, m->ld, lam);
+  if (r != RPHIP_OK) {
+    hipStreamSynchronize(ctx->stream);
+    hipFree(Nb);
+  } else {
+    r = rp_ease_solve_scale(ctx, X, m, Nb, alpha);
+  }
+  if (r != RPHIP_OK) {
+    rphip_model_destroy(m);
+    return r;
+  }
+  *out = m;
+  return RPHIP_OK;
+}
+
+// ---- the Gram kept for a sweep over l2 (pipelines grid-search l2, e.g. [10, 100, 1000]: the Gram does not depend on it)
+__global__ void k_add_diag(float* __restrict__ G, long long ld, int n, float lam) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) G[(long long)i * ld + i] += lam;
+}
+
+extern "C" int rphip_ease_gram_create(rphip_ctx* ctx, const rphip_csr* X, rphip_model** out) {
+  if (!ctx || !X || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (X->xt_row_end >= 0) RP_FAIL(RPHIP_ESTATE, "EASE needs a matrix with all item rows of X^T (not rphip_csr_from_device_rows)");
+  RP_TRY(rp_set_device(ctx));
+  const int n = (int)X->n_items;
+  if (n <= 0) RP_FAIL(RPHIP_EINVAL, "no items");
+  rphip_model* m = nullptr;
+  float* none = nullptr;
+  RP_TRY(rp_ease_alloc(ctx, n, 1, &m, &none));
+  m->is_gram = true;
+  hipLaunchKernelGGL(k_ease_init, dim3(4096), dim3(256), 0, ctx->stream, m->B, m->ld, n, (int)m->ld, 0.0f);
+  int r = rp_gram_dense(ctx, X, 0, n, m->B, m->ld, 0.0f);
+  if (r == RPHIP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) r = RPHIP_EHIP;
+  if (r != RPHIP_OK) {
+    rphip_model_destroy(m);
+    return r;
+  }
+  *out = m;
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_ease_fit_gram(rphip_ctx* ctx, const rphip_csr* X, const rphip_model* gram, double l2, double alpha, rphip_model** out) {
+  if (!ctx || !X || !gram || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (!(l2 > 0.0)) RP_FAIL(RPHIP_EINVAL, "l2 must be > 0 (got %g): G + l2*I has to be positive definite", l2);
+  if (!gram->is_gram || gram->kind != RPHIP_MODEL_DENSE) RP_FAIL(RPHIP_ESTATE, "not a Gram from rphip_ease_gram_create");
+  if (gram->n_items != X->n_items) RP_FAIL(RPHIP_EINVAL, "the Gram has %lld items, the matrix %lld", (long long)gram->n_items, (long long)X->n_items);
+  RP_TRY(rp_set_device(ctx));
+  const int n = (int)X->n_items;
+  rphip_model* m = nullptr;
+  float* Nb = nullptr;
+  RP_TRY(rp_ease_alloc(ctx, n, 2, &m, &Nb));
+  int r = RPHIP_OK;
+  if (hipMemcpyAsync(m->B, gram->B, (size_t)m->ld * m->ld * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) r = RPHIP_EHIP;
+  if (r == RPHIP_OK) {
+    // integer counts plus the float32 lambda: the same float32 sum the fused epilogue of rphip_ease_fit produces
+    hipLaunchKernelGGL(k_add_diag, dim3((unsigned)rp_cdiv(n, 256)), dim3(256), 0, ctx->stream, m->B, m->ld, n, (float)l2);
+    r = rp_ease_solve_scale(ctx, X, m, Nb, alpha);
+  } else {
+    hipFree(Nb);
+  }
   if (r != RPHIP_OK) {
     rphip_model_destroy(m);
     return r;

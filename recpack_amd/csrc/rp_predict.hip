@@ -811,6 +811,7 @@ int rp_model_finalize_topk(rphip_ctx* ctx, rphip_model* m) {
 static int rp_pred_check(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* X, int64_t ub, int64_t ue) {
   if (!ctx || !model || !X) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (model->kind != RPHIP_MODEL_TOPK && model->kind != RPHIP_MODEL_DENSE) RP_FAIL(RPHIP_ESTATE, "unknown model kind");
+  if (model->is_gram) RP_FAIL(RPHIP_ESTATE, "this handle holds a Gram matrix (rphip_ease_gram_create), not a fitted model");
   if (model->row_begin != 0 || model->row_end != model->n_items)
     RP_FAIL(RPHIP_ESTATE, "the model holds rows [%lld,%lld) of %lld: assemble all rows before predict", (long long)model->row_begin,
             (long long)model->row_end, (long long)model->n_items);

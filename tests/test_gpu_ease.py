@@ -307,3 +307,28 @@ def test_ease_xy_larger_vs_oracle(hip):
         B = _lib.ease_xy_fit(ctx, dX, dY, l2, alpha).dense_download()
         ref = onp.ease_xy_fit(X, Y, l2, alpha)
         assert rel_max(B, ref) <= EASE_TOL, rel_max(B, ref)
+
+
+def test_ease_l2_sweep_from_cached_gram(hip):
+    """a sweep over l2 (and alpha) with the Gram computed once equals independent fits bit for bit, and the
+    float64 oracle within the EASE tolerance; the Gram handle is refused by predict."""
+    from recpack_amd import EASE, EASEGram
+
+    _lib, ctx = hip
+    rng = np.random.default_rng(77)
+    X = sp.random(900, 300, density=0.03, random_state=rng, format="csr")
+    X.data[:] = 1.0
+    with EASEGram(X) as g:
+        with pytest.raises(_lib.RecpackHipError):
+            _lib.predict_topk(ctx, g._gram, g._dX, 5, False)
+        for l2, alpha in [(10.0, 0.0), (100.0, 0.0), (1000.0, 0.5)]:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                swept = g.fit(EASE(l2=l2, alpha=alpha))
+                alone = EASE(l2=l2, alpha=alpha).fit(X)
+            B_s, B_a = swept._model.dense_download(), alone._model.dense_download()
+            assert np.array_equal(B_s, B_a)
+            B_ref = onp.ease_fit(X, l2=l2, alpha=alpha)
+            assert rel_max(B_s.astype(np.float64), B_ref) <= EASE_TOL
+    with pytest.raises(RuntimeError):
+        g.fit(EASE(l2=1.0))
