@@ -149,6 +149,31 @@ int rphip_itemknn_fit(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int
 #define RPHIP_SIM_CONDITIONAL_PROBABILITY 1
 int rphip_itemknn_fit_ex(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K,
                          int32_t similarity, double pop_discount, int32_t normalize_X, rphip_model** out);
+/* ---- valued matrices: the time-aware ItemKNN family --------------------------------------------------
+ * TARSItemKNN (recpack/algorithms/time_aware_item_knn/base.py:34-201) weighs every interaction by a decay of its age
+ * (_add_decay_to_interaction_matrix, :181-195; the host class computes the weights), fits cosine / conditional
+ * probability / pearson on the weighted matrix (:166-179) and multiplies the weighted history with the neighbour
+ * lists (:139-150).
+ *
+ * rphip_csr_set_values attaches float64 values to the stored entries of a matrix handle (values_host[k] belongs to
+ * indices[k] as uploaded; NULL detaches them).  The binary fits above ignore them, as the reference's ItemKNN / EASE
+ * binarise their input (base.py:141-151).  EVERY predict entry point multiplies a neighbour-list model with the valued
+ * matrix when values are attached: score[u, j] = sum_i X[u, i] * S[i, j], each term the float64 product rounded once
+ * into the fixed-point sum (same bit-reproducible sums as the binary case); a dense model refuses a valued matrix.
+ *
+ * rphip_itemknn_fit_values: G_ij = sum over the users u of item i that hold j of L_ui * X_uj with L = X
+ * (left_binary = 0) or L = 1 (left_binary != 0: to_binary(X).T @ X, nearest_neighbour.py:45), then
+ * S_ij = G_ij * row_scale[i] (NULL: 1), diagonal excluded, top K per row with get_top_K_values' handling of stored
+ * zeros (recpack/util.py:80-96; see rp_itemknn_v.hip).  The host class passes
+ *   cosine / pearson          columns of the (centred) weighted matrix scaled to unit length, left_binary = 0
+ *                             (sklearn's cosine_similarity normalises first; nearest_neighbour.py:69-118)
+ *   conditional probability   the weighted matrix, left_binary = 1, row_scale[i] = 1 / c_i   (:22-66, pop_discount 0)
+ * Rows must be column-sorted.  Values agree with the reference to 1e-11 relative (float64 sums in a different order).
+ */
+int rphip_csr_set_values(rphip_ctx* ctx, rphip_csr* X, const double* values_host);
+int rphip_itemknn_fit_values(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K,
+                             int32_t left_binary, const double* row_scale_host, rphip_model** out);
+
 /* neighbour lists to host: idx int32[rows*K] (-1 padded), val float64[rows*K] (0 padded), nnz int32[rows] */
 int rphip_model_topk_download(rphip_ctx* ctx, const rphip_model* m, int32_t* idx_host, double* val_host,
                               int32_t* nnz_host);

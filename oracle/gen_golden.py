@@ -275,7 +275,89 @@ def pipeline_case():
     save("c1_pipeline_ml100k", **arrays)
 
 
+def _tars_events(seed, U, I, n_events, t_max=2_000_000):
+    """Seeded event log with repeated (user, item) pairs: power-law users and items, integer timestamps >= 1."""
+    rng = np.random.default_rng(seed)
+    pu = 1.0 / np.arange(1, U + 1) ** 0.7
+    pi = 1.0 / np.arange(1, I + 1) ** 0.9
+    uid = rng.choice(U, size=n_events, p=pu / pu.sum())
+    iid = rng.permutation(I)[rng.choice(I, size=n_events, p=pi / pi.sum())]
+    ts = rng.integers(1, t_max, size=n_events)
+    return uid.astype(np.int64), iid.astype(np.int64), ts.astype(np.int64)
+
+
+def _tars_run(algo, im, arrays, tag, weights=False):
+    if weights:  # the weighted matrices the algorithm builds (host logic of the drop-in classes)
+        arrays.update(csr_parts(f"Wfit_{tag}", algo._add_decay_to_fit_matrix(im)))
+        arrays.update(csr_parts(f"Wpred_{tag}", algo._add_decay_to_predict_matrix(im)))
+    algo.fit(im)
+    arrays.update(csr_parts(f"S_{tag}", algo.similarity_matrix_))
+    arrays.update(csr_parts(f"P_{tag}", algo.predict(im)))
+
+
+def tars_cases():
+    """Time-aware ItemKNN (recpack/algorithms/time_aware_item_knn/): the reference's own fixture
+    (recpack/tests/conftest.py:68-77 ``mat``, used by test_time_aware_item_knn_base.py:54-110) and seeded event logs;
+    every decay function x similarity of TARSItemKNN plus the weight-only variants.  Stored per case: the events,
+    ``similarity_matrix_`` and ``predict`` of the same interactions."""
+    import pandas as pd
+    from recpack.algorithms.time_aware_item_knn import (TARSItemKNN, TARSItemKNNDing, TARSItemKNNLee, TARSItemKNNLiu,
+                                                        TARSItemKNNLiu2012, TARSItemKNNVaz)
+    from recpack.matrix import InteractionMatrix
+
+    def matrix(uid, iid, ts, shape):
+        df = pd.DataFrame({"uid": uid, "iid": iid, "ts": ts})
+        im = InteractionMatrix(df, "iid", "uid", timestamp_ix="ts", shape=shape)
+        return im
+
+    # --- reference fixture
+    uid = np.array([0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5])
+    iid = np.array([0, 1, 2, 3, 0, 1, 2, 4, 0, 1, 2])
+    ts = np.array([3, 2, 1, 4, 0, 1, 2, 4, 0, 1, 2])
+    im = matrix(uid, iid, ts, (6, 5))
+    arrays = {"uid": uid, "iid": iid, "ts": ts, "shape": np.array([6, 5]), "K": np.array([2])}
+    arrays.update(csr_parts("T", im.last_timestamps_matrix))
+    for sim in ("cosine", "conditional_probability", "pearson"):
+        _tars_run(TARSItemKNN(K=2, fit_decay=0.5, predict_decay=0.5, similarity=sim), im, arrays, sim)
+    save("ref_tars_mat", **arrays)
+
+    # --- seeded log, every decay function x similarity
+    U, I, K = 400, 150, 10
+    uid, iid, ts = _tars_events(20260701, U, I, 7000)
+    im = matrix(uid, iid, ts, (U, I))
+    arrays = {"uid": uid, "iid": iid, "ts": ts, "shape": np.array([U, I]), "K": np.array([K]), "decay_interval": np.array([3600])}
+    decays = {"exponential": 0.004, "convex": 0.995, "concave": 0.3, "log": 5.0, "linear": 0.8, "inverse": 0.5}
+    arrays["decay_names"] = np.array(list(decays.keys()))
+    arrays["decay_values"] = np.array(list(decays.values()))
+    for fn, d in decays.items():
+        for sim in ("cosine", "conditional_probability", "pearson"):
+            _tars_run(TARSItemKNN(K=K, fit_decay=d, predict_decay=d, decay_interval=3600, similarity=sim, decay_function=fn), im, arrays,
+                      f"{fn}_{sim}", weights=(sim == "cosine"))
+    # weight-only variants
+    _tars_run(TARSItemKNNDing(K=K, predict_decay=1 / (24 * 3600), similarity="conditional_probability"), im, arrays, "ding")
+    _tars_run(TARSItemKNNLiu(K=K, fit_decay=1 / (24 * 3600), predict_decay=1 / (7 * 24 * 3600)), im, arrays, "liu")
+    _tars_run(TARSItemKNNVaz(K=K, fit_decay=1 / (24 * 3600), predict_decay=1 / (24 * 3600)), im, arrays, "vaz")
+    _tars_run(TARSItemKNNLiu2012(K=K, decay=3.0), im, arrays, "liu2012", weights=True)
+    for w in (3, 5):
+        for sim in ("cosine", "pearson"):
+            _tars_run(TARSItemKNNLee(K=K, w=w, similarity=sim), im, arrays, f"lee{w}_{sim}", weights=(sim == "cosine"))
+    save("syn_tars_400x150", **arrays)
+
+    # --- more items than one weighted LDS tile (12288 columns): per-tile candidates + merge
+    U, I, K = 3000, 13000, 5
+    uid, iid, ts = _tars_events(20260702, U, I, 60000)
+    im = matrix(uid, iid, ts, (U, I))
+    arrays = {"uid": uid, "iid": iid, "ts": ts, "shape": np.array([U, I]), "K": np.array([K])}
+    for sim in ("cosine", "pearson", "conditional_probability"):
+        algo = TARSItemKNN(K=K, fit_decay=1 / (24 * 3600), predict_decay=1 / (24 * 3600), similarity=sim).fit(im)
+        arrays.update(csr_parts(f"S_{sim}", algo.similarity_matrix_))
+    save("syn_tars_3000x13000", **arrays)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "tars":
+        tars_cases()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "pipeline":
         pipeline_case()
     elif len(sys.argv) > 1 and sys.argv[1] == "normalized":

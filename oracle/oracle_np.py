@@ -338,3 +338,113 @@ def metrics_topk(y_true: sp.csr_matrix, scores: sp.csr_matrix, K: int) -> dict:
         crec.append(hit.sum() / min(K, len(true)))
     return {"ndcg": float(np.mean(ndcg)), "recall": float(np.mean(rec)), "calibrated_recall": float(np.mean(crec)),
             "coverage": len(covered) / scores.shape[1]}
+
+
+# --------------------------------------------------------------------------------------
+# time-aware ItemKNN (recpack/algorithms/time_aware_item_knn/)
+# --------------------------------------------------------------------------------------
+def tars_decay(kind: str, decay: float, x: np.ndarray, max_distance: float) -> np.ndarray:
+    """decay_functions.py: ExponentialDecay :24-60, ConvexDecay :63-99, ConcaveDecay :102-142, LogDecay :145-185,
+    LinearDecay :188-228, InverseDecay :231-252; ``none`` is NoDecay (:255-259), ``liu`` is LiuDecay (liu_2012.py:16-48)."""
+    x = np.asarray(x, dtype=np.float64)
+    if kind == "none":
+        return np.exp(-0 * x)
+    if kind == "exponential":
+        return np.exp(-decay * x)
+    if kind == "convex":
+        return np.power(decay, x)
+    if kind == "concave":
+        return 1 - np.power(decay, 1 - (x / max_distance))
+    if kind == "log":
+        return np.log(((decay - 1) * (1 - x / max_distance)) + 1) / np.log(decay)
+    if kind == "linear":
+        r = 1 - (x / max_distance) * decay
+        r[r < 0] = 0
+        return r
+    if kind == "inverse":
+        r = x.astype(float).copy()
+        r[r > 0] = 1 / r[r > 0]
+        r[r == 0] = 1
+        return r
+    if kind == "liu":
+        return (np.log(((decay - 1) * x) + 1) / np.log(decay)) + 1
+    raise ValueError(kind)
+
+
+def tars_weights(T: sp.csr_matrix, decay: float, decay_function: str, decay_interval: int = 1) -> sp.csr_matrix:
+    """TARSItemKNN._add_decay_to_interaction_matrix (time_aware_item_knn/base.py:181-195) on the last-timestamp matrix T
+    (stored entries, timestamp 0 included): now = max + 1, age = (now - t) / interval, weight = decay(age)."""
+    T = sp.csr_matrix(T)
+    now = T.data.max() + 1
+    ages = (now - T.data) / decay_interval
+    kind = "none" if decay == 0 else decay_function
+    return sp.csr_matrix((tars_decay(kind, decay, ages, ages.max()), T.indices.copy(), T.indptr.copy()), shape=T.shape)
+
+
+def tars_similarity(W: sp.csr_matrix, similarity: str) -> sp.csr_matrix:
+    """The full item-item similarity of a weighted matrix, diagonal removed, zero sums not stored (scipy's product drops
+    them): compute_cosine_similarity (nearest_neighbour.py:69-84: unit-length item vectors, then the product),
+    compute_conditional_probability (:22-66, pop_discount 0: to_binary(X).T @ X, rows over the item frequencies),
+    compute_pearson_similarity (:87-112: positive entries centred by the item's mean of positive entries, then cosine)."""
+    W = sp.csr_matrix(W, dtype=np.float64)
+    n = W.shape[1]
+    if similarity == "pearson":
+        if (W == 1).sum() == W.nnz:
+            raise ValueError("Pearson similarity can not be computed on a binary matrix.")
+        cnt = np.asarray((W > 0).sum(axis=0)).ravel()
+        avg = np.asarray(W.sum(axis=0)).ravel().astype(float)
+        avg[cnt > 0] = avg[cnt > 0] / cnt[cnt > 0]
+        W = sp.csr_matrix(W - (W > 0).multiply(avg[None, :]))
+    if similarity in ("cosine", "pearson"):
+        Wt = sp.csr_matrix(W.T)
+        norms = np.sqrt(np.asarray(Wt.multiply(Wt).sum(axis=1)).ravel())
+        norms[norms == 0] = 1.0
+        Wn = Wt.copy()  # rows of X.T to unit length: a division per entry, as sklearn's normalize does
+        Wn.data = Wt.data / np.repeat(norms, np.diff(Wt.indptr))
+        S = sp.csr_matrix(Wn @ Wn.T)
+    elif similarity == "conditional_probability":
+        Wb = sp.csr_matrix(W.astype(bool).astype(np.float64))
+        co = Wb.T @ W
+        c = np.asarray(Wb.sum(axis=0)).ravel()
+        inv = np.zeros(n)
+        inv[c != 0] = 1.0 / c[c != 0]
+        S = sp.csr_matrix(sp.diags(inv) @ co)
+    else:
+        raise ValueError(similarity)
+    S.setdiag(0)
+    S.eliminate_zeros()
+    S.sort_indices()
+    return S
+
+
+def tars_fit(W: sp.csr_matrix, K: int, similarity: str):
+    """TARSItemKNN._fit (base.py:166-179): similarity of the weighted matrix, then get_top_K_values (recpack/util.py:80-96)
+    over the STORED entries - the non-zero similarities plus the explicit 0 that setdiag(0) leaves on the diagonal, which
+    outranks negative entries (pearson) - and the result without its zeros.  Rank order: value desc, column asc."""
+    S = tars_similarity(W, similarity)
+    n = S.shape[0]
+    gi = np.concatenate([np.repeat(np.arange(n, dtype=np.int64), np.diff(S.indptr)), np.arange(n, dtype=np.int64)])
+    gj = np.concatenate([S.indices.astype(np.int64), np.arange(n, dtype=np.int64)])
+    gv = np.concatenate([S.data.astype(np.float64), np.zeros(n)])
+    order = np.lexsort((gj, gi))
+    gi, gj, gv = gi[order], gj[order], gv[order]
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(gi, minlength=n), out=indptr[1:])
+    sel, _ = _segment_topk(indptr, gj, gv, K)
+    sel = sel[gv[sel] != 0]
+    nsel = np.bincount(gi[sel], minlength=n)
+    idx = np.full((n, K), -1, dtype=np.int32)
+    out = np.zeros((n, K), dtype=np.float64)
+    r = gi[sel]
+    pos = np.arange(sel.shape[0]) - np.repeat(np.concatenate([[0], np.cumsum(nsel)[:-1]]), nsel)
+    idx[r, pos] = gj[sel]
+    out[r, pos] = gv[sel]
+    return {"idx": idx, "val": out, "nnz": nsel.astype(np.int32), "full": S}
+
+
+def tars_predict(Wp: sp.csr_matrix, S: sp.csr_matrix) -> sp.csr_matrix:
+    """TARSItemKNN._predict (base.py:139-150): the decayed history times the similarity matrix; zero sums are not stored."""
+    P = sp.csr_matrix(sp.csr_matrix(Wp, dtype=np.float64) @ sp.csr_matrix(S, dtype=np.float64))
+    P.eliminate_zeros()
+    P.sort_indices()
+    return P

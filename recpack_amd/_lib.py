@@ -86,6 +86,8 @@ PROTOTYPES = {
     "rphip_predict_topk_filtered_dev": (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _i32, _p, _p, _p, _p]),
     "rphip_predict_full_count": (C.c_int, [_p, _p, _p, _i64, _i64, _p, C.POINTER(_i64)]),
     "rphip_predict_full_fill": (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p, _p]),
+    "rphip_csr_set_values": (C.c_int, [_p, _p, _p]),
+    "rphip_itemknn_fit_values": (C.c_int, [_p, _p, _i64, _i64, _i32, _i32, _p, _pp]),
     "rphip_ease_fit": (C.c_int, [_p, _p, _f64, _f64, _pp]),
     "rphip_model_dense_download": (C.c_int, [_p, _p, _p]),
     "rphip_model_dense_device": (C.c_int, [_p, _pp, C.POINTER(_i64), C.POINTER(_i64)]),
@@ -268,6 +270,29 @@ class DeviceCSR:
         check(self.ctx.lib.rphip_csr_download(self.ctx.handle, self.handle, _np_ptr(indptr), _np_ptr(indices)))
         return indptr, indices[: self.nnz]
 
+    @classmethod
+    def from_host_valued(cls, ctx: Context, X):
+        """From a scipy CSR with float values (sorted indices, no duplicates): pattern + values (rphip_csr_set_values)."""
+        m = cls.from_host(ctx, X.indptr, X.indices, X.shape)
+        try:
+            m.set_values(X.data)
+        except Exception:
+            m.close()
+            raise
+        return m
+
+    def set_values(self, values):
+        """Attach float64 values to the stored entries (order of the uploaded indices); None detaches them."""
+        if values is None:
+            check(self.ctx.lib.rphip_csr_set_values(self.ctx.handle, self.handle, None))
+            return
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        if values.shape != (self.nnz,):
+            raise ValueError(f"set_values: {values.shape} values for {self.nnz} stored entries")
+        if self.nnz == 0:
+            values = np.zeros(1)
+        check(self.ctx.lib.rphip_csr_set_values(self.ctx.handle, self.handle, _np_ptr(values)))
+
     def item_degrees(self) -> np.ndarray:
         out = np.empty(self.shape[1], dtype=np.int32)
         check(self.ctx.lib.rphip_csr_item_degrees(self.ctx.handle, self.handle, _np_ptr(out)))
@@ -391,6 +416,21 @@ def itemknn_fit(ctx: Context, X: DeviceCSR, K: int, row_begin: int = 0, row_end:
     else:
         check(ctx.lib.rphip_itemknn_fit_ex(ctx.handle, X.handle, int(row_begin), int(row_end), int(K), int(similarity),
                                            float(pop_discount), 1 if normalize_X else 0, C.byref(h)))
+    return Model(ctx, h)
+
+
+def itemknn_fit_values(ctx: Context, X: DeviceCSR, K: int, left_binary: bool = False, row_scale=None, row_begin: int = 0,
+                       row_end=None) -> Model:
+    """Top-K of G = L^T X on a valued matrix (L = X, or its pattern with left_binary), rows scaled by row_scale."""
+    h = C.c_void_p()
+    row_end = X.shape[1] if row_end is None else row_end
+    rs = None
+    if row_scale is not None:
+        rs = np.ascontiguousarray(row_scale, dtype=np.float64)
+        if rs.shape != (X.shape[1],):
+            raise ValueError("row_scale must have one entry per item")
+    check(ctx.lib.rphip_itemknn_fit_values(ctx.handle, X.handle, int(row_begin), int(row_end), int(K), 1 if left_binary else 0,
+                                           _np_ptr(rs) if rs is not None else None, C.byref(h)))
     return Model(ctx, h)
 
 

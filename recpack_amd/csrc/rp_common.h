@@ -85,6 +85,11 @@ struct rphip_csr {
   bool sorted_rows = false;
   int max_user_deg = 0;            // longest history (bounds |score| for predict's fixed-point scale)
   int64_t xt_row_begin = 0, xt_row_end = -1;  // item rows of X^T that were filled (-1: all); fit is limited to them
+  // optional float64 values of the stored entries (rphip_csr_set_values): the reference's weighted matrices
+  // (time decay, time_aware_item_knn/base.py:181-201).  NULL: the matrix is binary.
+  double* x_val = nullptr;         // [nnz], order of x_idx
+  double val_max_abs = 0.0;
+  bool val_neg = false;            // some value is negative
 };
 
 struct rphip_model {

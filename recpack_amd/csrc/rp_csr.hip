@@ -13,6 +13,8 @@
 //   k_inv_deg     inv_deg[j] = fl(1/c_j)
 #include <algorithm>
 
+#include <cmath>
+
 #include "rp_common.h"
 
 // Degrees and in-row ranks without hot global atomics: the item axis is cut into ranges that fit LDS, a block
@@ -295,7 +297,41 @@ extern "C" int rphip_csr_destroy(rphip_csr* m) {
   if (m->inv_deg) hipFree(m->inv_deg);
   if (m->tile_ptr) hipFree(m->tile_ptr);
   if (m->row_cost) hipFree(m->row_cost);
+  if (m->x_val) hipFree(m->x_val);
   delete m;
+  return RPHIP_OK;
+}
+
+// Values for the stored entries (NULL: back to binary).  Scanned on the host for the largest magnitude (predict's
+// fixed-point scale) and for negative entries (the signed selection rules of the weighted fit).
+extern "C" int rphip_csr_set_values(rphip_ctx* ctx, rphip_csr* m, const double* values_host) {
+  if (!ctx || !m) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  RP_TRY(rp_set_device(ctx));
+  RP_HIP(hipStreamSynchronize(ctx->stream));
+  if (m->x_val) {
+    hipFree(m->x_val);
+    m->x_val = nullptr;
+  }
+  m->val_max_abs = 0.0;
+  m->val_neg = false;
+  if (!values_host) return RPHIP_OK;
+  double mx = 0.0;
+  bool neg = false;
+  for (int64_t k = 0; k < m->nnz; ++k) {
+    const double v = values_host[k];
+    if (!std::isfinite(v)) RP_FAIL(RPHIP_EINVAL, "value %lld is not finite", (long long)k);
+    mx = std::max(mx, std::fabs(v));
+    neg |= v < 0.0;
+  }
+  const size_t bytes = (size_t)std::max<int64_t>(1, m->nnz) * sizeof(double);
+  if (hipMalloc((void**)&m->x_val, bytes) != hipSuccess) {
+    m->x_val = nullptr;
+    RP_FAIL(RPHIP_ENOMEM, "hipMalloc of %zu bytes for the values failed", bytes);
+  }
+  if (m->nnz > 0) RP_HIP(hipMemcpyAsync(m->x_val, values_host, (size_t)m->nnz * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  RP_HIP(hipStreamSynchronize(ctx->stream));
+  m->val_max_abs = mx;
+  m->val_neg = neg;
   return RPHIP_OK;
 }
 

@@ -1,0 +1,340 @@
+// ItemKNN on a VALUED interaction matrix: the Gram of per-entry float64 weights, K1-K3 for the time-aware family.
+//
+// Replaces TARSItemKNN._fit (recpack/algorithms/time_aware_item_knn/base.py:166-179): the decayed matrix W
+// (:181-201, built by the host class) goes through compute_cosine_similarity / compute_conditional_probability /
+// compute_pearson_similarity (recpack/algorithms/nearest_neighbour.py:22-118) and get_top_K_values (recpack/util.py:80-96).
+// All three are one kernel:
+//     G_ij = sum over the users u of item i that also hold j of  L_ui * R_uj,      S_ij = G_ij * rowscale_i
+//   cosine   L = R = W with every column scaled to unit length by the host (what sklearn's cosine_similarity does
+//            first: normalize(X.T), then the sparse product), rowscale = 1
+//   pearson  the same on the centred matrix (host), entries that centre to exactly 0 dropped as scipy's subtraction drops them
+//   conditional probability   L = 1 (to_binary(X).T @ X), R = W, rowscale_i = fl(1 / c_i)   (A @ co_mat, pop_discount = 0)
+//
+// Stored entries and zeros, as the reference has them: scipy's sparse product stores the (i, j) whose sum is not
+// exactly 0, setdiag(0) stores the diagonal as an explicit 0, get_top_K_values takes the min(K, stored) largest stored
+// values and the result drops the zero.  With negative entries (pearson) the diagonal's zero outranks them, so per row
+//     K_eff = min(K, n_pos) + max(0, min(K - n_pos - 1, n_neg))
+// non-zero entries are selected.
+// Float64 sums by LDS atomics: the order of the adds shows in the last bits, as scipy's own order does; parity is the
+// tie-aware rule with eps = 1e-9 and values at 1e-11 (tests/test_gpu_tars.py).  A coverage kernel like the normalize_X
+// variant (rp_itemknn_w.hip): no row slicing, no counter packing.
+#include <algorithm>
+
+#include "rp_common.h"
+#include "rp_select.h"
+
+constexpr int RP_VMERGE_THREADS = 256;
+constexpr int RP_VTILE_MAX = 12288;
+constexpr unsigned long long RP_SIGN64 = 0x8000000000000000ull;
+
+struct rp_vfit_params {
+  const int32_t* x_ptr;
+  const int32_t* x_idx;
+  const double* x_val;
+  const int32_t* xt_ptr;
+  const int32_t* xt_idx;
+  const int32_t* order;   // rows by descending cost
+  const double* roww;     // [I] or NULL
+  int left_binary, signed_vals;
+  int n_items, n_rows, n_tiles, tile_w, K, row_begin;
+  int32_t* ticket;
+  int32_t* out_idx;       // T == 1: model rows; T > 1: per-tile candidates
+  double* out_val;
+  int32_t* out_nnz;
+  int32_t* out_cnt;       // T > 1 and signed: n_pos per (row, tile)
+};
+
+// any double -> u64 in the same order
+__device__ __forceinline__ uint64_t rp_ordered_f64(double v) {
+  const uint64_t b = (uint64_t)__double_as_longlong(v);
+  return (b & RP_SIGN64) ? ~b : (b | RP_SIGN64);
+}
+
+struct rp_vdense_src {
+  const double* acc;
+  int t0, row;
+  __device__ __forceinline__ bool valid(int w) const { return acc[w] != 0.0 && (t0 + w) != row; }
+  __device__ __forceinline__ uint64_t key(int w) const { return rp_ordered_f64(acc[w]); }
+  __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)(t0 + w); }
+};
+
+__device__ __forceinline__ int rp_keff(int K, int n_pos, int n_neg) {
+  int k = min(K, n_pos);
+  const int rest = K - n_pos - 1;
+  if (rest > 0) k += min(rest, n_neg);
+  return k;
+}
+
+__global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_params P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NTHR = RP_FIT_THREADS, NW = NTHR / 64;
+  double* acc = reinterpret_cast<double*>(smem);
+  const int W = P.tile_w, T = P.n_tiles;
+  rp_select_smem sel = rp_select_carve(smem + (size_t)W * 8, W, NW);
+  int* s_task = &sel.misc[RPS_USER];
+  int* s_cnt = &sel.misc[RPS_USER + 1];  // [2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave * 4 + (lane >> 4), gl = lane & 15;  // 64 groups of 16 lanes: one user per group and round
+  for (int w = tid; w < W; w += NTHR) acc[w] = 0.0;
+  const long long n_tasks = (long long)P.n_rows * T;
+  while (true) {
+    __syncthreads();
+    if (tid == 0) {
+      s_task[0] = atomicAdd(P.ticket, 1);
+      s_cnt[0] = s_cnt[1] = 0;
+    }
+    __syncthreads();
+    const long long task = s_task[0];
+    if (task >= n_tasks) break;
+    const int row = P.order[task / T], tile = (int)(task % T);
+    const int t0 = tile * W, n_cols = min(W, P.n_items - t0);
+    // ---- accumulate
+    const int pe = P.xt_ptr[row + 1];
+    for (int p = P.xt_ptr[row] + grp; p < pe; p += 64) {
+      const int u = P.xt_idx[p];
+      int s = P.x_ptr[u], e = P.x_ptr[u + 1];
+      double q = 1.0;
+      if (!P.left_binary) {  // the user's value for this row's item: rows are column-sorted
+        int lo = s, hi = e;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (P.x_idx[mid] < row) lo = mid + 1; else hi = mid;
+        }
+        q = P.x_val[lo];
+      }
+      if (T > 1) {  // the slice of the row that falls into this tile
+        int lo = s, hi = e;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (P.x_idx[mid] < t0) lo = mid + 1; else hi = mid;
+        }
+        s = lo;
+        hi = e;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (P.x_idx[mid] < t0 + n_cols) lo = mid + 1; else hi = mid;
+        }
+        e = lo;
+      }
+      for (int k = s + gl; k < e; k += 16) atomicAdd(&acc[P.x_idx[k] - t0], q * P.x_val[k]);
+    }
+    __syncthreads();
+    // ---- with negative entries the diagonal's stored zero decides how many of them the reference keeps
+    int kk = P.K;
+    if (P.signed_vals) {
+      int np = 0, nn = 0;
+      for (int w = tid; w < n_cols; w += NTHR) {
+        if ((t0 + w) == row) continue;
+        const double v = acc[w];
+        np += v > 0.0;
+        nn += v < 0.0;
+      }
+      np = rp_wave_sum(np);
+      nn = rp_wave_sum(nn);
+      if (lane == 0) {
+        atomicAdd(&s_cnt[0], np);
+        atomicAdd(&s_cnt[1], nn);
+      }
+      __syncthreads();
+      if (T == 1) kk = rp_keff(P.K, s_cnt[0], s_cnt[1]);
+    }
+    // ---- select
+    rp_vdense_src src{acc, t0, row};
+    const int rl = row - P.row_begin;
+    int kp = 0;
+    if (kk > 0) kp = rp_select_topk<NTHR>(src, n_cols, kk, sel);
+    if (T == 1) {
+      const double ri = P.roww ? P.roww[row] : 1.0;
+      if (kk > 0)
+        rp_select_emit<NTHR>(n_cols, sel, [&](int pos, int w) {
+          P.out_idx[(int64_t)rl * P.K + pos] = t0 + w;
+          P.out_val[(int64_t)rl * P.K + pos] = acc[w] * ri;
+        });
+      if (tid == 0) P.out_nnz[rl] = kp;
+    } else {
+      const int64_t o = ((int64_t)rl * T + tile) * P.K;
+      rp_select_emit<NTHR>(n_cols, sel, [&](int pos, int w) {
+        P.out_idx[o + pos] = t0 + w;
+        P.out_val[o + pos] = acc[w];
+      });
+      if (tid == 0) {
+        P.out_nnz[(int64_t)rl * T + tile] = kp;
+        if (P.signed_vals) P.out_cnt[(int64_t)rl * T + tile] = s_cnt[0];
+      }
+    }
+    __syncthreads();
+    for (int w = tid; w < W; w += NTHR) acc[w] = 0.0;  // (the diagonal is in no list)
+  }
+}
+
+struct rp_vlist_src {
+  const double* g_;
+  const int32_t* col_;
+  int n;
+  __device__ __forceinline__ bool valid(int w) const { return w < n; }
+  __device__ __forceinline__ uint64_t key(int w) const { return rp_ordered_f64(g_[w]); }
+  __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)col_[w]; }
+};
+
+// top-K_eff of the T per-tile candidate lists of a row (each holds the tile's K largest non-zero entries)
+__global__ void __launch_bounds__(RP_VMERGE_THREADS) k_itemknn_merge_values(const int32_t* __restrict__ cand_idx, const double* __restrict__ cand_g,
+                                                                           const int32_t* __restrict__ cand_nnz, const int32_t* __restrict__ cand_cnt,
+                                                                           const double* __restrict__ roww, int signed_vals, int n_tiles, int K,
+                                                                           int n_rows, int row_begin, int32_t* __restrict__ out_idx,
+                                                                           double* __restrict__ out_val, int32_t* __restrict__ out_nnz) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = n_tiles, cap = T * K;
+  double* lg = reinterpret_cast<double*>(smem);
+  int32_t* lcol = reinterpret_cast<int32_t*>(smem + (size_t)cap * 8);
+  rp_select_smem sel = rp_select_carve(smem + (size_t)cap * 12 + ((cap & 1) ? 4 : 0), cap, RP_VMERGE_THREADS / 64);
+  int* s_off = &sel.misc[RPS_USER];  // [T + 1], then K_eff
+  const int tid = threadIdx.x;
+  for (int rl = blockIdx.x; rl < n_rows; rl += gridDim.x) {
+    __syncthreads();
+    if (tid == 0) {
+      int o = 0, np = 0;
+      for (int t = 0; t < T; ++t) {
+        s_off[t] = o;
+        o += cand_nnz[(int64_t)rl * T + t];
+        if (signed_vals) np += cand_cnt[(int64_t)rl * T + t];
+      }
+      s_off[T] = o;
+      // negatives beyond a tile's K never matter: at most K - n_pos of them are kept in total
+      s_off[T + 1] = signed_vals ? rp_keff(K, np, 0x3fffffff) : K;
+    }
+    __syncthreads();
+    const int n = s_off[T];
+    const int kk = min(s_off[T + 1], n);
+    for (int t = 0; t < T; ++t) {
+      const int cn = s_off[t + 1] - s_off[t];
+      const int64_t so = ((int64_t)rl * T + t) * K;
+      for (int k = tid; k < cn; k += RP_VMERGE_THREADS) {
+        lcol[s_off[t] + k] = cand_idx[so + k];
+        lg[s_off[t] + k] = cand_g[so + k];
+      }
+    }
+    __syncthreads();
+    rp_vlist_src src{lg, lcol, n};
+    int kp = 0;
+    if (kk > 0) {
+      kp = rp_select_topk<RP_VMERGE_THREADS>(src, n, kk, sel);
+      const double ri = roww ? roww[row_begin + rl] : 1.0;
+      rp_select_emit<RP_VMERGE_THREADS>(n, sel, [&](int pos, int w) {
+        out_idx[(int64_t)rl * K + pos] = lcol[w];
+        out_val[(int64_t)rl * K + pos] = lg[w] * ri;
+      });
+    }
+    if (tid == 0) out_nnz[rl] = kp;
+  }
+}
+
+extern "C" int rphip_itemknn_fit_values(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K, int32_t left_binary,
+                                        const double* row_scale_host, rphip_model** out) {
+  if (!ctx || !X || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (!X->x_val) RP_FAIL(RPHIP_ESTATE, "the matrix carries no values (rphip_csr_set_values)");
+  if (row_begin < 0 || row_end > X->n_items || row_begin > row_end)
+    RP_FAIL(RPHIP_EINVAL, "row range [%lld,%lld) outside 0..%lld", (long long)row_begin, (long long)row_end, (long long)X->n_items);
+  if (K < 1) RP_FAIL(RPHIP_EINVAL, "K must be >= 1 (got %d)", K);
+  if (X->xt_row_end >= 0) RP_FAIL(RPHIP_ESTATE, "the valued fit needs a matrix with all item rows of X^T (not rphip_csr_from_device_rows)");
+  RP_TRY(rp_set_device(ctx));
+  const int32_t Keff = (int32_t)std::min<int64_t>(K, std::max<int64_t>(1, X->n_items - 1));
+  if (Keff > RP_K_MAX) RP_FAIL(RPHIP_ELIMIT, "effective K=%d exceeds the supported maximum %d", Keff, RP_K_MAX);
+  K = Keff;
+  const int n_rows = (int)(row_end - row_begin);
+  const int64_t I = X->n_items;
+  const int T = (int)std::max<int64_t>(1, rp_cdiv(I, RP_VTILE_MAX));
+  const int W = (int)(rp_cdiv(rp_cdiv(std::max<int64_t>(I, 1), T), 64) * 64);
+  if (T > 15) RP_FAIL(RPHIP_ELIMIT, "%d valued column tiles (n_items=%lld) exceed the supported 15", T, (long long)I);
+  if ((T > 1 || !left_binary) && !X->sorted_rows) RP_FAIL(RPHIP_EINVAL, "the valued fit needs column-sorted rows");
+  hipStream_t st = ctx->stream;
+  rphip_model* m = nullptr;
+  RP_TRY(rp_model_alloc_topk(ctx, I, row_begin, row_end, K, &m));
+  const size_t nk = (size_t)std::max<int64_t>(1, (int64_t)n_rows * K);
+  hipMemsetAsync(m->idx, 0xFF, nk * sizeof(int32_t), st);
+  hipMemsetAsync(m->val, 0, nk * sizeof(double), st);
+  hipMemsetAsync(m->nnz, 0, (size_t)std::max(1, n_rows) * sizeof(int32_t), st);
+  auto fail = [&](int rc) {
+    rphip_model_destroy(m);
+    return rc;
+  };
+  if (n_rows > 0 && X->nnz > 0) {
+    char* sc = nullptr;
+    const size_t cand_n = (T > 1) ? (size_t)n_rows * T * K : 0;
+    const size_t bytes = (size_t)I * 8 + RP_PLAN_BUCKETS * 4 + (size_t)n_rows * 4 + 64 + cand_n * 12 + (size_t)n_rows * T * 8 + 512;
+    int rc = rp_scratch(ctx, 0, bytes, (void**)&sc);
+    if (rc != RPHIP_OK) return fail(rc);
+    size_t o = 0;
+    auto carve = [&](size_t b) {
+      char* p = sc + o;
+      o += (b + 15) & ~(size_t)15;
+      return p;
+    };
+    double* roww = (double*)carve((size_t)I * 8);
+    int32_t* bucket = (int32_t*)carve(RP_PLAN_BUCKETS * 4);
+    int32_t* order = (int32_t*)carve((size_t)n_rows * 4);
+    int32_t* ticket = (int32_t*)carve(64);
+    double* cand_g = (double*)carve(cand_n * 8);
+    int32_t* cand_idx = (int32_t*)carve(cand_n * 4);
+    int32_t* cand_nnz = (int32_t*)carve((size_t)n_rows * T * 4);
+    int32_t* cand_cnt = (int32_t*)carve((size_t)n_rows * T * 4);
+    hipEvent_t ev;
+    rp_time_begin(ctx, &ev);
+    hipMemsetAsync(ticket, 0, 64, st);
+    if (T > 1) {
+      hipMemsetAsync(cand_nnz, 0, (size_t)n_rows * T * 4, st);
+      hipMemsetAsync(cand_cnt, 0, (size_t)n_rows * T * 4, st);
+    }
+    rc = rp_plan_row_order(ctx, X, row_begin, n_rows, bucket, order);
+    if (rc != RPHIP_OK) return fail(rc);
+    if (row_scale_host && hipMemcpyAsync(roww, row_scale_host, (size_t)I * 8, hipMemcpyHostToDevice, st) != hipSuccess) return fail(RPHIP_EHIP);
+    rp_time_end(ctx, ev, RPHIP_T_FIT_PLAN, 0.0);
+    rp_vfit_params P;
+    P.x_ptr = X->x_ptr;
+    P.x_idx = X->x_idx;
+    P.x_val = X->x_val;
+    P.xt_ptr = X->xt_ptr;
+    P.xt_idx = X->xt_idx;
+    P.order = order;
+    P.roww = row_scale_host ? roww : nullptr;
+    P.left_binary = left_binary ? 1 : 0;
+    P.signed_vals = X->val_neg ? 1 : 0;
+    P.n_items = (int)I;
+    P.n_rows = n_rows;
+    P.n_tiles = T;
+    P.tile_w = W;
+    P.K = K;
+    P.row_begin = (int)row_begin;
+    P.ticket = ticket;
+    P.out_idx = (T == 1) ? m->idx : cand_idx;
+    P.out_val = (T == 1) ? m->val : cand_g;
+    P.out_nnz = (T == 1) ? m->nnz : cand_nnz;
+    P.out_cnt = cand_cnt;
+    const size_t lds = (size_t)W * 8 + rp_select_smem_bytes(W);
+    if (hipFuncSetAttribute((const void*)k_itemknn_fit_values, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(RPHIP_EHIP);
+    rp_time_begin(ctx, &ev);
+    hipLaunchKernelGGL(k_itemknn_fit_values, dim3(ctx->n_cu), dim3(RP_FIT_THREADS), lds, st, P);
+    rp_time_end(ctx, ev, RPHIP_T_GRAM_TOPK, 0.0);
+    if (T > 1) {
+      const size_t mlds = (size_t)T * K * 12 + 8 + rp_select_smem_bytes(T * K, RP_VMERGE_THREADS / 64);
+      if (mlds > 160 * 1024 || T * K >= RPS_FLAG) {
+        rp_set_error("K=%d with %d column tiles needs %zu bytes of LDS for the merge", K, T, mlds);
+        return fail(RPHIP_ELIMIT);
+      }
+      if (hipFuncSetAttribute((const void*)k_itemknn_merge_values, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds) != hipSuccess)
+        return fail(RPHIP_EHIP);
+      const int mper = std::max<int>(1, std::min<int>(8, (int)((160 * 1024) / mlds)));
+      rp_time_begin(ctx, &ev);
+      hipLaunchKernelGGL(k_itemknn_merge_values, dim3((unsigned)std::min<int64_t>(n_rows, (int64_t)ctx->n_cu * mper)), dim3(RP_VMERGE_THREADS),
+                         mlds, st, cand_idx, cand_g, cand_nnz, cand_cnt, P.roww, P.signed_vals, T, K, n_rows, (int)row_begin, m->idx, m->val,
+                         m->nnz);
+      rp_time_end(ctx, ev, RPHIP_T_TOPK_MERGE, 0.0);
+    }
+    if (hipGetLastError() != hipSuccess) return fail(RPHIP_EHIP);
+  }
+  int r = rp_model_finalize_topk(ctx, m);
+  if (r != RPHIP_OK) return fail(r);
+  *out = m;
+  return RPHIP_OK;
+}

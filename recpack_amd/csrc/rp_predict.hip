@@ -32,9 +32,9 @@ constexpr unsigned long long RP_KEY_FLIP = 0x8000000000000000ull;  // two's comp
 
 // Scale of the sums.  |score| <= max_deg * vmax_abs < 2^(e + dl): shift <= 62 - e - dl keeps every sum inside 63 bits;
 // shift <= 50 - e keeps every single term below 2^50 units so that the conversion below is one f64 add.
-static int rp_fix_shift(float vmax_abs, int max_deg) {
+static int rp_fix_shift(double vmax_abs, int max_deg) {
   int e = 0;
-  if (vmax_abs > 0.0f && std::isfinite(vmax_abs)) (void)std::frexp(vmax_abs, &e);  // vmax_abs < 2^e
+  if (vmax_abs > 0.0 && std::isfinite(vmax_abs)) (void)std::frexp(vmax_abs, &e);  // vmax_abs < 2^e
   int dl = 0;
   while ((1ll << dl) < (long long)std::max(max_deg, 1)) ++dl;
   return std::min(200, std::max(-100, std::min(62 - e - dl, 50 - e)));
@@ -58,11 +58,17 @@ __device__ __forceinline__ unsigned long long rp_f32_to_fix(int bits, const rp_f
   const double r = (double)__int_as_float(bits) + f.magic;
   return (unsigned long long)__double_as_longlong(r) - f.magic_bits;
 }
+// a weighted term (similarity * the entry's value, valued prediction matrices): the float64 product, same conversion
+__device__ __forceinline__ unsigned long long rp_f64_to_fix(double v, const rp_fix_scale& f) {
+  const double r = v + f.magic;
+  return (unsigned long long)__double_as_longlong(r) - f.magic_bits;
+}
 __device__ __forceinline__ double rp_fix_to_f64(unsigned long long sum, int shift) { return ldexp((double)(long long)sum, -shift); }
 
 struct rp_pred_params {
-  const int32_t* x_ptr;   // prediction input (binary CSR)
+  const int32_t* x_ptr;   // prediction input (CSR; binary unless x_val)
   const int32_t* x_idx;
+  const double* x_val;    // optional values of the entries (time-decayed histories, time_aware_item_knn/base.py:139-150)
   const int32_t* s_idx;   // model: [I*K]
   const float* s_val;
   const int32_t* s_nnz;
@@ -205,6 +211,14 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_tile(rp_pred_params
           const int nn = P.s_nnz[i];
           const int32_t* si = P.s_idx + (int64_t)i * K;
           const float* sv = P.s_val + (int64_t)i * K;
+          if (P.x_val) {
+            const double xw = P.x_val[h];
+            for (int k = lane; k < nn; k += 64) {
+              const int j = si[k] - t0;
+              if ((unsigned)j < (unsigned)n_cols) atomicAdd(&accq[j], rp_f64_to_fix((double)sv[k] * xw, P.fix));
+            }
+            continue;
+          }
           for (int k = lane; k < nn; k += 64) {
             const int j = si[k] - t0;
             if ((unsigned)j < (unsigned)n_cols) atomicAdd(&accq[j], rp_f32_to_fix(__float_as_int(sv[k]), P.fix));
@@ -341,6 +355,7 @@ struct rp_pw_params {
   const int2* pairs;
   const uint16_t* toff;  // [I * (n_wt + 1)]
   const uint8_t* keep;   // optional item filter: only items with keep[j] != 0 are candidates
+  const double* x_val;   // optional values of the prediction matrix's entries (WGT instances)
   int n_items, n_wt, K, Kp, exclude_history, user_begin, n_users;
   rp_fix_scale fix;
   int32_t* ticket;
@@ -374,7 +389,8 @@ struct rp_pw_state {
 #define PW_COUNT(ph, n) do { S.t_ph[ph] += (n); } while (0)
 #endif
 
-__device__ __forceinline__ void rp_pw_add_chunk(rp_pw_state& S, int n, const v4i_a4& a, const v4i_a4& b, int t0) {
+template <bool WGT>
+__device__ __forceinline__ void rp_pw_add_chunk(rp_pw_state& S, int n, const v4i_a4& a, const v4i_a4& b, int t0, double xw) {
   const int ec[4] = {a.x, a.z, b.x, b.z};
   const int ev[4] = {a.y, a.w, b.y, b.w};
   // Straight-line code, no per-entry branch: an entry past the chunk's end adds 0 to a dummy word of the lane's own
@@ -387,7 +403,11 @@ __device__ __forceinline__ void rp_pw_add_chunk(rp_pw_state& S, int n, const v4i
     const bool on = e < n;
     const int j = ec[e] - t0;
     RP_LDS unsigned long long* tgt = on ? &S.acc[j] : dummy;
-    const unsigned long long v = on ? rp_f32_to_fix(ev[e], S.fix) : 0ull;
+    unsigned long long v = 0ull;
+    if (WGT)  // the owner's value times the similarity, in float64
+      v = on ? rp_f64_to_fix((double)__int_as_float(ev[e]) * xw, S.fix) : 0ull;
+    else
+      v = on ? rp_f32_to_fix(ev[e], S.fix) : 0ull;
     RP_LDS uint32_t* dw = &S.dirty[on ? (j & 63) : S.lane];
     const uint32_t bit = on ? (1u << ((j >> 6) & 31)) : 0u;
     atomicAdd((unsigned long long*)tgt, v);
@@ -397,8 +417,9 @@ __device__ __forceinline__ void rp_pw_add_chunk(rp_pw_state& S, int n, const v4i
 
 // chunk c of a batch whose lanes hold (start, length, first chunk) of their slices: owner lane by binary search
 // over the exclusive chunk offsets, then the chunk's two 16-byte loads
+template <bool WGT>
 __device__ __forceinline__ int rp_pw_fetch_chunk(const rp_pw_state& S, int c, int n_chunks, int s, int len, int choff, v4i_a4* a,
-                                                 v4i_a4* b) {
+                                                 v4i_a4* b, double wt, double* wo) {
   int lo = 0;
 #pragma unroll
   for (int step = 32; step > 0; step >>= 1) {
@@ -406,6 +427,7 @@ __device__ __forceinline__ int rp_pw_fetch_chunk(const rp_pw_state& S, int c, in
     if (v <= c) lo += step;
   }
   const int us = __shfl(s, lo), ulen = __shfl(len, lo), co = __shfl(choff, lo);
+  if (WGT) *wo = __shfl(wt, lo);
   const int k0 = (c - co) * PW_CH;
   const int n = (c < n_chunks) ? min(PW_CH, ulen - k0) : 0;
   if (n > 0) {
@@ -419,8 +441,9 @@ __device__ __forceinline__ int rp_pw_fetch_chunk(const rp_pw_state& S, int c, in
 // The first 64 chunks of a batch (chunk = lane): every slice owner writes its lane id at its first chunk's slot of a
 // 64-word LDS scratch, a running maximum over the lanes (DPP) turns that into the owner of every chunk - two LDS
 // round trips where the binary search takes six.
+template <bool WGT>
 __device__ __forceinline__ int rp_pw_fetch_first(const rp_pw_state& S, int n_chunks, int nch, int s, int len, int choff, v4i_a4* a,
-                                                 v4i_a4* b) {
+                                                 v4i_a4* b, double wt, double* wo) {
   RP_LDS uint32_t* sc = S.pool.hist;  // idle while a tile's entries are fetched and added
   const int lane = S.lane;
   sc[lane] = 0u;
@@ -429,6 +452,7 @@ __device__ __forceinline__ int rp_pw_fetch_first(const rp_pw_state& S, int n_chu
   RP_WAVE_FENCE();
   const int lo = rp_wave_incl_max((int)sc[lane]);
   const int us = __shfl(s, lo), ulen = __shfl(len, lo), co = __shfl(choff, lo);
+  if (WGT) *wo = __shfl(wt, lo);
   const int k0 = (lane - co) * PW_CH;
   const int n = (lane < n_chunks) ? min(PW_CH, ulen - k0) : 0;
   if (n > 0) {
@@ -444,8 +468,10 @@ __device__ __forceinline__ int rp_pw_fetch_first(const rp_pw_state& S, int n_chu
 // the prefetched entries of the next tile in the middle of the current one.  As calls they cost nothing unless taken.
 //
 // Further chunk steps of one pipelined batch (more than 64 chunks of the batch fall into the tile).
+template <bool WGT>
 __device__ __attribute__((noinline)) void rp_pw_extra_steps(RP_LDS unsigned long long* acc, RP_LDS uint32_t* dirty, const int* pairs_i,
-                                                            rp_fix_scale fix, int lane, int s, int len, int choff, int nchunks, int t0) {
+                                                            rp_fix_scale fix, int lane, int s, int len, int choff, int nchunks, int t0,
+                                                            double wt) {
   rp_pw_state S;
   S.acc = acc;
   S.dirty = dirty;
@@ -454,16 +480,18 @@ __device__ __attribute__((noinline)) void rp_pw_extra_steps(RP_LDS unsigned long
   S.lane = lane;
   for (int c0 = 64; c0 < nchunks; c0 += 64) {
     v4i_a4 a = (v4i_a4){0, 0, 0, 0}, b2 = a;
-    const int n = rp_pw_fetch_chunk(S, c0 + lane, nchunks, s, len, choff, &a, &b2);
-    rp_pw_add_chunk(S, n, a, b2, t0);
+    double xw = 1.0;
+    const int n = rp_pw_fetch_chunk<WGT>(S, c0 + lane, nchunks, s, len, choff, &a, &b2, wt, &xw);
+    rp_pw_add_chunk<WGT>(S, n, a, b2, t0, xw);
   }
 }
 
 // History batches beyond the pipelined ones (items [h_from, he)): offsets and entries fetched on the spot.
 // Returns whether anything was added.
+template <bool WGT>
 __device__ __attribute__((noinline)) bool rp_pw_slow_batches(RP_LDS unsigned long long* acc, RP_LDS uint32_t* dirty, const int* pairs_i,
-                                                             rp_fix_scale fix, int lane, const int32_t* x_idx, const uint16_t* toff,
-                                                             int K, int NT, int t, int h_from, int he) {
+                                                             rp_fix_scale fix, int lane, const int32_t* x_idx, const double* x_val,
+                                                             const uint16_t* toff, int K, int NT, int t, int h_from, int he) {
   rp_pw_state S;
   S.acc = acc;
   S.dirty = dirty;
@@ -475,8 +503,10 @@ __device__ __attribute__((noinline)) bool rp_pw_slow_batches(RP_LDS unsigned lon
   for (int hb = h_from; hb < he; hb += 64) {
     const int h = hb + lane;
     int s = 0, len = 0;
+    double wt = 1.0;
     if (h < he) {
       const int itx = x_idx[h];
+      if (WGT) wt = x_val[h];
       const uint16_t* tx = toff + (long long)itx * (NT + 1) + t;
       const int o0 = tx[0], o1 = tx[1];
       s = itx * K + o0;
@@ -489,8 +519,9 @@ __device__ __attribute__((noinline)) bool rp_pw_slow_batches(RP_LDS unsigned lon
     if (n_chunks > 0) touched = true;
     for (int c0 = 0; c0 < n_chunks; c0 += 64) {
       v4i_a4 a = (v4i_a4){0, 0, 0, 0}, b2 = a;
-      const int n = rp_pw_fetch_chunk(S, c0 + lane, n_chunks, s, len, choff, &a, &b2);
-      rp_pw_add_chunk(S, n, a, b2, t0);
+      double xw = 1.0;
+      const int n = rp_pw_fetch_chunk<WGT>(S, c0 + lane, n_chunks, s, len, choff, &a, &b2, wt, &xw);
+      rp_pw_add_chunk<WGT>(S, n, a, b2, t0, xw);
     }
   }
   return touched;
@@ -524,13 +555,15 @@ template <int NB>
 struct rp_pw_set {
   int s[NB], len[NB], choff[NB], nchunks[NB], n[NB];
   v4i_a4 a[NB], b[NB];
+  double w[NB];  // WGT: the value of the history item the lane's first chunk belongs to
 };
 
-template <int NB>
+template <int NB, bool WGT>
 __device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_state& S, int ul, int hs, int he) {
   const int lane = S.lane, K = P.K, Kp = P.Kp, NT = P.n_wt, cap = S.cap;
   const int nb = min(NB, (he - hs + 63) >> 6);
   int it[NB], o_a[NB], o_b[NB], o_c[NB];
+  double wt[NB];
   const uint16_t* to[NB];
   // two register sets, used alternately as "current tile" and "tile being prefetched": the entries of tile t+1 are
   // loaded straight into the set tile t+1 will read, a whole tile period before they are needed (copying a prepared
@@ -543,11 +576,13 @@ __device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_st
     const int inc = rp_wave_incl_scan(nch, lane);
     D.choff[b] = inc - nch;
     D.nchunks[b] = __builtin_amdgcn_readlane(inc, 63);
-    D.n[b] = rp_pw_fetch_first(S, D.nchunks[b], nch, D.s[b], D.len[b], D.choff[b], &D.a[b], &D.b[b]);
+    D.n[b] = rp_pw_fetch_first<WGT>(S, D.nchunks[b], nch, D.s[b], D.len[b], D.choff[b], &D.a[b], &D.b[b], wt[b], &D.w[b]);
   };
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     it[b] = -1;
+    wt[b] = 1.0;
+    set0.w[b] = set1.w[b] = 1.0;
     to[b] = P.toff;
     o_a[b] = o_b[b] = o_c[b] = 0;
     set0.s[b] = set0.len[b] = set0.choff[b] = set0.nchunks[b] = set0.n[b] = 0;
@@ -556,6 +591,7 @@ __device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_st
     if (b < nb) {
       const int h = hs + 64 * b + lane;
       it[b] = (h < he) ? P.x_idx[h] : -1;
+      if (WGT) wt[b] = (h < he) ? P.x_val[h] : 0.0;
     }
   }
 #pragma unroll
@@ -590,13 +626,14 @@ __device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_st
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (b < nb) {
-        rp_pw_add_chunk(S, C.n[b], C.a[b], C.b[b], t0);  // the prefetched first step, then (rarely) further steps
-        if (C.nchunks[b] > 64) rp_pw_extra_steps(S.acc, S.dirty, S.pairs_i, S.fix, lane, C.s[b], C.len[b], C.choff[b], C.nchunks[b], t0);
+        rp_pw_add_chunk<WGT>(S, C.n[b], C.a[b], C.b[b], t0, C.w[b]);  // the prefetched first step, then (rarely) further steps
+        if (C.nchunks[b] > 64)
+          rp_pw_extra_steps<WGT>(S.acc, S.dirty, S.pairs_i, S.fix, lane, C.s[b], C.len[b], C.choff[b], C.nchunks[b], t0, wt[b]);
       }
     }
     // ---- histories longer than 64*NB items: the remaining batches, not pipelined
     if (hs + 64 * NB < he)
-      touched |= rp_pw_slow_batches(S.acc, S.dirty, S.pairs_i, S.fix, lane, P.x_idx, P.toff, K, NT, t, hs + 64 * NB, he);
+      touched |= rp_pw_slow_batches<WGT>(S.acc, S.dirty, S.pairs_i, S.fix, lane, P.x_idx, P.x_val, P.toff, K, NT, t, hs + 64 * NB, he);
     PW_STAMP(1);
     if (!touched) return;
     if (P.exclude_history) {  // the dirty bit stays: a zero sum is skipped below
@@ -681,6 +718,7 @@ __device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_st
   }
 }
 
+template <bool WGT>
 __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
@@ -720,11 +758,11 @@ __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
       PW_STAMP(0);
       const int nbu = (he - hs + 63) >> 6;
       if (nbu <= 1)
-        rp_pw_user_tiles<1>(P, S, ul, hs, he);
+        rp_pw_user_tiles<1, WGT>(P, S, ul, hs, he);
       else if (nbu <= 2)
-        rp_pw_user_tiles<2>(P, S, ul, hs, he);
+        rp_pw_user_tiles<2, WGT>(P, S, ul, hs, he);
       else
-        rp_pw_user_tiles<4>(P, S, ul, hs, he);
+        rp_pw_user_tiles<4, WGT>(P, S, ul, hs, he);
       // ---- final: best Kp by (score desc, column asc), then column order for the output row
       RP_WAVE_FENCE();
       if (S.pool.n > Kp) rp_wpool_cut<uint64_t, 0>(S.pool, Kp, lane);
@@ -817,6 +855,8 @@ static int rp_pred_check(rphip_ctx* ctx, const rphip_model* model, const rphip_c
             (long long)model->row_end, (long long)model->n_items);
   if (X->n_items != model->n_items)
     RP_FAIL(RPHIP_EINVAL, "prediction matrix has %lld items, the model %lld", (long long)X->n_items, (long long)model->n_items);
+  if (X->x_val && model->kind == RPHIP_MODEL_DENSE)
+    RP_FAIL(RPHIP_EINVAL, "a valued prediction matrix with a dense model: the reference's EASE binarises its input (base.py:141-151)");
   if (ub < 0 || ue > X->n_users || ub > ue) RP_FAIL(RPHIP_EINVAL, "user range [%lld,%lld) outside 0..%lld", (long long)ub, (long long)ue, (long long)X->n_users);
   return RPHIP_OK;
 }
@@ -838,7 +878,8 @@ static void rp_pred_fill(rp_pred_params& P, const rphip_model* m, const rphip_cs
     P.n_tiles = (int)std::max<int64_t>(1, rp_cdiv(X->n_items, RP_PRED_FIX_TILE));
     P.tile_w = (int)(rp_cdiv(rp_cdiv(std::max<int64_t>(X->n_items, 1), P.n_tiles), 64) * 64);
   }
-  P.fix = rp_fix_make(rp_fix_shift(m->vmax_abs, X->max_user_deg));
+  P.fix = rp_fix_make(rp_fix_shift((double)m->vmax_abs * (X->x_val ? X->val_max_abs : 1.0), X->max_user_deg));
+  P.x_val = (m->kind == RPHIP_MODEL_DENSE) ? nullptr : X->x_val;
   P.K = m->K;
   P.Kp = 0;
   P.exclude_history = 0;
@@ -944,10 +985,15 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
     }
 #endif
     const size_t wl = rp_pw_wave_bytes(Kp);
-    RP_HIP(hipFuncSetAttribute((const void*)k_predict_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl));
+    W.x_val = Xpred->x_val;
+    RP_HIP(hipFuncSetAttribute((const void*)k_predict_wave<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl));
+    RP_HIP(hipFuncSetAttribute((const void*)k_predict_wave<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl));
     const int wpc = std::max<int>(1, std::min<int>(16, (int)((160 * 1024) / wl)));
     const int wg = (int)std::min<int64_t>(rp_cdiv(n, PW_UCH), (int64_t)ctx->n_cu * wpc);
-    hipLaunchKernelGGL(k_predict_wave, dim3(wg), dim3(64), wl, st, W);
+    if (W.x_val)
+      hipLaunchKernelGGL(k_predict_wave<true>, dim3(wg), dim3(64), wl, st, W);
+    else
+      hipLaunchKernelGGL(k_predict_wave<false>, dim3(wg), dim3(64), wl, st, W);
     RP_HIP(hipGetLastError());
 #ifdef RP_STAMPS
     {

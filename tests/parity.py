@@ -13,7 +13,7 @@ def tie_aware_topk(cand: sp.csr_matrix, ref_sel: sp.csr_matrix, test_idx, test_n
     test_idx[r,:test_nnz[r]]: columns chosen by the implementation under test.
 
     With t = the reference's smallest selected value in the row:
-      MUST = {v > t(1+eps)}, MAY = {|v-t| <= eps t}; require MUST <= Sel <= MUST u MAY, |Sel| = K'.
+      MUST = {v > t + eps|t|}, MAY = {|v-t| <= eps|t|}; require MUST <= Sel <= MUST u MAY, |Sel| = K'.
     Returns (bad_rows list, exact_equal_count).
     """
     cand = sp.csr_matrix(cand)
@@ -36,7 +36,7 @@ def tie_aware_topk(cand: sp.csr_matrix, ref_sel: sp.csr_matrix, test_idx, test_n
             exact += 1
             continue
         t = rvals.min()
-        must = set(cols[vals > t * (1 + eps)].tolist())
+        must = set(cols[vals > t + eps * abs(t)].tolist())
         may = set(cols[np.abs(vals - t) <= eps * abs(t)].tolist())
         s = set(sel.tolist())
         if not (must <= s <= (must | may)):
