@@ -173,6 +173,24 @@ int rphip_itemknn_fit_ex(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, 
 int rphip_csr_set_values(rphip_ctx* ctx, rphip_csr* X, const double* values_host);
 int rphip_itemknn_fit_values(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K,
                              int32_t left_binary, const double* row_scale_host, rphip_model** out);
+/* TARSItemKNNCoocDistance._fit (time_aware_item_knn/base.py:260-294; TARSItemKNNXia, xia_2010.py): the values of X are the
+ * last timestamps in units of decay_interval, all > 0 (the host drops the others, as the reference's `> 0` masks do):
+ *   S_ij = row_scale[i] * sum over the users u of item i that hold j, t_uj != t_ui, of decay(|t_uj - t_ui|)
+ * decay = one of decay_functions.py:24-252 with parameter `decay` and, for the bounded ones, max_distance (the largest
+ * possible distance, base.py:268); pairs with equal timestamps add nothing (their difference is dropped by the sparse
+ * subtraction, base.py:279).  row_scale NULL ("cooc") or 1 / number of users of item i ("conditional_probability").
+ * Top K of the positive sums per row.
+ */
+#define RPHIP_DECAY_NONE 1
+#define RPHIP_DECAY_EXPONENTIAL 2
+#define RPHIP_DECAY_CONVEX 3
+#define RPHIP_DECAY_CONCAVE 4
+#define RPHIP_DECAY_LOG 5
+#define RPHIP_DECAY_LINEAR 6
+#define RPHIP_DECAY_INVERSE 7
+int rphip_itemknn_fit_timedist(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K,
+                               int32_t decay_kind, double decay, double max_distance, const double* row_scale_host,
+                               rphip_model** out);
 
 /* neighbour lists to host: idx int32[rows*K] (-1 padded), val float64[rows*K] (0 padded), nnz int32[rows] */
 int rphip_model_topk_download(rphip_ctx* ctx, const rphip_model* m, int32_t* idx_host, double* val_host,

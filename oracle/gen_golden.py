@@ -354,7 +354,53 @@ def tars_cases():
     save("syn_tars_3000x13000", **arrays)
 
 
+def tars_cooc_cases():
+    """TARSItemKNNCoocDistance / TARSItemKNNXia (time_aware_item_knn/base.py:204-294, xia_2010.py): the reference's fixture with
+    its known answers (recpack/tests/conftest.py:80-89 ``mat_no_zero_timestamp``, test_time_aware_item_knn_base.py:112-150) and a
+    seeded event log with some timestamps of 0 and repeated timestamps, every decay function x {cooc, conditional_probability}."""
+    import pandas as pd
+    from recpack.algorithms.time_aware_item_knn import TARSItemKNNCoocDistance, TARSItemKNNXia
+    from recpack.matrix import InteractionMatrix
+
+    def matrix(uid, iid, ts, shape):
+        return InteractionMatrix(pd.DataFrame({"uid": uid, "iid": iid, "ts": ts}), "iid", "uid", timestamp_ix="ts", shape=shape)
+
+    uid = np.array([0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5])
+    iid = np.array([0, 1, 2, 3, 0, 1, 2, 4, 0, 1, 2])
+    ts = np.array([4, 3, 2, 5, 1, 2, 3, 5, 1, 2, 3])
+    im = matrix(uid, iid, ts, (6, 5))
+    arrays = {"uid": uid, "iid": iid, "ts": ts, "shape": np.array([6, 5]), "K": np.array([2])}
+    for sim in ("cooc", "conditional_probability"):
+        algo = TARSItemKNNCoocDistance(K=2, fit_decay=0.5, similarity=sim).fit(im)
+        arrays.update(csr_parts(f"S_{sim}", algo.similarity_matrix_))
+        arrays.update(csr_parts(f"P_{sim}", algo.predict(im)))
+    save("ref_tars_cooc_mat", **arrays)
+
+    U, I, K = 300, 120, 8
+    uid, iid, ts = _tars_events(20260703, U, I, 4500, t_max=40 * 24 * 3600)
+    ts = (ts // 3600) * 3600  # whole hours: users with two events in the same hour (distance 0 adds nothing)
+    ts[::97] = 0  # some timestamps of 0: excluded by the `> 0` masks
+    im = matrix(uid, iid, ts, (U, I))
+    arrays = {"uid": uid, "iid": iid, "ts": ts, "shape": np.array([U, I]), "K": np.array([K]), "decay_interval": np.array([3600])}
+    decays = {"exponential": 0.02, "convex": 0.98, "concave": 0.3, "log": 5.0, "linear": 0.8, "inverse": 0.5}
+    arrays["decay_names"] = np.array(list(decays.keys()))
+    arrays["decay_values"] = np.array(list(decays.values()))
+    for fn, d in decays.items():
+        for sim in ("cooc", "conditional_probability"):
+            algo = TARSItemKNNCoocDistance(K=K, fit_decay=d, decay_interval=3600, similarity=sim, decay_function=fn).fit(im)
+            arrays.update(csr_parts(f"S_{fn}_{sim}", algo.similarity_matrix_))
+    algo = TARSItemKNNCoocDistance(K=K, fit_decay=0, decay_interval=3600, similarity="cooc").fit(im)  # no decay: co-occurrence counts
+    arrays.update(csr_parts("S_none_cooc", algo.similarity_matrix_))
+    algo = TARSItemKNNXia(K=K, fit_decay=0.6, decay_function="concave", decay_interval=24 * 3600).fit(im)
+    arrays.update(csr_parts("S_xia", algo.similarity_matrix_))
+    arrays.update(csr_parts("P_xia", algo.predict(im)))
+    save("syn_tars_cooc_300x120", **arrays)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "tars_cooc":
+        tars_cooc_cases()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "tars":
         tars_cases()
         sys.exit(0)

@@ -448,3 +448,45 @@ def tars_predict(Wp: sp.csr_matrix, S: sp.csr_matrix) -> sp.csr_matrix:
     P.eliminate_zeros()
     P.sort_indices()
     return P
+
+
+def tars_cooc_similarity(T: sp.csr_matrix, similarity: str, decay_function: str, decay: float, decay_interval: int = 1) -> sp.csr_matrix:
+    """TARSItemKNNCoocDistance._fit before the top-K (time_aware_item_knn/base.py:260-294), all rows at once: with
+    t = last timestamp / interval, S_ij = sum over the users with t_ui > 0 and t_uj > 0, t_uj != t_ui, of
+    decay(|t_uj - t_ui|) (equal timestamps: the difference is not stored, :279), divided by the number of users with
+    t_ui > 0 for "conditional_probability" (:288-289).  The bounded decays are normalised by max - min over all stored
+    timestamps (:268)."""
+    T = sp.csr_matrix(T, dtype=np.float64) / decay_interval
+    T = sp.csr_matrix(T)
+    n = T.shape[1]
+    max_dist = T.data.max() - T.data.min()
+    keep = T.data > 0
+    rows = np.repeat(np.arange(T.shape[0]), np.diff(T.indptr))[keep]
+    cols, t = T.indices[keep].astype(np.int64), T.data[keep]
+    d = np.bincount(rows, minlength=T.shape[0])
+    start = np.concatenate([[0], np.cumsum(d)[:-1]])
+    # all ordered pairs (a, b) of entries of the same user
+    a = np.repeat(np.arange(rows.shape[0]), d[rows])
+    b = np.arange(a.shape[0]) - np.repeat(np.cumsum(d[rows]) - d[rows], d[rows]) + start[rows[a]]
+    dist = np.abs(t[b] - t[a])
+    nz = dist != 0
+    kind = "none" if decay == 0 else decay_function
+    w = tars_decay(kind, decay, dist[nz], max_dist)
+    S = sp.coo_matrix((w, (cols[a][nz], cols[b][nz])), shape=(n, n)).tocsr()
+    if similarity == "conditional_probability":
+        c = np.bincount(cols, minlength=n).astype(np.float64)
+        inv = np.zeros(n)
+        inv[c > 0] = 1 / c[c > 0]
+        S = sp.csr_matrix(sp.diags(inv) @ S)
+    elif similarity != "cooc":
+        raise ValueError(similarity)
+    S.eliminate_zeros()
+    S.sort_indices()
+    return S
+
+
+def tars_cooc_fit(T: sp.csr_matrix, K: int, similarity: str, decay_function: str, decay: float, decay_interval: int = 1):
+    """... then get_top_K_values per row (base.py:292): the K largest stored (positive) sums; value desc, column asc."""
+    S = tars_cooc_similarity(T, similarity, decay_function, decay, decay_interval)
+    idx, val, nnz = topk_rows(S, K)
+    return {"idx": idx, "val": val, "nnz": nnz, "full": S}

@@ -88,6 +88,7 @@ PROTOTYPES = {
     "rphip_predict_full_fill": (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p, _p]),
     "rphip_csr_set_values": (C.c_int, [_p, _p, _p]),
     "rphip_itemknn_fit_values": (C.c_int, [_p, _p, _i64, _i64, _i32, _i32, _p, _pp]),
+    "rphip_itemknn_fit_timedist": (C.c_int, [_p, _p, _i64, _i64, _i32, _i32, _f64, _f64, _p, _pp]),
     "rphip_ease_fit": (C.c_int, [_p, _p, _f64, _f64, _pp]),
     "rphip_model_dense_download": (C.c_int, [_p, _p, _p]),
     "rphip_model_dense_device": (C.c_int, [_p, _pp, C.POINTER(_i64), C.POINTER(_i64)]),
@@ -431,6 +432,24 @@ def itemknn_fit_values(ctx: Context, X: DeviceCSR, K: int, left_binary: bool = F
             raise ValueError("row_scale must have one entry per item")
     check(ctx.lib.rphip_itemknn_fit_values(ctx.handle, X.handle, int(row_begin), int(row_end), int(K), 1 if left_binary else 0,
                                            _np_ptr(rs) if rs is not None else None, C.byref(h)))
+    return Model(ctx, h)
+
+
+DECAY_KINDS = {"none": 1, "exponential": 2, "convex": 3, "concave": 4, "log": 5, "linear": 6, "inverse": 7}
+
+
+def itemknn_fit_timedist(ctx: Context, X: DeviceCSR, K: int, decay_function: str, decay: float, max_distance: float, row_scale=None,
+                         row_begin: int = 0, row_end=None) -> Model:
+    """Top-K of S_ij = row_scale_i * sum_u decay(|t_uj - t_ui|) on a matrix whose values are timestamps > 0."""
+    h = C.c_void_p()
+    row_end = X.shape[1] if row_end is None else row_end
+    rs = None
+    if row_scale is not None:
+        rs = np.ascontiguousarray(row_scale, dtype=np.float64)
+        if rs.shape != (X.shape[1],):
+            raise ValueError("row_scale must have one entry per item")
+    check(ctx.lib.rphip_itemknn_fit_timedist(ctx.handle, X.handle, int(row_begin), int(row_end), int(K), int(DECAY_KINDS[decay_function]),
+                                             float(decay), float(max_distance), _np_ptr(rs) if rs is not None else None, C.byref(h)))
     return Model(ctx, h)
 
 

@@ -36,6 +36,8 @@ struct rp_vfit_params {
   const int32_t* order;   // rows by descending cost
   const double* roww;     // [I] or NULL
   int left_binary, signed_vals;
+  int pair_kind;          // 0: products L_ui * X_uj; > 0: a decay (RPHIP_DECAY_*) of |X_uj - X_ui|, equal values add nothing
+  double pair_decay, pair_max;
   int n_items, n_rows, n_tiles, tile_w, K, row_begin;
   int32_t* ticket;
   int32_t* out_idx;       // T == 1: model rows; T > 1: per-tile candidates
@@ -57,6 +59,22 @@ struct rp_vdense_src {
   __device__ __forceinline__ uint64_t key(int w) const { return rp_ordered_f64(acc[w]); }
   __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)(t0 + w); }
 };
+
+// time_aware_item_knn/decay_functions.py:24-252 on one distance d > 0 (N = the largest possible distance)
+__device__ __forceinline__ double rp_pair_decay(int kind, double a, double N, double d) {
+  switch (kind) {
+    case RPHIP_DECAY_EXPONENTIAL: return exp(-a * d);
+    case RPHIP_DECAY_CONVEX: return pow(a, d);
+    case RPHIP_DECAY_CONCAVE: return 1.0 - pow(a, 1.0 - (d / N));
+    case RPHIP_DECAY_LOG: return log(((a - 1.0) * (1.0 - d / N)) + 1.0) / log(a);
+    case RPHIP_DECAY_LINEAR: {
+      const double r = 1.0 - (d / N) * a;
+      return r < 0.0 ? 0.0 : r;
+    }
+    case RPHIP_DECAY_INVERSE: return 1.0 / d;
+    default: return 1.0;  // RPHIP_DECAY_NONE
+  }
+}
 
 __device__ __forceinline__ int rp_keff(int K, int n_pos, int n_neg) {
   int k = min(K, n_pos);
@@ -116,7 +134,14 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
         }
         e = lo;
       }
-      for (int k = s + gl; k < e; k += 16) atomicAdd(&acc[P.x_idx[k] - t0], q * P.x_val[k]);
+      if (P.pair_kind) {
+        for (int k = s + gl; k < e; k += 16) {
+          const double d = fabs(P.x_val[k] - q);
+          if (d != 0.0) atomicAdd(&acc[P.x_idx[k] - t0], rp_pair_decay(P.pair_kind, P.pair_decay, P.pair_max, d));
+        }
+      } else {
+        for (int k = s + gl; k < e; k += 16) atomicAdd(&acc[P.x_idx[k] - t0], q * P.x_val[k]);
+      }
     }
     __syncthreads();
     // ---- with negative entries the diagonal's stored zero decides how many of them the reference keeps
@@ -228,8 +253,8 @@ __global__ void __launch_bounds__(RP_VMERGE_THREADS) k_itemknn_merge_values(cons
   }
 }
 
-extern "C" int rphip_itemknn_fit_values(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K, int32_t left_binary,
-                                        const double* row_scale_host, rphip_model** out) {
+static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K, int32_t left_binary,
+                              const double* row_scale_host, int pair_kind, double pair_decay, double pair_max, rphip_model** out) {
   if (!ctx || !X || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   if (!X->x_val) RP_FAIL(RPHIP_ESTATE, "the matrix carries no values (rphip_csr_set_values)");
@@ -298,7 +323,10 @@ extern "C" int rphip_itemknn_fit_values(rphip_ctx* ctx, const rphip_csr* X, int6
     P.order = order;
     P.roww = row_scale_host ? roww : nullptr;
     P.left_binary = left_binary ? 1 : 0;
-    P.signed_vals = X->val_neg ? 1 : 0;
+    P.signed_vals = (X->val_neg && !pair_kind) ? 1 : 0;  // decayed distances are never negative
+    P.pair_kind = pair_kind;
+    P.pair_decay = pair_decay;
+    P.pair_max = pair_max;
     P.n_items = (int)I;
     P.n_rows = n_rows;
     P.n_tiles = T;
@@ -337,4 +365,18 @@ extern "C" int rphip_itemknn_fit_values(rphip_ctx* ctx, const rphip_csr* X, int6
   if (r != RPHIP_OK) return fail(r);
   *out = m;
   return RPHIP_OK;
+}
+
+extern "C" int rphip_itemknn_fit_values(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K, int32_t left_binary,
+                                        const double* row_scale_host, rphip_model** out) {
+  return rp_fit_values_impl(ctx, X, row_begin, row_end, K, left_binary, row_scale_host, 0, 0.0, 0.0, out);
+}
+
+extern "C" int rphip_itemknn_fit_timedist(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K, int32_t decay_kind,
+                                          double decay, double max_distance, const double* row_scale_host, rphip_model** out) {
+  if (decay_kind < RPHIP_DECAY_NONE || decay_kind > RPHIP_DECAY_INVERSE) RP_FAIL(RPHIP_EINVAL, "unknown decay function %d", decay_kind);
+  if ((decay_kind == RPHIP_DECAY_CONCAVE || decay_kind == RPHIP_DECAY_LOG || decay_kind == RPHIP_DECAY_LINEAR) && !(max_distance > 0.0))
+    RP_FAIL(RPHIP_EINVAL, "the %s decay needs max_distance > 0 (got %g)", decay_kind == RPHIP_DECAY_LOG ? "log" : decay_kind == RPHIP_DECAY_LINEAR ? "linear" : "concave",
+            max_distance);
+  return rp_fit_values_impl(ctx, X, row_begin, row_end, K, 0, row_scale_host, decay_kind, decay, max_distance, out);
 }

@@ -351,3 +351,54 @@ class TARSItemKNNLee(TARSItemKNN):
         l_ix = np.searchsorted(l_splits, launch[cols], side="left")  # first split >= value
         t_ix = np.searchsorted(t_splits, T.data[keep], side="left")
         return sp.csr_matrix((self.W[l_ix, t_ix], (rows, cols)), shape=T.shape)
+
+
+class TARSItemKNNCoocDistance(TARSItemKNN):
+    """time_aware_item_knn/base.py:204-294: the similarity of two items is the decayed time between a user's interactions
+    with them, summed over the users that hold both (``"cooc"``) or averaged over the users of the row's item
+    (``"conditional_probability"``).  Binary histories at predict."""
+
+    SUPPORTED_SIMILARITIES = ["cooc", "conditional_probability"]
+
+    def __init__(self, K: int = 200, fit_decay: float = 1 / (24 * 3600), decay_interval: int = 1, similarity: str = "cooc",
+                 decay_function: str = "exponential"):
+        super().__init__(K, fit_decay, 0, decay_interval, similarity, decay_function)
+
+    def _fit(self, X) -> None:
+        T = sp.csr_matrix(X.last_timestamps_matrix, dtype=np.float64) / self.decay_interval
+        n_items = T.shape[1]
+        if T.nnz == 0:
+            max_dist = 0.0
+        else:
+            max_dist = float(T.data.max() - T.data.min())  # over every stored pair (base.py:268)
+        T = sp.csr_matrix(T)
+        T.data = np.where(T.data > 0, T.data, 0.0)  # only timestamps > 0 take part (the `> 0` masks of base.py:273-279)
+        T = _canonical_valued(T)
+        kind = "none" if self.fit_decay == 0 else self.decay_function
+        row_scale = None
+        if self.similarity == "conditional_probability":
+            c = np.bincount(T.indices, minlength=n_items).astype(np.float64)
+            row_scale = np.zeros(n_items)
+            row_scale[c > 0] = 1 / c[c > 0]
+        ctx = get_context()
+        dT = _lib.DeviceCSR.from_host_valued(ctx, T)
+        try:
+            model = _lib.itemknn_fit_timedist(ctx, dT, int(self.K), kind, float(self.fit_decay), max_dist, row_scale=row_scale)
+            idx, val, nnz = model.topk_download()
+        finally:
+            dT.close()
+        self._model = model
+        self._empty_rows_ = int(np.count_nonzero(nnz == 0))
+        self.similarity_matrix_ = topk_arrays_to_csr(idx, val, nnz, n_items)
+
+
+class TARSItemKNNXia(TARSItemKNNCoocDistance):
+    """xia_2010.py:12-84: co-occurrence similarity with a concave, convex or linear decay of the time between the two
+    interactions, time in days by default."""
+
+    SUPPORTED_DECAY_FUNCTIONS = ["concave", "convex", "linear"]
+
+    def __init__(self, K: int = 200, fit_decay: float = 0.5, decay_function: str = "convex", decay_interval: int = 24 * 3600):
+        if decay_function not in self.SUPPORTED_DECAY_FUNCTIONS:
+            raise ValueError(f"decay_function {decay_function} not supported")
+        super().__init__(K=K, fit_decay=fit_decay, decay_interval=decay_interval, similarity="cooc", decay_function=decay_function)

@@ -199,3 +199,59 @@ def test_valued_api_errors(hip):
         TARSItemKNN(K=3, fit_decay=0, similarity="pearson").fit(TimedInteractions([0, 0, 1], [0, 1, 1], [5, 6, 7], (2, 2)))
     empty = TARSItemKNN(K=3).fit(TimedInteractions([], [], [], (4, 6)))
     assert empty.similarity_matrix_.nnz == 0
+
+
+COOC_DECAYS = {"exponential": 0.02, "convex": 0.98, "concave": 0.3, "log": 5.0, "linear": 0.8, "inverse": 0.5}
+
+
+def check_cooc(algo, g, tag, with_predict=False):
+    X = events(g)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        algo.fit(X)
+    S_ref = csr_from(g, f"S_{tag}")
+    S = sp.csr_matrix(algo.similarity_matrix_)
+    S.sort_indices()
+    full = onp.tars_cooc_similarity(X.last_timestamps_matrix, algo.similarity, algo.decay_function, algo.fit_decay, algo.decay_interval)
+    idx, _, nnz = dense_topk(S)
+    bad, exact = tie_aware_topk(full, S_ref, idx, nnz)
+    assert not bad, (tag, bad[:5])
+    assert abs(S.multiply(S_ref != 0) - S_ref.multiply(S != 0)).max() <= VAL_RTOL * max(1e-300, abs(S_ref).max())
+    if with_predict:  # binary histories (predict_decay = 0)
+        Wp = algo._add_decay_to_predict_matrix(X)
+        assert np.all(Wp.data == 1.0)
+        check_predict(algo, X, Wp, csr_from(g, f"P_{tag}"), exact == S.shape[0])
+
+
+def test_tars_cooc_reference_fixture(hip):
+    """recpack/tests/conftest.py:80-89 and the expected arrays of test_time_aware_item_knn_base.py:112-150."""
+    from recpack_amd.time_aware import TARSItemKNNCoocDistance
+
+    g = load_golden("ref_tars_cooc_mat")
+    e = np.exp
+    want = np.array([[0, e(-0.5) * 3, 0, 0, 0], [e(-0.5) * 3, 0, 0, 0, 0], [0, 0, 0, e(-1.5), e(-1.0)], [0, 0, e(-1.5), 0, 0],
+                     [0, 0, e(-1.0), 0, 0]])
+    algo = TARSItemKNNCoocDistance(K=2, fit_decay=0.5, similarity="cooc")
+    check_cooc(algo, g, "cooc", with_predict=True)
+    np.testing.assert_array_almost_equal(algo.similarity_matrix_.toarray(), want)
+    check_cooc(TARSItemKNNCoocDistance(K=2, fit_decay=0.5, similarity="conditional_probability"), g, "conditional_probability", with_predict=True)
+
+
+@pytest.mark.parametrize("fn", list(COOC_DECAYS))
+def test_tars_cooc_decay_functions(hip, fn):
+    from recpack_amd.time_aware import TARSItemKNNCoocDistance
+
+    g = load_golden("syn_tars_cooc_300x120")
+    K, interval = int(g["K"][0]), int(g["decay_interval"][0])
+    for sim in ("cooc", "conditional_probability"):
+        check_cooc(TARSItemKNNCoocDistance(K=K, fit_decay=COOC_DECAYS[fn], decay_interval=interval, similarity=sim, decay_function=fn), g,
+                   f"{fn}_{sim}")
+
+
+def test_tars_cooc_no_decay_and_xia(hip):
+    from recpack_amd.time_aware import TARSItemKNNCoocDistance, TARSItemKNNXia
+
+    g = load_golden("syn_tars_cooc_300x120")
+    K, interval = int(g["K"][0]), int(g["decay_interval"][0])
+    check_cooc(TARSItemKNNCoocDistance(K=K, fit_decay=0, decay_interval=interval, similarity="cooc"), g, "none_cooc")
+    check_cooc(TARSItemKNNXia(K=K, fit_decay=0.6, decay_function="concave", decay_interval=24 * 3600), g, "xia", with_predict=True)
