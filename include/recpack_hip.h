@@ -191,6 +191,12 @@ int rphip_itemknn_fit_values(rphip_ctx* ctx, const rphip_csr* X, int64_t row_beg
 int rphip_itemknn_fit_timedist(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K,
                                int32_t decay_kind, double decay, double max_distance, const double* row_scale_host,
                                rphip_model** out);
+/* TARSItemKNNHermann._fit (time_aware_item_knn/hermann_2010.py:64-103), values of X = last timestamps in units of
+ * decay_interval, all > 0, now = max timestamp + 1 / decay_interval (:70):
+ *   S_ij = (1 / n_ij) * sum over the users u holding i and j with t_uj != t_ui of 1 / (|t_uj - t_ui| + now - min(t_ui, t_uj))
+ * n_ij = number of users that hold both items (:97-98).  Top K of the positive entries per row. */
+int rphip_itemknn_fit_hermann(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K, double now,
+                              rphip_model** out);
 
 /* neighbour lists to host: idx int32[rows*K] (-1 padded), val float64[rows*K] (0 padded), nnz int32[rows] */
 int rphip_model_topk_download(rphip_ctx* ctx, const rphip_model* m, int32_t* idx_host, double* val_host,

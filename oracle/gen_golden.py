@@ -374,6 +374,9 @@ def tars_cooc_cases():
         algo = TARSItemKNNCoocDistance(K=2, fit_decay=0.5, similarity=sim).fit(im)
         arrays.update(csr_parts(f"S_{sim}", algo.similarity_matrix_))
         arrays.update(csr_parts(f"P_{sim}", algo.predict(im)))
+    from recpack.algorithms.time_aware_item_knn import TARSItemKNNHermann as _H
+
+    arrays.update(csr_parts("S_hermann", _H(K=2).fit(im).similarity_matrix_))
     save("ref_tars_cooc_mat", **arrays)
 
     U, I, K = 300, 120, 8
@@ -394,6 +397,12 @@ def tars_cooc_cases():
     algo = TARSItemKNNXia(K=K, fit_decay=0.6, decay_function="concave", decay_interval=24 * 3600).fit(im)
     arrays.update(csr_parts("S_xia", algo.similarity_matrix_))
     arrays.update(csr_parts("P_xia", algo.predict(im)))
+    from recpack.algorithms.time_aware_item_knn import TARSItemKNNHermann
+
+    for interval in (1, 3600):
+        algo = TARSItemKNNHermann(K=K, decay_interval=interval).fit(im)
+        arrays.update(csr_parts(f"S_hermann{interval}", algo.similarity_matrix_))
+    arrays.update(csr_parts("P_hermann3600", algo.predict(im)))
     save("syn_tars_cooc_300x120", **arrays)
 
 

@@ -490,3 +490,38 @@ def tars_cooc_fit(T: sp.csr_matrix, K: int, similarity: str, decay_function: str
     S = tars_cooc_similarity(T, similarity, decay_function, decay, decay_interval)
     idx, val, nnz = topk_rows(S, K)
     return {"idx": idx, "val": val, "nnz": nnz, "full": S}
+
+
+def tars_hermann_similarity(T: sp.csr_matrix, decay_interval: int = 1) -> sp.csr_matrix:
+    """TARSItemKNNHermann._fit before the top-K (time_aware_item_knn/hermann_2010.py:64-103), all rows at once: with
+    t = last timestamp / interval (> 0 only) and now = max t + 1 / interval (:70),
+    S_ij = (1 / n_ij) * sum over the users holding both, t_uj != t_ui, of 1 / (|t_uj - t_ui| + now - min(t_ui, t_uj)),
+    n_ij = the number of users holding both (:97-98, ``invert`` then ``multiply``)."""
+    T = sp.csr_matrix(sp.csr_matrix(T, dtype=np.float64) / decay_interval)
+    n = T.shape[1]
+    now = T.max() + 1 / decay_interval
+    keep = T.data > 0
+    rows = np.repeat(np.arange(T.shape[0]), np.diff(T.indptr))[keep]
+    cols, t = T.indices[keep].astype(np.int64), T.data[keep]
+    d = np.bincount(rows, minlength=T.shape[0])
+    start = np.concatenate([[0], np.cumsum(d)[:-1]])
+    a = np.repeat(np.arange(rows.shape[0]), d[rows])
+    b = np.arange(a.shape[0]) - np.repeat(np.cumsum(d[rows]) - d[rows], d[rows]) + start[rows[a]]
+    dist = np.abs(t[b] - t[a])
+    N = sp.coo_matrix((np.ones(a.shape[0]), (cols[a], cols[b])), shape=(n, n)).tocsr()
+    nz = dist != 0
+    w = 1 / (dist[nz] + (now - np.minimum(t[a][nz], t[b][nz])))
+    S = sp.coo_matrix((w, (cols[a][nz], cols[b][nz])), shape=(n, n)).tocsr()
+    Ninv = N.copy()
+    Ninv.data = 1 / N.data
+    S = sp.csr_matrix(S.multiply(Ninv))
+    S.setdiag(0)
+    S.eliminate_zeros()
+    S.sort_indices()
+    return S
+
+
+def tars_hermann_fit(T: sp.csr_matrix, K: int, decay_interval: int = 1):
+    S = tars_hermann_similarity(T, decay_interval)
+    idx, val, nnz = topk_rows(S, K)
+    return {"idx": idx, "val": val, "nnz": nnz, "full": S}

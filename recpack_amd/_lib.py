@@ -89,6 +89,7 @@ PROTOTYPES = {
     "rphip_csr_set_values": (C.c_int, [_p, _p, _p]),
     "rphip_itemknn_fit_values": (C.c_int, [_p, _p, _i64, _i64, _i32, _i32, _p, _pp]),
     "rphip_itemknn_fit_timedist": (C.c_int, [_p, _p, _i64, _i64, _i32, _i32, _f64, _f64, _p, _pp]),
+    "rphip_itemknn_fit_hermann": (C.c_int, [_p, _p, _i64, _i64, _i32, _f64, _pp]),
     "rphip_ease_fit": (C.c_int, [_p, _p, _f64, _f64, _pp]),
     "rphip_model_dense_download": (C.c_int, [_p, _p, _p]),
     "rphip_model_dense_device": (C.c_int, [_p, _pp, C.POINTER(_i64), C.POINTER(_i64)]),
@@ -450,6 +451,14 @@ def itemknn_fit_timedist(ctx: Context, X: DeviceCSR, K: int, decay_function: str
             raise ValueError("row_scale must have one entry per item")
     check(ctx.lib.rphip_itemknn_fit_timedist(ctx.handle, X.handle, int(row_begin), int(row_end), int(K), int(DECAY_KINDS[decay_function]),
                                              float(decay), float(max_distance), _np_ptr(rs) if rs is not None else None, C.byref(h)))
+    return Model(ctx, h)
+
+
+def itemknn_fit_hermann(ctx: Context, X: DeviceCSR, K: int, now: float, row_begin: int = 0, row_end=None) -> Model:
+    """Top-K of the average over the common users of 1 / (|t_uj - t_ui| + now - min(t_ui, t_uj)) (values = timestamps > 0)."""
+    h = C.c_void_p()
+    row_end = X.shape[1] if row_end is None else row_end
+    check(ctx.lib.rphip_itemknn_fit_hermann(ctx.handle, X.handle, int(row_begin), int(row_end), int(K), float(now), C.byref(h)))
     return Model(ctx, h)
 
 

@@ -25,6 +25,8 @@
 
 constexpr int RP_VMERGE_THREADS = 256;
 constexpr int RP_VTILE_MAX = 12288;
+constexpr int RP_VTILE_HERMANN = 8192;  // 12 bytes per column: the sum and the number of users behind it
+constexpr int RPHIP_PAIR_HERMANN = 100;
 constexpr unsigned long long RP_SIGN64 = 0x8000000000000000ull;
 
 struct rp_vfit_params {
@@ -54,9 +56,11 @@ __device__ __forceinline__ uint64_t rp_ordered_f64(double v) {
 
 struct rp_vdense_src {
   const double* acc;
+  const uint32_t* cnt;  // Hermann: the number of users behind every sum (the similarity is their average)
   int t0, row;
+  __device__ __forceinline__ double value(int w) const { return cnt ? acc[w] * (1.0 / (double)cnt[w]) : acc[w]; }
   __device__ __forceinline__ bool valid(int w) const { return acc[w] != 0.0 && (t0 + w) != row; }
-  __device__ __forceinline__ uint64_t key(int w) const { return rp_ordered_f64(acc[w]); }
+  __device__ __forceinline__ uint64_t key(int w) const { return rp_ordered_f64(value(w)); }
   __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)(t0 + w); }
 };
 
@@ -88,12 +92,17 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
   constexpr int NTHR = RP_FIT_THREADS, NW = NTHR / 64;
   double* acc = reinterpret_cast<double*>(smem);
   const int W = P.tile_w, T = P.n_tiles;
-  rp_select_smem sel = rp_select_carve(smem + (size_t)W * 8, W, NW);
+  const bool hermann = P.pair_kind == RPHIP_PAIR_HERMANN;
+  uint32_t* cntw = hermann ? reinterpret_cast<uint32_t*>(smem + (size_t)W * 8) : nullptr;
+  rp_select_smem sel = rp_select_carve(smem + (size_t)W * (hermann ? 12 : 8), W, NW);
   int* s_task = &sel.misc[RPS_USER];
   int* s_cnt = &sel.misc[RPS_USER + 1];  // [2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = wave * 4 + (lane >> 4), gl = lane & 15;  // 64 groups of 16 lanes: one user per group and round
-  for (int w = tid; w < W; w += NTHR) acc[w] = 0.0;
+  for (int w = tid; w < W; w += NTHR) {
+    acc[w] = 0.0;
+    if (hermann) cntw[w] = 0u;
+  }
   const long long n_tasks = (long long)P.n_rows * T;
   while (true) {
     __syncthreads();
@@ -134,7 +143,17 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
         }
         e = lo;
       }
-      if (P.pair_kind) {
+      if (hermann) {
+        // hermann_2010.py:64-103: S_u,i,j = 1 / (|t_uj - t_ui| + now - min(t_ui, t_uj)) for t_uj != t_ui, averaged over ALL
+        // users that hold both items (the equal-timestamp pairs count in the denominator only)
+        for (int k = s + gl; k < e; k += 16) {
+          const double x = P.x_val[k];
+          const double d = fabs(x - q);
+          const int j = P.x_idx[k] - t0;
+          atomicAdd(&cntw[j], 1u);
+          if (d != 0.0) atomicAdd(&acc[j], 1.0 / (d + (P.pair_max - fmin(x, q))));
+        }
+      } else if (P.pair_kind) {
         for (int k = s + gl; k < e; k += 16) {
           const double d = fabs(P.x_val[k] - q);
           if (d != 0.0) atomicAdd(&acc[P.x_idx[k] - t0], rp_pair_decay(P.pair_kind, P.pair_decay, P.pair_max, d));
@@ -164,7 +183,7 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
       if (T == 1) kk = rp_keff(P.K, s_cnt[0], s_cnt[1]);
     }
     // ---- select
-    rp_vdense_src src{acc, t0, row};
+    rp_vdense_src src{acc, cntw, t0, row};
     const int rl = row - P.row_begin;
     int kp = 0;
     if (kk > 0) kp = rp_select_topk<NTHR>(src, n_cols, kk, sel);
@@ -173,14 +192,14 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
       if (kk > 0)
         rp_select_emit<NTHR>(n_cols, sel, [&](int pos, int w) {
           P.out_idx[(int64_t)rl * P.K + pos] = t0 + w;
-          P.out_val[(int64_t)rl * P.K + pos] = acc[w] * ri;
+          P.out_val[(int64_t)rl * P.K + pos] = src.value(w) * ri;
         });
       if (tid == 0) P.out_nnz[rl] = kp;
     } else {
       const int64_t o = ((int64_t)rl * T + tile) * P.K;
       rp_select_emit<NTHR>(n_cols, sel, [&](int pos, int w) {
         P.out_idx[o + pos] = t0 + w;
-        P.out_val[o + pos] = acc[w];
+        P.out_val[o + pos] = src.value(w);
       });
       if (tid == 0) {
         P.out_nnz[(int64_t)rl * T + tile] = kp;
@@ -188,7 +207,10 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
       }
     }
     __syncthreads();
-    for (int w = tid; w < W; w += NTHR) acc[w] = 0.0;  // (the diagonal is in no list)
+    for (int w = tid; w < W; w += NTHR) {  // (the diagonal is in no list)
+      acc[w] = 0.0;
+      if (hermann) cntw[w] = 0u;
+    }
   }
 }
 
@@ -268,7 +290,8 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
   K = Keff;
   const int n_rows = (int)(row_end - row_begin);
   const int64_t I = X->n_items;
-  const int T = (int)std::max<int64_t>(1, rp_cdiv(I, RP_VTILE_MAX));
+  const int tile_max = (pair_kind == RPHIP_PAIR_HERMANN) ? RP_VTILE_HERMANN : RP_VTILE_MAX;
+  const int T = (int)std::max<int64_t>(1, rp_cdiv(I, tile_max));
   const int W = (int)(rp_cdiv(rp_cdiv(std::max<int64_t>(I, 1), T), 64) * 64);
   if (T > 15) RP_FAIL(RPHIP_ELIMIT, "%d valued column tiles (n_items=%lld) exceed the supported 15", T, (long long)I);
   if ((T > 1 || !left_binary) && !X->sorted_rows) RP_FAIL(RPHIP_EINVAL, "the valued fit needs column-sorted rows");
@@ -338,7 +361,7 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
     P.out_val = (T == 1) ? m->val : cand_g;
     P.out_nnz = (T == 1) ? m->nnz : cand_nnz;
     P.out_cnt = cand_cnt;
-    const size_t lds = (size_t)W * 8 + rp_select_smem_bytes(W);
+    const size_t lds = (size_t)W * (pair_kind == RPHIP_PAIR_HERMANN ? 12 : 8) + rp_select_smem_bytes(W);
     if (hipFuncSetAttribute((const void*)k_itemknn_fit_values, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return fail(RPHIP_EHIP);
     rp_time_begin(ctx, &ev);
@@ -379,4 +402,10 @@ extern "C" int rphip_itemknn_fit_timedist(rphip_ctx* ctx, const rphip_csr* X, in
     RP_FAIL(RPHIP_EINVAL, "the %s decay needs max_distance > 0 (got %g)", decay_kind == RPHIP_DECAY_LOG ? "log" : decay_kind == RPHIP_DECAY_LINEAR ? "linear" : "concave",
             max_distance);
   return rp_fit_values_impl(ctx, X, row_begin, row_end, K, 0, row_scale_host, decay_kind, decay, max_distance, out);
+}
+
+extern "C" int rphip_itemknn_fit_hermann(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K, double now,
+                                         rphip_model** out) {
+  if (X && X->x_val && !(now > X->val_max_abs)) RP_FAIL(RPHIP_EINVAL, "now = %g must lie after every timestamp (max %g)", now, X->val_max_abs);
+  return rp_fit_values_impl(ctx, X, row_begin, row_end, K, 0, nullptr, RPHIP_PAIR_HERMANN, 0.0, now, out);
 }

@@ -402,3 +402,36 @@ class TARSItemKNNXia(TARSItemKNNCoocDistance):
         if decay_function not in self.SUPPORTED_DECAY_FUNCTIONS:
             raise ValueError(f"decay_function {decay_function} not supported")
         super().__init__(K=K, fit_decay=fit_decay, decay_interval=decay_interval, similarity="cooc", decay_function=decay_function)
+
+
+class TARSItemKNNHermann(TopKItemSimilarityMatrixAlgorithm):
+    """hermann_2010.py:20-103: the similarity of two items is the average, over the users that hold both, of
+    1 / (time between the two interactions + age of the older one); binary histories at predict."""
+
+    def __init__(self, K: int = 200, decay_interval: int = 1):
+        super().__init__(K=K)
+        self.decay_interval = decay_interval
+
+    def _transform_fit_input(self, X):
+        if isinstance(X, (sp.spmatrix, np.ndarray)) or not hasattr(X, "last_timestamps_matrix"):
+            raise TypeError(f"{self.name} requires Interaction Matrix as input. Got {type(X)}.")
+        if not getattr(X, "has_timestamps", True):
+            raise ValueError(f"{self.name} requires timestamp information in the InteractionMatrix.")
+        return X
+
+    def _fit(self, X) -> None:
+        T = sp.csr_matrix(sp.csr_matrix(X.last_timestamps_matrix, dtype=np.float64) / self.decay_interval)
+        n_items = T.shape[1]
+        now = (T.max() if T.nnz else 0.0) + 1 / self.decay_interval  # hermann_2010.py:70
+        T.data = np.where(T.data > 0, T.data, 0.0)  # only timestamps > 0 take part (:76-79)
+        T = _canonical_valued(T)
+        ctx = get_context()
+        dT = _lib.DeviceCSR.from_host_valued(ctx, T)
+        try:
+            model = _lib.itemknn_fit_hermann(ctx, dT, int(self.K), float(now))
+            idx, val, nnz = model.topk_download()
+        finally:
+            dT.close()
+        self._model = model
+        self._empty_rows_ = int(np.count_nonzero(nnz == 0))
+        self.similarity_matrix_ = topk_arrays_to_csr(idx, val, nnz, n_items)

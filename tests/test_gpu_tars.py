@@ -255,3 +255,37 @@ def test_tars_cooc_no_decay_and_xia(hip):
     K, interval = int(g["K"][0]), int(g["decay_interval"][0])
     check_cooc(TARSItemKNNCoocDistance(K=K, fit_decay=0, decay_interval=interval, similarity="cooc"), g, "none_cooc")
     check_cooc(TARSItemKNNXia(K=K, fit_decay=0.6, decay_function="concave", decay_interval=24 * 3600), g, "xia", with_predict=True)
+
+
+def test_tars_hermann(hip):
+    """hermann_2010.py: the reference's fixture and the seeded log (two time units), then predict on binary histories."""
+    from recpack_amd.time_aware import TARSItemKNNHermann
+
+    def check(g, algo, tag, P_tag=None):
+        X = events(g)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            algo.fit(X)
+        S_ref = csr_from(g, f"S_{tag}")
+        S = sp.csr_matrix(algo.similarity_matrix_)
+        S.sort_indices()
+        full = onp.tars_hermann_similarity(X.last_timestamps_matrix, algo.decay_interval)
+        idx, _, nnz = dense_topk(S)
+        bad, exact = tie_aware_topk(full, S_ref, idx, nnz)
+        assert not bad, (tag, bad[:5])
+        assert abs(S.multiply(S_ref != 0) - S_ref.multiply(S != 0)).max() <= VAL_RTOL * abs(S_ref).max()
+        if P_tag:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                P = sp.csr_matrix(algo.predict(X))
+            want = onp.predict_full(X.binary_values, S.astype(np.float32).astype(np.float64))
+            assert abs(P - want).max() <= PRED_TOL * abs(want).max()
+            if exact == S.shape[0]:
+                P_ref = csr_from(g, f"P_{P_tag}")
+                assert abs(P - P_ref).max() <= 1e-6 * abs(P_ref).max()
+
+    check(load_golden("ref_tars_cooc_mat"), TARSItemKNNHermann(K=2), "hermann")
+    g = load_golden("syn_tars_cooc_300x120")
+    K = int(g["K"][0])
+    check(g, TARSItemKNNHermann(K=K, decay_interval=1), "hermann1")
+    check(g, TARSItemKNNHermann(K=K, decay_interval=3600), "hermann3600", P_tag="hermann3600")

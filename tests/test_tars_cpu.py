@@ -171,3 +171,19 @@ def test_cooc_constructor_checks():
     a = ta.TARSItemKNNXia(K=5)
     assert a.get_params() == {"K": 5, "decay_function": "convex", "decay_interval": 86400, "fit_decay": 0.5}
     assert a.predict_decay == 0 and a.similarity == "cooc"
+
+
+def test_oracle_tars_hermann():
+    """TARSItemKNNHermann (hermann_2010.py) against the reference's output on its own fixture and on the seeded log."""
+    g = load_golden("ref_tars_cooc_mat")
+    r = onp.tars_hermann_fit(last_timestamps(g), 2)
+    assert abs(onp.topk_to_csr(r["idx"], r["val"], r["nnz"], 5) - csr_from(g, "S_hermann")).max() <= 1e-15
+    g = load_golden("syn_tars_cooc_300x120")
+    T, K = last_timestamps(g), int(g["K"][0])
+    for interval in (1, 3600):
+        r = onp.tars_hermann_fit(T, K, interval)
+        S_ref = csr_from(g, f"S_hermann{interval}")
+        bad, _ = tie_aware_topk(r["full"], S_ref, r["idx"], r["nnz"])
+        assert not bad
+        S = onp.topk_to_csr(r["idx"], r["val"], r["nnz"], T.shape[1])
+        assert abs(S.multiply(S_ref != 0) - S_ref.multiply(S != 0)).max() <= 1e-12 * abs(S_ref).max()
