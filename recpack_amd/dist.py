@@ -109,9 +109,11 @@ def model_dense_tensor(model, device):
     return full[:, :n]
 
 
-def fit_itemknn_sharded(ctx, dX, K: int, parts: Sequence[Tuple[int, int]], device, group=None, **fit_kwargs):
+def fit_itemknn_sharded(ctx, dX, K: int, parts: Sequence[Tuple[int, int]], device, group=None, fit_fn=None, **fit_kwargs):
     """Fit this rank's item rows on its GPU, all-gather, return a predict-ready full model (replicated).
-    ``fit_kwargs`` (similarity, pop_discount, normalize_X) go to ``_lib.itemknn_fit``."""
+    ``fit_kwargs`` (similarity, pop_discount, normalize_X) go to ``_lib.itemknn_fit``; ``fit_fn(row_begin, row_end)``
+    replaces it for the other neighbour-list fits (``itemknn_fit_values`` / ``_timedist`` / ``_hermann`` of the
+    time-aware family: item rows are independent there as well)."""
     import torch
     import torch.distributed as dist
 
@@ -119,7 +121,7 @@ def fit_itemknn_sharded(ctx, dX, K: int, parts: Sequence[Tuple[int, int]], devic
 
     rank = dist.get_rank(group)
     b, e = parts[rank]
-    local = _lib.itemknn_fit(ctx, dX, K, b, e, **fit_kwargs)
+    local = fit_fn(b, e) if fit_fn is not None else _lib.itemknn_fit(ctx, dX, K, b, e, **fit_kwargs)
     idx, val, nnz = model_topk_tensors(local, device)
     ctx.sync()  # the collective runs on torch's stream: order it after the library's stream
     idx_f, val_f, nnz_f = allgather_topk(idx, val, nnz, parts, group)

@@ -289,3 +289,48 @@ def test_tars_hermann(hip):
     K = int(g["K"][0])
     check(g, TARSItemKNNHermann(K=K, decay_interval=1), "hermann1")
     check(g, TARSItemKNNHermann(K=K, decay_interval=3600), "hermann3600", P_tag="hermann3600")
+
+
+def same_rows(full, part, b, e, name):
+    """Float64 sums by atomics differ in the last bits from run to run (and may flip an exact tie): same row sizes, the
+    same selected values up to 1e-12, the same columns wherever the values are not tied."""
+    (fi, fv, fn), (pi, pv, pn) = full, part
+    np.testing.assert_array_equal(fn[b:e], pn, err_msg=name)
+    np.testing.assert_allclose(np.sort(fv[b:e], axis=1), np.sort(pv, axis=1), rtol=1e-12, err_msg=name)
+    assert e == b or (fi[b:e] == pi).mean() > 0.98, name
+
+
+def test_valued_fits_shard_by_item_rows(hip):
+    """SURVEY 8(e) for the time-aware fits: item rows are independent - any split of the rows gives the rows of the full fit,
+    and the sharded driver (world size 1: RCCL all-gather of one part) assembles a predict-ready model."""
+    import torch
+    import torch.distributed as dist
+
+    from recpack_amd import dist as rdist
+
+    _lib, ctx = hip
+    g = load_golden("syn_tars_cooc_300x120")
+    T = sp.csr_matrix(events(g).last_timestamps_matrix, dtype=np.float64)
+    T.eliminate_zeros()
+    T.sort_indices()
+    dT = _lib.DeviceCSR.from_host_valued(ctx, T)
+    n = T.shape[1]
+    fits = {
+        "values": lambda b, e: _lib.itemknn_fit_values(ctx, dT, 8, row_begin=b, row_end=e),
+        "timedist": lambda b, e: _lib.itemknn_fit_timedist(ctx, dT, 8, "exponential", 1e-6, float(T.data.max() - T.data.min()), row_begin=b, row_end=e),
+        "hermann": lambda b, e: _lib.itemknn_fit_hermann(ctx, dT, 8, float(T.data.max() + 1), row_begin=b, row_end=e),
+    }
+    for name, fit in fits.items():
+        full = fit(0, n).topk_download()
+        for b, e in ((0, 37), (37, 38), (38, n), (50, 50)):
+            part = fit(b, e).topk_download()
+            same_rows(full, part, b, e, name)
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29573", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        m = rdist.fit_itemknn_sharded(ctx, dT, 8, [(0, n)], torch.device("cuda", 0), fit_fn=fits["hermann"])
+        same_rows(fits["hermann"](0, n).topk_download(), m.topk_download(), 0, n, "sharded")
+        idx, val, nnz = _lib.predict_topk(ctx, m, dT, 5, False)
+        assert (nnz > 0).any()
+    finally:
+        dist.destroy_process_group()
