@@ -143,5 +143,7 @@ int rp_gram_dense(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t
 
 // rp_predict.hip: val (f64) -> val32 + pairs, column-order check; call once the lists are complete
 int rp_model_finalize_topk(rphip_ctx* ctx, rphip_model* m);
+// out[u * (T + 1) + t] = first position of (column-sorted) row u with column >= t * W   (rp_itemknn_v.hip)
+int rp_user_tile_ptr(rphip_ctx* ctx, const rphip_csr* X, int T, int W, int32_t* out);
 
 static inline int64_t rp_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

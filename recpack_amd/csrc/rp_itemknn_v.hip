@@ -36,6 +36,8 @@ struct rp_vfit_params {
   const int32_t* xt_ptr;
   const int32_t* xt_idx;
   const int32_t* order;   // rows by descending cost
+  const int32_t* vt_ptr;  // T > 1: [U * (T + 1)] first position of row u with column >= t * W
+  const double* xt_val;   // !left_binary: [nnz] the value of every X^T entry (order of xt_idx)
   const double* roww;     // [I] or NULL
   int left_binary, signed_vals;
   int pair_kind;          // 0: products L_ui * X_uj; > 0: a decay (RPHIP_DECAY_*) of |X_uj - X_ui|, equal values add nothing
@@ -116,51 +118,59 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
     const int row = P.order[task / T], tile = (int)(task % T);
     const int t0 = tile * W, n_cols = min(W, P.n_items - t0);
     // ---- accumulate
+    // Four users per 16-lane group and round, the loads of one kind issued together: user id and left value, then the
+    // slice bounds, then the first 16 entries of every slice.
     const int pe = P.xt_ptr[row + 1];
-    for (int p = P.xt_ptr[row] + grp; p < pe; p += 64) {
-      const int u = P.xt_idx[p];
-      int s = P.x_ptr[u], e = P.x_ptr[u + 1];
-      double q = 1.0;
-      if (!P.left_binary) {  // the user's value for this row's item: rows are column-sorted
-        int lo = s, hi = e;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (P.x_idx[mid] < row) lo = mid + 1; else hi = mid;
-        }
-        q = P.x_val[lo];
-      }
-      if (T > 1) {  // the slice of the row that falls into this tile
-        int lo = s, hi = e;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (P.x_idx[mid] < t0) lo = mid + 1; else hi = mid;
-        }
-        s = lo;
-        hi = e;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (P.x_idx[mid] < t0 + n_cols) lo = mid + 1; else hi = mid;
-        }
-        e = lo;
-      }
+    constexpr int UNR = 4;
+    auto add = [&](int j, double q, double x) __attribute__((always_inline)) {
       if (hermann) {
         // hermann_2010.py:64-103: S_u,i,j = 1 / (|t_uj - t_ui| + now - min(t_ui, t_uj)) for t_uj != t_ui, averaged over ALL
         // users that hold both items (the equal-timestamp pairs count in the denominator only)
-        for (int k = s + gl; k < e; k += 16) {
-          const double x = P.x_val[k];
-          const double d = fabs(x - q);
-          const int j = P.x_idx[k] - t0;
-          atomicAdd(&cntw[j], 1u);
-          if (d != 0.0) atomicAdd(&acc[j], 1.0 / (d + (P.pair_max - fmin(x, q))));
-        }
+        const double d = fabs(x - q);
+        atomicAdd(&cntw[j], 1u);
+        if (d != 0.0) atomicAdd(&acc[j], 1.0 / (d + (P.pair_max - fmin(x, q))));
       } else if (P.pair_kind) {
-        for (int k = s + gl; k < e; k += 16) {
-          const double d = fabs(P.x_val[k] - q);
-          if (d != 0.0) atomicAdd(&acc[P.x_idx[k] - t0], rp_pair_decay(P.pair_kind, P.pair_decay, P.pair_max, d));
-        }
+        const double d = fabs(x - q);
+        if (d != 0.0) atomicAdd(&acc[j], rp_pair_decay(P.pair_kind, P.pair_decay, P.pair_max, d));
       } else {
-        for (int k = s + gl; k < e; k += 16) atomicAdd(&acc[P.x_idx[k] - t0], q * P.x_val[k]);
+        atomicAdd(&acc[j], q * x);
       }
+    };
+    for (int p0 = P.xt_ptr[row] + grp; p0 < pe; p0 += 64 * UNR) {
+      int u[UNR], s[UNR], e[UNR], c[UNR];
+      double q[UNR], x[UNR];
+#pragma unroll
+      for (int r = 0; r < UNR; ++r) {
+        const int p = p0 + 64 * r;
+        u[r] = (p < pe) ? P.xt_idx[p] : -1;
+        q[r] = (p < pe && !P.left_binary) ? P.xt_val[p] : 1.0;  // the user's value for this row's item
+      }
+#pragma unroll
+      for (int r = 0; r < UNR; ++r) {
+        s[r] = e[r] = 0;
+        if (u[r] >= 0) {
+          if (T > 1) {  // the slice of the user's row that falls into this tile
+            const int32_t* tp = P.vt_ptr + (int64_t)u[r] * (T + 1) + tile;
+            s[r] = tp[0];
+            e[r] = tp[1];
+          } else {
+            s[r] = P.x_ptr[u[r]];
+            e[r] = P.x_ptr[u[r] + 1];
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < UNR; ++r) {
+        const int k = s[r] + gl;
+        c[r] = (k < e[r]) ? P.x_idx[k] : -1;
+        x[r] = (k < e[r]) ? P.x_val[k] : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < UNR; ++r)
+        if (c[r] >= 0) add(c[r] - t0, q[r], x[r]);
+#pragma unroll
+      for (int r = 0; r < UNR; ++r)  // slices longer than 16 entries
+        for (int k = s[r] + gl + 16; k < e[r]; k += 16) add(P.x_idx[k] - t0, q[r], P.x_val[k]);
     }
     __syncthreads();
     // ---- with negative entries the diagonal's stored zero decides how many of them the reference keeps
@@ -212,6 +222,55 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
       if (hermann) cntw[w] = 0u;
     }
   }
+}
+
+// The two lookups the accumulate loop would otherwise repeat per (row, user, tile), done once per fit:
+// tile pointers of every user row (rows are column-sorted) ...
+__global__ void k_user_tile_ptr(const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ x_idx, int64_t n_users, int T, int W,
+                                int32_t* __restrict__ out) {
+  const int64_t n = n_users * (T + 1);
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t u = g / (T + 1);
+    const int t = (int)(g % (T + 1));
+    int lo = x_ptr[u], hi = x_ptr[u + 1];
+    const int64_t c0 = (int64_t)t * W;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (x_idx[mid] < c0) lo = mid + 1; else hi = mid;
+    }
+    out[g] = lo;
+  }
+}
+
+// ... and the value of every X^T entry: entry p of item row i holds user u, its value is X[u, i] (found in the sorted row u)
+__global__ void k_xt_values(const int32_t* __restrict__ xt_ptr, const int32_t* __restrict__ xt_idx, const int32_t* __restrict__ x_ptr,
+                            const int32_t* __restrict__ x_idx, const double* __restrict__ x_val, int n_items, int64_t nnz,
+                            double* __restrict__ out) {
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n_items;  // the row i with xt_ptr[i] <= p < xt_ptr[i + 1]
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((int64_t)xt_ptr[mid + 1] <= p) lo = mid + 1; else hi = mid;
+    }
+    const int i = lo;
+    const int u = xt_idx[p];
+    lo = x_ptr[u];
+    hi = x_ptr[u + 1];
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (x_idx[mid] < i) lo = mid + 1; else hi = mid;
+    }
+    out[p] = x_val[lo];
+  }
+}
+
+int rp_user_tile_ptr(rphip_ctx* ctx, const rphip_csr* X, int T, int W, int32_t* out) {
+  const int64_t n = X->n_users * (int64_t)(T + 1);
+  if (n <= 0) return RPHIP_OK;
+  hipLaunchKernelGGL(k_user_tile_ptr, dim3((unsigned)std::min<int64_t>(65535, rp_cdiv(n, 256))), dim3(256), 0, ctx->stream, X->x_ptr, X->x_idx,
+                     X->n_users, T, W, out);
+  RP_HIP(hipGetLastError());
+  return RPHIP_OK;
 }
 
 struct rp_vlist_src {
@@ -309,7 +368,10 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
   if (n_rows > 0 && X->nnz > 0) {
     char* sc = nullptr;
     const size_t cand_n = (T > 1) ? (size_t)n_rows * T * K : 0;
-    const size_t bytes = (size_t)I * 8 + RP_PLAN_BUCKETS * 4 + (size_t)n_rows * 4 + 64 + cand_n * 12 + (size_t)n_rows * T * 8 + 512;
+    const size_t vt_n = (T > 1) ? (size_t)X->n_users * (T + 1) : 0;
+    const size_t xtv_n = left_binary ? 0 : (size_t)X->nnz;
+    const size_t bytes = (size_t)I * 8 + RP_PLAN_BUCKETS * 4 + (size_t)n_rows * 4 + 64 + cand_n * 12 + (size_t)n_rows * T * 8 + vt_n * 4 +
+                         xtv_n * 8 + 1024;
     int rc = rp_scratch(ctx, 0, bytes, (void**)&sc);
     if (rc != RPHIP_OK) return fail(rc);
     size_t o = 0;
@@ -326,6 +388,8 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
     int32_t* cand_idx = (int32_t*)carve(cand_n * 4);
     int32_t* cand_nnz = (int32_t*)carve((size_t)n_rows * T * 4);
     int32_t* cand_cnt = (int32_t*)carve((size_t)n_rows * T * 4);
+    int32_t* vt_ptr = (int32_t*)carve(vt_n * 4);
+    double* xt_val = (double*)carve(xtv_n * 8);
     hipEvent_t ev;
     rp_time_begin(ctx, &ev);
     hipMemsetAsync(ticket, 0, 64, st);
@@ -335,6 +399,13 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
     }
     rc = rp_plan_row_order(ctx, X, row_begin, n_rows, bucket, order);
     if (rc != RPHIP_OK) return fail(rc);
+    if (T > 1) {
+      rc = rp_user_tile_ptr(ctx, X, T, W, vt_ptr);
+      if (rc != RPHIP_OK) return fail(rc);
+    }
+    if (!left_binary)
+      hipLaunchKernelGGL(k_xt_values, dim3((unsigned)std::min<int64_t>(65535, rp_cdiv(X->nnz, 256))), dim3(256), 0, st, X->xt_ptr, X->xt_idx,
+                         X->x_ptr, X->x_idx, X->x_val, (int)I, X->nnz, xt_val);
     if (row_scale_host && hipMemcpyAsync(roww, row_scale_host, (size_t)I * 8, hipMemcpyHostToDevice, st) != hipSuccess) return fail(RPHIP_EHIP);
     rp_time_end(ctx, ev, RPHIP_T_FIT_PLAN, 0.0);
     rp_vfit_params P;
@@ -344,6 +415,8 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
     P.xt_ptr = X->xt_ptr;
     P.xt_idx = X->xt_idx;
     P.order = order;
+    P.vt_ptr = vt_ptr;
+    P.xt_val = xt_val;
     P.roww = row_scale_host ? roww : nullptr;
     P.left_binary = left_binary ? 1 : 0;
     P.signed_vals = (X->val_neg && !pair_kind) ? 1 : 0;  // decayed distances are never negative

@@ -21,6 +21,7 @@ struct rp_wfit_params {
   const int32_t* xt_ptr;
   const int32_t* xt_idx;
   const int32_t* order;    // rows by descending degree
+  const int32_t* vt_ptr;   // T > 1: [U * (T + 1)] tile pointers of the user rows
   const double* user_q;    // [U] what one common user adds
   const double* colw;      // [I] key = G_ij * colw_j (monotone in S_ij for a fixed row)
   const double* roww;      // [I] S_ij = key * roww_i
@@ -60,26 +61,44 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_weighted(rp_wfit
     const int row = P.order[task / T], tile = (int)(task % T);
     const int t0 = tile * W, n_cols = min(W, P.n_items - t0);
     // ---- accumulate
+    // four users per 16-lane group and round, the loads of one kind issued together (see rp_itemknn_v.hip)
     const int pe = P.xt_ptr[row + 1];
-    for (int p = P.xt_ptr[row] + grp; p < pe; p += 64) {
-      const int u = P.xt_idx[p];
-      const double q = P.user_q[u];
-      int s = P.x_ptr[u], e = P.x_ptr[u + 1];
-      if (T > 1) {  // the slice of the (column-sorted) row that falls into this tile
-        int lo = s, hi = e;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (P.x_idx[mid] < t0) lo = mid + 1; else hi = mid;
-        }
-        s = lo;
-        hi = e;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (P.x_idx[mid] < t0 + n_cols) lo = mid + 1; else hi = mid;
-        }
-        e = lo;
+    constexpr int UNR = 4;
+    for (int p0 = P.xt_ptr[row] + grp; p0 < pe; p0 += 64 * UNR) {
+      int u[UNR], s[UNR], e[UNR], c[UNR];
+      double q[UNR];
+#pragma unroll
+      for (int r = 0; r < UNR; ++r) {
+        const int p = p0 + 64 * r;
+        u[r] = (p < pe) ? P.xt_idx[p] : -1;
       }
-      for (int k = s + gl; k < e; k += 16) atomicAdd(&acc[P.x_idx[k] - t0], q);
+#pragma unroll
+      for (int r = 0; r < UNR; ++r) {
+        s[r] = e[r] = 0;
+        q[r] = 0.0;
+        if (u[r] >= 0) {
+          q[r] = P.user_q[u[r]];
+          if (T > 1) {  // the slice of the (column-sorted) row that falls into this tile
+            const int32_t* tp = P.vt_ptr + (int64_t)u[r] * (T + 1) + tile;
+            s[r] = tp[0];
+            e[r] = tp[1];
+          } else {
+            s[r] = P.x_ptr[u[r]];
+            e[r] = P.x_ptr[u[r] + 1];
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < UNR; ++r) {
+        const int k = s[r] + gl;
+        c[r] = (k < e[r]) ? P.x_idx[k] : -1;
+      }
+#pragma unroll
+      for (int r = 0; r < UNR; ++r)
+        if (c[r] >= 0) atomicAdd(&acc[c[r] - t0], q[r]);
+#pragma unroll
+      for (int r = 0; r < UNR; ++r)
+        for (int k = s[r] + gl + 16; k < e[r]; k += 16) atomicAdd(&acc[P.x_idx[k] - t0], q[r]);
     }
     __syncthreads();
     // ---- select
@@ -214,7 +233,9 @@ int rp_gram_weighted(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int6
   if (n_rows > 0 && X->nnz > 0) {
     char* sc = nullptr;
     const size_t cand_n = (T > 1) ? (size_t)n_rows * T * K : 0;
-    const size_t bytes = (size_t)U * 8 + (size_t)I * 8 + RP_PLAN_BUCKETS * 4 + (size_t)n_rows * 4 + 64 + cand_n * 12 + (size_t)n_rows * T * 4 + 256;
+    const size_t vt_n = (T > 1) ? (size_t)U * (T + 1) : 0;
+    const size_t bytes = (size_t)U * 8 + (size_t)I * 8 + RP_PLAN_BUCKETS * 4 + (size_t)n_rows * 4 + 64 + cand_n * 12 + (size_t)n_rows * T * 4 +
+                         vt_n * 4 + 512;
     int rc = rp_scratch(ctx, 0, bytes, (void**)&sc);
     if (rc != RPHIP_OK) return fail(rc);
     size_t o = 0;
@@ -231,12 +252,17 @@ int rp_gram_weighted(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int6
     double* cand_g = (double*)carve(cand_n * 8);
     int32_t* cand_idx = (int32_t*)carve(cand_n * 4);
     int32_t* cand_nnz = (int32_t*)carve((size_t)n_rows * T * 4);
+    int32_t* vt_ptr = (int32_t*)carve(vt_n * 4);
     hipEvent_t ev;
     rp_time_begin(ctx, &ev);
     hipMemsetAsync(ticket, 0, 64, st);
     if (T > 1) hipMemsetAsync(cand_nnz, 0, (size_t)n_rows * T * 4, st);
     rc = rp_plan_row_order(ctx, X, row_begin, n_rows, bucket, order);
     if (rc != RPHIP_OK) return fail(rc);
+    if (T > 1) {
+      rc = rp_user_tile_ptr(ctx, X, T, W, vt_ptr);
+      if (rc != RPHIP_OK) return fail(rc);
+    }
     hipLaunchKernelGGL(k_user_weights, dim3((unsigned)std::min<int64_t>(2048, rp_cdiv(U, 256))), dim3(256), 0, st, X->x_ptr, (int)U,
                        similarity == RPHIP_SIM_COSINE ? 1 : 0, user_q);
     const double* roww = nullptr;
@@ -255,6 +281,7 @@ int rp_gram_weighted(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int6
     P.xt_ptr = X->xt_ptr;
     P.xt_idx = X->xt_idx;
     P.order = order;
+    P.vt_ptr = vt_ptr;
     P.user_q = user_q;
     P.colw = colw;
     P.roww = roww;

@@ -24,6 +24,7 @@ __global__ void __launch_bounds__(1024) k_bench(int iters, int words, unsigned l
       if (MODE == 3) atomicAdd(&acc[(threadIdx.x + e * 1024 + i * 64) % words], 1u);
       if (MODE == 4) atomicAdd(reinterpret_cast<unsigned long long*>(acc) + (r >> 1), (unsigned long long)x);
       if (MODE == 5) { uint32_t old = atomicAdd(&acc[r], 1u); x += old; }
+      if (MODE == 6) atomicAdd(reinterpret_cast<double*>(acc) + (r >> 1), 1.0 + (double)(x & 1023u) * 1e-3);
     }
   }
   __syncthreads();
@@ -69,5 +70,6 @@ int main() {
   run<3>("u32 add, lane-linear", 25600);
   run<4>("u64 add, random, 12800 qwords", 25600);
   run<5>("u32 add returning, random", 25600);
+  run<6>("f64 add, random, 12288 doubles", 24576);
   return 0;
 }
