@@ -43,6 +43,7 @@ struct rp_vfit_params {
   int pair_kind;          // 0: products L_ui * X_uj; > 0: a decay (RPHIP_DECAY_*) of |X_uj - X_ui|, equal values add nothing
   double pair_decay, pair_max;
   int n_items, n_rows, n_tiles, tile_w, K, row_begin;
+  const int32_t* n_rows_dev;  // when set: the number of rows in `order` (a list built on the device)
   int32_t* ticket;
   int32_t* out_idx;       // T == 1: model rows; T > 1: per-tile candidates
   double* out_val;
@@ -82,6 +83,23 @@ __device__ __forceinline__ double rp_pair_decay(int kind, double a, double N, do
   }
 }
 
+// one term of the Gram: products, a decay of the time distance, or Hermann's 1 / (distance + age) with its user count
+__device__ __forceinline__ void rp_vadd(double* acc, uint32_t* cntw, int j, double q, double x, int pair_kind, double pair_decay,
+                                        double pair_max) {
+  if (pair_kind == RPHIP_PAIR_HERMANN) {
+    // hermann_2010.py:64-103: S_u,i,j = 1 / (|t_uj - t_ui| + now - min(t_ui, t_uj)) for t_uj != t_ui, averaged over ALL
+    // users that hold both items (the equal-timestamp pairs count in the denominator only)
+    const double d = fabs(x - q);
+    atomicAdd(&cntw[j], 1u);
+    if (d != 0.0) atomicAdd(&acc[j], 1.0 / (d + (pair_max - fmin(x, q))));
+  } else if (pair_kind) {
+    const double d = fabs(x - q);
+    if (d != 0.0) atomicAdd(&acc[j], rp_pair_decay(pair_kind, pair_decay, pair_max, d));
+  } else {
+    atomicAdd(&acc[j], q * x);
+  }
+}
+
 __device__ __forceinline__ int rp_keff(int K, int n_pos, int n_neg) {
   int k = min(K, n_pos);
   const int rest = K - n_pos - 1;
@@ -105,7 +123,7 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
     acc[w] = 0.0;
     if (hermann) cntw[w] = 0u;
   }
-  const long long n_tasks = (long long)P.n_rows * T;
+  const long long n_tasks = (long long)(P.n_rows_dev ? *P.n_rows_dev : P.n_rows) * T;
   while (true) {
     __syncthreads();
     if (tid == 0) {
@@ -123,18 +141,7 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
     const int pe = P.xt_ptr[row + 1];
     constexpr int UNR = 4;
     auto add = [&](int j, double q, double x) __attribute__((always_inline)) {
-      if (hermann) {
-        // hermann_2010.py:64-103: S_u,i,j = 1 / (|t_uj - t_ui| + now - min(t_ui, t_uj)) for t_uj != t_ui, averaged over ALL
-        // users that hold both items (the equal-timestamp pairs count in the denominator only)
-        const double d = fabs(x - q);
-        atomicAdd(&cntw[j], 1u);
-        if (d != 0.0) atomicAdd(&acc[j], 1.0 / (d + (P.pair_max - fmin(x, q))));
-      } else if (P.pair_kind) {
-        const double d = fabs(x - q);
-        if (d != 0.0) atomicAdd(&acc[j], rp_pair_decay(P.pair_kind, P.pair_decay, P.pair_max, d));
-      } else {
-        atomicAdd(&acc[j], q * x);
-      }
+      rp_vadd(acc, cntw, j, q, x, P.pair_kind, P.pair_decay, P.pair_max);
     };
     for (int p0 = P.xt_ptr[row] + grp; p0 < pe; p0 += 64 * UNR) {
       int u[UNR], s[UNR], e[UNR], c[UNR];
@@ -224,6 +231,192 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
   }
 }
 
+// ---- light rows: all columns at once in a hash table ------------------------------------------------------------------
+// With more items than one tile holds, every (row, tile) task walks the row's users again; for the many rows with a
+// handful of users that is all fixed cost (C4: 87 % of the rows have at most 64 users).  A row whose products number at
+// most RP_VHASH_MAX touches at most that many columns: they fit an open-addressing table in LDS (column -> float64 sum),
+// one task per row, no tiles, no merge.  Selection runs over the table's slots; the selected entries are put in column
+// order through a small staging area.
+constexpr int RP_VHASH_SLOTS = 8192;  // (a power of two)
+constexpr int RP_VHASH_MAX = 4800;    // products per row: load factor <= 0.59
+constexpr int RP_VHASH_KMAX = 512;    // staging area over the dead histogram: 4 + 8 bytes per selected entry
+constexpr uint32_t RP_VHASH_EMPTY = 0xffffffffu;
+
+__device__ __forceinline__ int rp_vhash_slot(uint32_t* keys, uint32_t col) {
+  uint32_t h = (col * 2654435761u) >> 19;
+  while (true) {
+    const uint32_t prev = atomicCAS(&keys[h], RP_VHASH_EMPTY, col);
+    if (prev == RP_VHASH_EMPTY || prev == col) return (int)h;
+    h = (h + 1) & (RP_VHASH_SLOTS - 1);
+  }
+}
+
+struct rp_vhash_src {
+  const double* acc;
+  const uint32_t* cnt;
+  const uint32_t* keys;
+  int row;
+  __device__ __forceinline__ double value(int w) const { return cnt ? acc[w] * (1.0 / (double)cnt[w]) : acc[w]; }
+  __device__ __forceinline__ bool valid(int w) const { return keys[w] != RP_VHASH_EMPTY && acc[w] != 0.0 && (int)keys[w] != row; }
+  __device__ __forceinline__ uint64_t key(int w) const { return rp_ordered_f64(value(w)); }
+  __device__ __forceinline__ uint32_t col(int w) const { return keys[w]; }
+};
+
+__global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values_hash(rp_vfit_params P, const int32_t* __restrict__ rows,
+                                                                           const int32_t* __restrict__ n_rows_dev) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NTHR = RP_FIT_THREADS, NW = NTHR / 64, W = RP_VHASH_SLOTS;
+  double* acc = reinterpret_cast<double*>(smem);
+  uint32_t* keys = reinterpret_cast<uint32_t*>(smem + (size_t)W * 8);
+  const bool hermann = P.pair_kind == RPHIP_PAIR_HERMANN;
+  uint32_t* cntw = hermann ? reinterpret_cast<uint32_t*>(smem + (size_t)W * 12) : nullptr;
+  rp_select_smem sel = rp_select_carve(smem + (size_t)W * (hermann ? 16 : 12), W, NW);
+  int* s_task = &sel.misc[RPS_USER];
+  int* s_cnt = &sel.misc[RPS_USER + 1];  // [2]
+  uint32_t* ecol = sel.hist;                                    // staging (the histogram is dead once the selection is done)
+  double* eval = reinterpret_cast<double*>(sel.hist + 1024);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave * 4 + (lane >> 4), gl = lane & 15;
+  for (int w = tid; w < W; w += NTHR) {
+    acc[w] = 0.0;
+    keys[w] = RP_VHASH_EMPTY;
+    if (hermann) cntw[w] = 0u;
+  }
+  const int n_tasks = *n_rows_dev;
+  while (true) {
+    __syncthreads();
+    if (tid == 0) {
+      s_task[0] = atomicAdd(P.ticket + 1, 1);
+      s_cnt[0] = s_cnt[1] = 0;
+    }
+    __syncthreads();
+    const int task = s_task[0];
+    if (task >= n_tasks) break;
+    const int row = rows[task];
+    // ---- accumulate: one user per 16-lane group and round (these rows have few users)
+    const int pe = P.xt_ptr[row + 1];
+    for (int p = P.xt_ptr[row] + grp; p < pe; p += 64) {
+      const int u = P.xt_idx[p];
+      const double q = P.left_binary ? 1.0 : P.xt_val[p];
+      const int e = P.x_ptr[u + 1];
+      for (int k = P.x_ptr[u] + gl; k < e; k += 16) {
+        const int slot = rp_vhash_slot(keys, (uint32_t)P.x_idx[k]);
+        rp_vadd(acc, cntw, slot, q, P.x_val[k], P.pair_kind, P.pair_decay, P.pair_max);
+      }
+    }
+    __syncthreads();
+    rp_vhash_src src{acc, cntw, keys, row};
+    int kk = P.K;
+    if (P.signed_vals) {
+      int np = 0, nn = 0;
+      for (int w = tid; w < W; w += NTHR) {
+        if (keys[w] == RP_VHASH_EMPTY || (int)keys[w] == row) continue;
+        const double v = acc[w];
+        np += v > 0.0;
+        nn += v < 0.0;
+      }
+      np = rp_wave_sum(np);
+      nn = rp_wave_sum(nn);
+      if (lane == 0) {
+        atomicAdd(&s_cnt[0], np);
+        atomicAdd(&s_cnt[1], nn);
+      }
+      __syncthreads();
+      kk = rp_keff(P.K, s_cnt[0], s_cnt[1]);
+    }
+    const int rl = row - P.row_begin;
+    int kp = 0;
+    if (kk > 0) {
+      kp = rp_select_topk<NTHR>(src, W, kk, sel);
+      const double ri = P.roww ? P.roww[row] : 1.0;
+      rp_select_emit<NTHR>(W, sel, [&](int pos, int w) {  // slot order: staged, then ranked by column
+        ecol[pos] = keys[w];
+        eval[pos] = src.value(w) * ri;
+      });
+      __syncthreads();
+      for (int e = tid; e < kp; e += NTHR) {
+        const uint32_t c = ecol[e];
+        int rank = 0;
+        for (int o = 0; o < kp; ++o) rank += ecol[o] < c;
+        P.out_idx[(int64_t)rl * P.K + rank] = (int)c;
+        P.out_val[(int64_t)rl * P.K + rank] = eval[e];
+      }
+    }
+    if (tid == 0) P.out_nnz[rl] = kp;
+    __syncthreads();
+    for (int w = tid; w < W; w += NTHR) {
+      acc[w] = 0.0;
+      keys[w] = RP_VHASH_EMPTY;
+      if (hermann) cntw[w] = 0u;
+    }
+  }
+}
+
+// light[rl] = the row's products (sum of its users' degrees) number at most RP_VHASH_MAX; one wave per row
+__global__ void k_vrow_light(const int32_t* __restrict__ xt_ptr, const int32_t* __restrict__ xt_idx, const int32_t* __restrict__ x_ptr,
+                             int row_begin, int n_rows, int32_t* __restrict__ light) {
+  const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  for (int rl = blockIdx.x * wpb + (threadIdx.x >> 6); rl < n_rows; rl += gridDim.x * wpb) {
+    const int i = row_begin + rl;
+    const int b = xt_ptr[i], e = xt_ptr[i + 1];
+    int ok = 0;
+    if (e - b <= RP_VHASH_MAX) {
+      int sum = 0;
+      for (int p = b + lane; p < e; p += 64) {
+        const int u = xt_idx[p];
+        sum += x_ptr[u + 1] - x_ptr[u];
+      }
+      sum = rp_wave_sum(sum);
+      ok = sum <= RP_VHASH_MAX;
+    }
+    if (lane == 0) light[rl] = ok;
+  }
+}
+
+// stable partition of `order` (descending cost) into the tiled kernel's list and the hash kernel's list; one workgroup
+__global__ void __launch_bounds__(1024) k_vrow_split(const int32_t* __restrict__ order, const int32_t* __restrict__ light, int row_begin,
+                                                     int n_rows, int32_t* __restrict__ heavy_list, int32_t* __restrict__ light_list,
+                                                     int32_t* __restrict__ counts) {
+  __shared__ int s_h[16], s_l[16], s_base[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_base[0] = s_base[1] = 0;
+  __syncthreads();
+  for (int k0 = 0; k0 < n_rows; k0 += 1024) {
+    const int k = k0 + tid;
+    const int row = (k < n_rows) ? order[k] : -1;
+    const bool is_l = row >= 0 && light[row - row_begin] != 0, is_h = row >= 0 && !is_l;
+    const uint64_t mh = __ballot(is_h), ml = __ballot(is_l);
+    if (lane == 0) {
+      s_h[wave] = __popcll(mh);
+      s_l[wave] = __popcll(ml);
+    }
+    __syncthreads();
+    int oh = s_base[0], ol = s_base[1];
+    for (int w = 0; w < wave; ++w) {
+      oh += s_h[w];
+      ol += s_l[w];
+    }
+    const uint64_t lt = (1ull << lane) - 1ull;
+    if (is_h) heavy_list[oh + __popcll(mh & lt)] = row;
+    if (is_l) light_list[ol + __popcll(ml & lt)] = row;
+    __syncthreads();
+    if (tid == 0) {
+      int th = 0, tl = 0;
+      for (int w = 0; w < 16; ++w) {
+        th += s_h[w];
+        tl += s_l[w];
+      }
+      s_base[0] += th;
+      s_base[1] += tl;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    counts[0] = s_base[0];
+    counts[1] = s_base[1];
+  }
+}
+
 // The two lookups the accumulate loop would otherwise repeat per (row, user, tile), done once per fit:
 // tile pointers of every user row (rows are column-sorted) ...
 __global__ void k_user_tile_ptr(const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ x_idx, int64_t n_users, int T, int W,
@@ -286,8 +479,9 @@ struct rp_vlist_src {
 __global__ void __launch_bounds__(RP_VMERGE_THREADS) k_itemknn_merge_values(const int32_t* __restrict__ cand_idx, const double* __restrict__ cand_g,
                                                                            const int32_t* __restrict__ cand_nnz, const int32_t* __restrict__ cand_cnt,
                                                                            const double* __restrict__ roww, int signed_vals, int n_tiles, int K,
-                                                                           int n_rows, int row_begin, int32_t* __restrict__ out_idx,
-                                                                           double* __restrict__ out_val, int32_t* __restrict__ out_nnz) {
+                                                                           int n_rows, int row_begin, const int32_t* __restrict__ light,
+                                                                           int32_t* __restrict__ out_idx, double* __restrict__ out_val,
+                                                                           int32_t* __restrict__ out_nnz) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int T = n_tiles, cap = T * K;
   double* lg = reinterpret_cast<double*>(smem);
@@ -296,6 +490,7 @@ __global__ void __launch_bounds__(RP_VMERGE_THREADS) k_itemknn_merge_values(cons
   int* s_off = &sel.misc[RPS_USER];  // [T + 1], then K_eff
   const int tid = threadIdx.x;
   for (int rl = blockIdx.x; rl < n_rows; rl += gridDim.x) {
+    if (light && light[rl]) continue;  // done by the hash kernel
     __syncthreads();
     if (tid == 0) {
       int o = 0, np = 0;
@@ -368,10 +563,11 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
   if (n_rows > 0 && X->nnz > 0) {
     char* sc = nullptr;
     const size_t cand_n = (T > 1) ? (size_t)n_rows * T * K : 0;
+    const bool use_hash = T > 1 && K <= RP_VHASH_KMAX;  // light rows: one task per row in a hash table instead of T tiles
     const size_t vt_n = (T > 1) ? (size_t)X->n_users * (T + 1) : 0;
     const size_t xtv_n = left_binary ? 0 : (size_t)X->nnz;
     const size_t bytes = (size_t)I * 8 + RP_PLAN_BUCKETS * 4 + (size_t)n_rows * 4 + 64 + cand_n * 12 + (size_t)n_rows * T * 8 + vt_n * 4 +
-                         xtv_n * 8 + 1024;
+                         xtv_n * 8 + (size_t)n_rows * 12 + 2048;
     int rc = rp_scratch(ctx, 0, bytes, (void**)&sc);
     if (rc != RPHIP_OK) return fail(rc);
     size_t o = 0;
@@ -388,6 +584,10 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
     int32_t* cand_idx = (int32_t*)carve(cand_n * 4);
     int32_t* cand_nnz = (int32_t*)carve((size_t)n_rows * T * 4);
     int32_t* cand_cnt = (int32_t*)carve((size_t)n_rows * T * 4);
+    int32_t* light_flag = (int32_t*)carve((size_t)n_rows * 4);
+    int32_t* heavy_list = (int32_t*)carve((size_t)n_rows * 4);
+    int32_t* light_list = (int32_t*)carve((size_t)n_rows * 4);
+    int32_t* list_counts = (int32_t*)carve(64);
     int32_t* vt_ptr = (int32_t*)carve(vt_n * 4);
     double* xt_val = (double*)carve(xtv_n * 8);
     hipEvent_t ev;
@@ -403,6 +603,12 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
       rc = rp_user_tile_ptr(ctx, X, T, W, vt_ptr);
       if (rc != RPHIP_OK) return fail(rc);
     }
+    if (use_hash) {
+      hipLaunchKernelGGL(k_vrow_light, dim3((unsigned)std::min<int64_t>(4096, rp_cdiv(n_rows, 4))), dim3(256), 0, st, X->xt_ptr, X->xt_idx,
+                         X->x_ptr, (int)row_begin, n_rows, light_flag);
+      hipLaunchKernelGGL(k_vrow_split, dim3(1), dim3(1024), 0, st, order, light_flag, (int)row_begin, n_rows, heavy_list, light_list,
+                         list_counts);
+    }
     if (!left_binary)
       hipLaunchKernelGGL(k_xt_values, dim3((unsigned)std::min<int64_t>(65535, rp_cdiv(X->nnz, 256))), dim3(256), 0, st, X->xt_ptr, X->xt_idx,
                          X->x_ptr, X->x_idx, X->x_val, (int)I, X->nnz, xt_val);
@@ -414,7 +620,8 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
     P.x_val = X->x_val;
     P.xt_ptr = X->xt_ptr;
     P.xt_idx = X->xt_idx;
-    P.order = order;
+    P.order = use_hash ? heavy_list : order;
+    P.n_rows_dev = use_hash ? list_counts : nullptr;
     P.vt_ptr = vt_ptr;
     P.xt_val = xt_val;
     P.roww = row_scale_host ? roww : nullptr;
@@ -440,6 +647,18 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
     rp_time_begin(ctx, &ev);
     hipLaunchKernelGGL(k_itemknn_fit_values, dim3(ctx->n_cu), dim3(RP_FIT_THREADS), lds, st, P);
     rp_time_end(ctx, ev, RPHIP_T_GRAM_TOPK, 0.0);
+    if (use_hash) {
+      rp_vfit_params H = P;  // writes the model rows directly
+      H.out_idx = m->idx;
+      H.out_val = m->val;
+      H.out_nnz = m->nnz;
+      const size_t hlds = (size_t)RP_VHASH_SLOTS * (pair_kind == RPHIP_PAIR_HERMANN ? 16 : 12) + rp_select_smem_bytes(RP_VHASH_SLOTS);
+      if (hipFuncSetAttribute((const void*)k_itemknn_fit_values_hash, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hlds) != hipSuccess)
+        return fail(RPHIP_EHIP);
+      rp_time_begin(ctx, &ev);
+      hipLaunchKernelGGL(k_itemknn_fit_values_hash, dim3(ctx->n_cu), dim3(RP_FIT_THREADS), hlds, st, H, light_list, list_counts + 1);
+      rp_time_end(ctx, ev, RPHIP_T_GRAM_TOPK_WAVE, 0.0);
+    }
     if (T > 1) {
       const size_t mlds = (size_t)T * K * 12 + 8 + rp_select_smem_bytes(T * K, RP_VMERGE_THREADS / 64);
       if (mlds > 160 * 1024 || T * K >= RPS_FLAG) {
@@ -451,8 +670,8 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
       const int mper = std::max<int>(1, std::min<int>(8, (int)((160 * 1024) / mlds)));
       rp_time_begin(ctx, &ev);
       hipLaunchKernelGGL(k_itemknn_merge_values, dim3((unsigned)std::min<int64_t>(n_rows, (int64_t)ctx->n_cu * mper)), dim3(RP_VMERGE_THREADS),
-                         mlds, st, cand_idx, cand_g, cand_nnz, cand_cnt, P.roww, P.signed_vals, T, K, n_rows, (int)row_begin, m->idx, m->val,
-                         m->nnz);
+                         mlds, st, cand_idx, cand_g, cand_nnz, cand_cnt, P.roww, P.signed_vals, T, K, n_rows, (int)row_begin,
+                         use_hash ? light_flag : nullptr, m->idx, m->val, m->nnz);
       rp_time_end(ctx, ev, RPHIP_T_TOPK_MERGE, 0.0);
     }
     if (hipGetLastError() != hipSuccess) return fail(RPHIP_EHIP);

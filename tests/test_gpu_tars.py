@@ -334,3 +334,31 @@ def test_valued_fits_shard_by_item_rows(hip):
         assert (nnz > 0).any()
     finally:
         dist.destroy_process_group()
+
+
+def test_time_distance_fits_beyond_one_tile(hip):
+    """13 000 items: light rows go through the hash-table kernel, the rest through column tiles and the merge; against the
+    oracle (pinned to the reference by the CPU suite) for the time-distance and Hermann similarities."""
+    from recpack_amd.time_aware import TARSItemKNNCoocDistance, TARSItemKNNHermann
+
+    g = load_golden("syn_tars_3000x13000")
+    X = events(g)
+    K = 6
+    T = X.last_timestamps_matrix
+    cases = [
+        (TARSItemKNNCoocDistance(K=K, fit_decay=0.3, decay_interval=24 * 3600, similarity="conditional_probability", decay_function="concave"),
+         lambda: onp.tars_cooc_fit(T, K, "conditional_probability", "concave", 0.3, 24 * 3600)),
+        (TARSItemKNNHermann(K=K, decay_interval=3600), lambda: onp.tars_hermann_fit(T, K, 3600)),
+    ]
+    for algo, oracle in cases:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            algo.fit(X)
+        r = oracle()
+        S_ref = onp.topk_to_csr(r["idx"], r["val"], r["nnz"], T.shape[1])
+        S = sp.csr_matrix(algo.similarity_matrix_)
+        S.sort_indices()
+        idx, _, nnz = dense_topk(S)
+        bad, _ = tie_aware_topk(r["full"], S_ref, idx, nnz)
+        assert not bad, (algo.name, bad[:5])
+        assert abs(S.multiply(S_ref != 0) - S_ref.multiply(S != 0)).max() <= VAL_RTOL * abs(S_ref).max()
