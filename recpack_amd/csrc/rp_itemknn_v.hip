@@ -22,6 +22,20 @@
 
 #include "rp_common.h"
 #include "rp_select.h"
+#include "rp_wave.h"
+
+#ifdef RP_STAMPS
+#define RPV_STAMP(ph)                                                       \
+  do {                                                                      \
+    if (tid == 0) {                                                         \
+      unsigned long long _t = __builtin_amdgcn_s_memtime();                 \
+      atomicAdd(&P.stamps[ph], _t - t_last);                                \
+      t_last = _t;                                                          \
+    }                                                                       \
+  } while (0)
+#else
+#define RPV_STAMP(ph) do { } while (0)
+#endif
 
 constexpr int RP_VMERGE_THREADS = 256;
 constexpr int RP_VTILE_MAX = 12288;
@@ -44,6 +58,7 @@ struct rp_vfit_params {
   double pair_decay, pair_max;
   int n_items, n_rows, n_tiles, tile_w, K, row_begin;
   const int32_t* n_rows_dev;  // when set: the number of rows in `order` (a list built on the device)
+  unsigned long long* stamps;  // diagnostic build only (-DRP_STAMPS): cycles per phase of the tiled kernel, summed over tasks
   int32_t* ticket;
   int32_t* out_idx;       // T == 1: model rows; T > 1: per-tile candidates
   double* out_val;
@@ -61,27 +76,12 @@ struct rp_vdense_src {
   const double* acc;
   const uint32_t* cnt;  // Hermann: the number of users behind every sum (the similarity is their average)
   int t0, row;
+  int sh;               // leading key bits shared by all candidates (rp_key_prefix): dropped, the radix digits start below them
   __device__ __forceinline__ double value(int w) const { return cnt ? acc[w] * (1.0 / (double)cnt[w]) : acc[w]; }
   __device__ __forceinline__ bool valid(int w) const { return acc[w] != 0.0 && (t0 + w) != row; }
-  __device__ __forceinline__ uint64_t key(int w) const { return rp_ordered_f64(value(w)); }
+  __device__ __forceinline__ uint64_t key(int w) const { return rp_ordered_f64(value(w)) << sh; }
   __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)(t0 + w); }
 };
-
-// time_aware_item_knn/decay_functions.py:24-252 on one distance d > 0 (N = the largest possible distance)
-__device__ __forceinline__ double rp_pair_decay(int kind, double a, double N, double d) {
-  switch (kind) {
-    case RPHIP_DECAY_EXPONENTIAL: return exp(-a * d);
-    case RPHIP_DECAY_CONVEX: return pow(a, d);
-    case RPHIP_DECAY_CONCAVE: return 1.0 - pow(a, 1.0 - (d / N));
-    case RPHIP_DECAY_LOG: return log(((a - 1.0) * (1.0 - d / N)) + 1.0) / log(a);
-    case RPHIP_DECAY_LINEAR: {
-      const double r = 1.0 - (d / N) * a;
-      return r < 0.0 ? 0.0 : r;
-    }
-    case RPHIP_DECAY_INVERSE: return 1.0 / d;
-    default: return 1.0;  // RPHIP_DECAY_NONE
-  }
-}
 
 // one term of the Gram: products, a decay of the time distance, or Hermann's 1 / (distance + age) with its user count
 __device__ __forceinline__ void rp_vadd(double* acc, uint32_t* cntw, int j, double q, double x, int pair_kind, double pair_decay,
@@ -117,6 +117,7 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
   rp_select_smem sel = rp_select_carve(smem + (size_t)W * (hermann ? 12 : 8), W, NW);
   int* s_task = &sel.misc[RPS_USER];
   int* s_cnt = &sel.misc[RPS_USER + 1];  // [2]
+  uint32_t* s_red = reinterpret_cast<uint32_t*>(&sel.misc[RPS_USER + 4]);  // [4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = wave * 4 + (lane >> 4), gl = lane & 15;  // 64 groups of 16 lanes: one user per group and round
   for (int w = tid; w < W; w += NTHR) {
@@ -124,17 +125,23 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
     if (hermann) cntw[w] = 0u;
   }
   const long long n_tasks = (long long)(P.n_rows_dev ? *P.n_rows_dev : P.n_rows) * T;
+#ifdef RP_STAMPS
+  unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
   while (true) {
     __syncthreads();
     if (tid == 0) {
       s_task[0] = atomicAdd(P.ticket, 1);
       s_cnt[0] = s_cnt[1] = 0;
+      s_red[0] = s_red[1] = 0xffffffffu;
+      s_red[2] = s_red[3] = 0u;
     }
     __syncthreads();
     const long long task = s_task[0];
     if (task >= n_tasks) break;
     const int row = P.order[task / T], tile = (int)(task % T);
     const int t0 = tile * W, n_cols = min(W, P.n_items - t0);
+    RPV_STAMP(0);
     // ---- accumulate
     // Four users per 16-lane group and round, the loads of one kind issued together: user id and left value, then the
     // slice bounds, then the first 16 entries of every slice.
@@ -180,6 +187,7 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
         for (int k = s[r] + gl + 16; k < e[r]; k += 16) add(P.x_idx[k] - t0, q[r], P.x_val[k]);
     }
     __syncthreads();
+    RPV_STAMP(1);
     // ---- with negative entries the diagonal's stored zero decides how many of them the reference keeps
     int kk = P.K;
     if (P.signed_vals) {
@@ -200,10 +208,12 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
       if (T == 1) kk = rp_keff(P.K, s_cnt[0], s_cnt[1]);
     }
     // ---- select
-    rp_vdense_src src{acc, cntw, t0, row};
+    rp_vdense_src src{acc, cntw, t0, row, 0};
+    src.sh = rp_key_prefix<NTHR>(src, n_cols, s_red);
     const int rl = row - P.row_begin;
     int kp = 0;
     if (kk > 0) kp = rp_select_topk<NTHR>(src, n_cols, kk, sel);
+    RPV_STAMP(2);
     if (T == 1) {
       const double ri = P.roww ? P.roww[row] : 1.0;
       if (kk > 0)
@@ -224,10 +234,13 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
       }
     }
     __syncthreads();
+    RPV_STAMP(3);
     for (int w = tid; w < W; w += NTHR) {  // (the diagonal is in no list)
       acc[w] = 0.0;
       if (hermann) cntw[w] = 0u;
     }
+    __syncthreads();
+    RPV_STAMP(4);
   }
 }
 
@@ -256,9 +269,10 @@ struct rp_vhash_src {
   const uint32_t* cnt;
   const uint32_t* keys;
   int row;
+  int sh;
   __device__ __forceinline__ double value(int w) const { return cnt ? acc[w] * (1.0 / (double)cnt[w]) : acc[w]; }
   __device__ __forceinline__ bool valid(int w) const { return keys[w] != RP_VHASH_EMPTY && acc[w] != 0.0 && (int)keys[w] != row; }
-  __device__ __forceinline__ uint64_t key(int w) const { return rp_ordered_f64(value(w)); }
+  __device__ __forceinline__ uint64_t key(int w) const { return rp_ordered_f64(value(w)) << sh; }
   __device__ __forceinline__ uint32_t col(int w) const { return keys[w]; }
 };
 
@@ -273,6 +287,7 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values_hash(rp_v
   rp_select_smem sel = rp_select_carve(smem + (size_t)W * (hermann ? 16 : 12), W, NW);
   int* s_task = &sel.misc[RPS_USER];
   int* s_cnt = &sel.misc[RPS_USER + 1];  // [2]
+  uint32_t* s_red = reinterpret_cast<uint32_t*>(&sel.misc[RPS_USER + 4]);  // [4]
   uint32_t* ecol = sel.hist;                                    // staging (the histogram is dead once the selection is done)
   double* eval = reinterpret_cast<double*>(sel.hist + 1024);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -288,6 +303,8 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values_hash(rp_v
     if (tid == 0) {
       s_task[0] = atomicAdd(P.ticket + 1, 1);
       s_cnt[0] = s_cnt[1] = 0;
+      s_red[0] = s_red[1] = 0xffffffffu;
+      s_red[2] = s_red[3] = 0u;
     }
     __syncthreads();
     const int task = s_task[0];
@@ -305,7 +322,8 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values_hash(rp_v
       }
     }
     __syncthreads();
-    rp_vhash_src src{acc, cntw, keys, row};
+    rp_vhash_src src{acc, cntw, keys, row, 0};
+    src.sh = rp_key_prefix<NTHR>(src, W, s_red);
     int kk = P.K;
     if (P.signed_vals) {
       int np = 0, nn = 0;
@@ -644,9 +662,28 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
     const size_t lds = (size_t)W * (pair_kind == RPHIP_PAIR_HERMANN ? 12 : 8) + rp_select_smem_bytes(W);
     if (hipFuncSetAttribute((const void*)k_itemknn_fit_values, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return fail(RPHIP_EHIP);
+    P.stamps = nullptr;
+#ifdef RP_STAMPS
+    {
+      void* sp = nullptr;
+      rc = rp_scratch(ctx, 6, 64 * 8, &sp);
+      if (rc != RPHIP_OK) return fail(rc);
+      P.stamps = (unsigned long long*)sp;
+      hipMemsetAsync(sp, 0, 64 * 8, st);
+    }
+#endif
     rp_time_begin(ctx, &ev);
     hipLaunchKernelGGL(k_itemknn_fit_values, dim3(ctx->n_cu), dim3(RP_FIT_THREADS), lds, st, P);
     rp_time_end(ctx, ev, RPHIP_T_GRAM_TOPK, 0.0);
+#ifdef RP_STAMPS
+    {
+      unsigned long long h[8];
+      hipMemcpyAsync(h, P.stamps, sizeof(h), hipMemcpyDeviceToHost, st);
+      hipStreamSynchronize(st);
+      fprintf(stderr, "[stamps valued] cycles/1e6: ticket+row %.1f accumulate %.1f select %.1f emit %.1f clear %.1f (T=%d)\n", h[0] / 1e6, h[1] / 1e6,
+              h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, T);
+    }
+#endif
     if (use_hash) {
       rp_vfit_params H = P;  // writes the model rows directly
       H.out_idx = m->idx;

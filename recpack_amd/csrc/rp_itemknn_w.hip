@@ -3,6 +3,7 @@
 
 #include "rp_common.h"
 #include "rp_select.h"
+#include "rp_wave.h"
 
 constexpr int RP_MERGE_THREADS = 256;
 
@@ -36,8 +37,9 @@ struct rp_wdense_src {
   const double* acc;
   const double* colw;
   int t0, row;
+  int sh;  // leading key bits shared by all candidates (rp_key_prefix, rp_wave.h)
   __device__ __forceinline__ bool valid(int w) const { return acc[w] != 0.0 && (t0 + w) != row; }
-  __device__ __forceinline__ uint64_t key(int w) const { return (uint64_t)__double_as_longlong(acc[w] * colw[t0 + w]); }  // > 0
+  __device__ __forceinline__ uint64_t key(int w) const { return (uint64_t)__double_as_longlong(acc[w] * colw[t0 + w]) << sh; }  // > 0
   __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)(t0 + w); }
 };
 
@@ -48,13 +50,18 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_weighted(rp_wfit
   const int W = P.tile_w, T = P.n_tiles;
   rp_select_smem sel = rp_select_carve(smem + (size_t)W * 8, W, NW);
   int* s_task = &sel.misc[RPS_USER];
+  uint32_t* s_red = reinterpret_cast<uint32_t*>(&sel.misc[RPS_USER + 4]);  // [4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = wave * 4 + (lane >> 4), gl = lane & 15;  // 64 groups of 16 lanes: one user per group and round
   for (int w = tid; w < W; w += NTHR) acc[w] = 0.0;
   const long long n_tasks = (long long)P.n_rows * T;
   while (true) {
     __syncthreads();
-    if (tid == 0) s_task[0] = atomicAdd(P.ticket, 1);
+    if (tid == 0) {
+      s_task[0] = atomicAdd(P.ticket, 1);
+      s_red[0] = s_red[1] = 0xffffffffu;
+      s_red[2] = s_red[3] = 0u;
+    }
     __syncthreads();
     const long long task = s_task[0];
     if (task >= n_tasks) break;
@@ -102,7 +109,8 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_weighted(rp_wfit
     }
     __syncthreads();
     // ---- select
-    rp_wdense_src src{acc, P.colw, t0, row};
+    rp_wdense_src src{acc, P.colw, t0, row, 0};
+    src.sh = rp_key_prefix<NTHR>(src, n_cols, s_red);
     const int kp = rp_select_topk<NTHR>(src, n_cols, P.K, sel);
     const int rl = row - P.row_begin;
     if (T == 1) {

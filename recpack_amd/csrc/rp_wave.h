@@ -273,3 +273,50 @@ __device__ __forceinline__ void rp_wpool_push(rp_wpool<KeyT>& P, int K, int cap,
   }
   P.n += __popcll(m);
 }
+
+// The similarities of one row lie within a few binades, so the sign and most exponent bits of their keys agree and the
+// first 11-bit radix digit of the raw key separates nothing.  One pass finds the bits all candidates share (AND and OR
+// over the keys); dropping them keeps the order and lets the first digit already resolve mantissa bits.
+// red[0..3] = {and_lo, and_hi, or_lo, or_hi}, preset to {~0, ~0, 0, 0} by the caller before the barrier that precedes
+// this call.  All threads must call; returns the number of shared leading bits (0..63).
+template <int NTHR, class Src>
+__device__ int rp_key_prefix(Src& src, int n_slots, uint32_t* red) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  uint64_t a = ~0ull, o = 0ull;
+  src.sh = 0;
+  for (int w = tid; w < n_slots; w += NTHR) {
+    if (!src.valid(w)) continue;
+    const uint64_t k = src.key(w);
+    a &= k;
+    o |= k;
+  }
+  const uint32_t alo = ~rp_wave_or(~(uint32_t)a), ahi = ~rp_wave_or(~(uint32_t)(a >> 32));
+  const uint32_t olo = rp_wave_or((uint32_t)o), ohi = rp_wave_or((uint32_t)(o >> 32));
+  if (lane == 0) {
+    atomicAnd(&red[0], alo);
+    atomicAnd(&red[1], ahi);
+    atomicOr(&red[2], olo);
+    atomicOr(&red[3], ohi);
+  }
+  __syncthreads();
+  const uint64_t A = ((uint64_t)red[1] << 32) | red[0], O = ((uint64_t)red[3] << 32) | red[2];
+  const uint64_t d = A ^ O;
+  return d ? min(63, (int)__builtin_clzll(d)) : 0;  // all keys equal (or no candidate): nothing to gain
+}
+
+// time_aware_item_knn/decay_functions.py:24-252 on one distance d > 0 (N = the largest possible distance)
+__device__ __forceinline__ double rp_pair_decay(int kind, double a, double N, double d) {
+  switch (kind) {
+    case RPHIP_DECAY_EXPONENTIAL: return exp(-a * d);
+    case RPHIP_DECAY_CONVEX: return pow(a, d);
+    case RPHIP_DECAY_CONCAVE: return 1.0 - pow(a, 1.0 - (d / N));
+    case RPHIP_DECAY_LOG: return log(((a - 1.0) * (1.0 - d / N)) + 1.0) / log(a);
+    case RPHIP_DECAY_LINEAR: {
+      const double r = 1.0 - (d / N) * a;
+      return r < 0.0 ? 0.0 : r;
+    }
+    case RPHIP_DECAY_INVERSE: return 1.0 / d;
+    default: return 1.0;  // RPHIP_DECAY_NONE
+  }
+}
+

@@ -9,6 +9,9 @@ import numpy as np
 import torch
 
 from recpack_amd import _lib
+
+if os.environ.get("RECPACK_STAMPS"):  # diagnostic build (make stamps): per-phase cycle counters on stderr
+    _lib.LIB_PATH = os.path.join(os.getcwd(), "recpack_amd/csrc/librecpack_hip_stamps.so")
 from recpack_amd.synth import CONFIGS, config_csr
 
 for cfg in (sys.argv[1:] or ["C2"]):
