@@ -359,6 +359,8 @@ extern "C" int rphip_gemm_nt_f32(rphip_ctx* ctx, int64_t M, int64_t N, int64_t K
 }
 
 // in-place inverse of the SPD matrix A (n_pad x n_pad, ld) using the workspace Nb (same size); result in A (full)
+constexpr int RP_CHOL_PANEL = 8;  // tiles per Cholesky panel (1024 columns)
+
 static int rp_spd_inverse(rphip_ctx* ctx, float* A, float* Nb, int n_pad, long long ld) {
   hipStream_t st = ctx->stream;
   const int nb = n_pad / GT;
@@ -377,26 +379,39 @@ static int rp_spd_inverse(rphip_ctx* ctx, float* A, float* Nb, int n_pad, long l
   // ---- K5: left-looking blocked Cholesky.  The 128x128 diagonal block (its update and its float64 factorisation, one
   // workgroup for 0.26 ms) runs on a side stream while the rest of the panel is updated on the main stream.
   struct side_stream {  // released on every way out of this function
-    hipStream_t s = nullptr;
-    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t s = nullptr, t = nullptr;
+    hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr;
     ~side_stream() {
       if (s) hipStreamSynchronize(s);
+      if (t) hipStreamSynchronize(t);
       if (a) hipEventDestroy(a);
       if (b) hipEventDestroy(b);
+      if (c) hipEventDestroy(c);
+      if (d) hipEventDestroy(d);
       if (s) hipStreamDestroy(s);
+      if (t) hipStreamDestroy(t);
     }
   } side;
   RP_HIP(hipStreamCreateWithFlags(&side.s, hipStreamNonBlocking));
+  RP_HIP(hipStreamCreateWithFlags(&side.t, hipStreamNonBlocking));
   RP_HIP(hipEventCreateWithFlags(&side.a, hipEventDisableTiming));
   RP_HIP(hipEventCreateWithFlags(&side.b, hipEventDisableTiming));
-  hipStream_t s2 = side.s;
-  hipEvent_t e_panel = side.a, e_diag = side.b;
+  RP_HIP(hipEventCreateWithFlags(&side.c, hipEventDisableTiming));
+  RP_HIP(hipEventCreateWithFlags(&side.d, hipEventDisableTiming));
+  hipStream_t s2 = side.s, s3 = side.t;
+  hipEvent_t e_panel = side.a, e_diag = side.b, e_fact = side.c, e_trail = side.d;
+  bool trail_pending = false;  // a trailing update is in flight on s3
   float* part_diag = part_all + (size_t)8 * (n_pad - GT) * GT;  // the side stream's own split-K partials
   rp_time_begin(ctx, &ev);
   int rc = RPHIP_OK;
+  // Blocked in two levels: wide panels of RP_CHOL_PANEL tiles are factored left-looking with K restricted to the panel
+  // (short, skinny products: ~n^2 * panel / 2 flop in total), then the whole trailing matrix takes the panel's
+  // rank-(128 * RP_CHOL_PANEL) update in ONE lower-triangular product at the square-GEMM rate.  Purely left-looking (K
+  // from 0 for every 128-column block) made every product of the factorisation skinny: 92 TFLOP/s at n = 100 000.
   for (int k = 0; k < nb && rc == RPHIP_OK; ++k) {
     const int r0 = k * GT;
-    RP_HIP(hipEventRecord(e_panel, st));  // panel k-1 (and everything before) is complete
+    const int pk0 = (k / RP_CHOL_PANEL) * RP_CHOL_PANEL * GT;  // first column of this block's panel
+    RP_HIP(hipEventRecord(e_panel, st));  // block k-1 (and everything before) is complete
     RP_HIP(hipStreamWaitEvent(s2, e_panel, 0));
     rp_gemm_args g{};
     g.A = A + (long long)r0 * ld;
@@ -406,11 +421,11 @@ static int rp_spd_inverse(rphip_ctx* ctx, float* A, float* Nb, int n_pad, long l
     g.C = A + (long long)r0 * ld + r0;
     g.ldc = ld;
     g.N = GT;
-    g.k0 = 0;
+    g.k0 = pk0;
     g.k1 = r0;
     g.alpha = -1.0f;
     g.beta = 1.0f;
-    if (k > 0) {  // A[k,k] -= L[k,0:k] L[k,0:k]^T on the side stream
+    if (r0 > pk0) {  // A[k,k] -= L[k,p:k] L[k,p:k]^T on the side stream (p = the panel's first column)
       g.M = GT;
       rc = rp_gemm_nt(ctx, g, s2, part_diag);
       if (rc != RPHIP_OK) break;
@@ -418,7 +433,7 @@ static int rp_spd_inverse(rphip_ctx* ctx, float* A, float* Nb, int n_pad, long l
     hipLaunchKernelGGL(k_potrf_trtri, dim3(1), dim3(1024), diag_lds, s2, A + (long long)r0 * ld + r0, ld, W + (size_t)k * GT * GT, info);
     RP_HIP(hipEventRecord(e_diag, s2));
     if (r0 + GT < n_pad) {
-      if (k > 0) {  // A[k+1:,k] -= L[k+1:,0:k] L[k,0:k]^T
+      if (r0 > pk0) {  // A[k+1:,k] -= L[k+1:,p:k] L[k,p:k]^T
         g.A = A + (long long)(r0 + GT) * ld;
         g.C = A + (long long)(r0 + GT) * ld + r0;
         g.M = n_pad - r0 - GT;
@@ -440,11 +455,51 @@ static int rp_spd_inverse(rphip_ctx* ctx, float* A, float* Nb, int n_pad, long l
       h.alpha = 1.0f;
       h.beta = 0.0f;
       rc = rp_gemm_nt(ctx, h);
+      if (rc != RPHIP_OK) break;
+      const int r1 = r0 + GT;
+      if ((k + 1) % RP_CHOL_PANEL == 0 && r1 < n_pad) {
+        // The panel is done: A[r1:, r1:] -= L[r1:, p:r1] L[r1:, p:r1]^T (lower tiles), in two pieces.  The columns of the NEXT
+        // panel are updated here, on the main stream; the rest of the trailing matrix - almost all of the flops - on a third
+        // stream, so that it runs beside the next panel's factorisation (a chain of small launches and one-workgroup diagonal
+        // blocks that leaves the chip idle).  Its columns are not touched by that factorisation; the piece after it waits.
+        const int wn = std::min(RP_CHOL_PANEL * GT, n_pad - r1);
+        RP_HIP(hipEventRecord(e_fact, st));
+        if (trail_pending) RP_HIP(hipStreamWaitEvent(st, e_trail, 0));  // the previous rest-update wrote these columns
+        rp_gemm_args t{};
+        t.A = A + (long long)r1 * ld;
+        t.lda = ld;
+        t.B = A + (long long)r1 * ld;
+        t.ldb = ld;
+        t.C = A + (long long)r1 * ld + r1;
+        t.ldc = ld;
+        t.M = n_pad - r1;
+        t.N = wn;
+        t.k0 = pk0;
+        t.k1 = r1;
+        t.tri = 1;
+        t.alpha = -1.0f;
+        t.beta = 1.0f;
+        rc = rp_gemm_nt(ctx, t);
+        if (rc != RPHIP_OK) break;
+        const int r2 = r1 + wn;
+        if (r2 < n_pad) {
+          RP_HIP(hipStreamWaitEvent(s3, e_fact, 0));
+          t.A = A + (long long)r2 * ld;
+          t.B = A + (long long)r2 * ld;
+          t.C = A + (long long)r2 * ld + r2;
+          t.M = n_pad - r2;
+          t.N = n_pad - r2;
+          rc = rp_gemm_nt(ctx, t, s3);
+          RP_HIP(hipEventRecord(e_trail, s3));
+          trail_pending = true;
+        }
+      }
     } else {
       RP_HIP(hipStreamWaitEvent(st, e_diag, 0));
     }
   }
   hipStreamSynchronize(s2);
+  if (trail_pending) hipStreamWaitEvent(st, e_trail, 0);
   if (rc != RPHIP_OK) return rc;
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, RPHIP_T_CHOLESKY, n3 / 3.0);
