@@ -359,8 +359,6 @@ extern "C" int rphip_gemm_nt_f32(rphip_ctx* ctx, int64_t M, int64_t N, int64_t K
 }
 
 // in-place inverse of the SPD matrix A (n_pad x n_pad, ld) using the workspace Nb (same size); result in A (full)
-constexpr int RP_CHOL_PANEL = 8;  // tiles per Cholesky panel (1024 columns)
-
 static int rp_spd_inverse(rphip_ctx* ctx, float* A, float* Nb, int n_pad, long long ld) {
   hipStream_t st = ctx->stream;
   const int nb = n_pad / GT;
@@ -404,10 +402,12 @@ static int rp_spd_inverse(rphip_ctx* ctx, float* A, float* Nb, int n_pad, long l
   float* part_diag = part_all + (size_t)8 * (n_pad - GT) * GT;  // the side stream's own split-K partials
   rp_time_begin(ctx, &ev);
   int rc = RPHIP_OK;
-  // Blocked in two levels: wide panels of RP_CHOL_PANEL tiles are factored left-looking with K restricted to the panel
+  // Blocked in two levels: wide panels of 16 or 32 tiles are factored left-looking with K restricted to the panel
   // (short, skinny products: ~n^2 * panel / 2 flop in total), then the whole trailing matrix takes the panel's
-  // rank-(128 * RP_CHOL_PANEL) update in ONE lower-triangular product at the square-GEMM rate.  Purely left-looking (K
+  // rank-(128 * panel) update in ONE lower-triangular product at the square-GEMM rate.  Purely left-looking (K
   // from 0 for every 128-column block) made every product of the factorisation skinny: 92 TFLOP/s at n = 100 000.
+  // (measured on MI355X: panels of 8 / 16 / 32 tiles give 91 / 96 / 89 TFLOP/s at n = 50 000 and 105 / 114 / 116 at 100 000)
+  const int RP_CHOL_PANEL = nb >= 640 ? 32 : 16;  // tiles per panel
   for (int k = 0; k < nb && rc == RPHIP_OK; ++k) {
     const int r0 = k * GT;
     const int pk0 = (k / RP_CHOL_PANEL) * RP_CHOL_PANEL * GT;  // first column of this block's panel
