@@ -260,6 +260,15 @@ __global__ void k_zero_f32(float* __restrict__ p, long long n) {
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) p[e] = 0.0f;
 }
 
+// dst (n x n, leading dimension ldd) = src^T (leading dimension lds); n a multiple of 32, block (32, 8), grid (n/32, n/32)
+__global__ void k_transpose_block(const float* __restrict__ src, long long lds, float* __restrict__ dst, long long ldd) {
+  __shared__ float t[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  for (int r = threadIdx.y; r < 32; r += 8) t[r][threadIdx.x] = src[(long long)(by + r) * lds + bx + threadIdx.x];
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += 8) dst[(long long)(bx + r) * ldd + by + threadIdx.x] = t[threadIdx.x][r];
+}
+
 // dst block (ld) = src^T, src is a 128x128 block with leading dimension 128
 __global__ void __launch_bounds__(256) k_transpose_128(const float* __restrict__ src, float* __restrict__ dst, long long ld) {
   __shared__ float t[GT][GT + 1];
@@ -359,14 +368,18 @@ extern "C" int rphip_gemm_nt_f32(rphip_ctx* ctx, int64_t M, int64_t N, int64_t K
 }
 
 // in-place inverse of the SPD matrix A (n_pad x n_pad, ld) using the workspace Nb (same size); result in A (full)
+constexpr int RP_INV_PANEL = 16;  // tiles per panel of N = L^-T (2048 columns)
+
 static int rp_spd_inverse(rphip_ctx* ctx, float* A, float* Nb, int n_pad, long long ld) {
   hipStream_t st = ctx->stream;
   const int nb = n_pad / GT;
   char* wsb = nullptr;
-  RP_TRY(rp_scratch(ctx, 5, (size_t)nb * GT * GT * 4 + (size_t)n_pad * GT * 4 + 256, (void**)&wsb));
+  const int inv_w = std::min(RP_INV_PANEL * GT, n_pad);  // columns of one panel of the inverse
+  RP_TRY(rp_scratch(ctx, 5, (size_t)nb * GT * GT * 4 + ((size_t)n_pad * inv_w + (size_t)inv_w * inv_w) * 4 + 256, (void**)&wsb));
   int* info = (int*)wsb;
   float* W = (float*)(wsb + 256);                 // [nb][128][128]
-  float* T = W + (size_t)nb * GT * GT;            // [n_pad][128]
+  float* T = W + (size_t)nb * GT * GT;            // [n_pad][inv_w]: N11 L21^T of a panel ([c0][128] inside a panel)
+  float* NT = T + (size_t)n_pad * inv_w;          // [inv_w][inv_w]: transpose of the panel's diagonal block of N
   float* part_all = nullptr;  // the split-K partials of the skinny products: sized once for the tallest of them
   RP_TRY(rp_scratch(ctx, 7, (size_t)8 * n_pad * GT * sizeof(float), (void**)&part_all));
   RP_HIP(hipMemsetAsync(info, 0, 4, st));
@@ -503,40 +516,81 @@ static int rp_spd_inverse(rphip_ctx* ctx, float* A, float* Nb, int n_pad, long l
   if (rc != RPHIP_OK) return rc;
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, RPHIP_T_CHOLESKY, n3 / 3.0);
-  // ---- K6a: N = L^-T (upper triangular), block column by block column
+  // ---- K6a: N = L^-T (upper triangular), panel by panel (N12 = -N11 L21^T N22 for the 2 x 2 block form of L).
+  // Inside a panel the 128-column blocks are done as before but with rows and K restricted to the panel (tiny products);
+  // then ONE product per panel against everything to its left, 2048 columns wide: T = N11 L21^T (K from the row block's
+  // first column), N12 = -T N22.  Block column by block column (128 wide, K from 0) every product was skinny:
+  // 101 TFLOP/s with split K; the wide ones run at the square-GEMM rate.
   rp_time_begin(ctx, &ev);
   hipLaunchKernelGGL(k_zero_f32, dim3(2048), dim3(256), 0, st, Nb, (long long)n_pad * ld);
-  for (int i = 0; i < nb; ++i) {
-    const int c0 = i * GT;
-    const float* Wi = W + (size_t)i * GT * GT;
-    hipLaunchKernelGGL(k_transpose_128, dim3(1), dim3(256), 0, st, Wi, Nb + (long long)c0 * ld + c0, ld);
-    if (i > 0) {
-      rp_gemm_args g{};
+  for (int pb = 0; pb < nb; pb += RP_INV_PANEL) {
+    const int pe = std::min(nb, pb + RP_INV_PANEL);
+    const int j = pb * GT, w = (pe - pb) * GT;
+    for (int i = pb; i < pe; ++i) {  // N22: the panel's own diagonal block
+      const int c0 = i * GT;
+      const float* Wi = W + (size_t)i * GT * GT;
+      hipLaunchKernelGGL(k_transpose_128, dim3(1), dim3(256), 0, st, Wi, Nb + (long long)c0 * ld + c0, ld);
+      if (i > pb) {
+        rp_gemm_args g{};
+        g.A = Nb + (long long)j * ld;
+        g.lda = ld;
+        g.B = A + (long long)c0 * ld;
+        g.ldb = ld;
+        g.C = T;
+        g.ldc = GT;
+        g.M = c0 - j;
+        g.N = GT;
+        g.k0 = j;
+        g.k1 = c0;
+        g.kb_m = 1;  // row block r of N starts at column r
+        g.m_off = j;
+        g.alpha = 1.0f;
+        g.beta = 0.0f;
+        RP_TRY(rp_gemm_nt(ctx, g));
+        rp_gemm_args h{};
+        h.A = T;
+        h.lda = GT;
+        h.B = Wi;
+        h.ldb = GT;
+        h.C = Nb + (long long)j * ld + c0;
+        h.ldc = ld;
+        h.M = c0 - j;
+        h.N = GT;
+        h.k0 = 0;
+        h.k1 = GT;
+        h.alpha = -1.0f;
+        h.beta = 0.0f;
+        RP_TRY(rp_gemm_nt(ctx, h));
+      }
+    }
+    if (j > 0) {
+      rp_gemm_args g{};  // T = N11 L21^T
       g.A = Nb;
       g.lda = ld;
-      g.B = A + (long long)c0 * ld;
+      g.B = A + (long long)j * ld;
       g.ldb = ld;
       g.C = T;
-      g.ldc = GT;
-      g.M = c0;
-      g.N = GT;
+      g.ldc = w;
+      g.M = j;
+      g.N = w;
       g.k0 = 0;
-      g.k1 = c0;
-      g.kb_m = 1;  // row block r of N starts at column r
+      g.k1 = j;
+      g.kb_m = 1;
       g.alpha = 1.0f;
       g.beta = 0.0f;
       RP_TRY(rp_gemm_nt(ctx, g));
-      rp_gemm_args h{};
+      hipLaunchKernelGGL(k_transpose_block, dim3(w / 32, w / 32), dim3(32, 8), 0, st, Nb + (long long)j * ld + j, ld, NT, (long long)w);
+      rp_gemm_args h{};  // N12 = -T N22 (N22 is upper triangular: the K range past the column tile only adds zeros)
       h.A = T;
-      h.lda = GT;
-      h.B = Wi;
-      h.ldb = GT;
-      h.C = Nb + c0;
+      h.lda = w;
+      h.B = NT;
+      h.ldb = w;
+      h.C = Nb + j;
       h.ldc = ld;
-      h.M = c0;
-      h.N = GT;
+      h.M = j;
+      h.N = w;
       h.k0 = 0;
-      h.k1 = GT;
+      h.k1 = w;
       h.alpha = -1.0f;
       h.beta = 0.0f;
       RP_TRY(rp_gemm_nt(ctx, h));
