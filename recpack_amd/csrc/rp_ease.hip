@@ -368,7 +368,7 @@ extern "C" int rphip_gemm_nt_f32(rphip_ctx* ctx, int64_t M, int64_t N, int64_t K
 }
 
 // in-place inverse of the SPD matrix A (n_pad x n_pad, ld) using the workspace Nb (same size); result in A (full)
-constexpr int RP_INV_PANEL = 16;  // tiles per panel of N = L^-T (2048 columns)
+constexpr int RP_INV_PANEL = 16;  // tiles per panel of N = L^-T (2048 columns; 8 / 16 / 32 tiles measured: 5.94 / 5.53 / 5.87 s at n = 100 000)
 
 static int rp_spd_inverse(rphip_ctx* ctx, float* A, float* Nb, int n_pad, long long ld) {
   hipStream_t st = ctx->stream;
