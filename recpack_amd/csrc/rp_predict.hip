@@ -96,6 +96,7 @@ struct rp_score_src {
   const void* acc_;
   int t0;
   const uint8_t* keep;
+  int sh;  // leading key bits shared by all candidates (rp_key_prefix, rp_wave.h): the radix digits start below them
   __device__ __forceinline__ bool valid(int w) const {
     const bool nz = DENSE ? ((const float*)acc_)[w] != 0.0f : ((const unsigned long long*)acc_)[w] != 0ull;
     return nz && (!keep || keep[t0 + w] != 0);
@@ -104,9 +105,9 @@ struct rp_score_src {
     if (DENSE) {  // order-preserving map of a float (any sign) to u32, placed in the high half
       uint32_t b = __float_as_uint(((const float*)acc_)[w]);
       b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-      return (uint64_t)b << 32;
+      return ((uint64_t)b << 32) << sh;
     }
-    return ((const unsigned long long*)acc_)[w] ^ RP_KEY_FLIP;
+    return (((const unsigned long long*)acc_)[w] ^ RP_KEY_FLIP) << sh;
   }
   __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)(t0 + w); }
 };
@@ -233,8 +234,17 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_tile(rp_pred_params
         }
         __syncthreads();
       }
-      // ---- select
-      rp_score_src<DENSE> src{smem, t0, P.mode == 0 ? P.keep : nullptr};
+      // ---- select (top-Kp: the scores of one user share their sign and most exponent bits - dropped first)
+      rp_score_src<DENSE> src{smem, t0, P.mode == 0 ? P.keep : nullptr, 0};
+      if (P.mode == 0) {
+        uint32_t* s_red = reinterpret_cast<uint32_t*>(&sel.misc[RPS_USER]);
+        if (tid == 0) {
+          s_red[0] = s_red[1] = 0xffffffffu;
+          s_red[2] = s_red[3] = 0u;
+        }
+        __syncthreads();
+        src.sh = rp_key_prefix<RP_PRED_THREADS>(src, n_cols, s_red);
+      }
       const int kk = (P.mode == 0) ? P.Kp : 0x7fffffff;
       const int kp = rp_select_topk<RP_PRED_THREADS>(src, n_cols, kk, sel);
       if (P.mode == 0) {
