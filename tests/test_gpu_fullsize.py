@@ -156,3 +156,70 @@ def test_ease_c3_full_size(hip):
         assert n == min(Kp, nzc)
         t = np.sort(sc[sc != 0])[::-1][n - 1]
         assert (sc[got] >= t - 2e-6 * np.abs(sc).max()).all()
+
+
+@pytest.mark.parametrize("mode", ["cosine", "pearson", "time_distance"])
+def test_time_aware_c2_sampled_rows(hip, mode):
+    """The valued fits at C2 (100K x 20K, two column tiles, rows from 10 to 66K users: hash rows, tiled rows, merge) with
+    seeded timestamps: 400 sampled rows tie-aware identical to the float64 oracle, values within 1e-11; weighted predict
+    of sampled users against float64 sums."""
+    from parity import tie_aware_topk
+
+    _lib, ctx = hip
+    _, X, _ = make("C2", hip)
+    U, I = X.shape
+    K = 50
+    rng = np.random.default_rng(11)
+    T = X.copy()
+    T.data = rng.integers(1, 60 * 24, size=X.nnz).astype(np.float64)  # hours over 60 days
+    rows = np.unique(np.concatenate([rng.choice(I, 380, replace=False), np.argsort(-np.diff(X.tocsc().indptr))[:20]]))
+    if mode == "time_distance":
+        dT = _lib.DeviceCSR.from_host_valued(ctx, T)
+        model = _lib.itemknn_fit_timedist(ctx, dT, K, "exponential", 0.01, float(T.data.max() - T.data.min()))
+        full = onp.tars_cooc_similarity(T, "cooc", "exponential", 0.01)
+        W = None
+    else:
+        W = onp.tars_weights(T, 0.003, "exponential")
+        if mode == "cosine":
+            Wn = W.copy()
+        else:
+            cnt = np.asarray((W > 0).sum(axis=0)).ravel()
+            avg = np.asarray(W.sum(axis=0)).ravel() / np.maximum(cnt, 1)
+            Wn = sp.csr_matrix(W - (W > 0).multiply(avg[None, :]))
+            Wn.eliminate_zeros()
+            Wn.sort_indices()
+        n2 = np.bincount(Wn.indices, weights=Wn.data * Wn.data, minlength=I)
+        norm = np.sqrt(n2)
+        norm[norm == 0] = 1.0
+        Wn.data = Wn.data / norm[Wn.indices]
+        dT = _lib.DeviceCSR.from_host_valued(ctx, Wn)
+        model = _lib.itemknn_fit_values(ctx, dT, K)
+        full = onp.tars_similarity(W, mode)
+    idx, val, nnz = model.topk_download()
+    sub = full[rows]
+    # the reference's rule on the sampled rows: stored = non-zero similarities + the diagonal's explicit 0
+    ref_idx = np.full((len(rows), K), -1, np.int32)
+    ref_val = np.zeros((len(rows), K))
+    ref_nnz = np.zeros(len(rows), np.int32)
+    for r in range(len(rows)):
+        c, v = sub.indices[sub.indptr[r]: sub.indptr[r + 1]], sub.data[sub.indptr[r]: sub.indptr[r + 1]]
+        c2, v2 = np.append(c, rows[r]), np.append(v, 0.0)
+        order = np.lexsort((c2, -v2))[:K]
+        keep = order[v2[order] != 0]
+        ref_nnz[r] = len(keep)
+        ref_idx[r, : len(keep)], ref_val[r, : len(keep)] = c2[keep], v2[keep]
+    S_ref = onp.topk_to_csr(ref_idx, ref_val, ref_nnz, I)
+    bad, exact = tie_aware_topk(sub, S_ref, idx[rows], nnz[rows], positive_only=False)
+    assert not bad, (mode, bad[:5])
+    S_dev = onp.topk_to_csr(idx[rows], val[rows], nnz[rows], I)
+    assert abs(S_dev.multiply(S_ref != 0) - S_ref.multiply(S_dev != 0)).max() <= 1e-11 * abs(S_ref).max()
+    # weighted predict of sampled users
+    users = rng.choice(U, 300, replace=False)
+    Wp = onp.tars_weights(T, 0.001, "exponential") if W is not None else sp.csr_matrix((np.ones(X.nnz), X.indices, X.indptr), shape=X.shape)
+    dP = _lib.DeviceCSR.from_host_valued(ctx, Wp)
+    pi, pv, pn = _lib.predict_topk(ctx, model, dP, 20, False)
+    S_all = onp.topk_to_csr(idx, val.astype(np.float32).astype(np.float64), nnz, I)
+    scores = onp.tars_predict(Wp[users], S_all)
+    ridx, rval, rnnz = onp.topk_rows(scores, 20)
+    bad, _ = tie_aware_topk(scores, onp.topk_to_csr(ridx, rval, rnnz, I), pi[users], pn[users], eps=1e-6, positive_only=False)
+    assert not bad, (mode, "predict", bad[:5])
