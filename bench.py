@@ -42,6 +42,9 @@ def parse():
                     help="configs of the EASE legs (N=1 only), comma separated: the first goes to `ease`, others to `ease_<cfg>`; "
                          "'none' disables them")
     ap.add_argument("--l2", type=float, default=200.0)
+    ap.add_argument("--tars-config", default="C4",
+                    help="config of the time-aware leg (N=1 only): TARSItemKNN-style valued cosine fit + decayed predict on the "
+                         "config's matrix with seeded timestamps; 'none' skips it")
     ap.add_argument("--ease-sharded", action="store_true",
                     help="N > 1 only: also time the multi-GPU EASE fit (recpack_amd.dist.ease_fit_sharded) + user-sharded predict on the "
                          "first config of --ease-config; off by default so that the scaling run of the ItemKNN metric cannot be held up")
@@ -153,6 +156,62 @@ def ease_leg(args, ctx, device, Kp, config, repeats):
             "solve_ms": round(solve_ms, 2),
         },
         "dtype": "f32 (MFMA f32 in / f32 accumulate), float64 diagonal blocks",
+    }
+
+
+def tars_leg(args, ctx, device, Kp, config):
+    """The time-aware family's device work on one config: every interaction gets a seeded timestamp
+    (hours over 90 days), the host computes the exponential-decay weights and unit-length columns as TARSItemKNN does
+    (time_aware_item_knn/base.py:181-195, sklearn's normalize), the GPU runs the valued cosine fit (rphip_itemknn_fit_values,
+    K neighbours) and the decayed predict + top-Kp for all users (the wave kernel on a valued matrix)."""
+    import torch
+
+    from recpack_amd import _lib
+    from recpack_amd.synth import CONFIG_SEED_BASE, CONFIGS, powerlaw_csr
+
+    U, I, dens = CONFIGS[config]
+    ip, ix = powerlaw_csr(U, I, dens, CONFIG_SEED_BASE + int(config[1:]), device=device)
+    indptr, indices = ip.cpu().numpy(), ix.cpu().numpy()
+    rng = np.random.default_rng(CONFIG_SEED_BASE + 100 + int(config[1:]))
+    t0 = time.perf_counter()
+    ts = rng.integers(1, 90 * 24, size=indices.shape[0]).astype(np.float64)
+    w = np.exp(-0.002 * (ts.max() + 1 - ts))
+    n2 = np.bincount(indices, weights=w * w, minlength=I)
+    wn = w / np.sqrt(np.where(n2 > 0, n2, 1.0))[indices]
+    host_s = time.perf_counter() - t0
+    dX = _lib.DeviceCSR.from_host(ctx, indptr, indices, (U, I))
+    out_idx = torch.empty((U, Kp), dtype=torch.int32, device=device)
+    out_val = torch.empty((U, Kp), dtype=torch.float32, device=device)
+    out_nnz = torch.empty((U,), dtype=torch.int32, device=device)
+    best = None
+    for it in range(2):
+        dX.set_values(wn)
+        ctx.reset_timings()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model = _lib.itemknn_fit_values(ctx, dX, args.K)
+        torch.cuda.synchronize()
+        t_fit = time.perf_counter() - t0
+        dX.set_values(w)
+        t0 = time.perf_counter()
+        _lib.predict_topk_dev(ctx, model, dX, Kp, out_idx, out_val, out_nnz)
+        torch.cuda.synchronize()
+        t_pred = time.perf_counter() - t0
+        tm = ctx.timings()
+        if best is None or t_fit + t_pred < best[0] + best[1]:
+            best = (t_fit, t_pred, tm)
+        del model
+    dX.close()
+    t_fit, t_pred, tm = best
+    return {
+        "workload": f"{config}: valued cosine ItemKNN K={args.K} on exponential-decay weights (TARSItemKNN), {U} users x {I} items, "
+                    f"nnz {int(indices.shape[0])}, decayed predict + top-{Kp} for all users",
+        "fit_s": round(t_fit, 4),
+        "predict_s": round(t_pred, 4),
+        "fit_plus_predict_s": round(t_fit + t_pred, 4),
+        "host_weights_s": round(host_s, 3),
+        "phases_ms": {k: round(v["ms"], 3) for k, v in tm.items() if v["launches"]},
+        "dtype": "f64 Gram (LDS f64 atomics), f64 weight x f32 similarity in exact 64-bit fixed-point sums",
     }
 
 
@@ -405,6 +464,9 @@ def main():
                 leg = ease_leg(args, ctx, device, Kp, cfg, 1 if CONFIGS[cfg][1] > 60000 else 2)
                 result["ease" if n == 0 else f"ease_{cfg.lower()}"] = leg
                 torch.cuda.empty_cache()
+        if world == 1 and args.tars_config.lower() != "none":
+            torch.cuda.empty_cache()
+            result["time_aware"] = tars_leg(args, ctx, device, Kp, args.tars_config.strip().upper())
         if ease_multi is not None:
             result["ease"] = ease_multi
         print(json.dumps(result), flush=True)
