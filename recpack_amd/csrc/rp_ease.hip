@@ -39,7 +39,8 @@ struct rp_gemm_args {
   int k0, k1;        // K range, multiples of 16
   int kb_m, kb_n;    // k_begin = max(k0, kb_m * (m_off + m0), kb_n * (n_off + n0))
   int m_off, n_off;
-  int tri;           // 0: all tiles; 1: only tiles with n_off + n0 <= m_off + m0
+  int tri;           // 0: all tiles; 1: only tiles with n_off + n0 <= m_off + m0; 2: strictly below the diagonal;
+                     // 3: the diagonal tiles only (grid.x = 1), written to C as a stack of blocks [M][128] (ldc = 128)
   float alpha, beta;
   // split-K (skinny products with few tiles and a long K): blockIdx.z = s handles K chunk s and writes its partial
   // tile to part[s][M][N] (alpha = 1, beta = 0); k_splitk_reduce applies alpha / beta to C afterwards
@@ -55,9 +56,10 @@ __global__ void __launch_bounds__(256) k_gemm_nt(rp_gemm_args g) {
   // Tiles in plain row-major order: with the clipped K ranges of the triangular factors the top tile rows carry the
   // longest K loops, so dispatch order = longest first.  (An XCD-contiguous regrouping for L2 reuse was measured and
   // lost 50 % on P = N N^T: it hands all long rows to one XCD.)
-  const int tm = blockIdx.y, tn = blockIdx.x;
+  const int tm = blockIdx.y, tn = (g.tri == 3) ? (int)blockIdx.y : (int)blockIdx.x;
   const int m0 = tm * GT, n0 = tn * GT;
   if (g.tri == 1 && g.n_off + n0 > g.m_off + m0) return;
+  if (g.tri == 2 && g.n_off + n0 >= g.m_off + m0) return;
   int kb = g.k0, ke = g.k1;
   if (g.part) {
     kb = g.k0 + (int)blockIdx.z * g.k_chunk;
@@ -128,7 +130,7 @@ __global__ void __launch_bounds__(256) k_gemm_nt(rp_gemm_args g) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wc * 64 + j * 32 + (lane & 31);
+      const int col = (g.tri == 3 ? 0 : n0) + wc * 64 + j * 32 + (lane & 31);  // tri == 3: C is a stack of 128-wide blocks
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -260,11 +262,22 @@ __global__ void k_zero_f32(float* __restrict__ p, long long n) {
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) p[e] = 0.0f;
 }
 
-// dst (n x n, leading dimension ldd) = src^T (leading dimension lds); n a multiple of 32, block (32, 8), grid (n/32, n/32)
+// diagonal block b of dst (leading dimension ld) = src[b] (128 x 128, leading dimension 128)
+__global__ void __launch_bounds__(256) k_copy_diag_blocks(const float* __restrict__ src, float* __restrict__ dst, long long ld) {
+  const long long b0 = (long long)blockIdx.x * GT;
+  for (int e = threadIdx.x; e < GT * GT; e += 256) {
+    const int i = e / GT, k = e % GT;
+    dst[(b0 + i) * ld + b0 + k] = src[(b0 + i) * GT + k];
+  }
+}
+
+// dst (n x n, leading dimension ldd) = src^T (leading dimension lds), where src is a block on the diagonal of the shared
+// L / N matrix: its 128-tiles below the diagonal hold L and count as zero.  n a multiple of 32, block (32, 8), grid (n/32, n/32)
 __global__ void k_transpose_block(const float* __restrict__ src, long long lds, float* __restrict__ dst, long long ldd) {
   __shared__ float t[32][33];
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
-  for (int r = threadIdx.y; r < 32; r += 8) t[r][threadIdx.x] = src[(long long)(by + r) * lds + bx + threadIdx.x];
+  const bool below = (by / GT) > (bx / GT);  // (32 divides 128: a 32 x 32 piece lies in one tile)
+  for (int r = threadIdx.y; r < 32; r += 8) t[r][threadIdx.x] = below ? 0.0f : src[(long long)(by + r) * lds + bx + threadIdx.x];
   __syncthreads();
   for (int r = threadIdx.y; r < 32; r += 8) dst[(long long)(bx + r) * ldd + by + threadIdx.x] = t[threadIdx.x][r];
 }
@@ -324,7 +337,7 @@ static int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st = nu
     if (S < 2) S = 1;
   }
   if (S == 1) {
-    hipLaunchKernelGGL(k_gemm_nt, dim3(g.N / GT, g.M / GT), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(k_gemm_nt, dim3(g.tri == 3 ? 1 : g.N / GT, g.M / GT), dim3(256), 0, st, g);
     RP_HIP(hipGetLastError());
     return RPHIP_OK;
   }
@@ -367,15 +380,19 @@ extern "C" int rphip_gemm_nt_f32(rphip_ctx* ctx, int64_t M, int64_t N, int64_t K
   return RPHIP_OK;
 }
 
-// in-place inverse of the SPD matrix A (n_pad x n_pad, ld) using the workspace Nb (same size); result in A (full)
+// In-place inverse of the SPD matrix A (n_pad x n_pad, ld), result in A (full).  ONE n x n matrix: after the Cholesky the
+// factor L sits strictly below the diagonal; N = L^-T is built on and above it (a diagonal block of L is only needed as its
+// inverse W_k, kept aside); P = N N^T then overwrites L below the diagonal (it reads N only), the diagonal tiles go through a
+// side buffer, and the lower half is mirrored over N.  200 000 items (160 GB) fit one 288 GB GPU this way.
 constexpr int RP_INV_PANEL = 16;  // tiles per panel of N = L^-T (2048 columns; 8 / 16 / 32 tiles measured: 5.94 / 5.53 / 5.87 s at n = 100 000)
 
-static int rp_spd_inverse(rphip_ctx* ctx, float* A, float* Nb, int n_pad, long long ld) {
+static int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld) {
   hipStream_t st = ctx->stream;
   const int nb = n_pad / GT;
   char* wsb = nullptr;
   const int inv_w = std::min(RP_INV_PANEL * GT, n_pad);  // columns of one panel of the inverse
   RP_TRY(rp_scratch(ctx, 5, (size_t)nb * GT * GT * 4 + ((size_t)n_pad * inv_w + (size_t)inv_w * inv_w) * 4 + 256, (void**)&wsb));
+  float* const Nb = A;  // N shares the matrix with L
   int* info = (int*)wsb;
   float* W = (float*)(wsb + 256);                 // [nb][128][128]
   float* T = W + (size_t)nb * GT * GT;            // [n_pad][inv_w]: N11 L21^T of a panel ([c0][128] inside a panel)
@@ -522,7 +539,6 @@ static int rp_spd_inverse(rphip_ctx* ctx, float* A, float* Nb, int n_pad, long l
   // first column), N12 = -T N22.  Block column by block column (128 wide, K from 0) every product was skinny:
   // 101 TFLOP/s with split K; the wide ones run at the square-GEMM rate.
   rp_time_begin(ctx, &ev);
-  hipLaunchKernelGGL(k_zero_f32, dim3(2048), dim3(256), 0, st, Nb, (long long)n_pad * ld);
   for (int pb = 0; pb < nb; pb += RP_INV_PANEL) {
     const int pe = std::min(nb, pb + RP_INV_PANEL);
     const int j = pb * GT, w = (pe - pb) * GT;
@@ -611,11 +627,16 @@ static int rp_spd_inverse(rphip_ctx* ctx, float* A, float* Nb, int n_pad, long l
     g.k1 = n_pad;
     g.kb_m = 1;
     g.kb_n = 1;
-    g.tri = 1;  // P is symmetric: lower tiles only, then mirrored
+    g.tri = 2;  // P is symmetric: the tiles below the diagonal (they read N on and above it, never what they write) ...
     g.alpha = 1.0f;
     g.beta = 0.0f;
     RP_TRY(rp_gemm_nt(ctx, g));
-    hipLaunchKernelGGL(k_mirror_lower, dim3(n_pad / 32, n_pad / 32), dim3(256), 0, st, A, ld, n_pad / 32);
+    g.tri = 3;  // ... the diagonal tiles into the (now free) T buffer, copied over N's diagonal blocks afterwards ...
+    g.C = T;
+    g.ldc = GT;
+    RP_TRY(rp_gemm_nt(ctx, g));
+    hipLaunchKernelGGL(k_copy_diag_blocks, dim3(nb), dim3(256), 0, st, T, A, ld);
+    hipLaunchKernelGGL(k_mirror_lower, dim3(n_pad / 32, n_pad / 32), dim3(256), 0, st, A, ld, n_pad / 32);  // ... and the mirror
   }
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, RPHIP_T_INVERSE, 2.0 * n3 / 3.0);  // n^3/3 (N = L^-T) + n^3/3 (lower half of N N^T)
@@ -797,7 +818,7 @@ extern "C" int rphip_ease_xy_fit(rphip_ctx* ctx, const rphip_csr* X, const rphip
   const float lam = (float)l2;
   hipLaunchKernelGGL(k_ease_init, dim3(4096), dim3(256), 0, st, Pm, ld, n, n_pad, lam);
   int r = rp_gram_dense(ctx, X, 0, n, Pm, ld, lam);
-  if (r == RPHIP_OK) r = rp_spd_inverse(ctx, Pm, Gyx, n_pad, ld);  // (Gyx is the workspace of the inverse first)
+  if (r == RPHIP_OK) r = rp_spd_inverse(ctx, Pm, n_pad, ld);
   if (r != RPHIP_OK) return fail(r);
   // Y^T X rows, then B_rr = P (X^T Y) = P (Y^T X)^T as an NT product
   hipLaunchKernelGGL(k_zero_f32, dim3(2048), dim3(256), 0, st, Gyx, (long long)n_pad * ld);
@@ -865,14 +886,13 @@ static int rp_ease_alloc(rphip_ctx* ctx, int n, int n_mats, rphip_model** mo, fl
   return RPHIP_OK;
 }
 
-// m->B holds G + lambda I (identity on the padding): P = its inverse (K5/K6, Nb = workspace, freed here), then K7
-static int rp_ease_solve_scale(rphip_ctx* ctx, const rphip_csr* X, rphip_model* m, float* Nb, double alpha) {
+// m->B holds G + lambda I (identity on the padding): P = its inverse (K5/K6, in place), then K7
+static int rp_ease_solve_scale(rphip_ctx* ctx, const rphip_csr* X, rphip_model* m, double alpha) {
   hipStream_t st = ctx->stream;
   const int n = (int)m->n_items;
   const int n_pad = (int)m->ld;
-  int r = rp_spd_inverse(ctx, m->B, Nb, n_pad, m->ld);
+  int r = rp_spd_inverse(ctx, m->B, n_pad, m->ld);
   hipStreamSynchronize(st);
-  hipFree(Nb);
   if (r != RPHIP_OK) return r;
   // ---- K7
   hipEvent_t ev;
@@ -896,18 +916,16 @@ extern "C" int rphip_ease_fit(rphip_ctx* ctx, const rphip_csr* X, double l2, dou
   const int n = (int)X->n_items;
   if (n <= 0) RP_FAIL(RPHIP_EINVAL, "no items");
   rphip_model* m = nullptr;
-  float* Nb = nullptr;
-  RP_TRY(rp_ease_alloc(ctx, n, 2, &m, &Nb));
+  float* none = nullptr;
+  RP_TRY(rp_ease_alloc(ctx, n, 1, &m, &none));
   // lambda is rounded to float32 exactly as the reference does (l2 * np.identity(dtype=float32), ease.py:82)
   const float lam = (float)l2;
   hipLaunchKernelGGL(k_ease_init, dim3(4096), dim3(256), 0, ctx->stream, m->B, m->ld, n, (int)m->ld, lam);
   int r = rp_gram_dense(ctx, X, 0, n, m->B, m->ld, lam);
-  if (r != RPHIP_OK) {
+  if (r != RPHIP_OK)
     hipStreamSynchronize(ctx->stream);
-    hipFree(Nb);
-  } else {
-    r = rp_ease_solve_scale(ctx, X, m, Nb, alpha);
-  }
+  else
+    r = rp_ease_solve_scale(ctx, X, m, alpha);
   if (r != RPHIP_OK) {
     rphip_model_destroy(m);
     return r;
@@ -952,16 +970,14 @@ extern "C" int rphip_ease_fit_gram(rphip_ctx* ctx, const rphip_csr* X, const rph
   RP_TRY(rp_set_device(ctx));
   const int n = (int)X->n_items;
   rphip_model* m = nullptr;
-  float* Nb = nullptr;
-  RP_TRY(rp_ease_alloc(ctx, n, 2, &m, &Nb));
+  float* none = nullptr;
+  RP_TRY(rp_ease_alloc(ctx, n, 1, &m, &none));
   int r = RPHIP_OK;
   if (hipMemcpyAsync(m->B, gram->B, (size_t)m->ld * m->ld * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) r = RPHIP_EHIP;
   if (r == RPHIP_OK) {
     // integer counts plus the float32 lambda: the same float32 sum the fused epilogue of rphip_ease_fit produces
     hipLaunchKernelGGL(k_add_diag, dim3((unsigned)rp_cdiv(n, 256)), dim3(256), 0, ctx->stream, m->B, m->ld, n, (float)l2);
-    r = rp_ease_solve_scale(ctx, X, m, Nb, alpha);
-  } else {
-    hipFree(Nb);
+    r = rp_ease_solve_scale(ctx, X, m, alpha);
   }
   if (r != RPHIP_OK) {
     rphip_model_destroy(m);
