@@ -39,6 +39,7 @@ struct rp_gemm_args {
   int k0, k1;        // K range, multiples of 16
   int kb_m, kb_n;    // k_begin = max(k0, kb_m * (m_off + m0), kb_n * (n_off + n0))
   int m_off, n_off;
+  int ke_n;          // k_end = min(k1, ke_n * (n_off + n0 + 128)): B is lower triangular (row n holds columns <= n)
   int tri;           // 0: all tiles; 1: only tiles with n_off + n0 <= m_off + m0; 2: strictly below the diagonal;
                      // 3: the diagonal tiles only (grid.x = 1), written to C as a stack of blocks [M][128] (ldc = 128)
   float alpha, beta;
@@ -67,6 +68,7 @@ __global__ void __launch_bounds__(256) k_gemm_nt(rp_gemm_args g) {
   }
   if (g.kb_m) kb = max(kb, g.m_off + m0);
   if (g.kb_n) kb = max(kb, g.n_off + n0);
+  if (g.ke_n) ke = min(ke, g.n_off + n0 + GT);
   kb &= ~(GBK - 1);
 
   f32x16 acc[2][2];
@@ -596,7 +598,8 @@ static int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld) {
       g.beta = 0.0f;
       RP_TRY(rp_gemm_nt(ctx, g));
       hipLaunchKernelGGL(k_transpose_block, dim3(w / 32, w / 32), dim3(32, 8), 0, st, Nb + (long long)j * ld + j, ld, NT, (long long)w);
-      rp_gemm_args h{};  // N12 = -T N22 (N22 is upper triangular: the K range past the column tile only adds zeros)
+      rp_gemm_args h{};  // N12 = -T N22 (N22 is upper triangular: K ends with the column tile)
+      h.ke_n = 1;
       h.A = T;
       h.lda = w;
       h.B = NT;
