@@ -531,6 +531,82 @@ __global__ void __launch_bounds__(RP_MERGE_THREADS) k_itemknn_merge(rp_merge_par
   }
 }
 
+// The same merge with one WAVE per row and no barriers: the T*K candidates stream through a wave-private top-K pool
+// (rp_wave.h, the pool of the predict kernel: exact radix-select cuts, admission exact for any arrival order).  The
+// payload is the candidate's position t*K + k, which orders like its column (tiles are ascending column ranges and a
+// tile's candidates are stored in column order), so ties go to the smaller column as everywhere else.  For K <= 384.
+constexpr int RP_MERGE_WAVE_KMAX = 384;
+__host__ __device__ constexpr int rp_merge_wave_cap(int K) { return ((K + 63) / 64) * 64 + 128; }
+__host__ __device__ constexpr size_t rp_merge_wave_bytes(int K) { return (size_t)rp_merge_wave_cap(K) * 12 + 1024 + 128; }
+
+__global__ void __launch_bounds__(64) k_itemknn_merge_wave(rp_merge_params P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int T = P.n_tiles, K = P.K, lane = threadIdx.x;
+  const int cap = rp_merge_wave_cap(K);
+  rp_wpool<uint64_t> pool;
+  pool.key = (RP_LDS uint64_t*)smem;
+  pool.pay = (RP_LDS uint32_t*)(pool.key + cap);
+  pool.hist = pool.pay + cap;
+  pool.gidx = (RP_LDS uint16_t*)(pool.hist + 256);
+  for (int rl = blockIdx.x; rl < P.n_rows; rl += gridDim.x) {
+    pool.n = 0;
+    pool.tau = 0;
+    pool.tau_col = 0;
+    const int64_t base = (int64_t)rl * T * K;
+    for (int t = 0; t < T; ++t) {
+      const int cn = P.cand_nnz[(int64_t)rl * T + t];
+      for (int k0 = 0; k0 < cn; k0 += 256) {  // four candidates per lane: the loads of a kind go out together
+        int col[4];
+        uint32_t cnt[4];
+        double iw[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = k0 + 64 * r + lane;
+          col[r] = (k < cn) ? P.cand_idx[base + t * K + k] : -1;
+          cnt[r] = (k < cn) ? P.cand_cnt[base + t * K + k] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) iw[r] = (col[r] >= 0) ? P.inv_deg[col[r]] : 0.0;
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r) {
+          if (k0 + 64 * r >= cn) break;  // (wave-uniform)
+          const uint32_t q = (uint32_t)(t * K + k0 + 64 * r + lane);
+          const uint64_t key = (col[0] >= 0) ? rp_fit_key(cnt[0], iw[0], P.key_pow) : 0ull;
+          const bool keep = col[0] >= 0 && rp_wpool_admits<uint64_t, 0>(pool, key, q);
+          rp_wpool_push<uint64_t, 0>(pool, K, cap, keep, key, q, lane);
+          col[0] = col[1]; col[1] = col[2]; col[2] = col[3];
+          cnt[0] = cnt[1]; cnt[1] = cnt[2]; cnt[2] = cnt[3];
+          iw[0] = iw[1]; iw[1] = iw[2]; iw[2] = iw[3];
+        }
+      }
+    }
+    RP_WAVE_FENCE();
+    if (pool.n > K) rp_wpool_cut<uint64_t, 0>(pool, K, lane);
+    const int n_out = pool.n;
+    RP_LDS uint32_t* pp = pool.pay;
+    if (lane < 4) pp[n_out + lane] = 0xffffffffu;  // pads the last group of four (n_out + 4 <= cap)
+    RP_WAVE_FENCE();
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    int32_t* oi = P.out_idx + (int64_t)rl * K;
+    double* ov = P.out_val + (int64_t)rl * K;
+    const double ci = (double)P.deg[P.row_begin + rl];
+    for (int e = lane; e < n_out; e += 64) {
+      const uint32_t q = pp[e];
+      int rank = 0;  // position order = column order
+      for (int o = 0; o < n_out; o += 4) {
+        const v4u w = *reinterpret_cast<RP_LDS v4u*>(&pp[o]);
+        rank += (w.x < q ? 1 : 0) + (w.y < q ? 1 : 0) + (w.z < q ? 1 : 0) + (w.w < q ? 1 : 0);
+      }
+      const int j = P.cand_idx[base + q];
+      const double c = (double)P.cand_cnt[base + q];
+      oi[rank] = j;
+      ov[rank] = (P.key_pow == 2) ? c / sqrt(ci * (double)P.deg[j]) : (c * P.inv_deg[j]) / ci;
+    }
+    if (lane == 0) P.out_nnz[rl] = n_out;
+    RP_WAVE_FENCE();
+  }
+}
+
 // ---- planning: order rows by degree (descending, coarse buckets), cut long rows into slices -------
 constexpr int PLAN_BUCKETS = RP_PLAN_BUCKETS;  // 0, then 8 per octave
 
@@ -982,6 +1058,14 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
     M.out_idx = m->idx;
     M.out_val = m->val;
     M.out_nnz = m->nnz;
+    if (Keff <= RP_MERGE_WAVE_KMAX) {
+      const size_t wl = rp_merge_wave_bytes(Keff);
+      RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_merge_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl));
+      const int wpc = std::max<int>(1, std::min<int>(24, (int)((160 * 1024) / wl)));
+      hipLaunchKernelGGL(k_itemknn_merge_wave, dim3((unsigned)std::min<int64_t>(n_rows, (int64_t)ctx->n_cu * wpc)), dim3(64), wl, st, M);
+      RP_HIP(hipGetLastError());
+      rp_time_end(ctx, ev, RPHIP_T_TOPK_MERGE, 16.0 * (double)n_rows * T * Keff);
+    } else {
     const size_t mlds = (size_t)T * Keff * 8 + rp_select_smem_bytes(T * Keff, RP_MERGE_THREADS / 64);
     if (mlds > 160 * 1024 || T * Keff >= RPS_FLAG) {
       rphip_model_destroy(m);
@@ -993,6 +1077,7 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
     hipLaunchKernelGGL(k_itemknn_merge, dim3(mg), dim3(RP_MERGE_THREADS), mlds, st, M);
     RP_HIP(hipGetLastError());
     rp_time_end(ctx, ev, RPHIP_T_TOPK_MERGE, 16.0 * (double)n_rows * T * Keff);
+    }
   }
   {
     int r = rp_model_finalize_topk(ctx, m);
