@@ -47,6 +47,14 @@ def binarize(X: sp.csr_matrix) -> sp.csr_matrix:
     return sp.csr_matrix((np.ones(X.nnz, dtype=np.int64), X.indices, X.indptr), shape=X.shape)
 
 
+def _libm_pow(x: np.ndarray, y: float) -> np.ndarray:
+    """x ** y through the C library's pow, element by element: numpy's vectorised power may differ from libm in the last
+    bit, and the selection key c_ij * c_j^-alpha (exact ties are common) must be the same double everywhere."""
+    import math
+
+    return np.array([math.pow(float(v), y) for v in np.asarray(x).ravel()], dtype=np.float64).reshape(np.shape(x))
+
+
 def item_degrees(Xb: sp.csr_matrix) -> np.ndarray:
     return np.bincount(Xb.indices, minlength=Xb.shape[1]).astype(np.int64)
 
@@ -110,7 +118,7 @@ def itemknn_fit_normalized(X: sp.csr_matrix, K: int, similarity: str = "cosine",
         alpha = float(pop_discount or 0.0)
         colw = np.zeros(n_items)
         nz = c > 0
-        colw[nz] = 1.0 if alpha == 0.0 else np.power(c[nz].astype(np.float64), -alpha)
+        colw[nz] = 1.0 if alpha == 0.0 else _libm_pow(c[nz], -alpha)
         with np.errstate(divide="ignore"):
             roww = np.where(c > 0, 1.0 / c.astype(np.float64), 0.0)
     else:
@@ -164,7 +172,7 @@ def itemknn_fit(X: sp.csr_matrix, K: int, rows=None, similarity: str = "cosine",
         alpha = float(pop_discount or 0.0)
         colw = np.zeros(n_items)
         nz = c > 0
-        colw[nz] = 1.0 if alpha == 0.0 else np.power(c[nz].astype(np.float64), -alpha)
+        colw[nz] = 1.0 if alpha == 0.0 else _libm_pow(c[nz], -alpha)
         key = gc.astype(np.float64) * colw[gj]
     else:
         raise ValueError(similarity)
