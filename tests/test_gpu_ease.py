@@ -122,7 +122,8 @@ def test_ease_prune_dropin(hip):
 
 
 @pytest.mark.parametrize("shape,l2,alpha,seed", [((20000, 3000, 0.004), 200.0, 0.0, 31), ((8000, 1100, 0.01), 5.0, 0.5, 32),
-                                                 ((4000, 700, 0.02), 0.5, 1.0, 33)])
+                                                 ((4000, 700, 0.02), 0.5, 1.0, 33),
+                                                 ((15000, 4400, 0.003), 50.0, 0.0, 34)])  # 35 tiles: three panels, the last one short
 def test_ease_fit_synthetic_vs_oracle(hip, shape, l2, alpha, seed):
     from recpack_amd.synth import powerlaw_csr
 

@@ -50,3 +50,62 @@ def test_fit_fuzz_against_oracle(seed, n_cases):
         np.testing.assert_allclose(val[:, :k], rval, rtol=1e-12, err_msg=what)
         dX.close()
         m.close()
+
+
+@pytest.mark.parametrize("seed,n_cases", [(3, 16), (11, 24)])
+def test_predict_fuzz_against_oracle(seed, n_cases):
+    """Fused top-Kp of random neighbour-list models (both predict kernels: wave per user, and the workgroup kernel for
+    Kp > 384 or unsorted/negative models), histories from empty to several hundred items, history removal and item filters:
+    tie-aware against float64 scores of the f32-rounded similarities; full CSR result exact in pattern."""
+    from recpack_amd import _lib, get_context
+    from test_gpu_itemknn import PRED_RTOL, check_topk_scores
+
+    ctx = get_context(0)
+    rng = np.random.default_rng(seed)
+    for case in range(n_cases):
+        I = int(rng.choice([5, 300, 2100, 5000, 40000]))
+        U = int(rng.integers(1, 1500))
+        K = int(rng.choice([1, 5, 50, 200]))
+        Kp = int(rng.choice([1, 10, 100, 384, 400]))
+        Kp = min(Kp, I)
+        signed = bool(rng.random() < 0.3)
+        nnz_row = rng.integers(0, min(K, I) + 1, size=I)
+        idx = np.full((I, K), -1, np.int32)
+        val = np.zeros((I, K))
+        for r in np.nonzero(nnz_row)[0][: 20000]:
+            n = nnz_row[r]
+            idx[r, :n] = np.sort(rng.choice(I, n, replace=False))
+            v = rng.random(n) + 1e-3
+            val[r, :n] = np.where(rng.random(n) < 0.4, -v, v) if signed else v
+        nnz_row[20000:] = 0 if I > 20000 else nnz_row[20000:]
+        model = _lib.Model.from_topk_host(ctx, idx, val, nnz_row.astype(np.int32))
+        S = onp.topk_to_csr(idx, val.astype(np.float32).astype(np.float64), nnz_row.astype(np.int32), I)
+        d = np.minimum(rng.pareto(1.0, size=U) * 5, min(I, 700)).astype(np.int64)
+        rows = np.repeat(np.arange(U), d)
+        cols = rng.integers(0, I, size=rows.shape[0])
+        X = sp.csr_matrix((np.ones(rows.shape[0]), (rows, cols)), shape=(U, I))
+        X.sum_duplicates()
+        X.data[:] = 1.0
+        X.sort_indices()
+        dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
+        scores = onp.predict_full(X, S)
+        scores.eliminate_zeros()
+        what = f"case {case}: U={U} I={I} K={K} Kp={Kp} signed={signed} nnz={X.nnz}"
+        ip, ind, dat = _lib.predict_full(ctx, model, dX)
+        out = sp.csr_matrix((dat, ind, ip), shape=scores.shape)
+        if not signed:  # (with signs a sum may cancel to a tiny non-zero in one arithmetic and to zero in the other)
+            assert (out.indptr == scores.indptr).all() and (out.indices == scores.indices).all(), what
+            np.testing.assert_allclose(out.data, scores.data, rtol=PRED_RTOL, err_msg=what)
+            keep = rng.random(I) < 0.6
+            for excl in (False, True):
+                pi, pv, pn = _lib.predict_topk(ctx, model, dX, Kp, exclude_history=excl)
+                check_topk_scores(scores, pi, pv, pn, Kp, exclude=X if excl else None)
+                pi, pv, pn = _lib.predict_topk(ctx, model, dX, Kp, exclude_history=excl, item_keep=keep)
+                check_topk_scores(onp.pipeline_scores(scores, item_keep=keep), pi, pv, pn, Kp, exclude=X if excl else None)
+        else:
+            assert abs(out - scores).max() <= 1e-6 * max(1e-300, abs(scores).max()), what
+            pi, pv, pn = _lib.predict_topk(ctx, model, dX, Kp)
+            got = onp.topk_to_csr(pi, pv.astype(np.float64), pn, I)
+            assert abs(got - scores.multiply(got != 0)).max() <= 1e-6 * max(1e-300, abs(scores).max()), what
+        dX.close()
+        model.close()
