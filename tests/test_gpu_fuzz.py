@@ -109,3 +109,64 @@ def test_predict_fuzz_against_oracle(seed, n_cases):
             assert abs(got - scores.multiply(got != 0)).max() <= 1e-6 * max(1e-300, abs(scores).max()), what
         dX.close()
         model.close()
+
+
+@pytest.mark.parametrize("seed,n_cases", [(5, 18)])
+def test_valued_fit_fuzz(seed, n_cases):
+    """rphip_itemknn_fit_values on random valued matrices (positive or signed values, binary or valued left operand, row
+    scales; one tile, several tiles with hash rows, K beyond the hash path's limit): G = L^T X in float64 by scipy, the
+    reference's stored-zero rule for the number of entries per row, tie-aware sets (eps 1e-9), values within 1e-11."""
+    from parity import tie_aware_topk
+    from recpack_amd import _lib, get_context
+
+    ctx = get_context(0)
+    rng = np.random.default_rng(seed)
+    for case in range(n_cases):
+        I = int(rng.choice([40, 3000, 13000, 30000]))
+        U = int(rng.integers(2, 3000))
+        K = int(rng.choice([1, 5, 50, 200, 512, 600]))
+        signed = bool(rng.random() < 0.4)
+        left_binary = bool(rng.random() < 0.3)
+        n = int(rng.integers(1, 150000))
+        cols = np.minimum((rng.pareto(1.1, size=n) * I / 40).astype(np.int64), I - 1)
+        rows = rng.integers(0, U, size=n)
+        X = sp.csr_matrix((np.ones(n), (rows, cols)), shape=(U, I))
+        X.sum_duplicates()
+        X.sort_indices()
+        w = rng.random(X.nnz) + 0.01
+        if signed:
+            w = np.where(rng.random(X.nnz) < 0.45, -w, w)
+        X.data = w
+        scale = (rng.random(I) + 0.5) if rng.random() < 0.5 else None
+        L = sp.csr_matrix((np.ones(X.nnz), X.indices, X.indptr), shape=X.shape) if left_binary else X
+        G = sp.csr_matrix(L.T @ X)
+        if scale is not None:
+            G = sp.csr_matrix(sp.diags(scale) @ G)
+        G.setdiag(0)
+        G.eliminate_zeros()
+        G.sort_indices()
+        # the reference's rule: stored = non-zero sums + the diagonal's explicit 0; K largest stored; zeros dropped
+        Keff = min(K, max(1, I - 1))
+        ref_idx = np.full((I, Keff), -1, np.int32)
+        ref_val = np.zeros((I, Keff))
+        ref_nnz = np.zeros(I, np.int32)
+        for r in range(I):
+            c, v = G.indices[G.indptr[r]: G.indptr[r + 1]], G.data[G.indptr[r]: G.indptr[r + 1]]
+            if not len(c):
+                continue
+            c2, v2 = np.append(c, r), np.append(v, 0.0)
+            order = np.lexsort((c2, -v2))[:Keff]
+            keep = order[v2[order] != 0]
+            ref_nnz[r] = len(keep)
+            ref_idx[r, : len(keep)], ref_val[r, : len(keep)] = c2[keep], v2[keep]
+        S_ref = onp.topk_to_csr(ref_idx, ref_val, ref_nnz, I)
+        dX = _lib.DeviceCSR.from_host_valued(ctx, X)
+        m = _lib.itemknn_fit_values(ctx, dX, K, left_binary=left_binary, row_scale=scale)
+        idx, val, nnz = m.topk_download()
+        what = f"case {case}: U={U} I={I} nnz={X.nnz} K={K} signed={signed} left_binary={left_binary} scaled={scale is not None}"
+        bad, _ = tie_aware_topk(G, S_ref, idx, nnz, positive_only=False)
+        assert not bad, (what, bad[:5])
+        S = onp.topk_to_csr(idx, val, nnz, I)
+        assert abs(S.multiply(S_ref != 0) - S_ref.multiply(S != 0)).max() <= 1e-11 * max(1e-300, abs(S_ref).max()), what
+        dX.close()
+        m.close()
