@@ -129,13 +129,15 @@ def fit_itemknn_sharded(ctx, dX, K: int, parts: Sequence[Tuple[int, int]], devic
     return _lib.Model.from_topk_device(ctx, idx_f, val_f, nnz_f)
 
 
-def ease_fit_sharded(ctx, dX, l2: float, alpha: float, device, group=None):
+def ease_fit_sharded(ctx, dX, l2: float, alpha: float, device, group=None, panel_tiles: int = 16):
     """EASE fit (recpack/algorithms/ease.py:63-95) on all ranks of ``group``, one GPU each.
 
     Every rank keeps ONE n x n float32 matrix: first G + l2*I, then the Cholesky factor L below the diagonal and
     N = L^-T on and above it (a diagonal block is only needed until its panel is done, then it holds N's block), finally B.
-    The O(n^3) work of every panel is split by row tiles over the ranks and the finished panel is all-gathered
-    (n^2/2 * 4 bytes in total per phase); P = N N^T and the scaling are computed for a rank's own rows and B is
+    The O(n^3) work is done in wide panels (``panel_tiles`` x 128 columns): a panel takes the update of everything to its
+    left in one product whose rows are split over the ranks, and the finished panel is all-gathered (n^2/2 * 4 bytes in
+    total per phase, ~n / 2048 large collectives plus one small one per 128 columns inside a panel);
+    P = N N^T and the scaling are computed for a rank's own rows and B is
     all-gathered into the big matrix, so predict can shard by users as for ItemKNN.  Peak memory n^2 * 4 * (1 + 1/world)
     bytes per GPU.  Returns a dense model on this rank's copy of B.
     """
@@ -173,10 +175,11 @@ def ease_fit_sharded(ctx, dX, l2: float, alpha: float, device, group=None):
     to_torch()
     mine.copy_(A[rank * rows:(rank + 1) * rows])
     gather(A, mine)
+    PW = min(nb, panel_tiles)  # tiles per wide panel
     max_per = -(-nb // world)
-    send = torch.empty((max_per * T, T), dtype=torch.float32, device=device)
-    recv = torch.empty((world * max_per * T, T), dtype=torch.float32, device=device)
-    tmp = torch.empty((max_per * T, T), dtype=torch.float32, device=device)
+    send = torch.empty((max_per * T, PW * T), dtype=torch.float32, device=device)
+    recv = torch.empty((world * max_per * T, PW * T), dtype=torch.float32, device=device)
+    tmp = torch.empty((max_per * T, PW * T), dtype=torch.float32, device=device)
 
     def split(first_tile, n_tiles):
         """This rank's share [lo, hi) of the tiles first_tile .. first_tile + n_tiles, and the per-rank chunk size."""
@@ -185,39 +188,78 @@ def ease_fit_sharded(ctx, dX, l2: float, alpha: float, device, group=None):
         hi = min(n_tiles, (rank + 1) * per)
         return first_tile + lo, first_tile + hi, per
 
-    # ---- K5: left-looking Cholesky, panel by panel
-    for k in range(nb):
-        r0 = k * T
-        diag = A[r0:r0 + T, r0:r0 + T]
-        if k > 0:  # every rank updates the diagonal tile itself (128 rows: negligible, and no broadcast)
-            _lib.gemm_nt_ex(ctx, A[r0:r0 + T], A[r0:r0 + T], diag, 0, r0, alpha=-1.0, beta=1.0)
-        _lib.potrf_trtri_128(ctx, diag, W[k], info)
-        lo, hi, per = split(k + 1, nb - k - 1)
-        if hi > lo:
-            R = slice(lo * T, hi * T)
-            if k > 0:
-                _lib.gemm_nt_ex(ctx, A[R], A[r0:r0 + T], A[R, r0:r0 + T], 0, r0, alpha=-1.0, beta=1.0)
-            _lib.gemm_nt_ex(ctx, A[R, r0:r0 + T], W[k], send[: (hi - lo) * T], 0, T)  # L[R, k] = A[R, k] W_k^T
-        if nb - k - 1 > 0:
-            gather(recv[: world * per * T], send[: per * T])
-            A[r0 + T:, r0:r0 + T].copy_(recv[: (nb - k - 1) * T])
-        else:
+    def gather_rows(dst, n_rows, cols, per, mine_rows):
+        """All-gather the ranks' row shares (mine_rows x cols, in send) and store the first n_rows rows into dst."""
+        sv = send.view(-1)[: per * T * cols].view(per * T, cols)
+        rv = recv.view(-1)[: world * per * T * cols].view(world * per * T, cols)
+        del mine_rows
+        gather(rv, sv)
+        dst.copy_(rv[:n_rows])
+
+    def share(cols, n_rows_mine):
+        return send.view(-1)[: max(1, n_rows_mine) * cols].view(max(1, n_rows_mine), cols)[:n_rows_mine]
+
+    # ---- K5: Cholesky in two levels, left-looking across wide panels.  Per panel: its columns take the update of
+    # everything to their left in ONE wide product (rows split over the ranks, one all-gather of the panel), then the panel is
+    # factored 128 columns at a time with K restricted to the panel (short products, rows split, small all-gathers).
+    for pb in range(0, nb, PW):
+        pe = min(nb, pb + PW)
+        j, w = pb * T, (pe - pb) * T
+        if j > 0:
+            lo, hi, per = split(pb, nb - pb)
+            mine_rows = (hi - lo) * T
+            if hi > lo:
+                R = slice(lo * T, hi * T)
+                out = share(w, mine_rows)
+                out.copy_(A[R, j:j + w])
+                _lib.gemm_nt_ex(ctx, A[R], A[j:j + w], out, 0, j, alpha=-1.0, beta=1.0)  # A[R, panel] -= L[R, :j] L[panel, :j]^T
+            gather_rows(A[j:, j:j + w], (nb - pb) * T, w, per, mine_rows)
+            if not lib_stream_is_torchs:
+                torch.cuda.current_stream().synchronize()
+        for k in range(pb, pe):
+            r0 = k * T
+            diag = A[r0:r0 + T, r0:r0 + T]
+            if r0 > j:  # every rank updates the diagonal tile itself (128 rows: negligible, and no broadcast)
+                _lib.gemm_nt_ex(ctx, A[r0:r0 + T], A[r0:r0 + T], diag, j, r0, alpha=-1.0, beta=1.0)
+            _lib.potrf_trtri_128(ctx, diag, W[k], info)
+            lo, hi, per = split(k + 1, nb - k - 1)
+            mine_rows = (hi - lo) * T
+            if hi > lo:
+                R = slice(lo * T, hi * T)
+                if r0 > j:
+                    _lib.gemm_nt_ex(ctx, A[R], A[r0:r0 + T], A[R, r0:r0 + T], j, r0, alpha=-1.0, beta=1.0)
+                _lib.gemm_nt_ex(ctx, A[R, r0:r0 + T], W[k], share(T, mine_rows), 0, T)  # L[R, k] = A[R, k] W_k^T
+            if nb - k - 1 > 0:
+                gather_rows(A[r0 + T:, r0:r0 + T], (nb - k - 1) * T, T, per, mine_rows)
+            else:
+                to_torch()
+            diag.copy_(W[k].t())  # from here on the block is N's diagonal block
+            if not lib_stream_is_torchs:
+                torch.cuda.current_stream().synchronize()
+    # ---- K6a: N = L^-T above the diagonal, panel by panel: the panel's own triangle on every rank (tiny products, no
+    # exchange), then T = N11 L21^T and N12 = -T N22 as two wide products with the rows split, one all-gather per panel
+    for pb in range(0, nb, PW):
+        pe = min(nb, pb + PW)
+        j, w = pb * T, (pe - pb) * T
+        for i in range(pb + 1, pe):
+            c0 = i * T
+            t1 = tmp.view(-1)[: (c0 - j) * T].view(c0 - j, T)
+            _lib.gemm_nt_ex(ctx, A[j:c0], A[c0:c0 + T], t1, j, c0, k_from_row=True, m_off=j)
+            _lib.gemm_nt_ex(ctx, t1, W[i], A[j:c0, c0:c0 + T], 0, T, alpha=-1.0)
+        if j > 0:
             to_torch()
-        diag.copy_(W[k].t())  # from here on the block is N's diagonal block
-        if not lib_stream_is_torchs:
-            torch.cuda.current_stream().synchronize()
-    # ---- K6a: N = L^-T above the diagonal, block column by block column
-    for i in range(1, nb):
-        c0 = i * T
-        lo, hi, per = split(0, i)
-        if hi > lo:
-            R = slice(lo * T, hi * T)
-            _lib.gemm_nt_ex(ctx, A[R], A[c0:c0 + T], tmp[: (hi - lo) * T], 0, c0, k_from_row=True, m_off=lo * T)
-            _lib.gemm_nt_ex(ctx, tmp[: (hi - lo) * T], W[i], send[: (hi - lo) * T], 0, T, alpha=-1.0)
-        gather(recv[: world * per * T], send[: per * T])
-        A[:c0, c0:c0 + T].copy_(recv[: i * T])
-        if not lib_stream_is_torchs:
-            torch.cuda.current_stream().synchronize()
+            NT = torch.triu(A[j:j + w, j:j + w]).t().contiguous()  # N22^T; the tiles below the diagonal hold L: zero
+            lo, hi, per = split(0, pb)
+            mine_rows = (hi - lo) * T
+            if hi > lo:
+                R = slice(lo * T, hi * T)
+                t2 = tmp.view(-1)[: mine_rows * w].view(mine_rows, w)
+                _lib.gemm_nt_ex(ctx, A[R], A[j:j + w], t2, 0, j, k_from_row=True, m_off=lo * T)
+                _lib.gemm_nt_ex(ctx, t2, NT, share(w, mine_rows), 0, w, alpha=-1.0)
+            gather_rows(A[:j, j:j + w], pb * T, w, per, mine_rows)
+            if not lib_stream_is_torchs:
+                torch.cuda.current_stream().synchronize()
+            del NT
     # ---- K6b: this rank's rows of P = N N^T, K7 scaling, B all-gathered into the big matrix
     Rr = slice(rank * rows, (rank + 1) * rows)
     P = torch.empty((rows, n_pad), dtype=torch.float32, device=device)

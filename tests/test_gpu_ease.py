@@ -233,11 +233,12 @@ def _run_dist_check(nproc, args=()):
     return subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
 
 
-@pytest.mark.parametrize("nproc,shape", [(2, (4000, 700, 0.02)), (3, (3000, 1000, 0.01))])
+@pytest.mark.parametrize("nproc,shape", [(2, (4000, 700, 0.02, 2)), (3, (3000, 1000, 0.01, 3)), (2, (3000, 1000, 0.01, 16))])
 def test_ease_fit_sharded_multi_rank(hip, nproc, shape):
-    """recpack_amd.dist.ease_fit_sharded (row-tile split panels + all-gather) with several ranks gives
-    every rank the B of the single-GPU solve (same kernels, same order of operations per tile: max relative difference 2e-5
-    allowed, 0 observed without alpha) and the same top-K."""
+    """recpack_amd.dist.ease_fit_sharded (wide panels with the rows split over the ranks + all-gather)
+    with several ranks gives every rank the B of the single-GPU solve (max relative difference 2e-5 allowed) and the same
+    top-K.  The fourth number is the panel width in tiles: 2 and 3 give several wide panels at these sizes (the last one
+    short), 16 is the default (one panel here)."""
     r = _run_dist_check(nproc, shape)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("top-20 agreement") == 2 * nproc
@@ -252,10 +253,10 @@ def test_ease_fit_sharded_one_rank(hip):
     _lib, ctx = hip
     X = powerlaw_csr(6000, 1500, 0.008, seed=77).to_scipy()
     dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
-    m = rdist.ease_fit_sharded(ctx, dX, 20.0, 0.0, torch.device("cuda", 0))
-    B = m.dense_download()
     ref = onp.ease_fit(X, 20.0, 0.0)
-    assert rel_max(B, ref) <= EASE_TOL
+    for panel_tiles in (16, 5):  # 12 tiles: one panel; three panels, the last one short
+        m = rdist.ease_fit_sharded(ctx, dX, 20.0, 0.0, torch.device("cuda", 0), panel_tiles=panel_tiles)
+        assert rel_max(m.dense_download(), ref) <= EASE_TOL
     with pytest.raises(_lib.RecpackHipError):
         rdist.ease_fit_sharded(ctx, dX, 0.0, 0.0, torch.device("cuda", 0))
 
@@ -269,7 +270,7 @@ def test_ease_fit_sharded_rccl_one_rank(hip):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RECPACK_FORCE_PG="1", RECPACK_DIST_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT="29591", RANK="0",
                WORLD_SIZE="1", LOCAL_RANK="0")
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dist_ease_check.py"), "3000", "600", "0.02"], cwd=root, env=env,
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dist_ease_check.py"), "3000", "600", "0.02", "2"], cwd=root, env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
 

@@ -1,6 +1,6 @@
 """Functional check of recpack_amd.dist.ease_fit_sharded against the single-GPU solve.
 
-    python tools/dist_ease_check.py [users items density]                       (one rank)
+    python tools/dist_ease_check.py [users items density [panel_tiles]]         (one rank)
     RECPACK_DIST_BACKEND=gloo python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tools/dist_ease_check.py
 (with gloo all ranks may share one GPU; with nccl one rank per GPU).  Exit code 0 = B of every rank equals the reference.
 """
@@ -17,6 +17,7 @@ from recpack_amd import dist as rdist  # noqa: E402
 from recpack_amd.synth import powerlaw_csr  # noqa: E402
 
 U, I, dens = (int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])) if len(sys.argv) > 3 else (4000, 700, 0.02)
+panel_tiles = int(sys.argv[4]) if len(sys.argv) > 4 else 16  # small values exercise the wide-panel steps at test sizes
 world = int(os.environ.get("WORLD_SIZE", "1"))
 rank = int(os.environ.get("RANK", "0"))
 backend = os.environ.get("RECPACK_DIST_BACKEND", "nccl")
@@ -36,7 +37,7 @@ ok = True
 for l2, alpha in ((50.0, 0.0), (5.0, 0.5)):
     ref = _lib.ease_fit(ctx, dX, l2, alpha)
     B_ref = ref.dense_download()
-    m = rdist.ease_fit_sharded(ctx, dX, l2, alpha, device)
+    m = rdist.ease_fit_sharded(ctx, dX, l2, alpha, device, panel_tiles=panel_tiles)
     B = m.dense_download()
     err = float(np.abs(B - B_ref).max() / np.abs(B_ref).max())
     same_empty = m.empty_rows() == ref.empty_rows()
