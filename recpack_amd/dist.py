@@ -137,7 +137,7 @@ def ease_fit_sharded(ctx, dX, l2: float, alpha: float, device, group=None, panel
     The O(n^3) work is done in wide panels (``panel_tiles`` x 128 columns): a panel takes the update of everything to its
     left in one product whose rows are split over the ranks, and the finished panel is all-gathered (n^2/2 * 4 bytes in
     total per phase, ~n / 2048 large collectives plus one small one per 128 columns inside a panel);
-    P = N N^T and the scaling are computed for a rank's own rows and B is
+    P = N N^T (lower triangle, row slabs of equal area) is exchanged with one broadcast per rank, mirrored and scaled; B is
     all-gathered into the big matrix, so predict can shard by users as for ItemKNN.  Peak memory n^2 * 4 * (1 + 1/world)
     bytes per GPU.  Returns a dense model on this rank's copy of B.
     """
@@ -260,27 +260,54 @@ def ease_fit_sharded(ctx, dX, l2: float, alpha: float, device, group=None, panel
             if not lib_stream_is_torchs:
                 torch.cuda.current_stream().synchronize()
             del NT
-    # ---- K6b: this rank's rows of P = N N^T, K7 scaling, B all-gathered into the big matrix
-    Rr = slice(rank * rows, (rank + 1) * rows)
-    P = torch.empty((rows, n_pad), dtype=torch.float32, device=device)
-    _lib.gemm_nt_ex(ctx, A[Rr], A, P, 0, n_pad, k_from_row=True, k_from_col=True, m_off=rank * rows)
-    to_torch()
-    d_mine = torch.diagonal(P[:, Rr]).contiguous()
-    d_all = torch.empty((n_pad,), dtype=torch.float32, device=device)
-    gather(d_all, d_mine)
+    # ---- K6b: P = N N^T, lower triangle only.  The row tiles are cut into `world` slabs of equal AREA under the diagonal
+    # (slab r ends at n * sqrt((r + 1) / world)); a rank computes the lower tiles of its slab in chunks (a chunk goes to a
+    # staging buffer and then over the L part of its rows - N on and above the diagonal is still read by the chunks after
+    # it), the slabs are exchanged with one broadcast each, the lower half is mirrored and K7 runs on the whole matrix.
+    import math
+
+    cut = [min(nb, int(round(nb * math.sqrt(r / world)))) for r in range(world)] + [nb]
+    for r in range(1, world + 1):
+        cut[r] = max(cut[r], cut[r - 1])
+    t_lo, t_hi = cut[rank], cut[rank + 1]
+    chunk_tiles = max(1, min(max_per, 64))
+    stage = torch.empty((chunk_tiles * T, n_pad), dtype=torch.float32, device=device)
+    done = []
+    for c_lo in range(t_lo, t_hi, chunk_tiles):
+        c_hi = min(t_hi, c_lo + chunk_tiles)
+        r0, r1 = c_lo * T, c_hi * T
+        Pc = stage[: r1 - r0, :r1]
+        _lib.gemm_nt_ex(ctx, A[r0:r1], A[:r1], Pc, 0, n_pad, k_from_row=True, k_from_col=True, m_off=r0, lower_only=True)
+        done.append((r0, r1))
+        to_torch()
+        A[r0:r1, :r1].copy_(Pc)  # (the tiles above the diagonal inside the chunk's square are overwritten by the mirror)
+    if not lib_stream_is_torchs:
+        torch.cuda.current_stream().synchronize()
+    if dist.is_initialized():
+        dist.barrier(group=group)  # every rank has finished reading N
+        for r in range(world):
+            if cut[r + 1] > cut[r]:
+                dist.broadcast(A[cut[r] * T: cut[r + 1] * T], src=dist.get_global_rank(group, r) if group is not None else r, group=group)
+    MB = 32 * T  # mirror the lower half over the upper one, a block row at a time (no second matrix)
+    for r0 in range(0, n_pad, MB):
+        r1 = min(n_pad, r0 + MB)
+        blk = A[r0:r1, r0:r1]
+        blk.copy_(torch.tril(blk) + torch.tril(blk, -1).t())
+        if r1 < n_pad:
+            A[r0:r1, r1:].copy_(A[r1:, r0:r1].t())
+    # ---- K7: B_ij = -P_ij / P_jj * w_j, B_ii = 0 (ease.py:85-90), padding zeroed; every rank on its own copy
+    d_all = torch.diagonal(A).clone()
     w = torch.ones((n_pad,), dtype=torch.float32, device=device)
     if alpha != 0.0:
         deg = torch.as_tensor(dX.item_degrees(), device=device).to(torch.float32)
         w[:n] = torch.where(deg > 0, deg.clamp(min=1).pow(-float(alpha)), torch.zeros_like(deg))
-    P.mul_((-w / d_all)[None, :])  # B_ij = -P_ij / P_jj * w_j (ease.py:85-90)
-    torch.diagonal(P[:, Rr]).zero_()
-    P[:, n:] = 0
-    if (rank + 1) * rows > n:
-        P[max(0, n - rank * rows):] = 0
-    if dist.is_initialized():
-        dist.barrier(group=group)  # every rank has finished reading N before it becomes B
-    gather(A, P)
-    del P
+    scale = -w / d_all
+    for r0 in range(0, n_pad, MB):  # (in block rows: no n x n temporary)
+        A[r0:r0 + MB].mul_(scale[None, :])
+    torch.diagonal(A).zero_()
+    A[:, n:] = 0
+    A[n:] = 0
+    del stage
     if not lib_stream_is_torchs:
         torch.cuda.current_stream().synchronize()
     bad = int(info.item())
