@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import threading
 
 import numpy as np
@@ -111,14 +112,16 @@ _lib = None
 
 
 def _build_in_tree():
-    """`make -C recpack_amd/csrc` when hipcc is there and the library has not been built yet (errors are left to the
-    loader's own message)."""
-    import shutil
-    import subprocess
+    """`make -C recpack_amd/csrc` when hipcc is there and the library has not been built yet.  Serialised across
+    processes by an flock on csrc/.build.lock (a torchrun start on a fresh checkout: one rank builds, the others wait
+    on the lock and find the finished library); make links to a temporary name and renames it, so a half-linked file
+    is never dlopened.  make's output is shown when it fails."""
+    from .build import build_hip
 
-    src = os.path.dirname(LIB_PATH)
-    if shutil.which("make") and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
-        subprocess.run(["make", "-C", src, "-j", "6"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+    try:
+        build_hip(jobs=6, quiet=True, only_if_missing=True)
+    except Exception as e:  # the loader's own message follows
+        sys.stderr.write(f"recpack_amd: in-tree build failed: {e}\n")
 
 
 def load_library(path: str | None = None):

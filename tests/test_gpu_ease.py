@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from conftest import csr_from, load_golden
+from conftest import csr_from, free_port, load_golden
 from oracle import oracle_np as onp
 from parity import tie_aware_topk
 
@@ -229,7 +229,7 @@ def _run_dist_check(nproc, args=()):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RECPACK_DIST_BACKEND="gloo")  # the ranks share this box's GPU(s); RCCL needs one GPU per rank
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29560 + nproc), os.path.join(root, "tools", "dist_ease_check.py"), *map(str, args)]
+           "--master-port", str(free_port()), os.path.join(root, "tools", "dist_ease_check.py"), *map(str, args)]
     return subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
 
 
@@ -268,7 +268,7 @@ def test_ease_fit_sharded_rccl_one_rank(hip):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, RECPACK_FORCE_PG="1", RECPACK_DIST_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT="29591", RANK="0",
+    env = dict(os.environ, RECPACK_FORCE_PG="1", RECPACK_DIST_BACKEND="nccl", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0",
                WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "dist_ease_check.py"), "3000", "600", "0.02", "2"], cwd=root, env=env,
                        capture_output=True, text=True, timeout=600)

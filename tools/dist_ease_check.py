@@ -28,7 +28,7 @@ torch.cuda.set_device(local)
 device = torch.device("cuda", local)
 if world > 1 or os.environ.get("RECPACK_FORCE_PG"):  # (RECPACK_FORCE_PG=1: a one-rank group, to exercise the RCCL calls)
     if "MASTER_ADDR" not in os.environ:
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1")
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29577"), RANK="0", WORLD_SIZE="1")
     dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
 ctx = _lib.Context(local)
 X = powerlaw_csr(U, I, dens, seed=123).to_scipy()
