@@ -247,6 +247,49 @@ def topk_rows(scores: sp.csr_matrix, K: int, exclude: sp.csr_matrix | None = Non
 
 
 # --------------------------------------------------------------------------------------
+# reference-SHAPED restatements: the same third-party calls in the same order as the reference makes them (the
+# vectorised functions above give the same sets faster; these are what bench.py's cpu_baseline times as "reference
+# shaped", and tests/test_oracle_golden.py checks them against the same goldens)
+# --------------------------------------------------------------------------------------
+def topk_per_row_loop(Xs: sp.csr_matrix, K: int) -> sp.csr_matrix:
+    """recpack/util.py:50-96 (get_top_K_ranks + get_top_K_values): a Python loop over the rows, np.argpartition with
+    the full list of the last K positions on every row's data, the K stored values kept.  Tie order is numpy's."""
+    Xs = sp.csr_matrix(Xs)
+    rows, cols, vals = [], [], []
+    for r, (le, ri) in enumerate(zip(Xs.indptr[:-1], Xs.indptr[1:])):
+        k = min(K, ri - le)
+        if k:
+            pick = le + np.argpartition(Xs.data[le:ri], list(range(-k, 0)))[-k:]
+            rows.append(np.full(k, r, dtype=np.int64))
+            cols.append(Xs.indices[pick])
+            vals.append(Xs.data[pick])
+    if not rows:
+        return sp.csr_matrix(Xs.shape, dtype=np.float64)
+    return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=Xs.shape)
+
+
+def itemknn_fit_reference_shaped(X: sp.csr_matrix, K: int, rows=None) -> sp.csr_matrix:
+    """nearest_neighbour.py:69-84 + :204-224: sklearn's cosine_similarity(X.T, dense_output=False), the diagonal
+    zeroed, then the per-row argpartition loop.  `rows` restricts the left operand to a sample of item rows (the
+    bench's bounded sample); the result has one row per sampled item."""
+    from sklearn.metrics.pairwise import cosine_similarity
+
+    Xt = sp.csr_matrix(binarize(X).T, dtype=np.float64)
+    left = Xt if rows is None else Xt[np.asarray(rows)]
+    S = sp.csr_matrix(cosine_similarity(left, Xt, dense_output=False))
+    row_ids = np.arange(Xt.shape[0]) if rows is None else np.asarray(rows)
+    own = np.repeat(row_ids, np.diff(S.indptr))
+    S.data[S.indices == own] = 0.0  # setdiag(0) (kept as an explicit zero, as scipy does)
+    return topk_per_row_loop(S, K)
+
+
+def predict_topk_reference_shaped(X: sp.csr_matrix, S: sp.csr_matrix, Kp: int) -> sp.csr_matrix:
+    """base.py:248 (X @ similarity_matrix_) followed by the metrics' per-row top-K loop (metrics/base.py:189 ->
+    util.py:50-77)."""
+    return topk_per_row_loop(sp.csr_matrix(binarize(X).astype(np.float64) @ S), Kp)
+
+
+# --------------------------------------------------------------------------------------
 # EASE
 # --------------------------------------------------------------------------------------
 def ease_fit(X: sp.csr_matrix, l2: float, alpha: float = 0.0) -> np.ndarray:

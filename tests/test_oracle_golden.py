@@ -207,3 +207,45 @@ def test_ease_xy_matches_reference(name):
         assert np.abs(B - ref).max() <= 1e-10 * np.abs(ref).max()
         out = onp.predict_full(X[:50], sp.csr_matrix(B)).toarray()
         assert np.abs(out - g[f"Pout{n}"]).max() <= 1e-9 * max(1e-300, np.abs(g[f"Pout{n}"]).max())
+
+
+@pytest.mark.parametrize("name", ["ref_itemknn_data", "ref_itemknn_larger_matrix", "syn_itemknn_2000x500"])
+def test_reference_shaped_fit_matches_reference(name):
+    """The restatement bench.py times as "reference shaped" (sklearn cosine + per-row argpartition loop) against the
+    same goldens, tie-aware (its tie order is numpy's, like the reference's)."""
+    g = load_golden(name)
+    X = csr_from(g, "X")
+    cand = csr_from(g, "cos")
+    K = int(g["Ks"][-1])
+    ref = csr_from(g, f"S{K}")
+    S = onp.itemknn_fit_reference_shaped(X, K)
+    S.eliminate_zeros()
+    S.sort_indices()
+    n = np.diff(S.indptr)
+    idx = np.full((S.shape[0], max(1, n.max())), -1, np.int64)
+    for r in range(S.shape[0]):
+        idx[r, : n[r]] = S.indices[S.indptr[r]: S.indptr[r + 1]]
+    bad, _ = tie_aware_topk(cand, ref, idx, n, eps=1e-9)
+    assert not bad, (name, bad[:5])
+    rows = np.array([0, X.shape[1] // 2, X.shape[1] - 1])
+    sub = onp.itemknn_fit_reference_shaped(X, K, rows=rows)
+    sub.eliminate_zeros()
+    assert abs(sub - S[rows]).max() == 0
+
+
+def test_reference_shaped_predict_topk():
+    g = load_golden("syn_itemknn_2000x500")
+    X = csr_from(g, "X")
+    out = onp.itemknn_fit(X, 50)
+    S = onp.topk_to_csr(out["idx"], out["val"], out["nnz"], X.shape[1])
+    scores = onp.predict_full(X[:300], S)
+    got = onp.predict_topk_reference_shaped(X[:300], S, 20)
+    got.sort_indices()
+    ridx, rval, rnnz = onp.topk_rows(scores, 20)
+    n = np.diff(got.indptr)
+    assert (n == rnnz).all()
+    idx = np.full((300, 20), -1, np.int64)
+    for r in range(300):
+        idx[r, : n[r]] = got.indices[got.indptr[r]: got.indptr[r + 1]]
+    bad, _ = tie_aware_topk(scores, onp.topk_to_csr(ridx, rval, rnnz, X.shape[1]), idx, n, eps=1e-12)
+    assert not bad
