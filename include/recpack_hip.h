@@ -82,6 +82,24 @@ int rphip_device_count(int* n_out);
 int rphip_ctx_create(int device, void* stream, rphip_ctx** out);
 int rphip_ctx_destroy(rphip_ctx* ctx);
 int rphip_ctx_sync(rphip_ctx* ctx);
+
+/* Device blocks of destroyed models / matrices are kept by the context (up to "cache_limit_bytes", default 48 GiB) and
+ * handed out again for a request of the same size, so a fit repeated in a loop allocates nothing after its first pass.
+ * rphip_ctx_trim releases them to the driver (e.g. before another library allocates most of the HBM). */
+int rphip_ctx_trim(rphip_ctx* ctx);
+
+/* Options of a context (name, integer value):
+ *   "predict_exact64"   0 (default) | 1.  The fused predict + top-Kp of neighbour-list models (rphip_predict_topk*) sums
+ *                       scores as integers.  Default: 32-bit sums with one power-of-two scale PER USER - a score is off by at
+ *                       most d_u * M_u * 2^-30 (d_u = history length, M_u = the user's score bound, the sum of his history
+ *                       lists' largest |similarity|), i.e. the size of the f32 rounding of the similarities and of the f32
+ *                       output.  1: 64-bit sums with one scale per call - exact sums (the reference's X @ S, base.py:248, in
+ *                       float64 differs from either only by the f32 storage of S).  Valued prediction matrices
+ *                       (rphip_csr_set_values) always use the 64-bit sums.  Both are independent of the order of the adds:
+ *                       predict is bit-reproducible run to run.
+ *   "predict_tile32"    2048 | 4096 (default): column tile of the 32-bit sums (tuning).
+ *   "cache_limit_bytes" see rphip_ctx_trim. */
+int rphip_ctx_set_option(rphip_ctx* ctx, const char* name, int64_t value);
 int rphip_get_timings(rphip_ctx* ctx, rphip_timings* out);
 int rphip_reset_timings(rphip_ctx* ctx);
 /* counters of the last rphip_itemknn_fit (int64[8]): [0] scalar products done by the light-row kernel,

@@ -97,6 +97,8 @@ PROTOTYPES = {
     "rphip_model_dense_prune": (C.c_int, [_p, _p, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
     "rphip_model_from_dense_host": (C.c_int, [_p, _i64, _p, _pp]),
     "rphip_model_empty_rows": (C.c_int, [_p, _p, C.POINTER(_i64)]),
+    "rphip_ctx_trim": (C.c_int, [_p]),
+    "rphip_ctx_set_option": (C.c_int, [_p, C.c_char_p, _i64]),
     "rphip_gemm_nt_f32": (C.c_int, [_p, _i64, _i64, _i64, C.c_float, _p, _i64, _p, _i64, C.c_float, _p, _i64]),
     "rphip_ease_xy_fit": (C.c_int, [_p, _p, _p, _f64, _f64, _pp]),
     "rphip_ease_gram_create": (C.c_int, [_p, _p, _pp]),
@@ -188,6 +190,14 @@ class Context:
             self.handle = None
 
     __del__ = close
+
+    def trim(self):
+        """Release the context's cached device blocks (rphip_ctx_trim)."""
+        check(self.lib.rphip_ctx_trim(self.handle))
+
+    def set_option(self, name: str, value: int):
+        """rphip_ctx_set_option: "predict_exact64" (0/1), "predict_tile32" (2048/4096), "cache_limit_bytes"."""
+        check(self.lib.rphip_ctx_set_option(self.handle, name.encode(), int(value)))
 
     def sync(self):
         check(self.lib.rphip_ctx_sync(self.handle))

@@ -3,6 +3,8 @@
 
 #include <string.h>
 
+#include <algorithm>
+
 static thread_local char g_err[1024] = "";
 
 void rp_set_error(const char* fmt, ...) {
@@ -75,6 +77,7 @@ extern "C" int rphip_ctx_destroy(rphip_ctx* ctx) {
     hipEventDestroy(p.a);
     hipEventDestroy(p.b);
   }
+  rp_dev_trim(ctx);
   for (auto e : ctx->ev_pool) hipEventDestroy(e);
   for (auto& b : ctx->scratch)
     if (b.p) hipFree(b.p);
@@ -116,6 +119,104 @@ int rp_scratch(rphip_ctx* ctx, int slot, size_t bytes, void** out) {
     b.cap = cap;
   }
   *out = b.p;
+  return RPHIP_OK;
+}
+
+// ---- block cache -------------------------------------------------------------------------------------
+// A freed block carries an event recorded on the context's stream at the time of the free: whoever gets the block
+// next waits for it first, so kernels that were still reading the block when its owner was destroyed are done
+// (hipFree would have synchronised the device; the cache must not be weaker than that for host-side copies).
+void rp_dev_trim(rphip_ctx* ctx) {
+  for (auto& b : ctx->free_blocks) {
+    hipFree(b.p);
+    if (b.freed) hipEventDestroy(b.freed);
+  }
+  ctx->free_blocks.clear();
+  ctx->cached_bytes = 0;
+}
+
+int rp_dev_alloc(rphip_ctx* ctx, size_t bytes, void** out) {
+  *out = nullptr;
+  const size_t want = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+  for (size_t i = 0; i < ctx->free_blocks.size(); ++i) {
+    if (ctx->free_blocks[i].bytes == want) {
+      rphip_ctx::block_t b = ctx->free_blocks[i];
+      ctx->free_blocks.erase(ctx->free_blocks.begin() + i);
+      ctx->cached_bytes -= want;
+      if (b.freed) {
+        hipEventSynchronize(b.freed);
+        hipEventDestroy(b.freed);
+      }
+      ctx->live_blocks[b.p] = want;
+      *out = b.p;
+      return RPHIP_OK;
+    }
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess && !ctx->free_blocks.empty()) {  // give the cache back and try again
+    (void)hipGetLastError();
+    rp_dev_trim(ctx);
+    e = hipMalloc(&p, want);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    RP_FAIL(RPHIP_ENOMEM, "hipMalloc of %zu bytes failed: %s", want, hipGetErrorString(e));
+  }
+  ctx->live_blocks[p] = want;
+  *out = p;
+  return RPHIP_OK;
+}
+
+void rp_dev_free(rphip_ctx* ctx, void* p) {
+  if (!p) return;
+  auto it = ctx ? ctx->live_blocks.find(p) : decltype(ctx->live_blocks.find(p))();
+  if (!ctx || it == ctx->live_blocks.end()) {
+    hipFree(p);
+    return;
+  }
+  const size_t bytes = it->second;
+  ctx->live_blocks.erase(it);
+  if (ctx->cached_bytes + bytes > ctx->cache_limit) {
+    hipFree(p);
+    return;
+  }
+  rphip_ctx::block_t b{p, bytes, nullptr};
+  if (hipEventCreateWithFlags(&b.freed, hipEventDisableTiming) == hipSuccess) {
+    hipEventRecord(b.freed, ctx->stream);
+  } else {
+    b.freed = nullptr;
+    hipStreamSynchronize(ctx->stream);
+  }
+  ctx->free_blocks.push_back(b);
+  ctx->cached_bytes += bytes;
+}
+
+extern "C" int rphip_ctx_trim(rphip_ctx* ctx) {
+  if (!ctx) RP_FAIL(RPHIP_EINVAL, "ctx is NULL");
+  RP_TRY(rp_set_device(ctx));
+  RP_HIP(hipStreamSynchronize(ctx->stream));
+  rp_dev_trim(ctx);
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_ctx_set_option(rphip_ctx* ctx, const char* name, int64_t value) {
+  if (!ctx || !name) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if (!strcmp(name, "predict_exact64")) {
+    ctx->predict_exact64 = value ? 1 : 0;
+  } else if (!strcmp(name, "predict_tile32")) {
+    if (value != 2048 && value != 4096) RP_FAIL(RPHIP_EINVAL, "predict_tile32 must be 2048 or 4096");
+    ctx->pw_wt32 = (int)value;
+  } else if (!strcmp(name, "cache_limit_bytes")) {
+    if (value < 0) RP_FAIL(RPHIP_EINVAL, "cache_limit_bytes must be >= 0");
+    ctx->cache_limit = (size_t)value;
+    if (ctx->cached_bytes > ctx->cache_limit) {
+      RP_HIP(hipStreamSynchronize(ctx->stream));
+      rp_dev_trim(ctx);
+    }
+  } else {
+    RP_FAIL(RPHIP_EINVAL, "unknown option '%s'", name);
+  }
   return RPHIP_OK;
 }
 

@@ -7,6 +7,7 @@
 #include <stdarg.h>
 
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/recpack_hip.h"
@@ -64,6 +65,16 @@ struct rphip_ctx {
   struct pending_t { hipEvent_t a, b; int slot; };
   std::vector<pending_t> pending;
   std::vector<hipEvent_t> ev_pool;
+  // device allocations of models / matrices: freed blocks are kept (up to cache_limit bytes) and handed out again for a
+  // request of the same size - a fit in a loop allocates nothing after its first pass (rp_dev_alloc / rp_dev_free)
+  struct block_t { void* p; size_t bytes; hipEvent_t freed; };
+  std::vector<block_t> free_blocks;
+  std::unordered_map<void*, size_t> live_blocks;
+  size_t cached_bytes = 0;
+  size_t cache_limit = (size_t)48 << 30;
+  // predict options (rphip_ctx_set_option)
+  int predict_exact64 = 0;   // 1: the wave predict kernel sums in 64 bits (exact) instead of the per-user-scaled 32 bits
+  int pw_wt32 = 4096;        // tile width of the 32-bit sums: 2048 or 4096 (tuning)
 };
 
 struct rphip_csr {
@@ -104,6 +115,8 @@ struct rphip_model {
   float* val32 = nullptr;   // [rows*K] (predict operand)
   int2* pairs = nullptr;    // [rows*K] {column, float bits}: what the wave-per-user predict kernel streams
   uint16_t* toff = nullptr; // [n_items * (n_wt + 1)] per-row offsets of the predict column tiles (built on first use)
+  int toff_wt = 0;          // tile width toff was built for
+  float* rowmax = nullptr;  // [n_items] largest |similarity| of each list (built with toff)
   int32_t* nnz = nullptr;   // [rows]
   bool cols_sorted = false; // every row's columns strictly increasing (checked when the model is finalised)
   float vmax_abs = 0.0f;    // largest |similarity| (f32): with the longest history it bounds |score|
@@ -117,6 +130,9 @@ struct rphip_model {
 
 // ---- helpers (rp_api.hip) ------------------------------------------------------------------------
 int rp_scratch(rphip_ctx* ctx, int slot, size_t bytes, void** out);
+int rp_dev_alloc(rphip_ctx* ctx, size_t bytes, void** out);  // hipMalloc through the context's block cache
+void rp_dev_free(rphip_ctx* ctx, void* p);                   // NULL is fine; blocks not from rp_dev_alloc go to hipFree
+void rp_dev_trim(rphip_ctx* ctx);                            // release every cached block
 void rp_time_begin(rphip_ctx* ctx, hipEvent_t* a);
 void rp_time_end(rphip_ctx* ctx, hipEvent_t a, int slot, double work);
 int rp_resolve_timings(rphip_ctx* ctx);

@@ -126,10 +126,10 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
   const int64_t U = m->n_users, I = m->n_items, nnz = m->nnz;
   m->n_tiles = (int)std::max<int64_t>(1, rp_cdiv(I, RP_TILE_MAX));
   m->tile_w = (int)(rp_cdiv(rp_cdiv(std::max<int64_t>(I, 1), m->n_tiles), 64) * 64);
-  RP_HIP(hipMalloc((void**)&m->xt_ptr, (size_t)(I + 1) * sizeof(int32_t)));
-  RP_HIP(hipMalloc((void**)&m->xt_idx, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t)));
-  RP_HIP(hipMalloc((void**)&m->deg, (size_t)std::max<int64_t>(I, 1) * sizeof(int32_t)));
-  RP_HIP(hipMalloc((void**)&m->inv_deg, (size_t)std::max<int64_t>(I, 1) * sizeof(double)));
+  RP_TRY(rp_dev_alloc(ctx, (size_t)(I + 1) * sizeof(int32_t), (void**)&m->xt_ptr));
+  RP_TRY(rp_dev_alloc(ctx, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t), (void**)&m->xt_idx));
+  RP_TRY(rp_dev_alloc(ctx, (size_t)std::max<int64_t>(I, 1) * sizeof(int32_t), (void**)&m->deg));
+  RP_TRY(rp_dev_alloc(ctx, (size_t)std::max<int64_t>(I, 1) * sizeof(double), (void**)&m->inv_deg));
   char* sc = nullptr;
   const size_t rank_bytes = ((size_t)std::max<int64_t>(nnz, 1) * 4 + 15) & ~(size_t)15;  // keeps p_sum 8-B aligned
   RP_TRY(rp_scratch(ctx, 0, rank_bytes + 64, (void**)&sc));
@@ -160,7 +160,7 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
                        (int)I, range_w, m->deg, rank, err);
   }
   RP_TRY(rp_exclusive_scan_i32(ctx, m->deg, m->xt_ptr, I));
-  if (m->n_tiles > 1) RP_HIP(hipMalloc((void**)&m->tile_ptr, (size_t)U * (m->n_tiles + 1) * sizeof(int32_t)));
+  if (m->n_tiles > 1) RP_TRY(rp_dev_alloc(ctx, (size_t)std::max<int64_t>(U, 1) * (m->n_tiles + 1) * sizeof(int32_t), (void**)&m->tile_ptr));
   if (U > 0) {  // (rows without entries still need their tile pointers)
     const int grid_s = (int)std::min<int64_t>((int64_t)ctx->n_cu * 16, std::max<int64_t>(1, rp_cdiv(U * 8, bt)));
     hipLaunchKernelGGL(k_scatter, dim3(grid_s), dim3(bt), 0, st, m->x_ptr, m->x_idx, (int)U, m->xt_ptr, rank, m->xt_idx, p_sum,
@@ -283,21 +283,18 @@ extern "C" int rphip_csr_from_device_rows(rphip_ctx* ctx, int64_t n_users, int64
 
 extern "C" int rphip_csr_destroy(rphip_csr* m) {
   if (!m) return RPHIP_OK;
-  if (m->ctx) {
-    hipSetDevice(m->ctx->device);
-    hipStreamSynchronize(m->ctx->stream);
-  }
-  if (m->owns_x) {
+  if (m->ctx) hipSetDevice(m->ctx->device);
+  if (m->owns_x) {  // (hipFree waits for the device; cached blocks carry an event instead)
     if (m->x_ptr) hipFree((void*)m->x_ptr);
     if (m->x_idx) hipFree((void*)m->x_idx);
   }
-  if (m->xt_ptr) hipFree(m->xt_ptr);
-  if (m->xt_idx) hipFree(m->xt_idx);
-  if (m->deg) hipFree(m->deg);
-  if (m->inv_deg) hipFree(m->inv_deg);
-  if (m->tile_ptr) hipFree(m->tile_ptr);
-  if (m->row_cost) hipFree(m->row_cost);
-  if (m->x_val) hipFree(m->x_val);
+  rp_dev_free(m->ctx, m->xt_ptr);
+  rp_dev_free(m->ctx, m->xt_idx);
+  rp_dev_free(m->ctx, m->deg);
+  rp_dev_free(m->ctx, m->inv_deg);
+  rp_dev_free(m->ctx, m->tile_ptr);
+  rp_dev_free(m->ctx, m->row_cost);
+  rp_dev_free(m->ctx, m->x_val);
   delete m;
   return RPHIP_OK;
 }
@@ -308,10 +305,8 @@ extern "C" int rphip_csr_set_values(rphip_ctx* ctx, rphip_csr* m, const double* 
   if (!ctx || !m) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   RP_TRY(rp_set_device(ctx));
   RP_HIP(hipStreamSynchronize(ctx->stream));
-  if (m->x_val) {
-    hipFree(m->x_val);
-    m->x_val = nullptr;
-  }
+  rp_dev_free(ctx, m->x_val);
+  m->x_val = nullptr;
   m->val_max_abs = 0.0;
   m->val_neg = false;
   if (!values_host) return RPHIP_OK;
@@ -324,10 +319,7 @@ extern "C" int rphip_csr_set_values(rphip_ctx* ctx, rphip_csr* m, const double* 
     neg |= v < 0.0;
   }
   const size_t bytes = (size_t)std::max<int64_t>(1, m->nnz) * sizeof(double);
-  if (hipMalloc((void**)&m->x_val, bytes) != hipSuccess) {
-    m->x_val = nullptr;
-    RP_FAIL(RPHIP_ENOMEM, "hipMalloc of %zu bytes for the values failed", bytes);
-  }
+  RP_TRY(rp_dev_alloc(ctx, bytes, (void**)&m->x_val));
   if (m->nnz > 0) RP_HIP(hipMemcpyAsync(m->x_val, values_host, (size_t)m->nnz * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   RP_HIP(hipStreamSynchronize(ctx->stream));
   m->val_max_abs = mx;

@@ -27,6 +27,7 @@ static int rp_dense_count_empty(rphip_ctx* ctx, rphip_model* m);
 constexpr int GT = 128;   // tile (and diagonal block) size
 constexpr int GBK = 16;   // K step
 constexpr int GLD = 20;   // LDS row stride in floats (16 + 4 pad: conflict-free ds_read_b128 over 16 rows)
+constexpr int GKC = 256;  // K steps between two flushes of the MFMA accumulators into the compensated master sums
 
 struct rp_gemm_args {
   const float* A;
@@ -49,9 +50,26 @@ struct rp_gemm_args {
   int k_chunk;
 };
 
-__global__ void __launch_bounds__(256) k_gemm_nt(rp_gemm_args g) {
+// Accumulation.  The MFMA adds into its fp32 accumulator in K order: over a K of 10^5 that alone loses ~ sqrt(K) eps, and
+// the Cholesky / inverse / product chain of EASE multiplies it by the condition of G + lambda I - measured against
+// host-certified float64 columns the plain kernel was 6e-4 off at 100 000 items (tests/ease_cg.py), six times the 1e-4 bar.
+// So every GKC = 256 steps of K the accumulators are emptied into MASTER sums held as an unevaluated pair hi + lo
+// (Knuth's two-sum: the rounding error of hi + acc is computed exactly and added to lo).  hi lives in registers; lo only
+// needs a few bits (|lo| <= ulp(hi)), so it is kept as bf16 in LDS, two per word (32 KB per workgroup: two workgroups per
+// CU still fit, and the 64 extra registers of an fp32 lo would have cost the second wave per SIMD).  The error of a sum
+// is then that of its 256-step pieces, whatever K is.  The epilogue forms beta*C + alpha*hi with ONE rounding (fma) and adds
+// alpha*lo, so the cancellation of C - L L^T happens before anything is rounded to fp32.
+__device__ __forceinline__ uint32_t rp_pack_bf16_rn(float a, float b) {  // round to nearest even; finite inputs
+  uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+  ua = (ua + 0x7fffu + ((ua >> 16) & 1u)) >> 16;
+  ub = (ub + 0x7fffu + ((ub >> 16) & 1u)) & 0xffff0000u;
+  return ua | ub;
+}
+
+__global__ void __launch_bounds__(256, 2) k_gemm_nt(rp_gemm_args g) {
   __shared__ __attribute__((aligned(16))) float As[2][GT * GLD];
   __shared__ __attribute__((aligned(16))) float Bs[2][GT * GLD];
+  __shared__ uint32_t Lo[32 * 256];  // [word][thread]: bf16 pairs of the 64 compensation terms of each thread
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   // Tiles in plain row-major order: with the clipped K ranges of the triangular factors the top tile rows carry the
@@ -71,13 +89,42 @@ __global__ void __launch_bounds__(256) k_gemm_nt(rp_gemm_args g) {
   if (g.ke_n) ke = min(ke, g.n_off + n0 + GT);
   kb &= ~(GBK - 1);
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][2], hi[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = hi[i][j][r] = 0.0f;
+  bool have_lo = false;  // Lo holds this tile's compensation terms (uniform over the workgroup)
+  // acc -> (hi, lo); `first`: there is no lo yet (nothing to read)
+  auto flush = [&](bool first) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const int w = ((i * 2 + j) * 16 + r) >> 1;
+          float l0 = 0.0f, l1 = 0.0f;
+          if (!first) {
+            const uint32_t pk = Lo[w * 256 + tid];
+            l0 = __uint_as_float(pk << 16);
+            l1 = __uint_as_float(pk & 0xffff0000u);
+          }
+          const float a0 = acc[i][j][r], a1 = acc[i][j][r + 1];
+          const float h0 = hi[i][j][r], h1 = hi[i][j][r + 1];
+          const float s0 = h0 + a0, s1 = h1 + a1;
+          const float b0 = s0 - h0, b1 = s1 - h1;
+          l0 += (h0 - (s0 - b0)) + (a0 - b0);
+          l1 += (h1 - (s1 - b1)) + (a1 - b1);
+          hi[i][j][r] = s0;
+          hi[i][j][r + 1] = s1;
+          acc[i][j][r] = 0.0f;
+          acc[i][j][r + 1] = 0.0f;
+          Lo[w * 256 + tid] = rp_pack_bf16_rn(l0, l1);
+        }
+  };
 
   if (kb < ke) {
     const int lr = tid >> 2, lk = (tid & 3) * 4;
@@ -102,6 +149,7 @@ __global__ void __launch_bounds__(256) k_gemm_nt(rp_gemm_args g) {
     const int arow = (wr * 64 + (lane & 31)) * GLD + (lane >> 5) * 4;
     const int brow = (wc * 64 + (lane & 31)) * GLD + (lane >> 5) * 4;
     int cur = 0;
+    int since = 0;  // K steps in acc since the last flush
     for (int k = kb; k < ke; k += GBK) {
       const bool more = (k + GBK) < ke;
       if (more) gload(k + GBK);
@@ -123,6 +171,12 @@ __global__ void __launch_bounds__(256) k_gemm_nt(rp_gemm_args g) {
         }
       }
       if (more) lstore(cur ^ 1);
+      since += GBK;
+      if (since == GKC && more) {  // (the last piece is flushed by the epilogue)
+        flush(!have_lo);
+        have_lo = true;
+        since = 0;
+      }
       __syncthreads();
       cur ^= 1;
     }
@@ -136,13 +190,23 @@ __global__ void __launch_bounds__(256) k_gemm_nt(rp_gemm_args g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        // the sum as hi + lo: the last piece still sits in acc
+        float h = acc[i][j][r], l = 0.0f;
+        if (have_lo) {
+          const int w = ((i * 2 + j) * 16 + r) >> 1;
+          const uint32_t pk = Lo[w * 256 + tid];
+          l = (r & 1) ? __uint_as_float(pk & 0xffff0000u) : __uint_as_float(pk << 16);
+          const float a = h, hh = hi[i][j][r];
+          const float s = hh + a, b = s - hh;
+          l += (hh - (s - b)) + (a - b);
+          h = s;
+        }
         if (g.part) {
-          g.part[((long long)blockIdx.z * g.M + row) * g.N + col] = acc[i][j][r];
+          g.part[((long long)blockIdx.z * g.M + row) * g.N + col] = h + l;
         } else {
           float* cp = g.C + (long long)row * g.ldc + col;
-          float v = g.alpha * acc[i][j][r];
-          if (g.beta != 0.0f) v += g.beta * (*cp);
-          *cp = v;
+          float v = (g.beta != 0.0f) ? fmaf(g.alpha, h, g.beta * (*cp)) : g.alpha * h;
+          *cp = fmaf(g.alpha, l, v);
         }
       }
     }
@@ -155,24 +219,28 @@ __global__ void k_splitk_reduce(const float* __restrict__ part, int S, int M, in
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const long long row = (e * 4) / N;
     const int col = (int)((e * 4) % N);
-    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;  // float64: one rounding for the whole sum and the update of C
     for (int s2 = 0; s2 < S; ++s2) {
       const float4 v = *reinterpret_cast<const float4*>(part + ((long long)s2 * M + row) * N + col);
-      sum.x += v.x;
-      sum.y += v.y;
-      sum.z += v.z;
-      sum.w += v.w;
+      sx += v.x;
+      sy += v.y;
+      sz += v.z;
+      sw += v.w;
     }
     float4* cp = reinterpret_cast<float4*>(C + row * ldc + col);
-    float4 o = make_float4(alpha * sum.x, alpha * sum.y, alpha * sum.z, alpha * sum.w);
+    const double al = alpha, be = beta;
+    sx *= al;
+    sy *= al;
+    sz *= al;
+    sw *= al;
     if (beta != 0.0f) {
       const float4 c = *cp;
-      o.x += beta * c.x;
-      o.y += beta * c.y;
-      o.z += beta * c.z;
-      o.w += beta * c.w;
+      sx += be * c.x;
+      sy += be * c.y;
+      sz += be * c.z;
+      sw += be * c.w;
     }
-    *cp = o;
+    *cp = make_float4((float)sx, (float)sy, (float)sz, (float)sw);
   }
 }
 
@@ -812,7 +880,7 @@ extern "C" int rphip_ease_xy_fit(rphip_ctx* ctx, const rphip_csr* X, const rphip
     rphip_model_destroy(m);
     return rc;
   };
-  if (hipMalloc((void**)&m->B, bytes) != hipSuccess || hipMalloc((void**)&Pm, bytes) != hipSuccess ||
+  if (rp_dev_alloc(ctx, bytes, (void**)&m->B) != RPHIP_OK || hipMalloc((void**)&Pm, bytes) != hipSuccess ||
       hipMalloc((void**)&Gyx, bytes) != hipSuccess) {
     rp_set_error("hipMalloc of the dense matrices failed");
     return fail(RPHIP_ENOMEM);
@@ -867,6 +935,18 @@ static int rp_ease_alloc(rphip_ctx* ctx, int n, int n_mats, rphip_model** mo, fl
   const size_t bytes = (size_t)n_pad * ld * sizeof(float);
   size_t free_b = 0, total_b = 0;
   hipMemGetInfo(&free_b, &total_b);
+  // cached blocks count as available: a block of exactly this size is reused, anything else is released first
+  if (n_mats * bytes + (1ull << 30) > free_b && ctx->cached_bytes > 0) {
+    bool has = false;
+    for (auto& b : ctx->free_blocks) has |= b.bytes == ((bytes + 255) & ~(size_t)255);
+    if (!has || n_mats > 1) {
+      hipStreamSynchronize(ctx->stream);
+      rp_dev_trim(ctx);
+      hipMemGetInfo(&free_b, &total_b);
+    } else {
+      free_b += bytes;
+    }
+  }
   if (n_mats * bytes + (1ull << 30) > free_b)
     RP_FAIL(RPHIP_ENOMEM, "EASE with %d items needs %.1f GB of HBM (%d %d x %d f32 matrices), %.1f GB free", n, n_mats * bytes / 1e9, n_mats,
             n_pad, n_pad, free_b / 1e9);
@@ -879,7 +959,7 @@ static int rp_ease_alloc(rphip_ctx* ctx, int n, int n_mats, rphip_model** mo, fl
   m->K = 0;
   m->ld = ld;
   *Nb = nullptr;
-  if (hipMalloc((void**)&m->B, bytes) != hipSuccess || (n_mats > 1 && hipMalloc((void**)Nb, bytes) != hipSuccess)) {
+  if (rp_dev_alloc(ctx, bytes, (void**)&m->B) != RPHIP_OK || (n_mats > 1 && hipMalloc((void**)Nb, bytes) != hipSuccess)) {
     if (*Nb) hipFree(*Nb);
     *Nb = nullptr;
     rphip_model_destroy(m);
@@ -1144,7 +1224,7 @@ extern "C" int rphip_model_from_dense_host(rphip_ctx* ctx, int64_t n_items, cons
   m->n_items = n_items;
   m->row_end = n_items;
   m->ld = rp_cdiv(n_items, 4) * 4;
-  if (hipMalloc((void**)&m->B, (size_t)n_items * m->ld * sizeof(float)) != hipSuccess) {
+  if (rp_dev_alloc(ctx, (size_t)n_items * m->ld * sizeof(float), (void**)&m->B) != RPHIP_OK) {
     rphip_model_destroy(m);
     RP_FAIL(RPHIP_ENOMEM, "hipMalloc of the dense matrix failed");
   }

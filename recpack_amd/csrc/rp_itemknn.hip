@@ -749,12 +749,12 @@ int rp_model_alloc_topk(rphip_ctx* ctx, int64_t n_items, int64_t r0, int64_t r1,
   m->row_end = r1;
   m->K = K;
   const size_t n = (size_t)std::max<int64_t>(1, (r1 - r0) * (int64_t)K);
-  hipError_t e1 = hipMalloc((void**)&m->idx, n * sizeof(int32_t));
-  hipError_t e2 = hipMalloc((void**)&m->val, n * sizeof(double));
-  hipError_t e3 = hipMalloc((void**)&m->val32, n * sizeof(float));
-  if (e3 == hipSuccess) e3 = hipMalloc((void**)&m->pairs, (n + 8) * sizeof(int2));  // +8: aligned 4-entry chunk loads may overrun
-  hipError_t e4 = hipMalloc((void**)&m->nnz, (size_t)std::max<int64_t>(1, r1 - r0) * sizeof(int32_t));
-  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+  const int e1 = rp_dev_alloc(ctx, n * sizeof(int32_t), (void**)&m->idx);
+  const int e2 = rp_dev_alloc(ctx, n * sizeof(double), (void**)&m->val);
+  int e3 = rp_dev_alloc(ctx, n * sizeof(float), (void**)&m->val32);
+  if (e3 == RPHIP_OK) e3 = rp_dev_alloc(ctx, (n + 8) * sizeof(int2), (void**)&m->pairs);  // +8: aligned 4-entry chunk loads may overrun
+  const int e4 = rp_dev_alloc(ctx, (size_t)std::max<int64_t>(1, r1 - r0) * sizeof(int32_t), (void**)&m->nnz);
+  if (e1 != RPHIP_OK || e2 != RPHIP_OK || e3 != RPHIP_OK || e4 != RPHIP_OK) {
     rphip_model_destroy(m);
     RP_FAIL(RPHIP_ENOMEM, "hipMalloc of the neighbour lists failed (%lld rows x K=%d)", (long long)(r1 - r0), K);
   }
@@ -765,13 +765,14 @@ int rp_model_alloc_topk(rphip_ctx* ctx, int64_t n_items, int64_t r0, int64_t r1,
 extern "C" int rphip_model_destroy(rphip_model* m) {
   if (!m) return RPHIP_OK;
   if (m->ctx) hipSetDevice(m->ctx->device);
-  if (m->idx) hipFree(m->idx);
-  if (m->val) hipFree(m->val);
-  if (m->val32) hipFree(m->val32);
-  if (m->pairs) hipFree(m->pairs);
-  if (m->toff) hipFree(m->toff);
-  if (m->nnz) hipFree(m->nnz);
-  if (m->B && !m->borrows_B) hipFree(m->B);
+  rp_dev_free(m->ctx, m->idx);
+  rp_dev_free(m->ctx, m->val);
+  rp_dev_free(m->ctx, m->val32);
+  rp_dev_free(m->ctx, m->pairs);
+  rp_dev_free(m->ctx, m->toff);
+  rp_dev_free(m->ctx, m->rowmax);
+  rp_dev_free(m->ctx, m->nnz);
+  if (!m->borrows_B) rp_dev_free(m->ctx, m->B);
   delete m;
   return RPHIP_OK;
 }

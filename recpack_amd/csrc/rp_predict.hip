@@ -347,7 +347,17 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_merge(const int32_t
 //     each lane walks the set bits of its word, reads and clears the sums and offers them to the wave's running
 //     top-Kp pool (rp_wave.h: exact radix-select cuts; admission is exact for any arrival order);
 //   * at the end the pool is cut to Kp, ranked by column and written out (score = (float)(sum * 2^-shift)).
-constexpr int PW_WT = 2048;
+//
+// Two flavours of the sums (template parameter AccT), both integer, both independent of the order of the adds:
+//   uint64_t  one scale per call (rp_fix_shift): exact - the f32 storage of the similarities is the only rounding.  2048-column
+//             tiles (16 KB of LDS per wave).  Valued prediction matrices (WGT) and RPHIP_PREDICT_EXACT64 run here.
+//   uint32_t  one scale PER USER: with M_u = sum over the history of the list's largest |similarity| (rowmax, an upper bound of
+//             any |score| of that user) and 2^(e-1) <= M_u (1 + 2^-12) < 2^e the terms are rint(s_ij * 2^(30-e)).  No sum can
+//             leave 31 bits (|sum| <= M_u 2^(30-e) + d_u / 2 < 2^30 + 2^29); a score is off by at most d_u * 2^(e-31)
+//             <= d_u * M_u * 2^-30 - for a 64-item history 6e-8 of the user's score BOUND, the size of the f32 rounding of the
+//             similarities themselves and of the f32 output value.  Half the LDS per column buys 4096-column tiles at the
+//             same occupancy: half the (user, tile) pairs, whose fixed cost is what the kernel spends its time on.
+constexpr int PW_WT = 2048;     // columns per tile per dirty word of a lane (a tile is PW_WT * DW columns)
 constexpr int PW_CH = 4;        // entries per chunk (32 bytes)
 constexpr int PW_UCH = 4;       // users per ticket
 constexpr int PW_KP_MAX = 384;  // pool capacity = Kp rounded up + 128 <= 512
@@ -357,13 +367,18 @@ __host__ __device__ constexpr int rp_pw_cap(int Kp) {
   const int base = ((Kp + 63) / 64) * 64;
   return base + 96;
 }
-__host__ __device__ constexpr size_t rp_pw_wave_bytes(int Kp) { return (size_t)PW_WT * 8 + 256 + (size_t)rp_pw_cap(Kp) * 12 + 1024 + 128; }
+__host__ __device__ constexpr size_t rp_pw_wave_bytes(int Kp, int acc_bytes, int wt) {
+  return (size_t)wt * acc_bytes + 256 * (wt / PW_WT) + (size_t)rp_pw_cap(Kp) * (acc_bytes + 4) + 1024 + 128;
+}
+template <typename T>
+__device__ __forceinline__ constexpr T rp_pw_flip() { return (T)1 << (8 * sizeof(T) - 1); }  // two's complement sum -> ordered key
 
 struct rp_pw_params {
   const int32_t* x_ptr;
   const int32_t* x_idx;
   const int2* pairs;
   const uint16_t* toff;  // [I * (n_wt + 1)]
+  const float* rowmax;   // [I] largest |similarity| of each neighbour list (the per-user scale of the 32-bit sums)
   const uint8_t* keep;   // optional item filter: only items with keep[j] != 0 are candidates
   const double* x_val;   // optional values of the prediction matrix's entries (WGT instances)
   int n_items, n_wt, K, Kp, exclude_history, user_begin, n_users;
@@ -382,13 +397,16 @@ struct rp_pw_params {
 
 typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
+template <typename AccT>
 struct rp_pw_state {
-  RP_LDS unsigned long long* acc;
+  RP_LDS AccT* acc;
   RP_LDS uint32_t* dirty;
-  rp_wpool<uint64_t> pool;
+  rp_wpool<AccT> pool;
   const int* pairs_i;
   int lane, cap;
-  rp_fix_scale fix;
+  rp_fix_scale fix;  // 64-bit sums: the call's scale
+  float fmul;        // 32-bit sums: 2^ushift, this user's scale
+  int ushift;
 #ifdef RP_STAMPS
   unsigned long long t_last, t_ph[8];
 #endif
@@ -399,36 +417,38 @@ struct rp_pw_state {
 #define PW_COUNT(ph, n) do { S.t_ph[ph] += (n); } while (0)
 #endif
 
-template <bool WGT>
-__device__ __forceinline__ void rp_pw_add_chunk(rp_pw_state& S, int n, const v4i_a4& a, const v4i_a4& b, int t0, double xw) {
+template <typename AccT, bool WGT>
+__device__ __forceinline__ void rp_pw_add_chunk(rp_pw_state<AccT>& S, int n, const v4i_a4& a, const v4i_a4& b, int t0, double xw) {
   const int ec[4] = {a.x, a.z, b.x, b.z};
   const int ev[4] = {a.y, a.w, b.y, b.w};
   // Straight-line code, no per-entry branch: an entry past the chunk's end adds 0 to a dummy word of the lane's own
   // (the idle upper half of the pool histogram) and ORs 0 into the lane's dirty word.  With a branch per entry the
   // compiler computed each entry's operands into the registers of the previous one behind an s_waitcnt lgkmcnt(0),
   // i.e. one full LDS round trip per entry; now the eight atomics of a step go out back to back.
-  RP_LDS unsigned long long* dummy = reinterpret_cast<RP_LDS unsigned long long*>(S.pool.hist + 128) + S.lane;
+  RP_LDS AccT* dummy = reinterpret_cast<RP_LDS AccT*>(S.pool.hist + 128) + S.lane;
 #pragma unroll
   for (int e = 0; e < PW_CH; ++e) {
     const bool on = e < n;
     const int j = ec[e] - t0;
-    RP_LDS unsigned long long* tgt = on ? &S.acc[j] : dummy;
-    unsigned long long v = 0ull;
-    if (WGT)  // the owner's value times the similarity, in float64
+    RP_LDS AccT* tgt = on ? &S.acc[j] : dummy;
+    AccT v = 0;
+    if constexpr (sizeof(AccT) == 4)  // this user's scale: rint(s * 2^ushift), exact integer adds from here on
+      v = on ? (AccT)__float2int_rn(__int_as_float(ev[e]) * S.fmul) : (AccT)0;
+    else if (WGT)  // the owner's value times the similarity, in float64
       v = on ? rp_f64_to_fix((double)__int_as_float(ev[e]) * xw, S.fix) : 0ull;
     else
       v = on ? rp_f32_to_fix(ev[e], S.fix) : 0ull;
-    RP_LDS uint32_t* dw = &S.dirty[on ? (j & 63) : S.lane];
+    RP_LDS uint32_t* dw = &S.dirty[on ? ((j & 63) + 64 * (j >> 11)) : S.lane];  // word (j mod 64) of the tile's (j / 2048)-th map
     const uint32_t bit = on ? (1u << ((j >> 6) & 31)) : 0u;
-    atomicAdd((unsigned long long*)tgt, v);
+    atomicAdd((AccT*)tgt, v);
     atomicOr((uint32_t*)dw, bit);
   }
 }
 
 // chunk c of a batch whose lanes hold (start, length, first chunk) of their slices: owner lane by binary search
 // over the exclusive chunk offsets, then the chunk's two 16-byte loads
-template <bool WGT>
-__device__ __forceinline__ int rp_pw_fetch_chunk(const rp_pw_state& S, int c, int n_chunks, int s, int len, int choff, v4i_a4* a,
+template <typename AccT, bool WGT>
+__device__ __forceinline__ int rp_pw_fetch_chunk(const rp_pw_state<AccT>& S, int c, int n_chunks, int s, int len, int choff, v4i_a4* a,
                                                  v4i_a4* b, double wt, double* wo) {
   int lo = 0;
 #pragma unroll
@@ -451,8 +471,8 @@ __device__ __forceinline__ int rp_pw_fetch_chunk(const rp_pw_state& S, int c, in
 // The first 64 chunks of a batch (chunk = lane): every slice owner writes its lane id at its first chunk's slot of a
 // 64-word LDS scratch, a running maximum over the lanes (DPP) turns that into the owner of every chunk - two LDS
 // round trips where the binary search takes six.
-template <bool WGT>
-__device__ __forceinline__ int rp_pw_fetch_first(const rp_pw_state& S, int n_chunks, int nch, int s, int len, int choff, v4i_a4* a,
+template <typename AccT, bool WGT>
+__device__ __forceinline__ int rp_pw_fetch_first(const rp_pw_state<AccT>& S, int n_chunks, int nch, int s, int len, int choff, v4i_a4* a,
                                                  v4i_a4* b, double wt, double* wo) {
   RP_LDS uint32_t* sc = S.pool.hist;  // idle while a tile's entries are fetched and added
   const int lane = S.lane;
@@ -478,37 +498,42 @@ __device__ __forceinline__ int rp_pw_fetch_first(const rp_pw_state& S, int n_chu
 // the prefetched entries of the next tile in the middle of the current one.  As calls they cost nothing unless taken.
 //
 // Further chunk steps of one pipelined batch (more than 64 chunks of the batch fall into the tile).
-template <bool WGT>
-__device__ __attribute__((noinline)) void rp_pw_extra_steps(RP_LDS unsigned long long* acc, RP_LDS uint32_t* dirty, const int* pairs_i,
-                                                            rp_fix_scale fix, int lane, int s, int len, int choff, int nchunks, int t0,
-                                                            double wt) {
-  rp_pw_state S;
+template <typename AccT, bool WGT>
+__device__ __attribute__((noinline)) void rp_pw_extra_steps(RP_LDS AccT* acc, RP_LDS uint32_t* dirty, RP_LDS uint32_t* hist,
+                                                            const int* pairs_i, rp_fix_scale fix, float fmul, int lane, int s, int len,
+                                                            int choff, int nchunks, int t0, double wt) {
+  rp_pw_state<AccT> S;
   S.acc = acc;
   S.dirty = dirty;
+  S.pool.hist = hist;
   S.pairs_i = pairs_i;
   S.fix = fix;
+  S.fmul = fmul;
   S.lane = lane;
   for (int c0 = 64; c0 < nchunks; c0 += 64) {
     v4i_a4 a = (v4i_a4){0, 0, 0, 0}, b2 = a;
     double xw = 1.0;
-    const int n = rp_pw_fetch_chunk<WGT>(S, c0 + lane, nchunks, s, len, choff, &a, &b2, wt, &xw);
-    rp_pw_add_chunk<WGT>(S, n, a, b2, t0, xw);
+    const int n = rp_pw_fetch_chunk<AccT, WGT>(S, c0 + lane, nchunks, s, len, choff, &a, &b2, wt, &xw);
+    rp_pw_add_chunk<AccT, WGT>(S, n, a, b2, t0, xw);
   }
 }
 
 // History batches beyond the pipelined ones (items [h_from, he)): offsets and entries fetched on the spot.
 // Returns whether anything was added.
-template <bool WGT>
-__device__ __attribute__((noinline)) bool rp_pw_slow_batches(RP_LDS unsigned long long* acc, RP_LDS uint32_t* dirty, const int* pairs_i,
-                                                             rp_fix_scale fix, int lane, const int32_t* x_idx, const double* x_val,
-                                                             const uint16_t* toff, int K, int NT, int t, int h_from, int he) {
-  rp_pw_state S;
+template <typename AccT, int WT, bool WGT>
+__device__ __attribute__((noinline)) bool rp_pw_slow_batches(RP_LDS AccT* acc, RP_LDS uint32_t* dirty, RP_LDS uint32_t* hist,
+                                                             const int* pairs_i, rp_fix_scale fix, float fmul, int lane,
+                                                             const int32_t* x_idx, const double* x_val, const uint16_t* toff, int K, int NT,
+                                                             int t, int h_from, int he) {
+  rp_pw_state<AccT> S;
   S.acc = acc;
   S.dirty = dirty;
+  S.pool.hist = hist;
   S.pairs_i = pairs_i;
   S.fix = fix;
+  S.fmul = fmul;
   S.lane = lane;
-  const int t0 = t * PW_WT;
+  const int t0 = t * WT;
   bool touched = false;
   for (int hb = h_from; hb < he; hb += 64) {
     const int h = hb + lane;
@@ -530,19 +555,19 @@ __device__ __attribute__((noinline)) bool rp_pw_slow_batches(RP_LDS unsigned lon
     for (int c0 = 0; c0 < n_chunks; c0 += 64) {
       v4i_a4 a = (v4i_a4){0, 0, 0, 0}, b2 = a;
       double xw = 1.0;
-      const int n = rp_pw_fetch_chunk<WGT>(S, c0 + lane, n_chunks, s, len, choff, &a, &b2, wt, &xw);
-      rp_pw_add_chunk<WGT>(S, n, a, b2, t0, xw);
+      const int n = rp_pw_fetch_chunk<AccT, WGT>(S, c0 + lane, n_chunks, s, len, choff, &a, &b2, wt, &xw);
+      rp_pw_add_chunk<AccT, WGT>(S, n, a, b2, t0, xw);
     }
   }
   return touched;
 }
 
 // history removal for the items of those batches
-__device__ __attribute__((noinline)) void rp_pw_slow_exclude(RP_LDS unsigned long long* acc, int lane, const int32_t* x_idx, int t0,
-                                                             int h_from, int he) {
+template <typename AccT, int WT>
+__device__ __attribute__((noinline)) void rp_pw_slow_exclude(RP_LDS AccT* acc, int lane, const int32_t* x_idx, int t0, int h_from, int he) {
   for (int h = h_from + lane; h < he; h += 64) {
     const int j = x_idx[h] - t0;
-    if ((unsigned)j < (unsigned)PW_WT) acc[j] = 0ull;
+    if ((unsigned)j < (unsigned)WT) acc[j] = 0;
   }
 }
 
@@ -568,8 +593,10 @@ struct rp_pw_set {
   double w[NB];  // WGT: the value of the history item the lane's first chunk belongs to
 };
 
-template <int NB, bool WGT>
-__device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_state& S, int ul, int hs, int he) {
+template <int NB, typename AccT, int WT, bool WGT>
+__device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_state<AccT>& S, int ul, int hs, int he) {
+  constexpr int DW = WT / PW_WT;
+  constexpr AccT FLIP = rp_pw_flip<AccT>();
   const int lane = S.lane, K = P.K, Kp = P.Kp, NT = P.n_wt, cap = S.cap;
   const int nb = min(NB, (he - hs + 63) >> 6);
   int it[NB], o_a[NB], o_b[NB], o_c[NB];
@@ -586,7 +613,7 @@ __device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_st
     const int inc = rp_wave_incl_scan(nch, lane);
     D.choff[b] = inc - nch;
     D.nchunks[b] = __builtin_amdgcn_readlane(inc, 63);
-    D.n[b] = rp_pw_fetch_first<WGT>(S, D.nchunks[b], nch, D.s[b], D.len[b], D.choff[b], &D.a[b], &D.b[b], wt[b], &D.w[b]);
+    D.n[b] = rp_pw_fetch_first<AccT, WGT>(S, D.nchunks[b], nch, D.s[b], D.len[b], D.choff[b], &D.a[b], &D.b[b], wt[b], &D.w[b]);
   };
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -619,7 +646,7 @@ __device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_st
 
   // one tile: C = the set prepared for it, N = the set to prepare for tile t+1
   auto tile = [&](int t, rp_pw_set<NB>& C, rp_pw_set<NB>& N) __attribute__((always_inline)) {
-    const int t0 = t * PW_WT;
+    const int t0 = t * WT;
     bool touched = false;
 #pragma unroll
     for (int b = 0; b < NB; ++b) touched |= C.nchunks[b] > 0;
@@ -636,54 +663,59 @@ __device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_st
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (b < nb) {
-        rp_pw_add_chunk<WGT>(S, C.n[b], C.a[b], C.b[b], t0, C.w[b]);  // the prefetched first step, then (rarely) further steps
+        rp_pw_add_chunk<AccT, WGT>(S, C.n[b], C.a[b], C.b[b], t0, C.w[b]);  // the prefetched first step, then (rarely) further steps
         if (C.nchunks[b] > 64)
-          rp_pw_extra_steps<WGT>(S.acc, S.dirty, S.pairs_i, S.fix, lane, C.s[b], C.len[b], C.choff[b], C.nchunks[b], t0, wt[b]);
+          rp_pw_extra_steps<AccT, WGT>(S.acc, S.dirty, S.pool.hist, S.pairs_i, S.fix, S.fmul, lane, C.s[b], C.len[b], C.choff[b],
+                                       C.nchunks[b], t0, wt[b]);
       }
     }
     // ---- histories longer than 64*NB items: the remaining batches, not pipelined
     if (hs + 64 * NB < he)
-      touched |= rp_pw_slow_batches<WGT>(S.acc, S.dirty, S.pairs_i, S.fix, lane, P.x_idx, P.x_val, P.toff, K, NT, t, hs + 64 * NB, he);
+      touched |= rp_pw_slow_batches<AccT, WT, WGT>(S.acc, S.dirty, S.pool.hist, S.pairs_i, S.fix, S.fmul, lane, P.x_idx, P.x_val, P.toff, K,
+                                                   NT, t, hs + 64 * NB, he);
     PW_STAMP(1);
     if (!touched) return;
     if (P.exclude_history) {  // the dirty bit stays: a zero sum is skipped below
 #pragma unroll
       for (int b = 0; b < NB; ++b) {  // item ids of the pipelined batches are in registers: no load to wait for here
         const int j = it[b] - t0;
-        if (b < nb && (unsigned)j < (unsigned)PW_WT) S.acc[j] = 0ull;
+        if (b < nb && (unsigned)j < (unsigned)WT) S.acc[j] = 0;
       }
-      if (hs + 64 * NB < he) rp_pw_slow_exclude(S.acc, lane, P.x_idx, t0, hs + 64 * NB, he);
+      if (hs + 64 * NB < he) rp_pw_slow_exclude<AccT, WT>(S.acc, lane, P.x_idx, t0, hs + 64 * NB, he);
     }
     RP_WAVE_FENCE();
     // ---- offer the touched columns to the pool: lane l walks the set bits of dirty word l
     // (word l covers columns l, l+64, ..: the lanes' reads of one round fall into different LDS banks), four set bits
     // per lane and round so that the sums of a round are read with one wait
-    uint32_t w = S.dirty[lane];
-    S.dirty[lane] = 0u;
     PW_STAMP(5);
+#pragma unroll 1
+    for (int dwi = 0; dwi < DW; ++dwi) {
+    uint32_t w = S.dirty[lane + 64 * dwi];
+    S.dirty[lane + 64 * dwi] = 0u;
+    const int jb = lane + PW_WT * dwi;  // column of bit 0 of this word
     while (__any(w != 0u)) {
       bool has[4];
       int j[4];
-      unsigned long long v[4];
+      AccT v[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         has[q] = w != 0u;
-        j[q] = lane + 64 * (has[q] ? (__ffs((int)w) - 1) : 0);
+        j[q] = jb + 64 * (has[q] ? (__ffs((int)w) - 1) : 0);
         w &= w - 1u;  // 0 stays 0
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = has[q] ? S.acc[j[q]] : 0ull;
+      for (int q = 0; q < 4; ++q) v[q] = has[q] ? S.acc[j[q]] : (AccT)0;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        if (has[q]) S.acc[j[q]] = 0ull;
+        if (has[q]) S.acc[j[q]] = 0;
       // most sums lose against the pool's threshold once it is warm: the slots of the round are voted on first and only
       // slots with a surviving lane are pushed (rolled loop: one inlined copy of the pool cut; values rotate through 0)
       bool kq[4];
       uint32_t live = 0;  // bit q: some lane keeps its slot q
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        v[q] ^= RP_KEY_FLIP;  // signed sum -> unsigned order; a zero sum is no candidate
-        kq[q] = has[q] && v[q] != RP_KEY_FLIP && rp_wpool_admits<uint64_t, 0>(S.pool, v[q], (uint32_t)(t0 + j[q]));
+        v[q] ^= FLIP;  // signed sum -> unsigned order; a zero sum is no candidate
+        kq[q] = has[q] && v[q] != FLIP && rp_wpool_admits<AccT, 0>(S.pool, v[q], (uint32_t)(t0 + j[q]));
       }
       if (P.keep) {  // item filter: only sums that would enter the pool pay the lookup
         const uint32_t want = (kq[0] ? 1u : 0u) | (kq[1] ? 2u : 0u) | (kq[2] ? 4u : 0u) | (kq[3] ? 8u : 0u);
@@ -702,11 +734,11 @@ __device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_st
         if (live & 1u) {
           const uint32_t col = (uint32_t)(t0 + j[0]);
           // the threshold may have moved since the vote (a cut inside an earlier push): ask again
-          const bool keep = kq[0] && rp_wpool_admits<uint64_t, 0>(S.pool, v[0], col);
+          const bool keep = kq[0] && rp_wpool_admits<AccT, 0>(S.pool, v[0], col);
 #ifdef RP_STAMPS
           const int n_before = S.pool.n;
 #endif
-          rp_wpool_push<uint64_t, 0>(S.pool, Kp, cap, keep, v[0], col, lane);
+          rp_wpool_push<AccT, 0>(S.pool, Kp, cap, keep, v[0], col, lane);
 #ifdef RP_STAMPS
           if (S.pool.n < n_before) PW_COUNT(6, 1);  // a cut happened
 #endif
@@ -720,6 +752,7 @@ __device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_st
       }
       PW_STAMP(7);
     }
+    }
     PW_STAMP(2);
   };
   for (int t = 0; t < NT; t += 2) {
@@ -728,25 +761,43 @@ __device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_st
   }
 }
 
-template <bool WGT>
+// sum of a non-negative float over the wave (DPP row shifts + row broadcasts), returned in every lane
+#define RP_DPP_F32(x, ctrl, rmask) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), (ctrl), (rmask), 0xf, false))
+__device__ __forceinline__ float rp_wave_sum_f32(float v) {
+  v += RP_DPP_F32(v, RP_DPP_ROW_SHR(1), 0xf);
+  v += RP_DPP_F32(v, RP_DPP_ROW_SHR(2), 0xf);
+  v += RP_DPP_F32(v, RP_DPP_ROW_SHR(4), 0xf);
+  v += RP_DPP_F32(v, RP_DPP_ROW_SHR(8), 0xf);
+  v += RP_DPP_F32(v, RP_DPP_ROW_BCAST15, 0xa);
+  v += RP_DPP_F32(v, RP_DPP_ROW_BCAST31, 0xc);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+template <typename AccT, int WT, bool WGT>
 __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
+  static_assert(sizeof(AccT) == 8 || !WGT, "valued prediction matrices use the 64-bit sums");
+  constexpr int DW = WT / PW_WT;
+  constexpr AccT FLIP = rp_pw_flip<AccT>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
   const int Kp = P.Kp;
-  rp_pw_state S;
+  rp_pw_state<AccT> S;
   S.lane = lane;
   S.cap = rp_pw_cap(Kp);
   S.fix = P.fix;
-  S.acc = (RP_LDS unsigned long long*)smem;
-  S.dirty = (RP_LDS uint32_t*)(smem + (size_t)PW_WT * 8);
-  S.pool.key = (RP_LDS uint64_t*)(smem + (size_t)PW_WT * 8 + 256);
+  S.fmul = 1.0f;
+  S.ushift = P.fix.shift;
+  S.acc = (RP_LDS AccT*)smem;
+  S.dirty = (RP_LDS uint32_t*)(smem + (size_t)WT * sizeof(AccT));
+  S.pool.key = (RP_LDS AccT*)(smem + (size_t)WT * sizeof(AccT) + 256 * DW);
   S.pool.pay = (RP_LDS uint32_t*)(S.pool.key + S.cap);
   S.pool.hist = S.pool.pay + S.cap;
   S.pool.gidx = (RP_LDS uint16_t*)(S.pool.hist + 256);
   S.pairs_i = reinterpret_cast<const int*>(P.pairs);
 
-  for (int i = lane; i < PW_WT; i += 64) S.acc[i] = 0ull;
-  S.dirty[lane] = 0u;
+  for (int i = lane; i < WT; i += 64) S.acc[i] = 0;
+#pragma unroll
+  for (int d = 0; d < DW; ++d) S.dirty[lane + 64 * d] = 0u;
 #ifdef RP_STAMPS
   S.t_last = __builtin_amdgcn_s_memtime();
   for (int _p = 0; _p < 8; ++_p) S.t_ph[_p] = 0;
@@ -762,22 +813,33 @@ __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
       const int u = P.user_begin + ul;
       const int hs = P.x_ptr[u], he = P.x_ptr[u + 1];
       if (he <= hs) continue;
+      if constexpr (sizeof(AccT) == 4) {
+        // this user's scale: M_u = sum of the history lists' largest |similarity| bounds every |score|;
+        // 2^ushift * M_u (1 + 2^-12) < 2^30 (the margin covers the f32 rounding of the sum itself)
+        float m = 0.0f;
+        for (int h = hs + lane; h < he; h += 64) m += P.rowmax[P.x_idx[h]];
+        m = rp_wave_sum_f32(m) * 1.000244140625f;
+        if (!(m > 0.0f)) continue;  // every list empty: no score
+        const int e = (int)((__float_as_uint(m) >> 23) & 255u) - 126;  // m < 2^e (m is normal: similarities are f32)
+        S.ushift = max(-96, min(96, 30 - e));
+        S.fmul = __uint_as_float((uint32_t)(S.ushift + 127) << 23);
+      }
       S.pool.n = 0;
       S.pool.tau = 0;
       S.pool.tau_col = 0;
       PW_STAMP(0);
       const int nbu = (he - hs + 63) >> 6;
       if (nbu <= 1)
-        rp_pw_user_tiles<1, WGT>(P, S, ul, hs, he);
+        rp_pw_user_tiles<1, AccT, WT, WGT>(P, S, ul, hs, he);
       else if (nbu <= 2)
-        rp_pw_user_tiles<2, WGT>(P, S, ul, hs, he);
+        rp_pw_user_tiles<2, AccT, WT, WGT>(P, S, ul, hs, he);
       else
-        rp_pw_user_tiles<4, WGT>(P, S, ul, hs, he);
+        rp_pw_user_tiles<4, AccT, WT, WGT>(P, S, ul, hs, he);
       // ---- final: best Kp by (score desc, column asc), then column order for the output row
       RP_WAVE_FENCE();
-      if (S.pool.n > Kp) rp_wpool_cut<uint64_t, 0>(S.pool, Kp, lane);
+      if (S.pool.n > Kp) rp_wpool_cut<AccT, 0>(S.pool, Kp, lane);
       const int n_out = S.pool.n;
-      RP_LDS uint64_t* pk = S.pool.key;
+      RP_LDS AccT* pk = S.pool.key;
       RP_LDS uint32_t* pp = S.pool.pay;
       if (lane < 4) pp[n_out + lane] = 0xffffffffu;  // pads the last group of four (n_out + 4 <= cap)
       typedef uint32_t v4u __attribute__((ext_vector_type(4)));
@@ -789,7 +851,10 @@ __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
           rank += (q.x < col ? 1 : 0) + (q.y < col ? 1 : 0) + (q.z < col ? 1 : 0) + (q.w < col ? 1 : 0);
         }
         P.out_idx[(int64_t)ul * Kp + rank] = (int)col;
-        P.out_val[(int64_t)ul * Kp + rank] = (float)rp_fix_to_f64(pk[e] ^ RP_KEY_FLIP, S.fix.shift);
+        if constexpr (sizeof(AccT) == 4)
+          P.out_val[(int64_t)ul * Kp + rank] = (float)ldexp((double)(int32_t)(pk[e] ^ FLIP), -S.ushift);
+        else
+          P.out_val[(int64_t)ul * Kp + rank] = (float)rp_fix_to_f64(pk[e] ^ FLIP, S.fix.shift);
       }
       if (lane == 0) P.out_nnz[ul] = n_out;
       RP_WAVE_FENCE();
@@ -804,20 +869,25 @@ __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
   }
 }
 
-// toff[i][t] = number of entries of neighbour list i with column < t*PW_WT (lists are column-sorted)
-__global__ void k_build_toff(const int32_t* __restrict__ idx, const int32_t* __restrict__ nnz, int K, int n_items, int n_wt,
-                             uint16_t* __restrict__ toff) {
+// toff[i][t] = number of entries of neighbour list i with column < t*wt (lists are column-sorted); rowmax[i] = the list's
+// largest |similarity| (f32)
+__global__ void k_build_toff(const int32_t* __restrict__ idx, const float* __restrict__ val32, const int32_t* __restrict__ nnz, int K,
+                             int n_items, int n_wt, int wt, uint16_t* __restrict__ toff, float* __restrict__ rowmax) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += gridDim.x * blockDim.x) {
     uint16_t* o = toff + (long long)i * (n_wt + 1);
     const int32_t* row = idx + (long long)i * K;
+    const float* rv = val32 + (long long)i * K;
     const int n = nnz[i];
     int t = 0;
+    float mx = 0.0f;
     o[0] = 0;
     for (int k = 0; k < n; ++k) {
-      const int tj = row[k] / PW_WT;
+      const int tj = row[k] / wt;
       while (t < tj) o[++t] = (uint16_t)k;
+      mx = fmaxf(mx, fabsf(rv[k]));
     }
     while (t < n_wt) o[++t] = (uint16_t)n;
+    rowmax[i] = mx;
   }
 }
 
@@ -958,11 +1028,24 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
   rp_time_begin(ctx, &ev);
   if (use_wave) {
     rphip_model* mm = const_cast<rphip_model*>(model);  // lazily built, cached acceleration structure
-    const int n_wt = (int)rp_cdiv(model->n_items, PW_WT);
-    if (!mm->toff) {
-      RP_HIP(hipMalloc((void**)&mm->toff, (size_t)model->n_items * (n_wt + 1) * sizeof(uint16_t)));
+    // 32-bit per-user-scaled sums on 4096-column tiles unless the caller asked for the exact 64-bit sums or the prediction
+    // matrix carries values (their products are formed in float64)
+    const bool x32 = !Xpred->x_val && ctx->predict_exact64 == 0;
+    const int wt = x32 ? ctx->pw_wt32 : PW_WT;
+    const int n_wt = (int)rp_cdiv(model->n_items, wt);
+    if (!mm->toff || mm->toff_wt != wt) {
+      if (mm->toff) {
+        RP_HIP(hipStreamSynchronize(st));
+        rp_dev_free(ctx, mm->toff);
+        rp_dev_free(ctx, mm->rowmax);
+        mm->toff = nullptr;
+        mm->rowmax = nullptr;
+      }
+      RP_TRY(rp_dev_alloc(ctx, (size_t)model->n_items * (n_wt + 1) * sizeof(uint16_t), (void**)&mm->toff));
+      RP_TRY(rp_dev_alloc(ctx, (size_t)model->n_items * sizeof(float), (void**)&mm->rowmax));
+      mm->toff_wt = wt;
       hipLaunchKernelGGL(k_build_toff, dim3((unsigned)std::min<int64_t>(4096, rp_cdiv(model->n_items, 256))), dim3(256), 0, st, model->idx,
-                         model->nnz, model->K, (int)model->n_items, n_wt, mm->toff);
+                         model->val32, model->nnz, model->K, (int)model->n_items, n_wt, wt, mm->toff, mm->rowmax);
     }
     int32_t* tk = nullptr;
     RP_TRY(rp_scratch(ctx, 4, 64, (void**)&tk));
@@ -972,6 +1055,7 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
     W.x_idx = Xpred->x_idx;
     W.pairs = model->pairs;
     W.toff = mm->toff;
+    W.rowmax = mm->rowmax;
     W.keep = keep_dev;
     W.n_items = (int)Xpred->n_items;
     W.n_wt = n_wt;
@@ -994,16 +1078,22 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
       hipMemsetAsync(sp, 0, 64 * 8, st);
     }
 #endif
-    const size_t wl = rp_pw_wave_bytes(Kp);
+    const size_t wl = rp_pw_wave_bytes(Kp, x32 ? 4 : 8, wt);
     W.x_val = Xpred->x_val;
-    RP_HIP(hipFuncSetAttribute((const void*)k_predict_wave<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl));
-    RP_HIP(hipFuncSetAttribute((const void*)k_predict_wave<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl));
     const int wpc = std::max<int>(1, std::min<int>(16, (int)((160 * 1024) / wl)));
     const int wg = (int)std::min<int64_t>(rp_cdiv(n, PW_UCH), (int64_t)ctx->n_cu * wpc);
+    auto launch = [&](auto kern) {
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
+      hipLaunchKernelGGL(kern, dim3(wg), dim3(64), wl, st, W);
+    };
     if (W.x_val)
-      hipLaunchKernelGGL(k_predict_wave<true>, dim3(wg), dim3(64), wl, st, W);
+      launch(k_predict_wave<uint64_t, PW_WT, true>);
+    else if (!x32)
+      launch(k_predict_wave<uint64_t, PW_WT, false>);
+    else if (wt == 2 * PW_WT)
+      launch(k_predict_wave<uint32_t, 2 * PW_WT, false>);
     else
-      hipLaunchKernelGGL(k_predict_wave<false>, dim3(wg), dim3(64), wl, st, W);
+      launch(k_predict_wave<uint32_t, PW_WT, false>);
     RP_HIP(hipGetLastError());
 #ifdef RP_STAMPS
     {

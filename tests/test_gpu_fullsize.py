@@ -88,7 +88,7 @@ def itemknn_full(hip, cfg, n_rows, n_users, K=200, Kp=100):
     assert (pv[live] > 0).all()
     users = np.sort(rng.choice(U, size=n_users, replace=False))
     scores = onp.predict_full(X[users], S)
-    check_topk_scores(scores, pi[users], pv[users], pn[users], Kp, exclude=X[users])
+    check_topk_scores(scores, pi[users], pv[users], pn[users], Kp, exclude=X[users], hist=X[users], S=S)
     # checksum of checksums on a user range: sum_j score[u, j] = sum_{i in hist(u)} sum_j S[i, j]
     u0, u1 = 1000, 3000
     ip_, ind_, dat_ = _lib.predict_full(ctx, m, dX, u0, u1)

@@ -102,9 +102,9 @@ def test_predict_fuzz_against_oracle(seed, n_cases):
             keep = rng.random(I) < 0.6
             for excl in (False, True):
                 pi, pv, pn = _lib.predict_topk(ctx, model, dX, Kp, exclude_history=excl)
-                check_topk_scores(scores, pi, pv, pn, Kp, exclude=X if excl else None)
+                check_topk_scores(scores, pi, pv, pn, Kp, exclude=X if excl else None, hist=X if Kp <= 384 else None, S=S)
                 pi, pv, pn = _lib.predict_topk(ctx, model, dX, Kp, exclude_history=excl, item_keep=keep)
-                check_topk_scores(onp.pipeline_scores(scores, item_keep=keep), pi, pv, pn, Kp, exclude=X if excl else None)
+                check_topk_scores(onp.pipeline_scores(scores, item_keep=keep), pi, pv, pn, Kp, exclude=X if excl else None, hist=X if Kp <= 384 else None, S=S)
         else:
             assert abs(out - scores).max() <= 1e-6 * max(1e-300, abs(scores).max()), what
             pi, pv, pn = _lib.predict_topk(ctx, model, dX, Kp)

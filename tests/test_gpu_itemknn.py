@@ -178,15 +178,21 @@ def test_fit_edge_cases(hip):
 
 
 # ---------------------------------------------------------------------------------------------------
-def check_topk_scores(scores_ref: sp.csr_matrix, idx, val, nnz, Kp, exclude=None, eps=1e-6):
-    """Tie-aware check of a fused top-Kp against float64 oracle scores (f32 similarities, exact sums => eps 1e-6)."""
+def check_topk_scores(scores_ref: sp.csr_matrix, idx, val, nnz, Kp, exclude=None, eps=1e-6, hist=None, S=None):
+    """Tie-aware check of a fused top-Kp against float64 oracle scores.  With exact 64-bit sums (hist is None) the only
+    rounding is the f32 storage of the similarities: eps 1e-6, values rtol 2e-7.  With the default 32-bit per-user-scaled
+    sums pass the histories `hist` and the model `S`: every score then carries the stated absolute bound
+    (parity.fx32_bound), which widens the tie band by twice that and the value tolerance by once."""
+    from parity import fx32_bound
+
     ridx, rval, rnnz = onp.topk_rows(scores_ref, Kp, exclude=exclude)
     cand = scores_ref
     if exclude is not None:
         cand = scores_ref - scores_ref.multiply(onp.binarize(exclude))
         cand.eliminate_zeros()
     ref_sel = onp.topk_to_csr(ridx, rval, rnnz, scores_ref.shape[1])
-    bad, exact = tie_aware_topk(sp.csr_matrix(cand), ref_sel, idx, nnz, eps=eps)
+    bound = fx32_bound(hist, S) if hist is not None else None
+    bad, exact = tie_aware_topk(sp.csr_matrix(cand), ref_sel, idx, nnz, eps=eps, abs_tol=None if bound is None else 2.0 * bound)
     assert not bad, bad[:5]
     lut = sp.csr_matrix(cand)
     for r in range(0, idx.shape[0], max(1, idx.shape[0] // 200)):
@@ -194,7 +200,7 @@ def check_topk_scores(scores_ref: sp.csr_matrix, idx, val, nnz, Kp, exclude=None
         assert (np.diff(idx[r, :n]) > 0).all()
         got = val[r, :n]
         want = np.asarray(lut[r, idx[r, :n]].todense()).ravel()
-        np.testing.assert_allclose(got, want, rtol=PRED_RTOL)
+        np.testing.assert_allclose(got, want, rtol=PRED_RTOL, atol=0.0 if bound is None else float(bound[r]))
     return exact
 
 
@@ -248,13 +254,13 @@ def test_predict_topk_vs_oracle(hip, shape, K, Kp, seed):
     # fused top-Kp, with and without history removal
     for excl in (False, True):
         pi, pv, pn = _lib.predict_topk(ctx, m, dX, Kp, exclude_history=excl, user_begin=0, user_end=1200)
-        check_topk_scores(scores, pi, pv, pn, Kp, exclude=X[users] if excl else None)
+        check_topk_scores(scores, pi, pv, pn, Kp, exclude=X[users] if excl else None, hist=X[users], S=S)
     # item filter (ExcludeItems / SelectItems fused into the kernel), with and without history removal
     keep = np.random.default_rng(seed).random(X.shape[1]) < 0.7
     for excl in (False, True):
         pi, pv, pn = _lib.predict_topk(ctx, m, dX, Kp, exclude_history=excl, user_begin=0, user_end=1200, item_keep=keep)
         assert keep[pi[pi >= 0]].all()
-        check_topk_scores(onp.pipeline_scores(scores, item_keep=keep), pi, pv, pn, Kp, exclude=X[users] if excl else None)
+        check_topk_scores(onp.pipeline_scores(scores, item_keep=keep), pi, pv, pn, Kp, exclude=X[users] if excl else None, hist=X[users], S=S)
     # a user range in the middle equals the same rows of the full call
     pi2, pv2, pn2 = _lib.predict_topk(ctx, m, dX, Kp, user_begin=100, user_end=300)
     pi, pv, pn = _lib.predict_topk(ctx, m, dX, Kp, user_begin=0, user_end=1200)
@@ -262,12 +268,17 @@ def test_predict_topk_vs_oracle(hip, shape, K, Kp, seed):
     np.testing.assert_array_equal(pn2, pn[100:300])
 
 
+@pytest.mark.parametrize("exact64", [True, False])
 @pytest.mark.parametrize("scale,signed", [(1.0, False), (3000.0, True), (1e-6, True)])
-def test_predict_signed_models_and_reproducibility(hip, scale, signed):
+def test_predict_signed_models_and_reproducibility(hip, scale, signed, exact64):
     """Neighbour-list models with any sign and magnitude (e.g. a pruned EASE matrix loaded with from_topk_host):
-    the fixed-point scale follows the model's largest |value| and the longest history; results are bit-identical
-    from run to run (integer sums do not depend on the order of the adds)."""
+    the fixed-point scale follows the model's largest |value| and the longest history (64-bit sums: exact) or the user's
+    own score bound (32-bit sums, the default: within parity.fx32_bound); either way results are bit-identical from run
+    to run (integer sums do not depend on the order of the adds)."""
+    from parity import fx32_bound
+
     _lib, ctx = hip
+    ctx.set_option("predict_exact64", 1 if exact64 else 0)
     rng = np.random.default_rng(5)
     I, K, U, Kp = 5000, 30, 700, 25
     idx = np.full((I, K), -1, np.int32)
@@ -299,6 +310,7 @@ def test_predict_signed_models_and_reproducibility(hip, scale, signed):
     assert np.abs(dense_out - dense_ref).max() <= 1e-12 * max(1.0, mag.max())  # the full result is exact to f64 rounding
     assert (np.abs(dense_out - dense_ref) <= 1e-13 * mag + 1e-300).all()
     runs = []
+    tol = 1e-12 * mag.max(axis=1) if exact64 else 2.0 * fx32_bound(X, S) + 1e-12 * mag.max(axis=1)
     for excl in (False, True, False, True):
         pi, pv, pn = _lib.predict_topk(ctx, model, dX, Kp, exclude_history=excl)
         runs.append((pi, pv, pn))
@@ -315,10 +327,11 @@ def test_predict_signed_models_and_reproducibility(hip, scale, signed):
             t = cand[r, order[-1]]
             got = pi[r, :n]
             assert (np.diff(got) > 0).all()
-            must = nz[cand[r, nz] > t + 1e-12 * mag[r].max()]
+            must = nz[cand[r, nz] > t + tol[r]]
             assert np.isin(must, got).all()
-            assert (cand[r, got] >= t - 1e-12 * mag[r].max()).all()
-            np.testing.assert_allclose(pv[r, :n], cand[r, got], rtol=2e-7, atol=1e-7 * mag[r].max() * 0 + 0)
+            assert (cand[r, got] >= t - tol[r]).all()
+            np.testing.assert_allclose(pv[r, :n], cand[r, got], rtol=2e-7, atol=0.0 if exact64 else 0.5 * tol[r])
+    ctx.set_option("predict_exact64", 0)
     for a, b in ((0, 2), (1, 3)):
         for x, y in zip(runs[a], runs[b]):
             np.testing.assert_array_equal(x, y)
@@ -590,6 +603,6 @@ def test_limits_and_dense_corners(hip):
         scores = onp.predict_full(X[:100], S)
         for Kp in (384, 385, 2048):  # wave kernel's largest pool, first value of the workgroup kernel, RP_K_MAX
             pi, pv, pn = _lib.predict_topk(ctx, m, dX, Kp, exclude_history=True, user_begin=0, user_end=100)
-            check_topk_scores(scores, pi, pv, pn, Kp, exclude=X[:100])
+            check_topk_scores(scores, pi, pv, pn, Kp, exclude=X[:100], hist=X[:100] if Kp <= 384 else None, S=S)
         with pytest.raises(_lib.RecpackHipError):
             _lib.predict_topk(ctx, m, dX, 2049)
