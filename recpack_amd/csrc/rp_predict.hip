@@ -362,13 +362,18 @@ constexpr int PW_CH = 4;        // entries per chunk (32 bytes)
 constexpr int PW_UCH = 4;       // users per ticket
 constexpr int PW_KP_MAX = 384;  // pool capacity = Kp rounded up + 128 <= 512
 
-// pool capacity (<= 512, the cut's limit): the more room above Kp, the fewer exact cuts per user
-__host__ __device__ constexpr int rp_pw_cap(int Kp) {
-  const int base = ((Kp + 63) / 64) * 64;
-  return base + 96;
+// LDS of one wave without the pool: sums, dirty map + history map, cut histogram (also the chunk-owner scratch), gather list
+__host__ __device__ constexpr size_t rp_pw_fixed_bytes(int acc_bytes, int wt) {
+  return (size_t)wt * acc_bytes + 512 * (wt / PW_WT) + 1024 + 128;
 }
-__host__ __device__ constexpr size_t rp_pw_wave_bytes(int Kp, int acc_bytes, int wt) {
-  return (size_t)wt * acc_bytes + 256 * (wt / PW_WT) + (size_t)rp_pw_cap(Kp) * (acc_bytes + 4) + 1024 + 128;
+// Pool capacity: every admitted candidate sits in the pool until the next exact cut back to Kp entries, and a cut costs about
+// as much as ten tiles - so the pool takes all the LDS that `waves` waves per CU leave (at most 512 entries, the cut's limit;
+// at least Kp rounded up + 64, what a push needs).  A stream of N scores admits about Kp (1 + ln(N / Kp)) of them.
+static int rp_pw_cap_for(int Kp, int acc_bytes, int wt, int waves) {
+  const int base = ((Kp + 63) / 64) * 64;
+  const long long budget = (160 * 1024) / waves - (long long)rp_pw_fixed_bytes(acc_bytes, wt);
+  const int fit = (int)(budget / (acc_bytes + 4)) / 16 * 16;
+  return std::max(base + 64, std::min(512, fit));
 }
 template <typename T>
 __device__ __forceinline__ constexpr T rp_pw_flip() { return (T)1 << (8 * sizeof(T) - 1); }  // two's complement sum -> ordered key
@@ -382,6 +387,7 @@ struct rp_pw_params {
   const uint8_t* keep;   // optional item filter: only items with keep[j] != 0 are candidates
   const double* x_val;   // optional values of the prediction matrix's entries (WGT instances)
   int n_items, n_wt, K, Kp, exclude_history, user_begin, n_users;
+  int cap;               // pool capacity (rp_pw_cap_for)
   rp_fix_scale fix;
   int32_t* ticket;
   int32_t* out_idx;
@@ -468,31 +474,6 @@ __device__ __forceinline__ int rp_pw_fetch_chunk(const rp_pw_state<AccT>& S, int
   return n;
 }
 
-// The first 64 chunks of a batch (chunk = lane): every slice owner writes its lane id at its first chunk's slot of a
-// 64-word LDS scratch, a running maximum over the lanes (DPP) turns that into the owner of every chunk - two LDS
-// round trips where the binary search takes six.
-template <typename AccT, bool WGT>
-__device__ __forceinline__ int rp_pw_fetch_first(const rp_pw_state<AccT>& S, int n_chunks, int nch, int s, int len, int choff, v4i_a4* a,
-                                                 v4i_a4* b, double wt, double* wo) {
-  RP_LDS uint32_t* sc = S.pool.hist;  // idle while a tile's entries are fetched and added
-  const int lane = S.lane;
-  sc[lane] = 0u;
-  RP_WAVE_FENCE();
-  if (nch > 0 && choff < 64) sc[choff] = (uint32_t)lane;
-  RP_WAVE_FENCE();
-  const int lo = rp_wave_incl_max((int)sc[lane]);
-  const int us = __shfl(s, lo), ulen = __shfl(len, lo), co = __shfl(choff, lo);
-  if (WGT) *wo = __shfl(wt, lo);
-  const int k0 = (lane - co) * PW_CH;
-  const int n = (lane < n_chunks) ? min(PW_CH, ulen - k0) : 0;
-  if (n > 0) {
-    const int* src = S.pairs_i + 2 * (long long)(us + k0);
-    *a = *reinterpret_cast<const v4i_a4*>(src);
-    *b = *reinterpret_cast<const v4i_a4*>(src + 4);
-  }
-  return n;
-}
-
 // ---- the rare paths of a tile, kept OUT OF LINE on purpose.  Both load and immediately consume global data; inlined,
 // their temporaries made the compiler put conservative s_waitcnt vmcnt(..) into the common path, which then waited for
 // the prefetched entries of the next tile in the middle of the current one.  As calls they cost nothing unless taken.
@@ -501,7 +482,7 @@ __device__ __forceinline__ int rp_pw_fetch_first(const rp_pw_state<AccT>& S, int
 template <typename AccT, bool WGT>
 __device__ __attribute__((noinline)) void rp_pw_extra_steps(RP_LDS AccT* acc, RP_LDS uint32_t* dirty, RP_LDS uint32_t* hist,
                                                             const int* pairs_i, rp_fix_scale fix, float fmul, int lane, int s, int len,
-                                                            int choff, int nchunks, int t0, double wt) {
+                                                            int choff, int nchunks, int t0, double wt, int c_from) {
   rp_pw_state<AccT> S;
   S.acc = acc;
   S.dirty = dirty;
@@ -510,64 +491,11 @@ __device__ __attribute__((noinline)) void rp_pw_extra_steps(RP_LDS AccT* acc, RP
   S.fix = fix;
   S.fmul = fmul;
   S.lane = lane;
-  for (int c0 = 64; c0 < nchunks; c0 += 64) {
+  for (int c0 = c_from; c0 < nchunks; c0 += 64) {
     v4i_a4 a = (v4i_a4){0, 0, 0, 0}, b2 = a;
     double xw = 1.0;
     const int n = rp_pw_fetch_chunk<AccT, WGT>(S, c0 + lane, nchunks, s, len, choff, &a, &b2, wt, &xw);
     rp_pw_add_chunk<AccT, WGT>(S, n, a, b2, t0, xw);
-  }
-}
-
-// History batches beyond the pipelined ones (items [h_from, he)): offsets and entries fetched on the spot.
-// Returns whether anything was added.
-template <typename AccT, int WT, bool WGT>
-__device__ __attribute__((noinline)) bool rp_pw_slow_batches(RP_LDS AccT* acc, RP_LDS uint32_t* dirty, RP_LDS uint32_t* hist,
-                                                             const int* pairs_i, rp_fix_scale fix, float fmul, int lane,
-                                                             const int32_t* x_idx, const double* x_val, const uint16_t* toff, int K, int NT,
-                                                             int t, int h_from, int he) {
-  rp_pw_state<AccT> S;
-  S.acc = acc;
-  S.dirty = dirty;
-  S.pool.hist = hist;
-  S.pairs_i = pairs_i;
-  S.fix = fix;
-  S.fmul = fmul;
-  S.lane = lane;
-  const int t0 = t * WT;
-  bool touched = false;
-  for (int hb = h_from; hb < he; hb += 64) {
-    const int h = hb + lane;
-    int s = 0, len = 0;
-    double wt = 1.0;
-    if (h < he) {
-      const int itx = x_idx[h];
-      if (WGT) wt = x_val[h];
-      const uint16_t* tx = toff + (long long)itx * (NT + 1) + t;
-      const int o0 = tx[0], o1 = tx[1];
-      s = itx * K + o0;
-      len = o1 - o0;
-    }
-    const int nch = (len + PW_CH - 1) / PW_CH;
-    const int inc = rp_wave_incl_scan(nch, lane);
-    const int choff = inc - nch;
-    const int n_chunks = __builtin_amdgcn_readlane(inc, 63);
-    if (n_chunks > 0) touched = true;
-    for (int c0 = 0; c0 < n_chunks; c0 += 64) {
-      v4i_a4 a = (v4i_a4){0, 0, 0, 0}, b2 = a;
-      double xw = 1.0;
-      const int n = rp_pw_fetch_chunk<AccT, WGT>(S, c0 + lane, n_chunks, s, len, choff, &a, &b2, wt, &xw);
-      rp_pw_add_chunk<AccT, WGT>(S, n, a, b2, t0, xw);
-    }
-  }
-  return touched;
-}
-
-// history removal for the items of those batches
-template <typename AccT, int WT>
-__device__ __attribute__((noinline)) void rp_pw_slow_exclude(RP_LDS AccT* acc, int lane, const int32_t* x_idx, int t0, int h_from, int he) {
-  for (int h = h_from + lane; h < he; h += 64) {
-    const int j = x_idx[h] - t0;
-    if ((unsigned)j < (unsigned)WT) acc[j] = 0;
   }
 }
 
@@ -581,183 +509,307 @@ __device__ __attribute__((noinline)) uint32_t rp_pw_keep_lookup(const uint8_t* k
   return ok;
 }
 
-// All tiles of one user.  The first NB batches of 64 history items are software-pipelined over the tiles: item ids stay
-// in registers, tile offsets are loaded two tiles ahead and the entries of tile t+1 are in flight while tile t is
-// added, scanned and pooled.  Without this the three dependent loads (item id -> offsets -> entries) are paid once
-// per tile and batch; batches beyond NB (histories longer than 64*NB) still go that way.
-// prepared first chunk step of one tile for the NB pipelined batches
-template <int NB>
-struct rp_pw_set {
-  int s[NB], len[NB], choff[NB], nchunks[NB], n[NB];
-  v4i_a4 a[NB], b[NB];
-  double w[NB];  // WGT: the value of the history item the lane's first chunk belongs to
+// One user.  The work is a sequence of UNITS (column tile t, batch g of 64 history items), tile-major; after the last batch
+// of a tile its touched columns are offered to the pool.  The sequence is software-pipelined three units deep, the same
+// way for every history length:
+//   iteration k   requests  the item ids of unit k+3                      (one coalesced load)
+//                           the tile offsets of unit k+2 (toff[item][t], [t+1]; needs the ids of k+2)
+//                           the entries of unit k+1: scan of the slice lengths, chunk -> lane assignment, ST steps of two
+//                           16-byte loads per lane (needs the offsets of k+1)
+//                 then adds the entries of unit k (requested one iteration earlier) and, at a tile's end, walks the tile.
+// Everything an iteration requests is consumed at the top of the next one at the earliest, i.e. after the adds and the walk
+// - the long part of an iteration - so the loads have that long to arrive.  All of them are UNCONDITIONAL (clamped
+// addresses; dead units and idle lanes read something harmless): with loads under branches the compiler loses count of
+// the loads in flight and falls back to s_waitcnt vmcnt(0) in front of the adds, which waits for the entries just requested.
+// Two entry sets alternate (the loop body handles two units), so no register is copied while its load is in flight.
+// ST steps of 64 chunks of 4 entries are prefetched per unit (3 for 4096-column tiles: a full batch has 64 x 8.2 entries in
+// about 160 chunks); chunks beyond them (rare) are fetched on the spot by rp_pw_extra_steps.
+// History removal: a lane whose item lies in the current tile sets its bit in `excl` (same layout as the dirty map); the walk
+// skips and clears those columns.
+template <int ST>
+struct rp_pw_uset {
+  int s, len, choff, nchunks;
+  int n[ST];
+  v4i_a4 a[ST], b[ST];
+  double w[ST];  // WGT: the value of the history item the lane's chunk belongs to
 };
 
-template <int NB, typename AccT, int WT, bool WGT>
-__device__ __forceinline__ void rp_pw_user_tiles(const rp_pw_params& P, rp_pw_state<AccT>& S, int ul, int hs, int he) {
+template <typename AccT, int WT, bool WGT, int ST>
+__device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_state<AccT>& S, int hs, int he) {
   constexpr int DW = WT / PW_WT;
   constexpr AccT FLIP = rp_pw_flip<AccT>();
   const int lane = S.lane, K = P.K, Kp = P.Kp, NT = P.n_wt, cap = S.cap;
-  const int nb = min(NB, (he - hs + 63) >> 6);
-  int it[NB], o_a[NB], o_b[NB], o_c[NB];
-  double wt[NB];
-  const uint16_t* to[NB];
-  // two register sets, used alternately as "current tile" and "tile being prefetched": the entries of tile t+1 are
-  // loaded straight into the set tile t+1 will read, a whole tile period before they are needed (copying a prepared
-  // set into a current one made the compiler wait for the loads at the end of every tile)
-  rp_pw_set<NB> set0, set1;
-  auto prepare = [&](int b, rp_pw_set<NB>& D) __attribute__((always_inline)) {
-    D.s[b] = (it[b] >= 0) ? it[b] * K + o_a[b] : 0;
-    D.len[b] = (it[b] >= 0) ? o_b[b] - o_a[b] : 0;
-    const int nch = (D.len[b] + PW_CH - 1) / PW_CH;
+  const int G = (he - hs + 63) >> 6;
+  const int NU = NT * G;
+  RP_LDS uint32_t* excl = S.dirty + 64 * DW;
+  rp_pw_uset<ST> set0, set1;
+
+  // ---- stage state.  (t, g) of units k .. k+3; ids / weights of k .. k+2; raw (just loaded) values of the youngest stages
+  int t0c = 0, g0c = 0, t1c = 0, g1c = 0, t2c = 0, g2c = 0, t3c = 0, g3c = 0;
+  auto next_unit = [&](int& t, int& g) __attribute__((always_inline)) {
+    ++g;
+    if (g == G) {
+      g = 0;
+      ++t;
+    }
+  };
+  int it0 = -1, it1 = -1, it2 = -1, raw_it = 0, raw_oa = 0, raw_ob = 0;
+  bool valid3 = false;
+  double wt0 = 1.0, wt1 = 1.0, wt2 = 1.0, raw_wt = 1.0;
+  auto load_ids = [&](int t, int g) __attribute__((always_inline)) {
+    const int h = hs + 64 * g + lane;
+    raw_it = P.x_idx[min(h, he - 1)];  // (he > hs: the clamped read stays inside the user's row)
+    if (WGT) raw_wt = P.x_val[min(h, he - 1)];
+    valid3 = (h < he) && (t < NT);
+  };
+  auto load_offs = [&](int it, int t) __attribute__((always_inline)) {
+    const uint16_t* to = P.toff + (long long)max(it, 0) * (NT + 1) + min(t, NT - 1);
+    raw_oa = (int)to[0];
+    raw_ob = (int)to[1];
+  };
+  // Entries of one unit.  Chunk c of the batch goes to lane c % 64 of step c / 64.  Owner of chunk c = the largest lane whose
+  // first chunk is <= c: every owner writes its lane id at its first chunk's slot of a 64 ST-word LDS scratch (the cut's
+  // histogram, idle here), a running maximum over the slots (DPP per step, carried from step to step) fills the gaps.  The
+  // scratch reads of all steps go out together, then the owners' (start, length, first chunk) broadcasts of all steps: two LDS
+  // round trips per unit whatever ST is.  Steps beyond the unit's chunks issue nothing.
+  auto fetch = [&](rp_pw_uset<ST>& D, int it, int oa, int ob, double wt) __attribute__((always_inline)) {
+    RP_LDS uint32_t* sc = S.pool.hist;
+    D.s = (it >= 0) ? it * K + oa : 0;
+    D.len = (it >= 0) ? ob - oa : 0;
+    const int nch = (D.len + PW_CH - 1) / PW_CH;
     const int inc = rp_wave_incl_scan(nch, lane);
-    D.choff[b] = inc - nch;
-    D.nchunks[b] = __builtin_amdgcn_readlane(inc, 63);
-    D.n[b] = rp_pw_fetch_first<AccT, WGT>(S, D.nchunks[b], nch, D.s[b], D.len[b], D.choff[b], &D.a[b], &D.b[b], wt[b], &D.w[b]);
+    D.choff = inc - nch;
+    D.nchunks = __builtin_amdgcn_readlane(inc, 63);
+#pragma unroll
+    for (int st = 0; st < ST; ++st) sc[64 * st + lane] = 0u;
+    RP_WAVE_FENCE();
+    if (nch > 0 && D.choff < 64 * ST) sc[D.choff] = (uint32_t)lane;
+    RP_WAVE_FENCE();
+    int own[ST];
+#pragma unroll
+    for (int st = 0; st < ST; ++st) own[st] = (int)sc[64 * st + lane];
+    int carry = 0;
+#pragma unroll
+    for (int st = 0; st < ST; ++st) {
+      own[st] = rp_wave_incl_max(max(own[st], (lane == 0) ? carry : 0));
+      carry = __builtin_amdgcn_readlane(own[st], 63);
+    }
+    int us[ST], ulen[ST], co[ST];
+#pragma unroll
+    for (int st = 0; st < ST; ++st) {
+      us[st] = __shfl(D.s, own[st]);
+      ulen[st] = __shfl(D.len, own[st]);
+      co[st] = __shfl(D.choff, own[st]);
+      if (WGT) D.w[st] = __shfl(wt, own[st]);
+    }
+#pragma unroll
+    for (int st = 0; st < ST; ++st) {
+      const int c = 64 * st + lane;
+      const int k0 = (c - co[st]) * PW_CH;
+      const int n = (c < D.nchunks) ? min(PW_CH, ulen[st] - k0) : 0;
+      D.n[st] = n;
+      if (64 * st < D.nchunks) {  // (uniform; whatever is requested here is used at the top of the next iteration at the earliest)
+        const int* src = S.pairs_i + 2 * (long long)(n > 0 ? us[st] + k0 : 0);  // (padded array: reading past a slice's end is harmless)
+        D.a[st] = *reinterpret_cast<const v4i_a4*>(src);
+        D.b[st] = *reinterpret_cast<const v4i_a4*>(src + 4);
+      }
+    }
   };
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    it[b] = -1;
-    wt[b] = 1.0;
-    set0.w[b] = set1.w[b] = 1.0;
-    to[b] = P.toff;
-    o_a[b] = o_b[b] = o_c[b] = 0;
-    set0.s[b] = set0.len[b] = set0.choff[b] = set0.nchunks[b] = set0.n[b] = 0;
-    set1.s[b] = set1.len[b] = set1.choff[b] = set1.nchunks[b] = set1.n[b] = 0;
-    set0.a[b] = set0.b[b] = set1.a[b] = set1.b[b] = (v4i_a4){0, 0, 0, 0};
-    if (b < nb) {
-      const int h = hs + 64 * b + lane;
-      it[b] = (h < he) ? P.x_idx[h] : -1;
-      if (WGT) wt[b] = (h < he) ? P.x_val[h] : 0.0;
-    }
+  for (int st = 0; st < ST; ++st) {
+    set0.w[st] = set1.w[st] = 1.0;
+    set0.n[st] = set1.n[st] = 0;
+    set0.a[st] = set0.b[st] = set1.a[st] = set1.b[st] = (v4i_a4){0, 0, 0, 0};
   }
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    if (b < nb) {
-      to[b] = P.toff + (long long)max(it[b], 0) * (NT + 1);
-      o_a[b] = (it[b] >= 0) ? (int)to[b][0] : 0;
-      o_b[b] = (it[b] >= 0) ? (int)to[b][1] : 0;
-      o_c[b] = (it[b] >= 0 && NT >= 2) ? (int)to[b][2] : o_b[b];
-    }
-  }
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-    if (b < nb) prepare(b, set0);  // tile 0
+  set0.s = set0.len = set0.choff = set0.nchunks = 0;
+  set1.s = set1.len = set1.choff = set1.nchunks = 0;
 
-  // one tile: C = the set prepared for it, N = the set to prepare for tile t+1
-  auto tile = [&](int t, rp_pw_set<NB>& C, rp_pw_set<NB>& N) __attribute__((always_inline)) {
-    const int t0 = t * WT;
-    bool touched = false;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) touched |= C.nchunks[b] > 0;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      if (b < nb) {
-        o_a[b] = o_b[b];
-        o_b[b] = o_c[b];
-        if (t + 3 <= NT && it[b] >= 0) o_c[b] = (int)to[b][t + 3];
-        if (t + 1 < NT) prepare(b, N);
-      }
-    }
+  // ---- prologue (dependent loads, once per user): ids of units 0..2, offsets of units 0..1, entries of unit 0
+  {
+    load_ids(0, 0);
+    const int i0 = valid3 ? raw_it : -1;
+    const double w0 = (WGT && valid3) ? raw_wt : 1.0;
+    t1c = 0, g1c = 0;
+    next_unit(t1c, g1c);  // unit 1
+    load_ids(t1c, g1c);
+    const int i1 = valid3 ? raw_it : -1;
+    const double w1 = (WGT && valid3) ? raw_wt : 1.0;
+    t2c = t1c, g2c = g1c;
+    next_unit(t2c, g2c);  // unit 2
+    load_offs(i0, 0);
+    const int oa0 = (i0 >= 0) ? raw_oa : 0, ob0 = (i0 >= 0) ? raw_ob : 0;
+    fetch(set0, i0, oa0, ob0, w0);  // entries of unit 0
+    load_offs(i1, t1c);             // offsets of unit 1: consumed at the top of iteration 0
+    load_ids(t2c, g2c);             // ids of unit 2: likewise
+    // the loop's top rotates: (it0, it1, it2) <- (it1, it2, raw); so unit 0 sits in it1, unit 1 in it2
+    it1 = i0;
+    wt1 = w0;
+    it2 = i1;
+    wt2 = w1;
+    // counters are rotated the same way: stage 1 holds unit 0, stage 2 unit 1, stage 3 unit 2
+    t3c = t2c, g3c = g2c;
+    t2c = t1c, g2c = g1c;
+    t1c = 0, g1c = 0;
+  }
+  bool touched = false;
+
+  // one iteration: C = entries of unit k (requested last iteration), N = set to fill for unit k+1
+  auto unit = [&](rp_pw_uset<ST>& C, rp_pw_uset<ST>& N) __attribute__((always_inline)) {
+    // ---- top: rotate the stages; what the previous iteration requested is used from here on
+    it0 = it1;
+    wt0 = wt1;
+    t0c = t1c, g0c = g1c;
+    it1 = it2;
+    wt1 = wt2;
+    t1c = t2c, g1c = g2c;
+    const int oa1 = (it1 >= 0) ? raw_oa : 0, ob1 = (it1 >= 0) ? raw_ob : 0;
+    it2 = valid3 ? raw_it : -1;
+    if (WGT) wt2 = valid3 ? raw_wt : 1.0;
+    t2c = t3c, g2c = g3c;
+    next_unit(t3c, g3c);
+    // ---- requests for the units ahead
+    fetch(N, it1, oa1, ob1, wt1);  // entries of unit k+1
+    load_offs(it2, t2c);           // offsets of unit k+2
+    load_ids(t3c, g3c);            // ids of unit k+3
     PW_STAMP(4);
+    // ---- unit k: adds
+    const int t0 = t0c * WT;
+    touched |= C.nchunks > 0;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      if (b < nb) {
-        rp_pw_add_chunk<AccT, WGT>(S, C.n[b], C.a[b], C.b[b], t0, C.w[b]);  // the prefetched first step, then (rarely) further steps
-        if (C.nchunks[b] > 64)
-          rp_pw_extra_steps<AccT, WGT>(S.acc, S.dirty, S.pool.hist, S.pairs_i, S.fix, S.fmul, lane, C.s[b], C.len[b], C.choff[b],
-                                       C.nchunks[b], t0, wt[b]);
-      }
+    for (int st = 0; st < ST; ++st)
+      if (64 * st < C.nchunks) rp_pw_add_chunk<AccT, WGT>(S, C.n[st], C.a[st], C.b[st], t0, C.w[st]);
+    if (C.nchunks > 64 * ST)
+      rp_pw_extra_steps<AccT, WGT>(S.acc, S.dirty, S.pool.hist, S.pairs_i, S.fix, S.fmul, lane, C.s, C.len, C.choff, C.nchunks, t0, wt0,
+                                   64 * ST);
+    if (P.exclude_history) {
+      const int j = it0 - t0;
+      if ((unsigned)j < (unsigned)WT) atomicOr((uint32_t*)&excl[(j & 63) + 64 * (j >> 11)], 1u << ((j >> 6) & 31));
     }
-    // ---- histories longer than 64*NB items: the remaining batches, not pipelined
-    if (hs + 64 * NB < he)
-      touched |= rp_pw_slow_batches<AccT, WT, WGT>(S.acc, S.dirty, S.pool.hist, S.pairs_i, S.fix, S.fmul, lane, P.x_idx, P.x_val, P.toff, K,
-                                                   NT, t, hs + 64 * NB, he);
     PW_STAMP(1);
-    if (!touched) return;
-    if (P.exclude_history) {  // the dirty bit stays: a zero sum is skipped below
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {  // item ids of the pipelined batches are in registers: no load to wait for here
-        const int j = it[b] - t0;
-        if (b < nb && (unsigned)j < (unsigned)WT) S.acc[j] = 0;
-      }
-      if (hs + 64 * NB < he) rp_pw_slow_exclude<AccT, WT>(S.acc, lane, P.x_idx, t0, hs + 64 * NB, he);
-    }
+    if (g0c != G - 1) return;  // more batches of this tile to come
+    // ---- end of tile t0c: offer the touched columns to the pool.  Lane l walks the set bits of dirty word l (word l
+    // covers columns l, l+64, ..: the lanes' reads of one round fall into different LDS banks), four set bits per lane and
+    // round so that the sums of a round are read with one wait
+    const bool was_touched = touched;
+    touched = false;
     RP_WAVE_FENCE();
-    // ---- offer the touched columns to the pool: lane l walks the set bits of dirty word l
-    // (word l covers columns l, l+64, ..: the lanes' reads of one round fall into different LDS banks), four set bits
-    // per lane and round so that the sums of a round are read with one wait
     PW_STAMP(5);
 #pragma unroll 1
     for (int dwi = 0; dwi < DW; ++dwi) {
-    uint32_t w = S.dirty[lane + 64 * dwi];
-    S.dirty[lane + 64 * dwi] = 0u;
-    const int jb = lane + PW_WT * dwi;  // column of bit 0 of this word
-    while (__any(w != 0u)) {
-      bool has[4];
-      int j[4];
-      AccT v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        has[q] = w != 0u;
-        j[q] = jb + 64 * (has[q] ? (__ffs((int)w) - 1) : 0);
-        w &= w - 1u;  // 0 stays 0
+      uint32_t ex = 0u;
+      if (P.exclude_history) {
+        ex = excl[lane + 64 * dwi];
+        excl[lane + 64 * dwi] = 0u;
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = has[q] ? S.acc[j[q]] : (AccT)0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (has[q]) S.acc[j[q]] = 0;
-      // most sums lose against the pool's threshold once it is warm: the slots of the round are voted on first and only
-      // slots with a surviving lane are pushed (rolled loop: one inlined copy of the pool cut; values rotate through 0)
-      bool kq[4];
-      uint32_t live = 0;  // bit q: some lane keeps its slot q
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        v[q] ^= FLIP;  // signed sum -> unsigned order; a zero sum is no candidate
-        kq[q] = has[q] && v[q] != FLIP && rp_wpool_admits<AccT, 0>(S.pool, v[q], (uint32_t)(t0 + j[q]));
+      if (!was_touched) continue;
+      uint32_t w = S.dirty[lane + 64 * dwi];
+      S.dirty[lane + 64 * dwi] = 0u;
+      const int jb = lane + PW_WT * dwi;  // column of bit 0 of this word
+      ex &= w;      // history items that were touched: their sums are dropped
+      w &= ~ex;
+      while (__any(ex != 0u)) {
+        if (ex != 0u) S.acc[jb + 64 * (__ffs((int)ex) - 1)] = 0;
+        ex &= ex - 1u;
       }
-      if (P.keep) {  // item filter: only sums that would enter the pool pay the lookup
-        const uint32_t want = (kq[0] ? 1u : 0u) | (kq[1] ? 2u : 0u) | (kq[2] ? 4u : 0u) | (kq[3] ? 8u : 0u);
-        if (__any(want != 0u)) {
-          const uint32_t ok = rp_pw_keep_lookup(P.keep, t0 + j[0], t0 + j[1], t0 + j[2], t0 + j[3], want);
+      while (__any(w != 0u)) {
+        bool has[4];
+        int j[4];
+        AccT v[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) kq[q] = (ok >> q) & 1u;
+        for (int q = 0; q < 4; ++q) {
+          has[q] = w != 0u;
+          j[q] = jb + 64 * (has[q] ? (__ffs((int)w) - 1) : 0);
+          w &= w - 1u;  // 0 stays 0
         }
-      }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) live |= __any(kq[q]) ? (1u << q) : 0u;
-      if (!live) continue;
-      PW_STAMP(2);
+        for (int q = 0; q < 4; ++q) v[q] = has[q] ? S.acc[j[q]] : (AccT)0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (has[q]) S.acc[j[q]] = 0;
+        // most sums lose against the pool's threshold once it is warm: the slots of the round are voted on first and only
+        // slots with a surviving lane are pushed (rolled loop: one inlined copy of the pool cut; values rotate through 0)
+        bool kq[4];
+        uint32_t live = 0;  // bit q: some lane keeps its slot q
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[q] ^= FLIP;  // signed sum -> unsigned order; a zero sum is no candidate
+          kq[q] = has[q] && v[q] != FLIP && rp_wpool_admits<AccT, 0>(S.pool, v[q], (uint32_t)(t0 + j[q]));
+        }
+        if (P.keep) {  // item filter: only sums that would enter the pool pay the lookup
+          const uint32_t want = (kq[0] ? 1u : 0u) | (kq[1] ? 2u : 0u) | (kq[2] ? 4u : 0u) | (kq[3] ? 8u : 0u);
+          if (__any(want != 0u)) {
+            const uint32_t ok = rp_pw_keep_lookup(P.keep, t0 + j[0], t0 + j[1], t0 + j[2], t0 + j[3], want);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) kq[q] = (ok >> q) & 1u;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) live |= __any(kq[q]) ? (1u << q) : 0u;
+        if (!live) continue;
+        PW_STAMP(2);
+        // the round's survivors in one go when they fit the pool as it is (the common case: a few of them); slot by slot
+        // with cuts in between otherwise
+        const uint64_t m0 = __ballot(kq[0]), m1 = __ballot(kq[1]), m2 = __ballot(kq[2]), m3 = __ballot(kq[3]);
+        const int c0n = __popcll(m0), c1n = __popcll(m1), c2n = __popcll(m2), c3n = __popcll(m3);
+        if (S.pool.n + c0n + c1n + c2n + c3n <= cap) {
+          const uint64_t below = (1ull << lane) - 1ull;
+          int base = S.pool.n;
+          if (kq[0]) {
+            const int pos = base + __popcll(m0 & below);
+            S.pool.key[pos] = v[0];
+            S.pool.pay[pos] = (uint32_t)(t0 + j[0]);
+          }
+          base += c0n;
+          if (kq[1]) {
+            const int pos = base + __popcll(m1 & below);
+            S.pool.key[pos] = v[1];
+            S.pool.pay[pos] = (uint32_t)(t0 + j[1]);
+          }
+          base += c1n;
+          if (kq[2]) {
+            const int pos = base + __popcll(m2 & below);
+            S.pool.key[pos] = v[2];
+            S.pool.pay[pos] = (uint32_t)(t0 + j[2]);
+          }
+          base += c2n;
+          if (kq[3]) {
+            const int pos = base + __popcll(m3 & below);
+            S.pool.key[pos] = v[3];
+            S.pool.pay[pos] = (uint32_t)(t0 + j[3]);
+          }
+          S.pool.n = base + c3n;
+          PW_STAMP(7);
+          continue;
+        }
 #pragma unroll 1
-      for (int q = 0; q < 4 && live; ++q, live >>= 1) {
-        if (live & 1u) {
-          const uint32_t col = (uint32_t)(t0 + j[0]);
-          // the threshold may have moved since the vote (a cut inside an earlier push): ask again
-          const bool keep = kq[0] && rp_wpool_admits<AccT, 0>(S.pool, v[0], col);
+        for (int q = 0; q < 4 && live; ++q, live >>= 1) {
+          if (live & 1u) {
+            const uint32_t col = (uint32_t)(t0 + j[0]);
+            // the threshold may have moved since the vote (a cut inside an earlier push): ask again
+            const bool keep = kq[0] && rp_wpool_admits<AccT, 0>(S.pool, v[0], col);
 #ifdef RP_STAMPS
-          const int n_before = S.pool.n;
+            const int n_before = S.pool.n;
 #endif
-          rp_wpool_push<AccT, 0>(S.pool, Kp, cap, keep, v[0], col, lane);
+            rp_wpool_push<AccT, 0>(S.pool, Kp, cap, keep, v[0], col, lane);
 #ifdef RP_STAMPS
-          if (S.pool.n < n_before) PW_COUNT(6, 1);  // a cut happened
+            if (S.pool.n < n_before) PW_COUNT(6, 1);  // a cut happened
 #endif
-        }
+          }
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          kq[r] = kq[r + 1];
-          j[r] = j[r + 1];
-          v[r] = v[r + 1];
+          for (int r = 0; r < 3; ++r) {
+            kq[r] = kq[r + 1];
+            j[r] = j[r + 1];
+            v[r] = v[r + 1];
+          }
         }
+        PW_STAMP(7);
       }
-      PW_STAMP(7);
-    }
     }
     PW_STAMP(2);
   };
-  for (int t = 0; t < NT; t += 2) {
-    tile(t, set0, set1);
-    if (t + 1 < NT) tile(t + 1, set1, set0);
+  for (int k = 0; k < NU; k += 2) {
+    unit(set0, set1);
+    if (k + 1 < NU) unit(set1, set0);
   }
 }
 
@@ -783,13 +835,13 @@ __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
   const int Kp = P.Kp;
   rp_pw_state<AccT> S;
   S.lane = lane;
-  S.cap = rp_pw_cap(Kp);
+  S.cap = P.cap;
   S.fix = P.fix;
   S.fmul = 1.0f;
   S.ushift = P.fix.shift;
   S.acc = (RP_LDS AccT*)smem;
   S.dirty = (RP_LDS uint32_t*)(smem + (size_t)WT * sizeof(AccT));
-  S.pool.key = (RP_LDS AccT*)(smem + (size_t)WT * sizeof(AccT) + 256 * DW);
+  S.pool.key = (RP_LDS AccT*)(smem + (size_t)WT * sizeof(AccT) + 512 * DW);  // dirty map, then the history map (256 B per 2048 columns each)
   S.pool.pay = (RP_LDS uint32_t*)(S.pool.key + S.cap);
   S.pool.hist = S.pool.pay + S.cap;
   S.pool.gidx = (RP_LDS uint16_t*)(S.pool.hist + 256);
@@ -797,7 +849,7 @@ __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
 
   for (int i = lane; i < WT; i += 64) S.acc[i] = 0;
 #pragma unroll
-  for (int d = 0; d < DW; ++d) S.dirty[lane + 64 * d] = 0u;
+  for (int d = 0; d < 2 * DW; ++d) S.dirty[lane + 64 * d] = 0u;
 #ifdef RP_STAMPS
   S.t_last = __builtin_amdgcn_s_memtime();
   for (int _p = 0; _p < 8; ++_p) S.t_ph[_p] = 0;
@@ -828,13 +880,7 @@ __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
       S.pool.tau = 0;
       S.pool.tau_col = 0;
       PW_STAMP(0);
-      const int nbu = (he - hs + 63) >> 6;
-      if (nbu <= 1)
-        rp_pw_user_tiles<1, AccT, WT, WGT>(P, S, ul, hs, he);
-      else if (nbu <= 2)
-        rp_pw_user_tiles<2, AccT, WT, WGT>(P, S, ul, hs, he);
-      else
-        rp_pw_user_tiles<4, AccT, WT, WGT>(P, S, ul, hs, he);
+      rp_pw_user_units<AccT, WT, WGT, (WT > PW_WT ? 3 : 2)>(P, S, hs, he);
       // ---- final: best Kp by (score desc, column asc), then column order for the output row
       RP_WAVE_FENCE();
       if (S.pool.n > Kp) rp_wpool_cut<AccT, 0>(S.pool, Kp, lane);
@@ -1078,9 +1124,13 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
       hipMemsetAsync(sp, 0, 64 * 8, st);
     }
 #endif
-    const size_t wl = rp_pw_wave_bytes(Kp, x32 ? 4 : 8, wt);
+    // waves per CU: 12 for the 2048-column tiles of the 32-bit sums (the kernel's registers allow three waves per SIMD), 8 else
+    const int acc_b = x32 ? 4 : 8;
+    int wpc = (x32 && wt == PW_WT) ? 12 : 8;
+    while (wpc > 1 && (160 * 1024) / wpc < (long long)(rp_pw_fixed_bytes(acc_b, wt) + (size_t)(((Kp + 63) / 64) * 64 + 64) * (acc_b + 4))) --wpc;
+    W.cap = rp_pw_cap_for(Kp, acc_b, wt, wpc);
+    const size_t wl = rp_pw_fixed_bytes(acc_b, wt) + (size_t)W.cap * (acc_b + 4);
     W.x_val = Xpred->x_val;
-    const int wpc = std::max<int>(1, std::min<int>(16, (int)((160 * 1024) / wl)));
     const int wg = (int)std::min<int64_t>(rp_cdiv(n, PW_UCH), (int64_t)ctx->n_cu * wpc);
     auto launch = [&](auto kern) {
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
