@@ -80,7 +80,7 @@ class _Ops:
         return out
 
 
-def solve_columns(indptr_t, indices_t, shape, l2, cols, tol=1e-12, max_iter=3000, log=None):
+def solve_columns(indptr_t, indices_t, shape, l2, cols, tol=1e-13, max_iter=3000, log=None):
     """P[:, cols] of P = (X^T X + l2 I)^-1 by preconditioned CG in float64.  Returns (P_cols [I, k] as numpy, iterations, the
     solver's own last relative residual)."""
     import torch

@@ -162,6 +162,29 @@ def test_ease_fit_synthetic_vs_oracle(hip, shape, l2, alpha, seed):
             assert (got >= t - 2 * EASE_TOL * smax).all()
 
 
+@pytest.mark.parametrize("n_items,n_users,dens", [(8192, 100000, 0.004), (16384, 200000, 0.002)])
+def test_ease_vs_float64_inverse_8k_16k(hip, n_items, n_users, dens):
+    """The largest sizes a host inverts in reasonable time: all of B against the reference's float64
+    inverse (ease.py:81-86 through the oracle), globally and per column; the achieved errors are printed for the trend
+    (tests/test_gpu_fullsize.py continues it to 50K, 100K and 200K items with certified float64 columns)."""
+    from recpack_amd.synth import powerlaw_csr
+
+    _lib, ctx = hip
+    X = powerlaw_csr(n_users, n_items, dens, seed=20260100 + n_items).to_scipy()
+    dX, m, B = ease_B(hip, X, 200.0, 0.0)
+    ref = onp.ease_fit(X, 200.0, 0.0)
+    err = rel_max(B, ref)
+    col = np.abs(B - ref).max(axis=0) / np.maximum(np.abs(ref).max(axis=0), 1e-300)
+    c_max = int(np.asarray(X.sum(axis=0)).max())
+    print(f"EASE vs float64 inverse: n_items={n_items} nnz={X.nnz} c_max={c_max} err_global={err:.3e} err_col_max={col.max():.3e} "
+          f"err_col_median={np.median(col):.3e}")
+    assert err <= EASE_TOL, err
+    assert col.max() <= EASE_TOL, col.max()
+    m.close()
+    dX.close()
+    ctx.trim()
+
+
 def test_ease_edge_cases(hip):
     _lib, ctx = hip
     from recpack_amd import EASE
