@@ -360,6 +360,8 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_merge(const int32_t
 constexpr int PW_WT = 2048;     // columns per tile per dirty word of a lane (a tile is PW_WT * DW columns)
 constexpr int PW_CH = 4;        // entries per chunk (32 bytes)
 constexpr int PW_UCH = 4;       // users per ticket
+constexpr int PW_HEAVY = 192;   // users with longer histories are handed out first (a 1700-item history is 40 typical users of work:
+                                // picked up at the end of the queue it would run on alone)
 constexpr int PW_KP_MAX = 384;  // pool capacity = Kp rounded up + 128 <= 512
 
 // LDS of one wave without the pool: sums, dirty map + history map, cut histogram (also the chunk-owner scratch), gather list
@@ -388,6 +390,8 @@ struct rp_pw_params {
   const double* x_val;   // optional values of the prediction matrix's entries (WGT instances)
   int n_items, n_wt, K, Kp, exclude_history, user_begin, n_users;
   int cap;               // pool capacity (rp_pw_cap_for)
+  const int32_t* heavy;  // local ids of the users with more than PW_HEAVY history items (they go first), count in *n_heavy
+  const int32_t* n_heavy;
   rp_fix_scale fix;
   int32_t* ticket;
   int32_t* out_idx;
@@ -655,7 +659,12 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
 
   // one iteration: C = entries of unit k (requested last iteration), N = set to fill for unit k+1
   auto unit = [&](rp_pw_uset<ST>& C, rp_pw_uset<ST>& N) __attribute__((always_inline)) {
-    // ---- top: rotate the stages; what the previous iteration requested is used from here on
+    // ---- top: rotate the stages; what the previous iteration requested is used from here on.  The empty asm makes the
+    // youngest of those loads (ids, offsets) "used" HERE: the compiler's wait for them then sits in front of this
+    // iteration's requests - placed at their first arithmetic use it would come after the entry loads below and wait for
+    // those too (loads return in order)
+    asm volatile("" : "+v"(raw_it), "+v"(raw_oa), "+v"(raw_ob));
+    if (WGT) asm volatile("" : "+v"(raw_wt));
     it0 = it1;
     wt0 = wt1;
     t0c = t1c, g0c = g1c;
@@ -859,12 +868,16 @@ __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
     int ubase = 0;
     if (lane == 0) ubase = atomicAdd(P.ticket, PW_UCH);
     ubase = __shfl(ubase, 0);
-    if (ubase >= P.n_users) break;
-    const int uend = min(ubase + PW_UCH, P.n_users);
-    for (int ul = ubase; ul < uend; ++ul) {
+    const int n_heavy = *P.n_heavy;
+    if (ubase >= P.n_users + n_heavy) break;
+    const int uend = min(ubase + PW_UCH, P.n_users + n_heavy);
+    for (int q = ubase; q < uend; ++q) {
+      // positions [0, n_heavy): the long histories; then every user in order, the long ones skipped
+      const int ul = (q < n_heavy) ? P.heavy[q] : q - n_heavy;
       const int u = P.user_begin + ul;
       const int hs = P.x_ptr[u], he = P.x_ptr[u + 1];
       if (he <= hs) continue;
+      if (q >= n_heavy && he - hs > PW_HEAVY) continue;  // done in the first part
       if constexpr (sizeof(AccT) == 4) {
         // this user's scale: M_u = sum of the history lists' largest |similarity| bounds every |score|;
         // 2^ushift * M_u (1 + 2^-12) < 2^30 (the margin covers the f32 rounding of the sum itself)
@@ -912,6 +925,15 @@ __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
       for (int _p = 0; _p < 8; ++_p) S.t_ph[_p] = 0;
 #endif
     }
+  }
+}
+
+// local ids of the users whose history is longer than PW_HEAVY (any order), count in *n
+__global__ void k_pw_heavy_users(const int32_t* __restrict__ x_ptr, int user_begin, int n_users, int32_t* __restrict__ list,
+                                 int32_t* __restrict__ n) {
+  for (int ul = blockIdx.x * blockDim.x + threadIdx.x; ul < n_users; ul += gridDim.x * blockDim.x) {
+    const int u = user_begin + ul;
+    if (x_ptr[u + 1] - x_ptr[u] > PW_HEAVY) list[atomicAdd(n, 1)] = ul;
   }
 }
 
@@ -1093,10 +1115,14 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
       hipLaunchKernelGGL(k_build_toff, dim3((unsigned)std::min<int64_t>(4096, rp_cdiv(model->n_items, 256))), dim3(256), 0, st, model->idx,
                          model->val32, model->nnz, model->K, (int)model->n_items, n_wt, wt, mm->toff, mm->rowmax);
     }
-    int32_t* tk = nullptr;
-    RP_TRY(rp_scratch(ctx, 4, 64, (void**)&tk));
+    int32_t* tk = nullptr;  // [0] ticket, [1] number of long-history users, [16..] their ids
+    RP_TRY(rp_scratch(ctx, 4, 64 + (size_t)n * 4, (void**)&tk));
     hipMemsetAsync(tk, 0, 64, st);
+    hipLaunchKernelGGL(k_pw_heavy_users, dim3((unsigned)std::min<int64_t>(2048, rp_cdiv(n, 256))), dim3(256), 0, st, Xpred->x_ptr,
+                       (int)user_begin, (int)n, tk + 16, tk + 1);
     rp_pw_params W;
+    W.heavy = tk + 16;
+    W.n_heavy = tk + 1;
     W.x_ptr = Xpred->x_ptr;
     W.x_idx = Xpred->x_idx;
     W.pairs = model->pairs;
