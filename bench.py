@@ -300,8 +300,8 @@ def tars_leg(args, ctx, device, Kp, config):
 
 
 def ease_leg_sharded(args, ctx, device, Kp, config, world, rank):
-    """EASE over all ranks: panels of the Cholesky / inverse split by row tiles and all-gathered, P rows and the scaling
-    local, B all-gathered (recpack_amd/dist.py::ease_fit_sharded); predict + top-Kp for this rank's users.  Runs on EVERY rank."""
+    """EASE over all ranks with B sharded by item columns (recpack_amd/dist.py::ease_fit_sharded: in-place block sweeps, one panel
+    broadcast per pivot block) and the column-sharded predict (local top-Kp per rank, all-gather, merge).  Runs on EVERY rank."""
     import torch
     import torch.distributed as dist
 
@@ -311,38 +311,40 @@ def ease_leg_sharded(args, ctx, device, Kp, config, world, rank):
     U, I, dens = CONFIGS[config]
     ip, ix = powerlaw_csr(U, I, dens, CONFIG_SEED_BASE + int(config[1:]), device=device)
     dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
-    ub, ue = rdist.partition_users(ip.cpu().numpy(), world)[rank]
-    out_idx = torch.empty((ue - ub, Kp), dtype=torch.int32, device=device)
-    out_val = torch.empty((ue - ub, Kp), dtype=torch.float32, device=device)
-    out_nnz = torch.empty((ue - ub,), dtype=torch.int32, device=device)
     dist.barrier()
     torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
     t0 = time.perf_counter()
-    model = rdist.ease_fit_sharded(ctx, dX, args.l2, 0.0, device)
+    model, (c0, nc) = rdist.ease_fit_sharded(ctx, dX, args.l2, 0.0, device)
     torch.cuda.synchronize()
     dist.barrier()
     t_fit = time.perf_counter() - t0
     t0 = time.perf_counter()
-    _lib.predict_topk_dev(ctx, model, dX, Kp, out_idx, out_val, out_nnz, user_begin=ub, user_end=ue)
+    rdist.predict_topk_sharded(ctx, model, dX, Kp, device, exclude_history=False)
     torch.cuda.synchronize()
     dist.barrier()
     t_pred = time.perf_counter() - t0
-    t = torch.tensor([t_fit, t_pred], dtype=torch.float64, device=device)
+    t = torch.tensor([t_fit, t_pred, float(torch.cuda.max_memory_allocated())], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     n_pad = -(-I // (128 * world)) * 128 * world
-    return {"workload": f"{config}: EASE l2={args.l2}, {U} users x {I} items over {world} GPUs (row-tile split panels + all-gather), "
-                        f"predict + top-{Kp} user-sharded",
+    return {"workload": f"{config}: EASE l2={args.l2}, {U} users x {I} items over {world} GPUs, B sharded by item columns (block sweeps, one panel "
+                        f"broadcast per pivot block), predict + top-{Kp} on the column slabs + merge",
             "fit_s": round(float(t[0]), 4), "predict_s": round(float(t[1]), 4), "fit_plus_predict_s": round(float(t[0] + t[1]), 4),
-            "n3_model_TFLOPs_aggregate": round(n_pad ** 3 / float(t[0]) / 1e12, 2)}
+            "flops_model": "2 n^3 (block sweeps update both triangles) + 2 n^2 nb per rank for the panel products",
+            "TFLOPs_aggregate": round(2.0 * n_pad ** 3 / float(t[0]) / 1e12, 2),
+            "peak_torch_bytes_per_rank": int(t[2]), "slab_bytes_per_rank": int(n_pad * (n_pad // world) * 4)}
 
 
 def pmc_traffic(config, kernel, world):
     """HBM bytes per launch of `kernel` from the committed PMC passes (tools/pmc_traffic.sh: one rocprofv3 --pmc run per
     counter on this same command).  FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B read
     requests as 64 B (MI355X_MICROARCH.md, HBM section), so it is doubled.  None when no pass exists for the config."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_pmc_traffic_{config.lower()}.json")
-    if world != 1 or not os.path.exists(path):
+    import glob
+
+    found = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r*_pmc_traffic_{config.lower()}.json")))
+    if world != 1 or not found:
         return None, "no PMC pass committed for this configuration"
+    path = found[-1]  # the latest round's pass (a kernel that was renamed since is simply not found: traffic = null)
     want = kernel.replace(" ", "")
     for name, c in json.load(open(path)).items():
         if want in name.replace(" ", "") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
@@ -481,11 +483,12 @@ def main():
             u_rank = user_parts[0][1] - user_parts[0][0]
             share = u_rank / U
             p_bytes = 8.0 * args.K * nnz * share + 4.0 * (nnz * share + u_rank) + 8.0 * u_rank * Kp
-            legs["k_predict_wave"] = (tp["ms"] / tp["launches"], p_bytes)
+            legs["k_predict_wave<unsigned int, 4096, false>"] = (tp["ms"] / tp["launches"], p_bytes)
         leg_what = {"k_itemknn_fit<false,1024,16>": "K1-K3 heavy rows: Gram + similarity key + top-K",
                     "k_itemknn_fit<false,256,8>": "K1-K3 light rows: Gram + similarity key + top-K",
-                    "k_predict_wave": "K8: scores X.S + fused top-Kp (bound by LDS atomics and instruction issue in practice: "
-                                      "the 400 MB model stays in L2/MALL)"}
+                    "k_predict_wave<unsigned int, 4096, false>": "K8: scores X.S + fused top-Kp, 32-bit per-user-scaled fixed-point sums, 4096-column "
+                                                                 "tiles (bound by instruction issue and LDS round trips per (user, tile) in "
+                                                                 "practice: the 400 MB model stays in L2/MALL)"}
         # `roofline` = the kernel with the longest launch; all of them are under `legs`
         dom = max(legs, key=lambda k: legs[k][0])
         avg_ms, algo_bytes = legs[dom]
@@ -505,7 +508,7 @@ def main():
             "higher_is_better": False,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "int32 counts, f64 similarity, f32 scores",
+            "dtype": "int32 counts, f64 similarity, i32 fixed-point score sums (per-user power-of-two scale) of f32 similarities",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.config}: ItemKNN cosine K={args.K}, {U} users x {I} items, nnz {nnz} "

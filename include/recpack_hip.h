@@ -319,6 +319,24 @@ int rphip_gemm_nt_f32(rphip_ctx* ctx, int64_t M, int64_t N, int64_t K, float alp
  * columns (n_cols >= n_items: rows/columns past n_items carry an identity block), leading dimension ld. */
 int rphip_ease_gram_rows(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int64_t n_cols, double l2,
                          float* G_dev, int64_t ld);
+/* ---- column-sharded EASE (multi-GPU: SURVEY.md 8(e); the reference has no multi-GPU path, base.py:454-455 leaves it as a TODO) ----
+ * Every rank owns a slab of item COLUMNS of the n x n matrix (all rows; row-major, ld = slab width) in caller-owned device
+ * memory.  recpack_amd/dist.py::ease_fit_sharded drives these between its collectives (one panel broadcast per pivot block):
+ *   rphip_ease_gram_rows + rphip_transpose_f32   G + l2 I, the rank's columns (Gram rows transposed: G is symmetric; ease.py:81)
+ *   rphip_spd_inverse_f32                        P = A_KK^-1 of a pivot block (in place; blocked Cholesky on MFMA tiles)
+ *   rphip_gemm_nt_f32                            T = A[:, K] P and the slab update A[:, J] -= T A[K, J]   (np.linalg.inv, ease.py:82)
+ *   rphip_ease_scale_cols                        B_ij = -P_ij / P_jj * w_j, B_jj = 0 on the slab (ease.py:85-90)
+ *   rphip_model_from_dense_cols                  a model on the slab: predict scores the slab's columns only
+ *   rphip_predict_merge_topk                     per-user merge of the ranks' local top-Kp lists (metrics/base.py:189 on the union) */
+int rphip_spd_inverse_f32(rphip_ctx* ctx, float* A_dev, int64_t n, int64_t ld);
+int rphip_transpose_f32(rphip_ctx* ctx, const float* src_dev, int64_t lds, int64_t rows, int64_t cols, float* dst_dev, int64_t ldd);
+int rphip_ease_scale_cols(rphip_ctx* ctx, const rphip_csr* X, float* S_dev, int64_t ld, int64_t n_rows, int64_t col_begin, int64_t n_cols,
+                          double alpha);
+int rphip_model_from_dense_cols(rphip_ctx* ctx, int64_t n_items, int64_t col_begin, int64_t n_cols, float* B_dev, int64_t ld,
+                                rphip_model** out);
+int rphip_predict_merge_topk(rphip_ctx* ctx, int32_t n_lists, int32_t Kp, int64_t n_users, const int32_t* cand_idx_dev,
+                             const float* cand_val_dev, const int32_t* cand_nnz_dev, int32_t* idx_dev, float* val_dev, int32_t* nnz_dev);
+
 /* Cholesky factor (lower) of a 128 x 128 block in place and its inverse into W (ld 128), in float64 internally;
  * *info_dev (device int32) receives pivot + 1 if the block is not positive definite. */
 int rphip_potrf_trtri_128(rphip_ctx* ctx, float* A_dev, int64_t lda, float* W_dev, int32_t* info_dev);

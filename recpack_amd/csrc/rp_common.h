@@ -125,6 +125,7 @@ struct rphip_model {
   bool borrows_B = false;   // B belongs to the caller (rphip_model_from_dense_device)
   bool is_gram = false;     // B holds the plain Gram X^T X (rphip_ease_gram_create): input of rphip_ease_fit_gram, not a model to predict with
   int64_t ld = 0;
+  int64_t col_begin = 0, n_cols = 0;  // n_cols > 0: B holds only the columns [col_begin, col_begin + n_cols) (rphip_model_from_dense_cols)
   int64_t empty_rows = -1;  // rows without any stored similarity (-1: not counted)
 };
 

@@ -822,6 +822,122 @@ extern "C" int rphip_model_from_dense_device(rphip_ctx* ctx, int64_t n_items, fl
 }
 
 
+// ---- building blocks of the COLUMN-SHARDED solve (recpack_amd/dist.py::ease_fit_sharded) ------------------------------------
+// Every rank holds a slab of columns [col_begin, col_begin + n_cols) of the n x n matrix, all rows, row-major with leading
+// dimension ld (= the slab's width).  The inverse is formed in place by block SWEEPS (Goodnight 1979): for a pivot block K with
+// P = A_KK^-1, T = A[:, K] P:   A[:, J] -= T A[K, J] (every other column),  A[K, J] = T[J, :]^T,  A[:, K] = T,  A[K, K] = -P;
+// after all blocks the matrix holds -A^-1.  One panel broadcast per block is the only communication, and a rank's work per block
+// is one plain product on its slab - the same kernel as everything else here (k_gemm_nt).
+
+// In-place inverse of an SPD matrix (n a multiple of 128, row-major, ld): the pivot block of a sweep.
+extern "C" int rphip_spd_inverse_f32(rphip_ctx* ctx, float* A_dev, int64_t n, int64_t ld) {
+  if (!ctx || !A_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if (n <= 0 || (n % GT) || ld < n || (ld % 4)) RP_FAIL(RPHIP_EINVAL, "n %lld must be a positive multiple of 128 and ld %lld >= n, a multiple of 4", (long long)n, (long long)ld);
+  RP_TRY(rp_set_device(ctx));
+  return rp_spd_inverse(ctx, A_dev, (int)n, (long long)ld);
+}
+
+// dst[c][r] = src[r][c]  (rows, cols multiples of 32)
+__global__ void k_transpose_f32(const float* __restrict__ src, long long lds, float* __restrict__ dst, long long ldd) {
+  __shared__ float t[32][33];
+  const long long bx = (long long)blockIdx.x * 32, by = (long long)blockIdx.y * 32;  // bx: column of src, by: row of src
+  for (int r = threadIdx.y; r < 32; r += 8) t[r][threadIdx.x] = src[(by + r) * lds + bx + threadIdx.x];
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += 8) dst[(bx + r) * ldd + by + threadIdx.x] = t[threadIdx.x][r];
+}
+
+extern "C" int rphip_transpose_f32(rphip_ctx* ctx, const float* src_dev, int64_t lds, int64_t rows, int64_t cols, float* dst_dev, int64_t ldd) {
+  if (!ctx || !src_dev || !dst_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if (rows <= 0 || cols <= 0 || (rows % 32) || (cols % 32) || lds < cols || ldd < rows)
+    RP_FAIL(RPHIP_EINVAL, "transpose of %lld x %lld (multiples of 32) with lds %lld, ldd %lld", (long long)rows, (long long)cols, (long long)lds, (long long)ldd);
+  if (cols / 32 > 0x7fffffffLL || rows / 32 > 65535) RP_FAIL(RPHIP_ELIMIT, "transpose of %lld x %lld: at most 2 097 120 rows", (long long)rows, (long long)cols);
+  RP_TRY(rp_set_device(ctx));
+  hipLaunchKernelGGL(k_transpose_f32, dim3((unsigned)(cols / 32), (unsigned)(rows / 32)), dim3(32, 8), 0, ctx->stream, src_dev, (long long)lds, dst_dev,
+                     (long long)ldd);
+  RP_HIP(hipGetLastError());
+  return RPHIP_OK;
+}
+
+// K7 on a column slab holding sign * P[:, col_begin : col_begin + n_cols]: B_ij = -P_ij / P_jj * w_j, B_jj = 0, rows and columns
+// of the padding zeroed (ease.py:85-90; w_j = c_j^-alpha, 0 for items nobody interacted with - the documented deviation)
+__global__ void k_ease_colscale(const float* __restrict__ S, long long ld, int n, int col_begin, int n_cols, const int32_t* __restrict__ deg,
+                                float alpha, float* __restrict__ colscale) {
+  for (int jl = blockIdx.x * blockDim.x + threadIdx.x; jl < n_cols; jl += gridDim.x * blockDim.x) {
+    const int j = col_begin + jl;
+    float sc = 0.0f;
+    if (j < n) {
+      const float d = S[(long long)j * ld + jl];  // sign * P_jj: the sign cancels in P_ij / P_jj
+      float w = 1.0f;
+      if (alpha != 0.0f) w = deg[j] > 0 ? powf((float)deg[j], -alpha) : 0.0f;
+      sc = -w / d;
+    }
+    colscale[jl] = sc;
+  }
+}
+
+__global__ void k_ease_scale_cols(float* __restrict__ S, long long ld, long long n_rows, int n, int col_begin, int n_cols,
+                                  const float* __restrict__ colscale) {
+  const long long total = n_rows * ld;
+  for (long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; e < total; e += (long long)gridDim.x * blockDim.x * 4) {
+    const long long i = e / ld;
+    const int jl = (int)(e % ld);  // ld is a multiple of 4
+    float4 v = *reinterpret_cast<float4*>(S + e);
+    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int q = jl + c;
+      o[c] = (q < n_cols && i < n && (long long)(col_begin + q) != i) ? o[c] * colscale[q] : 0.0f;
+    }
+    *reinterpret_cast<float4*>(S + e) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+extern "C" int rphip_ease_scale_cols(rphip_ctx* ctx, const rphip_csr* X, float* S_dev, int64_t ld, int64_t n_rows, int64_t col_begin,
+                                     int64_t n_cols, double alpha) {
+  if (!ctx || !X || !S_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if (n_rows < X->n_items || col_begin < 0 || n_cols <= 0 || n_cols > ld || (ld % 4) || col_begin + n_cols > n_rows)
+    RP_FAIL(RPHIP_EINVAL, "slab of columns [%lld,%lld) with %lld rows, ld %lld", (long long)col_begin, (long long)(col_begin + n_cols), (long long)n_rows, (long long)ld);
+  RP_TRY(rp_set_device(ctx));
+  float* colscale = nullptr;
+  RP_TRY(rp_scratch(ctx, 5, (size_t)n_cols * 4 + 64, (void**)&colscale));
+  hipEvent_t ev;
+  rp_time_begin(ctx, &ev);
+  hipLaunchKernelGGL(k_ease_colscale, dim3((unsigned)rp_cdiv(n_cols, 256)), dim3(256), 0, ctx->stream, S_dev, (long long)ld, (int)X->n_items,
+                     (int)col_begin, (int)n_cols, X->deg, (float)alpha, colscale);
+  hipLaunchKernelGGL(k_ease_scale_cols, dim3(4096), dim3(256), 0, ctx->stream, S_dev, (long long)ld, (long long)n_rows, (int)X->n_items, (int)col_begin,
+                     (int)n_cols, colscale);
+  RP_HIP(hipGetLastError());
+  rp_time_end(ctx, ev, RPHIP_T_EASE_SCALE, 8.0 * (double)n_rows * (double)n_cols);
+  return RPHIP_OK;
+}
+
+// A dense model that holds the COLUMNS [col_begin, col_begin + n_cols) of B (all n_items rows, leading dimension ld) in
+// caller-owned device memory: predict against it scores only those columns (B sharded by item columns, a
+// local top-Kp per user on every rank, then rphip_predict_merge_topk on the gathered lists).
+extern "C" int rphip_model_from_dense_cols(rphip_ctx* ctx, int64_t n_items, int64_t col_begin, int64_t n_cols, float* B_dev, int64_t ld,
+                                           rphip_model** out) {
+  if (!ctx || !B_dev || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (n_items <= 0 || col_begin < 0 || n_cols <= 0 || col_begin + n_cols > n_items || ld < n_cols || (ld % 64))
+    RP_FAIL(RPHIP_EINVAL, "columns [%lld,%lld) of %lld items, ld %lld (a multiple of 64)", (long long)col_begin, (long long)(col_begin + n_cols),
+            (long long)n_items, (long long)ld);
+  RP_TRY(rp_set_device(ctx));
+  rphip_model* m = new rphip_model();
+  m->ctx = ctx;
+  m->kind = RPHIP_MODEL_DENSE;
+  m->n_items = n_items;
+  m->row_end = n_items;
+  m->ld = ld;
+  m->B = B_dev;
+  m->borrows_B = true;
+  m->col_begin = col_begin;
+  m->n_cols = n_cols;
+  m->empty_rows = -1;  // (not counted on a slab)
+  *out = m;
+  return RPHIP_OK;
+}
+
+
 // ---- EASE_XY (recpack/algorithms/experimental/ease_xy.py:61-96) --------------------------------------------------------
 // B = P (X^T Y) - P diag(diag(P X^T Y) / diag(P)), columns scaled by c_j^-alpha; P = (X^T X + l2 I)^-1 as for EASE.
 // X^T Y is needed with its K index contiguous for the NT product, i.e. as rows of Y^T X: the dense Gram kernel with the

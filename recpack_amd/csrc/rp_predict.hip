@@ -74,6 +74,7 @@ struct rp_pred_params {
   const int32_t* s_nnz;
   const float* dense_B;   // K9: dense model (EASE), row-major with leading dimension dense_ld; NULL for neighbour lists
   long long dense_ld;
+  int col_begin;          // dense column slab: column 0 of dense_B is item col_begin (n_items = the slab's width then)
   const uint8_t* keep;    // optional item filter (mode 0): only items with keep[j] != 0 are candidates
   int n_items, n_tiles, tile_w, K, Kp, exclude_history;
   rp_fix_scale fix;       // neighbour lists: scale of the fixed-point sums
@@ -229,13 +230,13 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_tile(rp_pred_params
       __syncthreads();
       if (P.exclude_history) {
         for (int h = hs + tid; h < he; h += RP_PRED_THREADS) {
-          const int j = P.x_idx[h] - t0;
+          const int j = P.x_idx[h] - P.col_begin - t0;
           if ((unsigned)j < (unsigned)n_cols) clear(j);
         }
         __syncthreads();
       }
       // ---- select (top-Kp: the scores of one user share their sign and most exponent bits - dropped first)
-      rp_score_src<DENSE> src{smem, t0, P.mode == 0 ? P.keep : nullptr, 0};
+      rp_score_src<DENSE> src{smem, t0 + P.col_begin, P.mode == 0 ? P.keep : nullptr, 0};
       if (P.mode == 0) {
         uint32_t* s_red = reinterpret_cast<uint32_t*>(&sel.misc[RPS_USER]);
         if (tid == 0) {
@@ -250,13 +251,13 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_tile(rp_pred_params
       if (P.mode == 0) {
         const int64_t o = (T == 1) ? (int64_t)ul * P.Kp : ((int64_t)ul * T + tile) * P.Kp;
         rp_select_emit<RP_PRED_THREADS>(n_cols, sel, [&](int pos, int w) {
-          P.out_idx[o + pos] = t0 + w;
+          P.out_idx[o + pos] = P.col_begin + t0 + w;
           P.out_val[o + pos] = (float)score(w);
         });
         if (tid == 0) P.out_nnz[(T == 1) ? ul : ul * T + tile] = kp;
       } else if (P.mode == 2) {
         rp_select_emit<RP_PRED_THREADS>(n_cols, sel, [&](int pos, int w) {
-          P.full_idx[off + pos] = t0 + w;
+          P.full_idx[off + pos] = P.col_begin + t0 + w;
           P.full_val[off + pos] = score(w);
         });
         off += kp;
@@ -1019,7 +1020,13 @@ static void rp_pred_fill(rp_pred_params& P, const rphip_model* m, const rphip_cs
   P.dense_ld = m->ld;
   P.keep = nullptr;
   P.n_items = (int)X->n_items;
-  if (m->kind == RPHIP_MODEL_DENSE) {
+  P.col_begin = 0;
+  if (m->kind == RPHIP_MODEL_DENSE && m->n_cols > 0) {  // a column slab: the kernel walks the slab's own columns
+    P.n_items = (int)m->n_cols;
+    P.col_begin = (int)m->col_begin;
+    P.n_tiles = (int)std::max<int64_t>(1, rp_cdiv(m->n_cols, RP_TILE_MAX));
+    P.tile_w = (int)(rp_cdiv(rp_cdiv(m->n_cols, P.n_tiles), 64) * 64);
+  } else if (m->kind == RPHIP_MODEL_DENSE) {
     P.n_tiles = X->n_tiles;
     P.tile_w = X->tile_w;
   } else {  // 8-byte sums: narrower tiles than K0's plan
@@ -1064,7 +1071,7 @@ static int rp_pred_launch(rphip_ctx* ctx, const rp_pred_params& P, int grid) {
 static double rp_pred_work(const rphip_csr* X, const rphip_model* m, int64_t n_users, int Kp) {
   const double share = X->n_users > 0 ? (double)n_users / (double)X->n_users : 0.0;
   if (m->kind == RPHIP_MODEL_DENSE)  // K9: 4*I*nnz_pred (rows of B streamed) + 8*U*Kp
-    return 4.0 * (double)m->n_items * (double)X->nnz * share + 8.0 * (double)n_users * Kp;
+    return 4.0 * (double)(m->n_cols > 0 ? m->n_cols : m->n_items) * (double)X->nnz * share + 8.0 * (double)n_users * Kp;
   return 8.0 * m->K * (double)X->nnz * share + 4.0 * ((double)X->nnz * share + (double)n_users) + 8.0 * (double)n_users * Kp;
 }
 
@@ -1216,6 +1223,33 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
   }
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, RPHIP_T_PREDICT, rp_pred_work(Xpred, model, n, Kp));
+  return RPHIP_OK;
+}
+
+// Merge of per-user candidate lists (e.g. the local top-Kp of every rank's column slab, gathered): cand_idx / cand_val
+// [n_users][n_lists][Kp], cand_nnz [n_users][n_lists] (device) -> the best Kp of each user's union by (score desc, column asc),
+// columns ascending in the output row - the order of the single-GPU result.
+extern "C" int rphip_predict_merge_topk(rphip_ctx* ctx, int32_t n_lists, int32_t Kp, int64_t n_users, const int32_t* cand_idx_dev,
+                                        const float* cand_val_dev, const int32_t* cand_nnz_dev, int32_t* idx_dev, float* val_dev,
+                                        int32_t* nnz_dev) {
+  if (!ctx || !cand_idx_dev || !cand_val_dev || !cand_nnz_dev || !idx_dev || !val_dev || !nnz_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if (n_lists < 1 || Kp < 1 || Kp > RP_K_MAX || n_users < 0) RP_FAIL(RPHIP_EINVAL, "n_lists %d, Kp %d, n_users %lld", n_lists, Kp, (long long)n_users);
+  RP_TRY(rp_set_device(ctx));
+  if (n_users == 0) return RPHIP_OK;
+  const size_t mlds = (size_t)n_lists * Kp * 8 + rp_select_smem_bytes(n_lists * Kp);
+  if (mlds > 160 * 1024 || n_lists * Kp >= RPS_FLAG)
+    RP_FAIL(RPHIP_ELIMIT, "Kp=%d with %d lists needs %zu bytes of LDS for the merge", Kp, n_lists, mlds);
+  hipStream_t st = ctx->stream;
+  hipMemsetAsync(idx_dev, 0xFF, (size_t)n_users * Kp * 4, st);
+  hipMemsetAsync(val_dev, 0, (size_t)n_users * Kp * 4, st);
+  RP_HIP(hipFuncSetAttribute((const void*)k_predict_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+  const int mg = (int)std::min<int64_t>(n_users, (int64_t)ctx->n_cu * 8);
+  hipEvent_t ev;
+  rp_time_begin(ctx, &ev);
+  hipLaunchKernelGGL(k_predict_merge, dim3(mg), dim3(RP_PRED_THREADS), mlds, st, cand_idx_dev, cand_val_dev, cand_nnz_dev, (int)n_lists, (int)Kp,
+                     (int)n_users, nullptr, nullptr, idx_dev, val_dev, nnz_dev);
+  RP_HIP(hipGetLastError());
+  rp_time_end(ctx, ev, RPHIP_T_PREDICT, 16.0 * (double)n_users * n_lists * Kp);
   return RPHIP_OK;
 }
 

@@ -129,8 +129,156 @@ def fit_itemknn_sharded(ctx, dX, K: int, parts: Sequence[Tuple[int, int]], devic
     return _lib.Model.from_topk_device(ctx, idx_f, val_f, nnz_f)
 
 
-def ease_fit_sharded(ctx, dX, l2: float, alpha: float, device, group=None, panel_tiles: int = 16):
-    """EASE fit (recpack/algorithms/ease.py:63-95) on all ranks of ``group``, one GPU each.
+def ease_fit_sharded(ctx, dX, l2: float, alpha: float, device, group=None, panel_tiles: int = 8):
+    """EASE fit (recpack/algorithms/ease.py:63-95) with the n x n matrix SHARDED BY ITEM COLUMNS over the ranks of ``group``,
+    one GPU each.  Rank r owns the columns [r w, (r + 1) w) of everything, w = n_pad / world: a slab
+    of n_pad x w floats - G + l2 I first, -(G + l2 I)^-1 after the solve, its columns of B at the end.  Peak memory per rank:
+    the slab (n^2 * 4 / world bytes) + two panels of n_pad x (128 panel_tiles) + a Gram staging buffer of the same order.
+
+    The inverse is formed IN PLACE by block sweeps (Goodnight 1979; the symmetric Gauss-Jordan form of np.linalg.inv, ease.py:82).
+    For the pivot block K (128 panel_tiles columns, owned by one rank) with P = A_KK^-1 and T = A[:, K] P:
+        A[:, J] -= T A[K, J]  for every other column block J,   A[K, J] = T[J, :]^T,   A[:, K] = T,   A[K, K] = -P,
+    and after the last block the matrix is -(G + l2 I)^-1.  Per block: the owner inverts the pivot block (blocked Cholesky on
+    MFMA tiles, rphip_spd_inverse_f32) and broadcasts its panel column with P appended (n_pad * nb * 4 bytes - the only
+    communication, n^2 * 4 bytes over the whole solve); every rank forms T (a skinny product, repeated on every rank: 2 n nb^2
+    flop) and updates its slab with ONE plain product A[:, J] -= T A[J, K]^T (A is symmetric, so the rows J of the broadcast
+    panel are A[K, J]^T) on the same MFMA kernel as the single-GPU solve.  The update touches both triangles (2 n^3 / world flop
+    per rank against n^3 for the single-GPU Cholesky route): what that buys is no distributed triangular phases, no mirror
+    exchange, a layout that never changes - and the columns a rank ends up with are exactly what the column-sharded predict
+    (predict_topk_sharded) needs.  Accuracy: the same as the Cholesky route (tests: 1e-4 bar against float64).
+    Returns (model on this rank's slab or None when the rank owns only padding, (col_begin, n_cols)).
+    """
+    import torch
+    import torch.distributed as dist
+
+    from recpack_amd import _lib
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    T = 128
+    n = dX.shape[1]
+    n_pad = -(-n // (T * world)) * (T * world)
+    w = n_pad // world
+    c0 = rank * w
+    lib_stream_is_torchs = ctx.stream is not None and int(torch.cuda.current_stream().cuda_stream) == ctx.stream
+
+    def to_torch():  # library work -> visible to torch's stream
+        if not lib_stream_is_torchs:
+            ctx.sync()
+
+    def src_rank(r):
+        return dist.get_global_rank(group, r) if group is not None else r
+
+    S = torch.empty((n_pad, w), dtype=torch.float32, device=device)
+    # ---- G + l2 I, this rank's columns: Gram ROWS [c0, c0 + w) in chunks (K4), transposed into the slab (G is symmetric)
+    ch_rows = min(w, max(T, min(8 * T, int(0.08 * n_pad) // T * T)))  # the staging buffer stays within ~8 % of n_pad^2 floats
+    stage = torch.empty((ch_rows, n_pad), dtype=torch.float32, device=device)
+    for q in range(0, w, ch_rows):
+        ch = min(ch_rows, w - q)
+        _lib.ease_gram_rows_into(ctx, dX, c0 + q, c0 + q + ch, l2, stage, n_pad)
+        _lib.transpose(ctx, stage[:ch], S[:, q:q + ch])
+    to_torch()
+    del stage
+    # ---- the sweeps
+    pb_cols = min(w, max(1, panel_tiles) * T)
+    pbuf = torch.empty(((n_pad + pb_cols) * pb_cols,), dtype=torch.float32, device=device)
+    tbuf = torch.empty((n_pad * pb_cols,), dtype=torch.float32, device=device)
+    bad = None
+    for owner in range(world):
+        for q in range(0, w, pb_cols):
+            nb = min(pb_cols, w - q)
+            k0 = owner * w + q
+            k1 = k0 + nb
+            Pv = pbuf[: (n_pad + nb) * nb].view(n_pad + nb, nb)  # rows [0, n_pad): the panel column; then P
+            if rank == owner:
+                Pv[:n_pad].copy_(S[:, q:q + nb])
+                Pv[n_pad:].copy_(Pv[k0:k1])
+                try:
+                    _lib.spd_inverse(ctx, Pv[n_pad:])
+                except _lib.RecpackHipError as e:  # not positive definite: tell everyone through the panel
+                    bad = e
+                    Pv[n_pad:].fill_(float("nan"))
+                to_torch()
+            if dist.is_initialized():
+                dist.broadcast(Pv, src=src_rank(owner), group=group)
+            if bool(torch.isnan(Pv[n_pad, 0])):
+                raise bad if bad is not None else _lib.RecpackHipError(-8, f"pivot block at column {k0} is not positive definite (reported by rank {owner})")
+            Tv = tbuf[: n_pad * nb].view(n_pad, nb)
+            _lib.gemm_nt(ctx, Pv[:n_pad], Pv[n_pad:], Tv)                       # T = A[:, K] P   (P symmetric)
+            _lib.gemm_nt(ctx, Tv, Pv[c0:c0 + w], S, alpha=-1.0, beta=1.0)       # A[:, J] -= T A[J, K]^T
+            _lib.transpose(ctx, Tv[c0:c0 + w], S[k0:k1])                        # A[K, J] = T[J, :]^T
+            if rank == owner:
+                to_torch()
+                S[:, q:q + nb].copy_(Tv)                                        # A[:, K] = T
+                S[k0:k1, q:q + nb].copy_(Pv[n_pad:]).neg_()                     # A[K, K] = -P
+            to_torch()
+    del pbuf, tbuf
+    # ---- K7 on the slab: B_ij = -P_ij / P_jj * w_j, B_jj = 0 (ease.py:85-90); the slab holds -P, the sign cancels
+    _lib.ease_scale_cols(ctx, dX, S, c0, alpha)
+    to_torch()
+    n_cols = max(0, min(w, n - c0))
+    if n_cols == 0:
+        return None, (c0, 0)
+    return _lib.Model.from_dense_cols(ctx, n, c0, n_cols, S), (c0, n_cols)
+
+
+def predict_topk_sharded(ctx, model, dX, Kp: int, device, exclude_history: bool = False, group=None, user_chunk: int = 1 << 18):
+    """Top-Kp for every user with B sharded by item columns: every rank scores ALL users against its own
+    columns (`model` = ease_fit_sharded's slab model, None on a rank that owns only padding) and keeps a local top-Kp; the lists
+    are all-gathered (U * Kp * 8 bytes per rank) and merged per user by (score desc, column asc) - the single-GPU order.  The
+    merge of a chunk of users is split over the ranks; returns this rank's part: (user_ids int64 [m], idx int32 [m, Kp],
+    val float32 [m, Kp], nnz int32 [m]) as torch tensors.  Users are processed in chunks of ``user_chunk``."""
+    import torch
+    import torch.distributed as dist
+
+    from recpack_amd import _lib
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    U = dX.shape[0]
+    out_u, out_i, out_v, out_n = [], [], [], []
+    for u0 in range(0, U, user_chunk):
+        u1 = min(U, u0 + user_chunk)
+        nu = u1 - u0
+        li = torch.full((nu, Kp), -1, dtype=torch.int32, device=device)
+        lv = torch.zeros((nu, Kp), dtype=torch.float32, device=device)
+        ln = torch.zeros((nu,), dtype=torch.int32, device=device)
+        if model is not None:
+            _lib.predict_topk_dev(ctx, model, dX, Kp, li, lv, ln, exclude_history=exclude_history, user_begin=u0, user_end=u1)
+            ctx.sync()
+        if world > 1:
+            gi = torch.empty((world, nu, Kp), dtype=torch.int32, device=device)
+            gv = torch.empty((world, nu, Kp), dtype=torch.float32, device=device)
+            gn = torch.empty((world, nu), dtype=torch.int32, device=device)
+            dist.all_gather_into_tensor(gi, li, group=group)
+            dist.all_gather_into_tensor(gv, lv, group=group)
+            dist.all_gather_into_tensor(gn, ln, group=group)
+        else:
+            gi, gv, gn = li[None], lv[None], ln[None]
+        per = -(-nu // world)
+        a, b = min(nu, rank * per), min(nu, (rank + 1) * per)
+        if b > a:
+            ci = gi[:, a:b].permute(1, 0, 2).contiguous()
+            cv = gv[:, a:b].permute(1, 0, 2).contiguous()
+            cn = gn[:, a:b].t().contiguous()
+            oi = torch.empty((b - a, Kp), dtype=torch.int32, device=device)
+            ov = torch.empty((b - a, Kp), dtype=torch.float32, device=device)
+            on = torch.empty((b - a,), dtype=torch.int32, device=device)
+            _lib.predict_merge_topk(ctx, ci, cv, cn, oi, ov, on)
+            ctx.sync()
+            out_u.append(torch.arange(u0 + a, u0 + b, device=device))
+            out_i.append(oi)
+            out_v.append(ov)
+            out_n.append(on)
+    if not out_u:
+        return (torch.empty((0,), dtype=torch.int64, device=device), torch.empty((0, Kp), dtype=torch.int32, device=device),
+                torch.empty((0, Kp), dtype=torch.float32, device=device), torch.empty((0,), dtype=torch.int32, device=device))
+    return torch.cat(out_u), torch.cat(out_i), torch.cat(out_v), torch.cat(out_n)
+
+
+def ease_fit_replicated(ctx, dX, l2: float, alpha: float, device, group=None, panel_tiles: int = 16):
+    """EASE fit on all ranks with the matrix REPLICATED (the faster route while n^2 * 4 bytes fit every GPU: n^3 / world flop per
+    rank through the Cholesky phases, against 2 n^3 / world for the column-sharded sweeps of ease_fit_sharded).
 
     Every rank keeps ONE n x n float32 matrix: first G + l2*I, then the Cholesky factor L below the diagonal and
     N = L^-T on and above it (a diagonal block is only needed until its panel is done, then it holds N's block), finally B.

@@ -256,15 +256,17 @@ def _run_dist_check(nproc, args=()):
     return subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
 
 
-@pytest.mark.parametrize("nproc,shape", [(2, (4000, 700, 0.02, 2)), (3, (3000, 1000, 0.01, 3)), (2, (3000, 1000, 0.01, 16))])
+@pytest.mark.parametrize("nproc,shape", [(2, (4000, 700, 0.02, 2)), (3, (3000, 1000, 0.01, 3)), (2, (3000, 1000, 0.01, 16)),
+                                         (3, (12000, 3000, 0.005, 4))])  # (the last one is large enough for the memory bound to apply)
 def test_ease_fit_sharded_multi_rank(hip, nproc, shape):
-    """recpack_amd.dist.ease_fit_sharded (wide panels with the rows split over the ranks + all-gather)
-    with several ranks gives every rank the B of the single-GPU solve (max relative difference 2e-5 allowed) and the same
-    top-K.  The fourth number is the panel width in tiles: 2 and 3 give several wide panels at these sizes (the last one
-    short), 16 is the default (one panel here)."""
+    """Both multi-GPU routes of recpack_amd.dist with several ranks (gloo, sharing this box's GPU):
+    ease_fit_replicated gives every rank the B of the single-GPU solve (2e-5) and the same top-K; ease_fit_sharded gives every
+    rank its COLUMNS of B (1e-4) within n_pad^2 * 4 * (1 / world + 0.1) bytes of device memory, and predict_topk_sharded (local
+    top-Kp per column slab, all-gather, merge) reproduces the single-GPU top-K.  The fourth number is the panel width in
+    tiles: 2 and 3 give several panels at these sizes (the last one short), 16 is the replicated route's default."""
     r = _run_dist_check(nproc, shape)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count("top-20 agreement") == 2 * nproc
+    assert r.stdout.count("top-20 agreement") == 4 * nproc
 
 
 def test_ease_fit_sharded_one_rank(hip):
@@ -277,11 +279,28 @@ def test_ease_fit_sharded_one_rank(hip):
     X = powerlaw_csr(6000, 1500, 0.008, seed=77).to_scipy()
     dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
     ref = onp.ease_fit(X, 20.0, 0.0)
+    dev = torch.device("cuda", 0)
     for panel_tiles in (16, 5):  # 12 tiles: one panel; three panels, the last one short
-        m = rdist.ease_fit_sharded(ctx, dX, 20.0, 0.0, torch.device("cuda", 0), panel_tiles=panel_tiles)
+        m = rdist.ease_fit_replicated(ctx, dX, 20.0, 0.0, dev, panel_tiles=panel_tiles)
         assert rel_max(m.dense_download(), ref) <= EASE_TOL
+        del m
     with pytest.raises(_lib.RecpackHipError):
-        rdist.ease_fit_sharded(ctx, dX, 0.0, 0.0, torch.device("cuda", 0))
+        rdist.ease_fit_replicated(ctx, dX, 0.0, 0.0, dev)
+    # the column-sharded route on one rank (one slab = the whole matrix): block sweeps, K7 on the slab, predict + merge
+    single = _lib.ease_fit(ctx, dX, 20.0, 0.0)
+    want = _lib.predict_topk(ctx, single, dX, 30, exclude_history=True)
+    for panel_tiles in (8, 5, 1):
+        ms, (c0, nc) = rdist.ease_fit_sharded(ctx, dX, 20.0, 0.0, dev, panel_tiles=panel_tiles)
+        assert (c0, nc) == (0, 1500)
+        B = ms._keep[:1500, :1500].cpu().numpy()
+        assert rel_max(B, ref) <= EASE_TOL, (panel_tiles, rel_max(B, ref))
+        users, pi, pv, pn = rdist.predict_topk_sharded(ctx, ms, dX, 30, dev, exclude_history=True, user_chunk=2500)
+        assert (users.cpu().numpy() == np.arange(6000)).all()
+        assert (pn.cpu().numpy() == want[2]).all()
+        assert (pi.cpu().numpy() == want[0]).mean() > 0.999
+        del ms
+    with pytest.raises(_lib.RecpackHipError):
+        rdist.ease_fit_sharded(ctx, dX, 0.0, 0.0, dev)
 
 
 def test_ease_fit_sharded_rccl_one_rank(hip):

@@ -1,0 +1,10 @@
+#!/bin/bash
+# round-2 measurement pass on the GPU box: bench line, kernel stats of the same command, PMC passes
+cd "$GRAFT_REPO_ROOT"
+python3 bench.py --steps 20 --warmup 5 > gpurun_out/bench_r02.json 2> gpurun_out/bench_r02.err; tail -c 600 gpurun_out/bench_r02.json
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r02 -- python3 bench.py --steps 5 --warmup 2 --cpu-baseline-seconds 0 > gpurun_out/prof_r02.log 2>&1
+bash tools/pmc_traffic.sh > gpurun_out/pmc_traffic.txt 2>&1
+bash tools/pmc_sq.sh k_ C4 > gpurun_out/pmc_sq_all.txt 2>&1
+bash tools/pmc_mfma.sh > gpurun_out/pmc_mfma.txt 2>&1
+tail -5 gpurun_out/pmc_mfma.txt

@@ -29,13 +29,25 @@ torch.cuda.set_stream(stream)
 ctx = _lib.Context(local, stream.cuda_stream)
 ip, ix = powerlaw_csr(U, I, dens, seed=20260003, device=dev)
 dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
+route = sys.argv[5] if len(sys.argv) > 5 else "columns"
+pt = int(sys.argv[6]) if len(sys.argv) > 6 else 8
 for it in range(2):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    m = rdist.ease_fit_sharded(ctx, dX, l2, 0.0, dev)
+    if route == "columns":
+        m, cols = rdist.ease_fit_sharded(ctx, dX, l2, 0.0, dev, panel_tiles=pt)
+    else:
+        m = rdist.ease_fit_replicated(ctx, dX, l2, 0.0, dev)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:
         n_pad = -(-I // (128 * world)) * 128 * world
-        print(f"world {world}: I={I} sharded fit {dt*1e3:.1f} ms = {n_pad**3 / dt / 1e12:.1f} TF/s by the n^3 model", flush=True)
+        fl = 2.0 if route == "columns" else 1.0
+        print(f"world {world}: I={I} {route} fit {dt*1e3:.1f} ms = {fl * n_pad**3 / dt / 1e12:.1f} TF/s by the {fl:.0f} n^3 model", flush=True)
+    if route == "columns" and it == 1:
+        t0 = time.perf_counter()
+        rdist.predict_topk_sharded(ctx, m, dX, 100, dev)
+        torch.cuda.synchronize()
+        if rank == 0:
+            print(f"world {world}: sharded predict + top-100 of {U} users {1e3 * (time.perf_counter() - t0):.1f} ms", flush=True)
     del m
