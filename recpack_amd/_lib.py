@@ -618,8 +618,7 @@ def predict_topk_dev(ctx: Context, model: Model, X: DeviceCSR, Kp: int, idx_t, v
     """Outputs into torch CUDA tensors idx int32[n,Kp], val float32[n,Kp], nnz int32[n]; asynchronous.
     item_keep_t: optional torch uint8 CUDA tensor [n_items]."""
     user_end = X.shape[0] if user_end is None else user_end
-    if item_keep_t is not None:
-        _torch_inputs_ready(ctx)
+    _torch_inputs_ready(ctx)  # (also orders any pending torch fill of the OUTPUT tensors before the library's own writes)
     check(ctx.lib.rphip_predict_topk_filtered_dev(ctx.handle, model.handle, X.handle, int(user_begin), int(user_end), int(Kp),
                                                   1 if exclude_history else 0,
                                                   C.c_void_p(item_keep_t.data_ptr()) if item_keep_t is not None else None,

@@ -250,9 +250,9 @@ def predict_topk_sharded(ctx, model, dX, Kp: int, device, exclude_history: bool 
             gi = torch.empty((world, nu, Kp), dtype=torch.int32, device=device)
             gv = torch.empty((world, nu, Kp), dtype=torch.float32, device=device)
             gn = torch.empty((world, nu), dtype=torch.int32, device=device)
-            dist.all_gather_into_tensor(gi, li, group=group)
-            dist.all_gather_into_tensor(gv, lv, group=group)
-            dist.all_gather_into_tensor(gn, ln, group=group)
+            dist.all_gather_into_tensor(gi.view(world * nu, Kp), li, group=group)  # (output = the inputs concatenated along dim 0)
+            dist.all_gather_into_tensor(gv.view(world * nu, Kp), lv, group=group)
+            dist.all_gather_into_tensor(gn.view(world * nu), ln, group=group)
         else:
             gi, gv, gn = li[None], lv[None], ln[None]
         per = -(-nu // world)
