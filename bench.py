@@ -430,7 +430,10 @@ def main():
     keep = {}
 
     def step():
-        dX = _lib.DeviceCSR.from_device(ctx, indptr_t, indices_t, (U, I), fit_rows=row_parts[rank] if world > 1 else None)  # K0
+        if world > 1:  # K0 with the degree pass sharded by item rows + one all-reduce of the degree vector
+            dX = rdist.csr_for_shard(ctx, indptr_t, indices_t, (U, I), row_parts[rank], device)
+        else:
+            dX = _lib.DeviceCSR.from_device(ctx, indptr_t, indices_t, (U, I))  # K0
         if world == 1:
             model = _lib.itemknn_fit(ctx, dX, args.K)  # K1-K3
         else:

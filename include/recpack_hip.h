@@ -128,6 +128,15 @@ int rphip_csr_from_device(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int6
  * and predict are complete.  fit_row_end < 0 = all rows. */
 int rphip_csr_from_device_rows(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_t nnz, const int32_t* indptr_dev,
                                const int32_t* indices_dev, int64_t fit_row_begin, int64_t fit_row_end, rphip_csr** out);
+/* one shard of a multi-GPU fit with the degree pass SHARDED as well: the histogram and the in-row ranks of K0 are computed for the
+ * item rows [fit_row_begin, fit_row_end) only (1 / world of K0's atomics).  The handle is not usable for a fit until the caller
+ * has summed the degree arrays of all shards - rphip_csr_degrees_device gives the int32[n_items] device array for ONE
+ * all-reduce (RCCL over xGMI through torch.distributed in recpack_amd/dist.py::csr_for_shard; 4 * n_items bytes) - and called
+ * rphip_csr_finish_degrees.  (The reference has no multi-GPU path: base.py:454-455.) */
+int rphip_csr_from_device_shard(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_t nnz, const int32_t* indptr_dev,
+                                const int32_t* indices_dev, int64_t fit_row_begin, int64_t fit_row_end, rphip_csr** out);
+int rphip_csr_degrees_device(rphip_csr* X, int32_t** deg_dev);
+int rphip_csr_finish_degrees(rphip_ctx* ctx, rphip_csr* X);
 /* from raw (user id, item id) pairs, int64 as pandas holds them, in any order and with repeats: what
  * InteractionMatrix.values builds from its DataFrame (recpack/matrix/interaction_matrix.py:202-217:
  * csr_matrix((ones, (uid, iid)), shape), duplicates summed) before the path binarises it - here the DISTINCT pairs,

@@ -66,6 +66,9 @@ PROTOTYPES = {
     "rphip_csr_from_host": (C.c_int, [_p, _i64, _i64, _i64, _p, C.c_int, _p, _pp]),
     "rphip_csr_from_device": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _pp]),
     "rphip_csr_from_device_rows": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _i64, _i64, _pp]),
+    "rphip_csr_from_device_shard": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _i64, _i64, _pp]),
+    "rphip_csr_degrees_device": (C.c_int, [_p, _pp]),
+    "rphip_csr_finish_degrees": (C.c_int, [_p, _p]),
     "rphip_csr_from_coo_host": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _pp]),
     "rphip_csr_from_coo_device": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _pp]),
     "rphip_csr_download": (C.c_int, [_p, _p, _p, _p]),
@@ -258,6 +261,27 @@ class DeviceCSR:
         check(ctx.lib.rphip_csr_from_device_rows(ctx.handle, int(shape[0]), int(shape[1]), int(indices_t.numel()),
                                                  C.c_void_p(indptr_t.data_ptr()), C.c_void_p(indices_t.data_ptr()), b, e, C.byref(h)))
         return cls(ctx, h, keepalive=(indptr_t, indices_t))
+
+    @classmethod
+    def from_device_shard(cls, ctx: Context, indptr_t, indices_t, shape, fit_rows):
+        """A shard's matrix whose degree pass is sharded too (rphip_csr_from_device_shard): degrees hold the item rows
+        ``fit_rows`` only until the caller has all-reduced ``degrees_device_ptr()`` and called ``finish_degrees()``
+        (recpack_amd.dist.csr_for_shard does both)."""
+        _torch_inputs_ready(ctx)
+        h = C.c_void_p()
+        check(ctx.lib.rphip_csr_from_device_shard(ctx.handle, int(shape[0]), int(shape[1]), int(indices_t.numel()),
+                                                  C.c_void_p(indptr_t.data_ptr()), C.c_void_p(indices_t.data_ptr()), int(fit_rows[0]),
+                                                  int(fit_rows[1]), C.byref(h)))
+        return cls(ctx, h, keepalive=(indptr_t, indices_t))
+
+    def degrees_device_ptr(self) -> int:
+        p = C.c_void_p()
+        check(self.ctx.lib.rphip_csr_degrees_device(self.handle, C.byref(p)))
+        return int(p.value)
+
+    def finish_degrees(self):
+        _torch_inputs_ready(self.ctx)
+        check(self.ctx.lib.rphip_csr_finish_degrees(self.ctx.handle, self.handle))
 
     @classmethod
     def from_coo(cls, ctx: Context, uid, iid, shape):

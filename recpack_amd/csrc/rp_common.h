@@ -96,6 +96,8 @@ struct rphip_csr {
   bool sorted_rows = false;
   int max_user_deg = 0;            // longest history (bounds |score| for predict's fixed-point scale)
   int64_t xt_row_begin = 0, xt_row_end = -1;  // item rows of X^T that were filled (-1: all); fit is limited to them
+  bool deg_partial = false;        // rphip_csr_from_device_shard: deg holds the rows [xt_row_begin, xt_row_end) only until the
+                                   // caller's all-reduce + rphip_csr_finish_degrees
   // optional float64 values of the stored entries (rphip_csr_set_values): the reference's weighted matrices
   // (time decay, time_aware_item_knn/base.py:181-201).  NULL: the matrix is binary.
   double* x_val = nullptr;         // [nnz], order of x_idx

@@ -21,12 +21,13 @@
 // (chunk of nnz, range) counts its entries with returning LDS atomics (= rank inside the block), reserves a
 // span per item with ONE global atomic per (block, item), then adds the span's base to the stored ranks.
 // A popular item (84 % of the users at 1M x 100K) costs n_chunks global atomics instead of one per interaction.
+// Only items in [item_lo, item_hi) are counted (a shard's K0: the degrees of the other items come from an all-reduce).
 __global__ void __launch_bounds__(1024) k_rank_hist_ranges(const int32_t* __restrict__ idx, long long nnz, long long chunk, int n_items,
                                                           int range_w, int32_t* __restrict__ deg, int32_t* __restrict__ rank,
-                                                          int32_t* __restrict__ err) {
+                                                          int32_t* __restrict__ err, int item_lo, int item_hi) {
   extern __shared__ __attribute__((aligned(16))) char smem_h[];
   int* cnt = reinterpret_cast<int*>(smem_h);
-  const int lo = blockIdx.y * range_w, hi = min(n_items, lo + range_w);
+  const int lo = item_lo + blockIdx.y * range_w, hi = min(item_hi, lo + range_w);
   const long long k0 = (long long)blockIdx.x * chunk, k1 = min(nnz, k0 + chunk);
   for (int w = threadIdx.x; w < range_w; w += 1024) cnt[w] = 0;
   __syncthreads();
@@ -149,15 +150,19 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
   const int32_t h_err = h_chk[0];
   m->max_user_deg = h_chk[4];
   if (h_err) RP_FAIL(RPHIP_EINVAL, "indptr is not a valid row pointer array (not monotone, or indptr[0] != 0, or indptr[-1] != nnz)");
-  if (nnz > 0) {
-    const int n_ranges = (int)rp_cdiv(I, 32768);
-    const int range_w = (int)rp_cdiv(I, n_ranges);
+  // a shard with deg_partial counts (and ranks) only the item rows it will fit: 1 / world of the LDS and global atomics
+  const int64_t i_lo = m->deg_partial ? std::max<int64_t>(0, m->xt_row_begin) : 0;
+  const int64_t i_hi = m->deg_partial ? (m->xt_row_end < 0 ? I : std::min<int64_t>(I, m->xt_row_end)) : I;
+  if (nnz > 0 && I > 0) {
+    const int64_t span = std::max<int64_t>(1, i_hi - i_lo);
+    const int n_ranges = (int)rp_cdiv(span, 32768);
+    const int range_w = (int)rp_cdiv(span, n_ranges);
     const long long target_blocks = std::max<long long>(1, (long long)ctx->n_cu * 3 / n_ranges);
     const long long chunk = std::max<long long>(4096, rp_cdiv(nnz, target_blocks));
     const size_t hl = (size_t)range_w * 4;
     RP_HIP(hipFuncSetAttribute((const void*)k_rank_hist_ranges, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
     hipLaunchKernelGGL(k_rank_hist_ranges, dim3((unsigned)rp_cdiv(nnz, chunk), n_ranges), dim3(1024), hl, st, m->x_idx, (long long)nnz, chunk,
-                       (int)I, range_w, m->deg, rank, err);
+                       (int)I, range_w, m->deg, rank, err, (int)i_lo, (int)i_hi);
   }
   RP_TRY(rp_exclusive_scan_i32(ctx, m->deg, m->xt_ptr, I));
   if (m->n_tiles > 1) RP_TRY(rp_dev_alloc(ctx, (size_t)std::max<int64_t>(U, 1) * (m->n_tiles + 1) * sizeof(int32_t), (void**)&m->tile_ptr));
@@ -167,8 +172,9 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
                        (int)I, m->n_tiles, m->tile_w, m->tile_ptr, err, (int)std::max<int64_t>(0, m->xt_row_begin),
                        (int)(m->xt_row_end < 0 ? I : std::min<int64_t>(I, m->xt_row_end)));
   }
-  hipLaunchKernelGGL(k_inv_deg, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, rp_cdiv(I, bt)))), dim3(bt), 0, st,
-                     m->deg, m->inv_deg, (int)I);
+  if (!m->deg_partial)  // (a shard's degrees are completed by rphip_csr_finish_degrees after the all-reduce)
+    hipLaunchKernelGGL(k_inv_deg, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, rp_cdiv(I, bt)))), dim3(bt), 0, st,
+                       m->deg, m->inv_deg, (int)I);
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, RPHIP_T_CSR_TRANSPOSE, 12.0 * (double)nnz + 4.0 * (double)(U + I + 2) + 4.0 * (double)(I + 1));
   struct {
@@ -278,6 +284,57 @@ extern "C" int rphip_csr_from_device_rows(rphip_ctx* ctx, int64_t n_users, int64
     return r;
   }
   *out = m;
+  return RPHIP_OK;
+}
+
+// A shard's matrix for the multi-GPU fit (north_star: "all-reduce over xGMI"): like
+// rphip_csr_from_device_rows, but the degree histogram and the in-row ranks are computed for the item rows [fit_row_begin,
+// fit_row_end) only - the shard's share of K0's atomics.  The handle is NOT usable for a fit until the caller has summed the
+// degree arrays of all shards (rphip_csr_degrees_device -> one all-reduce of n_items int32) and called rphip_csr_finish_degrees.
+extern "C" int rphip_csr_from_device_shard(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_t nnz, const int32_t* indptr_dev,
+                                           const int32_t* indices_dev, int64_t fit_row_begin, int64_t fit_row_end, rphip_csr** out) {
+  if (!ctx || !out || !indptr_dev || (nnz > 0 && !indices_dev)) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  RP_TRY(rp_csr_check_shape(n_users, n_items, nnz));
+  if (fit_row_begin < 0 || fit_row_begin > fit_row_end || fit_row_end > n_items)
+    RP_FAIL(RPHIP_EINVAL, "fit row range [%lld,%lld) outside 0..%lld", (long long)fit_row_begin, (long long)fit_row_end, (long long)n_items);
+  RP_TRY(rp_set_device(ctx));
+  rphip_csr* m = new rphip_csr();
+  m->xt_row_begin = fit_row_begin;
+  m->xt_row_end = fit_row_end;
+  m->deg_partial = true;
+  m->ctx = ctx;
+  m->n_users = n_users;
+  m->n_items = n_items;
+  m->nnz = nnz;
+  m->owns_x = false;
+  m->x_ptr = indptr_dev;
+  m->x_idx = indices_dev;
+  int r = rp_csr_prepare(ctx, m);
+  if (r != RPHIP_OK) {
+    rphip_csr_destroy(m);
+    return r;
+  }
+  *out = m;
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_csr_degrees_device(rphip_csr* m, int32_t** deg_dev) {
+  if (!m || !deg_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *deg_dev = m->deg;
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_csr_finish_degrees(rphip_ctx* ctx, rphip_csr* m) {
+  if (!ctx || !m) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  RP_TRY(rp_set_device(ctx));
+  hipEvent_t ev;
+  rp_time_begin(ctx, &ev);
+  hipLaunchKernelGGL(k_inv_deg, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, rp_cdiv(m->n_items, 256)))), dim3(256), 0, ctx->stream,
+                     m->deg, m->inv_deg, (int)m->n_items);
+  RP_HIP(hipGetLastError());
+  rp_time_end(ctx, ev, RPHIP_T_CSR_TRANSPOSE, 12.0 * (double)m->n_items);
+  m->deg_partial = false;
   return RPHIP_OK;
 }
 

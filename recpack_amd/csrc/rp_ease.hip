@@ -738,6 +738,7 @@ extern "C" int rphip_ease_gram_rows(rphip_ctx* ctx, const rphip_csr* X, int64_t 
     RP_FAIL(RPHIP_EINVAL, "rows [%lld,%lld) of a %lld-column matrix with ld %lld", (long long)row_begin, (long long)row_end,
             (long long)n_cols, (long long)ld);
   if (!(l2 > 0.0)) RP_FAIL(RPHIP_EINVAL, "l2 must be > 0 (got %g)", l2);
+  if (X->deg_partial) RP_FAIL(RPHIP_ESTATE, "the shard's degrees are not complete (rphip_csr_finish_degrees)");
   if (X->xt_row_end >= 0 && (row_begin < X->xt_row_begin || std::min<int64_t>(row_end, X->n_items) > X->xt_row_end))
     RP_FAIL(RPHIP_ESTATE, "the matrix was built for item rows [%lld,%lld) only", (long long)X->xt_row_begin, (long long)X->xt_row_end);
   RP_TRY(rp_set_device(ctx));

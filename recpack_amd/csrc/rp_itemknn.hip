@@ -821,6 +821,8 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   if (row_begin < 0 || row_end > X->n_items || row_begin > row_end)
     RP_FAIL(RPHIP_EINVAL, "row range [%lld,%lld) outside 0..%lld", (long long)row_begin, (long long)row_end, (long long)X->n_items);
   if (K < 1) RP_FAIL(RPHIP_EINVAL, "K must be >= 1 (got %d)", K);
+  if (X->deg_partial || Xc->deg_partial)
+    RP_FAIL(RPHIP_ESTATE, "the shard's degrees are not complete: all-reduce rphip_csr_degrees_device over the shards, then rphip_csr_finish_degrees");
   if (X->xt_row_end >= 0 && (row_begin < X->xt_row_begin || row_end > X->xt_row_end))
     RP_FAIL(RPHIP_ESTATE, "the matrix was built for item rows [%lld,%lld) only (rphip_csr_from_device_rows)", (long long)X->xt_row_begin,
             (long long)X->xt_row_end);

@@ -109,6 +109,25 @@ def model_dense_tensor(model, device):
     return full[:, :n]
 
 
+def csr_for_shard(ctx, indptr_t, indices_t, shape, rows: Tuple[int, int], device, group=None):
+    """K0 for one shard of a multi-GPU fit with the degree pass sharded: this rank histograms (and ranks) only its own item rows
+    ``rows``, the int32 degree vector (4 * n_items bytes) is summed over the ranks with ONE all-reduce (RCCL over xGMI when the
+    backend is nccl - BASELINE.json's north_star), then the reciprocal degrees are formed.  X^T is filled for the shard's rows."""
+    import torch
+    import torch.distributed as dist
+
+    from recpack_amd import _lib
+
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return _lib.DeviceCSR.from_device(ctx, indptr_t, indices_t, shape, fit_rows=rows)
+    dX = _lib.DeviceCSR.from_device_shard(ctx, indptr_t, indices_t, shape, rows)
+    deg = torch.as_tensor(_DevPtr(dX.degrees_device_ptr(), (int(shape[1]),), "<i4", dX), device=device)
+    ctx.sync()  # the library's stream has written the partial degrees
+    dist.all_reduce(deg, op=dist.ReduceOp.SUM, group=group)
+    dX.finish_degrees()
+    return dX
+
+
 def fit_itemknn_sharded(ctx, dX, K: int, parts: Sequence[Tuple[int, int]], device, group=None, fit_fn=None, **fit_kwargs):
     """Fit this rank's item rows on its GPU, all-gather, return a predict-ready full model (replicated).
     ``fit_kwargs`` (similarity, pop_discount, normalize_X) go to ``_lib.itemknn_fit``; ``fit_fn(row_begin, row_end)``

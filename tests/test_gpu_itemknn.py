@@ -606,3 +606,24 @@ def test_limits_and_dense_corners(hip):
             check_topk_scores(scores, pi, pv, pn, Kp, exclude=X[:100], hist=X[:100] if Kp <= 384 else None, S=S)
         with pytest.raises(_lib.RecpackHipError):
             _lib.predict_topk(ctx, m, dX, 2049)
+
+
+@pytest.mark.parametrize("nproc,shape", [(2, (20000, 30000, 0.0015, 50)), (3, (6000, 900, 0.01, 20))])
+def test_sharded_fit_on_hip_multi_rank(hip, nproc, shape):
+    """The multi-GPU ItemKNN path with world > 1 ON THE KERNELS (ranks share this box's GPU over gloo): K0 with the degree pass
+    sharded + the all-reduce of the degree vector, the shard's rows fitted by the HIP kernels, all-gather, user-sharded
+    predict - model and predictions bit-identical to the single-GPU fit on every rank (tools/dist_itemknn_check.py; the
+    first shape has two column tiles, the second one)."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import free_port
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RECPACK_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(root, "tools", "dist_itemknn_check.py"), *map(str, shape)]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("model bit-identical: True") == nproc
