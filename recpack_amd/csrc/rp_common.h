@@ -81,6 +81,7 @@ struct rphip_csr {
   rphip_ctx* ctx = nullptr;
   int64_t n_users = 0, n_items = 0, nnz = 0;
   bool owns_x = false;
+  bool x_idx_padded = false;       // x_idx is the library's padded copy (matrices with fewer than 8 entries)
   const int32_t* x_ptr = nullptr;  // [U+1]
   const int32_t* x_idx = nullptr;  // [nnz]
   int32_t* xt_ptr = nullptr;       // [I+1]

@@ -125,6 +125,18 @@ __global__ void k_check_ptr(const int32_t* __restrict__ x_ptr, int n_users, int6
 int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
   hipStream_t st = ctx->stream;
   const int64_t U = m->n_users, I = m->n_items, nnz = m->nnz;
+  if (nnz < 8) {
+    // the fit kernels read the column indices in 8-entry pieces (the last piece of the matrix is the one that ENDS at nnz): a
+    // matrix with fewer entries gets a padded copy of its indices
+    int32_t* pad = nullptr;
+    RP_TRY(rp_dev_alloc(ctx, 8 * sizeof(int32_t), (void**)&pad));
+    RP_HIP(hipMemsetAsync(pad, 0, 8 * sizeof(int32_t), st));
+    if (nnz > 0) RP_HIP(hipMemcpyAsync(pad, m->x_idx, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    RP_HIP(hipStreamSynchronize(st));
+    if (m->owns_x && m->x_idx) hipFree((void*)m->x_idx);
+    m->x_idx = pad;
+    m->x_idx_padded = true;
+  }
   m->n_tiles = (int)std::max<int64_t>(1, rp_cdiv(I, RP_TILE_MAX));
   m->tile_w = (int)(rp_cdiv(rp_cdiv(std::max<int64_t>(I, 1), m->n_tiles), 64) * 64);
   RP_TRY(rp_dev_alloc(ctx, (size_t)(I + 1) * sizeof(int32_t), (void**)&m->xt_ptr));
@@ -341,6 +353,10 @@ extern "C" int rphip_csr_finish_degrees(rphip_ctx* ctx, rphip_csr* m) {
 extern "C" int rphip_csr_destroy(rphip_csr* m) {
   if (!m) return RPHIP_OK;
   if (m->ctx) hipSetDevice(m->ctx->device);
+  if (m->x_idx_padded) {
+    rp_dev_free(m->ctx, (void*)m->x_idx);
+    m->x_idx = nullptr;
+  }
   if (m->owns_x) {  // (hipFree waits for the device; cached blocks carry an event instead)
     if (m->x_ptr) hipFree((void*)m->x_ptr);
     if (m->x_idx) hipFree((void*)m->x_idx);

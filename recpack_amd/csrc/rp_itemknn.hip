@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
   int* s_task = &sel.misc[RPS_USER];  // all LDS lives in the dynamic region (keeps its base 16-B aligned)
 #ifdef RP_STAMPS
   sel.stamps = P.stamps;
+  tsel.stamps = P.stamps;
 #endif
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -247,36 +248,60 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
         // writes its lane id at that chunk's slot of a 64-word LDS scratch, a running maximum (DPP) fills the gaps;
         // slot 0 starts from the owner of the previous step's last chunk.  Steps are fetched in increasing order.
         int carry = 0;
-        auto fetch = [&](int c0, int (&jv)[CH]) {
-          const int c = c0 + lane;
-          own_sc[lane] = (lane == 0) ? (uint32_t)carry : 0u;
-          RP_WAVE_FENCE();
-          if (nch > 0 && (unsigned)(choff - c0) < 64u) own_sc[choff - c0] = (uint32_t)lane;
-          RP_WAVE_FENCE();
-          const int lo = rp_wave_incl_max((int)own_sc[lane]);
-          carry = __builtin_amdgcn_readlane(lo, 63);
-          const int us = __shfl(s, lo), ul = __shfl(len, lo), co = __shfl(choff, lo);
-          const int k0 = (c - co) * CH;
-          const int n = (c < n_chunks) ? min(CH, ul - k0) : 0;
-          const int32_t* src = P.x_idx + us + k0;
-          if (n > 0) {
-            if (us + k0 + CH <= P.nnz) {
-              // two 16-byte loads (dword-aligned is enough for global_load_dwordx4) instead of eight dword loads:
-              // the address path processes a quarter of the instructions; entries past n are read but ignored
-              typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));
-              const v4i_a4 a = *reinterpret_cast<const v4i_a4*>(src);
-              const v4i_a4 b = *reinterpret_cast<const v4i_a4*>(src + 4);
-              jv[0] = a.x; jv[1] = a.y; jv[2] = a.z; jv[3] = a.w;
-              jv[4] = b.x; jv[5] = b.y; jv[6] = b.z; jv[7] = b.w;
-            } else {  // the last few entries of the matrix
+        // One chunk step = (raw loaded entries, number of valid ones, shift).  The two 16-byte loads of a step are ALWAYS
+        // issued (a step past the batch's chunks, or a lane without a chunk, reads the head of the array): with the loads
+        // under branches the compiler cannot count the loads in flight and puts s_waitcnt vmcnt(0) in front of every use,
+        // which makes the step being applied wait for the step just requested.  The raw registers are only touched when the
+        // step is applied (masking included), so the next step's loads stay in flight meanwhile.
+        typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));
+        struct step_t {
+          v4i_a4 a, b;
+          int n, sh;
+        };
+        auto fetch = [&](int c0, step_t& S) {
+          int n = 0, pos = 0;
+          if (c0 < n_chunks) {  // (uniform; no loads inside)
+            const int c = c0 + lane;
+            own_sc[lane] = (lane == 0) ? (uint32_t)carry : 0u;
+            RP_WAVE_FENCE();
+            if (nch > 0 && (unsigned)(choff - c0) < 64u) own_sc[choff - c0] = (uint32_t)lane;
+            RP_WAVE_FENCE();
+            const int lo = rp_wave_incl_max((int)own_sc[lane]);
+            carry = __builtin_amdgcn_readlane(lo, 63);
+            const int us = __shfl(s, lo), ul = __shfl(len, lo), co = __shfl(choff, lo);
+            const int k0 = (c - co) * CH;
+            n = (c < n_chunks) ? min(CH, ul - k0) : 0;
+            pos = us + k0;
+          }
+          // the last chunk of the matrix may not have CH entries behind it: read the CH entries that END at nnz and shift
+          const int q = (n > 0) ? min(pos, P.nnz - CH) : 0;  // (nnz >= CH: rp_csr_prepare pads smaller matrices)
+          S.n = n;
+          S.sh = (n > 0) ? pos - q : 0;
+          const int32_t* src = P.x_idx + q;
+          S.a = *reinterpret_cast<const v4i_a4*>(src);
+          S.b = *reinterpret_cast<const v4i_a4*>(src + 4);
+        };
+        auto unpack = [&](const step_t& S, int (&jv)[CH]) {
+          jv[0] = S.a.x; jv[1] = S.a.y; jv[2] = S.a.z; jv[3] = S.a.w;
+          jv[4] = S.b.x; jv[5] = S.b.y; jv[6] = S.b.z; jv[7] = S.b.w;
+          if (__any(S.sh != 0)) {  // (only the wave that holds the matrix's last entries)
+            int t[CH];
 #pragma unroll
-              for (int e = 0; e < CH; ++e) jv[e] = (e < n) ? src[e] : -1;
+            for (int e = 0; e < CH; ++e) {
+              int v = -1;
+#pragma unroll
+              for (int f = 0; f < CH; ++f) v = (e + S.sh == f) ? jv[f] : v;
+              t[e] = v;
             }
+#pragma unroll
+            for (int e = 0; e < CH; ++e) jv[e] = t[e];
           }
 #pragma unroll
-          for (int e = 0; e < CH; ++e) jv[e] = (e < n) ? jv[e] : -1;
+          for (int e = 0; e < CH; ++e) jv[e] = (e < S.n) ? jv[e] : -1;
         };
-        auto apply = [&](const int (&jv)[CH]) {
+        auto apply = [&](const step_t& S) {
+          int jv[CH];
+          unpack(S, jv);
           if constexpr (BYTES) {
             // returning adds: the lane that finds its byte at zero is the column's first toucher and appends the
             // slot to the candidate list - the selection then never scans the tile.  The list is a pool of 64-entry
@@ -328,25 +353,14 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
               if (jv[e] >= 0) atomicAdd(&acc[jv[e] - t0], 1u);
           }
         };
-        if constexpr (PAIRS) {
-          // 32 waves per CU (two 1024-thread workgroups at 64 VGPRs) hide the load latency by themselves: one chunk
-          // step at a time keeps the register count down
-          int ja[CH];
-          for (int c0 = 0; c0 < n_chunks; c0 += 64) {
-            fetch(c0, ja);
-            apply(ja);
-          }
-        } else {
-          int ja[CH], jb[CH];
-          if (n_chunks > 0) fetch(0, ja);
-          for (int c0 = 0; c0 < n_chunks; c0 += 128) {
-            if (c0 + 64 < n_chunks) fetch(c0 + 64, jb);
-            apply(ja);
-            if (c0 + 64 < n_chunks) {
-              if (c0 + 128 < n_chunks) fetch(c0 + 128, ja);
-              apply(jb);
-            }
-          }
+        // the loads of step c0 + 64 are in flight while step c0 is applied (two register sets, used alternately)
+        step_t sa, sb;
+        fetch(0, sa);
+        for (int c0 = 0; c0 < n_chunks; c0 += 128) {
+          fetch(c0 + 64, sb);
+          apply(sa);
+          fetch(c0 + 128, sa);
+          if (c0 + 64 < n_chunks) apply(sb);
         }
       }
       if (BYTES && blk < NBLK && lane >= fill) ft_list[blk * 64 + lane] = (uint16_t)RPS_EMPTY;  // rest of the last block
@@ -938,7 +952,7 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   P.key_pow = key_pow;
   P.tile_ptr = Xc->tile_ptr;
   P.n_items = (int)X->n_items;
-  P.nnz = (int)Xc->nnz;
+  P.nnz = (int)std::max<int64_t>(Xc->nnz, 8);  // (matrices with fewer entries carry a padded copy of their indices)
   P.n_tiles = T;
   P.tile_w = W;
   P.K = K;
@@ -1039,8 +1053,8 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
     unsigned long long h[16];
     hipMemcpyAsync(h, P.stamps, sizeof(h), hipMemcpyDeviceToHost, st);
     hipStreamSynchronize(st);
-    fprintf(stderr, "[stamps] cycles/1e6: ticket %.1f accumulate %.1f dump %.1f select %.1f emit+clear %.1f | sel: compact %.1f levels %.1f sort %.1f pred %.1f\n",
-            h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, h[8] / 1e6, h[9] / 1e6, h[10] / 1e6, h[11] / 1e6);
+    fprintf(stderr, "[stamps] cycles/1e6: ticket %.1f accumulate %.1f dump %.1f select %.1f emit+clear %.1f | sel: sample/compact %.1f collect/levels %.1f list/sort %.1f full/pred %.1f; full fallbacks %llu\n",
+            h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, h[8] / 1e6, h[9] / 1e6, h[10] / 1e6, h[11] / 1e6, h[12]);
   }
 #endif
 

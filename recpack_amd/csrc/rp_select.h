@@ -518,16 +518,22 @@ __device__ __forceinline__ void rp_select_foreach(int n_slots, rp_select_smem s,
 // costs LDS.  Here every pass walks the slots (thread t takes slots t, t + NTHR, ..: the key's global operand, e.g.
 // 1/c_j, is then read coalesced), selected slots are recorded in a bitmap and emitted in slot (= column) order.
 // Same exact rule as rp_select_topk: larger key first, then smaller column.
+constexpr int RP_TSEL_LIST = 1024;  // candidates the sampled-threshold pass may collect (key 8 B + slot 2 B each)
 struct rp_tsel_smem {
   uint32_t* hist;    // RP_HIST_BINS u32, overlays skey / scol / spos of the boundary bin
   uint64_t* skey;
   uint32_t* scol;
   uint32_t* bitmap;  // (n_slots + 31) / 32 words
   int* misc;         // RPS_MISC_INTS
+  uint64_t* lkey;    // [RP_TSEL_LIST] keys of the collected candidates
+  uint16_t* lslot;   // [RP_TSEL_LIST] their slots
+#ifdef RP_STAMPS
+  unsigned long long* stamps;  // diagnostic build: [8]=sample [9]=collect [10]=exact on the list [11]=full fallback, [12]=fallbacks
+#endif
 };
 
 __host__ __device__ constexpr size_t rp_tsel_smem_bytes(int n_slots) {
-  return (size_t)RP_HIST_BINS * 4 + (size_t)((n_slots + 31) / 32 + 4) * 4 + RPS_MISC_INTS * 4;
+  return (size_t)RP_HIST_BINS * 4 + (size_t)((n_slots + 31) / 32 + 4) * 4 + RPS_MISC_INTS * 4 + (size_t)RP_TSEL_LIST * 10 + 16;
 }
 
 __device__ __forceinline__ rp_tsel_smem rp_tsel_carve(char* base, int n_slots) {
@@ -537,13 +543,29 @@ __device__ __forceinline__ rp_tsel_smem rp_tsel_carve(char* base, int n_slots) {
   s.scol = reinterpret_cast<uint32_t*>(base + (size_t)RP_SORT_CAP * 8);
   s.bitmap = reinterpret_cast<uint32_t*>(base + (size_t)RP_HIST_BINS * 4);
   s.misc = reinterpret_cast<int*>(base + (size_t)RP_HIST_BINS * 4 + (size_t)((n_slots + 31) / 32 + 4) * 4);
+  char* l = base + (size_t)RP_HIST_BINS * 4 + (size_t)((n_slots + 31) / 32 + 4) * 4 + RPS_MISC_INTS * 4;
+  l += (8 - (reinterpret_cast<uintptr_t>(l) & 7)) & 7;
+  s.lkey = reinterpret_cast<uint64_t*>(l);
+  s.lslot = reinterpret_cast<uint16_t*>(l + (size_t)RP_TSEL_LIST * 8);
   return s;
 }
 
-// Returns K' and leaves the selected slots in s.bitmap (bit w of word w/32).  The bitmap must be all zero on entry;
-// rp_select_tile_emit clears it again.
-template <int NTHR, class Src>
-__device__ int rp_select_tile(const Src& src, int n_slots, int K, rp_tsel_smem s) {
+// the collected candidates as a selection source: slot p of the list = tile slot lslot[p]
+template <class Src>
+struct rp_tlist_src {
+  const Src* tile;
+  const uint64_t* lkey;
+  const uint16_t* lslot;
+  int n;
+  __device__ __forceinline__ bool valid(int p) const { return p < n; }
+  __device__ __forceinline__ uint64_t key(int p) const { return lkey[p]; }
+  __device__ __forceinline__ uint32_t col(int p) const { return tile->col((int)lslot[p]); }
+};
+
+// Exact selection over the slots of `src`: the radix levels and the classification pass each walk ALL slots and evaluate
+// every valid slot's key.  mark(slot) records a selected slot.  Returns K'.
+template <int NTHR, class Src, class Mark>
+__device__ int rp_select_tile_full(const Src& src, int n_slots, int K, rp_tsel_smem s, Mark mark) {
   static_assert(RP_HIST_BINS % NTHR == 0, "bins must divide over the threads");
   constexpr int BPT = RP_HIST_BINS / NTHR;
   constexpr int NW = NTHR / 64;
@@ -680,7 +702,7 @@ __device__ int rp_select_tile(const Src& src, int n_slots, int K, rp_tsel_smem s
         spos[p] = (uint16_t)w;
       }
     }
-    if (sel) atomicOr(&s.bitmap[w >> 5], 1u << (w & 31));
+    if (sel) mark(w);
   }
   __syncthreads();
   if (have_fin && !fin_all) {
@@ -701,10 +723,7 @@ __device__ int rp_select_tile(const Src& src, int n_slots, int K, rp_tsel_smem s
           const uint64_t ok2 = ((uint64_t)ohi << 32) | olo;
           rank += ((ok2 > mk) || (ok2 == mk && oic > mic)) ? 1 : 0;
         }
-        if (lane < group && rank < need) {
-          const int w = spos[lane];
-          atomicOr(&s.bitmap[w >> 5], 1u << (w & 31));
-        }
+        if (lane < group && rank < need) mark((int)spos[lane]);
       }
     } else {
       int n2 = 1;
@@ -738,14 +757,120 @@ __device__ int rp_select_tile(const Src& src, int n_slots, int K, rp_tsel_smem s
           __syncthreads();
         }
       }
-      for (int i = tid; i < need; i += NTHR) {
-        const int w = spos[i];
-        atomicOr(&s.bitmap[w >> 5], 1u << (w & 31));
-      }
+      for (int i = tid; i < need; i += NTHR) mark((int)spos[i]);
     }
     __syncthreads();
   }
   return kprime;
+}
+
+// Returns K' and leaves the selected slots in s.bitmap (bit w of word w/32).  The bitmap must be all zero on entry;
+// rp_select_tile_emit clears it again.
+//
+// Sampled threshold first: the full routine evaluates every slot's key (an unpack, a gather of the column weight, a float64
+// product) once per radix level and once more to classify - three to four times per slot.  Here one slot in eight is
+// histogrammed by its first radix digit, the digit d* that holds rank ~ 1.5 K / 8 + 16 of the SAMPLE becomes a lower bound
+// for the K-th key of the tile, and ONE pass over all slots collects the slots whose first digit is >= d* (with their keys)
+// and counts the valid ones.  If at least K and at most RP_TSEL_LIST slots were collected, the K best of the tile are
+// among them by construction and the exact selection runs on that short list with cached keys (the same routine, a list
+// source).  Otherwise (a sample that misled, a crowded digit) the full routine runs: exactness never depends on the sample.
+template <int NTHR, class Src>
+__device__ int rp_select_tile(const Src& src, int n_slots, int K, rp_tsel_smem s) {
+  constexpr int SMP = 8;
+  constexpr int NW = NTHR / 64;
+  constexpr int BPT = RP_HIST_BINS / NTHR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto mark_tile = [&](int w) { atomicOr(&s.bitmap[w >> 5], 1u << (w & 31)); };
+#ifdef RP_STAMPS
+  unsigned long long ts_last = __builtin_amdgcn_s_memtime();
+#endif
+  int shift0, width0;
+  bool is_col0;
+  rp_level(0, &shift0, &width0, &is_col0);
+  // ---- sample
+  for (int i = tid; i < RP_HIST_BINS; i += NTHR) s.hist[i] = 0;
+  if (tid == 0) {
+    s.misc[RPS_BIN] = -1;
+    s.misc[RPS_CNT] = 0;
+  }
+  __syncthreads();
+  for (int w = tid * SMP; w < n_slots; w += NTHR * SMP) {
+    if (!src.valid(w)) continue;
+    atomicAdd(&s.hist[(uint32_t)(src.key(w) >> shift0) & ((1u << width0) - 1u)], 1u);
+  }
+  __syncthreads();
+  {
+    const int want = (3 * K) / (2 * SMP) + 16;  // sample rank whose digit becomes the bound
+    const int d_hi = RP_HIST_BINS - 1 - BPT * tid;
+    int h[BPT];
+    int sum = 0;
+#pragma unroll
+    for (int e = 0; e < BPT; ++e) {
+      h[e] = (int)s.hist[d_hi - e];
+      sum += h[e];
+    }
+    int inc = sum;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+      const int t = __shfl_up(inc, dd);
+      if (lane >= dd) inc += t;
+    }
+    if (lane == 63) s.misc[RPS_RED + wave] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int w2 = 0; w2 < wave; ++w2) woff += s.misc[RPS_RED + w2];
+    int above = woff + inc - sum;
+#pragma unroll
+    for (int e = 0; e < BPT; ++e) {
+      if (above < want && want <= above + h[e]) s.misc[RPS_BIN] = d_hi - e;
+      above += h[e];
+    }
+    __syncthreads();
+  }
+  RPS_STAMP(8);
+  const int dstar = s.misc[RPS_BIN];  // -1: the sample holds fewer than `want` candidates - collect everything
+  // ---- collect
+  int mine = 0;
+  for (int w = tid; w < n_slots; w += NTHR) {
+    if (!src.valid(w)) continue;
+    ++mine;
+    const uint64_t k = src.key(w);
+    if ((int)((uint32_t)(k >> shift0) & ((1u << width0) - 1u)) >= dstar) {
+      const int p = atomicAdd(&s.misc[RPS_CNT], 1);
+      if (p < RP_TSEL_LIST) {
+        s.lkey[p] = k;
+        s.lslot[p] = (uint16_t)w;
+      }
+    }
+  }
+  mine = rp_wave_sum(mine);
+  if (lane == 0) s.misc[RPS_RED + wave] = mine;
+  __syncthreads();
+  int n_valid = 0;
+#pragma unroll
+  for (int w2 = 0; w2 < NW; ++w2) n_valid += s.misc[RPS_RED + w2];
+  const int n_list = s.misc[RPS_CNT];
+  __syncthreads();
+  RPS_STAMP(9);
+  if (n_valid <= K) {  // fewer candidates than K: all of them
+    for (int w = tid; w < n_slots; w += NTHR)
+      if (src.valid(w)) mark_tile(w);
+    __syncthreads();
+    return n_valid;
+  }
+  if (n_list >= K && n_list <= RP_TSEL_LIST) {
+    rp_tlist_src<Src> ls{&src, s.lkey, s.lslot, n_list};
+    const uint16_t* lslot = s.lslot;
+    const int kp = rp_select_tile_full<NTHR>(ls, n_list, K, s, [&](int p) { mark_tile((int)lslot[p]); });
+    RPS_STAMP(10);
+    return kp;
+  }
+  const int kp = rp_select_tile_full<NTHR>(src, n_slots, K, s, mark_tile);
+  RPS_STAMP(11);
+#ifdef RP_STAMPS
+  if (threadIdx.x == 0 && s.stamps) atomicAdd(&s.stamps[12], 1ull);
+#endif
+  return kp;
 }
 
 // emit(pos, slot) for every selected slot in slot order; clears the bitmap
