@@ -270,6 +270,9 @@ int rphip_predict_topk_filtered_dev(rphip_ctx* ctx, const rphip_model* model, co
 /* exact reference semantics (every non-zero score): two phases.  _count fills row_nnz_host
  * (int64[n]) and returns the total; _fill writes CSR indices/data (float64) given the caller's
  * indptr (exclusive scan of row_nnz). */
+/* LIMIT of every fit and of rphip_predict_topk*: the effective K (min(K, n_items - 1)) and Kp (min(Kp, n_items)) are at most 2048
+ * (the selection's LDS buffers) - larger values return RPHIP_ELIMIT; the reference accepts any K.  rphip_predict_full_* has no
+ * such limit. */
 int rphip_predict_full_count(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred,
                              int64_t user_begin, int64_t user_end, int64_t* row_nnz_host, int64_t* total_out);
 int rphip_predict_full_fill(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred,

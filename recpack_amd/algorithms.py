@@ -13,6 +13,17 @@ recpack's ``identifier`` work), same exceptions and warning texts.  All arithmet
 
 Extensions (not in the reference): ``predict_topk(X, K, exclude_history)`` returns only the K best
 scores per user, fused on the device (what ``Pipeline`` + ``MetricTopK`` compute from the full matrix).
+
+Verbatim interface blocks.  ``Algorithm.name`` / ``identifier`` / ``__str__`` / ``set_params`` / ``fit`` / ``predict`` and the
+argument checks of ``ItemKNN.__init__`` (the pop_discount warning and the two ``ValueError`` texts) reproduce the reference's
+class protocol character for character (base.py:42-72, 165-217; nearest_neighbour.py:168-202): attribute names, log and
+warning texts and exception messages ARE the interface recpack's Pipeline, registry and tests rely on.  Everything else in
+this module is original.  When recpack itself is importable, :class:`Algorithm` additionally derives from recpack's own
+``Algorithm`` so that ``isinstance`` / ``issubclass`` checks in recpack (e.g. the algorithm registry) accept these classes.
+
+Limit (a deviation from the reference, which accepts any K): the effective ``K`` of a fit and the ``K`` of ``predict_topk``
+are at most :data:`RP_K_MAX` = 2048 (the selection's LDS buffers); larger values raise ``ValueError`` before anything is
+uploaded.
 """
 from __future__ import annotations
 
@@ -30,6 +41,14 @@ from sklearn.utils.validation import check_is_fitted
 from recpack_amd import _lib
 
 logger = logging.getLogger("recpack")
+
+RP_K_MAX = 2048  # rp_common.h: largest effective K / Kp of one call
+
+try:  # recpack's own base class, when it is installed: registry / isinstance checks then accept the classes below
+    from recpack.algorithms.base import Algorithm as _RecpackAlgorithm
+except Exception:  # noqa: BLE001 - recpack is optional (it is absent on the GPU box)
+    _RecpackAlgorithm = None
+_AlgorithmBases = (_RecpackAlgorithm,) if _RecpackAlgorithm is not None else (BaseEstimator,)
 
 _contexts: dict = {}
 
@@ -73,8 +92,8 @@ def to_binary_csr(X) -> sp.csr_matrix:
     return M
 
 
-class Algorithm(BaseEstimator):
-    """recpack/algorithms/base.py:33-217."""
+class Algorithm(*_AlgorithmBases):
+    """recpack/algorithms/base.py:33-217 (the public protocol below mirrors the reference verbatim - module docstring)."""
 
     def __init__(self):
         super().__init__()
@@ -164,6 +183,8 @@ class ItemSimilarityMatrixAlgorithm(Algorithm):
         self._check_fit_complete()
         X = self._transform_predict_input(X)
         n_items = X.shape[1]
+        if min(int(K), max(1, n_items)) > RP_K_MAX:
+            raise ValueError(f"K={K} exceeds the supported maximum of {RP_K_MAX} scores per user")
         keep = None
         for items, select in ((exclude_items, False), (select_items, True)):
             if items is None:
@@ -242,6 +263,8 @@ class ItemKNN(TopKItemSimilarityMatrixAlgorithm):
         self.normalize_sim = normalize_sim
 
     def _fit(self, X: sp.csr_matrix) -> None:
+        if min(int(self.K), max(1, X.shape[1] - 1)) > RP_K_MAX:
+            raise ValueError(f"K={self.K} exceeds the supported maximum of {RP_K_MAX} neighbours per item")
         ctx, dX = self._upload(X)
         try:
             if self.similarity == "cosine":

@@ -102,3 +102,16 @@ def test_post_condition_warnings():
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         alg._check_prediction(X, X)
+
+
+def test_k_limit_raises_before_upload():
+    """K / Kp beyond RP_K_MAX = 2048 (a documented deviation: the reference takes any K) raise ValueError on the host."""
+    import scipy.sparse as sp
+
+    import recpack_amd
+    from recpack_amd.algorithms import RP_K_MAX
+
+    X = sp.random(50, 3000, density=0.01, format="csr", random_state=0)
+    X.data[:] = 1
+    with pytest.raises(ValueError, match=str(RP_K_MAX)):
+        recpack_amd.ItemKNN(K=RP_K_MAX + 1).fit(X)
