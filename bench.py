@@ -128,7 +128,7 @@ def cpu_baseline(indptr, indices, shape, K, Kp, S_csr, budget_s, P_total):
     return out
 
 
-def cpu_baseline_ease(indptr, indices, shape, l2, Kp, sizes=(8192, 16384), budget_s=60.0):
+def cpu_baseline_ease(indptr, indices, shape, l2, Kp, sizes=(8192, 16384), budget_s=150.0):
     """The reference's EASE._fit (ease.py:78-86: dense Gram, float64 LAPACK inverse, column scaling) through the oracle, on the
     matrix restricted to a random sample of I' items for I' in `sizes`, on all host cores (BLAS threads reported), and
     X @ B for a sample of users; extrapolated to the full item count by I^3 (inverse) - labelled as such."""
