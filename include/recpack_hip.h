@@ -98,6 +98,8 @@ int rphip_ctx_trim(rphip_ctx* ctx);
  *                       (rphip_csr_set_values) always use the 64-bit sums.  Both are independent of the order of the adds:
  *                       predict is bit-reproducible run to run.
  *   "predict_tile32"    2048 | 4096 (default): column tile of the 32-bit sums (tuning).
+ *   "gemm_flush_k"      K steps between two flushes of the MFMA accumulators into the compensated (hi + lo) master sums of the
+ *                       EASE solve's GEMM (default 512, a multiple of 16; a value beyond any K = plain fp32 accumulation).
  *   "cache_limit_bytes" see rphip_ctx_trim. */
 int rphip_ctx_set_option(rphip_ctx* ctx, const char* name, int64_t value);
 int rphip_get_timings(rphip_ctx* ctx, rphip_timings* out);

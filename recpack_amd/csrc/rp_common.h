@@ -75,6 +75,7 @@ struct rphip_ctx {
   // predict options (rphip_ctx_set_option)
   int predict_exact64 = 0;   // 1: the wave predict kernel sums in 64 bits (exact) instead of the per-user-scaled 32 bits
   int pw_wt32 = 4096;        // tile width of the 32-bit sums: 2048 or 4096 (tuning)
+  int gemm_kc = 512;         // K steps between two flushes of the MFMA accumulators into the compensated master sums
 };
 
 struct rphip_csr {

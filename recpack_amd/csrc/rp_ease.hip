@@ -27,7 +27,7 @@ static int rp_dense_count_empty(rphip_ctx* ctx, rphip_model* m);
 constexpr int GT = 128;   // tile (and diagonal block) size
 constexpr int GBK = 16;   // K step
 constexpr int GLD = 20;   // LDS row stride in floats (16 + 4 pad: conflict-free ds_read_b128 over 16 rows)
-constexpr int GKC = 256;  // K steps between two flushes of the MFMA accumulators into the compensated master sums
+constexpr int GKC = 512;  // default K steps between two flushes of the MFMA accumulators into the compensated master sums (option gemm_flush_k)
 
 struct rp_gemm_args {
   const float* A;
@@ -48,12 +48,13 @@ struct rp_gemm_args {
   // tile to part[s][M][N] (alpha = 1, beta = 0); k_splitk_reduce applies alpha / beta to C afterwards
   float* part;
   int k_chunk;
+  int kc;            // K steps between two flushes into the master sums (set by rp_gemm_nt from the context: GKC by default)
 };
 
 // Accumulation.  The MFMA adds into its fp32 accumulator in K order: over a K of 10^5 that alone loses ~ sqrt(K) eps, and
 // the Cholesky / inverse / product chain of EASE multiplies it by the condition of G + lambda I - measured against
 // host-certified float64 columns the plain kernel was 6e-4 off at 100 000 items (tests/ease_cg.py), six times the 1e-4 bar.
-// So every GKC = 256 steps of K the accumulators are emptied into MASTER sums held as an unevaluated pair hi + lo
+// So every GKC = 512 steps of K (256: 8.2e-6 / 9.26 s at C4, 512: 1.2e-5 / 8.82 s, 1024: 2.3e-5 / 8.66 s) the accumulators are emptied into MASTER sums held as an unevaluated pair hi + lo
 // (Knuth's two-sum: the rounding error of hi + acc is computed exactly and added to lo).  hi lives in registers; lo only
 // needs a few bits (|lo| <= ulp(hi)), so it is kept as bf16 in LDS, two per word (32 KB per workgroup: two workgroups per
 // CU still fit, and the 64 extra registers of an fp32 lo would have cost the second wave per SIMD).  The error of a sum
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(rp_gemm_args g) {
       }
       if (more) lstore(cur ^ 1);
       since += GBK;
-      if (since == GKC && more) {  // (the last piece is flushed by the epilogue)
+      if (since >= g.kc && more) {  // (the last piece is flushed by the epilogue)
         flush(!have_lo);
         have_lo = true;
         since = 0;
@@ -407,11 +408,14 @@ static int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st = nu
     if (S < 2) S = 1;
   }
   if (S == 1) {
-    hipLaunchKernelGGL(k_gemm_nt, dim3(g.tri == 3 ? 1 : g.N / GT, g.M / GT), dim3(256), 0, st, g);
+    rp_gemm_args g1 = g;
+    g1.kc = ctx->gemm_kc;
+    hipLaunchKernelGGL(k_gemm_nt, dim3(g.tri == 3 ? 1 : g.N / GT, g.M / GT), dim3(256), 0, st, g1);
     RP_HIP(hipGetLastError());
     return RPHIP_OK;
   }
   rp_gemm_args h = g;
+  h.kc = ctx->gemm_kc;
   float* part = part_at;
   if (!part) RP_TRY(rp_scratch(ctx, 7, (size_t)S * g.M * g.N * sizeof(float), (void**)&part));
   h.part = part;

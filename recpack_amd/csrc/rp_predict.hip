@@ -432,27 +432,26 @@ template <typename AccT, bool WGT>
 __device__ __forceinline__ void rp_pw_add_chunk(rp_pw_state<AccT>& S, int n, const v4i_a4& a, const v4i_a4& b, int t0, double xw) {
   const int ec[4] = {a.x, a.z, b.x, b.z};
   const int ev[4] = {a.y, a.w, b.y, b.w};
-  // Straight-line code, no per-entry branch: an entry past the chunk's end adds 0 to a dummy word of the lane's own
-  // (the idle upper half of the pool histogram) and ORs 0 into the lane's dirty word.  With a branch per entry the
-  // compiler computed each entry's operands into the registers of the previous one behind an s_waitcnt lgkmcnt(0),
-  // i.e. one full LDS round trip per entry; now the eight atomics of a step go out back to back.
-  RP_LDS AccT* dummy = reinterpret_cast<RP_LDS AccT*>(S.pool.hist + 128) + S.lane;
+  // Straight-line code, no per-entry branch (with one the compiler computed each entry's operands behind an
+  // s_waitcnt lgkmcnt(0), i.e. one full LDS round trip per entry).  An entry past the chunk's end becomes (column `lane` of
+  // the tile, similarity 0, no map bit): it adds 0 to a word of the lane's own and ORs 0 into the lane's own map word - three
+  // selects per entry (column, value, bit) instead of four, and no two lanes meet on one address (all idle entries on ONE
+  // column serialise in the LDS: measured +38 % on the whole kernel).
 #pragma unroll
   for (int e = 0; e < PW_CH; ++e) {
     const bool on = e < n;
-    const int j = ec[e] - t0;
-    RP_LDS AccT* tgt = on ? &S.acc[j] : dummy;
-    AccT v = 0;
+    const int j = on ? ec[e] - t0 : S.lane;
+    const int bits = on ? ev[e] : 0;  // (+0.0f)
+    AccT v;
     if constexpr (sizeof(AccT) == 4)  // this user's scale: rint(s * 2^ushift), exact integer adds from here on
-      v = on ? (AccT)__float2int_rn(__int_as_float(ev[e]) * S.fmul) : (AccT)0;
+      v = (AccT)__float2int_rn(__int_as_float(bits) * S.fmul);
     else if (WGT)  // the owner's value times the similarity, in float64
-      v = on ? rp_f64_to_fix((double)__int_as_float(ev[e]) * xw, S.fix) : 0ull;
+      v = rp_f64_to_fix((double)__int_as_float(bits) * xw, S.fix);
     else
-      v = on ? rp_f32_to_fix(ev[e], S.fix) : 0ull;
-    RP_LDS uint32_t* dw = &S.dirty[on ? ((j & 63) + 64 * (j >> 11)) : S.lane];  // word (j mod 64) of the tile's (j / 2048)-th map
+      v = rp_f32_to_fix(bits, S.fix);
     const uint32_t bit = on ? (1u << ((j >> 6) & 31)) : 0u;
-    atomicAdd((AccT*)tgt, v);
-    atomicOr((uint32_t*)dw, bit);
+    atomicAdd((AccT*)&S.acc[j], v);
+    atomicOr((uint32_t*)&S.dirty[(j & 63) + 64 * (j >> 11)], bit);  // word (j mod 64) of the tile's (j / 2048)-th map
   }
 }
 
