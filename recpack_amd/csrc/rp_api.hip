@@ -207,6 +207,8 @@ extern "C" int rphip_ctx_set_option(rphip_ctx* ctx, const char* name, int64_t va
   } else if (!strcmp(name, "predict_tile32")) {
     if (value != 2048 && value != 4096) RP_FAIL(RPHIP_EINVAL, "predict_tile32 must be 2048 or 4096");
     ctx->pw_wt32 = (int)value;
+  } else if (!strcmp(name, "gemm_bf16x3")) {
+    ctx->gemm_bf16x3 = value ? 1 : 0;
   } else if (!strcmp(name, "gemm_flush_k")) {
     if (value < 16 || (value % 16)) RP_FAIL(RPHIP_EINVAL, "gemm_flush_k must be a positive multiple of 16");
     ctx->gemm_kc = (int)std::min<int64_t>(value, 1 << 30);

@@ -213,6 +213,195 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(rp_gemm_args g) {
     }
 }
 
+// ---- the same product on the bf16 matrix pipe: three-way split operands ------------------------------------------------------
+// v_mfma_f32_32x32x16_bf16 retires 16 K-steps in 32 cycles per SIMD where the fp32-input MFMA above takes 64 cycles for 2: 16x the
+// rate.  An fp32 operand is cut into three bf16 planes x = x1 + x2 + x3 (8 significant bits each, by truncation: x1 = the top 16
+// bits of x, x2 = the top 16 bits of x - x1, x3 likewise - every subtraction is exact), and a product keeps the six plane
+// products of weight >= 2^-16: a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1); the dropped ones are below 2^-24 of |a b|,
+// the size of fp32's own rounding.  Six MFMAs per K16 step and output tile instead of eight fp32 ones per K16: 2.7x fewer
+// matrix-pipe cycles.  Accumulation is fp32 in the MFMA with the same compensated master sums (hi + lo) as above.
+// The planes are cut when a tile is staged (global fp32 -> registers -> three bf16 images in LDS, 5.5 VALU per element in the
+// shadow of the other workgroup's MFMAs): memory holds fp32 only, 200 000 items still fit one GPU.
+// LDS: a plane row is 16 bf16 + 8 of padding (48 B: the 16-B fragment reads of 16 consecutive rows then cover all 64 banks
+// once); one buffer per operand (a second set of three planes would not leave room for two workgroups per CU next to the 32 KB
+// of lo), so a step has two barriers - the second workgroup on the CU computes meanwhile.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BLD = 24;  // plane row stride in bf16 elements
+
+__global__ void __launch_bounds__(256, 2) k_gemm_nt_b3(rp_gemm_args g) {
+  __shared__ __attribute__((aligned(16))) unsigned short As[3][GT * BLD];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[3][GT * BLD];
+  __shared__ uint32_t Lo[32 * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tm = blockIdx.y, tn = (g.tri == 3) ? (int)blockIdx.y : (int)blockIdx.x;
+  const int m0 = tm * GT, n0 = tn * GT;
+  if (g.tri == 1 && g.n_off + n0 > g.m_off + m0) return;
+  if (g.tri == 2 && g.n_off + n0 >= g.m_off + m0) return;
+  int kb = g.k0, ke = g.k1;
+  if (g.part) {
+    kb = g.k0 + (int)blockIdx.z * g.k_chunk;
+    ke = min(g.k1, kb + g.k_chunk);
+  }
+  if (g.kb_m) kb = max(kb, g.m_off + m0);
+  if (g.kb_n) kb = max(kb, g.n_off + n0);
+  if (g.ke_n) ke = min(ke, g.n_off + n0 + GT);
+  kb &= ~(GBK - 1);
+
+  f32x16 acc[2][2], hi[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = hi[i][j][r] = 0.0f;
+  bool have_lo = false;
+  auto flush = [&](bool first) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const int w = ((i * 2 + j) * 16 + r) >> 1;
+          float l0 = 0.0f, l1 = 0.0f;
+          if (!first) {
+            const uint32_t pk = Lo[w * 256 + tid];
+            l0 = __uint_as_float(pk << 16);
+            l1 = __uint_as_float(pk & 0xffff0000u);
+          }
+          const float a0 = acc[i][j][r], a1 = acc[i][j][r + 1];
+          const float h0 = hi[i][j][r], h1 = hi[i][j][r + 1];
+          const float s0 = h0 + a0, s1 = h1 + a1;
+          const float b0 = s0 - h0, b1 = s1 - h1;
+          l0 += (h0 - (s0 - b0)) + (a0 - b0);
+          l1 += (h1 - (s1 - b1)) + (a1 - b1);
+          hi[i][j][r] = s0;
+          hi[i][j][r + 1] = s1;
+          acc[i][j][r] = 0.0f;
+          acc[i][j][r + 1] = 0.0f;
+          Lo[w * 256 + tid] = rp_pack_bf16_rn(l0, l1);
+        }
+  };
+
+  if (kb < ke) {
+    const int lr = tid >> 1, lk = (tid & 1) * 8;  // one row, eight consecutive K per thread and operand
+    const float* Ap = g.A + (long long)(m0 + lr) * g.lda + lk;
+    const float* Bp = g.B + (long long)(n0 + lr) * g.ldb + lk;
+    float4 ra0, ra1, rb0, rb1;
+    auto gload = [&](int k) {
+      ra0 = *reinterpret_cast<const float4*>(Ap + k);
+      ra1 = *reinterpret_cast<const float4*>(Ap + k + 4);
+      rb0 = *reinterpret_cast<const float4*>(Bp + k);
+      rb1 = *reinterpret_cast<const float4*>(Bp + k + 4);
+    };
+    // eight floats -> three planes of eight bf16 (truncation splits; every residual is exact).  (Converting the next tile in
+    // front of the current step's MFMAs - work the MFMA pipe could shadow - was measured: 145 instead of 162 TF/s, the
+    // compiler does not interleave it and the 24 extra live registers cost more than the overlap gains.)
+    auto split_store = [&](const float4& u0, const float4& u1, unsigned short (*dst)[GT * BLD]) {
+      const float x[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+      uint32_t p1[8], p2[8], p3[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        p1[e] = __float_as_uint(x[e]) & 0xffff0000u;
+        const float r1 = x[e] - __uint_as_float(p1[e]);
+        p2[e] = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(p2[e]);
+        p3[e] = __float_as_uint(r2);
+      }
+      uint4 w1, w2, w3;  // pairs packed: element 2q in the low half
+      w1.x = __builtin_amdgcn_perm(p1[1], p1[0], 0x07060302u);
+      w1.y = __builtin_amdgcn_perm(p1[3], p1[2], 0x07060302u);
+      w1.z = __builtin_amdgcn_perm(p1[5], p1[4], 0x07060302u);
+      w1.w = __builtin_amdgcn_perm(p1[7], p1[6], 0x07060302u);
+      w2.x = __builtin_amdgcn_perm(p2[1], p2[0], 0x07060302u);
+      w2.y = __builtin_amdgcn_perm(p2[3], p2[2], 0x07060302u);
+      w2.z = __builtin_amdgcn_perm(p2[5], p2[4], 0x07060302u);
+      w2.w = __builtin_amdgcn_perm(p2[7], p2[6], 0x07060302u);
+      w3.x = __builtin_amdgcn_perm(p3[1], p3[0], 0x07060302u);
+      w3.y = __builtin_amdgcn_perm(p3[3], p3[2], 0x07060302u);
+      w3.z = __builtin_amdgcn_perm(p3[5], p3[4], 0x07060302u);
+      w3.w = __builtin_amdgcn_perm(p3[7], p3[6], 0x07060302u);
+      *reinterpret_cast<uint4*>(&dst[0][lr * BLD + lk]) = w1;
+      *reinterpret_cast<uint4*>(&dst[1][lr * BLD + lk]) = w2;
+      *reinterpret_cast<uint4*>(&dst[2][lr * BLD + lk]) = w3;
+    };
+    gload(kb);
+    split_store(ra0, ra1, As);
+    split_store(rb0, rb1, Bs);
+    __syncthreads();
+    // fragment of a 32-row block: lane (r = lane & 31, h = lane >> 5) holds row r, k = 8h .. 8h+7 (cdna guide, operand maps)
+    const int arow = (wr * 64 + (lane & 31)) * BLD + (lane >> 5) * 8;
+    const int brow = (wc * 64 + (lane & 31)) * BLD + (lane >> 5) * 8;
+    int since = 0;
+    for (int k = kb; k < ke; k += GBK) {
+      const bool more = (k + GBK) < ke;
+      if (more) gload(k + GBK);
+      bf16x8 a[3][2], b[3][2];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a[p][i] = *reinterpret_cast<const bf16x8*>(&As[p][arow + i * 32 * BLD]);
+          b[p][i] = *reinterpret_cast<const bf16x8*>(&Bs[p][brow + i * 32 * BLD]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16 c = acc[i][j];  // small products first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+      since += GBK;
+      if (since >= g.kc && more) {
+        flush(!have_lo);
+        have_lo = true;
+        since = 0;
+      }
+      __syncthreads();  // every wave has read this step's fragments
+      if (more) {
+        split_store(ra0, ra1, As);
+        split_store(rb0, rb1, Bs);
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = (g.tri == 3 ? 0 : n0) + wc * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float h = acc[i][j][r], l = 0.0f;
+        if (have_lo) {
+          const int w = ((i * 2 + j) * 16 + r) >> 1;
+          const uint32_t pk = Lo[w * 256 + tid];
+          l = (r & 1) ? __uint_as_float(pk & 0xffff0000u) : __uint_as_float(pk << 16);
+          const float a = h, hh = hi[i][j][r];
+          const float s = hh + a, b = s - hh;
+          l += (hh - (s - b)) + (a - b);
+          h = s;
+        }
+        if (g.part) {
+          g.part[((long long)blockIdx.z * g.M + row) * g.N + col] = h + l;
+        } else {
+          float* cp = g.C + (long long)row * g.ldc + col;
+          float v = (g.beta != 0.0f) ? fmaf(g.alpha, h, g.beta * (*cp)) : g.alpha * h;
+          *cp = fmaf(g.alpha, l, v);
+        }
+      }
+    }
+}
+
 // C = beta * C + alpha * sum_s part[s]  (fixed order of the partial sums: deterministic)
 __global__ void k_splitk_reduce(const float* __restrict__ part, int S, int M, int N, float alpha, float beta, float* __restrict__ C,
                                 long long ldc) {
@@ -410,7 +599,10 @@ static int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st = nu
   if (S == 1) {
     rp_gemm_args g1 = g;
     g1.kc = ctx->gemm_kc;
-    hipLaunchKernelGGL(k_gemm_nt, dim3(g.tri == 3 ? 1 : g.N / GT, g.M / GT), dim3(256), 0, st, g1);
+    if (ctx->gemm_bf16x3)
+      hipLaunchKernelGGL(k_gemm_nt_b3, dim3(g.tri == 3 ? 1 : g.N / GT, g.M / GT), dim3(256), 0, st, g1);
+    else
+      hipLaunchKernelGGL(k_gemm_nt, dim3(g.tri == 3 ? 1 : g.N / GT, g.M / GT), dim3(256), 0, st, g1);
     RP_HIP(hipGetLastError());
     return RPHIP_OK;
   }
@@ -420,7 +612,10 @@ static int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st = nu
   if (!part) RP_TRY(rp_scratch(ctx, 7, (size_t)S * g.M * g.N * sizeof(float), (void**)&part));
   h.part = part;
   h.k_chunk = (int)(rp_cdiv(rp_cdiv(klen, S), GBK) * GBK);
-  hipLaunchKernelGGL(k_gemm_nt, dim3(g.N / GT, g.M / GT, S), dim3(256), 0, st, h);
+  if (ctx->gemm_bf16x3)
+    hipLaunchKernelGGL(k_gemm_nt_b3, dim3(g.N / GT, g.M / GT, S), dim3(256), 0, st, h);
+  else
+    hipLaunchKernelGGL(k_gemm_nt, dim3(g.N / GT, g.M / GT, S), dim3(256), 0, st, h);
   RP_HIP(hipGetLastError());
   const long long quads = (long long)g.M * g.N / 4;
   hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)std::min<long long>(4096, rp_cdiv(quads, 256))), dim3(256), 0, st, part, S, g.M,
