@@ -229,9 +229,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int BLD = 24;  // plane row stride in bf16 elements
 
 __global__ void __launch_bounds__(256, 2) k_gemm_nt_b3(rp_gemm_args g) {
-  __shared__ __attribute__((aligned(16))) unsigned short As[3][GT * BLD];
-  __shared__ __attribute__((aligned(16))) unsigned short Bs[3][GT * BLD];
-  __shared__ uint32_t Lo[32 * 256];
+  // two buffers per operand (one barrier per step); the compensation terms lo live in REGISTERS here, packed two bf16 per
+  // word (32 registers): without the 32 KB of LDS they take in the fp32 kernel both buffers fit twice per CU
+  __shared__ __attribute__((aligned(16))) unsigned short As[2][3][GT * BLD];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[2][3][GT * BLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int tm = blockIdx.y, tn = (g.tri == 3) ? (int)blockIdx.y : (int)blockIdx.x;
@@ -249,27 +250,25 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_b3(rp_gemm_args g) {
   kb &= ~(GBK - 1);
 
   f32x16 acc[2][2], hi[2][2];
+  uint32_t lo[2][2][8];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = hi[i][j][r] = 0.0f;
-  bool have_lo = false;
-  auto flush = [&](bool first) __attribute__((always_inline)) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) lo[i][j][r] = 0u;
+    }
+  auto flush = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const int w = ((i * 2 + j) * 16 + r) >> 1;
-          float l0 = 0.0f, l1 = 0.0f;
-          if (!first) {
-            const uint32_t pk = Lo[w * 256 + tid];
-            l0 = __uint_as_float(pk << 16);
-            l1 = __uint_as_float(pk & 0xffff0000u);
-          }
+          const uint32_t pk = lo[i][j][r >> 1];
+          float l0 = __uint_as_float(pk << 16), l1 = __uint_as_float(pk & 0xffff0000u);
           const float a0 = acc[i][j][r], a1 = acc[i][j][r + 1];
           const float h0 = hi[i][j][r], h1 = hi[i][j][r + 1];
           const float s0 = h0 + a0, s1 = h1 + a1;
@@ -280,7 +279,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_b3(rp_gemm_args g) {
           hi[i][j][r + 1] = s1;
           acc[i][j][r] = 0.0f;
           acc[i][j][r + 1] = 0.0f;
-          Lo[w * 256 + tid] = rp_pack_bf16_rn(l0, l1);
+          lo[i][j][r >> 1] = rp_pack_bf16_rn(l0, l1);
         }
   };
 
@@ -295,9 +294,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_b3(rp_gemm_args g) {
       rb0 = *reinterpret_cast<const float4*>(Bp + k);
       rb1 = *reinterpret_cast<const float4*>(Bp + k + 4);
     };
-    // eight floats -> three planes of eight bf16 (truncation splits; every residual is exact).  (Converting the next tile in
-    // front of the current step's MFMAs - work the MFMA pipe could shadow - was measured: 145 instead of 162 TF/s, the
-    // compiler does not interleave it and the 24 extra live registers cost more than the overlap gains.)
+    // eight floats -> three planes of eight bf16 (truncation splits; every residual is exact)
     auto split_store = [&](const float4& u0, const float4& u1, unsigned short (*dst)[GT * BLD]) {
       const float x[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
       uint32_t p1[8], p2[8], p3[8];
@@ -327,13 +324,13 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_b3(rp_gemm_args g) {
       *reinterpret_cast<uint4*>(&dst[2][lr * BLD + lk]) = w3;
     };
     gload(kb);
-    split_store(ra0, ra1, As);
-    split_store(rb0, rb1, Bs);
+    split_store(ra0, ra1, As[0]);
+    split_store(rb0, rb1, Bs[0]);
     __syncthreads();
     // fragment of a 32-row block: lane (r = lane & 31, h = lane >> 5) holds row r, k = 8h .. 8h+7 (cdna guide, operand maps)
     const int arow = (wr * 64 + (lane & 31)) * BLD + (lane >> 5) * 8;
     const int brow = (wc * 64 + (lane & 31)) * BLD + (lane >> 5) * 8;
-    int since = 0;
+    int since = 0, cur = 0;
     for (int k = kb; k < ke; k += GBK) {
       const bool more = (k + GBK) < ke;
       if (more) gload(k + GBK);
@@ -342,8 +339,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_b3(rp_gemm_args g) {
       for (int p = 0; p < 3; ++p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          a[p][i] = *reinterpret_cast<const bf16x8*>(&As[p][arow + i * 32 * BLD]);
-          b[p][i] = *reinterpret_cast<const bf16x8*>(&Bs[p][brow + i * 32 * BLD]);
+          a[p][i] = *reinterpret_cast<const bf16x8*>(&As[cur][p][arow + i * 32 * BLD]);
+          b[p][i] = *reinterpret_cast<const bf16x8*>(&Bs[cur][p][brow + i * 32 * BLD]);
         }
       }
 #pragma unroll
@@ -359,20 +356,20 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_b3(rp_gemm_args g) {
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);
           acc[i][j] = c;
         }
+      if (more) {  // the next tile goes to the other buffer: one barrier per step
+        split_store(ra0, ra1, As[cur ^ 1]);
+        split_store(rb0, rb1, Bs[cur ^ 1]);
+      }
       since += GBK;
       if (since >= g.kc && more) {
-        flush(!have_lo);
-        have_lo = true;
+        flush();
         since = 0;
       }
-      __syncthreads();  // every wave has read this step's fragments
-      if (more) {
-        split_store(ra0, ra1, As);
-        split_store(rb0, rb1, Bs);
-      }
       __syncthreads();
+      cur ^= 1;
     }
   }
+  flush();  // the last piece
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -381,16 +378,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_b3(rp_gemm_args g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        float h = acc[i][j][r], l = 0.0f;
-        if (have_lo) {
-          const int w = ((i * 2 + j) * 16 + r) >> 1;
-          const uint32_t pk = Lo[w * 256 + tid];
-          l = (r & 1) ? __uint_as_float(pk & 0xffff0000u) : __uint_as_float(pk << 16);
-          const float a = h, hh = hi[i][j][r];
-          const float s = hh + a, b = s - hh;
-          l += (hh - (s - b)) + (a - b);
-          h = s;
-        }
+        const uint32_t pk = lo[i][j][r >> 1];
+        const float h = hi[i][j][r];
+        const float l = (r & 1) ? __uint_as_float(pk & 0xffff0000u) : __uint_as_float(pk << 16);
         if (g.part) {
           g.part[((long long)blockIdx.z * g.M + row) * g.N + col] = h + l;
         } else {
