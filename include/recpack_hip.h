@@ -98,6 +98,9 @@ int rphip_ctx_trim(rphip_ctx* ctx);
  *                       (rphip_csr_set_values) always use the 64-bit sums.  Both are independent of the order of the adds:
  *                       predict is bit-reproducible run to run.
  *   "predict_tile32"    2048 | 4096 (default): column tile of the 32-bit sums (tuning).
+ *   "gemm_bf16x3"       1 (default) | 0.  The O(n^3) products of the EASE solve run on the bf16 matrix pipe with fp32 operands cut into
+ *                       three bf16 planes (six plane products per step, fp32 accumulate: the accuracy of the fp32 MFMA kernel,
+ *                       1.5x its speed); 0 selects the fp32-input MFMA kernel (v_mfma_f32_32x32x2_f32).
  *   "gemm_flush_k"      K steps between two flushes of the MFMA accumulators into the compensated (hi + lo) master sums of the
  *                       EASE solve's GEMM (default 512, a multiple of 16; a value beyond any K = plain fp32 accumulation).
  *   "cache_limit_bytes" see rphip_ctx_trim. */

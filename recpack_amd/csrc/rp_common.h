@@ -75,7 +75,7 @@ struct rphip_ctx {
   // predict options (rphip_ctx_set_option)
   int predict_exact64 = 0;   // 1: the wave predict kernel sums in 64 bits (exact) instead of the per-user-scaled 32 bits
   int pw_wt32 = 4096;        // tile width of the 32-bit sums: 2048 or 4096 (tuning)
-  int gemm_bf16x3 = 0;       // 1: the solve's products run on the bf16 matrix pipe with three-way split operands
+  int gemm_bf16x3 = 1;       // 1 (default): the solve's products run on the bf16 matrix pipe with three-way split operands; 0: fp32 MFMA
   int gemm_kc = 512;         // K steps between two flushes of the MFMA accumulators into the compensated master sums
 };
 

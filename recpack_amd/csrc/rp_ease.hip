@@ -223,8 +223,14 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(rp_gemm_args g) {
 // The planes are cut when a tile is staged (global fp32 -> registers -> three bf16 images in LDS, 5.5 VALU per element in the
 // shadow of the other workgroup's MFMAs): memory holds fp32 only, 200 000 items still fit one GPU.
 // LDS: a plane row is 16 bf16 + 8 of padding (48 B: the 16-B fragment reads of 16 consecutive rows then cover all 64 banks
-// once); one buffer per operand (a second set of three planes would not leave room for two workgroups per CU next to the 32 KB
-// of lo), so a step has two barriers - the second workgroup on the CU computes meanwhile.
+// once), two buffers per operand and one barrier per step; the compensation terms lo sit in registers here (packed bf16
+// pairs, 32 registers), which is what lets both buffers fit twice per CU (74 KB per workgroup).
+// Measured (MI355X, 8192^3, fp32-equivalent 2 n^3 / t): 165 TF/s against 113 for the fp32 MFMA kernel, the same error to the
+// digit (2.5e-8 .. 2.5e-7 of sum |a||b|).  That is 40 % of the 417 TF/s the six-product scheme could reach: a step writes 37 KB
+// of planes to LDS per workgroup (ds_write_b128 sustains ~79 B/clk/CU) and reads 48 KB - the LDS pipe is as busy as the
+// matrix pipe.  Variants measured and dropped: one buffer + two barriers with lo in LDS (162), the next tile's conversion
+// hoisted in front of the MFMAs (145: 24 more live registers, no interleaving by the compiler), K32 steps in one buffer (168
+// on the square product, but 7.6 s instead of 6.5 s for the C4 fit: the clipped K ranges of the triangular factors).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int BLD = 24;  // plane row stride in bf16 elements
 
