@@ -68,8 +68,10 @@ for l2, alpha in ((50.0, 0.0), (5.0, 0.5)):
     users, pi, pv, pn = rdist.predict_topk_sharded(ctx, ms, dX, 20, device, exclude_history=True, user_chunk=257)
     users = users.cpu().numpy()
     sel = users < nu
-    agree_s = float((pi.cpu().numpy()[sel] == b[0][users[sel]]).mean()) if sel.any() else 1.0
-    dv = float(np.abs(pv.cpu().numpy()[sel] - b[1][users[sel]]).max() / max(1e-30, np.abs(b[1]).max())) if sel.any() else 0.0
+    same = pi.cpu().numpy()[sel] == b[0][users[sel]]
+    agree_s = float(same.mean()) if sel.any() else 1.0
+    # scores where both picked the same item at the same position (a near-tie at the K-th place shifts the rest of a row)
+    dv = float((np.abs(pv.cpu().numpy()[sel] - b[1][users[sel]]) * same).max() / max(1e-30, np.abs(b[1]).max())) if sel.any() else 0.0
     mem_ok = world == 1 or n_pad < 2560 or peak <= budget  # (below 20 tiles the 128-column granularity alone exceeds the 10 %)
     print(f"rank {rank}/{world} columns [{c0},{c0 + nc}) l2={l2} alpha={alpha}: max|dB|/max|B| = {err_s:.2e}, sharded top-20 agreement {agree_s:.4f}, "
           f"score diff {dv:.1e}, peak {peak / 2**20:.1f} MiB (budget n_pad^2*4*(1/world+0.1) = {budget / 2**20:.1f} MiB)", flush=True)
