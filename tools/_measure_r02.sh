@@ -6,5 +6,6 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r02 -- python3 bench.py --steps 5 --warmup 2 --cpu-baseline-seconds 0 > gpurun_out/prof_r02.log 2>&1
 bash tools/pmc_traffic.sh > gpurun_out/pmc_traffic.txt 2>&1
 bash tools/pmc_sq.sh k_ C4 > gpurun_out/pmc_sq_all.txt 2>&1
+RECPACK_GEMM_BF16X3=0 bash tools/pmc_mfma.sh > gpurun_out/pmc_mfma_f32.txt 2>&1; cp gpurun_out/pmc_mfma.json gpurun_out/pmc_mfma_f32.json
 bash tools/pmc_mfma.sh > gpurun_out/pmc_mfma.txt 2>&1
 tail -5 gpurun_out/pmc_mfma.txt

@@ -14,6 +14,8 @@ l2 = float(sys.argv[4]) if len(sys.argv) > 4 else 200.0
 dev = torch.device("cuda", 0)
 ip, ix = powerlaw_csr(U, I, dens, seed=20260003, device=dev)
 ctx = _lib.Context(0)
+if os.environ.get("RECPACK_GEMM_BF16X3"):
+    ctx.set_option("gemm_bf16x3", int(os.environ["RECPACK_GEMM_BF16X3"]))
 dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
 for it in range(2):
     ctx.reset_timings()

@@ -2,10 +2,10 @@
 # MFMA counters of the EASE solve's GEMM (k_gemm_nt): tools/pmc_mfma.sh [users items density]   (on the GPU box)
 # One rocprofv3 --pmc pass (SQ block: 8 slots) with --kernel-trace only; prints per-kernel sums and the derived utilisation:
 #   MFMA busy share  = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CU_CYCLES x 4 SIMDs)   [cycles the matrix pipes were busy]
-#   flops from MOPS  = SQ_INSTS_VALU_MFMA_MOPS_F32 x 512
+#   flops from MOPS  = (SQ_INSTS_VALU_MFMA_MOPS_F32 + _BF16) x 512   (the default solve runs bf16 plane products)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 U=${1:-200000}; I=${2:-50000}; D=${3:-0.001}
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_BUSY_CYCLES \
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA \
   --output-format csv -d gpurun_out/pmc_mfma -- python3 tools/ease_bench.py $U $I $D > gpurun_out/pmc_mfma.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections, json
@@ -30,8 +30,9 @@ for k, c in acc.items():
     d["total_seconds_profiled"] = dur[k]
     if c.get("SQ_BUSY_CU_CYCLES"):
         d["mfma_busy_share"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * c["SQ_BUSY_CU_CYCLES"])
-    if c.get("SQ_INSTS_VALU_MFMA_MOPS_F32") and dur[k] > 0:
-        d["tflops_from_mops"] = c["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512.0 / dur[k] / 1e12
+    mops = c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) + c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)
+    if mops and dur[k] > 0:
+        d["tflops_from_mops"] = mops * 512.0 / dur[k] / 1e12
     out[k] = d
 print(json.dumps(out, indent=1))
 json.dump(out, open("gpurun_out/pmc_mfma.json", "w"), indent=1)
