@@ -4,6 +4,7 @@ cd "$GRAFT_REPO_ROOT"
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/bench_r02.json 2> gpurun_out/bench_r02.err; tail -c 600 gpurun_out/bench_r02.json
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r02 -- python3 bench.py --steps 5 --warmup 2 --cpu-baseline-seconds 0 > gpurun_out/prof_r02.log 2>&1
+cp gpurun_out/prof_r02/*/*kernel_stats.csv gpurun_out/kernel_stats_r02.csv; rm -rf gpurun_out/prof_r02
 bash tools/pmc_traffic.sh > gpurun_out/pmc_traffic.txt 2>&1
 bash tools/pmc_sq.sh k_ C4 > gpurun_out/pmc_sq_all.txt 2>&1
 RECPACK_GEMM_BF16X3=0 bash tools/pmc_mfma.sh > gpurun_out/pmc_mfma_f32.txt 2>&1; cp gpurun_out/pmc_mfma.json gpurun_out/pmc_mfma_f32.json

@@ -38,3 +38,4 @@ print(json.dumps(out, indent=1))
 json.dump(out, open("gpurun_out/pmc_mfma.json", "w"), indent=1)
 PY
 tail -3 gpurun_out/pmc_mfma.log
+rm -rf gpurun_out/pmc_mfma

@@ -15,3 +15,4 @@ for f in glob.glob("gpurun_out/pmc_sq/**/*counter_collection.csv", recursive=Tru
 for (kn, c), (v, n) in sorted(acc.items()):
     print(f"{kn:60s} {c:22s} {v/n:16.0f}  (x{n})")
 PY
+rm -rf gpurun_out/pmc_sq
