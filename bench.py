@@ -182,7 +182,7 @@ def cpu_baseline_ease(indptr, indices, shape, l2, Kp, sizes=(8192, 16384), budge
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16); never the sparse figure
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 matrix peak (v_mfma_f32_32x32x16_bf16 / _f16); never the sparse figure
 
 
 def ease_leg(args, ctx, device, Kp, config, repeats):
@@ -230,23 +230,23 @@ def ease_leg(args, ctx, device, Kp, config, repeats):
         "wall_s_all_runs": walls,  # [warm-up, timed ...]: the warm-up pays the first allocation of B
         "kernel_s_in_fit": round(sum(v["ms"] for k, v in tm.items() if k != "predict") / 1e3, 4),  # HIP-event time inside the fit wall time
         "phases_ms": {k: round(v["ms"], 3) for k, v in tm.items() if v["launches"]},
-        # the solve's products run on the bf16 matrix pipe with fp32 operands cut into three bf16 planes: SIX bf16 MFMA products per
-        # fp32-equivalent product, so the matrix pipe executes 6 n^3 bf16 flop for the n^3 of the model - priced against the dense
-        # bf16 peak; `fp32_equivalent` is the same time against the n^3 model (what an fp32 MFMA kernel would have to sustain)
+        # the solve's products run on the 16-bit matrix pipe with fp32 operands cut into two fp16 planes: THREE fp16 MFMA products per
+        # fp32-equivalent product, so the matrix pipe executes 3 n^3 fp16 flop for the n^3 of the model - priced against the dense
+        # fp16 / bf16 peak; `fp32_equivalent` is the same time against the n^3 model (what an fp32 MFMA kernel would have to sustain)
         "roofline": {
-            "kernel": "k_gemm_nt_b3 (K5 Cholesky + K6 inverse: v_mfma_f32_32x32x16_bf16 on three-way split fp32 operands, fp32 accumulate, "
+            "kernel": "k_gemm_nt_h2 (K5 Cholesky + K6 inverse: v_mfma_f32_32x32x16_f16 on fp32 operands cut into two fp16 planes, fp32 accumulate, "
                       "compensated master sums)",
             "bound": "mfma",
-            "achieved": round(6.0 * tf, 2),
+            "achieved": round(3.0 * tf, 2),
             "peak": MFMA_BF16_PEAK_TFLOPS,
             "unit": "TFLOP/s",
-            "frac": round(6.0 * tf / MFMA_BF16_PEAK_TFLOPS, 4),
-            "flops_model": "6 bf16 plane products x n^3 (Cholesky n^3/3 + inverse 2n^3/3), n padded to 128",
+            "frac": round(3.0 * tf / MFMA_BF16_PEAK_TFLOPS, 4),
+            "flops_model": "3 fp16 plane products x n^3 (Cholesky n^3/3 + inverse 2n^3/3), n padded to 128",
             "fp32_equivalent": {"achieved": round(tf, 2), "peak_fp32_mfma": MFMA_F32_PEAK_TFLOPS, "frac_of_fp32_mfma_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
                                 "flops_model": "n^3"},
             "solve_ms": round(solve_ms, 2),
         },
-        "dtype": "f32 storage; products as 3 x bf16 planes on the bf16 MFMA (24 bits kept), f32 accumulate + compensated sums, float64 diagonal blocks",
+        "dtype": "f32 storage; products as 2 x fp16 planes on the fp16 MFMA (22 bits + rounding to nearest = fp32's 2^-24), f32 accumulate + compensated sums, float64 diagonal blocks",
     }
 
 

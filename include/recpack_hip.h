@@ -98,9 +98,16 @@ int rphip_ctx_trim(rphip_ctx* ctx);
  *                       (rphip_csr_set_values) always use the 64-bit sums.  Both are independent of the order of the adds:
  *                       predict is bit-reproducible run to run.
  *   "predict_tile32"    2048 | 4096 (default): column tile of the 32-bit sums (tuning).
- *   "gemm_bf16x3"       1 (default) | 0.  The O(n^3) products of the EASE solve run on the bf16 matrix pipe with fp32 operands cut into
- *                       three bf16 planes (six plane products per step, fp32 accumulate: the accuracy of the fp32 MFMA kernel,
- *                       1.5x its speed); 0 selects the fp32-input MFMA kernel (v_mfma_f32_32x32x2_f32).
+ *   "gemm_mode"         2 (default) | 1 | 0: how the O(n^3) products of the EASE solve (and rphip_gemm_nt_f32) multiply their fp32 operands.
+ *                       2: two fp16 planes per operand, both rounded to nearest (x = h1 + h2 to 2^-24 |x|), three plane products per
+ *                          step on v_mfma_f32_32x32x16_f16; each operand is scaled by a power of two taken from its largest magnitude
+ *                          over the rows and K range the launch reads (one extra pass over the operands), so fp16's range is never
+ *                          left; fp32 accumulate.  1: three bf16 planes by truncation, six plane products (no scaling pass).
+ *                          0: the fp32-input MFMA (v_mfma_f32_32x32x2_f32).  Error of one product, relative to sum |a||b|:
+ *                          the same for all three (2e-8 .. 2.5e-7); speed on MI355X 216 / 165 / 113 TFLOP/s fp32-equivalent.
+ *   "gemm_supertile"    0 (default) | 1.  Tile order of the GEMM's workgroups: supertiles of 64 tiles handed to the 8 XCDs round-robin
+ *                       (each XCD's L2 then holds the 8 + 8 panels of an 8 x 8 block of tiles), or the plain row-major grid
+ *                       (measured equal within 1 %: the products are not bound by operand traffic).
  *   "gemm_flush_k"      K steps between two flushes of the MFMA accumulators into the compensated (hi + lo) master sums of the
  *                       EASE solve's GEMM (default 512, a multiple of 16; a value beyond any K = plain fp32 accumulation).
  *   "cache_limit_bytes" see rphip_ctx_trim. */

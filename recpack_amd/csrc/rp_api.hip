@@ -82,6 +82,7 @@ extern "C" int rphip_ctx_destroy(rphip_ctx* ctx) {
   for (auto& b : ctx->scratch)
     if (b.p) hipFree(b.p);
   if (ctx->dev_counters) hipFree(ctx->dev_counters);
+  if (ctx->gemm_amax_ring) hipFree(ctx->gemm_amax_ring);
   if (ctx->own_stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return RPHIP_OK;
@@ -207,8 +208,11 @@ extern "C" int rphip_ctx_set_option(rphip_ctx* ctx, const char* name, int64_t va
   } else if (!strcmp(name, "predict_tile32")) {
     if (value != 2048 && value != 4096) RP_FAIL(RPHIP_EINVAL, "predict_tile32 must be 2048 or 4096");
     ctx->pw_wt32 = (int)value;
-  } else if (!strcmp(name, "gemm_bf16x3")) {
-    ctx->gemm_bf16x3 = value ? 1 : 0;
+  } else if (!strcmp(name, "gemm_mode")) {
+    if (value < 0 || value > 2) RP_FAIL(RPHIP_EINVAL, "gemm_mode must be 0 (fp32), 1 (bf16 x 3) or 2 (fp16 x 2)");
+    ctx->gemm_mode = (int)value;
+  } else if (!strcmp(name, "gemm_supertile")) {
+    ctx->gemm_supertile = value ? 1 : 0;
   } else if (!strcmp(name, "gemm_flush_k")) {
     if (value < 16 || (value % 16)) RP_FAIL(RPHIP_EINVAL, "gemm_flush_k must be a positive multiple of 16");
     ctx->gemm_kc = (int)std::min<int64_t>(value, 1 << 30);

@@ -75,9 +75,14 @@ struct rphip_ctx {
   // predict options (rphip_ctx_set_option)
   int predict_exact64 = 0;   // 1: the wave predict kernel sums in 64 bits (exact) instead of the per-user-scaled 32 bits
   int pw_wt32 = 4096;        // tile width of the 32-bit sums: 2048 or 4096 (tuning)
-  int gemm_bf16x3 = 1;       // 1 (default): the solve's products run on the bf16 matrix pipe with three-way split operands; 0: fp32 MFMA
+  int gemm_mode = 2;         // operands of the solve's products: 0 fp32 MFMA, 1 three bf16 planes (6 products), 2 two fp16 planes (3 products)
+  int gemm_supertile = 0;    // 1: GEMM workgroups walk the tiles in XCD-round-robin 8 x 8 supertiles (0: row-major 2-D grid)
+  unsigned* gemm_amax_ring = nullptr;  // mode 2: [RP_AMAX_SLOTS][2] words, the operands' largest magnitudes per launch
+  unsigned long long gemm_amax_seq = 0;
   int gemm_kc = 512;         // K steps between two flushes of the MFMA accumulators into the compensated master sums
 };
+
+constexpr int RP_AMAX_SLOTS = 4096;
 
 struct rphip_csr {
   rphip_ctx* ctx = nullptr;

@@ -49,7 +49,32 @@ struct rp_gemm_args {
   float* part;
   int k_chunk;
   int kc;            // K steps between two flushes into the master sums (set by rp_gemm_nt from the context: GKC by default)
+  const unsigned* amax;  // k_gemm_nt_h2: device words [max |A|, max |B|] over the ranges read (k_gemm_amax); set by rp_gemm_nt
+  int sw;            // tiles per row of a supertile (64 tiles: sw x 64/sw), 0 = plain row-major 2-D grid; set by rp_gemm_nt
 };
+
+// Which tile a workgroup computes.  Workgroups go to the 8 XCDs round-robin by their linear id, and each XCD has its own L2.  In
+// plain row-major order the 64 workgroups resident on an XCD are 64 different column tiles of one tile row: one A panel shared
+// by all of them and 64 B panels that nobody else on that XCD reads - B streams from HBM once per tile row (1.4 TB/s measured
+// over the solve at 50 000 items).  Here the grid is 1-D and an XCD's 64 consecutive workgroups form one SUPERTILE of sw x 64/sw
+// tiles (8 x 8 when the product is that wide: 8 + 8 panels for 64 tiles); supertile s goes to XCD s % 8, so that the XCDs walk
+// the matrix side by side in the same row-major (top = longest K first) order.  (Giving each XCD one contiguous range of tiles
+// instead was measured in round 1 and lost 50 % on P = N N^T: all the long rows land on one XCD.)
+__device__ __forceinline__ bool rp_gemm_tile(const rp_gemm_args& g, int& tm, int& tn) {
+  if (g.sw == 0) {
+    tm = blockIdx.y;
+    tn = (g.tri == 3) ? (int)blockIdx.y : (int)blockIdx.x;
+    return true;
+  }
+  const unsigned L = blockIdx.x, c = L >> 3;
+  const unsigned sup = (c >> 6) * 8 + (L & 7), w = c & 63;
+  const unsigned gx = g.N / GT, gy = g.M / GT, sh = 64u / g.sw;
+  const unsigned sxn = (gx + g.sw - 1) / g.sw;
+  const unsigned sy = sup / sxn, sx = sup - sy * sxn;
+  tn = (int)(sx * g.sw + w % g.sw);
+  tm = (int)(sy * sh + w / g.sw);
+  return (unsigned)tn < gx && (unsigned)tm < gy;
+}
 
 // Accumulation.  The MFMA adds into its fp32 accumulator in K order: over a K of 10^5 that alone loses ~ sqrt(K) eps, and
 // the Cholesky / inverse / product chain of EASE multiplies it by the condition of G + lambda I - measured against
@@ -73,10 +98,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(rp_gemm_args g) {
   __shared__ uint32_t Lo[32 * 256];  // [word][thread]: bf16 pairs of the 64 compensation terms of each thread
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  // Tiles in plain row-major order: with the clipped K ranges of the triangular factors the top tile rows carry the
-  // longest K loops, so dispatch order = longest first.  (An XCD-contiguous regrouping for L2 reuse was measured and
-  // lost 50 % on P = N N^T: it hands all long rows to one XCD.)
-  const int tm = blockIdx.y, tn = (g.tri == 3) ? (int)blockIdx.y : (int)blockIdx.x;
+  int tm, tn;
+  if (!rp_gemm_tile(g, tm, tn)) return;
   const int m0 = tm * GT, n0 = tn * GT;
   if (g.tri == 1 && g.n_off + n0 > g.m_off + m0) return;
   if (g.tri == 2 && g.n_off + n0 >= g.m_off + m0) return;
@@ -241,7 +264,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_b3(rp_gemm_args g) {
   __shared__ __attribute__((aligned(16))) unsigned short Bs[2][3][GT * BLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int tm = blockIdx.y, tn = (g.tri == 3) ? (int)blockIdx.y : (int)blockIdx.x;
+  int tm, tn;
+  if (!rp_gemm_tile(g, tm, tn)) return;
   const int m0 = tm * GT, n0 = tn * GT;
   if (g.tri == 1 && g.n_off + n0 > g.m_off + m0) return;
   if (g.tri == 2 && g.n_off + n0 >= g.m_off + m0) return;
@@ -365,6 +389,222 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_b3(rp_gemm_args g) {
       if (more) {  // the next tile goes to the other buffer: one barrier per step
         split_store(ra0, ra1, As[cur ^ 1]);
         split_store(rb0, rb1, Bs[cur ^ 1]);
+      }
+      since += GBK;
+      if (since >= g.kc && more) {
+        flush();
+        since = 0;
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  flush();  // the last piece
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = (g.tri == 3 ? 0 : n0) + wc * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const uint32_t pk = lo[i][j][r >> 1];
+        const float h = hi[i][j][r];
+        const float l = (r & 1) ? __uint_as_float(pk & 0xffff0000u) : __uint_as_float(pk << 16);
+        if (g.part) {
+          g.part[((long long)blockIdx.z * g.M + row) * g.N + col] = h + l;
+        } else {
+          float* cp = g.C + (long long)row * g.ldc + col;
+          float v = (g.beta != 0.0f) ? fmaf(g.alpha, h, g.beta * (*cp)) : g.alpha * h;
+          *cp = fmaf(g.alpha, l, v);
+        }
+      }
+    }
+}
+
+// ---- two fp16 planes: three plane products ---------------------------------------------------------------------------------------
+// fp16 carries 11 significant bits where bf16 carries 8: with round-to-nearest, x = h1 + h2 + e with h1 = fp16(x), h2 = fp16(x - h1)
+// (the subtraction is exact) and |e| <= 2^-12 |h2| <= 2^-24 |x| - TWO planes hold an fp32 operand to fp32's own rounding, and a
+// product keeps a1 b1 + (a1 b2 + a2 b1); the dropped a2 b2 is below 2^-24 |a b|.  Three MFMAs (v_mfma_f32_32x32x16_f16, the bf16
+// rate) per K16 step and output tile instead of six, 4 bytes of LDS per element instead of 6, and a cheaper cut (two conversions
+// and one subtraction per element).  What fp16 lacks is RANGE (2^-24 .. 65504), so each operand is multiplied by a power of two
+// that puts its largest magnitude - over exactly the rows and K range this launch reads: k_gemm_amax, one pass over the operand
+// beforehand - into [2^14, 2^15): entries down to 2^-39 of the largest still get their full 22 bits, smaller ones are absolute
+// to 2^-39 of it (a fixed-point tail that a product of magnitudes sum |a||b| does not see).  The scales leave the accumulators at
+// the flush (acc * 1 / (sA sB), exact), the compensated master sums and the epilogue are those of the kernels above.
+// (A register-side cut of bf16 planes - fp32 tile in LDS, each wave converting its own fragments, 2.3x less LDS traffic for 2x
+// the conversions - was measured at 157 TF/s against 165 for k_gemm_nt_b3, and dropped.)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float rp_h2_scale(unsigned amax_bits) {  // power of two s with s * amax in [2^14, 2^15)
+  const int E = (int)((amax_bits >> 23) & 0xffu);
+  if (E == 0 || E == 255) return 1.0f;  // all zero (or subnormal), or not finite: nothing to protect
+  const int se = min(max(268 - E, 67), 187);  // s = 2^(141 - E), kept within 2^+-60
+  return __uint_as_float((unsigned)se << 23);
+}
+
+struct rp_amax_op {
+  const float* P;
+  long long ld;
+  int tiles;    // 128-row tiles
+  int kb_flag;  // the tile's K range begins at off + r0 (see rp_gemm_args::kb_m / kb_n)
+  int ke_flag;  // ... ends at off + r0 + 128 (ke_n)
+  int off;
+};
+
+// out[0] = max |A|, out[1] = max |B| (fp32 bit patterns, zeroed by the caller) over the K ranges the product will read.
+// One workgroup per (row tile, 256-column chunk): a wave reads one row's chunk (1 KB) per instruction.
+__global__ void __launch_bounds__(256) k_gemm_amax(rp_amax_op a, rp_amax_op b, int k0, int k1, int dup, unsigned* out) {
+  __shared__ float red[4];
+  int t = blockIdx.x;
+  const bool is_b = t >= a.tiles;
+  const rp_amax_op o = is_b ? b : a;
+  if (is_b) t -= a.tiles;
+  const int r0 = t * GT;
+  int kb = k0, ke = k1;
+  if (o.kb_flag) kb = max(kb, o.off + r0);
+  if (o.ke_flag) ke = min(ke, o.off + r0 + GT);
+  kb &= ~(GBK - 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = k0 + (int)blockIdx.y * 256 + lane * 4;
+  float m = 0.0f;
+  if (c >= kb && c < ke) {
+    const float* p = o.P + (long long)r0 * o.ld + c;
+#pragma unroll 8
+    for (int r = wave; r < GT; r += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (long long)r * o.ld);
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+  }
+  // NaN never wins an fmaxf: a non-finite operand shows up as inf or not at all, and the product is NaN / inf either way
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (m > 0.0f) {
+      atomicMax(out + (is_b ? 1 : 0), __float_as_uint(m));
+      if (dup) atomicMax(out + 1, __float_as_uint(m));
+    }
+  }
+}
+
+constexpr int HLD = 24;  // plane row stride in fp16 elements (48 B, as BLD)
+
+__global__ void __launch_bounds__(256, 2) k_gemm_nt_h2(rp_gemm_args g) {
+  __shared__ __attribute__((aligned(16))) unsigned short As[2][2][GT * HLD];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[2][2][GT * HLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  int tm, tn;
+  if (!rp_gemm_tile(g, tm, tn)) return;
+  const int m0 = tm * GT, n0 = tn * GT;
+  if (g.tri == 1 && g.n_off + n0 > g.m_off + m0) return;
+  if (g.tri == 2 && g.n_off + n0 >= g.m_off + m0) return;
+  int kb = g.k0, ke = g.k1;
+  if (g.part) {
+    kb = g.k0 + (int)blockIdx.z * g.k_chunk;
+    ke = min(g.k1, kb + g.k_chunk);
+  }
+  if (g.kb_m) kb = max(kb, g.m_off + m0);
+  if (g.kb_n) kb = max(kb, g.n_off + n0);
+  if (g.ke_n) ke = min(ke, g.n_off + n0 + GT);
+  kb &= ~(GBK - 1);
+  const float sa = rp_h2_scale(g.amax[0]), sb = rp_h2_scale(g.amax[1]);
+  const float unscale = 1.0f / (sa * sb);  // a power of two
+
+  f32x16 acc[2][2], hi[2][2];
+  uint32_t lo[2][2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = hi[i][j][r] = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) lo[i][j][r] = 0u;
+    }
+  auto flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const uint32_t pk = lo[i][j][r >> 1];
+          float l0 = __uint_as_float(pk << 16), l1 = __uint_as_float(pk & 0xffff0000u);
+          const float a0 = acc[i][j][r] * unscale, a1 = acc[i][j][r + 1] * unscale;
+          const float h0 = hi[i][j][r], h1 = hi[i][j][r + 1];
+          const float s0 = h0 + a0, s1 = h1 + a1;
+          const float b0 = s0 - h0, b1 = s1 - h1;
+          l0 += (h0 - (s0 - b0)) + (a0 - b0);
+          l1 += (h1 - (s1 - b1)) + (a1 - b1);
+          hi[i][j][r] = s0;
+          hi[i][j][r + 1] = s1;
+          acc[i][j][r] = 0.0f;
+          acc[i][j][r + 1] = 0.0f;
+          lo[i][j][r >> 1] = rp_pack_bf16_rn(l0, l1);
+        }
+  };
+
+  if (kb < ke) {
+    const int lr = tid >> 1, lk = (tid & 1) * 8;  // one row, eight consecutive K per thread and operand
+    const float* Ap = g.A + (long long)(m0 + lr) * g.lda + lk;
+    const float* Bp = g.B + (long long)(n0 + lr) * g.ldb + lk;
+    float4 ra0, ra1, rb0, rb1;
+    auto gload = [&](int k) {
+      ra0 = *reinterpret_cast<const float4*>(Ap + k);
+      ra1 = *reinterpret_cast<const float4*>(Ap + k + 4);
+      rb0 = *reinterpret_cast<const float4*>(Bp + k);
+      rb1 = *reinterpret_cast<const float4*>(Bp + k + 4);
+    };
+    // eight floats -> two planes of eight fp16, both rounded to nearest
+    auto split_store = [&](const float4& u0, const float4& u1, float s, unsigned short (*dst)[GT * HLD]) {
+      const float x[8] = {u0.x * s, u0.y * s, u0.z * s, u0.w * s, u1.x * s, u1.y * s, u1.z * s, u1.w * s};
+      f16x8 h1, h2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const _Float16 t = (_Float16)x[e];
+        h1[e] = t;
+        h2[e] = (_Float16)(x[e] - (float)t);
+      }
+      *reinterpret_cast<f16x8*>(&dst[0][lr * HLD + lk]) = h1;
+      *reinterpret_cast<f16x8*>(&dst[1][lr * HLD + lk]) = h2;
+    };
+    gload(kb);
+    split_store(ra0, ra1, sa, As[0]);
+    split_store(rb0, rb1, sb, Bs[0]);
+    __syncthreads();
+    // fragment of a 32-row block: lane (r = lane & 31, h = lane >> 5) holds row r, k = 8h .. 8h+7 (the bf16 map)
+    const int arow = (wr * 64 + (lane & 31)) * HLD + (lane >> 5) * 8;
+    const int brow = (wc * 64 + (lane & 31)) * HLD + (lane >> 5) * 8;
+    int since = 0, cur = 0;
+    for (int k = kb; k < ke; k += GBK) {
+      const bool more = (k + GBK) < ke;
+      if (more) gload(k + GBK);
+      f16x8 a[2][2], b[2][2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a[p][i] = *reinterpret_cast<const f16x8*>(&As[cur][p][arow + i * 32 * HLD]);
+          b[p][i] = *reinterpret_cast<const f16x8*>(&Bs[cur][p][brow + i * 32 * HLD]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16 c = acc[i][j];  // small products first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[0][j], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+      if (more) {  // the next tile goes to the other buffer: one barrier per step
+        split_store(ra0, ra1, sa, As[cur ^ 1]);
+        split_store(rb0, rb1, sb, Bs[cur ^ 1]);
       }
       since += GBK;
       if (since >= g.kc && more) {
@@ -592,29 +832,47 @@ static int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st = nu
     S = (int)std::min<long long>(8, std::min<long long>(klen / 2048, rp_cdiv(3LL * ctx->n_cu, tiles)));
     if (S < 2) S = 1;
   }
-  if (S == 1) {
-    rp_gemm_args g1 = g;
-    g1.kc = ctx->gemm_kc;
-    if (ctx->gemm_bf16x3)
-      hipLaunchKernelGGL(k_gemm_nt_b3, dim3(g.tri == 3 ? 1 : g.N / GT, g.M / GT), dim3(256), 0, st, g1);
-    else
-      hipLaunchKernelGGL(k_gemm_nt, dim3(g.tri == 3 ? 1 : g.N / GT, g.M / GT), dim3(256), 0, st, g1);
-    RP_HIP(hipGetLastError());
-    return RPHIP_OK;
-  }
   rp_gemm_args h = g;
   h.kc = ctx->gemm_kc;
-  float* part = part_at;
-  if (!part) RP_TRY(rp_scratch(ctx, 7, (size_t)S * g.M * g.N * sizeof(float), (void**)&part));
-  h.part = part;
-  h.k_chunk = (int)(rp_cdiv(rp_cdiv(klen, S), GBK) * GBK);
-  if (ctx->gemm_bf16x3)
-    hipLaunchKernelGGL(k_gemm_nt_b3, dim3(g.N / GT, g.M / GT, S), dim3(256), 0, st, h);
-  else
-    hipLaunchKernelGGL(k_gemm_nt, dim3(g.N / GT, g.M / GT, S), dim3(256), 0, st, h);
+  dim3 grid(g.tri == 3 ? 1 : g.N / GT, g.M / GT, S);
+  h.sw = 0;
+  if (g.tri != 3 && ctx->gemm_supertile) {
+    const int gx = g.N / GT, gy = g.M / GT;
+    h.sw = gx >= 8 ? 8 : (gx >= 4 ? 4 : (gx >= 2 ? 2 : 1));
+    const long long ns = rp_cdiv(gx, h.sw) * rp_cdiv(gy, 64 / h.sw);
+    grid = dim3((unsigned)(rp_cdiv(ns, 8) * 512), 1, S);
+  }
+  if (S > 1) {
+    float* part = part_at;
+    if (!part) RP_TRY(rp_scratch(ctx, 7, (size_t)S * g.M * g.N * sizeof(float), (void**)&part));
+    h.part = part;
+    h.k_chunk = (int)(rp_cdiv(rp_cdiv(klen, S), GBK) * GBK);
+  }
+  if (ctx->gemm_mode == 2) {
+    // the operands' largest magnitudes over what this launch reads -> a slot of the context's ring (launches on different streams
+    // overlap: each gets its own two words)
+    if (!ctx->gemm_amax_ring) {
+      RP_HIP(hipMalloc((void**)&ctx->gemm_amax_ring, (size_t)RP_AMAX_SLOTS * 2 * sizeof(unsigned)));
+    }
+    unsigned* slot = ctx->gemm_amax_ring + 2 * (size_t)(ctx->gemm_amax_seq++ % RP_AMAX_SLOTS);
+    RP_HIP(hipMemsetAsync(slot, 0, 2 * sizeof(unsigned), st));
+    const int m_tiles = g.M / GT, n_tiles = g.N / GT;
+    rp_amax_op oa{g.A, g.lda, m_tiles, g.kb_m, 0, g.m_off};
+    rp_amax_op ob{g.B, g.ldb, n_tiles, g.kb_n, g.ke_n, g.n_off};
+    const int dup = (g.A == g.B && g.lda == g.ldb && m_tiles == n_tiles && g.kb_m == g.kb_n && !g.ke_n && (!g.kb_m || g.m_off == g.n_off)) ? 1 : 0;
+    if (dup) ob.tiles = 0;
+    hipLaunchKernelGGL(k_gemm_amax, dim3(oa.tiles + ob.tiles, (unsigned)rp_cdiv(klen, 256)), dim3(256), 0, st, oa, ob, g.k0, g.k1, dup, slot);
+    h.amax = slot;
+    hipLaunchKernelGGL(k_gemm_nt_h2, grid, dim3(256), 0, st, h);
+  } else if (ctx->gemm_mode == 1) {
+    hipLaunchKernelGGL(k_gemm_nt_b3, grid, dim3(256), 0, st, h);
+  } else {
+    hipLaunchKernelGGL(k_gemm_nt, grid, dim3(256), 0, st, h);
+  }
   RP_HIP(hipGetLastError());
+  if (S == 1) return RPHIP_OK;
   const long long quads = (long long)g.M * g.N / 4;
-  hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)std::min<long long>(4096, rp_cdiv(quads, 256))), dim3(256), 0, st, part, S, g.M,
+  hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)std::min<long long>(4096, rp_cdiv(quads, 256))), dim3(256), 0, st, h.part, S, g.M,
                      g.N, g.alpha, g.beta, g.C, g.ldc);
   RP_HIP(hipGetLastError());
   return RPHIP_OK;

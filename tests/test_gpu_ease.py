@@ -56,6 +56,14 @@ def test_gemm_nt_mfma(hip):
     Cd = torch.zeros((128, 128)).cuda()
     _lib.gemm_nt(ctx, I, Bd, Cd)
     ctx.sync()
+    # (the default two-plane fp16 product holds an operand to 2^-24 of its value - fp32's own rounding - not to the last bit)
+    np.testing.assert_allclose(Cd.cpu().numpy(), Bd.cpu().numpy().T, rtol=1.2e-7, atol=0)
+    ctx.set_option("gemm_mode", 1)  # three bf16 planes carry all 24 bits: exact
+    try:
+        _lib.gemm_nt(ctx, I, Bd, Cd)
+        ctx.sync()
+    finally:
+        ctx.set_option("gemm_mode", 2)
     np.testing.assert_array_equal(Cd.cpu().numpy(), Bd.cpu().numpy().T)
 
 

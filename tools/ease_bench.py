@@ -14,8 +14,10 @@ l2 = float(sys.argv[4]) if len(sys.argv) > 4 else 200.0
 dev = torch.device("cuda", 0)
 ip, ix = powerlaw_csr(U, I, dens, seed=20260003, device=dev)
 ctx = _lib.Context(0)
-if os.environ.get("RECPACK_GEMM_BF16X3"):
-    ctx.set_option("gemm_bf16x3", int(os.environ["RECPACK_GEMM_BF16X3"]))
+if os.environ.get("RECPACK_GEMM_MODE"):
+    ctx.set_option("gemm_mode", int(os.environ["RECPACK_GEMM_MODE"]))
+if os.environ.get("RECPACK_GEMM_SUPERTILE"):
+    ctx.set_option("gemm_supertile", int(os.environ["RECPACK_GEMM_SUPERTILE"]))
 dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
 for it in range(2):
     ctx.reset_timings()

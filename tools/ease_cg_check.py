@@ -11,8 +11,8 @@ import ease_cg  # noqa: E402
 from recpack_amd import _lib  # noqa: E402
 
 ctx = _lib.Context(0)
-if os.environ.get("RECPACK_GEMM_BF16X3"):
-    ctx.set_option("gemm_bf16x3", int(os.environ["RECPACK_GEMM_BF16X3"]))
+if os.environ.get("RECPACK_GEMM_MODE"):
+    ctx.set_option("gemm_mode", int(os.environ["RECPACK_GEMM_MODE"]))
 if os.environ.get("RECPACK_GEMM_FLUSH_K"):  # tuning: error and time against the flush period of the compensated accumulation
     ctx.set_option("gemm_flush_k", int(os.environ["RECPACK_GEMM_FLUSH_K"]))
 for cfg in sys.argv[1:] or ["C3"]:

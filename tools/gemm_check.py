@@ -1,4 +1,4 @@
-"""C = alpha A B^T + beta C of the library's GEMM (fp32 MFMA, or bf16 three-way split with gemm_bf16x3) against float64 numpy."""
+"""C = alpha A B^T + beta C of the library's GEMM (gemm_mode 0: fp32 MFMA, 1: three bf16 planes, 2: two fp16 planes) against float64 numpy."""
 import os
 import sys
 import time
@@ -11,8 +11,9 @@ from recpack_amd import _lib
 
 ctx = _lib.Context(0)
 dev = torch.device("cuda", 0)
-for mode in (0, 1):
-    ctx.set_option("gemm_bf16x3", mode)
+for mode, sup in ((0, 0), (1, 0), (2, 0), (2, 1)):
+    ctx.set_option("gemm_mode", mode)
+    ctx.set_option("gemm_supertile", sup)
     for (M, N, K) in ((256, 256, 512), (384, 256, 4096), (1024, 1024, 16384)):
         g = torch.Generator(device="cpu").manual_seed(5)
         A = torch.randn((M, K), generator=g, dtype=torch.float32) * torch.exp(2.0 * torch.randn((M, 1), generator=g))
@@ -23,7 +24,7 @@ for mode in (0, 1):
         _lib.gemm_nt(ctx, Ad, Bd, Cd, alpha=0.5, beta=-1.0)
         ctx.sync()
         err = ((Cd.cpu().double() - ref).abs() / (0.5 * (A.double().abs() @ B.double().abs().T) + C0.double().abs())).max().item()
-        print(f"mode {mode} M={M} N={N} K={K}: max error relative to sum |a||b| = {err:.2e}", flush=True)
+        print(f"mode {mode} sup {sup} M={M} N={N} K={K}: max error relative to sum |a||b| = {err:.2e}", flush=True)
     n = 8192
     A = torch.randn((n, n), dtype=torch.float32, device=dev)
     C = torch.empty((n, n), dtype=torch.float32, device=dev)
@@ -33,4 +34,4 @@ for mode in (0, 1):
         _lib.gemm_nt(ctx, A, A, C)
         ctx.sync()
         dt = time.perf_counter() - t0
-    print(f"mode {mode} {n}^3: {dt * 1e3:.1f} ms = {2 * n ** 3 / dt / 1e12:.1f} TFLOP/s (fp32-equivalent)", flush=True)
+    print(f"mode {mode} sup {sup} {n}^3: {dt * 1e3:.1f} ms = {2 * n ** 3 / dt / 1e12:.1f} TFLOP/s (fp32-equivalent)", flush=True)
