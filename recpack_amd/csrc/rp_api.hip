@@ -198,6 +198,12 @@ extern "C" int rphip_ctx_trim(rphip_ctx* ctx) {
   RP_TRY(rp_set_device(ctx));
   RP_HIP(hipStreamSynchronize(ctx->stream));
   rp_dev_trim(ctx);
+  for (int slot = 8; slot < 12; ++slot) {  // the plane workspaces of the large GEMMs
+    rp_buf& b = ctx->scratch[slot];
+    if (b.p) RP_HIP(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
   return RPHIP_OK;
 }
 
@@ -211,6 +217,11 @@ extern "C" int rphip_ctx_set_option(rphip_ctx* ctx, const char* name, int64_t va
   } else if (!strcmp(name, "gemm_mode")) {
     if (value < 0 || value > 2) RP_FAIL(RPHIP_EINVAL, "gemm_mode must be 0 (fp32), 1 (bf16 x 3) or 2 (fp16 x 2)");
     ctx->gemm_mode = (int)value;
+  } else if (!strcmp(name, "gemm_presplit")) {
+    ctx->gemm_presplit = value ? 1 : 0;
+  } else if (!strcmp(name, "gemm_workspace_bytes")) {
+    if (value < (64 << 20)) RP_FAIL(RPHIP_EINVAL, "gemm_workspace_bytes must be at least 64 MiB");
+    ctx->gemm_ws_bytes = (size_t)value;
   } else if (!strcmp(name, "gemm_supertile")) {
     ctx->gemm_supertile = value ? 1 : 0;
   } else if (!strcmp(name, "gemm_flush_k")) {

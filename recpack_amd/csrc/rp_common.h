@@ -59,7 +59,7 @@ struct rphip_ctx {
   char arch[64] = {0};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   rphip_timings tm;
-  rp_buf scratch[8];
+  rp_buf scratch[12];  // 8..11: plane workspaces of the large products (rp_ease.hip, k_gemm_hp): main stream A/B, side stream A/B
   unsigned long long* dev_counters = nullptr;  // 8 x u64 on the device: [0] products done by the wave fit kernel, [1] its rows
   // pending event pairs are resolved lazily (no sync inside *_dev calls)
   struct pending_t { hipEvent_t a, b; int slot; };
@@ -77,6 +77,8 @@ struct rphip_ctx {
   int pw_wt32 = 4096;        // tile width of the 32-bit sums: 2048 or 4096 (tuning)
   int gemm_mode = 2;         // operands of the solve's products: 0 fp32 MFMA, 1 three bf16 planes (6 products), 2 two fp16 planes (3 products)
   int gemm_supertile = 0;    // 1: GEMM workgroups walk the tiles in XCD-round-robin 8 x 8 supertiles (0: row-major 2-D grid)
+  int gemm_presplit = 1;     // mode 2: products with many tiles cut their operands into planes once (workspace) and run k_gemm_hp
+  size_t gemm_ws_bytes = (size_t)4 << 30;  // workspace per operand of those products (sets their K chunk)
   unsigned* gemm_amax_ring = nullptr;  // mode 2: [RP_AMAX_SLOTS][2] words, the operands' largest magnitudes per launch
   unsigned long long gemm_amax_seq = 0;
   int gemm_kc = 512;         // K steps between two flushes of the MFMA accumulators into the compensated master sums

@@ -638,6 +638,193 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_h2(rp_gemm_args g) {
     }
 }
 
+// ---- the large products: operands cut into planes ONCE, then a product kernel that only moves and multiplies -------------------
+// In k_gemm_nt_h2 every workgroup cuts the tiles it stages, so an operand element is converted N / 128 times and the conversion
+// (~100 VALU instructions per K16 step and wave beside 12 MFMAs) keeps the matrix pipe at 31 % busy.  For a product with many
+// tiles the operands are instead cut once per launch by k_split_planes into a workspace, K chunk by K chunk, laid out in the
+// order the product kernel consumes it: 1 KB pieces [plane][32-row block][K16 step][lane], lane l = row (l & 31), k = 8 (l >> 5)
+// .. +7 - the operand map of v_mfma_f32_32x32x16_f16.  k_gemm_hp then stages a tile with LDS-DMA loads (global_load_lds_dwordx4:
+// a wave moves one contiguous 1 KB piece straight into LDS, no registers, no ds_write, no arithmetic), reads fragments at
+// lane * 16 (conflict-free by construction) and runs 24 MFMAs per K32 step and wave; two buffers, one barrier per step.
+// A product whose K exceeds the workspace chunk is a sequence of launches, the later ones with beta = 1.
+struct rp_split_args {
+  const float* P;       // operand, row-major fp32
+  long long ld;
+  int rows;             // a multiple of 128
+  int kc0, kc1;         // K chunk (multiples of 32)
+  int kb_flag, ke_flag, off;  // the K range of a 128-row tile, as in rp_amax_op
+  int k0, k1;           // the whole product's K range
+  const unsigned* amax; // the operand's largest magnitude (one word)
+  unsigned char* W;     // planes: W + p * plane_stride
+  long long plane_stride;
+};
+
+__global__ void __launch_bounds__(256) k_split_planes(rp_split_args a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rb = blockIdx.x;                      // 32-row block
+  const int KS = (a.kc1 - a.kc0) >> 4;
+  const int r0t = (rb * 32) & ~(GT - 1);          // its tile's first row
+  int kb = a.k0, ke = a.k1;
+  if (a.kb_flag) kb = max(kb, a.off + r0t);
+  if (a.ke_flag) ke = min(ke, a.off + r0t + GT);
+  const float sc = rp_h2_scale(*a.amax);
+  const float* src = a.P + (long long)(rb * 32 + (lane & 31)) * a.ld + (lane >> 5) * 8;
+  unsigned char* dst = a.W + ((long long)rb * KS) * 1024 + lane * 16;
+#pragma unroll 2
+  for (int ks = blockIdx.y * 16 + wave; ks < min(KS, (int)blockIdx.y * 16 + 16); ks += 4) {
+    const int k = a.kc0 + ks * 16;
+    if (k + 16 <= kb || k >= ke) continue;  // never read by the product
+    const float4 u0 = *reinterpret_cast<const float4*>(src + k);
+    const float4 u1 = *reinterpret_cast<const float4*>(src + k + 4);
+    const float x[8] = {u0.x * sc, u0.y * sc, u0.z * sc, u0.w * sc, u1.x * sc, u1.y * sc, u1.z * sc, u1.w * sc};
+    f16x8 h1, h2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const _Float16 t = (_Float16)x[e];
+      h1[e] = t;
+      h2[e] = (_Float16)(x[e] - (float)t);
+    }
+    *reinterpret_cast<f16x8*>(dst + (long long)ks * 1024) = h1;
+    *reinterpret_cast<f16x8*>(dst + a.plane_stride + (long long)ks * 1024) = h2;
+  }
+}
+
+struct rp_hp_args {
+  rp_gemm_args g;       // k0 / k1 = this launch's K chunk; A / B unused
+  const unsigned char* WA;
+  const unsigned char* WB;
+  long long psa, psb;   // plane strides
+  int KS;               // K16 steps per 32-row block in the workspace
+  int kc0;              // first K of the workspace
+  int first;            // the product's first chunk: tiles with an empty K range still get beta * C
+};
+
+__global__ void __launch_bounds__(256, 2) k_gemm_hp(rp_hp_args q) {
+  // [buffer][operand][plane][32-row block][K16 step][1 KB]
+  __shared__ __attribute__((aligned(1024))) unsigned char sm[2][2][2][4][2][1024];
+  const rp_gemm_args& g = q.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  int tm, tn;
+  if (!rp_gemm_tile(g, tm, tn)) return;
+  const int m0 = tm * GT, n0 = tn * GT;
+  if (g.tri == 1 && g.n_off + n0 > g.m_off + m0) return;
+  if (g.tri == 2 && g.n_off + n0 >= g.m_off + m0) return;
+  int kb = g.k0, ke = g.k1;
+  if (g.kb_m) kb = max(kb, g.m_off + m0);
+  if (g.kb_n) kb = max(kb, g.n_off + n0);
+  if (g.ke_n) ke = min(ke, g.n_off + n0 + GT);
+  kb &= ~31;
+  if (kb >= ke && !q.first) return;  // nothing to add to C
+  const float unscale = 1.0f / (rp_h2_scale(g.amax[0]) * rp_h2_scale(g.amax[1]));  // a power of two
+
+  f32x16 acc[2][2], hi[2][2];
+  uint32_t lo[2][2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = hi[i][j][r] = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) lo[i][j][r] = 0u;
+    }
+  auto flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const uint32_t pk = lo[i][j][r >> 1];
+          float l0 = __uint_as_float(pk << 16), l1 = __uint_as_float(pk & 0xffff0000u);
+          const float a0 = acc[i][j][r] * unscale, a1 = acc[i][j][r + 1] * unscale;
+          const float h0 = hi[i][j][r], h1 = hi[i][j][r + 1];
+          const float s0 = h0 + a0, s1 = h1 + a1;
+          const float b0 = s0 - h0, b1 = s1 - h1;
+          l0 += (h0 - (s0 - b0)) + (a0 - b0);
+          l1 += (h1 - (s1 - b1)) + (a1 - b1);
+          hi[i][j][r] = s0;
+          hi[i][j][r + 1] = s1;
+          acc[i][j][r] = 0.0f;
+          acc[i][j][r + 1] = 0.0f;
+          lo[i][j][r >> 1] = rp_pack_bf16_rn(l0, l1);
+        }
+  };
+
+  if (kb < ke) {
+    // wave w stages the 32-row block w of both operands: 2 planes x 2 K16 steps x 2 operands = 8 pieces per K32 step
+    const unsigned char* asrc = q.WA + ((long long)(m0 / 32 + wave) * q.KS) * 1024 + lane * 16;
+    const unsigned char* bsrc = q.WB + ((long long)(n0 / 32 + wave) * q.KS) * 1024 + lane * 16;
+    auto issue = [&](int buf, int k) __attribute__((always_inline)) {
+      const long long ko = (long long)((k - q.kc0) >> 4) * 1024;
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc + p * q.psa + ko + s2 * 1024),
+                                           (__attribute__((address_space(3))) void*)&sm[buf][0][p][wave][s2][0], 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + p * q.psb + ko + s2 * 1024),
+                                           (__attribute__((address_space(3))) void*)&sm[buf][1][p][wave][s2][0], 16, 0, 0);
+        }
+    };
+    issue(0, kb);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int since = 0, cur = 0;
+    for (int k = kb; k < ke; k += 32) {
+      const bool more = (k + 32) < ke;
+      if (more) issue(cur ^ 1, k + 32);  // lands while this step multiplies
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        f16x8 a[2][2], b[2][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            a[p][i] = *reinterpret_cast<const f16x8*>(&sm[cur][0][p][wr * 2 + i][s2][lane * 16]);
+            b[p][i] = *reinterpret_cast<const f16x8*>(&sm[cur][1][p][wc * 2 + i][s2][lane * 16]);
+          }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            f32x16 c = acc[i][j];  // small products first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b[0][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[1][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[0][j], c, 0, 0, 0);
+            acc[i][j] = c;
+          }
+      }
+      since += 32;
+      if (since >= g.kc && more) {
+        flush();
+        since = 0;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile has landed
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  flush();  // the last piece
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wc * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const uint32_t pk = lo[i][j][r >> 1];
+        const float h = hi[i][j][r];
+        const float l = (r & 1) ? __uint_as_float(pk & 0xffff0000u) : __uint_as_float(pk << 16);
+        float* cp = g.C + (long long)row * g.ldc + col;
+        float v = (g.beta != 0.0f) ? fmaf(g.alpha, h, g.beta * (*cp)) : g.alpha * h;
+        *cp = fmaf(g.alpha, l, v);
+      }
+    }
+}
+
 // C = beta * C + alpha * sum_s part[s]  (fixed order of the partial sums: deterministic)
 __global__ void k_splitk_reduce(const float* __restrict__ part, int S, int M, int N, float alpha, float beta, float* __restrict__ C,
                                 long long ldc) {
@@ -860,9 +1047,59 @@ static int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st = nu
     rp_amax_op oa{g.A, g.lda, m_tiles, g.kb_m, 0, g.m_off};
     rp_amax_op ob{g.B, g.ldb, n_tiles, g.kb_n, g.ke_n, g.n_off};
     const int dup = (g.A == g.B && g.lda == g.ldb && m_tiles == n_tiles && g.kb_m == g.kb_n && !g.ke_n && (!g.kb_m || g.m_off == g.n_off)) ? 1 : 0;
-    if (dup) ob.tiles = 0;
-    hipLaunchKernelGGL(k_gemm_amax, dim3(oa.tiles + ob.tiles, (unsigned)rp_cdiv(klen, 256)), dim3(256), 0, st, oa, ob, g.k0, g.k1, dup, slot);
+    // many tiles and a K worth a pass of its own: planes cut once into the workspace, then the LDS-DMA product (see k_gemm_hp)
+    const bool presplit = ctx->gemm_presplit && S == 1 && g.tri != 3 && tiles >= 512 && klen >= 1024 && !(g.k0 % 32) && !(g.k1 % 32);
+    // B's rows may be a sub-range of A's (the next panel's columns of the trailing update): then one set of planes - and one scale:
+    // max |B| <= max |A| - serves both
+    const bool same_cols = g.lda == g.ldb && !g.kb_m && !g.kb_n && !g.ke_n && g.B >= g.A && (g.B - g.A) % g.lda == 0;
+    const long long row_shift = same_cols ? (g.B - g.A) / g.lda : -1;
+    const bool alias = presplit && (dup || (same_cols && !(row_shift % 32) && row_shift + g.N <= g.M));
+    const int one_max = (dup || alias) ? 1 : 0;
+    if (one_max) ob.tiles = 0;
+    hipLaunchKernelGGL(k_gemm_amax, dim3(oa.tiles + ob.tiles, (unsigned)rp_cdiv(klen, 256)), dim3(256), 0, st, oa, ob, g.k0, g.k1, one_max, slot);
     h.amax = slot;
+    if (presplit) {
+      const int rows_max = std::max(g.M, alias ? 0 : g.N);
+      long long Kc = (long long)(ctx->gemm_ws_bytes / ((size_t)rows_max * 4)) / 512 * 512;
+      Kc = std::max<long long>(512, std::min<long long>(Kc, (klen + 31) / 32 * 32));
+      const int slot_a = (st == ctx->stream) ? 8 : 10;  // a product on a side stream runs beside one on the main stream
+      unsigned char *WA = nullptr, *WB = nullptr;
+      auto ws_size = [&](size_t need) {  // grow in powers of two: the products of a solve come in many sizes
+        size_t c = (size_t)64 << 20;
+        while (c < need) c <<= 1;
+        return std::max(need, std::min(c, ctx->gemm_ws_bytes));
+      };
+      RP_TRY(rp_scratch(ctx, slot_a, ws_size((size_t)g.M * Kc * 4), (void**)&WA));
+      if (!alias) RP_TRY(rp_scratch(ctx, slot_a + 1, ws_size((size_t)g.N * Kc * 4), (void**)&WB));
+      for (long long kc0 = g.k0; kc0 < g.k1; kc0 += Kc) {
+        const int kc1 = (int)std::min<long long>(g.k1, kc0 + Kc);
+        const int KS = (kc1 - (int)kc0) / 16;
+        rp_split_args sa{g.A, g.lda, g.M, (int)kc0, kc1, g.kb_m, 0, g.m_off, g.k0, g.k1, slot, WA, (long long)g.M / 32 * KS * 1024};
+        hipLaunchKernelGGL(k_split_planes, dim3(g.M / 32, (unsigned)rp_cdiv(KS, 16)), dim3(256), 0, st, sa);
+        rp_hp_args q{};
+        q.g = h;
+        q.g.k0 = (int)kc0;
+        q.g.k1 = kc1;
+        q.g.beta = (kc0 == g.k0) ? g.beta : 1.0f;
+        q.first = (kc0 == g.k0) ? 1 : 0;
+        q.WA = WA;
+        q.psa = sa.plane_stride;
+        q.KS = KS;
+        q.kc0 = (int)kc0;
+        if (alias) {
+          q.WB = WA + (dup ? 0 : row_shift / 32 * KS * 1024);
+          q.psb = q.psa;
+        } else {
+          rp_split_args sb{g.B, g.ldb, g.N, (int)kc0, kc1, g.kb_n, g.ke_n, g.n_off, g.k0, g.k1, slot + 1, WB, (long long)g.N / 32 * KS * 1024};
+          hipLaunchKernelGGL(k_split_planes, dim3(g.N / 32, (unsigned)rp_cdiv(KS, 16)), dim3(256), 0, st, sb);
+          q.WB = WB;
+          q.psb = sb.plane_stride;
+        }
+        hipLaunchKernelGGL(k_gemm_hp, grid, dim3(256), 0, st, q);
+      }
+      RP_HIP(hipGetLastError());
+      return RPHIP_OK;
+    }
     hipLaunchKernelGGL(k_gemm_nt_h2, grid, dim3(256), 0, st, h);
   } else if (ctx->gemm_mode == 1) {
     hipLaunchKernelGGL(k_gemm_nt_b3, grid, dim3(256), 0, st, h);
