@@ -217,6 +217,8 @@ extern "C" int rphip_ctx_set_option(rphip_ctx* ctx, const char* name, int64_t va
   } else if (!strcmp(name, "gemm_mode")) {
     if (value < 0 || value > 2) RP_FAIL(RPHIP_EINVAL, "gemm_mode must be 0 (fp32), 1 (bf16 x 3) or 2 (fp16 x 2)");
     ctx->gemm_mode = (int)value;
+  } else if (!strcmp(name, "gemm_shape16")) {
+    ctx->gemm_shape16 = value ? 1 : 0;
   } else if (!strcmp(name, "gemm_presplit")) {
     ctx->gemm_presplit = value ? 1 : 0;
   } else if (!strcmp(name, "gemm_workspace_bytes")) {

@@ -16,6 +16,10 @@ ip, ix = powerlaw_csr(U, I, dens, seed=20260003, device=dev)
 ctx = _lib.Context(0)
 if os.environ.get("RECPACK_GEMM_MODE"):
     ctx.set_option("gemm_mode", int(os.environ["RECPACK_GEMM_MODE"]))
+if os.environ.get("RECPACK_GEMM_FLUSH_K"):
+    ctx.set_option("gemm_flush_k", int(os.environ["RECPACK_GEMM_FLUSH_K"]))
+if os.environ.get("RECPACK_GEMM_SHAPE16"):
+    ctx.set_option("gemm_shape16", int(os.environ["RECPACK_GEMM_SHAPE16"]))
 if os.environ.get("RECPACK_GEMM_SUPERTILE"):
     ctx.set_option("gemm_supertile", int(os.environ["RECPACK_GEMM_SUPERTILE"]))
 dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
