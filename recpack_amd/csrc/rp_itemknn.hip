@@ -1019,8 +1019,8 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
       unsigned long long h[16];
       hipMemcpyAsync(h, P.stamps, sizeof(h), hipMemcpyDeviceToHost, st);
       hipStreamSynchronize(st);
-      fprintf(stderr, "[stamps light] cycles/1e6: ticket %.1f accumulate %.1f select %.1f emit+clear %.1f | sel: compact %.1f levels %.1f sort %.1f pred %.1f\n",
-              h[0] / 1e6, h[1] / 1e6, h[3] / 1e6, h[4] / 1e6, h[8] / 1e6, h[9] / 1e6, h[10] / 1e6, h[11] / 1e6);
+      fprintf(stderr, "[stamps light] cycles/1e6: ticket %.1f accumulate %.1f select %.1f emit+clear %.1f | sel: compact %.1f levels %.1f (of which histogram loops %.1f) sort %.1f classify loop %.1f rest %.1f | tasks %llu candidates %llu levels %llu\n",
+              h[0] / 1e6, h[1] / 1e6, h[3] / 1e6, h[4] / 1e6, h[8] / 1e6, (h[9] + h[14]) / 1e6, h[14] / 1e6, h[10] / 1e6, h[13] / 1e6, h[11] / 1e6, h[5], h[6], h[7]);
       hipMemsetAsync(P.stamps, 0, 64 * 8, st);
     }
 #endif

@@ -196,6 +196,12 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
   const int kprime = min(K, n_valid);
   __syncthreads();
   RPS_STAMP(8);
+#ifdef RP_STAMPS
+  if (threadIdx.x == 0 && s.stamps) {
+    atomicAdd(&s.stamps[5], 1ull);
+    atomicAdd(&s.stamps[6], (unsigned long long)n_valid);
+  }
+#endif
 
   // outcome of the radix levels: the boundary bin (prefix fin_pkey/fin_pcol down to fin_shift) holds fin_group
   // candidates of which fin_need are selected
@@ -212,6 +218,9 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
       bool is_col;
       rp_level<BITS>(level, &shift, &width, &is_col);
       const int nb = 1 << width;
+#ifdef RP_STAMPS
+      if (threadIdx.x == 0 && s.stamps) atomicAdd(&s.stamps[7], 1ull);
+#endif
       for (int i = tid; i < BINS; i += NTHR) s.hist[i] = 0;
       if (tid == 0) {
         s.misc[RPS_BIN] = -1;
@@ -249,6 +258,7 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
           if (in_group) atomicAdd(&s.hist[d], 1u);
         }
       }
+      RPS_STAMP(14);
       __syncthreads();
       // find the bin where the count from the top reaches `need`: thread t owns BPT bins, descending
       {
@@ -358,6 +368,7 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
       wc += __popcll(__ballot(sel));
     }
   }
+  RPS_STAMP(13);
   if (lane == 0) s.misc[RPS_RED + wave] = wc;
   __syncthreads();
   RPS_STAMP(11);

@@ -7,6 +7,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r02 -- p
 cp gpurun_out/prof_r02/*/*kernel_stats.csv gpurun_out/kernel_stats_r02.csv; rm -rf gpurun_out/prof_r02
 bash tools/pmc_traffic.sh > gpurun_out/pmc_traffic.txt 2>&1
 bash tools/pmc_sq.sh k_ C4 > gpurun_out/pmc_sq_all.txt 2>&1
-RECPACK_GEMM_BF16X3=0 bash tools/pmc_mfma.sh > gpurun_out/pmc_mfma_f32.txt 2>&1; cp gpurun_out/pmc_mfma.json gpurun_out/pmc_mfma_f32.json
 bash tools/pmc_mfma.sh > gpurun_out/pmc_mfma.txt 2>&1
 tail -5 gpurun_out/pmc_mfma.txt
+bash tools/pmc_ta.sh C4 > gpurun_out/pmc_ta.txt 2>&1
