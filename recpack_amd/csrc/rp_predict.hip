@@ -408,6 +408,12 @@ struct rp_pw_params {
 
 typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
+// Diagnostic builds only (make ablate; tools/k8_ablate.py): RP_PW_ABL removes parts of the wave kernel to attribute its time -
+// 1: no sum atomics, 2: no walk, 4: no dirty-map atomics, 8: no entry loads.  Results are wrong by construction.
+#ifndef RP_PW_ABL
+#define RP_PW_ABL 0
+#endif
+
 template <typename AccT>
 struct rp_pw_state {
   RP_LDS AccT* acc;
@@ -428,7 +434,7 @@ struct rp_pw_state {
 #define PW_COUNT(ph, n) do { S.t_ph[ph] += (n); } while (0)
 #endif
 
-template <typename AccT, bool WGT>
+template <typename AccT, bool WGT, bool MAP = true>
 __device__ __forceinline__ void rp_pw_add_chunk(rp_pw_state<AccT>& S, int n, const v4i_a4& a, const v4i_a4& b, int t0, double xw) {
   const int ec[4] = {a.x, a.z, b.x, b.z};
   const int ev[4] = {a.y, a.w, b.y, b.w};
@@ -449,11 +455,20 @@ __device__ __forceinline__ void rp_pw_add_chunk(rp_pw_state<AccT>& S, int n, con
       v = rp_f64_to_fix((double)__int_as_float(bits) * xw, S.fix);
     else
       v = rp_f32_to_fix(bits, S.fix);
-    const uint32_t bit = on ? (1u << ((j >> 6) & 31)) : 0u;
-    atomicAdd((AccT*)&S.acc[j], v);
-    atomicOr((uint32_t*)&S.dirty[(j & 63) + 64 * (j >> 11)], bit);  // word (j mod 64) of the tile's (j / 2048)-th map
+    if (!(RP_PW_ABL & 1)) atomicAdd((AccT*)&S.acc[j], v);
+    if (RP_PW_ABL & 1) asm volatile("" ::"v"(v));
+    if constexpr (MAP) {
+      const uint32_t bit = on ? (1u << ((j >> 6) & 31)) : 0u;
+      if (!(RP_PW_ABL & 4)) atomicOr((uint32_t*)&S.dirty[(j & 63) + 64 * (j >> 11)], bit);  // word (j mod 64) of the tile's (j / 2048)-th map
+      if (RP_PW_ABL & 4) asm volatile("" ::"v"(bit));
+    }
   }
 }
+
+// take a sum out of the accumulator: returns it and leaves 0 (one returning LDS operation; of several lanes that hold the same
+// column exactly one gets the sum)
+__device__ __forceinline__ uint32_t rp_lds_exch(RP_LDS uint32_t* p) { return atomicExch((unsigned int*)p, 0u); }
+__device__ __forceinline__ uint64_t rp_lds_exch(RP_LDS uint64_t* p) { return (uint64_t)atomicExch((unsigned long long*)p, 0ull); }
 
 // chunk c of a batch whose lanes hold (start, length, first chunk) of their slices: owner lane by binary search
 // over the exclusive chunk offsets, then the chunk's two 16-byte loads
@@ -514,18 +529,19 @@ __device__ __attribute__((noinline)) uint32_t rp_pw_keep_lookup(const uint8_t* k
 }
 
 // One user.  The work is a sequence of UNITS (column tile t, batch g of 64 history items), tile-major; after the last batch
-// of a tile its touched columns are offered to the pool.  The sequence is software-pipelined three units deep, the same
+// of a tile its touched columns are offered to the pool.  The sequence is software-pipelined four units deep, the same
 // way for every history length:
-//   iteration k   requests  the item ids of unit k+3                      (one coalesced load)
-//                           the tile offsets of unit k+2 (toff[item][t], [t+1]; needs the ids of k+2)
-//                           the entries of unit k+1: scan of the slice lengths, chunk -> lane assignment, ST steps of two
-//                           16-byte loads per lane (needs the offsets of k+1)
-//                 then adds the entries of unit k (requested one iteration earlier) and, at a tile's end, walks the tile.
-// Everything an iteration requests is consumed at the top of the next one at the earliest, i.e. after the adds and the walk
-// - the long part of an iteration - so the loads have that long to arrive.  All of them are UNCONDITIONAL (clamped
-// addresses; dead units and idle lanes read something harmless): with loads under branches the compiler loses count of
-// the loads in flight and falls back to s_waitcnt vmcnt(0) in front of the adds, which waits for the entries just requested.
-// Two entry sets alternate (the loop body handles two units), so no register is copied while its load is in flight.
+//   iteration k   requests  the tile offsets of unit k+3 (toff[item][t], [t+1]; needs the ids of k+3)
+//                           the item ids of unit k+4                      (one coalesced load)
+//                           the entries of unit k+2: scan of the slice lengths, chunk -> lane assignment, ST steps of two
+//                           16-byte loads per lane (needs the offsets of k+2)
+//                 then adds the entries of unit k (requested two iterations earlier) and, at a tile's end, walks the tile.
+// The ids and offsets an iteration requests are consumed at the top of the next one, the entries two iterations later: loads
+// return in order, and the small loads are issued in front of the entry loads, so that the next top waits for them with
+// s_waitcnt vmcnt(2 ST) and leaves the entries just requested in flight.  All loads are UNCONDITIONAL (clamped addresses;
+// dead units and idle lanes read something harmless): with loads under branches the compiler loses count of the loads in
+// flight and falls back to s_waitcnt vmcnt(0).  Three entry sets rotate (the loop body handles three units), so no register
+// is copied while its load is in flight.
 // ST steps of 64 chunks of 4 entries are prefetched per unit (3 for 4096-column tiles: a full batch has 64 x 8.2 entries in
 // about 160 chunks); chunks beyond them (rare) are fetched on the spot by rp_pw_extra_steps.
 // History removal: a lane whose item lies in the current tile sets its bit in `excl` (same layout as the dirty map); the walk
@@ -538,7 +554,11 @@ struct rp_pw_uset {
   double w[ST];  // WGT: the value of the history item the lane's chunk belongs to
 };
 
-template <typename AccT, int WT, bool WGT, int ST>
+// ONE: the history fits one batch (at most 64 items), i.e. every unit is a whole tile and the unit's entries - still in
+// registers after the adds - ARE the list of touched columns: the walk exchanges each entry's sum against 0 (the first lane to
+// arrive at a column takes the sum, later ones read 0), so there is no dirty map to maintain in the adds, no bit scanning and no
+// imbalance between lanes in the walk (a lane whose map word holds nine bits made the whole wave run three rounds).
+template <typename AccT, int WT, bool WGT, int ST, bool ONE>
 __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_state<AccT>& S, int hs, int he) {
   constexpr int DW = WT / PW_WT;
   constexpr AccT FLIP = rp_pw_flip<AccT>();
@@ -546,10 +566,10 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
   const int G = (he - hs + 63) >> 6;
   const int NU = NT * G;
   RP_LDS uint32_t* excl = S.dirty + 64 * DW;
-  rp_pw_uset<ST> set0, set1;
+  rp_pw_uset<ST> set0, set1, set2;
 
-  // ---- stage state.  (t, g) of units k .. k+3; ids / weights of k .. k+2; raw (just loaded) values of the youngest stages
-  int t0c = 0, g0c = 0, t1c = 0, g1c = 0, t2c = 0, g2c = 0, t3c = 0, g3c = 0;
+  // ---- stage state.  (t, g) of units k .. k+4; ids / weights of k .. k+3; raw (just loaded) values of the youngest stages
+  int t0c = 0, g0c = 0, t1c = 0, g1c = 0, t2c = 0, g2c = 0, t3c = 0, g3c = 0, t4c = 0, g4c = 0;
   auto next_unit = [&](int& t, int& g) __attribute__((always_inline)) {
     ++g;
     if (g == G) {
@@ -557,9 +577,9 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
       ++t;
     }
   };
-  int it0 = -1, it1 = -1, it2 = -1, raw_it = 0, raw_oa = 0, raw_ob = 0;
-  bool valid3 = false;
-  double wt0 = 1.0, wt1 = 1.0, wt2 = 1.0, raw_wt = 1.0;
+  int it0 = -1, it1 = -1, it2 = -1, it3 = -1, raw_it = 0, raw_oa = 0, raw_ob = 0;
+  bool valid3 = false;  // validity of the ids in raw_it
+  double wt0 = 1.0, wt1 = 1.0, wt2 = 1.0, wt3 = 1.0, raw_wt = 1.0;
   auto load_ids = [&](int t, int g) __attribute__((always_inline)) {
     const int h = hs + 64 * g + lane;
     raw_it = P.x_idx[min(h, he - 1)];  // (he > hs: the clamped read stays inside the user's row)
@@ -612,8 +632,13 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
       const int k0 = (c - co[st]) * PW_CH;
       const int n = (c < D.nchunks) ? min(PW_CH, ulen[st] - k0) : 0;
       D.n[st] = n;
-      if (64 * st < D.nchunks) {  // (uniform; whatever is requested here is used at the top of the next iteration at the earliest)
-        const int* src = S.pairs_i + 2 * (long long)(n > 0 ? us[st] + k0 : 0);  // (padded array: reading past a slice's end is harmless)
+      // ALWAYS issued (a step past the unit's chunks reads the head of the array in every lane - one cache line): the next
+      // iteration waits for the small loads issued before these with a COUNTED s_waitcnt, which the compiler can only emit
+      // when the number of loads behind them does not depend on a branch
+      const int* src = S.pairs_i + 2 * (long long)(n > 0 ? us[st] + k0 : 0);  // (padded array: reading past a slice's end is harmless)
+      if (RP_PW_ABL & 8) {
+        D.a[st] = D.b[st] = (v4i_a4){(int)(long long)src & 4095, 0, (int)(long long)src & 4095, 0};
+      } else {
         D.a[st] = *reinterpret_cast<const v4i_a4*>(src);
         D.b[st] = *reinterpret_cast<const v4i_a4*>(src + 4);
       }
@@ -621,48 +646,60 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
   };
 #pragma unroll
   for (int st = 0; st < ST; ++st) {
-    set0.w[st] = set1.w[st] = 1.0;
-    set0.n[st] = set1.n[st] = 0;
-    set0.a[st] = set0.b[st] = set1.a[st] = set1.b[st] = (v4i_a4){0, 0, 0, 0};
+    set0.w[st] = set1.w[st] = set2.w[st] = 1.0;
+    set0.n[st] = set1.n[st] = set2.n[st] = 0;
+    set0.a[st] = set0.b[st] = set1.a[st] = set1.b[st] = set2.a[st] = set2.b[st] = (v4i_a4){0, 0, 0, 0};
   }
   set0.s = set0.len = set0.choff = set0.nchunks = 0;
   set1.s = set1.len = set1.choff = set1.nchunks = 0;
+  set2.s = set2.len = set2.choff = set2.nchunks = 0;
 
-  // ---- prologue (dependent loads, once per user): ids of units 0..2, offsets of units 0..1, entries of unit 0
+  // ---- prologue (dependent loads, once per user): ids of units 0..3, offsets of units 0..2, entries of units 0 and 1
   {
     load_ids(0, 0);
     const int i0 = valid3 ? raw_it : -1;
     const double w0 = (WGT && valid3) ? raw_wt : 1.0;
-    t1c = 0, g1c = 0;
-    next_unit(t1c, g1c);  // unit 1
-    load_ids(t1c, g1c);
+    int ta = 0, ga = 0;
+    next_unit(ta, ga);  // unit 1
+    load_ids(ta, ga);
     const int i1 = valid3 ? raw_it : -1;
     const double w1 = (WGT && valid3) ? raw_wt : 1.0;
-    t2c = t1c, g2c = g1c;
-    next_unit(t2c, g2c);  // unit 2
+    int tb = ta, gb = ga;
+    next_unit(tb, gb);  // unit 2
+    load_ids(tb, gb);
+    const int i2 = valid3 ? raw_it : -1;
+    const double w2 = (WGT && valid3) ? raw_wt : 1.0;
+    int tc = tb, gc = gb;
+    next_unit(tc, gc);  // unit 3
     load_offs(i0, 0);
     const int oa0 = (i0 >= 0) ? raw_oa : 0, ob0 = (i0 >= 0) ? raw_ob : 0;
+    load_offs(i1, ta);
+    const int oa1 = (i1 >= 0) ? raw_oa : 0, ob1 = (i1 >= 0) ? raw_ob : 0;
     fetch(set0, i0, oa0, ob0, w0);  // entries of unit 0
-    load_offs(i1, t1c);             // offsets of unit 1: consumed at the top of iteration 0
-    load_ids(t2c, g2c);             // ids of unit 2: likewise
-    // the loop's top rotates: (it0, it1, it2) <- (it1, it2, raw); so unit 0 sits in it1, unit 1 in it2
+    fetch(set1, i1, oa1, ob1, w1);  // entries of unit 1
+    load_offs(i2, tb);              // offsets of unit 2: consumed at the top of iteration 0
+    load_ids(tc, gc);               // ids of unit 3: likewise
+    // the loop's top rotates (it0, it1, it2, it3) <- (it1, it2, it3, raw): unit 0 sits in it1, unit 1 in it2, unit 2 in it3
     it1 = i0;
     wt1 = w0;
     it2 = i1;
     wt2 = w1;
-    // counters are rotated the same way: stage 1 holds unit 0, stage 2 unit 1, stage 3 unit 2
-    t3c = t2c, g3c = g2c;
-    t2c = t1c, g2c = g1c;
+    it3 = i2;
+    wt3 = w2;
     t1c = 0, g1c = 0;
+    t2c = ta, g2c = ga;
+    t3c = tb, g3c = gb;
+    t4c = tc, g4c = gc;
   }
   bool touched = false;
 
-  // one iteration: C = entries of unit k (requested last iteration), N = set to fill for unit k+1
+  // one iteration: C = entries of unit k (requested TWO iterations ago), N = set to fill for unit k+2
   auto unit = [&](rp_pw_uset<ST>& C, rp_pw_uset<ST>& N) __attribute__((always_inline)) {
-    // ---- top: rotate the stages; what the previous iteration requested is used from here on.  The empty asm makes the
-    // youngest of those loads (ids, offsets) "used" HERE: the compiler's wait for them then sits in front of this
-    // iteration's requests - placed at their first arithmetic use it would come after the entry loads below and wait for
-    // those too (loads return in order)
+    // ---- top: rotate the stages; the ids and offsets the previous iteration requested are used from here on.  The empty asm
+    // makes those loads "used" HERE, and they were issued BEFORE that iteration's entry loads: the compiler's wait for them
+    // (loads return in order) leaves the entries of unit k+1 in flight, and the entries of unit k - the oldest loads, needed
+    // by the adds below - have had two iterations to arrive (one was not enough: the model streams from L2 / MALL at 1-1.5 us
+    // and an iteration is shorter; the wait at this spot was 46 % of the kernel in the stamps build)
     asm volatile("" : "+v"(raw_it), "+v"(raw_oa), "+v"(raw_ob));
     if (WGT) asm volatile("" : "+v"(raw_wt));
     it0 = it1;
@@ -671,34 +708,169 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
     it1 = it2;
     wt1 = wt2;
     t1c = t2c, g1c = g2c;
-    const int oa1 = (it1 >= 0) ? raw_oa : 0, ob1 = (it1 >= 0) ? raw_ob : 0;
-    it2 = valid3 ? raw_it : -1;
-    if (WGT) wt2 = valid3 ? raw_wt : 1.0;
+    it2 = it3;
+    wt2 = wt3;
     t2c = t3c, g2c = g3c;
-    next_unit(t3c, g3c);
-    // ---- requests for the units ahead
-    fetch(N, it1, oa1, ob1, wt1);  // entries of unit k+1
-    load_offs(it2, t2c);           // offsets of unit k+2
-    load_ids(t3c, g3c);            // ids of unit k+3
+    const int oa2 = (it2 >= 0) ? raw_oa : 0, ob2 = (it2 >= 0) ? raw_ob : 0;
+    it3 = valid3 ? raw_it : -1;
+    if (WGT) wt3 = valid3 ? raw_wt : 1.0;
+    t3c = t4c, g3c = g4c;
+    next_unit(t4c, g4c);
+    // ---- requests for the units ahead: the small loads first, so that the next iteration can wait for them alone
+    load_offs(it3, t3c);           // offsets of unit k+3
+    load_ids(t4c, g4c);            // ids of unit k+4
+    fetch(N, it2, oa2, ob2, wt2);  // entries of unit k+2
     PW_STAMP(4);
     // ---- unit k: adds
     const int t0 = t0c * WT;
     touched |= C.nchunks > 0;
 #pragma unroll
     for (int st = 0; st < ST; ++st)
-      if (64 * st < C.nchunks) rp_pw_add_chunk<AccT, WGT>(S, C.n[st], C.a[st], C.b[st], t0, C.w[st]);
-    if (C.nchunks > 64 * ST)
+      if (64 * st < C.nchunks) rp_pw_add_chunk<AccT, WGT, !ONE>(S, C.n[st], C.a[st], C.b[st], t0, C.w[st]);
+    if (C.nchunks > 64 * ST)  // (rare; sets map bits, which the ONE form never reads: it scans such a tile densely)
       rp_pw_extra_steps<AccT, WGT>(S.acc, S.dirty, S.pool.hist, S.pairs_i, S.fix, S.fmul, lane, C.s, C.len, C.choff, C.nchunks, t0, wt0,
                                    64 * ST);
-    if (P.exclude_history) {
+    if (!ONE && P.exclude_history) {
       const int j = it0 - t0;
       if ((unsigned)j < (unsigned)WT) atomicOr((uint32_t*)&excl[(j & 63) + 64 * (j >> 11)], 1u << ((j >> 6) & 31));
     }
     PW_STAMP(1);
     if (g0c != G - 1) return;  // more batches of this tile to come
+    if (RP_PW_ABL & 2) return;
     // ---- end of tile t0c: offer the touched columns to the pool.  Lane l walks the set bits of dirty word l (word l
     // covers columns l, l+64, ..: the lanes' reads of one round fall into different LDS banks), four set bits per lane and
     // round so that the sums of a round are read with one wait
+    // one round of the walk: four slots per lane (has[q]: the slot holds a column, j[q] its index in the tile, v[q] its sum,
+    // already taken out of the accumulator) are offered to the pool
+    auto offer4 = [&](bool(&has)[4], int(&j)[4], AccT(&v)[4]) __attribute__((always_inline)) {
+      bool kq[4];
+      uint32_t live = 0;  // bit q: some lane keeps its slot q
+      // most sums lose against the pool's threshold once it is warm: the slots of the round are voted on first and only
+      // slots with a surviving lane are pushed (rolled loop: one inlined copy of the pool cut; values rotate through 0)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[q] ^= FLIP;  // signed sum -> unsigned order; a zero sum is no candidate
+        kq[q] = has[q] && v[q] != FLIP && rp_wpool_admits<AccT, 0>(S.pool, v[q], (uint32_t)(t0 + j[q]));
+      }
+      if (P.keep) {  // item filter: only sums that would enter the pool pay the lookup
+        const uint32_t want = (kq[0] ? 1u : 0u) | (kq[1] ? 2u : 0u) | (kq[2] ? 4u : 0u) | (kq[3] ? 8u : 0u);
+        if (__any(want != 0u)) {
+          const uint32_t ok = rp_pw_keep_lookup(P.keep, t0 + j[0], t0 + j[1], t0 + j[2], t0 + j[3], want);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) kq[q] = (ok >> q) & 1u;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) live |= __any(kq[q]) ? (1u << q) : 0u;
+      if (!live) return;
+      PW_STAMP(2);
+      // the round's survivors in one go when they fit the pool as it is (the common case: a few of them); slot by slot
+      // with cuts in between otherwise
+      const uint64_t m0 = __ballot(kq[0]), m1 = __ballot(kq[1]), m2 = __ballot(kq[2]), m3 = __ballot(kq[3]);
+      const int c0n = __popcll(m0), c1n = __popcll(m1), c2n = __popcll(m2), c3n = __popcll(m3);
+      if (S.pool.n + c0n + c1n + c2n + c3n <= cap) {
+        const uint64_t below = (1ull << lane) - 1ull;
+        int base = S.pool.n;
+        if (kq[0]) {
+          const int pos = base + __popcll(m0 & below);
+          S.pool.key[pos] = v[0];
+          S.pool.pay[pos] = (uint32_t)(t0 + j[0]);
+        }
+        base += c0n;
+        if (kq[1]) {
+          const int pos = base + __popcll(m1 & below);
+          S.pool.key[pos] = v[1];
+          S.pool.pay[pos] = (uint32_t)(t0 + j[1]);
+        }
+        base += c1n;
+        if (kq[2]) {
+          const int pos = base + __popcll(m2 & below);
+          S.pool.key[pos] = v[2];
+          S.pool.pay[pos] = (uint32_t)(t0 + j[2]);
+        }
+        base += c2n;
+        if (kq[3]) {
+          const int pos = base + __popcll(m3 & below);
+          S.pool.key[pos] = v[3];
+          S.pool.pay[pos] = (uint32_t)(t0 + j[3]);
+        }
+        S.pool.n = base + c3n;
+        PW_STAMP(7);
+        return;
+      }
+#pragma unroll 1
+      for (int q = 0; q < 4 && live; ++q, live >>= 1) {
+        if (live & 1u) {
+          const uint32_t col = (uint32_t)(t0 + j[0]);
+          // the threshold may have moved since the vote (a cut inside an earlier push): ask again
+          const bool keep = kq[0] && rp_wpool_admits<AccT, 0>(S.pool, v[0], col);
+#ifdef RP_STAMPS
+          const int n_before = S.pool.n;
+          const unsigned long long t_push = __builtin_amdgcn_s_memtime();
+#endif
+          rp_wpool_push<AccT, 0>(S.pool, Kp, cap, keep, v[0], col, lane);
+#ifdef RP_STAMPS
+          if (S.pool.n < n_before) PW_COUNT(6, __builtin_amdgcn_s_memtime() - t_push);  // a cut happened: its cycles
+#endif
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          kq[r] = kq[r + 1];
+          j[r] = j[r + 1];
+          v[r] = v[r + 1];
+        }
+      }
+      PW_STAMP(7);
+    };
+    if constexpr (ONE) {
+      RP_WAVE_FENCE();
+      if (P.exclude_history) {  // the user's own items: their sums are dropped before anybody takes them
+        const int jx = it0 - t0;
+        if ((unsigned)jx < (unsigned)WT) S.acc[jx] = 0;
+        RP_WAVE_FENCE();
+      }
+      PW_STAMP(5);
+      if (C.nchunks > 64 * ST) {
+        // more chunks than the prefetched steps hold (rp_pw_extra_steps added the rest): every column of the tile is looked at
+#pragma unroll 1
+        for (int r = 0; r < WT / 256; ++r) {
+          bool has[4];
+          int j[4];
+          AccT v[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            has[q] = true;
+            j[q] = lane + 64 * (4 * r + q);
+            v[q] = S.acc[j[q]];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) S.acc[j[q]] = 0;
+          offer4(has, j, v);
+        }
+#pragma unroll
+        for (int d = 0; d < DW; ++d) S.dirty[lane + 64 * d] = 0u;  // (the bits rp_pw_extra_steps set)
+      } else {
+#pragma unroll
+        for (int st = 0; st < ST; ++st) {
+          if (64 * st < C.nchunks) {  // (uniform)
+            const int ec[4] = {C.a[st].x, C.a[st].z, C.b[st].x, C.b[st].z};
+            bool has[4];
+            int j[4];
+            AccT v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              has[q] = q < C.n[st];
+              j[q] = has[q] ? ec[q] - t0 : lane;  // (an idle slot points at a word of the lane's own: no two lanes meet there)
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = has[q] ? (AccT)rp_lds_exch(&S.acc[j[q]]) : (AccT)0;
+            offer4(has, j, v);
+          }
+        }
+      }
+      PW_STAMP(2);
+      return;
+    }
     const bool was_touched = touched;
     touched = false;
     RP_WAVE_FENCE();
@@ -735,90 +907,15 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (has[q]) S.acc[j[q]] = 0;
-        // most sums lose against the pool's threshold once it is warm: the slots of the round are voted on first and only
-        // slots with a surviving lane are pushed (rolled loop: one inlined copy of the pool cut; values rotate through 0)
-        bool kq[4];
-        uint32_t live = 0;  // bit q: some lane keeps its slot q
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          v[q] ^= FLIP;  // signed sum -> unsigned order; a zero sum is no candidate
-          kq[q] = has[q] && v[q] != FLIP && rp_wpool_admits<AccT, 0>(S.pool, v[q], (uint32_t)(t0 + j[q]));
-        }
-        if (P.keep) {  // item filter: only sums that would enter the pool pay the lookup
-          const uint32_t want = (kq[0] ? 1u : 0u) | (kq[1] ? 2u : 0u) | (kq[2] ? 4u : 0u) | (kq[3] ? 8u : 0u);
-          if (__any(want != 0u)) {
-            const uint32_t ok = rp_pw_keep_lookup(P.keep, t0 + j[0], t0 + j[1], t0 + j[2], t0 + j[3], want);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) kq[q] = (ok >> q) & 1u;
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) live |= __any(kq[q]) ? (1u << q) : 0u;
-        if (!live) continue;
-        PW_STAMP(2);
-        // the round's survivors in one go when they fit the pool as it is (the common case: a few of them); slot by slot
-        // with cuts in between otherwise
-        const uint64_t m0 = __ballot(kq[0]), m1 = __ballot(kq[1]), m2 = __ballot(kq[2]), m3 = __ballot(kq[3]);
-        const int c0n = __popcll(m0), c1n = __popcll(m1), c2n = __popcll(m2), c3n = __popcll(m3);
-        if (S.pool.n + c0n + c1n + c2n + c3n <= cap) {
-          const uint64_t below = (1ull << lane) - 1ull;
-          int base = S.pool.n;
-          if (kq[0]) {
-            const int pos = base + __popcll(m0 & below);
-            S.pool.key[pos] = v[0];
-            S.pool.pay[pos] = (uint32_t)(t0 + j[0]);
-          }
-          base += c0n;
-          if (kq[1]) {
-            const int pos = base + __popcll(m1 & below);
-            S.pool.key[pos] = v[1];
-            S.pool.pay[pos] = (uint32_t)(t0 + j[1]);
-          }
-          base += c1n;
-          if (kq[2]) {
-            const int pos = base + __popcll(m2 & below);
-            S.pool.key[pos] = v[2];
-            S.pool.pay[pos] = (uint32_t)(t0 + j[2]);
-          }
-          base += c2n;
-          if (kq[3]) {
-            const int pos = base + __popcll(m3 & below);
-            S.pool.key[pos] = v[3];
-            S.pool.pay[pos] = (uint32_t)(t0 + j[3]);
-          }
-          S.pool.n = base + c3n;
-          PW_STAMP(7);
-          continue;
-        }
-#pragma unroll 1
-        for (int q = 0; q < 4 && live; ++q, live >>= 1) {
-          if (live & 1u) {
-            const uint32_t col = (uint32_t)(t0 + j[0]);
-            // the threshold may have moved since the vote (a cut inside an earlier push): ask again
-            const bool keep = kq[0] && rp_wpool_admits<AccT, 0>(S.pool, v[0], col);
-#ifdef RP_STAMPS
-            const int n_before = S.pool.n;
-#endif
-            rp_wpool_push<AccT, 0>(S.pool, Kp, cap, keep, v[0], col, lane);
-#ifdef RP_STAMPS
-            if (S.pool.n < n_before) PW_COUNT(6, 1);  // a cut happened
-#endif
-          }
-#pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            kq[r] = kq[r + 1];
-            j[r] = j[r + 1];
-            v[r] = v[r + 1];
-          }
-        }
-        PW_STAMP(7);
+        offer4(has, j, v);
       }
     }
     PW_STAMP(2);
   };
-  for (int k = 0; k < NU; k += 2) {
-    unit(set0, set1);
+  for (int k = 0; k < NU; k += 3) {
+    unit(set0, set2);
     if (k + 1 < NU) unit(set1, set0);
+    if (k + 2 < NU) unit(set2, set1);
   }
 }
 
@@ -893,7 +990,10 @@ __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
       S.pool.tau = 0;
       S.pool.tau_col = 0;
       PW_STAMP(0);
-      rp_pw_user_units<AccT, WT, WGT, (WT > PW_WT ? 3 : 2)>(P, S, hs, he);
+      if (he - hs <= 64)
+        rp_pw_user_units<AccT, WT, WGT, (WT > PW_WT ? 3 : 2), true>(P, S, hs, he);
+      else
+        rp_pw_user_units<AccT, WT, WGT, (WT > PW_WT ? 3 : 2), false>(P, S, hs, he);
       // ---- final: best Kp by (score desc, column asc), then column order for the output row
       RP_WAVE_FENCE();
       if (S.pool.n > Kp) rp_wpool_cut<AccT, 0>(S.pool, Kp, lane);
@@ -1183,8 +1283,8 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
       hipMemcpyAsync(h, W.stamps, sizeof(h), hipMemcpyDeviceToHost, st);
       hipStreamSynchronize(st);
       fprintf(stderr, "[stamps predict_wave] cycles/1e6: setup %.1f | per tile: prepare %.1f adds %.1f exclusion+dirty %.1f walk %.1f | final %.1f "
-                      "(grid %d); of the walk: push loops %.1f, pool cuts %llu\n",
-              h[0] / 1e6, h[4] / 1e6, h[1] / 1e6, h[5] / 1e6, (h[2] + h[7]) / 1e6, h[3] / 1e6, wg, h[7] / 1e6, h[6]);
+                      "(grid %d); of the walk: push loops %.1f, of which pushes with a pool cut %.1f\n",
+              h[0] / 1e6, h[4] / 1e6, h[1] / 1e6, h[5] / 1e6, (h[2] + h[7]) / 1e6, h[3] / 1e6, wg, h[7] / 1e6, h[6] / 1e6);
     }
 #endif
     rp_time_end(ctx, ev, RPHIP_T_PREDICT, rp_pred_work(Xpred, model, n, Kp));
