@@ -875,39 +875,49 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
     touched = false;
     RP_WAVE_FENCE();
     PW_STAMP(5);
-#pragma unroll 1
-    for (int dwi = 0; dwi < DW; ++dwi) {
-      uint32_t ex = 0u;
+    // the lane's map words as ONE 64-bit word (DW <= 2): bit b is column lane + 64 b of the tile.  Walking the two words one
+    // after the other ran as many rounds as the fullest lane of EACH needed; together the lanes' loads even out
+    static_assert(DW <= 2, "one 64-bit map word per lane");
+    {
+      uint64_t ex = 0ull;
       if (P.exclude_history) {
-        ex = excl[lane + 64 * dwi];
-        excl[lane + 64 * dwi] = 0u;
-      }
-      if (!was_touched) continue;
-      uint32_t w = S.dirty[lane + 64 * dwi];
-      S.dirty[lane + 64 * dwi] = 0u;
-      const int jb = lane + PW_WT * dwi;  // column of bit 0 of this word
-      ex &= w;      // history items that were touched: their sums are dropped
-      w &= ~ex;
-      while (__any(ex != 0u)) {
-        if (ex != 0u) S.acc[jb + 64 * (__ffs((int)ex) - 1)] = 0;
-        ex &= ex - 1u;
-      }
-      while (__any(w != 0u)) {
-        bool has[4];
-        int j[4];
-        AccT v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          has[q] = w != 0u;
-          j[q] = jb + 64 * (has[q] ? (__ffs((int)w) - 1) : 0);
-          w &= w - 1u;  // 0 stays 0
+        ex = excl[lane];
+        excl[lane] = 0u;
+        if (DW > 1) {
+          ex |= (uint64_t)excl[lane + 64] << 32;
+          excl[lane + 64] = 0u;
         }
+      }
+      if (was_touched) {
+        uint64_t w = S.dirty[lane];
+        S.dirty[lane] = 0u;
+        if (DW > 1) {
+          w |= (uint64_t)S.dirty[lane + 64] << 32;
+          S.dirty[lane + 64] = 0u;
+        }
+        ex &= w;  // history items that were touched: their sums are dropped
+        w &= ~ex;
+        while (__any(ex != 0ull)) {
+          if (ex != 0ull) S.acc[lane + 64 * (__ffsll((unsigned long long)ex) - 1)] = 0;
+          ex &= ex - 1ull;
+        }
+        while (__any(w != 0ull)) {
+          bool has[4];
+          int j[4];
+          AccT v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = has[q] ? S.acc[j[q]] : (AccT)0;
+          for (int q = 0; q < 4; ++q) {
+            has[q] = w != 0ull;
+            j[q] = lane + 64 * (has[q] ? (__ffsll((unsigned long long)w) - 1) : 0);
+            w &= w - 1ull;  // 0 stays 0
+          }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (has[q]) S.acc[j[q]] = 0;
-        offer4(has, j, v);
+          for (int q = 0; q < 4; ++q) v[q] = has[q] ? S.acc[j[q]] : (AccT)0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (has[q]) S.acc[j[q]] = 0;
+          offer4(has, j, v);
+        }
       }
     }
     PW_STAMP(2);
