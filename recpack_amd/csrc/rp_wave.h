@@ -239,6 +239,103 @@ __device__ rp_wcut<KeyT> rp_wpool_cut_impl(RP_LDS KeyT* pkey_, RP_LDS uint32_t* 
   return r;
 }
 
+// A cheaper way to make room: drop every entry whose key lies below the lower edge of the radix bin that holds the K-th best
+// key (digits resolved level by level until at most `limit` entries stay).  The K best are all kept - plus whoever shares the
+// boundary bin - and the edge becomes the admission bound; nothing is ranked and the columns are never looked at, which is most
+// of an exact cut's work.  Returns n = -1 when the keys cannot be separated that way (massive ties, or an edge of 0): the caller
+// then cuts exactly.
+template <typename KeyT, int COL_SHIFT>
+__device__ rp_wcut<KeyT> rp_wpool_trim_impl(RP_LDS KeyT* pkey_, RP_LDS uint32_t* ppay_, RP_LDS uint32_t* phist_, int n, int K, int limit,
+                                            int lane) {
+  constexpr int KEY_LEVELS = sizeof(KeyT);
+  RP_LDS KeyT* key = pkey_;
+  RP_LDS uint32_t* pay = ppay_;
+  RP_LDS uint32_t* hist = phist_;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  rp_wcut<KeyT> r;
+  r.n = -1;
+  r.tau = 0;
+  r.tau_col = 0;
+  KeyT pkey = 0;
+  int need = K;
+  int level0 = 0;
+  {
+    const KeyT k0 = key[0];
+    KeyT diff = 0;
+    for (int e = lane; e < n; e += 64) diff |= key[e] ^ k0;
+    uint32_t dlo = rp_wave_or((uint32_t)diff), dhi = 0;
+    if (sizeof(KeyT) == 8) dhi = rp_wave_or((uint32_t)((uint64_t)diff >> 32));
+    const uint64_t d64 = sizeof(KeyT) == 8 ? (((uint64_t)dhi << 32) | dlo) : ((uint64_t)dlo << 32);
+    if (!d64) return r;  // all keys equal
+    level0 = __builtin_clzll(d64) >> 3;
+    if (level0 > 0) pkey = (KeyT)(k0 & ~((((KeyT)1) << (8 * (KEY_LEVELS - level0))) - 1));
+  }
+  KeyT edge = 0;
+  bool found = false;
+  for (int level = level0; level < KEY_LEVELS && !found; ++level) {
+    const int shift = 8 * (KEY_LEVELS - 1 - level);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) hist[lane * 4 + b] = 0;
+    RP_WAVE_FENCE();
+    for (int e = lane; e < n; e += 64) {
+      const KeyT k = key[e];
+      const bool in_group = (level == 0) || ((k >> shift) >> 8) == ((pkey >> shift) >> 8);
+      if (in_group) atomicAdd((uint32_t*)&phist_[(uint32_t)(k >> shift) & 255u], 1u);
+    }
+    RP_WAVE_FENCE();
+    int h[4];
+    int sum = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      h[b] = (int)hist[255 - 4 * lane - b];
+      sum += h[b];
+    }
+    int above = rp_wave_incl_scan(sum, lane) - sum;
+    int fbin = -1, fabove = 0, fgroup = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (above < need && need <= above + h[b]) {
+        fbin = 255 - 4 * lane - b;
+        fabove = above;
+        fgroup = h[b];
+      }
+      above += h[b];
+    }
+    const uint64_t fm = __ballot(fbin >= 0);
+    const int src = __ffsll((unsigned long long)fm) - 1;
+    const int bin = __shfl(fbin, src);
+    const int group = __shfl(fgroup, src);
+    const int ab = __shfl(fabove, src);
+    pkey |= (KeyT)bin << shift;
+    // kept if the walk stops here: the K - need entries above the group, the bins above the boundary one, the boundary bin
+    if ((K - need) + ab + group <= limit) {
+      edge = pkey;
+      found = true;
+    }
+    need -= ab;
+  }
+  if (!found || edge == 0) return r;
+  int out = 0;
+  for (int e0 = 0; e0 < n; e0 += 64) {
+    const int e = e0 + lane;
+    const KeyT rk = (e < n) ? key[e] : (KeyT)0;
+    const uint32_t rp = (e < n) ? pay[e] : 0u;
+    const bool sel = (e < n) && rk >= edge;
+    const uint64_t m = __ballot(sel);
+    if (sel) {
+      const int pos = out + __popcll(m & lt_mask);
+      key[pos] = rk;
+      pay[pos] = rp;
+    }
+    out += __popcll(m);
+  }
+  RP_WAVE_FENCE();
+  r.n = out;
+  r.tau = (KeyT)(edge - 1);  // key > tau  <=>  key >= edge
+  r.tau_col = 0;
+  return r;
+}
+
 // Cut the pool to its K best entries by (key desc, column asc); requires pool.n > K.  Sets pool.tau / tau_col.
 template <typename KeyT, int COL_SHIFT>
 __device__ __forceinline__ void rp_wpool_cut(rp_wpool<KeyT>& P, int K, int lane) {
@@ -261,7 +358,15 @@ __device__ __forceinline__ void rp_wpool_push(rp_wpool<KeyT>& P, int K, int cap,
   uint64_t m = __ballot(keep);
   if (m == 0) return;
   if (P.n + 64 > cap && P.n > K) {  // cap >= K + 64
-    rp_wpool_cut<KeyT, COL_SHIFT>(P, K, lane);
+    // room for this push and a few more: a trim to at most cap - 96 entries when the keys allow it, an exact cut otherwise
+    const rp_wcut<KeyT> t = (cap - 96 > K) ? rp_wpool_trim_impl<KeyT, COL_SHIFT>(P.key, P.pay, P.hist, P.n, K, cap - 96, lane) : rp_wcut<KeyT>{0, 0, -1};
+    if (t.n >= 0) {
+      P.n = t.n;
+      P.tau = t.tau;
+      P.tau_col = t.tau_col;
+    } else {
+      rp_wpool_cut<KeyT, COL_SHIFT>(P, K, lane);
+    }
     keep = keep && rp_wpool_admits<KeyT, COL_SHIFT>(P, k, pay);
     m = __ballot(keep);
     if (m == 0) return;
