@@ -409,7 +409,8 @@ struct rp_pw_params {
 typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 // Diagnostic builds only (make ablate; tools/k8_ablate.py): RP_PW_ABL removes parts of the wave kernel to attribute its time -
-// 1: no sum atomics, 2: no walk, 4: no dirty-map atomics, 8: no entry loads.  Results are wrong by construction.
+// 1: no sum atomics, 2: no walk, 4: no dirty-map atomics, 8: no entry loads, 16: no owner search in the chunk assignment,
+// 32: no adds at all.  Results are wrong by construction.
 #ifndef RP_PW_ABL
 #define RP_PW_ABL 0
 #endif
@@ -618,12 +619,17 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
       own[st] = rp_wave_incl_max(max(own[st], (lane == 0) ? carry : 0));
       carry = __builtin_amdgcn_readlane(own[st], 63);
     }
+    if (RP_PW_ABL & 16) {  // (diagnostic: no owner search)
+#pragma unroll
+      for (int st = 0; st < ST; ++st) own[st] = lane;
+    }
     int us[ST], ulen[ST], co[ST];
 #pragma unroll
     for (int st = 0; st < ST; ++st) {
       us[st] = __shfl(D.s, own[st]);
       ulen[st] = __shfl(D.len, own[st]);
       co[st] = __shfl(D.choff, own[st]);
+      if (RP_PW_ABL & 16) co[st] = 64 * st + lane;  // (diagnostic: every lane reads the head of its own slice)
       if (WGT) D.w[st] = __shfl(wt, own[st]);
     }
 #pragma unroll
@@ -726,7 +732,11 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
     touched |= C.nchunks > 0;
 #pragma unroll
     for (int st = 0; st < ST; ++st)
-      if (64 * st < C.nchunks) rp_pw_add_chunk<AccT, WGT, !ONE>(S, C.n[st], C.a[st], C.b[st], t0, C.w[st]);
+      if (64 * st < C.nchunks && !(RP_PW_ABL & 32)) rp_pw_add_chunk<AccT, WGT, !ONE>(S, C.n[st], C.a[st], C.b[st], t0, C.w[st]);
+    if (RP_PW_ABL & 32) {  // (diagnostic: the entries are still waited for)
+#pragma unroll
+      for (int st = 0; st < ST; ++st) asm volatile("" ::"v"(C.a[st]), "v"(C.b[st]));
+    }
     if (C.nchunks > 64 * ST)  // (rare; sets map bits, which the ONE form never reads: it scans such a tile densely)
       rp_pw_extra_steps<AccT, WGT>(S.acc, S.dirty, S.pool.hist, S.pairs_i, S.fix, S.fmul, lane, C.s, C.len, C.choff, C.nchunks, t0, wt0,
                                    64 * ST);

@@ -80,6 +80,10 @@ __device__ __forceinline__ uint32_t rp_wave_or(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+#ifndef RP_TRIM_SLACK
+#define RP_TRIM_SLACK 96  // free entries a trim must leave (64 are needed by the push that asked; measured 64 / 96 / 128: see DESIGN.md)
+#endif
+
 template <typename KeyT>
 struct rp_wcut {
   KeyT tau;
@@ -358,8 +362,8 @@ __device__ __forceinline__ void rp_wpool_push(rp_wpool<KeyT>& P, int K, int cap,
   uint64_t m = __ballot(keep);
   if (m == 0) return;
   if (P.n + 64 > cap && P.n > K) {  // cap >= K + 64
-    // room for this push and a few more: a trim to at most cap - 96 entries when the keys allow it, an exact cut otherwise
-    const rp_wcut<KeyT> t = (cap - 96 > K) ? rp_wpool_trim_impl<KeyT, COL_SHIFT>(P.key, P.pay, P.hist, P.n, K, cap - 96, lane) : rp_wcut<KeyT>{0, 0, -1};
+    // room for this push and a few more: a trim to at most cap - RP_TRIM_SLACK entries when the keys allow it, an exact cut otherwise
+    const rp_wcut<KeyT> t = (cap - RP_TRIM_SLACK > K) ? rp_wpool_trim_impl<KeyT, COL_SHIFT>(P.key, P.pay, P.hist, P.n, K, cap - RP_TRIM_SLACK, lane) : rp_wcut<KeyT>{0, 0, -1};
     if (t.n >= 0) {
       P.n = t.n;
       P.tau = t.tau;
