@@ -105,6 +105,14 @@ int rphip_ctx_trim(rphip_ctx* ctx);
  *                          left; fp32 accumulate.  1: three bf16 planes by truncation, six plane products (no scaling pass).
  *                          0: the fp32-input MFMA (v_mfma_f32_32x32x2_f32).  Error of one product, relative to sum |a||b|:
  *                          the same for all three (2e-8 .. 2.5e-7); speed on MI355X 216 / 165 / 113 TFLOP/s fp32-equivalent.
+ *   "gemm_presplit"     1 (default) | 0.  gemm_mode 2: products with at least 512 tiles cut their operands into planes ONCE per K chunk
+ *                       (a workspace laid out in MFMA fragment order) and run a product kernel staged by LDS-DMA loads with no
+ *                       conversion arithmetic (363 against 225 TFLOP/s fp32-equivalent on a square product); 0: every workgroup
+ *                       converts the tiles it stages.
+ *   "gemm_workspace_bytes"  bytes of plane workspace per operand of those products (default 4 GiB, at least 64 MiB): sets the K
+ *                       chunk; a product on a side stream has a second pair.  rphip_ctx_trim releases them.
+ *   "gemm_shape16"      1 (default) | 0.  The plane product kernel on v_mfma_f32_16x16x32_f16 (the chip holds a higher clock on it:
+ *                       363 against 314 TFLOP/s) or on v_mfma_f32_32x32x16_f16.
  *   "gemm_supertile"    0 (default) | 1.  Tile order of the GEMM's workgroups: supertiles of 64 tiles handed to the 8 XCDs round-robin
  *                       (each XCD's L2 then holds the 8 + 8 panels of an 8 x 8 block of tiles), or the plain row-major grid
  *                       (measured equal within 1 %: the products are not bound by operand traffic).
