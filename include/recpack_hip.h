@@ -102,7 +102,8 @@ int rphip_ctx_trim(rphip_ctx* ctx);
  *                       2: two fp16 planes per operand, both rounded to nearest (x = h1 + h2 to 2^-24 |x|), three plane products per
  *                          step on v_mfma_f32_32x32x16_f16; each operand is scaled by a power of two taken from its largest magnitude
  *                          over the rows and K range the launch reads (one extra pass over the operands), so fp16's range is never
- *                          left; fp32 accumulate.  1: three bf16 planes by truncation, six plane products (no scaling pass).
+ *                          left; fp32 accumulate.  Entries below 2^-18 of that magnitude are held to an absolute 2^-40 of it
+ *                          instead of fp32's relative 2^-24 (rows of very different size: use mode 1 or 0).  1: three bf16 planes by truncation, six plane products (no scaling pass).
  *                          0: the fp32-input MFMA (v_mfma_f32_32x32x2_f32).  Error of one product, relative to sum |a||b|:
  *                          the same for all three (2e-8 .. 2.5e-7); speed on MI355X 216 / 165 / 113 TFLOP/s fp32-equivalent.
  *   "gemm_presplit"     1 (default) | 0.  gemm_mode 2: products with at least 512 tiles cut their operands into planes ONCE per K chunk

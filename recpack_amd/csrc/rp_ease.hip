@@ -429,8 +429,10 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_b3(rp_gemm_args g) {
 // rate) per K16 step and output tile instead of six, 4 bytes of LDS per element instead of 6, and a cheaper cut (two conversions
 // and one subtraction per element).  What fp16 lacks is RANGE (2^-24 .. 65504), so each operand is multiplied by a power of two
 // that puts its largest magnitude - over exactly the rows and K range this launch reads: k_gemm_amax, one pass over the operand
-// beforehand - into [2^14, 2^15): entries down to 2^-39 of the largest still get their full 22 bits, smaller ones are absolute
-// to 2^-39 of it (a fixed-point tail that a product of magnitudes sum |a||b| does not see).  The scales leave the accumulators at
+// beforehand - into [2^14, 2^15): entries down to 2^-18 of the largest keep both planes normal (fp32's precision), smaller ones
+// are held to an ABSOLUTE 2^-40 of the largest (the second plane goes subnormal): a fixed-point tail that sum |a||b| over a row
+// of comparable entries does not see - the factors and inverses of the EASE solve - but a row 2^-20 the size of the largest one
+// would (a per-row scale would lift that; the solve has no such rows).  The scales leave the accumulators at
 // the flush (acc * 1 / (sA sB), exact), the compensated master sums and the epilogue are those of the kernels above.
 // (A register-side cut of bf16 planes - fp32 tile in LDS, each wave converting its own fragments, 2.3x less LDS traffic for 2x
 // the conversions - was measured at 157 TF/s against 165 for k_gemm_nt_b3, and dropped.)

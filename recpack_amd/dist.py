@@ -309,7 +309,8 @@ def ease_fit_replicated(ctx, dX, l2: float, alpha: float, device, group=None, pa
     The O(n^3) work is done in wide panels (``panel_tiles`` x 128 columns): a panel takes the update of everything to its
     left in one product whose rows are split over the ranks, and the finished panel is all-gathered (n^2/2 * 4 bytes in
     total per phase, ~n / 2048 large collectives plus one small one per 128 columns inside a panel);
-    P = N N^T (lower triangle, row slabs of equal area) is exchanged with one broadcast per rank, mirrored and scaled; B is
+    P = N N^T (lower triangle, row slabs of equal area) is exchanged slab by slab (columns up to the diagonal only: n^2/2 * 4 bytes),
+    mirrored and scaled; B is
     all-gathered into the big matrix, so predict can shard by users as for ItemKNN.  Peak memory n^2 * 4 * (1 + 1/world)
     bytes per GPU.  Returns a dense model on this rank's copy of B.
     """
@@ -457,9 +458,22 @@ def ease_fit_replicated(ctx, dX, l2: float, alpha: float, device, group=None, pa
         torch.cuda.current_stream().synchronize()
     if dist.is_initialized():
         dist.barrier(group=group)  # every rank has finished reading N
+        # slab r: only its columns up to the diagonal (what was computed; the rest of those rows still holds N and is overwritten
+        # by the mirror below, which must therefore run before anything reads the upper tiles) - packed chunk by chunk through
+        # the staging buffer, since a collective wants contiguous memory: n^2 / 2 * 4 bytes in total
+        flat = stage.view(-1)
         for r in range(world):
-            if cut[r + 1] > cut[r]:
-                dist.broadcast(A[cut[r] * T: cut[r + 1] * T], src=dist.get_global_rank(group, r) if group is not None else r, group=group)
+            src = dist.get_global_rank(group, r) if group is not None else r
+            cols = cut[r + 1] * T
+            for c_lo in range(cut[r], cut[r + 1], chunk_tiles):
+                c_hi = min(cut[r + 1], c_lo + chunk_tiles)
+                r0, r1 = c_lo * T, c_hi * T
+                buf = flat[: (r1 - r0) * cols].view(r1 - r0, cols)
+                if rank == r:
+                    buf.copy_(A[r0:r1, :cols])
+                dist.broadcast(buf, src=src, group=group)
+                if rank != r:
+                    A[r0:r1, :cols].copy_(buf)
     MB = 32 * T  # mirror the lower half over the upper one, a block row at a time (no second matrix)
     for r0 in range(0, n_pad, MB):
         r1 = min(n_pad, r0 + MB)

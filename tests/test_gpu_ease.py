@@ -67,6 +67,55 @@ def test_gemm_nt_mfma(hip):
     np.testing.assert_array_equal(Cd.cpu().numpy(), Bd.cpu().numpy().T)
 
 
+def test_gemm_plane_workspace_paths(hip):
+    """The large-product route of the GEMM (operands cut into fp16 planes once per K chunk, LDS-DMA product kernel) against float64:
+    several K chunks (small workspace), both MFMA shapes, B = a row range of A (one set of planes serves both, one scale),
+    B = A, and the in-kernel conversion (gemm_presplit = 0) - all within the error of the plain kernel."""
+    import torch
+
+    _lib, ctx = hip
+    g = torch.Generator(device="cpu").manual_seed(11)
+    M, N, K = 3072, 2944, 4096  # 23 x 24 tiles >= 512: the workspace route
+    # rows of different size, within the 2^18 of the largest magnitude that keeps both fp16 planes normal (below that the planes'
+    # error becomes absolute: 2^-40 of the operand's largest magnitude - see include/recpack_hip.h, gemm_mode)
+    A = torch.randn((M, K), generator=g) * torch.exp(1.0 * torch.randn((M, 1), generator=g))
+    B = torch.randn((N, K), generator=g) * 37.0
+    C0 = torch.randn((M, M), generator=g)
+    Ad, Bd = A.cuda(), B.cuda()
+
+    def check(Ax, Bx, alpha, beta, what):
+        ref = alpha * (Ax.double().cpu() @ Bx.double().cpu().T) + beta * C0[:, : Bx.shape[0]].double()
+        bound = abs(alpha) * (Ax.double().cpu().abs() @ Bx.double().cpu().abs().T) + abs(beta) * C0[:, : Bx.shape[0]].double().abs()
+        Cd = C0[:, : Bx.shape[0]].contiguous().cuda()
+        _lib.gemm_nt(ctx, Ax, Bx, Cd, alpha=alpha, beta=beta)
+        ctx.sync()
+        err = ((Cd.cpu().double() - ref).abs() / bound).max().item()
+        assert err <= 5e-7, (what, err)
+
+    try:
+        for shape16 in (1, 0):
+            ctx.set_option("gemm_shape16", shape16)
+            ctx.set_option("gemm_workspace_bytes", 64 << 20)  # K chunks of 5120 -> one chunk here ...
+            check(Ad, Bd, 0.5, -1.0, ("one chunk", shape16))
+        ctx.set_option("gemm_shape16", 1)
+        big = torch.randn((2048, 16384), generator=g).cuda()  # ... and 16 x 16 tiles < 512: stays on the plain kernel
+        Cd = torch.zeros((2048, 2048)).cuda()
+        _lib.gemm_nt(ctx, big, big, Cd)
+        ctx.sync()
+        ref = big.double().cpu() @ big.double().cpu().T
+        assert ((Cd.cpu().double() - ref).abs() / (big.double().cpu().abs() @ big.double().cpu().abs().T)).max().item() <= 5e-7
+        A2 = torch.randn((3072, 16384), generator=g).cuda()  # 24 x 23 tiles, K in four chunks of 5120 (later chunks: beta = 1)
+        check(A2, A2[128:128 + N], -1.0, 1.0, "B = rows 128.. of A (aliased planes), four K chunks")
+        check(A2, A2, 1.0, 0.0, "B = A")
+        ctx.set_option("gemm_presplit", 0)
+        check(Ad, Bd, 0.5, -1.0, "conversion inside the product kernel")
+    finally:
+        ctx.set_option("gemm_presplit", 1)
+        ctx.set_option("gemm_shape16", 1)
+        ctx.set_option("gemm_workspace_bytes", 4 << 30)
+        ctx.trim()
+
+
 def ease_B(hip, X, l2, alpha=0.0):
     _lib, ctx = hip
     from recpack_amd.algorithms import to_binary_csr
