@@ -530,19 +530,18 @@ __device__ __attribute__((noinline)) uint32_t rp_pw_keep_lookup(const uint8_t* k
 }
 
 // One user.  The work is a sequence of UNITS (column tile t, batch g of 64 history items), tile-major; after the last batch
-// of a tile its touched columns are offered to the pool.  The sequence is software-pipelined four units deep, the same
+// of a tile its touched columns are offered to the pool.  The sequence is software-pipelined three units deep, the same
 // way for every history length:
-//   iteration k   requests  the tile offsets of unit k+3 (toff[item][t], [t+1]; needs the ids of k+3)
-//                           the item ids of unit k+4                      (one coalesced load)
-//                           the entries of unit k+2: scan of the slice lengths, chunk -> lane assignment, ST steps of two
-//                           16-byte loads per lane (needs the offsets of k+2)
-//                 then adds the entries of unit k (requested two iterations earlier) and, at a tile's end, walks the tile.
-// The ids and offsets an iteration requests are consumed at the top of the next one, the entries two iterations later: loads
-// return in order, and the small loads are issued in front of the entry loads, so that the next top waits for them with
-// s_waitcnt vmcnt(2 ST) and leaves the entries just requested in flight.  All loads are UNCONDITIONAL (clamped addresses;
-// dead units and idle lanes read something harmless): with loads under branches the compiler loses count of the loads in
-// flight and falls back to s_waitcnt vmcnt(0).  Three entry sets rotate (the loop body handles three units), so no register
-// is copied while its load is in flight.
+//   iteration k   requests  the item ids of unit k+3                      (one coalesced load)
+//                           the tile offsets of unit k+2 (toff[item][t], [t+1]; needs the ids of k+2)
+//                           the entries of unit k+1: scan of the slice lengths, chunk -> lane assignment, ST steps of two
+//                           16-byte loads per lane (needs the offsets of k+1)
+//                 then adds the entries of unit k (requested one iteration earlier) and, at a tile's end, walks the tile.
+// Everything an iteration requests is consumed at the top of the next one at the earliest, i.e. after the adds and the walk
+// - the long part of an iteration - so the loads have that long to arrive.  All of them are UNCONDITIONAL (clamped
+// addresses; dead units and idle lanes read something harmless): with loads under branches the compiler loses count of
+// the loads in flight and falls back to s_waitcnt vmcnt(0) in front of the adds, which waits for the entries just requested.
+// Two entry sets alternate (the loop body handles two units), so no register is copied while its load is in flight.
 // ST steps of 64 chunks of 4 entries are prefetched per unit (3 for 4096-column tiles: a full batch has 64 x 8.2 entries in
 // about 160 chunks); chunks beyond them (rare) are fetched on the spot by rp_pw_extra_steps.
 // History removal: a lane whose item lies in the current tile sets its bit in `excl` (same layout as the dirty map); the walk
@@ -567,10 +566,10 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
   const int G = (he - hs + 63) >> 6;
   const int NU = NT * G;
   RP_LDS uint32_t* excl = S.dirty + 64 * DW;
-  rp_pw_uset<ST> set0, set1, set2;
+  rp_pw_uset<ST> set0, set1;
 
-  // ---- stage state.  (t, g) of units k .. k+4; ids / weights of k .. k+3; raw (just loaded) values of the youngest stages
-  int t0c = 0, g0c = 0, t1c = 0, g1c = 0, t2c = 0, g2c = 0, t3c = 0, g3c = 0, t4c = 0, g4c = 0;
+  // ---- stage state.  (t, g) of units k .. k+3; ids / weights of k .. k+2; raw (just loaded) values of the youngest stages
+  int t0c = 0, g0c = 0, t1c = 0, g1c = 0, t2c = 0, g2c = 0, t3c = 0, g3c = 0;
   auto next_unit = [&](int& t, int& g) __attribute__((always_inline)) {
     ++g;
     if (g == G) {
@@ -578,9 +577,9 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
       ++t;
     }
   };
-  int it0 = -1, it1 = -1, it2 = -1, it3 = -1, raw_it = 0, raw_oa = 0, raw_ob = 0;
-  bool valid3 = false;  // validity of the ids in raw_it
-  double wt0 = 1.0, wt1 = 1.0, wt2 = 1.0, wt3 = 1.0, raw_wt = 1.0;
+  int it0 = -1, it1 = -1, it2 = -1, raw_it = 0, raw_oa = 0, raw_ob = 0;
+  bool valid3 = false;
+  double wt0 = 1.0, wt1 = 1.0, wt2 = 1.0, raw_wt = 1.0;
   auto load_ids = [&](int t, int g) __attribute__((always_inline)) {
     const int h = hs + 64 * g + lane;
     raw_it = P.x_idx[min(h, he - 1)];  // (he > hs: the clamped read stays inside the user's row)
@@ -638,13 +637,8 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
       const int k0 = (c - co[st]) * PW_CH;
       const int n = (c < D.nchunks) ? min(PW_CH, ulen[st] - k0) : 0;
       D.n[st] = n;
-      // ALWAYS issued (a step past the unit's chunks reads the head of the array in every lane - one cache line): the next
-      // iteration waits for the small loads issued before these with a COUNTED s_waitcnt, which the compiler can only emit
-      // when the number of loads behind them does not depend on a branch
-      const int* src = S.pairs_i + 2 * (long long)(n > 0 ? us[st] + k0 : 0);  // (padded array: reading past a slice's end is harmless)
-      if (RP_PW_ABL & 8) {
-        D.a[st] = D.b[st] = (v4i_a4){(int)(long long)src & 4095, 0, (int)(long long)src & 4095, 0};
-      } else {
+      if (64 * st < D.nchunks) {  // (uniform; whatever is requested here is used at the top of the next iteration at the earliest)
+        const int* src = S.pairs_i + 2 * (long long)(n > 0 ? us[st] + k0 : 0);  // (padded array: reading past a slice's end is harmless)
         D.a[st] = *reinterpret_cast<const v4i_a4*>(src);
         D.b[st] = *reinterpret_cast<const v4i_a4*>(src + 4);
       }
@@ -652,60 +646,48 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
   };
 #pragma unroll
   for (int st = 0; st < ST; ++st) {
-    set0.w[st] = set1.w[st] = set2.w[st] = 1.0;
-    set0.n[st] = set1.n[st] = set2.n[st] = 0;
-    set0.a[st] = set0.b[st] = set1.a[st] = set1.b[st] = set2.a[st] = set2.b[st] = (v4i_a4){0, 0, 0, 0};
+    set0.w[st] = set1.w[st] = 1.0;
+    set0.n[st] = set1.n[st] = 0;
+    set0.a[st] = set0.b[st] = set1.a[st] = set1.b[st] = (v4i_a4){0, 0, 0, 0};
   }
   set0.s = set0.len = set0.choff = set0.nchunks = 0;
   set1.s = set1.len = set1.choff = set1.nchunks = 0;
-  set2.s = set2.len = set2.choff = set2.nchunks = 0;
 
-  // ---- prologue (dependent loads, once per user): ids of units 0..3, offsets of units 0..2, entries of units 0 and 1
+  // ---- prologue (dependent loads, once per user): ids of units 0..2, offsets of units 0..1, entries of unit 0
   {
     load_ids(0, 0);
     const int i0 = valid3 ? raw_it : -1;
     const double w0 = (WGT && valid3) ? raw_wt : 1.0;
-    int ta = 0, ga = 0;
-    next_unit(ta, ga);  // unit 1
-    load_ids(ta, ga);
+    t1c = 0, g1c = 0;
+    next_unit(t1c, g1c);  // unit 1
+    load_ids(t1c, g1c);
     const int i1 = valid3 ? raw_it : -1;
     const double w1 = (WGT && valid3) ? raw_wt : 1.0;
-    int tb = ta, gb = ga;
-    next_unit(tb, gb);  // unit 2
-    load_ids(tb, gb);
-    const int i2 = valid3 ? raw_it : -1;
-    const double w2 = (WGT && valid3) ? raw_wt : 1.0;
-    int tc = tb, gc = gb;
-    next_unit(tc, gc);  // unit 3
+    t2c = t1c, g2c = g1c;
+    next_unit(t2c, g2c);  // unit 2
     load_offs(i0, 0);
     const int oa0 = (i0 >= 0) ? raw_oa : 0, ob0 = (i0 >= 0) ? raw_ob : 0;
-    load_offs(i1, ta);
-    const int oa1 = (i1 >= 0) ? raw_oa : 0, ob1 = (i1 >= 0) ? raw_ob : 0;
     fetch(set0, i0, oa0, ob0, w0);  // entries of unit 0
-    fetch(set1, i1, oa1, ob1, w1);  // entries of unit 1
-    load_offs(i2, tb);              // offsets of unit 2: consumed at the top of iteration 0
-    load_ids(tc, gc);               // ids of unit 3: likewise
-    // the loop's top rotates (it0, it1, it2, it3) <- (it1, it2, it3, raw): unit 0 sits in it1, unit 1 in it2, unit 2 in it3
+    load_offs(i1, t1c);             // offsets of unit 1: consumed at the top of iteration 0
+    load_ids(t2c, g2c);             // ids of unit 2: likewise
+    // the loop's top rotates: (it0, it1, it2) <- (it1, it2, raw); so unit 0 sits in it1, unit 1 in it2
     it1 = i0;
     wt1 = w0;
     it2 = i1;
     wt2 = w1;
-    it3 = i2;
-    wt3 = w2;
+    // counters are rotated the same way: stage 1 holds unit 0, stage 2 unit 1, stage 3 unit 2
+    t3c = t2c, g3c = g2c;
+    t2c = t1c, g2c = g1c;
     t1c = 0, g1c = 0;
-    t2c = ta, g2c = ga;
-    t3c = tb, g3c = gb;
-    t4c = tc, g4c = gc;
   }
   bool touched = false;
 
-  // one iteration: C = entries of unit k (requested TWO iterations ago), N = set to fill for unit k+2
+  // one iteration: C = entries of unit k (requested last iteration), N = set to fill for unit k+1
   auto unit = [&](rp_pw_uset<ST>& C, rp_pw_uset<ST>& N) __attribute__((always_inline)) {
-    // ---- top: rotate the stages; the ids and offsets the previous iteration requested are used from here on.  The empty asm
-    // makes those loads "used" HERE, and they were issued BEFORE that iteration's entry loads: the compiler's wait for them
-    // (loads return in order) leaves the entries of unit k+1 in flight, and the entries of unit k - the oldest loads, needed
-    // by the adds below - have had two iterations to arrive (one was not enough: the model streams from L2 / MALL at 1-1.5 us
-    // and an iteration is shorter; the wait at this spot was 46 % of the kernel in the stamps build)
+    // ---- top: rotate the stages; what the previous iteration requested is used from here on.  The empty asm makes the
+    // youngest of those loads (ids, offsets) "used" HERE: the compiler's wait for them then sits in front of this
+    // iteration's requests - placed at their first arithmetic use it would come after the entry loads below and wait for
+    // those too (loads return in order)
     asm volatile("" : "+v"(raw_it), "+v"(raw_oa), "+v"(raw_ob));
     if (WGT) asm volatile("" : "+v"(raw_wt));
     it0 = it1;
@@ -714,18 +696,15 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
     it1 = it2;
     wt1 = wt2;
     t1c = t2c, g1c = g2c;
-    it2 = it3;
-    wt2 = wt3;
+    const int oa1 = (it1 >= 0) ? raw_oa : 0, ob1 = (it1 >= 0) ? raw_ob : 0;
+    it2 = valid3 ? raw_it : -1;
+    if (WGT) wt2 = valid3 ? raw_wt : 1.0;
     t2c = t3c, g2c = g3c;
-    const int oa2 = (it2 >= 0) ? raw_oa : 0, ob2 = (it2 >= 0) ? raw_ob : 0;
-    it3 = valid3 ? raw_it : -1;
-    if (WGT) wt3 = valid3 ? raw_wt : 1.0;
-    t3c = t4c, g3c = g4c;
-    next_unit(t4c, g4c);
-    // ---- requests for the units ahead: the small loads first, so that the next iteration can wait for them alone
-    load_offs(it3, t3c);           // offsets of unit k+3
-    load_ids(t4c, g4c);            // ids of unit k+4
-    fetch(N, it2, oa2, ob2, wt2);  // entries of unit k+2
+    next_unit(t3c, g3c);
+    // ---- requests for the units ahead
+    fetch(N, it1, oa1, ob1, wt1);  // entries of unit k+1
+    load_offs(it2, t2c);           // offsets of unit k+2
+    load_ids(t3c, g3c);            // ids of unit k+3
     PW_STAMP(4);
     // ---- unit k: adds
     const int t0 = t0c * WT;
@@ -932,10 +911,9 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
     }
     PW_STAMP(2);
   };
-  for (int k = 0; k < NU; k += 3) {
-    unit(set0, set2);
+  for (int k = 0; k < NU; k += 2) {
+    unit(set0, set1);
     if (k + 1 < NU) unit(set1, set0);
-    if (k + 2 < NU) unit(set2, set1);
   }
 }
 
