@@ -410,7 +410,7 @@ typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 // Diagnostic builds only (make ablate; tools/k8_ablate.py): RP_PW_ABL removes parts of the wave kernel to attribute its time -
 // 1: no sum atomics, 2: no walk, 4: no dirty-map atomics, 8: no entry loads, 16: no owner search in the chunk assignment,
-// 32: no adds at all.  Results are wrong by construction.
+// 32: no adds at all, 64: no final cut and no column ranking of the output row.  Results are wrong by construction.
 #ifndef RP_PW_ABL
 #define RP_PW_ABL 0
 #endif
@@ -994,8 +994,8 @@ __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
         rp_pw_user_units<AccT, WT, WGT, (WT > PW_WT ? 3 : 2), false>(P, S, hs, he);
       // ---- final: best Kp by (score desc, column asc), then column order for the output row
       RP_WAVE_FENCE();
-      if (S.pool.n > Kp) rp_wpool_cut<AccT, 0>(S.pool, Kp, lane);
-      const int n_out = S.pool.n;
+      if (S.pool.n > Kp && !(RP_PW_ABL & 64)) rp_wpool_cut<AccT, 0>(S.pool, Kp, lane);
+      const int n_out = (RP_PW_ABL & 64) ? min(S.pool.n, Kp) : S.pool.n;
       RP_LDS AccT* pk = S.pool.key;
       RP_LDS uint32_t* pp = S.pool.pay;
       if (lane < 4) pp[n_out + lane] = 0xffffffffu;  // pads the last group of four (n_out + 4 <= cap)
@@ -1003,7 +1003,8 @@ __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
       for (int e = lane; e < n_out; e += 64) {
         const uint32_t col = pp[e];
         int rank = 0;
-        for (int o = 0; o < n_out; o += 4) {
+        if (RP_PW_ABL & 64) rank = e;
+        for (int o = 0; o < ((RP_PW_ABL & 64) ? 0 : n_out); o += 4) {
           const v4u q = *reinterpret_cast<RP_LDS v4u*>(&pp[o]);
           rank += (q.x < col ? 1 : 0) + (q.y < col ? 1 : 0) + (q.z < col ? 1 : 0) + (q.w < col ? 1 : 0);
         }
