@@ -71,6 +71,12 @@ struct rp_fit_params {
 #define RP_STAMP(ph) do { } while (0)
 #endif
 
+// Diagnostic builds only (make fitablate; tools/fit_ablate.py): RP_FIT_ABL removes parts of the fit kernels to attribute their time -
+// 1: no counter atomics, 2: no selection / emission (the tile is only cleared), 4: no index loads of the user rows.  Results are wrong.
+#ifndef RP_FIT_ABL
+#define RP_FIT_ABL 0
+#endif
+
 // Selection key of entry (i, j), monotone in the similarity for a fixed row i:
 //   cosine (pw = 2):                 fl(c*c) * fl(1/c_j)        (nearest_neighbour.py:69-84)
 //   conditional probability (pw = 1): fl(c) * c_j^-alpha         (nearest_neighbour.py:22-66; alpha = pop_discount)
@@ -278,8 +284,12 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
           S.n = n;
           S.sh = (n > 0) ? pos - q : 0;
           const int32_t* src = P.x_idx + q;
-          S.a = *reinterpret_cast<const v4i_a4*>(src);
-          S.b = *reinterpret_cast<const v4i_a4*>(src + 4);
+          if (RP_FIT_ABL & 4) {
+            S.a = S.b = (v4i_a4){t0 + (q & 1023), t0 + ((q >> 3) & 1023) + 1024, t0 + (lane << 4), t0 + (lane << 5) + 7};
+          } else {
+            S.a = *reinterpret_cast<const v4i_a4*>(src);
+            S.b = *reinterpret_cast<const v4i_a4*>(src + 4);
+          }
         };
         auto unpack = [&](const step_t& S, int (&jv)[CH]) {
           jv[0] = S.a.x; jv[1] = S.a.y; jv[2] = S.a.z; jv[3] = S.a.w;
@@ -310,7 +320,11 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
 #pragma unroll
             for (int e = 0; e < CH; ++e) {
               const int j = jv[e] - t0;
-              old[e] = (jv[e] >= 0) ? atomicAdd(&acc[j >> 2], 1u << (8 * (j & 3))) : 0xffffffffu;
+              if (RP_FIT_ABL & 1) {
+                old[e] = 0xffffffffu;
+                asm volatile("" ::"v"(j));
+              } else
+                old[e] = (jv[e] >= 0) ? atomicAdd(&acc[j >> 2], 1u << (8 * (j & 3))) : 0xffffffffu;
             }
 #pragma unroll
             for (int e = 0; e < CH; ++e) {
@@ -345,7 +359,10 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
             for (int e = 0; e < CH; ++e)
               if (jv[e] >= 0) {
                 const int j = jv[e] - t0;
-                atomicAdd(&acc[j >> 1], 1u << (16 * (j & 1)));
+                if (RP_FIT_ABL & 1)
+                  asm volatile("" ::"v"(j));
+                else
+                  atomicAdd(&acc[j >> 1], 1u << (16 * (j & 1)));
               }
           } else {
 #pragma unroll
@@ -401,6 +418,13 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
         g[w] = (float)acc[w] + ((t0 + w == row) ? P.diag_add : 0.0f);
         acc[w] = 0u;
       }
+      continue;
+    }
+    if (RP_FIT_ABL & 2) {  // (diagnostic: clear and go on)
+      __syncthreads();
+      for (int w = tid; w < acc_words; w += NTHR) acc[w] = 0u;
+      if (BYTES && tid == 0) *(&sel.misc[RPS_USER + 16]) = 0;
+      __syncthreads();
       continue;
     }
     // ---- select
