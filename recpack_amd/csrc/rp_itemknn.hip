@@ -105,6 +105,7 @@ struct rp_dense_src {
   __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)(t0 + w); }
 };
 
+constexpr int RP_TICKET_CHUNK = 8;      // light tasks a workgroup draws per ticket atomic
 constexpr int RP_LIGHT_THREADS = 256;   // light rows: 4-wave workgroups, several per CU
 constexpr int RP_LIGHT_SEG = 1024;      // candidate-list entries per wave (4096 per task); overflow -> heavy kernel
 constexpr int RP_LIGHT_MAX_DEG = 255;   // byte counters
@@ -162,9 +163,22 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
   // Tasks come from a ticket counter (heaviest first).  The NEXT task is fetched by one lane of the last
   // wave while the current one is processed (two LDS slots), so the ticket atomic and the descriptor load
   // never sit on the critical path.
+  // (tickets are drawn RP_TICKET_CHUNK at a time: one returning atomic on ONE word per task was the light kernel's bound - a word
+  // takes a few tens of such atomics per microsecond, and 313 835 tasks at C4 spent 8 of the kernel's 10.3 ms queueing for it)
+  int tk_next = 0, tk_end = 0;  // (live in the one thread that fetches)
+  int abl_iter = 0;
   auto fetch_task = [&](int q) {
     int* d = s_task + q * 8;
-    const int ti = atomicAdd(P.ticket, 1);
+    constexpr int TCH = BYTES ? RP_TICKET_CHUNK : 1;  // (heavy tasks are long and sorted heaviest first: one at a time)
+    if (tk_next == tk_end && !(RP_FIT_ABL & 64)) {
+      tk_next = atomicAdd(P.ticket, TCH);
+      tk_end = tk_next + TCH;
+    }
+    int ti = tk_next++;
+    if (RP_FIT_ABL & 64) {  // (diagnostic: static assignment, no ticket atomics)
+      ti = (int)blockIdx.x + abl_iter * (int)gridDim.x;
+      ++abl_iter;
+    }
     if (ti < n_tasks) {
       const rp_task t = P.tasks[ti];
       d[0] = t.row;
@@ -180,6 +194,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
   };
   if (tid == NTHR - 64) fetch_task(0);
   int par = 0;
+  long long n_prod_all = 0;  // this lane's share of the products of all the workgroup's tasks
 
   while (true) {
     __syncthreads();
@@ -381,10 +396,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
         }
       }
       if (BYTES && blk < NBLK && lane >= fill) ft_list[blk * 64 + lane] = (uint16_t)RPS_EMPTY;  // rest of the last block
-      if (BYTES && P.n_products) {  // products done by the light kernel (roofline split between the two kernels)
-        n_prod = rp_wave_sum(n_prod);
-        if (lane == 0 && n_prod) atomicAdd(P.n_products, (unsigned long long)n_prod);
-      }
+      if (BYTES) n_prod_all += n_prod;  // products done by the light kernel (roofline split between the two kernels)
       __syncthreads();
       RP_STAMP(1);
       if (!BYTES && tk.mode == 1) {
@@ -497,6 +509,12 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
       if (tid == 0 && (unsigned)(row - t0) < (unsigned)n_cols) acc[BYTES ? ((row - t0) >> 2) : (row - t0)] = 0u;
     }
     RP_STAMP(4);
+  }
+  if (BYTES && P.n_products) {  // one atomic per wave and launch
+    long long v = n_prod_all;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    if (lane == 0 && v) atomicAdd(P.n_products, (unsigned long long)v);
   }
 }
 
