@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
     int kp;
     if constexpr (BYTES) {
       const int handed = *blk_cnt;  // (the barrier after the accumulate phase has passed)
-      kp = rp_select_topk<NTHR, rp_dense_src<CB>, true, SBITS>(src, n_cols, P.K, sel, SEG, lcnt, handed > NBLK, min(handed, NBLK));
+      kp = rp_select_topk<NTHR, rp_dense_src<CB>, true, SBITS, 2>(src, n_cols, P.K, sel, SEG, lcnt, handed > NBLK, min(handed, NBLK));
       if (tid == 0) *blk_cnt = 0;  // every wave has read it before the barriers inside the selection
     } else if constexpr (PAIRS) {
       kp = rp_select_tile<NTHR>(src, n_cols, P.K, tsel);

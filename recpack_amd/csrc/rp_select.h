@@ -132,7 +132,9 @@ enum {
 // its wave appended (pre_cnt) and whether the pool overflowed (pre_over).  Afterwards the list holds the candidates
 // (RPS_LCNT + w entries to visit per wave), selected ones flagged with RPS_FLAG; use rp_select_emit /
 // rp_select_emit_sorted / rp_select_foreach with the same seg_cap.
-template <int NTHR, class Src, bool PRE = false, int BITS = 11>
+// NCACHE: the (slot, key, ~column) of a lane's first 4 * NCACHE list entries stay in registers from the first radix level on - a key
+// costs a global gather (the column weight), and the levels and the classification pass would each evaluate it again.
+template <int NTHR, class Src, bool PRE = false, int BITS = 11, int NCACHE = 0>
 __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem s, int seg_cap = 0, int pre_cnt = 0,
                               bool pre_over = false, int pre_blocks = 0) {
   constexpr int BINS = 1 << BITS, SCAP = BINS / 4;  // histogram bins; largest boundary bin that is ordered exactly
@@ -209,7 +211,29 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
   int fin_shift = 0, fin_group = 0, fin_need = 0;
   uint64_t fin_pkey = 0;
   uint32_t fin_pcol = 0;
+  // the cached entries (NCACHE > 0): filled once, before the first level
+  int c_sl[NCACHE > 0 ? NCACHE : 1][4];
+  bool c_ok[NCACHE > 0 ? NCACHE : 1][4];
+  uint64_t c_k[NCACHE > 0 ? NCACHE : 1][4];
+  uint32_t c_ic[NCACHE > 0 ? NCACHE : 1][4];
+  // four list entries of this lane at e0 .. e0 + 192: evaluated
+  auto entries4 = [&](int e0, int(&sl)[4], bool(&ok)[4], uint64_t(&kk)[4], uint32_t(&ic)[4], bool want_key) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * 64 + lane;
+      sl[u] = (e < cnt) ? (int)s.list[lpos(e)] : RPS_EMPTY;
+      ok[u] = PRE ? sl[u] != RPS_EMPTY : e < cnt;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) kk[u] = (ok[u] && want_key) ? src.key(sl[u]) : 0ull;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ic[u] = ok[u] ? ~src.col(sl[u]) : 0u;
+  };
   if (kprime < n_valid) {
+    if constexpr (NCACHE > 0) {
+#pragma unroll
+      for (int it = 0; it < NCACHE; ++it) entries4(it * 256, c_sl[it], c_ok[it], c_k[it], c_ic[it], true);
+    }
     uint64_t pkey = 0;  // decided prefix
     uint32_t pcol = 0;
     int need = kprime;
@@ -229,23 +253,12 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
       __syncthreads();
       // histogram of this level's digit over the undecided group (4 candidates per lane in flight:
       // the key needs a global gather)
-      for (int e0 = 0; e0 < cnt; e0 += 256) {
-        int sl[4];
-        bool ok[4];
-        uint64_t kk[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int e = e0 + u * 64 + lane;
-          sl[u] = (e < cnt) ? (int)s.list[lpos(e)] : RPS_EMPTY;
-          ok[u] = PRE ? sl[u] != RPS_EMPTY : e < cnt;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) kk[u] = ok[u] ? src.key(sl[u]) : 0ull;
+      auto hist4 = [&](const bool(&ok)[4], const uint64_t(&kk)[4], const uint32_t(&icv)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (!ok[u]) continue;
           const uint64_t k = kk[u];
-          const uint32_t ic = ~src.col(sl[u]);
+          const uint32_t ic = icv[u];
           bool in_group;
           uint32_t d;
           if (!is_col) {
@@ -257,6 +270,19 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
           }
           if (in_group) atomicAdd(&s.hist[d], 1u);
         }
+      };
+      if constexpr (NCACHE > 0) {
+#pragma unroll
+        for (int it = 0; it < NCACHE; ++it)
+          if (it * 256 < cnt) hist4(c_ok[it], c_k[it], c_ic[it]);
+      }
+      for (int e0 = NCACHE * 256; e0 < cnt; e0 += 256) {
+        int sl[4];
+        bool ok[4];
+        uint64_t kk[4];
+        uint32_t ic[4];
+        entries4(e0, sl, ok, kk, ic, true);
+        hist4(ok, kk, ic);
       }
       RPS_STAMP(14);
       __syncthreads();
@@ -324,20 +350,7 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
   // members of the bin -> flagged (whole bin selected) or gathered with their list position for the exact step.
   int wc = 0;
   uint16_t* spos = reinterpret_cast<uint16_t*>(s.scol + SCAP);  // [SCAP] list positions of the members
-  for (int e0 = 0; e0 < cnt; e0 += 256) {
-    int sl[4];
-    bool ok[4];
-    uint64_t kk[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = e0 + u * 64 + lane;
-      sl[u] = (e < cnt) ? (int)s.list[lpos(e)] : RPS_EMPTY;
-      ok[u] = PRE ? sl[u] != RPS_EMPTY : e < cnt;
-    }
-    if (have_fin) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) kk[u] = ok[u] ? src.key(sl[u]) : 0ull;
-    }
+  auto classify4 = [&](int e0, const int(&sl)[4], const bool(&ok)[4], const uint64_t(&kk)[4], const uint32_t(&icv)[4]) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       bool sel = false;
@@ -346,7 +359,7 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
           sel = true;  // fewer candidates than K: all of them
         } else {
           const uint64_t k = kk[u];
-          const uint32_t ic = ~src.col(sl[u]);
+          const uint32_t ic = icv[u];
           bool above, member;
           if (!fin_is_col) {
             above = (k >> fin_shift) > (fin_pkey >> fin_shift);
@@ -367,6 +380,21 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
       }
       wc += __popcll(__ballot(sel));
     }
+  };
+  if constexpr (NCACHE > 0) {
+    if (have_fin) {  // (the cache was filled)
+#pragma unroll
+      for (int it = 0; it < NCACHE; ++it)
+        if (it * 256 < cnt) classify4(it * 256, c_sl[it], c_ok[it], c_k[it], c_ic[it]);
+    }
+  }
+  for (int e0 = (NCACHE > 0 && have_fin) ? NCACHE * 256 : 0; e0 < cnt; e0 += 256) {
+    int sl[4];
+    bool ok[4];
+    uint64_t kk[4];
+    uint32_t ic[4];
+    entries4(e0, sl, ok, kk, ic, have_fin);
+    classify4(e0, sl, ok, kk, ic);
   }
   RPS_STAMP(13);
   if (lane == 0) s.misc[RPS_RED + wave] = wc;
