@@ -72,7 +72,8 @@ struct rp_fit_params {
 #endif
 
 // Diagnostic builds only (make fitablate; tools/fit_ablate.py): RP_FIT_ABL removes parts of the fit kernels to attribute their time -
-// 1: no counter atomics, 2: no selection / emission (the tile is only cleared), 4: no index loads of the user rows.  Results are wrong.
+// 1: no counter atomics, 2: no selection / emission (the tile is only cleared), 4: no index loads of the user rows, 8: no emission
+// of the light rows' selection, 16: their tile cleared densely, 64: static task assignment.  Results are wrong.
 #ifndef RP_FIT_ABL
 #define RP_FIT_ABL 0
 #endif
@@ -476,7 +477,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
                                    : ((double)src.count(w) * P.inv_deg[j]) / ci;
       };
       if constexpr (BYTES)
-        rp_select_emit_sorted<NTHR>(sel, emit);
+        rp_select_emit_bitmap<NTHR>(n_cols, sel, emit);
       else if constexpr (PAIRS)
         rp_select_tile_emit<NTHR>(n_cols, tsel, emit);
       else
@@ -488,9 +489,9 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
         P.out_idx[o + pos] = t0 + w;
         P.out_cnt[o + pos] = src.count(w);
       };
-      if constexpr (BYTES)
-        rp_select_emit_sorted<NTHR>(sel, emit);
-      else if constexpr (PAIRS)
+      if constexpr (BYTES) {
+        if (!(RP_FIT_ABL & 8)) rp_select_emit_bitmap<NTHR>(n_cols, sel, emit);  // (8: diagnostic, no emission)
+      } else if constexpr (PAIRS)
         rp_select_tile_emit<NTHR>(n_cols, tsel, emit);
       else
         rp_select_emit<NTHR>(n_cols, sel, emit, SEG);
@@ -502,7 +503,9 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
     if constexpr (PAIRS) {
       for (int w = tid; w < acc_words; w += NTHR) acc[w] = 0u;
     } else {
-      if (BYTES)
+      if (BYTES && (RP_FIT_ABL & 16)) {  // (16: diagnostic, dense clear instead of the list-driven one)
+        for (int w = tid; w < acc_words; w += NTHR) acc[w] = 0u;
+      } else if (BYTES)
         rp_select_foreach_pre<NTHR>(sel, [&](int w) { acc[w >> 2] = 0u; });
       else
         rp_select_foreach<NTHR>(n_cols, sel, [&](int w) { acc[w] = 0u; }, SEG);

@@ -530,6 +530,51 @@ __device__ __forceinline__ void rp_select_emit_sorted(rp_select_smem s, Emit emi
   }
 }
 
+// PRE lists, the same in column order through a BITMAP (one bit per slot, over the dead histogram: n_slots <= 32 * bins): the
+// flagged entries set their bits, a scan over the words' popcounts gives every thread the output position of its first bit, and
+// the bits are emitted in slot (= column) order.  Three barriers and a few dozen instructions per thread where ranking K slots
+// against each other (rp_select_emit_sorted) reads the whole selection once per selected slot: 2.1 of the light kernel's 9 ms.
+template <int NTHR, class Emit>
+__device__ __forceinline__ void rp_select_emit_bitmap(int n_slots, rp_select_smem s, Emit emit) {
+  constexpr int NW = NTHR / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t* bm = s.hist;
+  const int nw = (n_slots + 31) >> 5;
+  for (int i = tid; i < nw; i += NTHR) bm[i] = 0u;
+  __syncthreads();
+  const int cnt = s.misc[RPS_LCNT + wave];
+  for (int e = lane; e < cnt; e += 64) {
+    const int v = (int)s.list[rp_list_pos<NW, true>(wave, 0, e)];
+    if (v & RPS_FLAG) {
+      const int slot = v & (RPS_FLAG - 1);
+      atomicOr(&bm[slot >> 5], 1u << (slot & 31));
+    }
+  }
+  __syncthreads();
+  const int wpt = (nw + NTHR - 1) / NTHR;  // consecutive words per thread
+  const int w0 = tid * wpt, w1 = min(nw, w0 + wpt);
+  int mine = 0;
+  for (int w = w0; w < w1; ++w) mine += __popc(bm[w]);
+  int inc = mine;  // inclusive prefix over the wave
+#pragma unroll
+  for (int dd = 1; dd < 64; dd <<= 1) {
+    const int t = __shfl_up(inc, dd);
+    if (lane >= dd) inc += t;
+  }
+  if (lane == 63) s.misc[RPS_RED + wave] = inc;
+  __syncthreads();
+  int off = inc - mine;
+  for (int w2 = 0; w2 < wave; ++w2) off += s.misc[RPS_RED + w2];
+  for (int w = w0; w < w1; ++w) {
+    uint32_t bits = bm[w];
+    while (bits) {
+      const int b = __ffs((int)bits) - 1;
+      bits &= bits - 1u;
+      emit(off++, w * 32 + b);
+    }
+  }
+}
+
 // PRE lists: visit every candidate slot (selected or not).
 template <int NTHR, class F>
 __device__ __forceinline__ void rp_select_foreach_pre(rp_select_smem s, F f) {
