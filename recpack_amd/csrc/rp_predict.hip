@@ -410,7 +410,9 @@ typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 // Diagnostic builds only (make ablate; tools/k8_ablate.py): RP_PW_ABL removes parts of the wave kernel to attribute its time -
 // 1: no sum atomics, 2: no walk, 4: no dirty-map atomics, 8: no entry loads, 16: no owner search in the chunk assignment,
-// 32: no adds at all, 64: no final cut and no column ranking of the output row.  Results are wrong by construction.
+// 32: no adds at all, 64: no final cut and no column ranking of the output row, 128: no chunk assignment (empty units), 256: no gathers of the tile offsets (uniform 8-entry slices), 512: the offsets of 64 hot rows.
+// Results are
+// wrong by construction.
 #ifndef RP_PW_ABL
 #define RP_PW_ABL 0
 #endif
@@ -587,9 +589,14 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
     valid3 = (h < he) && (t < NT);
   };
   auto load_offs = [&](int it, int t) __attribute__((always_inline)) {
-    const uint16_t* to = P.toff + (long long)max(it, 0) * (NT + 1) + min(t, NT - 1);
-    raw_oa = (int)to[0];
-    raw_ob = (int)to[1];
+    const uint16_t* to = P.toff + (long long)((RP_PW_ABL & 512) ? (max(it, 0) & 63) : max(it, 0)) * (NT + 1) + min(t, NT - 1);  // (512: diagnostic, 64 hot rows)
+    if (RP_PW_ABL & 256) {  // (diagnostic: no offset gathers - every slice is entries 8 t .. 8 t + 8 of its list)
+      raw_oa = 8 * min(t, NT - 1);
+      raw_ob = raw_oa + 8;
+    } else {
+      raw_oa = (int)to[0];
+      raw_ob = (int)to[1];
+    }
   };
   // Entries of one unit.  Chunk c of the batch goes to lane c % 64 of step c / 64.  Owner of chunk c = the largest lane whose
   // first chunk is <= c: every owner writes its lane id at its first chunk's slot of a 64 ST-word LDS scratch (the cut's
@@ -598,6 +605,11 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
   // round trips per unit whatever ST is.  Steps beyond the unit's chunks issue nothing.
   auto fetch = [&](rp_pw_uset<ST>& D, int it, int oa, int ob, double wt) __attribute__((always_inline)) {
     RP_LDS uint32_t* sc = S.pool.hist;
+    if (RP_PW_ABL & 128) {  // (diagnostic: no chunk assignment at all - the unit stays empty)
+      D.nchunks = 0;
+      asm volatile("" ::"v"(it), "v"(oa), "v"(ob));
+      return;
+    }
     D.s = (it >= 0) ? it * K + oa : 0;
     D.len = (it >= 0) ? ob - oa : 0;
     const int nch = (D.len + PW_CH - 1) / PW_CH;
