@@ -14,6 +14,9 @@ U, I, dens = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])
 Kp = int(sys.argv[4]) if len(sys.argv) > 4 else 100
 dev = torch.device("cuda", 0)
 ip, ix = powerlaw_csr(U, I, dens, seed=20260003, device=dev)
+import recpack_amd._lib as _l
+if len(sys.argv) > 5:
+    _l.LIB_PATH = os.path.abspath(sys.argv[5])
 ctx = _lib.Context(0)
 dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
 ld = (I + 127) // 128 * 128
