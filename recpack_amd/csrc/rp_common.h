@@ -104,6 +104,8 @@ struct rphip_csr {
   int n_tiles = 1;
   int tile_w = 0;
   int32_t* tile_ptr = nullptr;
+  uint16_t* x_rel = nullptr;       // [nnz rounded up to 8, + 8] column of every entry RELATIVE to its tile (x_idx - tile * tile_w < 65536): what the
+                                   // fit kernels' accumulate loops read - half the bytes and half the load instructions of x_idx
   bool sorted_rows = false;
   int max_user_deg = 0;            // longest history (bounds |score| for predict's fixed-point scale)
   int64_t xt_row_begin = 0, xt_row_end = -1;  // item rows of X^T that were filled (-1: all); fit is limited to them

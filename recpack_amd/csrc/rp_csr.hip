@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(1024) k_rank_hist_ranges(const int32_t* __rest
 __global__ void k_scatter(const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ x_idx, int n_users,
                           const int32_t* __restrict__ xt_ptr, const int32_t* __restrict__ rank, int32_t* __restrict__ xt_idx,
                           unsigned long long* __restrict__ p_sum, int n_items, int n_tiles, int tile_w, int32_t* __restrict__ tile_ptr,
-                          int32_t* __restrict__ err, int xt_lo, int xt_hi) {
+                          int32_t* __restrict__ err, int xt_lo, int xt_hi, uint16_t* __restrict__ x_rel) {
   const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, sub = threadIdx.x & 7;
   const int ng = (gridDim.x * blockDim.x) >> 3;
   const float inv_w = 1.0f / (float)tile_w;
@@ -84,8 +84,11 @@ __global__ void k_scatter(const int32_t* __restrict__ x_ptr, const int32_t* __re
         err[1] = 1;
         if (tp) err[0] = 3;
       }
-      if (tp && (unsigned)j < (unsigned)n_items) {
-        const int tj = tile_of(j);
+      const bool in_range = (unsigned)j < (unsigned)n_items;
+      const int tj0 = (in_range && n_tiles > 1) ? tile_of(j) : 0;
+      x_rel[k] = (uint16_t)(in_range ? j - tj0 * tile_w : 0);  // (the column inside its tile)
+      if (tp && in_range) {
+        const int tj = tj0;
         const int tprev = (k > s && (unsigned)prev < (unsigned)n_items) ? tile_of(prev) : -1;
         for (int t = tprev + 1; t <= tj; ++t) tp[t] = k;
         if (k == e - 1)
@@ -178,11 +181,16 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
   }
   RP_TRY(rp_exclusive_scan_i32(ctx, m->deg, m->xt_ptr, I));
   if (m->n_tiles > 1) RP_TRY(rp_dev_alloc(ctx, (size_t)std::max<int64_t>(U, 1) * (m->n_tiles + 1) * sizeof(int32_t), (void**)&m->tile_ptr));
+  {  // tile-relative columns, padded so that a chunk of eight read at any entry stays inside
+    const size_t n_rel = (((size_t)nnz + 7) & ~(size_t)7) + 8;
+    RP_TRY(rp_dev_alloc(ctx, n_rel * sizeof(uint16_t), (void**)&m->x_rel));
+    RP_HIP(hipMemsetAsync(m->x_rel, 0, n_rel * sizeof(uint16_t), st));
+  }
   if (U > 0) {  // (rows without entries still need their tile pointers)
     const int grid_s = (int)std::min<int64_t>((int64_t)ctx->n_cu * 16, std::max<int64_t>(1, rp_cdiv(U * 8, bt)));
     hipLaunchKernelGGL(k_scatter, dim3(grid_s), dim3(bt), 0, st, m->x_ptr, m->x_idx, (int)U, m->xt_ptr, rank, m->xt_idx, p_sum,
                        (int)I, m->n_tiles, m->tile_w, m->tile_ptr, err, (int)std::max<int64_t>(0, m->xt_row_begin),
-                       (int)(m->xt_row_end < 0 ? I : std::min<int64_t>(I, m->xt_row_end)));
+                       (int)(m->xt_row_end < 0 ? I : std::min<int64_t>(I, m->xt_row_end)), m->x_rel);
   }
   if (!m->deg_partial)  // (a shard's degrees are completed by rphip_csr_finish_degrees after the all-reduce)
     hipLaunchKernelGGL(k_inv_deg, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, rp_cdiv(I, bt)))), dim3(bt), 0, st,
@@ -366,6 +374,7 @@ extern "C" int rphip_csr_destroy(rphip_csr* m) {
   rp_dev_free(m->ctx, m->deg);
   rp_dev_free(m->ctx, m->inv_deg);
   rp_dev_free(m->ctx, m->tile_ptr);
+  rp_dev_free(m->ctx, m->x_rel);
   rp_dev_free(m->ctx, m->row_cost);
   rp_dev_free(m->ctx, m->x_val);
   delete m;

@@ -33,6 +33,7 @@ struct rp_task {
 struct rp_fit_params {
   const int32_t* x_ptr;
   const int32_t* x_idx;
+  const uint16_t* x_rel;   // x_idx relative to the entry's column tile (rphip_csr::x_rel): what the accumulate loop reads
   const int32_t* xt_ptr;
   const int32_t* xt_idx;
   const int32_t* deg;
@@ -257,11 +258,15 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
       int s_cur, e_cur;
       load_seg(load_user(base), s_cur, e_cur);
       for (; base < tk.p_end; base += stride) {
-        const int s = s_cur, len = e_cur - s_cur;
+        // chunks of eight 16-bit tile-relative columns = ONE 16-byte load, on the dword grid of x_rel: a slice that starts at an odd
+        // entry begins one entry into its first chunk (`lead`, masked)
+        const int lead = (e_cur > s_cur) ? (s_cur & 1) : 0;
+        const int s = s_cur - lead, len = e_cur - s_cur + lead;
+        n_prod += e_cur - s_cur;
         load_seg(u_next, s_cur, e_cur);           // batch n+1
         u_next = load_user(base + 2 * stride);    // batch n+2
-        n_prod += len;
         const int nch = (len + CH - 1) / CH;
+        const int len_lead = len | (lead << 24);  // (one broadcast for both)
         const int inc = rp_wave_incl_scan(nch, lane);  // DPP: no LDS round trips
         const int choff = inc - nch;       // first chunk of this lane's user
         const int n_chunks = __builtin_amdgcn_readlane(inc, 63);
@@ -270,18 +275,18 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
         // writes its lane id at that chunk's slot of a 64-word LDS scratch, a running maximum (DPP) fills the gaps;
         // slot 0 starts from the owner of the previous step's last chunk.  Steps are fetched in increasing order.
         int carry = 0;
-        // One chunk step = (raw loaded entries, number of valid ones, shift).  The two 16-byte loads of a step are ALWAYS
-        // issued (a step past the batch's chunks, or a lane without a chunk, reads the head of the array): with the loads
-        // under branches the compiler cannot count the loads in flight and puts s_waitcnt vmcnt(0) in front of every use,
-        // which makes the step being applied wait for the step just requested.  The raw registers are only touched when the
-        // step is applied (masking included), so the next step's loads stay in flight meanwhile.
+        // One chunk step = (raw loaded entries, the valid range [lo, n) among them).  The 16-byte load of a step is ALWAYS issued (a
+        // step past the batch's chunks, or a lane without a chunk, reads the head of the array): with the loads under branches the
+        // compiler cannot count the loads in flight and puts s_waitcnt vmcnt(0) in front of every use, which makes the step being
+        // applied wait for the step just requested.  The raw registers are only touched when the step is applied (masking
+        // included), so the next step's loads stay in flight meanwhile.  x_rel is padded: no chunk reads past its end.
         typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));
         struct step_t {
-          v4i_a4 a, b;
-          int n, sh;
+          v4i_a4 a;
+          int n, lo;
         };
         auto fetch = [&](int c0, step_t& S) {
-          int n = 0, pos = 0;
+          int n = 0, pos = 0, lo_e = 0;
           if (c0 < n_chunks) {  // (uniform; no loads inside)
             const int c = c0 + lane;
             own_sc[lane] = (lane == 0) ? (uint32_t)carry : 0u;
@@ -290,40 +295,29 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
             RP_WAVE_FENCE();
             const int lo = rp_wave_incl_max((int)own_sc[lane]);
             carry = __builtin_amdgcn_readlane(lo, 63);
-            const int us = __shfl(s, lo), ul = __shfl(len, lo), co = __shfl(choff, lo);
+            const int us = __shfl(s, lo), ull = __shfl(len_lead, lo), co = __shfl(choff, lo);
+            const int ul = ull & 0xffffff;
             const int k0 = (c - co) * CH;
             n = (c < n_chunks) ? min(CH, ul - k0) : 0;
+            lo_e = (k0 == 0) ? (ull >> 24) : 0;
             pos = us + k0;
           }
-          // the last chunk of the matrix may not have CH entries behind it: read the CH entries that END at nnz and shift
-          const int q = (n > 0) ? min(pos, P.nnz - CH) : 0;  // (nnz >= CH: rp_csr_prepare pads smaller matrices)
           S.n = n;
-          S.sh = (n > 0) ? pos - q : 0;
-          const int32_t* src = P.x_idx + q;
+          S.lo = lo_e;
+          const uint16_t* src = P.x_rel + ((n > 0) ? pos : 0);  // (pos is even: a dword-aligned address)
           if (RP_FIT_ABL & 4) {
-            S.a = S.b = (v4i_a4){t0 + (q & 1023), t0 + ((q >> 3) & 1023) + 1024, t0 + (lane << 4), t0 + (lane << 5) + 7};
+            S.a = (v4i_a4){(pos & 1023) | (((pos >> 3) & 1023) + 1024) << 16, (lane << 4) | ((lane << 5) + 7) << 16, 3 | 5 << 16, 9 | 11 << 16};
           } else {
             S.a = *reinterpret_cast<const v4i_a4*>(src);
-            S.b = *reinterpret_cast<const v4i_a4*>(src + 4);
           }
         };
-        auto unpack = [&](const step_t& S, int (&jv)[CH]) {
-          jv[0] = S.a.x; jv[1] = S.a.y; jv[2] = S.a.z; jv[3] = S.a.w;
-          jv[4] = S.b.x; jv[5] = S.b.y; jv[6] = S.b.z; jv[7] = S.b.w;
-          if (__any(S.sh != 0)) {  // (only the wave that holds the matrix's last entries)
-            int t[CH];
+        auto unpack = [&](const step_t& S, int (&jv)[CH]) {  // columns inside the tile; -1 = no entry
+          const int w[4] = {S.a.x, S.a.y, S.a.z, S.a.w};
 #pragma unroll
-            for (int e = 0; e < CH; ++e) {
-              int v = -1;
-#pragma unroll
-              for (int f = 0; f < CH; ++f) v = (e + S.sh == f) ? jv[f] : v;
-              t[e] = v;
-            }
-#pragma unroll
-            for (int e = 0; e < CH; ++e) jv[e] = t[e];
+          for (int e = 0; e < CH; ++e) {
+            const int v = (e & 1) ? (int)((uint32_t)w[e >> 1] >> 16) : (w[e >> 1] & 0xffff);
+            jv[e] = (e >= S.lo && e < S.n) ? v : -1;
           }
-#pragma unroll
-          for (int e = 0; e < CH; ++e) jv[e] = (e < S.n) ? jv[e] : -1;
         };
         auto apply = [&](const step_t& S) {
           int jv[CH];
@@ -335,7 +329,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
             uint32_t old[CH];
 #pragma unroll
             for (int e = 0; e < CH; ++e) {
-              const int j = jv[e] - t0;
+              const int j = jv[e];
               if (RP_FIT_ABL & 1) {
                 old[e] = 0xffffffffu;
                 asm volatile("" ::"v"(j));
@@ -348,7 +342,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
             uint32_t fmask = 0;
 #pragma unroll
             for (int e = 0; e < CH; ++e) {
-              const int j = jv[e] - t0;
+              const int j = jv[e];
               const bool first = jv[e] >= 0 && ((old[e] >> (8 * (j & 3))) & 255u) == 0u && j != diag;
               fmask |= first ? (1u << e) : 0u;
             }
@@ -368,7 +362,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
               for (int e = 0; e < CH; ++e) {
                 if (fmask & (1u << e)) {
                   const int bk = (g < 64) ? blk : nb0 + ((g - 64) >> 6);
-                  if (bk < NBLK) ft_list[bk * 64 + (g & 63)] = (uint16_t)(jv[e] - t0);
+                  if (bk < NBLK) ft_list[bk * 64 + (g & 63)] = (uint16_t)jv[e];
                   ++g;
                 }
               }
@@ -384,7 +378,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
 #pragma unroll
             for (int e = 0; e < CH; ++e)
               if (jv[e] >= 0) {
-                const int j = jv[e] - t0;
+                const int j = jv[e];
                 if (RP_FIT_ABL & 1)
                   asm volatile("" ::"v"(j));
                 else
@@ -393,7 +387,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
           } else {
 #pragma unroll
             for (int e = 0; e < CH; ++e)
-              if (jv[e] >= 0) atomicAdd(&acc[jv[e] - t0], 1u);
+              if (jv[e] >= 0) atomicAdd(&acc[jv[e]], 1u);
           }
         };
         // the loads of step c0 + 64 are in flight while step c0 is applied (two register sets, used alternately)
@@ -1000,6 +994,7 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   rp_fit_params P;
   P.x_ptr = Xc->x_ptr;
   P.x_idx = Xc->x_idx;
+  P.x_rel = Xc->x_rel;
   P.xt_ptr = X->xt_ptr;
   P.xt_idx = X->xt_idx;
   P.deg = X->deg;
