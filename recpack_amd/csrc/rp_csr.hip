@@ -182,7 +182,7 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
   RP_TRY(rp_exclusive_scan_i32(ctx, m->deg, m->xt_ptr, I));
   if (m->n_tiles > 1) RP_TRY(rp_dev_alloc(ctx, (size_t)std::max<int64_t>(U, 1) * (m->n_tiles + 1) * sizeof(int32_t), (void**)&m->tile_ptr));
   {  // tile-relative columns, padded so that a chunk of eight read at any entry stays inside
-    const size_t n_rel = (((size_t)nnz + 7) & ~(size_t)7) + 8;
+    const size_t n_rel = (((size_t)nnz + 15) & ~(size_t)15) + 16;
     RP_TRY(rp_dev_alloc(ctx, n_rel * sizeof(uint16_t), (void**)&m->x_rel));
     RP_HIP(hipMemsetAsync(m->x_rel, 0, n_rel * sizeof(uint16_t), st));
   }

@@ -107,6 +107,9 @@ struct rp_dense_src {
   __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)(t0 + w); }
 };
 
+#ifndef RP_FIT_CH
+#define RP_FIT_CH 8  // entries per chunk of the accumulate loop (8 or 16: one or two 16-byte loads of x_rel)
+#endif
 constexpr int RP_TICKET_CHUNK = 8;      // light tasks a workgroup draws per ticket atomic
 constexpr int RP_LIGHT_THREADS = 256;   // light rows: 4-wave workgroups, several per CU
 constexpr int RP_LIGHT_SEG = 1024;      // candidate-list entries per wave (4096 per task); overflow -> heavy kernel
@@ -226,7 +229,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
       // A wave takes 64 users (one per lane: row pointer pair), cuts their index segments into chunks of
       // CH entries, and hands chunk c to lane c % 64: every lane then issues CH independent index loads
       // before the first LDS atomic, instead of one dependent load per user per round.
-      constexpr int CH = 8;
+      constexpr int CH = RP_FIT_CH;
       RP_LDS uint32_t* own_sc = (RP_LDS uint32_t*)sel.hist + wave * 64;  // the histogram is idle here
       RP_LDS uint16_t* ft_list = (RP_LDS uint16_t*)sel.list;  // light rows: first-touch candidates
       const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -282,7 +285,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
         // included), so the next step's loads stay in flight meanwhile.  x_rel is padded: no chunk reads past its end.
         typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));
         struct step_t {
-          v4i_a4 a;
+          v4i_a4 a[CH / 8];
           int n, lo;
         };
         auto fetch = [&](int c0, step_t& S) {
@@ -305,14 +308,23 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
           S.n = n;
           S.lo = lo_e;
           const uint16_t* src = P.x_rel + ((n > 0) ? pos : 0);  // (pos is even: a dword-aligned address)
-          if (RP_FIT_ABL & 4) {
-            S.a = (v4i_a4){(pos & 1023) | (((pos >> 3) & 1023) + 1024) << 16, (lane << 4) | ((lane << 5) + 7) << 16, 3 | 5 << 16, 9 | 11 << 16};
-          } else {
-            S.a = *reinterpret_cast<const v4i_a4*>(src);
+#pragma unroll
+          for (int h = 0; h < CH / 8; ++h) {
+            if (RP_FIT_ABL & 4)
+              S.a[h] = (v4i_a4){(pos & 1023) | (((pos >> 3) & 1023) + 1024) << 16, (lane << 4) | ((lane << 5) + 7) << 16, 3 | 5 << 16, 9 | 11 << 16};
+            else
+              S.a[h] = *reinterpret_cast<const v4i_a4*>(src + 8 * h);
           }
         };
         auto unpack = [&](const step_t& S, int (&jv)[CH]) {  // columns inside the tile; -1 = no entry
-          const int w[4] = {S.a.x, S.a.y, S.a.z, S.a.w};
+          int w[CH / 2];
+#pragma unroll
+          for (int h = 0; h < CH / 8; ++h) {
+            w[4 * h] = S.a[h].x;
+            w[4 * h + 1] = S.a[h].y;
+            w[4 * h + 2] = S.a[h].z;
+            w[4 * h + 3] = S.a[h].w;
+          }
 #pragma unroll
           for (int e = 0; e < CH; ++e) {
             const int v = (e & 1) ? (int)((uint32_t)w[e >> 1] >> 16) : (w[e >> 1] & 0xffff);
