@@ -27,6 +27,17 @@ def test_library_exports_every_declared_symbol():
     assert lib.rphip_version() == 100
 
 
+def test_context_options_documented():
+    """Every name rphip_ctx_set_option accepts is described in the header, and nothing else is."""
+    api = open(os.path.join(ROOT, "recpack_amd", "csrc", "rp_api.hip")).read()
+    body = api[api.index("extern \"C\" int rphip_ctx_set_option"):]
+    body = body[: body.index("\n}\n")]
+    accepted = set(re.findall(r'strcmp\(name, "([a-z0-9_]+)"\)', body))
+    header = open(os.path.join(ROOT, "include", "recpack_hip.h")).read()
+    documented = set(re.findall(r'^ \*   "([a-z0-9_]+)"', header, flags=re.M))
+    assert accepted and accepted == documented, accepted ^ documented
+
+
 def test_no_cpu_fallback_without_gpu():
     """Without a GPU the product path must fail loudly, not compute on the host."""
     import torch
