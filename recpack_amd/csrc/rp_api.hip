@@ -49,6 +49,8 @@ extern "C" int rphip_ctx_create(int device, void* stream, rphip_ctx** out) {
   c->device = device;
   c->n_cu = prop.multiProcessorCount;
   c->hbm_bytes = prop.totalGlobalMem;
+  // freed blocks the context keeps for the next fit: at most a quarter of the device (torch's allocator cannot see them)
+  c->cache_limit = std::min(c->cache_limit, (size_t)prop.totalGlobalMem / 4);
   strncpy(c->arch, prop.gcnArchName, sizeof(c->arch) - 1);
   if (stream) {
     c->stream = (hipStream_t)stream;
@@ -116,7 +118,18 @@ int rp_scratch(rphip_ctx* ctx, int slot, size_t bytes, void** out) {
       b.cap = 0;
     }
     size_t cap = (bytes + (size_t)4095) & ~(size_t)4095;
-    RP_HIP(hipMalloc(&b.p, cap));
+    hipError_t e = hipMalloc(&b.p, cap);
+    if (e != hipSuccess && !ctx->free_blocks.empty()) {  // the cached blocks of destroyed models / matrices are ours to give back
+      (void)hipGetLastError();
+      RP_HIP(hipStreamSynchronize(ctx->stream));
+      rp_dev_trim(ctx);
+      e = hipMalloc(&b.p, cap);
+    }
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      b.p = nullptr;
+      RP_FAIL(RPHIP_ENOMEM, "hipMalloc of %zu bytes of scratch failed: %s", cap, hipGetErrorString(e));
+    }
     b.cap = cap;
   }
   *out = b.p;

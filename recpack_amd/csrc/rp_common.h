@@ -36,6 +36,14 @@ void rp_set_error(const char* fmt, ...);
     if (_r != RPHIP_OK) return _r; \
   } while (0)
 
+// every entry point that reads deg / inv_deg of a matrix: a shard's degrees are partial until the caller's all-reduce
+#define RP_NEED_DEGREES(X)                                                                                              \
+  do {                                                                                                                  \
+    if ((X)->deg_partial)                                                                                               \
+      RP_FAIL(RPHIP_ESTATE, "the shard's degrees are not complete: all-reduce rphip_csr_degrees_device over the shards, " \
+                            "then rphip_csr_finish_degrees");                                                           \
+  } while (0)
+
 // ---- geometry ------------------------------------------------------------------------------------
 constexpr int RP_WAVE = 64;
 constexpr int RP_FIT_THREADS = 1024;      // 16 waves, one workgroup per CU (LDS-bound)
@@ -71,7 +79,7 @@ struct rphip_ctx {
   std::vector<block_t> free_blocks;
   std::unordered_map<void*, size_t> live_blocks;
   size_t cached_bytes = 0;
-  size_t cache_limit = (size_t)48 << 30;
+  size_t cache_limit = (size_t)48 << 30;  // lowered to a quarter of the device's memory by rphip_ctx_create
   // predict options (rphip_ctx_set_option)
   int predict_exact64 = 0;   // 1: the wave predict kernel sums in 64 bits (exact) instead of the per-user-scaled 32 bits
   int pw_wt32 = 4096;        // tile width of the 32-bit sums: 2048 or 4096 (tuning)

@@ -361,6 +361,9 @@ extern "C" int rphip_csr_finish_degrees(rphip_ctx* ctx, rphip_csr* m) {
 extern "C" int rphip_csr_destroy(rphip_csr* m) {
   if (!m) return RPHIP_OK;
   if (m->ctx) hipSetDevice(m->ctx->device);
+  // x_ptr / x_idx of a *_from_device matrix belong to the caller, who may release them the moment this returns: asynchronous
+  // launches (rphip_predict_topk_dev ...) may still be reading them on the context's stream
+  if (m->ctx && !m->owns_x) hipStreamSynchronize(m->ctx->stream);
   if (m->x_idx_padded) {
     rp_dev_free(m->ctx, (void*)m->x_idx);
     m->x_idx = nullptr;

@@ -1561,7 +1561,7 @@ extern "C" int rphip_ease_gram_rows(rphip_ctx* ctx, const rphip_csr* X, int64_t 
     RP_FAIL(RPHIP_EINVAL, "rows [%lld,%lld) of a %lld-column matrix with ld %lld", (long long)row_begin, (long long)row_end,
             (long long)n_cols, (long long)ld);
   if (!(l2 > 0.0)) RP_FAIL(RPHIP_EINVAL, "l2 must be > 0 (got %g)", l2);
-  if (X->deg_partial) RP_FAIL(RPHIP_ESTATE, "the shard's degrees are not complete (rphip_csr_finish_degrees)");
+  RP_NEED_DEGREES(X);
   if (X->xt_row_end >= 0 && (row_begin < X->xt_row_begin || std::min<int64_t>(row_end, X->n_items) > X->xt_row_end))
     RP_FAIL(RPHIP_ESTATE, "the matrix was built for item rows [%lld,%lld) only", (long long)X->xt_row_begin, (long long)X->xt_row_end);
   RP_TRY(rp_set_device(ctx));
@@ -1721,6 +1721,7 @@ extern "C" int rphip_ease_scale_cols(rphip_ctx* ctx, const rphip_csr* X, float* 
   if (!ctx || !X || !S_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (n_rows < X->n_items || col_begin < 0 || n_cols <= 0 || n_cols > ld || (ld % 4) || col_begin + n_cols > n_rows)
     RP_FAIL(RPHIP_EINVAL, "slab of columns [%lld,%lld) with %lld rows, ld %lld", (long long)col_begin, (long long)(col_begin + n_cols), (long long)n_rows, (long long)ld);
+  RP_NEED_DEGREES(X);
   RP_TRY(rp_set_device(ctx));
   float* colscale = nullptr;
   RP_TRY(rp_scratch(ctx, 5, (size_t)n_cols * 4 + 64, (void**)&colscale));
@@ -1794,6 +1795,8 @@ extern "C" int rphip_ease_xy_fit(rphip_ctx* ctx, const rphip_csr* X, const rphip
   if (!(l2 > 0.0)) RP_FAIL(RPHIP_EINVAL, "l2 must be > 0 (got %g): G + l2*I has to be positive definite", l2);
   if (X->n_users != Y->n_users || X->n_items != Y->n_items) RP_FAIL(RPHIP_EINVAL, "X and y must have the same shape");
   if (X->xt_row_end >= 0 || Y->xt_row_end >= 0) RP_FAIL(RPHIP_ESTATE, "EASE_XY needs matrices with all item rows of X^T");
+  RP_NEED_DEGREES(X);
+  RP_NEED_DEGREES(Y);
   RP_TRY(rp_set_device(ctx));
   const int n = (int)X->n_items;
   if (n <= 0) RP_FAIL(RPHIP_EINVAL, "no items");
@@ -1935,6 +1938,7 @@ extern "C" int rphip_ease_fit(rphip_ctx* ctx, const rphip_csr* X, double l2, dou
   *out = nullptr;
   if (!(l2 > 0.0)) RP_FAIL(RPHIP_EINVAL, "l2 must be > 0 (got %g): G + l2*I has to be positive definite", l2);
   if (X->xt_row_end >= 0) RP_FAIL(RPHIP_ESTATE, "EASE needs a matrix with all item rows of X^T (not rphip_csr_from_device_rows)");
+  RP_NEED_DEGREES(X);
   RP_TRY(rp_set_device(ctx));
   const int n = (int)X->n_items;
   if (n <= 0) RP_FAIL(RPHIP_EINVAL, "no items");
@@ -1966,6 +1970,7 @@ extern "C" int rphip_ease_gram_create(rphip_ctx* ctx, const rphip_csr* X, rphip_
   if (!ctx || !X || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   if (X->xt_row_end >= 0) RP_FAIL(RPHIP_ESTATE, "EASE needs a matrix with all item rows of X^T (not rphip_csr_from_device_rows)");
+  RP_NEED_DEGREES(X);
   RP_TRY(rp_set_device(ctx));
   const int n = (int)X->n_items;
   if (n <= 0) RP_FAIL(RPHIP_EINVAL, "no items");
@@ -1990,6 +1995,7 @@ extern "C" int rphip_ease_fit_gram(rphip_ctx* ctx, const rphip_csr* X, const rph
   if (!(l2 > 0.0)) RP_FAIL(RPHIP_EINVAL, "l2 must be > 0 (got %g): G + l2*I has to be positive definite", l2);
   if (!gram->is_gram || gram->kind != RPHIP_MODEL_DENSE) RP_FAIL(RPHIP_ESTATE, "not a Gram from rphip_ease_gram_create");
   if (gram->n_items != X->n_items) RP_FAIL(RPHIP_EINVAL, "the Gram has %lld items, the matrix %lld", (long long)gram->n_items, (long long)X->n_items);
+  RP_NEED_DEGREES(X);
   RP_TRY(rp_set_device(ctx));
   const int n = (int)X->n_items;
   rphip_model* m = nullptr;

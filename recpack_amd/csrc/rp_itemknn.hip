@@ -840,6 +840,7 @@ int rp_model_alloc_topk(rphip_ctx* ctx, int64_t n_items, int64_t r0, int64_t r1,
 extern "C" int rphip_model_destroy(rphip_model* m) {
   if (!m) return RPHIP_OK;
   if (m->ctx) hipSetDevice(m->ctx->device);
+  if (m->ctx && m->borrows_B) hipStreamSynchronize(m->ctx->stream);  // the caller's B may still be read by a launch in flight
   rp_dev_free(m->ctx, m->idx);
   rp_dev_free(m->ctx, m->val);
   rp_dev_free(m->ctx, m->val32);
@@ -896,8 +897,8 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   if (row_begin < 0 || row_end > X->n_items || row_begin > row_end)
     RP_FAIL(RPHIP_EINVAL, "row range [%lld,%lld) outside 0..%lld", (long long)row_begin, (long long)row_end, (long long)X->n_items);
   if (K < 1) RP_FAIL(RPHIP_EINVAL, "K must be >= 1 (got %d)", K);
-  if (X->deg_partial || Xc->deg_partial)
-    RP_FAIL(RPHIP_ESTATE, "the shard's degrees are not complete: all-reduce rphip_csr_degrees_device over the shards, then rphip_csr_finish_degrees");
+  RP_NEED_DEGREES(X);
+  RP_NEED_DEGREES(Xc);
   if (X->xt_row_end >= 0 && (row_begin < X->xt_row_begin || row_end > X->xt_row_end))
     RP_FAIL(RPHIP_ESTATE, "the matrix was built for item rows [%lld,%lld) only (rphip_csr_from_device_rows)", (long long)X->xt_row_begin,
             (long long)X->xt_row_end);

@@ -552,6 +552,7 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
   if (!ctx || !X || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   if (!X->x_val) RP_FAIL(RPHIP_ESTATE, "the matrix carries no values (rphip_csr_set_values)");
+  RP_NEED_DEGREES(X);
   if (row_begin < 0 || row_end > X->n_items || row_begin > row_end)
     RP_FAIL(RPHIP_EINVAL, "row range [%lld,%lld) outside 0..%lld", (long long)row_begin, (long long)row_end, (long long)X->n_items);
   if (K < 1) RP_FAIL(RPHIP_EINVAL, "K must be >= 1 (got %d)", K);

@@ -217,6 +217,7 @@ int rp_gram_weighted(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int6
   if (row_begin < 0 || row_end > X->n_items || row_begin > row_end)
     RP_FAIL(RPHIP_EINVAL, "row range [%lld,%lld) outside 0..%lld", (long long)row_begin, (long long)row_end, (long long)X->n_items);
   if (K < 1) RP_FAIL(RPHIP_EINVAL, "K must be >= 1 (got %d)", K);
+  RP_NEED_DEGREES(X);
   if (X->xt_row_end >= 0) RP_FAIL(RPHIP_ESTATE, "normalize_X needs a matrix with all item rows of X^T (not rphip_csr_from_device_rows)");
   const int32_t Keff = (int32_t)std::min<int64_t>(K, std::max<int64_t>(1, X->n_items - 1));
   if (Keff > RP_K_MAX) RP_FAIL(RPHIP_ELIMIT, "effective K=%d exceeds the supported maximum %d", Keff, RP_K_MAX);

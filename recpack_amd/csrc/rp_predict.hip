@@ -1352,6 +1352,8 @@ extern "C" int rphip_predict_merge_topk(rphip_ctx* ctx, int32_t n_lists, int32_t
                                         int32_t* nnz_dev) {
   if (!ctx || !cand_idx_dev || !cand_val_dev || !cand_nnz_dev || !idx_dev || !val_dev || !nnz_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (n_lists < 1 || Kp < 1 || Kp > RP_K_MAX || n_users < 0) RP_FAIL(RPHIP_EINVAL, "n_lists %d, Kp %d, n_users %lld", n_lists, Kp, (long long)n_users);
+  // the merge keeps the lists' offsets in the selection's 32 spare LDS words (RPS_MISC_INTS - RPS_USER)
+  if (n_lists > RPS_MISC_INTS - RPS_USER - 1) RP_FAIL(RPHIP_ELIMIT, "at most %d candidate lists per user (got %d)", RPS_MISC_INTS - RPS_USER - 1, n_lists);
   RP_TRY(rp_set_device(ctx));
   if (n_users == 0) return RPHIP_OK;
   const size_t mlds = (size_t)n_lists * Kp * 8 + rp_select_smem_bytes(n_lists * Kp);

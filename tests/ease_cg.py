@@ -117,7 +117,7 @@ def solve_columns(indptr_t, indices_t, shape, l2, cols, tol=1e-13, max_iter=3000
     return Xk.cpu().numpy(), it, rel
 
 
-def certify_on_host(X_csr, l2, cols, P_cols):
+def certify_on_host(X_csr, l2, cols, P_cols, alpha=0.0):
     """Host float64 residual of the CG iterate -> reference columns of B with a proven error bound.
 
     Returns (B_ref [I, k], bound [k]): |B_ref[:, j] - B_exact[:, j]|_max <= bound[j]."""
@@ -134,6 +134,11 @@ def certify_on_host(X_csr, l2, cols, P_cols):
     B_ref[cols, np.arange(k)] = 0.0
     # b = -p / p_jj: |db| <= dp / (p_jj - dp) * (1 + max|b|)
     bound = dp / (pjj - dp) * (1.0 + np.abs(B_ref).max(axis=0))
+    if alpha != 0:  # ease.py:88-90: column j times c_j^-alpha (a sampled column always has c_j > 0 or is all zero)
+        c = np.bincount(X_csr.indices, minlength=X_csr.shape[1])[cols].astype(np.float64)
+        w = np.where(c > 0, np.maximum(c, 1.0) ** -float(alpha), 0.0)
+        B_ref = B_ref * w[None, :]
+        bound = bound * w
     return B_ref, bound
 
 
@@ -145,7 +150,7 @@ def sample_columns(item_deg, n_popular, n_median, n_random, seed=3):
                                      rng.choice(I, n_random, replace=False)])).astype(np.int64)
 
 
-def run_parity(_lib, ctx, cfg, l2=200.0, n_cols=(16, 8, 8), n_users=48, Kp=100, log=print, model=None, keep_model=False):
+def run_parity(_lib, ctx, cfg, l2=200.0, n_cols=(16, 8, 8), n_users=48, Kp=100, log=print, model=None, keep_model=False, alpha=0.0):
     """EASE fit on config `cfg` through the C ABI, then: sampled columns of B against the host-certified float64
     columns, and scores of a block of users at those columns (the kernel behind predict, K9) against float64 sums of
     the reference columns.  Returns the measured errors; the caller asserts."""
@@ -162,7 +167,7 @@ def run_parity(_lib, ctx, cfg, l2=200.0, n_cols=(16, 8, 8), n_users=48, Kp=100, 
     ip, ix = config_csr(cfg, device=dev)
     dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
     t0 = time.perf_counter()
-    m = model if model is not None else _lib.ease_fit(ctx, dX, l2)
+    m = model if model is not None else _lib.ease_fit(ctx, dX, l2, alpha)
     ctx.sync()
     t_fit = time.perf_counter() - t0
     B = rdist.model_dense_tensor(m, dev)
@@ -176,11 +181,11 @@ def run_parity(_lib, ctx, cfg, l2=200.0, n_cols=(16, 8, 8), n_users=48, Kp=100, 
     indptr, indices = ip.cpu().numpy().astype(np.int64), ix.cpu().numpy()
     X = sp.csr_matrix((np.ones(len(indices), dtype=np.float64), indices, indptr), shape=(U, I))
     t0 = time.perf_counter()
-    B_ref, bound = certify_on_host(X, l2, cols, P_cols)
+    B_ref, bound = certify_on_host(X, l2, cols, P_cols, alpha)
     t_host = time.perf_counter() - t0
     B_gpu = B[:, torch.as_tensor(cols, device=dev)].double().cpu().numpy()
     col_max = np.abs(B_ref).max(axis=0)
-    err_col = np.abs(B_gpu - B_ref).max(axis=0) / col_max
+    err_col = np.abs(B_gpu - B_ref).max(axis=0) / np.where(col_max > 0, col_max, 1.0)
     # scores of a contiguous block of users (synthetic users are i.i.d.) at the sampled columns, through predict's kernel
     u0 = U // 3
     u1 = u0 + n_users
@@ -201,8 +206,10 @@ def run_parity(_lib, ctx, cfg, l2=200.0, n_cols=(16, 8, 8), n_users=48, Kp=100, 
         if len(hit) and row_max[r] > 0:
             ref = S_ref[r, np.searchsorted(cols, got[hit])]
             top_err = max(top_err, float(np.abs(pv[r, hit] - ref).max() / row_max[r]))
-    out = {"config": cfg, "n_items": I, "l2": l2, "columns": len(cols), "cg_iterations": iters, "cg_residual": rel,
-           "certified_bound_rel": float((bound / col_max).max()), "err_col_max": float(err_col.max()), "err_col_median": float(np.median(err_col)),
+    live_c = col_max > 0  # (an item nobody interacted with has an all-zero column)
+    err_col = err_col[live_c] if live_c.any() else np.zeros(1)
+    out = {"config": cfg, "n_items": I, "l2": l2, "alpha": alpha, "columns": len(cols), "cg_iterations": iters, "cg_residual": rel,
+           "certified_bound_rel": float((bound / np.where(col_max > 0, col_max, 1.0)).max()), "err_col_max": float(err_col.max()), "err_col_median": float(np.median(err_col)),
            "err_global": float(np.abs(B_gpu - B_ref).max() / col_max.max()), "err_score_max": float(err_score.max()),
            "topk_pairs_checked": in_top, "err_topk_score_max": top_err, "c_max": int(deg.max()),
            "fit_s": round(t_fit, 2), "cg_s": round(t_cg, 2), "host_certify_s": round(t_host, 2)}
