@@ -63,6 +63,9 @@ enum {
   RPHIP_T_D2H = 10,
   RPHIP_T_GRAM_FINALIZE = 11, /* second launch of K1-K3: sum of the partial tiles of sliced rows + top-K */
   RPHIP_T_GRAM_TOPK_WAVE = 12, /* K1-K3 for rows with <= 255 users: 256-thread workgroups, byte counters */
+  RPHIP_T_SWEEP_UPDATE = 13,  /* rphip_ease_fit_dist: the symmetric rank-nb updates of the own panels (the n^3 / world part) */
+  RPHIP_T_SWEEP_CHAIN = 14,   /* rphip_ease_fit_dist: pivot inverse, gather / broadcast of the pivot column, T, look-ahead updates */
+  RPHIP_T_MIRROR = 15,        /* rphip_ease_fit_dist: the exchange that fills the upper triangle */
   RPHIP_T_COUNT = 16
 };
 
@@ -83,7 +86,7 @@ int rphip_ctx_create(int device, void* stream, rphip_ctx** out);
 int rphip_ctx_destroy(rphip_ctx* ctx);
 int rphip_ctx_sync(rphip_ctx* ctx);
 
-/* Device blocks of destroyed models / matrices are kept by the context (up to "cache_limit_bytes", default 48 GiB) and
+/* Device blocks of destroyed models / matrices are kept by the context (up to "cache_limit_bytes", default 48 GiB or a quarter of the device's memory, whichever is less) and
  * handed out again for a request of the same size, so a fit repeated in a loop allocates nothing after its first pass.
  * rphip_ctx_trim releases them to the driver (e.g. before another library allocates most of the HBM). */
 int rphip_ctx_trim(rphip_ctx* ctx);
@@ -369,6 +372,64 @@ int rphip_model_from_dense_cols(rphip_ctx* ctx, int64_t n_items, int64_t col_beg
                                 rphip_model** out);
 int rphip_predict_merge_topk(rphip_ctx* ctx, int32_t n_lists, int32_t Kp, int64_t n_users, const int32_t* cand_idx_dev,
                              const float* cand_val_dev, const int32_t* cand_nnz_dev, int32_t* idx_dev, float* val_dev, int32_t* nnz_dev);
+
+
+/* ---- multi-GPU inside the library: a communicator and the distributed EASE fit -----------------------------------------
+ * One process per GPU.  An rphip_comm is a group of `world` ranks with stream-ordered collectives on device memory:
+ *   rphip_comm_rccl_*   the library's own RCCL communicator (RCCL over xGMI; librccl is opened at run time, the same copy the
+ *                       process already holds when torch loaded one).  Rank 0 draws the 128-byte id, the caller hands it to
+ *                       every rank (any out-of-band channel: torch.distributed's store, MPI, a file), every rank creates.
+ *   rphip_comm_from_ops the caller's own transport as a table of C callbacks (the tests run the same solve over gloo with the
+ *                       ranks sharing one GPU).  A callback enqueues its operation on `stream` (a hipStream_t) or completes it
+ *                       before returning; buffers are device pointers on the caller's device; returns 0 on success.
+ * The reference has no multi-GPU path (recpack/algorithms/base.py:454-455, 686-690 leave it as a TODO). */
+typedef struct rphip_comm rphip_comm;
+typedef struct rphip_comm_ops {
+  void* self;
+  int32_t world, rank;
+  /* buf (bytes) of rank `root` to every rank's buf */
+  int (*broadcast)(void* self, void* buf, int64_t bytes, int32_t root, void* stream);
+  /* recv = every rank's send (bytes_per_rank each), in rank order; send may not alias recv */
+  int (*all_gather)(void* self, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
+  /* rank r sends send + send_off[d] (send_bytes[d] bytes) to every rank d and receives recv_bytes[s] bytes from every rank s at
+   * recv + recv_off[s]; the arrays have `world` entries, the entry for the rank itself is a local copy */
+  int (*exchange)(void* self, const void* send, const int64_t* send_off, const int64_t* send_bytes, void* recv, const int64_t* recv_off,
+                  const int64_t* recv_bytes, void* stream);
+  /* element-wise sum of int32 buffers over the ranks, in place */
+  int (*all_reduce_sum_i32)(void* self, void* buf, int64_t count, void* stream);
+} rphip_comm_ops;
+#define RPHIP_COMM_ID_BYTES 128
+int rphip_comm_rccl_unique_id(void* id_out /* RPHIP_COMM_ID_BYTES */);
+int rphip_comm_rccl_create(rphip_ctx* ctx, int32_t world, int32_t rank, const void* id, rphip_comm** out);
+int rphip_comm_from_ops(rphip_ctx* ctx, const rphip_comm_ops* ops, rphip_comm** out);
+int rphip_comm_destroy(rphip_comm* comm);
+int rphip_comm_info(const rphip_comm* comm, int32_t* world, int32_t* rank, int32_t* is_rccl);
+/* int32 sum over the ranks of a device vector, in place (the item degrees of a sharded K0: rphip_csr_degrees_device) */
+int rphip_comm_all_reduce_sum_i32(rphip_ctx* ctx, rphip_comm* comm, int32_t* buf_dev, int64_t count);
+
+/* EASE fit over the ranks of `comm` with the n x n matrix SHARDED in memory (replaces EASE._fit,
+ * ease.py:63-95, whose np.linalg.inv is the n^3 step).  Layout: panels of nb = 128 * panel_tiles columns, panel p on rank
+ * p % world (1-D block-cyclic: every rank's share of the lower triangle is the same whatever the pivot); a rank stores its
+ * panels side by side, all n_pad rows (n_pad = n rounded up to nb), and only the lower triangle is worked on.
+ * Solve: symmetric block Gauss-Jordan sweeps (Goodnight 1979) - for pivot panel K: P = A_KK^-1 (blocked Cholesky on MFMA
+ * tiles, on the owner), V = the pivot's full column A[:, K] (the part left of the diagonal gathered from the row block K of
+ * everybody's panels, the part below it broadcast by the owner with P), T_j = V_j P for the own panels j, then the symmetric
+ * rank-nb update A_ij -= V_i T_j^T on the own lower tiles, A_iK = T_i, A_KK = -P.  n^3 / world flop per rank (the count of
+ * potrf + trtri + lauum), n^2 * 4 bytes received per rank over the whole solve; the next pivot's chain (its panel update, the
+ * pivot inverse, the gather / broadcast) runs beside the current update on other streams (look-ahead of one panel), nothing
+ * is read back by the host before the end.  The finished lower triangle is mirrored across the ranks (one personalised
+ * exchange per `world` panels), K7 runs on the panels.  panel_tiles <= 0: chosen by the library (16, fewer for small n).
+ * The model holds this rank's columns of B (rphip_model_dense_layout); predict against it scores those columns only
+ * (a local top-Kp per user; rphip_predict_merge_topk merges the ranks' lists).  *out = NULL on a rank that owns only padding. */
+int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip_csr* X, double l2, double alpha, int32_t panel_tiles,
+                        rphip_model** out);
+/* Layout of a dense model's columns: local column l is item ((l / panel) * world + rank) * panel + l % panel when panel > 0
+ * (block-cyclic, rphip_ease_fit_dist), col_begin + l otherwise; n_local_cols of them are items (the rest is padding). */
+int rphip_model_dense_layout(const rphip_model* m, int64_t* n_local_cols, int64_t* panel, int32_t* world, int32_t* rank, int64_t* col_begin);
+/* numbers of the last rphip_ease_fit_dist on this context: [0] slab bytes, [1] peak bytes of everything else the fit held
+ * (panel buffers, staging, plane workspaces), [2] bytes received through the communicator, [3] bytes sent, [4] pivots,
+ * [5] panel width, [6] n_pad, [7] flop of the rank's products */
+int rphip_ease_fit_dist_stats(rphip_ctx* ctx, int64_t* out8);
 
 /* Cholesky factor (lower) of a 128 x 128 block in place and its inverse into W (ld 128), in float64 internally;
  * *info_dev (device int32) receives pivot + 1 if the block is not positive definite. */

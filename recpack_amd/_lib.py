@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "librecpack_hip.so")
 
 RPHIP_T_NAMES = [
     "csr_transpose", "fit_plan", "gram_topk", "topk_merge", "predict", "gram_dense", "cholesky", "inverse",
-    "ease_scale", "h2d", "d2h", "gram_finalize", "gram_topk_wave",
+    "ease_scale", "h2d", "d2h", "gram_finalize", "gram_topk_wave", "sweep_update", "sweep_chain", "mirror",
 ]
 RPHIP_T_COUNT = 16
 RPHIP_MODEL_TOPK = 1
@@ -115,6 +115,15 @@ PROTOTYPES = {
     "rphip_ease_scale_cols": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _f64]),
     "rphip_model_from_dense_cols": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _pp]),
     "rphip_predict_merge_topk": (C.c_int, [_p, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p]),
+    "rphip_comm_rccl_unique_id": (C.c_int, [_p]),
+    "rphip_comm_rccl_create": (C.c_int, [_p, _i32, _i32, _p, _pp]),
+    "rphip_comm_from_ops": (C.c_int, [_p, _p, _pp]),
+    "rphip_comm_destroy": (C.c_int, [_p]),
+    "rphip_comm_info": (C.c_int, [_p, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "rphip_comm_all_reduce_sum_i32": (C.c_int, [_p, _p, _p, _i64]),
+    "rphip_ease_fit_dist": (C.c_int, [_p, _p, _p, _f64, _f64, _i32, _pp]),
+    "rphip_model_dense_layout": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64)]),
+    "rphip_ease_fit_dist_stats": (C.c_int, [_p, _p]),
 }
 
 _lock = threading.Lock()
@@ -441,6 +450,23 @@ class Model:
         check(self.ctx.lib.rphip_model_dense_device(self.handle, C.byref(ptr), C.byref(n), C.byref(ld)))
         return ptr.value, n.value, ld.value
 
+    def dense_layout(self) -> dict:
+        """Which items the columns of a dense model's B are (rphip_model_dense_layout): ``n_local`` columns; with ``panel`` > 0
+        they are block-cyclic panels (local column l = item ((l // panel) * world + rank) * panel + l % panel), otherwise the
+        range starting at ``col_begin``."""
+        n, nb, cb = C.c_int64(), C.c_int64(), C.c_int64()
+        w, r = C.c_int32(), C.c_int32()
+        check(self.ctx.lib.rphip_model_dense_layout(self.handle, C.byref(n), C.byref(nb), C.byref(w), C.byref(r), C.byref(cb)))
+        return {"n_local": n.value, "panel": nb.value, "world": w.value, "rank": r.value, "col_begin": cb.value}
+
+    def local_columns(self) -> np.ndarray:
+        """Item ids of the local columns of a dense model (ascending)."""
+        lay = self.dense_layout()
+        l = np.arange(lay["n_local"], dtype=np.int64)
+        if lay["panel"] > 0:
+            return ((l // lay["panel"]) * lay["world"] + lay["rank"]) * lay["panel"] + l % lay["panel"]
+        return lay["col_begin"] + l
+
     def dense_prune(self, keep: int):
         """Keep the ``keep`` largest |B_ij| on the device (ease.py:97-109); returns (nnz before, nnz after)."""
         a, b = C.c_int64(), C.c_int64()
@@ -458,6 +484,189 @@ class Model:
             self.handle = None
 
     __del__ = close
+
+
+# ---- communicator (include/recpack_hip.h: rphip_comm) --------------------------------------------------------------------
+_BCAST_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
+_AGATHER_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+_EXCH_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64),
+                      C.POINTER(C.c_int64), C.c_void_p)
+_ARED_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class CommOps(C.Structure):
+    _fields_ = [("self", C.c_void_p), ("world", C.c_int32), ("rank", C.c_int32), ("broadcast", _BCAST_T), ("all_gather", _AGATHER_T),
+                ("exchange", _EXCH_T), ("all_reduce_sum_i32", _ARED_T)]
+
+
+class _DevBytes:
+    """Zero-copy uint8 view of device memory for torch (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+class Comm:
+    """A group of ranks, one GPU each, with stream-ordered collectives on device memory (rphip_comm).
+
+    ``Comm.rccl`` is the library's own RCCL communicator (the product path on a multi-GPU node); ``Comm.torch`` hands the
+    library a table of callbacks that run the same operations through a torch.distributed group - any backend, so the
+    distributed solve can be driven over gloo with the ranks sharing a GPU (tests)."""
+
+    def __init__(self, ctx: Context, handle, keep=None):
+        self.ctx, self.handle, self._keep = ctx, handle, keep
+        w, r, k = C.c_int32(), C.c_int32(), C.c_int32()
+        check(ctx.lib.rphip_comm_info(handle, C.byref(w), C.byref(r), C.byref(k)))
+        self.world, self.rank, self.is_rccl = w.value, r.value, bool(k.value)
+        self.error = None
+
+    @classmethod
+    def rccl(cls, ctx: Context, group=None):
+        """The library's RCCL communicator over the ranks of a torch.distributed group (only the 128-byte id travels through
+        torch.distributed; a process outside any group gets a one-rank communicator)."""
+        import torch.distributed as dist
+
+        ident = C.create_string_buffer(128)
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if rank == 0:
+            check(ctx.lib.rphip_comm_rccl_unique_id(ident))
+        if world > 1:
+            box = [ident.raw]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = C.create_string_buffer(box[0], 128)
+        h = C.c_void_p()
+        check(ctx.lib.rphip_comm_rccl_create(ctx.handle, world, rank, ident, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def torch(cls, ctx: Context, device, group=None):
+        """Callbacks over a torch.distributed group.  Every operation first waits for the stream it was ordered on, then runs
+        (through host memory when the backend is gloo) and is complete when the callback returns."""
+        import torch
+        import torch.distributed as dist
+
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        via_host = dist.is_initialized() and dist.get_backend(group) != "nccl"
+        box = {"error": None}
+
+        def grank(r):
+            return dist.get_global_rank(group, r) if group is not None else r
+
+        def view(ptr, nbytes):
+            return torch.as_tensor(_DevBytes(ptr, nbytes), device=device)
+
+        def wait(stream):
+            if stream:
+                torch.cuda.ExternalStream(int(stream), device=device).synchronize()
+            else:
+                torch.cuda.synchronize(device)
+
+        def guarded(fn):
+            def run(*a):
+                try:
+                    fn(*a)
+                    torch.cuda.synchronize(device)
+                    return 0
+                except Exception as e:  # noqa: BLE001 - reported to the library as a failed transport call
+                    box["error"] = e
+                    return 1
+            return run
+
+        def bcast(_self, buf, nbytes, root, stream):
+            wait(stream)
+            t = view(buf, nbytes)
+            if via_host:
+                h = t.cpu()
+                dist.broadcast(h, src=grank(root), group=group)
+                if rank != root:
+                    t.copy_(h)
+            else:
+                dist.broadcast(t, src=grank(root), group=group)
+
+        def agather(_self, send, recv, nbytes, stream):
+            wait(stream)
+            s, r = view(send, nbytes), view(recv, nbytes * world)
+            if via_host:
+                h = torch.empty(nbytes * world, dtype=torch.uint8)
+                dist.all_gather_into_tensor(h, s.cpu(), group=group)
+                r.copy_(h)
+            else:
+                dist.all_gather_into_tensor(r, s, group=group)
+
+        def exch(_self, send, soff, sby, recv, roff, rby, stream):
+            wait(stream)
+            ops, landed = [], []
+            for p in range(world):
+                if p == rank:
+                    if sby[p] > 0:
+                        view(recv + roff[p], sby[p]).copy_(view(send + soff[p], sby[p]))
+                    continue
+                if sby[p] > 0:
+                    t = view(send + soff[p], sby[p])
+                    ops.append(dist.P2POp(dist.isend, t.cpu() if via_host else t, grank(p), group))
+                if rby[p] > 0:
+                    t = view(recv + roff[p], rby[p])
+                    h = torch.empty(rby[p], dtype=torch.uint8) if via_host else t
+                    landed.append((t, h))
+                    ops.append(dist.P2POp(dist.irecv, h, grank(p), group))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            if via_host:
+                for t, h in landed:
+                    t.copy_(h)
+
+        def ared(_self, buf, count, stream):
+            wait(stream)
+            t = view(buf, count * 4).view(torch.int32)
+            if via_host:
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+        cbs = (_BCAST_T(guarded(bcast)), _AGATHER_T(guarded(agather)), _EXCH_T(guarded(exch)), _ARED_T(guarded(ared)))
+        ops = CommOps(None, world, rank, *cbs)
+        h = C.c_void_p()
+        check(ctx.lib.rphip_comm_from_ops(ctx.handle, C.byref(ops), C.byref(h)))
+        c = cls(ctx, h, keep=(cbs, ops, box))
+        c.error = box
+        return c
+
+    def all_reduce_sum_i32(self, ptr: int, count: int):
+        check(self.ctx.lib.rphip_comm_all_reduce_sum_i32(self.ctx.handle, self.handle, C.c_void_p(ptr), int(count)))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.lib.rphip_comm_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+
+def ease_fit_dist(ctx: Context, comm: Comm, X: DeviceCSR, l2: float, alpha: float = 0.0, panel_tiles: int = 0):
+    """EASE fit over the ranks of ``comm`` with the matrix sharded in memory (rphip_ease_fit_dist: block-cyclic panels,
+    symmetric block sweeps, n^3 / world flop per rank).  Returns this rank's model (its columns of B: ``Model.local_columns``)
+    or None on a rank that owns only padding."""
+    h = C.c_void_p()
+    try:
+        check(ctx.lib.rphip_ease_fit_dist(ctx.handle, comm.handle, X.handle, float(l2), float(alpha), int(panel_tiles), C.byref(h)))
+    except RecpackHipError:
+        err = comm.error["error"] if isinstance(comm.error, dict) else None
+        if err is not None:
+            comm.error["error"] = None
+            raise err
+        raise
+    return Model(ctx, h) if h.value else None
+
+
+def ease_fit_dist_stats(ctx: Context) -> dict:
+    out = np.zeros(8, dtype=np.int64)
+    check(ctx.lib.rphip_ease_fit_dist_stats(ctx.handle, _np_ptr(out)))
+    return dict(zip(("slab_bytes", "other_peak_bytes", "bytes_received", "bytes_sent", "pivots", "panel", "n_pad", "flop"), (int(v) for v in out)))
 
 
 SIM_COSINE, SIM_CONDITIONAL_PROBABILITY = 0, 1

@@ -211,7 +211,7 @@ extern "C" int rphip_ctx_trim(rphip_ctx* ctx) {
   RP_TRY(rp_set_device(ctx));
   RP_HIP(hipStreamSynchronize(ctx->stream));
   rp_dev_trim(ctx);
-  for (int slot = 8; slot < 12; ++slot) {  // the plane workspaces of the large GEMMs
+  for (int slot = 8; slot < 14; ++slot) {  // the plane workspaces of the large GEMMs
     rp_buf& b = ctx->scratch[slot];
     if (b.p) RP_HIP(hipFree(b.p));
     b.p = nullptr;

@@ -67,7 +67,8 @@ struct rphip_ctx {
   char arch[64] = {0};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   rphip_timings tm;
-  rp_buf scratch[12];  // 8..11: plane workspaces of the large products (rp_ease.hip, k_gemm_hp): main stream A/B, side stream A/B
+  rp_buf scratch[16];  // 8..11: plane workspaces of the large products (rp_ease.hip, k_gemm_hp): main stream A/B, side stream A/B; 12..13: the
+                       // update stream of the distributed solve (rp_ease_dist.hip)
   unsigned long long* dev_counters = nullptr;  // 8 x u64 on the device: [0] products done by the wave fit kernel, [1] its rows
   // pending event pairs are resolved lazily (no sync inside *_dev calls)
   struct pending_t { hipEvent_t a, b; int slot; };
@@ -149,6 +150,9 @@ struct rphip_model {
   bool is_gram = false;     // B holds the plain Gram X^T X (rphip_ease_gram_create): input of rphip_ease_fit_gram, not a model to predict with
   int64_t ld = 0;
   int64_t col_begin = 0, n_cols = 0;  // n_cols > 0: B holds only the columns [col_begin, col_begin + n_cols) (rphip_model_from_dense_cols)
+  // n_cols > 0 and cyc_nb > 0: the columns are block-cyclic panels of cyc_nb columns (rphip_ease_fit_dist): local column l is item
+  // ((l / cyc_nb) * cyc_world + cyc_rank) * cyc_nb + l % cyc_nb; the n_cols items are a prefix of the local columns
+  int32_t cyc_nb = 0, cyc_world = 1, cyc_rank = 0;
   int64_t empty_rows = -1;  // rows without any stored similarity (-1: not counted)
 };
 

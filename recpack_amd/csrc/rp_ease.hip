@@ -19,39 +19,14 @@
 #include <vector>
 
 #include "rp_common.h"
+#include "rp_gemm.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-static int rp_dense_count_empty(rphip_ctx* ctx, rphip_model* m);
 
-constexpr int GT = 128;   // tile (and diagonal block) size
-constexpr int GBK = 16;   // K step
 constexpr int GLD = 20;   // LDS row stride in floats (16 + 4 pad: conflict-free ds_read_b128 over 16 rows)
 constexpr int GKC = 512;  // default K steps between two flushes of the MFMA accumulators into the compensated master sums (option gemm_flush_k)
 
-struct rp_gemm_args {
-  const float* A;
-  long long lda;
-  const float* B;
-  long long ldb;
-  float* C;
-  long long ldc;
-  int M, N;          // multiples of 128
-  int k0, k1;        // K range, multiples of 16
-  int kb_m, kb_n;    // k_begin = max(k0, kb_m * (m_off + m0), kb_n * (n_off + n0))
-  int m_off, n_off;
-  int ke_n;          // k_end = min(k1, ke_n * (n_off + n0 + 128)): B is lower triangular (row n holds columns <= n)
-  int tri;           // 0: all tiles; 1: only tiles with n_off + n0 <= m_off + m0; 2: strictly below the diagonal;
-                     // 3: the diagonal tiles only (grid.x = 1), written to C as a stack of blocks [M][128] (ldc = 128)
-  float alpha, beta;
-  // split-K (skinny products with few tiles and a long K): blockIdx.z = s handles K chunk s and writes its partial
-  // tile to part[s][M][N] (alpha = 1, beta = 0); k_splitk_reduce applies alpha / beta to C afterwards
-  float* part;
-  int k_chunk;
-  int kc;            // K steps between two flushes into the master sums (set by rp_gemm_nt from the context: GKC by default)
-  const unsigned* amax;  // k_gemm_nt_h2: device words [max |A|, max |B|] over the ranges read (k_gemm_amax); set by rp_gemm_nt
-  int sw;            // tiles per row of a supertile (64 tiles: sw x 64/sw), 0 = plain row-major 2-D grid; set by rp_gemm_nt
-};
 
 // Which tile a workgroup computes.  Workgroups go to the 8 XCDs round-robin by their linear id, and each XCD has its own L2.  In
 // plain row-major order the 64 workgroups resident on an XCD are 64 different column tiles of one tile row: one A panel shared
@@ -74,6 +49,18 @@ __device__ __forceinline__ bool rp_gemm_tile(const rp_gemm_args& g, int& tm, int
   tn = (int)(sx * g.sw + w % g.sw);
   tm = (int)(sy * sh + w / g.sw);
   return (unsigned)tn < gx && (unsigned)tm < gy;
+}
+
+// global column of C's tile column n0 (see rp_gemm_args::cyc_nb), and the `tri` rules
+__device__ __forceinline__ int rp_gemm_ncol(const rp_gemm_args& g, int n0) {
+  if (!g.cyc_nb) return g.n_off + n0;
+  const int l = g.cyc_l0 + n0;
+  return ((l / g.cyc_nb) * g.cyc_w + g.cyc_r) * g.cyc_nb + l % g.cyc_nb;
+}
+__device__ __forceinline__ bool rp_gemm_skip(const rp_gemm_args& g, int m0, int n0) {
+  if (g.tri == 1) return rp_gemm_ncol(g, n0) > g.m_off + m0;
+  if (g.tri == 2) return rp_gemm_ncol(g, n0) >= g.m_off + m0;
+  return false;
 }
 
 // Accumulation.  The MFMA adds into its fp32 accumulator in K order: over a K of 10^5 that alone loses ~ sqrt(K) eps, and
@@ -101,8 +88,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(rp_gemm_args g) {
   int tm, tn;
   if (!rp_gemm_tile(g, tm, tn)) return;
   const int m0 = tm * GT, n0 = tn * GT;
-  if (g.tri == 1 && g.n_off + n0 > g.m_off + m0) return;
-  if (g.tri == 2 && g.n_off + n0 >= g.m_off + m0) return;
+  if (rp_gemm_skip(g, m0, n0)) return;
   int kb = g.k0, ke = g.k1;
   if (g.part) {
     kb = g.k0 + (int)blockIdx.z * g.k_chunk;
@@ -267,8 +253,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_b3(rp_gemm_args g) {
   int tm, tn;
   if (!rp_gemm_tile(g, tm, tn)) return;
   const int m0 = tm * GT, n0 = tn * GT;
-  if (g.tri == 1 && g.n_off + n0 > g.m_off + m0) return;
-  if (g.tri == 2 && g.n_off + n0 >= g.m_off + m0) return;
+  if (rp_gemm_skip(g, m0, n0)) return;
   int kb = g.k0, ke = g.k1;
   if (g.part) {
     kb = g.k0 + (int)blockIdx.z * g.k_chunk;
@@ -502,8 +487,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_h2(rp_gemm_args g) {
   int tm, tn;
   if (!rp_gemm_tile(g, tm, tn)) return;
   const int m0 = tm * GT, n0 = tn * GT;
-  if (g.tri == 1 && g.n_off + n0 > g.m_off + m0) return;
-  if (g.tri == 2 && g.n_off + n0 >= g.m_off + m0) return;
+  if (rp_gemm_skip(g, m0, n0)) return;
   int kb = g.k0, ke = g.k1;
   if (g.part) {
     kb = g.k0 + (int)blockIdx.z * g.k_chunk;
@@ -710,8 +694,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_hp(rp_hp_args q) {
   int tm, tn;
   if (!rp_gemm_tile(g, tm, tn)) return;
   const int m0 = tm * GT, n0 = tn * GT;
-  if (g.tri == 1 && g.n_off + n0 > g.m_off + m0) return;
-  if (g.tri == 2 && g.n_off + n0 >= g.m_off + m0) return;
+  if (rp_gemm_skip(g, m0, n0)) return;
   int kb = g.k0, ke = g.k1;
   if (g.kb_m) kb = max(kb, g.m_off + m0);
   if (g.kb_n) kb = max(kb, g.n_off + n0);
@@ -840,8 +823,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_hp16(rp_hp_args q) {
   int tm, tn;
   if (!rp_gemm_tile(g, tm, tn)) return;
   const int m0 = tm * GT, n0 = tn * GT;
-  if (g.tri == 1 && g.n_off + n0 > g.m_off + m0) return;
-  if (g.tri == 2 && g.n_off + n0 >= g.m_off + m0) return;
+  if (rp_gemm_skip(g, m0, n0)) return;
   int kb = g.k0, ke = g.k1;
   if (g.kb_m) kb = max(kb, g.m_off + m0);
   if (g.kb_n) kb = max(kb, g.n_off + n0);
@@ -1136,7 +1118,7 @@ __global__ void k_ease_scale(float* __restrict__ P, long long ld, int n, const f
 // ---- host ------------------------------------------------------------------------------------------------------
 // `st` = stream to launch on (the context's by default); `part_at` = where this product's split-K partials go
 // (two products that run concurrently on different streams must not share them)
-static int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st = nullptr, float* part_at = nullptr) {
+int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st, float* part_at) {
   if (!st) st = ctx->stream;
   if (g.M <= 0 || g.N <= 0) return RPHIP_OK;
   if ((g.M % GT) || (g.N % GT) || (g.k0 % GBK) || (g.k1 % GBK)) RP_FAIL(RPHIP_EINVAL, "gemm_nt: sizes must be tile multiples");
@@ -1145,7 +1127,7 @@ static int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st = nu
   // few tiles and a long K: split K so that the launch fills the chip (partials in scratch, fixed-order reduce)
   int S = 1;
   // (thresholds 2-4 x CUs, targets 3-6 x CUs and minimum chunks of 512-2048 measured within noise of each other)
-  if (!g.tri && tiles < 2LL * ctx->n_cu && klen >= 4096 && (g.ldc % 4) == 0) {
+  if (!g.tri && !g.no_splitk && tiles < 2LL * ctx->n_cu && klen >= 4096 && (g.ldc % 4) == 0) {
     S = (int)std::min<long long>(8, std::min<long long>(klen / 2048, rp_cdiv(3LL * ctx->n_cu, tiles)));
     if (S < 2) S = 1;
   }
@@ -1192,7 +1174,7 @@ static int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st = nu
       const int rows_max = std::max(g.M, alias ? 0 : g.N);
       long long Kc = (long long)(ctx->gemm_ws_bytes / ((size_t)rows_max * 4)) / 512 * 512;
       Kc = std::max<long long>(512, std::min<long long>(Kc, (klen + 31) / 32 * 32));
-      const int slot_a = (st == ctx->stream) ? 8 : 10;  // a product on a side stream runs beside one on the main stream
+      const int slot_a = g.ws_slot ? g.ws_slot : ((st == ctx->stream) ? 8 : 10);  // a product on a side stream runs beside one on the main stream
       unsigned char *WA = nullptr, *WB = nullptr;
       auto ws_size = [&](size_t need) {  // grow in powers of two: the products of a solve come in many sizes
         size_t c = (size_t)64 << 20;
@@ -1279,20 +1261,20 @@ extern "C" int rphip_gemm_nt_f32(rphip_ctx* ctx, int64_t M, int64_t N, int64_t K
 // side buffer, and the lower half is mirrored over N.  200 000 items (160 GB) fit one 288 GB GPU this way.
 constexpr int RP_INV_PANEL = 16;  // tiles per panel of N = L^-T (2048 columns; 8 / 16 / 32 tiles measured: 5.94 / 5.53 / 5.87 s at n = 100 000)
 
-static int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld) {
+int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_ext) {
   hipStream_t st = ctx->stream;
   const int nb = n_pad / GT;
   char* wsb = nullptr;
   const int inv_w = std::min(RP_INV_PANEL * GT, n_pad);  // columns of one panel of the inverse
   RP_TRY(rp_scratch(ctx, 5, (size_t)nb * GT * GT * 4 + ((size_t)n_pad * inv_w + (size_t)inv_w * inv_w) * 4 + 256, (void**)&wsb));
   float* const Nb = A;  // N shares the matrix with L
-  int* info = (int*)wsb;
+  int* info = info_ext ? info_ext : (int*)wsb;
   float* W = (float*)(wsb + 256);                 // [nb][128][128]
   float* T = W + (size_t)nb * GT * GT;            // [n_pad][inv_w]: N11 L21^T of a panel ([c0][128] inside a panel)
   float* NT = T + (size_t)n_pad * inv_w;          // [inv_w][inv_w]: transpose of the panel's diagonal block of N
   float* part_all = nullptr;  // the split-K partials of the skinny products: sized once for the tallest of them
   RP_TRY(rp_scratch(ctx, 7, (size_t)8 * n_pad * GT * sizeof(float), (void**)&part_all));
-  RP_HIP(hipMemsetAsync(info, 0, 4, st));
+  if (!info_ext) RP_HIP(hipMemsetAsync(info, 0, 4, st));
   const size_t diag_lds = (size_t)GT * DS * sizeof(double);
   RP_HIP(hipFuncSetAttribute((const void*)k_potrf_trtri, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
   const double n3 = (double)n_pad * n_pad * n_pad;
@@ -1534,6 +1516,7 @@ static int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld) {
   }
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, RPHIP_T_INVERSE, 2.0 * n3 / 3.0);  // n^3/3 (N = L^-T) + n^3/3 (lower half of N N^T)
+  if (info_ext) return RPHIP_OK;  // the caller reads the flag when it next waits for the device
   int h_info = 0;
   RP_HIP(hipMemcpyAsync(&h_info, info, 4, hipMemcpyDeviceToHost, st));
   RP_HIP(hipStreamSynchronize(st));
@@ -1554,6 +1537,16 @@ __global__ void k_ease_init_rows(float* __restrict__ G, long long ld, int n, lon
   }
 }
 
+int rp_ease_gram_rows(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int64_t n_cols, float lam, float* G_dev, int64_t ld) {
+  if (row_end > row_begin)
+    hipLaunchKernelGGL(k_ease_init_rows, dim3(4096), dim3(256), 0, ctx->stream, G_dev, (long long)ld, (int)X->n_items, (long long)row_begin,
+                       (long long)row_end, (long long)n_cols, lam);
+  RP_HIP(hipGetLastError());
+  const int64_t r1 = std::min<int64_t>(row_end, X->n_items);
+  if (r1 > row_begin) RP_TRY(rp_gram_dense(ctx, X, row_begin, r1, G_dev, ld, lam));
+  return RPHIP_OK;
+}
+
 extern "C" int rphip_ease_gram_rows(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int64_t n_cols, double l2,
                                     float* G_dev, int64_t ld) {
   if (!ctx || !X || !G_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
@@ -1565,14 +1558,8 @@ extern "C" int rphip_ease_gram_rows(rphip_ctx* ctx, const rphip_csr* X, int64_t 
   if (X->xt_row_end >= 0 && (row_begin < X->xt_row_begin || std::min<int64_t>(row_end, X->n_items) > X->xt_row_end))
     RP_FAIL(RPHIP_ESTATE, "the matrix was built for item rows [%lld,%lld) only", (long long)X->xt_row_begin, (long long)X->xt_row_end);
   RP_TRY(rp_set_device(ctx));
-  const float lam = (float)l2;  // rounded to float32 as the reference does (ease.py:82)
-  if (row_end > row_begin)
-    hipLaunchKernelGGL(k_ease_init_rows, dim3(4096), dim3(256), 0, ctx->stream, G_dev, (long long)ld, (int)X->n_items, (long long)row_begin,
-                       (long long)row_end, (long long)n_cols, lam);
-  RP_HIP(hipGetLastError());
-  const int64_t r1 = std::min<int64_t>(row_end, X->n_items);
-  if (r1 > row_begin) RP_TRY(rp_gram_dense(ctx, X, row_begin, r1, G_dev, ld, lam));
-  return RPHIP_OK;
+  // lambda rounded to float32 as the reference does (ease.py:82)
+  return rp_ease_gram_rows(ctx, X, row_begin, row_end, n_cols, (float)l2, G_dev, ld);
 }
 
 // A (128 x 128 block, leading dimension lda) := its Cholesky factor (lower, upper part zeroed), W (128 x 128, ld 128) := the
@@ -1670,16 +1657,20 @@ __global__ void k_transpose_f32(const float* __restrict__ src, long long lds, fl
   for (int r = threadIdx.y; r < 32; r += 8) dst[(bx + r) * ldd + by + threadIdx.x] = t[threadIdx.x][r];
 }
 
+int rp_transpose_f32(rphip_ctx* ctx, const float* src, int64_t lds, int64_t rows, int64_t cols, float* dst, int64_t ldd, hipStream_t st) {
+  hipLaunchKernelGGL(k_transpose_f32, dim3((unsigned)(cols / 32), (unsigned)(rows / 32)), dim3(32, 8), 0, st ? st : ctx->stream, src, (long long)lds, dst,
+                     (long long)ldd);
+  RP_HIP(hipGetLastError());
+  return RPHIP_OK;
+}
+
 extern "C" int rphip_transpose_f32(rphip_ctx* ctx, const float* src_dev, int64_t lds, int64_t rows, int64_t cols, float* dst_dev, int64_t ldd) {
   if (!ctx || !src_dev || !dst_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (rows <= 0 || cols <= 0 || (rows % 32) || (cols % 32) || lds < cols || ldd < rows)
     RP_FAIL(RPHIP_EINVAL, "transpose of %lld x %lld (multiples of 32) with lds %lld, ldd %lld", (long long)rows, (long long)cols, (long long)lds, (long long)ldd);
   if (cols / 32 > 0x7fffffffLL || rows / 32 > 65535) RP_FAIL(RPHIP_ELIMIT, "transpose of %lld x %lld: at most 2 097 120 rows", (long long)rows, (long long)cols);
   RP_TRY(rp_set_device(ctx));
-  hipLaunchKernelGGL(k_transpose_f32, dim3((unsigned)(cols / 32), (unsigned)(rows / 32)), dim3(32, 8), 0, ctx->stream, src_dev, (long long)lds, dst_dev,
-                     (long long)ldd);
-  RP_HIP(hipGetLastError());
-  return RPHIP_OK;
+  return rp_transpose_f32(ctx, src_dev, lds, rows, cols, dst_dev, ldd);
 }
 
 // K7 on a column slab holding sign * P[:, col_begin : col_begin + n_cols]: B_ij = -P_ij / P_jj * w_j, B_jj = 0, rows and columns
@@ -2032,7 +2023,7 @@ __global__ void __launch_bounds__(256) k_count_empty_rows(const float* __restric
   }
 }
 
-static int rp_dense_count_empty(rphip_ctx* ctx, rphip_model* m) {
+int rp_dense_count_empty(rphip_ctx* ctx, rphip_model* m) {
   int* cnt = nullptr;
   RP_TRY(rp_scratch(ctx, 5, 64, (void**)&cnt));
   RP_HIP(hipMemsetAsync(cnt, 0, 4, ctx->stream));
@@ -2106,6 +2097,7 @@ __global__ void __launch_bounds__(256) k_prune_apply(float* __restrict__ B, long
 extern "C" int rphip_model_dense_prune(rphip_ctx* ctx, rphip_model* m, int64_t keep, int64_t* nnz_before, int64_t* nnz_after) {
   if (!ctx || !m) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (m->kind != RPHIP_MODEL_DENSE) RP_FAIL(RPHIP_ESTATE, "model is not a dense model");
+  if (m->n_cols > 0) RP_FAIL(RPHIP_ESTATE, "the model holds a slab of columns: prune the whole matrix");
   if (keep < 0) RP_FAIL(RPHIP_EINVAL, "keep must be >= 0");
   RP_TRY(rp_set_device(ctx));
   hipStream_t st = ctx->stream;
@@ -2192,6 +2184,7 @@ extern "C" int rphip_model_from_dense_host(rphip_ctx* ctx, int64_t n_items, cons
 extern "C" int rphip_model_dense_download(rphip_ctx* ctx, const rphip_model* m, float* B_host) {
   if (!ctx || !m || !B_host) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (m->kind != RPHIP_MODEL_DENSE) RP_FAIL(RPHIP_ESTATE, "model is not dense");
+  if (m->n_cols > 0) RP_FAIL(RPHIP_ESTATE, "the model holds a slab of columns (rphip_model_dense_layout), not the whole matrix");
   RP_TRY(rp_set_device(ctx));
   const size_t n = (size_t)m->n_items;
   hipEvent_t ev;

@@ -1,0 +1,745 @@
+// EASE fit with the n x n matrix sharded over the GPUs of one node: communicator + the distributed solve.
+//
+// Replaces the n^3 step of EASE._fit (recpack/algorithms/ease.py:81-82, np.linalg.inv of X^T X + l2 I) for matrices that one GPU
+// should not or cannot hold; the reference has no multi-GPU path (recpack/algorithms/base.py:454-455, 686-690: a TODO).
+//
+// Layout.  n_pad = n rounded up to the panel width nb = 128 * panel_tiles; panel p (columns [p nb, (p + 1) nb)) lives on rank
+// p % W at local panel p / W (1-D block-cyclic).  A rank stores its nl panels side by side: S[n_pad][nl * nb] row-major.  The
+// matrix is symmetric throughout, only blocks (i, j) with i >= j are kept current ("lower"); the diagonal blocks are kept in
+// their lower 128-tiles.
+//
+// Solve: symmetric block Gauss-Jordan sweeps (Goodnight 1979), the symmetric form of the sweeps of dist.ease_fit_sweeps.  For the
+// pivot panel K with P = A_KK^-1 and the pivot's full column V = A[:, K] (V_i = A_iK for i > K from the owner's panel, V_i = A_Ki^T
+// for i < K from row block K of everybody's panels), T = V P:
+//     A_ij -= V_i T_j^T  (i, j != K),     A_iK = T_i (i > K),     A_Ki = T_i^T (i < K),     A_KK = -P,
+// and after the last pivot the matrix is -(G + l2 I)^-1.  A rank updates the lower tiles of its own panels: n^2 nb / W flop per
+// pivot, n^3 / W in all - the count of potrf + trtri + lauum - in ONE kind of product (K = nb) on the solve's MFMA kernel.
+// What a pivot needs from the others is V: n nb floats (the row-block pieces all-gathered, the owner's part broadcast with P
+// appended), n^2 * 4 bytes per rank over the whole solve; T_j = V_j P is formed locally for the own panels only.
+//
+// Schedule (per rank, three streams; the host never waits before the end):
+//     main    chain(K): pivot inverse (owner), pack pieces, [comm], unpack V, T_own, writes of row / column K, then the
+//             LOOK-AHEAD part of update K: row block K + 1 of the own panels and panel K + 1 (what chain(K + 1) reads)
+//     comm    all-gather of the pieces + broadcast of the owner's part of V
+//     update  U(K): everything else of update K - it runs beside chain(K + 1)
+// U(K) leaves row blocks and panels K, K + 1 alone, the look-ahead of K + 1 waits for U(K) (both add to the same tiles).
+// V and T_own are double buffered.  A failing pivot (matrix not positive definite) leaves its index in a device flag that is
+// read once, after the last pivot.
+#include <dlfcn.h>
+#include <string.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "rp_common.h"
+#include "rp_gemm.h"
+
+// ---- communicator ---------------------------------------------------------------------------------------------------------
+struct rp_rccl_api {
+  void* dl = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static rp_rccl_api g_rccl;
+
+// librccl is opened at run time: the copy the process already holds (torch ships one) or ROCm's
+static int rp_rccl_load() {
+  if (g_rccl.dl) return RPHIP_OK;
+  void* dl = nullptr;
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names)
+    if ((dl = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
+  if (!dl)
+    for (const char* n : names)
+      if ((dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!dl) RP_FAIL(RPHIP_ENODEV, "librccl could not be opened: %s", dlerror());
+  rp_rccl_api a;
+  a.dl = dl;
+  bool ok = true;
+  auto sym = [&](const char* name) {
+    void* p = dlsym(dl, name);
+    if (!p) ok = false;
+    return p;
+  };
+  a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
+  a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
+  a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+  a.Broadcast = (decltype(a.Broadcast))sym("ncclBroadcast");
+  a.AllGather = (decltype(a.AllGather))sym("ncclAllGather");
+  a.AllReduce = (decltype(a.AllReduce))sym("ncclAllReduce");
+  a.Send = (decltype(a.Send))sym("ncclSend");
+  a.Recv = (decltype(a.Recv))sym("ncclRecv");
+  a.GroupStart = (decltype(a.GroupStart))sym("ncclGroupStart");
+  a.GroupEnd = (decltype(a.GroupEnd))sym("ncclGroupEnd");
+  a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
+  if (!ok) RP_FAIL(RPHIP_ENODEV, "librccl lacks an expected entry point");
+  g_rccl = a;
+  return RPHIP_OK;
+}
+
+#define RP_NCCL(expr)                                                                                            \
+  do {                                                                                                           \
+    ncclResult_t _r = (expr);                                                                                    \
+    if (_r != ncclSuccess) RP_FAIL(RPHIP_EHIP, "%s failed: %s", #expr, g_rccl.GetErrorString(_r));               \
+  } while (0)
+
+struct rphip_comm {
+  rphip_ctx* ctx = nullptr;
+  int world = 1, rank = 0;
+  bool is_rccl = false;
+  ncclComm_t nccl = nullptr;
+  rphip_comm_ops ops{};
+  int64_t bytes_recv = 0, bytes_sent = 0;
+};
+
+extern "C" int rphip_comm_rccl_unique_id(void* id_out) {
+  if (!id_out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  RP_TRY(rp_rccl_load());
+  static_assert(sizeof(ncclUniqueId) == RPHIP_COMM_ID_BYTES, "id size");
+  ncclUniqueId id;
+  RP_NCCL(g_rccl.GetUniqueId(&id));
+  ::memcpy(id_out, &id, sizeof(id));
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_comm_rccl_create(rphip_ctx* ctx, int32_t world, int32_t rank, const void* id, rphip_comm** out) {
+  if (!ctx || !id || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (world < 1 || rank < 0 || rank >= world) RP_FAIL(RPHIP_EINVAL, "rank %d of %d", rank, world);
+  RP_TRY(rp_rccl_load());
+  RP_TRY(rp_set_device(ctx));
+  ncclUniqueId uid;
+  ::memcpy(&uid, id, sizeof(uid));
+  rphip_comm* c = new rphip_comm();
+  c->ctx = ctx;
+  c->world = world;
+  c->rank = rank;
+  c->is_rccl = true;
+  ncclResult_t r = g_rccl.CommInitRank(&c->nccl, world, uid, rank);
+  if (r != ncclSuccess) {
+    delete c;
+    RP_FAIL(RPHIP_EHIP, "ncclCommInitRank (rank %d of %d) failed: %s", rank, world, g_rccl.GetErrorString(r));
+  }
+  *out = c;
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_comm_from_ops(rphip_ctx* ctx, const rphip_comm_ops* ops, rphip_comm** out) {
+  if (!ctx || !ops || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (ops->world < 1 || ops->rank < 0 || ops->rank >= ops->world) RP_FAIL(RPHIP_EINVAL, "rank %d of %d", ops->rank, ops->world);
+  if (ops->world > 1 && (!ops->broadcast || !ops->all_gather || !ops->exchange || !ops->all_reduce_sum_i32))
+    RP_FAIL(RPHIP_EINVAL, "a transport for more than one rank needs all four operations");
+  rphip_comm* c = new rphip_comm();
+  c->ctx = ctx;
+  c->world = ops->world;
+  c->rank = ops->rank;
+  c->ops = *ops;
+  *out = c;
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_comm_destroy(rphip_comm* c) {
+  if (!c) return RPHIP_OK;
+  if (c->is_rccl && c->nccl) {
+    if (c->ctx) {
+      hipSetDevice(c->ctx->device);
+      hipDeviceSynchronize();
+    }
+    g_rccl.CommDestroy(c->nccl);
+  }
+  delete c;
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_comm_info(const rphip_comm* c, int32_t* world, int32_t* rank, int32_t* is_rccl) {
+  if (!c) RP_FAIL(RPHIP_EINVAL, "communicator is NULL");
+  if (world) *world = c->world;
+  if (rank) *rank = c->rank;
+  if (is_rccl) *is_rccl = c->is_rccl ? 1 : 0;
+  return RPHIP_OK;
+}
+
+#define RP_OPS(expr, what)                                                                         \
+  do {                                                                                             \
+    if ((expr) != 0) RP_FAIL(RPHIP_EHIP, "the caller's transport failed in %s", what);             \
+  } while (0)
+
+static int rp_comm_broadcast(rphip_comm* c, void* buf, int64_t bytes, int root, hipStream_t st) {
+  if (c->world == 1 || bytes <= 0) return RPHIP_OK;
+  if (c->rank == root)
+    c->bytes_sent += bytes;
+  else
+    c->bytes_recv += bytes;
+  if (c->is_rccl) {
+    RP_NCCL(g_rccl.Broadcast(buf, buf, (size_t)bytes, ncclInt8, root, c->nccl, st));
+    return RPHIP_OK;
+  }
+  RP_OPS(c->ops.broadcast(c->ops.self, buf, bytes, root, (void*)st), "broadcast");
+  return RPHIP_OK;
+}
+
+static int rp_comm_all_gather(rphip_comm* c, const void* send, void* recv, int64_t bytes_per_rank, hipStream_t st) {
+  if (bytes_per_rank <= 0) return RPHIP_OK;
+  if (c->world == 1) {
+    if (send != recv) RP_HIP(hipMemcpyAsync(recv, send, (size_t)bytes_per_rank, hipMemcpyDeviceToDevice, st));
+    return RPHIP_OK;
+  }
+  c->bytes_sent += bytes_per_rank;
+  c->bytes_recv += bytes_per_rank * (c->world - 1);
+  if (c->is_rccl) {
+    RP_NCCL(g_rccl.AllGather(send, recv, (size_t)bytes_per_rank, ncclInt8, c->nccl, st));
+    return RPHIP_OK;
+  }
+  RP_OPS(c->ops.all_gather(c->ops.self, send, recv, bytes_per_rank, (void*)st), "all_gather");
+  return RPHIP_OK;
+}
+
+static int rp_comm_exchange(rphip_comm* c, const void* send, const int64_t* soff, const int64_t* sbytes, void* recv, const int64_t* roff,
+                            const int64_t* rbytes, hipStream_t st) {
+  const int me = c->rank;
+  for (int p = 0; p < c->world; ++p)
+    if (p != me) {
+      c->bytes_sent += sbytes[p];
+      c->bytes_recv += rbytes[p];
+    }
+  if (c->world == 1 || c->is_rccl) {
+    if (sbytes[me] > 0)
+      RP_HIP(hipMemcpyAsync((char*)recv + roff[me], (const char*)send + soff[me], (size_t)sbytes[me], hipMemcpyDeviceToDevice, st));
+    if (c->world == 1) return RPHIP_OK;
+    RP_NCCL(g_rccl.GroupStart());
+    for (int p = 0; p < c->world; ++p) {
+      if (p == me) continue;
+      if (sbytes[p] > 0) RP_NCCL(g_rccl.Send((const char*)send + soff[p], (size_t)sbytes[p], ncclInt8, p, c->nccl, st));
+      if (rbytes[p] > 0) RP_NCCL(g_rccl.Recv((char*)recv + roff[p], (size_t)rbytes[p], ncclInt8, p, c->nccl, st));
+    }
+    RP_NCCL(g_rccl.GroupEnd());
+    return RPHIP_OK;
+  }
+  RP_OPS(c->ops.exchange(c->ops.self, send, soff, sbytes, recv, roff, rbytes, (void*)st), "exchange");
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_comm_all_reduce_sum_i32(rphip_ctx* ctx, rphip_comm* c, int32_t* buf, int64_t count) {
+  if (!ctx || !c || !buf) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if (count <= 0 || c->world == 1) return RPHIP_OK;
+  RP_TRY(rp_set_device(ctx));
+  if (c->is_rccl) {
+    RP_NCCL(g_rccl.AllReduce(buf, buf, (size_t)count, ncclInt32, ncclSum, c->nccl, ctx->stream));
+    return RPHIP_OK;
+  }
+  RP_OPS(c->ops.all_reduce_sum_i32(c->ops.self, buf, count, (void*)ctx->stream), "all_reduce_sum_i32");
+  return RPHIP_OK;
+}
+
+// ---- small kernels ----------------------------------------------------------------------------------------------------------
+// batch of nb x nb blocks: dst_b[c][r] = src_b[r][c]; block b = blockIdx.z at src + b * sbs, dst + b * dbs
+__global__ void k_blk_transpose(const float* __restrict__ src, long long lds, long long sbs, float* __restrict__ dst, long long ldd,
+                                long long dbs) {
+  __shared__ float t[32][33];
+  src += (long long)blockIdx.z * sbs;
+  dst += (long long)blockIdx.z * dbs;
+  const long long bx = (long long)blockIdx.x * 32, by = (long long)blockIdx.y * 32;
+  for (int r = threadIdx.y; r < 32; r += 8) t[r][threadIdx.x] = src[(by + r) * lds + bx + threadIdx.x];
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += 8) dst[(bx + r) * ldd + by + threadIdx.x] = t[threadIdx.x][r];
+}
+
+// dst[r][c] = scale * src[r][c], rows x cols (cols a multiple of 4), 16-byte accesses
+__global__ void k_copy2d(const float* __restrict__ src, long long lds, float* __restrict__ dst, long long ldd, long long rows, int cols,
+                         float scale) {
+  const int c4 = cols >> 2;
+  const long long total = rows * c4;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long r = e / c4;
+    const int c = (int)(e % c4) * 4;
+    float4 v = *reinterpret_cast<const float4*>(src + r * lds + c);
+    v.x *= scale;
+    v.y *= scale;
+    v.z *= scale;
+    v.w *= scale;
+    *reinterpret_cast<float4*>(dst + r * ldd + c) = v;
+  }
+}
+
+// pieces gathered from the ranks: slot (r, q) at src + (r * slots + q) * nb * nb is the nb x nb block of global panel q * W + r;
+// blocks of panels < limit go to dst rows [panel * nb, +nb) (leading dimension ldd)
+__global__ void k_unpack_pieces(const float* __restrict__ src, int slots, int W, int limit, int nb, float* __restrict__ dst, long long ldd) {
+  const int z = blockIdx.y, r = z / slots, q = z % slots;
+  const int panel = q * W + r;
+  if (panel >= limit) return;
+  const float* s = src + (long long)z * nb * nb;
+  float* d = dst + (long long)panel * nb * ldd;
+  const int c4 = nb >> 2;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nb * c4; e += gridDim.x * blockDim.x) {
+    const int row = e / c4, c = (e % c4) * 4;
+    *reinterpret_cast<float4*>(d + (long long)row * ldd + c) = *reinterpret_cast<const float4*>(s + (long long)row * nb + c);
+  }
+}
+
+// upper 128-tiles of an nb x nb diagonal block from its lower ones (the block sits at P with leading dimension ld)
+__global__ void __launch_bounds__(256) k_mirror_block(float* __restrict__ P, long long ld) {
+  __shared__ float t[32][33];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj > bi) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) t[r][tx] = P[(long long)(bi * 32 + r) * ld + bj * 32 + tx];
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bj * 32 + r, j = bi * 32 + tx;
+    if (j > i) P[(long long)i * ld + j] = t[tx][r];
+  }
+}
+
+struct rp_cyc {
+  int nb, W, r;
+  __host__ __device__ int to_global(int l) const { return ((l / nb) * W + r) * nb + l % nb; }
+};
+
+// K7 on block-cyclic panels holding sign * P: colscale_l = -w_j / S_jl (the sign cancels in P_ij / P_jj), 0 for padding columns
+__global__ void k_dist_colscale(const float* __restrict__ S, long long ld, int n, int n_local, rp_cyc cy, const int32_t* __restrict__ deg,
+                                float alpha, float* __restrict__ colscale) {
+  for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < n_local; l += gridDim.x * blockDim.x) {
+    const int j = cy.to_global(l);
+    float sc = 0.0f;
+    if (j < n) {
+      const float d = S[(long long)j * ld + l];
+      float w = 1.0f;
+      if (alpha != 0.0f) w = deg[j] > 0 ? powf((float)deg[j], -alpha) : 0.0f;
+      sc = -w / d;
+    }
+    colscale[l] = sc;
+  }
+}
+
+__global__ void k_dist_scale(float* __restrict__ S, long long ld, long long n_rows, int n, rp_cyc cy, const float* __restrict__ colscale) {
+  const long long total = n_rows * ld;
+  for (long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; e < total; e += (long long)gridDim.x * blockDim.x * 4) {
+    const long long i = e / ld;
+    const int l = (int)(e % ld);
+    float4 v = *reinterpret_cast<float4*>(S + e);
+    float o[4] = {v.x, v.y, v.z, v.w};
+    const int j0 = cy.to_global(l);  // (four consecutive local columns lie in one panel)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = (i < n && (long long)(j0 + c) != i) ? o[c] * colscale[l + c] : 0.0f;
+    *reinterpret_cast<float4*>(S + e) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ---- the distributed fit ------------------------------------------------------------------------------------------------------
+namespace {
+
+struct dist_res {  // everything the fit holds besides the slab; released on every way out
+  rphip_ctx* ctx = nullptr;
+  hipStream_t su = nullptr, sc = nullptr;
+  std::vector<hipEvent_t> evs;
+  std::vector<void*> bufs;
+  int64_t held = 0, peak = 0;
+  int alloc(size_t bytes, void** out) {
+    RP_TRY(rp_dev_alloc(ctx, bytes, out));
+    bufs.push_back(*out);
+    held += (int64_t)bytes;
+    peak = std::max(peak, held);
+    return RPHIP_OK;
+  }
+  int event(hipEvent_t* e) {
+    RP_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    evs.push_back(*e);
+    return RPHIP_OK;
+  }
+  ~dist_res() {
+    if (su) hipStreamSynchronize(su);
+    if (sc) hipStreamSynchronize(sc);
+    if (ctx) hipStreamSynchronize(ctx->stream);
+    for (auto e : evs) hipEventDestroy(e);
+    for (auto p : bufs) rp_dev_free(ctx, p);
+    if (su) hipStreamDestroy(su);
+    if (sc) hipStreamDestroy(sc);
+  }
+};
+
+int64_t g_dist_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+}  // namespace
+
+extern "C" int rphip_ease_fit_dist_stats(rphip_ctx* ctx, int64_t* out8) {
+  if (!ctx || !out8) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  ::memcpy(out8, g_dist_stats, sizeof(g_dist_stats));
+  return RPHIP_OK;
+}
+
+extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip_csr* X, double l2, double alpha, int32_t panel_tiles,
+                                   rphip_model** out) {
+  if (!ctx || !comm || !X || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (!(l2 > 0.0)) RP_FAIL(RPHIP_EINVAL, "l2 must be > 0 (got %g): G + l2*I has to be positive definite", l2);
+  if (X->xt_row_end >= 0) RP_FAIL(RPHIP_ESTATE, "EASE needs a matrix with all item rows of X^T (not rphip_csr_from_device_rows)");
+  RP_NEED_DEGREES(X);
+  RP_TRY(rp_set_device(ctx));
+  const int n = (int)X->n_items;
+  if (n <= 0) RP_FAIL(RPHIP_EINVAL, "no items");
+  const int W = comm->world, me = comm->rank;
+  const int n128 = (int)(rp_cdiv(n, GT) * GT);
+  if (panel_tiles <= 0) {
+    // 16 tiles (2048 columns: the product kernel's plane path wants K >= 1024 and the pivot chain has to fit beside one update);
+    // fewer when that would leave a rank with fewer than four panels
+    panel_tiles = 16;
+    while (panel_tiles > 1 && n128 / (GT * panel_tiles) < 4 * W) panel_tiles >>= 1;
+  }
+  const int nb = GT * panel_tiles;
+  const int np = (int)rp_cdiv(n, nb);
+  const long long n_pad_ll = (long long)np * nb;
+  if (n_pad_ll > 0x7fffffffLL - nb) RP_FAIL(RPHIP_ELIMIT, "too many items");
+  const int n_pad = (int)n_pad_ll;
+  const int nl = np > me ? (np - me + W - 1) / W : 0;  // own panels: me, me + W, ...
+  const long long ld = (long long)std::max(nl, 1) * nb;
+  auto cnt_lt = [&](int K, int r) { return K > r ? (K - r + W - 1) / W : 0; };  // panels of rank r below K
+  const int slots = (int)rp_cdiv(np, W);                                        // pieces a rank contributes at most
+  const float lam = (float)l2;  // rounded to float32 as the reference does (ease.py:82)
+  hipStream_t st = ctx->stream;
+
+  dist_res R;  // (declared before the model: on a failure the streams are drained before the slab goes)
+  R.ctx = ctx;
+  rphip_model* m = new rphip_model();
+  m->ctx = ctx;
+  m->kind = RPHIP_MODEL_DENSE;
+  m->n_items = n;
+  m->row_end = n;
+  m->ld = ld;
+  m->empty_rows = -1;
+  m->cyc_nb = nb;
+  m->cyc_world = W;
+  m->cyc_rank = me;
+  auto fail = [&](int rc) {
+    if (R.su) hipStreamSynchronize(R.su);
+    if (R.sc) hipStreamSynchronize(R.sc);
+    hipStreamSynchronize(st);
+    rphip_model_destroy(m);
+    return rc;
+  };
+  const size_t slab_bytes = (size_t)n_pad * ld * sizeof(float);
+  {
+    int rc = rp_dev_alloc(ctx, slab_bytes, (void**)&m->B);
+    if (rc != RPHIP_OK) return fail(rc);
+  }
+  float* S = m->B;
+  int rc = RPHIP_OK;
+#define DTRY(expr)                    \
+  do {                                \
+    rc = (expr);                      \
+    if (rc != RPHIP_OK) return fail(rc); \
+  } while (0)
+#define DHIP(expr)                                                                                        \
+  do {                                                                                                    \
+    hipError_t _e = (expr);                                                                               \
+    if (_e != hipSuccess) {                                                                               \
+      rp_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);            \
+      return fail(_e == hipErrorOutOfMemory ? RPHIP_ENOMEM : RPHIP_EHIP);                                 \
+    }                                                                                                     \
+  } while (0)
+
+  DHIP(hipStreamCreateWithFlags(&R.su, hipStreamNonBlocking));
+  DHIP(hipStreamCreateWithFlags(&R.sc, hipStreamNonBlocking));
+  hipStream_t su = R.su, sc = R.sc;
+  // V[b]: the pivot column (n_pad rows) + P (nb rows); (W + 1) nb more rows make it the mirror's staging buffer as well
+  const size_t v_rows = (size_t)n_pad + (size_t)(W + 2) * nb;
+  float *V[2] = {nullptr, nullptr}, *Town[2] = {nullptr, nullptr}, *Vs = nullptr, *Vg = nullptr, *colscale = nullptr;
+  int* info = nullptr;
+  for (int b = 0; b < 2; ++b) {
+    DTRY(R.alloc(v_rows * nb * sizeof(float), (void**)&V[b]));
+    DTRY(R.alloc((size_t)std::max(nl, 1) * nb * nb * sizeof(float), (void**)&Town[b]));
+  }
+  DTRY(R.alloc((size_t)slots * nb * nb * sizeof(float), (void**)&Vs));
+  if (W > 1)
+    DTRY(R.alloc((size_t)W * slots * nb * nb * sizeof(float), (void**)&Vg));
+  else
+    Vg = Vs;
+  DTRY(R.alloc((size_t)ld * sizeof(float) + 256, (void**)&colscale));
+  DTRY(R.alloc(256, (void**)&info));
+  DHIP(hipMemsetAsync(info, 0, 4, st));
+  // plane workspaces of the update stream's products are sized once (a reallocation would pull them from under a running launch)
+  {
+    void* w = nullptr;
+    const size_t wa = std::min<size_t>(ctx->gemm_ws_bytes, std::max<size_t>((size_t)64 << 20, (size_t)n_pad * nb * 4));
+    const size_t wb = std::min<size_t>(ctx->gemm_ws_bytes, std::max<size_t>((size_t)64 << 20, (size_t)ld * nb * 4));
+    DTRY(rp_scratch(ctx, 12, wa, &w));
+    DTRY(rp_scratch(ctx, 13, wb, &w));
+    DTRY(rp_scratch(ctx, 8, wa, &w));  // (the main stream's too: growing them later would make the host wait for the stream)
+    DTRY(rp_scratch(ctx, 9, wb, &w));
+  }
+  hipEvent_t e_pack, e_comm, e_chain[2], e_upd, e_la;
+  DTRY(R.event(&e_pack));
+  DTRY(R.event(&e_comm));
+  DTRY(R.event(&e_chain[0]));
+  DTRY(R.event(&e_chain[1]));
+  DTRY(R.event(&e_upd));
+  DTRY(R.event(&e_la));
+  comm->bytes_recv = comm->bytes_sent = 0;
+  double flop = 0.0;
+
+  // ---- G + l2 I, the own panels: Gram rows of a panel (K4) into V[0], transposed into the panel (G is symmetric)
+  for (int q = 0; q < nl; ++q) {
+    const int p = q * W + me;
+    // (the entry point indexes rows absolutely: row p nb of the matrix is row 0 of the staging buffer)
+    DTRY(rp_ease_gram_rows(ctx, X, (int64_t)p * nb, (int64_t)(p + 1) * nb, n_pad, lam, V[0] - (long long)p * nb * n_pad, n_pad));
+    DTRY(rp_transpose_f32(ctx, V[0], n_pad, nb, n_pad, S + (long long)q * nb, ld));
+  }
+
+  auto gemm = [&](const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, int M, int N, float al, float be,
+                  hipStream_t s, int tri = 0, int m_off = 0, int l0 = 0) -> int {
+    if (M <= 0 || N <= 0) return RPHIP_OK;
+    rp_gemm_args g{};
+    g.A = A;
+    g.lda = lda;
+    g.B = B;
+    g.ldb = ldb;
+    g.C = C;
+    g.ldc = ldc;
+    g.M = M;
+    g.N = N;
+    g.k0 = 0;
+    g.k1 = nb;
+    g.alpha = al;
+    g.beta = be;
+    g.tri = tri;
+    g.m_off = m_off;
+    if (tri) {
+      g.cyc_nb = nb;
+      g.cyc_w = W;
+      g.cyc_r = me;
+      g.cyc_l0 = l0;
+    }
+    g.no_splitk = 1;
+    if (s == su) g.ws_slot = 12;
+    flop += 2.0 * M * (double)N * nb * (tri ? 0.5 : 1.0);
+    return rp_gemm_nt(ctx, g, s);
+  };
+  auto copy2d = [&](const float* src, long long lds_, float* dst, long long ldd, long long rows, int cols, float scale, hipStream_t s) {
+    if (rows <= 0) return;
+    const long long quads = rows * (cols / 4);
+    hipLaunchKernelGGL(k_copy2d, dim3((unsigned)std::min<long long>(8192, rp_cdiv(quads, 256))), dim3(256), 0, s, src, lds_, dst, ldd, rows, cols, scale);
+  };
+  auto timed = [&](hipStream_t s, hipEvent_t* a) {  // (event pairs on another stream than the context's)
+    *a = nullptr;
+    if (hipEventCreate(a) == hipSuccess) hipEventRecord(*a, s);
+  };
+  auto timed_end = [&](hipStream_t s, hipEvent_t a, int slot, double work) {
+    hipEvent_t b = nullptr;
+    if (!a || hipEventCreate(&b) != hipSuccess) return;
+    hipEventRecord(b, s);
+    ctx->pending.push_back({a, b, slot});
+    ctx->tm.launches[slot] += 1;
+    ctx->tm.work[slot] += work;
+  };
+
+  // ---- the sweeps
+  bool upd_pending = false;
+  for (int K = 0; K < np; ++K) {
+    const int cur = K & 1;
+    const int owner = K % W, lpK = K / W;
+    const int cnt = cnt_lt(K, me);                     // own panels left of the pivot: local panels [0, cnt)
+    const int own_K = (owner == me) ? 1 : 0;
+    const long long r0 = (long long)K * nb;
+    float* Vc = V[cur];
+    float* Pc = Vc + (long long)n_pad * nb;            // P = A_KK^-1 rides behind the pivot column
+    float* Tc = Town[cur];
+    hipEvent_t t_chain;
+    timed(st, &t_chain);
+    const double flop0 = flop;
+    // -- chain(K), main stream.  What it reads - row block K of the own panels, panel K - was finished by the look-ahead of K - 1.
+    if (own_K) {
+      copy2d(S + r0 * ld + (long long)lpK * nb, ld, Pc, nb, nb, nb, 1.0f, st);
+      DTRY(rp_spd_inverse(ctx, Pc, nb, nb, info));
+      copy2d(S + (r0 + nb) * ld + (long long)lpK * nb, ld, Vc + (r0 + nb) * nb, nb, (long long)n_pad - r0 - nb, nb, 1.0f, st);
+    }
+    if (cnt > 0)  // pieces V_i = A_Ki^T of the own panels i < K
+      hipLaunchKernelGGL(k_blk_transpose, dim3(nb / 32, nb / 32, cnt), dim3(32, 8), 0, st, S + r0 * ld, ld, (long long)nb, Vs, (long long)nb,
+                         (long long)nb * nb);
+    DHIP(hipGetLastError());
+    const int gslots = (int)rp_cdiv(K, W);  // pieces per rank in this gather (ranks with fewer send filler)
+    if (W > 1) {
+      DHIP(hipEventRecord(e_pack, st));
+      DHIP(hipStreamWaitEvent(sc, e_pack, 0));
+      if (gslots > 0) DTRY(rp_comm_all_gather(comm, Vs, Vg, (int64_t)gslots * nb * nb * 4, sc));
+      // rows (K + 1) nb .. n_pad of V and P behind them, from the owner
+      DTRY(rp_comm_broadcast(comm, Vc + (r0 + nb) * nb, ((int64_t)n_pad - r0) * nb * 4, owner, sc));
+      DHIP(hipEventRecord(e_comm, sc));
+      DHIP(hipStreamWaitEvent(st, e_comm, 0));
+    }
+    if (gslots > 0)
+      hipLaunchKernelGGL(k_unpack_pieces, dim3(64, W * gslots), dim3(256), 0, st, W > 1 ? Vg : Vs, gslots, W, K, nb, Vc, (long long)nb);
+    // T_j = V_j P for the own panels: the pieces in one product, the panels right of the pivot one by one (they are every W-th
+    // block of V); the owner forms T_i for every i > K straight into its panel K (the new column K)
+    DTRY(gemm(Vs, nb, Pc, nb, Tc, nb, cnt * nb, nb, 1.0f, 0.0f, st));
+    if (W == 1) {  // (one rank: the panels right of the pivot are consecutive rows of V)
+      DTRY(gemm(Vc + (r0 + nb) * nb, nb, Pc, nb, Tc + (long long)(K + 1) * nb * nb, nb, (nl - K - 1) * nb, nb, 1.0f, 0.0f, st));
+    } else {
+      for (int q = cnt + own_K; q < nl; ++q) {
+        const long long rows_at = (long long)(q * W + me) * nb;
+        DTRY(gemm(Vc + rows_at * nb, nb, Pc, nb, Tc + (long long)q * nb * nb, nb, nb, nb, 1.0f, 0.0f, st));
+      }
+    }
+    if (own_K) {
+      if (W == 1)  // (one rank: T_own already holds them)
+        copy2d(Tc + (long long)(K + 1) * nb * nb, nb, S + (r0 + nb) * ld + (long long)lpK * nb, ld, (long long)n_pad - r0 - nb, nb, 1.0f, st);
+      else
+        DTRY(gemm(Vc + (r0 + nb) * nb, nb, Pc, nb, S + (r0 + nb) * ld + (long long)lpK * nb, ld, n_pad - (int)r0 - nb, nb, 1.0f, 0.0f, st));
+      copy2d(Pc, nb, S + r0 * ld + (long long)lpK * nb, ld, nb, nb, -1.0f, st);  // A_KK = -P
+    }
+    if (cnt > 0)  // the new row K: A_Ki = T_i^T
+      hipLaunchKernelGGL(k_blk_transpose, dim3(nb / 32, nb / 32, cnt), dim3(32, 8), 0, st, Tc, (long long)nb, (long long)nb * nb, S + r0 * ld, ld,
+                         (long long)nb);
+    DHIP(hipGetLastError());
+    DHIP(hipEventRecord(e_chain[cur], st));
+    // -- look-ahead part of update K (main stream): what chain(K + 1) reads.  It adds to tiles U(K - 1) also adds to: wait for it.
+    if (K + 1 < np) {
+      if (upd_pending) DHIP(hipStreamWaitEvent(st, e_upd, 0));
+      const long long r1 = r0 + nb;
+      DTRY(gemm(Vc + r1 * nb, nb, Tc, nb, S + r1 * ld, ld, nb, cnt * nb, -1.0f, 1.0f, st));  // row block K + 1, own panels < K
+      if ((K + 1) % W == me) {  // panel K + 1 (rows from its diagonal block down)
+        const int q1 = (K + 1) / W;
+        DTRY(gemm(Vc + r1 * nb, nb, Tc + (long long)q1 * nb * nb, nb, S + r1 * ld + (long long)q1 * nb, ld, n_pad - (int)r1, nb, -1.0f, 1.0f, st,
+                  1, (int)r1, q1 * nb));
+      }
+      DHIP(hipEventRecord(e_la, st));
+    }
+    timed_end(st, t_chain, RPHIP_T_SWEEP_CHAIN, flop - flop0);
+    // -- U(K) on the update stream: own panels != K, K + 1, rows outside the blocks K, K + 1
+    {
+      const double flop1 = flop;
+      DHIP(hipStreamWaitEvent(su, e_chain[cur], 0));
+      hipEvent_t t_upd;
+      timed(su, &t_upd);
+      const int own_K1 = (K + 1 < np && (K + 1) % W == me) ? 1 : 0;
+      const int l3 = cnt + own_K + own_K1;        // first local panel right of K + 1
+      const long long r2 = r0 + 2LL * nb;         // first row below the block K + 1
+      // rows above the pivot, panels left of it (lower tiles)
+      DTRY(gemm(Vc, nb, Tc, nb, S, ld, (int)r0, cnt * nb, -1.0f, 1.0f, su, 1, 0, 0));
+      if (r2 < n_pad) {
+        // rows below block K + 1: panels left of the pivot (all tiles) ...
+        DTRY(gemm(Vc + r2 * nb, nb, Tc, nb, S + r2 * ld, ld, n_pad - (int)r2, cnt * nb, -1.0f, 1.0f, su));
+        // ... and panels right of K + 1 (lower tiles)
+        DTRY(gemm(Vc + r2 * nb, nb, Tc + (long long)l3 * nb * nb, nb, S + r2 * ld + (long long)l3 * nb, ld, n_pad - (int)r2, (nl - l3) * nb, -1.0f,
+                  1.0f, su, 1, (int)r2, l3 * nb));
+      }
+      timed_end(su, t_upd, RPHIP_T_SWEEP_UPDATE, flop - flop1);
+      DHIP(hipEventRecord(e_upd, su));
+      upd_pending = true;
+    }
+  }
+  DHIP(hipStreamWaitEvent(st, e_upd, 0));
+  // ---- the upper triangle.  Diagonal blocks: upper tiles from the lower ones; block (i, j), i < j, is block (j, i) of panel i's
+  // owner transposed: W panels at a time (every rank owns one of them) in one personalised exchange.
+  hipEvent_t t_mir;
+  rp_time_begin(ctx, &t_mir);
+  for (int q = 0; q < nl; ++q) {
+    const long long p = (long long)q * W + me;
+    hipLaunchKernelGGL(k_mirror_block, dim3(nb / 32, nb / 32), dim3(256), 0, st, S + p * nb * ld + (long long)q * nb, ld);
+  }
+  DHIP(hipGetLastError());
+  {
+    std::vector<int64_t> soff(W), sby(W), roff(W), rby(W);
+    const int64_t piece = (int64_t)nb * nb * 4;
+    float* sendb = V[0];
+    float* recvb = V[1];
+    for (int g0 = W; g0 < np + W; g0 += W) {  // panels [g0 - W, g0) ... (the first group with a non-empty exchange starts at panel 1)
+      const int base = g0 - W;
+      if (base >= np) break;
+      int64_t so = 0;
+      for (int d = 0; d < W; ++d) {
+        const int j = base + d;  // the panel of rank j % W ... = d only if base % W == 0 (it is: base is a multiple of W)
+        const int c = (j < np) ? cnt_lt(j, me) : 0;
+        soff[d] = so;
+        sby[d] = (int64_t)c * piece;
+        if (c > 0)  // my pieces of row block j, transposed
+          hipLaunchKernelGGL(k_blk_transpose, dim3(nb / 32, nb / 32, c), dim3(32, 8), 0, st, S + (long long)j * nb * ld, ld, (long long)nb,
+                             sendb + so / 4, (long long)nb, (long long)nb * nb);
+        so += sby[d];
+      }
+      const int jm = base + me;  // my panel of this group
+      const int gs = (jm < np) ? (int)rp_cdiv(jm, W) : 0;
+      for (int s = 0; s < W; ++s) {
+        roff[s] = (int64_t)s * gs * piece;
+        rby[s] = (jm < np) ? (int64_t)cnt_lt(jm, s) * piece : 0;
+      }
+      DHIP(hipGetLastError());
+      if (W > 1) {
+        DHIP(hipEventRecord(e_pack, st));
+        DHIP(hipStreamWaitEvent(sc, e_pack, 0));
+      }
+      DTRY(rp_comm_exchange(comm, sendb, soff.data(), sby.data(), recvb, roff.data(), rby.data(), W > 1 ? sc : st));
+      if (W > 1) {
+        DHIP(hipEventRecord(e_comm, sc));
+        DHIP(hipStreamWaitEvent(st, e_comm, 0));
+      }
+      if (gs > 0)
+        hipLaunchKernelGGL(k_unpack_pieces, dim3(64, W * gs), dim3(256), 0, st, recvb, gs, W, jm, nb, S + (long long)(jm / W) * nb, ld);
+      DHIP(hipGetLastError());
+    }
+  }
+  rp_time_end(ctx, t_mir, RPHIP_T_MIRROR, 4.0 * (double)n_pad * ld);
+  // ---- K7 on the panels: B_ij = -P_ij / P_jj * w_j, B_jj = 0, padding zeroed (ease.py:85-90)
+  hipEvent_t t_sc;
+  rp_time_begin(ctx, &t_sc);
+  const rp_cyc cy{nb, W, me};
+  const int n_local = nl * nb;
+  if (n_local > 0) {
+    hipLaunchKernelGGL(k_dist_colscale, dim3((unsigned)rp_cdiv(n_local, 256)), dim3(256), 0, st, S, ld, n, n_local, cy, X->deg, (float)alpha, colscale);
+    hipLaunchKernelGGL(k_dist_scale, dim3(4096), dim3(256), 0, st, S, ld, (long long)n_pad, n, cy, colscale);
+  }
+  DHIP(hipGetLastError());
+  rp_time_end(ctx, t_sc, RPHIP_T_EASE_SCALE, 8.0 * (double)n_pad * n_local);
+  int h_info = 0;
+  DHIP(hipMemcpyAsync(&h_info, info, 4, hipMemcpyDeviceToHost, st));
+  DHIP(hipStreamSynchronize(st));
+  DHIP(hipStreamSynchronize(su));
+  DHIP(hipStreamSynchronize(sc));
+  g_dist_stats[0] = (int64_t)slab_bytes;
+  g_dist_stats[1] = R.peak + (int64_t)ctx->scratch[12].cap + (int64_t)ctx->scratch[13].cap + (int64_t)ctx->scratch[8].cap + (int64_t)ctx->scratch[9].cap +
+                    (int64_t)ctx->scratch[10].cap + (int64_t)ctx->scratch[11].cap + (int64_t)ctx->scratch[5].cap + (int64_t)ctx->scratch[7].cap;
+  g_dist_stats[2] = comm->bytes_recv;
+  g_dist_stats[3] = comm->bytes_sent;
+  g_dist_stats[4] = np;
+  g_dist_stats[5] = nb;
+  g_dist_stats[6] = n_pad;
+  g_dist_stats[7] = (int64_t)flop;
+  if (h_info) {
+    rp_set_error("a pivot block is not positive definite (pivot %d of a diagonal block): G + l2*I is not positive definite", h_info);
+    return fail(RPHIP_ENUMERIC);
+  }
+  // items among the local columns: a prefix (the padding is the tail of the last panel)
+  int64_t n_cols = 0;
+  for (int q = 0; q < nl; ++q) n_cols += std::max<int64_t>(0, std::min<int64_t>(nb, (int64_t)n - (int64_t)(q * W + me) * nb));
+  m->n_cols = n_cols;
+  if (n_cols == 0) {  // this rank owns only padding
+    rphip_model_destroy(m);
+    return RPHIP_OK;
+  }
+  *out = m;
+  return RPHIP_OK;
+#undef DTRY
+#undef DHIP
+}
+
+extern "C" int rphip_model_dense_layout(const rphip_model* m, int64_t* n_local_cols, int64_t* panel, int32_t* world, int32_t* rank,
+                                        int64_t* col_begin) {
+  if (!m) RP_FAIL(RPHIP_EINVAL, "model is NULL");
+  if (m->kind != RPHIP_MODEL_DENSE) RP_FAIL(RPHIP_ESTATE, "model is not dense");
+  if (n_local_cols) *n_local_cols = m->n_cols > 0 ? m->n_cols : m->n_items;
+  if (panel) *panel = m->cyc_nb;
+  if (world) *world = m->cyc_nb ? m->cyc_world : 1;
+  if (rank) *rank = m->cyc_nb ? m->cyc_rank : 0;
+  if (col_begin) *col_begin = m->col_begin;
+  return RPHIP_OK;
+}

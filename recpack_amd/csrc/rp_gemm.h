@@ -1,0 +1,47 @@
+// The NT product of the EASE solve and its callers' view of it (rp_ease.hip implements, rp_ease_dist.hip drives it too).
+#pragma once
+#include "rp_common.h"
+
+constexpr int GT = 128;   // tile (and diagonal block) size
+constexpr int GBK = 16;   // K step
+
+struct rp_gemm_args {
+  const float* A;
+  long long lda;
+  const float* B;
+  long long ldb;
+  float* C;
+  long long ldc;
+  int M, N;          // multiples of 128
+  int k0, k1;        // K range, multiples of 16
+  int kb_m, kb_n;    // k_begin = max(k0, kb_m * (m_off + m0), kb_n * (n_off + n0))
+  int m_off, n_off;
+  int ke_n;          // k_end = min(k1, ke_n * (n_off + n0 + 128)): B is lower triangular (row n holds columns <= n)
+  int tri;           // 0: all tiles; 1: only tiles with n_off + n0 <= m_off + m0; 2: strictly below the diagonal;
+                     // 3: the diagonal tiles only (grid.x = 1), written to C as a stack of blocks [M][128] (ldc = 128)
+  float alpha, beta;
+  // split-K (skinny products with few tiles and a long K): blockIdx.z = s handles K chunk s and writes its partial
+  // tile to part[s][M][N] (alpha = 1, beta = 0); k_splitk_reduce applies alpha / beta to C afterwards
+  float* part;
+  int k_chunk;
+  int kc;            // K steps between two flushes into the master sums (set by rp_gemm_nt from the context: GKC by default)
+  const unsigned* amax;  // k_gemm_nt_h2: device words [max |A|, max |B|] over the ranges read (k_gemm_amax); set by rp_gemm_nt
+  int sw;            // tiles per row of a supertile (64 tiles: sw x 64/sw), 0 = plain row-major 2-D grid; set by rp_gemm_nt
+  // C's columns are LOCAL columns of a block-cyclic layout (rp_ease_dist.hip): panels of cyc_nb columns, panel p of the matrix on
+  // rank p % cyc_w at local panel p / cyc_w.  Local column cyc_l0 + n0 of rank cyc_r is then global column
+  // ((l / cyc_nb) * cyc_w + cyc_r) * cyc_nb + l % cyc_nb, which is what the `tri` tests compare with the row.  0 = off.
+  int cyc_nb, cyc_w, cyc_r, cyc_l0;
+  int no_splitk;     // never split K (the product runs beside others that use the shared partial-sum scratch)
+  int ws_slot;       // scratch slots ws_slot, ws_slot + 1 hold this product's plane workspaces (0: 8 / 9 on the context's stream, 10 / 11 elsewhere)
+};
+
+// C = alpha * A * B^T + beta * C on `st` (the context's stream when NULL)
+int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st = nullptr, float* part_at = nullptr);
+// In-place inverse of the SPD matrix A (n_pad x n_pad, a multiple of 128; reads the lower triangle).  info_dev == NULL: the
+// call waits for the result and fails with RPHIP_ENUMERIC when a pivot is not positive; otherwise nothing is waited for and a
+// failing pivot's index + 1 is left in *info_dev (device int, not cleared here).
+int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_dev = nullptr);
+// rows [r0, r1) of G + lam I (identity block on the padding rows >= n_items) into G (row-major, ld), all n_cols columns
+int rp_ease_gram_rows(rphip_ctx* ctx, const rphip_csr* X, int64_t r0, int64_t r1, int64_t n_cols, float lam, float* G, int64_t ld);
+int rp_transpose_f32(rphip_ctx* ctx, const float* src, int64_t lds, int64_t rows, int64_t cols, float* dst, int64_t ldd, hipStream_t st = nullptr);
+int rp_dense_count_empty(rphip_ctx* ctx, rphip_model* m);

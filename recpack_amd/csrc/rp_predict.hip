@@ -78,6 +78,8 @@ struct rp_pred_params {
   const float* dense_B;   // K9: dense model (EASE), row-major with leading dimension dense_ld; NULL for neighbour lists
   long long dense_ld;
   int col_begin;          // dense column slab: column 0 of dense_B is item col_begin (n_items = the slab's width then)
+  int cyc_nb, cyc_w, cyc_r;  // cyc_nb > 0: the slab's columns are block-cyclic panels (rphip_ease_fit_dist): local column l is item
+                             // ((l / cyc_nb) * cyc_w + cyc_r) * cyc_nb + l % cyc_nb
   const uint8_t* keep;    // optional item filter (mode 0): only items with keep[j] != 0 are candidates
   int n_items, n_tiles, tile_w, K, Kp, exclude_history;
   rp_fix_scale fix;       // neighbour lists: scale of the fixed-point sums
@@ -94,16 +96,27 @@ struct rp_pred_params {
   double* full_val;
 };
 
+// item of a slab's local column / local column of an item (-1: not in this slab)
+__device__ __forceinline__ int rp_pred_l2g(const rp_pred_params& P, int l) {
+  return P.cyc_nb ? ((l / P.cyc_nb) * P.cyc_w + P.cyc_r) * P.cyc_nb + l % P.cyc_nb : P.col_begin + l;
+}
+__device__ __forceinline__ int rp_pred_g2l(const rp_pred_params& P, int g) {
+  if (!P.cyc_nb) return g - P.col_begin;
+  const int p = g / P.cyc_nb;
+  return (p % P.cyc_w == P.cyc_r) ? (p / P.cyc_w) * P.cyc_nb + g % P.cyc_nb : -0x40000000;
+}
+
 // tile of f32 scores (dense models) or of fixed-point sums (neighbour lists)
 template <bool DENSE>
 struct rp_score_src {
   const void* acc_;
-  int t0;
+  int t0;  // first LOCAL column of the tile (ties go to the smaller column: local order is item order)
   const uint8_t* keep;
   int sh;  // leading key bits shared by all candidates (rp_key_prefix, rp_wave.h): the radix digits start below them
+  const rp_pred_params* P;
   __device__ __forceinline__ bool valid(int w) const {
     const bool nz = DENSE ? ((const float*)acc_)[w] != 0.0f : ((const unsigned long long*)acc_)[w] != 0ull;
-    return nz && (!keep || keep[t0 + w] != 0);
+    return nz && (!keep || keep[rp_pred_l2g(*P, t0 + w)] != 0);
   }
   __device__ __forceinline__ uint64_t key(int w) const {
     if (DENSE) {  // order-preserving map of a float (any sign) to u32, placed in the high half
@@ -233,7 +246,7 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_tile(rp_pred_params
       __syncthreads();
       if (P.exclude_history) {
         for (int h = hs + tid; h < he; h += RP_PRED_THREADS) {
-          const int j = P.x_idx[h] - P.col_begin - t0;
+          const int j = rp_pred_g2l(P, P.x_idx[h]) - t0;
           if ((unsigned)j < (unsigned)n_cols) clear(j);
         }
         __syncthreads();
@@ -244,7 +257,7 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_tile(rp_pred_params
         continue;
       }
       // ---- select (top-Kp: the scores of one user share their sign and most exponent bits - dropped first)
-      rp_score_src<DENSE> src{smem, t0 + P.col_begin, P.mode == 0 ? P.keep : nullptr, 0};
+      rp_score_src<DENSE> src{smem, t0, P.mode == 0 ? P.keep : nullptr, 0, &P};
       if (P.mode == 0) {
         uint32_t* s_red = reinterpret_cast<uint32_t*>(&sel.misc[RPS_USER]);
         if (tid == 0) {
@@ -259,13 +272,13 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_tile(rp_pred_params
       if (P.mode == 0) {
         const int64_t o = (T == 1) ? (int64_t)ul * P.Kp : ((int64_t)ul * T + tile) * P.Kp;
         rp_select_emit<RP_PRED_THREADS>(n_cols, sel, [&](int pos, int w) {
-          P.out_idx[o + pos] = P.col_begin + t0 + w;
+          P.out_idx[o + pos] = rp_pred_l2g(P, t0 + w);
           P.out_val[o + pos] = (float)score(w);
         });
         if (tid == 0) P.out_nnz[(T == 1) ? ul : ul * T + tile] = kp;
       } else if (P.mode == 2) {
         rp_select_emit<RP_PRED_THREADS>(n_cols, sel, [&](int pos, int w) {
-          P.full_idx[off + pos] = P.col_begin + t0 + w;
+          P.full_idx[off + pos] = rp_pred_l2g(P, t0 + w);
           P.full_val[off + pos] = score(w);
         });
         off += kp;
@@ -301,8 +314,13 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_merge(const int32_t
                                                                   const int32_t* __restrict__ cand_nnz, int n_tiles, int Kp, int n_users,
                                                                   const int32_t* __restrict__ user_list, const int32_t* __restrict__ n_list,
                                                                   int32_t* __restrict__ out_idx, float* __restrict__ out_val,
-                                                                  int32_t* __restrict__ out_nnz) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+                                                                  int32_t* __restrict__ out_nnz, int sort_cols) {
+  // sort_cols: the lists are not consecutive column ranges (the ranks' block-cyclic panels): the selected entries are ranked by
+  // column before they are written (Kp * 8 more bytes of LDS in front); otherwise list order is column order
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
+  char* smem = smem_all + (sort_cols ? (size_t)Kp * 8 : 0);
+  int32_t* scol = reinterpret_cast<int32_t*>(smem_all);
+  float* sval = reinterpret_cast<float*>(smem_all + (size_t)Kp * 4);
   const int T = n_tiles, cap = T * Kp;
   int32_t* lcol = reinterpret_cast<int32_t*>(smem);
   float* lval = reinterpret_cast<float*>(smem + (size_t)cap * 4);
@@ -334,10 +352,25 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_merge(const int32_t
     __syncthreads();
     rp_flist_src src{lcol, lval, n};
     const int kp = rp_select_topk<RP_PRED_THREADS>(src, n, Kp, sel);
-    rp_select_emit<RP_PRED_THREADS>(n, sel, [&](int pos, int w) {
-      out_idx[(int64_t)ul * Kp + pos] = lcol[w];
-      out_val[(int64_t)ul * Kp + pos] = lval[w];
-    });
+    if (sort_cols) {
+      rp_select_emit<RP_PRED_THREADS>(n, sel, [&](int pos, int w) {
+        scol[pos] = lcol[w];
+        sval[pos] = lval[w];
+      });
+      __syncthreads();
+      for (int p = tid; p < kp; p += RP_PRED_THREADS) {  // (columns are distinct: every item is in one list)
+        const int c = scol[p];
+        int r = 0;
+        for (int q = 0; q < kp; ++q) r += scol[q] < c;
+        out_idx[(int64_t)ul * Kp + r] = c;
+        out_val[(int64_t)ul * Kp + r] = sval[p];
+      }
+    } else {
+      rp_select_emit<RP_PRED_THREADS>(n, sel, [&](int pos, int w) {
+        out_idx[(int64_t)ul * Kp + pos] = lcol[w];
+        out_val[(int64_t)ul * Kp + pos] = lval[w];
+      });
+    }
     if (tid == 0) out_nnz[ul] = kp;
   }
 }
@@ -1139,9 +1172,16 @@ static void rp_pred_fill(rp_pred_params& P, const rphip_model* m, const rphip_cs
   P.keep = nullptr;
   P.n_items = (int)X->n_items;
   P.col_begin = 0;
+  P.cyc_nb = P.cyc_w = P.cyc_r = 0;
   if (m->kind == RPHIP_MODEL_DENSE && m->n_cols > 0) {  // a column slab: the kernel walks the slab's own columns
     P.n_items = (int)m->n_cols;
     P.col_begin = (int)m->col_begin;
+    if (m->cyc_nb > 0) {
+      P.cyc_nb = m->cyc_nb;
+      P.cyc_w = m->cyc_world;
+      P.cyc_r = m->cyc_rank;
+      P.col_begin = 0;
+    }
     P.n_tiles = (int)std::max<int64_t>(1, rp_cdiv(m->n_cols, RP_TILE_MAX));
     P.tile_w = (int)(rp_cdiv(rp_cdiv(m->n_cols, P.n_tiles), 64) * 64);
   } else if (m->kind == RPHIP_MODEL_DENSE) {
@@ -1337,7 +1377,7 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
     RP_HIP(hipFuncSetAttribute((const void*)k_predict_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
     const int mg = (int)std::min<int64_t>(n, (int64_t)ctx->n_cu * 8);
     hipLaunchKernelGGL(k_predict_merge, dim3(mg), dim3(RP_PRED_THREADS), mlds, st, cand_idx, cand_val, cand_nnz, T, Kp, (int)n,
-                       nullptr, nullptr, idx_dev, val_dev, nnz_dev);
+                       nullptr, nullptr, idx_dev, val_dev, nnz_dev, 0);
   }
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, RPHIP_T_PREDICT, rp_pred_work(Xpred, model, n, Kp));
@@ -1356,7 +1396,7 @@ extern "C" int rphip_predict_merge_topk(rphip_ctx* ctx, int32_t n_lists, int32_t
   if (n_lists > RPS_MISC_INTS - RPS_USER - 1) RP_FAIL(RPHIP_ELIMIT, "at most %d candidate lists per user (got %d)", RPS_MISC_INTS - RPS_USER - 1, n_lists);
   RP_TRY(rp_set_device(ctx));
   if (n_users == 0) return RPHIP_OK;
-  const size_t mlds = (size_t)n_lists * Kp * 8 + rp_select_smem_bytes(n_lists * Kp);
+  const size_t mlds = (size_t)n_lists * Kp * 8 + rp_select_smem_bytes(n_lists * Kp) + (size_t)Kp * 8;
   if (mlds > 160 * 1024 || n_lists * Kp >= RPS_FLAG)
     RP_FAIL(RPHIP_ELIMIT, "Kp=%d with %d lists needs %zu bytes of LDS for the merge", Kp, n_lists, mlds);
   hipStream_t st = ctx->stream;
@@ -1367,7 +1407,7 @@ extern "C" int rphip_predict_merge_topk(rphip_ctx* ctx, int32_t n_lists, int32_t
   hipEvent_t ev;
   rp_time_begin(ctx, &ev);
   hipLaunchKernelGGL(k_predict_merge, dim3(mg), dim3(RP_PRED_THREADS), mlds, st, cand_idx_dev, cand_val_dev, cand_nnz_dev, (int)n_lists, (int)Kp,
-                     (int)n_users, nullptr, nullptr, idx_dev, val_dev, nnz_dev);
+                     (int)n_users, nullptr, nullptr, idx_dev, val_dev, nnz_dev, 1);
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, RPHIP_T_PREDICT, 16.0 * (double)n_users * n_lists * Kp);
   return RPHIP_OK;

@@ -148,8 +148,52 @@ def fit_itemknn_sharded(ctx, dX, K: int, parts: Sequence[Tuple[int, int]], devic
     return _lib.Model.from_topk_device(ctx, idx_f, val_f, nnz_f)
 
 
-def ease_fit_sharded(ctx, dX, l2: float, alpha: float, device, group=None, panel_tiles=None):
-    """EASE fit (recpack/algorithms/ease.py:63-95) with the n x n matrix SHARDED BY ITEM COLUMNS over the ranks of ``group``,
+def make_comm(ctx, device, group=None, transport: str = "auto"):
+    """The communicator the library's distributed entry points run on (``_lib.Comm``).  ``transport``: "rccl" = the library's
+    own RCCL communicator (one rank per GPU, RCCL over xGMI; the default whenever the group's backend is nccl), "torch" =
+    callbacks through the torch.distributed group (any backend - what the gloo tests use), "auto" picks by the backend."""
+    import torch.distributed as dist
+
+    from recpack_amd import _lib
+
+    if transport == "auto":  # (outside any process group: a one-rank communicator whose operations are never called)
+        transport = "rccl" if (dist.is_initialized() and dist.get_backend(group) == "nccl") else "torch"
+    if transport == "rccl":
+        return _lib.Comm.rccl(ctx, group)
+    if transport == "torch":
+        return _lib.Comm.torch(ctx, device, group)
+    raise ValueError(f"unknown transport {transport!r}")
+
+
+def ease_fit_sharded(ctx, dX, l2: float, alpha: float, device, group=None, panel_tiles: int = 0, comm=None):
+    """EASE fit (recpack/algorithms/ease.py:63-95) with the n x n matrix SHARDED IN MEMORY over the ranks of ``group``, one GPU
+    each - the whole solve inside the library (rphip_ease_fit_dist): 1-D block-cyclic column panels,
+    symmetric block Gauss-Jordan sweeps on the lower triangle (n^3 / world flop per rank - the count of potrf + trtri + lauum -
+    every pivot block inverted by the blocked MFMA Cholesky), the pivot column gathered / broadcast on a communication stream
+    while the previous update still runs (look-ahead of one panel), no host read-back before the end, the upper triangle filled
+    by one personalised exchange per ``world`` panels, K7 on the panels.  Collectives: the library's own RCCL communicator
+    (``make_comm``; callbacks through torch.distributed when the backend is not nccl).  No torch tensor is allocated.
+    Returns (model with this rank's columns of B - ``model.local_columns()`` - or None when the rank owns only padding,
+    layout dict of ``Model.dense_layout`` or None)."""
+    from recpack_amd import _lib
+
+    own = comm is None
+    if own:
+        comm = make_comm(ctx, device, group)
+    try:
+        m = _lib.ease_fit_dist(ctx, comm, dX, l2, alpha, panel_tiles)
+    finally:
+        if own:
+            comm.close()
+    return m, (m.dense_layout() if m is not None else None)
+
+
+def ease_fit_sweeps(ctx, dX, l2: float, alpha: float, device, group=None, panel_tiles=None):
+    """Round 2's column-sharded route, kept as the fallback: contiguous column slabs in torch tensors, FULL block sweeps driven
+    from Python between torch.distributed collectives (2 n^3 / world flop, one blocking broadcast and one host read-back per
+    pivot).  ``ease_fit_sharded`` is the route to use.
+
+    EASE fit (recpack/algorithms/ease.py:63-95) with the n x n matrix SHARDED BY ITEM COLUMNS over the ranks of ``group``,
     one GPU each.  Rank r owns the columns [r w, (r + 1) w) of everything, w = n_pad / world: a slab
     of n_pad x w floats - G + l2 I first, -(G + l2 I)^-1 after the solve, its columns of B at the end.  Peak memory per rank:
     the slab (n^2 * 4 / world bytes) + two panels of n_pad x (128 panel_tiles) + a Gram staging buffer of the same order.

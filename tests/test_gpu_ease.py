@@ -313,17 +313,19 @@ def _run_dist_check(nproc, args=()):
     return subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
 
 
-@pytest.mark.parametrize("nproc,shape", [(2, (4000, 700, 0.02, 2)), (3, (3000, 1000, 0.01, 3)), (2, (3000, 1000, 0.01, 16)),
-                                         (3, (12000, 3000, 0.005, 4))])  # (the last one is large enough for the memory bound to apply)
+@pytest.mark.parametrize("nproc,shape", [(2, (4000, 700, 0.02, 2, 1)), (3, (3000, 1000, 0.01, 3, 2)), (2, (3000, 1000, 0.01, 16, 3)),
+                                         (3, (2000, 200, 0.03, 1, 1)),      # two panels for three ranks: one rank owns nothing
+                                         (3, (12000, 3000, 0.005, 4, 4))])  # 6 panels of 512 columns, then the library's own choice
 def test_ease_fit_sharded_multi_rank(hip, nproc, shape):
-    """Both multi-GPU routes of recpack_amd.dist with several ranks (gloo, sharing this box's GPU):
-    ease_fit_replicated gives every rank the B of the single-GPU solve (2e-5) and the same top-K; ease_fit_sharded gives every
-    rank its COLUMNS of B (1e-4) within n_pad^2 * 4 * (1 / world + 0.1) bytes of device memory, and predict_topk_sharded (local
-    top-Kp per column slab, all-gather, merge) reproduces the single-GPU top-K.  The fourth number is the panel width in
-    tiles: 2 and 3 give several panels at these sizes (the last one short), 16 is the replicated route's default."""
+    """The multi-GPU routes of recpack_amd.dist with several ranks (gloo, sharing this box's GPU).
+    ease_fit_sharded - the library's distributed solve (rphip_ease_fit_dist: block-cyclic panels, symmetric block sweeps, the
+    collectives behind the communicator's callback transport) - gives every rank its COLUMNS of B (1e-4 of the single-GPU B)
+    without a single torch allocation, and predict_topk_sharded (local top-Kp per rank, all-gather, merge) reproduces the
+    single-GPU top-K; ease_fit_replicated and ease_fit_sweeps (round 2's routes) stay green.  Fourth number: panel width of the
+    replicated route, fifth: of the distributed solve's first pass (the second pass lets the library choose)."""
     r = _run_dist_check(nproc, shape)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count("top-20 agreement") == 4 * nproc
+    assert r.stdout.count("top-20 agreement") == 6 * nproc
 
 
 def test_ease_fit_sharded_one_rank(hip):
@@ -346,10 +348,16 @@ def test_ease_fit_sharded_one_rank(hip):
     # the column-sharded route on one rank (one slab = the whole matrix): block sweeps, K7 on the slab, predict + merge
     single = _lib.ease_fit(ctx, dX, 20.0, 0.0)
     want = _lib.predict_topk(ctx, single, dX, 30, exclude_history=True)
-    for panel_tiles in (8, 5, 1):
-        ms, (c0, nc) = rdist.ease_fit_sharded(ctx, dX, 20.0, 0.0, dev, panel_tiles=panel_tiles)
-        assert (c0, nc) == (0, 1500)
-        B = ms._keep[:1500, :1500].cpu().numpy()
+    for panel_tiles in (8, 5, 1, 0, -1):  # -1: round 2's sweeps (the fallback)
+        if panel_tiles < 0:
+            ms, (c0, nc) = rdist.ease_fit_sweeps(ctx, dX, 20.0, 0.0, dev, panel_tiles=5)
+            assert (c0, nc) == (0, 1500)
+            B = ms._keep[:1500, :1500].cpu().numpy()
+        else:
+            ms, lay = rdist.ease_fit_sharded(ctx, dX, 20.0, 0.0, dev, panel_tiles=panel_tiles)
+            assert lay["n_local"] == 1500 and lay["world"] == 1 and (ms.local_columns() == np.arange(1500)).all()
+            ptr, _, ld = ms.dense_device_ptr()
+            B = torch.as_tensor(rdist._DevPtr(ptr, (1500, ld), "<f4", ms), device=dev)[:, :1500].cpu().numpy()
         assert rel_max(B, ref) <= EASE_TOL, (panel_tiles, rel_max(B, ref))
         users, pi, pv, pn = rdist.predict_topk_sharded(ctx, ms, dX, 30, dev, exclude_history=True, user_chunk=2500)
         assert (users.cpu().numpy() == np.arange(6000)).all()
