@@ -6,19 +6,22 @@
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own N ranks (a child
 `python -m torch.distributed.run`, before this process touches the GPU) and forwards rank 0's JSON line and the
 children's exit code; under torchrun (the driver's multi-GPU command) it is one of the ranks.
-`value` is the timed ItemKNN step (below); `value_ease` is the EASE fit + predict wall time on the same matrix, timed
-once after a warm-up fit (a step of 10 s cannot be repeated K times inside a bench that must finish in minutes).
+`value` = seconds per step; a step is ONE pass of the whole metric - ItemKNN fit + predict AND EASE fit + predict - over one
+synthetic interaction matrix that is already resident in HBM:
+  ItemKNN: K0 (X -> X^T, degrees) + K1-K3 (Gram + cosine + top-K, K=200) [+ all-gather of the neighbour lists when N > 1]
+           + K8 (predict with fused top-100 for every user)                                  -> `value_itemknn`
+  EASE:    K4 (dense Gram) + K5/K6 (the solve) + K7 + K9 (predict with fused top-100)        -> `value_ease`
+Default workload: C4 = 1M users x 100K items, 50M interactions - the shape BASELINE.json's metric is quoted on; it fits one
+MI355X.  With N > 1 the same matrix is sharded (ItemKNN: item rows for fit, users for predict; EASE: the library's distributed
+solve on block-cyclic column panels, rphip_ease_fit_dist, and the column-sharded predict + merge): strong scaling.
 
-A step is ONE pass of the hot path over one synthetic interaction matrix that is already resident in HBM:
-K0 (X -> X^T, degrees) + K1-K3 (Gram + cosine + top-K, K=200) [+ all-gather of the neighbour lists when N > 1]
-+ K8 (predict with fused top-100 for every user).  Default workload: C4 = 1M users x 100K items, 50M
-interactions - the shape BASELINE.json's metric is quoted on; it fits one MI355X.  With N > 1 the same
-matrix is sharded (item rows for fit, users for predict): strong scaling.
-
-Prints one JSON line (rank 0).  `roofline` prices the kernel with the longest launch of the step with its algorithmic
-byte model (4*P-model for the SpGEMM instances, 8*K*nnz-model for predict) against 8 TB/s - `legs`
-holds all three kernels, `spgemm_all_kernels` the whole K1-K3 group; `cpu_baseline` times the numpy/scipy oracle
-(a port of the reference's scipy path, 1 thread) on a bounded sample and scales it to the full workload.
+Prints one JSON line (rank 0).  `roofline` prices the HBM-bound kernel with the longest launch (K8) with its algorithmic byte
+model (4*P-model for the SpGEMM instances, 8*K*nnz-model for predict) against 8 TB/s - `legs` holds all three
+ItemKNN kernels, `spgemm_all_kernels` the whole K1-K3 group; `roofline_ease` prices the solve against the dense 16-bit MFMA peak
+(three fp16 plane products per fp32-equivalent product) and states the plain n^3 model beside it; `cpu_baseline` = the
+reference-shaped route (sklearn cosine + per-row argpartition loop, float64 np.linalg.inv) timed on a bounded sample on the host's
+cores and scaled, with the oracle's own vectorised route under `port`.  `status` is "ok" or names what failed; a failed or
+timed-out run exits non-zero.
 """
 import argparse
 import json
@@ -44,20 +47,20 @@ def parse():
     ap.add_argument("--K", type=int, default=200)
     ap.add_argument("--Kp", type=int, default=100)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="0 disables the CPU leg")
-    ap.add_argument("--ease-config", default="C4,C3",
-                    help="configs of the EASE legs (N=1 only), comma separated: the first goes to `ease`, others to `ease_<cfg>`; "
-                         "'none' disables them")
+    ap.add_argument("--ease-config", default="C3",
+                    help="extra EASE legs outside the timed step (N=1 only), comma separated configs -> `ease_<cfg>`; 'none' disables them")
+    ap.add_argument("--no-ease-in-step", dest="ease_in_step", action="store_false", default=True,
+                    help="time the ItemKNN half alone (the step then leaves EASE out and `status` says so)")
     ap.add_argument("--l2", type=float, default=200.0)
     ap.add_argument("--tars-config", default="C4",
                     help="config of the time-aware leg (N=1 only): TARSItemKNN-style valued cosine fit + decayed predict on the "
                          "config's matrix with seeded timestamps; 'none' skips it")
-    ap.add_argument("--ease-sharded", dest="ease_sharded", action="store_true", default=True,
-                    help="N > 1: also time the multi-GPU EASE fit (recpack_amd.dist.ease_fit_sharded) + user-sharded predict on the "
-                         "first config of --ease-config (default on; --no-ease-sharded skips it)")
-    ap.add_argument("--no-ease-sharded", dest="ease_sharded", action="store_false")
-    ap.add_argument("--ease-timeout", type=float, default=240.0,
-                    help="N > 1: seconds the sharded EASE leg may take; past it every rank prints / exits WITHOUT the leg, so the "
-                         "ItemKNN scaling line can never be held up by it")
+    ap.add_argument("--ease-transport", default="auto", choices=["auto", "rccl", "torch"],
+                    help="N > 1: collectives of the distributed EASE solve - the library's own RCCL communicator (auto with the nccl "
+                         "backend) or callbacks through torch.distributed")
+    ap.add_argument("--timeout", type=float, default=1500.0,
+                    help="seconds the timed region (warm-up + steps) may take; past it every rank prints what it has with status "
+                         "'timeout' and exits with code 3")
     return ap.parse_args()
 
 
@@ -228,7 +231,7 @@ def ease_leg(args, ctx, device, Kp, config, repeats):
         "predict_s": round(t_pred, 4),
         "fit_plus_predict_s": round(t_fit + t_pred, 4),
         "wall_s_all_runs": walls,  # [warm-up, timed ...]: the warm-up pays the first allocation of B
-        "kernel_s_in_fit": round(sum(v["ms"] for k, v in tm.items() if k != "predict") / 1e3, 4),  # HIP-event time inside the fit wall time
+        "kernel_s_in_fit": round(sum(v["ms"] for k, v in tm.items() if not k.startswith("predict")) / 1e3, 4),  # HIP-event time inside the fit wall time
         "phases_ms": {k: round(v["ms"], 3) for k, v in tm.items() if v["launches"]},
         # the solve's products run on the 16-bit matrix pipe with fp32 operands cut into two fp16 planes: THREE fp16 MFMA products per
         # fp32-equivalent product, so the matrix pipe executes 3 n^3 fp16 flop for the n^3 of the model - priced against the dense
@@ -306,40 +309,39 @@ def tars_leg(args, ctx, device, Kp, config):
     }
 
 
-def ease_leg_sharded(args, ctx, device, Kp, config, world, rank):
-    """EASE over all ranks with B sharded by item columns (recpack_amd/dist.py::ease_fit_sharded: in-place block sweeps, one panel
-    broadcast per pivot block) and the column-sharded predict (local top-Kp per rank, all-gather, merge).  Runs on EVERY rank."""
-    import torch
-    import torch.distributed as dist
-
-    from recpack_amd import _lib, dist as rdist
-    from recpack_amd.synth import CONFIG_SEED_BASE, CONFIGS, powerlaw_csr
-
-    U, I, dens = CONFIGS[config]
-    ip, ix = powerlaw_csr(U, I, dens, CONFIG_SEED_BASE + int(config[1:]), device=device)
-    dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
-    dist.barrier()
-    torch.cuda.synchronize()
-    torch.cuda.reset_peak_memory_stats()
-    t0 = time.perf_counter()
-    model, (c0, nc) = rdist.ease_fit_sharded(ctx, dX, args.l2, 0.0, device)
-    torch.cuda.synchronize()
-    dist.barrier()
-    t_fit = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    rdist.predict_topk_sharded(ctx, model, dX, Kp, device, exclude_history=False)
-    torch.cuda.synchronize()
-    dist.barrier()
-    t_pred = time.perf_counter() - t0
-    t = torch.tensor([t_fit, t_pred, float(torch.cuda.max_memory_allocated())], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    n_pad = -(-I // (128 * world)) * 128 * world
-    return {"workload": f"{config}: EASE l2={args.l2}, {U} users x {I} items over {world} GPUs, B sharded by item columns (block sweeps, one panel "
-                        f"broadcast per pivot block), predict + top-{Kp} on the column slabs + merge",
-            "fit_s": round(float(t[0]), 4), "predict_s": round(float(t[1]), 4), "fit_plus_predict_s": round(float(t[0] + t[1]), 4),
-            "flops_model": "2 n^3 (block sweeps update both triangles) + 2 n^2 nb per rank for the panel products",
-            "TFLOPs_aggregate": round(2.0 * n_pad ** 3 / float(t[0]) / 1e12, 2),
-            "peak_torch_bytes_per_rank": int(t[2]), "slab_bytes_per_rank": int(n_pad * (n_pad // world) * 4)}
+def roofline_ease(tm, I, world, steps, dist_stats, nnz, U, Kp):
+    """The EASE solve against the MFMA peak.  One rank: K5 (Cholesky) + K6 (inverse) of rphip_ease_fit, n^3 flop by SURVEY.md
+    section 8(d) (n padded to 128).  N > 1: the symmetric block sweeps of rphip_ease_fit_dist, the rank's own products as counted
+    by the library (n^3 / world + the T products).  The products run on the 16-bit matrix pipe with each fp32 operand cut into two
+    fp16 planes: THREE fp16 MFMA products per fp32-equivalent product - `achieved` counts those against the dense fp16 peak,
+    `frac_n3_model` is the plain flop model against the same peak, `fp32_equivalent` the same time against the fp32 MFMA peak."""
+    if world == 1:
+        n_pad = (I + 127) // 128 * 128
+        solve_ms = (tm["cholesky"]["ms"] + tm["inverse"]["ms"]) / steps
+        flop = float(n_pad) ** 3
+        what = "k_gemm_hp16 + k_split_planes (large products) / k_gemm_nt_h2 (skinny ones): K5 Cholesky + K6 inverse"
+    else:
+        solve_ms = tm["sweep_update"]["ms"] / steps  # the update stream's products (the chain runs beside them on other streams)
+        flop = float(dist_stats["flop"])
+        what = (f"k_gemm_hp16 + k_split_planes: the rank's symmetric rank-{dist_stats['panel']} updates of rphip_ease_fit_dist "
+                f"({dist_stats['pivots']} pivots; kernel time of the update stream, the pivot chain overlaps it)")
+    tf = flop / (solve_ms * 1e-3) / 1e12 if solve_ms > 0 else 0.0
+    k9 = tm["predict_dense"]
+    out = {
+        "kernel": what + " (v_mfma_f32_16x16x32_f16 on fp32 operands cut into two fp16 planes, fp32 accumulate, compensated master sums)",
+        "bound": "mfma", "achieved": round(3.0 * tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(3.0 * tf / MFMA_BF16_PEAK_TFLOPS, 4),
+        "flops_model": "3 fp16 plane products x the fp32-equivalent flop (n^3 per solve: Cholesky n^3/3 + inverse 2n^3/3, n padded to 128)",
+        "frac_n3_model": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+        "fp32_equivalent": {"achieved": round(tf, 2), "peak_fp32_mfma": MFMA_F32_PEAK_TFLOPS, "frac_of_fp32_mfma_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 4)},
+        "solve_ms_per_step": round(solve_ms, 2), "flop_per_solve": flop,
+    }
+    if k9["launches"]:  # K9 beside it: rows of B streamed, 4*I*nnz bytes by the no-reuse model of SURVEY.md 8(d)
+        ms = k9["ms"] / steps
+        by = 4.0 * I * nnz / world + 8.0 * U * Kp
+        out["k9_predict"] = {"ms_per_step": round(ms, 2), "algorithmic_bytes": by, "GBps_no_reuse_model": round(by / (ms * 1e-3) / 1e9, 1),
+                             "TFLOPs": round(2.0 * I * nnz / world / (ms * 1e-3) / 1e12, 2)}
+    return out
 
 
 def pmc_traffic(config, kernel, world):
@@ -352,13 +354,16 @@ def pmc_traffic(config, kernel, world):
     if world != 1 or not found:
         return None, "no PMC pass committed for this configuration"
     path = found[-1]  # the latest round's pass (a kernel that was renamed since is simply not found: traffic = null)
+    lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "recpack_amd", "csrc", "rp_predict.hip")
+    stale = os.path.exists(lib) and os.path.getmtime(path) < os.path.getmtime(lib)
     want = kernel.replace(" ", "")
     for name, c in json.load(open(path)).items():
         if want in name.replace(" ", "") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             f, w = c["FETCH_SIZE"]["avg_per_dispatch"], c["WRITE_SIZE"]["avg_per_dispatch"]
             return (2.0 * f + w) * 1024.0, (f"profiles/{os.path.basename(path)}: (2 x FETCH_SIZE {f:.0f} KiB + WRITE_SIZE {w:.0f} KiB) "
                                             "per launch; the x2 is the guide's gfx950 correction for wide reads and is an upper "
-                                            "bound for this kernel's 16-B gathers (uncalibrated width)")
+                                            "bound for this kernel's 16-B gathers (uncalibrated width)" +
+                                            ("; NOTE: the pass is older than the kernel's source - re-run tools/pmc_traffic.sh" if stale else ""))
     return None, "kernel not in the PMC pass"
 
 
@@ -383,6 +388,8 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
+    import threading
+
     import torch
     import torch.distributed as dist
 
@@ -433,10 +440,25 @@ def main():
     out_idx = torch.empty((ue - ub, Kp), dtype=torch.int32, device=device)
     out_val = torch.empty((ue - ub, Kp), dtype=torch.float32, device=device)
     out_nnz = torch.empty((ue - ub,), dtype=torch.int32, device=device)
+    ease_on = bool(args.ease_in_step)
+    e_idx = e_val = e_nnz = None
+    if ease_on and world == 1:
+        e_idx = torch.empty((U, Kp), dtype=torch.int32, device=device)
+        e_val = torch.empty((U, Kp), dtype=torch.float32, device=device)
+        e_nnz = torch.empty((U,), dtype=torch.int32, device=device)
+    comm = rdist.make_comm(ctx, device, transport=args.ease_transport) if (ease_on and world > 1) else None
 
     keep = {}
+    parts = {"itemknn": 0.0, "ease_fit": 0.0, "ease_predict": 0.0}
+    state = {"phase": "warm-up", "timing": False}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     def step():
+        t0 = time.perf_counter()
         if world > 1:  # K0 with the degree pass sharded by item rows + one all-reduce of the degree vector
             dX = rdist.csr_for_shard(ctx, indptr_t, indices_t, (U, I), row_parts[rank], device)
         else:
@@ -447,27 +469,67 @@ def main():
             model = rdist.fit_itemknn_sharded(ctx, dX, args.K, row_parts, device)  # K1-K3 + all-gather
         _lib.predict_topk_dev(ctx, model, dX, Kp, out_idx, out_val, out_nnz, user_begin=ub, user_end=ue)  # K8
         keep["model"], keep["dX"] = model, dX
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
+        if not ease_on:
+            return
+        torch.cuda.synchronize()  # (the two halves are timed apart; the ranks are NOT held together here)
+        t1 = time.perf_counter()
+        if world == 1:
+            em = _lib.ease_fit(ctx, dX, args.l2, 0.0)  # K4-K7 (X^T and the degrees are the ItemKNN half's)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            _lib.predict_topk_dev(ctx, em, dX, Kp, e_idx, e_val, e_nnz)  # K9
+        else:
+            dXe = _lib.DeviceCSR.from_device(ctx, indptr_t, indices_t, (U, I))  # (the ItemKNN shard holds its own rows of X^T only)
+            em, _ = rdist.ease_fit_sharded(ctx, dXe, args.l2, 0.0, device, comm=comm)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            rdist.predict_topk_sharded(ctx, em, dXe, Kp, device, exclude_history=False)
+            keep["dXe"] = dXe
         torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        if state["timing"]:
+            parts["itemknn"] += t1 - t0
+            parts["ease_fit"] += t2 - t1
+            parts["ease_predict"] += t3 - t2
+        keep["ease_model"] = em
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ctx.reset_timings()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    result = {"metric": "fit+predict wall-sec (ItemKNN, EASE) on 1M×100K synth; achieved HBM GB/s", "status": "starting", "n_gpus": world}
+
+    def give_up():  # every rank has the same timer: a hung collective or an overrun costs the run, and says so
+        if rank == 0:
+            result["status"] = f"timeout: the {state['phase']} did not finish within {args.timeout:.0f} s (--timeout)"
+            print(json.dumps(result), flush=True)
+        os._exit(3)
+
+    dog = threading.Timer(args.timeout, give_up)
+    dog.daemon = True
+    dog.start()
+    try:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        ctx.reset_timings()
+        state["phase"], state["timing"] = "timed steps", True
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        state["timing"] = False
+    except Exception as e:  # noqa: BLE001 - the other ranks may be stuck in a collective this rank left: report and leave, no barrier
+        dog.cancel()
+        if rank == 0:
+            result["status"] = f"failed in the {state['phase']}: {type(e).__name__}: {e}"
+            print(json.dumps(result), flush=True)
+        else:
+            sys.stderr.write(f"rank {rank}: {type(e).__name__}: {e}\n")
+        os._exit(4)
+    dog.cancel()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, parts["itemknn"], parts["ease_fit"], parts["ease_predict"]], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, parts["itemknn"], parts["ease_fit"], parts["ease_predict"] = (float(v) for v in t.tolist())
     tm = ctx.timings()
-    result = None
     if rank == 0:
         sec_per_step = elapsed / args.steps
         # The SpGEMM (K1-K3) runs as two instances of one kernel: k_itemknn_fit<false,1024,16> (rows with more than 255
@@ -487,19 +549,19 @@ def main():
                 avg = t["ms"] / t["launches"]
                 by = 4.0 * p_share + other * (p_share / p_rank if p_rank else 0.0)
                 legs[name] = (avg, by)
-        # K8 priced with its own byte model: 8*K*nnz + 4*(nnz+U) + 8*U*Kp per rank share
-        tp = tm["predict"]
-        if tp["launches"]:
-            u_rank = user_parts[0][1] - user_parts[0][0]
-            share = u_rank / U
-            p_bytes = 8.0 * args.K * nnz * share + 4.0 * (nnz * share + u_rank) + 8.0 * u_rank * Kp
-            legs["k_predict_wave<unsigned int, 4096, false>"] = (tp["ms"] / tp["launches"], p_bytes)
+        # K8 priced with its own byte model: 8*K*nnz + 4*(nnz+U) + 8*U*Kp per rank share (K9 has its own timing slot)
+        u_rank = user_parts[0][1] - user_parts[0][0]
+        share = u_rank / U
+        p_bytes = 8.0 * args.K * nnz * share + 4.0 * (nnz * share + u_rank) + 8.0 * u_rank * Kp
+        k8 = tm["predict"]
+        if k8["launches"]:
+            legs["k_predict_wave<unsigned int, 4096, false>"] = (k8["ms"] / k8["launches"], p_bytes)
         leg_what = {"k_itemknn_fit<false,1024,16>": "K1-K3 heavy rows: Gram + similarity key + top-K",
                     "k_itemknn_fit<false,256,8>": "K1-K3 light rows: Gram + similarity key + top-K",
                     "k_predict_wave<unsigned int, 4096, false>": "K8: scores X.S + fused top-Kp, 32-bit per-user-scaled fixed-point sums, 4096-column "
                                                                  "tiles (bound by instruction issue and LDS round trips per (user, tile) in "
                                                                  "practice: the 400 MB model stays in L2/MALL)"}
-        # `roofline` = the kernel with the longest launch; all of them are under `legs`
+        # `roofline` = the HBM-bound kernel with the longest launch; all of them are under `legs`
         dom = max(legs, key=lambda k: legs[k][0])
         avg_ms, algo_bytes = legs[dom]
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -507,8 +569,7 @@ def main():
         spgemm_bytes = 4.0 * p_rank + other
         phases = {k: round(v["ms"] / args.steps, 4) for k, v in tm.items() if v["launches"]}
         traffic, traffic_note = pmc_traffic(args.config, dom, world)
-        result = {
-            "metric": "fit+predict wall-sec (ItemKNN, EASE) on 1M\u00d7100K synth; achieved HBM GB/s",
+        result.update({
             "value": round(sec_per_step, 6),
             "unit": "s",
             "n_gpus": world,
@@ -518,12 +579,21 @@ def main():
             "higher_is_better": False,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "int32 counts, f64 similarity, i32 fixed-point score sums (per-user power-of-two scale) of f32 similarities",
+            "dtype": ("ItemKNN: int32 counts, f64 similarity, i32 fixed-point score sums (per-user power-of-two scale) of f32 similarities; "
+                      "EASE: f32 storage, products as 2 x fp16 planes on the fp16 MFMA with f32 accumulate + compensated sums, f64 diagonal blocks"),
             "data": "synthetic",
+            "status": "ok" if ease_on else "ok (ItemKNN half only: --no-ease-in-step)",
+            # the two halves of the metric, seconds per step (host clock around each half; max over the ranks)
+            "value_itemknn": round(parts["itemknn"] / args.steps, 6) if ease_on else round(sec_per_step, 6),
+            "value_ease": round((parts["ease_fit"] + parts["ease_predict"]) / args.steps, 6) if ease_on else None,
+            "value_ease_fit": round(parts["ease_fit"] / args.steps, 6) if ease_on else None,
+            "value_ease_predict": round(parts["ease_predict"] / args.steps, 6) if ease_on else None,
             "config": {
-                "workload": f"{args.config}: ItemKNN cosine K={args.K}, {U} users x {I} items, nnz {nnz} "
-                            f"(P={P_total} scalar products), predict + top-{Kp} for all users",
-                "parallelism": f"item-row shards x{world} (fit) + user shards x{world} (predict)" if world > 1 else "1 GPU",
+                "workload": f"{args.config}: {U} users x {I} items, nnz {nnz} (P={P_total} scalar products): ItemKNN cosine K={args.K} fit + predict "
+                            f"top-{Kp} for all users" + (f", then EASE l2={args.l2} fit + predict top-{Kp} for all users" if ease_on else ""),
+                "parallelism": (f"ItemKNN: item-row shards x{world} (fit) + user shards x{world} (predict); EASE: block-cyclic column panels x{world} "
+                                f"(library solve, {'own RCCL communicator' if comm is not None and comm.is_rccl else 'torch.distributed callbacks'}) + "
+                                f"column-sharded predict + merge") if world > 1 else "1 GPU",
                 "generate_s": round(t_gen, 2),
                 "device": info,
             },
@@ -557,62 +627,45 @@ def main():
                                        "GBps": round(spgemm_bytes / (spgemm_ms * 1e-3) / 1e9, 1) if spgemm_ms > 0 else None,
                                        "frac": round(spgemm_bytes / (spgemm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if spgemm_ms > 0 else None},
             },
-        }
+        })
+        if ease_on:
+            result["roofline_ease"] = roofline_ease(tm, I, world, args.steps, _lib.ease_fit_dist_stats(ctx) if world > 1 else None, nnz, U, Kp)
         if world == 1 and args.cpu_baseline_seconds > 0:
             idx, val, nnz_rows = keep["model"].topk_download()
             from recpack_amd.algorithms import topk_arrays_to_csr
 
             S = topk_arrays_to_csr(idx, val, nnz_rows, I)
             host_csr = (indptr_t.cpu().numpy(), indices_t.cpu().numpy())
-            result["cpu_baseline"] = cpu_baseline(host_csr[0], host_csr[1], (U, I), args.K, Kp, S, args.cpu_baseline_seconds, P_total)
+            port = cpu_baseline(host_csr[0], host_csr[1], (U, I), args.K, Kp, S, args.cpu_baseline_seconds, P_total)
+            ease_cpu = cpu_baseline_ease(host_csr[0], host_csr[1], (U, I), args.l2, Kp) if ease_on else None
+            ref = port.pop("reference_shaped")
+            # top level: the route recpack itself runs (sklearn cosine + per-row argpartition loop; float64 np.linalg.inv), both halves
+            result["cpu_baseline"] = {
+                "value": round(ref["value"] + (ease_cpu["value"] if ease_cpu else 0.0), 1), "unit": "s",
+                "cores": ease_cpu["cores"] if ease_cpu else 1, "kind": "port",
+                "sample": ("ItemKNN half, reference-shaped, 1 thread (scipy's SpGEMM and the per-row loops are single-threaded): " + ref["sample"] +
+                           (" | EASE half, all BLAS threads: " + ease_cpu["sample"] if ease_cpu else "")),
+                "itemknn_reference_shaped_s": ref["value"], "ease_s": ease_cpu["value"] if ease_cpu else None,
+                "ease_measured_points": ease_cpu["measured_points"] if ease_cpu else None,
+                "port": port,  # the oracle's own vectorised route (what the parity tests run)
+                "host_cpus": os.cpu_count(),
+            }
+        keep.clear()
         if world == 1 and args.ease_config.lower() != "none":
-            keep.clear()
-            del indptr_t, indices_t, out_idx, out_val, out_nnz
+            del out_idx, out_val, out_nnz, e_idx, e_val, e_nnz
+            ctx.trim()
             torch.cuda.empty_cache()
-            for n, cfg in enumerate(c.strip().upper() for c in args.ease_config.split(",")):
-                # (the 100K-item solve takes ~10 s: one timed run; smaller ones are repeated and the better run kept)
-                leg = ease_leg(args, ctx, device, Kp, cfg, 1 if CONFIGS[cfg][1] > 60000 else 2)
-                result["ease" if n == 0 else f"ease_{cfg.lower()}"] = leg
-                if n == 0:
-                    result["value_ease"] = leg["fit_plus_predict_s"]
+            for cfg in (c.strip().upper() for c in args.ease_config.split(",")):
+                result[f"ease_{cfg.lower()}"] = ease_leg(args, ctx, device, Kp, cfg, 1 if CONFIGS[cfg][1] > 60000 else 2)
                 torch.cuda.empty_cache()
-            if args.cpu_baseline_seconds > 0:
-                result["cpu_baseline"]["ease"] = cpu_baseline_ease(host_csr[0], host_csr[1], (U, I), args.l2, Kp)
         if world == 1 and args.tars_config.lower() != "none":
             torch.cuda.empty_cache()
             result["time_aware"] = tars_leg(args, ctx, device, Kp, args.tars_config.strip().upper())
-    if world > 1 and args.ease_sharded and args.ease_config.lower() != "none":
-        # the sharded EASE leg runs under a watchdog: the ItemKNN line above is already complete, so a leg that overruns (or a
-        # collective that hangs) costs only the leg - every rank has the same timer and leaves with exit code 0
-        import threading
-
-        def give_up():
-            if rank == 0:
-                result["ease"] = {"error": f"sharded EASE leg did not finish within {args.ease_timeout:.0f} s (--ease-timeout)"}
-                print(json.dumps(result), flush=True)
-            os._exit(0)
-
-        dog = threading.Timer(args.ease_timeout, give_up)
-        dog.daemon = True
-        dog.start()
-        keep.clear()
-        try:
-            leg = ease_leg_sharded(args, ctx, device, Kp, args.ease_config.split(",")[0].strip().upper(), world, rank)
-        except Exception as e:  # noqa: BLE001 - the headline line must still be printed
-            leg = {"error": f"{type(e).__name__}: {e}"}
-        dog.cancel()
-        if rank == 0:
-            result["ease"] = leg
-            if "fit_plus_predict_s" in leg:
-                result["value_ease"] = leg["fit_plus_predict_s"]
-        if "error" in leg:  # the other ranks may be stuck in a collective this rank left: print and leave, no final barrier
-            if rank == 0:
-                print(json.dumps(result), flush=True)
-            os._exit(0)
-    if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 

@@ -54,7 +54,7 @@ enum {
   RPHIP_T_FIT_PLAN = 1,      /* row costs, task list */
   RPHIP_T_GRAM_TOPK = 2,     /* K1-K3: row-blocked Gram + cosine key + per-row top-K (the SpGEMM) */
   RPHIP_T_TOPK_MERGE = 3,    /* merge of per-column-tile candidates (only when I > one LDS tile) */
-  RPHIP_T_PREDICT = 4,       /* K8 / K9 */
+  RPHIP_T_PREDICT = 4,       /* K8 (neighbour-list models) and the merges */
   RPHIP_T_GRAM_DENSE = 5,    /* K4 */
   RPHIP_T_CHOLESKY = 6,      /* K5 */
   RPHIP_T_INVERSE = 7,       /* K6 */
@@ -66,7 +66,8 @@ enum {
   RPHIP_T_SWEEP_UPDATE = 13,  /* rphip_ease_fit_dist: the symmetric rank-nb updates of the own panels (the n^3 / world part) */
   RPHIP_T_SWEEP_CHAIN = 14,   /* rphip_ease_fit_dist: pivot inverse, gather / broadcast of the pivot column, T, look-ahead updates */
   RPHIP_T_MIRROR = 15,        /* rphip_ease_fit_dist: the exchange that fills the upper triangle */
-  RPHIP_T_COUNT = 16
+  RPHIP_T_PREDICT_DENSE = 16, /* K9 (dense models) */
+  RPHIP_T_COUNT = 24
 };
 
 typedef struct rphip_timings {

@@ -18,9 +18,9 @@ LIB_PATH = os.path.join(_HERE, "csrc", "librecpack_hip.so")
 
 RPHIP_T_NAMES = [
     "csr_transpose", "fit_plan", "gram_topk", "topk_merge", "predict", "gram_dense", "cholesky", "inverse",
-    "ease_scale", "h2d", "d2h", "gram_finalize", "gram_topk_wave", "sweep_update", "sweep_chain", "mirror",
+    "ease_scale", "h2d", "d2h", "gram_finalize", "gram_topk_wave", "sweep_update", "sweep_chain", "mirror", "predict_dense",
 ]
-RPHIP_T_COUNT = 16
+RPHIP_T_COUNT = 24
 RPHIP_MODEL_TOPK = 1
 RPHIP_MODEL_DENSE = 2
 

@@ -1346,7 +1346,7 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
               h[0] / 1e6, h[4] / 1e6, h[1] / 1e6, h[5] / 1e6, (h[2] + h[7]) / 1e6, h[3] / 1e6, wg, h[7] / 1e6, h[6] / 1e6);
     }
 #endif
-    rp_time_end(ctx, ev, RPHIP_T_PREDICT, rp_pred_work(Xpred, model, n, Kp));
+    rp_time_end(ctx, ev, model->kind == RPHIP_MODEL_DENSE ? RPHIP_T_PREDICT_DENSE : RPHIP_T_PREDICT, rp_pred_work(Xpred, model, n, Kp));
     return RPHIP_OK;
   }
   int32_t* cand_idx = nullptr;
@@ -1380,7 +1380,7 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
                        nullptr, nullptr, idx_dev, val_dev, nnz_dev, 0);
   }
   RP_HIP(hipGetLastError());
-  rp_time_end(ctx, ev, RPHIP_T_PREDICT, rp_pred_work(Xpred, model, n, Kp));
+  rp_time_end(ctx, ev, model->kind == RPHIP_MODEL_DENSE ? RPHIP_T_PREDICT_DENSE : RPHIP_T_PREDICT, rp_pred_work(Xpred, model, n, Kp));
   return RPHIP_OK;
 }
 
