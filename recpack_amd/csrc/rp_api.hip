@@ -232,6 +232,8 @@ extern "C" int rphip_ctx_set_option(rphip_ctx* ctx, const char* name, int64_t va
     ctx->gemm_mode = (int)value;
   } else if (!strcmp(name, "gemm_shape16")) {
     ctx->gemm_shape16 = value ? 1 : 0;
+  } else if (!strcmp(name, "gemm_wide")) {
+    ctx->gemm_wide = value ? 1 : 0;
   } else if (!strcmp(name, "gemm_presplit")) {
     ctx->gemm_presplit = value ? 1 : 0;
   } else if (!strcmp(name, "gemm_workspace_bytes")) {

@@ -88,6 +88,7 @@ struct rphip_ctx {
   int gemm_supertile = 0;    // 1: GEMM workgroups walk the tiles in XCD-round-robin 8 x 8 supertiles (0: row-major 2-D grid)
   int gemm_presplit = 1;     // mode 2: products with many tiles cut their operands into planes once (workspace) and run k_gemm_hp
   int gemm_shape16 = 1;      // k_gemm_hp on v_mfma_f32_16x16x32_f16 (default; the chip holds a higher clock on it) or 32x32x16
+  int gemm_wide = 1;         // the plane product kernel on 256 x 128 tiles with three LDS stages (k_gemm_hp16w) instead of 128 x 128 / two
   size_t gemm_ws_bytes = (size_t)4 << 30;  // workspace per operand of those products (sets their K chunk)
   unsigned* gemm_amax_ring = nullptr;  // mode 2: [RP_AMAX_SLOTS][2] words, the operands' largest magnitudes per launch
   unsigned long long gemm_amax_seq = 0;

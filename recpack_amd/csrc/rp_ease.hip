@@ -683,6 +683,7 @@ struct rp_hp_args {
   int KS;               // K16 steps per 32-row block in the workspace
   int kc0;              // first K of the workspace
   int first;            // the product's first chunk: tiles with an empty K range still get beta * C
+  unsigned* stamps;     // diagnostic build (-DRP_GEMM_STAMPS): per-step clock stamps of one workgroup of k_gemm_hp16w
 };
 
 __global__ void __launch_bounds__(256, 2) k_gemm_hp(rp_hp_args q) {
@@ -918,6 +919,227 @@ __global__ void __launch_bounds__(256, 2) k_gemm_hp16(rp_hp_args q) {
       cur ^= 1;
     }
   }
+  flush();
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wc * 64 + j * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wr * 64 + i * 16 + 4 * (lane >> 4) + r;
+        const uint32_t pk = lo[i][j][r >> 1];
+        const float h = hi[i][j][r];
+        const float l = (r & 1) ? __uint_as_float(pk & 0xffff0000u) : __uint_as_float(pk << 16);
+        float* cp = g.C + (long long)row * g.ldc + col;
+        float v = (g.beta != 0.0f) ? fmaf(g.alpha, h, g.beta * (*cp)) : g.alpha * h;
+        *cp = fmaf(g.alpha, l, v);
+      }
+    }
+}
+
+// The same product on 256 x 128 tiles with THREE LDS stages and counted waits (round 3).  PMC on k_gemm_hp16 showed the matrix pipe
+// 56 % busy: every K32 step ended with s_waitcnt vmcnt(0) + barrier on a two-buffer ring, so a step's LDS-DMA pieces were requested
+// one step ahead and waited for in full, and a wave issued 8 pieces per 48 MFMAs.  Here a workgroup of 8 waves (4 x 2, 64 x 64 each)
+// owns 256 rows: 48 pieces per K32 step = 6 per wave for the same 48 MFMAs, the pieces of step k + 2 are requested while step k is
+// multiplied (three stages of 48 KB = 144 of the 160 KB), and the top of a step waits with vmcnt(6) - for its own pieces of step k,
+// two steps old - before the one barrier of the step (which also says that everybody has finished reading the stage about to be
+// refilled).  The two 128-row halves of a tile follow the 128-tile rules separately (tri, K clipping: a half that is excluded or
+// whose K range has not begun skips the MFMAs, wave-uniformly), so every caller's tile semantics are those of the 128 x 128 kernels.
+__global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
+  // [stage][A: plane 2 x block 8 x K16 2 | B: plane 2 x block 4 x K16 2][1 KB]
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smw[];
+  constexpr int STAGE = 48 * 1024, AOFF = 0, BOFF = 32 * 1024;
+#ifdef RP_GEMM_STAMPS
+  // [wave 8][step 48][slot 5] low 32 bits of s_memtime, kept in the 16 KB of LDS the stages leave, written out by the workgroup (5, 3)
+  unsigned* stl = reinterpret_cast<unsigned*>(smw + 3 * STAGE);
+  const bool stamping = blockIdx.x == 5 && blockIdx.y == 3 && q.stamps;
+  int st_step = 0;
+#define GST(slot)                                                                                   \
+  do {                                                                                              \
+    if (stamping && st_step < 48 && (threadIdx.x & 63) == 0)                                        \
+      stl[((threadIdx.x >> 6) * 48 + st_step) * 5 + (slot)] = (unsigned)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define GST(slot)
+#endif
+  const rp_gemm_args& g = q.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;  // wave rows 0..3 (64 rows each), columns 0..1
+  const int tm = blockIdx.y, tn = blockIdx.x;
+  const int m0 = tm * 256, n0 = tn * GT;
+  const bool has_lo = m0 + GT < g.M;  // the lower 128 rows exist
+  // per half: excluded by tri?  K range
+  bool act[2];
+  int kbh[2], keh[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int mh = m0 + h * GT;
+    act[h] = (h == 0 || has_lo) && !rp_gemm_skip(g, mh, n0);
+    int kb = g.k0, ke = g.k1;
+    if (g.kb_m) kb = max(kb, g.m_off + mh);
+    if (g.kb_n) kb = max(kb, g.n_off + n0);
+    if (g.ke_n) ke = min(ke, g.n_off + n0 + GT);
+    kbh[h] = kb & ~31;
+    keh[h] = ke;
+    if (kbh[h] >= keh[h] && !q.first) act[h] = false;  // nothing to add to C
+  }
+  if (!act[0] && !act[1]) return;
+  const int kb = act[0] && act[1] ? min(kbh[0], kbh[1]) : (act[0] ? kbh[0] : kbh[1]);
+  const int ke = act[0] && act[1] ? max(keh[0], keh[1]) : (act[0] ? keh[0] : keh[1]);
+  const int my = wr >> 1;  // this wave's half
+  const bool mine = act[my];
+  const int my_kb = kbh[my], my_ke = keh[my];
+  const float unscale = 1.0f / (rp_h2_scale(g.amax[0]) * rp_h2_scale(g.amax[1]));
+
+  f32x4 acc[4][4], hi[4][4];
+  uint32_t lo[4][4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = hi[i][j][r] = 0.0f;
+      lo[i][j][0] = lo[i][j][1] = 0u;
+    }
+  auto flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const uint32_t pk = lo[i][j][r >> 1];
+          float l0 = __uint_as_float(pk << 16), l1 = __uint_as_float(pk & 0xffff0000u);
+          const float a0 = acc[i][j][r] * unscale, a1 = acc[i][j][r + 1] * unscale;
+          const float h0 = hi[i][j][r], h1 = hi[i][j][r + 1];
+          const float s0 = h0 + a0, s1 = h1 + a1;
+          const float b0 = s0 - h0, b1 = s1 - h1;
+          l0 += (h0 - (s0 - b0)) + (a0 - b0);
+          l1 += (h1 - (s1 - b1)) + (a1 - b1);
+          hi[i][j][r] = s0;
+          hi[i][j][r + 1] = s1;
+          acc[i][j][r] = 0.0f;
+          acc[i][j][r + 1] = 0.0f;
+          lo[i][j][r >> 1] = rp_pack_bf16_rn(l0, l1);
+        }
+  };
+
+  if (kb < ke) {
+    // wave w stages A's 32-row block w (both planes, both K16 pieces: 4 pieces) and B's block w & 3, plane w >> 2 (2 pieces).
+    // A block that lies beyond M (half tile) is replaced by the tile's first block: the count of requests per wave stays 6.
+    const int ablk = (m0 / 32 + wave) * 32 < g.M ? wave : 0;
+    const unsigned char* asrc = q.WA + ((long long)(m0 / 32 + ablk) * q.KS) * 1024 + lane * 16;
+    const unsigned char* bsrc = q.WB + (long long)(wave >> 2) * q.psb + ((long long)(n0 / 32 + (wave & 3)) * q.KS) * 1024 + lane * 16;
+    auto issue = [&](int stage, int k) __attribute__((always_inline)) {
+      const long long ko = (long long)((k - q.kc0) >> 4) * 1024;
+      unsigned char* sa = smw + stage * STAGE + AOFF + (wave * 2) * 1024;
+      unsigned char* sb = smw + stage * STAGE + BOFF + (((wave >> 2) * 4 + (wave & 3)) * 2) * 1024;
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc + p * q.psa + ko + s2 * 1024),
+                                           (__attribute__((address_space(3))) void*)(sa + p * 16 * 1024 + s2 * 1024), 16, 0, 0);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + ko + s2 * 1024),
+                                         (__attribute__((address_space(3))) void*)(sb + s2 * 1024), 16, 0, 0);
+    };
+    // the same six requests one group at a time: part 0 = A plane 0, 1 = A plane 1, 2 / 3 = B's two K16 pieces
+    auto issue_part = [&](int stage, int k, int part) __attribute__((always_inline)) {
+      const long long ko = (long long)((k - q.kc0) >> 4) * 1024;
+      unsigned char* sa = smw + stage * STAGE + AOFF + (wave * 2) * 1024;
+      unsigned char* sb = smw + stage * STAGE + BOFF + (((wave >> 2) * 4 + (wave & 3)) * 2) * 1024;
+      if (part < 2) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc + part * q.psa + ko + s2 * 1024),
+                                           (__attribute__((address_space(3))) void*)(sa + part * 16 * 1024 + s2 * 1024), 16, 0, 0);
+      } else {
+        const int s2 = part - 2;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + ko + s2 * 1024),
+                                         (__attribute__((address_space(3))) void*)(sb + s2 * 1024), 16, 0, 0);
+      }
+    };
+    // a request past the K range re-reads the last step (harmless, keeps the counted waits uniform)
+    const int k_last = kb + ((ke - kb - 1) / 32) * 32;
+    issue(0, kb);
+    issue(1, min(kb + 32, k_last));
+    const int foff = (lane >> 5) * 1024 + ((((lane >> 4) & 1) * 32) + (lane & 15)) * 16;
+    int since = 0, stage = 0;
+    for (int k = kb; k < ke; k += 32) {
+      GST(0);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // my pieces of this step have landed (those of the next step may be in flight)
+      GST(1);
+      // everybody's have, and nobody still reads the stage refilled below (the fragment reads of the previous step were consumed by
+      // its MFMAs).  The bare barrier: __syncthreads() carries a fence that the compiler turns into vmcnt(0) - the counted wait gone.
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      GST(2);
+      int st2 = stage + 2;
+      if (st2 >= 3) st2 -= 3;
+      const int kn = min(k + 64, k_last);
+      if (mine && k >= my_kb && k < my_ke) {
+        const unsigned char* A0 = smw + stage * STAGE + AOFF;
+        const unsigned char* B0 = smw + stage * STAGE + BOFF;
+        // Issuing a piece holds a wave's instruction stream for 60 - 180 cycles (MI355X_MICROARCH.md): six of them cost as much as
+        // the step's 48 MFMAs.  SQ counters of the first version (all eight waves request at the top of the step, or between their
+        // MFMAs): matrix pipes 56 % busy, a wave parked a third of its time - the two waves of a SIMD (w and w + 4) ran the same
+        // program in step and sat in their request phases together.  So the halves take turns: waves 0-3 request BEFORE their MFMAs,
+        // waves 4-7 AFTER theirs - one partner's requests run beside the other's MFMAs.  (A row's A fragments are read while the row
+        // before it multiplies.)
+        if (wave < 4) issue(st2, kn);
+        GST(3);
+        f16x8 a[2][2], b[2][4];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            b[p][t] = *reinterpret_cast<const f16x8*>(B0 + p * 8 * 1024 + ((wc * 2 + (t >> 1)) * 2) * 1024 + foff + (t & 1) * 256);
+          a[p][0] = *reinterpret_cast<const f16x8*>(A0 + p * 16 * 1024 + ((wr * 2) * 2) * 1024 + foff);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (i < 3) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+              a[p][(i + 1) & 1] = *reinterpret_cast<const f16x8*>(A0 + p * 16 * 1024 + ((wr * 2 + ((i + 1) >> 1)) * 2) * 1024 + foff + ((i + 1) & 1) * 256);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            f32x4 c = acc[i][j];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1][i & 1], b[0][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][i & 1], b[1][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][i & 1], b[0][j], c, 0, 0, 0);
+            acc[i][j] = c;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        GST(4);
+        if (wave >= 4) issue(st2, kn);
+#ifdef RP_GEMM_STAMPS
+        ++st_step;
+#endif
+        since += 32;
+        if (since >= g.kc && k + 32 < my_ke) {
+          flush();
+          since = 0;
+        }
+      } else {
+        issue(st2, kn);
+      }
+      stage = stage == 2 ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the trailing re-reads)
+#ifdef RP_GEMM_STAMPS
+    if (stamping) {
+      __syncthreads();
+      for (int e = threadIdx.x; e < 8 * 48 * 5; e += 512) q.stamps[e] = stl[e];
+    }
+#endif
+  }
+  if (!mine) return;
   flush();
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -1207,7 +1429,24 @@ int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st, float* par
           q.WB = WB;
           q.psb = sb.plane_stride;
         }
-        if (ctx->gemm_shape16)
+        if (ctx->gemm_shape16 && ctx->gemm_wide && g.M >= 256 && !ctx->gemm_supertile) {
+#ifdef RP_GEMM_STAMPS
+          constexpr int wide_lds = 3 * 48 * 1024 + 8 * 48 * 5 * 4;
+          if (!ctx->scratch[15].p) {
+            void* sp = nullptr;
+            RP_TRY(rp_scratch(ctx, 15, 8 * 48 * 5 * 4, &sp));
+          }
+          q.stamps = (unsigned*)ctx->scratch[15].p;
+#else
+          constexpr int wide_lds = 3 * 48 * 1024;
+#endif
+          static bool attr_set = false;
+          if (!attr_set) {
+            RP_HIP(hipFuncSetAttribute((const void*)k_gemm_hp16w, hipFuncAttributeMaxDynamicSharedMemorySize, wide_lds));
+            attr_set = true;
+          }
+          hipLaunchKernelGGL(k_gemm_hp16w, dim3(g.N / GT, (unsigned)rp_cdiv(g.M, 256)), dim3(512), wide_lds, st, q);
+        } else if (ctx->gemm_shape16)
           hipLaunchKernelGGL(k_gemm_hp16, grid, dim3(256), 0, st, q);
         else
           hipLaunchKernelGGL(k_gemm_hp, grid, dim3(256), 0, st, q);
@@ -1229,6 +1468,14 @@ int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st, float* par
   RP_HIP(hipGetLastError());
   return RPHIP_OK;
 }
+
+#ifdef RP_GEMM_STAMPS
+extern "C" int rphip_debug_gemm_stamps(rphip_ctx* ctx, unsigned* out) {  // [8][48][5]
+  if (!ctx->scratch[15].p) return RPHIP_ESTATE;
+  hipStreamSynchronize(ctx->stream);
+  return hipMemcpy(out, ctx->scratch[15].p, 8 * 48 * 5 * 4, hipMemcpyDeviceToHost) == hipSuccess ? RPHIP_OK : RPHIP_EHIP;
+}
+#endif
 
 extern "C" int rphip_gemm_nt_f32(rphip_ctx* ctx, int64_t M, int64_t N, int64_t K, float alpha, const float* A_dev, int64_t lda,
                                  const float* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc) {

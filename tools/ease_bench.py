@@ -20,6 +20,8 @@ if os.environ.get("RECPACK_GEMM_FLUSH_K"):
     ctx.set_option("gemm_flush_k", int(os.environ["RECPACK_GEMM_FLUSH_K"]))
 if os.environ.get("RECPACK_GEMM_SHAPE16"):
     ctx.set_option("gemm_shape16", int(os.environ["RECPACK_GEMM_SHAPE16"]))
+if os.environ.get("RECPACK_GEMM_WIDE"):
+    ctx.set_option("gemm_wide", int(os.environ["RECPACK_GEMM_WIDE"]))
 if os.environ.get("RECPACK_GEMM_SUPERTILE"):
     ctx.set_option("gemm_supertile", int(os.environ["RECPACK_GEMM_SUPERTILE"]))
 dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
