@@ -224,6 +224,8 @@ extern "C" int rphip_ctx_set_option(rphip_ctx* ctx, const char* name, int64_t va
   if (!ctx || !name) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (!strcmp(name, "predict_exact64")) {
     ctx->predict_exact64 = value ? 1 : 0;
+  } else if (!strcmp(name, "predict_half")) {
+    ctx->predict_half = value ? 1 : 0;
   } else if (!strcmp(name, "predict_tile32")) {
     if (value != 2048 && value != 4096) RP_FAIL(RPHIP_EINVAL, "predict_tile32 must be 2048 or 4096");
     ctx->pw_wt32 = (int)value;

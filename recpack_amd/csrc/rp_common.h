@@ -83,6 +83,7 @@ struct rphip_ctx {
   size_t cache_limit = (size_t)48 << 30;  // lowered to a quarter of the device's memory by rphip_ctx_create
   // predict options (rphip_ctx_set_option)
   int predict_exact64 = 0;   // 1: the wave predict kernel sums in 64 bits (exact) instead of the per-user-scaled 32 bits
+  int predict_half = 1;      // dense models: K9 as two passes (fp16 rows for a candidate list, then exact f32 scores of the candidates)
   int pw_wt32 = 4096;        // tile width of the 32-bit sums: 2048 or 4096 (tuning)
   int gemm_mode = 2;         // operands of the solve's products: 0 fp32 MFMA, 1 three bf16 planes (6 products), 2 two fp16 planes (3 products)
   int gemm_supertile = 0;    // 1: GEMM workgroups walk the tiles in XCD-round-robin 8 x 8 supertiles (0: row-major 2-D grid)
@@ -154,6 +155,13 @@ struct rphip_model {
   // n_cols > 0 and cyc_nb > 0: the columns are block-cyclic panels of cyc_nb columns (rphip_ease_fit_dist): local column l is item
   // ((l / cyc_nb) * cyc_world + cyc_rank) * cyc_nb + l % cyc_nb; the n_cols items are a prefix of the local columns
   int32_t cyc_nb = 0, cyc_world = 1, cyc_rank = 0;
+  // fp16 copy of B for the first pass of the two-pass K9 (built on first use, rp_predict.hip): B16 = fp16(B * b16_scale), the same
+  // leading dimension; b16_delta[i] = the largest rounding error of row i (in B's units), b16_rowmax[i] = its largest |entry|
+  _Float16* B16 = nullptr;
+  float b16_scale = 0.0f;
+  float* b16_delta = nullptr;
+  float* b16_rowmax = nullptr;
+  bool b16_failed = false;  // the copy could not be allocated: the one-pass kernel is used
   int64_t empty_rows = -1;  // rows without any stored similarity (-1: not counted)
 };
 

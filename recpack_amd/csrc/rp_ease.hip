@@ -2395,6 +2395,13 @@ extern "C" int rphip_model_dense_prune(rphip_ctx* ctx, rphip_model* m, int64_t k
   RP_HIP(hipGetLastError());
   if (nnz_after) *nnz_after = keep;
   (void)above;
+  // B has changed: the fp16 copy of the two-pass predict is rebuilt on its next use
+  RP_HIP(hipStreamSynchronize(st));
+  rp_dev_free(ctx, m->B16);
+  rp_dev_free(ctx, m->b16_delta);
+  rp_dev_free(ctx, m->b16_rowmax);
+  m->B16 = nullptr;
+  m->b16_delta = m->b16_rowmax = nullptr;
   return rp_dense_count_empty(ctx, m);
 }
 

@@ -849,6 +849,9 @@ extern "C" int rphip_model_destroy(rphip_model* m) {
   rp_dev_free(m->ctx, m->rowmax);
   rp_dev_free(m->ctx, m->nnz);
   if (!m->borrows_B) rp_dev_free(m->ctx, m->B);
+  rp_dev_free(m->ctx, m->B16);
+  rp_dev_free(m->ctx, m->b16_delta);
+  rp_dev_free(m->ctx, m->b16_rowmax);
   delete m;
   return RPHIP_OK;
 }

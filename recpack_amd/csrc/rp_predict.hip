@@ -77,6 +77,8 @@ struct rp_pred_params {
   const int32_t* s_nnz;
   const float* dense_B;   // K9: dense model (EASE), row-major with leading dimension dense_ld; NULL for neighbour lists
   long long dense_ld;
+  const _Float16* dense_B16;  // HALF instances: fp16(B * b16_scale), same leading dimension (the first pass of the two-pass K9)
+  float b16_inv;              // 1 / b16_scale (a power of two)
   int col_begin;          // dense column slab: column 0 of dense_B is item col_begin (n_items = the slab's width then)
   int cyc_nb, cyc_w, cyc_r;  // cyc_nb > 0: the slab's columns are block-cyclic panels (rphip_ease_fit_dist): local column l is item
                              // ((l / cyc_nb) * cyc_w + cyc_r) * cyc_nb + l % cyc_nb
@@ -129,8 +131,13 @@ struct rp_score_src {
   __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)(t0 + w); }
 };
 
-template <bool DENSE>
+typedef _Float16 rp_h8 __attribute__((ext_vector_type(8)));
+
+// HALF (dense models only): the rows are read from the model's fp16 copy - half the bytes of the HBM-bound K9 - and summed in
+// f32: APPROXIMATE scores, good for a candidate list that rp_predict_rescore then scores exactly (see rp_predict_topk_impl).
+template <bool DENSE, bool HALF = false>
 __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_tile(rp_pred_params P) {
+  static_assert(DENSE || !HALF, "the fp16 first pass is for dense models");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ACC_B = DENSE ? 4 : 8;
   float* accf = reinterpret_cast<float*>(smem);
@@ -167,7 +174,61 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_tile(rp_pred_params
       const int t0 = tile * W;
       const int n_cols = min(W, P.n_items - t0);
       // ---- accumulate
-      if (DENSE) {
+      if (HALF) {
+        // eight consecutive columns per 16-byte load, four rows in flight
+        constexpr int C8 = (RP_TILE_MAX + 8 * RP_PRED_THREADS - 1) / (8 * RP_PRED_THREADS);
+        float r[C8][8];
+#pragma unroll
+        for (int c = 0; c < C8; ++c)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) r[c][e] = 0.0f;
+        const int w8 = (n_cols + 7) >> 3;  // (reads past n_cols stay inside the padded row)
+        int h = hs;
+        for (; h + 3 < he; h += 4) {
+          const _Float16* R0 = P.dense_B16 + (long long)P.x_idx[h] * P.dense_ld + t0;
+          const _Float16* R1 = P.dense_B16 + (long long)P.x_idx[h + 1] * P.dense_ld + t0;
+          const _Float16* R2 = P.dense_B16 + (long long)P.x_idx[h + 2] * P.dense_ld + t0;
+          const _Float16* R3 = P.dense_B16 + (long long)P.x_idx[h + 3] * P.dense_ld + t0;
+          rp_h8 v0[C8], v1[C8], v2[C8], v3[C8];
+#pragma unroll
+          for (int c = 0; c < C8; ++c) {
+            const int gq = tid + c * RP_PRED_THREADS;
+            if (gq < w8) {
+              v0[c] = *reinterpret_cast<const rp_h8*>(R0 + 8 * gq);
+              v1[c] = *reinterpret_cast<const rp_h8*>(R1 + 8 * gq);
+              v2[c] = *reinterpret_cast<const rp_h8*>(R2 + 8 * gq);
+              v3[c] = *reinterpret_cast<const rp_h8*>(R3 + 8 * gq);
+            } else {
+              v0[c] = v1[c] = v2[c] = v3[c] = (rp_h8)(_Float16)0.0f;
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < C8; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[c][e] += ((float)v0[c][e] + (float)v1[c][e]) + ((float)v2[c][e] + (float)v3[c][e]);
+        }
+        for (; h < he; ++h) {
+          const _Float16* R0 = P.dense_B16 + (long long)P.x_idx[h] * P.dense_ld + t0;
+#pragma unroll
+          for (int c = 0; c < C8; ++c) {
+            const int gq = tid + c * RP_PRED_THREADS;
+            if (gq < w8) {
+              const rp_h8 v = *reinterpret_cast<const rp_h8*>(R0 + 8 * gq);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) r[c][e] += (float)v[e];
+            }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < C8; ++c) {
+          const int gq = tid + c * RP_PRED_THREADS;
+          if (gq < w8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (8 * gq + e < n_cols) accf[8 * gq + e] = r[c][e] * P.b16_inv;
+          }
+        }
+      } else if (DENSE) {
         // K9: score[u, t0:t0+n_cols] = sum of the history items' rows of B.  Every thread owns groups of four
         // consecutive columns (registers, no atomics); a row is streamed with one 16-byte load per group, two rows in
         // flight (row stride and tile offsets are multiples of 64 floats, the rows are padded to 128)
@@ -293,6 +354,224 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_tile(rp_pred_params
       __syncthreads();
     }
     if (P.mode == 1 && tid == 0) P.row_nnz[ul] = total;
+  }
+}
+
+// ---- the two-pass K9: fp16 copy of B, exact rescoring of the candidates ---------------------------------------------------------
+// K9 streams 4 * I * nnz bytes of B from HBM (PMC: at the achievable rate), so the bytes are what is left to cut.  First pass: the
+// same kernel on an fp16 copy of B (half the bytes) keeps the Kc > Kp best APPROXIMATE scores of every user.  Second pass
+// (k_predict_rescore): the candidates' exact f32 scores - the same sums in the same order as the one-pass kernel's, bit for bit -
+// their exact top-Kp, and a PROOF that no other column could have been among them: a column outside the list has an approximate
+// score <= a_Kc (the Kc-th), hence an exact one <= a_Kc + E_u, where E_u = sum over the history of the row's largest rounding error
+// (+ the f32 summation slack) bounds |approximate - exact| for this user; if the Kp-th exact score of the list is above that, the
+// list's top-Kp IS the exact top-Kp.  A user whose list fails the test (measured: < 0.1 % at Kc = Kp + 64, tools/k9_half_gate.py)
+// goes to a list that the one-pass kernel then serves.  The results are those of the one-pass kernel, bit for bit.
+__global__ void __launch_bounds__(256) k_dense_rowmax(const float* __restrict__ B, long long ld, int n_rows, int n_cols, float* __restrict__ rowmax,
+                                                      unsigned* __restrict__ gmax) {
+  __shared__ float red[4];
+  for (int i = blockIdx.x; i < n_rows; i += gridDim.x) {
+    const float* row = B + (long long)i * ld;
+    float m = 0.0f;
+    for (int j = threadIdx.x * 4; j < n_cols; j += 1024) {  // (rows are padded to a multiple of 4 floats; the padding holds zeros)
+      const float4 v = *reinterpret_cast<const float4*>(row + j);
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+      rowmax[i] = m;
+      if (m > 0.0f) atomicMax(gmax, __float_as_uint(m));
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) k_dense_to_half(const float* __restrict__ B, long long ld, int n_rows, int n_cols8, float scale,
+                                                       _Float16* __restrict__ H, float* __restrict__ delta) {
+  __shared__ float red[4];
+  const float inv = 1.0f / scale;
+  for (int i = blockIdx.x; i < n_rows; i += gridDim.x) {
+    const float* row = B + (long long)i * ld;
+    _Float16* out = H + (long long)i * ld;
+    float m = 0.0f;
+    for (int j = threadIdx.x * 8; j < n_cols8; j += 2048) {
+      const float4 a = *reinterpret_cast<const float4*>(row + j), b = *reinterpret_cast<const float4*>(row + j + 4);
+      const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      rp_h8 h;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        h[e] = (_Float16)(x[e] * scale);
+        m = fmaxf(m, fabsf((float)h[e] * inv - x[e]));
+      }
+      *reinterpret_cast<rp_h8*>(out + j) = h;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) delta[i] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+  }
+}
+
+struct rp_rescore_params {
+  const int32_t* x_ptr;
+  const int32_t* x_idx;
+  const float* B;
+  long long ld;
+  int col_begin, cyc_nb, cyc_w, cyc_r;
+  const float* delta;
+  const float* rowmax;
+  const int32_t* cand_idx;  // [n][Kc] approximate top-Kc (any order), global column ids
+  const float* cand_val;
+  const int32_t* cand_nnz;
+  int user_begin, n_users, Kp, Kc;
+  int32_t* out_idx;
+  float* out_val;
+  int32_t* out_nnz;
+  int32_t* fail_list;  // users whose list does not prove its top-Kp; count in *n_fail
+  int32_t* n_fail;
+};
+
+// one wave per user; NQ = candidates per lane
+template <int NQ>
+__global__ void __launch_bounds__(256) k_predict_rescore(rp_rescore_params P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* se = reinterpret_cast<float*>(smem) + (size_t)wv * 2 * 64 * NQ;  // exact scores, then columns
+  int* sc = reinterpret_cast<int*>(se + 64 * NQ);
+  for (int ul = blockIdx.x * 4 + wv; ul < P.n_users; ul += gridDim.x * 4) {
+    const int u = P.user_begin + ul;
+    const int hs = P.x_ptr[u], he = P.x_ptr[u + 1];
+    const int nc = P.cand_nnz[ul];
+    int col[NQ], loc[NQ];
+    float e[NQ];
+    float amin = 3.0e38f;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int k = lane + 64 * q;
+      const bool on = k < nc;
+      col[q] = on ? P.cand_idx[(long long)ul * P.Kc + k] : -1;
+      if (on) amin = fminf(amin, P.cand_val[(long long)ul * P.Kc + k]);
+      int l = 0;
+      if (on) {
+        if (P.cyc_nb) {
+          const int p = col[q] / P.cyc_nb;
+          l = (p / P.cyc_w) * P.cyc_nb + col[q] % P.cyc_nb;
+        } else {
+          l = col[q] - P.col_begin;
+        }
+      }
+      loc[q] = l;
+      e[q] = 0.0f;
+    }
+    // the bound of |approximate - exact| for this user
+    float eu = 0.0f, rm = 0.0f;
+    for (int h = hs + lane; h < he; h += 64) {
+      const int i = P.x_idx[h];
+      eu += P.delta[i];
+      rm += P.rowmax[i];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      eu += __shfl_xor(eu, d);
+      rm += __shfl_xor(rm, d);
+      amin = fminf(amin, __shfl_xor(amin, d));
+    }
+    // (f32 summation slack of both passes: d terms of magnitude <= rowmax each; and a margin on the bound itself)
+    const float E = 1.0009765625f * (eu + 2.0f * (float)(he - hs) * 5.9604645e-8f * rm);
+    // a column outside the list: approximate score <= a_Kc, or exactly zero (never a candidate) - and a list shorter than Kc holds
+    // every column whose approximate score is not zero
+    const float a_bound = (nc == P.Kc) ? fmaxf(amin, 0.0f) : 0.0f;
+    // exact scores: the one-pass kernel's sums, same order (history order, one add per row)
+    int h = hs;
+    for (; h + 3 < he; h += 4) {
+      const float* R0 = P.B + (long long)P.x_idx[h] * P.ld;
+      const float* R1 = P.B + (long long)P.x_idx[h + 1] * P.ld;
+      const float* R2 = P.B + (long long)P.x_idx[h + 2] * P.ld;
+      const float* R3 = P.B + (long long)P.x_idx[h + 3] * P.ld;
+      float v0[NQ], v1[NQ], v2[NQ], v3[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        v0[q] = R0[loc[q]];
+        v1[q] = R1[loc[q]];
+        v2[q] = R2[loc[q]];
+        v3[q] = R3[loc[q]];
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) e[q] = (((e[q] + v0[q]) + v1[q]) + v2[q]) + v3[q];
+    }
+    for (; h < he; ++h) {
+      const float* R0 = P.B + (long long)P.x_idx[h] * P.ld;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) e[q] += R0[loc[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const bool ok = col[q] >= 0 && e[q] != 0.0f;  // (a score that cancels to exactly zero is not stored)
+      se[lane + 64 * q] = ok ? e[q] : -3.0e38f;
+      sc[lane + 64 * q] = ok ? col[q] : 0x7fffffff;
+    }
+    RP_WAVE_FENCE();
+    // rank by (score desc, column asc) among the list
+    const int n_all = 64 * NQ;
+    int rank[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) rank[q] = 0;
+    for (int k = 0; k < n_all; ++k) {
+      const float ek = se[k];
+      const int ck = sc[k];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const float mine_e = (col[q] >= 0 && e[q] != 0.0f) ? e[q] : -3.0e38f;
+        const int mine_c = (col[q] >= 0 && e[q] != 0.0f) ? col[q] : 0x7fffffff;
+        rank[q] += (ek > mine_e || (ek == mine_e && ck < mine_c)) ? 1 : 0;
+      }
+    }
+    int n_valid = 0;
+    float e_kp = -3.0e38f;  // the Kp-th exact score
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const bool ok = col[q] >= 0 && e[q] != 0.0f;
+      n_valid += __popcll(__ballot(ok));
+      if (ok && rank[q] == P.Kp - 1) e_kp = e[q];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) e_kp = fmaxf(e_kp, __shfl_xor(e_kp, d));
+    const bool proven = n_valid >= P.Kp && e_kp > a_bound + E;
+    if (!proven) {
+      if (lane == 0) P.fail_list[atomicAdd(P.n_fail, 1)] = ul;
+      RP_WAVE_FENCE();
+      continue;
+    }
+    // the selected ones in column order
+    RP_WAVE_FENCE();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const bool selq = col[q] >= 0 && e[q] != 0.0f && rank[q] < P.Kp;
+      sc[lane + 64 * q] = selq ? col[q] : 0x7fffffff;
+    }
+    RP_WAVE_FENCE();
+    int pos[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) pos[q] = 0;
+    for (int k = 0; k < n_all; ++k) {
+      const int ck = sc[k];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) pos[q] += (ck < col[q]) ? 1 : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (col[q] >= 0 && e[q] != 0.0f && rank[q] < P.Kp) {
+        P.out_idx[(long long)ul * P.Kp + pos[q]] = col[q];
+        P.out_val[(long long)ul * P.Kp + pos[q]] = e[q];
+      }
+    }
+    if (lane == 0) P.out_nnz[ul] = P.Kp;
+    RP_WAVE_FENCE();
   }
 }
 
@@ -1169,6 +1448,8 @@ static void rp_pred_fill(rp_pred_params& P, const rphip_model* m, const rphip_cs
   P.s_nnz = m->nnz;
   P.dense_B = (m->kind == RPHIP_MODEL_DENSE) ? m->B : nullptr;
   P.dense_ld = m->ld;
+  P.dense_B16 = nullptr;
+  P.b16_inv = 1.0f;
   P.keep = nullptr;
   P.n_items = (int)X->n_items;
   P.col_begin = 0;
@@ -1231,6 +1512,66 @@ static double rp_pred_work(const rphip_csr* X, const rphip_model* m, int64_t n_u
   if (m->kind == RPHIP_MODEL_DENSE)  // K9: 4*I*nnz_pred (rows of B streamed) + 8*U*Kp
     return 4.0 * (double)(m->n_cols > 0 ? m->n_cols : m->n_items) * (double)X->nnz * share + 8.0 * (double)n_users * Kp;
   return 8.0 * m->K * (double)X->nnz * share + 4.0 * ((double)X->nnz * share + (double)n_users) + 8.0 * (double)n_users * Kp;
+}
+
+// the model's fp16 copy (first use; a model is immutable once fitted - pruning rebuilds it)
+static int rp_model_half(rphip_ctx* ctx, rphip_model* m) {
+  if (m->B16 || m->b16_failed) return RPHIP_OK;
+  const int64_t rows = m->n_items;
+  const int64_t cols = m->n_cols > 0 ? m->n_cols : m->n_items;
+  if (m->ld % 8) {  // (16-byte loads of eight fp16)
+    m->b16_failed = true;
+    return RPHIP_OK;
+  }
+  hipStream_t st = ctx->stream;
+  unsigned* gmax = nullptr;
+  RP_TRY(rp_scratch(ctx, 5, 64, (void**)&gmax));
+  {  // the copy is an optimisation: it must leave room for everything else (16 GiB or a tenth of the device, whichever is less)
+    size_t free_b = 0, total_b = 0;
+    hipMemGetInfo(&free_b, &total_b);
+    const size_t need = (size_t)rows * m->ld * sizeof(_Float16) + std::min<size_t>((size_t)16 << 30, total_b / 10);
+    if (free_b + ctx->cached_bytes < need) {
+      m->b16_failed = true;
+      return RPHIP_OK;
+    }
+  }
+  if (rp_dev_alloc(ctx, (size_t)rows * m->ld * sizeof(_Float16), (void**)&m->B16) != RPHIP_OK ||
+      rp_dev_alloc(ctx, (size_t)rows * sizeof(float), (void**)&m->b16_delta) != RPHIP_OK ||
+      rp_dev_alloc(ctx, (size_t)rows * sizeof(float), (void**)&m->b16_rowmax) != RPHIP_OK) {
+    rp_dev_free(ctx, m->B16);
+    rp_dev_free(ctx, m->b16_delta);
+    rp_dev_free(ctx, m->b16_rowmax);
+    m->B16 = nullptr;
+    m->b16_delta = m->b16_rowmax = nullptr;
+    m->b16_failed = true;  // not an error: the one-pass kernel gives the same result
+    return RPHIP_OK;
+  }
+  RP_HIP(hipMemsetAsync(gmax, 0, 4, st));
+  const int grid = (int)std::min<int64_t>(rows, (int64_t)ctx->n_cu * 16);
+  const int cols4 = (int)(rp_cdiv(cols, 4) * 4), cols8 = (int)std::min<int64_t>(m->ld, rp_cdiv(cols, 8) * 8);
+  hipLaunchKernelGGL(k_dense_rowmax, dim3(grid), dim3(256), 0, st, m->B, (long long)m->ld, (int)rows, cols4, m->b16_rowmax, gmax);
+  unsigned h = 0;
+  RP_HIP(hipMemcpyAsync(&h, gmax, 4, hipMemcpyDeviceToHost, st));
+  RP_HIP(hipStreamSynchronize(st));
+  float mx;
+  memcpy(&mx, &h, 4);
+  // the largest magnitude goes to [2^14, 2^15): fp16's normal range then reaches down to 2^-29 of it
+  int e = 0;
+  float scale = 1.0f;
+  if (mx > 0.0f && std::isfinite(mx)) {
+    (void)std::frexp(mx, &e);  // mx in [2^(e-1), 2^e)
+    scale = std::ldexp(1.0f, std::max(-100, std::min(100, 15 - e)));
+  }
+  m->b16_scale = scale;
+  hipLaunchKernelGGL(k_dense_to_half, dim3(grid), dim3(256), 0, st, m->B, (long long)m->ld, (int)rows, cols8, scale, m->B16, m->b16_delta);
+  RP_HIP(hipGetLastError());
+  return RPHIP_OK;
+}
+
+template <int NQ>
+static void rp_launch_rescore(rphip_ctx* ctx, const rp_rescore_params& R) {
+  const int grid = (int)std::min<int64_t>(rp_cdiv(R.n_users, 4), (int64_t)ctx->n_cu * 8);
+  hipLaunchKernelGGL(k_predict_rescore<NQ>, dim3(grid), dim3(256), (size_t)4 * 2 * 64 * NQ * 4, ctx->stream, R);
 }
 
 static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin,
@@ -1348,6 +1689,107 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
 #endif
     rp_time_end(ctx, ev, model->kind == RPHIP_MODEL_DENSE ? RPHIP_T_PREDICT_DENSE : RPHIP_T_PREDICT, rp_pred_work(Xpred, model, n, Kp));
     return RPHIP_OK;
+  }
+  // ---- dense models: the two-pass K9 (see k_predict_rescore) unless switched off, the fp16 copy does not fit, or the candidate
+  // list would be most of the slab anyway
+  const int Kc = ((Kp + 24 + 63) / 64) * 64;  // (Kp = 100: 128 - measured to prove 99.9 % of the users at C3 / C4, tools/k9_half_gate.py; 192: the same share, +8 % time)
+  if (model->kind == RPHIP_MODEL_DENSE && ctx->predict_half && Kc <= 512 && (int64_t)4 * Kc <= (int64_t)P.n_items && T <= 15) {
+    rphip_model* mm = const_cast<rphip_model*>(model);
+    RP_TRY(rp_model_half(ctx, mm));
+    if (mm->B16) {
+      const int64_t UCH = 1 << 17;  // users per chunk: bounds the candidate scratch
+      const int64_t nchm = std::min<int64_t>(n, UCH);
+      const size_t szT = (T > 1) ? (size_t)nchm * T * Kc : 0, szA = (size_t)nchm * Kc;
+      char* sb = nullptr;
+      RP_TRY(rp_scratch(ctx, 14, (szT + szA) * 8 + (size_t)nchm * (T + 2) * 4 + 256, (void**)&sb));
+      int32_t* a_idx = (int32_t*)sb;
+      float* a_val = (float*)(sb + szA * 4);
+      int32_t* t_idx = (int32_t*)(sb + szA * 8);
+      float* t_val = (float*)(sb + szA * 8 + szT * 4);
+      int32_t* a_nnz = (int32_t*)(sb + (szA + szT) * 8);
+      int32_t* t_nnz = a_nnz + nchm;
+      int32_t* fail = t_nnz + nchm * T;
+      int32_t* n_fail = fail + nchm;  // (one word behind the list)
+      const size_t lds1 = rp_pred_lds(P);
+      RP_HIP(hipFuncSetAttribute((const void*)k_predict_tile<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+      RP_HIP(hipFuncSetAttribute((const void*)k_predict_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+      const size_t mlds_c = (size_t)T * Kc * 8 + rp_select_smem_bytes(T * Kc), mlds_p = (size_t)T * Kp * 8 + rp_select_smem_bytes(T * Kp);
+      if (T > 1) {
+        if (mlds_c > 160 * 1024 || T * Kc >= RPS_FLAG) RP_FAIL(RPHIP_ELIMIT, "Kp=%d with %d column tiles needs %zu bytes of LDS for the merge", Kp, T, mlds_c);
+        RP_HIP(hipFuncSetAttribute((const void*)k_predict_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds_c));
+      }
+      for (int64_t c0 = 0; c0 < n; c0 += UCH) {
+        const int64_t nch = std::min<int64_t>(UCH, n - c0);
+        const int grid = (int)std::min<int64_t>(nch * T, (int64_t)ctx->n_cu * 8), mgrid = (int)std::min<int64_t>(nch, (int64_t)ctx->n_cu * 8);
+        // first pass: approximate top-Kc from the fp16 rows
+        rp_pred_params H = P;
+        H.user_begin = (int)(user_begin + c0);
+        H.n_users = (int)nch;
+        H.Kp = Kc;
+        H.dense_B16 = mm->B16;
+        H.b16_inv = 1.0f / mm->b16_scale;
+        hipMemsetAsync(a_nnz, 0, (size_t)nch * 4, st);
+        if (T > 1) hipMemsetAsync(t_nnz, 0, (size_t)nch * T * 4, st);
+        hipMemsetAsync(n_fail, 0, 4, st);
+        H.out_idx = T > 1 ? t_idx : a_idx;
+        H.out_val = T > 1 ? t_val : a_val;
+        H.out_nnz = T > 1 ? t_nnz : a_nnz;
+        hipLaunchKernelGGL((k_predict_tile<true, true>), dim3(grid), dim3(RP_PRED_THREADS), lds1, st, H);
+        if (T > 1)
+          hipLaunchKernelGGL(k_predict_merge, dim3(mgrid), dim3(RP_PRED_THREADS), mlds_c, st, t_idx, t_val, t_nnz, T, Kc, (int)nch, nullptr, nullptr, a_idx,
+                             a_val, a_nnz, 0);
+        // second pass: exact scores of the candidates, their top-Kp, the proof; users without one go to `fail`
+        rp_rescore_params R;
+        R.x_ptr = Xpred->x_ptr;
+        R.x_idx = Xpred->x_idx;
+        R.B = model->B;
+        R.ld = model->ld;
+        R.col_begin = P.col_begin;
+        R.cyc_nb = P.cyc_nb;
+        R.cyc_w = P.cyc_w;
+        R.cyc_r = P.cyc_r;
+        R.delta = mm->b16_delta;
+        R.rowmax = mm->b16_rowmax;
+        R.cand_idx = a_idx;
+        R.cand_val = a_val;
+        R.cand_nnz = a_nnz;
+        R.user_begin = (int)(user_begin + c0);
+        R.n_users = (int)nch;
+        R.Kp = Kp;
+        R.Kc = Kc;
+        R.out_idx = idx_dev + c0 * Kp;
+        R.out_val = val_dev + c0 * Kp;
+        R.out_nnz = nnz_dev + c0;
+        R.fail_list = fail;
+        R.n_fail = n_fail;
+        switch (Kc / 64) {
+          case 2: rp_launch_rescore<2>(ctx, R); break;
+          case 3: rp_launch_rescore<3>(ctx, R); break;
+          case 4: rp_launch_rescore<4>(ctx, R); break;
+          case 5: rp_launch_rescore<5>(ctx, R); break;
+          case 6: rp_launch_rescore<6>(ctx, R); break;
+          case 7: rp_launch_rescore<7>(ctx, R); break;
+          default: rp_launch_rescore<8>(ctx, R); break;
+        }
+        // the one-pass kernel for the users on the list (its count stays on the device: an empty list costs two empty launches)
+        rp_pred_params F = P;
+        F.user_begin = (int)(user_begin + c0);
+        F.n_users = (int)nch;
+        F.user_list = fail;
+        F.n_list = n_fail;
+        if (T > 1) hipMemsetAsync(t_nnz, 0, (size_t)nch * T * 4, st);
+        F.out_idx = T > 1 ? t_idx : idx_dev + c0 * Kp;
+        F.out_val = T > 1 ? t_val : val_dev + c0 * Kp;
+        F.out_nnz = T > 1 ? t_nnz : nnz_dev + c0;
+        hipLaunchKernelGGL(k_predict_tile<true>, dim3(grid), dim3(RP_PRED_THREADS), lds1, st, F);
+        if (T > 1)
+          hipLaunchKernelGGL(k_predict_merge, dim3(mgrid), dim3(RP_PRED_THREADS), mlds_p, st, t_idx, t_val, t_nnz, T, Kp, (int)nch, fail, n_fail,
+                             idx_dev + c0 * Kp, val_dev + c0 * Kp, nnz_dev + c0, 0);
+        RP_HIP(hipGetLastError());
+      }
+      rp_time_end(ctx, ev, RPHIP_T_PREDICT_DENSE, rp_pred_work(Xpred, model, n, Kp));
+      return RPHIP_OK;
+    }
   }
   int32_t* cand_idx = nullptr;
   float* cand_val = nullptr;

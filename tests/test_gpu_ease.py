@@ -441,3 +441,44 @@ def test_ease_l2_sweep_from_cached_gram(hip):
             assert rel_max(B_s.astype(np.float64), B_ref) <= EASE_TOL
     with pytest.raises(RuntimeError):
         g.fit(EASE(l2=1.0))
+
+
+def test_predict_two_pass_equals_one_pass(hip):
+    """K9's two passes (fp16 rows for a candidate list, exact f32 scores of the candidates, a proof per user, the one-pass kernel for
+    users without one - option predict_half) give the one-pass kernel's top-Kp bit for bit: fitted models, several Kp, history
+    removal, an item filter, a pruned model (the fp16 copy is rebuilt), and a model of few distinct values whose ties at the
+    boundary no list can prove (everybody takes the fallback)."""
+    from recpack_amd.synth import powerlaw_csr
+
+    _lib, ctx = hip
+    X = powerlaw_csr(9000, 2600, 0.01, seed=91).to_scipy()
+    dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
+    m = _lib.ease_fit(ctx, dX, 30.0, 0.0)
+    rng = np.random.default_rng(5)
+    keep = (rng.random(X.shape[1]) < 0.7).astype(np.uint8)
+
+    def both(model, Kp, excl, flt=None):
+        out = []
+        for half in (0, 1):
+            ctx.set_option("predict_half", half)
+            if flt is None:
+                out.append(_lib.predict_topk(ctx, model, dX, Kp, exclude_history=excl))
+            else:
+                out.append(_lib.predict_topk(ctx, model, dX, Kp, exclude_history=excl, item_keep=flt))
+        ctx.set_option("predict_half", 1)
+        (i0, v0, n0), (i1, v1, n1) = out
+        np.testing.assert_array_equal(n0, n1)
+        np.testing.assert_array_equal(i0, i1)
+        np.testing.assert_array_equal(v0.view(np.uint32), v1.view(np.uint32))
+        return n1
+
+    try:
+        for Kp, excl in ((10, True), (100, True), (100, False), (300, True)):
+            assert (both(m, Kp, excl) > 0).any()
+        both(m, 50, True, keep)
+        m.dense_prune(int(0.05 * 2600 * 2600))
+        both(m, 100, True)
+        T = rng.choice(np.array([0.0, 0.25, -0.25, 0.5, 1.0], dtype=np.float32), size=(2600, 2600), p=[0.5, 0.2, 0.1, 0.15, 0.05])
+        both(_lib.Model.from_dense_host(ctx, T), 100, True)
+    finally:
+        ctx.set_option("predict_half", 1)
