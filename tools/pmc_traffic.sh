@@ -2,7 +2,7 @@
 # HBM traffic from PMC counters (separate passes per counter, as MI355X_MICROARCH.md prescribes; --kernel-trace only):
 #   tools/pmc_traffic.sh            (on the GPU box; prints per-kernel averages)
 # 1. the ItemKNN step at C4 -> gpurun_out/pmc_traffic_c4.json          (what bench.py's roofline.traffic reads from profiles/)
-# 2. EASE at C3 (K4-K7, K9)  -> gpurun_out/pmc_traffic_ease_c3.json
+# 2. the whole step (ItemKNN + EASE: K4-K7, K9's two passes) at C3  -> gpurun_out/pmc_traffic_ease_c3.json
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 run() {  # tag, command...
   tag=$1; shift
@@ -20,7 +20,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if row.get("Counter_Name") != c:
                 continue
             k = row["Kernel_Name"]
-            if any(s in k for s in ("k_itemknn", "k_predict", "k_rank_hist", "k_scatter", "k_gemm", "k_split", "k_ease", "k_potrf")):
+            if any(s in k for s in ("k_itemknn", "k_predict", "k_rank_hist", "k_scatter", "k_gemm", "k_split", "k_ease", "k_potrf", "k_dense")):
                 acc[k][0] += float(row["Counter_Value"])
                 acc[k][1] += 1
     for k, (v, n) in acc.items():
@@ -30,5 +30,5 @@ json.dump(out, open(f"gpurun_out/pmc_traffic_{tag}.json", "w"), indent=1)
 PY
   rm -rf gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE  # (raw CSVs: tens of MB; gpurun copies back <= 64 MiB)
 }
-run c4 python3 bench.py --config C4 --steps 2 --warmup 1 --cpu-baseline-seconds 0 --ease-config none --tars-config none
-run ease_c3 python3 bench.py --config C2 --steps 1 --warmup 1 --cpu-baseline-seconds 0 --ease-config C3 --tars-config none
+run c4 python3 bench.py --config C4 --steps 2 --warmup 1 --cpu-baseline-seconds 0 --no-ease-in-step --ease-config none --tars-config none
+run ease_c3 python3 bench.py --config C3 --steps 1 --warmup 1 --cpu-baseline-seconds 0 --ease-config none --tars-config none
