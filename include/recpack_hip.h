@@ -102,6 +102,14 @@ int rphip_ctx_trim(rphip_ctx* ctx);
  *                       (rphip_csr_set_values) always use the 64-bit sums.  Both are independent of the order of the adds:
  *                       predict is bit-reproducible run to run.
  *   "predict_tile32"    2048 | 4096 (default): column tile of the 32-bit sums (tuning).
+ *   "predict_half"      1 (default) | 0.  Fused predict + top-Kp of DENSE models (EASE; X @ B of base.py:248 is HBM-bound on the rows
+ *                       of B) in two passes: the rows are first read from an fp16 copy of B (built on first use, half the bytes) to
+ *                       keep Kp + 28..91 candidates per user by approximate score; the candidates are then scored exactly (the f32
+ *                       sums of the one-pass kernel, same order, bit for bit) and a per-user bound on |approximate - exact| - the
+ *                       sum over the history of each row's largest rounding error - proves that no column outside the list can be
+ *                       in the exact top-Kp; a user whose list cannot prove it (< 0.1 % measured) is served by the one-pass kernel.
+ *                       The results are those of the one-pass kernel.  Costs n_items * ld * 2 bytes beside B; skipped (as with 0)
+ *                       when that does not fit or Kp > 488.
  *   "gemm_mode"         2 (default) | 1 | 0: how the O(n^3) products of the EASE solve (and rphip_gemm_nt_f32) multiply their fp32 operands.
  *                       2: two fp16 planes per operand, both rounded to nearest (x = h1 + h2 to 2^-24 |x|), three plane products per
  *                          step on v_mfma_f32_32x32x16_f16; each operand is scaled by a power of two taken from its largest magnitude
@@ -118,6 +126,8 @@ int rphip_ctx_trim(rphip_ctx* ctx);
  *                       chunk; a product on a side stream has a second pair.  rphip_ctx_trim releases them.
  *   "gemm_shape16"      1 (default) | 0.  The plane product kernel on v_mfma_f32_16x16x32_f16 (the chip holds a higher clock on it:
  *                       363 against 314 TFLOP/s) or on v_mfma_f32_32x32x16_f16.
+ *   "gemm_wide"         1 (default) | 0.  The plane product kernel on 256 x 128 tiles, eight waves, three LDS stages with counted
+ *                       waits (k_gemm_hp16w; bit-identical results, +2..6 %) or on 128 x 128 tiles with two stages.
  *   "gemm_supertile"    0 (default) | 1.  Tile order of the GEMM's workgroups: supertiles of 64 tiles handed to the 8 XCDs round-robin
  *                       (each XCD's L2 then holds the 8 + 8 panels of an 8 x 8 block of tiles), or the plain row-major grid
  *                       (measured equal within 1 %: the products are not bound by operand traffic).

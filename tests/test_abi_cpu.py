@@ -126,3 +126,21 @@ def test_k_limit_raises_before_upload():
     X.data[:] = 1
     with pytest.raises(ValueError, match=str(RP_K_MAX)):
         recpack_amd.ItemKNN(K=RP_K_MAX + 1).fit(X)
+
+
+def test_host_code_under_asan():
+    """sanitizers belong on the CPU build.  `make -C recpack_amd/csrc asan` compiles the HOST side of rp_api.hip
+    (context, block cache with event-carrying frees, grow-only scratch, options, timing bookkeeping, argument validation) with
+    -fsanitize=address against a stub HIP runtime (tests/host_asan/hip_stub.cpp: malloc'ed "device" memory, no kernels) and
+    tests/host_asan/driver.cpp exercises it: exit code 0 = every check held, ASan and LeakSanitizer silent."""
+    import shutil
+    import subprocess
+
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "recpack_amd", "csrc")
+    b = subprocess.run(["make", "-C", csrc, "asan"], capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stdout[-2000:] + b.stderr[-2000:]
+    r = subprocess.run([os.path.join(csrc, "rp_host_asan")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "host asan driver: ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
