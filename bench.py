@@ -483,7 +483,7 @@ def main():
             em, _ = rdist.ease_fit_sharded(ctx, dXe, args.l2, 0.0, device, comm=comm)
             torch.cuda.synchronize()
             t2 = time.perf_counter()
-            rdist.predict_topk_sharded(ctx, em, dXe, Kp, device, exclude_history=False)
+            rdist.predict_topk_sharded(ctx, em, dXe, Kp, device, exclude_history=False, comm=comm)
             keep["dXe"] = dXe
         torch.cuda.synchronize()
         t3 = time.perf_counter()

@@ -434,6 +434,14 @@ int rphip_comm_all_reduce_sum_i32(rphip_ctx* ctx, rphip_comm* comm, int32_t* buf
  * (a local top-Kp per user; rphip_predict_merge_topk merges the ranks' lists).  *out = NULL on a rank that owns only padding. */
 int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip_csr* X, double l2, double alpha, int32_t panel_tiles,
                         rphip_model** out);
+/* Fused predict + top-Kp with the model's columns spread over the ranks of `comm` (the models of rphip_ease_fit_dist; `model` NULL
+ * on a rank that owns only padding): every rank scores the users against its own columns, the local lists travel to the rank
+ * that owns the user (one personalised exchange per chunk of users) and are merged there by (score desc, column asc) - the
+ * single-GPU result (base.py:248 + metrics/base.py:189).  Rank r ends with the users [r * per, (r + 1) * per), per =
+ * ceil(n_users / world): *user_begin_out, *n_users_out say which; idx / val / nnz (device) must hold per * Kp / per entries. */
+int rphip_predict_topk_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip_model* model, const rphip_csr* Xpred, int32_t Kp,
+                            int32_t exclude_history, int64_t* user_begin_out, int64_t* n_users_out, int32_t* idx_dev, float* val_dev,
+                            int32_t* nnz_dev);
 /* Layout of a dense model's columns: local column l is item ((l / panel) * world + rank) * panel + l % panel when panel > 0
  * (block-cyclic, rphip_ease_fit_dist), col_begin + l otherwise; n_local_cols of them are items (the rest is padding). */
 int rphip_model_dense_layout(const rphip_model* m, int64_t* n_local_cols, int64_t* panel, int32_t* world, int32_t* rank, int64_t* col_begin);

@@ -124,6 +124,7 @@ PROTOTYPES = {
     "rphip_ease_fit_dist": (C.c_int, [_p, _p, _p, _f64, _f64, _i32, _pp]),
     "rphip_model_dense_layout": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64)]),
     "rphip_ease_fit_dist_stats": (C.c_int, [_p, _p]),
+    "rphip_predict_topk_dist": (C.c_int, [_p, _p, _p, _p, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64), _p, _p, _p]),
 }
 
 _lock = threading.Lock()
@@ -661,6 +662,25 @@ def ease_fit_dist(ctx: Context, comm: Comm, X: DeviceCSR, l2: float, alpha: floa
             raise err
         raise
     return Model(ctx, h) if h.value else None
+
+
+def predict_topk_dist(ctx: Context, comm: Comm, model, X: DeviceCSR, Kp: int, idx_t, val_t, nnz_t, exclude_history: bool = False):
+    """Top-Kp of every user with the model's columns spread over the ranks of ``comm`` (rphip_predict_topk_dist): local lists,
+    one exchange per chunk inside the library, merge on the rank that owns the user.  The outputs (torch CUDA tensors of
+    ceil(n_users / world) rows) receive this rank's users; returns (first user, number of users)."""
+    _torch_inputs_ready(ctx)
+    ub, nu = C.c_int64(), C.c_int64()
+    try:
+        check(ctx.lib.rphip_predict_topk_dist(ctx.handle, comm.handle, model.handle if model is not None else None, X.handle, int(Kp),
+                                              1 if exclude_history else 0, C.byref(ub), C.byref(nu), C.c_void_p(idx_t.data_ptr()),
+                                              C.c_void_p(val_t.data_ptr()), C.c_void_p(nnz_t.data_ptr())))
+    except RecpackHipError:
+        err = comm.error["error"] if isinstance(comm.error, dict) else None
+        if err is not None:
+            comm.error["error"] = None
+            raise err
+        raise
+    return ub.value, nu.value
 
 
 def ease_fit_dist_stats(ctx: Context) -> dict:

@@ -1,0 +1,11 @@
+// The communicator's operations for the library's own distributed entry points (rp_ease_dist.hip implements them).
+#pragma once
+#include "rp_common.h"
+
+int rp_comm_world(const rphip_comm* c);
+int rp_comm_rank(const rphip_comm* c);
+// stream-ordered on `st`; see rphip_comm_ops in include/recpack_hip.h for the semantics
+int rp_comm_broadcast(rphip_comm* c, void* buf, int64_t bytes, int root, hipStream_t st);
+int rp_comm_all_gather(rphip_comm* c, const void* send, void* recv, int64_t bytes_per_rank, hipStream_t st);
+int rp_comm_exchange(rphip_comm* c, const void* send, const int64_t* soff, const int64_t* sbytes, void* recv, const int64_t* roff,
+                     const int64_t* rbytes, hipStream_t st);

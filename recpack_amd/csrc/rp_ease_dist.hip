@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "rp_common.h"
+#include "rp_comm.h"
 #include "rp_gemm.h"
 
 // ---- communicator ---------------------------------------------------------------------------------------------------------
@@ -176,7 +177,10 @@ extern "C" int rphip_comm_info(const rphip_comm* c, int32_t* world, int32_t* ran
     if ((expr) != 0) RP_FAIL(RPHIP_EHIP, "the caller's transport failed in %s", what);             \
   } while (0)
 
-static int rp_comm_broadcast(rphip_comm* c, void* buf, int64_t bytes, int root, hipStream_t st) {
+int rp_comm_world(const rphip_comm* c) { return c->world; }
+int rp_comm_rank(const rphip_comm* c) { return c->rank; }
+
+int rp_comm_broadcast(rphip_comm* c, void* buf, int64_t bytes, int root, hipStream_t st) {
   if (c->world == 1 || bytes <= 0) return RPHIP_OK;
   if (c->rank == root)
     c->bytes_sent += bytes;
@@ -190,7 +194,7 @@ static int rp_comm_broadcast(rphip_comm* c, void* buf, int64_t bytes, int root, 
   return RPHIP_OK;
 }
 
-static int rp_comm_all_gather(rphip_comm* c, const void* send, void* recv, int64_t bytes_per_rank, hipStream_t st) {
+int rp_comm_all_gather(rphip_comm* c, const void* send, void* recv, int64_t bytes_per_rank, hipStream_t st) {
   if (bytes_per_rank <= 0) return RPHIP_OK;
   if (c->world == 1) {
     if (send != recv) RP_HIP(hipMemcpyAsync(recv, send, (size_t)bytes_per_rank, hipMemcpyDeviceToDevice, st));
@@ -206,7 +210,7 @@ static int rp_comm_all_gather(rphip_comm* c, const void* send, void* recv, int64
   return RPHIP_OK;
 }
 
-static int rp_comm_exchange(rphip_comm* c, const void* send, const int64_t* soff, const int64_t* sbytes, void* recv, const int64_t* roff,
+int rp_comm_exchange(rphip_comm* c, const void* send, const int64_t* soff, const int64_t* sbytes, void* recv, const int64_t* roff,
                             const int64_t* rbytes, hipStream_t st) {
   const int me = c->rank;
   for (int p = 0; p < c->world; ++p)

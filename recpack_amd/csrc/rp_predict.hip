@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstring>
 
+#include "rp_comm.h"
 #include "rp_common.h"
 #include "rp_select.h"
 #include "rp_wave.h"
@@ -1852,6 +1853,101 @@ extern "C" int rphip_predict_merge_topk(rphip_ctx* ctx, int32_t n_lists, int32_t
                      (int)n_users, nullptr, nullptr, idx_dev, val_dev, nnz_dev, 1);
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, RPHIP_T_PREDICT, 16.0 * (double)n_users * n_lists * Kp);
+  return RPHIP_OK;
+}
+
+// ---- predict with the model's columns spread over the ranks of a communicator --------------------------
+// Every rank scores the users against ITS columns (a local top-Kp per user), the lists travel to the rank that owns the user - one
+// personalised exchange per chunk, each rank receives only its own users' lists: U * Kp * 8 bytes per rank over the whole call -
+// and are merged there by (score desc, column asc), the single-GPU order.  Rank r ends with the rows of users
+// [r * per, (r + 1) * per), per = ceil(U / world).
+// received slots [list s][user][Kp] -> the merge's [user][list][Kp]
+__global__ void k_lists_to_users(const char* __restrict__ recv, long long slot_bytes, int W, int cs, int n, int Kp, int32_t* __restrict__ ci,
+                                 float* __restrict__ cv, int32_t* __restrict__ cn) {
+  const long long total = (long long)n * W * Kp;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(e % Kp);
+    const long long uw = e / Kp;
+    const int s = (int)(uw % W);
+    const long long u = uw / W;
+    const char* slot = recv + (long long)s * slot_bytes;
+    ci[e] = reinterpret_cast<const int32_t*>(slot)[u * Kp + k];
+    cv[e] = reinterpret_cast<const float*>(slot + (long long)cs * Kp * 4)[u * Kp + k];
+    if (k == 0) cn[uw] = reinterpret_cast<const int32_t*>(slot + (long long)cs * Kp * 8)[u];
+  }
+}
+
+extern "C" int rphip_predict_topk_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip_model* model, const rphip_csr* X, int32_t Kp,
+                                       int32_t exclude_history, int64_t* user_begin_out, int64_t* n_users_out, int32_t* idx_dev, float* val_dev,
+                                       int32_t* nnz_dev) {
+  if (!ctx || !comm || !X || !idx_dev || !val_dev || !nnz_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if (Kp < 1 || Kp > RP_K_MAX) RP_FAIL(RPHIP_ELIMIT, "Kp=%d outside 1..%d", Kp, RP_K_MAX);
+  RP_TRY(rp_set_device(ctx));
+  const int W = rp_comm_world(comm), me = rp_comm_rank(comm);
+  const int64_t U = X->n_users;
+  const int64_t per = rp_cdiv(std::max<int64_t>(U, 1), W);
+  auto share = [&](int r) { return std::max<int64_t>(0, std::min<int64_t>(U, (int64_t)(r + 1) * per) - (int64_t)r * per); };
+  const int64_t mine = share(me);
+  if (user_begin_out) *user_begin_out = std::min<int64_t>(U, (int64_t)me * per);
+  if (n_users_out) *n_users_out = mine;
+  if (W > RPS_MISC_INTS - RPS_USER - 1) RP_FAIL(RPHIP_ELIMIT, "at most %d ranks", RPS_MISC_INTS - RPS_USER - 1);
+  hipStream_t st = ctx->stream;
+  const int cs = (int)std::min<int64_t>(per, std::max<int64_t>(1024, ((int64_t)1 << 18) / W));  // users per destination and chunk
+  const int64_t slot = (int64_t)cs * ((int64_t)Kp * 8 + 4);
+  char *sendb = nullptr, *recvb = nullptr, *cand = nullptr;
+  struct hold {  // released on every way out
+    rphip_ctx* c;
+    void* p[3] = {nullptr, nullptr, nullptr};
+    ~hold() {
+      hipStreamSynchronize(c->stream);
+      for (void* q : p) rp_dev_free(c, q);
+    }
+  } H{ctx};
+  RP_TRY(rp_dev_alloc(ctx, (size_t)slot * W, (void**)&sendb));
+  H.p[0] = sendb;
+  RP_TRY(rp_dev_alloc(ctx, (size_t)slot * W, (void**)&recvb));
+  H.p[1] = recvb;
+  RP_TRY(rp_dev_alloc(ctx, (size_t)slot * W, (void**)&cand));
+  H.p[2] = cand;
+  int32_t* ci = (int32_t*)cand;
+  float* cv = (float*)(cand + (int64_t)cs * W * Kp * 4);
+  int32_t* cn = (int32_t*)(cand + (int64_t)cs * W * Kp * 8);
+  const size_t mlds = (size_t)W * Kp * 8 + rp_select_smem_bytes(W * Kp) + (size_t)Kp * 8;
+  if (mlds > 160 * 1024 || W * Kp >= RPS_FLAG) RP_FAIL(RPHIP_ELIMIT, "Kp=%d with %d ranks needs %zu bytes of LDS for the merge", Kp, W, mlds);
+  std::vector<int64_t> soff(W), sby(W), roff(W), rby(W);
+  for (int64_t o = 0; o < per; o += cs) {
+    const int64_t len_me = std::max<int64_t>(0, std::min<int64_t>(cs, mine - o));
+    for (int d = 0; d < W; ++d) {
+      const int64_t len_d = std::max<int64_t>(0, std::min<int64_t>(cs, share(d) - o));
+      char* sl = sendb + (int64_t)d * slot;
+      soff[d] = (int64_t)d * slot;
+      sby[d] = len_d > 0 ? slot : 0;
+      roff[d] = (int64_t)d * slot;
+      rby[d] = len_me > 0 ? slot : 0;
+      if (len_d == 0) continue;
+      int32_t* li = (int32_t*)sl;
+      float* lv = (float*)(sl + (int64_t)cs * Kp * 4);
+      int32_t* ln = (int32_t*)(sl + (int64_t)cs * Kp * 8);
+      if (model) {
+        const int64_t ub = (int64_t)d * per + o;
+        RP_TRY(rp_predict_topk_impl(ctx, model, X, ub, ub + len_d, Kp, exclude_history, nullptr, li, lv, ln));
+      } else {  // this rank holds no columns: empty lists
+        RP_HIP(hipMemsetAsync(ln, 0, (size_t)len_d * 4, st));
+      }
+    }
+    RP_TRY(rp_comm_exchange(comm, sendb, soff.data(), sby.data(), recvb, roff.data(), rby.data(), st));
+    if (len_me > 0) {
+      const long long total = (long long)len_me * W * Kp;
+      hipLaunchKernelGGL(k_lists_to_users, dim3((unsigned)std::min<long long>(8192, rp_cdiv(total, 256))), dim3(256), 0, st, recvb, (long long)slot, W, cs,
+                         (int)len_me, (int)Kp, ci, cv, cn);
+      RP_HIP(hipMemsetAsync(idx_dev + o * Kp, 0xFF, (size_t)len_me * Kp * 4, st));
+      RP_HIP(hipMemsetAsync(val_dev + o * Kp, 0, (size_t)len_me * Kp * 4, st));
+      RP_HIP(hipFuncSetAttribute((const void*)k_predict_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+      hipLaunchKernelGGL(k_predict_merge, dim3((unsigned)std::min<int64_t>(len_me, (int64_t)ctx->n_cu * 8)), dim3(RP_PRED_THREADS), mlds, st, ci, cv, cn, W,
+                         (int)Kp, (int)len_me, nullptr, nullptr, idx_dev + o * Kp, val_dev + o * Kp, nnz_dev + o, 1);
+      RP_HIP(hipGetLastError());
+    }
+  }
   return RPHIP_OK;
 }
 

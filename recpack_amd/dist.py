@@ -290,58 +290,33 @@ def ease_fit_sweeps(ctx, dX, l2: float, alpha: float, device, group=None, panel_
     return _lib.Model.from_dense_cols(ctx, n, c0, n_cols, S), (c0, n_cols)
 
 
-def predict_topk_sharded(ctx, model, dX, Kp: int, device, exclude_history: bool = False, group=None, user_chunk: int = 1 << 18):
-    """Top-Kp for every user with B sharded by item columns: every rank scores ALL users against its own
-    columns (`model` = ease_fit_sharded's slab model, None on a rank that owns only padding) and keeps a local top-Kp; the lists
-    are all-gathered (U * Kp * 8 bytes per rank) and merged per user by (score desc, column asc) - the single-GPU order.  The
-    merge of a chunk of users is split over the ranks; returns this rank's part: (user_ids int64 [m], idx int32 [m, Kp],
-    val float32 [m, Kp], nnz int32 [m]) as torch tensors.  Users are processed in chunks of ``user_chunk``."""
+def predict_topk_sharded(ctx, model, dX, Kp: int, device, exclude_history: bool = False, group=None, user_chunk: int = 1 << 18, comm=None):
+    """Top-Kp for every user with B sharded by item columns, inside the library
+    (rphip_predict_topk_dist): every rank scores ALL users against its own columns (`model` = ease_fit_sharded's model, None
+    on a rank that owns only padding) and keeps a local top-Kp; the lists travel to the rank that owns the user - one personalised
+    exchange per chunk through the communicator, U * Kp * 8 bytes per rank in all - and are merged there by (score desc, column
+    asc), the single-GPU order.  Returns this rank's part: (user_ids int64 [m], idx int32 [m, Kp], val float32 [m, Kp],
+    nnz int32 [m]) as torch tensors; rank r owns the users [r * per, (r + 1) * per), per = ceil(U / world).
+    (``user_chunk`` is kept for callers of the earlier torch-driven version; the library picks its own chunking.)"""
     import torch
-    import torch.distributed as dist
 
     from recpack_amd import _lib
 
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    U = dX.shape[0]
-    out_u, out_i, out_v, out_n = [], [], [], []
-    for u0 in range(0, U, user_chunk):
-        u1 = min(U, u0 + user_chunk)
-        nu = u1 - u0
-        li = torch.full((nu, Kp), -1, dtype=torch.int32, device=device)
-        lv = torch.zeros((nu, Kp), dtype=torch.float32, device=device)
-        ln = torch.zeros((nu,), dtype=torch.int32, device=device)
-        if model is not None:
-            _lib.predict_topk_dev(ctx, model, dX, Kp, li, lv, ln, exclude_history=exclude_history, user_begin=u0, user_end=u1)
-            ctx.sync()
-        if world > 1:
-            gi = torch.empty((world, nu, Kp), dtype=torch.int32, device=device)
-            gv = torch.empty((world, nu, Kp), dtype=torch.float32, device=device)
-            gn = torch.empty((world, nu), dtype=torch.int32, device=device)
-            dist.all_gather_into_tensor(gi.view(world * nu, Kp), li, group=group)  # (output = the inputs concatenated along dim 0)
-            dist.all_gather_into_tensor(gv.view(world * nu, Kp), lv, group=group)
-            dist.all_gather_into_tensor(gn.view(world * nu), ln, group=group)
-        else:
-            gi, gv, gn = li[None], lv[None], ln[None]
-        per = -(-nu // world)
-        a, b = min(nu, rank * per), min(nu, (rank + 1) * per)
-        if b > a:
-            ci = gi[:, a:b].permute(1, 0, 2).contiguous()
-            cv = gv[:, a:b].permute(1, 0, 2).contiguous()
-            cn = gn[:, a:b].t().contiguous()
-            oi = torch.empty((b - a, Kp), dtype=torch.int32, device=device)
-            ov = torch.empty((b - a, Kp), dtype=torch.float32, device=device)
-            on = torch.empty((b - a,), dtype=torch.int32, device=device)
-            _lib.predict_merge_topk(ctx, ci, cv, cn, oi, ov, on)
-            ctx.sync()
-            out_u.append(torch.arange(u0 + a, u0 + b, device=device))
-            out_i.append(oi)
-            out_v.append(ov)
-            out_n.append(on)
-    if not out_u:
-        return (torch.empty((0,), dtype=torch.int64, device=device), torch.empty((0, Kp), dtype=torch.int32, device=device),
-                torch.empty((0, Kp), dtype=torch.float32, device=device), torch.empty((0,), dtype=torch.int32, device=device))
-    return torch.cat(out_u), torch.cat(out_i), torch.cat(out_v), torch.cat(out_n)
+    own = comm is None
+    if own:
+        comm = make_comm(ctx, device, group)
+    try:
+        U = dX.shape[0]
+        per = -(-max(U, 1) // comm.world)
+        oi = torch.empty((per, Kp), dtype=torch.int32, device=device)
+        ov = torch.empty((per, Kp), dtype=torch.float32, device=device)
+        on = torch.empty((per,), dtype=torch.int32, device=device)
+        ub, nu = _lib.predict_topk_dist(ctx, comm, model, dX, Kp, oi, ov, on, exclude_history=exclude_history)
+        ctx.sync()
+    finally:
+        if own:
+            comm.close()
+    return torch.arange(ub, ub + nu, device=device), oi[:nu], ov[:nu], on[:nu]
 
 
 def ease_fit_replicated(ctx, dX, l2: float, alpha: float, device, group=None, panel_tiles: int = 16):

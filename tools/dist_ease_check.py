@@ -71,7 +71,7 @@ for l2, alpha in ((50.0, 0.0), (5.0, 0.5)):
             ptr, _, ld = ms.dense_device_ptr()
             slab = torch.as_tensor(rdist._DevPtr(ptr, (I, ld), "<f4", ms), device=device)[:, :nc].cpu().numpy()
             err_s = float(np.abs(slab - B_ref[:, cols]).max() / np.abs(B_ref).max())
-        users, pi, pv, pn = rdist.predict_topk_sharded(ctx, ms, dX, 20, device, exclude_history=True, user_chunk=257)
+        users, pi, pv, pn = rdist.predict_topk_sharded(ctx, ms, dX, 20, device, exclude_history=True, comm=comm)
         users = users.cpu().numpy()
         sel = users < nu
         same = pi.cpu().numpy()[sel] == b[0][users[sel]]

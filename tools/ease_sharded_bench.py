@@ -60,7 +60,7 @@ for it in range(2):
         print(f"world {world}: I={I} {route} fit {dt*1e3:.1f} ms = {fl * n_pad**3 / dt / 1e12:.1f} TF/s by the {fl:.0f} n^3 model{extra}", flush=True)
     if route in ("dist", "sweeps") and it == 1:
         t0 = time.perf_counter()
-        rdist.predict_topk_sharded(ctx, m, dX, 100, dev)
+        rdist.predict_topk_sharded(ctx, m, dX, 100, dev, comm=comm)
         torch.cuda.synchronize()
         if rank == 0:
             print(f"world {world}: sharded predict + top-100 of {U} users {1e3 * (time.perf_counter() - t0):.1f} ms", flush=True)
