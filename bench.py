@@ -446,7 +446,7 @@ def main():
         e_idx = torch.empty((U, Kp), dtype=torch.int32, device=device)
         e_val = torch.empty((U, Kp), dtype=torch.float32, device=device)
         e_nnz = torch.empty((U,), dtype=torch.int32, device=device)
-    comm = rdist.make_comm(ctx, device, transport=args.ease_transport) if (ease_on and world > 1) else None
+    comm = rdist.make_comm(ctx, device, transport=args.ease_transport) if world > 1 else None  # the library's communicator: every collective below
 
     keep = {}
     parts = {"itemknn": 0.0, "ease_fit": 0.0, "ease_predict": 0.0}
@@ -460,13 +460,13 @@ def main():
     def step():
         t0 = time.perf_counter()
         if world > 1:  # K0 with the degree pass sharded by item rows + one all-reduce of the degree vector
-            dX = rdist.csr_for_shard(ctx, indptr_t, indices_t, (U, I), row_parts[rank], device)
+            dX = rdist.csr_for_shard(ctx, indptr_t, indices_t, (U, I), row_parts[rank], device, comm=comm)
         else:
             dX = _lib.DeviceCSR.from_device(ctx, indptr_t, indices_t, (U, I))  # K0
         if world == 1:
             model = _lib.itemknn_fit(ctx, dX, args.K)  # K1-K3
         else:
-            model = rdist.fit_itemknn_sharded(ctx, dX, args.K, row_parts, device)  # K1-K3 + all-gather
+            model = rdist.fit_itemknn_sharded(ctx, dX, args.K, row_parts, device, comm=comm)  # K1-K3 + all-gather
         _lib.predict_topk_dev(ctx, model, dX, Kp, out_idx, out_val, out_nnz, user_begin=ub, user_end=ue)  # K8
         keep["model"], keep["dX"] = model, dX
         if not ease_on:

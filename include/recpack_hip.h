@@ -418,6 +418,12 @@ int rphip_comm_info(const rphip_comm* comm, int32_t* world, int32_t* rank, int32
 /* int32 sum over the ranks of a device vector, in place (the item degrees of a sharded K0: rphip_csr_degrees_device) */
 int rphip_comm_all_reduce_sum_i32(rphip_ctx* ctx, rphip_comm* comm, int32_t* buf_dev, int64_t count);
 
+/* Multi-GPU ItemKNN fit: every rank has fitted the item rows [row_bounds[r], row_bounds[r + 1]) (rphip_itemknn_fit* with a row
+ * range; row_bounds has world + 1 entries, 0 .. n_items); the shards are exchanged with ONE all-gather through the communicator
+ * (n_items * K * 12 bytes in all, padded to the longest shard) straight into a new model holding all rows, ready for predict
+ * (the item rows of nearest_neighbour.py:204-224 are independent of each other; the reference has no multi-GPU path). */
+int rphip_itemknn_gather(rphip_ctx* ctx, rphip_comm* comm, const rphip_model* local, const int64_t* row_bounds, rphip_model** out);
+
 /* EASE fit over the ranks of `comm` with the n x n matrix SHARDED in memory (replaces EASE._fit,
  * ease.py:63-95, whose np.linalg.inv is the n^3 step).  Layout: panels of nb = 128 * panel_tiles columns, panel p on rank
  * p % world (1-D block-cyclic: every rank's share of the lower triangle is the same whatever the pivot); a rank stores its

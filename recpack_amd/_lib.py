@@ -124,6 +124,7 @@ PROTOTYPES = {
     "rphip_ease_fit_dist": (C.c_int, [_p, _p, _p, _f64, _f64, _i32, _pp]),
     "rphip_model_dense_layout": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64)]),
     "rphip_ease_fit_dist_stats": (C.c_int, [_p, _p]),
+    "rphip_itemknn_gather": (C.c_int, [_p, _p, _p, _p, _pp]),
     "rphip_predict_topk_dist": (C.c_int, [_p, _p, _p, _p, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64), _p, _p, _p]),
 }
 
@@ -646,6 +647,23 @@ class Comm:
             self.handle = None
 
     __del__ = close
+
+
+def itemknn_gather(ctx: Context, comm: Comm, local: Model, row_bounds) -> Model:
+    """The ranks' row shards of a multi-GPU ItemKNN fit into one model with all rows (rphip_itemknn_gather: one all-gather through
+    the communicator, landing in the model's own arrays).  ``row_bounds``: world + 1 row indices, 0 .. n_items."""
+    b = np.ascontiguousarray(row_bounds, dtype=np.int64)
+    assert b.shape == (comm.world + 1,)
+    h = C.c_void_p()
+    try:
+        check(ctx.lib.rphip_itemknn_gather(ctx.handle, comm.handle, local.handle, _np_ptr(b), C.byref(h)))
+    except RecpackHipError:
+        err = comm.error["error"] if isinstance(comm.error, dict) else None
+        if err is not None:
+            comm.error["error"] = None
+            raise err
+        raise
+    return Model(ctx, h)
 
 
 def ease_fit_dist(ctx: Context, comm: Comm, X: DeviceCSR, l2: float, alpha: float = 0.0, panel_tiles: int = 0):

@@ -17,6 +17,7 @@
 
 #include <algorithm>
 
+#include "rp_comm.h"
 #include "rp_common.h"
 #include "rp_select.h"
 #include "rp_wave.h"
@@ -1274,6 +1275,99 @@ static int rp_model_from_topk(rphip_ctx* ctx, int64_t n_items, int32_t K, const 
       return r;
     }
     if (kind == hipMemcpyHostToDevice) RP_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  *out = m;
+  return RPHIP_OK;
+}
+
+// ---- multi-GPU fit: the ranks' row shards into one model ---------------------------------------------
+// Every rank fitted the item rows [bounds[r], bounds[r + 1]) (rphip_itemknn_fit* with a row range); the neighbour lists are
+// exchanged with ONE all-gather through the communicator - the shards packed [idx | val | nnz] and padded to the longest one,
+// I * K * 12 bytes in all - and land directly in the new model's arrays (one unpack kernel), which is then finalised for predict.
+__global__ void k_pack_shard(const int32_t* __restrict__ idx, const double* __restrict__ val, const int32_t* __restrict__ nnz, long long rows, int K,
+                             long long max_rows, char* __restrict__ out) {
+  int32_t* oi = reinterpret_cast<int32_t*>(out + max_rows * K * 8);
+  double* ov = reinterpret_cast<double*>(out);  // (the 8-byte part first: alignment)
+  int32_t* on = reinterpret_cast<int32_t*>(out + max_rows * K * 12);
+  const long long n = rows * K;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    oi[e] = idx[e];
+    ov[e] = val[e];
+    if (e < rows) on[e] = nnz[e];
+  }
+}
+
+struct rp_bounds32 {
+  long long b[33];
+};
+
+__global__ void k_unpack_shards(const char* __restrict__ in, long long slot, long long max_rows, int K, int W, rp_bounds32 bd, int32_t* __restrict__ idx,
+                                double* __restrict__ val, int32_t* __restrict__ nnz) {
+  const int r = blockIdx.y;
+  const long long r0 = bd.b[r], rows = bd.b[r + 1] - r0;
+  const char* src = in + (long long)r * slot;
+  const double* sv = reinterpret_cast<const double*>(src);
+  const int32_t* si = reinterpret_cast<const int32_t*>(src + max_rows * K * 8);
+  const int32_t* sn = reinterpret_cast<const int32_t*>(src + max_rows * K * 12);
+  const long long n = rows * K;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    idx[r0 * K + e] = si[e];
+    val[r0 * K + e] = sv[e];
+    if (e < rows) nnz[r0 + e] = sn[e];
+  }
+}
+
+extern "C" int rphip_itemknn_gather(rphip_ctx* ctx, rphip_comm* comm, const rphip_model* local, const int64_t* row_bounds, rphip_model** out) {
+  if (!ctx || !comm || !local || !row_bounds || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (local->kind != RPHIP_MODEL_TOPK) RP_FAIL(RPHIP_ESTATE, "not a neighbour-list model");
+  const int W = rp_comm_world(comm), me = rp_comm_rank(comm);
+  if (W > 32) RP_FAIL(RPHIP_ELIMIT, "at most 32 ranks");
+  const int64_t I = local->n_items;
+  const int K = local->K;
+  rp_bounds32 bd;
+  long long max_rows = 0;
+  for (int r = 0; r <= W; ++r) {
+    bd.b[r] = row_bounds[r];
+    if (r > 0) {
+      if (row_bounds[r] < row_bounds[r - 1]) RP_FAIL(RPHIP_EINVAL, "row bounds must not decrease");
+      max_rows = std::max<long long>(max_rows, row_bounds[r] - row_bounds[r - 1]);
+    }
+  }
+  if (row_bounds[0] != 0 || row_bounds[W] != I) RP_FAIL(RPHIP_EINVAL, "the row bounds must cover [0, %lld)", (long long)I);
+  if (local->row_begin != row_bounds[me] || local->row_end != row_bounds[me + 1])
+    RP_FAIL(RPHIP_EINVAL, "this rank's model holds rows [%lld,%lld), the bounds say [%lld,%lld)", (long long)local->row_begin, (long long)local->row_end,
+            (long long)row_bounds[me], (long long)row_bounds[me + 1]);
+  RP_TRY(rp_set_device(ctx));
+  hipStream_t st = ctx->stream;
+  rphip_model* m = nullptr;
+  RP_TRY(rp_model_alloc_topk(ctx, I, 0, I, K, &m));
+  const long long slot = ((max_rows * K * 12 + max_rows * 4 + 255) / 256) * 256;
+  char *sendb = nullptr, *recvb = nullptr;
+  int rc = rp_dev_alloc(ctx, (size_t)std::max<long long>(slot, 256), (void**)&sendb);
+  if (rc == RPHIP_OK) rc = rp_dev_alloc(ctx, (size_t)std::max<long long>(slot, 256) * W, (void**)&recvb);
+  if (rc == RPHIP_OK && max_rows > 0) {
+    hipEvent_t ev;
+    rp_time_begin(ctx, &ev);
+    const long long rows = local->row_end - local->row_begin;
+    if (rows > 0)
+      hipLaunchKernelGGL(k_pack_shard, dim3((unsigned)std::min<long long>(4096, rp_cdiv(rows * K, 256))), dim3(256), 0, st, local->idx, local->val, local->nnz,
+                         rows, K, max_rows, sendb);
+    rc = rp_comm_all_gather(comm, sendb, recvb, slot, st);
+    if (rc == RPHIP_OK) {
+      hipLaunchKernelGGL(k_unpack_shards, dim3((unsigned)std::min<long long>(2048, std::max<long long>(1, rp_cdiv(max_rows * K, 256))), W), dim3(256), 0, st,
+                         recvb, slot, max_rows, K, W, bd, m->idx, m->val, m->nnz);
+      if (hipGetLastError() != hipSuccess) rc = RPHIP_EHIP;
+    }
+    rp_time_end(ctx, ev, RPHIP_T_TOPK_MERGE, (double)I * K * 24.0);
+    if (rc == RPHIP_OK) rc = rp_model_finalize_topk(ctx, m);
+  }
+  hipStreamSynchronize(st);
+  rp_dev_free(ctx, sendb);
+  rp_dev_free(ctx, recvb);
+  if (rc != RPHIP_OK) {
+    rphip_model_destroy(m);
+    return rc;
   }
   *out = m;
   return RPHIP_OK;

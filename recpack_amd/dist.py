@@ -109,7 +109,7 @@ def model_dense_tensor(model, device):
     return full[:, :n]
 
 
-def csr_for_shard(ctx, indptr_t, indices_t, shape, rows: Tuple[int, int], device, group=None):
+def csr_for_shard(ctx, indptr_t, indices_t, shape, rows: Tuple[int, int], device, group=None, comm=None):
     """K0 for one shard of a multi-GPU fit with the degree pass sharded: this rank histograms (and ranks) only its own item rows
     ``rows``, the int32 degree vector (4 * n_items bytes) is summed over the ranks with ONE all-reduce (RCCL over xGMI when the
     backend is nccl - BASELINE.json's north_star), then the reciprocal degrees are formed.  X^T is filled for the shard's rows."""
@@ -118,17 +118,20 @@ def csr_for_shard(ctx, indptr_t, indices_t, shape, rows: Tuple[int, int], device
 
     from recpack_amd import _lib
 
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if comm is not None and comm.world == 1 or comm is None and (not dist.is_initialized() or dist.get_world_size(group) == 1):
         return _lib.DeviceCSR.from_device(ctx, indptr_t, indices_t, shape, fit_rows=rows)
     dX = _lib.DeviceCSR.from_device_shard(ctx, indptr_t, indices_t, shape, rows)
-    deg = torch.as_tensor(_DevPtr(dX.degrees_device_ptr(), (int(shape[1]),), "<i4", dX), device=device)
-    ctx.sync()  # the library's stream has written the partial degrees
-    dist.all_reduce(deg, op=dist.ReduceOp.SUM, group=group)
+    if comm is not None:  # the library's communicator, on the library's stream: no host synchronisation
+        comm.all_reduce_sum_i32(dX.degrees_device_ptr(), int(shape[1]))
+    else:
+        deg = torch.as_tensor(_DevPtr(dX.degrees_device_ptr(), (int(shape[1]),), "<i4", dX), device=device)
+        ctx.sync()  # the library's stream has written the partial degrees
+        dist.all_reduce(deg, op=dist.ReduceOp.SUM, group=group)
     dX.finish_degrees()
     return dX
 
 
-def fit_itemknn_sharded(ctx, dX, K: int, parts: Sequence[Tuple[int, int]], device, group=None, fit_fn=None, **fit_kwargs):
+def fit_itemknn_sharded(ctx, dX, K: int, parts: Sequence[Tuple[int, int]], device, group=None, fit_fn=None, comm=None, **fit_kwargs):
     """Fit this rank's item rows on its GPU, all-gather, return a predict-ready full model (replicated).
     ``fit_kwargs`` (similarity, pop_discount, normalize_X) go to ``_lib.itemknn_fit``; ``fit_fn(row_begin, row_end)``
     replaces it for the other neighbour-list fits (``itemknn_fit_values`` / ``_timedist`` / ``_hermann`` of the
@@ -138,9 +141,11 @@ def fit_itemknn_sharded(ctx, dX, K: int, parts: Sequence[Tuple[int, int]], devic
 
     from recpack_amd import _lib
 
-    rank = dist.get_rank(group)
+    rank = comm.rank if comm is not None else dist.get_rank(group)
     b, e = parts[rank]
     local = fit_fn(b, e) if fit_fn is not None else _lib.itemknn_fit(ctx, dX, K, b, e, **fit_kwargs)
+    if comm is not None:  # one all-gather inside the library, straight into the full model's arrays (rphip_itemknn_gather)
+        return _lib.itemknn_gather(ctx, comm, local, [p[0] for p in parts] + [parts[-1][1]])
     idx, val, nnz = model_topk_tensors(local, device)
     ctx.sync()  # the collective runs on torch's stream: order it after the library's stream
     idx_f, val_f, nnz_f = allgather_topk(idx, val, nnz, parts, group)

@@ -39,17 +39,23 @@ deg0 = dX0.item_degrees()
 # ---- sharded: plan from the degrees, K0 per shard (+ all-reduce), fit of the shard's rows, all-gather, predict of the shard's users
 parts = rdist.partition_by_cost(rdist.item_row_cost(deg0, int(ix.numel()), dX0.num_products()), world)
 uparts = rdist.partition_users(ip.cpu().numpy(), world)
-dX = rdist.csr_for_shard(ctx, ip, ix, (U, I), parts[rank], device)
-deg_ok = bool((dX.item_degrees() == deg0).all())
-m = rdist.fit_itemknn_sharded(ctx, dX, K, parts, device)
-idx, val, nnz = m.topk_download()
-same_model = bool((idx == r_idx).all() and (nnz == r_nnz).all() and (val == r_val).all())
-ub, ue = uparts[rank]
-pi, pv, pn = _lib.predict_topk(ctx, m, dX, Kp, exclude_history=True, user_begin=ub, user_end=ue)
-same_pred = bool((pi == r_pi[ub:ue]).all() and (pn == r_pn[ub:ue]).all() and (pv == r_pv[ub:ue]).all())
-print(f"rank {rank}/{world}: rows {parts[rank]}, users [{ub},{ue}): degrees after the all-reduce equal: {deg_ok}, model bit-identical: {same_model}, "
-      f"predictions bit-identical: {same_pred}", flush=True)
-ok = deg_ok and same_model and same_pred
+ok = True
+# (1) the collectives inside the library (the communicator: RCCL with the nccl backend, torch.distributed callbacks otherwise),
+# (2) the torch-driven collectives of round 2
+for comm in (rdist.make_comm(ctx, device), None):
+    dX = rdist.csr_for_shard(ctx, ip, ix, (U, I), parts[rank], device, comm=comm)
+    deg_ok = bool((dX.item_degrees() == deg0).all())
+    m = rdist.fit_itemknn_sharded(ctx, dX, K, parts, device, comm=comm)
+    idx, val, nnz = m.topk_download()
+    same_model = bool((idx == r_idx).all() and (nnz == r_nnz).all() and (val == r_val).all())
+    ub, ue = uparts[rank]
+    pi, pv, pn = _lib.predict_topk(ctx, m, dX, Kp, exclude_history=True, user_begin=ub, user_end=ue)
+    same_pred = bool((pi == r_pi[ub:ue]).all() and (pn == r_pn[ub:ue]).all() and (pv == r_pv[ub:ue]).all())
+    print(f"rank {rank}/{world} ({'library communicator' if comm is not None else 'torch.distributed'}): rows {parts[rank]}, users [{ub},{ue}): "
+          f"degrees after the all-reduce equal: {deg_ok}, model bit-identical: {same_model}, predictions bit-identical: {same_pred}", flush=True)
+    ok = ok and deg_ok and same_model and same_pred
+    if comm is not None:
+        comm.close()
 t = torch.tensor([1 if ok else 0], device=device)
 dist.all_reduce(t, op=dist.ReduceOp.MIN)
 ok = bool(t.item())
