@@ -446,7 +446,15 @@ def main():
         e_idx = torch.empty((U, Kp), dtype=torch.int32, device=device)
         e_val = torch.empty((U, Kp), dtype=torch.float32, device=device)
         e_nnz = torch.empty((U,), dtype=torch.int32, device=device)
-    comm = rdist.make_comm(ctx, device, transport=args.ease_transport) if world > 1 else None  # the library's communicator: every collective below
+    comm = None
+    comm_note = None
+    if world > 1:  # the library's communicator: every collective of the step goes through it
+        try:
+            comm = rdist.make_comm(ctx, device, transport=args.ease_transport)
+        except Exception as e:  # noqa: BLE001 - e.g. librccl refuses to initialise: the same solve over torch.distributed's collectives
+            comm_note = f"library RCCL communicator failed ({type(e).__name__}: {e}); collectives through torch.distributed callbacks"
+            sys.stderr.write(f"rank {rank}: {comm_note}\n")
+            comm = rdist.make_comm(ctx, device, transport="torch")
 
     keep = {}
     parts = {"itemknn": 0.0, "ease_fit": 0.0, "ease_predict": 0.0}
@@ -596,6 +604,7 @@ def main():
                                 f"column-sharded predict + merge") if world > 1 else "1 GPU",
                 "generate_s": round(t_gen, 2),
                 "device": info,
+                "transport_note": comm_note,
             },
             "phases_ms_per_step": phases,
             "throughput": {
