@@ -25,7 +25,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 
 constexpr int GLD = 20;   // LDS row stride in floats (16 + 4 pad: conflict-free ds_read_b128 over 16 rows)
-constexpr int GKC = 512;  // default K steps between two flushes of the MFMA accumulators into the compensated master sums (option gemm_flush_k)
+constexpr int GKC = 1024;  // default K steps between two flushes of the MFMA accumulators into the compensated master sums (option gemm_flush_k)
 
 
 // Which tile a workgroup computes.  Workgroups go to the 8 XCDs round-robin by their linear id, and each XCD has its own L2.  In
@@ -946,6 +946,12 @@ __global__ void __launch_bounds__(256, 2) k_gemm_hp16(rp_hp_args q) {
 // two steps old - before the one barrier of the step (which also says that everybody has finished reading the stage about to be
 // refilled).  The two 128-row halves of a tile follow the 128-tile rules separately (tri, K clipping: a half that is excluded or
 // whose K range has not begun skips the MFMAs, wave-uniformly), so every caller's tile semantics are those of the 128 x 128 kernels.
+// Diagnostic builds only (make gemmablate; tools/gemm_ablate.py): RP_GEMM_ABL removes parts of k_gemm_hp16w to attribute its time -
+// 1: no LDS-DMA requests after the prologue, 2: the fragments are read once (no ds_read in the loop), 4: no barrier and no counted
+// wait, 8: no flush.  Results are wrong by construction.
+#ifndef RP_GEMM_ABL
+#define RP_GEMM_ABL 0
+#endif
 __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
   // [stage][A: plane 2 x block 8 x K16 2 | B: plane 2 x block 4 x K16 2][1 KB]
   extern __shared__ __attribute__((aligned(1024))) unsigned char smw[];
@@ -964,7 +970,10 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
 #define GST(slot)
 #endif
   const rp_gemm_args& g = q.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (the wave index as a SCALAR: with tid >> 6 in a vector register every address, K bound and branch derived from it was vector
+  // arithmetic - and vector instructions share the SIMD's issue port with the MFMAs: attribution by removal put the requests, the
+  // fragment reads and the flush at 15 / 13 / 8 % of the kernel, ADDING UP, i.e. not hidden behind the matrix pipe)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;  // wave rows 0..3 (64 rows each), columns 0..1
   const int tm = blockIdx.y, tn = blockIdx.x;
   const int m0 = tm * 256, n0 = tn * GT;
@@ -992,6 +1001,12 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
   const int my_kb = kbh[my], my_ke = keh[my];
   const float unscale = 1.0f / (rp_h2_scale(g.amax[0]) * rp_h2_scale(g.amax[1]));
 
+  // Master sums hi + lo; lo as packed bf16 pairs (gfx950 converts two floats with ONE v_cvt_pk_bf16_f32, round to nearest even; the
+  // integer rounding of the 128 x 128 kernels was 40 % of the flush's instructions - and an f32 lo spilled: 256 registers).  The
+  // accumulators are never zeroed: after a flush the next step's first product of every accumulator takes the constant 0 as its C
+  // operand (`fresh`).
+  typedef __bf16 rp_bf2 __attribute__((ext_vector_type(2)));
+  typedef float rp_f2 __attribute__((ext_vector_type(2)));
   f32x4 acc[4][4], hi[4][4];
   uint32_t lo[4][4][2];
 #pragma unroll
@@ -1002,27 +1017,26 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
       for (int r = 0; r < 4; ++r) acc[i][j][r] = hi[i][j][r] = 0.0f;
       lo[i][j][0] = lo[i][j][1] = 0u;
     }
+  bool fresh = true;  // the accumulators hold nothing (uniform)
   auto flush = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 av = acc[i][j] * unscale, h = hi[i][j];
+        const f32x4 sv = h + av;
+        const f32x4 bv = sv - h;
+        const f32x4 dl = (h - (sv - bv)) + (av - bv);
+        hi[i][j] = sv;
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {
           const uint32_t pk = lo[i][j][r >> 1];
-          float l0 = __uint_as_float(pk << 16), l1 = __uint_as_float(pk & 0xffff0000u);
-          const float a0 = acc[i][j][r] * unscale, a1 = acc[i][j][r + 1] * unscale;
-          const float h0 = hi[i][j][r], h1 = hi[i][j][r + 1];
-          const float s0 = h0 + a0, s1 = h1 + a1;
-          const float b0 = s0 - h0, b1 = s1 - h1;
-          l0 += (h0 - (s0 - b0)) + (a0 - b0);
-          l1 += (h1 - (s1 - b1)) + (a1 - b1);
-          hi[i][j][r] = s0;
-          hi[i][j][r + 1] = s1;
-          acc[i][j][r] = 0.0f;
-          acc[i][j][r + 1] = 0.0f;
-          lo[i][j][r >> 1] = rp_pack_bf16_rn(l0, l1);
+          rp_f2 l = {__uint_as_float(pk << 16) + dl[r], __uint_as_float(pk & 0xffff0000u) + dl[r + 1]};
+          const rp_bf2 pb = __builtin_convertvector(l, rp_bf2);
+          lo[i][j][r >> 1] = __builtin_bit_cast(uint32_t, pb);
         }
+      }
+    fresh = true;
   };
 
   if (kb < ke) {
@@ -1068,13 +1082,20 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
     issue(1, min(kb + 32, k_last));
     const int foff = (lane >> 5) * 1024 + ((((lane >> 4) & 1) * 32) + (lane & 15)) * 16;
     int since = 0, stage = 0;
+    f16x8 abl_a[2][2], abl_b[2][4];  // (RP_GEMM_ABL & 2 only)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) abl_b[p][t] = (f16x8)(_Float16)1.0f;
+      abl_a[p][0] = abl_a[p][1] = (f16x8)(_Float16)1.0f;
+    }
     for (int k = kb; k < ke; k += 32) {
       GST(0);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // my pieces of this step have landed (those of the next step may be in flight)
+      if (!(RP_GEMM_ABL & 4)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // my pieces of this step have landed (those of the next step may be in flight)
       GST(1);
       // everybody's have, and nobody still reads the stage refilled below (the fragment reads of the previous step were consumed by
       // its MFMAs).  The bare barrier: __syncthreads() carries a fence that the compiler turns into vmcnt(0) - the counted wait gone.
-      __builtin_amdgcn_s_barrier();
+      if (!(RP_GEMM_ABL & 4)) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       GST(2);
       int st2 = stage + 2;
@@ -1089,9 +1110,18 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
         // program in step and sat in their request phases together.  So the halves take turns: waves 0-3 request BEFORE their MFMAs,
         // waves 4-7 AFTER theirs - one partner's requests run beside the other's MFMAs.  (A row's A fragments are read while the row
         // before it multiplies.)
-        if (wave < 4) issue(st2, kn);
+        if (wave < 4 && !(RP_GEMM_ABL & 1)) issue(st2, kn);
         GST(3);
         f16x8 a[2][2], b[2][4];
+        if ((RP_GEMM_ABL & 2) && k != kb) {  // (diagnostic: stale fragments)
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b[p][t] = abl_b[p][t];
+            a[p][0] = abl_a[p][0];
+            a[p][1] = abl_a[p][1];
+          }
+        } else {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
 #pragma unroll
@@ -1099,30 +1129,43 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
             b[p][t] = *reinterpret_cast<const f16x8*>(B0 + p * 8 * 1024 + ((wc * 2 + (t >> 1)) * 2) * 1024 + foff + (t & 1) * 256);
           a[p][0] = *reinterpret_cast<const f16x8*>(A0 + p * 16 * 1024 + ((wr * 2) * 2) * 1024 + foff);
         }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          if (i < 3) {
+          if (i < 3 && !((RP_GEMM_ABL & 2) && k != kb)) {
 #pragma unroll
             for (int p = 0; p < 2; ++p)
               a[p][(i + 1) & 1] = *reinterpret_cast<const f16x8*>(A0 + p * 16 * 1024 + ((wr * 2 + ((i + 1) >> 1)) * 2) * 1024 + foff + ((i + 1) & 1) * 256);
           }
+          if (fresh) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            f32x4 c = acc[i][j];
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1][i & 1], b[0][j], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][i & 1], b[1][j], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][i & 1], b[0][j], c, 0, 0, 0);
-            acc[i][j] = c;
+            for (int j = 0; j < 4; ++j) {
+              f32x4 c = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1][i & 1], b[0][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][i & 1], b[1][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][i & 1], b[0][j], c, 0, 0, 0);
+              acc[i][j] = c;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              f32x4 c = acc[i][j];
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1][i & 1], b[0][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][i & 1], b[1][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][i & 1], b[0][j], c, 0, 0, 0);
+              acc[i][j] = c;
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
         }
+        fresh = false;
         GST(4);
-        if (wave >= 4) issue(st2, kn);
+        if (wave >= 4 && !(RP_GEMM_ABL & 1)) issue(st2, kn);
 #ifdef RP_GEMM_STAMPS
         ++st_step;
 #endif
         since += 32;
-        if (since >= g.kc && k + 32 < my_ke) {
+        if (since >= g.kc && k + 32 < my_ke && !(RP_GEMM_ABL & 8)) {
           flush();
           since = 0;
         }
@@ -1140,7 +1183,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
 #endif
   }
   if (!mine) return;
-  flush();
+  if (!fresh) flush();
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
