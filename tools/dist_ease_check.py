@@ -78,10 +78,11 @@ for l2, alpha in ((50.0, 0.0), (5.0, 0.5)):
         agree_s = float(same.mean()) if sel.any() else 1.0
         # scores where both picked the same item at the same position (a near-tie at the K-th place shifts the rest of a row)
         dv = float((np.abs(pv.cpu().numpy()[sel] - b[1][users[sel]]) * same).max() / max(1e-30, np.abs(b[1]).max())) if sel.any() else 0.0
-        # memory: the slab is n_pad'^2 * 4 / world; everything else the fit holds (two pivot columns, staging, plane workspaces)
-        # is O(n nb): asserted against 10 % of the matrix where the matrix is large enough for the fixed 64 MiB workspaces not
-        # to dominate (the full-size numbers are in DESIGN.md)
-        mem_ok = torch_peak == 0 and (st["n_pad"] < 16384 or st["slab_bytes"] + st["other_peak_bytes"] <= st["n_pad"] ** 2 * 4 * (1.0 / world + 0.1))
+        # memory: the panels are n_pad^2 * 4 / world bytes (+ one panel of imbalance); everything else the fit holds (two pivot columns,
+        # T, staging, the plane workspaces of the products) is O(n nb), not O(n^2): at most 8 n_pad nb floats + the fixed minimum sizes
+        # of the workspaces - 15 % of the matrix at 100 000 items with nb = 2048 - and nothing comes from torch
+        mem_ok = (torch_peak == 0 and st["slab_bytes"] <= (st["n_pad"] // world + st["panel"]) * st["n_pad"] * 4
+                  and st["other_peak_bytes"] <= 8 * st["n_pad"] * st["panel"] * 4 + (512 << 20))
         print(f"rank {rank}/{world} dist panel_tiles={pt} (nb {st['panel']}, {st['pivots']} pivots) l2={l2} alpha={alpha}: {nc} columns, "
               f"max|dB|/max|B| = {err_s:.2e}, sharded top-20 agreement {agree_s:.4f}, score diff {dv:.1e}, slab {st['slab_bytes'] / 2**20:.1f} MiB + "
               f"{st['other_peak_bytes'] / 2**20:.1f} MiB, torch allocations {torch_peak}, received {st['bytes_received'] / 2**20:.1f} MiB "
