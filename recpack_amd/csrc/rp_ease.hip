@@ -1551,8 +1551,9 @@ extern "C" int rphip_gemm_nt_f32(rphip_ctx* ctx, int64_t M, int64_t N, int64_t K
 // side buffer, and the lower half is mirrored over N.  200 000 items (160 GB) fit one 288 GB GPU this way.
 constexpr int RP_INV_PANEL = 16;  // tiles per panel of N = L^-T (2048 columns; 8 / 16 / 32 tiles measured: 5.94 / 5.53 / 5.87 s at n = 100 000)
 
-int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_ext) {
-  hipStream_t st = ctx->stream;
+int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_ext, hipStream_t on) {
+  hipStream_t st = on ? on : ctx->stream;  // (every launch below names its stream: the solve may run beside the caller's other streams)
+  const bool timed = st == ctx->stream;
   const int nb = n_pad / GT;
   char* wsb = nullptr;
   const int inv_w = std::min(RP_INV_PANEL * GT, n_pad);  // columns of one panel of the inverse
@@ -1595,7 +1596,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
   hipEvent_t e_panel = side.a, e_diag = side.b, e_fact = side.c, e_trail = side.d;
   bool trail_pending = false;  // a trailing update is in flight on s3
   float* part_diag = part_all + (size_t)8 * (n_pad - GT) * GT;  // the side stream's own split-K partials
-  rp_time_begin(ctx, &ev);
+  if (timed) rp_time_begin(ctx, &ev);
   int rc = RPHIP_OK;
   // Blocked in two levels: wide panels of 16 or 32 tiles are factored left-looking with K restricted to the panel
   // (short, skinny products: ~n^2 * panel / 2 flop in total), then the whole trailing matrix takes the panel's
@@ -1649,7 +1650,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
       h.k1 = GT;
       h.alpha = 1.0f;
       h.beta = 0.0f;
-      rc = rp_gemm_nt(ctx, h);
+      rc = rp_gemm_nt(ctx, h, st);
       if (rc != RPHIP_OK) break;
       const int r1 = r0 + GT;
       if ((k + 1) % RP_CHOL_PANEL == 0 && r1 < n_pad) {
@@ -1674,7 +1675,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
         t.tri = 1;
         t.alpha = -1.0f;
         t.beta = 1.0f;
-        rc = rp_gemm_nt(ctx, t);
+        rc = rp_gemm_nt(ctx, t, st);
         if (rc != RPHIP_OK) break;
         const int r2 = r1 + wn;
         if (r2 < n_pad) {
@@ -1697,13 +1698,13 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
   if (trail_pending) hipStreamWaitEvent(st, e_trail, 0);
   if (rc != RPHIP_OK) return rc;
   RP_HIP(hipGetLastError());
-  rp_time_end(ctx, ev, RPHIP_T_CHOLESKY, n3 / 3.0);
+  if (timed) rp_time_end(ctx, ev, RPHIP_T_CHOLESKY, n3 / 3.0);
   // ---- K6a: N = L^-T (upper triangular), panel by panel (N12 = -N11 L21^T N22 for the 2 x 2 block form of L).
   // Inside a panel the 128-column blocks are done as before but with rows and K restricted to the panel (tiny products);
   // then ONE product per panel against everything to its left, 2048 columns wide: T = N11 L21^T (K from the row block's
   // first column), N12 = -T N22.  Block column by block column (128 wide, K from 0) every product was skinny:
   // 101 TFLOP/s with split K; the wide ones run at the square-GEMM rate.
-  rp_time_begin(ctx, &ev);
+  if (timed) rp_time_begin(ctx, &ev);
   for (int pb = 0; pb < nb; pb += RP_INV_PANEL) {
     const int pe = std::min(nb, pb + RP_INV_PANEL);
     const int j = pb * GT, w = (pe - pb) * GT;
@@ -1727,7 +1728,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
         g.m_off = j;
         g.alpha = 1.0f;
         g.beta = 0.0f;
-        RP_TRY(rp_gemm_nt(ctx, g));
+        RP_TRY(rp_gemm_nt(ctx, g, st));
         rp_gemm_args h{};
         h.A = T;
         h.lda = GT;
@@ -1741,7 +1742,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
         h.k1 = GT;
         h.alpha = -1.0f;
         h.beta = 0.0f;
-        RP_TRY(rp_gemm_nt(ctx, h));
+        RP_TRY(rp_gemm_nt(ctx, h, st));
       }
     }
     if (j > 0) {
@@ -1759,7 +1760,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
       g.kb_m = 1;
       g.alpha = 1.0f;
       g.beta = 0.0f;
-      RP_TRY(rp_gemm_nt(ctx, g));
+      RP_TRY(rp_gemm_nt(ctx, g, st));
       hipLaunchKernelGGL(k_transpose_block, dim3(w / 32, w / 32), dim3(32, 8), 0, st, Nb + (long long)j * ld + j, ld, NT, (long long)w);
       rp_gemm_args h{};  // N12 = -T N22 (N22 is upper triangular: K ends with the column tile)
       h.ke_n = 1;
@@ -1775,7 +1776,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
       h.k1 = w;
       h.alpha = -1.0f;
       h.beta = 0.0f;
-      RP_TRY(rp_gemm_nt(ctx, h));
+      RP_TRY(rp_gemm_nt(ctx, h, st));
     }
   }
   // ---- K6b: P = N N^T (lower tiles, K from max(row, column) = row), mirrored into the upper half
@@ -1796,16 +1797,16 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
     g.tri = 2;  // P is symmetric: the tiles below the diagonal (they read N on and above it, never what they write) ...
     g.alpha = 1.0f;
     g.beta = 0.0f;
-    RP_TRY(rp_gemm_nt(ctx, g));
+    RP_TRY(rp_gemm_nt(ctx, g, st));
     g.tri = 3;  // ... the diagonal tiles into the (now free) T buffer, copied over N's diagonal blocks afterwards ...
     g.C = T;
     g.ldc = GT;
-    RP_TRY(rp_gemm_nt(ctx, g));
+    RP_TRY(rp_gemm_nt(ctx, g, st));
     hipLaunchKernelGGL(k_copy_diag_blocks, dim3(nb), dim3(256), 0, st, T, A, ld);
     hipLaunchKernelGGL(k_mirror_lower, dim3(n_pad / 32, n_pad / 32), dim3(256), 0, st, A, ld, n_pad / 32);  // ... and the mirror
   }
   RP_HIP(hipGetLastError());
-  rp_time_end(ctx, ev, RPHIP_T_INVERSE, 2.0 * n3 / 3.0);  // n^3/3 (N = L^-T) + n^3/3 (lower half of N N^T)
+  if (timed) rp_time_end(ctx, ev, RPHIP_T_INVERSE, 2.0 * n3 / 3.0);  // n^3/3 (N = L^-T) + n^3/3 (lower half of N N^T)
   if (info_ext) return RPHIP_OK;  // the caller reads the flag when it next waits for the device
   int h_info = 0;
   RP_HIP(hipMemcpyAsync(&h_info, info, 4, hipMemcpyDeviceToHost, st));

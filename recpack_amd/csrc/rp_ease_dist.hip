@@ -17,10 +17,11 @@
 // What a pivot needs from the others is V: n nb floats (the row-block pieces all-gathered, the owner's part broadcast with P
 // appended), n^2 * 4 bytes per rank over the whole solve; T_j = V_j P is formed locally for the own panels only.
 //
-// Schedule (per rank, three streams; the host never waits before the end):
-//     main    chain(K): pivot inverse (owner), pack pieces, [comm], unpack V, T_own, writes of row / column K, then the
-//             LOOK-AHEAD part of update K: row block K + 1 of the own panels and panel K + 1 (what chain(K + 1) reads)
-//     comm    all-gather of the pieces + broadcast of the owner's part of V
+// Schedule (per rank, four streams; the host never reads anything back before the end):
+//     main    chain(K): pack pieces, [comm], unpack V, T_own, writes of row / column K, then the LOOK-AHEAD part of update K:
+//             the diagonal block of panel K + 1 FIRST (-> pivot stream), row block K + 1 of the own panels, the rest of panel K + 1
+//     pivot   the inverse of the next pivot block, started as soon as that block has its update
+//     comm    all-gather of the pieces + broadcast of the owner's part of V (neither needs P), then the small broadcast of P
 //     update  U(K): everything else of update K - it runs beside chain(K + 1)
 // U(K) leaves row blocks and panels K, K + 1 alone, the look-ahead of K + 1 waits for U(K) (both add to the same tiles).
 // V and T_own are double buffered.  A failing pivot (matrix not positive definite) leaves its index in a device flag that is
@@ -346,7 +347,7 @@ namespace {
 
 struct dist_res {  // everything the fit holds besides the slab; released on every way out
   rphip_ctx* ctx = nullptr;
-  hipStream_t su = nullptr, sc = nullptr;
+  hipStream_t su = nullptr, sc = nullptr, sp = nullptr;
   std::vector<hipEvent_t> evs;
   std::vector<void*> bufs;
   int64_t held = 0, peak = 0;
@@ -363,6 +364,7 @@ struct dist_res {  // everything the fit holds besides the slab; released on eve
     return RPHIP_OK;
   }
   ~dist_res() {
+    if (sp) hipStreamSynchronize(sp);
     if (su) hipStreamSynchronize(su);
     if (sc) hipStreamSynchronize(sc);
     if (ctx) hipStreamSynchronize(ctx->stream);
@@ -370,6 +372,7 @@ struct dist_res {  // everything the fit holds besides the slab; released on eve
     for (auto p : bufs) rp_dev_free(ctx, p);
     if (su) hipStreamDestroy(su);
     if (sc) hipStreamDestroy(sc);
+    if (sp) hipStreamDestroy(sp);
   }
 };
 
@@ -426,6 +429,7 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
   m->cyc_world = W;
   m->cyc_rank = me;
   auto fail = [&](int rc) {
+    if (R.sp) hipStreamSynchronize(R.sp);
     if (R.su) hipStreamSynchronize(R.su);
     if (R.sc) hipStreamSynchronize(R.sc);
     hipStreamSynchronize(st);
@@ -455,7 +459,8 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
 
   DHIP(hipStreamCreateWithFlags(&R.su, hipStreamNonBlocking));
   DHIP(hipStreamCreateWithFlags(&R.sc, hipStreamNonBlocking));
-  hipStream_t su = R.su, sc = R.sc;
+  DHIP(hipStreamCreateWithFlags(&R.sp, hipStreamNonBlocking));
+  hipStream_t su = R.su, sc = R.sc, sp = R.sp;
   // V[b]: the pivot column (n_pad rows) + P (nb rows); (W + 1) nb more rows make it the mirror's staging buffer as well
   const size_t v_rows = (size_t)n_pad + (size_t)(W + 2) * nb;
   float *V[2] = {nullptr, nullptr}, *Town[2] = {nullptr, nullptr}, *Vs = nullptr, *Vg = nullptr, *colscale = nullptr;
@@ -482,13 +487,15 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
     DTRY(rp_scratch(ctx, 8, wa, &w));  // (the main stream's too: growing them later would make the host wait for the stream)
     DTRY(rp_scratch(ctx, 9, wb, &w));
   }
-  hipEvent_t e_pack, e_comm, e_chain[2], e_upd, e_la;
+  hipEvent_t e_pack, e_comm, e_chain[2], e_upd, e_la, e_diag, e_inv;
   DTRY(R.event(&e_pack));
   DTRY(R.event(&e_comm));
   DTRY(R.event(&e_chain[0]));
   DTRY(R.event(&e_chain[1]));
   DTRY(R.event(&e_upd));
   DTRY(R.event(&e_la));
+  DTRY(R.event(&e_diag));
+  DTRY(R.event(&e_inv));
   comm->bytes_recv = comm->bytes_sent = 0;
   double flop = 0.0;
 
@@ -548,6 +555,26 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
   };
 
   // ---- the sweeps
+  // The pivot inverse (a chain of nb / 128 float64 diagonal blocks, ~8 ms at nb = 2048) is the one step that nobody can start
+  // early: P_K needs the update of pivot K - 1 on its own nb x nb block only.  So that block is updated first (the first thing of
+  // the look-ahead), copied out, and inverted on a stream of its own while everything else of the pivot - the rest of the
+  // look-ahead, the big update, the next gather / broadcast of the pivot column (which does not need P) - goes on; P follows in a
+  // small broadcast of its own.  The recurrence per pivot is then: inverse -> T of one block -> update of one block -> next inverse.
+  auto start_inverse = [&](float* Pslot) -> int {  // on the pivot stream, after e_diag; the host waits inside (side-stream joins)
+    RP_HIP(hipStreamWaitEvent(sp, e_diag, 0));
+    const int ps = ctx->gemm_presplit;
+    ctx->gemm_presplit = 0;  // (its products are small; the plane workspaces belong to the streams that are busy now)
+    const int r = rp_spd_inverse(ctx, Pslot, nb, nb, info, sp);
+    ctx->gemm_presplit = ps;
+    if (r != RPHIP_OK) return r;
+    RP_HIP(hipEventRecord(e_inv, sp));
+    return RPHIP_OK;
+  };
+  if (np > 0 && 0 % W == me) {  // pivot 0
+    copy2d(S, ld, V[0] + (long long)n_pad * nb, nb, nb, nb, 1.0f, st);
+    DHIP(hipEventRecord(e_diag, st));
+    DTRY(start_inverse(V[0] + (long long)n_pad * nb));
+  }
   bool upd_pending = false;
   for (int K = 0; K < np; ++K) {
     const int cur = K & 1;
@@ -556,17 +583,13 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
     const int own_K = (owner == me) ? 1 : 0;
     const long long r0 = (long long)K * nb;
     float* Vc = V[cur];
-    float* Pc = Vc + (long long)n_pad * nb;            // P = A_KK^-1 rides behind the pivot column
+    float* Pc = Vc + (long long)n_pad * nb;            // P = A_KK^-1 sits behind the pivot column (the pivot stream is writing it)
     float* Tc = Town[cur];
     hipEvent_t t_chain;
     timed(st, &t_chain);
     const double flop0 = flop;
     // -- chain(K), main stream.  What it reads - row block K of the own panels, panel K - was finished by the look-ahead of K - 1.
-    if (own_K) {
-      copy2d(S + r0 * ld + (long long)lpK * nb, ld, Pc, nb, nb, nb, 1.0f, st);
-      DTRY(rp_spd_inverse(ctx, Pc, nb, nb, info));
-      copy2d(S + (r0 + nb) * ld + (long long)lpK * nb, ld, Vc + (r0 + nb) * nb, nb, (long long)n_pad - r0 - nb, nb, 1.0f, st);
-    }
+    if (own_K) copy2d(S + (r0 + nb) * ld + (long long)lpK * nb, ld, Vc + (r0 + nb) * nb, nb, (long long)n_pad - r0 - nb, nb, 1.0f, st);
     if (cnt > 0)  // pieces V_i = A_Ki^T of the own panels i < K
       hipLaunchKernelGGL(k_blk_transpose, dim3(nb / 32, nb / 32, cnt), dim3(32, 8), 0, st, S + r0 * ld, ld, (long long)nb, Vs, (long long)nb,
                          (long long)nb * nb);
@@ -576,10 +599,14 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
       DHIP(hipEventRecord(e_pack, st));
       DHIP(hipStreamWaitEvent(sc, e_pack, 0));
       if (gslots > 0) DTRY(rp_comm_all_gather(comm, Vs, Vg, (int64_t)gslots * nb * nb * 4, sc));
-      // rows (K + 1) nb .. n_pad of V and P behind them, from the owner
-      DTRY(rp_comm_broadcast(comm, Vc + (r0 + nb) * nb, ((int64_t)n_pad - r0) * nb * 4, owner, sc));
+      // rows (K + 1) nb .. n_pad of V from the owner - while its pivot stream may still be inverting - then P
+      DTRY(rp_comm_broadcast(comm, Vc + (r0 + nb) * nb, ((int64_t)n_pad - r0 - nb) * nb * 4, owner, sc));
+      if (own_K) DHIP(hipStreamWaitEvent(sc, e_inv, 0));
+      DTRY(rp_comm_broadcast(comm, Pc, (int64_t)nb * nb * 4, owner, sc));
       DHIP(hipEventRecord(e_comm, sc));
       DHIP(hipStreamWaitEvent(st, e_comm, 0));
+    } else {
+      DHIP(hipStreamWaitEvent(st, e_inv, 0));
     }
     if (gslots > 0)
       hipLaunchKernelGGL(k_unpack_pieces, dim3(64, W * gslots), dim3(256), 0, st, W > 1 ? Vg : Vs, gslots, W, K, nb, Vc, (long long)nb);
@@ -607,15 +634,20 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
     DHIP(hipGetLastError());
     DHIP(hipEventRecord(e_chain[cur], st));
     // -- look-ahead part of update K (main stream): what chain(K + 1) reads.  It adds to tiles U(K - 1) also adds to: wait for it.
+    const bool own_K1 = K + 1 < np && (K + 1) % W == me;
+    const int q1 = (K + 1) / W;
+    const long long r1 = r0 + nb;
     if (K + 1 < np) {
       if (upd_pending) DHIP(hipStreamWaitEvent(st, e_upd, 0));
-      const long long r1 = r0 + nb;
-      DTRY(gemm(Vc + r1 * nb, nb, Tc, nb, S + r1 * ld, ld, nb, cnt * nb, -1.0f, 1.0f, st));  // row block K + 1, own panels < K
-      if ((K + 1) % W == me) {  // panel K + 1 (rows from its diagonal block down)
-        const int q1 = (K + 1) / W;
-        DTRY(gemm(Vc + r1 * nb, nb, Tc + (long long)q1 * nb * nb, nb, S + r1 * ld + (long long)q1 * nb, ld, n_pad - (int)r1, nb, -1.0f, 1.0f, st,
-                  1, (int)r1, q1 * nb));
+      if (own_K1) {  // the next pivot's own block first: it goes to the pivot stream at once (below)
+        DTRY(gemm(Vc + r1 * nb, nb, Tc + (long long)q1 * nb * nb, nb, S + r1 * ld + (long long)q1 * nb, ld, nb, nb, -1.0f, 1.0f, st, 1, (int)r1, q1 * nb));
+        copy2d(S + r1 * ld + (long long)q1 * nb, ld, V[cur ^ 1] + (long long)n_pad * nb, nb, nb, nb, 1.0f, st);
+        DHIP(hipEventRecord(e_diag, st));
       }
+      DTRY(gemm(Vc + r1 * nb, nb, Tc, nb, S + r1 * ld, ld, nb, cnt * nb, -1.0f, 1.0f, st));  // row block K + 1, own panels < K
+      if (own_K1)  // panel K + 1 below its diagonal block
+        DTRY(gemm(Vc + (r1 + nb) * nb, nb, Tc + (long long)q1 * nb * nb, nb, S + (r1 + nb) * ld + (long long)q1 * nb, ld, n_pad - (int)r1 - nb, nb, -1.0f,
+                  1.0f, st));
       DHIP(hipEventRecord(e_la, st));
     }
     timed_end(st, t_chain, RPHIP_T_SWEEP_CHAIN, flop - flop0);
@@ -625,9 +657,8 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
       DHIP(hipStreamWaitEvent(su, e_chain[cur], 0));
       hipEvent_t t_upd;
       timed(su, &t_upd);
-      const int own_K1 = (K + 1 < np && (K + 1) % W == me) ? 1 : 0;
-      const int l3 = cnt + own_K + own_K1;        // first local panel right of K + 1
-      const long long r2 = r0 + 2LL * nb;         // first row below the block K + 1
+      const int l3 = cnt + own_K + (own_K1 ? 1 : 0);  // first local panel right of K + 1
+      const long long r2 = r0 + 2LL * nb;             // first row below the block K + 1
       // rows above the pivot, panels left of it (lower tiles)
       DTRY(gemm(Vc, nb, Tc, nb, S, ld, (int)r0, cnt * nb, -1.0f, 1.0f, su, 1, 0, 0));
       if (r2 < n_pad) {
@@ -641,6 +672,8 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
       DHIP(hipEventRecord(e_upd, su));
       upd_pending = true;
     }
+    // -- the next pivot's inverse, on the pivot stream (everything else of this pivot is enqueued: the host may wait in here)
+    if (own_K1) DTRY(start_inverse(V[cur ^ 1] + (long long)n_pad * nb));
   }
   DHIP(hipStreamWaitEvent(st, e_upd, 0));
   // ---- the upper triangle.  Diagonal blocks: upper tiles from the lower ones; block (i, j), i < j, is block (j, i) of panel i's
@@ -709,6 +742,7 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
   DHIP(hipStreamSynchronize(st));
   DHIP(hipStreamSynchronize(su));
   DHIP(hipStreamSynchronize(sc));
+  DHIP(hipStreamSynchronize(sp));
   g_dist_stats[0] = (int64_t)slab_bytes;
   g_dist_stats[1] = R.peak + (int64_t)ctx->scratch[12].cap + (int64_t)ctx->scratch[13].cap + (int64_t)ctx->scratch[8].cap + (int64_t)ctx->scratch[9].cap +
                     (int64_t)ctx->scratch[10].cap + (int64_t)ctx->scratch[11].cap + (int64_t)ctx->scratch[5].cap + (int64_t)ctx->scratch[7].cap;
