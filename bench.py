@@ -319,11 +319,11 @@ def roofline_ease(tm, I, world, steps, dist_stats, nnz, U, Kp):
         n_pad = (I + 127) // 128 * 128
         solve_ms = (tm["cholesky"]["ms"] + tm["inverse"]["ms"]) / steps
         flop = float(n_pad) ** 3
-        what = "k_gemm_hp16 + k_split_planes (large products) / k_gemm_nt_h2 (skinny ones): K5 Cholesky + K6 inverse"
+        what = "k_gemm_hp16w + k_split_planes (large products) / k_gemm_nt_h2 (skinny ones): K5 Cholesky + K6 inverse"
     else:
         solve_ms = tm["sweep_update"]["ms"] / steps  # the update stream's products (the chain runs beside them on other streams)
         flop = float(dist_stats["flop"])
-        what = (f"k_gemm_hp16 + k_split_planes: the rank's symmetric rank-{dist_stats['panel']} updates of rphip_ease_fit_dist "
+        what = (f"k_gemm_hp16w + k_split_planes: the rank's symmetric rank-{dist_stats['panel']} updates of rphip_ease_fit_dist "
                 f"({dist_stats['pivots']} pivots; kernel time of the update stream, the pivot chain overlaps it)")
     tf = flop / (solve_ms * 1e-3) / 1e12 if solve_ms > 0 else 0.0
     k9 = tm["predict_dense"]
