@@ -87,9 +87,12 @@ int rphip_ctx_create(int device, void* stream, rphip_ctx** out);
 int rphip_ctx_destroy(rphip_ctx* ctx);
 int rphip_ctx_sync(rphip_ctx* ctx);
 
-/* Device blocks of destroyed models / matrices are kept by the context (up to "cache_limit_bytes", default 48 GiB or a quarter of the device's memory, whichever is less) and
- * handed out again for a request of the same size, so a fit repeated in a loop allocates nothing after its first pass.
- * rphip_ctx_trim releases them to the driver (e.g. before another library allocates most of the HBM). */
+/* Device blocks of destroyed models / matrices are kept by the context (up to "cache_limit_bytes", default half of the device's memory) and
+ * handed out again for a request of the same size, so a fit repeated in a loop allocates nothing after its first pass.  This is
+ * not a nicety: the driver wipes freed memory in the background, and a hipMalloc that follows a hipFree of tens of GB waits for it
+ * (measured on MI355X, tools/alloc_bench.hip: 40 GiB allocated right after 40 GiB were freed: 1.8 - 6 s; from clean memory 0.3 ms).
+ * An EASE fit + predict at 100 000 items cycles through 40 GB (B), 40 GB (the inverse's plane cache) and 20 GB (the fp16 copy).
+ * rphip_ctx_trim releases the blocks to the driver (e.g. before another library allocates most of the HBM). */
 int rphip_ctx_trim(rphip_ctx* ctx);
 
 /* Options of a context (name, integer value):
@@ -128,6 +131,11 @@ int rphip_ctx_trim(rphip_ctx* ctx);
  *                       363 against 314 TFLOP/s) or on v_mfma_f32_32x32x16_f16.
  *   "gemm_wide"         1 (default) | 0.  The plane product kernel on 256 x 128 tiles, eight waves, three LDS stages with counted
  *                       waits (k_gemm_hp16w; bit-identical results, +2..6 %) or on 128 x 128 tiles with two stages.
+ *   "gemm_plane_cache"  1 (default) | 0 | bytes.  The inverse N = L^-T keeps the fp16 planes of the part of N it has finished
+ *                       (4 bytes per element of an n x n square, from the context's block cache) instead of cutting it anew for
+ *                       every panel: 1 = as much as the free memory holds (everything at 100 000 items; a prefix of the panels
+ *                       when the matrix itself fills the GPU), a larger value = at most that many bytes, 0 = off.  One scale per
+ *                       2048-column chunk of N instead of one per product.
  *   "gemm_supertile"    0 (default) | 1.  Tile order of the GEMM's workgroups: supertiles of 64 tiles handed to the 8 XCDs round-robin
  *                       (each XCD's L2 then holds the 8 + 8 panels of an 8 x 8 block of tiles), or the plain row-major grid
  *                       (measured equal within 1 %: the products are not bound by operand traffic).

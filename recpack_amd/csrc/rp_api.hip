@@ -49,8 +49,9 @@ extern "C" int rphip_ctx_create(int device, void* stream, rphip_ctx** out) {
   c->device = device;
   c->n_cu = prop.multiProcessorCount;
   c->hbm_bytes = prop.totalGlobalMem;
-  // freed blocks the context keeps for the next fit: at most a quarter of the device (torch's allocator cannot see them)
-  c->cache_limit = std::min(c->cache_limit, (size_t)prop.totalGlobalMem / 4);
+  // freed blocks the context keeps for the next fit: at most half of the device (torch's allocator cannot see them; see
+  // rphip_ctx_trim in the header for why they are kept at all)
+  c->cache_limit = std::min(c->cache_limit, (size_t)prop.totalGlobalMem / 2);
   strncpy(c->arch, prop.gcnArchName, sizeof(c->arch) - 1);
   if (stream) {
     c->stream = (hipStream_t)stream;
@@ -236,6 +237,9 @@ extern "C" int rphip_ctx_set_option(rphip_ctx* ctx, const char* name, int64_t va
     ctx->gemm_shape16 = value ? 1 : 0;
   } else if (!strcmp(name, "gemm_wide")) {
     ctx->gemm_wide = value ? 1 : 0;
+  } else if (!strcmp(name, "gemm_plane_cache")) {
+    if (value < 0) RP_FAIL(RPHIP_EINVAL, "gemm_plane_cache must be >= 0");
+    ctx->gemm_plane_cache = value;
   } else if (!strcmp(name, "gemm_presplit")) {
     ctx->gemm_presplit = value ? 1 : 0;
   } else if (!strcmp(name, "gemm_workspace_bytes")) {

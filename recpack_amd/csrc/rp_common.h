@@ -80,7 +80,7 @@ struct rphip_ctx {
   std::vector<block_t> free_blocks;
   std::unordered_map<void*, size_t> live_blocks;
   size_t cached_bytes = 0;
-  size_t cache_limit = (size_t)48 << 30;  // lowered to a quarter of the device's memory by rphip_ctx_create
+  size_t cache_limit = (size_t)1 << 62;  // set to half of the device's memory by rphip_ctx_create
   // predict options (rphip_ctx_set_option)
   int predict_exact64 = 0;   // 1: the wave predict kernel sums in 64 bits (exact) instead of the per-user-scaled 32 bits
   int predict_half = 1;      // dense models: K9 as two passes (fp16 rows for a candidate list, then exact f32 scores of the candidates)
@@ -91,6 +91,7 @@ struct rphip_ctx {
   int gemm_shape16 = 1;      // k_gemm_hp on v_mfma_f32_16x16x32_f16 (default; the chip holds a higher clock on it) or 32x32x16
   int gemm_wide = 1;         // the plane product kernel on 256 x 128 tiles with three LDS stages (k_gemm_hp16w) instead of 128 x 128 / two
   size_t gemm_ws_bytes = (size_t)4 << 30;  // workspace per operand of those products (sets their K chunk)
+  int64_t gemm_plane_cache = 1;  // the inverse keeps the planes of N = L^-T between its panels: 0 off, 1 as much as fits, > 1 at most that many bytes
   unsigned* gemm_amax_ring = nullptr;  // mode 2: [RP_AMAX_SLOTS][2] words, the operands' largest magnitudes per launch
   unsigned long long gemm_amax_seq = 0;
   int gemm_kc = 1024;        // K steps between two flushes of the MFMA accumulators into the compensated master sums (round 3: 1024;

@@ -643,6 +643,8 @@ struct rp_split_args {
   const unsigned* amax; // the operand's largest magnitude (one word)
   unsigned char* W;     // planes: W + p * plane_stride
   long long plane_stride;
+  long long KSw;        // K16 steps per 32-row block in W (0: those of this chunk) and the K its first step stands for: a chunk
+  int wk0;              // cut into a wider workspace (rp_plane_cache)
 };
 
 __global__ void __launch_bounds__(256) k_split_planes(rp_split_args a) {
@@ -655,7 +657,7 @@ __global__ void __launch_bounds__(256) k_split_planes(rp_split_args a) {
   if (a.ke_flag) ke = min(ke, a.off + r0t + GT);
   const float sc = rp_h2_scale(*a.amax);
   const float* src = a.P + (long long)(rb * 32 + (lane & 31)) * a.ld + (lane >> 5) * 8;
-  unsigned char* dst = a.W + ((long long)rb * KS) * 1024 + lane * 16;
+  unsigned char* dst = a.W + (a.KSw ? (long long)rb * a.KSw + ((a.kc0 - a.wk0) >> 4) : (long long)rb * KS) * 1024 + lane * 16;
 #pragma unroll 2
   for (int ks = blockIdx.y * 16 + wave; ks < min(KS, (int)blockIdx.y * 16 + 16); ks += 4) {
     const int k = a.kc0 + ks * 16;
@@ -683,6 +685,10 @@ struct rp_hp_args {
   int KS;               // K16 steps per 32-row block in the workspace
   int kc0;              // first K of the workspace
   int first;            // the product's first chunk: tiles with an empty K range still get beta * C
+  int KSb, kc0b;        // k_gemm_hp16w: B's workspace geometry (A's planes may come from a cache with its own)
+  const unsigned* sc_tab;  // k_gemm_hp16w: A's scale changes with the K chunk (k >> sc_shift): rp_plane_cache::amax
+  int sc_shift, sc_mask;
+  int b_tab;            // ... and B's is the same chunk's (B read from the same cache)
   unsigned* stamps;     // diagnostic build (-DRP_GEMM_STAMPS): per-step clock stamps of one workgroup of k_gemm_hp16w
 };
 
@@ -999,7 +1005,14 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
   const int my = wr >> 1;  // this wave's half
   const bool mine = act[my];
   const int my_kb = kbh[my], my_ke = keh[my];
-  const float unscale = 1.0f / (rp_h2_scale(g.amax[0]) * rp_h2_scale(g.amax[1]));
+  // the scales leave the accumulators at the flush.  With a plane cache A's scale belongs to the K chunk: the accumulators are
+  // flushed at every chunk edge and the factor follows
+  const float sb_fixed = q.b_tab ? 1.0f : rp_h2_scale(g.amax[1]);
+  auto chunk_unscale = [&](int k) __attribute__((always_inline)) {
+    const float sa = rp_h2_scale(q.sc_tab[k >> q.sc_shift]);
+    return 1.0f / (sa * (q.b_tab ? sa : sb_fixed));
+  };
+  float unscale = q.sc_tab ? chunk_unscale(my_kb < my_ke ? my_kb : g.k0) : 1.0f / (rp_h2_scale(g.amax[0]) * sb_fixed);
 
   // Master sums hi + lo; lo as packed bf16 pairs (gfx950 converts two floats with ONE v_cvt_pk_bf16_f32, round to nearest even; the
   // integer rounding of the 128 x 128 kernels was 40 % of the flush's instructions - and an f32 lo spilled: 256 registers).  The
@@ -1044,9 +1057,9 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
     // A block that lies beyond M (half tile) is replaced by the tile's first block: the count of requests per wave stays 6.
     const int ablk = (m0 / 32 + wave) * 32 < g.M ? wave : 0;
     const unsigned char* asrc = q.WA + ((long long)(m0 / 32 + ablk) * q.KS) * 1024 + lane * 16;
-    const unsigned char* bsrc = q.WB + (long long)(wave >> 2) * q.psb + ((long long)(n0 / 32 + (wave & 3)) * q.KS) * 1024 + lane * 16;
+    const unsigned char* bsrc = q.WB + (long long)(wave >> 2) * q.psb + ((long long)(n0 / 32 + (wave & 3)) * q.KSb) * 1024 + lane * 16;
     auto issue = [&](int stage, int k) __attribute__((always_inline)) {
-      const long long ko = (long long)((k - q.kc0) >> 4) * 1024;
+      const long long ko = (long long)((k - q.kc0) >> 4) * 1024, kob = (long long)((k - q.kc0b) >> 4) * 1024;
       unsigned char* sa = smw + stage * STAGE + AOFF + (wave * 2) * 1024;
       unsigned char* sb = smw + stage * STAGE + BOFF + (((wave >> 2) * 4 + (wave & 3)) * 2) * 1024;
 #pragma unroll
@@ -1057,12 +1070,12 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
                                            (__attribute__((address_space(3))) void*)(sa + p * 16 * 1024 + s2 * 1024), 16, 0, 0);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + ko + s2 * 1024),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + kob + s2 * 1024),
                                          (__attribute__((address_space(3))) void*)(sb + s2 * 1024), 16, 0, 0);
     };
     // the same six requests one group at a time: part 0 = A plane 0, 1 = A plane 1, 2 / 3 = B's two K16 pieces
     auto issue_part = [&](int stage, int k, int part) __attribute__((always_inline)) {
-      const long long ko = (long long)((k - q.kc0) >> 4) * 1024;
+      const long long ko = (long long)((k - q.kc0) >> 4) * 1024, kob = (long long)((k - q.kc0b) >> 4) * 1024;
       unsigned char* sa = smw + stage * STAGE + AOFF + (wave * 2) * 1024;
       unsigned char* sb = smw + stage * STAGE + BOFF + (((wave >> 2) * 4 + (wave & 3)) * 2) * 1024;
       if (part < 2) {
@@ -1072,7 +1085,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
                                            (__attribute__((address_space(3))) void*)(sa + part * 16 * 1024 + s2 * 1024), 16, 0, 0);
       } else {
         const int s2 = part - 2;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + ko + s2 * 1024),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + kob + s2 * 1024),
                                          (__attribute__((address_space(3))) void*)(sb + s2 * 1024), 16, 0, 0);
       }
     };
@@ -1165,9 +1178,11 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
         ++st_step;
 #endif
         since += 32;
-        if (since >= g.kc && k + 32 < my_ke && !(RP_GEMM_ABL & 8)) {
+        const bool edge = q.sc_tab && !((k + 32) & q.sc_mask);
+        if ((since >= g.kc || edge) && k + 32 < my_ke && !(RP_GEMM_ABL & 8)) {
           flush();
           since = 0;
+          if (edge) unscale = chunk_unscale(k + 32);
         }
       } else {
         issue(st2, kn);
@@ -1383,10 +1398,98 @@ __global__ void k_ease_scale(float* __restrict__ P, long long ld, int n, const f
 // ---- host ------------------------------------------------------------------------------------------------------
 // `st` = stream to launch on (the context's by default); `part_at` = where this product's split-K partials go
 // (two products that run concurrently on different streams must not share them)
+static bool rp_gemm_wide_ok(const rphip_ctx* ctx, const rp_gemm_args& g) {
+  return ctx->gemm_shape16 && ctx->gemm_wide && g.M >= 256 && !ctx->gemm_supertile;
+}
+
+static int rp_launch_hp16w(rphip_ctx* ctx, rp_hp_args& q, hipStream_t st) {
+#ifdef RP_GEMM_STAMPS
+  constexpr int wide_lds = 3 * 48 * 1024 + 8 * 48 * 5 * 4;
+  if (!ctx->scratch[15].p) {
+    void* sp = nullptr;
+    RP_TRY(rp_scratch(ctx, 15, 8 * 48 * 5 * 4, &sp));
+  }
+  q.stamps = (unsigned*)ctx->scratch[15].p;
+#else
+  constexpr int wide_lds = 3 * 48 * 1024;
+#endif
+  static bool attr_set = false;
+  if (!attr_set) {
+    RP_HIP(hipFuncSetAttribute((const void*)k_gemm_hp16w, hipFuncAttributeMaxDynamicSharedMemorySize, wide_lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_gemm_hp16w, dim3(q.g.N / GT, (unsigned)rp_cdiv(q.g.M, 256)), dim3(512), wide_lds, st, q);
+  return RPHIP_OK;
+}
+
+// A's planes (and B's, with g.cb) from a plane cache: nothing of A is measured or cut here; B is cut with one scale of its own
+static int rp_gemm_nt_cached(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st) {
+  const rp_plane_cache& pc = *g.ca;
+  if (!rp_gemm_wide_ok(ctx, g) || ctx->gemm_mode != 2 || g.tri == 3 || g.k0 < 0 || g.k1 > pc.K || g.M > pc.K || (g.cb && g.N > pc.K) ||
+      (g.k0 % 32) || (g.k1 % 32) || (pc.w & (pc.w - 1)))
+    RP_FAIL(RPHIP_EINVAL, "gemm_nt: this product cannot read its operand from the plane cache");
+  rp_hp_args q{};
+  q.g = g;
+  q.g.kc = ctx->gemm_kc;
+  q.g.sw = 0;
+  q.g.part = nullptr;
+  q.WA = pc.W;
+  q.psa = pc.ps;
+  q.KS = pc.K / 16;
+  q.kc0 = 0;
+  q.sc_tab = pc.amax;
+  q.sc_shift = __builtin_ctz((unsigned)pc.w);
+  q.sc_mask = pc.w - 1;
+  q.b_tab = g.cb ? 1 : 0;
+  if (g.cb) {
+    q.WB = pc.W;
+    q.psb = pc.ps;
+    q.KSb = q.KS;
+    q.kc0b = 0;
+    q.first = 1;
+    RP_TRY(rp_launch_hp16w(ctx, q, st));
+    RP_HIP(hipGetLastError());
+    return RPHIP_OK;
+  }
+  if (!ctx->gemm_amax_ring) RP_HIP(hipMalloc((void**)&ctx->gemm_amax_ring, (size_t)RP_AMAX_SLOTS * 2 * sizeof(unsigned)));
+  unsigned* slot = ctx->gemm_amax_ring + 2 * (size_t)(ctx->gemm_amax_seq++ % RP_AMAX_SLOTS);
+  RP_HIP(hipMemsetAsync(slot, 0, 2 * sizeof(unsigned), st));
+  const int klen = g.k1 - g.k0;
+  rp_amax_op oa{nullptr, 0, 0, 0, 0, 0};
+  rp_amax_op ob{g.B, g.ldb, g.N / GT, g.kb_n, g.ke_n, g.n_off};
+  hipLaunchKernelGGL(k_gemm_amax, dim3(ob.tiles, (unsigned)rp_cdiv(klen, 256)), dim3(256), 0, st, oa, ob, g.k0, g.k1, 0, slot);
+  q.g.amax = slot;
+  long long Kc = (long long)(ctx->gemm_ws_bytes / ((size_t)g.N * 4)) / 512 * 512;
+  Kc = std::max<long long>(512, std::min<long long>(Kc, (klen + 31) / 32 * 32));
+  const int slot_b = (g.ws_slot ? g.ws_slot : ((st == ctx->stream) ? 8 : 10)) + 1;
+  unsigned char* WB = nullptr;
+  size_t cap = (size_t)64 << 20;
+  while (cap < (size_t)g.N * Kc * 4) cap <<= 1;
+  RP_TRY(rp_scratch(ctx, slot_b, std::max<size_t>((size_t)g.N * Kc * 4, std::min<size_t>(cap, ctx->gemm_ws_bytes)), (void**)&WB));
+  for (long long kc0 = g.k0; kc0 < g.k1; kc0 += Kc) {
+    const int kc1 = (int)std::min<long long>(g.k1, kc0 + Kc);
+    const int KS = (kc1 - (int)kc0) / 16;
+    rp_split_args sb{g.B, g.ldb, g.N, (int)kc0, kc1, g.kb_n, g.ke_n, g.n_off, g.k0, g.k1, slot + 1, WB, (long long)g.N / 32 * KS * 1024};
+    hipLaunchKernelGGL(k_split_planes, dim3(g.N / 32, (unsigned)rp_cdiv(KS, 16)), dim3(256), 0, st, sb);
+    q.g.k0 = (int)kc0;
+    q.g.k1 = kc1;
+    q.g.beta = (kc0 == g.k0) ? g.beta : 1.0f;
+    q.first = (kc0 == g.k0) ? 1 : 0;
+    q.WB = WB;
+    q.psb = sb.plane_stride;
+    q.KSb = KS;
+    q.kc0b = (int)kc0;
+    RP_TRY(rp_launch_hp16w(ctx, q, st));
+  }
+  RP_HIP(hipGetLastError());
+  return RPHIP_OK;
+}
+
 int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st, float* part_at) {
   if (!st) st = ctx->stream;
   if (g.M <= 0 || g.N <= 0) return RPHIP_OK;
   if ((g.M % GT) || (g.N % GT) || (g.k0 % GBK) || (g.k1 % GBK)) RP_FAIL(RPHIP_EINVAL, "gemm_nt: sizes must be tile multiples");
+  if (g.ca) return rp_gemm_nt_cached(ctx, g, st);
   const long long tiles = (long long)(g.M / GT) * (g.N / GT);
   const int klen = g.k1 - g.k0;
   // few tiles and a long K: split K so that the launch fills the chip (partials in scratch, fixed-order reduce)
@@ -1461,8 +1564,8 @@ int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st, float* par
         q.first = (kc0 == g.k0) ? 1 : 0;
         q.WA = WA;
         q.psa = sa.plane_stride;
-        q.KS = KS;
-        q.kc0 = (int)kc0;
+        q.KS = q.KSb = KS;
+        q.kc0 = q.kc0b = (int)kc0;
         if (alias) {
           q.WB = WA + (dup ? 0 : row_shift / 32 * KS * 1024);
           q.psb = q.psa;
@@ -1472,23 +1575,8 @@ int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st, float* par
           q.WB = WB;
           q.psb = sb.plane_stride;
         }
-        if (ctx->gemm_shape16 && ctx->gemm_wide && g.M >= 256 && !ctx->gemm_supertile) {
-#ifdef RP_GEMM_STAMPS
-          constexpr int wide_lds = 3 * 48 * 1024 + 8 * 48 * 5 * 4;
-          if (!ctx->scratch[15].p) {
-            void* sp = nullptr;
-            RP_TRY(rp_scratch(ctx, 15, 8 * 48 * 5 * 4, &sp));
-          }
-          q.stamps = (unsigned*)ctx->scratch[15].p;
-#else
-          constexpr int wide_lds = 3 * 48 * 1024;
-#endif
-          static bool attr_set = false;
-          if (!attr_set) {
-            RP_HIP(hipFuncSetAttribute((const void*)k_gemm_hp16w, hipFuncAttributeMaxDynamicSharedMemorySize, wide_lds));
-            attr_set = true;
-          }
-          hipLaunchKernelGGL(k_gemm_hp16w, dim3(g.N / GT, (unsigned)rp_cdiv(g.M, 256)), dim3(512), wide_lds, st, q);
+        if (rp_gemm_wide_ok(ctx, g)) {
+          RP_TRY(rp_launch_hp16w(ctx, q, st));
         } else if (ctx->gemm_shape16)
           hipLaunchKernelGGL(k_gemm_hp16, grid, dim3(256), 0, st, q);
         else
@@ -1704,6 +1792,46 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
   // then ONE product per panel against everything to its left, 2048 columns wide: T = N11 L21^T (K from the row block's
   // first column), N12 = -T N22.  Block column by block column (128 wide, K from 0) every product was skinny:
   // 101 TFLOP/s with split K; the wide ones run at the square-GEMM rate.
+  // Plane cache of N (rp_plane_cache): rows and columns [0, Kc) - everything when 4 n^2 bytes are free, else as many whole panels
+  // as fit (the products below then come in two parts: K below Kc from the cache, the rest cut per product as before).
+  struct cache_guard {
+    rphip_ctx* ctx;
+    rp_plane_cache pc;
+    ~cache_guard() {
+      if (pc.W) rp_dev_free(ctx, pc.W);  // (the block carries an event of the context's stream; side-stream users are joined below)
+    }
+  } cg{ctx, {}};
+  rp_plane_cache& pc = cg.pc;
+  if (ctx->gemm_plane_cache && st == ctx->stream && ctx->gemm_mode == 2 && ctx->gemm_presplit && ctx->gemm_shape16 && ctx->gemm_wide &&
+      !ctx->gemm_supertile && n_pad >= 3 * inv_w) {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+      const size_t reserve = std::min<size_t>((size_t)12 << 30, tot / 16);
+      size_t avail = fr + ctx->cached_bytes > reserve ? fr + ctx->cached_bytes - reserve : 0;
+      if (ctx->gemm_plane_cache > 1) avail = std::min<size_t>(avail, (size_t)ctx->gemm_plane_cache);
+      long long Kc = (long long)std::sqrt((double)avail / 4.0);
+      if (Kc >= n_pad)
+        Kc = n_pad;
+      else
+        Kc = Kc / inv_w * inv_w;
+      if (Kc >= 2 * inv_w) {
+        const int chunks = (int)rp_cdiv(Kc, inv_w);
+        const size_t bytes = (size_t)4 * Kc * Kc + (size_t)chunks * sizeof(unsigned) + 256;
+        void* p = nullptr;
+        if (rp_dev_alloc(ctx, bytes, &p) == RPHIP_OK) {
+          pc.W = (unsigned char*)p;
+          pc.ps = 2LL * Kc * Kc;
+          pc.K = (int)Kc;
+          pc.w = inv_w;
+          pc.amax = (unsigned*)(pc.W + (size_t)4 * Kc * Kc);
+          RP_HIP(hipMemsetAsync(pc.amax, 0, (size_t)chunks * sizeof(unsigned), st));
+        } else {
+          rp_set_error("%s", "");  // (no cache: the products cut their operands as before)
+        }
+      }
+    }
+  }
+  const int Kc = pc.K;
   if (timed) rp_time_begin(ctx, &ev);
   for (int pb = 0; pb < nb; pb += RP_INV_PANEL) {
     const int pe = std::min(nb, pb + RP_INV_PANEL);
@@ -1760,6 +1888,19 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
       g.kb_m = 1;
       g.alpha = 1.0f;
       g.beta = 0.0f;
+      if (Kc > 0) {  // K >= Kc first (all rows, beta = 0), then K < Kc from the cache (rows < Kc only have such K)
+        const int jc = std::min(j, Kc);
+        if (j > jc) {
+          g.k0 = jc;
+          RP_TRY(rp_gemm_nt(ctx, g, st));
+          g.beta = 1.0f;
+        }
+        g.k0 = 0;
+        g.k1 = jc;
+        g.M = jc;
+        g.ca = &pc;
+        g.no_splitk = 1;
+      }
       RP_TRY(rp_gemm_nt(ctx, g, st));
       hipLaunchKernelGGL(k_transpose_block, dim3(w / 32, w / 32), dim3(32, 8), 0, st, Nb + (long long)j * ld + j, ld, NT, (long long)w);
       rp_gemm_args h{};  // N12 = -T N22 (N22 is upper triangular: K ends with the column tile)
@@ -1777,6 +1918,13 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
       h.alpha = -1.0f;
       h.beta = 0.0f;
       RP_TRY(rp_gemm_nt(ctx, h, st));
+    }
+    if (j < Kc) {  // columns [j, j + w) of N are final: into the cache (rows 0 .. j + w; a row tile's K starts at its own first column)
+      const int c = j / inv_w, rows = j + w;
+      rp_amax_op oa{Nb, ld, rows / GT, 1, 0, 0}, ob{nullptr, 0, 0, 0, 0, 0};
+      hipLaunchKernelGGL(k_gemm_amax, dim3(oa.tiles, (unsigned)rp_cdiv(w, 256)), dim3(256), 0, st, oa, ob, j, j + w, 0, pc.amax + c);
+      rp_split_args sa{Nb, ld, rows, j, j + w, 1, 0, 0, j, j + w, pc.amax + c, pc.W, pc.ps, (long long)pc.K / 16, 0};
+      hipLaunchKernelGGL(k_split_planes, dim3(rows / 32, (unsigned)rp_cdiv(w / 16, 16)), dim3(256), 0, st, sa);
     }
   }
   // ---- K6b: P = N N^T (lower tiles, K from max(row, column) = row), mirrored into the upper half
@@ -1797,7 +1945,22 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
     g.tri = 2;  // P is symmetric: the tiles below the diagonal (they read N on and above it, never what they write) ...
     g.alpha = 1.0f;
     g.beta = 0.0f;
-    RP_TRY(rp_gemm_nt(ctx, g, st));
+    if (Kc > 0) {  // as above: K >= Kc cut per product, K < Kc (rows and columns < Kc) straight from the cache
+      rp_gemm_args c = g;
+      if (Kc < n_pad) {
+        c.k0 = Kc;
+        RP_TRY(rp_gemm_nt(ctx, c, st));
+        c.beta = 1.0f;
+      }
+      c.k0 = 0;
+      c.k1 = Kc;
+      c.M = c.N = Kc;
+      c.ca = &pc;
+      c.cb = 1;
+      RP_TRY(rp_gemm_nt(ctx, c, st));
+    } else {
+      RP_TRY(rp_gemm_nt(ctx, g, st));
+    }
     g.tri = 3;  // ... the diagonal tiles into the (now free) T buffer, copied over N's diagonal blocks afterwards ...
     g.C = T;
     g.ldc = GT;

@@ -5,6 +5,18 @@
 constexpr int GT = 128;   // tile (and diagonal block) size
 constexpr int GBK = 16;   // K step
 
+// Planes of an operand kept between products.  Every panel of the inverse multiplies by ALL of N = L^-T found so far: cut anew
+// per product that was 0.65 TB of reads and writes per 100 000-item solve (k_split_planes + k_gemm_amax: 0.6 s of kernel time).
+// The cache holds k_split_planes' layout for rows [0, K) x columns [0, K) of the operand with one power-of-two scale per chunk
+// of w columns; a finished panel is cut into it once.
+struct rp_plane_cache {
+  unsigned char* W = nullptr;  // [plane 2][32-row block K/32][K16 step K/16][1 KB]
+  long long ps = 0;            // plane stride in bytes
+  int K = 0;                   // rows and columns covered (a multiple of 128)
+  int w = 0;                   // chunk width: a power of two
+  unsigned* amax = nullptr;    // [ceil(K / w)] largest magnitude of each chunk (fp32 bits)
+};
+
 struct rp_gemm_args {
   const float* A;
   long long lda;
@@ -33,6 +45,8 @@ struct rp_gemm_args {
   int cyc_nb, cyc_w, cyc_r, cyc_l0;
   int no_splitk;     // never split K (the product runs beside others that use the shared partial-sum scratch)
   int ws_slot;       // scratch slots ws_slot, ws_slot + 1 hold this product's plane workspaces (0: 8 / 9 on the context's stream, 10 / 11 elsewhere)
+  const rp_plane_cache* ca;  // A's planes are read from this cache (A unused; M and k1 <= ca->K; the wide product kernel only)
+  int cb;            // ... and B's as well (B is the same matrix)
 };
 
 // C = alpha * A * B^T + beta * C on `st` (the context's stream when NULL)
