@@ -131,6 +131,10 @@ int rphip_ctx_trim(rphip_ctx* ctx);
  *                       363 against 314 TFLOP/s) or on v_mfma_f32_32x32x16_f16.
  *   "gemm_wide"         1 (default) | 0.  The plane product kernel on 256 x 128 tiles, eight waves, three LDS stages with counted
  *                       waits (k_gemm_hp16w; bit-identical results, +2..6 %) or on 128 x 128 tiles with two stages.
+ *   "chol_sub_panel"    8 (default) | 0 .. 32 tiles.  The blocked Cholesky of the EASE solve works in panels of 32 tiles (16 below 640
+ *                       tiles) and, inside a panel, in sub-panels of this many: a block's left-looking products reach back to its
+ *                       sub-panel only, a finished sub-panel updates the rest of the panel in one wide product.  0 (or a value
+ *                       that does not divide the panel) = one level.
  *   "gemm_plane_cache"  1 (default) | 0 | bytes.  The inverse N = L^-T keeps the fp16 planes of the part of N it has finished
  *                       (4 bytes per element of an n x n square, from the context's block cache) instead of cutting it anew for
  *                       every panel: 1 = as much as the free memory holds (everything at 100 000 items; a prefix of the panels

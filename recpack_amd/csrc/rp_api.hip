@@ -237,6 +237,9 @@ extern "C" int rphip_ctx_set_option(rphip_ctx* ctx, const char* name, int64_t va
     ctx->gemm_shape16 = value ? 1 : 0;
   } else if (!strcmp(name, "gemm_wide")) {
     ctx->gemm_wide = value ? 1 : 0;
+  } else if (!strcmp(name, "chol_sub_panel")) {
+    if (value < 0 || value > 32) RP_FAIL(RPHIP_EINVAL, "chol_sub_panel must be 0 .. 32 tiles");
+    ctx->chol_sub = (int)value;
   } else if (!strcmp(name, "gemm_plane_cache")) {
     if (value < 0) RP_FAIL(RPHIP_EINVAL, "gemm_plane_cache must be >= 0");
     ctx->gemm_plane_cache = value;

@@ -91,6 +91,7 @@ struct rphip_ctx {
   int gemm_shape16 = 1;      // k_gemm_hp on v_mfma_f32_16x16x32_f16 (default; the chip holds a higher clock on it) or 32x32x16
   int gemm_wide = 1;         // the plane product kernel on 256 x 128 tiles with three LDS stages (k_gemm_hp16w) instead of 128 x 128 / two
   size_t gemm_ws_bytes = (size_t)4 << 30;  // workspace per operand of those products (sets their K chunk)
+  int chol_sub = 8;          // tiles per sub-panel of the blocked Cholesky (0: one level of panels)
   int64_t gemm_plane_cache = 1;  // the inverse keeps the planes of N = L^-T between its panels: 0 off, 1 as much as fits, > 1 at most that many bytes
   unsigned* gemm_amax_ring = nullptr;  // mode 2: [RP_AMAX_SLOTS][2] words, the operands' largest magnitudes per launch
   unsigned long long gemm_amax_seq = 0;

@@ -1252,57 +1252,149 @@ __global__ void k_splitk_reduce(const float* __restrict__ part, int S, int M, in
 // ---- diagonal block: Cholesky + inverse of a 128x128 block, float64 in LDS --------------------------------
 constexpr int DS = GT + 1;  // LDS row stride in doubles
 
-__global__ void __launch_bounds__(1024) k_potrf_trtri(float* __restrict__ A, long long lda, float* __restrict__ W, int* __restrict__ info) {
+// Blocked in 16 columns: the first version walked the 128 columns one by one with four workgroup barriers each (and two more per
+// column of the inverse): 768 barriers of 16 waves = the 0.3 ms the kernel took, a third of the Cholesky's per-block chain, which
+// is what the second half of the factorisation waits for (the trailing updates there are shorter than the chain).  Now per block
+// of 16 columns: the 16 x 16 diagonal block in the registers of one wave (shuffles, no barrier), the rows below by forward
+// substitution (a thread per row), the rank-16 update of the rest in 4 x 4 register blocks: 3 barriers; the inverse by block rows
+// with 2 barriers each.  40 barriers of 8 waves.
+constexpr int PB = 16;                                    // block width inside the diagonal block
+constexpr int PSTG = GT + 1;                              // row stride of the staging rows
+constexpr size_t RP_POTRF_LDS = ((size_t)GT * DS + (size_t)PB * PSTG + (size_t)PB * (PB + 1)) * sizeof(double);
+constexpr int RP_POTRF_THREADS = 512;
+
+__global__ void __launch_bounds__(RP_POTRF_THREADS) k_potrf_trtri(float* __restrict__ A, long long lda, float* __restrict__ W, int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* a = reinterpret_cast<double*>(smem_raw);
-  const int tid = threadIdx.x;
-  const int row = tid >> 3, part = tid & 7;  // 8 threads share one row's dot product
-  for (int e = tid; e < GT * GT; e += 1024) {
+  double* a = reinterpret_cast<double*>(smem_raw);  // [128][DS]
+  double* stg = a + GT * DS;                         // [PB][PSTG]
+  double* wii = stg + PB * PSTG;                     // [PB][PB + 1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NT = RP_POTRF_THREADS;
+  for (int e = tid; e < GT * GT; e += NT) {
     const int i = e / GT, k = e % GT;
     a[i * DS + k] = (k <= i) ? (double)A[(long long)i * lda + k] : 0.0;
   }
   __syncthreads();
-  // left-looking column Cholesky: column j needs dot(a[i][0:j], a[j][0:j]) for every row i >= j
-  for (int j = 0; j < GT; ++j) {
-    double t = 0.0;
-    if (row >= j)
-      for (int k = part; k < j; k += 8) t += a[row * DS + k] * a[j * DS + k];
-    t += __shfl_xor(t, 1);
-    t += __shfl_xor(t, 2);
-    t += __shfl_xor(t, 4);
+  // ---- Cholesky, right-looking in blocks of PB columns
+  for (int c0 = 0; c0 < GT; c0 += PB) {
+    if (wave == 0) {  // the diagonal block: lane r (r < 16; the other lanes mirror them) holds row r
+      const int r = lane & (PB - 1);
+      double x[PB];
+#pragma unroll
+      for (int c = 0; c < PB; ++c) x[c] = a[(c0 + r) * DS + c0 + c];  // (zero above the diagonal)
+#pragma unroll
+      for (int j = 0; j < PB; ++j) {
+        const double d = __shfl(x[j], j);
+        if (lane == 0 && !(d > 0.0)) atomicExch(info, c0 + j + 1);
+        const double djj = sqrt(d > 0.0 ? d : 1.0);
+        x[j] = (r == j) ? djj : x[j] / djj;
+#pragma unroll
+        for (int c = j + 1; c < PB; ++c) {
+          const double lcj = __shfl(x[j], c);
+          if (r >= c) x[c] -= x[j] * lcj;
+        }
+      }
+      if (lane < PB) {
+#pragma unroll
+        for (int c = 0; c < PB; ++c)
+          if (c <= r) a[(c0 + r) * DS + c0 + c] = x[c];
+      }
+    }
     __syncthreads();
-    if (part == 0 && row >= j) a[row * DS + j] -= t;
+    const int nrow = GT - c0 - PB;
+    if (tid < nrow) {  // the rows below: x L_dd^T = a[row][c0 : c0 + PB]
+      const int row = c0 + PB + tid;
+      double x[PB];
+#pragma unroll
+      for (int k = 0; k < PB; ++k) x[k] = a[row * DS + c0 + k];
+#pragma unroll
+      for (int k = 0; k < PB; ++k) {
+        double t = x[k];
+#pragma unroll
+        for (int m = 0; m < k; ++m) t -= x[m] * a[(c0 + k) * DS + c0 + m];
+        x[k] = t / a[(c0 + k) * DS + c0 + k];
+      }
+#pragma unroll
+      for (int k = 0; k < PB; ++k) a[row * DS + c0 + k] = x[k];
+    }
     __syncthreads();
-    const double d = a[j * DS + j];
-    if (tid == 0 && !(d > 0.0)) atomicExch(info, j + 1);
-    const double djj = sqrt(d > 0.0 ? d : 1.0);
-    __syncthreads();
-    if (part == 0 && row >= j) a[row * DS + j] = (row == j) ? djj : a[row * DS + j] / djj;
-    __syncthreads();
-  }
-  for (int e = tid; e < GT * GT; e += 1024) {
-    const int i = e / GT, k = e % GT;
-    A[(long long)i * lda + k] = (k <= i) ? (float)a[i * DS + k] : 0.0f;
-  }
-  __syncthreads();
-  // in-place inverse of the lower-triangular factor, columns from last to first:
-  // x_ij = -(sum_{k=j+1..i} X_ik l_kj) / l_jj with X the already inverted trailing block
-  for (int j = GT - 1; j >= 0; --j) {
-    const double ajj = 1.0 / a[j * DS + j];
-    double t = 0.0;
-    if (row > j)
-      for (int k = j + 1 + part; k <= row; k += 8) t += a[row * DS + k] * a[k * DS + j];
-    t += __shfl_xor(t, 1);
-    t += __shfl_xor(t, 2);
-    t += __shfl_xor(t, 4);
-    __syncthreads();
-    if (part == 0) {
-      if (row > j) a[row * DS + j] = -t * ajj;
-      if (row == j) a[j * DS + j] = ajj;
+    // the rest: a[i][j] -= sum_k a[i][c0 + k] a[j][c0 + k] for i >= j >= c0 + PB, in 4 x 4 blocks (bi >= bj)
+    const int nq = nrow / 4;  // nrow is a multiple of 16
+    for (int e = tid; e < nq * (nq + 1) / 2; e += NT) {
+      int bi = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+      while ((bi + 1) * (bi + 2) / 2 <= e) ++bi;
+      while (bi * (bi + 1) / 2 > e) --bi;
+      const int bj = e - bi * (bi + 1) / 2;
+      const int i0 = c0 + PB + 4 * bi, j0 = c0 + PB + 4 * bj;
+      double acc[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+#pragma unroll 4
+      for (int k = 0; k < PB; ++k) {
+        double li[4], lj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          li[u] = a[(i0 + u) * DS + c0 + k];
+          lj[u] = a[(j0 + u) * DS + c0 + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[u][v] += li[u] * lj[v];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (j0 + v <= i0 + u) a[(i0 + u) * DS + j0 + v] -= acc[u][v];
     }
     __syncthreads();
   }
-  for (int e = tid; e < GT * GT; e += 1024) {
+  for (int e = tid; e < GT * GT; e += NT) {
+    const int i = e / GT, k = e % GT;
+    A[(long long)i * lda + k] = (k <= i) ? (float)a[i * DS + k] : 0.0f;
+  }
+  // ---- W = L^-1 in place, block row by block row: W[I][J] = -W_II sum_{K = J .. I-1} L[I][K] W[K][J] (rows above I already hold W)
+  for (int r0 = 0; r0 < GT; r0 += PB) {
+    if (wave == 0) {  // W_II: lane c computes column c of the inverse of the 16 x 16 triangle by forward substitution
+      const int c = lane & (PB - 1);
+      double w[PB];
+#pragma unroll
+      for (int r = 0; r < PB; ++r) {
+        double t = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int m = 0; m < r; ++m) t -= a[(r0 + r) * DS + r0 + m] * w[m];
+        w[r] = (r >= c) ? t / a[(r0 + r) * DS + r0 + r] : 0.0;
+      }
+      if (lane < PB) {
+#pragma unroll
+        for (int r = 0; r < PB; ++r) wii[r * (PB + 1) + c] = w[r];
+      }
+    } else {  // T = L[I][0 : r0] W[0 : r0][0 : r0] (16 x r0), the other waves
+      for (int e = tid - 64; e < PB * r0; e += NT - 64) {
+        const int r = e / r0, col = e % r0;
+        double t = 0.0;
+        for (int m = col; m < r0; ++m) t += a[(r0 + r) * DS + m] * a[m * DS + col];
+        stg[r * PSTG + col] = t;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < PB * (r0 + PB); e += NT) {
+      const int r = e / (r0 + PB), col = e % (r0 + PB);
+      double t = 0.0;
+      if (col < r0) {
+#pragma unroll
+        for (int m = 0; m < PB; ++m) t -= wii[r * (PB + 1) + m] * stg[m * PSTG + col];  // (wii is zero above its diagonal)
+      } else {
+        t = wii[r * (PB + 1) + (col - r0)];
+      }
+      a[(r0 + r) * DS + col] = t;
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < GT * GT; e += NT) {
     const int i = e / GT, k = e % GT;
     W[i * GT + k] = (k <= i) ? (float)a[i * DS + k] : 0.0f;
   }
@@ -1654,7 +1746,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
   float* part_all = nullptr;  // the split-K partials of the skinny products: sized once for the tallest of them
   RP_TRY(rp_scratch(ctx, 7, (size_t)8 * n_pad * GT * sizeof(float), (void**)&part_all));
   if (!info_ext) RP_HIP(hipMemsetAsync(info, 0, 4, st));
-  const size_t diag_lds = (size_t)GT * DS * sizeof(double);
+  const size_t diag_lds = RP_POTRF_LDS;
   RP_HIP(hipFuncSetAttribute((const void*)k_potrf_trtri, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
   const double n3 = (double)n_pad * n_pad * n_pad;
   hipEvent_t ev;
@@ -1692,9 +1784,14 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
   // from 0 for every 128-column block) made every product of the factorisation skinny: 92 TFLOP/s at n = 100 000.
   // (measured on MI355X: panels of 8 / 16 / 32 tiles give 91 / 96 / 89 TFLOP/s at n = 50 000 and 105 / 114 / 116 at 100 000)
   const int RP_CHOL_PANEL = nb >= 640 ? 32 : 16;  // tiles per panel
+  // ... and a level between: sub-panels of `chol_sub` tiles.  The left-looking products of a block (one tile column wide: ~100
+  // TFLOP/s) only reach back to the sub-panel's first column; a finished sub-panel updates the REST OF ITS PANEL's columns in one
+  // wide product (K = 128 * chol_sub).  3/4 of the in-panel flop moves from the skinny kernel to the wide one.
+  const int SUB = (ctx->chol_sub > 0 && RP_CHOL_PANEL % ctx->chol_sub == 0) ? ctx->chol_sub : RP_CHOL_PANEL;
   for (int k = 0; k < nb && rc == RPHIP_OK; ++k) {
     const int r0 = k * GT;
     const int pk0 = (k / RP_CHOL_PANEL) * RP_CHOL_PANEL * GT;  // first column of this block's panel
+    const int sk0 = (k / SUB) * SUB * GT;                      // ... of its sub-panel
     RP_HIP(hipEventRecord(e_panel, st));  // block k-1 (and everything before) is complete
     RP_HIP(hipStreamWaitEvent(s2, e_panel, 0));
     rp_gemm_args g{};
@@ -1705,19 +1802,19 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
     g.C = A + (long long)r0 * ld + r0;
     g.ldc = ld;
     g.N = GT;
-    g.k0 = pk0;
+    g.k0 = sk0;
     g.k1 = r0;
     g.alpha = -1.0f;
     g.beta = 1.0f;
-    if (r0 > pk0) {  // A[k,k] -= L[k,p:k] L[k,p:k]^T on the side stream (p = the panel's first column)
+    if (r0 > sk0) {  // A[k,k] -= L[k,p:k] L[k,p:k]^T on the side stream (p = the sub-panel's first column)
       g.M = GT;
       rc = rp_gemm_nt(ctx, g, s2, part_diag);
       if (rc != RPHIP_OK) break;
     }
-    hipLaunchKernelGGL(k_potrf_trtri, dim3(1), dim3(1024), diag_lds, s2, A + (long long)r0 * ld + r0, ld, W + (size_t)k * GT * GT, info);
+    hipLaunchKernelGGL(k_potrf_trtri, dim3(1), dim3(RP_POTRF_THREADS), diag_lds, s2, A + (long long)r0 * ld + r0, ld, W + (size_t)k * GT * GT, info);
     RP_HIP(hipEventRecord(e_diag, s2));
     if (r0 + GT < n_pad) {
-      if (r0 > pk0) {  // A[k+1:,k] -= L[k+1:,p:k] L[k,p:k]^T
+      if (r0 > sk0) {  // A[k+1:,k] -= L[k+1:,p:k] L[k,p:k]^T
         g.A = A + (long long)(r0 + GT) * ld;
         g.C = A + (long long)(r0 + GT) * ld + r0;
         g.M = n_pad - r0 - GT;
@@ -1741,6 +1838,27 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
       rc = rp_gemm_nt(ctx, h, st);
       if (rc != RPHIP_OK) break;
       const int r1 = r0 + GT;
+      if ((k + 1) % SUB == 0 && (k + 1) % RP_CHOL_PANEL != 0 && r1 < n_pad) {
+        // the sub-panel is done: the panel's remaining columns take its rank-(128 SUB) update, A[r1:, r1:pe] -= L[r1:, s:r1] L[r1:pe, s:r1]^T
+        const int pe = std::min(pk0 + RP_CHOL_PANEL * GT, n_pad);
+        rp_gemm_args u{};
+        u.A = A + (long long)r1 * ld;
+        u.lda = ld;
+        u.B = A + (long long)r1 * ld;
+        u.ldb = ld;
+        u.C = A + (long long)r1 * ld + r1;
+        u.ldc = ld;
+        u.M = n_pad - r1;
+        u.N = pe - r1;
+        u.k0 = sk0;
+        u.k1 = r1;
+        u.tri = 1;
+        u.alpha = -1.0f;
+        u.beta = 1.0f;
+        u.no_splitk = 1;
+        rc = rp_gemm_nt(ctx, u, st);
+        if (rc != RPHIP_OK) break;
+      }
       if ((k + 1) % RP_CHOL_PANEL == 0 && r1 < n_pad) {
         // The panel is done: A[r1:, r1:] -= L[r1:, p:r1] L[r1:, p:r1]^T (lower tiles), in two pieces.  The columns of the NEXT
         // panel are updated here, on the main stream; the rest of the trailing matrix - almost all of the flops - on a third
@@ -2021,9 +2139,9 @@ extern "C" int rphip_ease_gram_rows(rphip_ctx* ctx, const rphip_csr* X, int64_t 
 extern "C" int rphip_potrf_trtri_128(rphip_ctx* ctx, float* A_dev, int64_t lda, float* W_dev, int32_t* info_dev) {
   if (!ctx || !A_dev || !W_dev || !info_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   RP_TRY(rp_set_device(ctx));
-  const size_t diag_lds = (size_t)GT * DS * sizeof(double);
+  const size_t diag_lds = RP_POTRF_LDS;
   RP_HIP(hipFuncSetAttribute((const void*)k_potrf_trtri, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
-  hipLaunchKernelGGL(k_potrf_trtri, dim3(1), dim3(1024), diag_lds, ctx->stream, A_dev, (long long)lda, W_dev, (int*)info_dev);
+  hipLaunchKernelGGL(k_potrf_trtri, dim3(1), dim3(RP_POTRF_THREADS), diag_lds, ctx->stream, A_dev, (long long)lda, W_dev, (int*)info_dev);
   RP_HIP(hipGetLastError());
   return RPHIP_OK;
 }

@@ -1,5 +1,7 @@
-"""The inverse's plane cache (context option gemm_plane_cache): B of a fit with the cache against B without it, and the fit time.
-    python tools/plane_cache_check.py [users items density [cache_bytes ...]]      (cache_bytes: 0 off, 1 auto, > 1 a limit)
+"""A context option of the EASE solve across its values (default: the inverse's plane cache, gemm_plane_cache): B of a fit with
+each value against B with the first, and the fit time.
+    python tools/plane_cache_check.py [users items density [value ...]]      (gemm_plane_cache: 0 off, 1 auto, > 1 a byte limit)
+    RP_OPT=chol_sub_panel python tools/plane_cache_check.py 100000 20000 0.002 0 8 4
 With `certify <config> <l2>` as the arguments: the certified column error (tests/ease_cg.py) with the cache in its default mode."""
 import os
 import sys
@@ -31,8 +33,9 @@ ip, ix = powerlaw_csr(U, I, dens, seed=7, device=dev)
 dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
 ref = None
 ok = True
+OPT = os.environ.get("RP_OPT", "gemm_plane_cache")
 for mode in modes:
-    ctx.set_option("gemm_plane_cache", mode)
+    ctx.set_option(OPT, mode)
     best = 1e9
     for _ in range(2):
         torch.cuda.synchronize()
@@ -51,7 +54,7 @@ for mode in modes:
     else:
         err = float((B - ref).abs().max() / ref.abs().max())
         ok = ok and err <= 2e-5 and bool(torch.isfinite(B).all())
-    print(f"I={I} gemm_plane_cache={mode}: fit {best * 1e3:.1f} ms (cholesky {tm['cholesky']['ms']:.1f} inverse {tm['inverse']['ms']:.1f}), "
+    print(f"I={I} {OPT}={mode}: fit {best * 1e3:.1f} ms (cholesky {tm['cholesky']['ms']:.1f} inverse {tm['inverse']['ms']:.1f}), "
           f"max|dB|/max|B| against the first mode {err:.2e}", flush=True)
     del m
 sys.exit(0 if ok else 1)
