@@ -1737,12 +1737,13 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
   const int nb = n_pad / GT;
   char* wsb = nullptr;
   const int inv_w = std::min(RP_INV_PANEL * GT, n_pad);  // columns of one panel of the inverse
-  RP_TRY(rp_scratch(ctx, 5, (size_t)nb * GT * GT * 4 + ((size_t)n_pad * inv_w + (size_t)inv_w * inv_w) * 4 + 256, (void**)&wsb));
+  RP_TRY(rp_scratch(ctx, 5, (size_t)nb * GT * GT * 4 + ((size_t)n_pad * inv_w + (size_t)inv_w * inv_w + (size_t)inv_w * GT) * 4 + 256, (void**)&wsb));
   float* const Nb = A;  // N shares the matrix with L
   int* info = info_ext ? info_ext : (int*)wsb;
   float* W = (float*)(wsb + 256);                 // [nb][128][128]
   float* T = W + (size_t)nb * GT * GT;            // [n_pad][inv_w]: N11 L21^T of a panel ([c0][128] inside a panel)
   float* NT = T + (size_t)n_pad * inv_w;          // [inv_w][inv_w]: transpose of the panel's diagonal block of N
+  float* T2 = NT + (size_t)inv_w * inv_w;         // [inv_w][128]: the side stream's own T for the diagonal blocks of N
   float* part_all = nullptr;  // the split-K partials of the skinny products: sized once for the tallest of them
   RP_TRY(rp_scratch(ctx, 7, (size_t)8 * n_pad * GT * sizeof(float), (void**)&part_all));
   if (!info_ext) RP_HIP(hipMemsetAsync(info, 0, 4, st));
@@ -1775,6 +1776,18 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
   hipStream_t s2 = side.s, s3 = side.t;
   hipEvent_t e_panel = side.a, e_diag = side.b, e_fact = side.c, e_trail = side.d;
   bool trail_pending = false;  // a trailing update is in flight on s3
+  // diagnostic (RP_CHOL_TRACE=1): per panel, ms since the start at which the panel was factored and its next-panel update done (main
+  // stream) and its rest update done (third stream) - shows where the factorisation is chain-bound and where product-bound
+  std::vector<hipEvent_t> tr_ev;
+  const bool trace = getenv("RP_CHOL_TRACE") != nullptr;
+  auto tr_rec = [&](hipStream_t s) {
+    if (!trace) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    hipEventRecord(e, s);
+    tr_ev.push_back(e);
+  };
+  tr_rec(st);
   float* part_diag = part_all + (size_t)8 * (n_pad - GT) * GT;  // the side stream's own split-K partials
   if (timed) rp_time_begin(ctx, &ev);
   int rc = RPHIP_OK;
@@ -1865,6 +1878,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
         // stream, so that it runs beside the next panel's factorisation (a chain of small launches and one-workgroup diagonal
         // blocks that leaves the chip idle).  Its columns are not touched by that factorisation; the piece after it waits.
         const int wn = std::min(RP_CHOL_PANEL * GT, n_pad - r1);
+        tr_rec(st);
         RP_HIP(hipEventRecord(e_fact, st));
         if (trail_pending) RP_HIP(hipStreamWaitEvent(st, e_trail, 0));  // the previous rest-update wrote these columns
         rp_gemm_args t{};
@@ -1883,6 +1897,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
         t.beta = 1.0f;
         rc = rp_gemm_nt(ctx, t, st);
         if (rc != RPHIP_OK) break;
+        tr_rec(st);
         const int r2 = r1 + wn;
         if (r2 < n_pad) {
           RP_HIP(hipStreamWaitEvent(s3, e_fact, 0));
@@ -1892,6 +1907,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
           t.M = n_pad - r2;
           t.N = n_pad - r2;
           rc = rp_gemm_nt(ctx, t, s3);
+          tr_rec(s3);
           RP_HIP(hipEventRecord(e_trail, s3));
           trail_pending = true;
         }
@@ -1901,6 +1917,16 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
     }
   }
   hipStreamSynchronize(s2);
+  if (trace) {
+    hipDeviceSynchronize();
+    for (size_t i = 1; i < tr_ev.size(); ++i) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, tr_ev[0], tr_ev[i]);
+      fprintf(stderr, "%s%.2f", (i % 3 == 1) ? "\nchol panel: " : " ", ms);
+    }
+    fprintf(stderr, "\n");
+    for (auto e : tr_ev) hipEventDestroy(e);
+  }
   if (trail_pending) hipStreamWaitEvent(st, e_trail, 0);
   if (rc != RPHIP_OK) return rc;
   RP_HIP(hipGetLastError());
@@ -1951,20 +1977,34 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
   }
   const int Kc = pc.K;
   if (timed) rp_time_begin(ctx, &ev);
-  for (int pb = 0; pb < nb; pb += RP_INV_PANEL) {
-    const int pe = std::min(nb, pb + RP_INV_PANEL);
-    const int j = pb * GT, w = (pe - pb) * GT;
-    for (int i = pb; i < pe; ++i) {  // N22: the panel's own diagonal block
+  // The panels' own diagonal blocks N22 - chains of ~50 small launches that depend on nothing but W and L inside the block - run
+  // AHEAD on the side stream (a few panels, so that the host gets to the main stream's products in time) beside the wide products
+  // of earlier panels: issued in line they were 13 % of the inverse at 60 000 items with the chip idle.
+  struct ev_list {
+    std::vector<hipEvent_t> v;
+    ~ev_list() {
+      for (auto e : v) hipEventDestroy(e);
+    }
+  } n22_ev;
+  const int n_inv_panels = (int)rp_cdiv(nb, RP_INV_PANEL);
+  n22_ev.v.resize(n_inv_panels, nullptr);
+  for (auto& e : n22_ev.v) RP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  RP_HIP(hipEventRecord(e_panel, st));  // (the factor is complete)
+  RP_HIP(hipStreamWaitEvent(s2, e_panel, 0));
+  auto n22 = [&](int P) -> int {
+    const int pb = P * RP_INV_PANEL, pe = std::min(nb, pb + RP_INV_PANEL);
+    const int j = pb * GT;
+    for (int i = pb; i < pe; ++i) {
       const int c0 = i * GT;
       const float* Wi = W + (size_t)i * GT * GT;
-      hipLaunchKernelGGL(k_transpose_128, dim3(1), dim3(256), 0, st, Wi, Nb + (long long)c0 * ld + c0, ld);
+      hipLaunchKernelGGL(k_transpose_128, dim3(1), dim3(256), 0, s2, Wi, Nb + (long long)c0 * ld + c0, ld);
       if (i > pb) {
         rp_gemm_args g{};
         g.A = Nb + (long long)j * ld;
         g.lda = ld;
         g.B = A + (long long)c0 * ld;
         g.ldb = ld;
-        g.C = T;
+        g.C = T2;
         g.ldc = GT;
         g.M = c0 - j;
         g.N = GT;
@@ -1974,9 +2014,10 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
         g.m_off = j;
         g.alpha = 1.0f;
         g.beta = 0.0f;
-        RP_TRY(rp_gemm_nt(ctx, g, st));
+        g.no_splitk = 1;
+        RP_TRY(rp_gemm_nt(ctx, g, s2));
         rp_gemm_args h{};
-        h.A = T;
+        h.A = T2;
         h.lda = GT;
         h.B = Wi;
         h.ldb = GT;
@@ -1988,9 +2029,21 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
         h.k1 = GT;
         h.alpha = -1.0f;
         h.beta = 0.0f;
-        RP_TRY(rp_gemm_nt(ctx, h, st));
+        h.no_splitk = 1;
+        RP_TRY(rp_gemm_nt(ctx, h, s2));
       }
     }
+    RP_HIP(hipEventRecord(n22_ev.v[P], s2));
+    return RPHIP_OK;
+  };
+  constexpr int N22_AHEAD = 3;
+  int n22_issued = 0;
+  for (int pb = 0; pb < nb; pb += RP_INV_PANEL) {
+    const int pe = std::min(nb, pb + RP_INV_PANEL);
+    const int j = pb * GT, w = (pe - pb) * GT;
+    const int P = pb / RP_INV_PANEL;
+    for (; n22_issued < std::min(n_inv_panels, P + 1 + N22_AHEAD); ++n22_issued) RP_TRY(n22(n22_issued));
+    RP_HIP(hipStreamWaitEvent(st, n22_ev.v[P], 0));
     if (j > 0) {
       rp_gemm_args g{};  // T = N11 L21^T
       g.A = Nb;
