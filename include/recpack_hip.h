@@ -113,6 +113,8 @@ int rphip_ctx_trim(rphip_ctx* ctx);
  *                       in the exact top-Kp; a user whose list cannot prove it (< 0.1 % measured) is served by the one-pass kernel.
  *                       The results are those of the one-pass kernel.  Costs n_items * ld * 2 bytes beside B; skipped (as with 0)
  *                       when that does not fit or Kp > 488.
+ *   "predict_half_tile" columns per tile of that first pass (default 11200, at most 16384; 0 = the model's own tiling).  Tiles of
+ *                       half the LDS let two workgroups share a CU: one streams rows while the other selects.
  *   "gemm_mode"         2 (default) | 1 | 0: how the O(n^3) products of the EASE solve (and rphip_gemm_nt_f32) multiply their fp32 operands.
  *                       2: two fp16 planes per operand, both rounded to nearest (x = h1 + h2 to 2^-24 |x|), three plane products per
  *                          step on v_mfma_f32_32x32x16_f16; each operand is scaled by a power of two taken from its largest magnitude

@@ -84,6 +84,7 @@ struct rphip_ctx {
   // predict options (rphip_ctx_set_option)
   int predict_exact64 = 0;   // 1: the wave predict kernel sums in 64 bits (exact) instead of the per-user-scaled 32 bits
   int predict_half = 1;      // dense models: K9 as two passes (fp16 rows for a candidate list, then exact f32 scores of the candidates)
+  int predict_half_w = 11200;  // columns per tile of that first pass (0: the model's own tiling, one workgroup per CU)
   int pw_wt32 = 4096;        // tile width of the 32-bit sums: 2048 or 4096 (tuning)
   int gemm_mode = 2;         // operands of the solve's products: 0 fp32 MFMA, 1 three bf16 planes (6 products), 2 two fp16 planes (3 products)
   int gemm_supertile = 0;    // 1: GEMM workgroups walk the tiles in XCD-round-robin 8 x 8 supertiles (0: row-major 2-D grid)

@@ -117,9 +117,13 @@ struct rp_score_src {
   const uint8_t* keep;
   int sh;  // leading key bits shared by all candidates (rp_key_prefix, rp_wave.h): the radix digits start below them
   const rp_pred_params* P;
+  float tau;  // DENSE: scores below it are no candidates (a lower bound of the K-th best score, see k_predict_tile; -inf = off)
   __device__ __forceinline__ bool valid(int w) const {
-    const bool nz = DENSE ? ((const float*)acc_)[w] != 0.0f : ((const unsigned long long*)acc_)[w] != 0ull;
-    return nz && (!keep || keep[rp_pred_l2g(*P, t0 + w)] != 0);
+    if (DENSE) {
+      const float v = ((const float*)acc_)[w];
+      return v != 0.0f && v >= tau && (!keep || keep[rp_pred_l2g(*P, t0 + w)] != 0);
+    }
+    return ((const unsigned long long*)acc_)[w] != 0ull && (!keep || keep[rp_pred_l2g(*P, t0 + w)] != 0);
   }
   __device__ __forceinline__ uint64_t key(int w) const {
     if (DENSE) {  // order-preserving map of a float (any sign) to u32, placed in the high half
@@ -136,8 +140,11 @@ typedef _Float16 rp_h8 __attribute__((ext_vector_type(8)));
 
 // HALF (dense models only): the rows are read from the model's fp16 copy - half the bytes of the HBM-bound K9 - and summed in
 // f32: APPROXIMATE scores, good for a candidate list that rp_predict_rescore then scores exactly (see rp_predict_topk_impl).
-template <bool DENSE, bool HALF = false>
-__global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_tile(rp_pred_params P) {
+// HC8 (HALF only): 16-byte column groups per thread.  The default covers RP_TILE_MAX columns with one workgroup per CU (its LDS
+// tile); HC8 = 2 (tiles of at most 16384 columns, half the LDS, at most 64 registers) lets TWO workgroups share a CU: one streams
+// rows while the other selects - with fp16 rows the selection and the per-task start-up are a third of the first pass.
+template <bool DENSE, bool HALF = false, int HC8 = 0>
+__global__ void __launch_bounds__(RP_PRED_THREADS, HC8 == 2 ? 8 : 4) k_predict_tile(rp_pred_params P) {
   static_assert(DENSE || !HALF, "the fp16 first pass is for dense models");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ACC_B = DENSE ? 4 : 8;
@@ -177,36 +184,40 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_tile(rp_pred_params
       // ---- accumulate
       if (HALF) {
         // eight consecutive columns per 16-byte load, four rows in flight
-        constexpr int C8 = (RP_TILE_MAX + 8 * RP_PRED_THREADS - 1) / (8 * RP_PRED_THREADS);
+        constexpr int C8 = HC8 ? HC8 : (RP_TILE_MAX + 8 * RP_PRED_THREADS - 1) / (8 * RP_PRED_THREADS);
         float r[C8][8];
 #pragma unroll
         for (int c = 0; c < C8; ++c)
 #pragma unroll
           for (int e = 0; e < 8; ++e) r[c][e] = 0.0f;
         const int w8 = (n_cols + 7) >> 3;  // (reads past n_cols stay inside the padded row)
+        constexpr int RIF = HC8 == 2 ? 2 : 4;  // rows in flight (two workgroups per CU: half as many each)
         int h = hs;
-        for (; h + 3 < he; h += 4) {
-          const _Float16* R0 = P.dense_B16 + (long long)P.x_idx[h] * P.dense_ld + t0;
-          const _Float16* R1 = P.dense_B16 + (long long)P.x_idx[h + 1] * P.dense_ld + t0;
-          const _Float16* R2 = P.dense_B16 + (long long)P.x_idx[h + 2] * P.dense_ld + t0;
-          const _Float16* R3 = P.dense_B16 + (long long)P.x_idx[h + 3] * P.dense_ld + t0;
-          rp_h8 v0[C8], v1[C8], v2[C8], v3[C8];
+        for (; h + RIF - 1 < he; h += RIF) {
+          const _Float16* R[RIF];
+#pragma unroll
+          for (int q = 0; q < RIF; ++q) R[q] = P.dense_B16 + (long long)P.x_idx[h + q] * P.dense_ld + t0;
+          rp_h8 v[RIF][C8];
 #pragma unroll
           for (int c = 0; c < C8; ++c) {
             const int gq = tid + c * RP_PRED_THREADS;
             if (gq < w8) {
-              v0[c] = *reinterpret_cast<const rp_h8*>(R0 + 8 * gq);
-              v1[c] = *reinterpret_cast<const rp_h8*>(R1 + 8 * gq);
-              v2[c] = *reinterpret_cast<const rp_h8*>(R2 + 8 * gq);
-              v3[c] = *reinterpret_cast<const rp_h8*>(R3 + 8 * gq);
+#pragma unroll
+              for (int q = 0; q < RIF; ++q) v[q][c] = *reinterpret_cast<const rp_h8*>(R[q] + 8 * gq);
             } else {
-              v0[c] = v1[c] = v2[c] = v3[c] = (rp_h8)(_Float16)0.0f;
+#pragma unroll
+              for (int q = 0; q < RIF; ++q) v[q][c] = (rp_h8)(_Float16)0.0f;
             }
           }
 #pragma unroll
           for (int c = 0; c < C8; ++c)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) r[c][e] += ((float)v0[c][e] + (float)v1[c][e]) + ((float)v2[c][e] + (float)v3[c][e]);
+            for (int e = 0; e < 8; ++e) {
+              if (RIF == 4)
+                r[c][e] += ((float)v[0][c][e] + (float)v[1][c][e]) + ((float)v[2 % RIF][c][e] + (float)v[3 % RIF][c][e]);
+              else
+                r[c][e] += (float)v[0][c][e] + (float)v[1][c][e];
+            }
         }
         for (; h < he; ++h) {
           const _Float16* R0 = P.dense_B16 + (long long)P.x_idx[h] * P.dense_ld + t0;
@@ -319,7 +330,39 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_tile(rp_pred_params
         continue;
       }
       // ---- select (top-Kp: the scores of one user share their sign and most exponent bits - dropped first)
-      rp_score_src<DENSE> src{smem, t0, P.mode == 0 ? P.keep : nullptr, 0, &P};
+      rp_score_src<DENSE> src{smem, t0, P.mode == 0 ? P.keep : nullptr, 0, &P, -INFINITY};
+      if (HALF && P.mode == 0 && !P.keep && P.Kp <= 16 * NW) {
+        // A dense tile makes every column a candidate and the selection walks the whole tile once per radix level.  A lower bound
+        // of the Kp-th best score first: every thread's best score, of those the R-th best of each wave (R = ceil(Kp / waves)): the
+        // waves' R best threads are R * waves >= Kp different columns, so the Kp-th best score of the tile is at least the smallest
+        // of these.  Only scores at or above it (a per cent of the tile) enter the candidate list; the selection's result is the same.
+        const int R = (P.Kp + NW - 1) / NW;
+        float m = -INFINITY;
+        for (int w = 8 * tid; w < n_cols; w += 8 * RP_PRED_THREADS) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = (w + e < n_cols) ? accf[w + e] : 0.0f;
+            if (v != 0.0f) m = fmaxf(m, v);
+          }
+        }
+        float rth = -INFINITY;
+        for (int it = 0; it < R; ++it) {
+          float mx = m;
+#pragma unroll
+          for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+          rth = mx;
+          const unsigned long long hit = __ballot(m == mx);
+          if (lane == __ffsll((long long)hit) - 1) m = -INFINITY;
+        }
+        float* s_tau = reinterpret_cast<float*>(&sel.misc[RPS_USER + 8]);
+        if (lane == 0) s_tau[wave] = rth;
+        __syncthreads();
+        float t = s_tau[0];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) t = fminf(t, s_tau[q]);
+        src.tau = t;
+        __syncthreads();
+      }
       if (P.mode == 0) {
         uint32_t* s_red = reinterpret_cast<uint32_t*>(&sel.misc[RPS_USER]);
         if (tid == 0) {
@@ -1700,44 +1743,68 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
     if (mm->B16) {
       const int64_t UCH = 1 << 17;  // users per chunk: bounds the candidate scratch
       const int64_t nchm = std::min<int64_t>(n, UCH);
-      const size_t szT = (T > 1) ? (size_t)nchm * T * Kc : 0, szA = (size_t)nchm * Kc;
+      // the first pass on narrower tiles, two workgroups per CU (k_predict_tile's HC8 = 2)
+      int Th = T, Wh = P.tile_w;
+      if (ctx->predict_half_w > 0) {
+        const int th = (int)rp_cdiv(P.n_items, ctx->predict_half_w);
+        const int wh = (int)(rp_cdiv(rp_cdiv(P.n_items, th), 64) * 64);
+        if (th <= 15 && wh <= 16384 && (size_t)wh * 4 + rp_select_smem_bytes(wh) <= (size_t)78 * 1024) {
+          Th = th;
+          Wh = wh;
+        }
+      }
+      const bool narrow = Th != T || Wh != P.tile_w;
+      const int Tm = std::max(T, Th);
+      const size_t szT = (Tm > 1) ? (size_t)nchm * Tm * Kc : 0, szA = (size_t)nchm * Kc;
       char* sb = nullptr;
-      RP_TRY(rp_scratch(ctx, 14, (szT + szA) * 8 + (size_t)nchm * (T + 2) * 4 + 256, (void**)&sb));
+      RP_TRY(rp_scratch(ctx, 14, (szT + szA) * 8 + (size_t)nchm * (Tm + 2) * 4 + 256, (void**)&sb));
       int32_t* a_idx = (int32_t*)sb;
       float* a_val = (float*)(sb + szA * 4);
       int32_t* t_idx = (int32_t*)(sb + szA * 8);
       float* t_val = (float*)(sb + szA * 8 + szT * 4);
       int32_t* a_nnz = (int32_t*)(sb + (szA + szT) * 8);
       int32_t* t_nnz = a_nnz + nchm;
-      int32_t* fail = t_nnz + nchm * T;
+      int32_t* fail = t_nnz + nchm * Tm;
       int32_t* n_fail = fail + nchm;  // (one word behind the list)
       const size_t lds1 = rp_pred_lds(P);
-      RP_HIP(hipFuncSetAttribute((const void*)k_predict_tile<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+      rp_pred_params Hh = P;
+      Hh.n_tiles = Th;
+      Hh.tile_w = Wh;
+      const size_t ldsh = rp_pred_lds(Hh);
+      if (narrow)
+        RP_HIP(hipFuncSetAttribute((const void*)k_predict_tile<true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh));
+      else
+        RP_HIP(hipFuncSetAttribute((const void*)k_predict_tile<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
       RP_HIP(hipFuncSetAttribute((const void*)k_predict_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-      const size_t mlds_c = (size_t)T * Kc * 8 + rp_select_smem_bytes(T * Kc), mlds_p = (size_t)T * Kp * 8 + rp_select_smem_bytes(T * Kp);
-      if (T > 1) {
-        if (mlds_c > 160 * 1024 || T * Kc >= RPS_FLAG) RP_FAIL(RPHIP_ELIMIT, "Kp=%d with %d column tiles needs %zu bytes of LDS for the merge", Kp, T, mlds_c);
-        RP_HIP(hipFuncSetAttribute((const void*)k_predict_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds_c));
+      const size_t mlds_c = (size_t)Th * Kc * 8 + rp_select_smem_bytes(Th * Kc), mlds_p = (size_t)T * Kp * 8 + rp_select_smem_bytes(T * Kp);
+      if (Tm > 1) {
+        if (std::max(mlds_c, mlds_p) > 160 * 1024 || Tm * Kc >= RPS_FLAG)
+          RP_FAIL(RPHIP_ELIMIT, "Kp=%d with %d column tiles needs %zu bytes of LDS for the merge", Kp, Tm, std::max(mlds_c, mlds_p));
+        RP_HIP(hipFuncSetAttribute((const void*)k_predict_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(mlds_c, mlds_p)));
       }
       for (int64_t c0 = 0; c0 < n; c0 += UCH) {
         const int64_t nch = std::min<int64_t>(UCH, n - c0);
         const int grid = (int)std::min<int64_t>(nch * T, (int64_t)ctx->n_cu * 8), mgrid = (int)std::min<int64_t>(nch, (int64_t)ctx->n_cu * 8);
+        const int gridh = (int)std::min<int64_t>(nch * Th, (int64_t)ctx->n_cu * 16);
         // first pass: approximate top-Kc from the fp16 rows
-        rp_pred_params H = P;
+        rp_pred_params H = Hh;
         H.user_begin = (int)(user_begin + c0);
         H.n_users = (int)nch;
         H.Kp = Kc;
         H.dense_B16 = mm->B16;
         H.b16_inv = 1.0f / mm->b16_scale;
         hipMemsetAsync(a_nnz, 0, (size_t)nch * 4, st);
-        if (T > 1) hipMemsetAsync(t_nnz, 0, (size_t)nch * T * 4, st);
+        if (Th > 1) hipMemsetAsync(t_nnz, 0, (size_t)nch * Th * 4, st);
         hipMemsetAsync(n_fail, 0, 4, st);
-        H.out_idx = T > 1 ? t_idx : a_idx;
-        H.out_val = T > 1 ? t_val : a_val;
-        H.out_nnz = T > 1 ? t_nnz : a_nnz;
-        hipLaunchKernelGGL((k_predict_tile<true, true>), dim3(grid), dim3(RP_PRED_THREADS), lds1, st, H);
-        if (T > 1)
-          hipLaunchKernelGGL(k_predict_merge, dim3(mgrid), dim3(RP_PRED_THREADS), mlds_c, st, t_idx, t_val, t_nnz, T, Kc, (int)nch, nullptr, nullptr, a_idx,
+        H.out_idx = Th > 1 ? t_idx : a_idx;
+        H.out_val = Th > 1 ? t_val : a_val;
+        H.out_nnz = Th > 1 ? t_nnz : a_nnz;
+        if (narrow)
+          hipLaunchKernelGGL((k_predict_tile<true, true, 2>), dim3(gridh), dim3(RP_PRED_THREADS), ldsh, st, H);
+        else
+          hipLaunchKernelGGL((k_predict_tile<true, true>), dim3(grid), dim3(RP_PRED_THREADS), lds1, st, H);
+        if (Th > 1)
+          hipLaunchKernelGGL(k_predict_merge, dim3(mgrid), dim3(RP_PRED_THREADS), mlds_c, st, t_idx, t_val, t_nnz, Th, Kc, (int)nch, nullptr, nullptr, a_idx,
                              a_val, a_nnz, 0);
         // second pass: exact scores of the candidates, their top-Kp, the proof; users without one go to `fail`
         rp_rescore_params R;

@@ -481,5 +481,15 @@ def test_predict_two_pass_equals_one_pass(hip):
         both(m, 100, True)
         T = rng.choice(np.array([0.0, 0.25, -0.25, 0.5, 1.0], dtype=np.float32), size=(2600, 2600), p=[0.5, 0.2, 0.1, 0.15, 0.05])
         both(_lib.Model.from_dense_host(ctx, T), 100, True)
+        # tiles wide enough that every thread of the first pass owns columns: the pre-filter of the selection (a lower bound of
+        # the Kc-th score from the threads' best scores) is active; and the narrow-tile instance (two workgroups per CU)
+        X2 = powerlaw_csr(3000, 9000, 0.004, seed=92).to_scipy()
+        dX = _lib.DeviceCSR.from_host(ctx, X2.indptr, X2.indices, X2.shape)
+        m2 = _lib.ease_fit(ctx, dX, 30.0, 0.0)
+        for tile in (0, 8960, 11200):
+            ctx.set_option("predict_half_tile", tile)
+            assert (both(m2, 100, True) > 0).any()
+            both(m2, 20, False)
     finally:
         ctx.set_option("predict_half", 1)
+        ctx.set_option("predict_half_tile", 11200)

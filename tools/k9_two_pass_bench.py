@@ -16,6 +16,8 @@ dev = torch.device("cuda", 0)
 U, I, _ = CONFIGS[cfg]
 ip, ix = config_csr(cfg, device=dev)
 ctx = _lib.Context(0)
+if os.environ.get("RP_HALF_TILE"):
+    ctx.set_option("predict_half_tile", int(os.environ["RP_HALF_TILE"]))
 dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
 m = _lib.ease_fit(ctx, dX, 200.0, 0.0)
 ctx.sync()
