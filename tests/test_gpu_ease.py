@@ -242,6 +242,61 @@ def test_ease_vs_float64_inverse_8k_16k(hip, n_items, n_users, dens):
     ctx.trim()
 
 
+def test_potrf_trtri_block(hip):
+    """The 128 x 128 diagonal block kernel of the blocked Cholesky (float64 factor + inverse in LDS, blocked in 16 columns)
+    against numpy float64 for condition numbers up to 1e5; the upper triangles are zero; a non-positive pivot is reported."""
+    import torch
+
+    _lib, ctx = hip
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    W = torch.zeros(128, 128, device=dev)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    for cond in (1e1, 1e3, 1e5):
+        Q, _ = np.linalg.qr(rng.standard_normal((128, 128)))
+        S = (Q * np.logspace(0, np.log10(cond), 128)) @ Q.T
+        S = ((S + S.T) / 2).astype(np.float32)
+        A = torch.tensor(S, device=dev)
+        _lib.potrf_trtri_128(ctx, A, W, info)
+        torch.cuda.synchronize()
+        L = np.linalg.cholesky(S.astype(np.float64))
+        Wr = np.linalg.inv(L)
+        assert rel_max(A.cpu().numpy(), L) < 2e-7
+        assert rel_max(W.cpu().numpy(), Wr) < 2e-7
+        assert np.triu(A.cpu().numpy(), 1).max() == 0.0 and np.triu(W.cpu().numpy(), 1).max() == 0.0
+        assert int(info.item()) == 0
+    S = np.eye(128, dtype=np.float32)
+    S[40, 40] = -1.0
+    _lib.potrf_trtri_128(ctx, torch.tensor(S, device=dev), W, info)
+    torch.cuda.synchronize()
+    assert int(info.item()) == 41
+
+
+def test_ease_solve_driver_options(hip):
+    """The solve driver's switches give the same B (to the rounding of the plane products): the inverse's plane cache off / whole /
+    a prefix of the panels (a byte limit: the products then come in a cached and a freshly cut part), the Cholesky's sub-panels
+    off / 8 / 4 tiles.  (The absolute accuracy of the default is what the float64 tests above and the full-size tests measure.)"""
+    from recpack_amd.synth import powerlaw_csr
+
+    _lib, ctx = hip
+    X = powerlaw_csr(40000, 9000, 0.004, seed=7).to_scipy()
+    dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
+    try:
+        ref = _lib.ease_fit(ctx, dX, 50.0, 0.0).dense_download()
+        assert np.isfinite(ref).all()
+        for opt, values, back in (("gemm_plane_cache", (0, 4 * 4096 * 4096 + (64 << 20)), 1), ("chol_sub_panel", (0, 4), 8)):
+            for v in values:
+                ctx.set_option(opt, v)
+                try:
+                    B = _lib.ease_fit(ctx, dX, 50.0, 0.0).dense_download()
+                finally:
+                    ctx.set_option(opt, back)
+                assert rel_max(B, ref) <= 2e-5, (opt, v, rel_max(B, ref))
+    finally:
+        dX.close()
+        ctx.trim()
+
+
 def test_ease_edge_cases(hip):
     _lib, ctx = hip
     from recpack_amd import EASE
