@@ -1260,7 +1260,7 @@ constexpr int DS = GT + 1;  // LDS row stride in doubles
 // with 2 barriers each.  40 barriers of 8 waves.
 constexpr int PB = 16;                                    // block width inside the diagonal block
 constexpr int PSTG = GT + 1;                              // row stride of the staging rows
-constexpr size_t RP_POTRF_LDS = ((size_t)GT * DS + (size_t)PB * PSTG + (size_t)PB * (PB + 1)) * sizeof(double);
+constexpr size_t RP_POTRF_LDS = ((size_t)GT * DS + (size_t)PB * PSTG + (size_t)PB * (PB + 1) + PB) * sizeof(double);
 constexpr int RP_POTRF_THREADS = 512;
 
 __global__ void __launch_bounds__(RP_POTRF_THREADS) k_potrf_trtri(float* __restrict__ A, long long lda, float* __restrict__ W, int* __restrict__ info) {
@@ -1268,6 +1268,7 @@ __global__ void __launch_bounds__(RP_POTRF_THREADS) k_potrf_trtri(float* __restr
   double* a = reinterpret_cast<double*>(smem_raw);  // [128][DS]
   double* stg = a + GT * DS;                         // [PB][PSTG]
   double* wii = stg + PB * PSTG;                     // [PB][PB + 1]
+  double* rdg = wii + PB * (PB + 1);                 // [PB]: reciprocals of the current block's diagonal
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NT = RP_POTRF_THREADS;
   for (int e = tid; e < GT * GT; e += NT) {
@@ -1286,8 +1287,9 @@ __global__ void __launch_bounds__(RP_POTRF_THREADS) k_potrf_trtri(float* __restr
       for (int j = 0; j < PB; ++j) {
         const double d = __shfl(x[j], j);
         if (lane == 0 && !(d > 0.0)) atomicExch(info, c0 + j + 1);
-        const double djj = sqrt(d > 0.0 ? d : 1.0);
-        x[j] = (r == j) ? djj : x[j] / djj;
+        const double djj = sqrt(d > 0.0 ? d : 1.0), rj = 1.0 / djj;
+        if (lane == 0) rdg[j] = rj;
+        x[j] = (r == j) ? djj : x[j] * rj;
 #pragma unroll
         for (int c = j + 1; c < PB; ++c) {
           const double lcj = __shfl(x[j], c);
@@ -1312,7 +1314,7 @@ __global__ void __launch_bounds__(RP_POTRF_THREADS) k_potrf_trtri(float* __restr
         double t = x[k];
 #pragma unroll
         for (int m = 0; m < k; ++m) t -= x[m] * a[(c0 + k) * DS + c0 + m];
-        x[k] = t / a[(c0 + k) * DS + c0 + k];
+        x[k] = t * rdg[k];
       }
 #pragma unroll
       for (int k = 0; k < PB; ++k) a[row * DS + c0 + k] = x[k];
@@ -1360,13 +1362,14 @@ __global__ void __launch_bounds__(RP_POTRF_THREADS) k_potrf_trtri(float* __restr
   for (int r0 = 0; r0 < GT; r0 += PB) {
     if (wave == 0) {  // W_II: lane c computes column c of the inverse of the 16 x 16 triangle by forward substitution
       const int c = lane & (PB - 1);
+      const double rc = 1.0 / a[(r0 + c) * DS + r0 + c];  // lane c: 1 / l_cc; row r's comes by shuffle
       double w[PB];
 #pragma unroll
       for (int r = 0; r < PB; ++r) {
         double t = (r == c) ? 1.0 : 0.0;
 #pragma unroll
         for (int m = 0; m < r; ++m) t -= a[(r0 + r) * DS + r0 + m] * w[m];
-        w[r] = (r >= c) ? t / a[(r0 + r) * DS + r0 + r] : 0.0;
+        w[r] = (r >= c) ? t * __shfl(rc, r) : 0.0;
       }
       if (lane < PB) {
 #pragma unroll
@@ -1607,7 +1610,8 @@ int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st, float* par
     h.part = part;
     h.k_chunk = (int)(rp_cdiv(rp_cdiv(klen, S), GBK) * GBK);
   }
-  if (ctx->gemm_mode == 2) {
+  const int mode = g.f32 ? 0 : ctx->gemm_mode;  // (g.f32: a short product of a launch-bound chain - one launch, no measuring pass)
+  if (mode == 2) {
     // the operands' largest magnitudes over what this launch reads -> a slot of the context's ring (launches on different streams
     // overlap: each gets its own two words)
     if (!ctx->gemm_amax_ring) {
@@ -1678,7 +1682,7 @@ int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st, float* par
       return RPHIP_OK;
     }
     hipLaunchKernelGGL(k_gemm_nt_h2, grid, dim3(256), 0, st, h);
-  } else if (ctx->gemm_mode == 1) {
+  } else if (mode == 1) {
     hipLaunchKernelGGL(k_gemm_nt_b3, grid, dim3(256), 0, st, h);
   } else {
     hipLaunchKernelGGL(k_gemm_nt, grid, dim3(256), 0, st, h);
@@ -1848,6 +1852,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
       h.k1 = GT;
       h.alpha = 1.0f;
       h.beta = 0.0f;
+      h.f32 = 1;  // (K = 128 on the per-block chain: the fp32 MFMA kernel in ONE launch instead of memset + amax + plane kernel)
       rc = rp_gemm_nt(ctx, h, st);
       if (rc != RPHIP_OK) break;
       const int r1 = r0 + GT;

@@ -47,6 +47,7 @@ struct rp_gemm_args {
   int ws_slot;       // scratch slots ws_slot, ws_slot + 1 hold this product's plane workspaces (0: 8 / 9 on the context's stream, 10 / 11 elsewhere)
   const rp_plane_cache* ca;  // A's planes are read from this cache (A unused; M and k1 <= ca->K; the wide product kernel only)
   int cb;            // ... and B's as well (B is the same matrix)
+  int f32;           // this product on the fp32 MFMA kernel (k_gemm_nt) whatever the context's gemm_mode
 };
 
 // C = alpha * A * B^T + beta * C on `st` (the context's stream when NULL)
