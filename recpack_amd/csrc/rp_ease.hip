@@ -192,6 +192,22 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(rp_gemm_args g) {
     }
   }
   // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  // (C's old values all at once, then arithmetic and stores: see k_gemm_hp16w's epilogue)
+  const bool rmw = !g.part && g.beta != 0.0f;
+  f32x16 cold[2][2];
+  if (rmw) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = (g.tri == 3 ? 0 : n0) + wc * 64 + j * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          cold[i][j][r] = g.C[(long long)row * g.ldc + col];
+        }
+      }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -214,9 +230,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(rp_gemm_args g) {
         if (g.part) {
           g.part[((long long)blockIdx.z * g.M + row) * g.N + col] = h + l;
         } else {
-          float* cp = g.C + (long long)row * g.ldc + col;
-          float v = (g.beta != 0.0f) ? fmaf(g.alpha, h, g.beta * (*cp)) : g.alpha * h;
-          *cp = fmaf(g.alpha, l, v);
+          const float v = rmw ? fmaf(g.alpha, h, g.beta * cold[i][j][r]) : g.alpha * h;
+          g.C[(long long)row * g.ldc + col] = fmaf(g.alpha, l, v);
         }
       }
     }
@@ -385,6 +400,21 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_b3(rp_gemm_args g) {
     }
   }
   flush();  // the last piece
+  // (C's old values all at once, into the dead accumulators, then arithmetic and stores: see k_gemm_hp16w's epilogue)
+  const bool rmw = !g.part && g.beta != 0.0f;
+  if (rmw) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = (g.tri == 3 ? 0 : n0) + wc * 64 + j * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          acc[i][j][r] = g.C[(long long)row * g.ldc + col];
+        }
+      }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -399,9 +429,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_b3(rp_gemm_args g) {
         if (g.part) {
           g.part[((long long)blockIdx.z * g.M + row) * g.N + col] = h + l;
         } else {
-          float* cp = g.C + (long long)row * g.ldc + col;
-          float v = (g.beta != 0.0f) ? fmaf(g.alpha, h, g.beta * (*cp)) : g.alpha * h;
-          *cp = fmaf(g.alpha, l, v);
+          const float v = rmw ? fmaf(g.alpha, h, g.beta * acc[i][j][r]) : g.alpha * h;
+          g.C[(long long)row * g.ldc + col] = fmaf(g.alpha, l, v);
         }
       }
     }
@@ -602,6 +631,21 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_h2(rp_gemm_args g) {
     }
   }
   flush();  // the last piece
+  // (C's old values all at once, into the dead accumulators, then arithmetic and stores: see k_gemm_hp16w's epilogue)
+  const bool rmw = !g.part && g.beta != 0.0f;
+  if (rmw) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = (g.tri == 3 ? 0 : n0) + wc * 64 + j * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          acc[i][j][r] = g.C[(long long)row * g.ldc + col];
+        }
+      }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -616,9 +660,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_h2(rp_gemm_args g) {
         if (g.part) {
           g.part[((long long)blockIdx.z * g.M + row) * g.N + col] = h + l;
         } else {
-          float* cp = g.C + (long long)row * g.ldc + col;
-          float v = (g.beta != 0.0f) ? fmaf(g.alpha, h, g.beta * (*cp)) : g.alpha * h;
-          *cp = fmaf(g.alpha, l, v);
+          const float v = rmw ? fmaf(g.alpha, h, g.beta * acc[i][j][r]) : g.alpha * h;
+          g.C[(long long)row * g.ldc + col] = fmaf(g.alpha, l, v);
         }
       }
     }
@@ -810,7 +853,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_hp(rp_hp_args q) {
         const uint32_t pk = lo[i][j][r >> 1];
         const float h = hi[i][j][r];
         const float l = (r & 1) ? __uint_as_float(pk & 0xffff0000u) : __uint_as_float(pk << 16);
-        float* cp = g.C + (long long)row * g.ldc + col;
+        float* cp = g.C + (long long)row * g.ldc + col;  // (one pass: the two-phase form of k_gemm_hp16w's epilogue spills here)
         float v = (g.beta != 0.0f) ? fmaf(g.alpha, h, g.beta * (*cp)) : g.alpha * h;
         *cp = fmaf(g.alpha, l, v);
       }
@@ -926,22 +969,34 @@ __global__ void __launch_bounds__(256, 2) k_gemm_hp16(rp_hp_args q) {
     }
   }
   flush();
+  // (C's old values all at once, into the dead accumulators, then arithmetic and stores: see k_gemm_hp16w's epilogue)
+  float* const c0p = g.C + (long long)(m0 + wr * 64 + 4 * (lane >> 4)) * g.ldc + n0 + wc * 64 + (lane & 15);
+  if (g.beta != 0.0f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = c0p[(long long)(i * 16 + r) * g.ldc + j * 16];
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = n0 + wc * 64 + j * 16 + (lane & 15);
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wr * 64 + i * 16 + 4 * (lane >> 4) + r;
         const uint32_t pk = lo[i][j][r >> 1];
         const float h = hi[i][j][r];
         const float l = (r & 1) ? __uint_as_float(pk & 0xffff0000u) : __uint_as_float(pk << 16);
-        float* cp = g.C + (long long)row * g.ldc + col;
-        float v = (g.beta != 0.0f) ? fmaf(g.alpha, h, g.beta * (*cp)) : g.alpha * h;
-        *cp = fmaf(g.alpha, l, v);
+        const float v = (g.beta != 0.0f) ? fmaf(g.alpha, h, g.beta * acc[i][j][r]) : g.alpha * h;
+        acc[i][j][r] = fmaf(g.alpha, l, v);
       }
-    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c0p[(long long)(i * 16 + r) * g.ldc + j * 16] = acc[i][j][r];
 }
 
 // The same product on 256 x 128 tiles with THREE LDS stages and counted waits (round 3).  PMC on k_gemm_hp16 showed the matrix pipe
@@ -1199,22 +1254,38 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
   }
   if (!mine) return;
   if (!fresh) flush();
+  // C in two phases: ALL of the tile's old values first (into the accumulators' registers, free now), then the arithmetic and the
+  // stores.  One loop (load, fma, store per element) made every load wait for the store before it - the compiler cannot know that
+  // the 64 addresses differ - i.e. 64 memory round trips in a row per thread: ~30 us per tile with nothing else on the CU, a fixed
+  // 1.0 ms per launch at 16384^2 (tools/gemm_k_sweep.py) that cost a product with K = 2048 a fifth of its rate.
+  float* const c0p = g.C + (long long)(m0 + wr * 64 + 4 * (lane >> 4)) * g.ldc + n0 + wc * 64 + (lane & 15);
+  if (g.beta != 0.0f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = c0p[(long long)(i * 16 + r) * g.ldc + j * 16];
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int col = n0 + wc * 64 + j * 16 + (lane & 15);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wr * 64 + i * 16 + 4 * (lane >> 4) + r;
         const uint32_t pk = lo[i][j][r >> 1];
         const float h = hi[i][j][r];
         const float l = (r & 1) ? __uint_as_float(pk & 0xffff0000u) : __uint_as_float(pk << 16);
-        float* cp = g.C + (long long)row * g.ldc + col;
-        float v = (g.beta != 0.0f) ? fmaf(g.alpha, h, g.beta * (*cp)) : g.alpha * h;
-        *cp = fmaf(g.alpha, l, v);
+        const float v = (g.beta != 0.0f) ? fmaf(g.alpha, h, g.beta * acc[i][j][r]) : g.alpha * h;
+        acc[i][j][r] = fmaf(g.alpha, l, v);
       }
     }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c0p[(long long)(i * 16 + r) * g.ldc + j * 16] = acc[i][j][r];
 }
 
 // C = beta * C + alpha * sum_s part[s]  (fixed order of the partial sums: deterministic)
