@@ -1491,11 +1491,19 @@ __global__ void __launch_bounds__(256) k_mirror_lower(float* __restrict__ P, lon
 
 // ---- small helpers -------------------------------------------------------------------------------------------
 // G = 0 everywhere, diag = lambda (real items) or 1 (padding)
+// (a workgroup per row, 16-byte stores: the element-per-thread form with its 64-bit division per element wrote 40 GB in 17 ms)
 __global__ void k_ease_init(float* __restrict__ G, long long ld, int n, int n_pad, float lam) {
-  const long long total = (long long)n_pad * ld;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    const long long i = e / ld, j = e % ld;
-    G[e] = (i == j) ? (i < n ? lam : 1.0f) : 0.0f;
+  for (long long i = blockIdx.x; i < n_pad; i += gridDim.x) {
+    float* row = G + i * ld;
+    const float d = i < n ? lam : 1.0f;
+    for (long long j = 4LL * threadIdx.x; j < ld; j += 4LL * blockDim.x) {  // (ld is a multiple of 4)
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i == j) v.x = d;
+      if (i == j + 1) v.y = d;
+      if (i == j + 2) v.z = d;
+      if (i == j + 3) v.w = d;
+      *reinterpret_cast<float4*>(row + j) = v;
+    }
   }
 }
 
@@ -1545,19 +1553,20 @@ __global__ void k_ease_diag(const float* __restrict__ P, long long ld, int n, co
 }
 
 // K7: B_ij = P_ij * colscale_j (= -P_ij / P_jj * w_j), B_ii = 0; in place
+// (a workgroup per row: no division per element, the column factors as 16-byte loads; colscale holds ld entries)
 __global__ void k_ease_scale(float* __restrict__ P, long long ld, int n, const float* __restrict__ colscale) {
-  const long long total = (long long)n * ld;
-  for (long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; e < total; e += (long long)gridDim.x * blockDim.x * 4) {
-    const long long i = e / ld;
-    const int j = (int)(e % ld);  // ld is a multiple of 4
-    float4 v = *reinterpret_cast<float4*>(P + e);
-    float o[4] = {v.x, v.y, v.z, v.w};
+  for (long long i = blockIdx.x; i < n; i += gridDim.x) {
+    float* row = P + i * ld;
+    for (long long j = 4LL * threadIdx.x; j < ld; j += 4LL * blockDim.x) {  // (ld is a multiple of 4)
+      const float4 v = *reinterpret_cast<const float4*>(row + j);
+      float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int jj = j + c;
-      o[c] = (jj < n && jj != (int)i) ? o[c] * colscale[jj] : 0.0f;
+      for (int c = 0; c < 4; ++c) {
+        const long long jj = j + c;
+        o[c] = (jj < n && jj != i) ? o[c] * colscale[jj] : 0.0f;
+      }
+      *reinterpret_cast<float4*>(row + j) = make_float4(o[0], o[1], o[2], o[3]);
     }
-    *reinterpret_cast<float4*>(P + e) = make_float4(o[0], o[1], o[2], o[3]);
   }
 }
 
