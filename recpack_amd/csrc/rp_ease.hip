@@ -1198,34 +1198,32 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
           a[p][0] = *reinterpret_cast<const f16x8*>(A0 + p * 16 * 1024 + ((wr * 2) * 2) * 1024 + foff);
         }
         }
+        // `fresh` is decided ONCE per step, outside the rows: with the branch inside, every row was a basic block of its own and
+        // the compiler's wait-count pass, merging the two ways in, put s_waitcnt lgkmcnt(0) in front of each row's MFMAs - the
+        // fragment reads issued for the NEXT row were waited for before the current row multiplied (found in the ISA listing)
+        auto rows = [&](auto is_fresh) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (i < 3 && !((RP_GEMM_ABL & 2) && k != kb)) {
+          for (int i = 0; i < 4; ++i) {
+            if (i < 3 && !((RP_GEMM_ABL & 2) && k != kb)) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
-              a[p][(i + 1) & 1] = *reinterpret_cast<const f16x8*>(A0 + p * 16 * 1024 + ((wr * 2 + ((i + 1) >> 1)) * 2) * 1024 + foff + ((i + 1) & 1) * 256);
-          }
-          if (fresh) {
+              for (int p = 0; p < 2; ++p)
+                a[p][(i + 1) & 1] = *reinterpret_cast<const f16x8*>(A0 + p * 16 * 1024 + ((wr * 2 + ((i + 1) >> 1)) * 2) * 1024 + foff + ((i + 1) & 1) * 256);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              f32x4 c = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+              f32x4 c = decltype(is_fresh)::value ? (f32x4){0.0f, 0.0f, 0.0f, 0.0f} : acc[i][j];
               c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1][i & 1], b[0][j], c, 0, 0, 0);
               c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][i & 1], b[1][j], c, 0, 0, 0);
               c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][i & 1], b[0][j], c, 0, 0, 0);
               acc[i][j] = c;
             }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              f32x4 c = acc[i][j];
-              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1][i & 1], b[0][j], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][i & 1], b[1][j], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][i & 1], b[0][j], c, 0, 0, 0);
-              acc[i][j] = c;
-            }
+            __builtin_amdgcn_sched_barrier(0);
           }
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        };
+        if (fresh)
+          rows(std::true_type{});
+        else
+          rows(std::false_type{});
         fresh = false;
         GST(4);
         if (wave >= 4 && !(RP_GEMM_ABL & 1)) issue(st2, kn);
