@@ -142,8 +142,9 @@ int rphip_ctx_trim(rphip_ctx* ctx);
  *                       every panel: 1 = as much as the free memory holds (everything at 100 000 items; a prefix of the panels
  *                       when the matrix itself fills the GPU), a larger value = at most that many bytes, 0 = off.  One scale per
  *                       2048-column chunk of N instead of one per product: a fit with the whole cache, a part of it or none agrees
- *                       to the rounding of the plane products (<= 1e-6 of max |B|), not bit for bit - so the last bits of B depend
- *                       on the memory that was free.
+ *                       to the rounding of the plane products (<= 1e-6 of max |B|), not bit for bit - which is why the cache's
+ *                       size is derived from the device's memory and the matrix, not from what happens to be free (if that much
+ *                       cannot be allocated after all, the solve runs without the cache).
  *   "gemm_supertile"    0 (default) | 1.  Tile order of the GEMM's workgroups: supertiles of 64 tiles handed to the 8 XCDs round-robin
  *                       (each XCD's L2 then holds the 8 + 8 panels of an 8 x 8 block of tiles), or the plain row-major grid
  *                       (measured equal within 1 %: the products are not bound by operand traffic).

@@ -2031,10 +2031,13 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
   rp_plane_cache& pc = cg.pc;
   if (ctx->gemm_plane_cache && st == ctx->stream && ctx->gemm_mode == 2 && ctx->gemm_presplit && ctx->gemm_shape16 && ctx->gemm_wide &&
       !ctx->gemm_supertile && n_pad >= 3 * inv_w) {
-    size_t fr = 0, tot = 0;
-    if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
-      const size_t reserve = std::min<size_t>((size_t)12 << 30, tot / 16);
-      size_t avail = fr + ctx->cached_bytes > reserve ? fr + ctx->cached_bytes - reserve : 0;
+    {
+      // The size is a function of the DEVICE and the matrix, not of what happens to be free: the cached and the freshly cut
+      // products round differently (one scale per chunk against one per product), and B should not depend on the memory other
+      // users hold.  What the device has, less the matrix itself, less an eighth of it (or 24 GiB) for everything else; when that
+      // much cannot be had after all, the allocation below fails and the solve runs without the cache.
+      const size_t tot = ctx->hbm_bytes, mat = (size_t)n_pad * (size_t)ld * 4, reserve = std::max<size_t>((size_t)24 << 30, tot / 8);
+      size_t avail = tot > mat + reserve ? tot - mat - reserve : 0;
       if (ctx->gemm_plane_cache > 1) avail = std::min<size_t>(avail, (size_t)ctx->gemm_plane_cache);
       long long Kc = (long long)std::sqrt((double)avail / 4.0);
       if (Kc >= n_pad)
