@@ -1837,10 +1837,11 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
   // workgroup for 0.26 ms) runs on a side stream while the rest of the panel is updated on the main stream.
   struct side_stream {  // released on every way out of this function
     hipStream_t s = nullptr, t = nullptr;
-    hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr;
+    hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr, f = nullptr;
     ~side_stream() {
       if (s) hipStreamSynchronize(s);
       if (t) hipStreamSynchronize(t);
+      if (f) hipEventDestroy(f);
       if (a) hipEventDestroy(a);
       if (b) hipEventDestroy(b);
       if (c) hipEventDestroy(c);
@@ -1856,7 +1857,9 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
   RP_HIP(hipEventCreateWithFlags(&side.c, hipEventDisableTiming));
   RP_HIP(hipEventCreateWithFlags(&side.d, hipEventDisableTiming));
   hipStream_t s2 = side.s, s3 = side.t;
-  hipEvent_t e_panel = side.a, e_diag = side.b, e_fact = side.c, e_trail = side.d;
+  RP_HIP(hipEventCreateWithFlags(&side.f, hipEventDisableTiming));
+  hipEvent_t e_panel = side.a, e_diag = side.b, e_fact = side.c, e_trail = side.d, e_cols = side.f;
+  bool cols_pending = false;  // the later sub-panels' columns of the current panel are still being updated on s3
   bool trail_pending = false;  // a trailing update is in flight on s3
   // diagnostic (RP_CHOL_TRACE=1): per panel, ms since the start at which the panel was factored and its next-panel update done (main
   // stream) and its rest update done (third stream) - shows where the factorisation is chain-bound and where product-bound
@@ -1952,6 +1955,10 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
         u.alpha = -1.0f;
         u.beta = 1.0f;
         u.no_splitk = 1;
+        if (cols_pending) {  // (these columns took the previous panel's update on the third stream)
+          RP_HIP(hipStreamWaitEvent(st, e_cols, 0));
+          cols_pending = false;
+        }
         rc = rp_gemm_nt(ctx, u, st);
         if (rc != RPHIP_OK) break;
       }
@@ -1971,8 +1978,12 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
         t.ldb = ld;
         t.C = A + (long long)r1 * ld + r1;
         t.ldc = ld;
+        // (of the next panel's columns only its FIRST sub-panel's are needed before its factorisation can start - the chain
+        // that the second half of the factorisation waits for; the others follow on the third stream, in front of the rest,
+        // and the next panel's first sub-panel update waits for them)
+        const int w1 = (SUB < RP_CHOL_PANEL) ? std::min(SUB * GT, wn) : wn;
         t.M = n_pad - r1;
-        t.N = wn;
+        t.N = w1;
         t.k0 = pk0;
         t.k1 = r1;
         t.tri = 1;
@@ -1981,6 +1992,19 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
         rc = rp_gemm_nt(ctx, t, st);
         if (rc != RPHIP_OK) break;
         tr_rec(st);
+        if (w1 < wn) {
+          const int rc1 = r1 + w1;
+          RP_HIP(hipStreamWaitEvent(s3, e_fact, 0));
+          t.A = A + (long long)rc1 * ld;
+          t.B = A + (long long)rc1 * ld;
+          t.C = A + (long long)rc1 * ld + rc1;
+          t.M = n_pad - rc1;
+          t.N = wn - w1;
+          rc = rp_gemm_nt(ctx, t, s3);
+          if (rc != RPHIP_OK) break;
+          RP_HIP(hipEventRecord(e_cols, s3));
+          cols_pending = true;
+        }
         const int r2 = r1 + wn;
         if (r2 < n_pad) {
           RP_HIP(hipStreamWaitEvent(s3, e_fact, 0));
