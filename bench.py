@@ -15,10 +15,11 @@ Default workload: C4 = 1M users x 100K items, 50M interactions - the shape BASEL
 MI355X.  With N > 1 the same matrix is sharded (ItemKNN: item rows for fit, users for predict; EASE: the library's distributed
 solve on block-cyclic column panels, rphip_ease_fit_dist, and the column-sharded predict + merge): strong scaling.
 
-Prints one JSON line (rank 0).  `roofline` prices the HBM-bound kernel with the longest launch (K8) with its algorithmic byte
-model (4*P-model for the SpGEMM instances, 8*K*nnz-model for predict) against 8 TB/s - `legs` holds all three
-ItemKNN kernels, `spgemm_all_kernels` the whole K1-K3 group; `roofline_ease` prices the solve against the dense 16-bit MFMA peak
-(three fp16 plane products per fp32-equivalent product) and states the plain n^3 model beside it; `cpu_baseline` = the
+Prints one JSON line (rank 0).  `roofline` is the dominant kernel's: the EASE solve against the dense 16-bit MFMA peak (three fp16
+plane products per fp32-equivalent product; `frac_n3_model` states the plain n^3 model beside it); `roofline_hbm` prices the HBM-bound
+ItemKNN kernel with the longest launch (K8) with its algorithmic byte model (4*P-model for the SpGEMM instances,
+8*K*nnz-model for predict) against 8 TB/s - its `legs` hold all three ItemKNN kernels, `spgemm_all_kernels` the whole K1-K3 group;
+`k9_predict` prices K9 by the bytes it streams; `cold_first_step_s` is the first step of the fresh context; `cpu_baseline` = the
 reference-shaped route (sklearn cosine + per-row argpartition loop, float64 np.linalg.inv) timed on a bounded sample on the host's
 cores and scaled, with the oracle's own vectorised route under `port`.  `status` is "ok" or names what failed; a failed or
 timed-out run exits non-zero.
@@ -336,10 +337,18 @@ def roofline_ease(tm, I, world, steps, dist_stats, nnz, U, Kp):
         "fp32_equivalent": {"achieved": round(tf, 2), "peak_fp32_mfma": MFMA_F32_PEAK_TFLOPS, "frac_of_fp32_mfma_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 4)},
         "solve_ms_per_step": round(solve_ms, 2), "flop_per_solve": flop,
     }
-    if k9["launches"]:  # K9 beside it: rows of B streamed, 4*I*nnz bytes by the no-reuse model of SURVEY.md 8(d)
+    if k9["launches"]:
+        # K9 beside it.  The kernel streams the fp16 copy of B's rows (2 bytes per column per interaction: pass 1 of the two-pass
+        # predict) and gathers the candidates' f32 entries for the exact rescoring (Kc = 128 columns of 4 bytes per interaction,
+        # a 64-byte line each at worst): `bytes_streamed` / time against the HBM peak is its roofline.  The 4*I*nnz no-reuse model of
+        # SURVEY.md 8(d) prices f32 rows that the kernel no longer reads - kept as `model_bytes_f32_rows` for reference only.
         ms = k9["ms"] / steps
-        by = 4.0 * I * nnz / world + 8.0 * U * Kp
-        out["k9_predict"] = {"ms_per_step": round(ms, 2), "algorithmic_bytes": by, "GBps_no_reuse_model": round(by / (ms * 1e-3) / 1e9, 1),
+        streamed = 2.0 * I * nnz / world + 4.0 * 128 * nnz / world + 8.0 * U * Kp
+        out["k9_predict"] = {"ms_per_step": round(ms, 2), "bytes_streamed": streamed,
+                             "bytes_streamed_what": "2*I*nnz (fp16 rows of B, first pass) + 4*Kc*nnz (candidates' f32 entries, Kc = 128) + 8*U*Kp (output)",
+                             "GBps": round(streamed / (ms * 1e-3) / 1e9, 1),
+                             "frac_of_hbm_peak": round(streamed / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "model_bytes_f32_rows": 4.0 * I * nnz / world + 8.0 * U * Kp,
                              "TFLOPs": round(2.0 * I * nnz / world / (ms * 1e-3) / 1e12, 2)}
     return out
 
@@ -448,13 +457,35 @@ def main():
         e_nnz = torch.empty((U,), dtype=torch.int32, device=device)
     comm = None
     comm_note = None
+    transport = None
     if world > 1:  # the library's communicator: every collective of the step goes through it
-        try:
-            comm = rdist.make_comm(ctx, device, transport=args.ease_transport)
-        except Exception as e:  # noqa: BLE001 - e.g. librccl refuses to initialise: the same solve over torch.distributed's collectives
-            comm_note = f"library RCCL communicator failed ({type(e).__name__}: {e}); collectives through torch.distributed callbacks"
-            sys.stderr.write(f"rank {rank}: {comm_note}\n")
+        # The choice of transport is COLLECTIVE: a rank whose RCCL communicator fails to come up must not fall back alone (the
+        # others would wait in ncclBroadcast for a rank that talks through torch.distributed): every rank reports, and if any
+        # failed they all switch - or, with an explicit --ease-transport rccl, the run stops with a status that says so.
+        want = "rccl" if (args.ease_transport == "rccl" or (args.ease_transport == "auto" and backend == "nccl")) else "torch"
+        err = None
+        if want == "rccl":
+            try:
+                comm = rdist.make_comm(ctx, device, transport="rccl")
+            except Exception as e:  # noqa: BLE001 - e.g. librccl refuses to initialise
+                err = f"{type(e).__name__}: {e}"
+                sys.stderr.write(f"rank {rank}: library RCCL communicator failed ({err})\n")
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                    comm = None
+                comm_note = f"library RCCL communicator failed on some rank ({err or 'another rank'})"
+                if args.ease_transport == "rccl":
+                    if rank == 0:
+                        print(json.dumps({"metric": "fit+predict wall-sec (ItemKNN, EASE) on 1M×100K synth; achieved HBM GB/s", "n_gpus": world,
+                                          "status": "failed: --ease-transport rccl was asked for and " + comm_note, "transport": "none"}), flush=True)
+                    os._exit(5)
+                want = "torch"
+        if comm is None:
             comm = rdist.make_comm(ctx, device, transport="torch")
+        transport = "rccl (library communicator)" if comm.is_rccl else "torch.distributed callbacks" + (f" (FALLBACK: {comm_note})" if comm_note else "")
 
     keep = {}
     parts = {"itemknn": 0.0, "ease_fit": 0.0, "ease_predict": 0.0}
@@ -513,8 +544,15 @@ def main():
     dog.daemon = True
     dog.start()
     try:
-        for _ in range(args.warmup):
+        cold_s = None
+        for w in range(args.warmup):
+            if w == 0:  # the first step of a fresh context: every allocation of the step is a hipMalloc (later steps take cached blocks)
+                torch.cuda.synchronize()
+                tc = time.perf_counter()
             step()
+            if w == 0:
+                torch.cuda.synchronize()
+                cold_s = time.perf_counter() - tc
         barrier()
         ctx.reset_timings()
         state["phase"], state["timing"] = "timed steps", True
@@ -606,6 +644,7 @@ def main():
                 "device": info,
                 "transport_note": comm_note,
             },
+            "transport": transport,  # N > 1: what the collectives of the step ran on (null at N = 1: there are none)
             "phases_ms_per_step": phases,
             "throughput": {
                 "interactions_per_s": round(nnz / sec_per_step, 1),
@@ -637,8 +676,19 @@ def main():
                                        "frac": round(spgemm_bytes / (spgemm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if spgemm_ms > 0 else None},
             },
         })
+        result["cold_first_step_s"] = round(cold_s, 4) if cold_s is not None else None  # (needs --warmup >= 1; `value` is the warm rate)
         if ease_on:
-            result["roofline_ease"] = roofline_ease(tm, I, world, args.steps, _lib.ease_fit_dist_stats(ctx) if world > 1 else None, nnz, U, Kp)
+            # the headline roofline is the DOMINANT kernel's: the EASE solve (two thirds of the step) against the dense 16-bit MFMA peak;
+            # the HBM-bound ItemKNN kernels (K8, the SpGEMM instances) follow under `roofline_hbm`
+            re_ = roofline_ease(tm, I, world, args.steps, _lib.ease_fit_dist_stats(ctx) if world > 1 else None, nnz, U, Kp)
+            hbm = result.pop("roofline")
+            k9 = re_.pop("k9_predict", None)
+            re_["share_of_step"] = round(re_["solve_ms_per_step"] / (sec_per_step * 1e3), 4)
+            re_["traffic"] = None  # (an MFMA-bound kernel: the operand traffic of the solve is in profiles/, not a bound)
+            result["roofline"] = re_
+            result["roofline_hbm"] = hbm
+            if k9:
+                result["k9_predict"] = k9
         if world == 1 and args.cpu_baseline_seconds > 0:
             idx, val, nnz_rows = keep["model"].topk_download()
             from recpack_amd.algorithms import topk_arrays_to_csr
@@ -662,8 +712,7 @@ def main():
         keep.clear()
         if world == 1 and args.ease_config.lower() != "none":
             del out_idx, out_val, out_nnz, e_idx, e_val, e_nnz
-            ctx.trim()
-            torch.cuda.empty_cache()
+            torch.cuda.empty_cache()  # (no ctx.trim(): the legs' smaller matrices are cut from the blocks the step left in the cache)
             for cfg in (c.strip().upper() for c in args.ease_config.split(",")):
                 result[f"ease_{cfg.lower()}"] = ease_leg(args, ctx, device, Kp, cfg, 1 if CONFIGS[cfg][1] > 60000 else 2)
                 torch.cuda.empty_cache()

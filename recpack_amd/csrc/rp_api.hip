@@ -141,31 +141,91 @@ int rp_scratch(rphip_ctx* ctx, int slot, size_t bytes, void** out) {
 // A freed block carries an event recorded on the context's stream at the time of the free: whoever gets the block
 // next waits for it first, so kernels that were still reading the block when its owner was destroyed are done
 // (hipFree would have synchronised the device; the cache must not be weaker than that for host-side copies).
-void rp_dev_trim(rphip_ctx* ctx) {
-  for (auto& b : ctx->free_blocks) {
-    hipFree(b.p);
-    if (b.freed) hipEventDestroy(b.freed);
+static void rp_block_wait(rphip_ctx::block_t& b) {
+  for (hipEvent_t e : b.freed) {
+    hipEventSynchronize(e);
+    hipEventDestroy(e);
   }
-  ctx->free_blocks.clear();
-  ctx->cached_bytes = 0;
+  b.freed.clear();
+}
+
+// join free blocks that touch inside one region
+static void rp_dev_coalesce(rphip_ctx* ctx) {
+  auto& fb = ctx->free_blocks;
+  std::sort(fb.begin(), fb.end(), [](const rphip_ctx::block_t& a, const rphip_ctx::block_t& b) { return a.p < b.p; });
+  size_t o = 0;
+  for (size_t i = 0; i < fb.size(); ++i) {
+    if (o > 0 && fb[o - 1].region == fb[i].region && fb[o - 1].p + fb[o - 1].bytes == fb[i].p) {
+      fb[o - 1].bytes += fb[i].bytes;
+      fb[o - 1].freed.insert(fb[o - 1].freed.end(), fb[i].freed.begin(), fb[i].freed.end());
+    } else {
+      if (o != i) fb[o] = std::move(fb[i]);
+      ++o;
+    }
+  }
+  fb.resize(o);
+}
+
+// release every cached block that is a whole region (a block whose region still has a live part stays cached)
+void rp_dev_trim(rphip_ctx* ctx) {
+  rp_dev_coalesce(ctx);
+  auto& fb = ctx->free_blocks;
+  size_t o = 0;
+  for (size_t i = 0; i < fb.size(); ++i) {
+    if (fb[i].p == fb[i].region && fb[i].bytes == fb[i].region_bytes) {
+      for (hipEvent_t e : fb[i].freed) hipEventDestroy(e);  // (hipFree waits for the device)
+      hipFree(fb[i].p);
+      ctx->cached_bytes -= fb[i].bytes;
+    } else {
+      if (o != i) fb[o] = std::move(fb[i]);
+      ++o;
+    }
+  }
+  fb.resize(o);
+}
+
+// how many of `n` requests of `bytes` the cache would serve without going to the driver (the rule of rp_dev_alloc, on a copy)
+int rp_dev_cache_serves(rphip_ctx* ctx, size_t bytes, int n) {
+  const size_t want = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+  rp_dev_coalesce(ctx);
+  std::vector<size_t> have;
+  for (auto& b : ctx->free_blocks) have.push_back(b.bytes);
+  int served = 0;
+  for (int r = 0; r < n; ++r) {
+    size_t best = (size_t)-1;
+    for (size_t i = 0; i < have.size(); ++i)
+      if (have[i] >= want && want >= have[i] / 16 && (best == (size_t)-1 || have[i] < have[best])) best = i;
+    if (best == (size_t)-1) break;
+    have[best] -= want;
+    ++served;
+  }
+  return served;
 }
 
 int rp_dev_alloc(rphip_ctx* ctx, size_t bytes, void** out) {
   *out = nullptr;
   const size_t want = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
-  for (size_t i = 0; i < ctx->free_blocks.size(); ++i) {
-    if (ctx->free_blocks[i].bytes == want) {
-      rphip_ctx::block_t b = ctx->free_blocks[i];
-      ctx->free_blocks.erase(ctx->free_blocks.begin() + i);
-      ctx->cached_bytes -= want;
-      if (b.freed) {
-        hipEventSynchronize(b.freed);
-        hipEventDestroy(b.freed);
+  for (int pass = 0; pass < 2; ++pass) {
+    size_t best = (size_t)-1;
+    for (size_t i = 0; i < ctx->free_blocks.size(); ++i) {
+      const size_t have = ctx->free_blocks[i].bytes;
+      if (have >= want && want >= have / 16 && (best == (size_t)-1 || have < ctx->free_blocks[best].bytes)) best = i;
+    }
+    if (best != (size_t)-1) {
+      rphip_ctx::block_t b = std::move(ctx->free_blocks[best]);
+      rp_block_wait(b);
+      if (b.bytes > want) {  // the rest stays cached (nothing pending on it any more)
+        ctx->free_blocks[best] = rphip_ctx::block_t{b.p + want, b.bytes - want, b.region, b.region_bytes, {}};
+      } else {
+        ctx->free_blocks.erase(ctx->free_blocks.begin() + best);
       }
-      ctx->live_blocks[b.p] = want;
+      ctx->cached_bytes -= want;
+      ctx->live_blocks[b.p] = rphip_ctx::live_t{want, b.region, b.region_bytes};
       *out = b.p;
       return RPHIP_OK;
     }
+    if (pass == 0 && ctx->free_blocks.size() > 1) rp_dev_coalesce(ctx);  // joined neighbours may fit
+    else break;
   }
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, want);
@@ -178,7 +238,7 @@ int rp_dev_alloc(rphip_ctx* ctx, size_t bytes, void** out) {
     (void)hipGetLastError();
     RP_FAIL(RPHIP_ENOMEM, "hipMalloc of %zu bytes failed: %s", want, hipGetErrorString(e));
   }
-  ctx->live_blocks[p] = want;
+  ctx->live_blocks[p] = rphip_ctx::live_t{want, (char*)p, want};
   *out = p;
   return RPHIP_OK;
 }
@@ -190,21 +250,37 @@ void rp_dev_free(rphip_ctx* ctx, void* p) {
     hipFree(p);
     return;
   }
-  const size_t bytes = it->second;
+  const rphip_ctx::live_t lv = it->second;
   ctx->live_blocks.erase(it);
-  if (ctx->cached_bytes + bytes > ctx->cache_limit) {
+  const bool whole = (char*)p == lv.region && lv.bytes == lv.region_bytes;
+  if (whole && ctx->cached_bytes + lv.bytes > ctx->cache_limit) {
     hipFree(p);
     return;
   }
-  rphip_ctx::block_t b{p, bytes, nullptr};
-  if (hipEventCreateWithFlags(&b.freed, hipEventDisableTiming) == hipSuccess) {
-    hipEventRecord(b.freed, ctx->stream);
+  rphip_ctx::block_t b{(char*)p, lv.bytes, lv.region, lv.region_bytes, {}};
+  hipEvent_t ev = nullptr;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+    hipEventRecord(ev, ctx->stream);
+    b.freed.push_back(ev);
   } else {
-    b.freed = nullptr;
     hipStreamSynchronize(ctx->stream);
   }
-  ctx->free_blocks.push_back(b);
-  ctx->cached_bytes += bytes;
+  ctx->free_blocks.push_back(std::move(b));
+  ctx->cached_bytes += lv.bytes;
+  if (!whole) {  // a part of a split region: join it with its neighbours; a region that is whole again obeys the limit
+    rp_dev_coalesce(ctx);
+    if (ctx->cached_bytes > ctx->cache_limit) {
+      auto& fb = ctx->free_blocks;
+      for (size_t i = 0; i < fb.size(); ++i)
+        if (fb[i].region == lv.region && fb[i].p == fb[i].region && fb[i].bytes == fb[i].region_bytes) {
+          for (hipEvent_t e : fb[i].freed) hipEventDestroy(e);
+          hipFree(fb[i].p);
+          ctx->cached_bytes -= fb[i].bytes;
+          fb.erase(fb.begin() + i);
+          break;
+        }
+    }
+  }
 }
 
 extern "C" int rphip_ctx_trim(rphip_ctx* ctx) {

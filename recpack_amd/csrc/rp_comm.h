@@ -9,3 +9,4 @@ int rp_comm_broadcast(rphip_comm* c, void* buf, int64_t bytes, int root, hipStre
 int rp_comm_all_gather(rphip_comm* c, const void* send, void* recv, int64_t bytes_per_rank, hipStream_t st);
 int rp_comm_exchange(rphip_comm* c, const void* send, const int64_t* soff, const int64_t* sbytes, void* recv, const int64_t* roff,
                      const int64_t* rbytes, hipStream_t st);
+int rp_comm_all_reduce_sum_i32(rphip_comm* c, int32_t* buf, int64_t count, hipStream_t st);

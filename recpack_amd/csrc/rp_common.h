@@ -48,6 +48,11 @@ void rp_set_error(const char* fmt, ...);
 constexpr int RP_WAVE = 64;
 constexpr int RP_FIT_THREADS = 1024;      // 16 waves, one workgroup per CU (LDS-bound)
 constexpr int RP_TILE_MAX = 25600;        // accumulator columns per LDS tile (100 KiB of u32/f32 + 50 KiB candidate list)
+#ifndef RP_BUILD_XP
+#define RP_BUILD_XP 0  // K0 builds the packed user rows (xp): only the experimental lane-group accumulate loop (RP_FIT_GROUPS) reads them
+#endif
+constexpr int RP_DUMP = 256;              // dump columns behind a tile's own: where the padding entries of the packed user rows (xp) add
+constexpr int RP_TILE_COLS = RP_TILE_MAX - RP_DUMP;  // widest column tile K0 plans
 constexpr int RP_SORT_CAP = 512;          // entries of the in-LDS exact sort (6 KiB, overlays the histogram)
 constexpr int RP_HIST_BINS = 2048;        // radix-select digit: 11 bits
 constexpr int RP_K_MAX = 2048;            // largest effective K / Kp of one call
@@ -74,11 +79,15 @@ struct rphip_ctx {
   struct pending_t { hipEvent_t a, b; int slot; };
   std::vector<pending_t> pending;
   std::vector<hipEvent_t> ev_pool;
-  // device allocations of models / matrices: freed blocks are kept (up to cache_limit bytes) and handed out again for a
-  // request of the same size - a fit in a loop allocates nothing after its first pass (rp_dev_alloc / rp_dev_free)
-  struct block_t { void* p; size_t bytes; hipEvent_t freed; };
+  // device allocations of models / matrices: freed blocks are kept (up to cache_limit bytes) and handed out again
+  // - a fit in a loop allocates nothing after its first pass (rp_dev_alloc / rp_dev_free)
+  // (round 4) a cached block also serves SMALLER requests: best fit, split when the request is at least 1/16 of the block (the rest
+  // stays cached; small requests never carve up a large block), neighbours of one hipMalloc region are joined again when freed;
+  // only whole regions go back to the driver
+  struct block_t { char* p; size_t bytes; char* region; size_t region_bytes; std::vector<hipEvent_t> freed; };
+  struct live_t { size_t bytes; char* region; size_t region_bytes; };
   std::vector<block_t> free_blocks;
-  std::unordered_map<void*, size_t> live_blocks;
+  std::unordered_map<void*, live_t> live_blocks;
   size_t cached_bytes = 0;
   size_t cache_limit = (size_t)1 << 62;  // set to half of the device's memory by rphip_ctx_create
   // predict options (rphip_ctx_set_option)
@@ -96,6 +105,7 @@ struct rphip_ctx {
   int64_t gemm_plane_cache = 1;  // the inverse keeps the planes of N = L^-T between its panels: 0 off, 1 as much as fits, > 1 at most that many bytes
   unsigned* gemm_amax_ring = nullptr;  // mode 2: [RP_AMAX_SLOTS][2] words, the operands' largest magnitudes per launch
   unsigned long long gemm_amax_seq = 0;
+  int64_t dist_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // rphip_ease_fit_dist's last run on this context (rphip_ease_fit_dist_stats)
   int gemm_kc = 1024;        // K steps between two flushes of the MFMA accumulators into the compensated master sums (round 3: 1024;
                              // certified column error at C3 / C4, lambda 10 and 200: 512: <= 7.4e-6, 1024: <= 1.2e-5, 2048: <= 1.9e-5; -2 % time)
 };
@@ -121,6 +131,11 @@ struct rphip_csr {
   int32_t* tile_ptr = nullptr;
   uint16_t* x_rel = nullptr;       // [nnz rounded up to 8, + 8] column of every entry RELATIVE to its tile (x_idx - tile * tile_w < 65536): what the
                                    // fit kernels' accumulate loops read - half the bytes and half the load instructions of x_idx
+  // packed user rows (K0, k_build_xp): every (user, tile) segment as whole 16-byte chunks of eight tile-relative columns, padded with
+  // dump columns in [tile_w, tile_w + RP_DUMP) spread over the dump range; xp_ptr[u * (T + 1) + t] = first chunk of segment (u, t),
+  // [.. + T] = one past the user's last.  What the accumulate loops of the heavy fit kernels read: a lane owns a whole segment.
+  uint4* xp = nullptr;
+  int32_t* xp_ptr = nullptr;
   bool sorted_rows = false;
   int max_user_deg = 0;            // longest history (bounds |score| for predict's fixed-point scale)
   int64_t xt_row_begin = 0, xt_row_end = -1;  // item rows of X^T that were filled (-1: all); fit is limited to them
@@ -173,7 +188,8 @@ struct rphip_model {
 int rp_scratch(rphip_ctx* ctx, int slot, size_t bytes, void** out);
 int rp_dev_alloc(rphip_ctx* ctx, size_t bytes, void** out);  // hipMalloc through the context's block cache
 void rp_dev_free(rphip_ctx* ctx, void* p);                   // NULL is fine; blocks not from rp_dev_alloc go to hipFree
-void rp_dev_trim(rphip_ctx* ctx);                            // release every cached block
+void rp_dev_trim(rphip_ctx* ctx);                            // release every cached block (whole regions; parts of a split region stay)
+int rp_dev_cache_serves(rphip_ctx* ctx, size_t bytes, int n);  // how many of n requests of that size the cache would serve
 void rp_time_begin(rphip_ctx* ctx, hipEvent_t* a);
 void rp_time_end(rphip_ctx* ctx, hipEvent_t a, int slot, double work);
 int rp_resolve_timings(rphip_ctx* ctx);

@@ -2604,16 +2604,17 @@ static int rp_ease_alloc(rphip_ctx* ctx, int n, int n_mats, rphip_model** mo, fl
   const size_t bytes = (size_t)n_pad * ld * sizeof(float);
   size_t free_b = 0, total_b = 0;
   hipMemGetInfo(&free_b, &total_b);
-  // cached blocks count as available: a block of exactly this size is reused, anything else is released first
+  // cached blocks count as available when the cache would serve the requests (best fit with splitting, rp_dev_alloc); what it
+  // cannot serve must come from the driver - if that does not fit either, the cache is released first
   if (n_mats * bytes + (1ull << 30) > free_b && ctx->cached_bytes > 0) {
-    bool has = false;
-    for (auto& b : ctx->free_blocks) has |= b.bytes == ((bytes + 255) & ~(size_t)255);
-    if (!has || n_mats > 1) {
+    const int served = rp_dev_cache_serves(ctx, bytes, n_mats);
+    if ((size_t)(n_mats - served) * bytes + (1ull << 30) > free_b) {
       hipStreamSynchronize(ctx->stream);
       rp_dev_trim(ctx);
       hipMemGetInfo(&free_b, &total_b);
+      free_b += (size_t)rp_dev_cache_serves(ctx, bytes, n_mats) * bytes;  // (parts of split regions stay cached)
     } else {
-      free_b += bytes;
+      free_b += (size_t)served * bytes;
     }
   }
   if (n_mats * bytes + (1ull << 30) > free_b)

@@ -98,6 +98,7 @@ static int rp_rccl_load() {
 
 struct rphip_comm {
   rphip_ctx* ctx = nullptr;
+  int device = 0;  // (kept apart: the context may be destroyed before the communicator)
   int world = 1, rank = 0;
   bool is_rccl = false;
   ncclComm_t nccl = nullptr;
@@ -125,6 +126,7 @@ extern "C" int rphip_comm_rccl_create(rphip_ctx* ctx, int32_t world, int32_t ran
   ::memcpy(&uid, id, sizeof(uid));
   rphip_comm* c = new rphip_comm();
   c->ctx = ctx;
+  c->device = ctx->device;
   c->world = world;
   c->rank = rank;
   c->is_rccl = true;
@@ -145,6 +147,7 @@ extern "C" int rphip_comm_from_ops(rphip_ctx* ctx, const rphip_comm_ops* ops, rp
     RP_FAIL(RPHIP_EINVAL, "a transport for more than one rank needs all four operations");
   rphip_comm* c = new rphip_comm();
   c->ctx = ctx;
+  c->device = ctx->device;
   c->world = ops->world;
   c->rank = ops->rank;
   c->ops = *ops;
@@ -155,10 +158,8 @@ extern "C" int rphip_comm_from_ops(rphip_ctx* ctx, const rphip_comm_ops* ops, rp
 extern "C" int rphip_comm_destroy(rphip_comm* c) {
   if (!c) return RPHIP_OK;
   if (c->is_rccl && c->nccl) {
-    if (c->ctx) {
-      hipSetDevice(c->ctx->device);
-      hipDeviceSynchronize();
-    }
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
     g_rccl.CommDestroy(c->nccl);
   }
   delete c;
@@ -236,16 +237,21 @@ int rp_comm_exchange(rphip_comm* c, const void* send, const int64_t* soff, const
   return RPHIP_OK;
 }
 
+int rp_comm_all_reduce_sum_i32(rphip_comm* c, int32_t* buf, int64_t count, hipStream_t st) {
+  if (count <= 0 || c->world == 1) return RPHIP_OK;
+  if (c->is_rccl) {
+    RP_NCCL(g_rccl.AllReduce(buf, buf, (size_t)count, ncclInt32, ncclSum, c->nccl, st));
+    return RPHIP_OK;
+  }
+  RP_OPS(c->ops.all_reduce_sum_i32(c->ops.self, buf, count, (void*)st), "all_reduce_sum_i32");
+  return RPHIP_OK;
+}
+
 extern "C" int rphip_comm_all_reduce_sum_i32(rphip_ctx* ctx, rphip_comm* c, int32_t* buf, int64_t count) {
   if (!ctx || !c || !buf) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (count <= 0 || c->world == 1) return RPHIP_OK;
   RP_TRY(rp_set_device(ctx));
-  if (c->is_rccl) {
-    RP_NCCL(g_rccl.AllReduce(buf, buf, (size_t)count, ncclInt32, ncclSum, c->nccl, ctx->stream));
-    return RPHIP_OK;
-  }
-  RP_OPS(c->ops.all_reduce_sum_i32(c->ops.self, buf, count, (void*)ctx->stream), "all_reduce_sum_i32");
-  return RPHIP_OK;
+  return rp_comm_all_reduce_sum_i32(c, buf, count, ctx->stream);
 }
 
 // ---- small kernels ----------------------------------------------------------------------------------------------------------
@@ -376,13 +382,11 @@ struct dist_res {  // everything the fit holds besides the slab; released on eve
   }
 };
 
-int64_t g_dist_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-
 }  // namespace
 
 extern "C" int rphip_ease_fit_dist_stats(rphip_ctx* ctx, int64_t* out8) {
   if (!ctx || !out8) RP_FAIL(RPHIP_EINVAL, "NULL argument");
-  ::memcpy(out8, g_dist_stats, sizeof(g_dist_stats));
+  ::memcpy(out8, ctx->dist_stats, sizeof(ctx->dist_stats));
   return RPHIP_OK;
 }
 
@@ -737,23 +741,27 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
   }
   DHIP(hipGetLastError());
   rp_time_end(ctx, t_sc, RPHIP_T_EASE_SCALE, 8.0 * (double)n_pad * n_local);
+  // the flag of a pivot block that broke down is one rank's: summed over the ranks so that EVERY rank returns the same status
+  // (the others received the broken pivot's garbage through the broadcasts and would otherwise serve it, or hang in the next
+  // exchange while the failing rank raises)
+  DTRY(rp_comm_all_reduce_sum_i32(comm, info, 1, st));
   int h_info = 0;
   DHIP(hipMemcpyAsync(&h_info, info, 4, hipMemcpyDeviceToHost, st));
   DHIP(hipStreamSynchronize(st));
   DHIP(hipStreamSynchronize(su));
   DHIP(hipStreamSynchronize(sc));
   DHIP(hipStreamSynchronize(sp));
-  g_dist_stats[0] = (int64_t)slab_bytes;
-  g_dist_stats[1] = R.peak + (int64_t)ctx->scratch[12].cap + (int64_t)ctx->scratch[13].cap + (int64_t)ctx->scratch[8].cap + (int64_t)ctx->scratch[9].cap +
+  ctx->dist_stats[0] = (int64_t)slab_bytes;
+  ctx->dist_stats[1] = R.peak + (int64_t)ctx->scratch[12].cap + (int64_t)ctx->scratch[13].cap + (int64_t)ctx->scratch[8].cap + (int64_t)ctx->scratch[9].cap +
                     (int64_t)ctx->scratch[10].cap + (int64_t)ctx->scratch[11].cap + (int64_t)ctx->scratch[5].cap + (int64_t)ctx->scratch[7].cap;
-  g_dist_stats[2] = comm->bytes_recv;
-  g_dist_stats[3] = comm->bytes_sent;
-  g_dist_stats[4] = np;
-  g_dist_stats[5] = nb;
-  g_dist_stats[6] = n_pad;
-  g_dist_stats[7] = (int64_t)flop;
+  ctx->dist_stats[2] = comm->bytes_recv;
+  ctx->dist_stats[3] = comm->bytes_sent;
+  ctx->dist_stats[4] = np;
+  ctx->dist_stats[5] = nb;
+  ctx->dist_stats[6] = n_pad;
+  ctx->dist_stats[7] = (int64_t)flop;
   if (h_info) {
-    rp_set_error("a pivot block is not positive definite (pivot %d of a diagonal block): G + l2*I is not positive definite", h_info);
+    rp_set_error("a pivot block is not positive definite on some rank (flag sum %d): G + l2*I is not positive definite", h_info);
     return fail(RPHIP_ENUMERIC);
   }
   // items among the local columns: a prefix (the padding is the tail of the last panel)

@@ -51,6 +51,33 @@ int main() {
   rp_dev_free(ctx, b);
   rp_dev_free(ctx, nullptr);
   CHECK(ctx->free_blocks.size() == 2 && stub_live_blocks() == base + 2);
+  // best fit with splitting: a request of at least 1/16 of a cached block is cut from it, the rest stays cached and the parts
+  // are joined again when freed; a request below 1/16 of every cached block goes to the runtime
+  {
+    rp_dev_trim(ctx);
+    void *big = nullptr, *p1 = nullptr, *p2 = nullptr, *small = nullptr;
+    const int b0 = stub_live_blocks();
+    CHECK(rp_dev_alloc(ctx, 1 << 16, &big) == RPHIP_OK);
+    rp_dev_free(ctx, big);
+    CHECK(rp_dev_cache_serves(ctx, 1 << 14, 8) == 4 && rp_dev_cache_serves(ctx, 1 << 17, 1) == 0);
+    CHECK(rp_dev_alloc(ctx, 1 << 14, &p1) == RPHIP_OK && p1 == big && ctx->cached_bytes == (3u << 14) && stub_live_blocks() == b0 + 1);
+    CHECK(rp_dev_alloc(ctx, 1 << 14, &p2) == RPHIP_OK && p2 == (char*)big + (1 << 14) && ctx->free_blocks.size() == 1);
+    memset(p1, 3, 1 << 14);
+    memset(p2, 4, 1 << 14);
+    CHECK(rp_dev_alloc(ctx, 256, &small) == RPHIP_OK && stub_live_blocks() == b0 + 2);  // (256 < 32 KB / 16: not carved from it)
+    rp_dev_trim(ctx);  // (a split region with live parts cannot go back)
+    CHECK(ctx->free_blocks.size() == 1 && stub_live_blocks() == b0 + 2);
+    rp_dev_free(ctx, p1);
+    CHECK(ctx->free_blocks.size() == 2);  // (p1 and the tail do not touch)
+    rp_dev_free(ctx, p2);
+    CHECK(ctx->free_blocks.size() == 1 && ctx->free_blocks[0].bytes == (1u << 16) && ctx->cached_bytes == (1u << 16));
+    rp_dev_free(ctx, small);
+    rp_dev_trim(ctx);
+    CHECK(ctx->free_blocks.empty() && ctx->cached_bytes == 0 && stub_live_blocks() == b0);
+    CHECK(rp_dev_alloc(ctx, 1000, &a) == RPHIP_OK && rp_dev_alloc(ctx, 5000, &b) == RPHIP_OK);
+    rp_dev_free(ctx, a);
+    rp_dev_free(ctx, b);
+  }
   // a failing allocation gives the cache back and retries
   stub_fail_mallocs(1);
   CHECK(rp_dev_alloc(ctx, 1 << 20, &a) == RPHIP_OK && ctx->free_blocks.empty() && stub_live_blocks() == base + 1);

@@ -24,8 +24,17 @@ for it in range(3):
     m = _lib.itemknn_fit(ctx, dX, 200)
     ctx.sync()
     tm = ctx.timings()
-    cur = {k: round(tm[k]["ms"], 2) for k in ("gram_topk", "gram_topk_wave", "topk_merge", "gram_finalize")}
+    cur = {k: round(tm[k]["ms"], 2) for k in ("gram_topk", "gram_topk_wave", "topk_merge", "gram_finalize", "csr_transpose", "fit_plan")}
     if best is None or sum(cur.values()) < sum(best.values()):
         best = cur
     del m
-print(f"{os.path.basename(sys.argv[1])}: heavy {best['gram_topk']} ms, light {best['gram_topk_wave']} ms, merge {best['topk_merge']} ms, finalize {best['gram_finalize']} ms", flush=True)
+print(f"{os.path.basename(sys.argv[1])}: heavy {best['gram_topk']} ms, light {best['gram_topk_wave']} ms, merge {best['topk_merge']} ms, finalize {best['gram_finalize']} ms"
+      f" | K0 {best['csr_transpose']} ms, plan {best['fit_plan']} ms | K1-K3 sum {best['gram_topk'] + best['gram_topk_wave'] + best['topk_merge'] + best['gram_finalize']:.2f} ms", flush=True)
+if len(sys.argv) > 3 and sys.argv[3] == "gram":  # K4: the dense Gram of EASE (the same accumulate loop, u32 counters)
+    dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
+    for it in range(2):
+        ctx.reset_timings()
+        g = _lib.ease_gram_create(ctx, dX)
+        ctx.sync()
+        print(f"  dense Gram (K4): {ctx.timings()['gram_dense']['ms']:.2f} ms", flush=True)
+        del g
