@@ -48,11 +48,6 @@ void rp_set_error(const char* fmt, ...);
 constexpr int RP_WAVE = 64;
 constexpr int RP_FIT_THREADS = 1024;      // 16 waves, one workgroup per CU (LDS-bound)
 constexpr int RP_TILE_MAX = 25600;        // accumulator columns per LDS tile (100 KiB of u32/f32 + 50 KiB candidate list)
-#ifndef RP_BUILD_XP
-#define RP_BUILD_XP 0  // K0 builds the packed user rows (xp): only the experimental lane-group accumulate loop (RP_FIT_GROUPS) reads them
-#endif
-constexpr int RP_DUMP = 256;              // dump columns behind a tile's own: where the padding entries of the packed user rows (xp) add
-constexpr int RP_TILE_COLS = RP_TILE_MAX - RP_DUMP;  // widest column tile K0 plans
 constexpr int RP_SORT_CAP = 512;          // entries of the in-LDS exact sort (6 KiB, overlays the histogram)
 constexpr int RP_HIST_BINS = 2048;        // radix-select digit: 11 bits
 constexpr int RP_K_MAX = 2048;            // largest effective K / Kp of one call
@@ -131,11 +126,6 @@ struct rphip_csr {
   int32_t* tile_ptr = nullptr;
   uint16_t* x_rel = nullptr;       // [nnz rounded up to 8, + 8] column of every entry RELATIVE to its tile (x_idx - tile * tile_w < 65536): what the
                                    // fit kernels' accumulate loops read - half the bytes and half the load instructions of x_idx
-  // packed user rows (K0, k_build_xp): every (user, tile) segment as whole 16-byte chunks of eight tile-relative columns, padded with
-  // dump columns in [tile_w, tile_w + RP_DUMP) spread over the dump range; xp_ptr[u * (T + 1) + t] = first chunk of segment (u, t),
-  // [.. + T] = one past the user's last.  What the accumulate loops of the heavy fit kernels read: a lane owns a whole segment.
-  uint4* xp = nullptr;
-  int32_t* xp_ptr = nullptr;
   bool sorted_rows = false;
   int max_user_deg = 0;            // longest history (bounds |score| for predict's fixed-point scale)
   int64_t xt_row_begin = 0, xt_row_end = -1;  // item rows of X^T that were filled (-1: all); fit is limited to them

@@ -101,47 +101,6 @@ __global__ void k_scatter(const int32_t* __restrict__ x_ptr, const int32_t* __re
   if ((threadIdx.x & 63) == 0 && local) atomicAdd(p_sum, local);
 }
 
-// Packed user rows: segment (u, t) = the entries of row u inside column tile t, copied as whole chunks of eight 16-bit tile-relative
-// columns; the last chunk is filled up with DUMP columns (>= tile_w, spread over RP_DUMP slots by user and position so that the lanes
-// of one LDS instruction rarely meet in one slot): the accumulate loops add every entry of a chunk without a mask.  A user's chunks
-// start at (x_ptr[u] >> 3) + u * (T + 1): sum_t ceil(len_t / 8) <= (d_u + 7 T) / 8 fits below the next user's start, no scan.
-// 16 lanes per user, one chunk per lane and round.
-__global__ void k_build_xp(const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ x_idx, const int32_t* __restrict__ tile_ptr, int n_users,
-                           int n_items, int T, int W, int32_t* __restrict__ xp_ptr, uint4* __restrict__ xp) {
-  const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
-  const int ng = (gridDim.x * blockDim.x) >> 4;
-  for (int u = g; u < n_users; u += ng) {
-    const int row_s = x_ptr[u], row_e = x_ptr[u + 1];
-    int c0 = (row_s >> 3) + u * (T + 1);
-    for (int t = 0; t < T; ++t) {
-      int s = row_s, e = row_e;
-      if (T > 1) {
-        s = tile_ptr[(int64_t)u * (T + 1) + t];
-        e = tile_ptr[(int64_t)u * (T + 1) + t + 1];
-      }
-      const int nch = (e - s + 7) >> 3;
-      if (sub == 0) xp_ptr[(int64_t)u * (T + 1) + t] = c0;
-      const int off = t * W;
-      for (int c = sub; c < nch; c += 16) {
-        uint32_t v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int k = s + c * 8 + q;
-          uint32_t r = (uint32_t)W + (((uint32_t)u * 29u + (uint32_t)c * 8u + (uint32_t)q * 37u) & (uint32_t)(RP_DUMP - 1));
-          if (k < e) {
-            const int j = x_idx[k];
-            if ((unsigned)(j - off) < (unsigned)W) r = (uint32_t)(j - off);  // (an index outside the tile is reported by k_scatter)
-          }
-          v[q] = r;
-        }
-        xp[c0 + c] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
-      }
-      c0 += nch;
-    }
-    if (sub == 0) xp_ptr[(int64_t)u * (T + 1) + T] = c0;
-  }
-}
-
 __global__ void k_inv_deg(const int32_t* __restrict__ deg, double* __restrict__ inv, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int d = deg[i];
@@ -181,7 +140,7 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
     m->x_idx = pad;
     m->x_idx_padded = true;
   }
-  m->n_tiles = (int)std::max<int64_t>(1, rp_cdiv(I, RP_TILE_COLS));  // (a tile's LDS image ends with RP_DUMP dump columns)
+  m->n_tiles = (int)std::max<int64_t>(1, rp_cdiv(I, RP_TILE_MAX));
   m->tile_w = (int)(rp_cdiv(rp_cdiv(std::max<int64_t>(I, 1), m->n_tiles), 64) * 64);
   RP_TRY(rp_dev_alloc(ctx, (size_t)(I + 1) * sizeof(int32_t), (void**)&m->xt_ptr));
   RP_TRY(rp_dev_alloc(ctx, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t), (void**)&m->xt_idx));
@@ -232,14 +191,6 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
     hipLaunchKernelGGL(k_scatter, dim3(grid_s), dim3(bt), 0, st, m->x_ptr, m->x_idx, (int)U, m->xt_ptr, rank, m->xt_idx, p_sum,
                        (int)I, m->n_tiles, m->tile_w, m->tile_ptr, err, (int)std::max<int64_t>(0, m->xt_row_begin),
                        (int)(m->xt_row_end < 0 ? I : std::min<int64_t>(I, m->xt_row_end)), m->x_rel);
-  }
-  if (U > 0 && RP_BUILD_XP) {  // packed user rows for the lane-group accumulate loops
-    const size_t n_chunks = (size_t)(nnz >> 3) + (size_t)U * (m->n_tiles + 1) + 2;
-    RP_TRY(rp_dev_alloc(ctx, n_chunks * sizeof(uint4), (void**)&m->xp));
-    RP_TRY(rp_dev_alloc(ctx, (size_t)U * (m->n_tiles + 1) * sizeof(int32_t), (void**)&m->xp_ptr));
-    const int grid_x = (int)std::min<int64_t>((int64_t)ctx->n_cu * 16, std::max<int64_t>(1, rp_cdiv(U * 16, bt)));
-    hipLaunchKernelGGL(k_build_xp, dim3(grid_x), dim3(bt), 0, st, m->x_ptr, m->x_idx, m->tile_ptr, (int)U, (int)I, m->n_tiles, m->tile_w, m->xp_ptr,
-                       m->xp);
   }
   if (!m->deg_partial)  // (a shard's degrees are completed by rphip_csr_finish_degrees after the all-reduce)
     hipLaunchKernelGGL(k_inv_deg, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, rp_cdiv(I, bt)))), dim3(bt), 0, st,
@@ -427,8 +378,6 @@ extern "C" int rphip_csr_destroy(rphip_csr* m) {
   rp_dev_free(m->ctx, m->inv_deg);
   rp_dev_free(m->ctx, m->tile_ptr);
   rp_dev_free(m->ctx, m->x_rel);
-  rp_dev_free(m->ctx, m->xp);
-  rp_dev_free(m->ctx, m->xp_ptr);
   rp_dev_free(m->ctx, m->row_cost);
   rp_dev_free(m->ctx, m->x_val);
   delete m;

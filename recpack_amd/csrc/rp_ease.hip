@@ -194,6 +194,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(rp_gemm_args g) {
   // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   // (C's old values all at once, then arithmetic and stores: see k_gemm_hp16w's epilogue)
   const bool rmw = !g.part && g.beta != 0.0f;
+  float omax = 0.0f;
   f32x16 cold[2][2];
   if (rmw) {
 #pragma unroll
@@ -231,10 +232,25 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(rp_gemm_args g) {
           g.part[((long long)blockIdx.z * g.M + row) * g.N + col] = h + l;
         } else {
           const float v = rmw ? fmaf(g.alpha, h, g.beta * cold[i][j][r]) : g.alpha * h;
-          g.C[(long long)row * g.ldc + col] = fmaf(g.alpha, l, v);
+          const float o = fmaf(g.alpha, l, v);
+          g.C[(long long)row * g.ldc + col] = o;
+          omax = fmaxf(omax, fabsf(o));
         }
       }
     }
+  if (g.amax_out && !g.part) {  // the largest magnitude written: the scale of the products that will read these columns
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) omax = fmaxf(omax, __shfl_xor(omax, d));
+    if (lane == 0 && omax > 0.0f) {
+      const unsigned b = __float_as_uint(omax);
+      atomicMax(g.amax_out, b);
+      atomicMax(g.amax_out + 1, b);
+      if (g.amax_out2) {
+        atomicMax(g.amax_out2, b);
+        atomicMax(g.amax_out2 + 1, b);
+      }
+    }
+  }
 }
 
 // ---- the same product on the bf16 matrix pipe: three-way split operands ------------------------------------------------------
@@ -1695,8 +1711,8 @@ int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st, float* par
     if (!ctx->gemm_amax_ring) {
       RP_HIP(hipMalloc((void**)&ctx->gemm_amax_ring, (size_t)RP_AMAX_SLOTS * 2 * sizeof(unsigned)));
     }
-    unsigned* slot = ctx->gemm_amax_ring + 2 * (size_t)(ctx->gemm_amax_seq++ % RP_AMAX_SLOTS);
-    RP_HIP(hipMemsetAsync(slot, 0, 2 * sizeof(unsigned), st));
+    unsigned* slot = g.amax_known ? const_cast<unsigned*>(g.amax_known) : ctx->gemm_amax_ring + 2 * (size_t)(ctx->gemm_amax_seq++ % RP_AMAX_SLOTS);
+    if (!g.amax_known) RP_HIP(hipMemsetAsync(slot, 0, 2 * sizeof(unsigned), st));
     const int m_tiles = g.M / GT, n_tiles = g.N / GT;
     rp_amax_op oa{g.A, g.lda, m_tiles, g.kb_m, 0, g.m_off};
     rp_amax_op ob{g.B, g.ldb, n_tiles, g.kb_n, g.ke_n, g.n_off};
@@ -1710,7 +1726,8 @@ int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st, float* par
     const bool alias = presplit && (dup || (same_cols && !(row_shift % 32) && row_shift + g.N <= g.M));
     const int one_max = (dup || alias) ? 1 : 0;
     if (one_max) ob.tiles = 0;
-    hipLaunchKernelGGL(k_gemm_amax, dim3(oa.tiles + ob.tiles, (unsigned)rp_cdiv(klen, 256)), dim3(256), 0, st, oa, ob, g.k0, g.k1, one_max, slot);
+    if (!g.amax_known)
+      hipLaunchKernelGGL(k_gemm_amax, dim3(oa.tiles + ob.tiles, (unsigned)rp_cdiv(klen, 256)), dim3(256), 0, st, oa, ob, g.k0, g.k1, one_max, slot);
     h.amax = slot;
     if (presplit) {
       const int rows_max = std::max(g.M, alias ? 0 : g.N);
@@ -1819,7 +1836,8 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
   const int nb = n_pad / GT;
   char* wsb = nullptr;
   const int inv_w = std::min(RP_INV_PANEL * GT, n_pad);  // columns of one panel of the inverse
-  RP_TRY(rp_scratch(ctx, 5, (size_t)nb * GT * GT * 4 + ((size_t)n_pad * inv_w + (size_t)inv_w * inv_w + (size_t)inv_w * GT) * 4 + 256, (void**)&wsb));
+  const size_t cmax_off = (size_t)nb * GT * GT * 4 + ((size_t)n_pad * inv_w + (size_t)inv_w * inv_w + (size_t)inv_w * GT) * 4 + 256;
+  RP_TRY(rp_scratch(ctx, 5, cmax_off + (size_t)(2 * nb + 8) * 2 * sizeof(unsigned), (void**)&wsb));
   float* const Nb = A;  // N shares the matrix with L
   int* info = info_ext ? info_ext : (int*)wsb;
   float* W = (float*)(wsb + 256);                 // [nb][128][128]
@@ -1829,6 +1847,15 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
   float* part_all = nullptr;  // the split-K partials of the skinny products: sized once for the tallest of them
   RP_TRY(rp_scratch(ctx, 7, (size_t)8 * n_pad * GT * sizeof(float), (void**)&part_all));
   if (!info_ext) RP_HIP(hipMemsetAsync(info, 0, 4, st));
+  // Scales of the factorisation's products without measuring passes (round 4): the product that writes a block column of L
+  // (L[k+1:, k] = A W_k^T, fp32 kernel) leaves the column's largest magnitude in two pairs of words - its sub-panel's and its
+  // panel's - and every product that reads L (the block chain's two skinny updates, the sub-panel and the trailing updates) takes
+  // its operands' scale from there: a bound over all rows of the columns it reads.  k_gemm_amax + its memset left the per-block
+  // chain (two of each per block: 3 100 launches and 0.5 s of kernel time per 100 000-item solve in round 3).
+  unsigned* cmax_sub = (unsigned*)(wsb + cmax_off);  // [nb + 4][2]: by sub-panel index
+  unsigned* cmax_pan = cmax_sub + (size_t)(nb + 4) * 2;  // [nb + 4][2]: by panel index
+  RP_HIP(hipMemsetAsync(cmax_sub, 0, (size_t)(2 * nb + 8) * 2 * sizeof(unsigned), st));
+  const bool known_scales = ctx->gemm_mode == 2 && getenv("RP_CHOL_MEASURE_SCALES") == nullptr;
   const size_t diag_lds = RP_POTRF_LDS;
   RP_HIP(hipFuncSetAttribute((const void*)k_potrf_trtri, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_lds));
   const double n3 = (double)n_pad * n_pad * n_pad;
@@ -1904,6 +1931,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
     g.k1 = r0;
     g.alpha = -1.0f;
     g.beta = 1.0f;
+    if (known_scales) g.amax_known = cmax_sub + 2 * (size_t)(k / SUB);
     if (r0 > sk0) {  // A[k,k] -= L[k,p:k] L[k,p:k]^T on the side stream (p = the sub-panel's first column)
       g.M = GT;
       rc = rp_gemm_nt(ctx, g, s2, part_diag);
@@ -1934,6 +1962,10 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
       h.alpha = 1.0f;
       h.beta = 0.0f;
       h.f32 = 1;  // (K = 128 on the per-block chain: the fp32 MFMA kernel in ONE launch instead of memset + amax + plane kernel)
+      if (known_scales) {
+        h.amax_out = cmax_sub + 2 * (size_t)(k / SUB);
+        h.amax_out2 = cmax_pan + 2 * (size_t)(k / RP_CHOL_PANEL);
+      }
       rc = rp_gemm_nt(ctx, h, st);
       if (rc != RPHIP_OK) break;
       const int r1 = r0 + GT;
@@ -1955,6 +1987,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
         u.alpha = -1.0f;
         u.beta = 1.0f;
         u.no_splitk = 1;
+        if (known_scales) u.amax_known = cmax_sub + 2 * (size_t)(k / SUB);
         if (cols_pending) {  // (these columns took the previous panel's update on the third stream)
           RP_HIP(hipStreamWaitEvent(st, e_cols, 0));
           cols_pending = false;
@@ -1989,6 +2022,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
         t.tri = 1;
         t.alpha = -1.0f;
         t.beta = 1.0f;
+        if (known_scales) t.amax_known = cmax_pan + 2 * (size_t)(k / RP_CHOL_PANEL);
         rc = rp_gemm_nt(ctx, t, st);
         if (rc != RPHIP_OK) break;
         tr_rec(st);

@@ -48,6 +48,12 @@ struct rp_gemm_args {
   const rp_plane_cache* ca;  // A's planes are read from this cache (A unused; M and k1 <= ca->K; the wide product kernel only)
   int cb;            // ... and B's as well (B is the same matrix)
   int f32;           // this product on the fp32 MFMA kernel (k_gemm_nt) whatever the context's gemm_mode
+  // (round 4) the scales of a chain's products without a measuring pass: amax_known = device words [max |A|, max |B|] that already
+  // bound what the launch reads (no memset, no k_gemm_amax); amax_out / amax_out2 = pairs of words that take max |C| of what this
+  // launch writes (atomicMax on both words of each; the fp32 kernel only) - the producer of a panel's columns measures them
+  const unsigned* amax_known;
+  unsigned* amax_out;
+  unsigned* amax_out2;
 };
 
 // C = alpha * A * B^T + beta * C on `st` (the context's stream when NULL)

@@ -40,8 +40,6 @@ struct rp_fit_params {
   const int32_t* deg;
   const double* inv_deg;   // column weight of the key: 1/c_j (cosine) or c_j^-alpha (conditional probability)
   const int32_t* tile_ptr;
-  const int32_t* xp_ptr;   // packed user rows (rphip_csr::xp): first chunk of every (user, tile) segment ...
-  const uint4* xp;         // ... and the chunks: eight tile-relative columns each, padded with dump columns
   int n_items, n_tiles, tile_w, K, row_begin;
   int nnz;
   int key_pow;             // 2 = cosine, 1 = conditional probability
@@ -110,12 +108,6 @@ struct rp_dense_src {
   __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)(t0 + w); }
 };
 
-#ifndef RP_FIT_XCD
-#define RP_FIT_XCD 1  // heavy rows / dense Gram: tasks handed out per XCD (0: one ticket counter for the chip - diagnostic)
-#endif
-#ifndef RP_FIT_GROUPS
-#define RP_FIT_GROUPS 0  // 1: the heavy rows' accumulate loop on the packed rows (xp) with power-of-two lane groups (measured slower: DESIGN.md)
-#endif
 #ifndef RP_FIT_CH
 #define RP_FIT_CH 8  // entries per chunk of the accumulate loop (8 or 16: one or two 16-byte loads of x_rel)
 #endif
@@ -144,7 +136,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
   constexpr int SBITS = BYTES ? RP_LIGHT_BITS : 11;  // radix digit of the selection (light rows: 10 -> 4 KB histogram)
   uint32_t* acc = reinterpret_cast<uint32_t*>(smem);
   const int W = P.tile_w;
-  const int acc_words = ((W + ((BYTES || !RP_FIT_GROUPS) ? 0 : RP_DUMP)) * CB + 31) / 32;  // (the packed rows' padding entries add into dump columns behind the tile)
+  const int acc_words = (W * CB + 31) / 32;
   char* sel_base = smem + (((size_t)acc_words * 4 + 15) & ~(size_t)15);
   rp_tsel_smem tsel = rp_tsel_carve(sel_base, W);
   rp_select_smem sel;
@@ -185,12 +177,13 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
     int* d = s_task + q * 8;
     constexpr int TCH = BYTES ? RP_TICKET_CHUNK : 1;  // (heavy tasks are long and sorted heaviest first: one at a time)
     int ti;
-    if constexpr (!BYTES && !FINALIZE && RP_FIT_XCD) {
-      // XCD-aware hand-out (heavy rows, dense Gram): the T column-tile tasks of one (row, user range) are consecutive in the task
-      // array; group g of T tasks belongs to the XCD g mod 8, which has its own ticket counter - the workgroups that share an
-      // L2 (blockIdx mod 8, MI355X_MICROARCH.md) take the tiles of one row at about the same time: its users' ids, their tile
-      // pointers (one 20-byte record serves all T tiles) and the lines of a user row that straddle two tiles are fetched over the
-      // fabric once instead of T times.  A workgroup whose own list is exhausted takes from the next XCD's.
+    if constexpr (!BYTES && !FINALIZE) {
+      // XCD-aware hand-out (heavy rows, dense Gram; round 4): the T column-tile tasks of one (row, user range) are consecutive in
+      // the task array; group g of T tasks belongs to the XCD g mod 8, which has its own ticket counter - the workgroups that share
+      // an L2 (blockIdx mod 8, MI355X_MICROARCH.md) take the tiles of one row at about the same time: its users' ids, their tile
+      // pointers (one 4 (T + 1)-byte record serves all T tiles) and the lines of a user row that straddle two tiles are fetched
+      // over the fabric once instead of T times.  A workgroup whose own list is exhausted takes from the next XCD's.
+      // Measured at 1M x 100K: heavy rows 8.92 -> 8.66 ms, the dense Gram of EASE 18.7 -> 16.9 ms.
       ti = n_tasks;
       while (xq < 8) {
         const int x = ((int)blockIdx.x + xq) & 7;
@@ -203,11 +196,11 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
         ++xq;
       }
     } else {
-    if (tk_next == tk_end && !(RP_FIT_ABL & 64)) {
-      tk_next = atomicAdd(P.ticket, TCH);
-      tk_end = tk_next + TCH;
-    }
-    ti = tk_next++;
+      if (tk_next == tk_end && !(RP_FIT_ABL & 64)) {
+        tk_next = atomicAdd(P.ticket, TCH);
+        tk_end = tk_next + TCH;
+      }
+      ti = tk_next++;
     }
     if (RP_FIT_ABL & 64) {  // (diagnostic: static assignment, no ticket atomics)
       ti = (int)blockIdx.x + abl_iter * (int)gridDim.x;
@@ -253,108 +246,8 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
     int lcnt = 0;             // candidates this wave appended
     int blk = NBLK, fill = 64;  // current block (none yet) and its fill
 
-    if (tk.mode != 2 && !BYTES && RP_FIT_GROUPS) {
-      // ---- accumulate, heavy rows: users p in [p_begin, p_end) of item `row`.  The users of a heavy row are sorted by history
-      // length (k_sort_row_users), so the 64 segments of a wave's batch hold about the same number of chunks; with nmax the
-      // largest of them, G = the next power of two lanes share a user: lane (slot, sub) reads chunk `sub` of the step's user
-      // `slot` - G adjacent lanes read G adjacent 16-byte chunks of the packed rows (xp): whole cache lines - and adds its eight
-      // columns, padding included (it lands in the dump columns): no masks per entry, no scan, no chunk -> lane search.  A batch
-      // takes G steps of 64 / G users; the step's (first chunk, chunks) come from their lane by one shuffle pair; step k + 1 is
-      // requested before step k is added.  (A lane per whole segment, G = 1 always, was measured first: 11.3 ms against 9.0 - every
-      // 16-byte read then pulls its own 128-byte line from beyond L2, and the line is gone when the lane comes back for the next.)
-      const int TP = T + 1;
-      auto load_user = [&](int bs) -> int {
-        const int p = bs + lane;
-        return (p < tk.p_end) ? P.xt_idx[p] : -1;
-      };
-      auto load_seg = [&](int u, int& s, int& n) {
-        s = 0;
-        n = 0;
-        if (u >= 0) {
-          const int32_t* q = P.xp_ptr + (int64_t)u * TP + tile;
-          s = q[0];
-          n = q[1] - s;
-        }
-      };
-      auto add8 = [&](const uint4& v) {
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const uint32_t j = (e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu);
-          if (RP_FIT_ABL & 1)
-            asm volatile("" ::"v"(j));
-          else if constexpr (PAIRS)
-            atomicAdd(&acc[j >> 1], 1u << (16 * (j & 1)));
-          else
-            atomicAdd(&acc[j], 1u);
-        }
-      };
-      // batches of 64 users, dealt to the waves in snake order (w, 2 NW - 1 - w, 2 NW + w, ..): the batches come longest first
-      const int n_batches = (tk.p_end - tk.p_begin + 63) >> 6;
-      auto batch_of = [&](int k) -> int {  // the wave's k-th batch
-        const int r = k >> 1;
-        return (k & 1) ? (2 * r + 2) * NW - 1 - wave : 2 * r * NW + wave;
-      };
-      int kb = 0;
-      int b_cur = batch_of(0), b_n1 = batch_of(1), b_n2 = batch_of(2);
-      int u_next = (b_n1 < n_batches) ? load_user(tk.p_begin + b_n1 * 64) : -1;
-      int s_cur, n_cur;
-      load_seg((b_cur < n_batches) ? load_user(tk.p_begin + b_cur * 64) : -1, s_cur, n_cur);
-      for (; b_cur < n_batches; ++kb) {
-        const int s = s_cur, n = n_cur;
-        load_seg(u_next, s_cur, n_cur);                                            // batch k+1
-        u_next = (b_n2 < n_batches) ? load_user(tk.p_begin + b_n2 * 64) : -1;    // batch k+2
-        b_cur = b_n1;
-        b_n1 = b_n2;
-        b_n2 = batch_of(kb + 3);
-        const int nmax = __builtin_amdgcn_readlane(rp_wave_incl_max(n), 63);
-        if (nmax == 0) continue;
-        const int lg = (nmax > 32) ? 6 : (32 - __clz(nmax - 1)) * (nmax > 1);  // G = 2^lg >= nmax (64 at most)
-        const int G = 1 << lg, ups = 64 >> lg;
-        const int sub = lane & (G - 1), slot = lane >> lg;
-        auto fetch = [&](int step, uint4& v, bool& act, int& su, int& nu) {
-          const int src = step * ups + slot;
-          su = __shfl(s, src);
-          nu = __shfl(n, src);
-          act = sub < nu;
-          v = P.xp[act ? su + sub : 0];
-        };
-        uint4 va, vb;
-        bool aa, ab;
-        int sa, na, sb, nb;
-        fetch(0, va, aa, sa, na);
-        for (int st = 0; st < G; st += 2) {
-          if (st + 1 < G) fetch(st + 1, vb, ab, sb, nb);
-          if (aa) add8(va);
-          if (lg == 6 && na > 64)  // (a segment of more than 512 entries: the rest of it, 64 chunks at a time)
-            for (int q = 64 + sub; q < na; q += 64) add8(P.xp[sa + q]);
-          if (st + 2 < G) fetch(st + 2, va, aa, sa, na);
-          if (st + 1 < G) {
-            if (ab) add8(vb);
-            if (lg == 6 && nb > 64)
-              for (int q = 64 + sub; q < nb; q += 64) add8(P.xp[sb + q]);
-          }
-        }
-      }
-      __syncthreads();
-      RP_STAMP(1);
-      if (tk.mode == 1) {
-        uint32_t* dst = P.part + (int64_t)tk.slot * W;
-        if constexpr (PAIRS) {
-          for (int w = tid; w < W; w += NTHR) dst[w] = (acc[w >> 1] >> (16 * (w & 1))) & 65535u;
-          __syncthreads();
-          for (int w = tid; w < acc_words; w += NTHR) acc[w] = 0u;
-        } else {
-          for (int w = tid; w < W; w += NTHR) {
-            dst[w] = acc[w];
-            acc[w] = 0u;
-          }
-        }
-        RP_STAMP(2);
-        continue;
-      }
-    } else if (tk.mode != 2) {
-      // ---- accumulate, light rows: users p in [p_begin, p_end) of item `row`.
+    if (tk.mode != 2) {
+      // ---- accumulate: users p in [p_begin, p_end) of item `row`.
       // A wave takes 64 users (one per lane: row pointer pair), cuts their index segments into chunks of
       // CH entries, and hands chunk c to lane c % 64: every lane then issues CH independent index loads
       // before the first LDS atomic, instead of one dependent load per user per round.
@@ -944,57 +837,6 @@ __global__ void k_plan_write(const int32_t* __restrict__ deg, const int32_t* __r
   }
 }
 
-// The users of every heavy row (and of every slice of a sliced row), reordered by history length, longest first (the degree
-// buckets of the row ordering: 8 per octave).  The order of the users inside a row of X^T is free - the Gram only counts - and
-// with it the 64 user segments a wave of the heavy kernel walks together (a lane per user) are about equally long: measured on the
-// 1M x 100K matrix, 66 % of the lane-rounds carry an entry against 16 % in the order K0's scatter leaves.  Pieces of 8192 users
-// are sorted independently (counting sort, returning LDS atomics for the rank inside a bucket); rows of at most 64 users - one
-// batch whatever the order - are left alone.
-constexpr int RP_SORTU_THREADS = 256, RP_SORTU_R = 32;
-__global__ void __launch_bounds__(RP_SORTU_THREADS) k_sort_row_users(const rp_task* __restrict__ tasks, const int32_t* __restrict__ n_tasks,
-                                                                     const int32_t* __restrict__ x_ptr, int32_t* __restrict__ xt_idx) {
-  __shared__ int cnt[PLAN_BUCKETS];
-  const int tid = threadIdx.x;
-  const int nt = *n_tasks;
-  constexpr int PIECE = RP_SORTU_THREADS * RP_SORTU_R;
-  for (int ti = blockIdx.x; ti < nt; ti += gridDim.x) {
-    const rp_task t = tasks[ti];
-    if (t.tile != 0 || t.mode == 2 || t.p_end - t.p_begin <= 64) continue;
-    for (int q0 = t.p_begin; q0 < t.p_end; q0 += PIECE) {
-      const int q1 = min(t.p_end, q0 + PIECE);
-      __syncthreads();
-      for (int i = tid; i < PLAN_BUCKETS; i += RP_SORTU_THREADS) cnt[i] = 0;
-      __syncthreads();
-      int uu[RP_SORTU_R], br[RP_SORTU_R];
-#pragma unroll
-      for (int r = 0; r < RP_SORTU_R; ++r) {
-        const int p = q0 + r * RP_SORTU_THREADS + tid;
-        uu[r] = -1;
-        br[r] = 0;
-        if (p < q1) {
-          const int u = xt_idx[p];
-          const int b = rp_deg_bucket(x_ptr[u + 1] - x_ptr[u]);
-          uu[r] = u;
-          br[r] = (b << 16) | atomicAdd(&cnt[b], 1);
-        }
-      }
-      __syncthreads();
-      if (tid == 0) {  // start of every bucket, longest histories first
-        int off = 0;
-        for (int b = PLAN_BUCKETS - 1; b >= 0; --b) {
-          const int c = cnt[b];
-          cnt[b] = off;
-          off += c;
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < RP_SORTU_R; ++r)
-        if (uu[r] >= 0) xt_idx[q0 + cnt[br[r] >> 16] + (br[r] & 0xffff)] = uu[r];
-    }
-  }
-}
-
 // ---- host side -------------------------------------------------------------------------------------
 int rp_model_alloc_topk(rphip_ctx* ctx, int64_t n_items, int64_t r0, int64_t r1, int32_t K, rphip_model** out) {
   rphip_model* m = new rphip_model();
@@ -1054,7 +896,7 @@ extern "C" int rphip_model_info(const rphip_model* m, int32_t* kind, int64_t* n_
   return RPHIP_OK;
 }
 
-static size_t rp_fit_lds_bytes(int tile_w) { return (size_t)(tile_w + RP_DUMP) * 4 + rp_select_smem_bytes(tile_w); }
+static size_t rp_fit_lds_bytes(int tile_w) { return (size_t)tile_w * 4 + rp_select_smem_bytes(tile_w); }
 
 // rows [row_begin, row_begin + n_rows) in descending degree order (coarse buckets): `bucket` = PLAN_BUCKETS ints of scratch
 int rp_plan_row_order(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int n_rows, int32_t* bucket, int32_t* order) {
@@ -1151,7 +993,7 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   int32_t* off_slot = (int32_t*)carve((size_t)(n_rows + 1) * 4);
   int32_t* n_light = (int32_t*)carve((size_t)n_rows * 4);
   int32_t* off_light = (int32_t*)carve((size_t)(n_rows + 1) * 4);
-  int32_t* tickets = (int32_t*)carve(64);  // [0..7] heavy rows, one per XCD; [8] finalize; [9] light rows
+  int32_t* tickets = (int32_t*)carve(64);  // [0..7] heavy rows / dense Gram, one per XCD; [8] finalize; [9] light rows
   rp_task* acc_tasks = (rp_task*)carve((size_t)(max_acc + max_light) * sizeof(rp_task));
   rp_task* fin_tasks = (rp_task*)carve((size_t)max_fin * sizeof(rp_task));
   rp_task* light_tasks = (rp_task*)carve((size_t)std::max<int64_t>(1, max_light) * sizeof(rp_task));
@@ -1169,9 +1011,6 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   RP_TRY(rp_exclusive_scan_i32(ctx, n_light, off_light, n_rows));
   hipLaunchKernelGGL(k_plan_write, dim3(pg), dim3(pb), 0, st, X->deg, X->xt_ptr, order, n_rows, T, slice_users, heavy_thr, light_max,
                      off_acc, off_fin, off_slot, off_light, acc_tasks, fin_tasks, light_tasks);
-  // heavy rows: users by history length (the lane-per-segment accumulate loop)
-  if (RP_FIT_GROUPS && Xc->xp)
-    hipLaunchKernelGGL(k_sort_row_users, dim3(ctx->n_cu * 8), dim3(RP_SORTU_THREADS), 0, st, acc_tasks, off_acc + n_rows, Xc->x_ptr, X->xt_idx);
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, RPHIP_T_FIT_PLAN, 0.0);
 
@@ -1201,8 +1040,6 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   P.inv_deg = colw ? colw : X->inv_deg;
   P.key_pow = key_pow;
   P.tile_ptr = Xc->tile_ptr;
-  P.xp_ptr = Xc->xp_ptr;
-  P.xp = Xc->xp;
   P.n_items = (int)X->n_items;
   P.nnz = (int)std::max<int64_t>(Xc->nnz, 8);  // (matrices with fewer entries carry a padded copy of their indices)
   P.n_tiles = T;
@@ -1246,7 +1083,7 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_fit<true, RP_FIT_THREADS, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = ctx->n_cu;
   // heavy rows of the neighbour-list path: u16 pairs, no list
-  const size_t plds = ((((size_t)(W + RP_DUMP) * 2 + 3) & ~(size_t)3) + 15 & ~(size_t)15) + rp_tsel_smem_bytes(W);
+  const size_t plds = ((((size_t)W * 2 + 3) & ~(size_t)3) + 15 & ~(size_t)15) + rp_tsel_smem_bytes(W);
   RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_fit<false, RP_PAIR_THREADS, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
   const int pair_per_cu = std::max<int>(1, std::min<int>(4, (int)((160 * 1024) / plds)));
 
