@@ -431,6 +431,12 @@ typedef struct rphip_comm_ops {
 int rphip_comm_rccl_unique_id(void* id_out /* RPHIP_COMM_ID_BYTES */);
 int rphip_comm_rccl_create(rphip_ctx* ctx, int32_t world, int32_t rank, const void* id, rphip_comm** out);
 int rphip_comm_from_ops(rphip_ctx* ctx, const rphip_comm_ops* ops, rphip_comm** out);
+/* A LOOP-BACK communicator for measuring ONE rank of a `world`-rank run on a single GPU (tools/dist_rank_emulate.py): every
+ * operation is stream-ordered and asynchronous like the RCCL ones, moves no data between ranks - what a rank would receive is
+ * filled with its own data or small noise of the right size - and holds its stream for latency_us + bytes / gbytes_per_s, bytes =
+ * what the rank would receive (broadcast root: what it sends).  The results of a run on it are meaningless; its kernel sequence,
+ * launch for launch, is rank `rank`'s.  The reference has no multi-GPU path (recpack/algorithms/base.py:454-455 TODO). */
+int rphip_comm_loopback_create(rphip_ctx* ctx, int32_t world, int32_t rank, double gbytes_per_s, double latency_us, rphip_comm** out);
 int rphip_comm_destroy(rphip_comm* comm);
 int rphip_comm_info(const rphip_comm* comm, int32_t* world, int32_t* rank, int32_t* is_rccl);
 /* int32 sum over the ranks of a device vector, in place (the item degrees of a sharded K0: rphip_csr_degrees_device) */

@@ -118,6 +118,7 @@ PROTOTYPES = {
     "rphip_comm_rccl_unique_id": (C.c_int, [_p]),
     "rphip_comm_rccl_create": (C.c_int, [_p, _i32, _i32, _p, _pp]),
     "rphip_comm_from_ops": (C.c_int, [_p, _p, _pp]),
+    "rphip_comm_loopback_create": (C.c_int, [_p, _i32, _i32, C.c_double, C.c_double, _pp]),
     "rphip_comm_destroy": (C.c_int, [_p]),
     "rphip_comm_info": (C.c_int, [_p, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "rphip_comm_all_reduce_sum_i32": (C.c_int, [_p, _p, _p, _i64]),
@@ -637,6 +638,15 @@ class Comm:
         c = cls(ctx, h, keep=(cbs, ops, box))
         c.error = box
         return c
+
+    @classmethod
+    def loopback(cls, ctx: Context, world: int, rank: int, gbytes_per_s: float = 100.0, latency_us: float = 10.0):
+        """ONE rank of a ``world``-rank run measured alone on one GPU (rphip_comm_loopback_create): the collectives move nothing
+        between ranks and hold their stream for the time the modelled link would take.  Results are meaningless; the kernel sequence
+        is rank ``rank``'s (tools/dist_rank_emulate.py)."""
+        h = C.c_void_p()
+        check(ctx.lib.rphip_comm_loopback_create(ctx.handle, int(world), int(rank), float(gbytes_per_s), float(latency_us), C.byref(h)))
+        return cls(ctx, h)
 
     def all_reduce_sum_i32(self, ptr: int, count: int):
         check(self.ctx.lib.rphip_comm_all_reduce_sum_i32(self.ctx.handle, self.handle, C.c_void_p(ptr), int(count)))

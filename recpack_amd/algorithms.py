@@ -156,10 +156,61 @@ class Algorithm(*_AlgorithmBases):
 
 
 class ItemSimilarityMatrixAlgorithm(Algorithm):
-    """base.py:220-279; the model lives on the GPU, ``similarity_matrix_`` is its host view."""
+    """base.py:220-279; the model lives on the GPU, ``similarity_matrix_`` is its host view.
 
-    _model = None          # _lib.Model
+    Pickling (``pickle`` / ``joblib.dump``, what a ``BaseEstimator`` user expects - recpack/algorithms/base.py:33): the device handle
+    never travels.  ``__getstate__`` replaces it by host arrays (a neighbour-list model is rebuilt from ``similarity_matrix_``, which
+    the estimator holds anyway; a dense model is downloaded once as float32), ``__setstate__`` keeps them, and the model is uploaded
+    again on its first use - on whatever MI355X the unpickling process has; without one that first use raises, as every other call."""
+
+    _model_dev = None      # _lib.Model on the device
+    _model_host = None     # what an unpickled estimator re-uploads from on first use: ("topk", idx, val, nnz) or ("dense", B float32)
     _empty_rows_ = None    # rows of the similarity matrix without any stored value (set by _fit)
+
+    @property
+    def _model(self):
+        if self._model_dev is None and self._model_host is not None:
+            kind = self._model_host[0]
+            ctx = get_context()
+            if kind == "topk":
+                self._model_dev = _lib.Model.from_topk_host(ctx, *self._model_host[1:])
+            else:
+                self._model_dev = _lib.Model.from_dense_host(ctx, self._model_host[1])
+            self._model_host = None
+        return self._model_dev
+
+    @_model.setter
+    def _model(self, m):
+        self._model_dev = m
+        self._model_host = None
+
+    def _host_model(self):
+        """The fitted model as host arrays (None when nothing is fitted)."""
+        if self._model_host is not None:
+            return self._model_host
+        m = self._model_dev
+        if m is None:
+            return None
+        if m.kind == _lib.RPHIP_MODEL_TOPK:
+            return ("topk",) + tuple(m.topk_download())
+        return ("dense", m.dense_download())
+
+    def __getstate__(self):
+        base = super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__
+        state = dict(base)
+        state.pop("_model_dev", None)
+        state.pop("_sim_cache", None)
+        state["_model_host"] = self._host_model()
+        return state
+
+    def __setstate__(self, state):
+        host = state.pop("_model_host", None)
+        if hasattr(super(), "__setstate__"):
+            super().__setstate__(state)
+        else:
+            self.__dict__.update(state)
+        self._model_dev = None
+        self._model_host = host
 
     def _upload(self, X: sp.csr_matrix):
         ctx = get_context()
@@ -298,6 +349,8 @@ class EASE(ItemSimilarityMatrixAlgorithm):
     20 GB download plus a CSR conversion, so predict() never touches it.
     ``density`` (ease.py:97-109) prunes on the device with the reference's rule.
     """
+
+    _sim_cache = None  # host CSR view of B (never pickled: rebuilt from the model on demand)
 
     def __init__(self, l2=1e3, alpha=0, density=None):
         super().__init__()

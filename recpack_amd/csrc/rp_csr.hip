@@ -4,12 +4,17 @@
 // recpack/matrix/util.py:27-48) as far as the hot path needs them: only the pattern (indptr, indices) is used.
 // X^T is what scipy builds implicitly for `X.T @ X` (nearest_neighbour.py:80 via sklearn, ease.py:81).
 //
-//   k_rank_hist_ranges   degrees AND the position of every entry inside its item row, one pass over nnz per item
-//                 range (LDS counters per block, one global atomic per (block, item))
+// Round 4: the transposition is a two-level counting sort whose scattered writes stay inside L2 (round 3: every entry's rank by
+// returning LDS atomics with x_idx read once per 32 768-item range, then 5 * 10^7 isolated 4-byte stores over 200 MB: 3.4 ms):
+//   k_rows        8 lanes per user row: column order check, tile pointers, tile-relative columns, P = sum d_u^2, and the number of
+//                 entries per BUCKET of 512 consecutive items (LDS histogram per block)
+//   scan          bucket offsets
+//   k_partition   8192 consecutive entries per block: (item inside its bucket, user) packed into one word, reordered in LDS by
+//                 bucket and written out in runs - every bucket's entries end up contiguous (coalesced writes)
+//   k_bucket<0>   per 8192 entries of ONE bucket: LDS counters of its 512 items -> deg (one global atomic per (block, item))
 //   scan          xt_ptr = exclusive_scan(deg)
-//   k_scatter     xt_idx[xt_ptr[j] + rank[k]] = u          8 lanes per user row, coalesced 32-B segments; the same
-//                 pass checks the column order and (n_items > one LDS tile) writes per user the first position
-//                 with column >= t*W
+//   k_bucket<1>   the same blocks: rank inside the block by returning LDS atomics, a span per (block, item) from a global cursor,
+//                 xt_idx[xt_ptr[j] + rank] = u - the stores of a bucket land in the ~1 MB its 512 item rows occupy
 //   k_inv_deg     inv_deg[j] = fl(1/c_j)
 #include <algorithm>
 
@@ -17,47 +22,25 @@
 
 #include "rp_common.h"
 
-// Degrees and in-row ranks without hot global atomics: the item axis is cut into ranges that fit LDS, a block
-// (chunk of nnz, range) counts its entries with returning LDS atomics (= rank inside the block), reserves a
-// span per item with ONE global atomic per (block, item), then adds the span's base to the stored ranks.
-// A popular item (84 % of the users at 1M x 100K) costs n_chunks global atomics instead of one per interaction.
-// Only items in [item_lo, item_hi) are counted (a shard's K0: the degrees of the other items come from an all-reduce).
-__global__ void __launch_bounds__(1024) k_rank_hist_ranges(const int32_t* __restrict__ idx, long long nnz, long long chunk, int n_items,
-                                                          int range_w, int32_t* __restrict__ deg, int32_t* __restrict__ rank,
-                                                          int32_t* __restrict__ err, int item_lo, int item_hi) {
-  extern __shared__ __attribute__((aligned(16))) char smem_h[];
-  int* cnt = reinterpret_cast<int*>(smem_h);
-  const int lo = item_lo + blockIdx.y * range_w, hi = min(item_hi, lo + range_w);
-  const long long k0 = (long long)blockIdx.x * chunk, k1 = min(nnz, k0 + chunk);
-  for (int w = threadIdx.x; w < range_w; w += 1024) cnt[w] = 0;
-  __syncthreads();
-  for (long long k = k0 + threadIdx.x; k < k1; k += 1024) {
-    const int j = idx[k];
-    if (j >= lo && j < hi) rank[k] = atomicAdd(&cnt[j - lo], 1);
-    if (blockIdx.y == 0 && (unsigned)j >= (unsigned)n_items) *err = 1;
-  }
-  __syncthreads();
-  for (int w = threadIdx.x; w < hi - lo; w += 1024) {
-    const int c = cnt[w];
-    cnt[w] = c ? atomicAdd(&deg[lo + w], c) : 0;
-  }
-  __syncthreads();
-  for (long long k = k0 + threadIdx.x; k < k1; k += 1024) {
-    const int j = idx[k];
-    if (j >= lo && j < hi) rank[k] += cnt[j - lo];
-  }
-}
+constexpr int RP_K0_BUCKET_MAX = 4096;  // buckets the partition pass can keep in LDS
+constexpr int RP_K0_E = 8192;           // entries per block of the partition and bucket passes
+constexpr int RP_K0_T = 256;            // threads of those blocks
 
 // One pass over X with 8 lanes per user row (coalesced 32-byte segments):
-//   * X^T: xt_idx[xt_ptr[j] + rank[k]] = u
 //   * are the column indices of every row strictly increasing?  (err[1] = 1 if not; with several column tiles err[0] = 3)
+//   * a column outside [0, n_items): err[0] = 1
 //   * n_tiles > 1: tile_ptr[u][t] = first position of row u with column >= t * tile_w - an entry whose tile differs from
 //     its predecessor's opens the tiles in between; the row's first entry opens tiles 0.., its last closes the rest
+//   * x_rel = the column inside its tile
 //   * P = sum_u d_u^2
-__global__ void k_scatter(const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ x_idx, int n_users,
-                          const int32_t* __restrict__ xt_ptr, const int32_t* __restrict__ rank, int32_t* __restrict__ xt_idx,
-                          unsigned long long* __restrict__ p_sum, int n_items, int n_tiles, int tile_w, int32_t* __restrict__ tile_ptr,
-                          int32_t* __restrict__ err, int xt_lo, int xt_hi, uint16_t* __restrict__ x_rel) {
+//   * bucket_cnt[b] += entries with item in bucket b (items [xt_lo, xt_hi) only: a shard counts the rows it will fit)
+__global__ void __launch_bounds__(256) k_rows(const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ x_idx, int n_users,
+                                             unsigned long long* __restrict__ p_sum, int n_items, int n_tiles, int tile_w,
+                                             int32_t* __restrict__ tile_ptr, int32_t* __restrict__ err, int xt_lo, int xt_hi,
+                                             uint16_t* __restrict__ x_rel, int bshift, int n_buckets, int32_t* __restrict__ bucket_cnt) {
+  extern __shared__ int bh[];
+  for (int b = threadIdx.x; b < n_buckets; b += blockDim.x) bh[b] = 0;
+  __syncthreads();
   const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, sub = threadIdx.x & 7;
   const int ng = (gridDim.x * blockDim.x) >> 3;
   const float inv_w = 1.0f / (float)tile_w;
@@ -79,12 +62,13 @@ __global__ void k_scatter(const int32_t* __restrict__ x_ptr, const int32_t* __re
     for (int k = s + sub; k < e; k += 8) {
       const int j = x_idx[k];
       const int prev = (k > s) ? x_idx[k - 1] : -1;
-      if (j >= xt_lo && j < xt_hi) xt_idx[xt_ptr[j] + rank[k]] = u;  // (a shard only fills the item rows it will fit)
       if (j <= prev) {
         err[1] = 1;
         if (tp) err[0] = 3;
       }
       const bool in_range = (unsigned)j < (unsigned)n_items;
+      if (!in_range) err[0] = 1;
+      if (in_range && j >= xt_lo && j < xt_hi) atomicAdd(&bh[j >> bshift], 1);
       const int tj0 = (in_range && n_tiles > 1) ? tile_of(j) : 0;
       x_rel[k] = (uint16_t)(in_range ? j - tj0 * tile_w : 0);  // (the column inside its tile)
       if (tp && in_range) {
@@ -99,6 +83,186 @@ __global__ void k_scatter(const int32_t* __restrict__ x_ptr, const int32_t* __re
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) local += __shfl_xor(local, d);
   if ((threadIdx.x & 63) == 0 && local) atomicAdd(p_sum, local);
+  __syncthreads();
+  for (int b = threadIdx.x; b < n_buckets; b += blockDim.x)
+    if (bh[b]) atomicAdd(&bucket_cnt[b], bh[b]);
+}
+
+// Entries [k0, k0 + E) of X (flat) into their buckets: word = (item - bucket * 2^bshift) << ubits | user.  The block's users are
+// found once (two binary searches over x_ptr), their row pointers cached in LDS, every entry then finds its row by a search there.
+// Per block: LDS histogram over the buckets (the returning add is the entry's rank inside the block's share of its bucket), one
+// global atomic per (block, bucket) reserves the share's place, the entries are laid out bucket by bucket in LDS and copied out:
+// consecutive threads write consecutive words of a bucket.
+template <typename PT>
+__global__ void __launch_bounds__(RP_K0_T) k_partition(const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ x_idx, int n_users, long long nnz,
+                                                       int n_items, int xt_lo, int xt_hi, int bshift, int ubits, int n_buckets,
+                                                       const int32_t* __restrict__ bucket_off, int32_t* __restrict__ bucket_fill, PT* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char sm_p[];
+  constexpr int R = RP_K0_E / RP_K0_T;
+  PT* stage = reinterpret_cast<PT*>(sm_p);                                        // [E]
+  int* hist = reinterpret_cast<int*>(sm_p + (size_t)RP_K0_E * sizeof(PT));       // [n_buckets] count, then global base - local start
+  int* lstart = hist + n_buckets;                                                // [n_buckets + 1] start inside the stage
+  int* rows = lstart + n_buckets + 1;                                            // [<= E + 2] row pointers of the block's users
+  __shared__ int s_u0, s_u1;
+  const int tid = threadIdx.x;
+  const long long k0 = (long long)blockIdx.x * RP_K0_E, k1 = min(nnz, k0 + RP_K0_E);
+  for (int b = tid; b < n_buckets; b += RP_K0_T) hist[b] = 0;
+  if (tid == 0) {  // users whose rows meet [k0, k1): first u with x_ptr[u + 1] > k0, last u with x_ptr[u] < k1
+    int lo = 0, hi = n_users;
+    while (lo < hi) {
+      const int m = (lo + hi) >> 1;
+      if (x_ptr[m + 1] > k0) hi = m; else lo = m + 1;
+    }
+    s_u0 = lo;
+    hi = n_users;
+    while (lo < hi) {
+      const int m = (lo + hi) >> 1;
+      if (x_ptr[m] >= k1) hi = m; else lo = m + 1;
+    }
+    s_u1 = lo;  // one past the last such user
+  }
+  __syncthreads();
+  const int u0 = s_u0, nu = s_u1 - s_u0;  // (rows without entries inside the range are harmless: the search skips them)
+  for (int i = tid; i <= nu; i += RP_K0_T) rows[i] = x_ptr[u0 + i];
+  __syncthreads();
+  int bk[R];
+  PT pay[R];
+  int rk[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const long long k = k0 + tid + (long long)r * RP_K0_T;
+    bk[r] = -1;
+    rk[r] = 0;
+    pay[r] = 0;
+    if (k < k1) {
+      const int j = x_idx[k];
+      if ((unsigned)j < (unsigned)n_items && j >= xt_lo && j < xt_hi) {
+        int lo = 0, hi = nu;  // the row u0 + lo with rows[lo] <= k < rows[lo + 1]
+        while (hi - lo > 1) {
+          const int m = (lo + hi) >> 1;
+          if (rows[m] <= (int)k) lo = m; else hi = m;
+        }
+        const int b = j >> bshift;
+        bk[r] = b;
+        pay[r] = ((PT)(j - (b << bshift)) << ubits) | (PT)(u0 + lo);
+        rk[r] = atomicAdd(&hist[b], 1);
+      }
+    }
+  }
+  __syncthreads();
+  // start of every bucket inside the stage (exclusive scan over the buckets, 256 threads: a serial run per thread + a scan of the sums)
+  {
+    const int per = (n_buckets + RP_K0_T - 1) / RP_K0_T;
+    const int b0 = tid * per, b1 = min(n_buckets, b0 + per);
+    int sum = 0;
+    for (int b = b0; b < b1; ++b) sum += hist[b];
+    __shared__ int tsum[RP_K0_T];
+    tsum[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0;
+      for (int t = 0; t < RP_K0_T; ++t) {
+        const int c = tsum[t];
+        tsum[t] = run;
+        run += c;
+      }
+      lstart[n_buckets] = run;
+    }
+    __syncthreads();
+    int run = tsum[tid];
+    for (int b = b0; b < b1; ++b) {
+      const int c = hist[b];
+      lstart[b] = run;
+      // the share's place in the bucket: ONE global atomic per (block, bucket); hist[b] becomes (global position of the share) - (its start in the stage)
+      hist[b] = c ? bucket_off[b] + atomicAdd(&bucket_fill[b], c) - run : 0;
+      run += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (bk[r] >= 0) stage[lstart[bk[r]] + rk[r]] = pay[r];
+  __syncthreads();
+  const int total = lstart[n_buckets];
+  for (int i = tid; i < total; i += RP_K0_T) {
+    int lo = 0, hi = n_buckets;  // the bucket with lstart[lo] <= i < lstart[lo + 1] (empty buckets share a start: take the last)
+    while (hi - lo > 1) {
+      const int m = (lo + hi) >> 1;
+      if (lstart[m] <= i) lo = m; else hi = m;
+    }
+    out[hist[lo] + i] = stage[i];
+  }
+}
+
+// Blocks of the bucket passes: bucket b has ceil(size_b / E) of them; blk_off = exclusive scan of that.  One thread per bucket.
+__global__ void k_bucket_blocks(const int32_t* __restrict__ bucket_off, int n_buckets, int32_t* __restrict__ n_blk) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < n_buckets) n_blk[b] = (bucket_off[b + 1] - bucket_off[b] + RP_K0_E - 1) / RP_K0_E;
+}
+
+// FILL = false: deg[item] += the block's count.  FILL = true: xt_idx[xt_ptr[item] + place] = user, place = the block's span of the
+// item's row (one returning global atomic per (block, item) on `cursor`) + the entry's rank inside the block (returning LDS add).
+// A block works on at most E entries of ONE bucket: the item counters are 2^bshift words of LDS.  Blocks are dealt so that the eight
+// XCDs each take a contiguous eighth of them (blockIdx mod 8 names the XCD): the stores of a bucket meet in one L2.
+template <typename PT, bool FILL>
+__global__ void __launch_bounds__(RP_K0_T) k_bucket(const PT* __restrict__ part, const int32_t* __restrict__ bucket_off, const int32_t* __restrict__ blk_off,
+                                                    int n_buckets, int bshift, int ubits, int32_t* __restrict__ deg, const int32_t* __restrict__ xt_ptr,
+                                                    int32_t* __restrict__ cursor, int32_t* __restrict__ xt_idx, int f_lo, int f_hi) {
+  extern __shared__ int cnt[];
+  constexpr int R = RP_K0_E / RP_K0_T;
+  const int tid = threadIdx.x;
+  const int nblk = blk_off[n_buckets];
+  const int per_x = ((int)gridDim.x + 7) >> 3;
+  const int vb = ((int)blockIdx.x & 7) * per_x + ((int)blockIdx.x >> 3);
+  if (vb >= nblk) return;
+  __shared__ int s_b;
+  if (tid == 0) {
+    int lo = 0, hi = n_buckets;  // the bucket with blk_off[lo] <= vb < blk_off[lo + 1] (buckets without blocks share a start: the last)
+    while (hi - lo > 1) {
+      const int m = (lo + hi) >> 1;
+      if (blk_off[m] <= vb) lo = m; else hi = m;
+    }
+    s_b = lo;
+  }
+  const int bw = 1 << bshift;
+  for (int w = tid; w < bw; w += RP_K0_T) cnt[w] = 0;
+  __syncthreads();
+  const int b = s_b;
+  const int e0 = bucket_off[b] + (vb - blk_off[b]) * RP_K0_E, e1 = min(bucket_off[b + 1], e0 + RP_K0_E);
+  const PT umask = ((PT)1 << ubits) - 1;
+  PT pay[R];
+  int rk[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int e = e0 + tid + r * RP_K0_T;
+    pay[r] = 0;
+    rk[r] = -1;
+    if (e < e1) {
+      pay[r] = part[e];
+      rk[r] = atomicAdd(&cnt[(int)(pay[r] >> ubits)], 1);
+    }
+  }
+  __syncthreads();
+  const int item0 = b << bshift;
+  for (int w = tid; w < bw; w += RP_K0_T) {
+    const int c = cnt[w];
+    if (c) {
+      if (FILL)  // (rows outside [f_lo, f_hi) are not wanted - a matrix built for a row range: marked, their entries skipped)
+        cnt[w] = (item0 + w >= f_lo && item0 + w < f_hi) ? xt_ptr[item0 + w] + atomicAdd(&cursor[item0 + w], c) : -1;
+      else
+        atomicAdd(&deg[item0 + w], c);
+    } else if (FILL) {
+      cnt[w] = -1;
+    }
+  }
+  if (!FILL) return;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (rk[r] >= 0) {
+      const int base = cnt[(int)(pay[r] >> ubits)];
+      if (base >= 0) xt_idx[base + rk[r]] = (int32_t)(pay[r] & umask);
+    }
 }
 
 __global__ void k_inv_deg(const int32_t* __restrict__ deg, double* __restrict__ inv, int n) {
@@ -122,7 +286,14 @@ __global__ void k_check_ptr(const int32_t* __restrict__ x_ptr, int n_users, int6
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, __shfl_xor(dmax, o));
-  if ((threadIdx.x & 63) == 0 && dmax > 0) atomicMax(&err[4], dmax);  // longest history
+  // (one atomic per BLOCK: 16 000 waves queueing for one word were 0.16 of this kernel's 0.18 ms)
+  __shared__ int s_max[16];
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = dmax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) dmax = max(dmax, s_max[w]);
+    if (dmax > 0) atomicMax(&err[4], dmax);  // longest history
+  }
 }
 
 int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
@@ -146,18 +317,33 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
   RP_TRY(rp_dev_alloc(ctx, (size_t)std::max<int64_t>(nnz, 1) * sizeof(int32_t), (void**)&m->xt_idx));
   RP_TRY(rp_dev_alloc(ctx, (size_t)std::max<int64_t>(I, 1) * sizeof(int32_t), (void**)&m->deg));
   RP_TRY(rp_dev_alloc(ctx, (size_t)std::max<int64_t>(I, 1) * sizeof(double), (void**)&m->inv_deg));
+  // buckets of 2^bshift consecutive items (512, more when that would give over RP_K0_BUCKET_MAX buckets); a partitioned entry packs
+  // (item inside its bucket, user) into 32 bits when they fit (8M users at 512 items per bucket), into 64 otherwise
+  int bshift = 9;
+  while (((I + ((int64_t)1 << bshift) - 1) >> bshift) > RP_K0_BUCKET_MAX) ++bshift;
+  const int n_buckets = (int)std::max<int64_t>(1, (I + ((int64_t)1 << bshift) - 1) >> bshift);
+  int ubits = 1;
+  while (((int64_t)1 << ubits) < U) ++ubits;
+  const bool wide = bshift + ubits > 32;
+  if (((size_t)4 << bshift) > (size_t)128 * 1024) RP_FAIL(RPHIP_ELIMIT, "n_items=%lld is beyond what K0's bucket pass holds in LDS", (long long)I);
   char* sc = nullptr;
-  const size_t rank_bytes = ((size_t)std::max<int64_t>(nnz, 1) * 4 + 15) & ~(size_t)15;  // keeps p_sum 8-B aligned
-  RP_TRY(rp_scratch(ctx, 0, rank_bytes + 64, (void**)&sc));
-  int32_t* rank = (int32_t*)sc;
-  int32_t* err = (int32_t*)(sc + rank_bytes);
+  const size_t part_bytes = ((size_t)std::max<int64_t>(nnz, 1) * (wide ? 8 : 4) + 15) & ~(size_t)15;  // keeps p_sum 8-B aligned
+  const size_t aux_ints = (size_t)5 * n_buckets + 8 + (size_t)std::max<int64_t>(I, 1);
+  RP_TRY(rp_scratch(ctx, 0, part_bytes + 64 + aux_ints * 4, (void**)&sc));
+  int32_t* err = (int32_t*)(sc + part_bytes);
   unsigned long long* p_sum = (unsigned long long*)(err + 2);
+  int32_t* bucket_cnt = (int32_t*)(sc + part_bytes + 64);  // [nb]
+  int32_t* bucket_fill = bucket_cnt + n_buckets;             // [nb]
+  int32_t* n_blk = bucket_fill + n_buckets;                  // [nb]
+  int32_t* bucket_off = n_blk + n_buckets;                   // [nb + 1]
+  int32_t* blk_off = bucket_off + n_buckets + 1;             // [nb + 1]
+  int32_t* cursor = blk_off + n_buckets + 1;                 // [I]
   hipEvent_t ev;
   rp_time_begin(ctx, &ev);
   RP_HIP(hipMemsetAsync(m->deg, 0, (size_t)std::max<int64_t>(I, 1) * sizeof(int32_t), st));
-  RP_HIP(hipMemsetAsync(err, 0, 64, st));
+  RP_HIP(hipMemsetAsync(err, 0, 64 + aux_ints * 4, st));  // (flags, P, bucket counters, cursor)
   const int bt = 256;
-  const int grid_u = (int)std::min<int64_t>((int64_t)ctx->n_cu * 16, std::max<int64_t>(1, rp_cdiv(U + 1, bt)));
+  const int grid_u = (int)std::min<int64_t>((int64_t)ctx->n_cu * 4, std::max<int64_t>(1, rp_cdiv(U + 1, bt)));
   hipLaunchKernelGGL(k_check_ptr, dim3(grid_u), dim3(bt), 0, st, m->x_ptr, (int)U, nnz, err);
   int32_t h_chk[5] = {0, 0, 0, 0, 0};
   RP_HIP(hipMemcpyAsync(h_chk, err, sizeof(h_chk), hipMemcpyDeviceToHost, st));
@@ -165,21 +351,11 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
   const int32_t h_err = h_chk[0];
   m->max_user_deg = h_chk[4];
   if (h_err) RP_FAIL(RPHIP_EINVAL, "indptr is not a valid row pointer array (not monotone, or indptr[0] != 0, or indptr[-1] != nnz)");
-  // a shard with deg_partial counts (and ranks) only the item rows it will fit: 1 / world of the LDS and global atomics
+  // a shard with deg_partial counts (and fills) only the item rows it will fit
   const int64_t i_lo = m->deg_partial ? std::max<int64_t>(0, m->xt_row_begin) : 0;
   const int64_t i_hi = m->deg_partial ? (m->xt_row_end < 0 ? I : std::min<int64_t>(I, m->xt_row_end)) : I;
-  if (nnz > 0 && I > 0) {
-    const int64_t span = std::max<int64_t>(1, i_hi - i_lo);
-    const int n_ranges = (int)rp_cdiv(span, 32768);
-    const int range_w = (int)rp_cdiv(span, n_ranges);
-    const long long target_blocks = std::max<long long>(1, (long long)ctx->n_cu * 3 / n_ranges);
-    const long long chunk = std::max<long long>(4096, rp_cdiv(nnz, target_blocks));
-    const size_t hl = (size_t)range_w * 4;
-    RP_HIP(hipFuncSetAttribute((const void*)k_rank_hist_ranges, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
-    hipLaunchKernelGGL(k_rank_hist_ranges, dim3((unsigned)rp_cdiv(nnz, chunk), n_ranges), dim3(1024), hl, st, m->x_idx, (long long)nnz, chunk,
-                       (int)I, range_w, m->deg, rank, err, (int)i_lo, (int)i_hi);
-  }
-  RP_TRY(rp_exclusive_scan_i32(ctx, m->deg, m->xt_ptr, I));
+  // (the rows of X^T that are filled: a matrix built for a row range fills those rows only, its degrees cover all items)
+  const int64_t f_lo = std::max<int64_t>(0, m->xt_row_begin), f_hi = m->xt_row_end < 0 ? I : std::min<int64_t>(I, m->xt_row_end);
   if (m->n_tiles > 1) RP_TRY(rp_dev_alloc(ctx, (size_t)std::max<int64_t>(U, 1) * (m->n_tiles + 1) * sizeof(int32_t), (void**)&m->tile_ptr));
   {  // tile-relative columns, padded so that a chunk of eight read at any entry stays inside
     const size_t n_rel = (((size_t)nnz + 15) & ~(size_t)15) + 16;
@@ -187,10 +363,48 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
     RP_HIP(hipMemsetAsync(m->x_rel, 0, n_rel * sizeof(uint16_t), st));
   }
   if (U > 0) {  // (rows without entries still need their tile pointers)
-    const int grid_s = (int)std::min<int64_t>((int64_t)ctx->n_cu * 16, std::max<int64_t>(1, rp_cdiv(U * 8, bt)));
-    hipLaunchKernelGGL(k_scatter, dim3(grid_s), dim3(bt), 0, st, m->x_ptr, m->x_idx, (int)U, m->xt_ptr, rank, m->xt_idx, p_sum,
-                       (int)I, m->n_tiles, m->tile_w, m->tile_ptr, err, (int)std::max<int64_t>(0, m->xt_row_begin),
-                       (int)(m->xt_row_end < 0 ? I : std::min<int64_t>(I, m->xt_row_end)), m->x_rel);
+    const int grid_s = (int)std::min<int64_t>((int64_t)ctx->n_cu * 8, std::max<int64_t>(1, rp_cdiv(U * 8, bt)));
+    hipLaunchKernelGGL(k_rows, dim3(grid_s), dim3(bt), (size_t)n_buckets * 4, st, m->x_ptr, m->x_idx, (int)U, p_sum, (int)I, m->n_tiles, m->tile_w,
+                       m->tile_ptr, err, (int)i_lo, (int)i_hi, m->x_rel, bshift, n_buckets, bucket_cnt);
+  }
+  RP_TRY(rp_exclusive_scan_i32(ctx, bucket_cnt, bucket_off, n_buckets));
+  if (nnz > 0 && I > 0) {
+    const unsigned pgrid = (unsigned)rp_cdiv(nnz, RP_K0_E);
+    const size_t plds = (size_t)RP_K0_E * (wide ? 8 : 4) + ((size_t)2 * n_buckets + 1) * 4 + ((size_t)RP_K0_E + 2) * 4;
+    if (wide) {
+      RP_HIP(hipFuncSetAttribute((const void*)k_partition<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+      hipLaunchKernelGGL(k_partition<uint64_t>, dim3(pgrid), dim3(RP_K0_T), plds, st, m->x_ptr, m->x_idx, (int)U, (long long)nnz, (int)I, (int)i_lo,
+                         (int)i_hi, bshift, ubits, n_buckets, bucket_off, bucket_fill, (uint64_t*)sc);
+    } else {
+      RP_HIP(hipFuncSetAttribute((const void*)k_partition<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+      hipLaunchKernelGGL(k_partition<uint32_t>, dim3(pgrid), dim3(RP_K0_T), plds, st, m->x_ptr, m->x_idx, (int)U, (long long)nnz, (int)I, (int)i_lo,
+                         (int)i_hi, bshift, ubits, n_buckets, bucket_off, bucket_fill, (uint32_t*)sc);
+    }
+    hipLaunchKernelGGL(k_bucket_blocks, dim3((unsigned)rp_cdiv(n_buckets, 256)), dim3(256), 0, st, bucket_off, n_buckets, n_blk);
+    RP_TRY(rp_exclusive_scan_i32(ctx, n_blk, blk_off, n_buckets));
+    const unsigned bgrid = (unsigned)(rp_cdiv(rp_cdiv(nnz, RP_K0_E) + n_buckets, 8) * 8);
+    const size_t blds = (size_t)4 << bshift;
+    if (wide) {
+      RP_HIP(hipFuncSetAttribute((const void*)k_bucket<uint64_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
+      RP_HIP(hipFuncSetAttribute((const void*)k_bucket<uint64_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
+      hipLaunchKernelGGL((k_bucket<uint64_t, false>), dim3(bgrid), dim3(RP_K0_T), blds, st, (const uint64_t*)sc, bucket_off, blk_off, n_buckets, bshift, ubits,
+                         m->deg, nullptr, nullptr, nullptr, 0, 0);
+    } else {
+      RP_HIP(hipFuncSetAttribute((const void*)k_bucket<uint32_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
+      RP_HIP(hipFuncSetAttribute((const void*)k_bucket<uint32_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));
+      hipLaunchKernelGGL((k_bucket<uint32_t, false>), dim3(bgrid), dim3(RP_K0_T), blds, st, (const uint32_t*)sc, bucket_off, blk_off, n_buckets, bshift, ubits,
+                         m->deg, nullptr, nullptr, nullptr, 0, 0);
+    }
+    RP_TRY(rp_exclusive_scan_i32(ctx, m->deg, m->xt_ptr, I));
+    // (a shard's degrees - and with them xt_ptr - cover its own rows [i_lo, i_hi): exactly the rows it fills)
+    if (wide)
+      hipLaunchKernelGGL((k_bucket<uint64_t, true>), dim3(bgrid), dim3(RP_K0_T), blds, st, (const uint64_t*)sc, bucket_off, blk_off, n_buckets, bshift, ubits,
+                         m->deg, m->xt_ptr, cursor, m->xt_idx, (int)f_lo, (int)f_hi);
+    else
+      hipLaunchKernelGGL((k_bucket<uint32_t, true>), dim3(bgrid), dim3(RP_K0_T), blds, st, (const uint32_t*)sc, bucket_off, blk_off, n_buckets, bshift, ubits,
+                         m->deg, m->xt_ptr, cursor, m->xt_idx, (int)f_lo, (int)f_hi);
+  } else {
+    RP_TRY(rp_exclusive_scan_i32(ctx, m->deg, m->xt_ptr, I));
   }
   if (!m->deg_partial)  // (a shard's degrees are completed by rphip_csr_finish_degrees after the all-reduce)
     hipLaunchKernelGGL(k_inv_deg, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, rp_cdiv(I, bt)))), dim3(bt), 0, st,

@@ -101,6 +101,8 @@ struct rphip_comm {
   int device = 0;  // (kept apart: the context may be destroyed before the communicator)
   int world = 1, rank = 0;
   bool is_rccl = false;
+  bool is_loop = false;  // rphip_comm_loopback_create: one rank of a larger run measured alone
+  double loop_bw = 0.0, loop_lat = 0.0;  // bytes per second, seconds
   ncclComm_t nccl = nullptr;
   rphip_comm_ops ops{};
   int64_t bytes_recv = 0, bytes_sent = 0;
@@ -155,6 +157,46 @@ extern "C" int rphip_comm_from_ops(rphip_ctx* ctx, const rphip_comm_ops* ops, rp
   return RPHIP_OK;
 }
 
+// ---- loop-back transport: the time of a transfer without the transfer -----------------------------------------------------------
+__global__ void k_comm_delay(long long ticks) {  // holds its stream: s_memrealtime counts at 100 MHz
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < ticks) __builtin_amdgcn_s_sleep(32);
+}
+__global__ void k_comm_noise(float* __restrict__ p, long long n, unsigned seed) {  // small values of both signs (never all zero: the clock a
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {  // chip holds depends on the data)
+    unsigned h = (unsigned)i * 2654435761u + seed;
+    h ^= h >> 15;
+    h *= 2246822519u;
+    h ^= h >> 13;
+    p[i] = ((float)(h & 0xffffu) - 32768.0f) * (1.0f / 33554432.0f);
+  }
+}
+static void rp_loop_delay(rphip_comm* c, int64_t bytes, hipStream_t st) {
+  const double sec = c->loop_lat + (c->loop_bw > 0.0 ? (double)bytes / c->loop_bw : 0.0);
+  hipLaunchKernelGGL(k_comm_delay, dim3(1), dim3(1), 0, st, (long long)(sec * 1e8));
+}
+static void rp_loop_noise(void* p, int64_t bytes, hipStream_t st, unsigned seed) {
+  const long long n = bytes / 4;
+  if (n > 0) hipLaunchKernelGGL(k_comm_noise, dim3((unsigned)std::min<long long>(4096, rp_cdiv(n, 256))), dim3(256), 0, st, (float*)p, n, seed);
+}
+
+extern "C" int rphip_comm_loopback_create(rphip_ctx* ctx, int32_t world, int32_t rank, double gbytes_per_s, double latency_us, rphip_comm** out) {
+  if (!ctx || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (world < 1 || rank < 0 || rank >= world) RP_FAIL(RPHIP_EINVAL, "rank %d of %d", rank, world);
+  if (!(gbytes_per_s > 0.0) || latency_us < 0.0) RP_FAIL(RPHIP_EINVAL, "the modelled link needs a positive rate and a non-negative latency");
+  rphip_comm* c = new rphip_comm();
+  c->ctx = ctx;
+  c->device = ctx->device;
+  c->world = world;
+  c->rank = rank;
+  c->is_loop = true;
+  c->loop_bw = gbytes_per_s * 1e9;
+  c->loop_lat = latency_us * 1e-6;
+  *out = c;
+  return RPHIP_OK;
+}
+
 extern "C" int rphip_comm_destroy(rphip_comm* c) {
   if (!c) return RPHIP_OK;
   if (c->is_rccl && c->nccl) {
@@ -180,6 +222,7 @@ extern "C" int rphip_comm_info(const rphip_comm* c, int32_t* world, int32_t* ran
   } while (0)
 
 int rp_comm_world(const rphip_comm* c) { return c->world; }
+bool rp_comm_is_loopback(const rphip_comm* c) { return c->is_loop; }
 int rp_comm_rank(const rphip_comm* c) { return c->rank; }
 
 int rp_comm_broadcast(rphip_comm* c, void* buf, int64_t bytes, int root, hipStream_t st) {
@@ -190,6 +233,12 @@ int rp_comm_broadcast(rphip_comm* c, void* buf, int64_t bytes, int root, hipStre
     c->bytes_recv += bytes;
   if (c->is_rccl) {
     RP_NCCL(g_rccl.Broadcast(buf, buf, (size_t)bytes, ncclInt8, root, c->nccl, st));
+    return RPHIP_OK;
+  }
+  if (c->is_loop) {
+    if (c->rank != root) rp_loop_noise(buf, bytes, st, (unsigned)c->bytes_recv);
+    rp_loop_delay(c, bytes, st);
+    RP_HIP(hipGetLastError());
     return RPHIP_OK;
   }
   RP_OPS(c->ops.broadcast(c->ops.self, buf, bytes, root, (void*)st), "broadcast");
@@ -208,6 +257,13 @@ int rp_comm_all_gather(rphip_comm* c, const void* send, void* recv, int64_t byte
     RP_NCCL(g_rccl.AllGather(send, recv, (size_t)bytes_per_rank, ncclInt8, c->nccl, st));
     return RPHIP_OK;
   }
+  if (c->is_loop) {  // every slot takes this rank's own part: data of the right kind and size
+    for (int p = 0; p < c->world; ++p)
+      RP_HIP(hipMemcpyAsync((char*)recv + (size_t)p * bytes_per_rank, send, (size_t)bytes_per_rank, hipMemcpyDeviceToDevice, st));
+    rp_loop_delay(c, bytes_per_rank * (c->world - 1), st);
+    RP_HIP(hipGetLastError());
+    return RPHIP_OK;
+  }
   RP_OPS(c->ops.all_gather(c->ops.self, send, recv, bytes_per_rank, (void*)st), "all_gather");
   return RPHIP_OK;
 }
@@ -220,10 +276,29 @@ int rp_comm_exchange(rphip_comm* c, const void* send, const int64_t* soff, const
       c->bytes_sent += sbytes[p];
       c->bytes_recv += rbytes[p];
     }
-  if (c->world == 1 || c->is_rccl) {
+  if (c->world == 1 || c->is_rccl || c->is_loop) {
     if (sbytes[me] > 0)
       RP_HIP(hipMemcpyAsync((char*)recv + roff[me], (const char*)send + soff[me], (size_t)sbytes[me], hipMemcpyDeviceToDevice, st));
     if (c->world == 1) return RPHIP_OK;
+    if (c->is_loop) {
+      int64_t in = 0, outb = 0;
+      for (int p = 0; p < c->world; ++p) {
+        if (p == me) continue;
+        in += rbytes[p];
+        outb += sbytes[p];
+        // what comes from rank p: this rank's own piece FOR rank p when it is large enough (data of the right kind - lists of
+        // (column, score), blocks of the matrix), noise otherwise
+        if (rbytes[p] > 0) {
+          if (sbytes[p] >= rbytes[p])
+            RP_HIP(hipMemcpyAsync((char*)recv + roff[p], (const char*)send + soff[p], (size_t)rbytes[p], hipMemcpyDeviceToDevice, st));
+          else
+            rp_loop_noise((char*)recv + roff[p], rbytes[p] & ~(int64_t)3, st, (unsigned)(p * 977 + 13));
+        }
+      }
+      rp_loop_delay(c, std::max(in, outb), st);
+      RP_HIP(hipGetLastError());
+      return RPHIP_OK;
+    }
     RP_NCCL(g_rccl.GroupStart());
     for (int p = 0; p < c->world; ++p) {
       if (p == me) continue;
@@ -241,6 +316,11 @@ int rp_comm_all_reduce_sum_i32(rphip_comm* c, int32_t* buf, int64_t count, hipSt
   if (count <= 0 || c->world == 1) return RPHIP_OK;
   if (c->is_rccl) {
     RP_NCCL(g_rccl.AllReduce(buf, buf, (size_t)count, ncclInt32, ncclSum, c->nccl, st));
+    return RPHIP_OK;
+  }
+  if (c->is_loop) {  // (the buffer keeps this rank's own part)
+    rp_loop_delay(c, 2 * count * 4, st);
+    RP_HIP(hipGetLastError());
     return RPHIP_OK;
   }
   RP_OPS(c->ops.all_reduce_sum_i32(c->ops.self, buf, count, (void*)st), "all_reduce_sum_i32");
@@ -760,7 +840,7 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
   ctx->dist_stats[5] = nb;
   ctx->dist_stats[6] = n_pad;
   ctx->dist_stats[7] = (int64_t)flop;
-  if (h_info) {
+  if (h_info && !comm->is_loop) {  // (a loop-back run works on noise: its result is meaningless by contract, its timing is the point)
     rp_set_error("a pivot block is not positive definite on some rank (flag sum %d): G + l2*I is not positive definite", h_info);
     return fail(RPHIP_ENUMERIC);
   }

@@ -1372,6 +1372,8 @@ extern "C" int rphip_itemknn_gather(rphip_ctx* ctx, rphip_comm* comm, const rphi
     hipEvent_t ev;
     rp_time_begin(ctx, &ev);
     const long long rows = local->row_end - local->row_begin;
+    // (a loop-back run hands every slot this rank's own send buffer: the part of it behind the rank's rows must read as empty lists)
+    if (rp_comm_is_loopback(comm)) hipMemsetAsync(sendb, 0, (size_t)slot, st);
     if (rows > 0)
       hipLaunchKernelGGL(k_pack_shard, dim3((unsigned)std::min<long long>(4096, rp_cdiv(rows * K, 256))), dim3(256), 0, st, local->idx, local->val, local->nnz,
                          rows, K, max_rows, sendb);

@@ -128,6 +128,50 @@ def test_k_limit_raises_before_upload():
         recpack_amd.ItemKNN(K=RP_K_MAX + 1).fit(X)
 
 
+def test_fitted_models_pickle_round_trip(tmp_path):
+    """A fitted drop-in estimator goes through pickle / joblib as a BaseEstimator user expects (recpack/algorithms/base.py:33):
+    the device handle stays behind, the model travels as host arrays and is uploaded again on first use (here: without a GPU that
+    first use raises - there is no CPU fallback - but the round trip itself needs no device)."""
+    import pickle
+
+    import joblib
+    import torch
+
+    import recpack_amd
+    from recpack_amd._lib import RecpackHipError
+
+    idx = np.array([[1, 2], [0, 2], [0, 1]], dtype=np.int32)
+    val = np.array([[0.5, 0.8], [0.5, 0.8], [0.8, 0.8]])
+    nnz = np.array([2, 2, 2], dtype=np.int32)
+    knn = recpack_amd.ItemKNN(K=2)
+    knn._model_host = ("topk", idx, val, nnz)
+    knn._empty_rows_ = 0
+    knn.similarity_matrix_ = recpack_amd.algorithms.topk_arrays_to_csr(idx, val, nnz, 3)
+    B = np.array([[0.0, 0.1, 0.9], [0.2, 0.0, 0.2], [0.9, 0.1, 0.0]], dtype=np.float32)
+    ease = recpack_amd.EASE(l2=0.03)
+    ease._model_host = ("dense", B)
+    ease.n_items_ = 3
+    ease._empty_rows_ = 0
+    for algo, how in ((knn, "pickle"), (ease, "joblib")):
+        if how == "pickle":
+            back = pickle.loads(pickle.dumps(algo))
+        else:
+            joblib.dump(algo, tmp_path / "m.joblib")
+            back = joblib.load(tmp_path / "m.joblib")
+        assert type(back) is type(algo) and back.get_params() == algo.get_params() and back.identifier == algo.identifier
+        assert back._model_dev is None and back._model_host[0] == algo._model_host[0]
+        for a, b in zip(back._model_host[1:], algo._model_host[1:]):
+            np.testing.assert_array_equal(a, b)
+        assert back._empty_rows_ == 0
+        if not torch.cuda.is_available():
+            with pytest.raises(RecpackHipError):
+                back._model  # the first use uploads: no device, no model - never a host computation
+    assert (pickle.loads(pickle.dumps(knn)).similarity_matrix_ != knn.similarity_matrix_).nnz == 0
+    # an unfitted estimator round-trips too
+    fresh = pickle.loads(pickle.dumps(recpack_amd.ItemKNN(K=7)))
+    assert fresh.K == 7 and fresh._model_host is None
+
+
 def test_host_code_under_asan():
     """sanitizers belong on the CPU build.  `make -C recpack_amd/csrc asan` compiles the HOST side of rp_api.hip
     (context, block cache with event-carrying frees, grow-only scratch, options, timing bookkeeping, argument validation) with

@@ -19,8 +19,8 @@ U, I, _ = CONFIGS[cfg]
 ctx = _lib.Context(0)
 best = None
 for it in range(3):
-    dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
     ctx.reset_timings()
+    dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
     m = _lib.itemknn_fit(ctx, dX, 200)
     ctx.sync()
     tm = ctx.timings()
