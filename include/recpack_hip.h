@@ -115,22 +115,21 @@ int rphip_ctx_trim(rphip_ctx* ctx);
  *                       when that does not fit or Kp > 488.
  *   "predict_half_tile" columns per tile of that first pass (default 11200, at most 16384; 0 = the model's own tiling).  Tiles of
  *                       half the LDS let two workgroups share a CU: one streams rows while the other selects.
- *   "gemm_mode"         2 (default) | 1 | 0: how the O(n^3) products of the EASE solve (and rphip_gemm_nt_f32) multiply their fp32 operands.
+ *   "gemm_mode"         2 (default) | 0: how the O(n^3) products of the EASE solve (and rphip_gemm_nt_f32) multiply their fp32 operands.
  *                       2: two fp16 planes per operand, both rounded to nearest (x = h1 + h2 to 2^-24 |x|), three plane products per
  *                          step on v_mfma_f32_32x32x16_f16; each operand is scaled by a power of two taken from its largest magnitude
  *                          over the rows and K range the launch reads (one extra pass over the operands), so fp16's range is never
  *                          left; fp32 accumulate.  Entries below 2^-18 of that magnitude are held to an absolute 2^-40 of it
- *                          instead of fp32's relative 2^-24 (rows of very different size: use mode 1 or 0).  1: three bf16 planes by truncation, six plane products (no scaling pass).
- *                          0: the fp32-input MFMA (v_mfma_f32_32x32x2_f32).  Error of one product, relative to sum |a||b|:
- *                          the same for all three (2e-8 .. 2.5e-7); speed on MI355X 216 / 165 / 113 TFLOP/s fp32-equivalent.
+ *                          instead of fp32's relative 2^-24 (rows of very different size: use mode 0).
+ *                          0: the fp32-input MFMA (v_mfma_f32_32x32x2_f32): the cross-check.  Error of one product, relative to
+ *                          sum |a||b|: the same for both (2e-8 .. 2.5e-7); speed on MI355X 360 / 113 TFLOP/s fp32-equivalent.
+ *                          (Round 2's three-bf16-plane mode 1 was removed in round 4: slower than 2, no more exact than 0.)
  *   "gemm_presplit"     1 (default) | 0.  gemm_mode 2: products with at least 512 tiles cut their operands into planes ONCE per K chunk
  *                       (a workspace laid out in MFMA fragment order) and run a product kernel staged by LDS-DMA loads with no
  *                       conversion arithmetic (363 against 225 TFLOP/s fp32-equivalent on a square product); 0: every workgroup
  *                       converts the tiles it stages.
  *   "gemm_workspace_bytes"  bytes of plane workspace per operand of those products (default 4 GiB, at least 64 MiB): sets the K
  *                       chunk; a product on a side stream has a second pair.  rphip_ctx_trim releases them.
- *   "gemm_shape16"      1 (default) | 0.  The plane product kernel on v_mfma_f32_16x16x32_f16 (the chip holds a higher clock on it:
- *                       363 against 314 TFLOP/s) or on v_mfma_f32_32x32x16_f16.
  *   "gemm_wide"         1 (default) | 0.  The plane product kernel on 256 x 128 tiles, eight waves, three LDS stages with counted
  *                       waits (k_gemm_hp16w; bit-identical results, +2..6 %) or on 128 x 128 tiles with two stages.
  *   "chol_sub_panel"    8 (default) | 0 .. 32 tiles.  The blocked Cholesky of the EASE solve works in panels of 32 tiles (16 below 640
@@ -376,27 +375,12 @@ int rphip_model_empty_rows(rphip_ctx* ctx, const rphip_model* m, int64_t* out);
 int rphip_gemm_nt_f32(rphip_ctx* ctx, int64_t M, int64_t N, int64_t K, float alpha, const float* A_dev, int64_t lda,
                       const float* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc);
 
-/* ---- building blocks of the multi-GPU EASE solve ---------------------------------------------------------------
- * One process per GPU holds the matrix in its own device memory; the collectives (RCCL through torch.distributed)
- * run between these calls (recpack_amd/dist.py::ease_fit_sharded).
- *
- * rphip_ease_gram_rows: rows [row_begin, row_end) of G + l2*I (ease.py:78-82) into a row-major matrix with n_cols
- * columns (n_cols >= n_items: rows/columns past n_items carry an identity block), leading dimension ld. */
-int rphip_ease_gram_rows(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int64_t n_cols, double l2,
-                         float* G_dev, int64_t ld);
-/* ---- column-sharded EASE (multi-GPU: SURVEY.md 8(e); the reference has no multi-GPU path, base.py:454-455 leaves it as a TODO) ----
- * Every rank owns a slab of item COLUMNS of the n x n matrix (all rows; row-major, ld = slab width) in caller-owned device
- * memory.  recpack_amd/dist.py::ease_fit_sharded drives these between its collectives (one panel broadcast per pivot block):
- *   rphip_ease_gram_rows + rphip_transpose_f32   G + l2 I, the rank's columns (Gram rows transposed: G is symmetric; ease.py:81)
- *   rphip_spd_inverse_f32                        P = A_KK^-1 of a pivot block (in place; blocked Cholesky on MFMA tiles)
- *   rphip_gemm_nt_f32                            T = A[:, K] P and the slab update A[:, J] -= T A[K, J]   (np.linalg.inv, ease.py:82)
- *   rphip_ease_scale_cols                        B_ij = -P_ij / P_jj * w_j, B_jj = 0 on the slab (ease.py:85-90)
- *   rphip_model_from_dense_cols                  a model on the slab: predict scores the slab's columns only
- *   rphip_predict_merge_topk                     per-user merge of the ranks' local top-Kp lists (metrics/base.py:189 on the union) */
-int rphip_spd_inverse_f32(rphip_ctx* ctx, float* A_dev, int64_t n, int64_t ld);
-int rphip_transpose_f32(rphip_ctx* ctx, const float* src_dev, int64_t lds, int64_t rows, int64_t cols, float* dst_dev, int64_t ldd);
-int rphip_ease_scale_cols(rphip_ctx* ctx, const rphip_csr* X, float* S_dev, int64_t ld, int64_t n_rows, int64_t col_begin, int64_t n_cols,
-                          double alpha);
+/* ---- column slabs of a dense model (multi-GPU predict: SURVEY.md 8(e); the reference has no multi-GPU path, base.py:454-455) ----
+ *   rphip_model_from_dense_cols   a model on a slab of item COLUMNS of B (all rows; row-major, caller-owned device memory, not
+ *                                 copied: it must outlive the model): predict scores the slab's columns only
+ *   rphip_predict_merge_topk      per-user merge of the ranks' local top-Kp lists (metrics/base.py:189 on the union)
+ * (Round 2's torch-driven solve - rphip_ease_gram_rows, rphip_transpose_f32, rphip_spd_inverse_f32, rphip_ease_scale_cols - was
+ * removed in round 4: the distributed solve lives in the library, rphip_ease_fit_dist below.) */
 int rphip_model_from_dense_cols(rphip_ctx* ctx, int64_t n_items, int64_t col_begin, int64_t n_cols, float* B_dev, int64_t ld,
                                 rphip_model** out);
 int rphip_predict_merge_topk(rphip_ctx* ctx, int32_t n_lists, int32_t Kp, int64_t n_users, const int32_t* cand_idx_dev,
@@ -433,9 +417,10 @@ int rphip_comm_rccl_create(rphip_ctx* ctx, int32_t world, int32_t rank, const vo
 int rphip_comm_from_ops(rphip_ctx* ctx, const rphip_comm_ops* ops, rphip_comm** out);
 /* A LOOP-BACK communicator for measuring ONE rank of a `world`-rank run on a single GPU (tools/dist_rank_emulate.py): every
  * operation is stream-ordered and asynchronous like the RCCL ones, moves no data between ranks - what a rank would receive is
- * filled with its own data or small noise of the right size - and holds its stream for latency_us + bytes / gbytes_per_s, bytes =
- * what the rank would receive (broadcast root: what it sends).  The results of a run on it are meaningless; its kernel sequence,
- * launch for launch, is rank `rank`'s.  The reference has no multi-GPU path (recpack/algorithms/base.py:454-455 TODO). */
+ * filled with its own data or small noise of the right size - and holds its stream for latency_us + bytes / gbytes_per_s, where
+ * gbytes_per_s is the rate of ONE link of a fully connected node (xGMI: every pair of GPUs has its own) and bytes what the busiest
+ * link carries: a broadcast its whole message, an all-gather one rank's part, an exchange the largest piece to or from one peer.
+ * The results of a run on it are meaningless; its kernel sequence, launch for launch, is rank `rank`'s.  The reference has no multi-GPU path (recpack/algorithms/base.py:454-455 TODO). */
 int rphip_comm_loopback_create(rphip_ctx* ctx, int32_t world, int32_t rank, double gbytes_per_s, double latency_us, rphip_comm** out);
 int rphip_comm_destroy(rphip_comm* comm);
 int rphip_comm_info(const rphip_comm* comm, int32_t* world, int32_t* rank, int32_t* is_rccl);
@@ -487,8 +472,6 @@ int rphip_potrf_trtri_128(rphip_ctx* ctx, float* A_dev, int64_t lda, float* W_de
 int rphip_gemm_nt_f32_ex(rphip_ctx* ctx, int64_t M, int64_t N, int64_t k_begin, int64_t k_end, float alpha, const float* A_dev,
                          int64_t lda, const float* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc, int32_t k_from_row,
                          int32_t k_from_col, int64_t m_off, int64_t n_off, int32_t lower_only);
-/* a dense model on caller-owned device memory (not copied; must outlive the model) */
-int rphip_model_from_dense_device(rphip_ctx* ctx, int64_t n_items, float* B_dev, int64_t ld, rphip_model** out);
 
 #ifdef __cplusplus
 }

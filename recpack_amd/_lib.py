@@ -106,13 +106,8 @@ PROTOTYPES = {
     "rphip_ease_xy_fit": (C.c_int, [_p, _p, _p, _f64, _f64, _pp]),
     "rphip_ease_gram_create": (C.c_int, [_p, _p, _pp]),
     "rphip_ease_fit_gram": (C.c_int, [_p, _p, _p, _f64, _f64, _pp]),
-    "rphip_ease_gram_rows": (C.c_int, [_p, _p, _i64, _i64, _i64, _f64, _p, _i64]),
     "rphip_potrf_trtri_128": (C.c_int, [_p, _p, _i64, _p, _p]),
     "rphip_gemm_nt_f32_ex": (C.c_int, [_p, _i64, _i64, _i64, _i64, C.c_float, _p, _i64, _p, _i64, C.c_float, _p, _i64, _i32, _i32, _i64, _i64, _i32]),
-    "rphip_model_from_dense_device": (C.c_int, [_p, _i64, _p, _i64, _pp]),
-    "rphip_spd_inverse_f32": (C.c_int, [_p, _p, _i64, _i64]),
-    "rphip_transpose_f32": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _i64]),
-    "rphip_ease_scale_cols": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _i64, _f64]),
     "rphip_model_from_dense_cols": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _pp]),
     "rphip_predict_merge_topk": (C.c_int, [_p, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p]),
     "rphip_comm_rccl_unique_id": (C.c_int, [_p]),
@@ -411,16 +406,6 @@ class Model:
         check(ctx.lib.rphip_model_from_topk_device(ctx.handle, int(idx_t.shape[0]), int(idx_t.shape[1]), C.c_void_p(idx_t.data_ptr()),
                                                    C.c_void_p(val_t.data_ptr()), C.c_void_p(nnz_t.data_ptr()), C.byref(h)))
         return cls(ctx, h)
-
-    @classmethod
-    def from_dense_device(cls, ctx: Context, n_items: int, B_t):
-        """A dense model on a torch float32 CUDA matrix (not copied; kept alive by the model object)."""
-        _torch_inputs_ready(ctx)
-        h = C.c_void_p()
-        check(ctx.lib.rphip_model_from_dense_device(ctx.handle, int(n_items), C.c_void_p(B_t.data_ptr()), B_t.stride(0), C.byref(h)))
-        m = cls(ctx, h)
-        m._keep = B_t
-        return m
 
     @classmethod
     def from_dense_cols(cls, ctx: Context, n_items: int, col_begin: int, n_cols: int, B_t):
@@ -824,43 +809,6 @@ def potrf_trtri_128(ctx: Context, A_block_t, W_t, info_t):
     _torch_inputs_ready(ctx)
     check(ctx.lib.rphip_potrf_trtri_128(ctx.handle, C.c_void_p(A_block_t.data_ptr()), A_block_t.stride(0), C.c_void_p(W_t.data_ptr()),
                                         C.c_void_p(info_t.data_ptr())))
-
-
-def ease_gram_rows(ctx: Context, X: DeviceCSR, row_begin: int, row_end: int, l2: float, G_t):
-    """Rows [row_begin, row_end) of G + l2*I into the square torch matrix G_t (identity block on the padding)."""
-    _torch_inputs_ready(ctx)
-    check(ctx.lib.rphip_ease_gram_rows(ctx.handle, X.handle, int(row_begin), int(row_end), int(G_t.shape[1]), float(l2),
-                                       C.c_void_p(G_t.data_ptr()), G_t.stride(0)))
-
-
-def ease_gram_rows_into(ctx: Context, X: DeviceCSR, row_begin: int, row_end: int, l2: float, stage_t, n_cols: int):
-    """Rows [row_begin, row_end) of G + l2*I (n_cols columns, identity block on the padding) into stage_t[0 : row_end - row_begin]:
-    a staging buffer whose row 0 stands for matrix row row_begin."""
-    _torch_inputs_ready(ctx)
-    assert stage_t.shape[0] >= row_end - row_begin and stage_t.shape[1] >= n_cols
-    base = stage_t.data_ptr() - int(row_begin) * stage_t.stride(0) * 4  # the entry point indexes rows absolutely
-    check(ctx.lib.rphip_ease_gram_rows(ctx.handle, X.handle, int(row_begin), int(row_end), int(n_cols), float(l2), C.c_void_p(base), stage_t.stride(0)))
-
-
-def spd_inverse(ctx: Context, A_t):
-    """In-place inverse of a symmetric positive definite torch float32 CUDA matrix (size a multiple of 128)."""
-    _torch_inputs_ready(ctx)
-    check(ctx.lib.rphip_spd_inverse_f32(ctx.handle, C.c_void_p(A_t.data_ptr()), A_t.shape[0], A_t.stride(0)))
-
-
-def transpose(ctx: Context, src_t, dst_t):
-    """dst_t = src_t.T (torch float32 CUDA matrices, row strides free, sizes multiples of 32)."""
-    _torch_inputs_ready(ctx)
-    rows, cols = src_t.shape
-    assert tuple(dst_t.shape) == (cols, rows) and src_t.stride(1) == 1 and dst_t.stride(1) == 1
-    check(ctx.lib.rphip_transpose_f32(ctx.handle, C.c_void_p(src_t.data_ptr()), src_t.stride(0), rows, cols, C.c_void_p(dst_t.data_ptr()), dst_t.stride(0)))
-
-
-def ease_scale_cols(ctx: Context, X: DeviceCSR, S_t, col_begin: int, alpha: float = 0.0):
-    """K7 on a column slab S_t = +-P[:, col_begin : col_begin + S_t.shape[1]] (all rows), in place."""
-    _torch_inputs_ready(ctx)
-    check(ctx.lib.rphip_ease_scale_cols(ctx.handle, X.handle, C.c_void_p(S_t.data_ptr()), S_t.stride(0), S_t.shape[0], int(col_begin), S_t.shape[1],
-                                        float(alpha)))
 
 
 def predict_merge_topk(ctx: Context, cand_idx_t, cand_val_t, cand_nnz_t, idx_t, val_t, nnz_t):

@@ -21,9 +21,11 @@ warning texts and exception messages ARE the interface recpack's Pipeline, regis
 this module is original.  When recpack itself is importable, :class:`Algorithm` additionally derives from recpack's own
 ``Algorithm`` so that ``isinstance`` / ``issubclass`` checks in recpack (e.g. the algorithm registry) accept these classes.
 
-Limit (a deviation from the reference, which accepts any K): the effective ``K`` of a fit and the ``K`` of ``predict_topk``
-are at most :data:`RP_K_MAX` = 2048 (the selection's LDS buffers); larger values raise ``ValueError`` before anything is
-uploaded.
+Limit (a deviation from the reference, which accepts any K): with more than :data:`RP_TILE_MAX` = 25 600 items (several column
+tiles) - and for the ``normalize_X`` and time-aware fits at any size - the effective ``K`` of a fit is at most :data:`RP_K_MAX` =
+2048 (the per-tile candidate lists of a row meet in the LDS of a merge); up to 25 600 items ``ItemKNN`` takes any ``K`` (round 4).
+The ``K`` of ``predict_topk`` - an extension, not part of the reference - is at most 2048.  Larger values raise ``ValueError``
+before anything is uploaded.
 """
 from __future__ import annotations
 
@@ -42,7 +44,8 @@ from recpack_amd import _lib
 
 logger = logging.getLogger("recpack")
 
-RP_K_MAX = 2048  # rp_common.h: largest effective K / Kp of one call
+RP_K_MAX = 2048  # rp_common.h: largest effective K of a fit over several column tiles, and largest Kp of the fused top-Kp
+RP_TILE_MAX = 25600  # rp_common.h: items of one column tile - up to here ItemKNN takes any K (round 4)
 
 try:  # recpack's own base class, when it is installed: registry / isinstance checks then accept the classes below
     from recpack.algorithms.base import Algorithm as _RecpackAlgorithm
@@ -314,8 +317,9 @@ class ItemKNN(TopKItemSimilarityMatrixAlgorithm):
         self.normalize_sim = normalize_sim
 
     def _fit(self, X: sp.csr_matrix) -> None:
-        if min(int(self.K), max(1, X.shape[1] - 1)) > RP_K_MAX:
-            raise ValueError(f"K={self.K} exceeds the supported maximum of {RP_K_MAX} neighbours per item")
+        if min(int(self.K), max(1, X.shape[1] - 1)) > RP_K_MAX and (X.shape[1] > RP_TILE_MAX or self.normalize_X):
+            raise ValueError(f"K={self.K} exceeds the supported maximum of {RP_K_MAX} neighbours per item for {X.shape[1]} items "
+                             f"(any K up to {RP_TILE_MAX} items)")
         ctx, dX = self._upload(X)
         try:
             if self.similarity == "cosine":

@@ -310,10 +310,8 @@ extern "C" int rphip_ctx_set_option(rphip_ctx* ctx, const char* name, int64_t va
     if (value != 2048 && value != 4096) RP_FAIL(RPHIP_EINVAL, "predict_tile32 must be 2048 or 4096");
     ctx->pw_wt32 = (int)value;
   } else if (!strcmp(name, "gemm_mode")) {
-    if (value < 0 || value > 2) RP_FAIL(RPHIP_EINVAL, "gemm_mode must be 0 (fp32), 1 (bf16 x 3) or 2 (fp16 x 2)");
+    if (value != 0 && value != 2) RP_FAIL(RPHIP_EINVAL, "gemm_mode must be 0 (fp32 MFMA) or 2 (two fp16 planes)");
     ctx->gemm_mode = (int)value;
-  } else if (!strcmp(name, "gemm_shape16")) {
-    ctx->gemm_shape16 = value ? 1 : 0;
   } else if (!strcmp(name, "gemm_wide")) {
     ctx->gemm_wide = value ? 1 : 0;
   } else if (!strcmp(name, "chol_sub_panel")) {

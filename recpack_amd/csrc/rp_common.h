@@ -90,10 +90,9 @@ struct rphip_ctx {
   int predict_half = 1;      // dense models: K9 as two passes (fp16 rows for a candidate list, then exact f32 scores of the candidates)
   int predict_half_w = 11200;  // columns per tile of that first pass (0: the model's own tiling, one workgroup per CU)
   int pw_wt32 = 4096;        // tile width of the 32-bit sums: 2048 or 4096 (tuning)
-  int gemm_mode = 2;         // operands of the solve's products: 0 fp32 MFMA, 1 three bf16 planes (6 products), 2 two fp16 planes (3 products)
+  int gemm_mode = 2;         // operands of the solve's products: 0 fp32 MFMA (cross-check), 2 two fp16 planes (3 products; default)
   int gemm_supertile = 0;    // 1: GEMM workgroups walk the tiles in XCD-round-robin 8 x 8 supertiles (0: row-major 2-D grid)
   int gemm_presplit = 1;     // mode 2: products with many tiles cut their operands into planes once (workspace) and run k_gemm_hp
-  int gemm_shape16 = 1;      // k_gemm_hp on v_mfma_f32_16x16x32_f16 (default; the chip holds a higher clock on it) or 32x32x16
   int gemm_wide = 1;         // the plane product kernel on 256 x 128 tiles with three LDS stages (k_gemm_hp16w) instead of 128 x 128 / two
   size_t gemm_ws_bytes = (size_t)4 << 30;  // workspace per operand of those products (sets their K chunk)
   int chol_sub = 8;          // tiles per sub-panel of the blocked Cholesky (0: one level of panels)

@@ -274,184 +274,6 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(rp_gemm_args g) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int BLD = 24;  // plane row stride in bf16 elements
 
-__global__ void __launch_bounds__(256, 2) k_gemm_nt_b3(rp_gemm_args g) {
-  // two buffers per operand (one barrier per step); the compensation terms lo live in REGISTERS here, packed two bf16 per
-  // word (32 registers): without the 32 KB of LDS they take in the fp32 kernel both buffers fit twice per CU
-  __shared__ __attribute__((aligned(16))) unsigned short As[2][3][GT * BLD];
-  __shared__ __attribute__((aligned(16))) unsigned short Bs[2][3][GT * BLD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  int tm, tn;
-  if (!rp_gemm_tile(g, tm, tn)) return;
-  const int m0 = tm * GT, n0 = tn * GT;
-  if (rp_gemm_skip(g, m0, n0)) return;
-  int kb = g.k0, ke = g.k1;
-  if (g.part) {
-    kb = g.k0 + (int)blockIdx.z * g.k_chunk;
-    ke = min(g.k1, kb + g.k_chunk);
-  }
-  if (g.kb_m) kb = max(kb, g.m_off + m0);
-  if (g.kb_n) kb = max(kb, g.n_off + n0);
-  if (g.ke_n) ke = min(ke, g.n_off + n0 + GT);
-  kb &= ~(GBK - 1);
-
-  f32x16 acc[2][2], hi[2][2];
-  uint32_t lo[2][2][8];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = hi[i][j][r] = 0.0f;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) lo[i][j][r] = 0u;
-    }
-  auto flush = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const uint32_t pk = lo[i][j][r >> 1];
-          float l0 = __uint_as_float(pk << 16), l1 = __uint_as_float(pk & 0xffff0000u);
-          const float a0 = acc[i][j][r], a1 = acc[i][j][r + 1];
-          const float h0 = hi[i][j][r], h1 = hi[i][j][r + 1];
-          const float s0 = h0 + a0, s1 = h1 + a1;
-          const float b0 = s0 - h0, b1 = s1 - h1;
-          l0 += (h0 - (s0 - b0)) + (a0 - b0);
-          l1 += (h1 - (s1 - b1)) + (a1 - b1);
-          hi[i][j][r] = s0;
-          hi[i][j][r + 1] = s1;
-          acc[i][j][r] = 0.0f;
-          acc[i][j][r + 1] = 0.0f;
-          lo[i][j][r >> 1] = rp_pack_bf16_rn(l0, l1);
-        }
-  };
-
-  if (kb < ke) {
-    const int lr = tid >> 1, lk = (tid & 1) * 8;  // one row, eight consecutive K per thread and operand
-    const float* Ap = g.A + (long long)(m0 + lr) * g.lda + lk;
-    const float* Bp = g.B + (long long)(n0 + lr) * g.ldb + lk;
-    float4 ra0, ra1, rb0, rb1;
-    auto gload = [&](int k) {
-      ra0 = *reinterpret_cast<const float4*>(Ap + k);
-      ra1 = *reinterpret_cast<const float4*>(Ap + k + 4);
-      rb0 = *reinterpret_cast<const float4*>(Bp + k);
-      rb1 = *reinterpret_cast<const float4*>(Bp + k + 4);
-    };
-    // eight floats -> three planes of eight bf16 (truncation splits; every residual is exact)
-    auto split_store = [&](const float4& u0, const float4& u1, unsigned short (*dst)[GT * BLD]) {
-      const float x[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
-      uint32_t p1[8], p2[8], p3[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        p1[e] = __float_as_uint(x[e]) & 0xffff0000u;
-        const float r1 = x[e] - __uint_as_float(p1[e]);
-        p2[e] = __float_as_uint(r1) & 0xffff0000u;
-        const float r2 = r1 - __uint_as_float(p2[e]);
-        p3[e] = __float_as_uint(r2);
-      }
-      uint4 w1, w2, w3;  // pairs packed: element 2q in the low half
-      w1.x = __builtin_amdgcn_perm(p1[1], p1[0], 0x07060302u);
-      w1.y = __builtin_amdgcn_perm(p1[3], p1[2], 0x07060302u);
-      w1.z = __builtin_amdgcn_perm(p1[5], p1[4], 0x07060302u);
-      w1.w = __builtin_amdgcn_perm(p1[7], p1[6], 0x07060302u);
-      w2.x = __builtin_amdgcn_perm(p2[1], p2[0], 0x07060302u);
-      w2.y = __builtin_amdgcn_perm(p2[3], p2[2], 0x07060302u);
-      w2.z = __builtin_amdgcn_perm(p2[5], p2[4], 0x07060302u);
-      w2.w = __builtin_amdgcn_perm(p2[7], p2[6], 0x07060302u);
-      w3.x = __builtin_amdgcn_perm(p3[1], p3[0], 0x07060302u);
-      w3.y = __builtin_amdgcn_perm(p3[3], p3[2], 0x07060302u);
-      w3.z = __builtin_amdgcn_perm(p3[5], p3[4], 0x07060302u);
-      w3.w = __builtin_amdgcn_perm(p3[7], p3[6], 0x07060302u);
-      *reinterpret_cast<uint4*>(&dst[0][lr * BLD + lk]) = w1;
-      *reinterpret_cast<uint4*>(&dst[1][lr * BLD + lk]) = w2;
-      *reinterpret_cast<uint4*>(&dst[2][lr * BLD + lk]) = w3;
-    };
-    gload(kb);
-    split_store(ra0, ra1, As[0]);
-    split_store(rb0, rb1, Bs[0]);
-    __syncthreads();
-    // fragment of a 32-row block: lane (r = lane & 31, h = lane >> 5) holds row r, k = 8h .. 8h+7 (cdna guide, operand maps)
-    const int arow = (wr * 64 + (lane & 31)) * BLD + (lane >> 5) * 8;
-    const int brow = (wc * 64 + (lane & 31)) * BLD + (lane >> 5) * 8;
-    int since = 0, cur = 0;
-    for (int k = kb; k < ke; k += GBK) {
-      const bool more = (k + GBK) < ke;
-      if (more) gload(k + GBK);
-      bf16x8 a[3][2], b[3][2];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          a[p][i] = *reinterpret_cast<const bf16x8*>(&As[cur][p][arow + i * 32 * BLD]);
-          b[p][i] = *reinterpret_cast<const bf16x8*>(&Bs[cur][p][brow + i * 32 * BLD]);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          f32x16 c = acc[i][j];  // small products first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);
-          acc[i][j] = c;
-        }
-      if (more) {  // the next tile goes to the other buffer: one barrier per step
-        split_store(ra0, ra1, As[cur ^ 1]);
-        split_store(rb0, rb1, Bs[cur ^ 1]);
-      }
-      since += GBK;
-      if (since >= g.kc && more) {
-        flush();
-        since = 0;
-      }
-      __syncthreads();
-      cur ^= 1;
-    }
-  }
-  flush();  // the last piece
-  // (C's old values all at once, into the dead accumulators, then arithmetic and stores: see k_gemm_hp16w's epilogue)
-  const bool rmw = !g.part && g.beta != 0.0f;
-  if (rmw) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int col = (g.tri == 3 ? 0 : n0) + wc * 64 + j * 32 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          acc[i][j][r] = g.C[(long long)row * g.ldc + col];
-        }
-      }
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = (g.tri == 3 ? 0 : n0) + wc * 64 + j * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const uint32_t pk = lo[i][j][r >> 1];
-        const float h = hi[i][j][r];
-        const float l = (r & 1) ? __uint_as_float(pk & 0xffff0000u) : __uint_as_float(pk << 16);
-        if (g.part) {
-          g.part[((long long)blockIdx.z * g.M + row) * g.N + col] = h + l;
-        } else {
-          const float v = rmw ? fmaf(g.alpha, h, g.beta * acc[i][j][r]) : g.alpha * h;
-          g.C[(long long)row * g.ldc + col] = fmaf(g.alpha, l, v);
-        }
-      }
-    }
-}
-
 // ---- two fp16 planes: three plane products ---------------------------------------------------------------------------------------
 // fp16 carries 11 significant bits where bf16 carries 8: with round-to-nearest, x = h1 + h2 + e with h1 = fp16(x), h2 = fp16(x - h1)
 // (the subtraction is exact) and |e| <= 2^-12 |h2| <= 2^-24 |x| - TWO planes hold an fp32 operand to fp32's own rounding, and a
@@ -750,131 +572,6 @@ struct rp_hp_args {
   int b_tab;            // ... and B's is the same chunk's (B read from the same cache)
   unsigned* stamps;     // diagnostic build (-DRP_GEMM_STAMPS): per-step clock stamps of one workgroup of k_gemm_hp16w
 };
-
-__global__ void __launch_bounds__(256, 2) k_gemm_hp(rp_hp_args q) {
-  // [buffer][operand][plane][32-row block][K16 step][1 KB]
-  __shared__ __attribute__((aligned(1024))) unsigned char sm[2][2][2][4][2][1024];
-  const rp_gemm_args& g = q.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  int tm, tn;
-  if (!rp_gemm_tile(g, tm, tn)) return;
-  const int m0 = tm * GT, n0 = tn * GT;
-  if (rp_gemm_skip(g, m0, n0)) return;
-  int kb = g.k0, ke = g.k1;
-  if (g.kb_m) kb = max(kb, g.m_off + m0);
-  if (g.kb_n) kb = max(kb, g.n_off + n0);
-  if (g.ke_n) ke = min(ke, g.n_off + n0 + GT);
-  kb &= ~31;
-  if (kb >= ke && !q.first) return;  // nothing to add to C
-  const float unscale = 1.0f / (rp_h2_scale(g.amax[0]) * rp_h2_scale(g.amax[1]));  // a power of two
-
-  f32x16 acc[2][2], hi[2][2];
-  uint32_t lo[2][2][8];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = hi[i][j][r] = 0.0f;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) lo[i][j][r] = 0u;
-    }
-  auto flush = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const uint32_t pk = lo[i][j][r >> 1];
-          float l0 = __uint_as_float(pk << 16), l1 = __uint_as_float(pk & 0xffff0000u);
-          const float a0 = acc[i][j][r] * unscale, a1 = acc[i][j][r + 1] * unscale;
-          const float h0 = hi[i][j][r], h1 = hi[i][j][r + 1];
-          const float s0 = h0 + a0, s1 = h1 + a1;
-          const float b0 = s0 - h0, b1 = s1 - h1;
-          l0 += (h0 - (s0 - b0)) + (a0 - b0);
-          l1 += (h1 - (s1 - b1)) + (a1 - b1);
-          hi[i][j][r] = s0;
-          hi[i][j][r + 1] = s1;
-          acc[i][j][r] = 0.0f;
-          acc[i][j][r + 1] = 0.0f;
-          lo[i][j][r >> 1] = rp_pack_bf16_rn(l0, l1);
-        }
-  };
-
-  if (kb < ke) {
-    // wave w stages the 32-row block w of both operands: 2 planes x 2 K16 steps x 2 operands = 8 pieces per K32 step
-    const unsigned char* asrc = q.WA + ((long long)(m0 / 32 + wave) * q.KS) * 1024 + lane * 16;
-    const unsigned char* bsrc = q.WB + ((long long)(n0 / 32 + wave) * q.KS) * 1024 + lane * 16;
-    auto issue = [&](int buf, int k) __attribute__((always_inline)) {
-      const long long ko = (long long)((k - q.kc0) >> 4) * 1024;
-#pragma unroll
-      for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc + p * q.psa + ko + s2 * 1024),
-                                           (__attribute__((address_space(3))) void*)&sm[buf][0][p][wave][s2][0], 16, 0, 0);
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + p * q.psb + ko + s2 * 1024),
-                                           (__attribute__((address_space(3))) void*)&sm[buf][1][p][wave][s2][0], 16, 0, 0);
-        }
-    };
-    issue(0, kb);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int since = 0, cur = 0;
-    for (int k = kb; k < ke; k += 32) {
-      const bool more = (k + 32) < ke;
-      if (more) issue(cur ^ 1, k + 32);  // lands while this step multiplies
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        f16x8 a[2][2], b[2][2];
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            a[p][i] = *reinterpret_cast<const f16x8*>(&sm[cur][0][p][wr * 2 + i][s2][lane * 16]);
-            b[p][i] = *reinterpret_cast<const f16x8*>(&sm[cur][1][p][wc * 2 + i][s2][lane * 16]);
-          }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            f32x16 c = acc[i][j];  // small products first
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b[0][j], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[1][j], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[0][j], c, 0, 0, 0);
-            acc[i][j] = c;
-          }
-      }
-      since += 32;
-      if (since >= g.kc && more) {
-        flush();
-        since = 0;
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile has landed
-      __syncthreads();
-      cur ^= 1;
-    }
-  }
-  flush();  // the last piece
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wc * 64 + j * 32 + (lane & 31);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const uint32_t pk = lo[i][j][r >> 1];
-        const float h = hi[i][j][r];
-        const float l = (r & 1) ? __uint_as_float(pk & 0xffff0000u) : __uint_as_float(pk << 16);
-        float* cp = g.C + (long long)row * g.ldc + col;  // (one pass: the two-phase form of k_gemm_hp16w's epilogue spills here)
-        float v = (g.beta != 0.0f) ? fmaf(g.alpha, h, g.beta * (*cp)) : g.alpha * h;
-        *cp = fmaf(g.alpha, l, v);
-      }
-    }
-}
 
 // The same product on v_mfma_f32_16x16x32_f16 (same workspace, same LDS image: the 16-row operand of a K32 step is read from two
 // K16 pieces).  The solve runs with the chip holding its clock down (1.49 GHz at 51 % matrix-pipe occupancy in the 32x32x16
@@ -1588,7 +1285,7 @@ __global__ void k_ease_scale(float* __restrict__ P, long long ld, int n, const f
 // `st` = stream to launch on (the context's by default); `part_at` = where this product's split-K partials go
 // (two products that run concurrently on different streams must not share them)
 static bool rp_gemm_wide_ok(const rphip_ctx* ctx, const rp_gemm_args& g) {
-  return ctx->gemm_shape16 && ctx->gemm_wide && g.M >= 256 && !ctx->gemm_supertile;
+  return ctx->gemm_wide && g.M >= 256 && !ctx->gemm_supertile;
 }
 
 static int rp_launch_hp16w(rphip_ctx* ctx, rp_hp_args& q, hipStream_t st) {
@@ -1768,17 +1465,13 @@ int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st, float* par
         }
         if (rp_gemm_wide_ok(ctx, g)) {
           RP_TRY(rp_launch_hp16w(ctx, q, st));
-        } else if (ctx->gemm_shape16)
+        } else
           hipLaunchKernelGGL(k_gemm_hp16, grid, dim3(256), 0, st, q);
-        else
-          hipLaunchKernelGGL(k_gemm_hp, grid, dim3(256), 0, st, q);
       }
       RP_HIP(hipGetLastError());
       return RPHIP_OK;
     }
     hipLaunchKernelGGL(k_gemm_nt_h2, grid, dim3(256), 0, st, h);
-  } else if (mode == 1) {
-    hipLaunchKernelGGL(k_gemm_nt_b3, grid, dim3(256), 0, st, h);
   } else {
     hipLaunchKernelGGL(k_gemm_nt, grid, dim3(256), 0, st, h);
   }
@@ -2087,7 +1780,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
     }
   } cg{ctx, {}};
   rp_plane_cache& pc = cg.pc;
-  if (ctx->gemm_plane_cache && st == ctx->stream && ctx->gemm_mode == 2 && ctx->gemm_presplit && ctx->gemm_shape16 && ctx->gemm_wide &&
+  if (ctx->gemm_plane_cache && st == ctx->stream && ctx->gemm_mode == 2 && ctx->gemm_presplit && ctx->gemm_wide &&
       !ctx->gemm_supertile && n_pad >= 3 * inv_w) {
     {
       // The size is a function of the DEVICE and the matrix, not of what happens to be free: the cached and the freshly cut
@@ -2316,21 +2009,6 @@ int rp_ease_gram_rows(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int
   return RPHIP_OK;
 }
 
-extern "C" int rphip_ease_gram_rows(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int64_t n_cols, double l2,
-                                    float* G_dev, int64_t ld) {
-  if (!ctx || !X || !G_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
-  if (row_begin < 0 || row_begin > row_end || row_end > n_cols || n_cols < X->n_items || ld < n_cols || (ld % 4))
-    RP_FAIL(RPHIP_EINVAL, "rows [%lld,%lld) of a %lld-column matrix with ld %lld", (long long)row_begin, (long long)row_end,
-            (long long)n_cols, (long long)ld);
-  if (!(l2 > 0.0)) RP_FAIL(RPHIP_EINVAL, "l2 must be > 0 (got %g)", l2);
-  RP_NEED_DEGREES(X);
-  if (X->xt_row_end >= 0 && (row_begin < X->xt_row_begin || std::min<int64_t>(row_end, X->n_items) > X->xt_row_end))
-    RP_FAIL(RPHIP_ESTATE, "the matrix was built for item rows [%lld,%lld) only", (long long)X->xt_row_begin, (long long)X->xt_row_end);
-  RP_TRY(rp_set_device(ctx));
-  // lambda rounded to float32 as the reference does (ease.py:82)
-  return rp_ease_gram_rows(ctx, X, row_begin, row_end, n_cols, (float)l2, G_dev, ld);
-}
-
 // A (128 x 128 block, leading dimension lda) := its Cholesky factor (lower, upper part zeroed), W (128 x 128, ld 128) := the
 // factor's inverse; *info_dev (device int) is set to the failing pivot + 1 when the block is not positive definite
 extern "C" int rphip_potrf_trtri_128(rphip_ctx* ctx, float* A_dev, int64_t lda, float* W_dev, int32_t* info_dev) {
@@ -2377,45 +2055,12 @@ extern "C" int rphip_gemm_nt_f32_ex(rphip_ctx* ctx, int64_t M, int64_t N, int64_
   return RPHIP_OK;
 }
 
-// a dense model on caller-owned device memory (row-major float32, leading dimension ld >= n_items, ld % 4 == 0): not copied,
-// must outlive the model
-extern "C" int rphip_model_from_dense_device(rphip_ctx* ctx, int64_t n_items, float* B_dev, int64_t ld, rphip_model** out) {
-  if (!ctx || !B_dev || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
-  *out = nullptr;
-  if (n_items <= 0 || ld < n_items || (ld % 4)) RP_FAIL(RPHIP_EINVAL, "n_items %lld, ld %lld", (long long)n_items, (long long)ld);
-  RP_TRY(rp_set_device(ctx));
-  rphip_model* m = new rphip_model();
-  m->ctx = ctx;
-  m->kind = RPHIP_MODEL_DENSE;
-  m->n_items = n_items;
-  m->row_end = n_items;
-  m->ld = ld;
-  m->B = B_dev;
-  m->borrows_B = true;
-  int r = rp_dense_count_empty(ctx, m);
-  if (r != RPHIP_OK) {
-    rphip_model_destroy(m);
-    return r;
-  }
-  *out = m;
-  return RPHIP_OK;
-}
-
-
 // ---- building blocks of the COLUMN-SHARDED solve (recpack_amd/dist.py::ease_fit_sharded) ------------------------------------
 // Every rank holds a slab of columns [col_begin, col_begin + n_cols) of the n x n matrix, all rows, row-major with leading
 // dimension ld (= the slab's width).  The inverse is formed in place by block SWEEPS (Goodnight 1979): for a pivot block K with
 // P = A_KK^-1, T = A[:, K] P:   A[:, J] -= T A[K, J] (every other column),  A[K, J] = T[J, :]^T,  A[:, K] = T,  A[K, K] = -P;
 // after all blocks the matrix holds -A^-1.  One panel broadcast per block is the only communication, and a rank's work per block
 // is one plain product on its slab - the same kernel as everything else here (k_gemm_nt).
-
-// In-place inverse of an SPD matrix (n a multiple of 128, row-major, ld): the pivot block of a sweep.
-extern "C" int rphip_spd_inverse_f32(rphip_ctx* ctx, float* A_dev, int64_t n, int64_t ld) {
-  if (!ctx || !A_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
-  if (n <= 0 || (n % GT) || ld < n || (ld % 4)) RP_FAIL(RPHIP_EINVAL, "n %lld must be a positive multiple of 128 and ld %lld >= n, a multiple of 4", (long long)n, (long long)ld);
-  RP_TRY(rp_set_device(ctx));
-  return rp_spd_inverse(ctx, A_dev, (int)n, (long long)ld);
-}
 
 // dst[c][r] = src[r][c]  (rows, cols multiples of 32)
 __global__ void k_transpose_f32(const float* __restrict__ src, long long lds, float* __restrict__ dst, long long ldd) {
@@ -2430,69 +2075,6 @@ int rp_transpose_f32(rphip_ctx* ctx, const float* src, int64_t lds, int64_t rows
   hipLaunchKernelGGL(k_transpose_f32, dim3((unsigned)(cols / 32), (unsigned)(rows / 32)), dim3(32, 8), 0, st ? st : ctx->stream, src, (long long)lds, dst,
                      (long long)ldd);
   RP_HIP(hipGetLastError());
-  return RPHIP_OK;
-}
-
-extern "C" int rphip_transpose_f32(rphip_ctx* ctx, const float* src_dev, int64_t lds, int64_t rows, int64_t cols, float* dst_dev, int64_t ldd) {
-  if (!ctx || !src_dev || !dst_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
-  if (rows <= 0 || cols <= 0 || (rows % 32) || (cols % 32) || lds < cols || ldd < rows)
-    RP_FAIL(RPHIP_EINVAL, "transpose of %lld x %lld (multiples of 32) with lds %lld, ldd %lld", (long long)rows, (long long)cols, (long long)lds, (long long)ldd);
-  if (cols / 32 > 0x7fffffffLL || rows / 32 > 65535) RP_FAIL(RPHIP_ELIMIT, "transpose of %lld x %lld: at most 2 097 120 rows", (long long)rows, (long long)cols);
-  RP_TRY(rp_set_device(ctx));
-  return rp_transpose_f32(ctx, src_dev, lds, rows, cols, dst_dev, ldd);
-}
-
-// K7 on a column slab holding sign * P[:, col_begin : col_begin + n_cols]: B_ij = -P_ij / P_jj * w_j, B_jj = 0, rows and columns
-// of the padding zeroed (ease.py:85-90; w_j = c_j^-alpha, 0 for items nobody interacted with - the documented deviation)
-__global__ void k_ease_colscale(const float* __restrict__ S, long long ld, int n, int col_begin, int n_cols, const int32_t* __restrict__ deg,
-                                float alpha, float* __restrict__ colscale) {
-  for (int jl = blockIdx.x * blockDim.x + threadIdx.x; jl < n_cols; jl += gridDim.x * blockDim.x) {
-    const int j = col_begin + jl;
-    float sc = 0.0f;
-    if (j < n) {
-      const float d = S[(long long)j * ld + jl];  // sign * P_jj: the sign cancels in P_ij / P_jj
-      float w = 1.0f;
-      if (alpha != 0.0f) w = deg[j] > 0 ? powf((float)deg[j], -alpha) : 0.0f;
-      sc = -w / d;
-    }
-    colscale[jl] = sc;
-  }
-}
-
-__global__ void k_ease_scale_cols(float* __restrict__ S, long long ld, long long n_rows, int n, int col_begin, int n_cols,
-                                  const float* __restrict__ colscale) {
-  const long long total = n_rows * ld;
-  for (long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; e < total; e += (long long)gridDim.x * blockDim.x * 4) {
-    const long long i = e / ld;
-    const int jl = (int)(e % ld);  // ld is a multiple of 4
-    float4 v = *reinterpret_cast<float4*>(S + e);
-    float o[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int q = jl + c;
-      o[c] = (q < n_cols && i < n && (long long)(col_begin + q) != i) ? o[c] * colscale[q] : 0.0f;
-    }
-    *reinterpret_cast<float4*>(S + e) = make_float4(o[0], o[1], o[2], o[3]);
-  }
-}
-
-extern "C" int rphip_ease_scale_cols(rphip_ctx* ctx, const rphip_csr* X, float* S_dev, int64_t ld, int64_t n_rows, int64_t col_begin,
-                                     int64_t n_cols, double alpha) {
-  if (!ctx || !X || !S_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
-  if (n_rows < X->n_items || col_begin < 0 || n_cols <= 0 || n_cols > ld || (ld % 4) || col_begin + n_cols > n_rows)
-    RP_FAIL(RPHIP_EINVAL, "slab of columns [%lld,%lld) with %lld rows, ld %lld", (long long)col_begin, (long long)(col_begin + n_cols), (long long)n_rows, (long long)ld);
-  RP_NEED_DEGREES(X);
-  RP_TRY(rp_set_device(ctx));
-  float* colscale = nullptr;
-  RP_TRY(rp_scratch(ctx, 5, (size_t)n_cols * 4 + 64, (void**)&colscale));
-  hipEvent_t ev;
-  rp_time_begin(ctx, &ev);
-  hipLaunchKernelGGL(k_ease_colscale, dim3((unsigned)rp_cdiv(n_cols, 256)), dim3(256), 0, ctx->stream, S_dev, (long long)ld, (int)X->n_items,
-                     (int)col_begin, (int)n_cols, X->deg, (float)alpha, colscale);
-  hipLaunchKernelGGL(k_ease_scale_cols, dim3(4096), dim3(256), 0, ctx->stream, S_dev, (long long)ld, (long long)n_rows, (int)X->n_items, (int)col_begin,
-                     (int)n_cols, colscale);
-  RP_HIP(hipGetLastError());
-  rp_time_end(ctx, ev, RPHIP_T_EASE_SCALE, 8.0 * (double)n_rows * (double)n_cols);
   return RPHIP_OK;
 }
 

@@ -8,7 +8,7 @@
 // matrix is symmetric throughout, only blocks (i, j) with i >= j are kept current ("lower"); the diagonal blocks are kept in
 // their lower 128-tiles.
 //
-// Solve: symmetric block Gauss-Jordan sweeps (Goodnight 1979), the symmetric form of the sweeps of dist.ease_fit_sweeps.  For the
+// Solve: symmetric block Gauss-Jordan sweeps (Goodnight 1979), the symmetric form of the full sweeps round 2 drove from Python (removed in round 4).  For the
 // pivot panel K with P = A_KK^-1 and the pivot's full column V = A[:, K] (V_i = A_iK for i > K from the owner's panel, V_i = A_Ki^T
 // for i < K from row block K of everybody's panels), T = V P:
 //     A_ij -= V_i T_j^T  (i, j != K),     A_iK = T_i (i > K),     A_Ki = T_i^T (i < K),     A_KK = -P,
@@ -260,7 +260,7 @@ int rp_comm_all_gather(rphip_comm* c, const void* send, void* recv, int64_t byte
   if (c->is_loop) {  // every slot takes this rank's own part: data of the right kind and size
     for (int p = 0; p < c->world; ++p)
       RP_HIP(hipMemcpyAsync((char*)recv + (size_t)p * bytes_per_rank, send, (size_t)bytes_per_rank, hipMemcpyDeviceToDevice, st));
-    rp_loop_delay(c, bytes_per_rank * (c->world - 1), st);
+    rp_loop_delay(c, bytes_per_rank, st);  // (W - 1 parts over W - 1 links at once)
     RP_HIP(hipGetLastError());
     return RPHIP_OK;
   }
@@ -284,8 +284,8 @@ int rp_comm_exchange(rphip_comm* c, const void* send, const int64_t* soff, const
       int64_t in = 0, outb = 0;
       for (int p = 0; p < c->world; ++p) {
         if (p == me) continue;
-        in += rbytes[p];
-        outb += sbytes[p];
+        in = std::max(in, rbytes[p]);  // (every peer over its own link)
+        outb = std::max(outb, sbytes[p]);
         // what comes from rank p: this rank's own piece FOR rank p when it is large enough (data of the right kind - lists of
         // (column, score), blocks of the matrix), noise otherwise
         if (rbytes[p] > 0) {

@@ -931,9 +931,14 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   RP_TRY(rp_set_device(ctx));
   // a row has at most n_items-1 neighbours
   const int32_t Keff = (int32_t)std::min<int64_t>(K, std::max<int64_t>(1, X->n_items - 1));
-  if (Keff > RP_K_MAX) RP_FAIL(RPHIP_ELIMIT, "effective K=%d exceeds the supported maximum %d", Keff, RP_K_MAX);
   const int n_rows = (int)(row_end - row_begin);
   const int T = X->n_tiles, W = X->tile_w;
+  // (round 4) one column tile - up to RP_TILE_MAX items - takes ANY K, as the reference does (recpack/algorithms/base.py:302-304,
+  // recpack/util.py:63-66): the selection runs on the tile itself and writes the row.  With several tiles a row's per-tile
+  // candidate lists meet in the LDS of the merge: K <= RP_K_MAX there.
+  if (Keff > RP_K_MAX && T > 1)
+    RP_FAIL(RPHIP_ELIMIT, "effective K=%d exceeds the supported maximum %d for %lld items (%d column tiles; any K up to %d items)", Keff, RP_K_MAX,
+            (long long)X->n_items, T, RP_TILE_MAX);
 
   K = Keff;  // the model's row stride; rphip_model_info reports it
   if (T > 15) RP_FAIL(RPHIP_ELIMIT, "%d column tiles (n_items=%lld) exceed the supported 15", T, (long long)X->n_items);

@@ -31,13 +31,13 @@ int main() {
   char arch[8];
   CHECK(rphip_device_info(ctx, &ncu, &hbm, arch, sizeof(arch)) == RPHIP_OK && ncu == 256 && !strncmp(arch, "gfx950", 6) && strlen(arch) == 7);
   // options: every documented name, bad values, an unknown name
-  const char* names[] = {"predict_exact64", "predict_half", "gemm_mode", "gemm_shape16", "gemm_wide", "gemm_presplit", "gemm_supertile"};
-  for (const char* nm : names) CHECK(rphip_ctx_set_option(ctx, nm, 1) == RPHIP_OK);
-  CHECK(rphip_ctx_set_option(ctx, "gemm_mode", 2) == RPHIP_OK && rphip_ctx_set_option(ctx, "gemm_mode", 3) == RPHIP_EINVAL);
+  const char* names[] = {"predict_exact64", "predict_half", "gemm_mode", "gemm_wide", "gemm_presplit", "gemm_supertile"};
+  for (const char* nm : names) CHECK(rphip_ctx_set_option(ctx, nm, 0) == RPHIP_OK && rphip_ctx_set_option(ctx, nm, strcmp(nm, "gemm_mode") ? 1 : 2) == RPHIP_OK);
+  CHECK(rphip_ctx_set_option(ctx, "gemm_mode", 2) == RPHIP_OK && rphip_ctx_set_option(ctx, "gemm_mode", 1) == RPHIP_EINVAL);
   CHECK(rphip_ctx_set_option(ctx, "predict_tile32", 1000) == RPHIP_EINVAL && rphip_ctx_set_option(ctx, "predict_tile32", 2048) == RPHIP_OK);
   CHECK(rphip_ctx_set_option(ctx, "gemm_flush_k", 100) == RPHIP_EINVAL && rphip_ctx_set_option(ctx, "gemm_flush_k", 512) == RPHIP_OK);
   CHECK(rphip_ctx_set_option(ctx, "gemm_workspace_bytes", 1) == RPHIP_EINVAL);
-  CHECK(rphip_ctx_set_option(ctx, "no_such_option", 1) == RPHIP_EINVAL && rphip_ctx_set_option(nullptr, "gemm_mode", 1) == RPHIP_EINVAL);
+  CHECK(rphip_ctx_set_option(ctx, "no_such_option", 1) == RPHIP_EINVAL && rphip_ctx_set_option(nullptr, "gemm_mode", 2) == RPHIP_EINVAL);
   // block cache: a freed block comes back for a request of the same (rounded) size; other sizes allocate
   const int base = stub_live_blocks();
   void *a = nullptr, *b = nullptr, *c = nullptr;

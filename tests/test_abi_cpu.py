@@ -116,16 +116,26 @@ def test_post_condition_warnings():
 
 
 def test_k_limit_raises_before_upload():
-    """K / Kp beyond RP_K_MAX = 2048 (a documented deviation: the reference takes any K) raise ValueError on the host."""
+    """K beyond RP_K_MAX = 2048 with more items than one column tile holds (a documented deviation: the reference takes any K)
+    raises ValueError on the host; up to RP_TILE_MAX items any K goes to the device (round 4)."""
     import scipy.sparse as sp
+    import torch
 
     import recpack_amd
-    from recpack_amd.algorithms import RP_K_MAX
+    from recpack_amd._lib import RecpackHipError
+    from recpack_amd.algorithms import RP_K_MAX, RP_TILE_MAX
 
-    X = sp.random(50, 3000, density=0.01, format="csr", random_state=0)
+    X = sp.random(50, RP_TILE_MAX + 400, density=0.002, format="csr", random_state=0)
     X.data[:] = 1
     with pytest.raises(ValueError, match=str(RP_K_MAX)):
         recpack_amd.ItemKNN(K=RP_K_MAX + 1).fit(X)
+    Xs = sp.random(50, 3000, density=0.01, format="csr", random_state=0)
+    Xs.data[:] = 1
+    with pytest.raises(ValueError, match=str(RP_K_MAX)):
+        recpack_amd.ItemKNN(K=RP_K_MAX + 1, normalize_X=True).fit(Xs)
+    if not torch.cuda.is_available():  # one tile: no host-side limit any more - the call reaches the (absent) device
+        with pytest.raises(RecpackHipError):
+            recpack_amd.ItemKNN(K=RP_K_MAX + 1).fit(Xs)
 
 
 def test_fitted_models_pickle_round_trip(tmp_path):

@@ -58,18 +58,20 @@ def test_gemm_nt_mfma(hip):
     ctx.sync()
     # (the default two-plane fp16 product holds an operand to 2^-24 of its value - fp32's own rounding - not to the last bit)
     np.testing.assert_allclose(Cd.cpu().numpy(), Bd.cpu().numpy().T, rtol=1.2e-7, atol=0)
-    ctx.set_option("gemm_mode", 1)  # three bf16 planes carry all 24 bits: exact
+    ctx.set_option("gemm_mode", 0)  # the fp32-input MFMA (the cross-check mode): exact
     try:
         _lib.gemm_nt(ctx, I, Bd, Cd)
         ctx.sync()
     finally:
         ctx.set_option("gemm_mode", 2)
     np.testing.assert_array_equal(Cd.cpu().numpy(), Bd.cpu().numpy().T)
+    with pytest.raises(_lib.RecpackHipError):
+        ctx.set_option("gemm_mode", 1)  # (round 2's three-bf16-plane mode was removed in round 4)
 
 
 def test_gemm_plane_workspace_paths(hip):
     """The large-product route of the GEMM (operands cut into fp16 planes once per K chunk, LDS-DMA product kernel) against float64:
-    several K chunks (small workspace), both MFMA shapes, B = a row range of A (one set of planes serves both, one scale),
+    several K chunks (small workspace), B = a row range of A (one set of planes serves both, one scale),
     B = A, and the in-kernel conversion (gemm_presplit = 0) - all within the error of the plain kernel."""
     import torch
 
@@ -93,11 +95,8 @@ def test_gemm_plane_workspace_paths(hip):
         assert err <= 5e-7, (what, err)
 
     try:
-        for shape16 in (1, 0):
-            ctx.set_option("gemm_shape16", shape16)
-            ctx.set_option("gemm_workspace_bytes", 64 << 20)  # K chunks of 5120 -> one chunk here ...
-            check(Ad, Bd, 0.5, -1.0, ("one chunk", shape16))
-        ctx.set_option("gemm_shape16", 1)
+        ctx.set_option("gemm_workspace_bytes", 64 << 20)  # K chunks of 5120 -> one chunk here ...
+        check(Ad, Bd, 0.5, -1.0, "one chunk")
         big = torch.randn((2048, 16384), generator=g).cuda()  # ... and 16 x 16 tiles < 512: stays on the plain kernel
         Cd = torch.zeros((2048, 2048)).cuda()
         _lib.gemm_nt(ctx, big, big, Cd)
@@ -111,7 +110,6 @@ def test_gemm_plane_workspace_paths(hip):
         check(Ad, Bd, 0.5, -1.0, "conversion inside the product kernel")
     finally:
         ctx.set_option("gemm_presplit", 1)
-        ctx.set_option("gemm_shape16", 1)
         ctx.set_option("gemm_workspace_bytes", 4 << 30)
         ctx.trim()
 
@@ -377,11 +375,11 @@ def test_ease_fit_sharded_multi_rank(hip, nproc, shape):
     ease_fit_sharded - the library's distributed solve (rphip_ease_fit_dist: block-cyclic panels, symmetric block sweeps, the
     collectives behind the communicator's callback transport) - gives every rank its COLUMNS of B (1e-4 of the single-GPU B)
     without a single torch allocation, and predict_topk_sharded (local top-Kp per rank, all-gather, merge) reproduces the
-    single-GPU top-K; ease_fit_replicated and ease_fit_sweeps (round 2's routes) stay green.  Fourth number: panel width of the
-    replicated route, fifth: of the distributed solve's first pass (the second pass lets the library choose)."""
+    single-GPU top-K.  Fifth number: panel width of the distributed solve's first pass (the second pass lets the library choose;
+    the fourth was the panel width of round 2's replicated route, removed in round 4)."""
     r = _run_dist_check(nproc, shape)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count("top-20 agreement") == 6 * nproc
+    assert r.stdout.count("top-20 agreement") == 4 * nproc
 
 
 def test_ease_fit_sharded_one_rank(hip):
@@ -395,25 +393,14 @@ def test_ease_fit_sharded_one_rank(hip):
     dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
     ref = onp.ease_fit(X, 20.0, 0.0)
     dev = torch.device("cuda", 0)
-    for panel_tiles in (16, 5):  # 12 tiles: one panel; three panels, the last one short
-        m = rdist.ease_fit_replicated(ctx, dX, 20.0, 0.0, dev, panel_tiles=panel_tiles)
-        assert rel_max(m.dense_download(), ref) <= EASE_TOL
-        del m
-    with pytest.raises(_lib.RecpackHipError):
-        rdist.ease_fit_replicated(ctx, dX, 0.0, 0.0, dev)
     # the column-sharded route on one rank (one slab = the whole matrix): block sweeps, K7 on the slab, predict + merge
     single = _lib.ease_fit(ctx, dX, 20.0, 0.0)
     want = _lib.predict_topk(ctx, single, dX, 30, exclude_history=True)
-    for panel_tiles in (8, 5, 1, 0, -1):  # -1: round 2's sweeps (the fallback)
-        if panel_tiles < 0:
-            ms, (c0, nc) = rdist.ease_fit_sweeps(ctx, dX, 20.0, 0.0, dev, panel_tiles=5)
-            assert (c0, nc) == (0, 1500)
-            B = ms._keep[:1500, :1500].cpu().numpy()
-        else:
-            ms, lay = rdist.ease_fit_sharded(ctx, dX, 20.0, 0.0, dev, panel_tiles=panel_tiles)
-            assert lay["n_local"] == 1500 and lay["world"] == 1 and (ms.local_columns() == np.arange(1500)).all()
-            ptr, _, ld = ms.dense_device_ptr()
-            B = torch.as_tensor(rdist._DevPtr(ptr, (1500, ld), "<f4", ms), device=dev)[:, :1500].cpu().numpy()
+    for panel_tiles in (8, 5, 1, 0):
+        ms, lay = rdist.ease_fit_sharded(ctx, dX, 20.0, 0.0, dev, panel_tiles=panel_tiles)
+        assert lay["n_local"] == 1500 and lay["world"] == 1 and (ms.local_columns() == np.arange(1500)).all()
+        ptr, _, ld = ms.dense_device_ptr()
+        B = torch.as_tensor(rdist._DevPtr(ptr, (1500, ld), "<f4", ms), device=dev)[:, :1500].cpu().numpy()
         assert rel_max(B, ref) <= EASE_TOL, (panel_tiles, rel_max(B, ref))
         users, pi, pv, pn = rdist.predict_topk_sharded(ctx, ms, dX, 30, dev, exclude_history=True, user_chunk=2500)
         assert (users.cpu().numpy() == np.arange(6000)).all()

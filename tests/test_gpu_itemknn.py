@@ -591,12 +591,9 @@ def test_limits_and_dense_corners(hip):
     X = sp.csr_matrix(X)
     X.sort_indices()
     dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
-    for K in (2048, 5000):  # RP_K_MAX, and a request beyond the number of items (clipped to I - 1)
-        if min(K, I - 1) > 2048:
-            with pytest.raises(_lib.RecpackHipError):
-                _lib.itemknn_fit(ctx, dX, K)
-            continue
+    for K in (2048, 5000):  # RP_K_MAX, and a request beyond the number of items (clipped to I - 1 = 2299: one column tile takes any K)
         m = _lib.itemknn_fit(ctx, dX, K)
+        assert m.K == min(K, I - 1)
         idx, val, nnz = m.topk_download()
         assert_same_as_oracle(idx, val, nnz, onp.itemknn_fit(X, m.K))
         S = onp.topk_to_csr(idx, val, nnz, I)
@@ -606,6 +603,30 @@ def test_limits_and_dense_corners(hip):
             check_topk_scores(scores, pi, pv, pn, Kp, exclude=X[:100], hist=X[:100] if Kp <= 384 else None, S=S)
         with pytest.raises(_lib.RecpackHipError):
             _lib.predict_topk(ctx, m, dX, 2049)
+
+
+def test_fit_any_k_on_one_tile(hip):
+    """ItemKNN(K=5000) on 20 000 x 8 000: up to RP_TILE_MAX items the fit takes any K, as the reference
+    does (recpack/algorithms/base.py:302-304, recpack/util.py:63-66); with several column tiles K stays <= 2048."""
+    from recpack_amd.synth import powerlaw_csr
+
+    _lib, ctx = hip
+    X = powerlaw_csr(20000, 8000, 0.004, seed=41).to_scipy()
+    _, m, idx, val, nnz = fit_arrays(hip, X, 5000)
+    assert m.K == 5000
+    assert_same_as_oracle(idx, val, nnz, onp.itemknn_fit(X, 5000))
+    # the drop-in class and predict() on such a model
+    import recpack_amd
+
+    algo = recpack_amd.ItemKNN(K=5000).fit(X)
+    S = algo.similarity_matrix_
+    assert S.shape == (8000, 8000) and S.getnnz(axis=1).max() <= 5000
+    got = algo.predict(X[:300])
+    want = onp.predict_full(X[:300], S)
+    assert abs(got - want).max() <= 2e-7 * abs(want).max()
+    Xw = powerlaw_csr(200, 26000, 0.002, seed=42).to_scipy()  # two column tiles: the limit stands
+    with pytest.raises(ValueError):
+        recpack_amd.ItemKNN(K=3000).fit(Xw)
 
 
 @pytest.mark.parametrize("nproc,shape", [(2, (20000, 30000, 0.0015, 50)), (3, (6000, 900, 0.01, 20))])

@@ -6,8 +6,9 @@ checkable without an 8-GPU node).
 For every rank asked for, the process runs that rank's EXACT kernel sequence of the distributed step on the loop-back communicator
 (rphip_comm_loopback_create): the collectives are stream-ordered and asynchronous like the RCCL ones, move nothing between ranks
 - what the rank would receive is filled with its own data or noise of the right size - and hold their stream for
-latency + bytes / rate (defaults: 10 us + bytes / 100 GB/s: below the 153 GB/s of one xGMI link, above what a 7-way ring gets
-per link).  Measured per rank:
+latency + bytes / rate, rate = ONE link of the fully connected node (default 100 GB/s: two thirds of an xGMI link's 153 GB/s)
+and bytes = what the busiest link carries: a broadcast its whole message (the root feeds 7 links at once), an all-gather one rank's
+part (7 parts over 7 links), an exchange the largest piece to or from one peer.  Measured per rank:
 
   ItemKNN half   K0 of the shard (rphip_csr_from_device_shard: the degree pass over the rank's item rows) + the all-reduce of the
                  degree vector (modelled) + the fit of the rank's rows (cost-balanced ranges, as bench.py cuts them) + the
@@ -15,7 +16,9 @@ per link).  Measured per rank:
                  full model + K8 for the rank's users
   EASE half      rphip_ease_fit_dist (Gram of the rank's panels, the symmetric block sweeps with look-ahead: update stream, chain,
                  pivot stream, communication stream) + rphip_predict_topk_dist (all users against the rank's columns, the
-                 personalised exchange, the merge of the rank's users)
+                 personalised exchange, the merge of the rank's users).  The predict runs on a REAL slab of B - n / world columns of
+                 the single-GPU model of the same process: the emulated fit works on noise, and on noise the fp16 first pass of K9
+                 cannot prove its lists (every user would take the exact second pass: 4x the time)
 
 The results of such a run are meaningless (the data of the other ranks never existed); the launches, their sizes and their
 overlap are rank r's.  `speedup_emulated` = the single-GPU step of the same build (measured in the same process) divided by the
@@ -99,10 +102,21 @@ def main():
             cur = {"itemknn_s": t1 - t0, "ease_fit_s": t2 - t1, "ease_predict_s": t3 - t2, "step_s": t3 - t0}
             if best is None or cur["step_s"] < best["step_s"]:
                 best = cur
-            del m, em
+            del m
+            if _ < args.repeats:
+                del em
             dX.close()
         out["single_gpu"] = {k: round(v, 5) for k, v in best.items()}
         del oi, ov, on
+        # rank r's columns of the real B (contiguous n / world columns: the cost of a cyclic map is the same), copied out of the model
+        ptr, n_it, ld = em.dense_device_ptr()
+        Bfull = torch.as_tensor(rdist._DevPtr(ptr, (n_it, ld), "<f4", em), device=dev)
+        slabs = {}
+        for r in [int(x) for x in args.ranks.split(",")]:
+            c0, c1 = (I * r) // W, (I * (r + 1)) // W
+            slabs[r] = (c0, Bfull[:I, c0:c1].contiguous())
+        del Bfull, em
+        ctx.trim()
         print("single GPU:", out["single_gpu"], flush=True)
 
     # ---- one rank at a time
@@ -149,9 +163,19 @@ def main():
             print(f"  rank {r}: EASE fit done", flush=True)
             tm = ctx.timings()
             st = _lib.ease_fit_dist_stats(ctx)
-            rdist.predict_topk_sharded(ctx, em, dXe, Kp, dev, exclude_history=False, comm=comm)
+            del em
+            if not args.skip_single:
+                c0, slab = slabs[r]
+                pm = _lib.Model.from_dense_cols(ctx, I, c0, slab.shape[1], slab)
+            else:
+                pm = None
             sync()
-            t3 = time.perf_counter()
+            t2b = time.perf_counter()
+            if pm is not None:
+                rdist.predict_topk_sharded(ctx, pm, dXe, Kp, dev, exclude_history=False, comm=comm)
+            sync()
+            t3 = time.perf_counter() - (t2b - t2)
+            del pm
             cur = {"step_s": t3 - t0, "itemknn_s": t1 - t0, "itemknn_k0_shard_s": t_k0 - t0, "itemknn_fit_rows_s": t_fit - t_k0,
                    "itemknn_gather_finalize_s": t_gather - t_fit, "itemknn_predict_users_s": t1 - t_gather,
                    "ease_fit_s": t2 - t1, "ease_predict_s": t3 - t2,
@@ -161,7 +185,7 @@ def main():
                    "ease_panel": st["panel"], "rows": [int(rb), int(re_)], "users": [int(ub), int(ue)]}
             if best is None or cur["step_s"] < best["step_s"]:
                 best = cur
-            del local, full, em
+            del local, full
             dX.close()
             dXe.close()
         out["ranks"][str(r)] = {k: (round(v, 5) if isinstance(v, float) else v) for k, v in best.items()}

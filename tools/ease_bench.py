@@ -18,8 +18,6 @@ if os.environ.get("RECPACK_GEMM_MODE"):
     ctx.set_option("gemm_mode", int(os.environ["RECPACK_GEMM_MODE"]))
 if os.environ.get("RECPACK_GEMM_FLUSH_K"):
     ctx.set_option("gemm_flush_k", int(os.environ["RECPACK_GEMM_FLUSH_K"]))
-if os.environ.get("RECPACK_GEMM_SHAPE16"):
-    ctx.set_option("gemm_shape16", int(os.environ["RECPACK_GEMM_SHAPE16"]))
 if os.environ.get("RECPACK_GEMM_WIDE"):
     ctx.set_option("gemm_wide", int(os.environ["RECPACK_GEMM_WIDE"]))
 if os.environ.get("RECPACK_GEMM_SUPERTILE"):
