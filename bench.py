@@ -522,7 +522,16 @@ def main():
             em, _ = rdist.ease_fit_sharded(ctx, dXe, args.l2, 0.0, device, comm=comm)
             torch.cuda.synchronize()
             t2 = time.perf_counter()
-            rdist.predict_topk_sharded(ctx, em, dXe, Kp, device, exclude_history=False, comm=comm)
+            # predict: while the whole of B fits every GPU, gather the panels and score this rank's USERS with the single-GPU kernels
+            # (full-width rows, no lists to exchange); otherwise every rank scores all users against its own columns + merge
+            if rdist.ease_gather_fits(I, _lib.ease_fit_dist_stats(ctx)["panel"], info["hbm_bytes"]):
+                full = rdist.ease_gather_model(ctx, em, I, comm)
+                _lib.predict_topk_dev(ctx, full, dXe, Kp, out_idx, out_val, out_nnz, user_begin=ub, user_end=ue)
+                keep["ease_full"] = full
+                keep["ease_predict_route"] = "panels all-gathered, users sharded"
+            else:
+                rdist.predict_topk_sharded(ctx, em, dXe, Kp, device, exclude_history=False, comm=comm)
+                keep["ease_predict_route"] = "columns sharded, lists exchanged and merged"
             keep["dXe"] = dXe
         torch.cuda.synchronize()
         t3 = time.perf_counter()
@@ -639,7 +648,7 @@ def main():
                             f"top-{Kp} for all users" + (f", then EASE l2={args.l2} fit + predict top-{Kp} for all users" if ease_on else ""),
                 "parallelism": (f"ItemKNN: item-row shards x{world} (fit) + user shards x{world} (predict); EASE: block-cyclic column panels x{world} "
                                 f"(library solve, {'own RCCL communicator' if comm is not None and comm.is_rccl else 'torch.distributed callbacks'}) + "
-                                f"column-sharded predict + merge") if world > 1 else "1 GPU",
+                                f"predict: {keep.get('ease_predict_route', '-')}") if world > 1 else "1 GPU",
                 "generate_s": round(t_gen, 2),
                 "device": info,
                 "transport_note": comm_note,

@@ -449,6 +449,13 @@ int rphip_itemknn_gather(rphip_ctx* ctx, rphip_comm* comm, const rphip_model* lo
  * (a local top-Kp per user; rphip_predict_merge_topk merges the ranks' lists).  *out = NULL on a rank that owns only padding. */
 int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip_csr* X, double l2, double alpha, int32_t panel_tiles,
                         rphip_model** out);
+/* The ranks' column panels of rphip_ease_fit_dist into ONE full dense model on every rank (strips of rows, one all-gather each):
+ * while 3 n^2 floats fit a GPU the fastest multi-GPU predict is the single-GPU rphip_predict_topk* on a share of the USERS - each
+ * rank then streams full-width rows of B for its own users only.  `local`: this rank's model (NULL on a rank that owns only
+ * padding); n_items and panel_cols as rphip_model_dense_layout reports them.  rphip_predict_topk_dist (below) stays for matrices
+ * that do not fit.  The reference has no multi-GPU path (recpack/algorithms/base.py:454-455). */
+int rphip_ease_model_allgather(rphip_ctx* ctx, rphip_comm* comm, const rphip_model* local, int64_t n_items, int64_t panel_cols,
+                               rphip_model** out);
 /* Fused predict + top-Kp with the model's columns spread over the ranks of `comm` (the models of rphip_ease_fit_dist; `model` NULL
  * on a rank that owns only padding): every rank scores the users against its own columns, the local lists travel to the rank
  * that owns the user (one personalised exchange per chunk of users) and are merged there by (score desc, column asc) - the

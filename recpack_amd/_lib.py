@@ -114,6 +114,7 @@ PROTOTYPES = {
     "rphip_comm_rccl_create": (C.c_int, [_p, _i32, _i32, _p, _pp]),
     "rphip_comm_from_ops": (C.c_int, [_p, _p, _pp]),
     "rphip_comm_loopback_create": (C.c_int, [_p, _i32, _i32, C.c_double, C.c_double, _pp]),
+    "rphip_ease_model_allgather": (C.c_int, [_p, _p, _p, _i64, _i64, _pp]),
     "rphip_comm_destroy": (C.c_int, [_p]),
     "rphip_comm_info": (C.c_int, [_p, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "rphip_comm_all_reduce_sum_i32": (C.c_int, [_p, _p, _p, _i64]),
@@ -675,6 +676,22 @@ def ease_fit_dist(ctx: Context, comm: Comm, X: DeviceCSR, l2: float, alpha: floa
             raise err
         raise
     return Model(ctx, h) if h.value else None
+
+
+def ease_model_allgather(ctx: Context, comm: Comm, model, n_items: int, panel_cols: int) -> Model:
+    """Every rank's column panels of a distributed EASE fit into one full model on this rank (rphip_ease_model_allgather): predict
+    then shards by users, as for ItemKNN.  ``model`` may be None on a rank that owns only padding."""
+    h = C.c_void_p()
+    try:
+        check(ctx.lib.rphip_ease_model_allgather(ctx.handle, comm.handle, model.handle if model is not None else None, int(n_items), int(panel_cols),
+                                                 C.byref(h)))
+    except RecpackHipError:
+        err = comm.error["error"] if isinstance(comm.error, dict) else None
+        if err is not None:
+            comm.error["error"] = None
+            raise err
+        raise
+    return Model(ctx, h)
 
 
 def predict_topk_dist(ctx: Context, comm: Comm, model, X: DeviceCSR, Kp: int, idx_t, val_t, nnz_t, exclude_history: bool = False):

@@ -564,8 +564,15 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
   // plane workspaces of the update stream's products are sized once (a reallocation would pull them from under a running launch)
   {
     void* w = nullptr;
-    const size_t wa = std::min<size_t>(ctx->gemm_ws_bytes, std::max<size_t>((size_t)64 << 20, (size_t)n_pad * nb * 4));
-    const size_t wb = std::min<size_t>(ctx->gemm_ws_bytes, std::max<size_t>((size_t)64 << 20, (size_t)ld * nb * 4));
+    // (the sizes rp_gemm_nt will ask for: powers of two from 64 MiB, capped at the context's workspace limit - a request that
+    // exceeded a smaller pre-sized buffer would free and reallocate it under the running streams)
+    auto ws_size = [&](size_t need) {
+      size_t c = (size_t)64 << 20;
+      while (c < need) c <<= 1;
+      return std::max(need, std::min(c, ctx->gemm_ws_bytes));
+    };
+    const size_t wa = ws_size(std::min<size_t>(ctx->gemm_ws_bytes, (size_t)n_pad * nb * 4));
+    const size_t wb = ws_size(std::min<size_t>(ctx->gemm_ws_bytes, (size_t)ld * nb * 4));
     DTRY(rp_scratch(ctx, 12, wa, &w));
     DTRY(rp_scratch(ctx, 13, wb, &w));
     DTRY(rp_scratch(ctx, 8, wa, &w));  // (the main stream's too: growing them later would make the host wait for the stream)
@@ -856,6 +863,91 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
   return RPHIP_OK;
 #undef DTRY
 #undef DHIP
+}
+
+// ---- the ranks' column panels into ONE full model on every rank --------------------------------------------------------------
+// rows [r0, r0 + rows) of every rank's panels (recv[q][i][a * nb + c], leading dimension ldl) into B[r0 + i][(a * W + q) * nb + c]
+__global__ void k_unpack_panels(const float* __restrict__ recv, long long slot_floats, int ldl, int rows, int nb, int W, int np, float* __restrict__ B,
+                                long long ldB, long long r0) {
+  const int c4 = nb >> 2;
+  const int q = blockIdx.z;                 // source rank
+  const int a = blockIdx.y;                 // its local panel
+  const int p = a * W + q;                  // the panel of the matrix
+  if (p >= np) return;
+  const float* src = recv + (long long)q * slot_floats + (long long)a * nb;
+  float* dst = B + r0 * ldB + (long long)p * nb;
+  const long long total = (long long)rows * c4;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long i = e / c4;
+    const int c = (int)(e % c4) * 4;
+    *reinterpret_cast<float4*>(dst + i * ldB + c) = *reinterpret_cast<const float4*>(src + i * ldl + c);
+  }
+}
+
+// While 3 n^2 floats fit a GPU (B, its fp16 copy, a staging strip) the fastest multi-GPU predict is the single-GPU one on a share
+// of the USERS: every rank gathers all panels (n^2 * 4 * (W - 1) / W bytes in over W - 1 links: 50 ms at 100 000 items and 100 GB/s
+// per link) and scores its own users against the whole of B - K9's two passes with their full-width rows, no per-rank candidate lists
+// to rescore W times over, no exchange of lists.  The column-sharded rphip_predict_topk_dist stays for matrices that do not fit
+// (5M x 200K: B alone is 160 GB).  `local` = this rank's model of rphip_ease_fit_dist (NULL on a rank that owns only padding),
+// n_items and panel_cols as every rank's layout reports them.  Strips of rows travel one all-gather each.
+extern "C" int rphip_ease_model_allgather(rphip_ctx* ctx, rphip_comm* comm, const rphip_model* local, int64_t n_items, int64_t panel_cols,
+                                          rphip_model** out) {
+  if (!ctx || !comm || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  *out = nullptr;
+  const int W = comm->world, me = comm->rank;
+  const int nb = (int)panel_cols;
+  if (n_items < 1 || nb < 128 || (nb % 128)) RP_FAIL(RPHIP_EINVAL, "n_items %lld, panel of %lld columns", (long long)n_items, (long long)panel_cols);
+  if (local && (local->kind != RPHIP_MODEL_DENSE || local->cyc_nb != nb || local->cyc_world != W || local->cyc_rank != me || local->n_items != n_items))
+    RP_FAIL(RPHIP_EINVAL, "the local model is not this rank's part of a %d-rank fit with panels of %d columns", W, nb);
+  RP_TRY(rp_set_device(ctx));
+  const long long n_pad = rp_cdiv(n_items, nb) * nb;
+  const int np = (int)(n_pad / nb), nl_max = (int)rp_cdiv(np, W);
+  const int nl = (np > me) ? (np - me + W - 1) / W : 0;
+  const int ldl = nl_max * nb;
+  hipStream_t st = ctx->stream;
+  rphip_model* m = new rphip_model();
+  m->ctx = ctx;
+  m->kind = RPHIP_MODEL_DENSE;
+  m->n_items = n_items;
+  m->row_begin = 0;
+  m->row_end = n_items;
+  m->ld = n_pad;
+  int rc = rp_dev_alloc(ctx, (size_t)n_pad * n_pad * sizeof(float), (void**)&m->B);
+  // strips of rows: W slots of strip x ldl floats, at most ~2 GiB of staging in all
+  long long strip = std::max<long long>(128, ((long long)((size_t)2 << 30) / ((long long)(W + 1) * ldl * 4)) / 128 * 128);
+  strip = std::min(strip, n_pad);
+  float *sendb = nullptr, *recvb = nullptr;
+  const long long slot = strip * ldl;
+  if (rc == RPHIP_OK) rc = rp_dev_alloc(ctx, (size_t)slot * sizeof(float), (void**)&sendb);
+  if (rc == RPHIP_OK) rc = rp_dev_alloc(ctx, (size_t)slot * W * sizeof(float), (void**)&recvb);
+  hipEvent_t ev;
+  rp_time_begin(ctx, &ev);
+  for (long long r0 = 0; r0 < n_pad && rc == RPHIP_OK; r0 += strip) {
+    const long long rows = std::min(strip, n_pad - r0);
+    // this rank's strip with the common leading dimension (a rank with fewer panels pads with zeros)
+    if (nl < nl_max || !local) hipMemsetAsync(sendb, 0, (size_t)slot * sizeof(float), st);
+    if (local && nl > 0) {
+      const long long quads = rows * (long long)(nl * nb / 4);
+      hipLaunchKernelGGL(k_copy2d, dim3((unsigned)std::min<long long>(8192, rp_cdiv(quads, 256))), dim3(256), 0, st, local->B + r0 * local->ld, (long long)local->ld,
+                         sendb, (long long)ldl, rows, nl * nb, 1.0f);
+    }
+    rc = rp_comm_all_gather(comm, sendb, recvb, slot * (long long)sizeof(float), st);
+    if (rc != RPHIP_OK) break;
+    hipLaunchKernelGGL(k_unpack_panels, dim3((unsigned)std::min<long long>(256, rp_cdiv(rows * (nb / 4), 256)), nl_max, W), dim3(256), 0, st, recvb, slot, ldl,
+                       (int)rows, nb, W, np, m->B, n_pad, r0);
+    if (hipGetLastError() != hipSuccess) rc = RPHIP_EHIP;
+  }
+  rp_time_end(ctx, ev, RPHIP_T_MIRROR, 8.0 * (double)n_pad * n_pad);
+  hipStreamSynchronize(st);
+  rp_dev_free(ctx, sendb);
+  rp_dev_free(ctx, recvb);
+  if (rc == RPHIP_OK) rc = rp_dense_count_empty(ctx, m);
+  if (rc != RPHIP_OK) {
+    rphip_model_destroy(m);
+    return rc;
+  }
+  *out = m;
+  return RPHIP_OK;
 }
 
 extern "C" int rphip_model_dense_layout(const rphip_model* m, int64_t* n_local_cols, int64_t* panel, int32_t* world, int32_t* rank,

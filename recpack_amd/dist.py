@@ -193,6 +193,24 @@ def ease_fit_sharded(ctx, dX, l2: float, alpha: float, device, group=None, panel
     return m, (m.dense_layout() if m is not None else None)
 
 
+def ease_gather_model(ctx, model, n_items: int, comm):
+    """Every rank's column panels of ``ease_fit_sharded`` into ONE full model on this rank (rphip_ease_model_allgather: strips of
+    rows, one all-gather each).  While 3 n^2 floats fit a GPU this is the faster multi-GPU predict: every rank then runs the
+    single-GPU fused predict on ITS USERS (``_lib.predict_topk_dev(..., user_begin, user_end)``) - full-width rows of B, no per-rank
+    candidate lists rescored world times over, no exchange of lists; ``predict_topk_sharded`` stays for matrices that do not fit.
+    ``model`` is None on a rank that owns only padding (it takes part all the same)."""
+    from recpack_amd import _lib
+
+    panel = _lib.ease_fit_dist_stats(ctx)["panel"]  # (of the fit that just ran on this context: known on every rank)
+    return _lib.ease_model_allgather(ctx, comm, model, int(n_items), int(panel))
+
+
+def ease_gather_fits(n_items: int, panel: int, hbm_bytes: int) -> bool:
+    """Does the gathered model (B, its fp16 copy for the first pass of K9, the staging strips) fit beside a rank's own panels?"""
+    n_pad = -(-int(n_items) // max(int(panel), 128)) * max(int(panel), 128)
+    return 3 * n_pad * n_pad * 4 < 0.8 * hbm_bytes
+
+
 def predict_topk_sharded(ctx, model, dX, Kp: int, device, exclude_history: bool = False, group=None, user_chunk: int = 1 << 18, comm=None):
     """Top-Kp for every user with B sharded by item columns, inside the library
     (rphip_predict_topk_dist): every rank scores ALL users against its own columns (`model` = ease_fit_sharded's model, None

@@ -1,9 +1,5 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_itemknn.py -x -q -m gpu -k "any_k or limits or csr or edge" > gpurun_out/r04c_tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/r04c_tests.log
-tail -4 gpurun_out/r04c_tests.log
-python -m pytest tests/test_gpu_ease.py -x -q -m gpu > gpurun_out/r04c_ease.log 2>&1; echo "ease rc=$?" >> gpurun_out/r04c_ease.log
-tail -4 gpurun_out/r04c_ease.log
 timeout 900 python tools/dist_rank_emulate.py --world 8 --ranks 0,7 --config C4 --out gpurun_out/r04_rank_emulation.json > gpurun_out/r04d_emul.log 2>&1; echo "rc=$?" >> gpurun_out/r04d_emul.log
-grep -v amdgpu.ids gpurun_out/r04d_emul.log | grep -v "^  rank" | tail -8 | cut -c1-2500
+grep -v amdgpu.ids gpurun_out/r04d_emul.log | grep -v "^  rank" | tail -4 | cut -c1-2600

@@ -70,13 +70,23 @@ for l2, alpha in ((50.0, 0.0), (5.0, 0.5)):
         # T, staging, the plane workspaces of the products) is O(n nb), not O(n^2): at most 10 n_pad nb floats + the fixed minimum sizes
         # of the workspaces - 15 % of the matrix at 100 000 items with nb = 2048 - and nothing comes from torch
         mem_ok = (torch_peak == 0 and st["slab_bytes"] <= (st["n_pad"] // world + st["panel"]) * st["n_pad"] * 4
-                  and st["other_peak_bytes"] <= 10 * st["n_pad"] * st["panel"] * 4 + (512 << 20))
+                  and st["other_peak_bytes"] <= 10 * st["n_pad"] * st["panel"] * 4 + (1024 << 20))  # (workspaces: powers of two from 64 MiB)
         print(f"rank {rank}/{world} dist panel_tiles={pt} (nb {st['panel']}, {st['pivots']} pivots) l2={l2} alpha={alpha}: {nc} columns, "
               f"max|dB|/max|B| = {err_s:.2e}, sharded top-20 agreement {agree_s:.4f}, score diff {dv:.1e}, slab {st['slab_bytes'] / 2**20:.1f} MiB + "
               f"{st['other_peak_bytes'] / 2**20:.1f} MiB, torch allocations {torch_peak}, received {st['bytes_received'] / 2**20:.1f} MiB "
               f"(n_pad^2*4 = {st['n_pad'] ** 2 * 4 / 2**20:.1f} MiB), rccl {comm.is_rccl}", flush=True)
         ok = ok and err_s <= 1e-4 and agree_s > 0.99 and dv <= 1e-4 and mem_ok
-        del ms
+        # the panels gathered into one full model on every rank: all of B, and the single-GPU predict on this rank's share of the users
+        full = rdist.ease_gather_model(ctx, ms, I, comm)
+        Bg = full.dense_download()
+        err_g = float(np.abs(Bg - B_ref).max() / np.abs(B_ref).max())
+        ub_, ue_ = (nu * rank) // world, (nu * (rank + 1)) // world
+        g = _lib.predict_topk(ctx, full, dX, 20, exclude_history=True, user_begin=ub_, user_end=ue_)
+        agree_g = float((g[0] == b[0][ub_:ue_]).mean()) if ue_ > ub_ else 1.0
+        print(f"rank {rank}/{world} gathered model: max|dB|/max|B| = {err_g:.2e}, empty rows equal: {full.empty_rows() == ref.empty_rows()}, "
+              f"users [{ub_},{ue_}) agreement {agree_g:.4f}", flush=True)
+        ok = ok and err_g <= 1e-4 and full.empty_rows() == ref.empty_rows() and agree_g > 0.99
+        del ms, full
     comm.close()
 if dist.is_initialized():
     t = torch.tensor([1 if ok else 0], device=device)

@@ -15,10 +15,11 @@ part (7 parts over 7 links), an exchange the largest piece to or from one peer. 
                  all-gather of the neighbour lists (modelled; the rank's own lists stand in for the others') + finalisation of the
                  full model + K8 for the rank's users
   EASE half      rphip_ease_fit_dist (Gram of the rank's panels, the symmetric block sweeps with look-ahead: update stream, chain,
-                 pivot stream, communication stream) + rphip_predict_topk_dist (all users against the rank's columns, the
-                 personalised exchange, the merge of the rank's users).  The predict runs on a REAL slab of B - n / world columns of
-                 the single-GPU model of the same process: the emulated fit works on noise, and on noise the fp16 first pass of K9
-                 cannot prove its lists (every user would take the exact second pass: 4x the time)
+                 pivot stream, communication stream) + the predict route bench.py takes at this size: rphip_ease_model_allgather (the
+                 panels into one full model: strips of rows, one modelled all-gather each) + the single-GPU fused predict for the
+                 rank's USERS.  That predict runs on the REAL B of the single-GPU fit of the same process (a fresh model object per
+                 run: the fp16 copy of the first pass is rebuilt as it would be): the emulated fit works on noise, and on noise the
+                 fp16 first pass of K9 cannot prove its lists (every user would take the exact second pass)
 
 The results of such a run are meaningless (the data of the other ranks never existed); the launches, their sizes and their
 overlap are rank r's.  `speedup_emulated` = the single-GPU step of the same build (measured in the same process) divided by the
@@ -47,6 +48,7 @@ def main():
     ap.add_argument("--Kp", type=int, default=100)
     ap.add_argument("--l2", type=float, default=200.0)
     ap.add_argument("--repeats", type=int, default=2)
+    ap.add_argument("--panel-tiles", type=int, default=0, help="panel width of the distributed solve in 128-column tiles (0: the library's choice)")
     ap.add_argument("--skip-single", action="store_true", help="do not measure the single-GPU step (no speed-up is computed then)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
@@ -108,16 +110,8 @@ def main():
             dX.close()
         out["single_gpu"] = {k: round(v, 5) for k, v in best.items()}
         del oi, ov, on
-        # rank r's columns of the real B (contiguous n / world columns: the cost of a cyclic map is the same), copied out of the model
         ptr, n_it, ld = em.dense_device_ptr()
-        Bfull = torch.as_tensor(rdist._DevPtr(ptr, (n_it, ld), "<f4", em), device=dev)
-        slabs = {}
-        for r in [int(x) for x in args.ranks.split(",")]:
-            c0, c1 = (I * r) // W, (I * (r + 1)) // W
-            slabs[r] = (c0, Bfull[:I, c0:c1].contiguous())
-        del Bfull, em
-        ctx.trim()
-        print("single GPU:", out["single_gpu"], flush=True)
+        Breal = torch.as_tensor(rdist._DevPtr(ptr, (n_it, ld), "<f4", em), device=dev)  # (the single-GPU model stays alive: its B is the emulated ranks' "gathered" B)
 
     # ---- one rank at a time
     for r in [int(x) for x in args.ranks.split(",")]:
@@ -157,28 +151,29 @@ def main():
             # EASE half
             dXe = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
             ctx.reset_timings()
-            em = _lib.ease_fit_dist(ctx, comm, dXe, args.l2, 0.0)
+            em_r = _lib.ease_fit_dist(ctx, comm, dXe, args.l2, 0.0, args.panel_tiles)
             sync()
             t2 = time.perf_counter()
             print(f"  rank {r}: EASE fit done", flush=True)
             tm = ctx.timings()
             st = _lib.ease_fit_dist_stats(ctx)
-            del em
+            efull = rdist.ease_gather_model(ctx, em_r, I, comm)  # (its contents are the emulated fit's noise: only its time counts)
+            sync()
+            t_g = time.perf_counter()
+            del efull, em_r
+            t_skip = 0.0
             if not args.skip_single:
-                c0, slab = slabs[r]
-                pm = _lib.Model.from_dense_cols(ctx, I, c0, slab.shape[1], slab)
-            else:
-                pm = None
-            sync()
-            t2b = time.perf_counter()
-            if pm is not None:
-                rdist.predict_topk_sharded(ctx, pm, dXe, Kp, dev, exclude_history=False, comm=comm)
-            sync()
-            t3 = time.perf_counter() - (t2b - t2)
-            del pm
+                ts = time.perf_counter()
+                pm = _lib.Model.from_dense_cols(ctx, I, 0, I, Breal[:, :I])
+                sync()
+                t_skip = time.perf_counter() - ts
+                _lib.predict_topk_dev(ctx, pm, dXe, Kp, oi, ov, on, user_begin=ub, user_end=ue)
+                sync()
+                del pm
+            t3 = time.perf_counter() - t_skip
             cur = {"step_s": t3 - t0, "itemknn_s": t1 - t0, "itemknn_k0_shard_s": t_k0 - t0, "itemknn_fit_rows_s": t_fit - t_k0,
                    "itemknn_gather_finalize_s": t_gather - t_fit, "itemknn_predict_users_s": t1 - t_gather,
-                   "ease_fit_s": t2 - t1, "ease_predict_s": t3 - t2,
+                   "ease_fit_s": t2 - t1, "ease_predict_s": t3 - t2, "ease_gather_model_s": t_g - t2,
                    "ease_update_stream_kernel_s": tm["sweep_update"]["ms"] / 1e3, "ease_chain_kernel_s": tm["sweep_chain"]["ms"] / 1e3,
                    "ease_gram_s": tm["gram_dense"]["ms"] / 1e3, "ease_mirror_s": tm["mirror"]["ms"] / 1e3,
                    "ease_bytes_received": st["bytes_received"], "ease_bytes_sent": st["bytes_sent"], "ease_pivots": st["pivots"],
