@@ -434,8 +434,9 @@ int rphip_comm_all_reduce_sum_i32(rphip_ctx* ctx, rphip_comm* comm, int32_t* buf
 int rphip_itemknn_gather(rphip_ctx* ctx, rphip_comm* comm, const rphip_model* local, const int64_t* row_bounds, rphip_model** out);
 
 /* EASE fit over the ranks of `comm` with the n x n matrix SHARDED in memory (replaces EASE._fit,
- * ease.py:63-95, whose np.linalg.inv is the n^3 step).  Layout: panels of nb = 128 * panel_tiles columns, panel p on rank
- * p % world (1-D block-cyclic: every rank's share of the lower triangle is the same whatever the pivot); a rank stores its
+ * ease.py:63-95, whose np.linalg.inv is the n^3 step).  Layout: panels of nb = 128 * panel_tiles columns, 1-D block-cyclic with
+ * reflected odd rounds (rphip_model_dense_layout: every pair of rounds gives every rank the same share of the lower triangle -
+ * plain cyclic left rank 0 a third more update flop than the last rank at 8 ranks and 49 panels); a rank stores its
  * panels side by side, all n_pad rows (n_pad = n rounded up to nb), and only the lower triangle is worked on.
  * Solve: symmetric block Gauss-Jordan sweeps (Goodnight 1979) - for pivot panel K: P = A_KK^-1 (blocked Cholesky on MFMA
  * tiles, on the owner), V = the pivot's full column A[:, K] (the part left of the diagonal gathered from the row block K of
@@ -464,8 +465,10 @@ int rphip_ease_model_allgather(rphip_ctx* ctx, rphip_comm* comm, const rphip_mod
 int rphip_predict_topk_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip_model* model, const rphip_csr* Xpred, int32_t Kp,
                             int32_t exclude_history, int64_t* user_begin_out, int64_t* n_users_out, int32_t* idx_dev, float* val_dev,
                             int32_t* nnz_dev);
-/* Layout of a dense model's columns: local column l is item ((l / panel) * world + rank) * panel + l % panel when panel > 0
- * (block-cyclic, rphip_ease_fit_dist), col_begin + l otherwise; n_local_cols of them are items (the rest is padding). */
+/* Layout of a dense model's columns.  panel > 0 (rphip_ease_fit_dist): block-cyclic panels of `panel` columns with reflected odd
+ * rounds - local panel q = l / panel is the matrix's panel q * world + rank for even q, q * world + (world - 1 - rank) for odd q
+ * (every pair of rounds gives every rank the same share of the lower triangle), item = that panel * panel + l % panel.  Otherwise
+ * col_begin + l.  n_local_cols of the local columns are items (the rest is padding). */
 int rphip_model_dense_layout(const rphip_model* m, int64_t* n_local_cols, int64_t* panel, int32_t* world, int32_t* rank, int64_t* col_begin);
 /* numbers of the last rphip_ease_fit_dist on this context: [0] slab bytes, [1] peak bytes of everything else the fit held
  * (panel buffers, staging, plane workspaces), [2] bytes received through the communicator, [3] bytes sent, [4] pivots,

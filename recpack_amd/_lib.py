@@ -441,7 +441,8 @@ class Model:
 
     def dense_layout(self) -> dict:
         """Which items the columns of a dense model's B are (rphip_model_dense_layout): ``n_local`` columns; with ``panel`` > 0
-        they are block-cyclic panels (local column l = item ((l // panel) * world + rank) * panel + l % panel), otherwise the
+        they are block-cyclic panels with reflected odd rounds (local panel q = l // panel is the matrix's panel q * world + rank for even q,
+        q * world + world - 1 - rank for odd q), otherwise the
         range starting at ``col_begin``."""
         n, nb, cb = C.c_int64(), C.c_int64(), C.c_int64()
         w, r = C.c_int32(), C.c_int32()
@@ -452,8 +453,10 @@ class Model:
         """Item ids of the local columns of a dense model (ascending)."""
         lay = self.dense_layout()
         l = np.arange(lay["n_local"], dtype=np.int64)
-        if lay["panel"] > 0:
-            return ((l // lay["panel"]) * lay["world"] + lay["rank"]) * lay["panel"] + l % lay["panel"]
+        if lay["panel"] > 0:  # rp_common.h rp_cyc_panel: block-cyclic with reflected odd rounds
+            q = l // lay["panel"]
+            pos = np.where(q % 2 == 1, lay["world"] - 1 - lay["rank"], lay["rank"])
+            return (q * lay["world"] + pos) * lay["panel"] + l % lay["panel"]
         return lay["col_begin"] + l
 
     def dense_prune(self, keep: int):

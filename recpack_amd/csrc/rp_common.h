@@ -161,7 +161,7 @@ struct rphip_model {
   int64_t ld = 0;
   int64_t col_begin = 0, n_cols = 0;  // n_cols > 0: B holds only the columns [col_begin, col_begin + n_cols) (rphip_model_from_dense_cols)
   // n_cols > 0 and cyc_nb > 0: the columns are block-cyclic panels of cyc_nb columns (rphip_ease_fit_dist): local column l is item
-  // ((l / cyc_nb) * cyc_world + cyc_rank) * cyc_nb + l % cyc_nb; the n_cols items are a prefix of the local columns
+  // rp_cyc_panel(l / cyc_nb, cyc_rank, cyc_world) * cyc_nb + l % cyc_nb (below); the n_cols items are a prefix of the local columns
   int32_t cyc_nb = 0, cyc_world = 1, cyc_rank = 0;
   // fp16 copy of B for the first pass of the two-pass K9 (built on first use, rp_predict.hip): B16 = fp16(B * b16_scale), the same
   // leading dimension; b16_delta[i] = the largest rounding error of row i (in B's units), b16_rowmax[i] = its largest |entry|
@@ -209,3 +209,15 @@ int rp_model_finalize_topk(rphip_ctx* ctx, rphip_model* m);
 int rp_user_tile_ptr(rphip_ctx* ctx, const rphip_csr* X, int T, int W, int32_t* out);
 
 static inline int64_t rp_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- the panel layout of the distributed EASE solve (rp_ease_dist.hip, rp_predict.hip, rp_ease.hip) --------------------------------
+// 1-D block-cyclic with REFLECTED odd rounds (round 4): round q = panels [q W, (q + 1) W) of the matrix; rank r holds the panel at
+// position r of an even round and W - 1 - r of an odd one, as its local panel q.  The solve works on the lower triangle, where panel
+// p carries np - p tiles: plain cyclic (rank p mod W) gave rank 0 a third more update flop than rank W - 1 at W = 8 and 49 panels;
+// reflected, every pair of rounds gives every rank the same count.  Local panels stay in the matrix's order.
+__host__ __device__ inline int rp_cyc_pos(int q, int r, int W) { return (q & 1) ? W - 1 - r : r; }
+__host__ __device__ inline int rp_cyc_panel(int q, int r, int W) { return q * W + rp_cyc_pos(q, r, W); }  // the matrix's panel of rank r's local panel q
+__host__ __device__ inline int rp_cyc_owner(int p, int W) { return rp_cyc_pos(p / W, p % W, W); }          // (the reflection is its own inverse)
+__host__ __device__ inline int rp_cyc_count(int np, int r, int W) {  // panels < np that rank r holds
+  return np / W + ((np % W) && rp_cyc_pos(np / W, r, W) < np % W ? 1 : 0);
+}

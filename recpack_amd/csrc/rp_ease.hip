@@ -55,7 +55,7 @@ __device__ __forceinline__ bool rp_gemm_tile(const rp_gemm_args& g, int& tm, int
 __device__ __forceinline__ int rp_gemm_ncol(const rp_gemm_args& g, int n0) {
   if (!g.cyc_nb) return g.n_off + n0;
   const int l = g.cyc_l0 + n0;
-  return ((l / g.cyc_nb) * g.cyc_w + g.cyc_r) * g.cyc_nb + l % g.cyc_nb;
+  return rp_cyc_panel(l / g.cyc_nb, g.cyc_r, g.cyc_w) * g.cyc_nb + l % g.cyc_nb;
 }
 __device__ __forceinline__ bool rp_gemm_skip(const rp_gemm_args& g, int m0, int n0) {
   if (g.tri == 1) return rp_gemm_ncol(g, n0) > g.m_off + m0;

@@ -4,7 +4,7 @@
 // should not or cannot hold; the reference has no multi-GPU path (recpack/algorithms/base.py:454-455, 686-690: a TODO).
 //
 // Layout.  n_pad = n rounded up to the panel width nb = 128 * panel_tiles; panel p (columns [p nb, (p + 1) nb)) lives on rank
-// p % W at local panel p / W (1-D block-cyclic).  A rank stores its nl panels side by side: S[n_pad][nl * nb] row-major.  The
+// rp_cyc_owner(p) at local panel p / W (1-D block-cyclic with reflected odd rounds: rp_common.h).  A rank stores its nl panels side by side: S[n_pad][nl * nb] row-major.  The
 // matrix is symmetric throughout, only blocks (i, j) with i >= j are kept current ("lower"); the diagonal blocks are kept in
 // their lower 128-tiles.
 //
@@ -364,11 +364,11 @@ __global__ void k_copy2d(const float* __restrict__ src, long long lds, float* __
   }
 }
 
-// pieces gathered from the ranks: slot (r, q) at src + (r * slots + q) * nb * nb is the nb x nb block of global panel q * W + r;
+// pieces gathered from the ranks: slot (r, q) at src + (r * slots + q) * nb * nb is the nb x nb block of rank r's local panel q;
 // blocks of panels < limit go to dst rows [panel * nb, +nb) (leading dimension ldd)
 __global__ void k_unpack_pieces(const float* __restrict__ src, int slots, int W, int limit, int nb, float* __restrict__ dst, long long ldd) {
   const int z = blockIdx.y, r = z / slots, q = z % slots;
-  const int panel = q * W + r;
+  const int panel = rp_cyc_panel(q, r, W);
   if (panel >= limit) return;
   const float* s = src + (long long)z * nb * nb;
   float* d = dst + (long long)panel * nb * ldd;
@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(256) k_mirror_block(float* __restrict__ P, lon
 
 struct rp_cyc {
   int nb, W, r;
-  __host__ __device__ int to_global(int l) const { return ((l / nb) * W + r) * nb + l % nb; }
+  __host__ __device__ int to_global(int l) const { return rp_cyc_panel(l / nb, r, W) * nb + l % nb; }
 };
 
 // K7 on block-cyclic panels holding sign * P: colscale_l = -w_j / S_jl (the sign cancels in P_ij / P_jj), 0 for padding columns
@@ -493,9 +493,9 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
   const long long n_pad_ll = (long long)np * nb;
   if (n_pad_ll > 0x7fffffffLL - nb) RP_FAIL(RPHIP_ELIMIT, "too many items");
   const int n_pad = (int)n_pad_ll;
-  const int nl = np > me ? (np - me + W - 1) / W : 0;  // own panels: me, me + W, ...
+  const int nl = rp_cyc_count(np, me, W);  // own panels: one per round (rp_cyc_panel)
   const long long ld = (long long)std::max(nl, 1) * nb;
-  auto cnt_lt = [&](int K, int r) { return K > r ? (K - r + W - 1) / W : 0; };  // panels of rank r below K
+  auto cnt_lt = [&](int K, int r) { return rp_cyc_count(K, r, W); };  // panels of rank r below K
   const int slots = (int)rp_cdiv(np, W);                                        // pieces a rank contributes at most
   const float lam = (float)l2;  // rounded to float32 as the reference does (ease.py:82)
   hipStream_t st = ctx->stream;
@@ -592,7 +592,7 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
 
   // ---- G + l2 I, the own panels: Gram rows of a panel (K4) into V[0], transposed into the panel (G is symmetric)
   for (int q = 0; q < nl; ++q) {
-    const int p = q * W + me;
+    const int p = rp_cyc_panel(q, me, W);
     // (the entry point indexes rows absolutely: row p nb of the matrix is row 0 of the staging buffer)
     DTRY(rp_ease_gram_rows(ctx, X, (int64_t)p * nb, (int64_t)(p + 1) * nb, n_pad, lam, V[0] - (long long)p * nb * n_pad, n_pad));
     DTRY(rp_transpose_f32(ctx, V[0], n_pad, nb, n_pad, S + (long long)q * nb, ld));
@@ -661,7 +661,7 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
     RP_HIP(hipEventRecord(e_inv, sp));
     return RPHIP_OK;
   };
-  if (np > 0 && 0 % W == me) {  // pivot 0
+  if (np > 0 && rp_cyc_owner(0, W) == me) {  // pivot 0
     copy2d(S, ld, V[0] + (long long)n_pad * nb, nb, nb, nb, 1.0f, st);
     DHIP(hipEventRecord(e_diag, st));
     DTRY(start_inverse(V[0] + (long long)n_pad * nb));
@@ -669,7 +669,7 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
   bool upd_pending = false;
   for (int K = 0; K < np; ++K) {
     const int cur = K & 1;
-    const int owner = K % W, lpK = K / W;
+    const int owner = rp_cyc_owner(K, W), lpK = K / W;
     const int cnt = cnt_lt(K, me);                     // own panels left of the pivot: local panels [0, cnt)
     const int own_K = (owner == me) ? 1 : 0;
     const long long r0 = (long long)K * nb;
@@ -708,7 +708,7 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
       DTRY(gemm(Vc + (r0 + nb) * nb, nb, Pc, nb, Tc + (long long)(K + 1) * nb * nb, nb, (nl - K - 1) * nb, nb, 1.0f, 0.0f, st));
     } else {
       for (int q = cnt + own_K; q < nl; ++q) {
-        const long long rows_at = (long long)(q * W + me) * nb;
+        const long long rows_at = (long long)rp_cyc_panel(q, me, W) * nb;
         DTRY(gemm(Vc + rows_at * nb, nb, Pc, nb, Tc + (long long)q * nb * nb, nb, nb, nb, 1.0f, 0.0f, st));
       }
     }
@@ -725,7 +725,7 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
     DHIP(hipGetLastError());
     DHIP(hipEventRecord(e_chain[cur], st));
     // -- look-ahead part of update K (main stream): what chain(K + 1) reads.  It adds to tiles U(K - 1) also adds to: wait for it.
-    const bool own_K1 = K + 1 < np && (K + 1) % W == me;
+    const bool own_K1 = K + 1 < np && rp_cyc_owner(K + 1, W) == me;
     const int q1 = (K + 1) / W;
     const long long r1 = r0 + nb;
     if (K + 1 < np) {
@@ -772,7 +772,7 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
   hipEvent_t t_mir;
   rp_time_begin(ctx, &t_mir);
   for (int q = 0; q < nl; ++q) {
-    const long long p = (long long)q * W + me;
+    const long long p = rp_cyc_panel(q, me, W);
     hipLaunchKernelGGL(k_mirror_block, dim3(nb / 32, nb / 32), dim3(256), 0, st, S + p * nb * ld + (long long)q * nb, ld);
   }
   DHIP(hipGetLastError());
@@ -786,7 +786,7 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
       if (base >= np) break;
       int64_t so = 0;
       for (int d = 0; d < W; ++d) {
-        const int j = base + d;  // the panel of rank j % W ... = d only if base % W == 0 (it is: base is a multiple of W)
+        const int j = rp_cyc_panel(base / W, d, W);  // rank d's panel of this round
         const int c = (j < np) ? cnt_lt(j, me) : 0;
         soff[d] = so;
         sby[d] = (int64_t)c * piece;
@@ -795,7 +795,7 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
                              sendb + so / 4, (long long)nb, (long long)nb * nb);
         so += sby[d];
       }
-      const int jm = base + me;  // my panel of this group
+      const int jm = rp_cyc_panel(base / W, me, W);  // my panel of this round
       const int gs = (jm < np) ? (int)rp_cdiv(jm, W) : 0;
       for (int s = 0; s < W; ++s) {
         roff[s] = (int64_t)s * gs * piece;
@@ -853,7 +853,7 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
   }
   // items among the local columns: a prefix (the padding is the tail of the last panel)
   int64_t n_cols = 0;
-  for (int q = 0; q < nl; ++q) n_cols += std::max<int64_t>(0, std::min<int64_t>(nb, (int64_t)n - (int64_t)(q * W + me) * nb));
+  for (int q = 0; q < nl; ++q) n_cols += std::max<int64_t>(0, std::min<int64_t>(nb, (int64_t)n - (int64_t)rp_cyc_panel(q, me, W) * nb));
   m->n_cols = n_cols;
   if (n_cols == 0) {  // this rank owns only padding
     rphip_model_destroy(m);
@@ -866,13 +866,13 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
 }
 
 // ---- the ranks' column panels into ONE full model on every rank --------------------------------------------------------------
-// rows [r0, r0 + rows) of every rank's panels (recv[q][i][a * nb + c], leading dimension ldl) into B[r0 + i][(a * W + q) * nb + c]
+// rows [r0, r0 + rows) of every rank's panels (recv[q][i][a * nb + c], leading dimension ldl) into B[r0 + i][panel(a, q) * nb + c]
 __global__ void k_unpack_panels(const float* __restrict__ recv, long long slot_floats, int ldl, int rows, int nb, int W, int np, float* __restrict__ B,
                                 long long ldB, long long r0) {
   const int c4 = nb >> 2;
   const int q = blockIdx.z;                 // source rank
   const int a = blockIdx.y;                 // its local panel
-  const int p = a * W + q;                  // the panel of the matrix
+  const int p = rp_cyc_panel(a, q, W);      // the panel of the matrix
   if (p >= np) return;
   const float* src = recv + (long long)q * slot_floats + (long long)a * nb;
   float* dst = B + r0 * ldB + (long long)p * nb;
@@ -902,7 +902,7 @@ extern "C" int rphip_ease_model_allgather(rphip_ctx* ctx, rphip_comm* comm, cons
   RP_TRY(rp_set_device(ctx));
   const long long n_pad = rp_cdiv(n_items, nb) * nb;
   const int np = (int)(n_pad / nb), nl_max = (int)rp_cdiv(np, W);
-  const int nl = (np > me) ? (np - me + W - 1) / W : 0;
+  const int nl = rp_cyc_count(np, me, W);
   const int ldl = nl_max * nb;
   hipStream_t st = ctx->stream;
   rphip_model* m = new rphip_model();

@@ -40,8 +40,8 @@ struct rp_gemm_args {
   const unsigned* amax;  // k_gemm_nt_h2: device words [max |A|, max |B|] over the ranges read (k_gemm_amax); set by rp_gemm_nt
   int sw;            // tiles per row of a supertile (64 tiles: sw x 64/sw), 0 = plain row-major 2-D grid; set by rp_gemm_nt
   // C's columns are LOCAL columns of a block-cyclic layout (rp_ease_dist.hip): panels of cyc_nb columns, panel p of the matrix on
-  // rank p % cyc_w at local panel p / cyc_w.  Local column cyc_l0 + n0 of rank cyc_r is then global column
-  // ((l / cyc_nb) * cyc_w + cyc_r) * cyc_nb + l % cyc_nb, which is what the `tri` tests compare with the row.  0 = off.
+  // rank rp_cyc_owner(p) at local panel p / cyc_w (rp_common.h).  Local column l = cyc_l0 + n0 of rank cyc_r is then global column
+  // rp_cyc_panel(l / cyc_nb, cyc_r, cyc_w) * cyc_nb + l % cyc_nb, which is what the `tri` tests compare with the row.  0 = off.
   int cyc_nb, cyc_w, cyc_r, cyc_l0;
   int no_splitk;     // never split K (the product runs beside others that use the shared partial-sum scratch)
   int ws_slot;       // scratch slots ws_slot, ws_slot + 1 hold this product's plane workspaces (0: 8 / 9 on the context's stream, 10 / 11 elsewhere)

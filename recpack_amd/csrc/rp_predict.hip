@@ -82,7 +82,7 @@ struct rp_pred_params {
   float b16_inv;              // 1 / b16_scale (a power of two)
   int col_begin;          // dense column slab: column 0 of dense_B is item col_begin (n_items = the slab's width then)
   int cyc_nb, cyc_w, cyc_r;  // cyc_nb > 0: the slab's columns are block-cyclic panels (rphip_ease_fit_dist): local column l is item
-                             // ((l / cyc_nb) * cyc_w + cyc_r) * cyc_nb + l % cyc_nb
+                             // rp_cyc_panel(l / cyc_nb, cyc_r, cyc_w) * cyc_nb + l % cyc_nb (rp_common.h)
   const uint8_t* keep;    // optional item filter (mode 0): only items with keep[j] != 0 are candidates
   int n_items, n_tiles, tile_w, K, Kp, exclude_history;
   rp_fix_scale fix;       // neighbour lists: scale of the fixed-point sums
@@ -101,12 +101,12 @@ struct rp_pred_params {
 
 // item of a slab's local column / local column of an item (-1: not in this slab)
 __device__ __forceinline__ int rp_pred_l2g(const rp_pred_params& P, int l) {
-  return P.cyc_nb ? ((l / P.cyc_nb) * P.cyc_w + P.cyc_r) * P.cyc_nb + l % P.cyc_nb : P.col_begin + l;
+  return P.cyc_nb ? rp_cyc_panel(l / P.cyc_nb, P.cyc_r, P.cyc_w) * P.cyc_nb + l % P.cyc_nb : P.col_begin + l;
 }
 __device__ __forceinline__ int rp_pred_g2l(const rp_pred_params& P, int g) {
   if (!P.cyc_nb) return g - P.col_begin;
   const int p = g / P.cyc_nb;
-  return (p % P.cyc_w == P.cyc_r) ? (p / P.cyc_w) * P.cyc_nb + g % P.cyc_nb : -0x40000000;
+  return (rp_cyc_owner(p, P.cyc_w) == P.cyc_r) ? (p / P.cyc_w) * P.cyc_nb + g % P.cyc_nb : -0x40000000;
 }
 
 // tile of f32 scores (dense models) or of fixed-point sums (neighbour lists)

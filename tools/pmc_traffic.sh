@@ -20,7 +20,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if row.get("Counter_Name") != c:
                 continue
             k = row["Kernel_Name"]
-            if any(s in k for s in ("k_itemknn", "k_predict", "k_rank_hist", "k_scatter", "k_gemm", "k_split", "k_ease", "k_potrf", "k_dense")):
+            if any(s in k for s in ("k_itemknn", "k_predict", "k_rows", "k_partition", "k_bucket", "k_gemm", "k_split", "k_ease", "k_potrf", "k_dense")):
                 acc[k][0] += float(row["Counter_Value"])
                 acc[k][1] += 1
     for k, (v, n) in acc.items():
