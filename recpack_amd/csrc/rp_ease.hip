@@ -1828,6 +1828,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
   for (auto& e : n22_ev.v) RP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   RP_HIP(hipEventRecord(e_panel, st));  // (the factor is complete)
   RP_HIP(hipStreamWaitEvent(s2, e_panel, 0));
+  const int n22_f32 = getenv("RP_N22_PLANES") == nullptr ? 1 : 0;
   auto n22 = [&](int P) -> int {
     const int pb = P * RP_INV_PANEL, pe = std::min(nb, pb + RP_INV_PANEL);
     const int j = pb * GT;
@@ -1852,8 +1853,10 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
         g.alpha = 1.0f;
         g.beta = 0.0f;
         g.no_splitk = 1;
+        g.f32 = n22_f32;  // (round 4: these tiny products - at most 15 x 1 tiles - on the fp32 kernel: one launch each, no measuring pass, no memset)
         RP_TRY(rp_gemm_nt(ctx, g, s2));
         rp_gemm_args h{};
+        h.f32 = n22_f32;
         h.A = T2;
         h.lda = GT;
         h.B = Wi;

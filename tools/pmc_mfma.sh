@@ -2,8 +2,8 @@
 # MFMA counters of the EASE solve's GEMM (k_gemm_nt): tools/pmc_mfma.sh [users items density]   (on the GPU box)
 # One rocprofv3 --pmc pass (SQ block: 8 slots) with --kernel-trace only; prints per-kernel sums and the derived utilisation:
 #   MFMA busy share  = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CU_CYCLES x 4 SIMDs)   [cycles the matrix pipes were busy]
-#   flops from MOPS  = (SQ_INSTS_VALU_MFMA_MOPS_F16 + _BF16) x 512   (the default solve runs fp16 plane products; RECPACK_GEMM_MODE=1
-#                      in the environment selects the bf16 three-plane kernel, whose products count under _BF16)
+#   flops from MOPS  = (SQ_INSTS_VALU_MFMA_MOPS_F16 + _BF16) x 512   (the default solve runs fp16 plane products; the _BF16 counter is kept
+#                      in the pass and reads 0 since round 4)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 U=${1:-200000}; I=${2:-50000}; D=${3:-0.001}
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA \
