@@ -726,6 +726,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm_hp16(rp_hp_args q) {
 #ifndef RP_GEMM_ABL
 #define RP_GEMM_ABL 0
 #endif
+#ifndef RP_FLUSH_FAST
+#define RP_FLUSH_FAST 1  // 0: the six-operation two-sum of rounds 2 and 3
+#endif
 __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
   // [stage][A: plane 2 x block 8 x K16 2 | B: plane 2 x block 4 x K16 2][1 KB]
   extern __shared__ __attribute__((aligned(1024))) unsigned char smw[];
@@ -800,10 +803,46 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
     }
   bool fresh = true;  // the accumulators hold nothing (uniform)
   auto flush = [&]() __attribute__((always_inline)) {
+    const rp_f2 us2 = {unscale, unscale};
+    // the bf16 pairs (1, 0) and (0, 1) from scalar registers: as an immediate the first becomes the inline constant "1.0", which
+    // the instruction does not read as this pair (found as an error of 1e-5 in a K = 4096 product)
+    uint32_t c10, c01;
+    asm("s_mov_b32 %0, 0x3f80" : "=s"(c10));
+    asm("s_mov_b32 %0, 0x3f800000" : "=s"(c01));
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+#if RP_FLUSH_FAST
+        // (round 4) The flush is VALU time, ~80 cycles per pair of elements for two waves per SIMD, with nothing beside it (8 % of a
+        // long-K product by removal; packed fp32 instructions take two passes per wave64 and buy nothing).  Fewer operations:
+        // * the error of hi + p by Dekker's three operations (s = hi + p, e = p - (s - hi)) instead of Knuth's six.  Exact while
+        //   |hi| >= |p|; when a block's partial sum p outgrows the running sum (cancellation, the first blocks) the term it misses
+        //   is below ulp(p) - less than what the block's own 32 fp32 accumulation steps inside the matrix pipe have already put
+        //   on p.  (s, e) never loses more than an uncompensated sum would.
+        // * lo + e through v_dot2_f32_bf16 against the constant pairs (1, 0) and (0, 1): the packed bf16 halves are read where they
+        //   stand - one instruction per element instead of shift / mask + add.
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const rp_f2 a2 = {acc[i][j][r], acc[i][j][r + 1]}, h2 = {hi[i][j][r], hi[i][j][r + 1]};
+          const rp_f2 m1 = {-1.0f, -1.0f};
+          const rp_f2 sv = __builtin_elementwise_fma(a2, us2, h2);
+          const rp_f2 z = __builtin_elementwise_fma(h2, m1, sv);
+          const rp_f2 e = __builtin_elementwise_fma(a2, us2, -z);
+          hi[i][j][r] = sv[0];
+          hi[i][j][r + 1] = sv[1];
+#if RP_FLUSH_FAST == 2
+          const uint32_t pk = lo[i][j][r >> 1];
+          const rp_f2 l = {__uint_as_float(pk << 16) + e[0], __uint_as_float(pk & 0xffff0000u) + e[1]};
+#else
+          const rp_bf2 lp = __builtin_bit_cast(rp_bf2, lo[i][j][r >> 1]);
+          const rp_f2 l = {__builtin_amdgcn_fdot2_f32_bf16(lp, __builtin_bit_cast(rp_bf2, c10), e[0], false),
+                           __builtin_amdgcn_fdot2_f32_bf16(lp, __builtin_bit_cast(rp_bf2, c01), e[1], false)};
+#endif
+          const rp_bf2 pb = __builtin_convertvector(l, rp_bf2);
+          lo[i][j][r >> 1] = __builtin_bit_cast(uint32_t, pb);
+        }
+#else
         const f32x4 av = acc[i][j] * unscale, h = hi[i][j];
         const f32x4 sv = h + av;
         const f32x4 bv = sv - h;
@@ -816,6 +855,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
           const rp_bf2 pb = __builtin_convertvector(l, rp_bf2);
           lo[i][j][r >> 1] = __builtin_bit_cast(uint32_t, pb);
         }
+#endif
       }
     fresh = true;
   };
@@ -1878,12 +1918,23 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
   };
   constexpr int N22_AHEAD = 3;
   int n22_issued = 0;
+  // diagnostic (RP_INV_TRACE=1): where the inverse's main stream spends its time, summed over the panels
+  std::vector<hipEvent_t> iv_ev;
+  const bool itrace = getenv("RP_INV_TRACE") != nullptr;
+  auto iv_rec = [&]() {
+    if (!itrace) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    hipEventRecord(e, st);
+    iv_ev.push_back(e);
+  };
   for (int pb = 0; pb < nb; pb += RP_INV_PANEL) {
     const int pe = std::min(nb, pb + RP_INV_PANEL);
     const int j = pb * GT, w = (pe - pb) * GT;
     const int P = pb / RP_INV_PANEL;
     for (; n22_issued < std::min(n_inv_panels, P + 1 + N22_AHEAD); ++n22_issued) RP_TRY(n22(n22_issued));
     RP_HIP(hipStreamWaitEvent(st, n22_ev.v[P], 0));
+    iv_rec();  // 0: after the wait for N22
     if (j > 0) {
       rp_gemm_args g{};  // T = N11 L21^T
       g.A = Nb;
@@ -1913,6 +1964,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
         g.no_splitk = 1;
       }
       RP_TRY(rp_gemm_nt(ctx, g, st));
+      iv_rec();  // 1: T done
       hipLaunchKernelGGL(k_transpose_block, dim3(w / 32, w / 32), dim3(32, 8), 0, st, Nb + (long long)j * ld + j, ld, NT, (long long)w);
       rp_gemm_args h{};  // N12 = -T N22 (N22 is upper triangular: K ends with the column tile)
       h.ke_n = 1;
@@ -1929,7 +1981,10 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
       h.alpha = -1.0f;
       h.beta = 0.0f;
       RP_TRY(rp_gemm_nt(ctx, h, st));
+    } else {
+      iv_rec();
     }
+    iv_rec();  // 2: N12 done
     if (j < Kc) {  // columns [j, j + w) of N are final: into the cache (rows 0 .. j + w; a row tile's K starts at its own first column)
       const int c = j / inv_w, rows = j + w;
       rp_amax_op oa{Nb, ld, rows / GT, 1, 0, 0}, ob{nullptr, 0, 0, 0, 0, 0};
@@ -1937,6 +1992,26 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
       rp_split_args sa{Nb, ld, rows, j, j + w, 1, 0, 0, j, j + w, pc.amax + c, pc.W, pc.ps, (long long)pc.K / 16, 0};
       hipLaunchKernelGGL(k_split_planes, dim3(rows / 32, (unsigned)rp_cdiv(w / 16, 16)), dim3(256), 0, st, sa);
     }
+    iv_rec();  // 3: into the cache
+  }
+  if (itrace) {
+    hipStreamSynchronize(st);
+    double sum[4] = {0, 0, 0, 0};
+    std::string per;
+    for (size_t i = 1; i < iv_ev.size(); ++i) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, iv_ev[i - 1], iv_ev[i]);
+      sum[i % 4] += ms;
+      if (i % 4 == 1 || i % 4 == 2) {
+        char b[32];
+        snprintf(b, sizeof b, (i % 4 == 1) ? " | %.1f" : " %.1f", ms);
+        per += b;
+      }
+    }
+    fprintf(stderr, "inverse main stream: wait for N22 %.1f ms, T %.1f, N12 %.1f, cache %.1f; per panel (T, N12):%s\n", sum[0], sum[1], sum[2], sum[3], per.c_str());
+    for (auto e : iv_ev) hipEventDestroy(e);
+    iv_ev.clear();
+    iv_rec();
   }
   // ---- K6b: P = N N^T (lower tiles, K from max(row, column) = row), mirrored into the upper half
   {
@@ -1972,12 +2047,30 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
     } else {
       RP_TRY(rp_gemm_nt(ctx, g, st));
     }
+    if (itrace) {
+      iv_rec();
+      hipStreamSynchronize(st);
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, iv_ev[0], iv_ev[1]);
+      fprintf(stderr, "inverse: N N^T (lower tiles) %.1f ms\n", ms);
+      for (auto e : iv_ev) hipEventDestroy(e);
+      iv_ev.clear();
+      iv_rec();
+    }
     g.tri = 3;  // ... the diagonal tiles into the (now free) T buffer, copied over N's diagonal blocks afterwards ...
     g.C = T;
     g.ldc = GT;
     RP_TRY(rp_gemm_nt(ctx, g, st));
     hipLaunchKernelGGL(k_copy_diag_blocks, dim3(nb), dim3(256), 0, st, T, A, ld);
     hipLaunchKernelGGL(k_mirror_lower, dim3(n_pad / 32, n_pad / 32), dim3(256), 0, st, A, ld, n_pad / 32);  // ... and the mirror
+    if (itrace) {
+      iv_rec();
+      hipStreamSynchronize(st);
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, iv_ev[0], iv_ev[1]);
+      fprintf(stderr, "inverse: diagonal tiles + mirror %.1f ms\n", ms);
+      for (auto e : iv_ev) hipEventDestroy(e);
+    }
   }
   RP_HIP(hipGetLastError());
   if (timed) rp_time_end(ctx, ev, RPHIP_T_INVERSE, 2.0 * n3 / 3.0);  // n^3/3 (N = L^-T) + n^3/3 (lower half of N N^T)

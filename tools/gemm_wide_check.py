@@ -9,6 +9,9 @@ import torch
 
 from recpack_amd import _lib
 
+if os.environ.get('RP_LIB'):
+    _lib.LIB_PATH = os.environ['RP_LIB']  # (diagnostic builds)
+
 ctx = _lib.Context(0)
 dev = torch.device("cuda", 0)
 g = torch.Generator(device="cpu").manual_seed(7)
