@@ -1,7 +1,10 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-(echo "== C4"; python tools/ease_bench.py 1000000 100000 0.0005; python tools/ease_bench.py 1000000 100000 0.0005; echo "== C3"; python tools/ease_bench.py 200000 50000 0.001) > gpurun_out/r04f_bench.log 2>&1
-grep -v amdgpu.ids gpurun_out/r04f_bench.log
-python -m pytest tests/test_gpu_fullsize.py -x -q -m gpu -k "ease" -s > gpurun_out/r04f_full.log 2>&1; echo "full rc=$?" >> gpurun_out/r04f_full.log; grep -i "parity\|passed\|failed\|rc=" gpurun_out/r04f_full.log | cut -c1-330 | tail -12
-python -m pytest tests/test_gpu_ease.py -x -q -m gpu > gpurun_out/r04f_tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/r04f_tests.log; tail -2 gpurun_out/r04f_tests.log
+mkdir -p gpurun_out; rm -rf gpurun_out/kt
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt -- python3 tools/ease_bench.py 1000000 100000 0.0005 > gpurun_out/r04f_kt.log 2>&1
+tail -2 gpurun_out/r04f_kt.log
+python3 tools/chol_tail_trace.py gpurun_out/kt 600 2 > gpurun_out/r04f_chain.txt 2>&1
+python3 tools/chol_tail_trace.py gpurun_out/kt 700 2 >> gpurun_out/r04f_chain.txt 2>&1
+python3 tools/chol_tail_trace.py gpurun_out/kt 200 1 >> gpurun_out/r04f_chain.txt 2>&1
+rm -rf gpurun_out/kt
+cat gpurun_out/r04f_chain.txt
