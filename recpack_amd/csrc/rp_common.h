@@ -89,6 +89,7 @@ struct rphip_ctx {
   int predict_exact64 = 0;   // 1: the wave predict kernel sums in 64 bits (exact) instead of the per-user-scaled 32 bits
   int predict_half = 1;      // dense models: K9 as two passes (fp16 rows for a candidate list, then exact f32 scores of the candidates)
   int predict_half_w = 11200;  // columns per tile of that first pass (0: the model's own tiling, one workgroup per CU)
+  int predict_int8 = 1;      // ... on int8 rows (one scale per row) instead of fp16 ones: half the bytes again, a longer candidate list
   int pw_wt32 = 4096;        // tile width of the 32-bit sums: 2048 or 4096 (tuning)
   int gemm_mode = 2;         // operands of the solve's products: 0 fp32 MFMA (cross-check), 2 two fp16 planes (3 products; default)
   int gemm_supertile = 0;    // 1: GEMM workgroups walk the tiles in XCD-round-robin 8 x 8 supertiles (0: row-major 2-D grid)
@@ -165,7 +166,9 @@ struct rphip_model {
   int32_t cyc_nb = 0, cyc_world = 1, cyc_rank = 0;
   // fp16 copy of B for the first pass of the two-pass K9 (built on first use, rp_predict.hip): B16 = fp16(B * b16_scale), the same
   // leading dimension; b16_delta[i] = the largest rounding error of row i (in B's units), b16_rowmax[i] = its largest |entry|
-  _Float16* B16 = nullptr;
+  _Float16* B16 = nullptr;   // (b16_kind 2: int8 rows, q = rint(b / b8_scale[row]) in [-127, 127], the same leading dimension in BYTES)
+  int b16_kind = 0;          // 1: fp16 copy, 2: int8 copy (round 4); the copy is rebuilt when the context asks for the other kind
+  float* b8_scale = nullptr; // int8 copy: the rows' steps (rowmax / 127)
   float b16_scale = 0.0f;
   float* b16_delta = nullptr;
   float* b16_rowmax = nullptr;

@@ -2601,8 +2601,10 @@ extern "C" int rphip_model_dense_prune(rphip_ctx* ctx, rphip_model* m, int64_t k
   rp_dev_free(ctx, m->B16);
   rp_dev_free(ctx, m->b16_delta);
   rp_dev_free(ctx, m->b16_rowmax);
+  rp_dev_free(ctx, m->b8_scale);
   m->B16 = nullptr;
-  m->b16_delta = m->b16_rowmax = nullptr;
+  m->b16_delta = m->b16_rowmax = m->b8_scale = nullptr;
+  m->b16_kind = 0;
   return rp_dense_count_empty(ctx, m);
 }
 

@@ -875,6 +875,7 @@ extern "C" int rphip_model_destroy(rphip_model* m) {
   rp_dev_free(m->ctx, m->B16);
   rp_dev_free(m->ctx, m->b16_delta);
   rp_dev_free(m->ctx, m->b16_rowmax);
+  rp_dev_free(m->ctx, m->b8_scale);
   delete m;
   return RPHIP_OK;
 }

@@ -80,6 +80,10 @@ struct rp_pred_params {
   long long dense_ld;
   const _Float16* dense_B16;  // HALF instances: fp16(B * b16_scale), same leading dimension (the first pass of the two-pass K9)
   float b16_inv;              // 1 / b16_scale (a power of two)
+  const int8_t* dense_B8;     // I8 instances: int8 rows (same leading dimension, in bytes), entry = q * b8_scale[row]
+  const float* b8_scale;
+  int tile_cap;               // HALF instances, mode 0: > 0 = a tile hands on EVERY column at or above its lower bound of the Kp-th best
+                              // score (at most tile_cap of them; lists of that stride) instead of selecting exactly Kp
   int col_begin;          // dense column slab: column 0 of dense_B is item col_begin (n_items = the slab's width then)
   int cyc_nb, cyc_w, cyc_r;  // cyc_nb > 0: the slab's columns are block-cyclic panels (rphip_ease_fit_dist): local column l is item
                              // rp_cyc_panel(l / cyc_nb, cyc_r, cyc_w) * cyc_nb + l % cyc_nb (rp_common.h)
@@ -87,7 +91,8 @@ struct rp_pred_params {
   int n_items, n_tiles, tile_w, K, Kp, exclude_history;
   rp_fix_scale fix;       // neighbour lists: scale of the fixed-point sums
   int user_begin, n_users;
-  const int32_t* user_list;  // optional: local user ids to process (mode 0); count in *n_list
+  const int32_t* user_list;  // optional: local user ids to process (mode 0); count in *n_list (n_list NULL: n_users of them)
+  int list_compact;          // with user_list and several tiles: the per-tile candidate lists are indexed by the POSITION in the list
   const int32_t* n_list;
   int mode;               // 0 = top-Kp, 1 = count, 2 = fill
   int32_t* out_idx;       // mode 0, T==1: [n*Kp]; T>1: candidates [n*T*Kp]
@@ -143,9 +148,13 @@ typedef _Float16 rp_h8 __attribute__((ext_vector_type(8)));
 // HC8 (HALF only): 16-byte column groups per thread.  The default covers RP_TILE_MAX columns with one workgroup per CU (its LDS
 // tile); HC8 = 2 (tiles of at most 16384 columns, half the LDS, at most 64 registers) lets TWO workgroups share a CU: one streams
 // rows while the other selects - with fp16 rows the selection and the per-task start-up are a third of the first pass.
-template <bool DENSE, bool HALF = false, int HC8 = 0>
+// I8 (HALF only, round 4): the rows come from the model's int8 copy - q = rint(b / s_row), s_row = rowmax / 127 - a quarter of B's bytes:
+// sixteen columns per 16-byte load, score += float(q) * s_row.  The candidate list has to be longer for the same proof (the bound
+// is the sum of the rows' half-steps), tools/k9_fp8_gate.py.
+template <bool DENSE, bool HALF = false, int HC8 = 0, bool I8 = false>
 __global__ void __launch_bounds__(RP_PRED_THREADS, HC8 == 2 ? 8 : 4) k_predict_tile(rp_pred_params P) {
   static_assert(DENSE || !HALF, "the fp16 first pass is for dense models");
+  static_assert(HALF || !I8, "the int8 rows are a first pass");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ACC_B = DENSE ? 4 : 8;
   float* accf = reinterpret_cast<float*>(smem);
@@ -167,11 +176,12 @@ __global__ void __launch_bounds__(RP_PRED_THREADS, HC8 == 2 ? 8 : 4) k_predict_t
 
   // modes 1/2 walk the tiles of a user inside the workgroup (output offsets are sequential);
   // mode 0 treats (user, tile) as independent tasks.
-  const int n_u = P.user_list ? *P.n_list : P.n_users;
+  const int n_u = (P.user_list && P.n_list) ? *P.n_list : P.n_users;
   const long long n_tasks = (P.mode == 0) ? (long long)n_u * T : (long long)n_u;
   for (long long task = blockIdx.x; task < n_tasks; task += gridDim.x) {
     const int uk = (P.mode == 0) ? (int)(task / T) : (int)task;
     const int ul = P.user_list ? P.user_list[uk] : uk;
+    const int uo = (P.user_list && P.list_compact) ? uk : ul;  // index of the user's candidate lists
     const int u = P.user_begin + ul;
     const int hs = P.x_ptr[u], he = P.x_ptr[u + 1];
     long long off = (P.mode == 2) ? P.indptr[ul] : 0;
@@ -182,7 +192,94 @@ __global__ void __launch_bounds__(RP_PRED_THREADS, HC8 == 2 ? 8 : 4) k_predict_t
       const int t0 = tile * W;
       const int n_cols = min(W, P.n_items - t0);
       // ---- accumulate
-      if (HALF) {
+      if (HALF && I8) {
+        // sixteen consecutive columns per 16-byte load, four rows in flight
+        constexpr int C16 = HC8 ? (HC8 + 1) / 2 : (RP_TILE_MAX + 16 * RP_PRED_THREADS - 1) / (16 * RP_PRED_THREADS);
+        float r[C16][16];
+#pragma unroll
+        for (int c = 0; c < C16; ++c)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) r[c][e] = 0.0f;
+        const int w16 = (n_cols + 15) >> 4;  // (reads past n_cols stay inside the padded row: its length is a multiple of 64)
+#ifndef RP_K9_I8_RIF
+#define RP_K9_I8_RIF 4  // (8 rows in flight: C4 predict 1.43 s against 1.33)
+#endif
+        constexpr int RIF = RP_K9_I8_RIF;  // rows in flight
+        typedef int rp_i4 __attribute__((ext_vector_type(4)));
+        // One 32-bit word at a time - four sign-extending byte conversions (v_cvt_f32_i32 sext(BYTE_n): one instruction each) and four
+        // fmas - and the words strictly in order: the empty asm statements tie each word to the sums the previous one wrote.
+        // Left to itself the compiler converted all 64 bytes of the four rows first and spilled 230 registers (two workgroups
+        // per CU leave a thread 64).
+        auto add16 = [&](float(&acc)[16], const rp_i4& v, float sc) __attribute__((always_inline)) {
+#pragma unroll
+          for (int wd = 0; wd < 4; ++wd) {
+            unsigned w = (unsigned)v[wd];
+            if (wd == 0)
+              asm volatile("" : "+v"(w), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]));
+            else
+              asm volatile("" : "+v"(w), "+v"(acc[4 * wd - 4]), "+v"(acc[4 * wd - 3]), "+v"(acc[4 * wd - 2]), "+v"(acc[4 * wd - 1]));
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[4 * wd + b] = fmaf((float)(int)(int8_t)(w >> (8 * b)), sc, acc[4 * wd + b]);
+          }
+        };
+        // NR rows in flight: their sixteen-byte pieces are requested together, then added one row at a time
+        auto rows_block = [&](int h0, auto nr) __attribute__((always_inline)) {
+          constexpr int NR = decltype(nr)::value;
+          typedef const __attribute__((address_space(1))) int8_t* rp_gptr;  // (a GLOBAL pointer: rebuilt from an integer it would be a flat one)
+          rp_gptr R[NR];
+          float sc[NR];
+#pragma unroll
+          for (int q = 0; q < NR; ++q) {
+            const int it = __builtin_amdgcn_readfirstlane(P.x_idx[h0 + q]);  // (uniform: the row's base and its scale in scalar registers)
+            const unsigned long long rb = reinterpret_cast<unsigned long long>(P.dense_B8 + (long long)it * P.dense_ld + t0);
+            R[q] = (rp_gptr)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rb >> 32)) << 32) |
+                             (unsigned)__builtin_amdgcn_readfirstlane((int)rb));
+            sc[q] = P.b8_scale[it];
+          }
+          rp_i4 v[NR][C16];
+#pragma unroll
+          for (int c = 0; c < C16; ++c) {
+            const int gq = tid + c * RP_PRED_THREADS;
+            if (gq < w16) {
+#pragma unroll
+              for (int q = 0; q < NR; ++q)  // (scalar base + 32-bit offset: no address registers)
+                v[q][c] = *reinterpret_cast<const __attribute__((address_space(1))) rp_i4*>(R[q] + (unsigned)(16 * gq));
+            } else {
+#pragma unroll
+              for (int q = 0; q < NR; ++q) v[q][c] = (rp_i4){0, 0, 0, 0};
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < C16; ++c)
+#pragma unroll
+            for (int q = 0; q < NR; ++q) add16(r[c], v[q][c], sc[q]);
+        };
+        int h = hs;
+        for (; h + RIF - 1 < he; h += RIF) rows_block(h, std::integral_constant<int, RIF>{});
+        if (RIF > 4 && h + 3 < he) {
+          rows_block(h, std::integral_constant<int, 4>{});
+          h += 4;
+        }
+        for (; h < he; ++h) {
+          const int it = __builtin_amdgcn_readfirstlane(P.x_idx[h]);
+          const int8_t* R0 = P.dense_B8 + (long long)it * P.dense_ld + t0;
+          const float sc0 = P.b8_scale[it];
+#pragma unroll
+          for (int c = 0; c < C16; ++c) {
+            const int gq = tid + c * RP_PRED_THREADS;
+            if (gq < w16) add16(r[c], *reinterpret_cast<const rp_i4*>(R0 + 16 * gq), sc0);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < C16; ++c) {
+          const int gq = tid + c * RP_PRED_THREADS;
+          if (gq < w16) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              if (16 * gq + e < n_cols) accf[16 * gq + e] = r[c][e];
+          }
+        }
+      } else if (HALF) {
         // eight consecutive columns per 16-byte load, four rows in flight
         constexpr int C8 = HC8 ? HC8 : (RP_TILE_MAX + 8 * RP_PRED_THREADS - 1) / (8 * RP_PRED_THREADS);
         float r[C8][8];
@@ -362,6 +459,43 @@ __global__ void __launch_bounds__(RP_PRED_THREADS, HC8 == 2 ? 8 : 4) k_predict_t
         for (int q = 1; q < NW; ++q) t = fminf(t, s_tau[q]);
         src.tau = t;
         __syncthreads();
+        if (P.tile_cap > 0 && T > 1) {
+          // (round 4) ... and that is all the first pass needs: at least Kp columns of the tile reach tau, so the Kp-th best of the
+          // user's merged lists does too, and a column below tau is below everything the merge keeps - the proof of the second pass
+          // (k_predict_rescore: nothing outside the list beats its smallest entry) holds for the union of such lists as it does for
+          // exact per-tile selections.  One pass over the tile instead of the key prefix, the compaction, the radix levels, the
+          // classification and the emit: the selection was a third of the first pass's time once the rows were int8.
+          int* s_cnt = &sel.misc[RPS_USER + 8 + NW];
+          if (tid == 0) *s_cnt = 0;
+          __syncthreads();
+          const int64_t o = ((int64_t)uo * T + tile) * P.tile_cap;
+          for (int w0 = 0; w0 < n_cols; w0 += RP_PRED_THREADS) {
+            const int w = w0 + tid;
+            const float v = (w < n_cols) ? accf[w] : 0.0f;
+            const bool take = v != 0.0f && v >= t;
+            const unsigned long long m = __ballot(take);
+            if (m) {
+              int base = 0;
+              if (lane == 0) base = atomicAdd(s_cnt, __popcll(m));
+              base = __shfl(base, 0);
+              const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+              if (take && pos < P.tile_cap) {
+                P.out_idx[o + pos] = rp_pred_l2g(P, t0 + w);
+                P.out_val[o + pos] = v;
+              }
+            }
+          }
+          __syncthreads();
+          const int n_take = *s_cnt;
+          if (n_take <= P.tile_cap) {
+            if (tid == 0) P.out_nnz[uo * T + tile] = n_take;
+            for (int w = tid; w < n_cols; w += RP_PRED_THREADS) clear(w);
+            __syncthreads();
+            total += n_take;
+            continue;
+          }
+          // (more than the list holds: the exact selection below writes the tile's best Kp over the list's head)
+        }
       }
       if (P.mode == 0) {
         uint32_t* s_red = reinterpret_cast<uint32_t*>(&sel.misc[RPS_USER]);
@@ -375,12 +509,12 @@ __global__ void __launch_bounds__(RP_PRED_THREADS, HC8 == 2 ? 8 : 4) k_predict_t
       const int kk = (P.mode == 0) ? P.Kp : 0x7fffffff;
       const int kp = rp_select_topk<RP_PRED_THREADS>(src, n_cols, kk, sel);
       if (P.mode == 0) {
-        const int64_t o = (T == 1) ? (int64_t)ul * P.Kp : ((int64_t)ul * T + tile) * P.Kp;
+        const int64_t o = (T == 1) ? (int64_t)ul * P.Kp : ((int64_t)uo * T + tile) * (P.tile_cap > 0 ? P.tile_cap : P.Kp);
         rp_select_emit<RP_PRED_THREADS>(n_cols, sel, [&](int pos, int w) {
           P.out_idx[o + pos] = rp_pred_l2g(P, t0 + w);
           P.out_val[o + pos] = (float)score(w);
         });
-        if (tid == 0) P.out_nnz[(T == 1) ? ul : ul * T + tile] = kp;
+        if (tid == 0) P.out_nnz[(T == 1) ? ul : uo * T + tile] = kp;
       } else if (P.mode == 2) {
         rp_select_emit<RP_PRED_THREADS>(n_cols, sel, [&](int pos, int w) {
           P.full_idx[off + pos] = rp_pred_l2g(P, t0 + w);
@@ -461,6 +595,58 @@ __global__ void __launch_bounds__(256) k_dense_to_half(const float* __restrict__
   }
 }
 
+// the int8 copy: q = rint(b / s), s = rowmax / 127, one workgroup per row in two sweeps (the second one finds the row in L2);
+// delta = the row's largest |q s - b| as measured
+__global__ void __launch_bounds__(256) k_dense_to_i8(const float* __restrict__ B, long long ld, int n_rows, int n_cols, int8_t* __restrict__ Q,
+                                                     float* __restrict__ scale, float* __restrict__ delta, float* __restrict__ rowmax) {
+  __shared__ float red[4];
+  auto wg_max = [&](float m) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    __syncthreads();  // (red is free again)
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  };
+  const int n16 = n_cols;  // (a multiple of 16 inside the padded row; the padding holds zeros)
+  for (int i = blockIdx.x; i < n_rows; i += gridDim.x) {
+    const float* row = B + (long long)i * ld;
+    int8_t* out = Q + (long long)i * ld;
+    float m = 0.0f;
+    for (int j = threadIdx.x * 4; j < n16; j += 1024) {
+      const float4 v = *reinterpret_cast<const float4*>(row + j);
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    m = wg_max(m);
+    const bool ok = m > 0.0f && m < 3.0e38f;
+    const float s = ok ? m / 127.0f : 0.0f, inv = ok ? 127.0f / m : 0.0f;
+    float err = 0.0f;
+    for (int j = threadIdx.x * 16; j < n16; j += 4096) {
+      uint32_t w[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(row + j + 4 * g);
+        const float x[4] = {v.x, v.y, v.z, v.w};
+        uint32_t pk = 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float qf = fminf(fmaxf(rintf(x[e] * inv), -127.0f), 127.0f);
+          err = fmaxf(err, fabsf(qf * s - x[e]));
+          pk |= ((uint32_t)(int)qf & 0xffu) << (8 * e);
+        }
+        w[g] = pk;
+      }
+      *reinterpret_cast<uint4*>(out + j) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    err = wg_max(err);
+    if (threadIdx.x == 0) {
+      scale[i] = s;
+      delta[i] = ok ? err : 3.0e38f;  // (a row with an infinite entry proves nothing: its users take the exact pass)
+      rowmax[i] = m;
+    }
+  }
+}
+
 struct rp_rescore_params {
   const int32_t* x_ptr;
   const int32_t* x_idx;
@@ -476,7 +662,8 @@ struct rp_rescore_params {
   int32_t* out_idx;
   float* out_val;
   int32_t* out_nnz;
-  int32_t* fail_list;  // users whose list does not prove its top-Kp; count in *n_fail
+  int32_t* fail_list;  // users whose list does not prove its top-Kp (ul + fail_base); count in *n_fail
+  int fail_base;
   int32_t* n_fail;
 };
 
@@ -587,7 +774,7 @@ __global__ void __launch_bounds__(256) k_predict_rescore(rp_rescore_params P) {
     for (int d = 32; d > 0; d >>= 1) e_kp = fmaxf(e_kp, __shfl_xor(e_kp, d));
     const bool proven = n_valid >= P.Kp && e_kp > a_bound + E;
     if (!proven) {
-      if (lane == 0) P.fail_list[atomicAdd(P.n_fail, 1)] = ul;
+      if (lane == 0) P.fail_list[atomicAdd(P.n_fail, 1)] = P.fail_base + ul;
       RP_WAVE_FENCE();
       continue;
     }
@@ -637,28 +824,32 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_merge(const int32_t
                                                                   const int32_t* __restrict__ cand_nnz, int n_tiles, int Kp, int n_users,
                                                                   const int32_t* __restrict__ user_list, const int32_t* __restrict__ n_list,
                                                                   int32_t* __restrict__ out_idx, float* __restrict__ out_val,
-                                                                  int32_t* __restrict__ out_nnz, int sort_cols) {
+                                                                  int32_t* __restrict__ out_nnz, int sort_cols, int stride = 0, int compact = 0) {
+  // compact (with user_list): the candidate lists of the uk-th user of the list are the uk-th ones (n_list NULL: n_users entries)
+  // stride: entries between two lists of a user (0: Kp; larger when the lists may hold more than Kp entries each)
+  if (stride <= 0) stride = Kp;
   // sort_cols: the lists are not consecutive column ranges (the ranks' block-cyclic panels): the selected entries are ranked by
   // column before they are written (Kp * 8 more bytes of LDS in front); otherwise list order is column order
   extern __shared__ __attribute__((aligned(16))) char smem_all[];
   char* smem = smem_all + (sort_cols ? (size_t)Kp * 8 : 0);
   int32_t* scol = reinterpret_cast<int32_t*>(smem_all);
   float* sval = reinterpret_cast<float*>(smem_all + (size_t)Kp * 4);
-  const int T = n_tiles, cap = T * Kp;
+  const int T = n_tiles, cap = T * stride;
   int32_t* lcol = reinterpret_cast<int32_t*>(smem);
   float* lval = reinterpret_cast<float*>(smem + (size_t)cap * 4);
   rp_select_smem sel = rp_select_carve(smem + (size_t)cap * 8, cap);
   int* s_off = &sel.misc[RPS_USER];
   const int tid = threadIdx.x;
-  const int n_u = user_list ? *n_list : n_users;
+  const int n_u = (user_list && n_list) ? *n_list : n_users;
   for (int uk = blockIdx.x; uk < n_u; uk += gridDim.x) {
     const int ul = user_list ? user_list[uk] : uk;
+    const int uc = (user_list && compact) ? uk : ul;
     __syncthreads();
     if (tid == 0) {
       int o = 0;
       for (int t = 0; t < T; ++t) {
         s_off[t] = o;
-        o += cand_nnz[(int64_t)ul * T + t];
+        o += cand_nnz[(int64_t)uc * T + t];
       }
       s_off[T] = o;
     }
@@ -666,7 +857,7 @@ __global__ void __launch_bounds__(RP_PRED_THREADS) k_predict_merge(const int32_t
     const int n = s_off[T];
     for (int t = 0; t < T; ++t) {
       const int cn = s_off[t + 1] - s_off[t];
-      const int64_t so = ((int64_t)ul * T + t) * Kp;
+      const int64_t so = ((int64_t)uc * T + t) * stride;
       for (int k = tid; k < cn; k += RP_PRED_THREADS) {
         lcol[s_off[t] + k] = cand_idx[so + k];
         lval[s_off[t] + k] = cand_val[so + k];
@@ -1494,6 +1685,9 @@ static void rp_pred_fill(rp_pred_params& P, const rphip_model* m, const rphip_cs
   P.dense_ld = m->ld;
   P.dense_B16 = nullptr;
   P.b16_inv = 1.0f;
+  P.dense_B8 = nullptr;
+  P.b8_scale = nullptr;
+  P.tile_cap = 0;
   P.keep = nullptr;
   P.n_items = (int)X->n_items;
   P.col_begin = 0;
@@ -1524,6 +1718,7 @@ static void rp_pred_fill(rp_pred_params& P, const rphip_model* m, const rphip_cs
   P.user_begin = (int)ub;
   P.n_users = (int)(ue - ub);
   P.user_list = nullptr;
+  P.list_compact = 0;
   P.n_list = nullptr;
   P.mode = 0;
   P.out_idx = nullptr;
@@ -1558,36 +1753,61 @@ static double rp_pred_work(const rphip_csr* X, const rphip_model* m, int64_t n_u
   return 8.0 * m->K * (double)X->nnz * share + 4.0 * ((double)X->nnz * share + (double)n_users) + 8.0 * (double)n_users * Kp;
 }
 
-// the model's fp16 copy (first use; a model is immutable once fitted - pruning rebuilds it)
-static int rp_model_half(rphip_ctx* ctx, rphip_model* m) {
-  if (m->B16 || m->b16_failed) return RPHIP_OK;
+// the model's fp16 (kind 1) or int8 (kind 2) copy (first use; a model is immutable once fitted - pruning rebuilds it; a context
+// that asks for the other kind gets it rebuilt)
+static int rp_model_half(rphip_ctx* ctx, rphip_model* m, int kind) {
+  if (m->b16_failed) return RPHIP_OK;
+  if (m->B16 && m->b16_kind == kind) return RPHIP_OK;
+  hipStream_t st = ctx->stream;
+  if (m->B16) {
+    RP_HIP(hipStreamSynchronize(st));
+    rp_dev_free(ctx, m->B16);
+    rp_dev_free(ctx, m->b16_delta);
+    rp_dev_free(ctx, m->b16_rowmax);
+    rp_dev_free(ctx, m->b8_scale);
+    m->B16 = nullptr;
+    m->b16_delta = m->b16_rowmax = m->b8_scale = nullptr;
+    m->b16_kind = 0;
+  }
   const int64_t rows = m->n_items;
   const int64_t cols = m->n_cols > 0 ? m->n_cols : m->n_items;
-  if (m->ld % 8) {  // (16-byte loads of eight fp16)
+  if (m->ld % 16) {  // (16-byte loads of eight fp16 / sixteen int8)
     m->b16_failed = true;
     return RPHIP_OK;
   }
-  hipStream_t st = ctx->stream;
+  const size_t esz = kind == 2 ? 1 : sizeof(_Float16);
   unsigned* gmax = nullptr;
   RP_TRY(rp_scratch(ctx, 5, 64, (void**)&gmax));
   {  // the copy is an optimisation: it must leave room for everything else (16 GiB or a tenth of the device, whichever is less)
     size_t free_b = 0, total_b = 0;
     hipMemGetInfo(&free_b, &total_b);
-    const size_t need = (size_t)rows * m->ld * sizeof(_Float16) + std::min<size_t>((size_t)16 << 30, total_b / 10);
+    const size_t need = (size_t)rows * m->ld * esz + std::min<size_t>((size_t)16 << 30, total_b / 10);
     if (free_b + ctx->cached_bytes < need) {
       m->b16_failed = true;
       return RPHIP_OK;
     }
   }
-  if (rp_dev_alloc(ctx, (size_t)rows * m->ld * sizeof(_Float16), (void**)&m->B16) != RPHIP_OK ||
+  if (rp_dev_alloc(ctx, (size_t)rows * m->ld * esz, (void**)&m->B16) != RPHIP_OK ||
       rp_dev_alloc(ctx, (size_t)rows * sizeof(float), (void**)&m->b16_delta) != RPHIP_OK ||
-      rp_dev_alloc(ctx, (size_t)rows * sizeof(float), (void**)&m->b16_rowmax) != RPHIP_OK) {
+      rp_dev_alloc(ctx, (size_t)rows * sizeof(float), (void**)&m->b16_rowmax) != RPHIP_OK ||
+      (kind == 2 && rp_dev_alloc(ctx, (size_t)rows * sizeof(float), (void**)&m->b8_scale) != RPHIP_OK)) {
     rp_dev_free(ctx, m->B16);
     rp_dev_free(ctx, m->b16_delta);
     rp_dev_free(ctx, m->b16_rowmax);
+    rp_dev_free(ctx, m->b8_scale);
     m->B16 = nullptr;
-    m->b16_delta = m->b16_rowmax = nullptr;
+    m->b16_delta = m->b16_rowmax = m->b8_scale = nullptr;
     m->b16_failed = true;  // not an error: the one-pass kernel gives the same result
+    rp_set_error("%s", "");
+    return RPHIP_OK;
+  }
+  m->b16_kind = kind;
+  if (kind == 2) {
+    const int grid8 = (int)std::min<int64_t>(rows, (int64_t)ctx->n_cu * 16);
+    hipLaunchKernelGGL(k_dense_to_i8, dim3(grid8), dim3(256), 0, st, m->B, (long long)m->ld, (int)rows, (int)std::min<int64_t>(m->ld, rp_cdiv(cols, 16) * 16),
+                       reinterpret_cast<int8_t*>(m->B16), m->b8_scale, m->b16_delta, m->b16_rowmax);
+    RP_HIP(hipGetLastError());
+    m->b16_scale = 1.0f;
     return RPHIP_OK;
   }
   RP_HIP(hipMemsetAsync(gmax, 0, 4, st));
@@ -1736,52 +1956,72 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
   }
   // ---- dense models: the two-pass K9 (see k_predict_rescore) unless switched off, the fp16 copy does not fit, or the candidate
   // list would be most of the slab anyway
-  const int Kc = ((Kp + 24 + 63) / 64) * 64;  // (Kp = 100: 128 - measured to prove 99.9 % of the users at C3 / C4, tools/k9_half_gate.py; 192: the same share, +8 % time)
+  // Candidates per user.  fp16 rows: Kp + 24 .. (Kp = 100: 128 - measured to prove 99.9 % of the users at C3 / C4, tools/k9_half_gate.py;
+  // 192: the same share, +8 % time).  int8 rows (round 4): the bound is the sum of the rows' half-steps, 2^-8 of the rows' largest
+  // entries instead of 2^-12: at Kp = 100 a list of 192 proves 98.5 % of the users, 256 99.8 % (tools/k9_fp8_gate.py, C3 and C4; the
+  // median user needs 133)
+  // the first pass on narrower tiles, two workgroups per CU (k_predict_tile's HC8 = 2; the int8 rows know no other form)
+  int Th = T, Wh = P.tile_w;
+  bool fits2 = false;
+  if (ctx->predict_half_w > 0 && model->kind == RPHIP_MODEL_DENSE) {
+    const int th = (int)rp_cdiv(P.n_items, ctx->predict_half_w);
+    const int wh = (int)(rp_cdiv(rp_cdiv(P.n_items, th), 64) * 64);
+    if (th <= 15 && wh <= 16384 && (size_t)wh * 4 + rp_select_smem_bytes(wh) <= (size_t)78 * 1024) {
+      Th = th;
+      Wh = wh;
+      fits2 = true;
+    }
+  }
+  const bool want_i8 = ctx->predict_int8 && fits2;
+  int kc_i8 = ((Kp + 92 + 63) / 64) * 64;
+  if (const char* e = getenv("RP_K9_I8_KC")) kc_i8 = std::max(64, atoi(e) / 64 * 64);
+  const int Kc = want_i8 && kc_i8 <= 512 && (int64_t)4 * kc_i8 <= (int64_t)P.n_items ? kc_i8 : ((Kp + 24 + 63) / 64) * 64;
   if (model->kind == RPHIP_MODEL_DENSE && ctx->predict_half && Kc <= 512 && (int64_t)4 * Kc <= (int64_t)P.n_items && T <= 15) {
     rphip_model* mm = const_cast<rphip_model*>(model);
-    RP_TRY(rp_model_half(ctx, mm));
+    RP_TRY(rp_model_half(ctx, mm, want_i8 && Kc == kc_i8 ? 2 : 1));
     if (mm->B16) {
-      const int64_t UCH = 1 << 17;  // users per chunk: bounds the candidate scratch
-      const int64_t nchm = std::min<int64_t>(n, UCH);
-      // the first pass on narrower tiles, two workgroups per CU (k_predict_tile's HC8 = 2)
-      int Th = T, Wh = P.tile_w;
-      if (ctx->predict_half_w > 0) {
-        const int th = (int)rp_cdiv(P.n_items, ctx->predict_half_w);
-        const int wh = (int)(rp_cdiv(rp_cdiv(P.n_items, th), 64) * 64);
-        if (th <= 15 && wh <= 16384 && (size_t)wh * 4 + rp_select_smem_bytes(wh) <= (size_t)78 * 1024) {
-          Th = th;
-          Wh = wh;
-        }
+      const bool i8 = mm->b16_kind == 2;
+      const bool narrow = fits2 && (i8 || Th != T || Wh != P.tile_w);
+      if (!fits2) {
+        Th = T;
+        Wh = P.tile_w;
       }
-      const bool narrow = Th != T || Wh != P.tile_w;
       const int Tm = std::max(T, Th);
-      const size_t szT = (Tm > 1) ? (size_t)nchm * Tm * Kc : 0, szA = (size_t)nchm * Kc;
+      // first-pass tiles hand on every column above their bound (k_predict_tile, tile_cap): lists of up to 4 Kc entries
+      const int cap_t = (narrow && Th > 1 && !keep_dev && Kc <= 256 && getenv("RP_K9_EXACT_TILES") == nullptr) ? 4 * Kc : 0;
+      const int stride_t = cap_t > 0 ? cap_t : Kc;
+      const int64_t UCH = cap_t > 0 ? 1 << 16 : 1 << 17;  // users per chunk: bounds the candidate scratch
+      const int64_t nchm = std::min<int64_t>(n, UCH);
+      const size_t szT = (Tm > 1) ? (size_t)nchm * Tm * stride_t : 0, szA = (size_t)nchm * Kc;
       char* sb = nullptr;
-      RP_TRY(rp_scratch(ctx, 14, (szT + szA) * 8 + (size_t)nchm * (Tm + 2) * 4 + 256, (void**)&sb));
+      RP_TRY(rp_scratch(ctx, 14, (szT + szA) * 8 + (size_t)nchm * (Tm + 1) * 4 + (size_t)n * 4 + 256, (void**)&sb));
       int32_t* a_idx = (int32_t*)sb;
       float* a_val = (float*)(sb + szA * 4);
       int32_t* t_idx = (int32_t*)(sb + szA * 8);
       float* t_val = (float*)(sb + szA * 8 + szT * 4);
       int32_t* a_nnz = (int32_t*)(sb + (szA + szT) * 8);
       int32_t* t_nnz = a_nnz + nchm;
-      int32_t* fail = t_nnz + nchm * Tm;
-      int32_t* n_fail = fail + nchm;  // (one word behind the list)
+      int32_t* fail = t_nnz + nchm * Tm;  // [n]: the users of ALL chunks whose list proves nothing (ids relative to user_begin)
+      int32_t* n_fail = fail + n;      // (one word behind the list)
       const size_t lds1 = rp_pred_lds(P);
       rp_pred_params Hh = P;
       Hh.n_tiles = Th;
       Hh.tile_w = Wh;
       const size_t ldsh = rp_pred_lds(Hh);
-      if (narrow)
+      if (i8)
+        RP_HIP(hipFuncSetAttribute((const void*)k_predict_tile<true, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh));
+      else if (narrow)
         RP_HIP(hipFuncSetAttribute((const void*)k_predict_tile<true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh));
       else
         RP_HIP(hipFuncSetAttribute((const void*)k_predict_tile<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
       RP_HIP(hipFuncSetAttribute((const void*)k_predict_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-      const size_t mlds_c = (size_t)Th * Kc * 8 + rp_select_smem_bytes(Th * Kc), mlds_p = (size_t)T * Kp * 8 + rp_select_smem_bytes(T * Kp);
+      const size_t mlds_c = (size_t)Th * stride_t * 8 + rp_select_smem_bytes(Th * stride_t), mlds_p = (size_t)T * Kp * 8 + rp_select_smem_bytes(T * Kp);
       if (Tm > 1) {
-        if (std::max(mlds_c, mlds_p) > 160 * 1024 || Tm * Kc >= RPS_FLAG)
+        if (std::max(mlds_c, mlds_p) > 160 * 1024 || Tm * stride_t >= RPS_FLAG)
           RP_FAIL(RPHIP_ELIMIT, "Kp=%d with %d column tiles needs %zu bytes of LDS for the merge", Kp, Tm, std::max(mlds_c, mlds_p));
         RP_HIP(hipFuncSetAttribute((const void*)k_predict_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(mlds_c, mlds_p)));
       }
+      hipMemsetAsync(n_fail, 0, 4, st);
       for (int64_t c0 = 0; c0 < n; c0 += UCH) {
         const int64_t nch = std::min<int64_t>(UCH, n - c0);
         const int grid = (int)std::min<int64_t>(nch * T, (int64_t)ctx->n_cu * 8), mgrid = (int)std::min<int64_t>(nch, (int64_t)ctx->n_cu * 8);
@@ -1793,19 +2033,23 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
         H.Kp = Kc;
         H.dense_B16 = mm->B16;
         H.b16_inv = 1.0f / mm->b16_scale;
+        H.dense_B8 = reinterpret_cast<const int8_t*>(mm->B16);
+        H.b8_scale = mm->b8_scale;
+        H.tile_cap = cap_t;
         hipMemsetAsync(a_nnz, 0, (size_t)nch * 4, st);
         if (Th > 1) hipMemsetAsync(t_nnz, 0, (size_t)nch * Th * 4, st);
-        hipMemsetAsync(n_fail, 0, 4, st);
         H.out_idx = Th > 1 ? t_idx : a_idx;
         H.out_val = Th > 1 ? t_val : a_val;
         H.out_nnz = Th > 1 ? t_nnz : a_nnz;
-        if (narrow)
+        if (i8)
+          hipLaunchKernelGGL((k_predict_tile<true, true, 2, true>), dim3(gridh), dim3(RP_PRED_THREADS), ldsh, st, H);
+        else if (narrow)
           hipLaunchKernelGGL((k_predict_tile<true, true, 2>), dim3(gridh), dim3(RP_PRED_THREADS), ldsh, st, H);
         else
           hipLaunchKernelGGL((k_predict_tile<true, true>), dim3(grid), dim3(RP_PRED_THREADS), lds1, st, H);
         if (Th > 1)
           hipLaunchKernelGGL(k_predict_merge, dim3(mgrid), dim3(RP_PRED_THREADS), mlds_c, st, t_idx, t_val, t_nnz, Th, Kc, (int)nch, nullptr, nullptr, a_idx,
-                             a_val, a_nnz, 0);
+                             a_val, a_nnz, 0, stride_t);
         // second pass: exact scores of the candidates, their top-Kp, the proof; users without one go to `fail`
         rp_rescore_params R;
         R.x_ptr = Xpred->x_ptr;
@@ -1830,6 +2074,7 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
         R.out_nnz = nnz_dev + c0;
         R.fail_list = fail;
         R.n_fail = n_fail;
+        R.fail_base = (int)c0;
         switch (Kc / 64) {
           case 2: rp_launch_rescore<2>(ctx, R); break;
           case 3: rp_launch_rescore<3>(ctx, R); break;
@@ -1839,20 +2084,32 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
           case 7: rp_launch_rescore<7>(ctx, R); break;
           default: rp_launch_rescore<8>(ctx, R); break;
         }
-        // the one-pass kernel for the users on the list (its count stays on the device: an empty list costs two empty launches)
+        RP_HIP(hipGetLastError());
+      }
+      // The one-pass kernel for the users without a proof - of ALL chunks, in as few launches as possible (round 4: per chunk the
+      // ~1 000 users of a 65 536-user chunk left most of the chip idle: 146 of 1 290 ms at C4).  Their count comes to the host.
+      int h_fail = 0;
+      RP_HIP(hipMemcpyAsync(&h_fail, n_fail, 4, hipMemcpyDeviceToHost, st));
+      RP_HIP(hipStreamSynchronize(st));
+      // list entries per launch: what the tile lists hold (one tile: no lists, the kernel writes the output rows themselves)
+      const int64_t FCH = T == 1 ? std::max<int64_t>(1, h_fail) : std::max<int64_t>(1, std::min<int64_t>(nchm, (int64_t)(szT / ((size_t)T * Kp))));
+      for (int64_t f0 = 0; f0 < h_fail; f0 += FCH) {
+        const int64_t nf = std::min<int64_t>(FCH, h_fail - f0);
+        const int grid = (int)std::min<int64_t>(nf * T, (int64_t)ctx->n_cu * 8), mgrid = (int)std::min<int64_t>(nf, (int64_t)ctx->n_cu * 8);
         rp_pred_params F = P;
-        F.user_begin = (int)(user_begin + c0);
-        F.n_users = (int)nch;
-        F.user_list = fail;
-        F.n_list = n_fail;
-        if (T > 1) hipMemsetAsync(t_nnz, 0, (size_t)nch * T * 4, st);
-        F.out_idx = T > 1 ? t_idx : idx_dev + c0 * Kp;
-        F.out_val = T > 1 ? t_val : val_dev + c0 * Kp;
-        F.out_nnz = T > 1 ? t_nnz : nnz_dev + c0;
+        F.user_begin = (int)user_begin;
+        F.n_users = (int)nf;
+        F.user_list = fail + f0;
+        F.n_list = nullptr;
+        F.list_compact = 1;
+        if (T > 1) hipMemsetAsync(t_nnz, 0, (size_t)nf * T * 4, st);
+        F.out_idx = T > 1 ? t_idx : idx_dev;
+        F.out_val = T > 1 ? t_val : val_dev;
+        F.out_nnz = T > 1 ? t_nnz : nnz_dev;
         hipLaunchKernelGGL(k_predict_tile<true>, dim3(grid), dim3(RP_PRED_THREADS), lds1, st, F);
         if (T > 1)
-          hipLaunchKernelGGL(k_predict_merge, dim3(mgrid), dim3(RP_PRED_THREADS), mlds_p, st, t_idx, t_val, t_nnz, T, Kp, (int)nch, fail, n_fail,
-                             idx_dev + c0 * Kp, val_dev + c0 * Kp, nnz_dev + c0, 0);
+          hipLaunchKernelGGL(k_predict_merge, dim3(mgrid), dim3(RP_PRED_THREADS), mlds_p, st, t_idx, t_val, t_nnz, T, Kp, (int)nf, fail + f0, nullptr,
+                             idx_dev, val_dev, nnz_dev, 0, 0, 1);
         RP_HIP(hipGetLastError());
       }
       rp_time_end(ctx, ev, RPHIP_T_PREDICT_DENSE, rp_pred_work(Xpred, model, n, Kp));

@@ -1,4 +1,4 @@
-"""K9 on a fitted EASE model: the one-pass kernel against the two-pass route (option predict_half), times and equality.
+"""K9 on a fitted EASE model: the one-pass kernel against the two-pass routes (options predict_half, predict_int8), times and equality.
 python tools/k9_two_pass_bench.py [config [Kp]]"""
 import os
 import sys
@@ -22,8 +22,9 @@ dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
 m = _lib.ease_fit(ctx, dX, 200.0, 0.0)
 ctx.sync()
 outs = {}
-for half in (0, 1, 1):
+for name, half, i8 in (("one pass", 0, 0), ("fp16 rows", 1, 0), ("int8 rows", 1, 1), ("int8 rows", 1, 1)):
     ctx.set_option("predict_half", half)
+    ctx.set_option("predict_int8", i8)
     oi = torch.empty((U, Kp), dtype=torch.int32, device=dev)
     ov = torch.empty((U, Kp), dtype=torch.float32, device=dev)
     on = torch.empty((U,), dtype=torch.int32, device=dev)
@@ -33,8 +34,10 @@ for half in (0, 1, 1):
         _lib.predict_topk_dev(ctx, m, dX, Kp, oi, ov, on, exclude_history=True)
         ctx.sync()
         dt = time.perf_counter() - t0
-        print(f"{cfg} Kp={Kp} predict_half={half} run {it}: {dt * 1e3:.1f} ms = {4.0 * I * int(ix.numel()) / dt / 1e12:.2f} TB/s by the 4*I*nnz model", flush=True)
-    outs[half] = (oi, ov, on)
-a, b = outs[0], outs[1]
-print("identical idx:", bool((a[0] == b[0]).all()), "identical values:", bool((a[1].view(torch.int32) == b[1].view(torch.int32)).all()),
-      "identical nnz:", bool((a[2] == b[2]).all()))
+        print(f"{cfg} Kp={Kp} {name} run {it}: {dt * 1e3:.1f} ms = {4.0 * I * int(ix.numel()) / dt / 1e12:.2f} TB/s by the 4*I*nnz model", flush=True)
+    outs[name] = (oi, ov, on)
+a = outs["one pass"]
+for name in ("fp16 rows", "int8 rows"):
+    b = outs[name]
+    print(name, "against one pass: identical idx:", bool((a[0] == b[0]).all()), "identical values:", bool((a[1].view(torch.int32) == b[1].view(torch.int32)).all()),
+          "identical nnz:", bool((a[2] == b[2]).all()))
