@@ -338,14 +338,20 @@ def roofline_ease(tm, I, world, steps, dist_stats, nnz, U, Kp):
         "solve_ms_per_step": round(solve_ms, 2), "flop_per_solve": flop,
     }
     if k9["launches"]:
-        # K9 beside it.  The kernel streams the fp16 copy of B's rows (2 bytes per column per interaction: pass 1 of the two-pass
-        # predict) and gathers the candidates' f32 entries for the exact rescoring (Kc = 128 columns of 4 bytes per interaction,
-        # a 64-byte line each at worst): `bytes_streamed` / time against the HBM peak is its roofline.  The 4*I*nnz no-reuse model of
-        # SURVEY.md 8(d) prices f32 rows that the kernel no longer reads - kept as `model_bytes_f32_rows` for reference only.
+        # K9 beside it.  Since round 4 the first pass streams the INT8 copy of B's rows (1 byte per column per interaction) for a
+        # candidate list of Kc = 192 (Kp = 100) and the second pass gathers the candidates' f32 entries for the exact rescoring
+        # (4 bytes per candidate per interaction, a 64-byte line each at worst); the ~1.5 % of users whose list proves nothing
+        # take the one-pass kernel on the f32 rows (4*I bytes per interaction; priced at that share).  `bytes_streamed` / time
+        # against the HBM peak is the roofline of what the kernels read; at half the bytes of the fp16 pass the first pass is no
+        # longer bound by them alone.  The 4*I*nnz no-reuse model of SURVEY.md 8(d) prices f32 rows that the
+        # kernel no longer reads - kept as `model_bytes_f32_rows` for reference only.
         ms = k9["ms"] / steps
-        streamed = 2.0 * I * nnz / world + 4.0 * 128 * nnz / world + 8.0 * U * Kp
+        kc = ((Kp + 92 + 63) // 64) * 64
+        fail_share = 0.015
+        streamed = 1.0 * I * nnz / world + 4.0 * kc * nnz / world + fail_share * 4.0 * I * nnz / world + 8.0 * U * Kp
         out["k9_predict"] = {"ms_per_step": round(ms, 2), "bytes_streamed": streamed,
-                             "bytes_streamed_what": "2*I*nnz (fp16 rows of B, first pass) + 4*Kc*nnz (candidates' f32 entries, Kc = 128) + 8*U*Kp (output)",
+                             "bytes_streamed_what": f"1*I*nnz (int8 rows of B, first pass) + 4*Kc*nnz (candidates' f32 entries, Kc = {kc}) + "
+                                                    f"{fail_share}*4*I*nnz (users without a proof: the one-pass kernel) + 8*U*Kp (output)",
                              "GBps": round(streamed / (ms * 1e-3) / 1e9, 1),
                              "frac_of_hbm_peak": round(streamed / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              "model_bytes_f32_rows": 4.0 * I * nnz / world + 8.0 * U * Kp,

@@ -115,6 +115,13 @@ int rphip_ctx_trim(rphip_ctx* ctx);
  *                       when that does not fit or Kp > 488.
  *   "predict_half_tile" columns per tile of that first pass (default 11200, at most 16384; 0 = the model's own tiling).  Tiles of
  *                       half the LDS let two workgroups share a CU: one streams rows while the other selects.
+ *   "predict_int8"      1 (default) | 0.  The first pass of "predict_half" on an INT8 copy of B instead of the fp16 one (a quarter of
+ *                       B's bytes: q = rint(b / s_row) in [-127, 127], s_row = the row's largest magnitude / 127; n_items * ld bytes
+ *                       beside B).  The bound on |approximate - exact| is the sum of the rows' measured half-steps, 2^-8 of their
+ *                       largest entries, so the candidate list is longer (Kp + 92 rounded up to 64: 192 at Kp = 100, which proves
+ *                       98.5 % of the users of the 200K x 50K and 1M x 100K workloads; the others take the one-pass kernel) - the
+ *                       results are still those of the one-pass kernel, bit for bit.  Needs "predict_half_tile" > 0; a context
+ *                       that switches the option has the copy rebuilt on the next call.
  *   "gemm_mode"         2 (default) | 0: how the O(n^3) products of the EASE solve (and rphip_gemm_nt_f32) multiply their fp32 operands.
  *                       2: two fp16 planes per operand, both rounded to nearest (x = h1 + h2 to 2^-24 |x|), three plane products per
  *                          step on v_mfma_f32_32x32x16_f16; each operand is scaled by a power of two taken from its largest magnitude

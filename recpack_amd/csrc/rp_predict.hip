@@ -487,10 +487,8 @@ __global__ void __launch_bounds__(RP_PRED_THREADS, HC8 == 2 ? 8 : 4) k_predict_t
           }
           __syncthreads();
           const int n_take = *s_cnt;
-          if (n_take <= P.tile_cap) {
+          if (n_take <= P.tile_cap) {  // (no clearing: the next tile's sums overwrite every column, and the barrier above is behind the last read)
             if (tid == 0) P.out_nnz[uo * T + tile] = n_take;
-            for (int w = tid; w < n_cols; w += RP_PRED_THREADS) clear(w);
-            __syncthreads();
             total += n_take;
             continue;
           }

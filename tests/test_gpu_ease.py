@@ -487,8 +487,8 @@ def test_ease_l2_sweep_from_cached_gram(hip):
 
 
 def test_predict_two_pass_equals_one_pass(hip):
-    """K9's two passes (fp16 rows for a candidate list, exact f32 scores of the candidates, a proof per user, the one-pass kernel for
-    users without one - option predict_half) give the one-pass kernel's top-Kp bit for bit: fitted models, several Kp, history
+    """K9's two passes (fp16 or int8 rows for a candidate list, exact f32 scores of the candidates, a proof per user, the one-pass kernel
+    for users without one - options predict_half, predict_int8) give the one-pass kernel's top-Kp bit for bit: fitted models, several Kp, history
     removal, an item filter, a pruned model (the fp16 copy is rebuilt), and a model of few distinct values whose ties at the
     boundary no list can prove (everybody takes the fallback)."""
     from recpack_amd.synth import powerlaw_csr
@@ -502,18 +502,21 @@ def test_predict_two_pass_equals_one_pass(hip):
 
     def both(model, Kp, excl, flt=None):
         out = []
-        for half in (0, 1):
+        for half, i8 in ((0, 1), (1, 0), (1, 1)):  # one pass; first pass on fp16 rows; on int8 rows (the default)
             ctx.set_option("predict_half", half)
+            ctx.set_option("predict_int8", i8)
             if flt is None:
                 out.append(_lib.predict_topk(ctx, model, dX, Kp, exclude_history=excl))
             else:
                 out.append(_lib.predict_topk(ctx, model, dX, Kp, exclude_history=excl, item_keep=flt))
         ctx.set_option("predict_half", 1)
-        (i0, v0, n0), (i1, v1, n1) = out
-        np.testing.assert_array_equal(n0, n1)
-        np.testing.assert_array_equal(i0, i1)
-        np.testing.assert_array_equal(v0.view(np.uint32), v1.view(np.uint32))
-        return n1
+        ctx.set_option("predict_int8", 1)
+        i0, v0, n0 = out[0]
+        for i1, v1, n1 in out[1:]:
+            np.testing.assert_array_equal(n0, n1)
+            np.testing.assert_array_equal(i0, i1)
+            np.testing.assert_array_equal(v0.view(np.uint32), v1.view(np.uint32))
+        return n0
 
     try:
         for Kp, excl in ((10, True), (100, True), (100, False), (300, True)):
@@ -534,4 +537,5 @@ def test_predict_two_pass_equals_one_pass(hip):
             both(m2, 20, False)
     finally:
         ctx.set_option("predict_half", 1)
+        ctx.set_option("predict_int8", 1)
         ctx.set_option("predict_half_tile", 11200)
