@@ -677,14 +677,15 @@ __global__ void __launch_bounds__(256) k_predict_rescore(rp_rescore_params P) {
     const int hs = P.x_ptr[u], he = P.x_ptr[u + 1];
     const int nc = P.cand_nnz[ul];
     int col[NQ], loc[NQ];
-    float e[NQ];
+    float e[NQ], av[NQ];
     float amin = 3.0e38f;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int k = lane + 64 * q;
       const bool on = k < nc;
       col[q] = on ? P.cand_idx[(long long)ul * P.Kc + k] : -1;
-      if (on) amin = fminf(amin, P.cand_val[(long long)ul * P.Kc + k]);
+      av[q] = on ? P.cand_val[(long long)ul * P.Kc + k] : -3.0e38f;
+      if (on) amin = fminf(amin, av[q]);
       int l = 0;
       if (on) {
         if (P.cyc_nb) {
@@ -715,6 +716,48 @@ __global__ void __launch_bounds__(256) k_predict_rescore(rp_rescore_params P) {
     // a column outside the list: approximate score <= a_Kc, or exactly zero (never a candidate) - and a list shorter than Kc holds
     // every column whose approximate score is not zero
     const float a_bound = (nc == P.Kc) ? fmaxf(amin, 0.0f) : 0.0f;
+    // (round 4) Candidates that cannot be among the best Kp are not scored: with a_Kp the Kp-th largest APPROXIMATE score of the
+    // list, Kp candidates have exact scores >= a_Kp - E, and one with a_j + E < a_Kp - E lies below all of them.  The gathers -
+    // a 64-byte line per candidate and history item - are the cost of this kernel, and the list is as long as the hardest users
+    // need (the median user of the int8 first pass needs 133 of its 192).  What was skipped is treated like a column outside the
+    // list: the proof below also asks the Kp-th exact score to beat the best skipped bound.
+    bool skip[NQ];
+    float a_skip = -3.0e38f;
+    {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        se[lane + 64 * q] = av[q];
+        skip[q] = false;
+      }
+      RP_WAVE_FENCE();
+      if (nc > P.Kp) {
+        int gt[NQ], ge[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) gt[q] = ge[q] = 0;
+        for (int k = 0; k < 64 * NQ; ++k) {
+          const float ak = se[k];
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            gt[q] += ak > av[q] ? 1 : 0;
+            ge[q] += ak >= av[q] ? 1 : 0;
+          }
+        }
+        float a_kp = -3.0e38f;  // the value with fewer than Kp above it and at least Kp at or above it
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          if (gt[q] < P.Kp && P.Kp <= ge[q]) a_kp = fmaxf(a_kp, av[q]);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) a_kp = fmaxf(a_kp, __shfl_xor(a_kp, d));
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          skip[q] = col[q] >= 0 && av[q] + E < a_kp - E;
+          if (skip[q]) a_skip = fmaxf(a_skip, av[q]);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) a_skip = fmaxf(a_skip, __shfl_xor(a_skip, d));
+      }
+      RP_WAVE_FENCE();
+    }
     // exact scores: the one-pass kernel's sums, same order (history order, one add per row)
     int h = hs;
     for (; h + 3 < he; h += 4) {
@@ -725,10 +768,13 @@ __global__ void __launch_bounds__(256) k_predict_rescore(rp_rescore_params P) {
       float v0[NQ], v1[NQ], v2[NQ], v3[NQ];
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        v0[q] = R0[loc[q]];
-        v1[q] = R1[loc[q]];
-        v2[q] = R2[loc[q]];
-        v3[q] = R3[loc[q]];
+        v0[q] = v1[q] = v2[q] = v3[q] = 0.0f;
+        if (!skip[q]) {
+          v0[q] = R0[loc[q]];
+          v1[q] = R1[loc[q]];
+          v2[q] = R2[loc[q]];
+          v3[q] = R3[loc[q]];
+        }
       }
 #pragma unroll
       for (int q = 0; q < NQ; ++q) e[q] = (((e[q] + v0[q]) + v1[q]) + v2[q]) + v3[q];
@@ -736,8 +782,12 @@ __global__ void __launch_bounds__(256) k_predict_rescore(rp_rescore_params P) {
     for (; h < he; ++h) {
       const float* R0 = P.B + (long long)P.x_idx[h] * P.ld;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) e[q] += R0[loc[q]];
+      for (int q = 0; q < NQ; ++q)
+        if (!skip[q]) e[q] += R0[loc[q]];
     }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      if (skip[q]) e[q] = 0.0f;  // (not a candidate any more: a zero score is none)
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const bool ok = col[q] >= 0 && e[q] != 0.0f;  // (a score that cancels to exactly zero is not stored)
@@ -770,7 +820,7 @@ __global__ void __launch_bounds__(256) k_predict_rescore(rp_rescore_params P) {
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) e_kp = fmaxf(e_kp, __shfl_xor(e_kp, d));
-    const bool proven = n_valid >= P.Kp && e_kp > a_bound + E;
+    const bool proven = n_valid >= P.Kp && e_kp > fmaxf(a_bound, a_skip) + E;
     if (!proven) {
       if (lane == 0) P.fail_list[atomicAdd(P.n_fail, 1)] = P.fail_base + ul;
       RP_WAVE_FENCE();
