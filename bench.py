@@ -369,16 +369,26 @@ def pmc_traffic(config, kernel, world):
     if world != 1 or not found:
         return None, "no PMC pass committed for this configuration"
     path = found[-1]  # the latest round's pass (a kernel that was renamed since is simply not found: traffic = null)
-    lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "recpack_amd", "csrc", "rp_predict.hip")
-    stale = os.path.exists(lib) and os.path.getmtime(path) < os.path.getmtime(lib)
+    prof = json.load(open(path))
+    # stale = the sources of the kernels differ from those the pass was taken on (hashes recorded by tools/pmc_traffic.sh)
+    import hashlib
+
+    src_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "recpack_amd", "csrc")
+    stale = False
+    for f, h in prof.get("_sources_sha256", {"rp_predict.hip": None}).items():
+        fp = os.path.join(src_dir, f)
+        if h is None or not os.path.exists(fp) or hashlib.sha256(open(fp, "rb").read()).hexdigest() != h:
+            stale = True
     want = kernel.replace(" ", "")
-    for name, c in json.load(open(path)).items():
+    for name, c in prof.items():
+        if name.startswith("_"):
+            continue
         if want in name.replace(" ", "") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             f, w = c["FETCH_SIZE"]["avg_per_dispatch"], c["WRITE_SIZE"]["avg_per_dispatch"]
             return (2.0 * f + w) * 1024.0, (f"profiles/{os.path.basename(path)}: (2 x FETCH_SIZE {f:.0f} KiB + WRITE_SIZE {w:.0f} KiB) "
                                             "per launch; the x2 is the guide's gfx950 correction for wide reads and is an upper "
                                             "bound for this kernel's 16-B gathers (uncalibrated width)" +
-                                            ("; NOTE: the pass is older than the kernel's source - re-run tools/pmc_traffic.sh" if stale else ""))
+                                            ("; NOTE: the kernels' sources have changed since the pass - re-run tools/pmc_traffic.sh" if stale else ""))
     return None, "kernel not in the PMC pass"
 
 

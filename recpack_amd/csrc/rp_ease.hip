@@ -25,7 +25,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 
 constexpr int GLD = 20;   // LDS row stride in floats (16 + 4 pad: conflict-free ds_read_b128 over 16 rows)
-constexpr int GKC = 1024;  // default K steps between two flushes of the MFMA accumulators into the compensated master sums (option gemm_flush_k)
+[[maybe_unused]] constexpr int GKC = 1024;  // default K steps between two flushes of the MFMA accumulators into the compensated master sums (option gemm_flush_k)
 
 
 // Which tile a workgroup computes.  Workgroups go to the 8 XCDs round-robin by their linear id, and each XCD has its own L2.  In
@@ -272,7 +272,6 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(rp_gemm_args g) {
 // hoisted in front of the MFMAs (145: 24 more live registers, no interleaving by the compiler), K32 steps in one buffer (168
 // on the square product, but 7.6 s instead of 6.5 s for the C4 fit: the clipped K ranges of the triangular factors).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int BLD = 24;  // plane row stride in bf16 elements
 
 // ---- two fp16 planes: three plane products ---------------------------------------------------------------------------------------
 // fp16 carries 11 significant bits where bf16 carries 8: with round-to-nearest, x = h1 + h2 + e with h1 = fp16(x), h2 = fp16(x - h1)
@@ -344,7 +343,7 @@ __global__ void __launch_bounds__(256) k_gemm_amax(rp_amax_op a, rp_amax_op b, i
   }
 }
 
-constexpr int HLD = 24;  // plane row stride in fp16 elements (48 B, as BLD)
+constexpr int HLD = 24;  // plane row stride in fp16 elements (48 B)
 
 __global__ void __launch_bounds__(256, 2) k_gemm_nt_h2(rp_gemm_args g) {
   __shared__ __attribute__((aligned(16))) unsigned short As[2][2][GT * HLD];
@@ -881,22 +880,6 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + kob + s2 * 1024),
                                          (__attribute__((address_space(3))) void*)(sb + s2 * 1024), 16, 0, 0);
     };
-    // the same six requests one group at a time: part 0 = A plane 0, 1 = A plane 1, 2 / 3 = B's two K16 pieces
-    auto issue_part = [&](int stage, int k, int part) __attribute__((always_inline)) {
-      const long long ko = (long long)((k - q.kc0) >> 4) * 1024, kob = (long long)((k - q.kc0b) >> 4) * 1024;
-      unsigned char* sa = smw + stage * STAGE + AOFF + (wave * 2) * 1024;
-      unsigned char* sb = smw + stage * STAGE + BOFF + (((wave >> 2) * 4 + (wave & 3)) * 2) * 1024;
-      if (part < 2) {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc + part * q.psa + ko + s2 * 1024),
-                                           (__attribute__((address_space(3))) void*)(sa + part * 16 * 1024 + s2 * 1024), 16, 0, 0);
-      } else {
-        const int s2 = part - 2;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + kob + s2 * 1024),
-                                         (__attribute__((address_space(3))) void*)(sb + s2 * 1024), 16, 0, 0);
-      }
-    };
     // a request past the K range re-reads the last step (harmless, keeps the counted waits uniform)
     const int k_last = kb + ((ke - kb - 1) / 32) * 32;
     issue(0, kb);
@@ -1085,7 +1068,10 @@ constexpr int PSTG = GT + 1;                              // row stride of the s
 constexpr size_t RP_POTRF_LDS = ((size_t)GT * DS + (size_t)PB * PSTG + (size_t)PB * (PB + 1) + PB) * sizeof(double);
 constexpr int RP_POTRF_THREADS = 512;
 
-__global__ void __launch_bounds__(RP_POTRF_THREADS) k_potrf_trtri(float* __restrict__ A, long long lda, float* __restrict__ W, int* __restrict__ info) {
+// wt != 0: the block of A receives W^T (upper triangular) instead of L: in the fused solve nothing reads a diagonal block of L again
+// (the column below it is solved with W), and W^T is what N = L^-T holds there - one k_transpose_128 launch per block less.
+__global__ void __launch_bounds__(RP_POTRF_THREADS) k_potrf_trtri(float* __restrict__ A, long long lda, float* __restrict__ W, int* __restrict__ info,
+                                                                  int wt = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* a = reinterpret_cast<double*>(smem_raw);  // [128][DS]
   double* stg = a + GT * DS;                         // [PB][PSTG]
@@ -1176,9 +1162,11 @@ __global__ void __launch_bounds__(RP_POTRF_THREADS) k_potrf_trtri(float* __restr
     }
     __syncthreads();
   }
-  for (int e = tid; e < GT * GT; e += NT) {
-    const int i = e / GT, k = e % GT;
-    A[(long long)i * lda + k] = (k <= i) ? (float)a[i * DS + k] : 0.0f;
+  if (!wt) {
+    for (int e = tid; e < GT * GT; e += NT) {
+      const int i = e / GT, k = e % GT;
+      A[(long long)i * lda + k] = (k <= i) ? (float)a[i * DS + k] : 0.0f;
+    }
   }
   // ---- W = L^-1 in place, block row by block row: W[I][J] = -W_II sum_{K = J .. I-1} L[I][K] W[K][J] (rows above I already hold W)
   for (int r0 = 0; r0 < GT; r0 += PB) {
@@ -1222,6 +1210,7 @@ __global__ void __launch_bounds__(RP_POTRF_THREADS) k_potrf_trtri(float* __restr
   for (int e = tid; e < GT * GT; e += NT) {
     const int i = e / GT, k = e % GT;
     W[i * GT + k] = (k <= i) ? (float)a[i * DS + k] : 0.0f;
+    if (wt) A[(long long)i * lda + k] = (k >= i) ? (float)a[k * DS + i] : 0.0f;
   }
 }
 
@@ -1280,17 +1269,6 @@ __global__ void k_transpose_block(const float* __restrict__ src, long long lds, 
   for (int r = threadIdx.y; r < 32; r += 8) t[r][threadIdx.x] = below ? 0.0f : src[(long long)(by + r) * lds + bx + threadIdx.x];
   __syncthreads();
   for (int r = threadIdx.y; r < 32; r += 8) dst[(long long)(bx + r) * ldd + by + threadIdx.x] = t[threadIdx.x][r];
-}
-
-// dst block (ld) = src^T, src is a 128x128 block with leading dimension 128
-__global__ void __launch_bounds__(256) k_transpose_128(const float* __restrict__ src, float* __restrict__ dst, long long ld) {
-  __shared__ float t[GT][GT + 1];
-  for (int e = threadIdx.x; e < GT * GT; e += 256) t[e / GT][e % GT] = src[e];
-  __syncthreads();
-  for (int e = threadIdx.x; e < GT * GT; e += 256) {
-    const int i = e / GT, k = e % GT;
-    dst[(long long)i * ld + k] = t[k][i];
-  }
 }
 
 __global__ void k_ease_diag(const float* __restrict__ P, long long ld, int n, const int32_t* __restrict__ deg, float alpha,
@@ -1670,7 +1648,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
       rc = rp_gemm_nt(ctx, g, s2, part_diag);
       if (rc != RPHIP_OK) break;
     }
-    hipLaunchKernelGGL(k_potrf_trtri, dim3(1), dim3(RP_POTRF_THREADS), diag_lds, s2, A + (long long)r0 * ld + r0, ld, W + (size_t)k * GT * GT, info);
+    hipLaunchKernelGGL(k_potrf_trtri, dim3(1), dim3(RP_POTRF_THREADS), diag_lds, s2, A + (long long)r0 * ld + r0, ld, W + (size_t)k * GT * GT, info, 1);
     RP_HIP(hipEventRecord(e_diag, s2));
     if (r0 + GT < n_pad) {
       if (r0 > sk0) {  // A[k+1:,k] -= L[k+1:,p:k] L[k,p:k]^T
@@ -1875,7 +1853,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
     for (int i = pb; i < pe; ++i) {
       const int c0 = i * GT;
       const float* Wi = W + (size_t)i * GT * GT;
-      hipLaunchKernelGGL(k_transpose_128, dim3(1), dim3(256), 0, s2, Wi, Nb + (long long)c0 * ld + c0, ld);
+      // (N's diagonal block W_i^T is where the factorisation left it: k_potrf_trtri, wt)
       if (i > pb) {
         rp_gemm_args g{};
         g.A = Nb + (long long)j * ld;
