@@ -217,17 +217,20 @@ def test_ease_fit_synthetic_vs_oracle(hip, shape, l2, alpha, seed):
             assert (got >= t - 2 * EASE_TOL * smax).all()
 
 
-@pytest.mark.parametrize("n_items,n_users,dens", [(8192, 100000, 0.004), (16384, 200000, 0.002)])
-def test_ease_vs_float64_inverse_8k_16k(hip, n_items, n_users, dens):
+@pytest.mark.parametrize("n_items,n_users,dens,l2,alpha", [(8192, 100000, 0.004, 200.0, 0.0), (16384, 200000, 0.002, 200.0, 0.0),
+                                                         (8192, 100000, 0.004, 10.0, 1.0)])
+def test_ease_vs_float64_inverse_8k_16k(hip, n_items, n_users, dens, l2, alpha):
     """The largest sizes a host inverts in reasonable time: all of B against the reference's float64
     inverse (ease.py:81-86 through the oracle), globally and per column; the achieved errors are printed for the trend
-    (tests/test_gpu_fullsize.py continues it to 50K, 100K and 200K items with certified float64 columns)."""
+    (tests/test_gpu_fullsize.py continues it to 50K, 100K and 200K items with certified float64 columns).  The third case is the
+    wide-dynamic-range one: a small l2 (the Gram's own conditioning) and alpha = 1 (columns scaled by 1 / c_j over three decades of
+    item popularity, ease.py:88-90) - every column still to the same relative bar."""
     from recpack_amd.synth import powerlaw_csr
 
     _lib, ctx = hip
     X = powerlaw_csr(n_users, n_items, dens, seed=20260100 + n_items).to_scipy()
-    dX, m, B = ease_B(hip, X, 200.0, 0.0)
-    ref = onp.ease_fit(X, 200.0, 0.0)
+    dX, m, B = ease_B(hip, X, l2, alpha)
+    ref = onp.ease_fit(X, l2, alpha)
     err = rel_max(B, ref)
     col = np.abs(B - ref).max(axis=0) / np.maximum(np.abs(ref).max(axis=0), 1e-300)
     c_max = int(np.asarray(X.sum(axis=0)).max())
@@ -526,6 +529,14 @@ def test_predict_two_pass_equals_one_pass(hip):
         both(m, 100, True)
         T = rng.choice(np.array([0.0, 0.25, -0.25, 0.5, 1.0], dtype=np.float32), size=(2600, 2600), p=[0.5, 0.2, 0.1, 0.15, 0.05])
         both(_lib.Model.from_dense_host(ctx, T), 100, True)
+        # rows of wildly different scale, all-zero rows, rows whose one outlier leaves every other entry below the int8 step: the
+        # quantised copies prove little here, whoever is not proven takes the exact pass, the results stay the one-pass kernel's
+        T2 = (rng.standard_normal((2600, 2600)) * 10.0 ** rng.uniform(-6, 6, size=(2600, 1))).astype(np.float32)
+        T2[rng.random(2600) < 0.05] = 0.0
+        out = rng.choice(2600, 200, replace=False)
+        T2[out, rng.integers(0, 2600, 200)] = 1e9
+        both(_lib.Model.from_dense_host(ctx, T2), 100, True)
+        both(_lib.Model.from_dense_host(ctx, T2), 20, False)
         # tiles wide enough that every thread of the first pass owns columns: the pre-filter of the selection (a lower bound of
         # the Kc-th score from the threads' best scores) is active; and the narrow-tile instance (two workgroups per CU)
         X2 = powerlaw_csr(3000, 9000, 0.004, seed=92).to_scipy()
