@@ -371,6 +371,11 @@ int rphip_model_from_dense_host(rphip_ctx* ctx, int64_t n_items, const float* B_
  * (keep = min(int(density * n * n), nnz) in the reference).  Entries equal to the threshold are kept up to the exact
  * count in no particular order, as np.argpartition does.  nnz_before / nnz_after may be NULL. */
 int rphip_model_dense_prune(rphip_ctx* ctx, rphip_model* m, int64_t keep, int64_t* nnz_before, int64_t* nnz_after);
+/* The caller has rewritten the matrix of a dense model that BORROWS its memory (rphip_model_from_dense_cols and the other borrowing
+ * constructors): the quantised copy the two-pass predict built from the old values (option "predict_half") is dropped and rebuilt
+ * on the next predict, and the empty-row count is taken again.  Without this call the proof of the second pass would use the old
+ * rows' error bounds.  (No reference counterpart: recpack's similarity_matrix_ is an ordinary attribute.) */
+int rphip_model_dense_changed(rphip_ctx* ctx, rphip_model* m);
 /* number of similarity rows without any stored value (dense models; -1 if not counted): what
  * ItemSimilarityMatrixAlgorithm._check_fit_complete warns about (recpack/algorithms/base.py:257-279) */
 int rphip_model_empty_rows(rphip_ctx* ctx, const rphip_model* m, int64_t* out);

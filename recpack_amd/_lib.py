@@ -98,6 +98,7 @@ PROTOTYPES = {
     "rphip_model_dense_download": (C.c_int, [_p, _p, _p]),
     "rphip_model_dense_device": (C.c_int, [_p, _pp, C.POINTER(_i64), C.POINTER(_i64)]),
     "rphip_model_dense_prune": (C.c_int, [_p, _p, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
+    "rphip_model_dense_changed": (C.c_int, [_p, _p]),
     "rphip_model_from_dense_host": (C.c_int, [_p, _i64, _p, _pp]),
     "rphip_model_empty_rows": (C.c_int, [_p, _p, C.POINTER(_i64)]),
     "rphip_ctx_trim": (C.c_int, [_p]),
@@ -464,6 +465,10 @@ class Model:
         a, b = C.c_int64(), C.c_int64()
         check(self.ctx.lib.rphip_model_dense_prune(self.ctx.handle, self.handle, int(keep), C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def dense_changed(self):
+        """The caller rewrote the borrowed matrix of this dense model: the two-pass predict's quantised copy is rebuilt on next use."""
+        check(self.ctx.lib.rphip_model_dense_changed(self.ctx.handle, self.handle))
 
     def dense_download(self) -> np.ndarray:
         out = np.empty((self.n_items, self.n_items), dtype=np.float32)

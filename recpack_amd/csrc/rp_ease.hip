@@ -2520,6 +2520,22 @@ __global__ void __launch_bounds__(256) k_prune_apply(float* __restrict__ B, long
   }
 }
 
+extern "C" int rphip_model_dense_changed(rphip_ctx* ctx, rphip_model* m) {
+  if (!ctx || !m) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if (m->kind != RPHIP_MODEL_DENSE || !m->B) RP_FAIL(RPHIP_ESTATE, "not a dense model");
+  RP_TRY(rp_set_device(ctx));
+  RP_HIP(hipStreamSynchronize(ctx->stream));
+  rp_dev_free(ctx, m->B16);
+  rp_dev_free(ctx, m->b16_delta);
+  rp_dev_free(ctx, m->b16_rowmax);
+  rp_dev_free(ctx, m->b8_scale);
+  m->B16 = nullptr;
+  m->b16_delta = m->b16_rowmax = m->b8_scale = nullptr;
+  m->b16_kind = 0;
+  m->b16_failed = false;
+  return rp_dense_count_empty(ctx, m);
+}
+
 extern "C" int rphip_model_dense_prune(rphip_ctx* ctx, rphip_model* m, int64_t keep, int64_t* nnz_before, int64_t* nnz_after) {
   if (!ctx || !m) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (m->kind != RPHIP_MODEL_DENSE) RP_FAIL(RPHIP_ESTATE, "model is not a dense model");

@@ -537,6 +537,18 @@ def test_predict_two_pass_equals_one_pass(hip):
         T2[out, rng.integers(0, 2600, 200)] = 1e9
         both(_lib.Model.from_dense_host(ctx, T2), 100, True)
         both(_lib.Model.from_dense_host(ctx, T2), 20, False)
+        # a model that borrows its matrix, rewritten by its owner: dense_changed drops the quantised copy of the old values
+        import torch
+
+        Bt = torch.zeros((2600, 2624), dtype=torch.float32, device="cuda:0")
+        Bt[:, :2600] = torch.as_tensor(T2, device="cuda:0")
+        mb = _lib.Model.from_dense_cols(ctx, 2600, 0, 2600, Bt)
+        both(mb, 50, True)
+        Bt[:, :2600] = torch.as_tensor(rng.standard_normal((2600, 2600)).astype(np.float32), device="cuda:0")
+        torch.cuda.synchronize()
+        mb.dense_changed()
+        both(mb, 50, True)
+        mb.close()
         # tiles wide enough that every thread of the first pass owns columns: the pre-filter of the selection (a lower bound of
         # the Kc-th score from the threads' best scores) is active; and the narrow-tile instance (two workgroups per CU)
         X2 = powerlaw_csr(3000, 9000, 0.004, seed=92).to_scipy()
