@@ -1283,9 +1283,12 @@ __global__ void k_ease_diag(const float* __restrict__ P, long long ld, int n, co
 
 // K7: B_ij = P_ij * colscale_j (= -P_ij / P_jj * w_j), B_ii = 0; in place
 // (a workgroup per row: no division per element, the column factors as 16-byte loads; colscale holds ld entries)
-__global__ void k_ease_scale(float* __restrict__ P, long long ld, int n, const float* __restrict__ colscale) {
+// (empty != NULL: rows of B without any stored value are counted on the way - what _check_fit_complete warns about; a pass of its
+// own over the matrix before round 4)
+__global__ void k_ease_scale(float* __restrict__ P, long long ld, int n, const float* __restrict__ colscale, int* __restrict__ empty) {
   for (long long i = blockIdx.x; i < n; i += gridDim.x) {
     float* row = P + i * ld;
+    int nz = 0;
     for (long long j = 4LL * threadIdx.x; j < ld; j += 4LL * blockDim.x) {  // (ld is a multiple of 4)
       const float4 v = *reinterpret_cast<const float4*>(row + j);
       float o[4] = {v.x, v.y, v.z, v.w};
@@ -1293,8 +1296,13 @@ __global__ void k_ease_scale(float* __restrict__ P, long long ld, int n, const f
       for (int c = 0; c < 4; ++c) {
         const long long jj = j + c;
         o[c] = (jj < n && jj != i) ? o[c] * colscale[jj] : 0.0f;
+        nz |= (o[c] != 0.0f) ? 1 : 0;
       }
       *reinterpret_cast<float4*>(row + j) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (empty) {  // (uniform)
+      const int any = __syncthreads_or(nz);
+      if (threadIdx.x == 0 && !any) atomicAdd(empty, 1);
     }
   }
 }
@@ -2341,13 +2349,18 @@ static int rp_ease_solve_scale(rphip_ctx* ctx, const rphip_csr* X, rphip_model* 
   hipEvent_t ev;
   rp_time_begin(ctx, &ev);
   float* colscale = nullptr;
-  RP_TRY(rp_scratch(ctx, 5, (size_t)n_pad * 4, (void**)&colscale));
+  RP_TRY(rp_scratch(ctx, 5, (size_t)n_pad * 4 + 64, (void**)&colscale));
+  int* empty = reinterpret_cast<int*>(colscale + n_pad);
+  RP_HIP(hipMemsetAsync(empty, 0, 4, st));
   hipLaunchKernelGGL(k_ease_diag, dim3((unsigned)rp_cdiv(n, 256)), dim3(256), 0, st, m->B, m->ld, n, X->deg, (float)alpha, colscale);
-  hipLaunchKernelGGL(k_ease_scale, dim3(4096), dim3(256), 0, st, m->B, m->ld, n, colscale);
+  hipLaunchKernelGGL(k_ease_scale, dim3(4096), dim3(256), 0, st, m->B, m->ld, n, colscale, empty);
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, RPHIP_T_EASE_SCALE, 8.0 * (double)n * (double)n);
+  int h_empty = 0;
+  RP_HIP(hipMemcpyAsync(&h_empty, empty, 4, hipMemcpyDeviceToHost, st));
   RP_HIP(hipStreamSynchronize(st));
-  return rp_dense_count_empty(ctx, m);
+  m->empty_rows = h_empty;
+  return RPHIP_OK;
 }
 
 extern "C" int rphip_ease_fit(rphip_ctx* ctx, const rphip_csr* X, double l2, double alpha, rphip_model** out) {
