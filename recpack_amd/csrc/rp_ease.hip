@@ -1307,6 +1307,52 @@ __global__ void k_ease_scale(float* __restrict__ P, long long ld, int n, const f
   }
 }
 
+// K7 straight from the LOWER half of P (round 4): B_ij = P_ij * colscale[j] below the diagonal and, from the same 32 x 32 tile,
+// B_ji = P_ij * colscale[i] above it - the mirror of the inverse and the scaling in one pass (20 GB read + 40 GB written at 100 000
+// items instead of 60 + 60).  Values on the diagonal and in the padding are zero; rownz[i] is set when row i keeps a stored value.
+__global__ void __launch_bounds__(256) k_ease_scale_sym(float* __restrict__ P, long long ld, int n, const float* __restrict__ colscale,
+                                                        int* __restrict__ rownz) {
+  __shared__ float t[32][33];
+  __shared__ int nz_lo[32], nz_up[32];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj > bi) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  if (threadIdx.x < 32) nz_lo[threadIdx.x] = nz_up[threadIdx.x] = 0;
+  for (int r = ty; r < 32; r += 8) t[r][tx] = P[(long long)(bi * 32 + r) * ld + bj * 32 + tx];
+  __syncthreads();
+  // the tile itself: rows bi*32 + r, columns bj*32 + tx (on a diagonal tile only its lower part: the upper part comes from the mirror)
+  const int jl = bj * 32 + tx;
+  const float cl = jl < n ? colscale[jl] : 0.0f;
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bi * 32 + r;
+    if (bi == bj && tx > r) continue;
+    const float v = (i < n && jl < n && i != jl) ? t[r][tx] * cl : 0.0f;
+    P[(long long)i * ld + jl] = v;
+    if (v != 0.0f) nz_lo[r] = 1;
+  }
+  // its mirror: rows bj*32 + r, columns bi*32 + tx, element (i, j) = P[j][i] = t[tx][r]
+  const int ju = bi * 32 + tx;
+  const float cu = ju < n ? colscale[ju] : 0.0f;
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bj * 32 + r;
+    if (ju <= i) continue;  // (strictly above the diagonal)
+    const float v = (i < n && ju < n) ? t[tx][r] * cu : 0.0f;
+    P[(long long)i * ld + ju] = v;
+    if (v != 0.0f) nz_up[r] = 1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    if (nz_lo[threadIdx.x] && bi * 32 + threadIdx.x < n) rownz[bi * 32 + threadIdx.x] = 1;
+    if (nz_up[threadIdx.x] && bj * 32 + threadIdx.x < n) rownz[bj * 32 + threadIdx.x] = 1;
+  }
+}
+
+__global__ void k_count_zero_flags(const int* __restrict__ f, int n, int* __restrict__ cnt) {
+  int c = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c += f[i] == 0 ? 1 : 0;
+  if (c) atomicAdd(cnt, c);
+}
+
 // ---- host ------------------------------------------------------------------------------------------------------
 // `st` = stream to launch on (the context's by default); `part_at` = where this product's split-K partials go
 // (two products that run concurrently on different streams must not share them)
@@ -1549,7 +1595,7 @@ extern "C" int rphip_gemm_nt_f32(rphip_ctx* ctx, int64_t M, int64_t N, int64_t K
 // side buffer, and the lower half is mirrored over N.  200 000 items (160 GB) fit one 288 GB GPU this way.
 constexpr int RP_INV_PANEL = 16;  // tiles per panel of N = L^-T (2048 columns; 8 / 16 / 32 tiles measured: 5.94 / 5.53 / 5.87 s at n = 100 000)
 
-int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_ext, hipStream_t on) {
+int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_ext, hipStream_t on, bool lower_only) {
   hipStream_t st = on ? on : ctx->stream;  // (every launch below names its stream: the solve may run beside the caller's other streams)
   const bool timed = st == ctx->stream;
   const int nb = n_pad / GT;
@@ -2048,7 +2094,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
     g.ldc = GT;
     RP_TRY(rp_gemm_nt(ctx, g, st));
     hipLaunchKernelGGL(k_copy_diag_blocks, dim3(nb), dim3(256), 0, st, T, A, ld);
-    hipLaunchKernelGGL(k_mirror_lower, dim3(n_pad / 32, n_pad / 32), dim3(256), 0, st, A, ld, n_pad / 32);  // ... and the mirror
+    if (!lower_only) hipLaunchKernelGGL(k_mirror_lower, dim3(n_pad / 32, n_pad / 32), dim3(256), 0, st, A, ld, n_pad / 32);  // ... and the mirror
     if (itrace) {
       iv_rec();
       hipStreamSynchronize(st);
@@ -2342,18 +2388,25 @@ static int rp_ease_solve_scale(rphip_ctx* ctx, const rphip_csr* X, rphip_model* 
   hipStream_t st = ctx->stream;
   const int n = (int)m->n_items;
   const int n_pad = (int)m->ld;
-  int r = rp_spd_inverse(ctx, m->B, n_pad, m->ld);
+  const bool sym = (n_pad % 32 == 0) && m->ld == n_pad && getenv("RP_EASE_SCALE_ROWS") == nullptr;  // mirror + scaling in one pass
+  int r = rp_spd_inverse(ctx, m->B, n_pad, m->ld, nullptr, nullptr, sym);
   hipStreamSynchronize(st);
   if (r != RPHIP_OK) return r;
   // ---- K7
   hipEvent_t ev;
   rp_time_begin(ctx, &ev);
   float* colscale = nullptr;
-  RP_TRY(rp_scratch(ctx, 5, (size_t)n_pad * 4 + 64, (void**)&colscale));
-  int* empty = reinterpret_cast<int*>(colscale + n_pad);
-  RP_HIP(hipMemsetAsync(empty, 0, 4, st));
+  RP_TRY(rp_scratch(ctx, 5, (size_t)n_pad * 8 + 64, (void**)&colscale));
+  int* rownz = reinterpret_cast<int*>(colscale + n_pad);  // [n_pad]
+  int* empty = rownz + n_pad;
+  RP_HIP(hipMemsetAsync(rownz, 0, (size_t)n_pad * 4 + 4, st));
   hipLaunchKernelGGL(k_ease_diag, dim3((unsigned)rp_cdiv(n, 256)), dim3(256), 0, st, m->B, m->ld, n, X->deg, (float)alpha, colscale);
-  hipLaunchKernelGGL(k_ease_scale, dim3(4096), dim3(256), 0, st, m->B, m->ld, n, colscale, empty);
+  if (sym) {
+    hipLaunchKernelGGL(k_ease_scale_sym, dim3(n_pad / 32, n_pad / 32), dim3(256), 0, st, m->B, m->ld, n, colscale, rownz);
+    hipLaunchKernelGGL(k_count_zero_flags, dim3(64), dim3(256), 0, st, rownz, n, empty);
+  } else {
+    hipLaunchKernelGGL(k_ease_scale, dim3(4096), dim3(256), 0, st, m->B, m->ld, n, colscale, empty);
+  }
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, RPHIP_T_EASE_SCALE, 8.0 * (double)n * (double)n);
   int h_empty = 0;

@@ -61,7 +61,9 @@ int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st = nullptr, 
 // In-place inverse of the SPD matrix A (n_pad x n_pad, a multiple of 128; reads the lower triangle).  info_dev == NULL: the
 // call waits for the result and fails with RPHIP_ENUMERIC when a pivot is not positive; otherwise nothing is waited for and a
 // failing pivot's index + 1 is left in *info_dev (device int, not cleared here).
-int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_dev = nullptr, hipStream_t on = nullptr);  // `on`: the stream to run on (the context's when NULL)
+// `on`: the stream to run on (the context's when NULL); lower_only: the upper half of the result is NOT mirrored from the lower one
+// (the caller's next pass does it: k_ease_scale_sym)
+int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_dev = nullptr, hipStream_t on = nullptr, bool lower_only = false);
 // rows [r0, r1) of G + lam I (identity block on the padding rows >= n_items) into G (row-major, ld), all n_cols columns
 int rp_ease_gram_rows(rphip_ctx* ctx, const rphip_csr* X, int64_t r0, int64_t r1, int64_t n_cols, float lam, float* G, int64_t ld);
 int rp_transpose_f32(rphip_ctx* ctx, const float* src, int64_t lds, int64_t rows, int64_t cols, float* dst, int64_t ldd, hipStream_t st = nullptr);
