@@ -143,6 +143,9 @@ int rphip_ctx_trim(rphip_ctx* ctx);
  *                       tiles) and, inside a panel, in sub-panels of this many: a block's left-looking products reach back to its
  *                       sub-panel only, a finished sub-panel updates the rest of the panel in one wide product.  0 (or a value
  *                       that does not divide the panel) = one level.
+ *   "chol_panel"        0 (default: 32 tiles from 640 tiles = 81 920 items, 16 below) | 8 | 16 | 32 | 64: tiles per panel of that Cholesky
+ *                       (tuning; the trailing update of a finished panel is one product with K = 128 x this).
+ *   "inv_panel"         16 (default) | 8 | 32: tiles per column panel of N = L^-T in the inverse (tuning).
  *   "gemm_plane_cache"  1 (default) | 0 | bytes.  The inverse N = L^-T keeps the fp16 planes of the part of N it has finished
  *                       (4 bytes per element of an n x n square, from the context's block cache) instead of cutting it anew for
  *                       every panel: 1 = as much as the free memory holds (everything at 100 000 items; a prefix of the panels

@@ -319,6 +319,12 @@ extern "C" int rphip_ctx_set_option(rphip_ctx* ctx, const char* name, int64_t va
   } else if (!strcmp(name, "chol_sub_panel")) {
     if (value < 0 || value > 32) RP_FAIL(RPHIP_EINVAL, "chol_sub_panel must be 0 .. 32 tiles");
     ctx->chol_sub = (int)value;
+  } else if (!strcmp(name, "chol_panel")) {
+    if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) RP_FAIL(RPHIP_EINVAL, "chol_panel must be 0 (automatic), 8, 16, 32 or 64 tiles");
+    ctx->chol_panel = (int)value;
+  } else if (!strcmp(name, "inv_panel")) {
+    if (value != 8 && value != 16 && value != 32) RP_FAIL(RPHIP_EINVAL, "inv_panel must be 8, 16 or 32 tiles");
+    ctx->inv_panel = (int)value;
   } else if (!strcmp(name, "gemm_plane_cache")) {
     if (value < 0) RP_FAIL(RPHIP_EINVAL, "gemm_plane_cache must be >= 0");
     ctx->gemm_plane_cache = value;

@@ -97,6 +97,8 @@ struct rphip_ctx {
   int gemm_wide = 1;         // the plane product kernel on 256 x 128 tiles with three LDS stages (k_gemm_hp16w) instead of 128 x 128 / two
   size_t gemm_ws_bytes = (size_t)4 << 30;  // workspace per operand of those products (sets their K chunk)
   int chol_sub = 8;          // tiles per sub-panel of the blocked Cholesky (0: one level of panels)
+  int chol_panel = 0;        // tiles per panel of the blocked Cholesky (0: 32 from 640 tiles, else 16)
+  int inv_panel = 16;        // tiles per panel of N = L^-T
   int64_t gemm_plane_cache = 1;  // the inverse keeps the planes of N = L^-T between its panels: 0 off, 1 as much as fits, > 1 at most that many bytes
   unsigned* gemm_amax_ring = nullptr;  // mode 2: [RP_AMAX_SLOTS][2] words, the operands' largest magnitudes per launch
   unsigned long long gemm_amax_seq = 0;

@@ -123,8 +123,13 @@ __global__ void __launch_bounds__(RP_K0_T) k_partition(const int32_t* __restrict
   }
   __syncthreads();
   const int u0 = s_u0, nu = s_u1 - s_u0;  // (rows without entries inside the range are harmless: the search skips them)
-  for (int i = tid; i <= nu; i += RP_K0_T) rows[i] = x_ptr[u0 + i];
+  // nu counts the EMPTY rows inside the range too, so it is unbounded (50 000 history-less users between two entries): the LDS copy
+  // holds E + 2 pointers - longer ranges are searched in x_ptr itself
+  const bool cached = nu <= RP_K0_E + 1;
+  if (cached)
+    for (int i = tid; i <= nu; i += RP_K0_T) rows[i] = x_ptr[u0 + i];
   __syncthreads();
+  const int32_t* __restrict__ grow = x_ptr + u0;
   int bk[R];
   PT pay[R];
   int rk[R];
@@ -138,9 +143,16 @@ __global__ void __launch_bounds__(RP_K0_T) k_partition(const int32_t* __restrict
       const int j = x_idx[k];
       if ((unsigned)j < (unsigned)n_items && j >= xt_lo && j < xt_hi) {
         int lo = 0, hi = nu;  // the row u0 + lo with rows[lo] <= k < rows[lo + 1]
-        while (hi - lo > 1) {
-          const int m = (lo + hi) >> 1;
-          if (rows[m] <= (int)k) lo = m; else hi = m;
+        if (cached) {
+          while (hi - lo > 1) {
+            const int m = (lo + hi) >> 1;
+            if (rows[m] <= (int)k) lo = m; else hi = m;
+          }
+        } else {
+          while (hi - lo > 1) {
+            const int m = (lo + hi) >> 1;
+            if (grow[m] <= (int)k) lo = m; else hi = m;
+          }
         }
         const int b = j >> bshift;
         bk[r] = b;

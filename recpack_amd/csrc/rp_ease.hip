@@ -1593,13 +1593,14 @@ extern "C" int rphip_gemm_nt_f32(rphip_ctx* ctx, int64_t M, int64_t N, int64_t K
 // factor L sits strictly below the diagonal; N = L^-T is built on and above it (a diagonal block of L is only needed as its
 // inverse W_k, kept aside); P = N N^T then overwrites L below the diagonal (it reads N only), the diagonal tiles go through a
 // side buffer, and the lower half is mirrored over N.  200 000 items (160 GB) fit one 288 GB GPU this way.
-constexpr int RP_INV_PANEL = 16;  // tiles per panel of N = L^-T (2048 columns; 8 / 16 / 32 tiles measured: 5.94 / 5.53 / 5.87 s at n = 100 000)
+// tiles per panel of N = L^-T: ctx->inv_panel (default 16 = 2048 columns; 8 / 16 / 32 tiles measured in round 1: 5.94 / 5.53 / 5.87 s at n = 100 000)
 
 int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_ext, hipStream_t on, bool lower_only) {
   hipStream_t st = on ? on : ctx->stream;  // (every launch below names its stream: the solve may run beside the caller's other streams)
   const bool timed = st == ctx->stream;
   const int nb = n_pad / GT;
   char* wsb = nullptr;
+  const int RP_INV_PANEL = ctx->inv_panel;
   const int inv_w = std::min(RP_INV_PANEL * GT, n_pad);  // columns of one panel of the inverse
   const size_t cmax_off = (size_t)nb * GT * GT * 4 + ((size_t)n_pad * inv_w + (size_t)inv_w * inv_w + (size_t)inv_w * GT) * 4 + 256;
   RP_TRY(rp_scratch(ctx, 5, cmax_off + (size_t)(2 * nb + 8) * 2 * sizeof(unsigned), (void**)&wsb));
@@ -1673,7 +1674,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
   // rank-(128 * panel) update in ONE lower-triangular product at the square-GEMM rate.  Purely left-looking (K
   // from 0 for every 128-column block) made every product of the factorisation skinny: 92 TFLOP/s at n = 100 000.
   // (measured on MI355X: panels of 8 / 16 / 32 tiles give 91 / 96 / 89 TFLOP/s at n = 50 000 and 105 / 114 / 116 at 100 000)
-  const int RP_CHOL_PANEL = nb >= 640 ? 32 : 16;  // tiles per panel
+  const int RP_CHOL_PANEL = ctx->chol_panel ? ctx->chol_panel : (nb >= 640 ? 32 : 16);  // tiles per panel
   // ... and a level between: sub-panels of `chol_sub` tiles.  The left-looking products of a block (one tile column wide: ~100
   // TFLOP/s) only reach back to the sub-panel's first column; a finished sub-panel updates the REST OF ITS PANEL's columns in one
   // wide product (K = 128 * chol_sub).  3/4 of the in-panel flop moves from the skinny kernel to the wide one.

@@ -143,6 +143,39 @@ def test_fit_tie_heavy(hip):
     assert_same_as_oracle(idx, val, nnz, onp.itemknn_fit(H, 7))
 
 
+def test_fit_long_runs_of_empty_users(hip):
+    """K0's partition pass caches the row pointers of the users an 8192-entry window meets: a run of more than 8192 history-less
+    users inside a window must not overrun that cache - X^T, the degrees and both fits against the oracle."""
+    _lib, ctx = hip
+    rng = np.random.default_rng(77)
+    # (a) 50 000 users, two of them with a history, far apart
+    rows = np.r_[np.full(6, 3), np.full(5, 49_000)]
+    cols = np.r_[[0, 2, 3, 5, 7, 8], [0, 3, 4, 8, 9]]
+    A = sp.csr_matrix((np.ones(rows.size), (rows, cols)), shape=(50_000, 10))
+    # (b) 95 % empty rows, runs of up to 40 000 empty users between active ones, enough entries for several partition blocks
+    U, I = 400_000, 700
+    active = np.sort(rng.choice(U, U // 20, replace=False))
+    active = active[(active < 100_000) | (active > 140_000)]  # one run of 40 000 empty users in the middle
+    deg = rng.integers(1, 6, active.size)
+    r = np.repeat(active, deg)
+    c = rng.integers(0, I, r.size)
+    Bm = sp.csr_matrix((np.ones(r.size), (r, c)), shape=(U, I))
+    Bm.sum_duplicates()
+    Bm.data[:] = 1
+    # (c) the same with several column tiles (tile pointers of empty rows)
+    c2 = rng.integers(0, 30_000, r.size)
+    C = sp.csr_matrix((np.ones(r.size), (r, c2)), shape=(U, 30_000))
+    C.sum_duplicates()
+    C.data[:] = 1
+    for X, K in ((A, 4), (Bm, 20), (C, 10)):
+        dX, m, idx, val, nnz = fit_arrays(hip, X, K)
+        np.testing.assert_array_equal(dX.item_degrees(), np.asarray(X.sum(axis=0)).ravel().astype(np.int32))
+        assert_same_as_oracle(idx, val, nnz, onp.itemknn_fit(X, K))
+    B_gpu = _lib.ease_fit(ctx, _lib.DeviceCSR.from_host(ctx, Bm.indptr, Bm.indices, Bm.shape), 5.0).dense_download()
+    B_ref = onp.ease_fit(Bm, 5.0)
+    assert np.abs(B_gpu - B_ref).max() <= 1e-4 * np.abs(B_ref).max()
+
+
 def test_fit_edge_cases(hip):
     _lib, ctx = hip
     # empty matrix, empty rows / columns

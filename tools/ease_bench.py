@@ -22,8 +22,11 @@ if os.environ.get("RECPACK_GEMM_WIDE"):
     ctx.set_option("gemm_wide", int(os.environ["RECPACK_GEMM_WIDE"]))
 if os.environ.get("RECPACK_GEMM_SUPERTILE"):
     ctx.set_option("gemm_supertile", int(os.environ["RECPACK_GEMM_SUPERTILE"]))
+for name, opt in (("RECPACK_CHOL_PANEL", "chol_panel"), ("RECPACK_INV_PANEL", "inv_panel"), ("RECPACK_CHOL_SUB", "chol_sub_panel")):
+    if os.environ.get(name):
+        ctx.set_option(opt, int(os.environ[name]))
 dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
-for it in range(2):
+for it in range(int(os.environ.get('RECPACK_BENCH_ITERS', '3'))):
     ctx.reset_timings()
     t0 = time.perf_counter()
     m = _lib.ease_fit(ctx, dX, l2, 0.0)
