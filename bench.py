@@ -541,8 +541,14 @@ def main():
             t2 = time.perf_counter()
             # predict: while the whole of B fits every GPU, gather the panels and score this rank's USERS with the single-GPU kernels
             # (full-width rows, no lists to exchange); otherwise every rank scores all users against its own columns + merge
-            if rdist.ease_gather_fits(I, _lib.ease_fit_dist_stats(ctx)["panel"], info["hbm_bytes"]):
-                full = rdist.ease_gather_model(ctx, em, I, comm)
+            full = None
+            if rdist.ease_gather_fits(I, _lib.ease_fit_dist_stats(ctx)["panel"], info["hbm_bytes"], world):
+                try:
+                    full = rdist.ease_gather_model(ctx, em, I, comm)
+                except _lib.RecpackHipError as e:  # (the ranks agree on their allocations: everybody lands here or nobody)
+                    if e.code != _lib.RPHIP_ENOMEM:
+                        raise
+            if full is not None:
                 _lib.predict_topk_dev(ctx, full, dXe, Kp, out_idx, out_val, out_nnz, user_begin=ub, user_end=ue)
                 keep["ease_full"] = full
                 keep["ease_predict_route"] = "panels all-gathered, users sharded"

@@ -14,13 +14,15 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librecpack_hip.so")
+# (RECPACK_HIP_LIB: another build of the same library - the diagnostic build `make diag`, an A/B variant of a tool run)
+LIB_PATH = os.environ.get("RECPACK_HIP_LIB") or os.path.join(_HERE, "csrc", "librecpack_hip.so")
 
 RPHIP_T_NAMES = [
     "csr_transpose", "fit_plan", "gram_topk", "topk_merge", "predict", "gram_dense", "cholesky", "inverse",
     "ease_scale", "h2d", "d2h", "gram_finalize", "gram_topk_wave", "sweep_update", "sweep_chain", "mirror", "predict_dense",
 ]
 RPHIP_T_COUNT = 24
+RPHIP_EINVAL, RPHIP_EHIP, RPHIP_ENOMEM, RPHIP_ENODEV, RPHIP_EUNSORTED, RPHIP_ELIMIT, RPHIP_ESTATE, RPHIP_ENUMERIC = -1, -2, -3, -4, -5, -6, -7, -8
 RPHIP_MODEL_TOPK = 1
 RPHIP_MODEL_DENSE = 2
 

@@ -44,6 +44,15 @@ void rp_set_error(const char* fmt, ...);
                             "then rphip_csr_finish_degrees");                                                           \
   } while (0)
 
+// Diagnostic switches (RP_CHOL_TRACE, RP_INV_TRACE, RP_CHOL_MEASURE_SCALES, RP_N22_PLANES, RP_EASE_SCALE_ROWS, RP_K9_I8_KC): read from
+// the environment only by the diagnostic build (make diag: -DRP_DIAG, librecpack_hip_diag.so); the shipped library has none.
+#ifdef RP_DIAG
+#include <stdlib.h>
+static inline const char* rp_diag_env(const char* name) { return getenv(name); }
+#else
+static inline const char* rp_diag_env(const char*) { return nullptr; }
+#endif
+
 // ---- geometry ------------------------------------------------------------------------------------
 constexpr int RP_WAVE = 64;
 constexpr int RP_FIT_THREADS = 1024;      // 16 waves, one workgroup per CU (LDS-bound)

@@ -912,6 +912,15 @@ extern "C" int rphip_ease_model_allgather(rphip_ctx* ctx, rphip_comm* comm, cons
   m->row_begin = 0;
   m->row_end = n_items;
   m->ld = n_pad;
+  // the word the ranks agree on (taken before the large blocks)
+  int32_t* agree = nullptr;
+  {
+    const int ra = rp_dev_alloc(ctx, 256, (void**)&agree);
+    if (ra != RPHIP_OK) {
+      delete m;
+      return ra;
+    }
+  }
   int rc = rp_dev_alloc(ctx, (size_t)n_pad * n_pad * sizeof(float), (void**)&m->B);
   // strips of rows: W slots of strip x ldl floats, at most ~2 GiB of staging in all
   long long strip = std::max<long long>(128, ((long long)((size_t)2 << 30) / ((long long)(W + 1) * ldl * 4)) / 128 * 128);
@@ -920,6 +929,26 @@ extern "C" int rphip_ease_model_allgather(rphip_ctx* ctx, rphip_comm* comm, cons
   const long long slot = strip * ldl;
   if (rc == RPHIP_OK) rc = rp_dev_alloc(ctx, (size_t)slot * sizeof(float), (void**)&sendb);
   if (rc == RPHIP_OK) rc = rp_dev_alloc(ctx, (size_t)slot * W * sizeof(float), (void**)&recvb);
+  {
+    //  A rank whose allocations failed must not leave alone: the others would sit in the first all-gather for
+    // ever.  The ranks sum a 0 / 1 flag and return RPHIP_ENOMEM TOGETHER; the caller can then take rphip_predict_topk_dist.
+    int32_t h_bad = rc == RPHIP_OK ? 0 : 1;
+    hipError_t e1 = hipMemcpyAsync(agree, &h_bad, 4, hipMemcpyHostToDevice, st);
+    hipError_t e2 = hipStreamSynchronize(st);  // (h_bad is read by the copy)
+    const int rca = rp_comm_all_reduce_sum_i32(comm, agree, 1, st);
+    int32_t h_sum = 1;
+    hipError_t e3 = hipMemcpyAsync(&h_sum, agree, 4, hipMemcpyDeviceToHost, st);
+    hipError_t e4 = hipStreamSynchronize(st);
+    rp_dev_free(ctx, agree);
+    if (rca != RPHIP_OK || e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || h_sum != 0) {
+      rp_dev_free(ctx, sendb);
+      rp_dev_free(ctx, recvb);
+      rphip_model_destroy(m);
+      if (rca != RPHIP_OK) return rca;
+      RP_FAIL(RPHIP_ENOMEM, "%d of %d ranks could not allocate the gathered model (%lld x %lld floats + staging): use rphip_predict_topk_dist", (int)h_sum, W,
+              n_pad, n_pad);
+    }
+  }
   hipEvent_t ev;
   rp_time_begin(ctx, &ev);
   for (long long r0 = 0; r0 < n_pad && rc == RPHIP_OK; r0 += strip) {

@@ -1819,7 +1819,7 @@ static int rp_model_half(rphip_ctx* ctx, rphip_model* m, int kind) {
   }
   const int64_t rows = m->n_items;
   const int64_t cols = m->n_cols > 0 ? m->n_cols : m->n_items;
-  if (m->ld % 16) {  // (16-byte loads of eight fp16 / sixteen int8)
+  if (m->ld % (kind == 2 ? 16 : 8)) {  // (16-byte loads of eight fp16 / sixteen int8)
     m->b16_failed = true;
     return RPHIP_OK;
   }
@@ -2020,9 +2020,10 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
       fits2 = true;
     }
   }
-  const bool want_i8 = ctx->predict_int8 && fits2;
+  // (a borrowed slab whose leading dimension is a multiple of 8 but not of 16 cannot be read as int8 rows: it keeps the fp16 copy)
+  const bool want_i8 = ctx->predict_int8 && fits2 && (model->ld % 16) == 0;
   int kc_i8 = ((Kp + 92 + 63) / 64) * 64;
-  if (const char* e = getenv("RP_K9_I8_KC")) kc_i8 = std::max(64, atoi(e) / 64 * 64);
+  if (const char* e = rp_diag_env("RP_K9_I8_KC")) kc_i8 = std::max(64, atoi(e) / 64 * 64);
   const int Kc = want_i8 && kc_i8 <= 512 && (int64_t)4 * kc_i8 <= (int64_t)P.n_items ? kc_i8 : ((Kp + 24 + 63) / 64) * 64;
   if (model->kind == RPHIP_MODEL_DENSE && ctx->predict_half && Kc <= 512 && (int64_t)4 * Kc <= (int64_t)P.n_items && T <= 15) {
     rphip_model* mm = const_cast<rphip_model*>(model);
@@ -2036,7 +2037,12 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
       }
       const int Tm = std::max(T, Th);
       // first-pass tiles hand on every column above their bound (k_predict_tile, tile_cap): lists of up to 4 Kc entries
-      const int cap_t = (narrow && Th > 1 && !keep_dev && Kc <= 256 && getenv("RP_K9_EXACT_TILES") == nullptr) ? 4 * Kc : 0;
+      int cap_t = (narrow && Th > 1 && !keep_dev && Kc <= 256) ? 4 * Kc : 0;
+      //  the threshold lists are four times as long as the exact ones: where their merge would not fit the LDS
+      // (15 tiles x 4 x 256 entries = 162 KB) or their scratch would pass 6 GB the tiles select exactly, as in round 3
+      if (cap_t > 0 && ((size_t)Th * cap_t * 8 + rp_select_smem_bytes(Th * cap_t) > (size_t)160 * 1024 || Th * cap_t >= RPS_FLAG ||
+                        (size_t)std::min<int64_t>(n, 1 << 16) * std::max(T, Th) * cap_t * 8 > ((size_t)6 << 30)))
+        cap_t = 0;
       const int stride_t = cap_t > 0 ? cap_t : Kc;
       const int64_t UCH = cap_t > 0 ? 1 << 16 : 1 << 17;  // users per chunk: bounds the candidate scratch
       const int64_t nchm = std::min<int64_t>(n, UCH);

@@ -205,10 +205,17 @@ def ease_gather_model(ctx, model, n_items: int, comm):
     return _lib.ease_model_allgather(ctx, comm, model, int(n_items), int(panel))
 
 
-def ease_gather_fits(n_items: int, panel: int, hbm_bytes: int) -> bool:
-    """Does the gathered model (B, its fp16 copy for the first pass of K9, the staging strips) fit beside a rank's own panels?"""
+def ease_gather_fits(n_items: int, panel: int, hbm_bytes: int, world: int = 1, free_bytes: int | None = None) -> bool:
+    """Does the gathered model fit beside a rank's own panels?  Needed: B (4 n^2 bytes), its quantised copy for the first pass of
+    K9 (n^2 bytes as int8, 2 n^2 as fp16: the larger is assumed), 2 GiB of staging strips - while the rank's own panels
+    (4 n^2 / world) are still alive.  `free_bytes` = what the device can still hand out (hipMemGetInfo's free + the context's cached
+    blocks); without it 80 % of the device less the rank's panels is assumed.  A wrong "yes" is not fatal: the ranks of
+    rphip_ease_model_allgather agree on their allocations and fail together with RPHIP_ENOMEM."""
     n_pad = -(-int(n_items) // max(int(panel), 128)) * max(int(panel), 128)
-    return 3 * n_pad * n_pad * 4 < 0.8 * hbm_bytes
+    need = 6 * n_pad * n_pad + (2 << 30)
+    if free_bytes is None:
+        free_bytes = int(0.8 * hbm_bytes) - 4 * n_pad * n_pad // max(int(world), 1)
+    return need < free_bytes
 
 
 def predict_topk_sharded(ctx, model, dX, Kp: int, device, exclude_history: bool = False, group=None, user_chunk: int = 1 << 18, comm=None):
