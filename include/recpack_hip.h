@@ -157,6 +157,10 @@ int rphip_ctx_trim(rphip_ctx* ctx);
  *   "gemm_supertile"    0 (default) | 1.  Tile order of the GEMM's workgroups: supertiles of 64 tiles handed to the 8 XCDs round-robin
  *                       (each XCD's L2 then holds the 8 + 8 panels of an 8 x 8 block of tiles), or the plain row-major grid
  *                       (measured equal within 1 %: the products are not bound by operand traffic).
+ *   "gemm_xcd_block"    4 (default) | 0 | 1 | 2 | 8 | 16 | 32: order of the wide plane product kernel's tiles.  Workgroups are dealt to the 8 XCDs round-robin
+ *                       and an XCD (32 CUs, its own L2) runs 32 tiles at a time; with a value R > 0 those 32 tiles form a block of R tile
+ *                       rows x 32 / R tile columns, so that an XCD's L2 serves R + 32 / R operand panels per K step instead of 17 - 33 (0: the
+ *                       plain row-major grid).  Results are bit-identical.
  *   "gemm_flush_k"      K steps between two flushes of the MFMA accumulators into the compensated (hi + lo) master sums of the
  *                       EASE solve's GEMM (default 1024, a multiple of 16; a value beyond any K = plain fp32 accumulation).  Certified
  *                       column error at 50K / 100K items, l2 = 10 and 200: 512: <= 7.4e-6, 1024: <= 1.2e-5, 2048: <= 1.9e-5.

@@ -335,6 +335,9 @@ extern "C" int rphip_ctx_set_option(rphip_ctx* ctx, const char* name, int64_t va
     ctx->gemm_ws_bytes = (size_t)value;
   } else if (!strcmp(name, "gemm_supertile")) {
     ctx->gemm_supertile = value ? 1 : 0;
+  } else if (!strcmp(name, "gemm_xcd_block")) {
+    if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32) RP_FAIL(RPHIP_EINVAL, "gemm_xcd_block must be 0, 1, 2, 4, 8, 16 or 32 tile rows");
+    ctx->gemm_xcd_block = (int)value;
   } else if (!strcmp(name, "gemm_flush_k")) {
     if (value < 16 || (value % 16)) RP_FAIL(RPHIP_EINVAL, "gemm_flush_k must be a positive multiple of 16");
     ctx->gemm_kc = (int)std::min<int64_t>(value, 1 << 30);

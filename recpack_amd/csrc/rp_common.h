@@ -102,6 +102,7 @@ struct rphip_ctx {
   int pw_wt32 = 4096;        // tile width of the 32-bit sums: 2048 or 4096 (tuning)
   int gemm_mode = 2;         // operands of the solve's products: 0 fp32 MFMA (cross-check), 2 two fp16 planes (3 products; default)
   int gemm_supertile = 0;    // 1: GEMM workgroups walk the tiles in XCD-round-robin 8 x 8 supertiles (0: row-major 2-D grid)
+  int gemm_xcd_block = 4;    // k_gemm_hp16w: an XCD's 32 concurrent tiles form a block of this many tile rows x 32 / this tile columns (0: plain grid)
   int gemm_presplit = 1;     // mode 2: products with many tiles cut their operands into planes once (workspace) and run k_gemm_hp
   int gemm_wide = 1;         // the plane product kernel on 256 x 128 tiles with three LDS stages (k_gemm_hp16w) instead of 128 x 128 / two
   size_t gemm_ws_bytes = (size_t)4 << 30;  // workspace per operand of those products (sets their K chunk)

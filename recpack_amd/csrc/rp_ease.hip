@@ -570,6 +570,7 @@ struct rp_hp_args {
   int sc_shift, sc_mask;
   int b_tab;            // ... and B's is the same chunk's (B read from the same cache)
   unsigned* stamps;     // diagnostic build (-DRP_GEMM_STAMPS): per-step clock stamps of one workgroup of k_gemm_hp16w
+  int xb;               // k_gemm_hp16w: tile rows of an XCD's block of 32 tiles (0: plain 2-D grid)
 };
 
 // The same product on v_mfma_f32_16x16x32_f16 (same workspace, same LDS image: the 16-row operand of a K32 step is read from two
@@ -751,7 +752,22 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
   // fragment reads and the flush at 15 / 13 / 8 % of the kernel, ADDING UP, i.e. not hidden behind the matrix pipe)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;  // wave rows 0..3 (64 rows each), columns 0..1
-  const int tm = blockIdx.y, tn = blockIdx.x;
+  int tm = blockIdx.y, tn = blockIdx.x;
+  if (q.xb) {
+    // XCD-aware order (option gemm_xcd_block): workgroups are dealt to the 8 XCDs round-robin by their linear id and an XCD runs 32 of
+    // them at a time (one per CU).  In the plain 2-D order those 32 are 2 column tiles of 16 tile rows (T = N11 L21^T) or 32 column
+    // tiles of one row (N N^T): 17-33 operand panels per XCD and K step for 32 tiles.  Here the 32 consecutive workgroups of one
+    // XCD form a block of xb tile rows x 32 / xb tile columns (4 x 8: 12 panels), blocks go to the XCDs round-robin in row-major
+    // order - the XCDs walk the matrix side by side, top (longest K) first.
+    const unsigned L = blockIdx.x, x = L & 7u, s8 = L >> 3, beta = s8 >> 5, pp = s8 & 31u;
+    const unsigned R = (unsigned)q.xb, Cc = 32u / R;
+    const unsigned gy = (unsigned)((g.M + 255) / 256), gx = (unsigned)(g.N / GT);
+    const unsigned nbc = (gx + Cc - 1) / Cc;
+    const unsigned gb = beta * 8u + x, g_row = gb / nbc, g_col = gb - g_row * nbc;
+    tm = (int)(g_row * R + pp / Cc);
+    tn = (int)(g_col * Cc + pp % Cc);
+    if ((unsigned)tm >= gy || (unsigned)tn >= gx) return;
+  }
   const int m0 = tm * 256, n0 = tn * GT;
   const bool has_lo = m0 + GT < g.M;  // the lower 128 rows exist
   // per half: excluded by tri?  K range
@@ -1384,7 +1400,18 @@ static int rp_launch_hp16w(rphip_ctx* ctx, rp_hp_args& q, hipStream_t st) {
     RP_HIP(hipFuncSetAttribute((const void*)k_gemm_hp16w, hipFuncAttributeMaxDynamicSharedMemorySize, wide_lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_gemm_hp16w, dim3(q.g.N / GT, (unsigned)rp_cdiv(q.g.M, 256)), dim3(512), wide_lds, st, q);
+  q.xb = 0;
+  const long long gx = q.g.N / GT, gy = rp_cdiv(q.g.M, 256);
+  if (ctx->gemm_xcd_block > 0 && q.g.tri != 3 && gx * gy >= 512) {
+    int R = ctx->gemm_xcd_block;
+    while (R > 1 && 32 / R < 2 && gx >= 2) R >>= 1;
+    while (32 / R > gx && R < 32) R <<= 1;  // (narrow products: taller blocks)
+    q.xb = R;
+    const long long Cc = 32 / R, blocks = rp_cdiv(gy, R) * rp_cdiv(gx, Cc);
+    hipLaunchKernelGGL(k_gemm_hp16w, dim3((unsigned)(rp_cdiv(blocks, 8) * 8 * 32)), dim3(512), wide_lds, st, q);
+    return RPHIP_OK;
+  }
+  hipLaunchKernelGGL(k_gemm_hp16w, dim3((unsigned)gx, (unsigned)gy), dim3(512), wide_lds, st, q);
   return RPHIP_OK;
 }
 

@@ -11,6 +11,8 @@ from recpack_amd import _lib
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 ctx = _lib.Context(0)
+if os.environ.get("RECPACK_XCD_BLOCK"):
+    ctx.set_option("gemm_xcd_block", int(os.environ["RECPACK_XCD_BLOCK"]))
 dev = torch.device("cuda", 0)
 A = torch.randn((n, 16384), dtype=torch.float32, device=dev)
 C = torch.zeros((n, n), dtype=torch.float32, device=dev)
