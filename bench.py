@@ -588,11 +588,18 @@ def main():
         barrier()
         ctx.reset_timings()
         state["phase"], state["timing"] = "timed steps", True
+        # clock and power of this rank's GPU during the timed steps (a sysfs sampler thread: recpack_amd/devmon.py) - the boxes of a
+        # pool differ by several per cent on the MFMA-bound solve, and the line should say which kind of box it was measured on
+        from recpack_amd.devmon import DeviceMonitor
+
+        mon = DeviceMonitor(local_rank).start() if rank == 0 else None
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         barrier()
         elapsed = time.perf_counter() - t0
+        if mon is not None:
+            mon.stop()
         state["timing"] = False
     except Exception as e:  # noqa: BLE001 - the other ranks may be stuck in a collective this rank left: report and leave, no barrier
         dog.cancel()
@@ -673,7 +680,9 @@ def main():
                                 f"(library solve, {'own RCCL communicator' if comm is not None and comm.is_rccl else 'torch.distributed callbacks'}) + "
                                 f"predict: {keep.get('ease_predict_route', '-')}") if world > 1 else "1 GPU",
                 "generate_s": round(t_gen, 2),
-                "device": info,
+                "device": dict(info, under_load=mon.summary() if mon is not None else None,
+                               sclk_mhz_under_load=(mon.summary().get("sclk_mhz") if mon is not None else None),
+                               power_w_under_load=(mon.summary().get("power_w") if mon is not None else None)),
                 "transport_note": comm_note,
             },
             "transport": transport,  # N > 1: what the collectives of the step ran on (null at N = 1: there are none)
