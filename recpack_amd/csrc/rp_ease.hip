@@ -60,6 +60,7 @@ __device__ __forceinline__ int rp_gemm_ncol(const rp_gemm_args& g, int n0) {
 __device__ __forceinline__ bool rp_gemm_skip(const rp_gemm_args& g, int m0, int n0) {
   if (g.tri == 1) return rp_gemm_ncol(g, n0) > g.m_off + m0;
   if (g.tri == 2) return rp_gemm_ncol(g, n0) >= g.m_off + m0;
+  if (g.tri == 4) return rp_gemm_ncol(g, n0) > g.m_off + m0;  // (the wide plane product only: diagonal tiles go to g.Cd)
   return false;
 }
 
@@ -1016,14 +1017,22 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
   // stores.  One loop (load, fma, store per element) made every load wait for the store before it - the compiler cannot know that
   // the 64 addresses differ - i.e. 64 memory round trips in a row per thread: ~30 us per tile with nothing else on the CU, a fixed
   // 1.0 ms per launch at 16384^2 (tools/gemm_k_sweep.py) that cost a product with K = 2048 a fifth of its rate.
-  float* const c0p = g.C + (long long)(m0 + wr * 64 + 4 * (lane >> 4)) * g.ldc + n0 + wc * 64 + (lane & 15);
+  float* c0p = g.C + (long long)(m0 + wr * 64 + 4 * (lane >> 4)) * g.ldc + n0 + wc * 64 + (lane & 15);
+  long long ldc = g.ldc;
+  if (g.tri == 4 && rp_gemm_ncol(g, n0) == g.m_off + m0 + my * GT) {
+    // (round 5) a DIAGONAL tile of P = N N^T: the tiles of its row still read N's diagonal block, so it goes to the side stack
+    // g.Cd [tile][128][128] (copied over the diagonal afterwards) - in the same launch as the rest, on this kernel, instead of a
+    // second product on the 128 x 128 kernel (782 tiles with K up to n: 11 ms of a 100 000-item solve on their own)
+    c0p = g.Cd + (long long)((g.m_off + m0) / GT + my) * GT * GT + (long long)((wr & 1) * 64 + 4 * (lane >> 4)) * GT + wc * 64 + (lane & 15);
+    ldc = GT;
+  }
   if (g.beta != 0.0f) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = c0p[(long long)(i * 16 + r) * g.ldc + j * 16];
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = c0p[(long long)(i * 16 + r) * ldc + j * 16];
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -1043,7 +1052,7 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) c0p[(long long)(i * 16 + r) * g.ldc + j * 16] = acc[i][j][r];
+      for (int r = 0; r < 4; ++r) c0p[(long long)(i * 16 + r) * ldc + j * 16] = acc[i][j][r];
 }
 
 // C = beta * C + alpha * sum_s part[s]  (fixed order of the partial sums: deterministic)
@@ -1482,6 +1491,7 @@ int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st, float* par
   if (!st) st = ctx->stream;
   if (g.M <= 0 || g.N <= 0) return RPHIP_OK;
   if ((g.M % GT) || (g.N % GT) || (g.k0 % GBK) || (g.k1 % GBK)) RP_FAIL(RPHIP_EINVAL, "gemm_nt: sizes must be tile multiples");
+  if (g.tri == 4 && !(g.ca && g.cb)) RP_FAIL(RPHIP_EINVAL, "gemm_nt: tri = 4 is the cached N N^T product's");
   if (g.ca) return rp_gemm_nt_cached(ctx, g, st);
   const long long tiles = (long long)(g.M / GT) * (g.N / GT);
   const int klen = g.k1 - g.k0;
@@ -2099,6 +2109,11 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
     g.tri = 2;  // P is symmetric: the tiles below the diagonal (they read N on and above it, never what they write) ...
     g.alpha = 1.0f;
     g.beta = 0.0f;
+    const bool diag_inline = Kc == n_pad;  // the whole product is ONE launch of the wide kernel: its diagonal tiles go along (tri = 4)
+    if (diag_inline) {
+      g.tri = 4;
+      g.Cd = T;
+    }
     if (Kc > 0) {  // as above: K >= Kc cut per product, K < Kc (rows and columns < Kc) straight from the cache
       rp_gemm_args c = g;
       if (Kc < n_pad) {
@@ -2125,10 +2140,12 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
       iv_ev.clear();
       iv_rec();
     }
-    g.tri = 3;  // ... the diagonal tiles into the (now free) T buffer, copied over N's diagonal blocks afterwards ...
-    g.C = T;
-    g.ldc = GT;
-    RP_TRY(rp_gemm_nt(ctx, g, st));
+    if (!diag_inline) {
+      g.tri = 3;  // ... the diagonal tiles into the (now free) T buffer, copied over N's diagonal blocks afterwards ...
+      g.C = T;
+      g.ldc = GT;
+      RP_TRY(rp_gemm_nt(ctx, g, st));
+    }
     hipLaunchKernelGGL(k_copy_diag_blocks, dim3(nb), dim3(256), 0, st, T, A, ld);
     if (!lower_only) hipLaunchKernelGGL(k_mirror_lower, dim3(n_pad / 32, n_pad / 32), dim3(256), 0, st, A, ld, n_pad / 32);  // ... and the mirror
     if (itrace) {

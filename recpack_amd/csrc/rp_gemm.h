@@ -30,7 +30,9 @@ struct rp_gemm_args {
   int m_off, n_off;
   int ke_n;          // k_end = min(k1, ke_n * (n_off + n0 + 128)): B is lower triangular (row n holds columns <= n)
   int tri;           // 0: all tiles; 1: only tiles with n_off + n0 <= m_off + m0; 2: strictly below the diagonal;
-                     // 3: the diagonal tiles only (grid.x = 1), written to C as a stack of blocks [M][128] (ldc = 128)
+                     // 3: the diagonal tiles only (grid.x = 1), written to C as a stack of blocks [M][128] (ldc = 128);
+                     // 4 (the wide plane product, both operands cached): as 1, the diagonal tiles written to the stack Cd instead of C
+  float* Cd;         // tri = 4: [tile][128][128]
   float alpha, beta;
   // split-K (skinny products with few tiles and a long K): blockIdx.z = s handles K chunk s and writes its partial
   // tile to part[s][M][N] (alpha = 1, beta = 0); k_splitk_reduce applies alpha / beta to C afterwards

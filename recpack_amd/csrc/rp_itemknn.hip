@@ -254,7 +254,6 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
       constexpr int CH = RP_FIT_CH;
       RP_LDS uint32_t* own_sc = (RP_LDS uint32_t*)sel.hist + wave * 64;  // the histogram is idle here
       RP_LDS uint16_t* ft_list = (RP_LDS uint16_t*)sel.list;  // light rows: first-touch candidates
-      const uint64_t lt_mask = (1ull << lane) - 1ull;
       const int diag = row - t0;
       int n_prod = 0;
       const int stride = NW * 64;
