@@ -122,6 +122,11 @@ int rphip_ctx_trim(rphip_ctx* ctx);
  *                       98.5 % of the users of the 200K x 50K and 1M x 100K workloads; the others take the one-pass kernel) - the
  *                       results are still those of the one-pass kernel, bit for bit.  Needs "predict_half_tile" > 0; a context
  *                       that switches the option has the copy rebuilt on the next call.
+ *   "predict_user_tasks"  1 (default) | 0.  The int8 first pass with one task per USER (round 5): a workgroup walks all column tiles of a
+ *                       user, keeps a tile's sums in registers, hands the columns above a running lower bound of the user's Kc-th best
+ *                       score to ONE candidate list in LDS and cuts it to Kc entries itself - no per-tile lists, no merge kernel.  0: one
+ *                       task per (user, column tile) and a merge (round 4; also taken with an item filter, when history removal meets
+ *                       unsorted rows, and for candidate lists longer than 256).  The results are identical either way.
  *   "gemm_mode"         2 (default) | 0: how the O(n^3) products of the EASE solve (and rphip_gemm_nt_f32) multiply their fp32 operands.
  *                       2: two fp16 planes per operand, both rounded to nearest (x = h1 + h2 to 2^-24 |x|), three plane products per
  *                          step on v_mfma_f32_32x32x16_f16; each operand is scaled by a power of two taken from its largest magnitude

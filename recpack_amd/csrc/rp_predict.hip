@@ -24,6 +24,7 @@
 
 #include "rp_comm.h"
 #include "rp_common.h"
+#include "rp_predict_i8.h"
 #include "rp_select.h"
 #include "rp_wave.h"
 
@@ -676,6 +677,7 @@ __global__ void __launch_bounds__(256) k_predict_rescore(rp_rescore_params P) {
     const int u = P.user_begin + ul;
     const int hs = P.x_ptr[u], he = P.x_ptr[u + 1];
     const int nc = P.cand_nnz[ul];
+    if (nc < 0) continue;  // (the first pass per user gave this one to the fallback list itself: his candidate list overflowed)
     int col[NQ], loc[NQ];
     float e[NQ], av[NQ];
     float amin = 3.0e38f;
@@ -2030,6 +2032,111 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
     RP_TRY(rp_model_half(ctx, mm, want_i8 && Kc == kc_i8 ? 2 : 1));
     if (mm->B16) {
       const bool i8 = mm->b16_kind == 2;
+      if (i8 && ctx->predict_user_tasks && !keep_dev && Kc <= 256 && (!exclude_history || Xpred->sorted_rows)) {
+        // ---- (round 5) first pass with ONE TASK PER USER (rp_predict_i8.hip): the sums of a column tile stay in registers, a running
+        // threshold hands candidates to one list per user in LDS, the workgroup cuts it to Kc entries itself - no per-tile lists in
+        // HBM, no merge kernel, one launch for all users of the call - then the rescoring and the fallback as before
+        const size_t szA = (size_t)n * Kc;
+        const int64_t FCH = T == 1 ? n : std::min<int64_t>(n, 16384);  // users per launch of the fallback: bounds its per-tile lists
+        const size_t szF = T > 1 ? (size_t)FCH * T * Kp : 0;
+        char* sb = nullptr;
+        RP_TRY(rp_scratch(ctx, 14, (szA + szF) * 8 + (size_t)FCH * T * 4 + (size_t)n * 8 + 256, (void**)&sb));
+        int32_t* a_idx = (int32_t*)sb;
+        float* a_val = (float*)(sb + szA * 4);
+        int32_t* t_idx = (int32_t*)(sb + szA * 8);
+        float* t_val = (float*)(sb + szA * 8 + szF * 4);
+        int32_t* t_nnz = (int32_t*)(sb + (szA + szF) * 8);
+        int32_t* a_nnz = t_nnz + FCH * T;
+        int32_t* fail = a_nnz + n;
+        int32_t* n_fail = fail + n;  // [0] count, [1] the first pass's ticket
+        hipMemsetAsync(n_fail, 0, 8, st);
+        rp_i8_params U8;
+        U8.x_ptr = Xpred->x_ptr;
+        U8.x_idx = Xpred->x_idx;
+        U8.B8 = reinterpret_cast<const int8_t*>(mm->B16);
+        U8.ld = model->ld;
+        U8.b8_scale = mm->b8_scale;
+        U8.n_items = P.n_items;
+        RP_TRY(rp_predict_user_i8_geometry(P.n_items, &U8.n_tiles, &U8.tile_w));
+        U8.col_begin = P.col_begin;
+        U8.cyc_nb = P.cyc_nb;
+        U8.cyc_w = P.cyc_w;
+        U8.cyc_r = P.cyc_r;
+        U8.exclude_history = exclude_history;
+        U8.user_begin = (int)user_begin;
+        U8.n_users = (int)n;
+        U8.Kc = Kc;
+        U8.out_idx = a_idx;
+        U8.out_val = a_val;
+        U8.out_nnz = a_nnz;
+        U8.fail_list = fail;
+        U8.n_fail = n_fail;
+        U8.fail_base = 0;
+        U8.ticket = nullptr;
+        RP_TRY(rp_predict_user_i8(ctx, U8, n_fail + 1));
+        rp_rescore_params R;
+        R.x_ptr = Xpred->x_ptr;
+        R.x_idx = Xpred->x_idx;
+        R.B = model->B;
+        R.ld = model->ld;
+        R.col_begin = P.col_begin;
+        R.cyc_nb = P.cyc_nb;
+        R.cyc_w = P.cyc_w;
+        R.cyc_r = P.cyc_r;
+        R.delta = mm->b16_delta;
+        R.rowmax = mm->b16_rowmax;
+        R.cand_idx = a_idx;
+        R.cand_val = a_val;
+        R.cand_nnz = a_nnz;
+        R.user_begin = (int)user_begin;
+        R.n_users = (int)n;
+        R.Kp = Kp;
+        R.Kc = Kc;
+        R.out_idx = idx_dev;
+        R.out_val = val_dev;
+        R.out_nnz = nnz_dev;
+        R.fail_list = fail;
+        R.n_fail = n_fail;
+        R.fail_base = 0;
+        switch (Kc / 64) {
+          case 2: rp_launch_rescore<2>(ctx, R); break;
+          case 3: rp_launch_rescore<3>(ctx, R); break;
+          default: rp_launch_rescore<4>(ctx, R); break;
+        }
+        RP_HIP(hipGetLastError());
+        // the users without a proof (and those whose list overflowed): the one-pass kernel, as few launches as their lists allow
+        const size_t lds1 = rp_pred_lds(P);
+        RP_HIP(hipFuncSetAttribute((const void*)k_predict_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        const size_t mlds_p = (size_t)T * Kp * 8 + rp_select_smem_bytes(T * Kp);
+        if (T > 1) {
+          if (mlds_p > 160 * 1024 || T * Kp >= RPS_FLAG) RP_FAIL(RPHIP_ELIMIT, "Kp=%d with %d column tiles needs %zu bytes of LDS for the merge", Kp, T, mlds_p);
+          RP_HIP(hipFuncSetAttribute((const void*)k_predict_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds_p));
+        }
+        int h_fail = 0;
+        RP_HIP(hipMemcpyAsync(&h_fail, n_fail, 4, hipMemcpyDeviceToHost, st));
+        RP_HIP(hipStreamSynchronize(st));
+        for (int64_t f0 = 0; f0 < h_fail; f0 += FCH) {
+          const int64_t nf = std::min<int64_t>(FCH, h_fail - f0);
+          const int grid = (int)std::min<int64_t>(nf * T, (int64_t)ctx->n_cu * 8), mgrid = (int)std::min<int64_t>(nf, (int64_t)ctx->n_cu * 8);
+          rp_pred_params F = P;
+          F.user_begin = (int)user_begin;
+          F.n_users = (int)nf;
+          F.user_list = fail + f0;
+          F.n_list = nullptr;
+          F.list_compact = 1;
+          if (T > 1) hipMemsetAsync(t_nnz, 0, (size_t)nf * T * 4, st);
+          F.out_idx = T > 1 ? t_idx : idx_dev;
+          F.out_val = T > 1 ? t_val : val_dev;
+          F.out_nnz = T > 1 ? t_nnz : nnz_dev;
+          hipLaunchKernelGGL(k_predict_tile<true>, dim3(grid), dim3(RP_PRED_THREADS), lds1, st, F);
+          if (T > 1)
+            hipLaunchKernelGGL(k_predict_merge, dim3(mgrid), dim3(RP_PRED_THREADS), mlds_p, st, t_idx, t_val, t_nnz, T, Kp, (int)nf, fail + f0, nullptr,
+                               idx_dev, val_dev, nnz_dev, 0, 0, 1);
+          RP_HIP(hipGetLastError());
+        }
+        rp_time_end(ctx, ev, RPHIP_T_PREDICT_DENSE, rp_pred_work(Xpred, model, n, Kp));
+        return RPHIP_OK;
+      }
       const bool narrow = fits2 && (i8 || Th != T || Wh != P.tile_w);
       if (!fits2) {
         Th = T;

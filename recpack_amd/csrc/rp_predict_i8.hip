@@ -1,0 +1,320 @@
+// K9, first pass of the two-pass predict on the int8 copy of B - ONE TASK PER USER (round 5).
+//
+// Replaces, with rp_predict.hip's rescoring, ItemSimilarityMatrixAlgorithm._predict for dense models (recpack/algorithms/base.py:248,
+// `X @ similarity_matrix_`) followed by the per-user top-K of MetricTopK (recpack/metrics/base.py:189).
+//
+// Round 4's first pass made (user, column tile) the task of a workgroup: every task wrote its sums to an LDS tile, found a lower bound
+// of the tile's Kc-th best score, handed every column above it to a per-(user, tile) list in HBM, and a merge kernel then cut the
+// user's T lists to Kc candidates for the rescoring.  Kernel time at 1M x 100K: 0.89 s for a stream that alone runs in 0.66 s -
+// 0.23 s of per-(user, tile) selection and start-up - plus 0.07 s of merges.
+//
+// Here a workgroup owns a USER and walks his column tiles one after the other:
+//   * the sums of a tile stay in the registers they were accumulated in (16 columns per thread, no LDS tile: tiles are 16 384
+//     columns wide whatever the LDS allows, 7 instead of 9 at 100 000 items);
+//   * a running threshold tau - a lower bound of the user's Kc-th best approximate score - decides from the registers which columns
+//     are candidates; they are appended to ONE list per user in LDS (a rare branch: ~2 % of the threads of a tile have one).  The
+//     first tile finds tau as round 4 did (every thread's best score, of those the R-th best of every wave: R x waves >= Kc columns
+//     reach it); whenever the list passes half its capacity it is cut to its Kc best entries and tau rises to the smallest of them;
+//   * after the last tile the list is cut to Kc entries and written as the rescoring's input: no per-tile lists, no merge kernel,
+//     no barrier per tile but one.
+// Every column the list drops lies below Kc columns that stay, so the list ends as the user's Kc best columns by approximate
+// score - what the merge produced - and the rescoring's proof (k_predict_rescore) is unchanged.  A user whose list overflows (a
+// model of few distinct values: everything ties) goes to the fallback list that the one-pass kernel serves, like an unproven one.
+#include <algorithm>
+
+#include "rp_common.h"
+#include "rp_predict_i8.h"
+#include "rp_select.h"
+#include "rp_wave.h"
+
+constexpr int RPU_THREADS = 1024;
+constexpr int RPU_CAP = 2048;    // entries of a user's candidate list in LDS
+constexpr int RPU_PRUNE = 1024;  // the list is cut to Kc entries when it holds more than this after a tile
+constexpr int RPU_KC_MAX = 256;
+constexpr int RPU_HIST = 2048;   // history items kept in LDS for the membership test of history removal (longer histories: searched in memory)
+
+struct rpu_list_src {
+  const int32_t* col_;
+  const float* val_;
+  int n;
+  __device__ __forceinline__ bool valid(int w) const { return w < n; }
+  __device__ __forceinline__ uint64_t key(int w) const {
+    uint32_t b = __float_as_uint(val_[w]);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return (uint64_t)b << 32;
+  }
+  __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)col_[w]; }
+};
+
+__device__ __forceinline__ int rpu_l2g(const rp_i8_params& P, int l) {
+  return P.cyc_nb ? rp_cyc_panel(l / P.cyc_nb, P.cyc_r, P.cyc_w) * P.cyc_nb + l % P.cyc_nb : P.col_begin + l;
+}
+
+// is item g in the (ascending) history h[0, n) ?
+template <class Ptr>
+__device__ __forceinline__ bool rpu_in_history(Ptr h, int n, int g) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int m = (lo + hi) >> 1;
+    const int v = h[m];
+    if (v == g) return true;
+    if (v < g) lo = m + 1; else hi = m;
+  }
+  return false;
+}
+
+__global__ void __launch_bounds__(RPU_THREADS, 8) k_predict_user_i8(rp_i8_params P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // (explicit LDS pointers: generic ones kept in structs compile to FLAT accesses whose waits drain the global loads in flight)
+  RP_LDS int32_t* lcol = (RP_LDS int32_t*)smem;                             // [CAP]
+  RP_LDS float* lval = (RP_LDS float*)(smem + (size_t)RPU_CAP * 4);         // [CAP]
+  RP_LDS int32_t* tcol = (RP_LDS int32_t*)(smem + (size_t)RPU_CAP * 8);     // [KC_MAX]
+  RP_LDS float* tval = (RP_LDS float*)(smem + (size_t)RPU_CAP * 8 + (size_t)RPU_KC_MAX * 4);
+  RP_LDS int32_t* s_hist = (RP_LDS int32_t*)(smem + (size_t)RPU_CAP * 8 + (size_t)RPU_KC_MAX * 8);  // [HIST]
+  char* sel_base = smem + (size_t)RPU_CAP * 8 + (size_t)RPU_KC_MAX * 8 + (size_t)RPU_HIST * 4;
+  rp_select_smem sel = rp_select_carve(sel_base, RPU_CAP);
+  RP_LDS int* s_cnt = (RP_LDS int*)&sel.misc[RPS_USER];                    // [0] list entries, [1] history items inside the tile, [2] next user
+  RP_LDS float* s_tau = (RP_LDS float*)&sel.misc[RPS_USER + 8];            // [16]
+  const int32_t* lcol_g = reinterpret_cast<const int32_t*>(smem);          // (the selection's source takes generic pointers)
+  const float* lval_g = reinterpret_cast<const float*>(smem + (size_t)RPU_CAP * 4);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = RPU_THREADS / 64;
+  const int W = P.tile_w, T = P.n_tiles, Kc = P.Kc;
+
+  typedef int rp_i4 __attribute__((ext_vector_type(4)));
+  // One 32-bit word at a time - four sign-extending byte conversions and four fmas - and the words strictly in order: the empty asm
+  // statements tie each word to the sums the previous one wrote (left to itself the compiler converts all 64 bytes of the four rows
+  // first and spills: two workgroups per CU leave a thread 64 registers).
+  auto add16 = [&](float(&acc)[16], const rp_i4& v, float sc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int wd = 0; wd < 4; ++wd) {
+      unsigned w = (unsigned)v[wd];
+      if (wd == 0)
+        asm volatile("" : "+v"(w), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]));
+      else
+        asm volatile("" : "+v"(w), "+v"(acc[4 * wd - 4]), "+v"(acc[4 * wd - 3]), "+v"(acc[4 * wd - 2]), "+v"(acc[4 * wd - 1]));
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[4 * wd + b] = fmaf((float)(int)(int8_t)(w >> (8 * b)), sc, acc[4 * wd + b]);
+    }
+  };
+
+  while (true) {
+    // ---- next user (a ticket: histories differ by two orders of magnitude)
+    __syncthreads();
+    if (tid == 0) {
+      s_cnt[2] = atomicAdd(P.ticket, 1);
+      s_cnt[0] = 0;
+    }
+    __syncthreads();
+    const int ul = s_cnt[2];
+    if (ul >= P.n_users) break;
+    const int u = P.user_begin + ul;
+    const int hs = P.x_ptr[u], he = P.x_ptr[u + 1];
+    if (he <= hs) {  // no history: no score
+      if (tid == 0) P.out_nnz[ul] = 0;
+      continue;
+    }
+    float tau = -INFINITY;
+    bool have_tau = false, failed = false;
+    const bool hist_lds = P.exclude_history && he - hs <= RPU_HIST;
+    if (hist_lds)  // (visible behind the first tile's barrier, long before the first candidate)
+      for (int k = tid; k < he - hs; k += RPU_THREADS) s_hist[k] = P.x_idx[hs + k];
+
+    for (int tile = 0; tile < T; ++tile) {
+      const int t0 = tile * W;
+      const int n_cols = min(W, P.n_items - t0);
+      const int w16 = (n_cols + 15) >> 4;  // (reads past n_cols stay inside the padded row: its length is a multiple of 64)
+      const bool active = tid < w16;
+      // ---- accumulate: sixteen consecutive columns per 16-byte load, four rows in flight
+      float r[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) r[e] = 0.0f;
+      constexpr int RIF = 4;
+      typedef const __attribute__((address_space(1))) int8_t* rp_gptr;  // (a GLOBAL pointer: rebuilt from an integer it would be a flat one)
+      int h = hs;
+      for (; h + RIF - 1 < he; h += RIF) {
+        rp_gptr R[RIF];
+        float sc[RIF];
+#pragma unroll
+        for (int q = 0; q < RIF; ++q) {
+          const int it = __builtin_amdgcn_readfirstlane(P.x_idx[h + q]);  // (uniform: the row's base and its scale in scalar registers)
+          const unsigned long long rb = reinterpret_cast<unsigned long long>(P.B8 + (long long)it * P.ld + t0);
+          R[q] = (rp_gptr)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rb >> 32)) << 32) |
+                           (unsigned)__builtin_amdgcn_readfirstlane((int)rb));
+          sc[q] = P.b8_scale[it];
+        }
+        rp_i4 v[RIF];
+        if (active) {
+#pragma unroll
+          for (int q = 0; q < RIF; ++q)  // (scalar base + 32-bit offset: no address registers)
+            v[q] = *reinterpret_cast<const __attribute__((address_space(1))) rp_i4*>(R[q] + (unsigned)(16 * tid));
+        } else {
+#pragma unroll
+          for (int q = 0; q < RIF; ++q) v[q] = (rp_i4){0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int q = 0; q < RIF; ++q) add16(r, v[q], sc[q]);
+      }
+      for (; h < he; ++h) {
+        const int it = __builtin_amdgcn_readfirstlane(P.x_idx[h]);
+        const int8_t* R0 = P.B8 + (long long)it * P.ld + t0;
+        const float sc0 = P.b8_scale[it];
+        if (active) add16(r, *reinterpret_cast<const rp_i4*>(R0 + 16 * tid), sc0);
+      }
+      // (columns past the tile's end and zero sums are no candidates)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (!active || 16 * tid + e >= n_cols) r[e] = 0.0f;
+
+      if (!have_tau) {
+        // ---- a lower bound of the Kc-th best score: every thread's best, of those the R-th best of every wave that owns columns.
+        // With history removal the best columns may be history items (dropped when they are appended): as many more are counted.
+        int n_hist = P.exclude_history ? he - hs : 0;  // (short histories: all of them counted - no pass, no barrier)
+        if (P.exclude_history && he - hs > 128) {
+          if (tid == 0) s_cnt[1] = 0;
+          __syncthreads();
+          int c = 0;
+          for (int k = hs + tid; k < he; k += RPU_THREADS) {
+            int g = P.x_idx[k], l;
+            if (P.cyc_nb) {
+              const int p = g / P.cyc_nb;
+              l = (rp_cyc_owner(p, P.cyc_w) == P.cyc_r) ? (p / P.cyc_w) * P.cyc_nb + g % P.cyc_nb : -1;
+            } else {
+              l = g - P.col_begin;
+            }
+            c += ((unsigned)(l - t0) < (unsigned)n_cols) ? 1 : 0;
+          }
+          c = rp_wave_sum(c);
+          if (lane == 0 && c) atomicAdd((int*)&s_cnt[1], c);
+          __syncthreads();
+          n_hist = s_cnt[1];
+        }
+        const int nwa = (w16 + 63) >> 6;  // waves that own columns of this tile
+        const int R = (Kc + n_hist + nwa - 1) / nwa;
+        float m = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (r[e] != 0.0f) m = fmaxf(m, r[e]);
+        float rth = -INFINITY;
+        if (wave < nwa && R <= 64) {
+          for (int it = 0; it < R; ++it) {
+            float mx = m;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+            rth = mx;
+            const unsigned long long hit = __ballot(m == mx);
+            if (lane == __ffsll((long long)hit) - 1) m = -INFINITY;
+          }
+        }
+        if (lane == 0) s_tau[wave] = (wave < nwa) ? rth : INFINITY;
+        __syncthreads();
+        float t = s_tau[0];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) t = fminf(t, s_tau[q]);
+        if (t > -INFINITY && t < INFINITY) {  // (fewer than R scores in some wave: this tile hands on everything, the next one tries again)
+          tau = t;
+          have_tau = true;
+        }
+      }
+      // ---- the candidates of this tile, from the registers
+      {
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) any |= (r[e] != 0.0f && r[e] >= tau);
+        if (any) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float v = r[e];
+            if (v != 0.0f && v >= tau) {
+              const int g = rpu_l2g(P, t0 + 16 * tid + e);
+              if (!P.exclude_history || !(hist_lds ? rpu_in_history(s_hist, he - hs, g) : rpu_in_history(P.x_idx + hs, he - hs, g))) {
+                const int pos = atomicAdd((int*)&s_cnt[0], 1);
+                if (pos < RPU_CAP) {
+                  lcol[pos] = g;
+                  lval[pos] = v;
+                }
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+      const int n = s_cnt[0];
+      if (n > RPU_CAP) {  // (more candidates than the list holds - scores that tie by the thousand: the exact pass serves this user)
+        failed = true;
+        break;
+      }
+      const bool last = tile == T - 1;
+      if (n > RPU_PRUNE || last) {
+        // ---- the list's Kc best entries; they become the list (and its smallest entry the threshold), or - after the last tile - the
+        // rescoring's candidates
+        rpu_list_src src{lcol_g, lval_g, n};
+        const int kp = rp_select_topk<RPU_THREADS>(src, n, Kc, sel);
+        if (last) {
+          const long long o = (long long)ul * Kc;
+          rp_select_emit<RPU_THREADS>(n, sel, [&](int pos, int w) {
+            P.out_idx[o + pos] = lcol[w];
+            P.out_val[o + pos] = lval[w];
+          });
+          if (tid == 0) P.out_nnz[ul] = kp;
+        } else {
+          rp_select_emit<RPU_THREADS>(n, sel, [&](int pos, int w) {
+            tcol[pos] = lcol[w];
+            tval[pos] = lval[w];
+          });
+          __syncthreads();
+          float mn = INFINITY;
+          if (tid < kp) {
+            lcol[tid] = tcol[tid];
+            mn = lval[tid] = tval[tid];
+          }
+          if (tid < RPU_KC_MAX) {  // (the waves that hold entries)
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) mn = fminf(mn, __shfl_xor(mn, d));
+            if (lane == 0) s_tau[wave] = mn;
+          }
+          if (tid == 0) s_cnt[0] = kp;
+          __syncthreads();
+          if (kp == Kc) {
+            float t = s_tau[0];
+#pragma unroll
+            for (int q = 1; q < RPU_KC_MAX / 64; ++q) t = fminf(t, s_tau[q]);
+            tau = fmaxf(tau, t);
+            have_tau = true;
+          }
+        }
+      }
+    }
+    if (failed && tid == 0) {
+      P.out_nnz[ul] = -1;  // (the rescoring skips this user)
+      P.fail_list[atomicAdd(P.n_fail, 1)] = P.fail_base + ul;
+    }
+  }
+}
+
+size_t rp_predict_user_i8_lds() { return (size_t)RPU_CAP * 8 + (size_t)RPU_KC_MAX * 8 + (size_t)RPU_HIST * 4 + rp_select_smem_bytes(RPU_CAP); }
+
+int rp_predict_user_i8_geometry(int64_t n_cols, int* n_tiles, int* tile_w) {
+  // sixteen columns per thread: at most 16 384 per tile; tiles of equal width, a multiple of 64 (the rows' padding)
+  const int64_t T = std::max<int64_t>(1, rp_cdiv(n_cols, 16 * RPU_THREADS));
+  *n_tiles = (int)T;
+  *tile_w = (int)(rp_cdiv(rp_cdiv(n_cols, T), 64) * 64);
+  return RPHIP_OK;
+}
+
+int rp_predict_user_i8(rphip_ctx* ctx, const rp_i8_params& P0, int32_t* ticket_dev) {
+  if (P0.Kc < 1 || P0.Kc > RPU_KC_MAX) RP_FAIL(RPHIP_ELIMIT, "first pass per user: Kc = %d outside 1..%d", P0.Kc, RPU_KC_MAX);
+  rp_i8_params P = P0;
+  P.ticket = ticket_dev;
+  const size_t lds = rp_predict_user_i8_lds();
+  static bool attr_set = false;
+  if (!attr_set) {
+    RP_HIP(hipFuncSetAttribute((const void*)k_predict_user_i8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  RP_HIP(hipMemsetAsync(ticket_dev, 0, 4, ctx->stream));
+  const int grid = (int)std::min<int64_t>(P.n_users, (int64_t)ctx->n_cu * 2);
+  hipLaunchKernelGGL(k_predict_user_i8, dim3(grid), dim3(RPU_THREADS), lds, ctx->stream, P);
+  RP_HIP(hipGetLastError());
+  return RPHIP_OK;
+}

@@ -112,7 +112,39 @@ def test_itemknn_c4_full_size(hip):
 EASE_TOL = 1e-4  # BASELINE.json north_star: EASE scores within 1e-4 relative (the reference inverts in float64, ease.py:82)
 
 
-def ease_full_size(hip, cfg, n_cols, n_users, l2=200.0, alpha=0.0):
+def routes_agree_for_all_users(hip, m, dX, n_route_users, Kp=100):
+    """The route the bench times for K9 - first pass on int8 rows for ALL users of the call (several column tiles, and, until round 5,
+    several 65 536-user chunks whose unproven users meet in ONE fallback pass), exact rescoring, proof, fallback - against the
+    one-pass kernel on the same users: index sets, order and the f32 bits of every score."""
+    import torch
+
+    _lib, ctx = hip
+    dev = torch.device("cuda", 0)
+    U = dX.shape[0]
+    n = min(U, n_route_users)
+    u0 = (U - n) // 2
+    out = []
+    try:
+        for half in (1, 0):
+            ctx.set_option("predict_half", half)
+            oi = torch.empty((n, Kp), dtype=torch.int32, device=dev)
+            ov = torch.empty((n, Kp), dtype=torch.float32, device=dev)
+            on = torch.empty((n,), dtype=torch.int32, device=dev)
+            for excl in (False, True):
+                _lib.predict_topk_dev(ctx, m, dX, Kp, oi, ov, on, exclude_history=excl, user_begin=u0, user_end=u0 + n)
+                ctx.sync()
+                out.append((excl, oi.clone(), ov.clone().view(torch.int32), on.clone()))
+    finally:
+        ctx.set_option("predict_half", 1)
+    for (e1, i1, v1, n1), (e0, i0, v0, n0) in zip(out[:2], out[2:]):
+        assert e1 == e0
+        assert torch.equal(n1, n0), f"exclude_history={e1}: row lengths differ for {int((n1 != n0).sum())} of {n} users"
+        assert torch.equal(i1, i0), f"exclude_history={e1}: index rows differ for {int((i1 != i0).any(dim=1).sum())} of {n} users"
+        assert torch.equal(v1, v0), f"exclude_history={e1}: score bits differ for {int((v1 != v0).any(dim=1).sum())} of {n} users"
+    assert int(out[0][3].max()) == Kp
+
+
+def ease_full_size(hip, cfg, n_cols, n_users, l2=200.0, alpha=0.0, n_route_users=0):
     """EASE at a size no host can invert: sampled columns of B (popular, median and random items) against float64
     columns that the host CERTIFIES (tests/ease_cg.py: conjugate gradients for (X^T X + lambda I) p = e_j, then the float64
     residual on the host bounds the distance to the exact solution), per column
@@ -156,6 +188,8 @@ def ease_full_size(hip, cfg, n_cols, n_users, l2=200.0, alpha=0.0):
         t = np.sort(sc[sc != 0])[::-1][n - 1]
         assert (sc[got] >= t - 2e-6 * np.abs(sc).max()).all()
     del B
+    if n_route_users:
+        routes_agree_for_all_users(hip, m, dX, n_route_users, Kp)
     m.close()
     dX.close()
     ctx.trim()
@@ -163,7 +197,7 @@ def ease_full_size(hip, cfg, n_cols, n_users, l2=200.0, alpha=0.0):
 
 
 def test_ease_c3_full_size(hip):
-    ease_full_size(hip, "C3", n_cols=(16, 8, 8), n_users=48)
+    ease_full_size(hip, "C3", n_cols=(16, 8, 8), n_users=48, n_route_users=200_000)  # all 200 000 users through both routes
 
 
 @pytest.mark.parametrize("l2,alpha", [(10.0, 0.0), (1000.0, 0.5)])
@@ -180,7 +214,7 @@ def test_ease_c4_full_size_l2_10(hip):
 
 def test_ease_c4_full_size(hip):
     """The metric's own matrix (1M x 100K, 40 GB of B)."""
-    ease_full_size(hip, "C4", n_cols=(16, 8, 8), n_users=48)
+    ease_full_size(hip, "C4", n_cols=(16, 8, 8), n_users=48, n_route_users=300_000)  # 300 000 users through both routes
 
 
 def test_ease_c5_full_size(hip):
