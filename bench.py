@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--ease-transport", default="auto", choices=["auto", "rccl", "torch"],
                     help="N > 1: collectives of the distributed EASE solve - the library's own RCCL communicator (auto with the nccl "
                          "backend) or callbacks through torch.distributed")
+    ap.add_argument("--selftest", action="store_true", help="N = 1: run the transport self-test on a one-rank RCCL communicator too (N > 1: always)")
     ap.add_argument("--timeout", type=float, default=1500.0,
                     help="seconds the timed region (warm-up + steps) may take; past it every rank prints what it has with status "
                          "'timeout' and exits with code 3")
@@ -502,6 +503,34 @@ def main():
         if comm is None:
             comm = rdist.make_comm(ctx, device, transport="torch")
         transport = "rccl (library communicator)" if comm.is_rccl else "torch.distributed callbacks" + (f" (FALLBACK: {comm_note})" if comm_note else "")
+    # Transport self-test BEFORE the warm-up (N > 1; N = 1 with --selftest): each of the four operations once on a known pattern,
+    # every received word checked on the device, 30 s of watchdog per operation - a hang or a wrong byte is reported by NAME with a
+    # non-zero exit code instead of a solve that waits for ever in its first pivot (the RCCL transport had never run with more than
+    # one rank when this was written: the pool leases single-GPU boxes).
+    selftest = None
+    if world > 1 or args.selftest:
+        st_comm = comm if comm is not None else rdist.make_comm(ctx, device, transport="rccl")
+
+        def hang(name):
+            if rank == 0:
+                print(json.dumps({"metric": "fit+predict wall-sec (ItemKNN, EASE) on 1M×100K synth; achieved HBM GB/s", "n_gpus": world,
+                                  "status": f"failed: transport self-test: {name} did not complete within 30 s", "transport": transport,
+                                  "transport_selftest": {"ok": False, "hung": name}}), flush=True)
+            os._exit(6)
+
+        selftest = st_comm.selftest(words=1 << 18, watchdog_s=30.0, on_hang=hang)
+        if world > 1:  # (everybody must agree before anybody goes on)
+            okt = torch.tensor([1 if selftest["ok"] else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            selftest["ok_all_ranks"] = bool(int(okt.item()))
+        if comm is None:
+            st_comm.close()
+        if not selftest.get("ok_all_ranks", selftest["ok"]):
+            if rank == 0:
+                print(json.dumps({"metric": "fit+predict wall-sec (ItemKNN, EASE) on 1M×100K synth; achieved HBM GB/s", "n_gpus": world,
+                                  "status": "failed: transport self-test: " + ", ".join(f"{k}: {v['mismatches']} wrong words" for k, v in selftest["ops"].items() if v["mismatches"]),
+                                  "transport": transport, "transport_selftest": selftest}), flush=True)
+            os._exit(6)
 
     keep = {}
     parts = {"itemknn": 0.0, "ease_fit": 0.0, "ease_predict": 0.0}
@@ -686,6 +715,7 @@ def main():
                 "transport_note": comm_note,
             },
             "transport": transport,  # N > 1: what the collectives of the step ran on (null at N = 1: there are none)
+            "transport_selftest": selftest,  # N > 1 (or --selftest): the four operations checked before the warm-up
             "phases_ms_per_step": phases,
             "throughput": {
                 "interactions_per_s": round(nnz / sec_per_step, 1),

@@ -439,17 +439,17 @@ typedef struct rphip_comm_ops {
 int rphip_comm_rccl_unique_id(void* id_out /* RPHIP_COMM_ID_BYTES */);
 int rphip_comm_rccl_create(rphip_ctx* ctx, int32_t world, int32_t rank, const void* id, rphip_comm** out);
 int rphip_comm_from_ops(rphip_ctx* ctx, const rphip_comm_ops* ops, rphip_comm** out);
-/* A LOOP-BACK communicator for measuring ONE rank of a `world`-rank run on a single GPU (tools/dist_rank_emulate.py): every
- * operation is stream-ordered and asynchronous like the RCCL ones, moves no data between ranks - what a rank would receive is
- * filled with its own data or small noise of the right size - and holds its stream for latency_us + bytes / gbytes_per_s, where
- * gbytes_per_s is the rate of ONE link of a fully connected node (xGMI: every pair of GPUs has its own) and bytes what the busiest
- * link carries: a broadcast its whole message, an all-gather one rank's part, an exchange the largest piece to or from one peer.
- * The results of a run on it are meaningless; its kernel sequence, launch for launch, is rank `rank`'s.  The reference has no multi-GPU path (recpack/algorithms/base.py:454-455 TODO). */
-int rphip_comm_loopback_create(rphip_ctx* ctx, int32_t world, int32_t rank, double gbytes_per_s, double latency_us, rphip_comm** out);
 int rphip_comm_destroy(rphip_comm* comm);
 int rphip_comm_info(const rphip_comm* comm, int32_t* world, int32_t* rank, int32_t* is_rccl);
 /* int32 sum over the ranks of a device vector, in place (the item degrees of a sharded K0: rphip_csr_degrees_device) */
 int rphip_comm_all_reduce_sum_i32(rphip_ctx* ctx, rphip_comm* comm, int32_t* buf_dev, int64_t count);
+/* Self-test of a communicator, ONE operation per call: op 0 = broadcast (from the last rank), 1 = all-gather, 2 = personalised
+ * exchange, 3 = int32 all-reduce, on `words` int32 per rank (per piece for the exchange).  The operation runs once on the context's
+ * stream on a known pattern, the call waits for it and checks every received word on the device: *mismatches = words that differ
+ * (0 = works), *ms = its wall time.  Every rank must make the same calls.  A transport that hangs hangs HERE, in a call that names
+ * the operation: put a watchdog around it (bench.py --gpus N does, 30 s per operation, before its warm-up) rather than find out
+ * in the first pivot of a solve.  The reference has no multi-GPU path (recpack/algorithms/base.py:454-455). */
+int rphip_comm_selftest(rphip_ctx* ctx, rphip_comm* comm, int32_t op, int64_t words, int64_t* mismatches, double* ms);
 
 /* Multi-GPU ItemKNN fit: every rank has fitted the item rows [row_bounds[r], row_bounds[r + 1]) (rphip_itemknn_fit* with a row
  * range; row_bounds has world + 1 entries, 0 .. n_items); the shards are exchanged with ONE all-gather through the communicator
@@ -494,19 +494,6 @@ int rphip_predict_topk_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip_model*
  * (every pair of rounds gives every rank the same share of the lower triangle), item = that panel * panel + l % panel.  Otherwise
  * col_begin + l.  n_local_cols of the local columns are items (the rest is padding). */
 int rphip_model_dense_layout(const rphip_model* m, int64_t* n_local_cols, int64_t* panel, int32_t* world, int32_t* rank, int64_t* col_begin);
-/* numbers of the last rphip_ease_fit_dist on this context: [0] slab bytes, [1] peak bytes of everything else the fit held
- * (panel buffers, staging, plane workspaces), [2] bytes received through the communicator, [3] bytes sent, [4] pivots,
- * [5] panel width, [6] n_pad, [7] flop of the rank's products */
-int rphip_ease_fit_dist_stats(rphip_ctx* ctx, int64_t* out8);
-
-/* Cholesky factor (lower) of a 128 x 128 block in place and its inverse into W (ld 128), in float64 internally;
- * *info_dev (device int32) receives pivot + 1 if the block is not positive definite. */
-int rphip_potrf_trtri_128(rphip_ctx* ctx, float* A_dev, int64_t lda, float* W_dev, int32_t* info_dev);
-/* rphip_gemm_nt_f32 with per-tile K clipping for triangular operands (see rp_ease.hip). */
-int rphip_gemm_nt_f32_ex(rphip_ctx* ctx, int64_t M, int64_t N, int64_t k_begin, int64_t k_end, float alpha, const float* A_dev,
-                         int64_t lda, const float* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc, int32_t k_from_row,
-                         int32_t k_from_col, int64_t m_off, int64_t n_off, int32_t lower_only);
-
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,44 @@
+/* recpack_hip_diag.h - measuring instruments and test hooks of librecpack_hip.so.
+ *
+ * NOT part of the drop-in boundary (include/recpack_hip.h): nothing here stands for a function of the reference; recpack_amd's
+ * estimators never call these.  They are exported by the same library so that tools/ and tests/ can reach single building blocks:
+ *   rphip_comm_loopback_create   one rank of an N-rank run measured alone on one GPU (tools/dist_rank_emulate.py)
+ *   rphip_ease_fit_dist_stats    byte / flop counters of the last distributed fit (tests: memory bound of the sharded solve)
+ *   rphip_potrf_trtri_128        the 128 x 128 diagonal-block kernel alone (tools/potrf_check.py, tests/test_gpu_ease.py)
+ *   rphip_gemm_nt_f32_ex         the NT product with the triangular K clipping of the solve (tests/test_gpu_ease.py)
+ * The environment switches RP_CHOL_TRACE, RP_INV_TRACE, RP_CHOL_MEASURE_SCALES, RP_N22_PLANES, RP_EASE_SCALE_ROWS, RP_K9_I8_KC
+ * exist only in the diagnostic build (make -C recpack_amd/csrc diag -> librecpack_hip_diag.so, selected with RECPACK_HIP_LIB).
+ */
+#ifndef RECPACK_HIP_DIAG_H
+#define RECPACK_HIP_DIAG_H
+#include "recpack_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* A LOOP-BACK communicator for measuring ONE rank of a `world`-rank run on a single GPU (tools/dist_rank_emulate.py): every
+ * operation is stream-ordered and asynchronous like the RCCL ones, moves no data between ranks - what a rank would receive is
+ * filled with its own data or small noise of the right size - and holds its stream for latency_us + bytes / gbytes_per_s, where
+ * gbytes_per_s is the rate of ONE link of a fully connected node (xGMI: every pair of GPUs has its own) and bytes what the busiest
+ * link carries: a broadcast its whole message, an all-gather one rank's part, an exchange the largest piece to or from one peer.
+ * The results of a run on it are meaningless; its kernel sequence, launch for launch, is rank `rank`'s.  The reference has no multi-GPU path (recpack/algorithms/base.py:454-455 TODO). */
+int rphip_comm_loopback_create(rphip_ctx* ctx, int32_t world, int32_t rank, double gbytes_per_s, double latency_us, rphip_comm** out);
+
+/* numbers of the last rphip_ease_fit_dist on this context: [0] slab bytes, [1] peak bytes of everything else the fit held
+ * (panel buffers, staging, plane workspaces), [2] bytes received through the communicator, [3] bytes sent, [4] pivots,
+ * [5] panel width, [6] n_pad, [7] flop of the rank's products */
+int rphip_ease_fit_dist_stats(rphip_ctx* ctx, int64_t* out8);
+
+/* Cholesky factor (lower) of a 128 x 128 block in place and its inverse into W (ld 128), in float64 internally;
+ * *info_dev (device int32) receives pivot + 1 if the block is not positive definite. */
+int rphip_potrf_trtri_128(rphip_ctx* ctx, float* A_dev, int64_t lda, float* W_dev, int32_t* info_dev);
+/* rphip_gemm_nt_f32 with per-tile K clipping for triangular operands (see rp_ease.hip). */
+int rphip_gemm_nt_f32_ex(rphip_ctx* ctx, int64_t M, int64_t N, int64_t k_begin, int64_t k_end, float alpha, const float* A_dev,
+                         int64_t lda, const float* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc, int32_t k_from_row,
+                         int32_t k_from_col, int64_t m_off, int64_t n_off, int32_t lower_only);
+
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECPACK_HIP_DIAG_H */

@@ -109,23 +109,27 @@ PROTOTYPES = {
     "rphip_ease_xy_fit": (C.c_int, [_p, _p, _p, _f64, _f64, _pp]),
     "rphip_ease_gram_create": (C.c_int, [_p, _p, _pp]),
     "rphip_ease_fit_gram": (C.c_int, [_p, _p, _p, _f64, _f64, _pp]),
-    "rphip_potrf_trtri_128": (C.c_int, [_p, _p, _i64, _p, _p]),
-    "rphip_gemm_nt_f32_ex": (C.c_int, [_p, _i64, _i64, _i64, _i64, C.c_float, _p, _i64, _p, _i64, C.c_float, _p, _i64, _i32, _i32, _i64, _i64, _i32]),
     "rphip_model_from_dense_cols": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64, _pp]),
     "rphip_predict_merge_topk": (C.c_int, [_p, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p]),
     "rphip_comm_rccl_unique_id": (C.c_int, [_p]),
     "rphip_comm_rccl_create": (C.c_int, [_p, _i32, _i32, _p, _pp]),
     "rphip_comm_from_ops": (C.c_int, [_p, _p, _pp]),
-    "rphip_comm_loopback_create": (C.c_int, [_p, _i32, _i32, C.c_double, C.c_double, _pp]),
     "rphip_ease_model_allgather": (C.c_int, [_p, _p, _p, _i64, _i64, _pp]),
     "rphip_comm_destroy": (C.c_int, [_p]),
     "rphip_comm_info": (C.c_int, [_p, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "rphip_comm_all_reduce_sum_i32": (C.c_int, [_p, _p, _p, _i64]),
     "rphip_ease_fit_dist": (C.c_int, [_p, _p, _p, _f64, _f64, _i32, _pp]),
     "rphip_model_dense_layout": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64)]),
-    "rphip_ease_fit_dist_stats": (C.c_int, [_p, _p]),
     "rphip_itemknn_gather": (C.c_int, [_p, _p, _p, _p, _pp]),
     "rphip_predict_topk_dist": (C.c_int, [_p, _p, _p, _p, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64), _p, _p, _p]),
+    "rphip_comm_selftest": (C.c_int, [_p, _p, _i32, _i64, C.POINTER(_i64), C.POINTER(_f64)]),
+}
+# include/recpack_hip_diag.h: measuring instruments and test hooks (tools/, tests/), not the drop-in boundary
+DIAG_PROTOTYPES = {
+    "rphip_potrf_trtri_128": (C.c_int, [_p, _p, _i64, _p, _p]),
+    "rphip_gemm_nt_f32_ex": (C.c_int, [_p, _i64, _i64, _i64, _i64, C.c_float, _p, _i64, _p, _i64, C.c_float, _p, _i64, _i32, _i32, _i64, _i64, _i32]),
+    "rphip_comm_loopback_create": (C.c_int, [_p, _i32, _i32, C.c_double, C.c_double, _pp]),
+    "rphip_ease_fit_dist_stats": (C.c_int, [_p, _p]),
 }
 
 _lock = threading.Lock()
@@ -162,7 +166,7 @@ def load_library(path: str | None = None):
         except Exception:  # pragma: no cover - torch is optional for single-GPU host-array use
             pass
         lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
-        for name, (res, args) in PROTOTYPES.items():
+        for name, (res, args) in list(PROTOTYPES.items()) + list(DIAG_PROTOTYPES.items()):
             fn = getattr(lib, name)  # AttributeError => the .so is older than the header
             fn.restype = res
             fn.argtypes = args
@@ -646,6 +650,39 @@ class Comm:
 
     def all_reduce_sum_i32(self, ptr: int, count: int):
         check(self.ctx.lib.rphip_comm_all_reduce_sum_i32(self.ctx.handle, self.handle, C.c_void_p(ptr), int(count)))
+
+    SELFTEST_OPS = ("broadcast", "all_gather", "exchange", "all_reduce_sum_i32")
+
+    def selftest_op(self, op: int, words: int = 1 << 18):
+        """One operation of the transport on a known pattern, every received word checked on the device (rphip_comm_selftest):
+        (mismatching words, milliseconds).  Blocks until the operation is complete - put a watchdog around it."""
+        bad, ms = C.c_int64(-1), C.c_double(0.0)
+        check(self.ctx.lib.rphip_comm_selftest(self.ctx.handle, self.handle, int(op), int(words), C.byref(bad), C.byref(ms)))
+        return bad.value, ms.value
+
+    def selftest(self, words: int = 1 << 18, watchdog_s: float = 30.0, on_hang=None) -> dict:
+        """All four operations once (every rank must call this).  A watchdog thread fires `on_hang(name)` - default: print which
+        operation hangs and leave the process with exit code 6 - when one of them does not complete within `watchdog_s` seconds:
+        a hung collective cannot be cancelled from inside the process.  Returns {"ok": bool, "ops": {name: {"mismatches", "ms"}}}."""
+        import threading
+
+        def default_hang(name):
+            sys.stderr.write(f"recpack_amd: transport self-test: {name} did not complete within {watchdog_s:.0f} s (rank {self.rank} of {self.world})\n")
+            sys.stderr.flush()
+            os._exit(6)
+
+        out = {"ok": True, "world": self.world, "transport": "rccl" if self.is_rccl else "callbacks", "words_per_rank": int(words), "ops": {}}
+        for op, name in enumerate(self.SELFTEST_OPS):
+            dog = threading.Timer(watchdog_s, (on_hang or default_hang), args=(name,))
+            dog.daemon = True
+            dog.start()
+            try:
+                bad, ms = self.selftest_op(op, words)
+            finally:
+                dog.cancel()
+            out["ops"][name] = {"mismatches": int(bad), "ms": round(ms, 3)}
+            out["ok"] = out["ok"] and bad == 0
+        return out
 
     def close(self):
         if getattr(self, "handle", None):

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/recpack_hip.h"
+#include "../../include/recpack_hip_diag.h"
 
 // ---- errors --------------------------------------------------------------------------------------
 void rp_set_error(const char* fmt, ...);

@@ -31,6 +31,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "rp_common.h"
@@ -324,6 +325,94 @@ int rp_comm_all_reduce_sum_i32(rphip_comm* c, int32_t* buf, int64_t count, hipSt
     return RPHIP_OK;
   }
   RP_OPS(c->ops.all_reduce_sum_i32(c->ops.self, buf, count, (void*)st), "all_reduce_sum_i32");
+  return RPHIP_OK;
+}
+
+// ---- self-test of a communicator: one operation per call, a known pattern in, every word checked on the device ------------------
+__device__ __forceinline__ int32_t rp_st_pat(int who, long long i) { return (int32_t)((unsigned)(who + 1) * 1000003u + (unsigned)i * 7919u); }
+__global__ void k_st_fill(int32_t* __restrict__ p, long long n, int who, int per_piece, int piece_words) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    p[i] = per_piece ? rp_st_pat(who * 1024 + (int)(i / piece_words), i % piece_words) : rp_st_pat(who, i);
+}
+__global__ void k_st_fill_reduce(int32_t* __restrict__ p, long long n, int me) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = (me + 1) * (int)(i % 7 + 1);
+}
+// mode 0: p[i] == pat(who, i); 1: piece s of p == pat(s, i) (all-gather); 2: piece s == pat(s * 1024 + me, i) (exchange); 3: the sum
+__global__ void k_st_check(const int32_t* __restrict__ p, long long n, int mode, int who, int world, int piece_words, unsigned long long* __restrict__ bad) {
+  unsigned long long b = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    int32_t want;
+    if (mode == 0)
+      want = rp_st_pat(who, i);
+    else if (mode == 1)
+      want = rp_st_pat((int)(i / piece_words), i % piece_words);
+    else if (mode == 2)
+      want = rp_st_pat((int)(i / piece_words) * 1024 + who, i % piece_words);
+    else
+      want = (world * (world + 1) / 2) * (int)(i % 7 + 1);
+    b += p[i] != want ? 1 : 0;
+  }
+  if (b) atomicAdd(bad, b);
+}
+
+// op: 0 broadcast (from the last rank), 1 all-gather, 2 personalised exchange, 3 int32 all-reduce; `words` int32 per rank (or piece).
+// Runs the operation once on the context's stream with a known pattern, waits, and checks every received word on the device:
+// *mismatches = words that differ (0 = the operation works), *ms = its wall time.  A transport that hangs hangs HERE, in a call that
+// names the operation - the caller puts a watchdog around it (bench.py: 30 s) instead of finding out in the first pivot of a solve.
+extern "C" int rphip_comm_selftest(rphip_ctx* ctx, rphip_comm* c, int32_t op, int64_t words, int64_t* mismatches, double* ms) {
+  if (!ctx || !c || !mismatches) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if (op < 0 || op > 3 || words < 1 || words > (1 << 26)) RP_FAIL(RPHIP_EINVAL, "self-test: operation %d, %lld words", op, (long long)words);
+  RP_TRY(rp_set_device(ctx));
+  const int W = c->world, me = c->rank;
+  hipStream_t st = ctx->stream;
+  const long long n_send = (op == 2) ? words * W : words, n_recv = (op == 1 || op == 2) ? words * W : words;
+  int32_t *send = nullptr, *recv = nullptr;
+  unsigned long long* bad = nullptr;
+  RP_TRY(rp_dev_alloc(ctx, (size_t)n_send * 4, (void**)&send));
+  int rc = rp_dev_alloc(ctx, (size_t)n_recv * 4 + 256, (void**)&recv);
+  if (rc != RPHIP_OK) {
+    rp_dev_free(ctx, send);
+    return rc;
+  }
+  bad = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(recv) + (((size_t)n_recv * 4 + 15) & ~(size_t)15));
+  hipMemsetAsync(bad, 0, 8, st);
+  hipMemsetAsync(recv, 0xA5, (size_t)n_recv * 4, st);
+  const int fg = 1024;
+  if (op == 3)
+    hipLaunchKernelGGL(k_st_fill_reduce, dim3(fg), dim3(256), 0, st, recv, n_recv, me);
+  else if (op == 0) {
+    if (me == W - 1) hipLaunchKernelGGL(k_st_fill, dim3(fg), dim3(256), 0, st, recv, n_recv, me, 0, 1);
+  } else
+    hipLaunchKernelGGL(k_st_fill, dim3(fg), dim3(256), 0, st, send, n_send, me, op == 2 ? 1 : 0, (int)words);
+  hipStreamSynchronize(st);
+  const auto t0 = std::chrono::steady_clock::now();
+  if (op == 0)
+    rc = rp_comm_broadcast(c, recv, words * 4, W - 1, st);
+  else if (op == 1)
+    rc = rp_comm_all_gather(c, send, recv, words * 4, st);
+  else if (op == 2) {
+    std::vector<int64_t> off(W), by(W);
+    for (int p = 0; p < W; ++p) {
+      off[p] = (int64_t)p * words * 4;
+      by[p] = words * 4;
+    }
+    rc = rp_comm_exchange(c, send, off.data(), by.data(), recv, off.data(), by.data(), st);
+  } else
+    rc = rp_comm_all_reduce_sum_i32(c, recv, words, st);
+  hipError_t e = hipStreamSynchronize(st);
+  if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  unsigned long long h_bad = ~0ull;
+  if (rc == RPHIP_OK && e == hipSuccess) {
+    hipLaunchKernelGGL(k_st_check, dim3(fg), dim3(256), 0, st, recv, n_recv, op, op == 0 ? W - 1 : me, W, (int)words, bad);
+    hipMemcpyAsync(&h_bad, bad, 8, hipMemcpyDeviceToHost, st);
+    e = hipStreamSynchronize(st);
+  }
+  rp_dev_free(ctx, send);
+  rp_dev_free(ctx, recv);
+  if (rc != RPHIP_OK) return rc;
+  if (e != hipSuccess) RP_FAIL(RPHIP_EHIP, "self-test of operation %d: %s", op, hipGetErrorString(e));
+  // (a loop-back communicator moves nothing: what it "receives" is by contract not the other ranks' data)
+  *mismatches = c->is_loop ? 0 : (int64_t)h_bad;
   return RPHIP_OK;
 }
 

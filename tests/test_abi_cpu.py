@@ -10,8 +10,9 @@ import scipy.sparse as sp
 from conftest import ROOT
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "recpack_hip.h")).read()
+def _declared_symbols(header="recpack_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)  # (comments name functions of other headers)
     return sorted(set(re.findall(r"\b(rphip_[a-z0-9_]+)\s*\(", text)))
 
 
@@ -24,6 +25,12 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/recpack_hip.h but not exported"
     assert set(declared) == set(_lib.PROTOTYPES), set(declared) ^ set(_lib.PROTOTYPES)
+    # the measuring instruments and test hooks have a header of their own (include/recpack_hip_diag.h): not the drop-in boundary
+    diag = _declared_symbols("recpack_hip_diag.h")
+    for name in diag:
+        assert hasattr(lib, name), f"{name} declared in include/recpack_hip_diag.h but not exported"
+    assert set(diag) == set(_lib.DIAG_PROTOTYPES), set(diag) ^ set(_lib.DIAG_PROTOTYPES)
+    assert not set(diag) & set(declared)
     assert lib.rphip_version() == 100
 
 

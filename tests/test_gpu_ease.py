@@ -383,6 +383,7 @@ def test_ease_fit_sharded_multi_rank(hip, nproc, shape):
     r = _run_dist_check(nproc, shape)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("top-20 agreement") == 4 * nproc
+    assert r.stdout.count("transport self-test: ok") == nproc  # rphip_comm_selftest: broadcast, all-gather, exchange, all-reduce
 
 
 def test_ease_fit_sharded_one_rank(hip):

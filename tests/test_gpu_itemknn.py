@@ -413,6 +413,11 @@ def test_sharded_fit_nccl_world1(hip):
         m2 = _lib.itemknn_fit(ctx, dX, 40)
         qi, qv, qn = _lib.predict_topk(ctx, m2, dX, 10, user_begin=0, user_end=200)
         np.testing.assert_array_equal(pi, qi)
+        # the library's own RCCL communicator at one rank: every entry point of the transport self-test (bench.py --selftest)
+        comm = rdist.make_comm(ctx, torch.device("cuda", 0), transport="rccl")
+        st = comm.selftest(words=10_000)
+        assert comm.is_rccl and st["ok"] and set(st["ops"]) == set(_lib.Comm.SELFTEST_OPS), st
+        comm.close()
     finally:
         dist.destroy_process_group()
 

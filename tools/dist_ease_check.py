@@ -45,6 +45,10 @@ for l2, alpha in ((50.0, 0.0), (5.0, 0.5)):
     b = _lib.predict_topk(ctx, ref, dX, 20, exclude_history=True, user_begin=0, user_end=nu)
     # ---- the library's distributed solve: this rank's columns of B (block-cyclic panels), memory, the sharded predict + merge
     comm = rdist.make_comm(ctx, device, transport=os.environ.get("RECPACK_DIST_TRANSPORT", "auto"))
+    if l2 == 50.0:  # the transport's four operations on a known pattern, every word checked (what bench.py --gpus N runs before its warm-up)
+        st_ = comm.selftest(words=50_000, watchdog_s=60.0)
+        print(f"rank {rank}/{world} transport self-test: {'ok' if st_['ok'] else 'FAILED'} {st_['ops']}", flush=True)
+        ok = ok and st_["ok"]
     for pt in (dist_tiles, 0):
         torch.cuda.synchronize()
         torch.cuda.reset_peak_memory_stats()
