@@ -14,8 +14,12 @@
  *  - plain pointers and sizes only; "host" pointers are caller-owned host memory, "dev" pointers are
  *    device memory on the context's GPU (e.g. a torch tensor's data_ptr());
  *  - indices are int32, row pointers int32 or int64 (flag); nnz must be < 2^31;
- *  - a context is bound to one GPU and one HIP stream; it must not be used from two threads at once;
- *    host-output calls are synchronous on return, *_dev calls are ordered on the context's stream;
+ *  - a context is bound to one GPU and one HIP stream.  Every entry point that takes a context holds the context's lock for the
+ *    duration of the call (round 5): a context - and the models and matrices created on it, whose acceleration structures
+ *    (predict's tile offsets, the quantised copy of a dense model) are built on first use - may be used from several threads, whose
+ *    calls are serialised; host-output calls are synchronous on return, *_dev calls are ordered on the context's stream, with ONE
+ *    exception: the fused predict of a DENSE model in two passes (option "predict_half", the default) reads back the number of
+ *    users without a proof before it launches their exact pass, i.e. rphip_predict_topk*_dev waits for the stream once per call;
  *  - objects (ctx, csr, model) are opaque and freed by their *_destroy.
  */
 #ifndef RECPACK_HIP_H

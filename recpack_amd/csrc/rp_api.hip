@@ -92,6 +92,7 @@ extern "C" int rphip_ctx_destroy(rphip_ctx* ctx) {
 }
 
 extern "C" int rphip_ctx_sync(rphip_ctx* ctx) {
+  RP_ENTER(ctx);
   if (!ctx) RP_FAIL(RPHIP_EINVAL, "ctx is NULL");
   RP_TRY(rp_set_device(ctx));
   RP_HIP(hipStreamSynchronize(ctx->stream));
@@ -99,6 +100,7 @@ extern "C" int rphip_ctx_sync(rphip_ctx* ctx) {
 }
 
 extern "C" int rphip_device_info(rphip_ctx* ctx, int* n_cu, int64_t* hbm_bytes, char* arch_buf, int arch_buf_len) {
+  RP_ENTER(ctx);
   if (!ctx) RP_FAIL(RPHIP_EINVAL, "ctx is NULL");
   if (n_cu) *n_cu = ctx->n_cu;
   if (hbm_bytes) *hbm_bytes = (int64_t)ctx->hbm_bytes;
@@ -284,6 +286,7 @@ void rp_dev_free(rphip_ctx* ctx, void* p) {
 }
 
 extern "C" int rphip_ctx_trim(rphip_ctx* ctx) {
+  RP_ENTER(ctx);
   if (!ctx) RP_FAIL(RPHIP_EINVAL, "ctx is NULL");
   RP_TRY(rp_set_device(ctx));
   RP_HIP(hipStreamSynchronize(ctx->stream));
@@ -298,6 +301,7 @@ extern "C" int rphip_ctx_trim(rphip_ctx* ctx) {
 }
 
 extern "C" int rphip_ctx_set_option(rphip_ctx* ctx, const char* name, int64_t value) {
+  RP_ENTER(ctx);
   if (!ctx || !name) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (!strcmp(name, "predict_exact64")) {
     ctx->predict_exact64 = value ? 1 : 0;
@@ -396,6 +400,7 @@ int rp_resolve_timings(rphip_ctx* ctx) {
 }
 
 extern "C" int rphip_get_timings(rphip_ctx* ctx, rphip_timings* out) {
+  RP_ENTER(ctx);
   if (!ctx || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   RP_TRY(rp_set_device(ctx));
   RP_TRY(rp_resolve_timings(ctx));
@@ -404,6 +409,7 @@ extern "C" int rphip_get_timings(rphip_ctx* ctx, rphip_timings* out) {
 }
 
 extern "C" int rphip_get_counters(rphip_ctx* ctx, int64_t* out8) {
+  RP_ENTER(ctx);
   if (!ctx || !out8) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   RP_TRY(rp_set_device(ctx));
   RP_HIP(hipMemcpyAsync(out8, ctx->dev_counters, 64, hipMemcpyDeviceToHost, ctx->stream));
@@ -412,6 +418,7 @@ extern "C" int rphip_get_counters(rphip_ctx* ctx, int64_t* out8) {
 }
 
 extern "C" int rphip_reset_timings(rphip_ctx* ctx) {
+  RP_ENTER(ctx);
   if (!ctx) RP_FAIL(RPHIP_EINVAL, "ctx is NULL");
   RP_TRY(rp_set_device(ctx));
   RP_TRY(rp_resolve_timings(ctx));

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -68,7 +69,15 @@ struct rp_buf {  // grow-only device scratch
   size_t cap = 0;
 };
 
+// Every entry point that takes a context holds its lock for the duration of the call: a context (its stream, scratch buffers, block
+// cache, timing slots - and the lazily built acceleration structures of its models: predict's tile offsets and quantised copy of B)
+// may be used from several threads, whose calls are serialised.  Recursive: entry points call each other.
+#define RP_ENTER(ctx)                                          \
+  std::unique_lock<std::recursive_mutex> rp_enter_lock_;       \
+  if (ctx) rp_enter_lock_ = std::unique_lock<std::recursive_mutex>((ctx)->api_mu)
+
 struct rphip_ctx {
+  std::recursive_mutex api_mu;
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -163,9 +172,9 @@ struct rphip_model {
   double* val = nullptr;    // [rows*K]
   float* val32 = nullptr;   // [rows*K] (predict operand)
   int2* pairs = nullptr;    // [rows*K] {column, float bits}: what the wave-per-user predict kernel streams
-  uint16_t* toff = nullptr; // [n_items * (n_wt + 1)] per-row offsets of the predict column tiles (built on first use)
-  int toff_wt = 0;          // tile width toff was built for
-  float* rowmax = nullptr;  // [n_items] largest |similarity| of each list (built with toff)
+  mutable uint16_t* toff = nullptr; // [n_items * (n_wt + 1)] per-row offsets of the predict column tiles (built on first use)
+  mutable int toff_wt = 0;          // tile width toff was built for
+  mutable float* rowmax = nullptr;  // [n_items] largest |similarity| of each list (built with toff)
   int32_t* nnz = nullptr;   // [rows]
   bool cols_sorted = false; // every row's columns strictly increasing (checked when the model is finalised)
   float vmax_abs = 0.0f;    // largest |similarity| (f32): with the longest history it bounds |score|
@@ -178,15 +187,16 @@ struct rphip_model {
   // n_cols > 0 and cyc_nb > 0: the columns are block-cyclic panels of cyc_nb columns (rphip_ease_fit_dist): local column l is item
   // rp_cyc_panel(l / cyc_nb, cyc_rank, cyc_world) * cyc_nb + l % cyc_nb (below); the n_cols items are a prefix of the local columns
   int32_t cyc_nb = 0, cyc_world = 1, cyc_rank = 0;
+  // (the `mutable` members are acceleration structures built on first use by predict under the owning context's lock, RP_ENTER)
   // fp16 copy of B for the first pass of the two-pass K9 (built on first use, rp_predict.hip): B16 = fp16(B * b16_scale), the same
   // leading dimension; b16_delta[i] = the largest rounding error of row i (in B's units), b16_rowmax[i] = its largest |entry|
-  _Float16* B16 = nullptr;   // (b16_kind 2: int8 rows, q = rint(b / b8_scale[row]) in [-127, 127], the same leading dimension in BYTES)
-  int b16_kind = 0;          // 1: fp16 copy, 2: int8 copy (round 4); the copy is rebuilt when the context asks for the other kind
-  float* b8_scale = nullptr; // int8 copy: the rows' steps (rowmax / 127)
-  float b16_scale = 0.0f;
-  float* b16_delta = nullptr;
-  float* b16_rowmax = nullptr;
-  bool b16_failed = false;  // the copy could not be allocated: the one-pass kernel is used
+  mutable _Float16* B16 = nullptr;   // (b16_kind 2: int8 rows, q = rint(b / b8_scale[row]) in [-127, 127], the same leading dimension in BYTES)
+  mutable int b16_kind = 0;          // 1: fp16 copy, 2: int8 copy (round 4); the copy is rebuilt when the context asks for the other kind
+  mutable float* b8_scale = nullptr; // int8 copy: the rows' steps (rowmax / 127)
+  mutable float b16_scale = 0.0f;
+  mutable float* b16_delta = nullptr;
+  mutable float* b16_rowmax = nullptr;
+  mutable bool b16_failed = false;  // the copy could not be allocated: the one-pass kernel is used
   int64_t empty_rows = -1;  // rows without any stored similarity (-1: not counted)
 };
 

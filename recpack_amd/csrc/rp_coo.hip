@@ -137,6 +137,7 @@ static int rp_coo_build(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_
 
 extern "C" int rphip_csr_from_coo_device(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_t n_pairs, const int64_t* uid_dev,
                                          const int64_t* iid_dev, rphip_csr** out) {
+  RP_ENTER(ctx);
   if (!ctx || !out || (n_pairs > 0 && (!uid_dev || !iid_dev))) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   RP_TRY(rp_set_device(ctx));
@@ -145,6 +146,7 @@ extern "C" int rphip_csr_from_coo_device(rphip_ctx* ctx, int64_t n_users, int64_
 
 extern "C" int rphip_csr_from_coo_host(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_t n_pairs, const int64_t* uid_host,
                                        const int64_t* iid_host, rphip_csr** out) {
+  RP_ENTER(ctx);
   if (!ctx || !out || (n_pairs > 0 && (!uid_host || !iid_host))) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   RP_TRY(rp_set_device(ctx));
@@ -167,6 +169,7 @@ extern "C" int rphip_csr_from_coo_host(rphip_ctx* ctx, int64_t n_users, int64_t 
 
 // the CSR arrays of a device matrix (int32 indptr[n_users + 1], int32 indices[nnz]) to the host
 extern "C" int rphip_csr_download(rphip_ctx* ctx, const rphip_csr* m, int32_t* indptr_host, int32_t* indices_host) {
+  RP_ENTER(ctx);
   if (!ctx || !m || !indptr_host || (m->nnz > 0 && !indices_host)) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   RP_TRY(rp_set_device(ctx));
   RP_HIP(hipMemcpyAsync(indptr_host, m->x_ptr, (size_t)(m->n_users + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));

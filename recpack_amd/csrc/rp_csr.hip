@@ -448,6 +448,7 @@ static int rp_csr_check_shape(int64_t U, int64_t I, int64_t nnz) {
 
 extern "C" int rphip_csr_from_host(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_t nnz, const void* indptr_host,
                                    int indptr_is_int64, const int32_t* indices_host, rphip_csr** out) {
+  RP_ENTER(ctx);
   if (!ctx || !out || !indptr_host || (nnz > 0 && !indices_host)) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   RP_TRY(rp_csr_check_shape(n_users, n_items, nnz));
@@ -503,11 +504,13 @@ extern "C" int rphip_csr_from_host(rphip_ctx* ctx, int64_t n_users, int64_t n_it
 
 extern "C" int rphip_csr_from_device(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_t nnz, const int32_t* indptr_dev,
                                      const int32_t* indices_dev, rphip_csr** out) {
+  RP_ENTER(ctx);
   return rphip_csr_from_device_rows(ctx, n_users, n_items, nnz, indptr_dev, indices_dev, 0, -1, out);
 }
 
 extern "C" int rphip_csr_from_device_rows(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_t nnz, const int32_t* indptr_dev,
                                           const int32_t* indices_dev, int64_t fit_row_begin, int64_t fit_row_end, rphip_csr** out) {
+  RP_ENTER(ctx);
   if (!ctx || !out || !indptr_dev || (nnz > 0 && !indices_dev)) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   RP_TRY(rp_csr_check_shape(n_users, n_items, nnz));
@@ -539,6 +542,7 @@ extern "C" int rphip_csr_from_device_rows(rphip_ctx* ctx, int64_t n_users, int64
 // degree arrays of all shards (rphip_csr_degrees_device -> one all-reduce of n_items int32) and called rphip_csr_finish_degrees.
 extern "C" int rphip_csr_from_device_shard(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_t nnz, const int32_t* indptr_dev,
                                            const int32_t* indices_dev, int64_t fit_row_begin, int64_t fit_row_end, rphip_csr** out) {
+  RP_ENTER(ctx);
   if (!ctx || !out || !indptr_dev || (nnz > 0 && !indices_dev)) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   RP_TRY(rp_csr_check_shape(n_users, n_items, nnz));
@@ -572,6 +576,7 @@ extern "C" int rphip_csr_degrees_device(rphip_csr* m, int32_t** deg_dev) {
 }
 
 extern "C" int rphip_csr_finish_degrees(rphip_ctx* ctx, rphip_csr* m) {
+  RP_ENTER(ctx);
   if (!ctx || !m) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   RP_TRY(rp_set_device(ctx));
   hipEvent_t ev;
@@ -613,6 +618,7 @@ extern "C" int rphip_csr_destroy(rphip_csr* m) {
 // Values for the stored entries (NULL: back to binary).  Scanned on the host for the largest magnitude (predict's
 // fixed-point scale) and for negative entries (the signed selection rules of the weighted fit).
 extern "C" int rphip_csr_set_values(rphip_ctx* ctx, rphip_csr* m, const double* values_host) {
+  RP_ENTER(ctx);
   if (!ctx || !m) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   RP_TRY(rp_set_device(ctx));
   RP_HIP(hipStreamSynchronize(ctx->stream));
@@ -647,6 +653,7 @@ extern "C" int rphip_csr_shape(const rphip_csr* m, int64_t* n_users, int64_t* n_
 }
 
 extern "C" int rphip_csr_item_degrees(rphip_ctx* ctx, const rphip_csr* m, int32_t* deg_host) {
+  RP_ENTER(ctx);
   if (!ctx || !m || !deg_host) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   RP_TRY(rp_set_device(ctx));
   if (m->n_items > 0) RP_HIP(hipMemcpyAsync(deg_host, m->deg, (size_t)m->n_items * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -655,6 +662,7 @@ extern "C" int rphip_csr_item_degrees(rphip_ctx* ctx, const rphip_csr* m, int32_
 }
 
 extern "C" int rphip_csr_num_products(rphip_ctx* ctx, const rphip_csr* m, int64_t* p_out) {
+  RP_ENTER(ctx);
   if (!ctx || !m || !p_out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *p_out = m->n_products;
   return RPHIP_OK;

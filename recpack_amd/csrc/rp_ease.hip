@@ -1611,6 +1611,7 @@ extern "C" int rphip_debug_gemm_stamps(rphip_ctx* ctx, unsigned* out) {  // [8][
 
 extern "C" int rphip_gemm_nt_f32(rphip_ctx* ctx, int64_t M, int64_t N, int64_t K, float alpha, const float* A_dev, int64_t lda,
                                  const float* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc) {
+  RP_ENTER(ctx);
   if (!ctx || !A_dev || !B_dev || !C_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if ((M % GT) || (N % GT) || (K % GBK) || (lda % 4) || (ldb % 4)) RP_FAIL(RPHIP_EINVAL, "M, N must be multiples of 128, K of 16, lda/ldb of 4");
   RP_TRY(rp_set_device(ctx));
@@ -2193,6 +2194,7 @@ int rp_ease_gram_rows(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int
 // A (128 x 128 block, leading dimension lda) := its Cholesky factor (lower, upper part zeroed), W (128 x 128, ld 128) := the
 // factor's inverse; *info_dev (device int) is set to the failing pivot + 1 when the block is not positive definite
 extern "C" int rphip_potrf_trtri_128(rphip_ctx* ctx, float* A_dev, int64_t lda, float* W_dev, int32_t* info_dev) {
+  RP_ENTER(ctx);
   if (!ctx || !A_dev || !W_dev || !info_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   RP_TRY(rp_set_device(ctx));
   const size_t diag_lds = RP_POTRF_LDS;
@@ -2207,6 +2209,7 @@ extern "C" int rphip_potrf_trtri_128(rphip_ctx* ctx, float* A_dev, int64_t lda, 
 extern "C" int rphip_gemm_nt_f32_ex(rphip_ctx* ctx, int64_t M, int64_t N, int64_t k_begin, int64_t k_end, float alpha, const float* A_dev,
                                     int64_t lda, const float* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc, int32_t k_from_row,
                                     int32_t k_from_col, int64_t m_off, int64_t n_off, int32_t lower_only) {
+  RP_ENTER(ctx);
   if (!ctx || !A_dev || !B_dev || !C_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if ((M % GT) || (N % GT) || (k_begin % GBK) || (k_end % GBK) || (lda % 4) || (ldb % 4) || (m_off % GT) || (n_off % GT))
     RP_FAIL(RPHIP_EINVAL, "M, N, m_off, n_off must be multiples of 128, the K range of 16, lda/ldb of 4");
@@ -2264,6 +2267,7 @@ int rp_transpose_f32(rphip_ctx* ctx, const float* src, int64_t lds, int64_t rows
 // local top-Kp per user on every rank, then rphip_predict_merge_topk on the gathered lists).
 extern "C" int rphip_model_from_dense_cols(rphip_ctx* ctx, int64_t n_items, int64_t col_begin, int64_t n_cols, float* B_dev, int64_t ld,
                                            rphip_model** out) {
+  RP_ENTER(ctx);
   if (!ctx || !B_dev || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   if (n_items <= 0 || col_begin < 0 || n_cols <= 0 || col_begin + n_cols > n_items || ld < n_cols || (ld % 64))
@@ -2313,6 +2317,7 @@ __global__ void k_zero_diag(float* __restrict__ B, long long ld, int n) {
 }
 
 extern "C" int rphip_ease_xy_fit(rphip_ctx* ctx, const rphip_csr* X, const rphip_csr* Y, double l2, double alpha, rphip_model** out) {
+  RP_ENTER(ctx);
   if (!ctx || !X || !Y || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   if (!(l2 > 0.0)) RP_FAIL(RPHIP_EINVAL, "l2 must be > 0 (got %g): G + l2*I has to be positive definite", l2);
@@ -2470,6 +2475,7 @@ static int rp_ease_solve_scale(rphip_ctx* ctx, const rphip_csr* X, rphip_model* 
 }
 
 extern "C" int rphip_ease_fit(rphip_ctx* ctx, const rphip_csr* X, double l2, double alpha, rphip_model** out) {
+  RP_ENTER(ctx);
   if (!ctx || !X || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   if (!(l2 > 0.0)) RP_FAIL(RPHIP_EINVAL, "l2 must be > 0 (got %g): G + l2*I has to be positive definite", l2);
@@ -2503,6 +2509,7 @@ __global__ void k_add_diag(float* __restrict__ G, long long ld, int n, float lam
 }
 
 extern "C" int rphip_ease_gram_create(rphip_ctx* ctx, const rphip_csr* X, rphip_model** out) {
+  RP_ENTER(ctx);
   if (!ctx || !X || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   if (X->xt_row_end >= 0) RP_FAIL(RPHIP_ESTATE, "EASE needs a matrix with all item rows of X^T (not rphip_csr_from_device_rows)");
@@ -2526,6 +2533,7 @@ extern "C" int rphip_ease_gram_create(rphip_ctx* ctx, const rphip_csr* X, rphip_
 }
 
 extern "C" int rphip_ease_fit_gram(rphip_ctx* ctx, const rphip_csr* X, const rphip_model* gram, double l2, double alpha, rphip_model** out) {
+  RP_ENTER(ctx);
   if (!ctx || !X || !gram || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   if (!(l2 > 0.0)) RP_FAIL(RPHIP_EINVAL, "l2 must be > 0 (got %g): G + l2*I has to be positive definite", l2);
@@ -2640,6 +2648,7 @@ __global__ void __launch_bounds__(256) k_prune_apply(float* __restrict__ B, long
 }
 
 extern "C" int rphip_model_dense_changed(rphip_ctx* ctx, rphip_model* m) {
+  RP_ENTER(ctx);
   if (!ctx || !m) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (m->kind != RPHIP_MODEL_DENSE || !m->B) RP_FAIL(RPHIP_ESTATE, "not a dense model");
   RP_TRY(rp_set_device(ctx));
@@ -2656,6 +2665,7 @@ extern "C" int rphip_model_dense_changed(rphip_ctx* ctx, rphip_model* m) {
 }
 
 extern "C" int rphip_model_dense_prune(rphip_ctx* ctx, rphip_model* m, int64_t keep, int64_t* nnz_before, int64_t* nnz_after) {
+  RP_ENTER(ctx);
   if (!ctx || !m) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (m->kind != RPHIP_MODEL_DENSE) RP_FAIL(RPHIP_ESTATE, "model is not a dense model");
   if (m->n_cols > 0) RP_FAIL(RPHIP_ESTATE, "the model holds a slab of columns: prune the whole matrix");
@@ -2722,6 +2732,7 @@ extern "C" int rphip_model_dense_prune(rphip_ctx* ctx, rphip_model* m, int64_t k
 }
 
 extern "C" int rphip_model_from_dense_host(rphip_ctx* ctx, int64_t n_items, const float* B_host, rphip_model** out) {
+  RP_ENTER(ctx);
   if (!ctx || !B_host || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   if (n_items <= 0) RP_FAIL(RPHIP_EINVAL, "no items");
@@ -2752,6 +2763,7 @@ extern "C" int rphip_model_from_dense_host(rphip_ctx* ctx, int64_t n_items, cons
 }
 
 extern "C" int rphip_model_dense_download(rphip_ctx* ctx, const rphip_model* m, float* B_host) {
+  RP_ENTER(ctx);
   if (!ctx || !m || !B_host) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (m->kind != RPHIP_MODEL_DENSE) RP_FAIL(RPHIP_ESTATE, "model is not dense");
   if (m->n_cols > 0) RP_FAIL(RPHIP_ESTATE, "the model holds a slab of columns (rphip_model_dense_layout), not the whole matrix");

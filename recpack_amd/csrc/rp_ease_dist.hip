@@ -120,6 +120,7 @@ extern "C" int rphip_comm_rccl_unique_id(void* id_out) {
 }
 
 extern "C" int rphip_comm_rccl_create(rphip_ctx* ctx, int32_t world, int32_t rank, const void* id, rphip_comm** out) {
+  RP_ENTER(ctx);
   if (!ctx || !id || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   if (world < 1 || rank < 0 || rank >= world) RP_FAIL(RPHIP_EINVAL, "rank %d of %d", rank, world);
@@ -143,6 +144,7 @@ extern "C" int rphip_comm_rccl_create(rphip_ctx* ctx, int32_t world, int32_t ran
 }
 
 extern "C" int rphip_comm_from_ops(rphip_ctx* ctx, const rphip_comm_ops* ops, rphip_comm** out) {
+  RP_ENTER(ctx);
   if (!ctx || !ops || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   if (ops->world < 1 || ops->rank < 0 || ops->rank >= ops->world) RP_FAIL(RPHIP_EINVAL, "rank %d of %d", ops->rank, ops->world);
@@ -182,6 +184,7 @@ static void rp_loop_noise(void* p, int64_t bytes, hipStream_t st, unsigned seed)
 }
 
 extern "C" int rphip_comm_loopback_create(rphip_ctx* ctx, int32_t world, int32_t rank, double gbytes_per_s, double latency_us, rphip_comm** out) {
+  RP_ENTER(ctx);
   if (!ctx || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   if (world < 1 || rank < 0 || rank >= world) RP_FAIL(RPHIP_EINVAL, "rank %d of %d", rank, world);
@@ -360,6 +363,7 @@ __global__ void k_st_check(const int32_t* __restrict__ p, long long n, int mode,
 // *mismatches = words that differ (0 = the operation works), *ms = its wall time.  A transport that hangs hangs HERE, in a call that
 // names the operation - the caller puts a watchdog around it (bench.py: 30 s) instead of finding out in the first pivot of a solve.
 extern "C" int rphip_comm_selftest(rphip_ctx* ctx, rphip_comm* c, int32_t op, int64_t words, int64_t* mismatches, double* ms) {
+  RP_ENTER(ctx);
   if (!ctx || !c || !mismatches) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (op < 0 || op > 3 || words < 1 || words > (1 << 26)) RP_FAIL(RPHIP_EINVAL, "self-test: operation %d, %lld words", op, (long long)words);
   RP_TRY(rp_set_device(ctx));
@@ -417,6 +421,7 @@ extern "C" int rphip_comm_selftest(rphip_ctx* ctx, rphip_comm* c, int32_t op, in
 }
 
 extern "C" int rphip_comm_all_reduce_sum_i32(rphip_ctx* ctx, rphip_comm* c, int32_t* buf, int64_t count) {
+  RP_ENTER(ctx);
   if (!ctx || !c || !buf) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (count <= 0 || c->world == 1) return RPHIP_OK;
   RP_TRY(rp_set_device(ctx));
@@ -554,6 +559,7 @@ struct dist_res {  // everything the fit holds besides the slab; released on eve
 }  // namespace
 
 extern "C" int rphip_ease_fit_dist_stats(rphip_ctx* ctx, int64_t* out8) {
+  RP_ENTER(ctx);
   if (!ctx || !out8) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   ::memcpy(out8, ctx->dist_stats, sizeof(ctx->dist_stats));
   return RPHIP_OK;
@@ -561,6 +567,7 @@ extern "C" int rphip_ease_fit_dist_stats(rphip_ctx* ctx, int64_t* out8) {
 
 extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip_csr* X, double l2, double alpha, int32_t panel_tiles,
                                    rphip_model** out) {
+  RP_ENTER(ctx);
   if (!ctx || !comm || !X || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   if (!(l2 > 0.0)) RP_FAIL(RPHIP_EINVAL, "l2 must be > 0 (got %g): G + l2*I has to be positive definite", l2);
@@ -981,6 +988,7 @@ __global__ void k_unpack_panels(const float* __restrict__ recv, long long slot_f
 // n_items and panel_cols as every rank's layout reports them.  Strips of rows travel one all-gather each.
 extern "C" int rphip_ease_model_allgather(rphip_ctx* ctx, rphip_comm* comm, const rphip_model* local, int64_t n_items, int64_t panel_cols,
                                           rphip_model** out) {
+  RP_ENTER(ctx);
   if (!ctx || !comm || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   const int W = comm->world, me = comm->rank;

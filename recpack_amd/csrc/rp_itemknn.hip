@@ -880,6 +880,7 @@ extern "C" int rphip_model_destroy(rphip_model* m) {
 }
 
 extern "C" int rphip_model_empty_rows(rphip_ctx* ctx, const rphip_model* m, int64_t* out) {
+  RP_ENTER(ctx);
   if (!ctx || !m || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = m->empty_rows;
   return RPHIP_OK;
@@ -1204,12 +1205,14 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
 
 extern "C" int rphip_itemknn_fit(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K,
                                  rphip_model** out) {
+  RP_ENTER(ctx);
   if (!out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   return rp_gram_core(ctx, X, row_begin, row_end, K, out, nullptr, 0, 0.0f);
 }
 
 extern "C" int rphip_itemknn_fit_ex(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K,
                                     int32_t similarity, double pop_discount, int32_t normalize_X, rphip_model** out) {
+  RP_ENTER(ctx);
   if (!ctx || !X || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   if (similarity != RPHIP_SIM_COSINE && similarity != RPHIP_SIM_CONDITIONAL_PROBABILITY) RP_FAIL(RPHIP_EINVAL, "unknown similarity %d", similarity);
@@ -1248,6 +1251,7 @@ int rp_gram_dense(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t
 
 extern "C" int rphip_model_topk_download(rphip_ctx* ctx, const rphip_model* m, int32_t* idx_host, double* val_host,
                                          int32_t* nnz_host) {
+  RP_ENTER(ctx);
   if (!ctx || !m) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (m->kind != RPHIP_MODEL_TOPK) RP_FAIL(RPHIP_ESTATE, "model is not a neighbour-list model");
   RP_TRY(rp_set_device(ctx));
@@ -1345,6 +1349,7 @@ __global__ void k_unpack_shards(const char* __restrict__ in, long long slot, lon
 }
 
 extern "C" int rphip_itemknn_gather(rphip_ctx* ctx, rphip_comm* comm, const rphip_model* local, const int64_t* row_bounds, rphip_model** out) {
+  RP_ENTER(ctx);
   if (!ctx || !comm || !local || !row_bounds || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   if (local->kind != RPHIP_MODEL_TOPK) RP_FAIL(RPHIP_ESTATE, "not a neighbour-list model");
@@ -1404,10 +1409,12 @@ extern "C" int rphip_itemknn_gather(rphip_ctx* ctx, rphip_comm* comm, const rphi
 
 extern "C" int rphip_model_from_topk_host(rphip_ctx* ctx, int64_t n_items, int32_t K, const int32_t* idx_host,
                                           const double* val_host, const int32_t* nnz_host, rphip_model** out) {
+  RP_ENTER(ctx);
   return rp_model_from_topk(ctx, n_items, K, idx_host, val_host, nnz_host, hipMemcpyHostToDevice, out);
 }
 
 extern "C" int rphip_model_from_topk_device(rphip_ctx* ctx, int64_t n_items, int32_t K, const int32_t* idx_dev,
                                             const double* val_dev, const int32_t* nnz_dev, rphip_model** out) {
+  RP_ENTER(ctx);
   return rp_model_from_topk(ctx, n_items, K, idx_dev, val_dev, nnz_dev, hipMemcpyDeviceToDevice, out);
 }

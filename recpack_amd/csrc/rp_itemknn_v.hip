@@ -722,11 +722,13 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
 
 extern "C" int rphip_itemknn_fit_values(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K, int32_t left_binary,
                                         const double* row_scale_host, rphip_model** out) {
+  RP_ENTER(ctx);
   return rp_fit_values_impl(ctx, X, row_begin, row_end, K, left_binary, row_scale_host, 0, 0.0, 0.0, out);
 }
 
 extern "C" int rphip_itemknn_fit_timedist(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K, int32_t decay_kind,
                                           double decay, double max_distance, const double* row_scale_host, rphip_model** out) {
+  RP_ENTER(ctx);
   if (decay_kind < RPHIP_DECAY_NONE || decay_kind > RPHIP_DECAY_INVERSE) RP_FAIL(RPHIP_EINVAL, "unknown decay function %d", decay_kind);
   if ((decay_kind == RPHIP_DECAY_CONCAVE || decay_kind == RPHIP_DECAY_LOG || decay_kind == RPHIP_DECAY_LINEAR) && !(max_distance > 0.0))
     RP_FAIL(RPHIP_EINVAL, "the %s decay needs max_distance > 0 (got %g)", decay_kind == RPHIP_DECAY_LOG ? "log" : decay_kind == RPHIP_DECAY_LINEAR ? "linear" : "concave",
@@ -736,6 +738,7 @@ extern "C" int rphip_itemknn_fit_timedist(rphip_ctx* ctx, const rphip_csr* X, in
 
 extern "C" int rphip_itemknn_fit_hermann(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K, double now,
                                          rphip_model** out) {
+  RP_ENTER(ctx);
   if (X && X->x_val && !(now > X->val_max_abs)) RP_FAIL(RPHIP_EINVAL, "now = %g must lie after every timestamp (max %g)", now, X->val_max_abs);
   return rp_fit_values_impl(ctx, X, row_begin, row_end, K, 0, nullptr, RPHIP_PAIR_HERMANN, 0.0, now, out);
 }

@@ -1805,7 +1805,7 @@ static double rp_pred_work(const rphip_csr* X, const rphip_model* m, int64_t n_u
 
 // the model's fp16 (kind 1) or int8 (kind 2) copy (first use; a model is immutable once fitted - pruning rebuilds it; a context
 // that asks for the other kind gets it rebuilt)
-static int rp_model_half(rphip_ctx* ctx, rphip_model* m, int kind) {
+static int rp_model_half(rphip_ctx* ctx, const rphip_model* m, int kind) {
   if (m->b16_failed) return RPHIP_OK;
   if (m->B16 && m->b16_kind == kind) return RPHIP_OK;
   hipStream_t st = ctx->stream;
@@ -1915,7 +1915,7 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
   hipEvent_t ev;
   rp_time_begin(ctx, &ev);
   if (use_wave) {
-    rphip_model* mm = const_cast<rphip_model*>(model);  // lazily built, cached acceleration structure
+    const rphip_model* mm = model;  // (its tile offsets are built on first use: mutable members, under the context's lock)
     // 32-bit per-user-scaled sums on 4096-column tiles unless the caller asked for the exact 64-bit sums or the prediction
     // matrix carries values (their products are formed in float64)
     const bool x32 = !Xpred->x_val && ctx->predict_exact64 == 0;
@@ -2028,7 +2028,7 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
   if (const char* e = rp_diag_env("RP_K9_I8_KC")) kc_i8 = std::max(64, atoi(e) / 64 * 64);
   const int Kc = want_i8 && kc_i8 <= 512 && (int64_t)4 * kc_i8 <= (int64_t)P.n_items ? kc_i8 : ((Kp + 24 + 63) / 64) * 64;
   if (model->kind == RPHIP_MODEL_DENSE && ctx->predict_half && Kc <= 512 && (int64_t)4 * Kc <= (int64_t)P.n_items && T <= 15) {
-    rphip_model* mm = const_cast<rphip_model*>(model);
+    const rphip_model* mm = model;  // (the quantised copy is built on first use: mutable members, under the context's lock)
     RP_TRY(rp_model_half(ctx, mm, want_i8 && Kc == kc_i8 ? 2 : 1));
     if (mm->B16) {
       const bool i8 = mm->b16_kind == 2;
@@ -2318,6 +2318,7 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
 extern "C" int rphip_predict_merge_topk(rphip_ctx* ctx, int32_t n_lists, int32_t Kp, int64_t n_users, const int32_t* cand_idx_dev,
                                         const float* cand_val_dev, const int32_t* cand_nnz_dev, int32_t* idx_dev, float* val_dev,
                                         int32_t* nnz_dev) {
+  RP_ENTER(ctx);
   if (!ctx || !cand_idx_dev || !cand_val_dev || !cand_nnz_dev || !idx_dev || !val_dev || !nnz_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (n_lists < 1 || Kp < 1 || Kp > RP_K_MAX || n_users < 0) RP_FAIL(RPHIP_EINVAL, "n_lists %d, Kp %d, n_users %lld", n_lists, Kp, (long long)n_users);
   // the merge keeps the lists' offsets in the selection's 32 spare LDS words (RPS_MISC_INTS - RPS_USER)
@@ -2365,6 +2366,7 @@ __global__ void k_lists_to_users(const char* __restrict__ recv, long long slot_b
 extern "C" int rphip_predict_topk_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip_model* model, const rphip_csr* X, int32_t Kp,
                                        int32_t exclude_history, int64_t* user_begin_out, int64_t* n_users_out, int32_t* idx_dev, float* val_dev,
                                        int32_t* nnz_dev) {
+  RP_ENTER(ctx);
   if (!ctx || !comm || !X || !idx_dev || !val_dev || !nnz_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (Kp < 1 || Kp > RP_K_MAX) RP_FAIL(RPHIP_ELIMIT, "Kp=%d outside 1..%d", Kp, RP_K_MAX);
   RP_TRY(rp_set_device(ctx));
@@ -2439,24 +2441,28 @@ extern "C" int rphip_predict_topk_dist(rphip_ctx* ctx, rphip_comm* comm, const r
 extern "C" int rphip_predict_topk_dev(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin,
                                       int64_t user_end, int32_t Kp, int32_t exclude_history, int32_t* idx_dev, float* val_dev,
                                       int32_t* nnz_dev) {
+  RP_ENTER(ctx);
   return rp_predict_topk_impl(ctx, model, Xpred, user_begin, user_end, Kp, exclude_history, nullptr, idx_dev, val_dev, nnz_dev);
 }
 
 extern "C" int rphip_predict_topk_filtered_dev(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin,
                                                int64_t user_end, int32_t Kp, int32_t exclude_history, const uint8_t* item_keep_dev,
                                                int32_t* idx_dev, float* val_dev, int32_t* nnz_dev) {
+  RP_ENTER(ctx);
   return rp_predict_topk_impl(ctx, model, Xpred, user_begin, user_end, Kp, exclude_history, item_keep_dev, idx_dev, val_dev, nnz_dev);
 }
 
 extern "C" int rphip_predict_topk(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin,
                                   int64_t user_end, int32_t Kp, int32_t exclude_history, int32_t* idx_host, float* val_host,
                                   int32_t* nnz_host) {
+  RP_ENTER(ctx);
   return rphip_predict_topk_filtered(ctx, model, Xpred, user_begin, user_end, Kp, exclude_history, nullptr, idx_host, val_host, nnz_host);
 }
 
 extern "C" int rphip_predict_topk_filtered(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin,
                                            int64_t user_end, int32_t Kp, int32_t exclude_history, const uint8_t* item_keep_host,
                                            int32_t* idx_host, float* val_host, int32_t* nnz_host) {
+  RP_ENTER(ctx);
   RP_TRY(rp_pred_check(ctx, model, Xpred, user_begin, user_end));
   if (!idx_host || !val_host || !nnz_host) RP_FAIL(RPHIP_EINVAL, "NULL output");
   if (Kp < 1 || Kp > RP_K_MAX) RP_FAIL(RPHIP_ELIMIT, "Kp=%d outside 1..%d", Kp, RP_K_MAX);
@@ -2486,6 +2492,7 @@ extern "C" int rphip_predict_topk_filtered(rphip_ctx* ctx, const rphip_model* mo
 
 extern "C" int rphip_predict_full_count(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin,
                                         int64_t user_end, int64_t* row_nnz_host, int64_t* total_out) {
+  RP_ENTER(ctx);
   RP_TRY(rp_pred_check(ctx, model, Xpred, user_begin, user_end));
   if (!row_nnz_host || !total_out) RP_FAIL(RPHIP_EINVAL, "NULL output");
   RP_TRY(rp_set_device(ctx));
@@ -2513,6 +2520,7 @@ extern "C" int rphip_predict_full_count(rphip_ctx* ctx, const rphip_model* model
 
 extern "C" int rphip_predict_full_fill(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin,
                                        int64_t user_end, const int64_t* indptr_host, int32_t* indices_host, double* data_host) {
+  RP_ENTER(ctx);
   RP_TRY(rp_pred_check(ctx, model, Xpred, user_begin, user_end));
   if (!indptr_host) RP_FAIL(RPHIP_EINVAL, "indptr is NULL");
   RP_TRY(rp_set_device(ctx));

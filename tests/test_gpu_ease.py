@@ -490,6 +490,40 @@ def test_ease_l2_sweep_from_cached_gram(hip):
         g.fit(EASE(l2=1.0))
 
 
+def test_predict_from_two_threads(hip):
+    """Two threads predict on ONE freshly fitted model through one context at the same time: the model's acceleration structures
+    (K9's quantised copy of B, K8's tile offsets) are built on first use - under the context's lock since round 5 (every entry
+    point holds it: calls on a context are serialised) - and both threads must get the single-threaded result."""
+    import threading
+
+    from recpack_amd.synth import powerlaw_csr
+
+    _lib, ctx = hip
+    X = powerlaw_csr(7000, 2400, 0.01, seed=93).to_scipy()
+    dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
+    for fit in (lambda: _lib.ease_fit(ctx, dX, 30.0, 0.0), lambda: _lib.itemknn_fit(ctx, dX, 50)):
+        want = _lib.predict_topk(ctx, fit(), dX, 40, exclude_history=True)
+        for _ in range(3):
+            m = fit()  # (fresh: nothing built yet)
+            got, err = [None, None], []
+            gate = threading.Barrier(2)
+
+            def work(k):
+                try:
+                    gate.wait()
+                    got[k] = _lib.predict_topk(ctx, m, dX, 40, exclude_history=True)
+                except Exception as e:  # noqa: BLE001
+                    err.append(e)
+
+            ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            assert not err, err
+            for g in got:
+                for a, b in zip(g, want):
+                    np.testing.assert_array_equal(a, b)
+
+
 def test_predict_two_pass_equals_one_pass(hip):
     """K9's two passes (fp16 or int8 rows for a candidate list, exact f32 scores of the candidates, a proof per user, the one-pass kernel
     for users without one - options predict_half, predict_int8) give the one-pass kernel's top-Kp bit for bit: fitted models, several Kp, history
