@@ -583,13 +583,37 @@ struct rp_merge_params {
 
 constexpr int RP_MERGE_THREADS = 256;  // a row's T*K candidates are few: small workgroups, many per CU
 
+// The per-tile lists of one row where they lie in memory (large K, round 5): slot w of the row's concatenated lists is entry
+// w - off[t] of tile t's list - the candidates are not staged in LDS (T * K * 8 bytes: 160 KB at K = 5000 and four tiles), only the
+// selection's own list of slot numbers is (2 bytes per candidate: T * K < 32 768).  A key costs two loads more than from LDS; the
+// lists of a row are L2-resident after the first radix level.
+struct rp_glist_src {
+  const int32_t* idx_;   // the row's lists: tile t at idx_ + t * K
+  const uint32_t* cnt_;
+  const int* off;        // [T + 1] in LDS
+  const double* inv_deg;
+  int T, K, n, key_pow;
+  __device__ __forceinline__ int at(int w) const {
+    int t = 0;
+    while (t + 1 < T && w >= off[t + 1]) ++t;
+    return t * K + (w - off[t]);
+  }
+  __device__ __forceinline__ bool valid(int w) const { return w < n; }
+  __device__ __forceinline__ uint64_t key(int w) const {
+    const int a = at(w);
+    return rp_fit_key(cnt_[a], inv_deg[idx_[a]], key_pow);
+  }
+  __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)idx_[at(w)]; }
+};
+
+template <bool GLOBAL>
 __global__ void __launch_bounds__(RP_MERGE_THREADS) k_itemknn_merge(rp_merge_params P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int T = P.n_tiles, K = P.K;
   const int cap = T * K;
   int32_t* lcol = reinterpret_cast<int32_t*>(smem);
   uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 4);
-  rp_select_smem sel = rp_select_carve(smem + (size_t)cap * 8, cap, RP_MERGE_THREADS / 64);
+  rp_select_smem sel = rp_select_carve(smem + (GLOBAL ? 0 : (size_t)cap * 8), cap, RP_MERGE_THREADS / 64);
   int* s_off = &sel.misc[RPS_USER];  // n_tiles + 1 <= 16 entries
   const int tid = threadIdx.x;
   for (int rl = blockIdx.x; rl < P.n_rows; rl += gridDim.x) {
@@ -604,26 +628,41 @@ __global__ void __launch_bounds__(RP_MERGE_THREADS) k_itemknn_merge(rp_merge_par
     }
     __syncthreads();
     const int n = s_off[T];
-    for (int t = 0; t < T; ++t) {
-      const int cn = s_off[t + 1] - s_off[t];
-      const int64_t src = ((int64_t)rl * T + t) * K;
-      for (int k = tid; k < cn; k += RP_MERGE_THREADS) {
-        lcol[s_off[t] + k] = P.cand_idx[src + k];
-        lcnt[s_off[t] + k] = P.cand_cnt[src + k];
-      }
-    }
-    __syncthreads();
-    rp_list_src src{lcol, lcnt, P.inv_deg, n, P.key_pow};
-    const int kp = rp_select_topk<RP_MERGE_THREADS>(src, n, K, sel);
     int32_t* oi = P.out_idx + (int64_t)rl * K;
     double* ov = P.out_val + (int64_t)rl * K;
     const double ci = (double)P.deg[P.row_begin + rl];
-    rp_select_emit<RP_MERGE_THREADS>(n, sel, [&](int pos, int w) {
-      const int j = lcol[w];
-      oi[pos] = j;
-      ov[pos] = (P.key_pow == 2) ? (double)lcnt[w] / sqrt(ci * (double)P.deg[j]) : ((double)lcnt[w] * P.inv_deg[j]) / ci;
-    });
-    if (tid == 0) P.out_nnz[rl] = kp;
+    if constexpr (GLOBAL) {
+      const int32_t* gi = P.cand_idx + (int64_t)rl * T * K;
+      const uint32_t* gc = P.cand_cnt + (int64_t)rl * T * K;
+      rp_glist_src src{gi, gc, s_off, P.inv_deg, T, K, n, P.key_pow};
+      const int kp = rp_select_topk<RP_MERGE_THREADS>(src, n, K, sel);
+      rp_select_emit<RP_MERGE_THREADS>(n, sel, [&](int pos, int w) {
+        const int a = src.at(w);
+        const int j = gi[a];
+        const uint32_t c = gc[a];
+        oi[pos] = j;
+        ov[pos] = (P.key_pow == 2) ? (double)c / sqrt(ci * (double)P.deg[j]) : ((double)c * P.inv_deg[j]) / ci;
+      });
+      if (tid == 0) P.out_nnz[rl] = kp;
+    } else {
+      for (int t = 0; t < T; ++t) {
+        const int cn = s_off[t + 1] - s_off[t];
+        const int64_t src = ((int64_t)rl * T + t) * K;
+        for (int k = tid; k < cn; k += RP_MERGE_THREADS) {
+          lcol[s_off[t] + k] = P.cand_idx[src + k];
+          lcnt[s_off[t] + k] = P.cand_cnt[src + k];
+        }
+      }
+      __syncthreads();
+      rp_list_src src{lcol, lcnt, P.inv_deg, n, P.key_pow};
+      const int kp = rp_select_topk<RP_MERGE_THREADS>(src, n, K, sel);
+      rp_select_emit<RP_MERGE_THREADS>(n, sel, [&](int pos, int w) {
+        const int j = lcol[w];
+        oi[pos] = j;
+        ov[pos] = (P.key_pow == 2) ? (double)lcnt[w] / sqrt(ci * (double)P.deg[j]) : ((double)lcnt[w] * P.inv_deg[j]) / ci;
+      });
+      if (tid == 0) P.out_nnz[rl] = kp;
+    }
   }
 }
 
@@ -937,9 +976,11 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   // (round 4) one column tile - up to RP_TILE_MAX items - takes ANY K, as the reference does (recpack/algorithms/base.py:302-304,
   // recpack/util.py:63-66): the selection runs on the tile itself and writes the row.  With several tiles a row's per-tile
   // candidate lists meet in the LDS of the merge: K <= RP_K_MAX there.
-  if (Keff > RP_K_MAX && T > 1)
-    RP_FAIL(RPHIP_ELIMIT, "effective K=%d exceeds the supported maximum %d for %lld items (%d column tiles; any K up to %d items)", Keff, RP_K_MAX,
-            (long long)X->n_items, T, RP_TILE_MAX);
+  // (round 5) ... any K with K x tiles < 32 768 (the selection's list of slot numbers): the merge reads the per-tile lists where
+  // they lie when they do not fit the LDS (k_itemknn_merge<true>) - K = 8 191 at 100 000 items, 4 095 at 200 000
+  if (T > 1 && (int64_t)T * Keff >= RPS_FLAG)
+    RP_FAIL(RPHIP_ELIMIT, "effective K=%d with %d column tiles (%lld items): K x tiles must stay below %d (any K up to %d items)", Keff, T,
+            (long long)X->n_items, RPS_FLAG, RP_TILE_MAX);
 
   K = Keff;  // the model's row stride; rphip_model_info reports it
   if (T > 15) RP_FAIL(RPHIP_ELIMIT, "%d column tiles (n_items=%lld) exceed the supported 15", T, (long long)X->n_items);
@@ -1178,15 +1219,22 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
       RP_HIP(hipGetLastError());
       rp_time_end(ctx, ev, RPHIP_T_TOPK_MERGE, 16.0 * (double)n_rows * T * Keff);
     } else {
-    const size_t mlds = (size_t)T * Keff * 8 + rp_select_smem_bytes(T * Keff, RP_MERGE_THREADS / 64);
+    const size_t sel_lds = rp_select_smem_bytes(T * Keff, RP_MERGE_THREADS / 64);
+    const bool in_lds = (size_t)T * Keff * 8 + sel_lds <= (size_t)160 * 1024;
+    const size_t mlds = in_lds ? (size_t)T * Keff * 8 + sel_lds : sel_lds;
     if (mlds > 160 * 1024 || T * Keff >= RPS_FLAG) {
       rphip_model_destroy(m);
       RP_FAIL(RPHIP_ELIMIT, "K=%d with %d column tiles needs %zu bytes of LDS for the merge", K, T, mlds);
     }
-    RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
     const int mper = std::max<int>(1, std::min<int>(8, (int)((160 * 1024) / mlds)));
     const int mg = (int)std::min<int64_t>(n_rows, (int64_t)ctx->n_cu * mper);
-    hipLaunchKernelGGL(k_itemknn_merge, dim3(mg), dim3(RP_MERGE_THREADS), mlds, st, M);
+    if (in_lds) {
+      RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_merge<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+      hipLaunchKernelGGL(k_itemknn_merge<false>, dim3(mg), dim3(RP_MERGE_THREADS), mlds, st, M);
+    } else {  // (the lists stay in memory: large K)
+      RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_merge<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+      hipLaunchKernelGGL(k_itemknn_merge<true>, dim3(mg), dim3(RP_MERGE_THREADS), mlds, st, M);
+    }
     RP_HIP(hipGetLastError());
     rp_time_end(ctx, ev, RPHIP_T_TOPK_MERGE, 16.0 * (double)n_rows * T * Keff);
     }

@@ -123,8 +123,8 @@ def test_post_condition_warnings():
 
 
 def test_k_limit_raises_before_upload():
-    """K beyond RP_K_MAX = 2048 with more items than one column tile holds (a documented deviation: the reference takes any K)
-    raises ValueError on the host; up to RP_TILE_MAX items any K goes to the device (round 4)."""
+    """What is left of the K limit (a documented deviation: the reference takes any K) raises ValueError on the host: K x column tiles
+    >= 32 768 for the binary fit over several tiles (round 5; any K on one tile since round 4), K > RP_K_MAX = 2048 with normalize_X."""
     import scipy.sparse as sp
     import torch
 
@@ -134,8 +134,11 @@ def test_k_limit_raises_before_upload():
 
     X = sp.random(50, RP_TILE_MAX + 400, density=0.002, format="csr", random_state=0)
     X.data[:] = 1
-    with pytest.raises(ValueError, match=str(RP_K_MAX)):
-        recpack_amd.ItemKNN(K=RP_K_MAX + 1).fit(X)
+    with pytest.raises(ValueError, match="32768"):
+        recpack_amd.ItemKNN(K=16384).fit(X)  # two column tiles: 2 x 16 384 slots
+    if not torch.cuda.is_available():  # below that no host-side limit: the call reaches the (absent) device
+        with pytest.raises(RecpackHipError):
+            recpack_amd.ItemKNN(K=RP_K_MAX + 1).fit(X)
     Xs = sp.random(50, 3000, density=0.01, format="csr", random_state=0)
     Xs.data[:] = 1
     with pytest.raises(ValueError, match=str(RP_K_MAX)):

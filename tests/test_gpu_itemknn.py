@@ -662,9 +662,26 @@ def test_fit_any_k_on_one_tile(hip):
     got = algo.predict(X[:300])
     want = onp.predict_full(X[:300], S)
     assert abs(got - want).max() <= 2e-7 * abs(want).max()
-    Xw = powerlaw_csr(200, 26000, 0.002, seed=42).to_scipy()  # two column tiles: the limit stands
+    Xw = powerlaw_csr(200, 26000, 0.002, seed=42).to_scipy()  # two column tiles: K x tiles < 32 768 is what is left of the limit
     with pytest.raises(ValueError):
-        recpack_amd.ItemKNN(K=3000).fit(Xw)
+        recpack_amd.ItemKNN(K=17000).fit(Xw)
+
+
+def test_fit_any_k_over_several_tiles(hip):
+    """ItemKNN(K=5000) on 60 000 x 40 000: two column tiles, a row's per-tile lists (2 x 5 000 candidates)
+    merged where they lie in memory (k_itemknn_merge<true>); K = 2 500 on the same matrix merges in LDS; both equal the oracle
+    (recpack/algorithms/base.py:302-304, recpack/util.py:63-66: the reference takes any K)."""
+    from recpack_amd.synth import powerlaw_csr
+
+    X = powerlaw_csr(60000, 40000, 0.002, seed=43).to_scipy()
+    for K in (5000, 2500):
+        _, m, idx, val, nnz = fit_arrays(hip, X, K)
+        assert m.K == K
+        assert_same_as_oracle(idx, val, nnz, onp.itemknn_fit(X, K))
+    import recpack_amd
+
+    S = recpack_amd.ItemKNN(K=5000).fit(X).similarity_matrix_
+    assert S.shape == (40000, 40000) and 2048 < S.getnnz(axis=1).max() <= 5000
 
 
 @pytest.mark.parametrize("nproc,shape", [(2, (20000, 30000, 0.0015, 50)), (3, (6000, 900, 0.01, 20))])
