@@ -1413,6 +1413,9 @@ static int rp_launch_hp16w(rphip_ctx* ctx, rp_hp_args& q, hipStream_t st) {
   const long long gx = q.g.N / GT, gy = rp_cdiv(q.g.M, 256);
   if (ctx->gemm_xcd_block > 0 && q.g.tri != 3 && gx * gy >= 512) {
     int R = ctx->gemm_xcd_block;
+    // (the default, 4, is a rule: the factorisation's trailing updates - lower-triangular products whose A and B planes are one
+    // workspace - measured best on 16 x 2 blocks (969 against 977 ms of Cholesky phase), everything else on 4 x 8)
+    if (R == 4 && q.g.tri == 1) R = 16;
     while (R > 1 && 32 / R < 2 && gx >= 2) R >>= 1;
     while (32 / R > gx && R < 32) R <<= 1;  // (narrow products: taller blocks)
     q.xb = R;
