@@ -5,6 +5,7 @@
  *   rphip_comm_loopback_create   one rank of an N-rank run measured alone on one GPU (tools/dist_rank_emulate.py)
  *   rphip_ease_fit_dist_stats    byte / flop counters of the last distributed fit (tests: memory bound of the sharded solve)
  *   rphip_potrf_trtri_128        the 128 x 128 diagonal-block kernel alone (tools/potrf_check.py, tests/test_gpu_ease.py)
+ *   rphip_model_adopt_gather     hand a pending panel gather to another model (tools/dist_rank_emulate.py)
  *   rphip_gemm_nt_f32_ex         the NT product with the triangular K clipping of the solve (tests/test_gpu_ease.py)
  * The environment switches RP_CHOL_TRACE, RP_INV_TRACE, RP_CHOL_MEASURE_SCALES, RP_N22_PLANES, RP_EASE_SCALE_ROWS, RP_K9_I8_KC
  * exist only in the diagnostic build (make -C recpack_amd/csrc diag -> librecpack_hip_diag.so, selected with RECPACK_HIP_LIB).
@@ -37,6 +38,11 @@ int rphip_gemm_nt_f32_ex(rphip_ctx* ctx, int64_t M, int64_t N, int64_t k_begin, 
                          int64_t lda, const float* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc, int32_t k_from_row,
                          int32_t k_from_col, int64_t m_off, int64_t n_off, int32_t lower_only);
 
+
+/* `dst` takes over the pending f32 gather of `src` (a model of rphip_ease_model_allgather whose f32 rows are still arriving on their
+ * own stream): tools/dist_rank_emulate.py predicts on the real matrix of a single-GPU fit while the emulated rank's gather - of noise -
+ * is in flight, and that predict's rescoring has to wait for it as the rank's own would. */
+int rphip_model_adopt_gather(rphip_model* dst, rphip_model* src);
 
 #ifdef __cplusplus
 }

@@ -126,6 +126,7 @@ PROTOTYPES = {
 }
 # include/recpack_hip_diag.h: measuring instruments and test hooks (tools/, tests/), not the drop-in boundary
 DIAG_PROTOTYPES = {
+    "rphip_model_adopt_gather": (C.c_int, [_p, _p]),
     "rphip_potrf_trtri_128": (C.c_int, [_p, _p, _i64, _p, _p]),
     "rphip_gemm_nt_f32_ex": (C.c_int, [_p, _i64, _i64, _i64, _i64, C.c_float, _p, _i64, _p, _i64, C.c_float, _p, _i64, _i32, _i32, _i64, _i64, _i32]),
     "rphip_comm_loopback_create": (C.c_int, [_p, _i32, _i32, C.c_double, C.c_double, _pp]),
@@ -480,6 +481,10 @@ class Model:
         out = np.empty((self.n_items, self.n_items), dtype=np.float32)
         check(self.ctx.lib.rphip_model_dense_download(self.ctx.handle, self.handle, _np_ptr(out)))
         return out
+
+    def adopt_gather(self, other: "Model"):
+        """(diagnostic: include/recpack_hip_diag.h) take over the pending panel gather of `other` - tools/dist_rank_emulate.py."""
+        check(self.ctx.lib.rphip_model_adopt_gather(self.handle, other.handle))
 
     def close(self):
         if getattr(self, "handle", None):

@@ -197,8 +197,17 @@ struct rphip_model {
   mutable float* b16_delta = nullptr;
   mutable float* b16_rowmax = nullptr;
   mutable bool b16_failed = false;  // the copy could not be allocated: the one-pass kernel is used
-  int64_t empty_rows = -1;  // rows without any stored similarity (-1: not counted)
+  mutable int64_t empty_rows = -1;  // rows without any stored similarity (-1: not counted)
+  // rphip_ease_model_allgather (round 5): the int8 rows of the gathered model are complete when the call returns, its f32 rows
+  // arrive on a stream of their own behind it - whoever reads B first waits for gather_ev (rp_model_gather_wait)
+  mutable hipEvent_t gather_ev = nullptr;
+  mutable hipStream_t gather_stream = nullptr;
+  mutable void* gather_tmp[2] = {nullptr, nullptr};  // the f32 strips' staging, released with the event
 };
+
+// B of a gathered model is about to be read: on_stream = by launches on the context's stream (they are ordered behind the gather),
+// otherwise by the host (the call waits).  A no-op for every other model.   (rp_ease_dist.hip)
+int rp_model_gather_wait(rphip_ctx* ctx, const rphip_model* m, bool on_stream);
 
 // ---- helpers (rp_api.hip) ------------------------------------------------------------------------
 int rp_scratch(rphip_ctx* ctx, int slot, size_t bytes, void** out);

@@ -2655,6 +2655,7 @@ extern "C" int rphip_model_dense_changed(rphip_ctx* ctx, rphip_model* m) {
   if (!ctx || !m) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (m->kind != RPHIP_MODEL_DENSE || !m->B) RP_FAIL(RPHIP_ESTATE, "not a dense model");
   RP_TRY(rp_set_device(ctx));
+  RP_TRY(rp_model_gather_wait(ctx, m, false));
   RP_HIP(hipStreamSynchronize(ctx->stream));
   rp_dev_free(ctx, m->B16);
   rp_dev_free(ctx, m->b16_delta);
@@ -2674,6 +2675,7 @@ extern "C" int rphip_model_dense_prune(rphip_ctx* ctx, rphip_model* m, int64_t k
   if (m->n_cols > 0) RP_FAIL(RPHIP_ESTATE, "the model holds a slab of columns: prune the whole matrix");
   if (keep < 0) RP_FAIL(RPHIP_EINVAL, "keep must be >= 0");
   RP_TRY(rp_set_device(ctx));
+  RP_TRY(rp_model_gather_wait(ctx, m, true));
   hipStream_t st = ctx->stream;
   const int n = (int)m->n_items;
   unsigned long long* hist = nullptr;
@@ -2771,6 +2773,7 @@ extern "C" int rphip_model_dense_download(rphip_ctx* ctx, const rphip_model* m, 
   if (m->kind != RPHIP_MODEL_DENSE) RP_FAIL(RPHIP_ESTATE, "model is not dense");
   if (m->n_cols > 0) RP_FAIL(RPHIP_ESTATE, "the model holds a slab of columns (rphip_model_dense_layout), not the whole matrix");
   RP_TRY(rp_set_device(ctx));
+  RP_TRY(rp_model_gather_wait(ctx, m, true));
   const size_t n = (size_t)m->n_items;
   hipEvent_t ev;
   rp_time_begin(ctx, &ev);
@@ -2784,6 +2787,11 @@ extern "C" int rphip_model_dense_download(rphip_ctx* ctx, const rphip_model* m, 
 extern "C" int rphip_model_dense_device(const rphip_model* m, void** B_dev, int64_t* n_items, int64_t* ld) {
   if (!m) RP_FAIL(RPHIP_EINVAL, "model is NULL");
   if (m->kind != RPHIP_MODEL_DENSE) RP_FAIL(RPHIP_ESTATE, "model is not dense");
+  if (m->gather_ev && m->ctx) {  // (the caller will read the matrix outside the library's stream: the gather has to be over)
+    std::unique_lock<std::recursive_mutex> lk(m->ctx->api_mu);
+    RP_TRY(rp_set_device(m->ctx));
+    RP_TRY(rp_model_gather_wait(m->ctx, m, false));
+  }
   if (B_dev) *B_dev = m->B;
   if (n_items) *n_items = m->n_items;
   if (ld) *ld = m->ld;

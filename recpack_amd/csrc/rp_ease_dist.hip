@@ -174,8 +174,11 @@ __global__ void k_comm_noise(float* __restrict__ p, long long n, unsigned seed) 
     p[i] = ((float)(h & 0xffffu) - 32768.0f) * (1.0f / 33554432.0f);
   }
 }
-static void rp_loop_delay(rphip_comm* c, int64_t bytes, hipStream_t st) {
-  const double sec = c->loop_lat + (c->loop_bw > 0.0 ? (double)bytes / c->loop_bw : 0.0);
+// `landed` = bytes the emulation has just written in place of the peers' incoming data: on a real node those writes happen WHILE the
+// link is busy, so the time they took here (priced at 2.5 TB/s, a memset beside other traffic) is taken off the link time
+static void rp_loop_delay(rphip_comm* c, int64_t bytes, hipStream_t st, int64_t landed = 0) {
+  double sec = c->loop_lat + (c->loop_bw > 0.0 ? (double)bytes / c->loop_bw : 0.0);
+  if (landed > 0) sec = std::max(c->loop_lat, sec - (double)landed / 2.5e12);
   hipLaunchKernelGGL(k_comm_delay, dim3(1), dim3(1), 0, st, (long long)(sec * 1e8));
 }
 static void rp_loop_noise(void* p, int64_t bytes, hipStream_t st, unsigned seed) {
@@ -262,9 +265,17 @@ int rp_comm_all_gather(rphip_comm* c, const void* send, void* recv, int64_t byte
     return RPHIP_OK;
   }
   if (c->is_loop) {  // every slot takes this rank's own part: data of the right kind and size
-    for (int p = 0; p < c->world; ++p)
-      RP_HIP(hipMemcpyAsync((char*)recv + (size_t)p * bytes_per_rank, send, (size_t)bytes_per_rank, hipMemcpyDeviceToDevice, st));
-    rp_loop_delay(c, bytes_per_rank, st);  // (W - 1 parts over W - 1 links at once)
+    // (parts of 32 MiB and more - the strips of a panel gather, whose contents nobody computes with: the other ranks' slots are WRITTEN
+    // only, as the peers' incoming xGMI writes would - eight device copies per strip read 40 GB more than a real gather does, beside
+    // a predict pass that is bound by HBM bandwidth)
+    const bool big = bytes_per_rank >= ((int64_t)32 << 20);
+    for (int p = 0; p < c->world; ++p) {
+      if (big && p != c->rank)
+        RP_HIP(hipMemsetAsync((char*)recv + (size_t)p * bytes_per_rank, 0, (size_t)bytes_per_rank, st));
+      else
+        RP_HIP(hipMemcpyAsync((char*)recv + (size_t)p * bytes_per_rank, send, (size_t)bytes_per_rank, hipMemcpyDeviceToDevice, st));
+    }
+    rp_loop_delay(c, bytes_per_rank, st, big ? bytes_per_rank * (c->world - 1) : 0);  // (W - 1 parts over W - 1 links at once)
     RP_HIP(hipGetLastError());
     return RPHIP_OK;
   }
@@ -980,6 +991,92 @@ __global__ void k_unpack_panels(const float* __restrict__ recv, long long slot_f
   }
 }
 
+// ---- the int8 rows of the gathered model (phase 1 of rphip_ease_model_allgather) ------------------------------------------------------
+// pm[i] = largest |B[i][c]| over this rank's item columns c < ncl of row i < n_items (0 for the padding rows)
+__global__ void __launch_bounds__(256) k_panel_rowmax(const float* __restrict__ B, long long ld, int n_pad, int n_items, int ncl, float* __restrict__ pm) {
+  __shared__ float red[4];
+  for (int i = blockIdx.x; i < n_pad; i += gridDim.x) {
+    float m = 0.0f;
+    if (B && i < n_items) {
+      const float* row = B + (long long)i * ld;
+      for (int j = threadIdx.x * 4; j < ncl; j += 1024) {  // (ld is a multiple of 128: whole quads inside the row; columns >= ncl are padding = 0)
+        const float4 v = *reinterpret_cast<const float4*>(row + j);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+      }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) pm[i] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  }
+}
+// out[i] = max over the ranks' parts; with_scale: scale[i] = out[i] / 127 (k_dense_to_i8's step; 0 for an all-zero or non-finite row)
+__global__ void k_max_over_ranks(const float* __restrict__ g, int n, int W, float* __restrict__ out, float* __restrict__ scale, int with_scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float m = 0.0f;
+  for (int r = 0; r < W; ++r) m = fmaxf(m, g[(long long)r * n + i]);
+  out[i] = m;
+  if (with_scale) scale[i] = (m > 0.0f && m < 3.0e38f) ? m / 127.0f : 0.0f;
+}
+// rows [0, rows) of this rank's panels (cols columns, the first ncl of them items) quantised with the rows' global maxima, exactly as
+// k_dense_to_i8 does: q = rint(b * 127 / max) clamped to +-127; err[i] = the row's largest |q s - b| over this rank's columns
+// (3e38 for a non-finite row).  Rows >= n_real are padding (zeros).
+__global__ void __launch_bounds__(256) k_panel_quantise(const float* __restrict__ B, long long ld, int rows, int cols, int ncl, int n_real,
+                                                        const float* __restrict__ rowmax, int8_t* __restrict__ Q, long long ldq, float* __restrict__ err) {
+  __shared__ float red[4];
+  for (int i = blockIdx.x; i < rows; i += gridDim.x) {
+    const float* row = B + (long long)i * ld;
+    int8_t* out = Q + (long long)i * ldq;
+    const float m = rowmax[i];
+    const bool ok = m > 0.0f && m < 3.0e38f && i < n_real;
+    const float s = ok ? m / 127.0f : 0.0f, inv = ok ? 127.0f / m : 0.0f;
+    float e = 0.0f;
+    for (int j = threadIdx.x * 16; j < cols; j += 4096) {
+      uint32_t w[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(row + j + 4 * g);
+        const float x[4] = {v.x, v.y, v.z, v.w};
+        uint32_t pk = 0u;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const bool item = j + 4 * g + c < ncl;
+          const float qf = item ? fminf(fmaxf(rintf(x[c] * inv), -127.0f), 127.0f) : 0.0f;
+          if (item) e = fmaxf(e, fabsf(qf * s - x[c]));
+          pk |= ((uint32_t)(int)qf & 0xffu) << (8 * c);
+        }
+        w[g] = pk;
+      }
+      *reinterpret_cast<uint4*>(out + j) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) e = fmaxf(e, __shfl_xor(e, d));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0 && i < n_real) err[i] = (m < 3.0e38f) ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : 3.0e38f;
+  }
+}
+// k_unpack_panels for int8 strips (16 bytes per access)
+__global__ void k_unpack_panels_i8(const int8_t* __restrict__ recv, long long slot_bytes, int ldl, int rows, int nb, int W, int np, int8_t* __restrict__ B,
+                                   long long ldB, long long r0) {
+  const int c16 = nb >> 4;
+  const int q = blockIdx.z, a = blockIdx.y;
+  const int p = rp_cyc_panel(a, q, W);
+  if (p >= np) return;
+  const int8_t* src = recv + (long long)q * slot_bytes + (long long)a * nb;
+  int8_t* dst = B + r0 * ldB + (long long)p * nb;
+  const long long total = (long long)rows * c16;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long i = e / c16;
+    const int c = (int)(e % c16) * 16;
+    *reinterpret_cast<uint4*>(dst + i * ldB + c) = *reinterpret_cast<const uint4*>(src + i * ldl + c);
+  }
+}
+
 // While 3 n^2 floats fit a GPU (B, its fp16 copy, a staging strip) the fastest multi-GPU predict is the single-GPU one on a share
 // of the USERS: every rank gathers all panels (n^2 * 4 * (W - 1) / W bytes in over W - 1 links: 50 ms at 100 000 items and 100 GB/s
 // per link) and scores its own users against the whole of B - K9's two passes with their full-width rows, no per-rank candidate lists
@@ -1048,23 +1145,103 @@ extern "C" int rphip_ease_model_allgather(rphip_ctx* ctx, rphip_comm* comm, cons
   }
   hipEvent_t ev;
   rp_time_begin(ctx, &ev);
+  // ---- phase 1 (round 5): the INT8 rows K9's first pass streams - a quarter of the bytes - complete when this call returns.
+  // Row maxima over the ranks' columns (one all-gather of n floats per rank), every rank quantises its own panels with the row's
+  // scale exactly as k_dense_to_i8 does on one GPU (q = rint(b * 127 / max), the row's largest |q s - b| measured), the int8 strips
+  // travel like the f32 ones.  The emulation of round 4 had the predict of a rank wait 0.10 s for 40 GB of f32 panels that its
+  // first pass then read as int8.
+  const bool q8 = ctx->predict_half && ctx->predict_int8 && (n_pad % 16) == 0 && W > 1;
+  if (q8) {
+    const size_t nB = (size_t)n_pad;
+    float *pm = nullptr, *gm = nullptr;  // partial [2][n]: row max, then quantisation error; gathered [W][2][n]
+    int r8 = rp_dev_alloc(ctx, nB * n_pad, (void**)&m->B16);
+    if (r8 == RPHIP_OK) r8 = rp_dev_alloc(ctx, nB * 4, (void**)&m->b8_scale);
+    if (r8 == RPHIP_OK) r8 = rp_dev_alloc(ctx, nB * 4, (void**)&m->b16_delta);
+    if (r8 == RPHIP_OK) r8 = rp_dev_alloc(ctx, nB * 4, (void**)&m->b16_rowmax);
+    if (r8 == RPHIP_OK) r8 = rp_dev_alloc(ctx, nB * 4, (void**)&pm);
+    if (r8 == RPHIP_OK) r8 = rp_dev_alloc(ctx, nB * 4 * W, (void**)&gm);
+    // (these are small beside B and its staging, which the ranks have agreed on: a failure here is reported, not negotiated)
+    if (r8 != RPHIP_OK) {
+      rp_dev_free(ctx, pm);
+      rp_dev_free(ctx, gm);
+      rp_dev_free(ctx, sendb);
+      rp_dev_free(ctx, recvb);
+      rphip_model_destroy(m);
+      return r8;
+    }
+    const int ncl = local ? (int)local->n_cols : 0;  // items among this rank's local columns (a prefix)
+    const int rgrid = (int)std::min<long long>(n_pad, (long long)ctx->n_cu * 16);
+    hipLaunchKernelGGL(k_panel_rowmax, dim3(rgrid), dim3(256), 0, st, local ? local->B : nullptr, local ? (long long)local->ld : 0, (int)n_pad, (int)n_items, ncl, pm);
+    rc = rp_comm_all_gather(comm, pm, gm, (int64_t)nB * 4, st);
+    hipLaunchKernelGGL(k_max_over_ranks, dim3((unsigned)rp_cdiv(n_pad, 256)), dim3(256), 0, st, gm, (int)n_pad, W, m->b16_rowmax, m->b8_scale, 1);
+    hipMemsetAsync(pm, 0, nB * 4, st);
+    // int8 strips: four times the rows of an f32 strip in the same staging
+    const long long strip8 = std::min<long long>(n_pad, strip * 4);
+    for (long long r0 = 0; r0 < n_pad && rc == RPHIP_OK; r0 += strip8) {
+      const long long rows = std::min(strip8, n_pad - r0);
+      if (nl < nl_max || !local) hipMemsetAsync(sendb, 0, (size_t)strip8 * ldl, st);
+      if (local && nl > 0)
+        hipLaunchKernelGGL(k_panel_quantise, dim3((unsigned)std::min<long long>(rows, (long long)ctx->n_cu * 16)), dim3(256), 0, st, local->B + r0 * local->ld,
+                           (long long)local->ld, (int)rows, nl * nb, ncl, (int)std::max<long long>(0, std::min<long long>(rows, n_items - r0)), m->b16_rowmax + r0,
+                           reinterpret_cast<int8_t*>(sendb), (long long)ldl, pm + r0);
+      rc = rp_comm_all_gather(comm, sendb, recvb, strip8 * ldl, st);
+      if (rc != RPHIP_OK) break;
+      hipLaunchKernelGGL(k_unpack_panels_i8, dim3((unsigned)std::min<long long>(256, rp_cdiv(rows * (nb / 16), 256)), nl_max, W), dim3(256), 0, st,
+                         reinterpret_cast<const int8_t*>(recvb), strip8 * ldl, ldl, (int)rows, nb, W, np, reinterpret_cast<int8_t*>(m->B16), n_pad, r0);
+    }
+    if (rc == RPHIP_OK) rc = rp_comm_all_gather(comm, pm, gm, (int64_t)nB * 4, st);
+    hipLaunchKernelGGL(k_max_over_ranks, dim3((unsigned)rp_cdiv(n_pad, 256)), dim3(256), 0, st, gm, (int)n_pad, W, m->b16_delta, nullptr, 0);
+    if (hipGetLastError() != hipSuccess && rc == RPHIP_OK) rc = RPHIP_EHIP;
+    rp_dev_free(ctx, pm);
+    rp_dev_free(ctx, gm);
+    m->b16_kind = 2;
+    m->b16_scale = 1.0f;
+  }
+  // ---- phase 2: the f32 rows (the rescoring and the exact pass read them), on a stream of their own when the int8 rows exist:
+  // K9's first pass for this rank's users runs beside it
+  hipStream_t gs = st;
+  if (q8 && rc == RPHIP_OK && !comm->ops.all_gather) {  // (a callback transport completes every operation on the host: nothing to overlap)
+    if (hipStreamCreateWithFlags(&m->gather_stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&m->gather_ev, hipEventDisableTiming) == hipSuccess) {
+      hipEventRecord(m->gather_ev, st);  // (this rank's panels and the staging's last use)
+      hipStreamWaitEvent(m->gather_stream, m->gather_ev, 0);
+      gs = m->gather_stream;
+    } else {
+      if (m->gather_stream) hipStreamDestroy(m->gather_stream);
+      m->gather_stream = nullptr;
+      m->gather_ev = nullptr;
+    }
+  }
   for (long long r0 = 0; r0 < n_pad && rc == RPHIP_OK; r0 += strip) {
     const long long rows = std::min(strip, n_pad - r0);
     // this rank's strip with the common leading dimension (a rank with fewer panels pads with zeros)
-    if (nl < nl_max || !local) hipMemsetAsync(sendb, 0, (size_t)slot * sizeof(float), st);
+    if (nl < nl_max || !local) hipMemsetAsync(sendb, 0, (size_t)slot * sizeof(float), gs);
     if (local && nl > 0) {
       const long long quads = rows * (long long)(nl * nb / 4);
-      hipLaunchKernelGGL(k_copy2d, dim3((unsigned)std::min<long long>(8192, rp_cdiv(quads, 256))), dim3(256), 0, st, local->B + r0 * local->ld, (long long)local->ld,
+      hipLaunchKernelGGL(k_copy2d, dim3((unsigned)std::min<long long>(8192, rp_cdiv(quads, 256))), dim3(256), 0, gs, local->B + r0 * local->ld, (long long)local->ld,
                          sendb, (long long)ldl, rows, nl * nb, 1.0f);
     }
-    rc = rp_comm_all_gather(comm, sendb, recvb, slot * (long long)sizeof(float), st);
+    rc = rp_comm_all_gather(comm, sendb, recvb, slot * (long long)sizeof(float), gs);
     if (rc != RPHIP_OK) break;
-    hipLaunchKernelGGL(k_unpack_panels, dim3((unsigned)std::min<long long>(256, rp_cdiv(rows * (nb / 4), 256)), nl_max, W), dim3(256), 0, st, recvb, slot, ldl,
+    hipLaunchKernelGGL(k_unpack_panels, dim3((unsigned)std::min<long long>(256, rp_cdiv(rows * (nb / 4), 256)), nl_max, W), dim3(256), 0, gs, recvb, slot, ldl,
                        (int)rows, nb, W, np, m->B, n_pad, r0);
     if (hipGetLastError() != hipSuccess) rc = RPHIP_EHIP;
   }
   rp_time_end(ctx, ev, RPHIP_T_MIRROR, 8.0 * (double)n_pad * n_pad);
-  hipStreamSynchronize(st);
+  if (gs != st && rc == RPHIP_OK) {
+    // asynchronous: `local` must stay alive until the event (rp_model_gather_wait is called by everything that reads B, by
+    // rphip_model_destroy of this model - and the caller keeps `local` at least as long as the gathered model)
+    hipEventRecord(m->gather_ev, gs);
+    m->gather_tmp[0] = sendb;
+    m->gather_tmp[1] = recvb;
+    m->empty_rows = -1;  // (counted when asked for: rphip_model_empty_rows)
+    *out = m;
+    return RPHIP_OK;
+  }
+  hipStreamSynchronize(gs);
+  if (m->gather_ev) hipEventDestroy(m->gather_ev);
+  if (m->gather_stream) hipStreamDestroy(m->gather_stream);
+  m->gather_ev = nullptr;
+  m->gather_stream = nullptr;
   rp_dev_free(ctx, sendb);
   rp_dev_free(ctx, recvb);
   if (rc == RPHIP_OK) rc = rp_dense_count_empty(ctx, m);
@@ -1073,6 +1250,39 @@ extern "C" int rphip_ease_model_allgather(rphip_ctx* ctx, rphip_comm* comm, cons
     return rc;
   }
   *out = m;
+  return RPHIP_OK;
+}
+
+int rp_model_gather_wait(rphip_ctx* ctx, const rphip_model* m, bool on_stream) {
+  if (!m || !m->gather_ev) return RPHIP_OK;
+  if (on_stream)
+    RP_HIP(hipStreamWaitEvent(ctx->stream, m->gather_ev, 0));
+  else
+    RP_HIP(hipEventSynchronize(m->gather_ev));
+  // the staging goes back to the block cache: a freed block carries the context's stream position, which now lies behind the gather
+  rp_dev_free(ctx, m->gather_tmp[0]);
+  rp_dev_free(ctx, m->gather_tmp[1]);
+  m->gather_tmp[0] = m->gather_tmp[1] = nullptr;
+  hipEventDestroy(m->gather_ev);       // (both are released by the runtime once their work is complete)
+  hipStreamDestroy(m->gather_stream);
+  m->gather_ev = nullptr;
+  m->gather_stream = nullptr;
+  return RPHIP_OK;
+}
+
+// (diagnostic, include/recpack_hip_diag.h) `dst` takes over the pending f32 gather of `src`: tools/dist_rank_emulate.py predicts on the
+// REAL matrix of a single-GPU fit while the emulated rank's gather - of noise - is still in flight, and the rescoring of that predict
+// has to wait for it as the rank's own would
+extern "C" int rphip_model_adopt_gather(rphip_model* dst, rphip_model* src) {
+  if (!dst || !src) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if (dst->gather_ev) RP_FAIL(RPHIP_ESTATE, "the model already waits for a gather");
+  dst->gather_ev = src->gather_ev;
+  dst->gather_stream = src->gather_stream;
+  dst->gather_tmp[0] = src->gather_tmp[0];
+  dst->gather_tmp[1] = src->gather_tmp[1];
+  src->gather_ev = nullptr;
+  src->gather_stream = nullptr;
+  src->gather_tmp[0] = src->gather_tmp[1] = nullptr;
   return RPHIP_OK;
 }
 

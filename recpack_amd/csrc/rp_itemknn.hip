@@ -19,6 +19,7 @@
 
 #include "rp_comm.h"
 #include "rp_common.h"
+#include "rp_gemm.h"
 #include "rp_select.h"
 #include "rp_wave.h"
 
@@ -902,6 +903,7 @@ extern "C" int rphip_model_destroy(rphip_model* m) {
   if (!m) return RPHIP_OK;
   if (m->ctx) hipSetDevice(m->ctx->device);
   if (m->ctx && m->borrows_B) hipStreamSynchronize(m->ctx->stream);  // the caller's B may still be read by a launch in flight
+  if (m->ctx && m->gather_ev) rp_model_gather_wait(m->ctx, m, false);   // (a gathered model whose f32 rows are still arriving)
   rp_dev_free(m->ctx, m->idx);
   rp_dev_free(m->ctx, m->val);
   rp_dev_free(m->ctx, m->val32);
@@ -921,6 +923,11 @@ extern "C" int rphip_model_destroy(rphip_model* m) {
 extern "C" int rphip_model_empty_rows(rphip_ctx* ctx, const rphip_model* m, int64_t* out) {
   RP_ENTER(ctx);
   if (!ctx || !m || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if (m->empty_rows < 0 && m->kind == RPHIP_MODEL_DENSE && m->B && !m->is_gram && m->n_cols == 0) {  // (a gathered model: counted when asked for)
+    RP_TRY(rp_set_device(ctx));
+    RP_TRY(rp_model_gather_wait(ctx, m, true));
+    RP_TRY(rp_dense_count_empty(ctx, const_cast<rphip_model*>(m)));
+  }
   *out = m->empty_rows;
   return RPHIP_OK;
 }

@@ -1908,6 +1908,8 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
   P.mode = 0;
   P.keep = keep_dev;
   const int T = P.n_tiles;
+  if (model->gather_ev && !(ctx->predict_half && ctx->predict_int8 && ctx->predict_user_tasks && model->b16_kind == 2 && !keep_dev))
+    RP_TRY(rp_model_gather_wait(ctx, model, true));  // (every route but the per-user first pass reads the f32 rows at once)
   // neighbour-list models with column-sorted rows: wave-per-user kernel (any history length); otherwise (dense
   // models, unsorted lists, very large Kp) the workgroup kernel below
   const bool use_wave = model->kind == RPHIP_MODEL_TOPK && model->cols_sorted && Kp <= PW_KP_MAX && model->K < 65536 &&
@@ -2073,7 +2075,8 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
         U8.n_fail = n_fail;
         U8.fail_base = 0;
         U8.ticket = nullptr;
-        RP_TRY(rp_predict_user_i8(ctx, U8, n_fail + 1));
+        RP_TRY(rp_predict_user_i8(ctx, U8, n_fail + 1, model->gather_ev != nullptr));
+        RP_TRY(rp_model_gather_wait(ctx, model, true));  // (a gathered model: the f32 rows the rescoring reads arrive beside the first pass)
         rp_rescore_params R;
         R.x_ptr = Xpred->x_ptr;
         R.x_idx = Xpred->x_idx;
@@ -2464,6 +2467,7 @@ extern "C" int rphip_predict_topk_filtered(rphip_ctx* ctx, const rphip_model* mo
                                            int32_t* idx_host, float* val_host, int32_t* nnz_host) {
   RP_ENTER(ctx);
   RP_TRY(rp_pred_check(ctx, model, Xpred, user_begin, user_end));
+  RP_TRY(rp_model_gather_wait(ctx, model, true));
   if (!idx_host || !val_host || !nnz_host) RP_FAIL(RPHIP_EINVAL, "NULL output");
   if (Kp < 1 || Kp > RP_K_MAX) RP_FAIL(RPHIP_ELIMIT, "Kp=%d outside 1..%d", Kp, RP_K_MAX);
   RP_TRY(rp_set_device(ctx));
@@ -2494,6 +2498,7 @@ extern "C" int rphip_predict_full_count(rphip_ctx* ctx, const rphip_model* model
                                         int64_t user_end, int64_t* row_nnz_host, int64_t* total_out) {
   RP_ENTER(ctx);
   RP_TRY(rp_pred_check(ctx, model, Xpred, user_begin, user_end));
+  RP_TRY(rp_model_gather_wait(ctx, model, true));
   if (!row_nnz_host || !total_out) RP_FAIL(RPHIP_EINVAL, "NULL output");
   RP_TRY(rp_set_device(ctx));
   const int64_t n = user_end - user_begin;
@@ -2522,6 +2527,7 @@ extern "C" int rphip_predict_full_fill(rphip_ctx* ctx, const rphip_model* model,
                                        int64_t user_end, const int64_t* indptr_host, int32_t* indices_host, double* data_host) {
   RP_ENTER(ctx);
   RP_TRY(rp_pred_check(ctx, model, Xpred, user_begin, user_end));
+  RP_TRY(rp_model_gather_wait(ctx, model, true));
   if (!indptr_host) RP_FAIL(RPHIP_EINVAL, "indptr is NULL");
   RP_TRY(rp_set_device(ctx));
   const int64_t n = user_end - user_begin;

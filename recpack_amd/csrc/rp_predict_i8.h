@@ -27,4 +27,4 @@ struct rp_i8_params {
 size_t rp_predict_user_i8_lds();
 int rp_predict_user_i8_geometry(int64_t n_cols, int* n_tiles, int* tile_w);
 // one launch over all users of P; ticket_dev = one device word of scratch
-int rp_predict_user_i8(rphip_ctx* ctx, const rp_i8_params& P, int32_t* ticket_dev);
+int rp_predict_user_i8(rphip_ctx* ctx, const rp_i8_params& P, int32_t* ticket_dev, bool leave_room = false);

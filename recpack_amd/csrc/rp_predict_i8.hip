@@ -302,7 +302,7 @@ int rp_predict_user_i8_geometry(int64_t n_cols, int* n_tiles, int* tile_w) {
   return RPHIP_OK;
 }
 
-int rp_predict_user_i8(rphip_ctx* ctx, const rp_i8_params& P0, int32_t* ticket_dev) {
+int rp_predict_user_i8(rphip_ctx* ctx, const rp_i8_params& P0, int32_t* ticket_dev, bool leave_room) {
   if (P0.Kc < 1 || P0.Kc > RPU_KC_MAX) RP_FAIL(RPHIP_ELIMIT, "first pass per user: Kc = %d outside 1..%d", P0.Kc, RPU_KC_MAX);
   rp_i8_params P = P0;
   P.ticket = ticket_dev;
@@ -313,7 +313,10 @@ int rp_predict_user_i8(rphip_ctx* ctx, const rp_i8_params& P0, int32_t* ticket_d
     attr_set = true;
   }
   RP_HIP(hipMemsetAsync(ticket_dev, 0, 4, ctx->stream));
-  const int grid = (int)std::min<int64_t>(P.n_users, (int64_t)ctx->n_cu * 2);
+  // two workgroups per CU fill every thread slot of the chip; leave_room: a quarter of the CUs get one - the strips of a panel gather
+  // that arrive beside this pass (rphip_ease_model_allgather) are unpacked by kernels that need somewhere to run (with the chip full
+  // they started when this pass ended: no overlap at all - measured with the loop-back communicator)
+  const int grid = (int)std::min<int64_t>(P.n_users, (int64_t)ctx->n_cu * 2 - (leave_room ? ctx->n_cu / 4 : 0));
   hipLaunchKernelGGL(k_predict_user_i8, dim3(grid), dim3(RPU_THREADS), lds, ctx->stream, P);
   RP_HIP(hipGetLastError());
   return RPHIP_OK;
