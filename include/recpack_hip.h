@@ -450,7 +450,8 @@ int rphip_comm_info(const rphip_comm* comm, int32_t* world, int32_t* rank, int32
 /* int32 sum over the ranks of a device vector, in place (the item degrees of a sharded K0: rphip_csr_degrees_device) */
 int rphip_comm_all_reduce_sum_i32(rphip_ctx* ctx, rphip_comm* comm, int32_t* buf_dev, int64_t count);
 /* Self-test of a communicator, ONE operation per call: op 0 = broadcast (from the last rank), 1 = all-gather, 2 = personalised
- * exchange, 3 = int32 all-reduce, on `words` int32 per rank (per piece for the exchange).  The operation runs once on the context's
+ * exchange, 3 = int32 all-reduce, 4 = the broadcast of a large message (12 MiB or more: the library sends it as scatter + all-gather so
+ * that no xGMI link carries more than 2 / world of it), on `words` int32 per rank (per piece for the exchange).  The operation runs once on the context's
  * stream on a known pattern, the call waits for it and checks every received word on the device: *mismatches = words that differ
  * (0 = works), *ms = its wall time.  Every rank must make the same calls.  A transport that hangs hangs HERE, in a call that names
  * the operation: put a watchdog around it (bench.py --gpus N does, 30 s per operation, before its warm-up) rather than find out

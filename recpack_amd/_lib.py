@@ -656,7 +656,7 @@ class Comm:
     def all_reduce_sum_i32(self, ptr: int, count: int):
         check(self.ctx.lib.rphip_comm_all_reduce_sum_i32(self.ctx.handle, self.handle, C.c_void_p(ptr), int(count)))
 
-    SELFTEST_OPS = ("broadcast", "all_gather", "exchange", "all_reduce_sum_i32")
+    SELFTEST_OPS = ("broadcast", "all_gather", "exchange", "all_reduce_sum_i32", "broadcast_large")
 
     def selftest_op(self, op: int, words: int = 1 << 18):
         """One operation of the transport on a known pattern, every received word checked on the device (rphip_comm_selftest):

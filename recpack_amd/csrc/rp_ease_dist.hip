@@ -238,13 +238,46 @@ int rp_comm_broadcast(rphip_comm* c, void* buf, int64_t bytes, int root, hipStre
     c->bytes_sent += bytes;
   else
     c->bytes_recv += bytes;
+  // (round 5) A LARGE message travels as scatter + all-gather: the root sends piece p (1 / W of the message) to rank p, then every
+  // rank sends its piece to the others - on a fully connected node (xGMI: every pair of GPUs has its own link) no link carries more
+  // than 2 / W of the message, where a root that feeds every peer the whole message - or a ring - puts all of it on every link:
+  // the pivot column of the distributed solve (0.4 GB on average at 100 000 items) was 4 of the ~8 ms of the per-pivot recurrence
+  // in the 8-rank emulation.  Below 8 MiB (and for two ranks) the transport's own broadcast.
+  const int W = c->world, me = c->rank;
+  const bool split = W > 2 && bytes >= ((int64_t)8 << 20);
+  const int64_t chunk = split ? ((bytes + W - 1) / W + 255) / 256 * 256 : 0;
+  auto piece_len = [&](int p) { return std::max<int64_t>(0, std::min<int64_t>(chunk, bytes - (int64_t)p * chunk)); };
   if (c->is_rccl) {
-    RP_NCCL(g_rccl.Broadcast(buf, buf, (size_t)bytes, ncclInt8, root, c->nccl, st));
+    if (!split) {
+      RP_NCCL(g_rccl.Broadcast(buf, buf, (size_t)bytes, ncclInt8, root, c->nccl, st));
+      return RPHIP_OK;
+    }
+    char* b = (char*)buf;
+    RP_NCCL(g_rccl.GroupStart());  // scatter
+    if (me == root) {
+      for (int p = 0; p < W; ++p)
+        if (p != me && piece_len(p) > 0) RP_NCCL(g_rccl.Send(b + (int64_t)p * chunk, (size_t)piece_len(p), ncclInt8, p, c->nccl, st));
+    } else if (piece_len(me) > 0) {
+      RP_NCCL(g_rccl.Recv(b + (int64_t)me * chunk, (size_t)piece_len(me), ncclInt8, root, c->nccl, st));
+    }
+    RP_NCCL(g_rccl.GroupEnd());
+    RP_NCCL(g_rccl.GroupStart());  // every piece to everybody who lacks it (the root lacks nothing)
+    for (int q = 0; q < W; ++q) {
+      if (q == me) continue;
+      if (q != root && piece_len(me) > 0) RP_NCCL(g_rccl.Send(b + (int64_t)me * chunk, (size_t)piece_len(me), ncclInt8, q, c->nccl, st));
+      if (me != root && piece_len(q) > 0) RP_NCCL(g_rccl.Recv(b + (int64_t)q * chunk, (size_t)piece_len(q), ncclInt8, q, c->nccl, st));
+    }
+    RP_NCCL(g_rccl.GroupEnd());
     return RPHIP_OK;
   }
   if (c->is_loop) {
     if (c->rank != root) rp_loop_noise(buf, bytes, st, (unsigned)c->bytes_recv);
-    rp_loop_delay(c, bytes, st);
+    if (split) {
+      rp_loop_delay(c, chunk, st);  // scatter: one piece per link
+      rp_loop_delay(c, chunk, st);  // all-gather: one piece per link and direction
+    } else {
+      rp_loop_delay(c, bytes, st);
+    }
     RP_HIP(hipGetLastError());
     return RPHIP_OK;
   }
@@ -369,14 +402,20 @@ __global__ void k_st_check(const int32_t* __restrict__ p, long long n, int mode,
   if (b) atomicAdd(bad, b);
 }
 
-// op: 0 broadcast (from the last rank), 1 all-gather, 2 personalised exchange, 3 int32 all-reduce; `words` int32 per rank (or piece).
+// op: 0 broadcast (from the last rank), 1 all-gather, 2 personalised exchange, 3 int32 all-reduce, 4 the broadcast of a large message
+// (scatter + all-gather); `words` int32 per rank (or piece).
 // Runs the operation once on the context's stream with a known pattern, waits, and checks every received word on the device:
 // *mismatches = words that differ (0 = the operation works), *ms = its wall time.  A transport that hangs hangs HERE, in a call that
 // names the operation - the caller puts a watchdog around it (bench.py: 30 s) instead of finding out in the first pivot of a solve.
 extern "C" int rphip_comm_selftest(rphip_ctx* ctx, rphip_comm* c, int32_t op, int64_t words, int64_t* mismatches, double* ms) {
   RP_ENTER(ctx);
   if (!ctx || !c || !mismatches) RP_FAIL(RPHIP_EINVAL, "NULL argument");
-  if (op < 0 || op > 3 || words < 1 || words > (1 << 26)) RP_FAIL(RPHIP_EINVAL, "self-test: operation %d, %lld words", op, (long long)words);
+  if (op < 0 || op > 4 || words < 1 || words > (1 << 26)) RP_FAIL(RPHIP_EINVAL, "self-test: operation %d, %lld words", op, (long long)words);
+  const bool big_bcast = op == 4;  // the broadcast's scatter + all-gather form (messages of 8 MiB and more): at least 3M words
+  if (big_bcast) {
+    op = 0;
+    words = std::max<int64_t>(words, (int64_t)3 << 20);
+  }
   RP_TRY(rp_set_device(ctx));
   const int W = c->world, me = c->rank;
   hipStream_t st = ctx->stream;
