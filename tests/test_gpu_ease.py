@@ -524,6 +524,41 @@ def test_predict_from_two_threads(hip):
                     np.testing.assert_array_equal(a, b)
 
 
+def test_predict_user_route_corner_cases(hip):
+    """K9's first pass with one task per user (rp_predict_i8.hip, round 5) against the one-pass kernel, bit for bit, where its special
+    paths run: histories longer than its LDS copy (2 048 items) under history removal, users without a history, a catalogue of one
+    column tile and of three, Kp at the edge of the route (Kc = 256) and beyond it (the per-(user, tile) route takes over), and the
+    per-(user, tile) route itself (`predict_user_tasks` = 0), which stays the fallback for filters and unsorted rows."""
+    from recpack_amd.synth import powerlaw_csr
+
+    _lib, ctx = hip
+    rng = np.random.default_rng(17)
+    for n_items in (3000, 40000):
+        X = powerlaw_csr(2500, n_items, 40.0 / n_items, seed=94).to_scipy().tolil()
+        X[3, :] = 0                                   # no history
+        big = rng.choice(n_items, size=2600, replace=False)
+        X[5, big] = 1                                 # longer than the LDS copy of a history
+        X = X.tocsr()
+        X.sort_indices()
+        dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
+        m = _lib.ease_fit(ctx, dX, 20.0, 0.0)
+        try:
+            for Kp, excl in ((100, True), (100, False), (164, True), (200, True), (7, True)):
+                ctx.set_option("predict_half", 0)
+                want = _lib.predict_topk(ctx, m, dX, Kp, exclude_history=excl)
+                ctx.set_option("predict_half", 1)
+                for route in (1, 0):
+                    ctx.set_option("predict_user_tasks", route)
+                    got = _lib.predict_topk(ctx, m, dX, Kp, exclude_history=excl)
+                    for a, b in zip(got, want):
+                        np.testing.assert_array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b,
+                                                      err_msg=f"{n_items} items, Kp {Kp}, exclude {excl}, route {route}")
+                assert want[2][3] == 0 and (want[2][[0, 1, 2, 5]] > 0).all()
+        finally:
+            ctx.set_option("predict_half", 1)
+            ctx.set_option("predict_user_tasks", 1)
+
+
 def test_predict_two_pass_equals_one_pass(hip):
     """K9's two passes (fp16 or int8 rows for a candidate list, exact f32 scores of the candidates, a proof per user, the one-pass kernel
     for users without one - options predict_half, predict_int8) give the one-pass kernel's top-Kp bit for bit: fitted models, several Kp, history
