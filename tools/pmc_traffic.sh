@@ -28,7 +28,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 # what the pass was taken on: bench.py compares these with the sources it runs beside (a checkout's mtimes say nothing)
 import hashlib
 out["_sources_sha256"] = {f: hashlib.sha256(open(f"recpack_amd/csrc/{f}", "rb").read()).hexdigest()
-                          for f in ("rp_predict.hip", "rp_itemknn.hip", "rp_csr.hip", "rp_wave.h", "rp_select.h")}
+                          for f in ("rp_predict.hip", "rp_predict_i8.hip", "rp_itemknn.hip", "rp_csr.hip", "rp_wave.h", "rp_select.h")}
 print(json.dumps(out, indent=1))
 json.dump(out, open(f"gpurun_out/pmc_traffic_{tag}.json", "w"), indent=1)
 PY
