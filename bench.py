@@ -239,7 +239,7 @@ def ease_leg(args, ctx, device, Kp, config, repeats):
         # fp32-equivalent product, so the matrix pipe executes 3 n^3 fp16 flop for the n^3 of the model - priced against the dense
         # fp16 / bf16 peak; `fp32_equivalent` is the same time against the n^3 model (what an fp32 MFMA kernel would have to sustain)
         "roofline": {
-            "kernel": "k_gemm_hp16 + k_split_planes (large products) / k_gemm_nt_h2 (skinny ones) (K5 Cholesky + K6 inverse: v_mfma_f32_16x16x32_f16 on "
+            "kernel": "k_gemm_hp16w + k_split_planes (large products) / k_gemm_nt_h2 (skinny ones) (K5 Cholesky + K6 inverse: v_mfma_f32_16x16x32_f16 on "
                       "fp32 operands cut into two fp16 planes, fp32 accumulate, compensated master sums)",
             "bound": "mfma",
             "achieved": round(3.0 * tf, 2),
