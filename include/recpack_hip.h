@@ -131,6 +131,10 @@ int rphip_ctx_trim(rphip_ctx* ctx);
  *                       score to ONE candidate list in LDS and cuts it to Kc entries itself - no per-tile lists, no merge kernel.  0: one
  *                       task per (user, column tile) and a merge (round 4; also taken with an item filter, when history removal meets
  *                       unsorted rows, and for candidate lists longer than 256).  The results are identical either way.
+ *   "comm_broadcast_split"  1 (default) | 0.  Broadcasts of 8 MiB and more among MORE than two ranks travel as scatter + all-gather
+ *                       (grouped point-to-point sends on RCCL: no link of a fully connected xGMI node carries more than 2 / W of the
+ *                       message); 0: the transport's own broadcast for every size.  bench.py switches it off when operation 4 of
+ *                       rphip_comm_selftest (the large broadcast) is the only one that fails.
  *   "gemm_mode"         2 (default) | 0: how the O(n^3) products of the EASE solve (and rphip_gemm_nt_f32) multiply their fp32 operands.
  *                       2: two fp16 planes per operand, both rounded to nearest (x = h1 + h2 to 2^-24 |x|), three plane products per
  *                          step on v_mfma_f32_32x32x16_f16; each operand is scaled by a power of two taken from its largest magnitude

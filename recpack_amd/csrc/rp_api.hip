@@ -311,6 +311,8 @@ extern "C" int rphip_ctx_set_option(rphip_ctx* ctx, const char* name, int64_t va
     ctx->predict_int8 = value ? 1 : 0;
   } else if (!strcmp(name, "predict_user_tasks")) {
     ctx->predict_user_tasks = value ? 1 : 0;
+  } else if (!strcmp(name, "comm_broadcast_split")) {
+    ctx->comm_broadcast_split = value ? 1 : 0;
   } else if (!strcmp(name, "predict_half_tile")) {
     if (value < 0 || value > 16384) RP_FAIL(RPHIP_EINVAL, "predict_half_tile must be 0 .. 16384 columns");
     ctx->predict_half_w = (int)value;

@@ -244,7 +244,7 @@ int rp_comm_broadcast(rphip_comm* c, void* buf, int64_t bytes, int root, hipStre
   // the pivot column of the distributed solve (0.4 GB on average at 100 000 items) was 4 of the ~8 ms of the per-pivot recurrence
   // in the 8-rank emulation.  Below 8 MiB (and for two ranks) the transport's own broadcast.
   const int W = c->world, me = c->rank;
-  const bool split = W > 2 && bytes >= ((int64_t)8 << 20);
+  const bool split = W > 2 && bytes >= ((int64_t)8 << 20) && (!c->ctx || c->ctx->comm_broadcast_split);
   const int64_t chunk = split ? ((bytes + W - 1) / W + 255) / 256 * 256 : 0;
   auto piece_len = [&](int p) { return std::max<int64_t>(0, std::min<int64_t>(chunk, bytes - (int64_t)p * chunk)); };
   if (c->is_rccl) {
