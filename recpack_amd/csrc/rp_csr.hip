@@ -6,8 +6,12 @@
 //
 // Round 4: the transposition is a two-level counting sort whose scattered writes stay inside L2 (round 3: every entry's rank by
 // returning LDS atomics with x_idx read once per 32 768-item range, then 5 * 10^7 isolated 4-byte stores over 200 MB: 3.4 ms):
-//   k_rows        8 lanes per user row: column order check, tile pointers, tile-relative columns, P = sum d_u^2, and the number of
-//                 entries per BUCKET of 512 consecutive items (LDS histogram per block)
+//   k_check_ptr   per user: the row pointers are one (monotone, first 0, last nnz), longest history, P = sum d_u^2, the tile pointers
+//                 of rows without entries
+//   k_rows        per ENTRY (round 5; 8 lanes per user row before: 0.86 ms at 1M x 100K, bound by its per-row chains): persistent
+//                 blocks take 4096 consecutive entries, four per thread in one 16-byte load, an entry's row by a search in the
+//                 block's row pointers (LDS); column order check, tile pointers, tile-relative columns (one 8-byte store per
+//                 four), and the number of entries per BUCKET of 512 consecutive items (LDS histogram per block)
 //   scan          bucket offsets
 //   k_partition   8192 consecutive entries per block: (item inside its bucket, user) packed into one word, reordered in LDS by
 //                 bucket and written out in runs - every bucket's entries end up contiguous (coalesced writes)
@@ -26,23 +30,25 @@ constexpr int RP_K0_BUCKET_MAX = 4096;  // buckets the partition pass can keep i
 constexpr int RP_K0_E = 8192;           // entries per block of the partition and bucket passes
 constexpr int RP_K0_T = 256;            // threads of those blocks
 
-// One pass over X with 8 lanes per user row (coalesced 32-byte segments):
+constexpr int RP_K0_RE = 4096;          // entries per chunk of the row pass
+
+// One pass over the entries of X, flat (see the header):
 //   * are the column indices of every row strictly increasing?  (err[1] = 1 if not; with several column tiles err[0] = 3)
 //   * a column outside [0, n_items): err[0] = 1
 //   * n_tiles > 1: tile_ptr[u][t] = first position of row u with column >= t * tile_w - an entry whose tile differs from
-//     its predecessor's opens the tiles in between; the row's first entry opens tiles 0.., its last closes the rest
+//     its predecessor's opens the tiles in between; the row's first entry opens tiles 0.., its last closes the rest (rows without
+//     entries: k_check_ptr)
 //   * x_rel = the column inside its tile
-//   * P = sum_u d_u^2
 //   * bucket_cnt[b] += entries with item in bucket b (items [xt_lo, xt_hi) only: a shard counts the rows it will fit)
-__global__ void __launch_bounds__(256) k_rows(const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ x_idx, int n_users,
-                                             unsigned long long* __restrict__ p_sum, int n_items, int n_tiles, int tile_w,
-                                             int32_t* __restrict__ tile_ptr, int32_t* __restrict__ err, int xt_lo, int xt_hi,
-                                             uint16_t* __restrict__ x_rel, int bshift, int n_buckets, int32_t* __restrict__ bucket_cnt) {
-  extern __shared__ int bh[];
-  for (int b = threadIdx.x; b < n_buckets; b += blockDim.x) bh[b] = 0;
-  __syncthreads();
-  const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, sub = threadIdx.x & 7;
-  const int ng = (gridDim.x * blockDim.x) >> 3;
+__global__ void __launch_bounds__(256) k_rows(const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ x_idx, int n_users, long long nnz,
+                                             int n_items, int n_tiles, int tile_w, int32_t* __restrict__ tile_ptr, int32_t* __restrict__ err,
+                                             int xt_lo, int xt_hi, uint16_t* __restrict__ x_rel, int bshift, int n_buckets,
+                                             int32_t* __restrict__ bucket_cnt, int vec_ok) {
+  extern __shared__ int bh[];      // [n_buckets], then the chunk's row pointers [RP_K0_RE + 2]
+  int* rows = bh + n_buckets;
+  __shared__ int s_u0, s_u1;
+  const int tid = threadIdx.x;
+  for (int b = tid; b < n_buckets; b += 256) bh[b] = 0;
   const float inv_w = 1.0f / (float)tile_w;
   auto tile_of = [&](int j) {
     int t = (int)((float)j * inv_w);
@@ -50,41 +56,91 @@ __global__ void __launch_bounds__(256) k_rows(const int32_t* __restrict__ x_ptr,
     while ((long long)t * tile_w > j) --t;
     return t;
   };
-  unsigned long long local = 0;
-  for (int u = g; u < n_users; u += ng) {
-    const int s = x_ptr[u], e = x_ptr[u + 1];
-    int32_t* tp = (n_tiles > 1) ? tile_ptr + (int64_t)u * (n_tiles + 1) : nullptr;
-    if (sub == 0) {
-      local += (unsigned long long)(e - s) * (unsigned long long)(e - s);
-      if (tp && e == s)
-        for (int t = 0; t <= n_tiles; ++t) tp[t] = s;
-    }
-    for (int k = s + sub; k < e; k += 8) {
-      const int j = x_idx[k];
-      const int prev = (k > s) ? x_idx[k - 1] : -1;
-      if (j <= prev) {
-        err[1] = 1;
-        if (tp) err[0] = 3;
+  const long long n_chunks = (nnz + RP_K0_RE - 1) / RP_K0_RE;
+  for (long long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const long long k0 = c * RP_K0_RE, k1 = min(nnz, k0 + RP_K0_RE);
+    __syncthreads();  // (the previous chunk's row pointers are dead; the histogram is cleared)
+    if (tid == 0) {   // users whose rows meet [k0, k1): first u with x_ptr[u + 1] > k0, one past the last u with x_ptr[u] < k1
+      int lo = 0, hi = n_users;
+      while (lo < hi) {
+        const int m = (lo + hi) >> 1;
+        if (x_ptr[m + 1] > k0) hi = m; else lo = m + 1;
       }
-      const bool in_range = (unsigned)j < (unsigned)n_items;
-      if (!in_range) err[0] = 1;
-      if (in_range && j >= xt_lo && j < xt_hi) atomicAdd(&bh[j >> bshift], 1);
-      const int tj0 = (in_range && n_tiles > 1) ? tile_of(j) : 0;
-      x_rel[k] = (uint16_t)(in_range ? j - tj0 * tile_w : 0);  // (the column inside its tile)
-      if (tp && in_range) {
-        const int tj = tj0;
-        const int tprev = (k > s && (unsigned)prev < (unsigned)n_items) ? tile_of(prev) : -1;
-        for (int t = tprev + 1; t <= tj; ++t) tp[t] = k;
-        if (k == e - 1)
-          for (int t = tj + 1; t <= n_tiles; ++t) tp[t] = e;
+      s_u0 = lo;
+      hi = n_users;
+      while (lo < hi) {
+        const int m = (lo + hi) >> 1;
+        if (x_ptr[m] >= k1) hi = m; else lo = m + 1;
+      }
+      s_u1 = lo;
+    }
+    __syncthreads();
+    const int u0 = s_u0, nu = s_u1 - s_u0;
+    const bool cached = nu <= RP_K0_RE + 1;  // (rows without entries inside the range count too: longer ranges are searched in x_ptr itself)
+    if (cached)
+      for (int i = tid; i <= nu; i += 256) rows[i] = x_ptr[u0 + i];
+    __syncthreads();
+    const int32_t* __restrict__ grow = x_ptr + u0;
+    auto R = [&](int i) { return cached ? rows[i] : grow[i]; };
+#pragma unroll 2
+    for (int g = tid; g < RP_K0_RE / 4; g += 256) {
+      const long long k = k0 + 4 * (long long)g;
+      if (k >= k1) break;
+      const int n = (int)min((long long)4, k1 - k);
+      int j4[4] = {0, 0, 0, 0};
+      if (vec_ok && n == 4) {
+        const int4 v = *reinterpret_cast<const int4*>(x_idx + k);
+        j4[0] = v.x, j4[1] = v.y, j4[2] = v.z, j4[3] = v.w;
+      } else {
+        for (int e = 0; e < n; ++e) j4[e] = x_idx[k + e];
+      }
+      int prev = (k > 0) ? x_idx[k - 1] : -1;
+      int lo = 0, hi = nu;  // the row u0 + lo with R(lo) <= k < R(lo + 1)
+      while (hi - lo > 1) {
+        const int m = (lo + hi) >> 1;
+        if (R(m) <= (int)k) lo = m; else hi = m;
+      }
+      int rs = R(lo), re = R(lo + 1);
+      uint32_t rel[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (e < n) {
+          const int kk = (int)k + e;
+          while (kk >= re) {  // the next row with entries
+            ++lo;
+            rs = re;
+            re = R(lo + 1);
+          }
+          const bool first = kk == rs;
+          const int j = j4[e];
+          if (!first && j <= prev) {
+            err[1] = 1;
+            if (tile_ptr) err[0] = 3;
+          }
+          const bool in_range = (unsigned)j < (unsigned)n_items;
+          if (!in_range) err[0] = 1;
+          if (in_range && j >= xt_lo && j < xt_hi) atomicAdd(&bh[j >> bshift], 1);
+          const int tj = (in_range && n_tiles > 1) ? tile_of(j) : 0;
+          rel[e] = in_range ? (uint32_t)(j - tj * tile_w) : 0u;
+          if (tile_ptr && in_range) {
+            int32_t* tp = tile_ptr + (int64_t)(u0 + lo) * (n_tiles + 1);
+            const int tprev = (!first && (unsigned)prev < (unsigned)n_items) ? tile_of(prev) : -1;
+            for (int t = tprev + 1; t <= tj; ++t) tp[t] = kk;
+            if (kk == re - 1)
+              for (int t = tj + 1; t <= n_tiles; ++t) tp[t] = re;
+          }
+          prev = j;
+        }
+      }
+      if (n == 4) {
+        *reinterpret_cast<uint2*>(x_rel + k) = make_uint2(rel[0] | (rel[1] << 16), rel[2] | (rel[3] << 16));
+      } else {
+        for (int e = 0; e < n; ++e) x_rel[k + e] = (uint16_t)rel[e];
       }
     }
   }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) local += __shfl_xor(local, d);
-  if ((threadIdx.x & 63) == 0 && local) atomicAdd(p_sum, local);
   __syncthreads();
-  for (int b = threadIdx.x; b < n_buckets; b += blockDim.x)
+  for (int b = tid; b < n_buckets; b += 256)
     if (bh[b]) atomicAdd(&bucket_cnt[b], bh[b]);
 }
 
@@ -284,8 +340,12 @@ __global__ void k_inv_deg(const int32_t* __restrict__ deg, double* __restrict__ 
   }
 }
 
-__global__ void k_check_ptr(const int32_t* __restrict__ x_ptr, int n_users, int64_t nnz, int32_t* __restrict__ err) {
+// per user: the row pointers are valid, the longest history (err[4]), P = sum d_u^2 (*p_sum), and - several column tiles - the
+// tile pointers of the rows WITHOUT entries (k_rows visits entries)
+__global__ void k_check_ptr(const int32_t* __restrict__ x_ptr, int n_users, int64_t nnz, int32_t* __restrict__ err,
+                            unsigned long long* __restrict__ p_sum, int32_t* __restrict__ tile_ptr, int n_tiles) {
   int dmax = 0;
+  unsigned long long local = 0;
   for (int u = blockIdx.x * blockDim.x + threadIdx.x; u <= n_users; u += gridDim.x * blockDim.x) {
     const int a = x_ptr[u];
     if (u == 0 && a != 0) *err = 2;
@@ -294,17 +354,33 @@ __global__ void k_check_ptr(const int32_t* __restrict__ x_ptr, int n_users, int6
       const int d = x_ptr[u + 1] - a;
       if (d < 0) *err = 2;
       dmax = max(dmax, d);
+      if (d > 0) local += (unsigned long long)d * (unsigned long long)d;
+      if (d == 0 && tile_ptr) {
+        int32_t* tp = tile_ptr + (int64_t)u * (n_tiles + 1);
+        for (int t = 0; t <= n_tiles; ++t) tp[t] = a;
+      }
     }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, __shfl_xor(dmax, o));
+  for (int o = 32; o > 0; o >>= 1) {
+    dmax = max(dmax, __shfl_xor(dmax, o));
+    local += __shfl_xor(local, o);
+  }
   // (one atomic per BLOCK: 16 000 waves queueing for one word were 0.16 of this kernel's 0.18 ms)
   __shared__ int s_max[16];
-  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = dmax;
+  __shared__ unsigned long long s_sum[16];
+  if ((threadIdx.x & 63) == 0) {
+    s_max[threadIdx.x >> 6] = dmax;
+    s_sum[threadIdx.x >> 6] = local;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) dmax = max(dmax, s_max[w]);
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+      dmax = max(dmax, s_max[w]);
+      local += s_sum[w];
+    }
     if (dmax > 0) atomicMax(&err[4], dmax);  // longest history
+    if (local) atomicAdd(p_sum, local);
   }
 }
 
@@ -356,7 +432,8 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
   RP_HIP(hipMemsetAsync(err, 0, 64 + aux_ints * 4, st));  // (flags, P, bucket counters, cursor)
   const int bt = 256;
   const int grid_u = (int)std::min<int64_t>((int64_t)ctx->n_cu * 4, std::max<int64_t>(1, rp_cdiv(U + 1, bt)));
-  hipLaunchKernelGGL(k_check_ptr, dim3(grid_u), dim3(bt), 0, st, m->x_ptr, (int)U, nnz, err);
+  if (m->n_tiles > 1) RP_TRY(rp_dev_alloc(ctx, (size_t)std::max<int64_t>(U, 1) * (m->n_tiles + 1) * sizeof(int32_t), (void**)&m->tile_ptr));
+  hipLaunchKernelGGL(k_check_ptr, dim3(grid_u), dim3(bt), 0, st, m->x_ptr, (int)U, nnz, err, p_sum, m->tile_ptr, m->n_tiles);
   int32_t h_chk[5] = {0, 0, 0, 0, 0};
   RP_HIP(hipMemcpyAsync(h_chk, err, sizeof(h_chk), hipMemcpyDeviceToHost, st));
   RP_HIP(hipStreamSynchronize(st));
@@ -368,16 +445,16 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
   const int64_t i_hi = m->deg_partial ? (m->xt_row_end < 0 ? I : std::min<int64_t>(I, m->xt_row_end)) : I;
   // (the rows of X^T that are filled: a matrix built for a row range fills those rows only, its degrees cover all items)
   const int64_t f_lo = std::max<int64_t>(0, m->xt_row_begin), f_hi = m->xt_row_end < 0 ? I : std::min<int64_t>(I, m->xt_row_end);
-  if (m->n_tiles > 1) RP_TRY(rp_dev_alloc(ctx, (size_t)std::max<int64_t>(U, 1) * (m->n_tiles + 1) * sizeof(int32_t), (void**)&m->tile_ptr));
   {  // tile-relative columns, padded so that a chunk of eight read at any entry stays inside
     const size_t n_rel = (((size_t)nnz + 15) & ~(size_t)15) + 16;
     RP_TRY(rp_dev_alloc(ctx, n_rel * sizeof(uint16_t), (void**)&m->x_rel));
     RP_HIP(hipMemsetAsync(m->x_rel, 0, n_rel * sizeof(uint16_t), st));
   }
-  if (U > 0) {  // (rows without entries still need their tile pointers)
-    const int grid_s = (int)std::min<int64_t>((int64_t)ctx->n_cu * 8, std::max<int64_t>(1, rp_cdiv(U * 8, bt)));
-    hipLaunchKernelGGL(k_rows, dim3(grid_s), dim3(bt), (size_t)n_buckets * 4, st, m->x_ptr, m->x_idx, (int)U, p_sum, (int)I, m->n_tiles, m->tile_w,
-                       m->tile_ptr, err, (int)i_lo, (int)i_hi, m->x_rel, bshift, n_buckets, bucket_cnt);
+  if (nnz > 0) {
+    const int grid_s = (int)std::min<int64_t>((int64_t)ctx->n_cu * 6, rp_cdiv(nnz, RP_K0_RE));
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(m->x_idx) & 15) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(k_rows, dim3(grid_s), dim3(bt), ((size_t)n_buckets + RP_K0_RE + 2) * 4, st, m->x_ptr, m->x_idx, (int)U, (long long)nnz, (int)I,
+                       m->n_tiles, m->tile_w, m->tile_ptr, err, (int)i_lo, (int)i_hi, m->x_rel, bshift, n_buckets, bucket_cnt, vec_ok);
   }
   RP_TRY(rp_exclusive_scan_i32(ctx, bucket_cnt, bucket_off, n_buckets));
   if (nnz > 0 && I > 0) {
