@@ -43,10 +43,9 @@ constexpr int RP_K0_RE = 4096;          // entries per chunk of the row pass
 __global__ void __launch_bounds__(256) k_rows(const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ x_idx, int n_users, long long nnz,
                                              int n_items, int n_tiles, int tile_w, int32_t* __restrict__ tile_ptr, int32_t* __restrict__ err,
                                              int xt_lo, int xt_hi, uint16_t* __restrict__ x_rel, int bshift, int n_buckets,
-                                             int32_t* __restrict__ bucket_cnt, int vec_ok) {
+                                             int32_t* __restrict__ bucket_cnt, int vec_ok, const int32_t* __restrict__ chunk_u0) {
   extern __shared__ int bh[];      // [n_buckets], then the chunk's row pointers [RP_K0_RE + 2]
   int* rows = bh + n_buckets;
-  __shared__ int s_u0, s_u1;
   const int tid = threadIdx.x;
   for (int b = tid; b < n_buckets; b += 256) bh[b] = 0;
   const float inv_w = 1.0f / (float)tile_w;
@@ -60,22 +59,9 @@ __global__ void __launch_bounds__(256) k_rows(const int32_t* __restrict__ x_ptr,
   for (long long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     const long long k0 = c * RP_K0_RE, k1 = min(nnz, k0 + RP_K0_RE);
     __syncthreads();  // (the previous chunk's row pointers are dead; the histogram is cleared)
-    if (tid == 0) {   // users whose rows meet [k0, k1): first u with x_ptr[u + 1] > k0, one past the last u with x_ptr[u] < k1
-      int lo = 0, hi = n_users;
-      while (lo < hi) {
-        const int m = (lo + hi) >> 1;
-        if (x_ptr[m + 1] > k0) hi = m; else lo = m + 1;
-      }
-      s_u0 = lo;
-      hi = n_users;
-      while (lo < hi) {
-        const int m = (lo + hi) >> 1;
-        if (x_ptr[m] >= k1) hi = m; else lo = m + 1;
-      }
-      s_u1 = lo;
-    }
-    __syncthreads();
-    const int u0 = s_u0, nu = s_u1 - s_u0;
+    // users whose rows meet [k0, k1): from the user of entry k0 to the user of entry k1 (k_check_ptr left both; two binary searches
+    // over x_ptr by one thread per chunk were ~20 dependent loads with the other 255 waiting)
+    const int u0 = chunk_u0[c], nu = chunk_u0[c + 1] + 1 - u0;  // (x_ptr[u0 + nu] >= k1)
     const bool cached = nu <= RP_K0_RE + 1;  // (rows without entries inside the range count too: longer ranges are searched in x_ptr itself)
     if (cached)
       for (int i = tid; i <= nu; i += 256) rows[i] = x_ptr[u0 + i];
@@ -152,33 +138,21 @@ __global__ void __launch_bounds__(256) k_rows(const int32_t* __restrict__ x_ptr,
 template <typename PT>
 __global__ void __launch_bounds__(RP_K0_T) k_partition(const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ x_idx, int n_users, long long nnz,
                                                        int n_items, int xt_lo, int xt_hi, int bshift, int ubits, int n_buckets,
-                                                       const int32_t* __restrict__ bucket_off, int32_t* __restrict__ bucket_fill, PT* __restrict__ out) {
+                                                       const int32_t* __restrict__ bucket_off, int32_t* __restrict__ bucket_fill, PT* __restrict__ out,
+                                                       const int32_t* __restrict__ chunk_u0, int n_chunks_re) {
   extern __shared__ __attribute__((aligned(16))) char sm_p[];
   constexpr int R = RP_K0_E / RP_K0_T;
   PT* stage = reinterpret_cast<PT*>(sm_p);                                        // [E]
   int* hist = reinterpret_cast<int*>(sm_p + (size_t)RP_K0_E * sizeof(PT));       // [n_buckets] count, then global base - local start
   int* lstart = hist + n_buckets;                                                // [n_buckets + 1] start inside the stage
   int* rows = lstart + n_buckets + 1;                                            // [<= E + 2] row pointers of the block's users
-  __shared__ int s_u0, s_u1;
+  static_assert(RP_K0_E % RP_K0_RE == 0, "a partition block is a whole number of row-pass chunks");
   const int tid = threadIdx.x;
   const long long k0 = (long long)blockIdx.x * RP_K0_E, k1 = min(nnz, k0 + RP_K0_E);
   for (int b = tid; b < n_buckets; b += RP_K0_T) hist[b] = 0;
-  if (tid == 0) {  // users whose rows meet [k0, k1): first u with x_ptr[u + 1] > k0, last u with x_ptr[u] < k1
-    int lo = 0, hi = n_users;
-    while (lo < hi) {
-      const int m = (lo + hi) >> 1;
-      if (x_ptr[m + 1] > k0) hi = m; else lo = m + 1;
-    }
-    s_u0 = lo;
-    hi = n_users;
-    while (lo < hi) {
-      const int m = (lo + hi) >> 1;
-      if (x_ptr[m] >= k1) hi = m; else lo = m + 1;
-    }
-    s_u1 = lo;  // one past the last such user
-  }
-  __syncthreads();
-  const int u0 = s_u0, nu = s_u1 - s_u0;  // (rows without entries inside the range are harmless: the search skips them)
+  // users whose rows meet [k0, k1): the user of entry k0 .. the user of entry k1 (chunk_u0 of k_check_ptr, see k_rows)
+  const int cc = (int)blockIdx.x * (RP_K0_E / RP_K0_RE);
+  const int u0 = chunk_u0[cc], nu = chunk_u0[min(cc + RP_K0_E / RP_K0_RE, n_chunks_re)] + 1 - u0;  // (rows without entries inside the range are harmless: the search skips them)
   // nu counts the EMPTY rows inside the range too, so it is unbounded (50 000 history-less users between two entries): the LDS copy
   // holds E + 2 pointers - longer ranges are searched in x_ptr itself
   const bool cached = nu <= RP_K0_E + 1;
@@ -343,9 +317,11 @@ __global__ void k_inv_deg(const int32_t* __restrict__ deg, double* __restrict__ 
 // per user: the row pointers are valid, the longest history (err[4]), P = sum d_u^2 (*p_sum), and - several column tiles - the
 // tile pointers of the rows WITHOUT entries (k_rows visits entries)
 __global__ void k_check_ptr(const int32_t* __restrict__ x_ptr, int n_users, int64_t nnz, int32_t* __restrict__ err,
-                            unsigned long long* __restrict__ p_sum, int32_t* __restrict__ tile_ptr, int n_tiles) {
+                            unsigned long long* __restrict__ p_sum, int32_t* __restrict__ tile_ptr, int n_tiles, int32_t* __restrict__ chunk_u0) {
   int dmax = 0;
   unsigned long long local = 0;
+  const int n_chunks = (int)((nnz + RP_K0_RE - 1) / RP_K0_RE);
+  if (blockIdx.x == 0 && threadIdx.x == 0) chunk_u0[n_chunks] = max(n_users - 1, 0);
   for (int u = blockIdx.x * blockDim.x + threadIdx.x; u <= n_users; u += gridDim.x * blockDim.x) {
     const int a = x_ptr[u];
     if (u == 0 && a != 0) *err = 2;
@@ -355,6 +331,10 @@ __global__ void k_check_ptr(const int32_t* __restrict__ x_ptr, int n_users, int6
       if (d < 0) *err = 2;
       dmax = max(dmax, d);
       if (d > 0) local += (unsigned long long)d * (unsigned long long)d;
+      // chunk_u0[c] = the user whose row holds entry c * RP_K0_RE (the entry passes start their row search there; with invalid
+      // pointers - a or a + d outside [0, nnz] - nothing is written: the passes do not run then)
+      if (d > 0 && a >= 0 && (int64_t)a + d <= nnz)
+        for (int c = (a + RP_K0_RE - 1) / RP_K0_RE; (int64_t)c * RP_K0_RE < (int64_t)a + d; ++c) chunk_u0[c] = u;
       if (d == 0 && tile_ptr) {
         int32_t* tp = tile_ptr + (int64_t)u * (n_tiles + 1);
         for (int t = 0; t <= n_tiles; ++t) tp[t] = a;
@@ -416,7 +396,7 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
   if (((size_t)4 << bshift) > (size_t)128 * 1024) RP_FAIL(RPHIP_ELIMIT, "n_items=%lld is beyond what K0's bucket pass holds in LDS", (long long)I);
   char* sc = nullptr;
   const size_t part_bytes = ((size_t)std::max<int64_t>(nnz, 1) * (wide ? 8 : 4) + 15) & ~(size_t)15;  // keeps p_sum 8-B aligned
-  const size_t aux_ints = (size_t)5 * n_buckets + 8 + (size_t)std::max<int64_t>(I, 1);
+  const size_t aux_ints = (size_t)5 * n_buckets + 8 + (size_t)std::max<int64_t>(I, 1) + (size_t)rp_cdiv(nnz, RP_K0_RE) + 2;
   RP_TRY(rp_scratch(ctx, 0, part_bytes + 64 + aux_ints * 4, (void**)&sc));
   int32_t* err = (int32_t*)(sc + part_bytes);
   unsigned long long* p_sum = (unsigned long long*)(err + 2);
@@ -426,6 +406,8 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
   int32_t* bucket_off = n_blk + n_buckets;                   // [nb + 1]
   int32_t* blk_off = bucket_off + n_buckets + 1;             // [nb + 1]
   int32_t* cursor = blk_off + n_buckets + 1;                 // [I]
+  const int n_chunks_re = (int)rp_cdiv(nnz, RP_K0_RE);
+  int32_t* chunk_u0 = cursor + std::max<int64_t>(I, 1);      // [n_chunks_re + 1]: the user of every RP_K0_RE-th entry
   hipEvent_t ev;
   rp_time_begin(ctx, &ev);
   RP_HIP(hipMemsetAsync(m->deg, 0, (size_t)std::max<int64_t>(I, 1) * sizeof(int32_t), st));
@@ -433,7 +415,7 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
   const int bt = 256;
   const int grid_u = (int)std::min<int64_t>((int64_t)ctx->n_cu * 4, std::max<int64_t>(1, rp_cdiv(U + 1, bt)));
   if (m->n_tiles > 1) RP_TRY(rp_dev_alloc(ctx, (size_t)std::max<int64_t>(U, 1) * (m->n_tiles + 1) * sizeof(int32_t), (void**)&m->tile_ptr));
-  hipLaunchKernelGGL(k_check_ptr, dim3(grid_u), dim3(bt), 0, st, m->x_ptr, (int)U, nnz, err, p_sum, m->tile_ptr, m->n_tiles);
+  hipLaunchKernelGGL(k_check_ptr, dim3(grid_u), dim3(bt), 0, st, m->x_ptr, (int)U, nnz, err, p_sum, m->tile_ptr, m->n_tiles, chunk_u0);
   int32_t h_chk[5] = {0, 0, 0, 0, 0};
   RP_HIP(hipMemcpyAsync(h_chk, err, sizeof(h_chk), hipMemcpyDeviceToHost, st));
   RP_HIP(hipStreamSynchronize(st));
@@ -454,7 +436,7 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
     const int grid_s = (int)std::min<int64_t>((int64_t)ctx->n_cu * 6, rp_cdiv(nnz, RP_K0_RE));
     const int vec_ok = ((reinterpret_cast<uintptr_t>(m->x_idx) & 15) == 0) ? 1 : 0;
     hipLaunchKernelGGL(k_rows, dim3(grid_s), dim3(bt), ((size_t)n_buckets + RP_K0_RE + 2) * 4, st, m->x_ptr, m->x_idx, (int)U, (long long)nnz, (int)I,
-                       m->n_tiles, m->tile_w, m->tile_ptr, err, (int)i_lo, (int)i_hi, m->x_rel, bshift, n_buckets, bucket_cnt, vec_ok);
+                       m->n_tiles, m->tile_w, m->tile_ptr, err, (int)i_lo, (int)i_hi, m->x_rel, bshift, n_buckets, bucket_cnt, vec_ok, chunk_u0);
   }
   RP_TRY(rp_exclusive_scan_i32(ctx, bucket_cnt, bucket_off, n_buckets));
   if (nnz > 0 && I > 0) {
@@ -463,11 +445,11 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
     if (wide) {
       RP_HIP(hipFuncSetAttribute((const void*)k_partition<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
       hipLaunchKernelGGL(k_partition<uint64_t>, dim3(pgrid), dim3(RP_K0_T), plds, st, m->x_ptr, m->x_idx, (int)U, (long long)nnz, (int)I, (int)i_lo,
-                         (int)i_hi, bshift, ubits, n_buckets, bucket_off, bucket_fill, (uint64_t*)sc);
+                         (int)i_hi, bshift, ubits, n_buckets, bucket_off, bucket_fill, (uint64_t*)sc, chunk_u0, n_chunks_re);
     } else {
       RP_HIP(hipFuncSetAttribute((const void*)k_partition<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
       hipLaunchKernelGGL(k_partition<uint32_t>, dim3(pgrid), dim3(RP_K0_T), plds, st, m->x_ptr, m->x_idx, (int)U, (long long)nnz, (int)I, (int)i_lo,
-                         (int)i_hi, bshift, ubits, n_buckets, bucket_off, bucket_fill, (uint32_t*)sc);
+                         (int)i_hi, bshift, ubits, n_buckets, bucket_off, bucket_fill, (uint32_t*)sc, chunk_u0, n_chunks_re);
     }
     hipLaunchKernelGGL(k_bucket_blocks, dim3((unsigned)rp_cdiv(n_buckets, 256)), dim3(256), 0, st, bucket_off, n_buckets, n_blk);
     RP_TRY(rp_exclusive_scan_i32(ctx, n_blk, blk_off, n_buckets));
