@@ -25,6 +25,7 @@
 #include <cmath>
 
 #include "rp_common.h"
+#include "rp_wave.h"
 
 constexpr int RP_K0_BUCKET_MAX = 4096;  // buckets the partition pass can keep in LDS
 constexpr int RP_K0_E = 8192;           // entries per block of the partition and bucket passes
@@ -130,24 +131,29 @@ __global__ void __launch_bounds__(256) k_rows(const int32_t* __restrict__ x_ptr,
     if (bh[b]) atomicAdd(&bucket_cnt[b], bh[b]);
 }
 
-// Entries [k0, k0 + E) of X (flat) into their buckets: word = (item - bucket * 2^bshift) << ubits | user.  The block's users are
-// found once (two binary searches over x_ptr), their row pointers cached in LDS, every entry then finds its row by a search there.
-// Per block: LDS histogram over the buckets (the returning add is the entry's rank inside the block's share of its bucket), one
-// global atomic per (block, bucket) reserves the share's place, the entries are laid out bucket by bucket in LDS and copied out:
-// consecutive threads write consecutive words of a bucket.
+// Entries [k0, k0 + E) of X (flat) into their buckets: word = (item - bucket * 2^bshift) << ubits | user.  A thread takes groups of
+// four consecutive entries (one 16-byte load); the block's row pointers sit in LDS relative to k0 (16 bits each), the first entry of
+// a group finds its row by a search there and the others walk on.  Per block: LDS histogram over the buckets (the returning add is
+// the entry's rank inside the block's share of its bucket), one global atomic per (block, bucket) reserves the share's place, the
+// entries are laid out bucket by bucket in LDS and copied out: consecutive threads write consecutive words of a bucket (the bucket
+// of a stage position from a table of every 16th position's bucket + a short walk).
 template <typename PT>
 __global__ void __launch_bounds__(RP_K0_T) k_partition(const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ x_idx, int n_users, long long nnz,
                                                        int n_items, int xt_lo, int xt_hi, int bshift, int ubits, int n_buckets,
                                                        const int32_t* __restrict__ bucket_off, int32_t* __restrict__ bucket_fill, PT* __restrict__ out,
-                                                       const int32_t* __restrict__ chunk_u0, int n_chunks_re) {
+                                                       const int32_t* __restrict__ chunk_u0, int n_chunks_re, int vec_ok) {
   extern __shared__ __attribute__((aligned(16))) char sm_p[];
-  constexpr int R = RP_K0_E / RP_K0_T;
-  PT* stage = reinterpret_cast<PT*>(sm_p);                                        // [E]
+  static_assert(RP_K0_E % RP_K0_RE == 0, "a partition block is a whole number of row-pass chunks");
+  static_assert(RP_K0_E <= 65535, "row pointers relative to the block's first entry are kept in 16 bits");
+  constexpr int G = RP_K0_E / 4 / RP_K0_T;  // groups of four entries per thread
+  constexpr int R = 4 * G;
+  PT* stage = reinterpret_cast<PT*>(sm_p);                                       // [E]
   int* hist = reinterpret_cast<int*>(sm_p + (size_t)RP_K0_E * sizeof(PT));       // [n_buckets] count, then global base - local start
   int* lstart = hist + n_buckets;                                                // [n_buckets + 1] start inside the stage
-  int* rows = lstart + n_buckets + 1;                                            // [<= E + 2] row pointers of the block's users
-  static_assert(RP_K0_E % RP_K0_RE == 0, "a partition block is a whole number of row-pass chunks");
-  const int tid = threadIdx.x;
+  uint16_t* ptab = reinterpret_cast<uint16_t*>(lstart + n_buckets + 1);          // [E / 16 + 2] bucket of every 16th stage position
+  uint16_t* rows = ptab + (RP_K0_E / 16 + 2);                                    // [E + 2] row pointers - k0, clamped to [0, E]
+  __shared__ int wsum[RP_K0_T / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long k0 = (long long)blockIdx.x * RP_K0_E, k1 = min(nnz, k0 + RP_K0_E);
   for (int b = tid; b < n_buckets; b += RP_K0_T) hist[b] = 0;
   // users whose rows meet [k0, k1): the user of entry k0 .. the user of entry k1 (chunk_u0 of k_check_ptr, see k_rows)
@@ -156,62 +162,69 @@ __global__ void __launch_bounds__(RP_K0_T) k_partition(const int32_t* __restrict
   // nu counts the EMPTY rows inside the range too, so it is unbounded (50 000 history-less users between two entries): the LDS copy
   // holds E + 2 pointers - longer ranges are searched in x_ptr itself
   const bool cached = nu <= RP_K0_E + 1;
-  if (cached)
-    for (int i = tid; i <= nu; i += RP_K0_T) rows[i] = x_ptr[u0 + i];
-  __syncthreads();
   const int32_t* __restrict__ grow = x_ptr + u0;
+  auto rel = [&](int p) { return (int)min((long long)RP_K0_E, max((long long)0, (long long)p - k0)); };
+  if (cached)
+    for (int i = tid; i <= nu; i += RP_K0_T) rows[i] = (uint16_t)rel(grow[i]);
+  __syncthreads();
+  auto RW = [&](int i) { return cached ? (int)rows[i] : rel(grow[i]); };
   int bk[R];
   PT pay[R];
   int rk[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const long long k = k0 + tid + (long long)r * RP_K0_T;
-    bk[r] = -1;
-    rk[r] = 0;
-    pay[r] = 0;
-    if (k < k1) {
-      const int j = x_idx[k];
-      if ((unsigned)j < (unsigned)n_items && j >= xt_lo && j < xt_hi) {
-        int lo = 0, hi = nu;  // the row u0 + lo with rows[lo] <= k < rows[lo + 1]
-        if (cached) {
-          while (hi - lo > 1) {
-            const int m = (lo + hi) >> 1;
-            if (rows[m] <= (int)k) lo = m; else hi = m;
-          }
-        } else {
-          while (hi - lo > 1) {
-            const int m = (lo + hi) >> 1;
-            if (grow[m] <= (int)k) lo = m; else hi = m;
-          }
+  for (int g = 0; g < G; ++g) {
+    const int kr = 4 * (tid + g * RP_K0_T);  // first entry of the group, relative to k0
+    const long long k = k0 + kr;
+    const int n = (int)max((long long)0, min((long long)4, k1 - k));
+    int j4[4] = {-1, -1, -1, -1};
+    if (vec_ok && n == 4) {
+      const int4 v = *reinterpret_cast<const int4*>(x_idx + k);
+      j4[0] = v.x, j4[1] = v.y, j4[2] = v.z, j4[3] = v.w;
+    } else {
+      for (int e = 0; e < n; ++e) j4[e] = x_idx[k + e];
+    }
+    int lo = 0, hi = nu;  // the row u0 + lo with RW(lo) <= kr < RW(lo + 1)
+    if (n > 0) {
+      while (hi - lo > 1) {
+        const int m = (lo + hi) >> 1;
+        if (RW(m) <= kr) lo = m; else hi = m;
+      }
+    }
+    int re = (n > 0) ? RW(lo + 1) : 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * g + e;
+      bk[r] = -1;
+      rk[r] = 0;
+      pay[r] = 0;
+      if (e < n) {
+        while (kr + e >= re) {  // the next row with entries
+          ++lo;
+          re = RW(lo + 1);
         }
-        const int b = j >> bshift;
-        bk[r] = b;
-        pay[r] = ((PT)(j - (b << bshift)) << ubits) | (PT)(u0 + lo);
-        rk[r] = atomicAdd(&hist[b], 1);
+        const int j = j4[e];
+        if ((unsigned)j < (unsigned)n_items && j >= xt_lo && j < xt_hi) {
+          const int b = j >> bshift;
+          bk[r] = b;
+          pay[r] = ((PT)(j - (b << bshift)) << ubits) | (PT)(u0 + lo);
+          rk[r] = atomicAdd(&hist[b], 1);
+        }
       }
     }
   }
   __syncthreads();
-  // start of every bucket inside the stage (exclusive scan over the buckets, 256 threads: a serial run per thread + a scan of the sums)
+  // start of every bucket inside the stage: exclusive scan over the buckets (a serial run per thread + a scan of the threads' sums)
   {
     const int per = (n_buckets + RP_K0_T - 1) / RP_K0_T;
     const int b0 = tid * per, b1 = min(n_buckets, b0 + per);
     int sum = 0;
     for (int b = b0; b < b1; ++b) sum += hist[b];
-    __shared__ int tsum[RP_K0_T];
-    tsum[tid] = sum;
+    const int inc = rp_wave_incl_scan(sum, lane);
+    if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    if (tid == 0) {
-      int run = 0;
-      for (int t = 0; t < RP_K0_T; ++t) {
-        const int c = tsum[t];
-        tsum[t] = run;
-        run += c;
-      }
-      lstart[n_buckets] = run;
-    }
-    __syncthreads();
-    int run = tsum[tid];
+    int run = inc - sum;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    if (tid == RP_K0_T - 1) lstart[n_buckets] = run + sum;
     for (int b = b0; b < b1; ++b) {
       const int c = hist[b];
       lstart[b] = run;
@@ -224,15 +237,21 @@ __global__ void __launch_bounds__(RP_K0_T) k_partition(const int32_t* __restrict
 #pragma unroll
   for (int r = 0; r < R; ++r)
     if (bk[r] >= 0) stage[lstart[bk[r]] + rk[r]] = pay[r];
-  __syncthreads();
-  const int total = lstart[n_buckets];
-  for (int i = tid; i < total; i += RP_K0_T) {
+  for (int sl = tid; sl <= RP_K0_E / 16; sl += RP_K0_T) {
+    const int i = 16 * sl;
     int lo = 0, hi = n_buckets;  // the bucket with lstart[lo] <= i < lstart[lo + 1] (empty buckets share a start: take the last)
     while (hi - lo > 1) {
       const int m = (lo + hi) >> 1;
       if (lstart[m] <= i) lo = m; else hi = m;
     }
-    out[hist[lo] + i] = stage[i];
+    ptab[sl] = (uint16_t)lo;
+  }
+  __syncthreads();
+  const int total = lstart[n_buckets];
+  for (int i = tid; i < total; i += RP_K0_T) {
+    int b = ptab[i >> 4];
+    while (lstart[b + 1] <= i) ++b;
+    out[hist[b] + i] = stage[i];
   }
 }
 
@@ -441,15 +460,16 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
   RP_TRY(rp_exclusive_scan_i32(ctx, bucket_cnt, bucket_off, n_buckets));
   if (nnz > 0 && I > 0) {
     const unsigned pgrid = (unsigned)rp_cdiv(nnz, RP_K0_E);
-    const size_t plds = (size_t)RP_K0_E * (wide ? 8 : 4) + ((size_t)2 * n_buckets + 1) * 4 + ((size_t)RP_K0_E + 2) * 4;
+    const size_t plds = (size_t)RP_K0_E * (wide ? 8 : 4) + ((size_t)2 * n_buckets + 1) * 4 + ((size_t)RP_K0_E / 16 + 2) * 2 + ((size_t)RP_K0_E + 2) * 2 + 16;
+    const int pvec_ok = ((reinterpret_cast<uintptr_t>(m->x_idx) & 15) == 0) ? 1 : 0;
     if (wide) {
       RP_HIP(hipFuncSetAttribute((const void*)k_partition<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
       hipLaunchKernelGGL(k_partition<uint64_t>, dim3(pgrid), dim3(RP_K0_T), plds, st, m->x_ptr, m->x_idx, (int)U, (long long)nnz, (int)I, (int)i_lo,
-                         (int)i_hi, bshift, ubits, n_buckets, bucket_off, bucket_fill, (uint64_t*)sc, chunk_u0, n_chunks_re);
+                         (int)i_hi, bshift, ubits, n_buckets, bucket_off, bucket_fill, (uint64_t*)sc, chunk_u0, n_chunks_re, pvec_ok);
     } else {
       RP_HIP(hipFuncSetAttribute((const void*)k_partition<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
       hipLaunchKernelGGL(k_partition<uint32_t>, dim3(pgrid), dim3(RP_K0_T), plds, st, m->x_ptr, m->x_idx, (int)U, (long long)nnz, (int)I, (int)i_lo,
-                         (int)i_hi, bshift, ubits, n_buckets, bucket_off, bucket_fill, (uint32_t*)sc, chunk_u0, n_chunks_re);
+                         (int)i_hi, bshift, ubits, n_buckets, bucket_off, bucket_fill, (uint32_t*)sc, chunk_u0, n_chunks_re, pvec_ok);
     }
     hipLaunchKernelGGL(k_bucket_blocks, dim3((unsigned)rp_cdiv(n_buckets, 256)), dim3(256), 0, st, bucket_off, n_buckets, n_blk);
     RP_TRY(rp_exclusive_scan_i32(ctx, n_blk, blk_off, n_buckets));
