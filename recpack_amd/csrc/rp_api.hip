@@ -508,9 +508,35 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_final(const int32_t* __restrict
   }
 }
 
+// n <= SCAN_B: the whole scan in one launch (K0's bucket tables: three launches of 5 us each for 196 numbers)
+__global__ void __launch_bounds__(SCAN_T) k_scan_small(const int32_t* __restrict__ in, int32_t* __restrict__ out, int n) {
+  __shared__ int sm[32];
+  const int base = (int)threadIdx.x * SCAN_E;
+  int v[SCAN_E];
+  int s = 0;
+#pragma unroll
+  for (int e = 0; e < SCAN_E; ++e) {
+    v[e] = (base + e < n) ? in[base + e] : 0;
+    s += v[e];
+  }
+  int tot;
+  int ex = block_excl_scan(s, &tot, sm);
+#pragma unroll
+  for (int e = 0; e < SCAN_E; ++e) {
+    if (base + e < n) out[base + e] = ex;
+    ex += v[e];
+  }
+  if (threadIdx.x == 0) out[n] = tot;
+}
+
 int rp_exclusive_scan_i32(rphip_ctx* ctx, const int32_t* in, int32_t* out, int64_t n) {
   if (n <= 0) {
     RP_HIP(hipMemsetAsync(out, 0, sizeof(int32_t), ctx->stream));
+    return RPHIP_OK;
+  }
+  if (n <= SCAN_B) {
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(SCAN_T), 0, ctx->stream, in, out, (int)n);
+    RP_HIP(hipGetLastError());
     return RPHIP_OK;
   }
   int64_t nb = rp_cdiv(n, SCAN_B);

@@ -449,7 +449,9 @@ int rp_csr_prepare(rphip_ctx* ctx, rphip_csr* m) {
   {  // tile-relative columns, padded so that a chunk of eight read at any entry stays inside
     const size_t n_rel = (((size_t)nnz + 15) & ~(size_t)15) + 16;
     RP_TRY(rp_dev_alloc(ctx, n_rel * sizeof(uint16_t), (void**)&m->x_rel));
-    RP_HIP(hipMemsetAsync(m->x_rel, 0, n_rel * sizeof(uint16_t), st));
+    // (k_rows writes every entry; only the padding behind them is cleared)
+    const size_t done = (size_t)nnz & ~(size_t)7;
+    RP_HIP(hipMemsetAsync(m->x_rel + done, 0, (n_rel - done) * sizeof(uint16_t), st));
   }
   if (nnz > 0) {
     const int grid_s = (int)std::min<int64_t>((int64_t)ctx->n_cu * 6, rp_cdiv(nnz, RP_K0_RE));
