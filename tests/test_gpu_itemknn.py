@@ -615,6 +615,37 @@ def test_csr_for_a_row_shard(hip):
         np.testing.assert_array_equal(x, y)
 
 
+def test_csr_from_a_misaligned_index_array(hip):
+    """K0 reads four column indices per 16-byte load when the caller's index array allows it: a view that starts 4 bytes into an
+    allocation takes the scalar loads, the transposed matrix, degrees and neighbour lists are the same; several column tiles and a
+    single tile; a matrix whose entries end inside a chunk of 4 096."""
+    import torch
+
+    from recpack_amd.synth import powerlaw_csr
+
+    _lib, ctx = hip
+    dev = torch.device("cuda", 0)
+    for U, I, dens, seed in ((9000, 30000, 0.002, 92), (5000, 3000, 0.004, 93)):
+        ip, ix = powerlaw_csr(U, I, dens, seed=seed, device=dev)
+        assert ix.data_ptr() % 16 == 0
+        holder = torch.empty(ix.numel() + 1, dtype=torch.int32, device=dev)
+        holder[1:] = ix
+        ix_off = holder[1:]
+        assert ix_off.data_ptr() % 16 == 4
+        a = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
+        b = _lib.DeviceCSR.from_device(ctx, ip, ix_off, (U, I))
+        np.testing.assert_array_equal(a.item_degrees(), b.item_degrees())
+        assert a.num_products() == b.num_products()
+        ra = _lib.itemknn_fit(ctx, a, 40).topk_download()
+        rb = _lib.itemknn_fit(ctx, b, 40).topk_download()
+        for x, y in zip(ra, rb):
+            np.testing.assert_array_equal(x, y)
+        # against scipy's transpose
+        Xs = sp.csr_matrix((np.ones(ix.numel(), dtype=np.float32), ix.cpu().numpy(), ip.cpu().numpy()), shape=(U, I))
+        np.testing.assert_array_equal(b.item_degrees(), np.asarray(Xs.sum(axis=0)).ravel().astype(np.int32))
+        assert b.num_products() == int((np.diff(ip.cpu().numpy()).astype(np.int64) ** 2).sum())
+
+
 def test_limits_and_dense_corners(hip):
     """The corners of the supported range: K and Kp at their maxima, a column every user has, a user with every item,
     more neighbours requested than items exist."""
