@@ -693,13 +693,14 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
   hipStream_t su = R.su, sc = R.sc, sp = R.sp;
   // V[b]: the pivot column (n_pad rows) + P (nb rows); (W + 1) nb more rows make it the mirror's staging buffer as well
   const size_t v_rows = (size_t)n_pad + (size_t)(W + 2) * nb;
-  float *V[2] = {nullptr, nullptr}, *Town[2] = {nullptr, nullptr}, *Vs = nullptr, *Vg = nullptr, *colscale = nullptr;
+  float *V[2] = {nullptr, nullptr}, *Town[2] = {nullptr, nullptr}, *Vs = nullptr, *Vg = nullptr, *colscale = nullptr, *Ag = nullptr;
   int* info = nullptr;
   for (int b = 0; b < 2; ++b) {
     DTRY(R.alloc(v_rows * nb * sizeof(float), (void**)&V[b]));
     DTRY(R.alloc((size_t)std::max(nl, 1) * nb * nb * sizeof(float), (void**)&Town[b]));
   }
   DTRY(R.alloc((size_t)slots * nb * nb * sizeof(float), (void**)&Vs));
+  if (W > 1) DTRY(R.alloc((size_t)std::max(nl, 1) * nb * nb * sizeof(float), (void**)&Ag));  // the own panels' blocks of V right of the pivot, side by side
   if (W > 1)
     DTRY(R.alloc((size_t)W * slots * nb * nb * sizeof(float), (void**)&Vg));
   else
@@ -853,9 +854,19 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
     if (W == 1) {  // (one rank: the panels right of the pivot are consecutive rows of V)
       DTRY(gemm(Vc + (r0 + nb) * nb, nb, Pc, nb, Tc + (long long)(K + 1) * nb * nb, nb, (nl - K - 1) * nb, nb, 1.0f, 0.0f, st));
     } else {
-      for (int q = cnt + own_K; q < nl; ++q) {
-        const long long rows_at = (long long)rp_cyc_panel(q, me, W) * nb;
-        DTRY(gemm(Vc + rows_at * nb, nb, Pc, nb, Tc + (long long)q * nb * nb, nb, nb, nb, 1.0f, 0.0f, st));
+      // (round 5) ... in ONE product when there are several: their blocks of V are copied side by side (16 MB each at nb = 2048) and
+      // the product has enough tiles for the wide plane kernel; one by one they ran on the skinny kernel that cuts its planes on
+      // the fly (50 ms of an emulated rank's 476 ms fit at 100 000 items and eight ranks, tools/r05_e23.sh)
+      const int q0 = cnt + own_K, nq = nl - q0;
+      if (nq >= 2) {
+        for (int q = q0; q < nl; ++q)
+          copy2d(Vc + (long long)rp_cyc_panel(q, me, W) * nb * nb, nb, Ag + (long long)(q - q0) * nb * nb, nb, nb, nb, 1.0f, st);
+        DTRY(gemm(Ag, nb, Pc, nb, Tc + (long long)q0 * nb * nb, nb, nq * nb, nb, 1.0f, 0.0f, st));
+      } else {
+        for (int q = q0; q < nl; ++q) {
+          const long long rows_at = (long long)rp_cyc_panel(q, me, W) * nb;
+          DTRY(gemm(Vc + rows_at * nb, nb, Pc, nb, Tc + (long long)q * nb * nb, nb, nb, nb, 1.0f, 0.0f, st));
+        }
       }
     }
     if (own_K) {
