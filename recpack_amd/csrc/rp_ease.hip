@@ -58,6 +58,7 @@ __device__ __forceinline__ int rp_gemm_ncol(const rp_gemm_args& g, int n0) {
   return rp_cyc_panel(l / g.cyc_nb, g.cyc_r, g.cyc_w) * g.cyc_nb + l % g.cyc_nb;
 }
 __device__ __forceinline__ bool rp_gemm_skip(const rp_gemm_args& g, int m0, int n0) {
+  if (n0 >= g.n_skip0 && n0 < g.n_skip1) return true;
   if (g.tri == 1) return rp_gemm_ncol(g, n0) > g.m_off + m0;
   if (g.tri == 2) return rp_gemm_ncol(g, n0) >= g.m_off + m0;
   if (g.tri == 4) return rp_gemm_ncol(g, n0) > g.m_off + m0;  // (the wide plane product only: diagonal tiles go to g.Cd)
@@ -304,6 +305,7 @@ struct rp_amax_op {
   int kb_flag;  // the tile's K range begins at off + r0 (see rp_gemm_args::kb_m / kb_n)
   int ke_flag;  // ... ends at off + r0 + 128 (ke_n)
   int off;
+  int skip0, skip1;  // row tiles with r0 in [skip0, skip1) are not measured (rp_gemm_args::n_skip0 / n_skip1: nothing reads them)
 };
 
 // out[0] = max |A|, out[1] = max |B| (fp32 bit patterns, zeroed by the caller) over the K ranges the product will read.
@@ -315,6 +317,7 @@ __global__ void __launch_bounds__(256) k_gemm_amax(rp_amax_op a, rp_amax_op b, i
   const rp_amax_op o = is_b ? b : a;
   if (is_b) t -= a.tiles;
   const int r0 = t * GT;
+  if (r0 >= o.skip0 && r0 < o.skip1) return;  // (uniform over the workgroup)
   int kb = k0, ke = k1;
   if (o.kb_flag) kb = max(kb, o.off + r0);
   if (o.ke_flag) ke = min(ke, o.off + r0 + GT);
@@ -1531,8 +1534,8 @@ int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st, float* par
     unsigned* slot = g.amax_known ? const_cast<unsigned*>(g.amax_known) : ctx->gemm_amax_ring + 2 * (size_t)(ctx->gemm_amax_seq++ % RP_AMAX_SLOTS);
     if (!g.amax_known) RP_HIP(hipMemsetAsync(slot, 0, 2 * sizeof(unsigned), st));
     const int m_tiles = g.M / GT, n_tiles = g.N / GT;
-    rp_amax_op oa{g.A, g.lda, m_tiles, g.kb_m, 0, g.m_off};
-    rp_amax_op ob{g.B, g.ldb, n_tiles, g.kb_n, g.ke_n, g.n_off};
+    rp_amax_op oa{g.A, g.lda, m_tiles, g.kb_m, 0, g.m_off, 0, 0};
+    rp_amax_op ob{g.B, g.ldb, n_tiles, g.kb_n, g.ke_n, g.n_off, g.n_skip0, g.n_skip1};
     const int dup = (g.A == g.B && g.lda == g.ldb && m_tiles == n_tiles && g.kb_m == g.kb_n && !g.ke_n && (!g.kb_m || g.m_off == g.n_off)) ? 1 : 0;
     // many tiles and a K worth a pass of its own: planes cut once into the workspace, then the LDS-DMA product (see k_gemm_hp)
     const bool presplit = ctx->gemm_presplit && S == 1 && g.tri != 3 && tiles >= 512 && klen >= 1024 && !(g.k0 % 32) && !(g.k1 % 32);

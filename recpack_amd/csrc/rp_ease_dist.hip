@@ -746,7 +746,7 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
   }
 
   auto gemm = [&](const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, int M, int N, float al, float be,
-                  hipStream_t s, int tri = 0, int m_off = 0, int l0 = 0) -> int {
+                  hipStream_t s, int tri = 0, int m_off = 0, int l0 = 0, int skip0 = 0, int skip1 = 0) -> int {
     if (M <= 0 || N <= 0) return RPHIP_OK;
     rp_gemm_args g{};
     g.A = A;
@@ -770,8 +770,10 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
       g.cyc_l0 = l0;
     }
     g.no_splitk = 1;
+    g.n_skip0 = skip0;
+    g.n_skip1 = skip1;
     if (s == su) g.ws_slot = 12;
-    flop += 2.0 * M * (double)N * nb * (tri ? 0.5 : 1.0);
+    flop += 2.0 * M * (double)(N - (skip1 - skip0)) * nb * (tri ? 0.5 : 1.0);
     return rp_gemm_nt(ctx, g, s);
   };
   auto copy2d = [&](const float* src, long long lds_, float* dst, long long ldd, long long rows, int cols, float scale, hipStream_t s) {
@@ -909,12 +911,13 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
       const long long r2 = r0 + 2LL * nb;             // first row below the block K + 1
       // rows above the pivot, panels left of it (lower tiles)
       DTRY(gemm(Vc, nb, Tc, nb, S, ld, (int)r0, cnt * nb, -1.0f, 1.0f, su, 1, 0, 0));
-      if (r2 < n_pad) {
-        // rows below block K + 1: panels left of the pivot (all tiles) ...
-        DTRY(gemm(Vc + r2 * nb, nb, Tc, nb, S + r2 * ld, ld, n_pad - (int)r2, cnt * nb, -1.0f, 1.0f, su));
-        // ... and panels right of K + 1 (lower tiles)
-        DTRY(gemm(Vc + r2 * nb, nb, Tc + (long long)l3 * nb * nb, nb, S + r2 * ld + (long long)l3 * nb, ld, n_pad - (int)r2, (nl - l3) * nb, -1.0f,
-                  1.0f, su, 1, (int)r2, l3 * nb));
+      if (r2 < n_pad && (cnt > 0 || l3 < nl)) {
+        // rows below block K + 1, ALL own panels in one product (round 5; two before - the rows' planes cut twice): panels left of the
+        // pivot take every tile and panels right of K + 1 the lower tiles - the tri rule says exactly that, a column left of the
+        // pivot lies below every one of these rows - and the panels K, K + 1 themselves are skipped
+        const double f0 = flop;
+        DTRY(gemm(Vc + r2 * nb, nb, Tc, nb, S + r2 * ld, ld, n_pad - (int)r2, nl * nb, -1.0f, 1.0f, su, 1, (int)r2, 0, cnt * nb, l3 * nb));
+        flop = f0 + 2.0 * (double)(n_pad - r2) * nb * ((double)cnt * nb + 0.5 * (double)(nl - l3) * nb);
       }
       timed_end(su, t_upd, RPHIP_T_SWEEP_UPDATE, flop - flop1);
       DHIP(hipEventRecord(e_upd, su));

@@ -33,6 +33,7 @@ struct rp_gemm_args {
                      // 3: the diagonal tiles only (grid.x = 1), written to C as a stack of blocks [M][128] (ldc = 128);
                      // 4 (the wide plane product, both operands cached): as 1, the diagonal tiles written to the stack Cd instead of C
   float* Cd;         // tri = 4: [tile][128][128]
+  int n_skip0, n_skip1;  // tiles whose first column n0 lies in [n_skip0, n_skip1) are not computed (0, 0: every tile the tri rule leaves)
   float alpha, beta;
   // split-K (skinny products with few tiles and a long K): blockIdx.z = s handles K chunk s and writes its partial
   // tile to part[s][M][N] (alpha = 1, beta = 0); k_splitk_reduce applies alpha / beta to C afterwards
