@@ -59,6 +59,7 @@ __device__ __forceinline__ int rp_gemm_ncol(const rp_gemm_args& g, int n0) {
 }
 __device__ __forceinline__ bool rp_gemm_skip(const rp_gemm_args& g, int m0, int n0) {
   if (n0 >= g.n_skip0 && n0 < g.n_skip1) return true;
+  if (m0 >= g.m_skip0 && m0 < g.m_skip1) return true;
   if (g.tri == 1) return rp_gemm_ncol(g, n0) > g.m_off + m0;
   if (g.tri == 2) return rp_gemm_ncol(g, n0) >= g.m_off + m0;
   if (g.tri == 4) return rp_gemm_ncol(g, n0) > g.m_off + m0;  // (the wide plane product only: diagonal tiles go to g.Cd)
@@ -1534,7 +1535,7 @@ int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st, float* par
     unsigned* slot = g.amax_known ? const_cast<unsigned*>(g.amax_known) : ctx->gemm_amax_ring + 2 * (size_t)(ctx->gemm_amax_seq++ % RP_AMAX_SLOTS);
     if (!g.amax_known) RP_HIP(hipMemsetAsync(slot, 0, 2 * sizeof(unsigned), st));
     const int m_tiles = g.M / GT, n_tiles = g.N / GT;
-    rp_amax_op oa{g.A, g.lda, m_tiles, g.kb_m, 0, g.m_off, 0, 0};
+    rp_amax_op oa{g.A, g.lda, m_tiles, g.kb_m, 0, g.m_off, g.m_skip0, g.m_skip1};
     rp_amax_op ob{g.B, g.ldb, n_tiles, g.kb_n, g.ke_n, g.n_off, g.n_skip0, g.n_skip1};
     const int dup = (g.A == g.B && g.lda == g.ldb && m_tiles == n_tiles && g.kb_m == g.kb_n && !g.ke_n && (!g.kb_m || g.m_off == g.n_off)) ? 1 : 0;
     // many tiles and a K worth a pass of its own: planes cut once into the workspace, then the LDS-DMA product (see k_gemm_hp)

@@ -746,7 +746,7 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
   }
 
   auto gemm = [&](const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, int M, int N, float al, float be,
-                  hipStream_t s, int tri = 0, int m_off = 0, int l0 = 0, int skip0 = 0, int skip1 = 0) -> int {
+                  hipStream_t s, int tri = 0, int m_off = 0, int l0 = 0, int skip0 = 0, int skip1 = 0, int mskip0 = 0, int mskip1 = 0) -> int {
     if (M <= 0 || N <= 0) return RPHIP_OK;
     rp_gemm_args g{};
     g.A = A;
@@ -772,6 +772,8 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
     g.no_splitk = 1;
     g.n_skip0 = skip0;
     g.n_skip1 = skip1;
+    g.m_skip0 = mskip0;
+    g.m_skip1 = mskip1;
     if (s == su) g.ws_slot = 12;
     flop += 2.0 * M * (double)(N - (skip1 - skip0)) * nb * (tri ? 0.5 : 1.0);
     return rp_gemm_nt(ctx, g, s);
@@ -909,15 +911,17 @@ extern "C" int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip
       timed(su, &t_upd);
       const int l3 = cnt + own_K + (own_K1 ? 1 : 0);  // first local panel right of K + 1
       const long long r2 = r0 + 2LL * nb;             // first row below the block K + 1
-      // rows above the pivot, panels left of it (lower tiles)
-      DTRY(gemm(Vc, nb, Tc, nb, S, ld, (int)r0, cnt * nb, -1.0f, 1.0f, su, 1, 0, 0));
-      if (r2 < n_pad && (cnt > 0 || l3 < nl)) {
-        // rows below block K + 1, ALL own panels in one product (round 5; two before - the rows' planes cut twice): panels left of the
-        // pivot take every tile and panels right of K + 1 the lower tiles - the tri rule says exactly that, a column left of the
-        // pivot lies below every one of these rows - and the panels K, K + 1 themselves are skipped
+      // (round 5) ONE product for the whole update - three before, the planes of V's rows and of T cut twice: all rows of V except the
+      // blocks K and K + 1 (skipped), all own panels except K and K + 1 (skipped), lower tiles (tri = 1).  The tri rule gives each
+      // part what it had: rows above the pivot x panels left of it their lower tiles, rows below x panels left every tile (a column
+      // left of the pivot lies below all of these rows), rows below x panels right of K + 1 the lower tiles, rows above x panels
+      // right nothing.
+      if ((cnt > 0 && (r0 > 0 || r2 < n_pad)) || (l3 < nl && r2 < n_pad)) {
         const double f0 = flop;
-        DTRY(gemm(Vc + r2 * nb, nb, Tc, nb, S + r2 * ld, ld, n_pad - (int)r2, nl * nb, -1.0f, 1.0f, su, 1, (int)r2, 0, cnt * nb, l3 * nb));
-        flop = f0 + 2.0 * (double)(n_pad - r2) * nb * ((double)cnt * nb + 0.5 * (double)(nl - l3) * nb);
+        const int m_rows = (int)std::min<long long>(n_pad, std::max<long long>(r2 < n_pad ? n_pad : r0, 0));
+        DTRY(gemm(Vc, nb, Tc, nb, S, ld, m_rows, nl * nb, -1.0f, 1.0f, su, 1, 0, 0, cnt * nb, l3 * nb, (int)r0, (int)std::min<long long>(r2, m_rows)));
+        flop = f0 + 2.0 * nb * (0.5 * (double)r0 * cnt * nb +
+                                (r2 < n_pad ? (double)(n_pad - r2) * ((double)cnt * nb + 0.5 * (double)(nl - l3) * nb) : 0.0));
       }
       timed_end(su, t_upd, RPHIP_T_SWEEP_UPDATE, flop - flop1);
       DHIP(hipEventRecord(e_upd, su));

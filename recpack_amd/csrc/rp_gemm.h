@@ -34,6 +34,7 @@ struct rp_gemm_args {
                      // 4 (the wide plane product, both operands cached): as 1, the diagonal tiles written to the stack Cd instead of C
   float* Cd;         // tri = 4: [tile][128][128]
   int n_skip0, n_skip1;  // tiles whose first column n0 lies in [n_skip0, n_skip1) are not computed (0, 0: every tile the tri rule leaves)
+  int m_skip0, m_skip1;  // ... and tiles (128-row halves of the wide kernel's) whose first row m0 lies in [m_skip0, m_skip1)
   float alpha, beta;
   // split-K (skinny products with few tiles and a long K): blockIdx.z = s handles K chunk s and writes its partial
   // tile to part[s][M][N] (alpha = 1, beta = 0); k_splitk_reduce applies alpha / beta to C afterwards
