@@ -492,6 +492,24 @@ int rphip_ease_fit_dist(rphip_ctx* ctx, rphip_comm* comm, const rphip_csr* X, do
  * that do not fit.  The reference has no multi-GPU path (recpack/algorithms/base.py:454-455). */
 int rphip_ease_model_allgather(rphip_ctx* ctx, rphip_comm* comm, const rphip_model* local, int64_t n_items, int64_t panel_cols,
                                rphip_model** out);
+/* (round 5) The gathered model's int8 rows ALONE - their scales and error bounds with them, n^2 bytes where the full model takes
+ * 5 n^2: what rphip_predict_topk_owner needs on every rank.  The result's f32 matrix is absent: every other entry point refuses it
+ * (RPHIP_ESTATE).  Needs the options predict_half and predict_int8 (the defaults) and more than one rank. */
+int rphip_ease_model_allgather_i8(rphip_ctx* ctx, rphip_comm* comm, const rphip_model* local, int64_t n_items, int64_t panel_cols,
+                                  rphip_model** out);
+/* Fused predict + top-Kp for this rank's users [user_bounds[rank], user_bounds[rank + 1]) (the same world + 1 bounds on every rank,
+ * from 0 to n_users; the prediction matrix replicated) with the exact scores formed by the OWNERS of the columns: every rank runs
+ * the int8 first pass for its users on `rows_i8` (rphip_ease_model_allgather_i8), the candidate lists are all-gathered, every rank
+ * sums the f32 entries of the candidates whose column lies in `local` (its model of rphip_ease_fit_dist; NULL on a rank that owns
+ * only padding) for the users of ALL ranks - history order, one add per row: the single-GPU sums - one personalised exchange returns
+ * them, the user's rank ranks and proves its list; users without a proof are scored exactly by every rank on its own columns and
+ * their local lists merged on their rank.  The result is the single-GPU rphip_predict_topk's (base.py:248 + metrics/base.py:189) bit
+ * for bit; no rank ever holds the f32 matrix.  idx / val / nnz (device): n * Kp / n entries for the rank's n users.  RPHIP_ELIMIT
+ * outside the first pass's range (Kp > 164, fewer than 4 * (Kp + 92) items, history removal on unsorted rows) and RPHIP_ENOMEM (agreed
+ * on by all ranks) when the buffers do not fit: rphip_predict_topk_dist serves those. */
+int rphip_predict_topk_owner(rphip_ctx* ctx, rphip_comm* comm, const rphip_model* local, const rphip_model* rows_i8, const rphip_csr* Xpred,
+                             const int64_t* user_bounds, int32_t Kp, int32_t exclude_history, int32_t* idx_dev, float* val_dev,
+                             int32_t* nnz_dev);
 /* Fused predict + top-Kp with the model's columns spread over the ranks of `comm` (the models of rphip_ease_fit_dist; `model` NULL
  * on a rank that owns only padding): every rank scores the users against its own columns, the local lists travel to the rank
  * that owns the user (one personalised exchange per chunk of users) and are merged there by (score desc, column asc) - the

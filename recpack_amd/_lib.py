@@ -121,6 +121,8 @@ PROTOTYPES = {
     "rphip_ease_fit_dist": (C.c_int, [_p, _p, _p, _f64, _f64, _i32, _pp]),
     "rphip_model_dense_layout": (C.c_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64)]),
     "rphip_itemknn_gather": (C.c_int, [_p, _p, _p, _p, _pp]),
+    "rphip_ease_model_allgather_i8": (C.c_int, [_p, _p, _p, _i64, _i64, _pp]),
+    "rphip_predict_topk_owner": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p]),
     "rphip_predict_topk_dist": (C.c_int, [_p, _p, _p, _p, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64), _p, _p, _p]),
     "rphip_comm_selftest": (C.c_int, [_p, _p, _i32, _i64, C.POINTER(_i64), C.POINTER(_f64)]),
 }
@@ -131,6 +133,7 @@ DIAG_PROTOTYPES = {
     "rphip_gemm_nt_f32_ex": (C.c_int, [_p, _i64, _i64, _i64, _i64, C.c_float, _p, _i64, _p, _i64, C.c_float, _p, _i64, _i32, _i32, _i64, _i64, _i32]),
     "rphip_comm_loopback_create": (C.c_int, [_p, _i32, _i32, C.c_double, C.c_double, _pp]),
     "rphip_ease_fit_dist_stats": (C.c_int, [_p, _p]),
+    "rphip_predict_owner_stats": (C.c_int, [_p, _p]),
 }
 
 _lock = threading.Lock()
@@ -746,6 +749,43 @@ def ease_model_allgather(ctx: Context, comm: Comm, model, n_items: int, panel_co
     return Model(ctx, h)
 
 
+def _comm_call(comm: Comm, fn):
+    """Run a library call that may invoke the communicator's callbacks: an exception raised inside one of them is re-raised here."""
+    try:
+        return fn()
+    except RecpackHipError:
+        err = comm.error["error"] if isinstance(comm.error, dict) else None
+        if err is not None:
+            comm.error["error"] = None
+            raise err
+        raise
+
+
+def ease_model_allgather_i8(ctx: Context, comm: Comm, model, n_items: int, panel_cols: int) -> Model:
+    """The gathered model's int8 rows alone (rphip_ease_model_allgather_i8): a fifth of the full gathered model's memory, what
+    :func:`predict_topk_owner` needs on every rank.  ``model`` may be None on a rank that owns only padding."""
+    h = C.c_void_p()
+    _comm_call(comm, lambda: check(ctx.lib.rphip_ease_model_allgather_i8(ctx.handle, comm.handle, model.handle if model is not None else None,
+                                                                        int(n_items), int(panel_cols), C.byref(h))))
+    return Model(ctx, h)
+
+
+def predict_topk_owner(ctx: Context, comm: Comm, local, rows_i8: Model, X: DeviceCSR, user_bounds, Kp: int, idx_t, val_t, nnz_t,
+                       exclude_history: bool = False):
+    """Top-Kp of this rank's users ``[user_bounds[rank], user_bounds[rank + 1])`` with the exact scores formed by the owners of the
+    columns (rphip_predict_topk_owner): first pass on the gathered int8 rows, candidates all-gathered, sums from every rank's own
+    panels, one exchange back, ranking and proof here; the single-GPU result bit for bit.  ``user_bounds``: world + 1 ints, the same
+    on every rank.  The outputs (torch CUDA tensors) hold this rank's users."""
+    _torch_inputs_ready(ctx)
+    ub = np.ascontiguousarray(np.asarray(user_bounds, dtype=np.int64))
+    if ub.shape != (comm.world + 1,):
+        raise ValueError(f"user_bounds must hold world + 1 = {comm.world + 1} entries")
+    _comm_call(comm, lambda: check(ctx.lib.rphip_predict_topk_owner(ctx.handle, comm.handle, local.handle if local is not None else None, rows_i8.handle,
+                                                                   X.handle, _np_ptr(ub), int(Kp), 1 if exclude_history else 0,
+                                                                   C.c_void_p(idx_t.data_ptr()), C.c_void_p(val_t.data_ptr()),
+                                                                   C.c_void_p(nnz_t.data_ptr()))))
+
+
 def predict_topk_dist(ctx: Context, comm: Comm, model, X: DeviceCSR, Kp: int, idx_t, val_t, nnz_t, exclude_history: bool = False):
     """Top-Kp of every user with the model's columns spread over the ranks of ``comm`` (rphip_predict_topk_dist): local lists,
     one exchange per chunk inside the library, merge on the rank that owns the user.  The outputs (torch CUDA tensors of
@@ -763,6 +803,14 @@ def predict_topk_dist(ctx: Context, comm: Comm, model, X: DeviceCSR, Kp: int, id
             raise err
         raise
     return ub.value, nu.value
+
+
+def predict_owner_stats(ctx: Context) -> dict:
+    """The last :func:`predict_topk_owner` of this context (diagnostic): users without a proof over all ranks / of this rank,
+    candidates per user, bytes of the route's buffers."""
+    out = np.zeros(4, dtype=np.int64)
+    check(ctx.lib.rphip_predict_owner_stats(ctx.handle, _np_ptr(out)))
+    return {"unproven_all_ranks": int(out[0]), "unproven_here": int(out[1]), "candidates_per_user": int(out[2]), "buffer_bytes": int(out[3])}
 
 
 def ease_fit_dist_stats(ctx: Context) -> dict:

@@ -1140,9 +1140,26 @@ __global__ void k_unpack_panels_i8(const int8_t* __restrict__ recv, long long sl
 // to rescore W times over, no exchange of lists.  The column-sharded rphip_predict_topk_dist stays for matrices that do not fit
 // (5M x 200K: B alone is 160 GB).  `local` = this rank's model of rphip_ease_fit_dist (NULL on a rank that owns only padding),
 // n_items and panel_cols as every rank's layout reports them.  Strips of rows travel one all-gather each.
+static int rp_model_allgather_impl(rphip_ctx* ctx, rphip_comm* comm, const rphip_model* local, int64_t n_items, int64_t panel_cols, bool i8_only,
+                                   rphip_model** out);
+
 extern "C" int rphip_ease_model_allgather(rphip_ctx* ctx, rphip_comm* comm, const rphip_model* local, int64_t n_items, int64_t panel_cols,
                                           rphip_model** out) {
   RP_ENTER(ctx);
+  return rp_model_allgather_impl(ctx, comm, local, n_items, panel_cols, false, out);
+}
+
+// (round 5) Only the int8 rows, their scales and error bounds - n^2 bytes instead of 5 n^2: the model of rphip_predict_topk_owner,
+// whose exact scores are formed by the owners of the candidates' columns from the panels where the fit left them.  B of the result is
+// NULL: every other entry point refuses it.
+extern "C" int rphip_ease_model_allgather_i8(rphip_ctx* ctx, rphip_comm* comm, const rphip_model* local, int64_t n_items, int64_t panel_cols,
+                                             rphip_model** out) {
+  RP_ENTER(ctx);
+  return rp_model_allgather_impl(ctx, comm, local, n_items, panel_cols, true, out);
+}
+
+static int rp_model_allgather_impl(rphip_ctx* ctx, rphip_comm* comm, const rphip_model* local, int64_t n_items, int64_t panel_cols, bool i8_only,
+                                   rphip_model** out) {
   if (!ctx || !comm || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   *out = nullptr;
   const int W = comm->world, me = comm->rank;
@@ -1172,7 +1189,13 @@ extern "C" int rphip_ease_model_allgather(rphip_ctx* ctx, rphip_comm* comm, cons
       return ra;
     }
   }
-  int rc = rp_dev_alloc(ctx, (size_t)n_pad * n_pad * sizeof(float), (void**)&m->B);
+  if (i8_only && !(ctx->predict_half && ctx->predict_int8 && (n_pad % 16) == 0 && comm->world > 1)) {
+    rp_dev_free(ctx, agree);
+    delete m;
+    RP_FAIL(RPHIP_ESTATE, "the int8 rows alone need predict_half, predict_int8, more than one rank and a padded size that is a multiple of 16");
+  }
+  m->rows_i8_only = i8_only;
+  int rc = i8_only ? RPHIP_OK : rp_dev_alloc(ctx, (size_t)n_pad * n_pad * sizeof(float), (void**)&m->B);
   // strips of rows: W slots of strip x ldl floats, at most ~2 GiB of staging in all
   long long strip = std::max<long long>(128, ((long long)((size_t)2 << 30) / ((long long)(W + 1) * ldl * 4)) / 128 * 128);
   strip = std::min(strip, n_pad);
@@ -1256,6 +1279,19 @@ extern "C" int rphip_ease_model_allgather(rphip_ctx* ctx, rphip_comm* comm, cons
   }
   // ---- phase 2: the f32 rows (the rescoring and the exact pass read them), on a stream of their own when the int8 rows exist:
   // K9's first pass for this rank's users runs beside it
+  if (i8_only) {
+    rp_time_end(ctx, ev, RPHIP_T_MIRROR, (double)n_pad * n_pad);
+    hipStreamSynchronize(st);  // (the staging is released; the call is synchronous like the other model constructors)
+    rp_dev_free(ctx, sendb);
+    rp_dev_free(ctx, recvb);
+    if (rc != RPHIP_OK) {
+      rphip_model_destroy(m);
+      return rc;
+    }
+    m->empty_rows = -1;
+    *out = m;
+    return RPHIP_OK;
+  }
   hipStream_t gs = st;
   if (q8 && rc == RPHIP_OK && !comm->ops.all_gather) {  // (a callback transport completes every operation on the host: nothing to overlap)
     if (hipStreamCreateWithFlags(&m->gather_stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&m->gather_ev, hipEventDisableTiming) == hipSuccess) {

@@ -508,12 +508,13 @@ __global__ void __launch_bounds__(RP_PRED_THREADS, HC8 == 2 ? 8 : 4) k_predict_t
       const int kk = (P.mode == 0) ? P.Kp : 0x7fffffff;
       const int kp = rp_select_topk<RP_PRED_THREADS>(src, n_cols, kk, sel);
       if (P.mode == 0) {
-        const int64_t o = (T == 1) ? (int64_t)ul * P.Kp : ((int64_t)uo * T + tile) * (P.tile_cap > 0 ? P.tile_cap : P.Kp);
+        const int urow = (P.list_compact == 2) ? uo : ul;  // (2: one tile and a user list - the output rows go by list position too)
+        const int64_t o = (T == 1) ? (int64_t)urow * P.Kp : ((int64_t)uo * T + tile) * (P.tile_cap > 0 ? P.tile_cap : P.Kp);
         rp_select_emit<RP_PRED_THREADS>(n_cols, sel, [&](int pos, int w) {
           P.out_idx[o + pos] = rp_pred_l2g(P, t0 + w);
           P.out_val[o + pos] = (float)score(w);
         });
-        if (tid == 0) P.out_nnz[(T == 1) ? ul : uo * T + tile] = kp;
+        if (tid == 0) P.out_nnz[(T == 1) ? urow : uo * T + tile] = kp;
       } else if (P.mode == 2) {
         rp_select_emit<RP_PRED_THREADS>(n_cols, sel, [&](int pos, int w) {
           P.full_idx[off + pos] = rp_pred_l2g(P, t0 + w);
@@ -664,10 +665,20 @@ struct rp_rescore_params {
   int32_t* fail_list;  // users whose list does not prove its top-Kp (ul + fail_base); count in *n_fail
   int fail_base;
   int32_t* n_fail;
+  // (round 5) the rescoring split between the owners of the candidates' columns (rphip_predict_topk_owner), MODE of the kernel:
+  //   1  B holds THIS rank's columns only (col_begin / n_own_cols or cyc_*): the exact sums of the candidates it owns go to
+  //      part_out[ul][Kc] (0 for the others and for what the skip rule leaves out), nothing is ranked;
+  //   2  nothing is gathered: a candidate's exact sum is the sum over the n_parts ranks' parts part_in[s][n_users][Kc] - one of them
+  //      holds it, the others 0 - then the ranking and the proof as in mode 0.  Both modes take the skip decisions from the same
+  //      code on the same numbers, so every rank leaves out the same candidates.
+  float* part_out;
+  const float* part_in;
+  int n_parts;
+  int n_own_cols;  // mode 1 without a block-cyclic layout: the rank owns columns [col_begin, col_begin + n_own_cols)
 };
 
 // one wave per user; NQ = candidates per lane
-template <int NQ>
+template <int NQ, int MODE = 0>
 __global__ void __launch_bounds__(256) k_predict_rescore(rp_rescore_params P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -679,6 +690,7 @@ __global__ void __launch_bounds__(256) k_predict_rescore(rp_rescore_params P) {
     const int nc = P.cand_nnz[ul];
     if (nc < 0) continue;  // (the first pass per user gave this one to the fallback list itself: his candidate list overflowed)
     int col[NQ], loc[NQ];
+    bool mine[NQ];  // (mode 1: the candidate's column is this rank's)
     float e[NQ], av[NQ];
     float amin = 3.0e38f;
 #pragma unroll
@@ -689,15 +701,19 @@ __global__ void __launch_bounds__(256) k_predict_rescore(rp_rescore_params P) {
       av[q] = on ? P.cand_val[(long long)ul * P.Kc + k] : -3.0e38f;
       if (on) amin = fminf(amin, av[q]);
       int l = 0;
+      bool own = true;
       if (on) {
         if (P.cyc_nb) {
           const int p = col[q] / P.cyc_nb;
           l = (p / P.cyc_w) * P.cyc_nb + col[q] % P.cyc_nb;
+          if (MODE == 1) own = rp_cyc_owner(p, P.cyc_w) == P.cyc_r;  // (block-cyclic with reflected odd rounds, rp_common.h)
         } else {
           l = col[q] - P.col_begin;
+          if (MODE == 1) own = (unsigned)l < (unsigned)P.n_own_cols;
         }
       }
-      loc[q] = l;
+      loc[q] = (MODE == 1 && !own) ? 0 : l;
+      mine[q] = on && own;
       e[q] = 0.0f;
     }
     // the bound of |approximate - exact| for this user
@@ -760,8 +776,23 @@ __global__ void __launch_bounds__(256) k_predict_rescore(rp_rescore_params P) {
       }
       RP_WAVE_FENCE();
     }
+    if (MODE == 1) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) skip[q] = skip[q] || !mine[q];  // (a_skip keeps the value every rank computes: all candidates)
+    }
     // exact scores: the one-pass kernel's sums, same order (history order, one add per row)
-    int h = hs;
+    int h = (MODE == 2) ? he : hs;
+    if (MODE == 2) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int k = lane + 64 * q;
+        if (k < nc && !skip[q]) {
+          float sum = 0.0f;  // (one part holds the score, the others +0: the sum is that score, bit for bit)
+          for (int sp = 0; sp < P.n_parts; ++sp) sum += P.part_in[((long long)sp * P.n_users + ul) * P.Kc + k];
+          e[q] = sum;
+        }
+      }
+    }
     for (; h + 3 < he; h += 4) {
       const float* R0 = P.B + (long long)P.x_idx[h] * P.ld;
       const float* R1 = P.B + (long long)P.x_idx[h + 1] * P.ld;
@@ -790,6 +821,15 @@ __global__ void __launch_bounds__(256) k_predict_rescore(rp_rescore_params P) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
       if (skip[q]) e[q] = 0.0f;  // (not a candidate any more: a zero score is none)
+    if (MODE == 1) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int k = lane + 64 * q;
+        if (k < P.Kc) P.part_out[(long long)ul * P.Kc + k] = e[q];
+      }
+      RP_WAVE_FENCE();
+      continue;
+    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const bool ok = col[q] >= 0 && e[q] != 0.0f;  // (a score that cancels to exactly zero is not stored)
@@ -1714,6 +1754,8 @@ static int rp_pred_check(rphip_ctx* ctx, const rphip_model* model, const rphip_c
   if (!ctx || !model || !X) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   if (model->kind != RPHIP_MODEL_TOPK && model->kind != RPHIP_MODEL_DENSE) RP_FAIL(RPHIP_ESTATE, "unknown model kind");
   if (model->is_gram) RP_FAIL(RPHIP_ESTATE, "this handle holds a Gram matrix (rphip_ease_gram_create), not a fitted model");
+  if (model->kind == RPHIP_MODEL_DENSE && !model->B)
+    RP_FAIL(RPHIP_ESTATE, "this model holds the int8 rows only (rphip_ease_model_allgather_i8): predict with rphip_predict_topk_owner");
   if (model->row_begin != 0 || model->row_end != model->n_items)
     RP_FAIL(RPHIP_ESTATE, "the model holds rows [%lld,%lld) of %lld: assemble all rows before predict", (long long)model->row_begin,
             (long long)model->row_end, (long long)model->n_items);
@@ -1882,10 +1924,51 @@ static int rp_model_half(rphip_ctx* ctx, const rphip_model* m, int kind) {
   return RPHIP_OK;
 }
 
-template <int NQ>
+template <int NQ, int MODE = 0>
 static void rp_launch_rescore(rphip_ctx* ctx, const rp_rescore_params& R) {
   const int grid = (int)std::min<int64_t>(rp_cdiv(R.n_users, 4), (int64_t)ctx->n_cu * 8);
-  hipLaunchKernelGGL(k_predict_rescore<NQ>, dim3(grid), dim3(256), (size_t)4 * 2 * 64 * NQ * 4, ctx->stream, R);
+  hipLaunchKernelGGL((k_predict_rescore<NQ, MODE>), dim3(grid), dim3(256), (size_t)4 * 2 * 64 * NQ * 4, ctx->stream, R);
+}
+template <int MODE>
+static void rp_launch_rescore_kc(rphip_ctx* ctx, const rp_rescore_params& R) {  // Kc <= 256
+  switch (R.Kc / 64) {
+    case 1: rp_launch_rescore<1, MODE>(ctx, R); break;
+    case 2: rp_launch_rescore<2, MODE>(ctx, R); break;
+    case 3: rp_launch_rescore<3, MODE>(ctx, R); break;
+    default: rp_launch_rescore<4, MODE>(ctx, R); break;
+  }
+}
+
+// The first pass with one task per user (rp_predict_i8.hip) on the int8 rows of `mm`: approximate top-Kc of users
+// [user_begin, user_begin + n) into a_idx / a_val [n][Kc] and a_nnz [n] (-1: the user's list overflowed - he is appended to `fail`
+// by his local id).  n_fail: [0] the fail list's count, [1] the pass's ticket (both zeroed by the caller).
+static int rp_first_pass_i8(rphip_ctx* ctx, const rphip_model* mm, const rphip_csr* Xpred, const rp_pred_params& P, int64_t user_begin, int64_t n,
+                            int Kc, int exclude_history, int32_t* a_idx, float* a_val, int32_t* a_nnz, int32_t* fail, int32_t* n_fail,
+                            bool leave_room) {
+  rp_i8_params U8;
+  U8.x_ptr = Xpred->x_ptr;
+  U8.x_idx = Xpred->x_idx;
+  U8.B8 = reinterpret_cast<const int8_t*>(mm->B16);
+  U8.ld = mm->ld;
+  U8.b8_scale = mm->b8_scale;
+  U8.n_items = P.n_items;
+  RP_TRY(rp_predict_user_i8_geometry(P.n_items, &U8.n_tiles, &U8.tile_w));
+  U8.col_begin = P.col_begin;
+  U8.cyc_nb = P.cyc_nb;
+  U8.cyc_w = P.cyc_w;
+  U8.cyc_r = P.cyc_r;
+  U8.exclude_history = exclude_history;
+  U8.user_begin = (int)user_begin;
+  U8.n_users = (int)n;
+  U8.Kc = Kc;
+  U8.out_idx = a_idx;
+  U8.out_val = a_val;
+  U8.out_nnz = a_nnz;
+  U8.fail_list = fail;
+  U8.n_fail = n_fail;
+  U8.fail_base = 0;
+  U8.ticket = nullptr;
+  return rp_predict_user_i8(ctx, U8, n_fail + 1, leave_room);
 }
 
 static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin,
@@ -2052,32 +2135,9 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
         int32_t* fail = a_nnz + n;
         int32_t* n_fail = fail + n;  // [0] count, [1] the first pass's ticket
         hipMemsetAsync(n_fail, 0, 8, st);
-        rp_i8_params U8;
-        U8.x_ptr = Xpred->x_ptr;
-        U8.x_idx = Xpred->x_idx;
-        U8.B8 = reinterpret_cast<const int8_t*>(mm->B16);
-        U8.ld = model->ld;
-        U8.b8_scale = mm->b8_scale;
-        U8.n_items = P.n_items;
-        RP_TRY(rp_predict_user_i8_geometry(P.n_items, &U8.n_tiles, &U8.tile_w));
-        U8.col_begin = P.col_begin;
-        U8.cyc_nb = P.cyc_nb;
-        U8.cyc_w = P.cyc_w;
-        U8.cyc_r = P.cyc_r;
-        U8.exclude_history = exclude_history;
-        U8.user_begin = (int)user_begin;
-        U8.n_users = (int)n;
-        U8.Kc = Kc;
-        U8.out_idx = a_idx;
-        U8.out_val = a_val;
-        U8.out_nnz = a_nnz;
-        U8.fail_list = fail;
-        U8.n_fail = n_fail;
-        U8.fail_base = 0;
-        U8.ticket = nullptr;
-        RP_TRY(rp_predict_user_i8(ctx, U8, n_fail + 1, model->gather_ev != nullptr));
+        RP_TRY(rp_first_pass_i8(ctx, mm, Xpred, P, user_begin, n, Kc, exclude_history, a_idx, a_val, a_nnz, fail, n_fail, model->gather_ev != nullptr));
         RP_TRY(rp_model_gather_wait(ctx, model, true));  // (a gathered model: the f32 rows the rescoring reads arrive beside the first pass)
-        rp_rescore_params R;
+        rp_rescore_params R{};
         R.x_ptr = Xpred->x_ptr;
         R.x_idx = Xpred->x_idx;
         R.B = model->B;
@@ -2215,7 +2275,7 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
           hipLaunchKernelGGL(k_predict_merge, dim3(mgrid), dim3(RP_PRED_THREADS), mlds_c, st, t_idx, t_val, t_nnz, Th, Kc, (int)nch, nullptr, nullptr, a_idx,
                              a_val, a_nnz, 0, stride_t);
         // second pass: exact scores of the candidates, their top-Kp, the proof; users without one go to `fail`
-        rp_rescore_params R;
+        rp_rescore_params R{};
         R.x_ptr = Xpred->x_ptr;
         R.x_idx = Xpred->x_idx;
         R.B = model->B;
@@ -2438,6 +2498,302 @@ extern "C" int rphip_predict_topk_dist(rphip_ctx* ctx, rphip_comm* comm, const r
       RP_HIP(hipGetLastError());
     }
   }
+  return RPHIP_OK;
+}
+
+// ---- (round 5) predict with the exact scores formed WHERE THE COLUMNS ARE -----------------------------------------------------------
+// The gathered-model route (rphip_ease_model_allgather + the single-GPU predict per rank) moves 4 n^2 bytes to every rank for a
+// rescoring that reads 4 Kc nnz of them; in the 8-rank emulation at 1M x 100K the f32 strips and their unpacking took the first pass
+// a third of its HBM (predict 167 ms where the pass and the rescoring alone take 103).  Here only the int8 rows travel
+// (rphip_ease_model_allgather_i8: n^2 bytes):
+//   1. every rank runs the first pass (rp_predict_i8.hip) for ITS users on the gathered int8 rows: Kc candidates per user;
+//   2. the candidate lists are all-gathered (U Kc 8 bytes per rank: 1.5 GB at C4, 2 ms);
+//   3. every rank forms the exact f32 sums of the candidates whose COLUMN it owns, for the users of all ranks, from its own panels
+//      (k_predict_rescore mode 1: the one-pass kernel's sums - history order, one add per row - as on one GPU; X is replicated);
+//   4. one personalised exchange returns the sums to the users' ranks (U Kc 4 bytes per rank);
+//   5. ranking and proof per user (mode 2); users without a proof - of all ranks - are scored exactly by every rank on its own columns
+//      (the one-pass kernel on a user list), their local top-Kp lists exchanged and merged like rphip_predict_topk_dist's.
+// The results are the single-GPU predict's bit for bit (tests: gloo, two and three ranks).  user_bounds[world + 1]: rank r's users are
+// [user_bounds[r], user_bounds[r + 1]) - the same array on every rank; the outputs hold this rank's users.
+__global__ void k_owner_fail_concat(const int32_t* __restrict__ g, int slot, int W, const int32_t* __restrict__ off, const int64_t* __restrict__ bounds,
+                                    int32_t* __restrict__ out) {
+  const int r = blockIdx.y;
+  const int n = g[(long long)r * slot];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    out[off[r] + i] = (int32_t)bounds[r] + g[(long long)r * slot + 1 + i];
+}
+
+extern "C" int rphip_predict_topk_owner(rphip_ctx* ctx, rphip_comm* comm, const rphip_model* local, const rphip_model* rows8, const rphip_csr* X,
+                                        const int64_t* user_bounds, int32_t Kp, int32_t exclude_history, int32_t* idx_dev, float* val_dev,
+                                        int32_t* nnz_dev) {
+  RP_ENTER(ctx);
+  if (!ctx || !comm || !rows8 || !X || !user_bounds || !idx_dev || !val_dev || !nnz_dev) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if (Kp < 1 || Kp > RP_K_MAX) RP_FAIL(RPHIP_ELIMIT, "Kp=%d outside 1..%d", Kp, RP_K_MAX);
+  const int W = rp_comm_world(comm), me = rp_comm_rank(comm);
+  if (rows8->kind != RPHIP_MODEL_DENSE || !rows8->B16 || rows8->b16_kind != 2 || !rows8->b8_scale)
+    RP_FAIL(RPHIP_ESTATE, "the second model must hold the gathered int8 rows (rphip_ease_model_allgather_i8)");
+  if (rows8->n_items != X->n_items) RP_FAIL(RPHIP_EINVAL, "prediction matrix has %lld items, the model %lld", (long long)X->n_items, (long long)rows8->n_items);
+  if (local && (local->kind != RPHIP_MODEL_DENSE || !local->B || local->n_items != rows8->n_items || local->n_cols <= 0))
+    RP_FAIL(RPHIP_EINVAL, "the first model must be this rank's columns of the same fit (rphip_ease_fit_dist), or NULL on a rank without columns");
+  if (user_bounds[0] != 0 || user_bounds[W] != X->n_users) RP_FAIL(RPHIP_EINVAL, "user_bounds must run from 0 to the matrix's %lld users", (long long)X->n_users);
+  for (int r = 0; r < W; ++r)
+    if (user_bounds[r + 1] < user_bounds[r]) RP_FAIL(RPHIP_EINVAL, "user_bounds must not decrease");
+  const int Kc = ((Kp + 92 + 63) / 64) * 64;
+  if (Kc > 256 || (int64_t)4 * Kc > X->n_items || (exclude_history && !X->sorted_rows) || W > RPS_MISC_INTS - RPS_USER - 1)
+    RP_FAIL(RPHIP_ELIMIT, "Kp=%d, %lld items, %d ranks%s: outside what this route serves (use rphip_predict_topk_dist)", Kp, (long long)X->n_items, W,
+            (exclude_history && !X->sorted_rows) ? ", history removal on unsorted rows" : "");
+  RP_TRY(rp_set_device(ctx));
+  hipStream_t st = ctx->stream;
+  const int64_t U = X->n_users, ub = user_bounds[me], n_me = user_bounds[me + 1] - ub;
+  int64_t n_max = 0;
+  for (int r = 0; r < W; ++r) n_max = std::max(n_max, user_bounds[r + 1] - user_bounds[r]);
+  if (n_max == 0) return RPHIP_OK;
+  hipEvent_t ev;
+  rp_time_begin(ctx, &ev);
+  if (n_me > 0) {
+    hipMemsetAsync(idx_dev, 0xFF, (size_t)n_me * Kp * 4, st);
+    hipMemsetAsync(val_dev, 0, (size_t)n_me * Kp * 4, st);
+    hipMemsetAsync(nnz_dev, 0, (size_t)n_me * 4, st);
+  }
+  struct hold {  // released on every way out
+    rphip_ctx* c;
+    std::vector<void*> p;
+    ~hold() {
+      hipStreamSynchronize(c->stream);
+      for (void* q : p) rp_dev_free(c, q);
+    }
+    int get(size_t bytes, void** out) {
+      RP_TRY(rp_dev_alloc(c, std::max<size_t>(bytes, 256), out));
+      p.push_back(*out);
+      return RPHIP_OK;
+    }
+  } H{ctx, {}};
+  // candidates of all ranks: [W][n_max][Kc] columns and approximate scores, [W][n_max] counts
+  const size_t slotA = (size_t)n_max * Kc;
+  int32_t *A_idx = nullptr, *A_nnz = nullptr, *my_idx = nullptr, *my_nnz = nullptr, *fail = nullptr, *n_fail = nullptr;
+  float *A_val = nullptr, *my_val = nullptr, *part_s = nullptr, *part_r = nullptr;
+  RP_TRY(H.get(64, (void**)&n_fail));  // [0] count of users without a proof, [1] the first pass's ticket, [8] the ranks' agreement
+  int arc = RPHIP_OK;
+  auto get = [&](size_t bytes, void** o) {
+    if (arc == RPHIP_OK) arc = H.get(bytes, o);
+  };
+  get(slotA * W * 4, (void**)&A_idx);
+  get(slotA * W * 4, (void**)&A_val);
+  get((size_t)n_max * W * 4, (void**)&A_nnz);
+  get(slotA * 4, (void**)&my_idx);
+  get(slotA * 4, (void**)&my_val);
+  get((size_t)n_max * 4, (void**)&my_nnz);
+  get((size_t)(n_max + 1) * 4 + 64, (void**)&fail);  // [0] count, [1 ..] local ids (the all-gather's slot)
+  get((size_t)std::max<int64_t>(U, 1) * Kc * 4, (void**)&part_s);
+  get((size_t)std::max<int64_t>(n_me, 1) * Kc * 4 * W, (void**)&part_r);
+  {
+    // a rank whose large blocks did not fit must not leave alone (the others would wait in the first all-gather): the ranks sum
+    // a 0 / 1 flag and return RPHIP_ENOMEM together - the caller can then take rphip_predict_topk_dist
+    int32_t h_bad = arc == RPHIP_OK ? 0 : 1, h_sum = 1;
+    RP_HIP(hipMemcpyAsync(n_fail + 8, &h_bad, 4, hipMemcpyHostToDevice, st));
+    RP_HIP(hipStreamSynchronize(st));
+    RP_TRY(rp_comm_all_reduce_sum_i32(comm, n_fail + 8, 1, st));
+    RP_HIP(hipMemcpyAsync(&h_sum, n_fail + 8, 4, hipMemcpyDeviceToHost, st));
+    RP_HIP(hipStreamSynchronize(st));
+    if (h_sum != 0)
+      RP_FAIL(RPHIP_ENOMEM, "%d of %d ranks could not allocate the candidate and part buffers (%zu bytes here): use rphip_predict_topk_dist", (int)h_sum, W,
+              slotA * W * 8 + (size_t)U * Kc * 4 + (size_t)n_me * Kc * 4 * W);
+  }
+  hipMemsetAsync(n_fail, 0, 64, st);
+  hipMemsetAsync(my_nnz, 0, (size_t)n_max * 4, st);
+  hipMemsetAsync(my_idx, 0xFF, slotA * 4, st);
+  hipMemsetAsync(my_val, 0, slotA * 4, st);
+  rp_pred_params P8;  // the gathered rows: every column, no layout
+  rp_pred_fill(P8, rows8, X, ub, ub + n_me);
+  // ---- 1. first pass for this rank's users
+  if (n_me > 0) RP_TRY(rp_first_pass_i8(ctx, rows8, X, P8, ub, n_me, Kc, exclude_history, my_idx, my_val, my_nnz, fail + 1, n_fail, false));
+  // ---- 2. everybody's candidates
+  RP_TRY(rp_comm_all_gather(comm, my_idx, A_idx, (int64_t)slotA * 4, st));
+  RP_TRY(rp_comm_all_gather(comm, my_val, A_val, (int64_t)slotA * 4, st));
+  RP_TRY(rp_comm_all_gather(comm, my_nnz, A_nnz, (int64_t)n_max * 4, st));
+  // ---- 3. the exact sums of the candidates in this rank's columns, users of all ranks
+  rp_pred_params PL;
+  if (local) rp_pred_fill(PL, local, X, 0, U);
+  auto fill_rescore = [&](rp_rescore_params& R, int r) {
+    R.x_ptr = X->x_ptr;
+    R.x_idx = X->x_idx;
+    R.delta = rows8->b16_delta;
+    R.rowmax = rows8->b16_rowmax;
+    R.cand_idx = A_idx + (size_t)r * slotA;
+    R.cand_val = A_val + (size_t)r * slotA;
+    R.cand_nnz = A_nnz + (size_t)r * n_max;
+    R.user_begin = (int)user_bounds[r];
+    R.n_users = (int)(user_bounds[r + 1] - user_bounds[r]);
+    R.Kp = Kp;
+    R.Kc = Kc;
+  };
+  for (int r = 0; r < W; ++r) {
+    const int64_t n_r = user_bounds[r + 1] - user_bounds[r];
+    if (n_r == 0) continue;
+    float* dst = part_s + (size_t)user_bounds[r] * Kc;
+    if (!local) {  // no columns here: every part is zero
+      hipMemsetAsync(dst, 0, (size_t)n_r * Kc * 4, st);
+      continue;
+    }
+    rp_rescore_params R{};
+    fill_rescore(R, r);
+    R.B = local->B;
+    R.ld = local->ld;
+    R.col_begin = PL.col_begin;
+    R.cyc_nb = PL.cyc_nb;
+    R.cyc_w = PL.cyc_w;
+    R.cyc_r = PL.cyc_r;
+    R.n_own_cols = (int)local->n_cols;
+    R.part_out = dst;
+    rp_launch_rescore_kc<1>(ctx, R);
+  }
+  RP_HIP(hipGetLastError());
+  // ---- 4. the parts to the users' ranks
+  std::vector<int64_t> soff(W), sby(W), roff(W), rby(W);
+  for (int r = 0; r < W; ++r) {
+    soff[r] = user_bounds[r] * (int64_t)Kc * 4;
+    sby[r] = (user_bounds[r + 1] - user_bounds[r]) * (int64_t)Kc * 4;
+    roff[r] = (int64_t)r * n_me * Kc * 4;
+    rby[r] = n_me * (int64_t)Kc * 4;
+  }
+  RP_TRY(rp_comm_exchange(comm, part_s, soff.data(), sby.data(), part_r, roff.data(), rby.data(), st));
+  // ---- 5. ranking and proof for this rank's users
+  if (n_me > 0) {
+    rp_rescore_params R{};
+    fill_rescore(R, me);
+    R.cand_idx = my_idx;
+    R.cand_val = my_val;
+    R.cand_nnz = my_nnz;
+    R.part_in = part_r;
+    R.n_parts = W;
+    R.out_idx = idx_dev;
+    R.out_val = val_dev;
+    R.out_nnz = nnz_dev;
+    R.fail_list = fail + 1;
+    R.n_fail = n_fail;
+    R.fail_base = 0;
+    rp_launch_rescore_kc<2>(ctx, R);
+    RP_HIP(hipGetLastError());
+  }
+  // ---- the users without a proof, of all ranks: [count, local ids] per rank
+  RP_HIP(hipMemcpyAsync(fail, n_fail, 4, hipMemcpyDeviceToDevice, st));
+  const int fslot = (int)n_max + 1;
+  int32_t *G = nullptr, *glist = nullptr, *goff_dev = nullptr;
+  int64_t* bounds_dev = nullptr;
+  RP_TRY(H.get((size_t)fslot * W * 4, (void**)&G));
+  RP_TRY(rp_comm_all_gather(comm, fail, G, (int64_t)fslot * 4, st));
+  std::vector<int32_t> cnt(W, 0), off(W + 1, 0);
+  for (int r = 0; r < W; ++r) RP_HIP(hipMemcpyAsync(&cnt[r], G + (size_t)r * fslot, 4, hipMemcpyDeviceToHost, st));
+  RP_HIP(hipStreamSynchronize(st));
+  for (int r = 0; r < W; ++r) {
+    if (cnt[r] < 0 || cnt[r] > user_bounds[r + 1] - user_bounds[r]) RP_FAIL(RPHIP_EHIP, "rank %d reports %d users without a proof of its %lld", r, cnt[r], (long long)(user_bounds[r + 1] - user_bounds[r]));
+    off[r + 1] = off[r] + cnt[r];
+  }
+  const int n_f = off[W], f_me = cnt[me];
+  ctx->owner_stats[0] = n_f;
+  ctx->owner_stats[1] = f_me;
+  ctx->owner_stats[2] = Kc;
+  ctx->owner_stats[3] = (int64_t)(slotA * W * 8 + (size_t)U * Kc * 4 + (size_t)n_me * Kc * 4 * W);
+  if (n_f > 0) {
+    RP_TRY(H.get((size_t)n_f * 4, (void**)&glist));
+    RP_TRY(H.get((size_t)(W + 1) * 4, (void**)&goff_dev));
+    RP_TRY(H.get((size_t)(W + 1) * 8, (void**)&bounds_dev));
+    RP_HIP(hipMemcpyAsync(goff_dev, off.data(), (size_t)(W + 1) * 4, hipMemcpyHostToDevice, st));
+    RP_HIP(hipMemcpyAsync(bounds_dev, user_bounds, (size_t)(W + 1) * 8, hipMemcpyHostToDevice, st));
+    RP_HIP(hipStreamSynchronize(st));  // (the host arrays are read by the copies)
+    hipLaunchKernelGGL(k_owner_fail_concat, dim3(64, W), dim3(256), 0, st, G, fslot, W, goff_dev, bounds_dev, glist);
+    // local top-Kp of every such user over this rank's columns: [n_f][Kp] by position in the list
+    int32_t *L_idx = nullptr, *L_nnz = nullptr;
+    float* L_val = nullptr;
+    RP_TRY(H.get((size_t)n_f * Kp * 4, (void**)&L_idx));
+    RP_TRY(H.get((size_t)n_f * Kp * 4, (void**)&L_val));
+    RP_TRY(H.get((size_t)n_f * 4, (void**)&L_nnz));
+    hipMemsetAsync(L_nnz, 0, (size_t)n_f * 4, st);
+    if (local) {
+      rp_pred_params F = PL;
+      F.Kp = Kp;
+      F.exclude_history = exclude_history;
+      F.mode = 0;
+      F.user_begin = 0;
+      F.n_users = n_f;
+      F.user_list = glist;
+      F.n_list = nullptr;
+      const int T = F.n_tiles;
+      const size_t lds1 = rp_pred_lds(F);
+      RP_HIP(hipFuncSetAttribute((const void*)k_predict_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+      if (T == 1) {
+        F.list_compact = 2;
+        F.out_idx = L_idx;
+        F.out_val = L_val;
+        F.out_nnz = L_nnz;
+        hipLaunchKernelGGL(k_predict_tile<true>, dim3((unsigned)std::min<int64_t>(n_f, (int64_t)ctx->n_cu * 8)), dim3(RP_PRED_THREADS), lds1, st, F);
+      } else {
+        if (T > 15) RP_FAIL(RPHIP_ELIMIT, "%d column tiles exceed the supported 15", T);
+        int32_t *t_idx = nullptr, *t_nnz = nullptr, *seq = nullptr;
+        float* t_val = nullptr;
+        RP_TRY(H.get((size_t)n_f * T * Kp * 4, (void**)&t_idx));
+        RP_TRY(H.get((size_t)n_f * T * Kp * 4, (void**)&t_val));
+        RP_TRY(H.get((size_t)n_f * T * 4, (void**)&t_nnz));
+        hipMemsetAsync(t_nnz, 0, (size_t)n_f * T * 4, st);
+        F.list_compact = 1;
+        F.out_idx = t_idx;
+        F.out_val = t_val;
+        F.out_nnz = t_nnz;
+        hipLaunchKernelGGL(k_predict_tile<true>, dim3((unsigned)std::min<int64_t>((int64_t)n_f * T, (int64_t)ctx->n_cu * 8)), dim3(RP_PRED_THREADS), lds1, st, F);
+        const size_t mlds_p = (size_t)T * Kp * 8 + rp_select_smem_bytes(T * Kp) + (size_t)Kp * 8;
+        if (mlds_p > 160 * 1024 || T * Kp >= RPS_FLAG) RP_FAIL(RPHIP_ELIMIT, "Kp=%d with %d column tiles needs %zu bytes of LDS for the merge", Kp, T, mlds_p);
+        RP_HIP(hipFuncSetAttribute((const void*)k_predict_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds_p));
+        (void)seq;
+        // (the tiles of a block-cyclic slab are not consecutive column ranges: sort_cols; rows by list position: no user list)
+        hipLaunchKernelGGL(k_predict_merge, dim3((unsigned)std::min<int64_t>(n_f, (int64_t)ctx->n_cu * 8)), dim3(RP_PRED_THREADS), mlds_p, st, t_idx, t_val, t_nnz, T,
+                           Kp, n_f, nullptr, nullptr, L_idx, L_val, L_nnz, 1);
+      }
+      RP_HIP(hipGetLastError());
+    }
+    // the lists to the users' ranks: slots [source][f_me][Kp] columns, scores, [f_me] counts - k_lists_to_users' layout
+    const int64_t cs = std::max(f_me, 1);
+    const int64_t slot = cs * ((int64_t)Kp * 8 + 4);
+    char* recvb = nullptr;
+    RP_TRY(H.get((size_t)slot * W, (void**)&recvb));
+    for (int sec = 0; sec < 3; ++sec) {  // columns, scores, counts
+      const int64_t per = sec < 2 ? (int64_t)Kp * 4 : 4;
+      const char* sendb = sec == 0 ? (const char*)L_idx : (sec == 1 ? (const char*)L_val : (const char*)L_nnz);
+      for (int r = 0; r < W; ++r) {
+        soff[r] = (int64_t)off[r] * per;
+        sby[r] = (int64_t)cnt[r] * per;
+        roff[r] = (int64_t)r * slot + (sec == 0 ? 0 : (sec == 1 ? cs * Kp * 4 : cs * Kp * 8));
+        rby[r] = (int64_t)f_me * per;
+      }
+      RP_TRY(rp_comm_exchange(comm, sendb, soff.data(), sby.data(), recvb, roff.data(), rby.data(), st));
+    }
+    if (f_me > 0) {
+      int32_t *ci = nullptr, *cn = nullptr;
+      float* cv = nullptr;
+      RP_TRY(H.get((size_t)f_me * W * Kp * 4, (void**)&ci));
+      RP_TRY(H.get((size_t)f_me * W * Kp * 4, (void**)&cv));
+      RP_TRY(H.get((size_t)f_me * W * 4, (void**)&cn));
+      const long long total = (long long)f_me * W * Kp;
+      hipLaunchKernelGGL(k_lists_to_users, dim3((unsigned)std::min<long long>(8192, rp_cdiv(total, 256))), dim3(256), 0, st, recvb, (long long)slot, W, (int)cs, f_me,
+                         (int)Kp, ci, cv, cn);
+      const size_t mlds = (size_t)W * Kp * 8 + rp_select_smem_bytes(W * Kp) + (size_t)Kp * 8;
+      if (mlds > 160 * 1024 || W * Kp >= RPS_FLAG) RP_FAIL(RPHIP_ELIMIT, "Kp=%d with %d ranks needs %zu bytes of LDS for the merge", Kp, W, mlds);
+      RP_HIP(hipFuncSetAttribute((const void*)k_predict_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+      // rows of this rank's users without a proof: user_list = their local ids (behind the count in `fail`), lists by position
+      hipLaunchKernelGGL(k_predict_merge, dim3((unsigned)std::min<int64_t>(f_me, (int64_t)ctx->n_cu * 8)), dim3(RP_PRED_THREADS), mlds, st, ci, cv, cn, W, (int)Kp, f_me,
+                         fail + 1, nullptr, idx_dev, val_dev, nnz_dev, 1, 0, 1);
+      RP_HIP(hipGetLastError());
+    }
+  }
+  rp_time_end(ctx, ev, RPHIP_T_PREDICT_DENSE, 0.0);
+  return RPHIP_OK;
+}
+
+// (diagnostic, include/recpack_hip_diag.h) the last rphip_predict_topk_owner of this context: [0] users without a proof over all
+// ranks, [1] this rank's, [2] candidates per user, [3] bytes of the candidate and part buffers
+extern "C" int rphip_predict_owner_stats(rphip_ctx* ctx, int64_t* out4) {
+  RP_ENTER(ctx);
+  if (!ctx || !out4) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  ::memcpy(out4, ctx->owner_stats, sizeof(ctx->owner_stats));
   return RPHIP_OK;
 }
 

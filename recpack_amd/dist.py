@@ -205,6 +205,35 @@ def ease_gather_model(ctx, model, n_items: int, comm):
     return _lib.ease_model_allgather(ctx, comm, model, int(n_items), int(panel))
 
 
+def ease_gather_rows_i8(ctx, model, n_items: int, comm):
+    """Only the int8 rows of the gathered model on every rank (rphip_ease_model_allgather_i8: n^2 bytes instead of 5 n^2) - the
+    model :func:`predict_topk_owner` runs its first pass on.  ``model`` is None on a rank that owns only padding."""
+    from recpack_amd import _lib
+
+    panel = _lib.ease_fit_dist_stats(ctx)["panel"]
+    return _lib.ease_model_allgather_i8(ctx, comm, model, int(n_items), int(panel))
+
+
+def predict_topk_owner(ctx, local, rows_i8, dX, Kp: int, user_parts: Sequence[Tuple[int, int]], device, comm, exclude_history: bool = False):
+    """Top-Kp of this rank's users with the exact scores formed by the owners of the columns (rphip_predict_topk_owner; round 5):
+    no rank holds the f32 matrix - the first pass reads the gathered int8 rows, the candidates are all-gathered, every rank sums the
+    entries of the candidates in ITS columns for all users, one exchange returns the sums.  ``user_parts``: the ranks' contiguous user
+    ranges (``partition_users``).  Returns (idx int32 [m, Kp], val float32 [m, Kp], nnz int32 [m]) for this rank's users - the
+    single-GPU result bit for bit.  Raises ``_lib.RecpackHipError`` (code RPHIP_ELIMIT / RPHIP_ENOMEM, on every rank alike) when the
+    route does not apply: take :func:`predict_topk_sharded` then."""
+    import torch
+
+    from recpack_amd import _lib
+
+    bounds = [int(p[0]) for p in user_parts] + [int(user_parts[-1][1])]
+    ub, ue = user_parts[comm.rank]
+    oi = torch.empty((max(ue - ub, 1), Kp), dtype=torch.int32, device=device)
+    ov = torch.empty((max(ue - ub, 1), Kp), dtype=torch.float32, device=device)
+    on = torch.empty((max(ue - ub, 1),), dtype=torch.int32, device=device)
+    _lib.predict_topk_owner(ctx, comm, local, rows_i8, dX, bounds, Kp, oi, ov, on, exclude_history=exclude_history)
+    return oi[: ue - ub], ov[: ue - ub], on[: ue - ub]
+
+
 def ease_gather_fits(n_items: int, panel: int, hbm_bytes: int, world: int = 1, free_bytes: int | None = None) -> bool:
     """Does the gathered model fit beside a rank's own panels?  Needed: B (4 n^2 bytes), its quantised copy for the first pass of
     K9 (n^2 bytes as int8, 2 n^2 as fp16: the larger is assumed), 2 GiB of staging strips - while the rank's own panels

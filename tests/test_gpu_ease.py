@@ -384,6 +384,16 @@ def test_ease_fit_sharded_multi_rank(hip, nproc, shape):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("top-20 agreement") == 4 * nproc
     assert r.stdout.count("transport self-test: ok") == nproc  # rphip_comm_selftest: broadcast, all-gather, exchange, all-reduce
+    # the owner route (rphip_predict_topk_owner): the gathered model's predict bit for bit, with and without history removal, for
+    # both fits and both values of l2 - or refused by every rank alike where the first pass has too few items
+    if shape[1] >= 512:
+        assert r.stdout.count("identical to the gathered model's predict: True") == 8 * nproc, r.stdout[-3000:]
+        import re
+
+        unproven = [int(x) for x in re.findall(r"users without a proof: \d+ here, (\d+) on all ranks", r.stdout)]
+        print("owner route, users without a proof per call:", unproven)
+    else:
+        assert r.stdout.count("owner route refused (expected") == 4 * nproc, r.stdout[-3000:]
 
 
 def test_ease_fit_sharded_one_rank(hip):

@@ -90,6 +90,28 @@ for l2, alpha in ((50.0, 0.0), (5.0, 0.5)):
         print(f"rank {rank}/{world} gathered model: max|dB|/max|B| = {err_g:.2e}, empty rows equal: {full.empty_rows() == ref.empty_rows()}, "
               f"users [{ub_},{ue_}) agreement {agree_g:.4f}", flush=True)
         ok = ok and err_g <= 1e-4 and full.empty_rows() == ref.empty_rows() and agree_g > 0.99
+        # the owner route (round 5): first pass on the gathered int8 rows, the candidates' exact sums from every rank's own panels, one
+        # exchange back - the predict of the gathered model on this rank's users, bit for bit (columns, f32 scores, counts), with and
+        # without history removal; refused alike by every rank where the first pass does not apply (fewer than 4 Kc items)
+        if world > 1:
+            uparts = rdist.partition_users(X.indptr, world)
+            ub2, ue2 = uparts[rank]
+            try:
+                rows8 = rdist.ease_gather_rows_i8(ctx, ms, I, comm)
+                for excl in (True, False):
+                    oi, ov, on = rdist.predict_topk_owner(ctx, ms, rows8, dX, 20, uparts, device, comm, exclude_history=excl)
+                    g2 = _lib.predict_topk(ctx, full, dX, 20, exclude_history=excl, user_begin=ub2, user_end=ue2)
+                    same_o = (np.array_equal(oi.cpu().numpy(), g2[0]) and np.array_equal(ov.cpu().numpy().view(np.uint32), g2[1].view(np.uint32))
+                              and np.array_equal(on.cpu().numpy(), g2[2]))
+                    so = _lib.predict_owner_stats(ctx)
+                    print(f"rank {rank}/{world} owner route (exclude_history={excl}): users [{ub2},{ue2}) identical to the gathered model's predict: {same_o}"
+                          f" (users without a proof: {so['unproven_here']} here, {so['unproven_all_ranks']} on all ranks)", flush=True)
+                    ok = ok and same_o
+                del rows8
+            except _lib.RecpackHipError as e:
+                refused = e.code == _lib.RPHIP_ELIMIT and I < 4 * 128
+                print(f"rank {rank}/{world} owner route refused ({'expected: too few items for the first pass' if refused else e})", flush=True)
+                ok = ok and refused
         del ms, full
     comm.close()
 if dist.is_initialized():
