@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--ease-transport", default="auto", choices=["auto", "rccl", "torch"],
                     help="N > 1: collectives of the distributed EASE solve - the library's own RCCL communicator (auto with the nccl "
                          "backend) or callbacks through torch.distributed")
+    ap.add_argument("--ease-predict-route", choices=("auto", "owner", "gather"), default="auto",
+                    help="N > 1: auto = the owner route (int8 rows gathered, exact sums by the columns' owners), then the gathered model, then "
+                         "columns sharded; owner = that route or an error; gather = round 5's first route (the full model gathered)")
     ap.add_argument("--selftest", action="store_true", help="N = 1: run the transport self-test on a one-rank RCCL communicator too (N > 1: always)")
     ap.add_argument("--timeout", type=float, default=1500.0,
                     help="seconds the timed region (warm-up + steps) may take; past it every rank prints what it has with status "
@@ -582,16 +585,34 @@ def main():
             em, _ = rdist.ease_fit_sharded(ctx, dXe, args.l2, 0.0, device, comm=comm)
             torch.cuda.synchronize()
             t2 = time.perf_counter()
-            # predict: while the whole of B fits every GPU, gather the panels and score this rank's USERS with the single-GPU kernels
-            # (full-width rows, no lists to exchange); otherwise every rank scores all users against its own columns + merge
+            # predict.  First choice (round 5): the owner route - only the int8 rows are gathered, every rank runs the first pass for
+            # ITS users, the candidates' exact sums come from every rank's own panels (rphip_predict_topk_owner); refused by every
+            # rank alike (RPHIP_ELIMIT / RPHIP_ENOMEM) when it does not apply.  Then: while the whole of B fits every GPU, gather the
+            # panels and score this rank's users with the single-GPU kernels; otherwise every rank scores all users against its
+            # own columns + merge
             full = None
-            if rdist.ease_gather_fits(I, _lib.ease_fit_dist_stats(ctx)["panel"], info["hbm_bytes"], world):
+            owner_done = False
+            if args.ease_predict_route in ("auto", "owner"):
+                try:
+                    rows8 = rdist.ease_gather_rows_i8(ctx, em, I, comm)
+                    _lib.predict_topk_owner(ctx, comm, em, rows8, dXe, [p[0] for p in user_parts] + [user_parts[-1][1]], Kp, out_idx, out_val, out_nnz)
+                    keep["ease_rows8"] = rows8
+                    keep["ease_predict_route"] = "int8 rows all-gathered, users sharded, exact sums by the columns' owners"
+                    owner_done = True
+                except _lib.RecpackHipError as e:  # (decided before the first collective or agreed on by the ranks: everybody lands here or nobody)
+                    if e.code not in (_lib.RPHIP_ENOMEM, _lib.RPHIP_ELIMIT, _lib.RPHIP_ESTATE) or args.ease_predict_route == "owner":
+                        raise
+            if owner_done:
+                pass
+            elif rdist.ease_gather_fits(I, _lib.ease_fit_dist_stats(ctx)["panel"], info["hbm_bytes"], world):
                 try:
                     full = rdist.ease_gather_model(ctx, em, I, comm)
                 except _lib.RecpackHipError as e:  # (the ranks agree on their allocations: everybody lands here or nobody)
                     if e.code != _lib.RPHIP_ENOMEM:
                         raise
-            if full is not None:
+            if owner_done:
+                pass
+            elif full is not None:
                 _lib.predict_topk_dev(ctx, full, dXe, Kp, out_idx, out_val, out_nnz, user_begin=ub, user_end=ue)
                 keep["ease_full"] = full
                 keep["ease_predict_route"] = "panels all-gathered, users sharded"

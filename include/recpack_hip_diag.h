@@ -45,7 +45,8 @@ int rphip_gemm_nt_f32_ex(rphip_ctx* ctx, int64_t M, int64_t N, int64_t k_begin, 
 int rphip_model_adopt_gather(rphip_model* dst, rphip_model* src);
 
 /* The last rphip_predict_topk_owner of this context: out4[0] users without a proof over all ranks (they took the exact pass on every
- * rank's columns), [1] this rank's, [2] candidates per user, [3] bytes of the candidate and part buffers. */
+ * rank's columns), [1] this rank's, [2] candidates per user, [3] on a loop-back communicator: microseconds of the stand-in that forms the other ranks'
+ * parts from the f32 matrix passed with the int8 rows (tools/dist_rank_emulate.py subtracts it). */
 int rphip_predict_owner_stats(rphip_ctx* ctx, int64_t* out4);
 
 #ifdef __cplusplus

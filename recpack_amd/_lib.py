@@ -807,10 +807,10 @@ def predict_topk_dist(ctx: Context, comm: Comm, model, X: DeviceCSR, Kp: int, id
 
 def predict_owner_stats(ctx: Context) -> dict:
     """The last :func:`predict_topk_owner` of this context (diagnostic): users without a proof over all ranks / of this rank,
-    candidates per user, bytes of the route's buffers."""
+    candidates per user, and on a loop-back communicator the microseconds of the stand-in for the other ranks' parts."""
     out = np.zeros(4, dtype=np.int64)
     check(ctx.lib.rphip_predict_owner_stats(ctx.handle, _np_ptr(out)))
-    return {"unproven_all_ranks": int(out[0]), "unproven_here": int(out[1]), "candidates_per_user": int(out[2]), "buffer_bytes": int(out[3])}
+    return {"unproven_all_ranks": int(out[0]), "unproven_here": int(out[1]), "candidates_per_user": int(out[2]), "loopback_standin_us": int(out[3])}
 
 
 def ease_fit_dist_stats(ctx: Context) -> dict:

@@ -103,6 +103,7 @@ struct rphip_comm {
   int world = 1, rank = 0;
   bool is_rccl = false;
   bool is_loop = false;  // rphip_comm_loopback_create: one rank of a larger run measured alone
+  bool loop_replicate = false;  // (rp_comm_loop_replicate)
   double loop_bw = 0.0, loop_lat = 0.0;  // bytes per second, seconds
   ncclComm_t nccl = nullptr;
   rphip_comm_ops ops{};
@@ -230,6 +231,7 @@ extern "C" int rphip_comm_info(const rphip_comm* c, int32_t* world, int32_t* ran
 
 int rp_comm_world(const rphip_comm* c) { return c->world; }
 bool rp_comm_is_loopback(const rphip_comm* c) { return c->is_loop; }
+void rp_comm_loop_replicate(rphip_comm* c, bool on) { c->loop_replicate = on; }
 int rp_comm_rank(const rphip_comm* c) { return c->rank; }
 
 int rp_comm_broadcast(rphip_comm* c, void* buf, int64_t bytes, int root, hipStream_t st) {
@@ -301,7 +303,7 @@ int rp_comm_all_gather(rphip_comm* c, const void* send, void* recv, int64_t byte
     // (parts of 32 MiB and more - the strips of a panel gather, whose contents nobody computes with: the other ranks' slots are WRITTEN
     // only, as the peers' incoming xGMI writes would - eight device copies per strip read 40 GB more than a real gather does, beside
     // a predict pass that is bound by HBM bandwidth)
-    const bool big = bytes_per_rank >= ((int64_t)32 << 20);
+    const bool big = bytes_per_rank >= ((int64_t)32 << 20) && !c->loop_replicate;
     for (int p = 0; p < c->world; ++p) {
       if (big && p != c->rank)
         RP_HIP(hipMemsetAsync((char*)recv + (size_t)p * bytes_per_rank, 0, (size_t)bytes_per_rank, st));

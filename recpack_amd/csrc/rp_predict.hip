@@ -2520,7 +2520,7 @@ __global__ void k_owner_fail_concat(const int32_t* __restrict__ g, int slot, int
   const int r = blockIdx.y;
   const int n = g[(long long)r * slot];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    out[off[r] + i] = (int32_t)bounds[r] + g[(long long)r * slot + 1 + i];
+    out[off[r] + i] = (int32_t)bounds[r] + min(g[(long long)r * slot + 1 + i], (int32_t)(bounds[r + 1] - bounds[r]) - 1);  // (the clamp only ever acts on a loop-back communicator's copies)
 }
 
 extern "C" int rphip_predict_topk_owner(rphip_ctx* ctx, rphip_comm* comm, const rphip_model* local, const rphip_model* rows8, const rphip_csr* X,
@@ -2608,9 +2608,12 @@ extern "C" int rphip_predict_topk_owner(rphip_ctx* ctx, rphip_comm* comm, const 
   // ---- 1. first pass for this rank's users
   if (n_me > 0) RP_TRY(rp_first_pass_i8(ctx, rows8, X, P8, ub, n_me, Kc, exclude_history, my_idx, my_val, my_nnz, fail + 1, n_fail, false));
   // ---- 2. everybody's candidates
+  const bool loop = rp_comm_is_loopback(comm);
+  if (loop) rp_comm_loop_replicate(comm, true);  // (an emulated rank scores its own users' candidates in the others' places: the same work)
   RP_TRY(rp_comm_all_gather(comm, my_idx, A_idx, (int64_t)slotA * 4, st));
   RP_TRY(rp_comm_all_gather(comm, my_val, A_val, (int64_t)slotA * 4, st));
   RP_TRY(rp_comm_all_gather(comm, my_nnz, A_nnz, (int64_t)n_max * 4, st));
+  if (loop) rp_comm_loop_replicate(comm, false);
   // ---- 3. the exact sums of the candidates in this rank's columns, users of all ranks
   rp_pred_params PL;
   if (local) rp_pred_fill(PL, local, X, 0, U);
@@ -2657,6 +2660,36 @@ extern "C" int rphip_predict_topk_owner(rphip_ctx* ctx, rphip_comm* comm, const 
     rby[r] = n_me * (int64_t)Kc * 4;
   }
   RP_TRY(rp_comm_exchange(comm, part_s, soff.data(), sby.data(), part_r, roff.data(), rby.data(), st));
+  ctx->owner_stats[3] = 0;
+  if (loop && rows8->B && n_me > 0) {
+    // (diagnostic: one rank of several measured alone, tools/dist_rank_emulate.py) what the other ranks would have sent never existed.
+    // When the int8 rows come with their f32 matrix - the emulation passes the single-GPU model - the parts of this rank's users are
+    // formed from it, all columns, so that the ranking below sees the true scores and sends the true few users to the exact pass; the
+    // time of this stand-in is recorded (owner_stats[3], microseconds) and the emulation subtracts it.
+    hipEvent_t o0 = nullptr, o1 = nullptr;
+    RP_HIP(hipEventCreate(&o0));
+    RP_HIP(hipEventCreate(&o1));
+    RP_HIP(hipEventRecord(o0, st));
+    hipMemsetAsync(part_r, 0, (size_t)n_me * Kc * 4 * W, st);
+    rp_rescore_params R{};
+    fill_rescore(R, me);
+    R.cand_idx = my_idx;
+    R.cand_val = my_val;
+    R.cand_nnz = my_nnz;
+    R.B = rows8->B;
+    R.ld = rows8->ld;
+    R.col_begin = 0;
+    R.n_own_cols = (int)rows8->n_items;
+    R.part_out = part_r;
+    rp_launch_rescore_kc<1>(ctx, R);
+    RP_HIP(hipEventRecord(o1, st));
+    RP_HIP(hipEventSynchronize(o1));
+    float oms = 0.0f;
+    hipEventElapsedTime(&oms, o0, o1);
+    hipEventDestroy(o0);
+    hipEventDestroy(o1);
+    ctx->owner_stats[3] = (int64_t)(oms * 1000.0f);
+  }
   // ---- 5. ranking and proof for this rank's users
   if (n_me > 0) {
     rp_rescore_params R{};
@@ -2693,7 +2726,6 @@ extern "C" int rphip_predict_topk_owner(rphip_ctx* ctx, rphip_comm* comm, const 
   ctx->owner_stats[0] = n_f;
   ctx->owner_stats[1] = f_me;
   ctx->owner_stats[2] = Kc;
-  ctx->owner_stats[3] = (int64_t)(slotA * W * 8 + (size_t)U * Kc * 4 + (size_t)n_me * Kc * 4 * W);
   if (n_f > 0) {
     RP_TRY(H.get((size_t)n_f * 4, (void**)&glist));
     RP_TRY(H.get((size_t)(W + 1) * 4, (void**)&goff_dev));
@@ -2789,7 +2821,7 @@ extern "C" int rphip_predict_topk_owner(rphip_ctx* ctx, rphip_comm* comm, const 
 }
 
 // (diagnostic, include/recpack_hip_diag.h) the last rphip_predict_topk_owner of this context: [0] users without a proof over all
-// ranks, [1] this rank's, [2] candidates per user, [3] bytes of the candidate and part buffers
+// ranks, [1] this rank's, [2] candidates per user, [3] loop-back communicators only: microseconds of the stand-in for the other ranks' parts
 extern "C" int rphip_predict_owner_stats(rphip_ctx* ctx, int64_t* out4) {
   RP_ENTER(ctx);
   if (!ctx || !out4) RP_FAIL(RPHIP_EINVAL, "NULL argument");

@@ -396,6 +396,32 @@ def test_ease_fit_sharded_multi_rank(hip, nproc, shape):
         assert r.stdout.count("owner route refused (expected") == 4 * nproc, r.stdout[-3000:]
 
 
+def test_bench_two_ranks_share_the_gpu(hip):
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank) - here over gloo with both ranks on
+    this box's GPU: the transport self-test, the sharded ItemKNN half, the library's distributed EASE solve and the owner route of
+    the predict all run, and rank 0 prints one JSON line with the contract's keys."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RECPACK_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", "C2", "--cpu-baseline-seconds", "0",
+           "--ease-config", "none", "--tars-config", "none"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    d = json.loads(lines[0])
+    assert d["status"] == "ok" and d["n_gpus"] == 2 and d["steps"] == 1 and d["warmup"] == 1 and d["value"] > 0
+    assert d["transport_selftest"]["ok"] and d["transport_selftest"].get("ok_all_ranks", True)
+    assert "exact sums by the columns' owners" in d["config"]["parallelism"]
+    for k in ("metric", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d
+
+
 def test_ease_fit_sharded_one_rank(hip):
     import torch
 

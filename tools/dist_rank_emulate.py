@@ -15,9 +15,10 @@ part (7 parts over 7 links), an exchange the largest piece to or from one peer. 
                  all-gather of the neighbour lists (modelled; the rank's own lists stand in for the others') + finalisation of the
                  full model + K8 for the rank's users
   EASE half      rphip_ease_fit_dist (Gram of the rank's panels, the symmetric block sweeps with look-ahead: update stream, chain,
-                 pivot stream, communication stream) + the predict route bench.py takes at this size: rphip_ease_model_allgather (the
-                 panels into one full model: strips of rows, one modelled all-gather each) + the single-GPU fused predict for the
-                 rank's USERS.  That predict runs on the REAL B of the single-GPU fit of the same process (a fresh model object per
+                 pivot stream, communication stream) + the predict route bench.py takes at this size: rphip_ease_model_allgather_i8 (the
+                 int8 rows of the panels on every rank) + rphip_predict_topk_owner for the rank's USERS (first pass, candidates
+                 all-gathered, exact sums of the candidates in the rank's columns for the users of all ranks, one exchange, ranking and
+                 proof; --predict-route gather: the full model gathered + the single-GPU predict).  That predict runs on the REAL B of the single-GPU fit of the same process (a fresh model object per
                  run: the fp16 copy of the first pass is rebuilt as it would be): the emulated fit works on noise, and on noise the
                  fp16 first pass of K9 cannot prove its lists (every user would take the exact second pass)
 
@@ -50,6 +51,9 @@ def main():
     ap.add_argument("--repeats", type=int, default=2)
     ap.add_argument("--panel-tiles", type=int, default=0, help="panel width of the distributed solve in 128-column tiles (0: the library's choice)")
     ap.add_argument("--skip-single", action="store_true", help="do not measure the single-GPU step (no speed-up is computed then)")
+    ap.add_argument("--predict-route", choices=("owner", "gather"), default="owner",
+                    help="EASE predict of a rank: owner = int8 rows gathered, exact sums by the columns' owners (rphip_predict_topk_owner); "
+                         "gather = the full model gathered in two phases (round 5's first route)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
 
@@ -169,21 +173,42 @@ def main():
             # own (its contents are the emulated fit's noise: only its time counts).  The predict of the rank's users runs on the REAL
             # matrix and ADOPTS the pending gather: its first pass runs beside the f32 strips, its rescoring waits for them - what the
             # rank's own predict on the gathered model does.
-            efull = rdist.ease_gather_model(ctx, em_r, I, comm)
-            t_g = time.perf_counter()
-            if not args.skip_single:
-                pm.adopt_gather(efull)
-                _lib.predict_topk_dev(ctx, pm, dXe, Kp, oi, ov, on, user_begin=ub, user_end=ue)
+            standin_s = 0.0
+            if args.predict_route == "owner" and not args.skip_single:
+                # the owner route: the int8 rows of the emulated fit's panels are gathered (timed: quantisation, all-gathers, unpacking),
+                # then the route runs on the REAL matrix - its int8 rows (pm) for the first pass, the rank's share of the real columns
+                # (a contiguous eighth: the same number of columns as its block-cyclic panels) for the exact sums; the library's stand-in
+                # for the other ranks' parts is timed inside and subtracted
+                efull = rdist.ease_gather_rows_i8(ctx, em_r, I, comm)
+                t_g = time.perf_counter()
+                cb, ce = (I * r) // W, (I * (r + 1)) // W
+                local_real = _lib.Model.from_dense_cols(ctx, I, cb, ce - cb, Breal[:, cb:ce])
+                bounds = [p[0] for p in user_parts] + [user_parts[-1][1]]
+                _lib.predict_topk_owner(ctx, comm, local_real, pm, dXe, bounds, Kp, oi, ov, on)
+                sync()
+                so = _lib.predict_owner_stats(ctx)
+                standin_s = so["loopback_standin_us"] / 1e6
+                del local_real
+            else:
+                efull = rdist.ease_gather_model(ctx, em_r, I, comm)
+                t_g = time.perf_counter()
+                if not args.skip_single:
+                    pm.adopt_gather(efull)
+                    _lib.predict_topk_dev(ctx, pm, dXe, Kp, oi, ov, on, user_begin=ub, user_end=ue)
+                so = None
             sync()
             del efull, em_r
-            t3 = time.perf_counter()
+            t3 = time.perf_counter() - standin_s
             cur = {"step_s": t3 - t0, "itemknn_s": t1 - t0, "itemknn_k0_shard_s": t_k0 - t0, "itemknn_fit_rows_s": t_fit - t_k0,
                    "itemknn_gather_finalize_s": t_gather - t_fit, "itemknn_predict_users_s": t1 - t_gather,
                    "ease_fit_s": t2 - t1, "ease_predict_s": t3 - t2, "ease_gather_call_s": t_g - t2,
                    "ease_update_stream_kernel_s": tm["sweep_update"]["ms"] / 1e3, "ease_chain_kernel_s": tm["sweep_chain"]["ms"] / 1e3,
                    "ease_gram_s": tm["gram_dense"]["ms"] / 1e3, "ease_mirror_s": tm["mirror"]["ms"] / 1e3,
                    "ease_bytes_received": st["bytes_received"], "ease_bytes_sent": st["bytes_sent"], "ease_pivots": st["pivots"],
-                   "ease_panel": st["panel"], "rows": [int(rb), int(re_)], "users": [int(ub), int(ue)]}
+                   "ease_panel": st["panel"], "rows": [int(rb), int(re_)], "users": [int(ub), int(ue)], "ease_predict_route": args.predict_route}
+            if so is not None:
+                cur["ease_predict_unproven_users"] = so["unproven_here"]
+                cur["ease_predict_standin_subtracted_s"] = standin_s
             if best is None or cur["step_s"] < best["step_s"]:
                 best = cur
             del local, full
