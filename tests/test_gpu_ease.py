@@ -371,6 +371,7 @@ def _run_dist_check(nproc, args=()):
 
 @pytest.mark.parametrize("nproc,shape", [(2, (4000, 700, 0.02, 2, 1)), (3, (3000, 1000, 0.01, 3, 2)), (2, (3000, 1000, 0.01, 16, 3)),
                                          (3, (2000, 200, 0.03, 1, 1)),      # two panels for three ranks: one rank owns nothing
+                                         (3, (3000, 1000, 0.01, 4, 4)),     # two 512-column panels for three ranks, enough items for the owner route
                                          (3, (12000, 3000, 0.005, 4, 4)),     # 6 panels of 512 columns, then the library's own choice
                                          (2, (60000, 20000, 0.002, 16, 16))])  # 2048-column panels: the plane-product kernel with the block-cyclic tile rules
 def test_ease_fit_sharded_multi_rank(hip, nproc, shape):
