@@ -257,12 +257,16 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
       RP_LDS uint16_t* ft_list = (RP_LDS uint16_t*)sel.list;  // light rows: first-touch candidates
       const int diag = row - t0;
       int n_prod = 0;
-      const int stride = NW * 64;
+      // users per wave and batch: 64 - but a light row (at most 255 users) is spread EVENLY over the four waves (round 5): in batches of
+      // 64 a row of 87 users gave wave 0 its 64, wave 1 the other 23 and left two waves idle through the task's longest phase
+      // (the heavier instances alike: a row - or slice - with fewer than 64 NW users is dealt out evenly)
+      const int bw = max(1, min(64, (tk.p_end - tk.p_begin + NW - 1) / NW));
+      const int stride = NW * bw;
       // software pipeline over the wave's batches of 64 users: the user ids of batch n+2 and the row pointers of
       // batch n+1 are in flight while batch n is expanded into chunks
       auto load_user = [&](int bs) -> int {
         const int p = bs + lane;
-        return (p < tk.p_end) ? P.xt_idx[p] : -1;
+        return (lane < bw && p < tk.p_end) ? P.xt_idx[p] : -1;
       };
       auto load_seg = [&](int u, int& s, int& e) {
         s = 0;
@@ -278,7 +282,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
           }
         }
       };
-      int base = tk.p_begin + wave * 64;
+      int base = tk.p_begin + wave * bw;
       int u_next = load_user(base + stride);
       int s_cur, e_cur;
       load_seg(load_user(base), s_cur, e_cur);
