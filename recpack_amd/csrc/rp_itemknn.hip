@@ -5,14 +5,17 @@
 // called at nearest_neighbour.py:217).  The I x I similarity matrix is never materialised:
 //
 //   task = (item row i, column tile t, slice of the users of i)
-//   accumulate  c_ij = |users(i) & users(j)| for j in tile t into a dense u32 tile in LDS
-//               (one LDS atomic per scalar product; indices of X rows are gathered coalesced, 16 lanes
-//               per user row, 4 user rows per wave-step, 16 waves per workgroup)
+//   accumulate  c_ij = |users(i) & users(j)| for j in tile t into a dense counter tile in LDS: bytes for rows of at most 255 users,
+//               16-bit pairs for the others, 32 bits for the sums of sliced rows and the dense Gram of EASE (one LDS atomic per
+//               scalar product).  A wave takes its even share of the task's users (one per lane, at most 64 per batch), cuts their
+//               tile segments into chunks of eight 16-bit tile-relative columns (K0's x_rel: one 16-byte load) and deals chunk c to
+//               lane c mod 64
 //   select      exact top-K of key(i,j) = fl(c_ij^2) * fl(1/c_j)  (monotone in cosine for fixed i), ties by
-//               smaller j (rp_select.h); emit (j, c_ij / sqrt(c_i c_j)) in column order
+//               smaller j (rp_select.h); emit (j, c_ij / sqrt(c_i c_j)) in column order - several tiles: per-tile lists of
+//               (j, c_ij), merged per row by k_itemknn_merge[_wave]
 //
-// Rows whose user list is long are cut into slices (partial tiles summed by a second launch), rows are
-// handed out heaviest first through a ticket counter to persistent workgroups (one per CU).
+// Rows whose user list is long are cut into slices (partial tiles summed by a second launch); tasks are handed out heaviest
+// first through ticket counters (one per XCD for the heavy instance) to persistent workgroups.
 #include <math.h>
 
 #include <algorithm>
