@@ -2060,7 +2060,11 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
     int wpc = (x32 && wt == PW_WT) ? 12 : 8;
     while (wpc > 1 && (160 * 1024) / wpc < (long long)(rp_pw_fixed_bytes(acc_b, wt) + (size_t)(((Kp + 63) / 64) * 64 + 64) * (acc_b + 4))) --wpc;
     W.cap = rp_pw_cap_for(Kp, acc_b, wt, wpc);
-    const size_t wl = rp_pw_fixed_bytes(acc_b, wt) + (size_t)W.cap * (acc_b + 4);
+    size_t wl = rp_pw_fixed_bytes(acc_b, wt) + (size_t)W.cap * (acc_b + 4);
+    if (const char* e = rp_diag_env("RP_PW_WPC")) {  // (diagnostic build, tools/k8_wpc.py: fewer waves per CU by asking for more LDS than a wave needs)
+      wpc = std::max(1, std::min(wpc, atoi(e)));
+      wl = std::max<size_t>(wl, (size_t)(160 * 1024) / wpc - 512);
+    }
     W.x_val = Xpred->x_val;
     const int wg = (int)std::min<int64_t>(rp_cdiv(n, PW_UCH), (int64_t)ctx->n_cu * wpc);
     auto launch = [&](auto kern) {
