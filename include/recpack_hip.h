@@ -349,11 +349,11 @@ int rphip_predict_topk_filtered_dev(rphip_ctx* ctx, const rphip_model* model, co
 /* exact reference semantics (every non-zero score): two phases.  _count fills row_nnz_host
  * (int64[n]) and returns the total; _fill writes CSR indices/data (float64) given the caller's
  * indptr (exclusive scan of row_nnz). */
-/* LIMITS (the reference accepts any K: base.py:302-304, util.py:63-66).  rphip_itemknn_fit[_ex] without normalize_X: any K up to
- * 25 600 items (one column tile, round 4); over T > 1 column tiles any K with K x T < 32 768 (round 5: the merge of a row's per-tile
- * lists reads them where they lie when they do not fit the LDS).  The normalize_X and valued fits and the Kp of rphip_predict_topk*
- * (min(Kp, n_items)): at most 2048 (the selection's LDS buffers).  Larger values return RPHIP_ELIMIT.  rphip_predict_full_* has no
- * such limit. */
+/* LIMITS (the reference accepts any K: base.py:302-304, util.py:63-66).  rphip_itemknn_fit[_ex]: any K on one column tile - 25 600
+ * items without normalize_X (round 4), 12 288 with it (float64 sums) - and over T > 1 column tiles any K with K x T < 32 768 (round 5:
+ * the merge of a row's per-tile lists reads them where they lie when they do not fit the LDS).  The valued (time-aware) fits and the Kp
+ * of rphip_predict_topk* (min(Kp, n_items)): at most 2048 (the selection's LDS buffers).  Larger values return RPHIP_ELIMIT.
+ * rphip_predict_full_* has no such limit. */
 int rphip_predict_full_count(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred,
                              int64_t user_begin, int64_t user_end, int64_t* row_nnz_host, int64_t* total_out);
 int rphip_predict_full_fill(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred,

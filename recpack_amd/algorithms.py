@@ -23,8 +23,8 @@ this module is original.  When recpack itself is importable, :class:`Algorithm` 
 
 Limit (a deviation from the reference, which accepts any K): up to :data:`RP_TILE_MAX` = 25 600 items ``ItemKNN`` takes any ``K``
 (round 4); beyond, over T = ceil(items / 25 600) column tiles, any ``K`` with K x T < 32 768 (round 5: K = 8 191 at 100 000 items -
-the merge of a row's per-tile lists reads them where they lie when they do not fit the LDS).  For the ``normalize_X`` and time-aware
-fits the effective ``K`` is at most :data:`RP_K_MAX` = 2048.  The ``K`` of ``predict_topk`` - an extension, not part of the
+the merge of a row's per-tile lists reads them where they lie when they do not fit the LDS); with ``normalize_X`` the same over tiles of
+12 288 items (K = 3 640 at 100 000 items).  For the time-aware fits the effective ``K`` is at most :data:`RP_K_MAX` = 2048.  The ``K`` of ``predict_topk`` - an extension, not part of the
 reference - is at most 2048.  Larger values raise ``ValueError`` before anything is uploaded.
 """
 from __future__ import annotations
@@ -44,6 +44,7 @@ from recpack_amd import _lib
 
 logger = logging.getLogger("recpack")
 
+RP_WTILE_MAX = 12288  # rp_itemknn_w.hip: items per column tile of the normalize_X fit (float64 sums)
 RP_K_TILES_MAX = 32768  # rp_select.h (RPS_FLAG): K x column tiles of a binary fit over several tiles stays below this
 RP_K_MAX = 2048  # rp_common.h: largest effective K of a fit over several column tiles, and largest Kp of the fused top-Kp
 RP_TILE_MAX = 25600  # rp_common.h: items of one column tile - up to here ItemKNN takes any K (round 4)
@@ -318,14 +319,16 @@ class ItemKNN(TopKItemSimilarityMatrixAlgorithm):
         self.normalize_sim = normalize_sim
 
     def _fit(self, X: sp.csr_matrix) -> None:
-        # the binary fit takes ANY K on one column tile (<= RP_TILE_MAX items) and K x tiles < 32 768 beyond (K = 8 191 at 100 000 items:
-        # the merge of the per-tile lists reads them where they lie); the normalize_X fit keeps RP_K_MAX (deviation 5)
+        # ANY K on one column tile (<= RP_TILE_MAX items; normalize_X: RP_WTILE_MAX, its sums are float64) and K x tiles < 32 768 beyond
+        # (binary: K = 8 191 at 100 000 items, normalize_X: 3 640): the merge of the per-tile lists reads them where they lie
+        # (deviation 5)
         k_eff = min(int(self.K), max(1, X.shape[1] - 1))
-        n_tiles = -(-X.shape[1] // RP_TILE_MAX)
-        if (self.normalize_X and k_eff > RP_K_MAX) or (not self.normalize_X and n_tiles > 1 and k_eff * n_tiles >= RP_K_TILES_MAX):
+        tile = RP_WTILE_MAX if self.normalize_X else RP_TILE_MAX
+        n_tiles = -(-X.shape[1] // tile)
+        if n_tiles > 1 and k_eff * n_tiles >= RP_K_TILES_MAX:
             raise ValueError(f"K={self.K} exceeds the supported maximum for {X.shape[1]} items"
-                             + (f" with normalize_X ({RP_K_MAX})" if self.normalize_X else f": K x {n_tiles} column tiles must stay below {RP_K_TILES_MAX}")
-                             + f" (any K up to {RP_TILE_MAX} items)")
+                             + (" with normalize_X" if self.normalize_X else "") + f": K x {n_tiles} column tiles must stay below {RP_K_TILES_MAX}"
+                             + f" (any K up to {tile} items)")
         ctx, dX = self._upload(X)
         try:
             if self.similarity == "cosine":

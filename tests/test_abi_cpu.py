@@ -124,13 +124,14 @@ def test_post_condition_warnings():
 
 def test_k_limit_raises_before_upload():
     """What is left of the K limit (a documented deviation: the reference takes any K) raises ValueError on the host: K x column tiles
-    >= 32 768 for the binary fit over several tiles (round 5; any K on one tile since round 4), K > RP_K_MAX = 2048 with normalize_X."""
+    >= 32 768 over several tiles (round 5; any K on one tile since round 4) - tiles of 25 600 items for the binary fit, of 12 288 with
+    normalize_X."""
     import scipy.sparse as sp
     import torch
 
     import recpack_amd
     from recpack_amd._lib import RecpackHipError
-    from recpack_amd.algorithms import RP_K_MAX, RP_TILE_MAX
+    from recpack_amd.algorithms import RP_K_MAX, RP_TILE_MAX, RP_WTILE_MAX
 
     X = sp.random(50, RP_TILE_MAX + 400, density=0.002, format="csr", random_state=0)
     X.data[:] = 1
@@ -141,11 +142,15 @@ def test_k_limit_raises_before_upload():
             recpack_amd.ItemKNN(K=RP_K_MAX + 1).fit(X)
     Xs = sp.random(50, 3000, density=0.01, format="csr", random_state=0)
     Xs.data[:] = 1
-    with pytest.raises(ValueError, match=str(RP_K_MAX)):
-        recpack_amd.ItemKNN(K=RP_K_MAX + 1, normalize_X=True).fit(Xs)
+    Xw = sp.random(50, 2 * RP_WTILE_MAX + 400, density=0.002, format="csr", random_state=0)
+    Xw.data[:] = 1
+    with pytest.raises(ValueError, match="normalize_X"):
+        recpack_amd.ItemKNN(K=16384, normalize_X=True).fit(Xw)  # three tiles of the float64 fit: 3 x 16 384 slots
     if not torch.cuda.is_available():  # one tile: no host-side limit any more - the call reaches the (absent) device
         with pytest.raises(RecpackHipError):
             recpack_amd.ItemKNN(K=RP_K_MAX + 1).fit(Xs)
+        with pytest.raises(RecpackHipError):
+            recpack_amd.ItemKNN(K=RP_K_MAX + 1, normalize_X=True).fit(Xs)
 
 
 def test_fitted_models_pickle_round_trip(tmp_path):

@@ -718,6 +718,31 @@ def test_fit_any_k_over_several_tiles(hip):
     assert S.shape == (40000, 40000) and 2048 < S.getnnz(axis=1).max() <= 5000
 
 
+def test_fit_normalize_X_any_k(hip):
+    """normalize_X=True with K beyond 2 048 (round 5): 30 000 items = three column tiles of the float64 fit; K = 3 000 merges a row's
+    lists in LDS, K = 7 000 where they lie in memory (k_itemknn_merge_weighted<true>); one tile (3 000 items) takes any K.  Tie-aware
+    against the oracle (the float64 sums depend on the order of the adds in the last bits, as in scipy)."""
+    from recpack_amd.synth import powerlaw_csr
+
+    _lib, ctx = hip
+    for (U, I, dens, Ks) in ((30000, 30000, 0.002, (3000, 7000)), (6000, 3000, 0.01, (2500,))):
+        X = powerlaw_csr(U, I, dens, seed=47).to_scipy()
+        dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
+        cand = onp.itemknn_fit_normalized(X, None)  # every candidate of the similarity (CSR)
+        for K in Ks:
+            m = _lib.itemknn_fit(ctx, dX, K, normalize_X=True)
+            idx, val, nnz = m.topk_download()
+            assert m.K == K and nnz.max() > 2048
+            live = np.arange(idx.shape[1])[None, :] < nnz[:, None]
+            assert ((idx[:, 1:] > idx[:, :-1]) | ~live[:, 1:]).all()  # canonical rows
+            o = onp.itemknn_fit_normalized(X, m.K)
+            osel = onp.topk_to_csr(o["idx"], o["val"], o["nnz"], X.shape[1])
+            assert (np.diff(osel.indptr) == nnz).all()
+            bad, exact = tie_aware_topk(cand, osel, idx, nnz, eps=1e-9)
+            assert not bad, (I, K, bad[:5])
+            topk_vals_close(osel, idx, val, nnz, rtol=1e-11)
+
+
 @pytest.mark.parametrize("nproc,shape", [(2, (20000, 30000, 0.0015, 50)), (3, (6000, 900, 0.01, 20))])
 def test_sharded_fit_on_hip_multi_rank(hip, nproc, shape):
     """The multi-GPU ItemKNN path with world > 1 ON THE KERNELS (ranks share this box's GPU over gloo): K0 with the degree pass
