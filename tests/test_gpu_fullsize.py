@@ -200,7 +200,7 @@ def test_ease_c3_full_size(hip):
     ease_full_size(hip, "C3", n_cols=(16, 8, 8), n_users=48, n_route_users=200_000)  # all 200 000 users through both routes
 
 
-@pytest.mark.parametrize("l2,alpha", [(10.0, 0.0), (1000.0, 0.5)])
+@pytest.mark.parametrize("l2,alpha", [(10.0, 0.0), (1000.0, 0.5), (10.0, 1.0)])
 def test_ease_c3_full_size_grid(hip, l2, alpha):
     """The ends of the reference's own grid (doc/source/guides.create_algorithm.rst:681: l2 in [10, 100, 1000]) at 50 000 items:
     cond(G + l2 I) is ~20 x larger at l2 = 10 than at the benchmark's 200, and the error of an fp32 solve scales with it."""
