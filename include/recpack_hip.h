@@ -351,9 +351,9 @@ int rphip_predict_topk_filtered_dev(rphip_ctx* ctx, const rphip_model* model, co
  * indptr (exclusive scan of row_nnz). */
 /* LIMITS (the reference accepts any K: base.py:302-304, util.py:63-66).  rphip_itemknn_fit[_ex]: any K on one column tile - 25 600
  * items without normalize_X (round 4), 12 288 with it (float64 sums) - and over T > 1 column tiles any K with K x T < 32 768 (round 5:
- * the merge of a row's per-tile lists reads them where they lie when they do not fit the LDS).  The valued (time-aware) fits and the Kp
- * of rphip_predict_topk* (min(Kp, n_items)): at most 2048 (the selection's LDS buffers).  Larger values return RPHIP_ELIMIT.
- * rphip_predict_full_* has no such limit. */
+ * the merge of a row's per-tile lists reads them where they lie when they do not fit the LDS); the valued (time-aware) fits alike over
+ * tiles of 12 288 items (8 192 for rphip_itemknn_fit_hermann).  The Kp of rphip_predict_topk* (min(Kp, n_items)): at most 2048 (the
+ * selection's LDS buffers).  Larger values return RPHIP_ELIMIT.  rphip_predict_full_* has no such limit. */
 int rphip_predict_full_count(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred,
                              int64_t user_begin, int64_t user_end, int64_t* row_nnz_host, int64_t* total_out);
 int rphip_predict_full_fill(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred,

@@ -24,7 +24,7 @@ this module is original.  When recpack itself is importable, :class:`Algorithm` 
 Limit (a deviation from the reference, which accepts any K): up to :data:`RP_TILE_MAX` = 25 600 items ``ItemKNN`` takes any ``K``
 (round 4); beyond, over T = ceil(items / 25 600) column tiles, any ``K`` with K x T < 32 768 (round 5: K = 8 191 at 100 000 items -
 the merge of a row's per-tile lists reads them where they lie when they do not fit the LDS); with ``normalize_X`` the same over tiles of
-12 288 items (K = 3 640 at 100 000 items).  For the time-aware fits the effective ``K`` is at most :data:`RP_K_MAX` = 2048.  The ``K`` of ``predict_topk`` - an extension, not part of the
+12 288 items (K = 3 640 at 100 000 items), and the time-aware fits alike.  The ``K`` of ``predict_topk`` - an extension, not part of the
 reference - is at most 2048.  Larger values raise ``ValueError`` before anything is uploaded.
 """
 from __future__ import annotations

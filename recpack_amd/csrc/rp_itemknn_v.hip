@@ -493,7 +493,25 @@ struct rp_vlist_src {
   __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)col_[w]; }
 };
 
-// top-K_eff of the T per-tile candidate lists of a row (each holds the tile's K largest non-zero entries)
+// The per-tile lists of one row where they lie in memory (large K, round 5; rp_glist_src of the binary fit)
+struct rp_vglist_src {
+  const int32_t* idx_;   // the row's lists: tile t at idx_ + t * K
+  const double* g_;
+  const int* off;        // [T + 1] in LDS
+  int T, K, n;
+  __device__ __forceinline__ int at(int w) const {
+    int t = 0;
+    while (t + 1 < T && w >= off[t + 1]) ++t;
+    return t * K + (w - off[t]);
+  }
+  __device__ __forceinline__ bool valid(int w) const { return w < n; }
+  __device__ __forceinline__ uint64_t key(int w) const { return rp_ordered_f64(g_[at(w)]); }
+  __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)idx_[at(w)]; }
+};
+
+// top-K_eff of the T per-tile candidate lists of a row (each holds the tile's K largest non-zero entries); GLOBAL: the lists are
+// not staged in LDS
+template <bool GLOBAL>
 __global__ void __launch_bounds__(RP_VMERGE_THREADS) k_itemknn_merge_values(const int32_t* __restrict__ cand_idx, const double* __restrict__ cand_g,
                                                                            const int32_t* __restrict__ cand_nnz, const int32_t* __restrict__ cand_cnt,
                                                                            const double* __restrict__ roww, int signed_vals, int n_tiles, int K,
@@ -504,7 +522,7 @@ __global__ void __launch_bounds__(RP_VMERGE_THREADS) k_itemknn_merge_values(cons
   const int T = n_tiles, cap = T * K;
   double* lg = reinterpret_cast<double*>(smem);
   int32_t* lcol = reinterpret_cast<int32_t*>(smem + (size_t)cap * 8);
-  rp_select_smem sel = rp_select_carve(smem + (size_t)cap * 12 + ((cap & 1) ? 4 : 0), cap, RP_VMERGE_THREADS / 64);
+  rp_select_smem sel = rp_select_carve(smem + (GLOBAL ? 0 : (size_t)cap * 12 + ((cap & 1) ? 4 : 0)), cap, RP_VMERGE_THREADS / 64);
   int* s_off = &sel.misc[RPS_USER];  // [T + 1], then K_eff
   const int tid = threadIdx.x;
   for (int rl = blockIdx.x; rl < n_rows; rl += gridDim.x) {
@@ -524,24 +542,38 @@ __global__ void __launch_bounds__(RP_VMERGE_THREADS) k_itemknn_merge_values(cons
     __syncthreads();
     const int n = s_off[T];
     const int kk = min(s_off[T + 1], n);
-    for (int t = 0; t < T; ++t) {
-      const int cn = s_off[t + 1] - s_off[t];
-      const int64_t so = ((int64_t)rl * T + t) * K;
-      for (int k = tid; k < cn; k += RP_VMERGE_THREADS) {
-        lcol[s_off[t] + k] = cand_idx[so + k];
-        lg[s_off[t] + k] = cand_g[so + k];
-      }
-    }
-    __syncthreads();
-    rp_vlist_src src{lg, lcol, n};
+    const double ri = roww ? roww[row_begin + rl] : 1.0;
     int kp = 0;
-    if (kk > 0) {
-      kp = rp_select_topk<RP_VMERGE_THREADS>(src, n, kk, sel);
-      const double ri = roww ? roww[row_begin + rl] : 1.0;
-      rp_select_emit<RP_VMERGE_THREADS>(n, sel, [&](int pos, int w) {
-        out_idx[(int64_t)rl * K + pos] = lcol[w];
-        out_val[(int64_t)rl * K + pos] = lg[w] * ri;
-      });
+    if constexpr (GLOBAL) {
+      const int32_t* gi = cand_idx + (int64_t)rl * T * K;
+      const double* gg = cand_g + (int64_t)rl * T * K;
+      rp_vglist_src src{gi, gg, s_off, T, K, n};
+      if (kk > 0) {
+        kp = rp_select_topk<RP_VMERGE_THREADS>(src, n, kk, sel);
+        rp_select_emit<RP_VMERGE_THREADS>(n, sel, [&](int pos, int w) {
+          const int a = src.at(w);
+          out_idx[(int64_t)rl * K + pos] = gi[a];
+          out_val[(int64_t)rl * K + pos] = gg[a] * ri;
+        });
+      }
+    } else {
+      for (int t = 0; t < T; ++t) {
+        const int cn = s_off[t + 1] - s_off[t];
+        const int64_t so = ((int64_t)rl * T + t) * K;
+        for (int k = tid; k < cn; k += RP_VMERGE_THREADS) {
+          lcol[s_off[t] + k] = cand_idx[so + k];
+          lg[s_off[t] + k] = cand_g[so + k];
+        }
+      }
+      __syncthreads();
+      rp_vlist_src src{lg, lcol, n};
+      if (kk > 0) {
+        kp = rp_select_topk<RP_VMERGE_THREADS>(src, n, kk, sel);
+        rp_select_emit<RP_VMERGE_THREADS>(n, sel, [&](int pos, int w) {
+          out_idx[(int64_t)rl * K + pos] = lcol[w];
+          out_val[(int64_t)rl * K + pos] = lg[w] * ri;
+        });
+      }
     }
     if (tid == 0) out_nnz[rl] = kp;
   }
@@ -559,12 +591,13 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
   if (X->xt_row_end >= 0) RP_FAIL(RPHIP_ESTATE, "the valued fit needs a matrix with all item rows of X^T (not rphip_csr_from_device_rows)");
   RP_TRY(rp_set_device(ctx));
   const int32_t Keff = (int32_t)std::min<int64_t>(K, std::max<int64_t>(1, X->n_items - 1));
-  if (Keff > RP_K_MAX) RP_FAIL(RPHIP_ELIMIT, "effective K=%d exceeds the supported maximum %d", Keff, RP_K_MAX);
   K = Keff;
   const int n_rows = (int)(row_end - row_begin);
   const int64_t I = X->n_items;
   const int tile_max = (pair_kind == RPHIP_PAIR_HERMANN) ? RP_VTILE_HERMANN : RP_VTILE_MAX;
   const int T = (int)std::max<int64_t>(1, rp_cdiv(I, tile_max));
+  // (round 5) any K on one column tile; over several tiles the merge keeps a 15-bit slot number per candidate (rp_select.h)
+  if (T > 1 && (int64_t)T * Keff >= RPS_FLAG) RP_FAIL(RPHIP_ELIMIT, "K=%d over %d column tiles: K x tiles must stay below %d", Keff, T, RPS_FLAG);
   const int W = (int)(rp_cdiv(rp_cdiv(std::max<int64_t>(I, 1), T), 64) * 64);
   if (T > 15) RP_FAIL(RPHIP_ELIMIT, "%d valued column tiles (n_items=%lld) exceed the supported 15", T, (long long)I);
   if ((T > 1 || !left_binary) && !X->sorted_rows) RP_FAIL(RPHIP_EINVAL, "the valued fit needs column-sorted rows");
@@ -698,18 +731,24 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
       rp_time_end(ctx, ev, RPHIP_T_GRAM_TOPK_WAVE, 0.0);
     }
     if (T > 1) {
-      const size_t mlds = (size_t)T * K * 12 + 8 + rp_select_smem_bytes(T * K, RP_VMERGE_THREADS / 64);
+      size_t mlds = (size_t)T * K * 12 + 8 + rp_select_smem_bytes(T * K, RP_VMERGE_THREADS / 64);
+      const bool glob = mlds > 160 * 1024;  // the lists of a row do not fit the LDS: they are read where they lie (slot numbers only in LDS)
+      if (glob) mlds = rp_select_smem_bytes(T * K, RP_VMERGE_THREADS / 64);
       if (mlds > 160 * 1024 || T * K >= RPS_FLAG) {
         rp_set_error("K=%d with %d column tiles needs %zu bytes of LDS for the merge", K, T, mlds);
         return fail(RPHIP_ELIMIT);
       }
-      if (hipFuncSetAttribute((const void*)k_itemknn_merge_values, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds) != hipSuccess)
-        return fail(RPHIP_EHIP);
+      const void* mk = glob ? (const void*)k_itemknn_merge_values<true> : (const void*)k_itemknn_merge_values<false>;
+      if (hipFuncSetAttribute(mk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds) != hipSuccess) return fail(RPHIP_EHIP);
       const int mper = std::max<int>(1, std::min<int>(8, (int)((160 * 1024) / mlds)));
+      const dim3 mgrid((unsigned)std::min<int64_t>(n_rows, (int64_t)ctx->n_cu * mper));
       rp_time_begin(ctx, &ev);
-      hipLaunchKernelGGL(k_itemknn_merge_values, dim3((unsigned)std::min<int64_t>(n_rows, (int64_t)ctx->n_cu * mper)), dim3(RP_VMERGE_THREADS),
-                         mlds, st, cand_idx, cand_g, cand_nnz, cand_cnt, P.roww, P.signed_vals, T, K, n_rows, (int)row_begin,
-                         use_hash ? light_flag : nullptr, m->idx, m->val, m->nnz);
+      if (glob)
+        hipLaunchKernelGGL(k_itemknn_merge_values<true>, mgrid, dim3(RP_VMERGE_THREADS), mlds, st, cand_idx, cand_g, cand_nnz, cand_cnt, P.roww, P.signed_vals, T, K,
+                           n_rows, (int)row_begin, use_hash ? light_flag : nullptr, m->idx, m->val, m->nnz);
+      else
+        hipLaunchKernelGGL(k_itemknn_merge_values<false>, mgrid, dim3(RP_VMERGE_THREADS), mlds, st, cand_idx, cand_g, cand_nnz, cand_cnt, P.roww, P.signed_vals, T, K,
+                           n_rows, (int)row_begin, use_hash ? light_flag : nullptr, m->idx, m->val, m->nnz);
       rp_time_end(ctx, ev, RPHIP_T_TOPK_MERGE, 0.0);
     }
     if (hipGetLastError() != hipSuccess) return fail(RPHIP_EHIP);

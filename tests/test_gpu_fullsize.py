@@ -222,17 +222,17 @@ def test_ease_c5_full_size(hip):
     ease_full_size(hip, "C5", n_cols=(8, 4, 4), n_users=32)
 
 
-@pytest.mark.parametrize("mode", ["cosine", "pearson", "time_distance"])
-def test_time_aware_c2_sampled_rows(hip, mode):
+@pytest.mark.parametrize("mode,K", [("cosine", 50), ("pearson", 50), ("time_distance", 50), ("cosine", 7000), ("pearson", 3000)])
+def test_time_aware_c2_sampled_rows(hip, mode, K):
     """The valued fits at C2 (100K x 20K, two column tiles, rows from 10 to 66K users: hash rows, tiled rows, merge) with
     seeded timestamps: 400 sampled rows tie-aware identical to the float64 oracle, values within 1e-11; weighted predict
-    of sampled users against float64 sums."""
+    of sampled users against float64 sums.  K = 3 000 / 7 000 (round 5: any K for the valued fits too): a row's two per-tile lists
+    merged in LDS / where they lie in memory (k_itemknn_merge_values<true>)."""
     from parity import tie_aware_topk
 
     _lib, ctx = hip
     _, X, _ = make("C2", hip)
     U, I = X.shape
-    K = 50
     rng = np.random.default_rng(11)
     T = X.copy()
     T.data = rng.integers(1, 60 * 24, size=X.nnz).astype(np.float64)  # hours over 60 days
