@@ -592,7 +592,15 @@ def main():
             # own columns + merge
             full = None
             owner_done = False
-            if args.ease_predict_route in ("auto", "owner"):
+            #  the route's static limits are checked ONCE, here, not by gathering n^2 bytes of int8 rows in every step for
+            # a call that then refuses: Kc = ceil64(Kp + 92) <= 256, 4 Kc <= items (rows of X are sorted: powerlaw_csr); a refusal the
+            # ranks agreed on at run time (memory, the exact pass's limits) is remembered for the steps that follow
+            owner_ok = args.ease_predict_route in ("auto", "owner") and not state.get("owner_refused")
+            if owner_ok and args.ease_predict_route == "auto":
+                kc = (Kp + 92 + 63) // 64 * 64
+                owner_ok = kc <= 256 and 4 * kc <= I
+            if owner_ok:
+                rows8 = None
                 try:
                     rows8 = rdist.ease_gather_rows_i8(ctx, em, I, comm)
                     _lib.predict_topk_owner(ctx, comm, em, rows8, dXe, [p[0] for p in user_parts] + [user_parts[-1][1]], Kp, out_idx, out_val, out_nnz)
@@ -600,8 +608,11 @@ def main():
                     keep["ease_predict_route"] = "int8 rows all-gathered, users sharded, exact sums by the columns' owners"
                     owner_done = True
                 except _lib.RecpackHipError as e:  # (decided before the first collective or agreed on by the ranks: everybody lands here or nobody)
+                    if rows8 is not None:
+                        rows8.close()  # (n^2 bytes back to the block cache now, not at the next collection)
                     if e.code not in (_lib.RPHIP_ENOMEM, _lib.RPHIP_ELIMIT, _lib.RPHIP_ESTATE) or args.ease_predict_route == "owner":
                         raise
+                    state["owner_refused"] = f"{type(e).__name__}: {e}"
             if owner_done:
                 pass
             elif rdist.ease_gather_fits(I, _lib.ease_fit_dist_stats(ctx)["panel"], info["hbm_bytes"], world):

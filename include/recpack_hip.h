@@ -20,6 +20,9 @@
  *    calls are serialised; host-output calls are synchronous on return, *_dev calls are ordered on the context's stream, with ONE
  *    exception: the fused predict of a DENSE model in two passes (option "predict_half", the default) reads back the number of
  *    users without a proof before it launches their exact pass, i.e. rphip_predict_topk*_dev waits for the stream once per call;
+ *    rphip_model_destroy / rphip_csr_destroy take the same lock (round 6: a destructor running on a garbage collector's thread waits
+ *    for the call in flight).  NOT covered: rphip_ctx_destroy and rphip_comm_destroy - the caller destroys a context or a
+ *    communicator only when no call that uses it is in flight (a communicator may outlive its context and so cannot lock it);
  *  - objects (ctx, csr, model) are opaque and freed by their *_destroy.
  */
 #ifndef RECPACK_HIP_H

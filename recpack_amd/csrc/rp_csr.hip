@@ -672,6 +672,7 @@ extern "C" int rphip_csr_finish_degrees(rphip_ctx* ctx, rphip_csr* m) {
 
 extern "C" int rphip_csr_destroy(rphip_csr* m) {
   if (!m) return RPHIP_OK;
+  RP_ENTER(m->ctx);  // (the block cache and the stream belong to the context: a destructor on another thread waits its turn)
   if (m->ctx) hipSetDevice(m->ctx->device);
   // x_ptr / x_idx of a *_from_device matrix belong to the caller, who may release them the moment this returns: asynchronous
   // launches (rphip_predict_topk_dev ...) may still be reading them on the context's stream

@@ -1370,6 +1370,7 @@ int rp_model_gather_wait(rphip_ctx* ctx, const rphip_model* m, bool on_stream) {
 // has to wait for it as the rank's own would
 extern "C" int rphip_model_adopt_gather(rphip_model* dst, rphip_model* src) {
   if (!dst || !src) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  RP_ENTER(dst->ctx);
   if (dst->gather_ev) RP_FAIL(RPHIP_ESTATE, "the model already waits for a gather");
   dst->gather_ev = src->gather_ev;
   dst->gather_stream = src->gather_stream;

@@ -908,6 +908,7 @@ int rp_model_alloc_topk(rphip_ctx* ctx, int64_t n_items, int64_t r0, int64_t r1,
 
 extern "C" int rphip_model_destroy(rphip_model* m) {
   if (!m) return RPHIP_OK;
+  RP_ENTER(m->ctx);  // (the block cache, the stream and a pending gather belong to the context: a destructor on another thread waits its turn)
   if (m->ctx) hipSetDevice(m->ctx->device);
   if (m->ctx && m->borrows_B) hipStreamSynchronize(m->ctx->stream);  // the caller's B may still be read by a launch in flight
   if (m->ctx && m->gather_ev) rp_model_gather_wait(m->ctx, m, false);   // (a gathered model whose f32 rows are still arriving)

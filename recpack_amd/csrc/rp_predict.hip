@@ -1991,8 +1991,6 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
   P.mode = 0;
   P.keep = keep_dev;
   const int T = P.n_tiles;
-  if (model->gather_ev && !(ctx->predict_half && ctx->predict_int8 && ctx->predict_user_tasks && model->b16_kind == 2 && !keep_dev))
-    RP_TRY(rp_model_gather_wait(ctx, model, true));  // (every route but the per-user first pass reads the f32 rows at once)
   // neighbour-list models with column-sorted rows: wave-per-user kernel (any history length); otherwise (dense
   // models, unsorted lists, very large Kp) the workgroup kernel below
   const bool use_wave = model->kind == RPHIP_MODEL_TOPK && model->cols_sorted && Kp <= PW_KP_MAX && model->K < 65536 &&
@@ -2000,6 +1998,7 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
   hipEvent_t ev;
   rp_time_begin(ctx, &ev);
   if (use_wave) {
+    RP_TRY(rp_model_gather_wait(ctx, model, true));
     const rphip_model* mm = model;  // (its tile offsets are built on first use: mutable members, under the context's lock)
     // 32-bit per-user-scaled sums on 4096-column tiles unless the caller asked for the exact 64-bit sums or the prediction
     // matrix carries values (their products are formed in float64)
@@ -2116,7 +2115,14 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
   int kc_i8 = ((Kp + 92 + 63) / 64) * 64;
   if (const char* e = rp_diag_env("RP_K9_I8_KC")) kc_i8 = std::max(64, atoi(e) / 64 * 64);
   const int Kc = want_i8 && kc_i8 <= 512 && (int64_t)4 * kc_i8 <= (int64_t)P.n_items ? kc_i8 : ((Kp + 24 + 63) / 64) * 64;
-  if (model->kind == RPHIP_MODEL_DENSE && ctx->predict_half && Kc <= 512 && (int64_t)4 * Kc <= (int64_t)P.n_items && T <= 15) {
+  const bool two_pass = model->kind == RPHIP_MODEL_DENSE && ctx->predict_half && Kc <= 512 && (int64_t)4 * Kc <= (int64_t)P.n_items && T <= 15;
+  // ONE predicate decides both who enters the per-user first pass and who may leave a gathered model's f32 rows in flight
+  // (every other route - the (user, tile) first pass, its rescoring, the one-pass kernel, a rebuild of the
+  // quantised copy from B - reads the f32 rows at once and waits for the gather here)
+  const bool per_user_first_pass = two_pass && want_i8 && Kc == kc_i8 && model->B16 && model->b16_kind == 2 && !model->b16_failed &&
+                                   ctx->predict_user_tasks && !keep_dev && Kc <= 256 && (!exclude_history || Xpred->sorted_rows);
+  if (!per_user_first_pass) RP_TRY(rp_model_gather_wait(ctx, model, true));
+  if (two_pass) {
     const rphip_model* mm = model;  // (the quantised copy is built on first use: mutable members, under the context's lock)
     RP_TRY(rp_model_half(ctx, mm, want_i8 && Kc == kc_i8 ? 2 : 1));
     if (mm->B16) {
@@ -2590,17 +2596,36 @@ extern "C" int rphip_predict_topk_owner(rphip_ctx* ctx, rphip_comm* comm, const 
   get((size_t)(n_max + 1) * 4 + 64, (void**)&fail);  // [0] count, [1 ..] local ids (the all-gather's slot)
   get((size_t)std::max<int64_t>(U, 1) * Kc * 4, (void**)&part_s);
   get((size_t)std::max<int64_t>(n_me, 1) * Kc * 4 * W, (void**)&part_r);
+  const int fslot = (int)n_max + 1;
+  int32_t* G = nullptr;  // [W][fslot]: every rank's users without a proof
+  get((size_t)fslot * W * 4, (void**)&G);
+  // No rank may leave alone once the collectives have begun (the others would wait in the next one: ADVICE round 5).  Everything a
+  // single rank can trip over is therefore decided HERE: its allocations, and the limits that depend on its own columns (the exact
+  // pass's tiles and the two merges' LDS).  The ranks sum two 0 / 1 flags and return RPHIP_ENOMEM / RPHIP_ELIMIT together - the
+  // caller can then take rphip_predict_topk_dist.  agree() is repeated after the second group of allocations below.
+  rp_pred_params PL;
+  if (local) rp_pred_fill(PL, local, X, 0, U);
+  const int T_l = local ? PL.n_tiles : 1;
+  const size_t mlds_t = (size_t)T_l * Kp * 8 + rp_select_smem_bytes(T_l * Kp) + (size_t)Kp * 8;
+  const size_t mlds_w = (size_t)W * Kp * 8 + rp_select_smem_bytes(W * Kp) + (size_t)Kp * 8;
+  const bool lim_bad = T_l > 15 || (T_l > 1 && (mlds_t > 160 * 1024 || T_l * Kp >= RPS_FLAG)) || mlds_w > 160 * 1024 || W * Kp >= RPS_FLAG;
+  auto agree = [&](bool mem_bad, bool limit_bad, int32_t* sums) -> int {
+    int32_t h[2] = {mem_bad ? 1 : 0, limit_bad ? 1 : 0};
+    RP_HIP(hipMemcpyAsync(n_fail + 8, h, 8, hipMemcpyHostToDevice, st));
+    RP_HIP(hipStreamSynchronize(st));
+    RP_TRY(rp_comm_all_reduce_sum_i32(comm, n_fail + 8, 2, st));
+    RP_HIP(hipMemcpyAsync(sums, n_fail + 8, 8, hipMemcpyDeviceToHost, st));
+    RP_HIP(hipStreamSynchronize(st));
+    return RPHIP_OK;
+  };
   {
-    // a rank whose large blocks did not fit must not leave alone (the others would wait in the first all-gather): the ranks sum
-    // a 0 / 1 flag and return RPHIP_ENOMEM together - the caller can then take rphip_predict_topk_dist
-    int32_t h_bad = arc == RPHIP_OK ? 0 : 1, h_sum = 1;
-    RP_HIP(hipMemcpyAsync(n_fail + 8, &h_bad, 4, hipMemcpyHostToDevice, st));
-    RP_HIP(hipStreamSynchronize(st));
-    RP_TRY(rp_comm_all_reduce_sum_i32(comm, n_fail + 8, 1, st));
-    RP_HIP(hipMemcpyAsync(&h_sum, n_fail + 8, 4, hipMemcpyDeviceToHost, st));
-    RP_HIP(hipStreamSynchronize(st));
-    if (h_sum != 0)
-      RP_FAIL(RPHIP_ENOMEM, "%d of %d ranks could not allocate the candidate and part buffers (%zu bytes here): use rphip_predict_topk_dist", (int)h_sum, W,
+    int32_t h_sum[2] = {1, 1};
+    RP_TRY(agree(arc != RPHIP_OK, lim_bad, h_sum));
+    if (h_sum[1] != 0)
+      RP_FAIL(RPHIP_ELIMIT, "%d of %d ranks: Kp=%d with %d column tiles here and %d ranks is outside what the exact pass and its merges serve: use rphip_predict_topk_dist",
+              (int)h_sum[1], W, Kp, T_l, W);
+    if (h_sum[0] != 0)
+      RP_FAIL(RPHIP_ENOMEM, "%d of %d ranks could not allocate the candidate and part buffers (%zu bytes here): use rphip_predict_topk_dist", (int)h_sum[0], W,
               slotA * W * 8 + (size_t)U * Kc * 4 + (size_t)n_me * Kc * 4 * W);
   }
   hipMemsetAsync(n_fail, 0, 64, st);
@@ -2619,8 +2644,6 @@ extern "C" int rphip_predict_topk_owner(rphip_ctx* ctx, rphip_comm* comm, const 
   RP_TRY(rp_comm_all_gather(comm, my_nnz, A_nnz, (int64_t)n_max * 4, st));
   if (loop) rp_comm_loop_replicate(comm, false);
   // ---- 3. the exact sums of the candidates in this rank's columns, users of all ranks
-  rp_pred_params PL;
-  if (local) rp_pred_fill(PL, local, X, 0, U);
   auto fill_rescore = [&](rp_rescore_params& R, int r) {
     R.x_ptr = X->x_ptr;
     R.x_idx = X->x_idx;
@@ -2714,10 +2737,8 @@ extern "C" int rphip_predict_topk_owner(rphip_ctx* ctx, rphip_comm* comm, const 
   }
   // ---- the users without a proof, of all ranks: [count, local ids] per rank
   RP_HIP(hipMemcpyAsync(fail, n_fail, 4, hipMemcpyDeviceToDevice, st));
-  const int fslot = (int)n_max + 1;
-  int32_t *G = nullptr, *glist = nullptr, *goff_dev = nullptr;
+  int32_t *glist = nullptr, *goff_dev = nullptr;
   int64_t* bounds_dev = nullptr;
-  RP_TRY(H.get((size_t)fslot * W * 4, (void**)&G));
   RP_TRY(rp_comm_all_gather(comm, fail, G, (int64_t)fslot * 4, st));
   std::vector<int32_t> cnt(W, 0), off(W + 1, 0);
   for (int r = 0; r < W; ++r) RP_HIP(hipMemcpyAsync(&cnt[r], G + (size_t)r * fslot, 4, hipMemcpyDeviceToHost, st));
@@ -2731,19 +2752,41 @@ extern "C" int rphip_predict_topk_owner(rphip_ctx* ctx, rphip_comm* comm, const 
   ctx->owner_stats[1] = f_me;
   ctx->owner_stats[2] = Kc;
   if (n_f > 0) {
-    RP_TRY(H.get((size_t)n_f * 4, (void**)&glist));
-    RP_TRY(H.get((size_t)(W + 1) * 4, (void**)&goff_dev));
-    RP_TRY(H.get((size_t)(W + 1) * 8, (void**)&bounds_dev));
+    // the second group of allocations (sizes known only now; n_f and the counts are the same numbers on every rank): agreed as above
+    int32_t *L_idx = nullptr, *L_nnz = nullptr, *t_idx = nullptr, *t_nnz = nullptr, *ci = nullptr, *cn = nullptr;
+    float *L_val = nullptr, *t_val = nullptr, *cv = nullptr;
+    char* recvb = nullptr;
+    const int64_t cs = std::max(f_me, 1);
+    const int64_t slot = cs * ((int64_t)Kp * 8 + 4);
+    arc = RPHIP_OK;
+    get((size_t)n_f * 4, (void**)&glist);
+    get((size_t)(W + 1) * 4, (void**)&goff_dev);
+    get((size_t)(W + 1) * 8, (void**)&bounds_dev);
+    get((size_t)n_f * Kp * 4, (void**)&L_idx);
+    get((size_t)n_f * Kp * 4, (void**)&L_val);
+    get((size_t)n_f * 4, (void**)&L_nnz);
+    if (local && T_l > 1) {
+      get((size_t)n_f * T_l * Kp * 4, (void**)&t_idx);
+      get((size_t)n_f * T_l * Kp * 4, (void**)&t_val);
+      get((size_t)n_f * T_l * 4, (void**)&t_nnz);
+    }
+    get((size_t)slot * W, (void**)&recvb);
+    if (f_me > 0) {
+      get((size_t)f_me * W * Kp * 4, (void**)&ci);
+      get((size_t)f_me * W * Kp * 4, (void**)&cv);
+      get((size_t)f_me * W * 4, (void**)&cn);
+    }
+    {
+      int32_t h_sum[2] = {1, 1};
+      RP_TRY(agree(arc != RPHIP_OK, false, h_sum));
+      if (h_sum[0] != 0)
+        RP_FAIL(RPHIP_ENOMEM, "%d of %d ranks could not allocate the exact pass's lists for %d users without a proof: use rphip_predict_topk_dist", (int)h_sum[0], W, n_f);
+    }
     RP_HIP(hipMemcpyAsync(goff_dev, off.data(), (size_t)(W + 1) * 4, hipMemcpyHostToDevice, st));
     RP_HIP(hipMemcpyAsync(bounds_dev, user_bounds, (size_t)(W + 1) * 8, hipMemcpyHostToDevice, st));
     RP_HIP(hipStreamSynchronize(st));  // (the host arrays are read by the copies)
     hipLaunchKernelGGL(k_owner_fail_concat, dim3(64, W), dim3(256), 0, st, G, fslot, W, goff_dev, bounds_dev, glist);
     // local top-Kp of every such user over this rank's columns: [n_f][Kp] by position in the list
-    int32_t *L_idx = nullptr, *L_nnz = nullptr;
-    float* L_val = nullptr;
-    RP_TRY(H.get((size_t)n_f * Kp * 4, (void**)&L_idx));
-    RP_TRY(H.get((size_t)n_f * Kp * 4, (void**)&L_val));
-    RP_TRY(H.get((size_t)n_f * 4, (void**)&L_nnz));
     hipMemsetAsync(L_nnz, 0, (size_t)n_f * 4, st);
     if (local) {
       rp_pred_params F = PL;
@@ -2764,22 +2807,14 @@ extern "C" int rphip_predict_topk_owner(rphip_ctx* ctx, rphip_comm* comm, const 
         F.out_nnz = L_nnz;
         hipLaunchKernelGGL(k_predict_tile<true>, dim3((unsigned)std::min<int64_t>(n_f, (int64_t)ctx->n_cu * 8)), dim3(RP_PRED_THREADS), lds1, st, F);
       } else {
-        if (T > 15) RP_FAIL(RPHIP_ELIMIT, "%d column tiles exceed the supported 15", T);
-        int32_t *t_idx = nullptr, *t_nnz = nullptr, *seq = nullptr;
-        float* t_val = nullptr;
-        RP_TRY(H.get((size_t)n_f * T * Kp * 4, (void**)&t_idx));
-        RP_TRY(H.get((size_t)n_f * T * Kp * 4, (void**)&t_val));
-        RP_TRY(H.get((size_t)n_f * T * 4, (void**)&t_nnz));
         hipMemsetAsync(t_nnz, 0, (size_t)n_f * T * 4, st);
         F.list_compact = 1;
         F.out_idx = t_idx;
         F.out_val = t_val;
         F.out_nnz = t_nnz;
         hipLaunchKernelGGL(k_predict_tile<true>, dim3((unsigned)std::min<int64_t>((int64_t)n_f * T, (int64_t)ctx->n_cu * 8)), dim3(RP_PRED_THREADS), lds1, st, F);
-        const size_t mlds_p = (size_t)T * Kp * 8 + rp_select_smem_bytes(T * Kp) + (size_t)Kp * 8;
-        if (mlds_p > 160 * 1024 || T * Kp >= RPS_FLAG) RP_FAIL(RPHIP_ELIMIT, "Kp=%d with %d column tiles needs %zu bytes of LDS for the merge", Kp, T, mlds_p);
+        const size_t mlds_p = mlds_t;  // (checked before the first collective)
         RP_HIP(hipFuncSetAttribute((const void*)k_predict_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds_p));
-        (void)seq;
         // (the tiles of a block-cyclic slab are not consecutive column ranges: sort_cols; rows by list position: no user list)
         hipLaunchKernelGGL(k_predict_merge, dim3((unsigned)std::min<int64_t>(n_f, (int64_t)ctx->n_cu * 8)), dim3(RP_PRED_THREADS), mlds_p, st, t_idx, t_val, t_nnz, T,
                            Kp, n_f, nullptr, nullptr, L_idx, L_val, L_nnz, 1);
@@ -2787,10 +2822,6 @@ extern "C" int rphip_predict_topk_owner(rphip_ctx* ctx, rphip_comm* comm, const 
       RP_HIP(hipGetLastError());
     }
     // the lists to the users' ranks: slots [source][f_me][Kp] columns, scores, [f_me] counts - k_lists_to_users' layout
-    const int64_t cs = std::max(f_me, 1);
-    const int64_t slot = cs * ((int64_t)Kp * 8 + 4);
-    char* recvb = nullptr;
-    RP_TRY(H.get((size_t)slot * W, (void**)&recvb));
     for (int sec = 0; sec < 3; ++sec) {  // columns, scores, counts
       const int64_t per = sec < 2 ? (int64_t)Kp * 4 : 4;
       const char* sendb = sec == 0 ? (const char*)L_idx : (sec == 1 ? (const char*)L_val : (const char*)L_nnz);
@@ -2803,16 +2834,10 @@ extern "C" int rphip_predict_topk_owner(rphip_ctx* ctx, rphip_comm* comm, const 
       RP_TRY(rp_comm_exchange(comm, sendb, soff.data(), sby.data(), recvb, roff.data(), rby.data(), st));
     }
     if (f_me > 0) {
-      int32_t *ci = nullptr, *cn = nullptr;
-      float* cv = nullptr;
-      RP_TRY(H.get((size_t)f_me * W * Kp * 4, (void**)&ci));
-      RP_TRY(H.get((size_t)f_me * W * Kp * 4, (void**)&cv));
-      RP_TRY(H.get((size_t)f_me * W * 4, (void**)&cn));
       const long long total = (long long)f_me * W * Kp;
       hipLaunchKernelGGL(k_lists_to_users, dim3((unsigned)std::min<long long>(8192, rp_cdiv(total, 256))), dim3(256), 0, st, recvb, (long long)slot, W, (int)cs, f_me,
                          (int)Kp, ci, cv, cn);
-      const size_t mlds = (size_t)W * Kp * 8 + rp_select_smem_bytes(W * Kp) + (size_t)Kp * 8;
-      if (mlds > 160 * 1024 || W * Kp >= RPS_FLAG) RP_FAIL(RPHIP_ELIMIT, "Kp=%d with %d ranks needs %zu bytes of LDS for the merge", Kp, W, mlds);
+      const size_t mlds = mlds_w;  // (checked before the first collective)
       RP_HIP(hipFuncSetAttribute((const void*)k_predict_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
       // rows of this rank's users without a proof: user_list = their local ids (behind the count in `fail`), lists by position
       hipLaunchKernelGGL(k_predict_merge, dim3((unsigned)std::min<int64_t>(f_me, (int64_t)ctx->n_cu * 8)), dim3(RP_PRED_THREADS), mlds, st, ci, cv, cn, W, (int)Kp, f_me,

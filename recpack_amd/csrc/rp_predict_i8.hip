@@ -73,7 +73,8 @@ __global__ void __launch_bounds__(RPU_THREADS, 8) k_predict_user_i8(rp_i8_params
   RP_LDS int32_t* s_hist = (RP_LDS int32_t*)(smem + (size_t)RPU_CAP * 8 + (size_t)RPU_KC_MAX * 8);  // [HIST]
   char* sel_base = smem + (size_t)RPU_CAP * 8 + (size_t)RPU_KC_MAX * 8 + (size_t)RPU_HIST * 4;
   rp_select_smem sel = rp_select_carve(sel_base, RPU_CAP);
-  RP_LDS int* s_cnt = (RP_LDS int*)&sel.misc[RPS_USER];                    // [0] list entries, [1] history items inside the tile, [2] next user
+  RP_LDS int* s_cnt = (RP_LDS int*)&sel.misc[RPS_USER];                    // [0] list entries (the append position), [1] history items inside the tile, [2] next user,
+                                                                           // [4], [5] entries appended by the even / odd tiles (see the count below)
   RP_LDS float* s_tau = (RP_LDS float*)&sel.misc[RPS_USER + 8];            // [16]
   const int32_t* lcol_g = reinterpret_cast<const int32_t*>(smem);          // (the selection's source takes generic pointers)
   const float* lval_g = reinterpret_cast<const float*>(smem + (size_t)RPU_CAP * 4);
@@ -104,6 +105,7 @@ __global__ void __launch_bounds__(RPU_THREADS, 8) k_predict_user_i8(rp_i8_params
     if (tid == 0) {
       s_cnt[2] = atomicAdd(P.ticket, 1);
       s_cnt[0] = 0;
+      s_cnt[4] = s_cnt[5] = 0;
     }
     __syncthreads();
     const int ul = s_cnt[2];
@@ -116,6 +118,7 @@ __global__ void __launch_bounds__(RPU_THREADS, 8) k_predict_user_i8(rp_i8_params
     }
     float tau = -INFINITY;
     bool have_tau = false, failed = false;
+    int n_other = 0;  // entries appended by the tiles of the other parity, as of the previous tile's barrier
     const bool hist_lds = P.exclude_history && he - hs <= RPU_HIST;
     if (hist_lds)  // (visible behind the first tile's barrier, long before the first candidate)
       for (int k = tid; k < he - hs; k += RPU_THREADS) s_hist[k] = P.x_idx[hs + k];
@@ -222,6 +225,7 @@ __global__ void __launch_bounds__(RPU_THREADS, 8) k_predict_user_i8(rp_i8_params
 #pragma unroll
         for (int e = 0; e < 16; ++e) any |= (r[e] != 0.0f && r[e] >= tau);
         if (any) {
+          int mine = 0;
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const float v = r[e];
@@ -229,6 +233,7 @@ __global__ void __launch_bounds__(RPU_THREADS, 8) k_predict_user_i8(rp_i8_params
               const int g = rpu_l2g(P, t0 + 16 * tid + e);
               if (!P.exclude_history || !(hist_lds ? rpu_in_history(s_hist, he - hs, g) : rpu_in_history(P.x_idx + hs, he - hs, g))) {
                 const int pos = atomicAdd((int*)&s_cnt[0], 1);
+                ++mine;
                 if (pos < RPU_CAP) {
                   lcol[pos] = g;
                   lval[pos] = v;
@@ -236,10 +241,16 @@ __global__ void __launch_bounds__(RPU_THREADS, 8) k_predict_user_i8(rp_i8_params
               }
             }
           }
+          if (mine) atomicAdd((int*)&s_cnt[4 + (tile & 1)], mine);
         }
       }
       __syncthreads();
-      const int n = s_cnt[0];
+      // The list's length, the SAME number in every thread: s_cnt[0] may already be moving - a wave that needs no
+      // threshold pass goes straight on to the next tile's appends - but the counter of this tile's parity stands still until the
+      // tile after the next, which nobody reaches before the next barrier; the other parity's was read behind the previous barrier.
+      const int n_mine = s_cnt[4 + (tile & 1)];
+      const int n = n_mine + n_other;
+      n_other = n_mine;
       if (n > RPU_CAP) {  // (more candidates than the list holds - scores that tie by the thousand: the exact pass serves this user)
         failed = true;
         break;
@@ -273,7 +284,12 @@ __global__ void __launch_bounds__(RPU_THREADS, 8) k_predict_user_i8(rp_i8_params
             for (int d = 32; d > 0; d >>= 1) mn = fminf(mn, __shfl_xor(mn, d));
             if (lane == 0) s_tau[wave] = mn;
           }
-          if (tid == 0) s_cnt[0] = kp;
+          if (tid == 0) {
+            s_cnt[0] = kp;
+            s_cnt[4 + (tile & 1)] = kp;
+            s_cnt[5 - (tile & 1)] = 0;
+          }
+          n_other = kp;
           __syncthreads();
           if (kp == Kc) {
             float t = s_tau[0];

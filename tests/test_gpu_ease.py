@@ -452,6 +452,67 @@ def test_ease_fit_sharded_one_rank(hip):
         rdist.ease_fit_sharded(ctx, dX, 0.0, 0.0, dev)
 
 
+@pytest.mark.parametrize("Kp,excl,unsorted", [(200, False, False), (100, True, True), (100, True, False), (600, False, False)])
+def test_gathered_model_predict_waits_for_the_f32_rows(hip, Kp, excl, unsorted):
+    """a gathered model's f32 rows arrive on a stream of their own (rphip_ease_model_allgather, phase 2); only
+    the per-user first pass may run beside them - every other predict route (Kc > 256: Kp = 200 / 600; history removal on unsorted
+    rows) must wait for the gather before it reads B.  One rank of two on a loop-back communicator with a SLOW link (the strips
+    take ~0.5 s): the predict issued at once must equal the predict after the gather has completed, bit for bit, and the host's
+    float64 scores of the downloaded matrix."""
+    import torch
+
+    from recpack_amd import dist as rdist
+    from recpack_amd.synth import powerlaw_csr
+
+    _lib, ctx = hip
+    n_items = 2048
+    X = powerlaw_csr(1500, n_items, 0.01, seed=123).to_scipy()
+    dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
+    Xp = X[:600].copy()
+    if unsorted:  # reverse every row's column order
+        idx = Xp.indices.copy()
+        for u in range(Xp.shape[0]):
+            idx[Xp.indptr[u]:Xp.indptr[u + 1]] = idx[Xp.indptr[u]:Xp.indptr[u + 1]][::-1]
+        Xp = sp.csr_matrix((Xp.data, idx, Xp.indptr), shape=Xp.shape)
+    dXp = _lib.DeviceCSR.from_host(ctx, Xp.indptr, Xp.indices, Xp.shape)
+    dev = torch.device("cuda", 0)
+    comm = _lib.Comm.loopback(ctx, 2, 0, gbytes_per_s=0.02, latency_us=10.0)
+    try:
+        ms, lay = rdist.ease_fit_sharded(ctx, dX, 20.0, 0.0, dev, panel_tiles=4, comm=comm)
+        # (a loop-back fit computes with noise in the peers' places: the rank's panels are overwritten with known numbers)
+        ptr, _, ld = ms.dense_device_ptr()
+        n_loc = lay["n_local"]
+        Bl = torch.as_tensor(rdist._DevPtr(ptr, (n_items, ld), "<f4", ms), device=dev)
+        g = torch.Generator(device="cpu").manual_seed(5)
+        Bl[:, :n_loc] = (torch.randn((n_items, n_loc), generator=g) * 0.05).to(dev)
+        torch.cuda.synchronize()
+        full = rdist.ease_gather_model(ctx, ms, n_items, comm)
+        first = _lib.predict_topk(ctx, full, dXp, Kp, exclude_history=excl)  # (the strips are still on their way)
+        ctx.sync()
+        B = full.dense_download().astype(np.float64)
+        again = _lib.predict_topk(ctx, full, dXp, Kp, exclude_history=excl)
+        for a, b in zip(first, again):
+            np.testing.assert_array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+        assert np.abs(B).max() > 0.01
+        S = np.asarray(Xp @ B)
+        if excl:
+            S[Xp.nonzero()] = -np.inf
+        smax = np.abs(S[np.isfinite(S)]).max()
+        pi, pv, pn = first
+        for u in range(0, Xp.shape[0], 7):
+            k = int(pn[u])
+            if Xp.indptr[u + 1] == Xp.indptr[u]:
+                assert k == 0
+                continue
+            want = np.sort(S[u][np.isfinite(S[u]) & (S[u] != 0.0)])[::-1][:Kp]
+            assert k == len(want)
+            assert np.abs(np.sort(pv[u, :k].astype(np.float64))[::-1] - want).max() <= 1e-5 * smax
+            np.testing.assert_allclose(S[u][pi[u, :k]], pv[u, :k], atol=1e-5 * smax)
+        del full, ms
+    finally:
+        comm.close()
+
+
 def test_ease_fit_sharded_rccl_one_rank(hip):
     """The same code with a one-rank NCCL (= RCCL) group: every collective call of the multi-GPU path runs through RCCL."""
     import os
