@@ -50,6 +50,11 @@ def parse():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0, help="0 disables the CPU leg")
     ap.add_argument("--ease-config", default="C3",
                     help="extra EASE legs outside the timed step (N=1 only), comma separated configs -> `ease_<cfg>`; 'none' disables them")
+    ap.add_argument("--itemknn-config", default="C2",
+                    help="extra ItemKNN legs outside the timed step (N=1 only), comma separated configs -> `itemknn_<cfg>` (C2 = BASELINE.json "
+                         "configs[1]); 'none' disables them")
+    ap.add_argument("--no-parity-check", dest="parity_check", action="store_false", default=True,
+                    help="skip the parity verdict (oracle rows of the ItemKNN model, whole-matrix probe of the EASE model) printed under `parity`")
     ap.add_argument("--no-ease-in-step", dest="ease_in_step", action="store_false", default=True,
                     help="time the ItemKNN half alone (the step then leaves EASE out and `status` says so)")
     ap.add_argument("--l2", type=float, default=200.0)
@@ -314,6 +319,105 @@ def tars_leg(args, ctx, device, Kp, config):
     }
 
 
+def itemknn_leg(args, ctx, device, Kp, config, repeats):
+    """ItemKNN cosine fit + predict on one config outside the timed step (C2 = BASELINE.json configs[1]: 100K users x 20K items):
+    K0 + K1-K3 + K8 with the CSR resident in HBM, best of `repeats` after one warm-up."""
+    import torch
+
+    from recpack_amd import _lib
+    from recpack_amd.synth import CONFIG_SEED_BASE, CONFIGS, powerlaw_csr
+
+    U, I, dens = CONFIGS[config]
+    ip, ix = powerlaw_csr(U, I, dens, CONFIG_SEED_BASE + int(config[1:]), device=device)
+    out_idx = torch.empty((U, Kp), dtype=torch.int32, device=device)
+    out_val = torch.empty((U, Kp), dtype=torch.float32, device=device)
+    out_nnz = torch.empty((U,), dtype=torch.int32, device=device)
+    best = None
+    walls = []
+    P_cfg = None
+    for it in range(repeats + 1):
+        ctx.reset_timings()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
+        model = _lib.itemknn_fit(ctx, dX, args.K)
+        torch.cuda.synchronize()
+        t_fit = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        _lib.predict_topk_dev(ctx, model, dX, Kp, out_idx, out_val, out_nnz)
+        torch.cuda.synchronize()
+        t_pred = time.perf_counter() - t0
+        tm = ctx.timings()
+        P_cfg = dX.num_products()
+        walls.append(round(t_fit + t_pred, 5))
+        if it > 0 and (best is None or t_fit + t_pred < best[0] + best[1]):
+            best = (t_fit, t_pred, tm)
+        del model, dX
+    t_fit, t_pred, tm = best
+    nnz = int(ix.numel())
+    sp_ms = sum(tm[k]["ms"] for k in ("gram_topk", "gram_topk_wave", "gram_finalize", "topk_merge"))
+    sp_bytes = 4.0 * P_cfg + 8.0 * nnz + 4.0 * (U + I + 2) + 8.0 * I * args.K
+    k8_bytes = 8.0 * args.K * nnz + 4.0 * (nnz + U) + 8.0 * U * Kp
+    k8_ms = tm["predict"]["ms"]
+    return {
+        "workload": f"{config}: ItemKNN cosine K={args.K}, {U} users x {I} items, nnz {nnz} (P={P_cfg}), predict + top-{Kp} for all users",
+        "fit_s": round(t_fit, 5), "predict_s": round(t_pred, 5), "fit_plus_predict_s": round(t_fit + t_pred, 5),
+        "wall_s_all_runs": walls,
+        "phases_ms": {k: round(v["ms"], 4) for k, v in tm.items() if v["launches"]},
+        "spgemm_all_kernels": {"ms": round(sp_ms, 4), "algorithmic_bytes": sp_bytes, "GBps": round(sp_bytes / (sp_ms * 1e-3) / 1e9, 1) if sp_ms > 0 else None,
+                               "frac": round(sp_bytes / (sp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sp_ms > 0 else None},
+        "k8_predict": {"ms": round(k8_ms, 4), "algorithmic_bytes": k8_bytes, "GBps": round(k8_bytes / (k8_ms * 1e-3) / 1e9, 1) if k8_ms > 0 else None,
+                       "frac": round(k8_bytes / (k8_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k8_ms > 0 else None},
+        "dtype": "int32 counts, f64 similarity, i32 fixed-point score sums",
+    }
+
+
+def parity_verdict(args, ctx, device, indptr_t, indices_t, shape, knn_model, ease_model, n_rows=384):
+    """SURVEY.md 8(d) "parity gates per run", AFTER the timed steps, on the models the last step left (N = 1): the oracle as the
+    checker, never inside the timed region.
+      ItemKNN: `n_rows` random item rows of the fitted model against oracle/oracle_np.py::itemknn_fit on the same matrix - neighbour
+               sets and order bit-identical, values to 1e-12 (the full-size test checks 10 000 rows);
+      EASE:    the whole-matrix probe (oracle/ease_probe.py): A (I - B) is diagonal, so two random float64 probes must give the
+               same 1 / P_jj for every item - every entry of B takes part; bar 1e-4 relative per item (north_star)."""
+    import scipy.sparse as sp
+    import torch
+
+    from oracle import oracle_np as onp
+    from oracle.ease_probe import ease_probe
+    from recpack_amd import dist as rdist
+
+    U, I = shape
+    out = {"checked_after_timed_steps": True}
+    t0 = time.perf_counter()
+    idx, val, nnz_rows = knn_model.topk_download()
+    ip, ix = indptr_t.cpu().numpy(), indices_t.cpu().numpy()
+    X = sp.csr_matrix((np.ones(ix.shape[0], dtype=np.int32), ix, ip), shape=shape)
+    rows = np.sort(np.random.default_rng(11).choice(I, size=min(I, n_rows), replace=False))
+    ref = onp.itemknn_fit(X, args.K, rows=rows)
+    key = np.where(ref["idx"] < 0, np.iinfo(np.int32).max, ref["idx"])
+    perm = np.argsort(key, axis=1, kind="stable")  # (the oracle's rows are in rank order, the model's in column order)
+    ridx = np.take_along_axis(ref["idx"], perm, axis=1)
+    rval = np.take_along_axis(ref["val"], perm, axis=1)
+    same = (idx[rows] == ridx).all(axis=1) & (nnz_rows[rows] == ref["nnz"])
+    live = ridx >= 0
+    vrel = float(np.max(np.abs(val[rows][live] - rval[live]) / rval[live])) if live.any() and same.all() else None
+    out.update({"itemknn_rows_checked": int(len(rows)), "itemknn_rows_identical": int(same.sum()), "itemknn_value_max_rel": vrel,
+                "itemknn_ok": bool(same.all() and vrel is not None and vrel <= 1e-12), "itemknn_check_s": round(time.perf_counter() - t0, 2)})
+    del X, ref
+    if ease_model is not None:
+        t0 = time.perf_counter()
+        B = rdist.model_dense_tensor(ease_model, device)
+        pr = ease_probe(indptr_t, indices_t, shape, B, args.l2, 0.0)
+        torch.cuda.synchronize()
+        del B
+        out.update({"ease_probe_rel": pr["probe_rel"], "ease_probe_rel_median": pr["probe_rel_median"], "ease_items_checked": pr["items_checked"],
+                    "ease_bounds_violation": pr["bounds_violation"], "ease_diag_max": pr["diag_max"],
+                    "ease_ok": bool(pr["probe_rel"] <= 1e-4 and pr["diag_max"] == 0.0 and pr["bounds_violation"] <= 1e-6),
+                    "ease_check_s": round(time.perf_counter() - t0, 2),
+                    "ease_probe_what": "max over items of |r_1 - r_0| / |r_0|, r_p = (X^T X + l2 I)(z_p - B z_p) / z_p = 1 / P_jj for two random float64 probes"})
+    return out
+
+
 def roofline_ease(tm, I, world, steps, dist_stats, nnz, U, Kp):
     """The EASE solve against the MFMA peak.  One rank: K5 (Cholesky) + K6 (inverse) of rphip_ease_fit, n^3 flop by SURVEY.md
     section 8(d) (n padded to 128).  N > 1: the symmetric block sweeps of rphip_ease_fit_dist, the rank's own products as counted
@@ -333,7 +437,9 @@ def roofline_ease(tm, I, world, steps, dist_stats, nnz, U, Kp):
     tf = flop / (solve_ms * 1e-3) / 1e12 if solve_ms > 0 else 0.0
     k9 = tm["predict_dense"]
     out = {
-        "kernel": what + " (v_mfma_f32_16x16x32_f16 on fp32 operands cut into two fp16 planes, fp32 accumulate, compensated master sums)",
+        "kernel": what + " (v_mfma_f32_16x16x32_f16 on fp32 operands cut into two fp16 planes, fp32 accumulate, compensated master sums); "
+                  f"`frac` = {3.0 * tf / MFMA_BF16_PEAK_TFLOPS:.3f} of the matrix pipe by the THREE executed plane products per fp32 product, "
+                  f"{tf / MFMA_BF16_PEAK_TFLOPS:.3f} by SURVEY 8(d)'s n^3 model (`frac_n3_model`)",
         "bound": "mfma", "achieved": round(3.0 * tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(3.0 * tf / MFMA_BF16_PEAK_TFLOPS, 4),
         "flops_model": "3 fp16 plane products x the fp32-equivalent flop (n^3 per solve: Cholesky n^3/3 + inverse 2n^3/3, n padded to 128)",
@@ -417,6 +523,11 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # under an external launcher (the driver's `python -m torch.distributed.run ... bench.py`): this host driver supports dmabuf
+        # IPC only, RCCL's peer mappings fail with hipIpcGetMemHandle otherwise.  Set before torch (and with it HIP) is imported: the
+        # process has not touched the GPU yet, nothing is re-executed.
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import threading
 
     import torch
@@ -478,6 +589,54 @@ def main():
     comm = None
     comm_note = None
     transport = None
+    METRIC = "fit+predict wall-sec (ItemKNN, EASE) on 1M×100K synth; achieved HBM GB/s"
+    state = {"phase": "communicator set-up", "timing": False}
+    # ---- first-contact hardening (N > 1): EVERY way out of this process leaves a status line on rank 0.
+    # A rank != 0 that fails writes a one-line note beside the rendezvous (a file named after MASTER_PORT) before it leaves; rank 0
+    # polls for such notes from a thread and, when one appears while it is itself stuck in a collective the dead rank will never
+    # join, prints the line - status, phase, the rank and its reason - and exits non-zero.  A watchdog covers the set-up and the
+    # self-test too (the timed region has its own).
+    note_base = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"recpack_bench_{os.environ.get('MASTER_PORT', '0')}")
+    if world > 1:
+        try:
+            os.remove(f"{note_base}.rank{rank}")
+        except OSError:
+            pass
+
+    def die(code, status, extra=None):
+        if rank == 0:
+            line = {"metric": METRIC, "n_gpus": world, "status": status, "phase": state["phase"], "transport": transport}
+            line.update(extra or {})
+            print(json.dumps(line), flush=True)
+        else:
+            sys.stderr.write(f"rank {rank}: {status}\n")
+            try:
+                with open(f"{note_base}.rank{rank}", "w") as f:
+                    f.write(status)
+            except OSError:
+                pass
+        os._exit(code)
+
+    if world > 1 and rank == 0:
+        def watch_notes():
+            import glob
+
+            while True:
+                time.sleep(1.0)
+                for fn in glob.glob(note_base + ".rank*"):
+                    try:
+                        msg = open(fn).read().strip()
+                    except OSError:
+                        continue
+                    if msg:
+                        die(4, f"failed on rank {fn.rsplit('rank', 1)[1]} during the {state['phase']}: {msg}")
+
+        threading.Thread(target=watch_notes, daemon=True).start()
+    setup_dog = None
+    if world > 1:
+        setup_dog = threading.Timer(min(args.timeout, 600.0), lambda: die(3, f"timeout: the {state['phase']} did not finish within {min(args.timeout, 600.0):.0f} s"))
+        setup_dog.daemon = True
+        setup_dog.start()
     if world > 1:  # the library's communicator: every collective of the step goes through it
         # The choice of transport is COLLECTIVE: a rank whose RCCL communicator fails to come up must not fall back alone (the
         # others would wait in ncclBroadcast for a rank that talks through torch.distributed): every rank reports, and if any
@@ -498,10 +657,7 @@ def main():
                     comm = None
                 comm_note = f"library RCCL communicator failed on some rank ({err or 'another rank'})"
                 if args.ease_transport == "rccl":
-                    if rank == 0:
-                        print(json.dumps({"metric": "fit+predict wall-sec (ItemKNN, EASE) on 1M×100K synth; achieved HBM GB/s", "n_gpus": world,
-                                          "status": "failed: --ease-transport rccl was asked for and " + comm_note, "transport": "none"}), flush=True)
-                    os._exit(5)
+                    die(5, "failed: --ease-transport rccl was asked for and " + comm_note, {"transport": "none"})
                 want = "torch"
         if comm is None:
             comm = rdist.make_comm(ctx, device, transport="torch")
@@ -514,12 +670,10 @@ def main():
     if world > 1 or args.selftest:
         st_comm = comm if comm is not None else rdist.make_comm(ctx, device, transport="rccl")
 
+        state["phase"] = "transport self-test"
+
         def hang(name):
-            if rank == 0:
-                print(json.dumps({"metric": "fit+predict wall-sec (ItemKNN, EASE) on 1M×100K synth; achieved HBM GB/s", "n_gpus": world,
-                                  "status": f"failed: transport self-test: {name} did not complete within 30 s", "transport": transport,
-                                  "transport_selftest": {"ok": False, "hung": name}}), flush=True)
-            os._exit(6)
+            die(6, f"failed: transport self-test: {name} did not complete within 30 s", {"transport_selftest": {"ok": False, "hung": name}})
 
         def run_selftest():
             res = st_comm.selftest(words=1 << 18, watchdog_s=30.0, on_hang=hang)
@@ -543,15 +697,15 @@ def main():
         if comm is None:
             st_comm.close()
         if not selftest.get("ok_all_ranks", selftest["ok"]):
-            if rank == 0:
-                print(json.dumps({"metric": "fit+predict wall-sec (ItemKNN, EASE) on 1M×100K synth; achieved HBM GB/s", "n_gpus": world,
-                                  "status": "failed: transport self-test: " + ", ".join(f"{k}: {v['mismatches']} wrong words" for k, v in selftest["ops"].items() if v["mismatches"]),
-                                  "transport": transport, "transport_selftest": selftest}), flush=True)
-            os._exit(6)
+            bad = ", ".join(f"{k}: {v['mismatches']} wrong words" for k, v in selftest["ops"].items() if v["mismatches"]) or \
+                "wrong words on another rank in " + ", ".join(selftest.get("failed_on_some_rank", []))
+            die(6, "failed: transport self-test: " + bad, {"transport_selftest": selftest})
+    if setup_dog is not None:
+        setup_dog.cancel()
 
     keep = {}
     parts = {"itemknn": 0.0, "ease_fit": 0.0, "ease_predict": 0.0}
-    state = {"phase": "warm-up", "timing": False}
+    state["phase"] = "warm-up"
 
     def barrier():
         if world > 1:
@@ -562,12 +716,14 @@ def main():
         keep.clear()  # the step before's models and matrices go back to the context's block cache BEFORE the new ones are asked for
         t0 = time.perf_counter()
         if world > 1:  # K0 with the degree pass sharded by item rows + one all-reduce of the degree vector
+            state["collective"] = "all-reduce of the item degrees (K0, rphip_comm_all_reduce_sum_i32)"
             dX = rdist.csr_for_shard(ctx, indptr_t, indices_t, (U, I), row_parts[rank], device, comm=comm)
         else:
             dX = _lib.DeviceCSR.from_device(ctx, indptr_t, indices_t, (U, I))  # K0
         if world == 1:
             model = _lib.itemknn_fit(ctx, dX, args.K)  # K1-K3
         else:
+            state["collective"] = "all-gather of the neighbour lists (rphip_itemknn_gather)"
             model = rdist.fit_itemknn_sharded(ctx, dX, args.K, row_parts, device, comm=comm)  # K1-K3 + all-gather
         _lib.predict_topk_dev(ctx, model, dX, Kp, out_idx, out_val, out_nnz, user_begin=ub, user_end=ue)  # K8
         keep["model"], keep["dX"] = model, dX
@@ -582,6 +738,7 @@ def main():
             _lib.predict_topk_dev(ctx, em, dX, Kp, e_idx, e_val, e_nnz)  # K9
         else:
             dXe = _lib.DeviceCSR.from_device(ctx, indptr_t, indices_t, (U, I))  # (the ItemKNN shard holds its own rows of X^T only)
+            state["collective"] = "distributed EASE solve (rphip_ease_fit_dist: pivot broadcasts, panel exchange)"
             em, _ = rdist.ease_fit_sharded(ctx, dXe, args.l2, 0.0, device, comm=comm)
             torch.cuda.synchronize()
             t2 = time.perf_counter()
@@ -602,7 +759,9 @@ def main():
             if owner_ok:
                 rows8 = None
                 try:
+                    state["collective"] = "all-gather of the int8 rows (rphip_ease_model_allgather_i8)"
                     rows8 = rdist.ease_gather_rows_i8(ctx, em, I, comm)
+                    state["collective"] = "owner-route predict (rphip_predict_topk_owner: candidate all-gather, part exchange)"
                     _lib.predict_topk_owner(ctx, comm, em, rows8, dXe, [p[0] for p in user_parts] + [user_parts[-1][1]], Kp, out_idx, out_val, out_nnz)
                     keep["ease_rows8"] = rows8
                     keep["ease_predict_route"] = "int8 rows all-gathered, users sharded, exact sums by the columns' owners"
@@ -617,6 +776,7 @@ def main():
                 pass
             elif rdist.ease_gather_fits(I, _lib.ease_fit_dist_stats(ctx)["panel"], info["hbm_bytes"], world):
                 try:
+                    state["collective"] = "all-gather of the model's panels (rphip_ease_model_allgather)"
                     full = rdist.ease_gather_model(ctx, em, I, comm)
                 except _lib.RecpackHipError as e:  # (the ranks agree on their allocations: everybody lands here or nobody)
                     if e.code != _lib.RPHIP_ENOMEM:
@@ -628,6 +788,7 @@ def main():
                 keep["ease_full"] = full
                 keep["ease_predict_route"] = "panels all-gathered, users sharded"
             else:
+                state["collective"] = "column-sharded predict (rphip_predict_topk_dist: list exchange)"
                 rdist.predict_topk_sharded(ctx, em, dXe, Kp, device, exclude_history=False, comm=comm)
                 keep["ease_predict_route"] = "columns sharded, lists exchanged and merged"
             keep["dXe"] = dXe
@@ -639,13 +800,11 @@ def main():
             parts["ease_predict"] += t3 - t2
         keep["ease_model"] = em
 
-    result = {"metric": "fit+predict wall-sec (ItemKNN, EASE) on 1M×100K synth; achieved HBM GB/s", "status": "starting", "n_gpus": world}
+    result = {"metric": METRIC, "status": "starting", "n_gpus": world}
 
     def give_up():  # every rank has the same timer: a hung collective or an overrun costs the run, and says so
-        if rank == 0:
-            result["status"] = f"timeout: the {state['phase']} did not finish within {args.timeout:.0f} s (--timeout)"
-            print(json.dumps(result), flush=True)
-        os._exit(3)
+        die(3, f"timeout: the {state['phase']} did not finish within {args.timeout:.0f} s (--timeout)" +
+            (f"; last collective entered: {state.get('collective')}" if state.get("collective") else ""))
 
     dog = threading.Timer(args.timeout, give_up)
     dog.daemon = True
@@ -678,12 +837,8 @@ def main():
         state["timing"] = False
     except Exception as e:  # noqa: BLE001 - the other ranks may be stuck in a collective this rank left: report and leave, no barrier
         dog.cancel()
-        if rank == 0:
-            result["status"] = f"failed in the {state['phase']}: {type(e).__name__}: {e}"
-            print(json.dumps(result), flush=True)
-        else:
-            sys.stderr.write(f"rank {rank}: {type(e).__name__}: {e}\n")
-        os._exit(4)
+        die(4, f"failed in the {state['phase']}" + (f" (last collective entered: {state.get('collective')})" if state.get("collective") else "") +
+            f": {type(e).__name__}: {e}")
     dog.cancel()
     if world > 1:
         t = torch.tensor([elapsed, parts["itemknn"], parts["ease_fit"], parts["ease_predict"]], dtype=torch.float64, device=device)
@@ -729,6 +884,14 @@ def main():
         spgemm_bytes = 4.0 * p_rank + other
         phases = {k: round(v["ms"] / args.steps, 4) for k, v in tm.items() if v["launches"]}
         traffic, traffic_note = pmc_traffic(args.config, dom, world)
+        # (ii) of SURVEY.md 8(d)'s three SpGEMM numbers: the bytes the PMC pass saw for every kernel of the K1-K3 group (per launch),
+        # over the group's time in THIS run
+        sp_traffic = {}
+        for kname in ("k_itemknn_fit<false,1024,16>", "k_itemknn_fit<false,256,8>", "k_itemknn_fit<true,1024,32>", "k_itemknn_merge_wave", "k_itemknn_merge("):
+            tb, _ = pmc_traffic(args.config, kname, world)
+            if tb:
+                sp_traffic[kname.rstrip("(")] = tb
+        sp_traffic_sum = sum(sp_traffic.values()) if sp_traffic else None
         result.update({
             "value": round(sec_per_step, 6),
             "unit": "s",
@@ -780,7 +943,9 @@ def main():
                 "avg_launch_ms": round(avg_ms, 4),
                 "legs": {k: {"what": leg_what[k], "avg_launch_ms": round(v[0], 4), "algorithmic_bytes": v[1],
                              "GBps": round(v[1] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None,
-                             "frac": round(v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v[0] > 0 else None} for k, v in legs.items()},
+                             "frac": round(v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v[0] > 0 else None,
+                             "traffic": sp_traffic.get(k) if k in sp_traffic else (traffic if k == dom else None),
+                             "traffic_over_algorithmic": round(sp_traffic[k] / v[1], 3) if k in sp_traffic and v[1] > 0 else None} for k, v in legs.items()},
                 # the three numbers of the SpGEMM - (i) the 4*P model above, (ii) bytes the PMC
                 # counters saw / time, (iii) accumulator updates per second against the LDS-atomic peak measured with
                 # tools/lds_atomic_bench.hip on MI355X (u32 adds, no return: 4.8 per clock per CU, 2.7e12/s chip-wide)
@@ -790,7 +955,12 @@ def main():
                                         "frac": round(p_rank / (spgemm_ms * 1e-3) / LDS_ATOMIC_PEAK, 4) if spgemm_ms > 0 else None},
                 "spgemm_all_kernels": {"ms": round(spgemm_ms, 4), "algorithmic_bytes": spgemm_bytes,
                                        "GBps": round(spgemm_bytes / (spgemm_ms * 1e-3) / 1e9, 1) if spgemm_ms > 0 else None,
-                                       "frac": round(spgemm_bytes / (spgemm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if spgemm_ms > 0 else None},
+                                       "frac": round(spgemm_bytes / (spgemm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if spgemm_ms > 0 else None,
+                                       # (ii): fabric bytes of the committed PMC pass (2 x FETCH_SIZE + WRITE_SIZE per launch, every kernel
+                                       # of the group) over this run's time; (iii) is `accumulator_updates` above
+                                       "traffic": sp_traffic_sum, "traffic_per_kernel": sp_traffic or None,
+                                       "measured_fabric_GBps": round(sp_traffic_sum / (spgemm_ms * 1e-3) / 1e9, 1) if sp_traffic_sum and spgemm_ms > 0 else None,
+                                       "traffic_over_algorithmic": round(sp_traffic_sum / spgemm_bytes, 3) if sp_traffic_sum else None},
             },
         })
         result["cold_first_step_s"] = round(cold_s, 4) if cold_s is not None else None  # (needs --warmup >= 1; `value` is the warm rate)
@@ -826,7 +996,18 @@ def main():
                 "port": port,  # the oracle's own vectorised route (what the parity tests run)
                 "host_cpus": os.cpu_count(),
             }
+        if world == 1 and args.parity_check:
+            try:
+                result["parity"] = parity_verdict(args, ctx, device, indptr_t, indices_t, (U, I), keep["model"], keep.get("ease_model") if ease_on else None)
+            except Exception as e:  # noqa: BLE001 - the checker must not cost the measurement: the line says what happened
+                result["parity"] = {"error": f"{type(e).__name__}: {e}"}
+            if not (result["parity"].get("itemknn_ok", False) and result["parity"].get("ease_ok", True)):
+                result["status"] = "parity check failed" if "error" not in result["parity"] else "parity check did not run: " + result["parity"]["error"]
         keep.clear()
+        if world == 1 and args.itemknn_config.lower() != "none":
+            torch.cuda.empty_cache()
+            for cfg in (c.strip().upper() for c in args.itemknn_config.split(",")):
+                result[f"itemknn_{cfg.lower()}"] = itemknn_leg(args, ctx, device, Kp, cfg, 3)
         if world == 1 and args.ease_config.lower() != "none":
             del out_idx, out_val, out_nnz, e_idx, e_val, e_nnz
             torch.cuda.empty_cache()  # (no ctx.trim(): the legs' smaller matrices are cut from the blocks the step left in the cache)

@@ -136,6 +136,10 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = NTHR / 64;
   constexpr bool BYTES = (CB == 8), PAIRS = (CB == 16);
+  // selection straight from the tile (rp_select_tile: sampled threshold, no candidate list): the heavy rows' u16 tiles and - round 6 -
+  // the finalize launch, whose rows (more than 65 535 users) have tiles without a zero: the list-driven selection evaluated every
+  // one of 25 600 keys once per radix level, 0.47 ms for a launch of a few dozen tasks (half of K1-K3 at 100K x 20K)
+  constexpr bool TSEL = PAIRS || (FINALIZE && CB == 32);
   constexpr int SEG = BYTES ? RP_LIGHT_SEG : 0;
   constexpr int SBITS = BYTES ? RP_LIGHT_BITS : 11;  // radix digit of the selection (light rows: 10 -> 4 KB histogram)
   uint32_t* acc = reinterpret_cast<uint32_t*>(smem);
@@ -144,7 +148,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
   char* sel_base = smem + (((size_t)acc_words * 4 + 15) & ~(size_t)15);
   rp_tsel_smem tsel = rp_tsel_carve(sel_base, W);
   rp_select_smem sel;
-  if constexpr (PAIRS) {  // no list: only the histogram (scratch of the accumulate phase) and misc are shared
+  if constexpr (TSEL) {  // no list: only the histogram (scratch of the accumulate phase) and misc are shared
     sel.hist = tsel.hist;
     sel.skey = tsel.skey;
     sel.scol = tsel.scol;
@@ -461,10 +465,34 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
         continue;
       }
     } else if constexpr (CB == 32) {
-      for (int w = tid; w < W; w += NTHR) {
-        uint32_t sum = 0;
-        for (int sl = tk.p_begin; sl < tk.p_end; ++sl) sum += P.part[(int64_t)sl * W + w];
-        acc[w] = sum;
+      // (round 6) the sum of a row's partial tiles: ONE workgroup reads slices x W words, and with one load per iteration in flight
+      // this loop was the whole 0.46 ms of the finalize launch (35 slices of the most popular row at 1M x 100K: 875 dependent round
+      // trips per thread).  Eight slices of two columns per thread are requested before the first is added.
+      const uint32_t* __restrict__ pp = P.part;
+      for (int w = tid; w < W; w += 2 * NTHR) {
+        const int w2 = w + NTHR;
+        const bool two = w2 < W;
+        uint32_t s0 = 0, s1 = 0;
+        int sl = tk.p_begin;
+        for (; sl + 8 <= tk.p_end; sl += 8) {
+          uint32_t v0[8], v1[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            v0[q] = pp[(int64_t)(sl + q) * W + w];
+            v1[q] = two ? pp[(int64_t)(sl + q) * W + w2] : 0u;
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            s0 += v0[q];
+            s1 += v1[q];
+          }
+        }
+        for (; sl < tk.p_end; ++sl) {
+          s0 += pp[(int64_t)sl * W + w];
+          if (two) s1 += pp[(int64_t)sl * W + w2];
+        }
+        acc[w] = s0;
+        if (two) acc[w2] = s1;
       }
       __syncthreads();
     }
@@ -492,7 +520,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
       const int handed = *blk_cnt;  // (the barrier after the accumulate phase has passed)
       kp = rp_select_topk<NTHR, rp_dense_src<CB>, true, SBITS, 2>(src, n_cols, P.K, sel, SEG, lcnt, handed > NBLK, min(handed, NBLK));
       if (tid == 0) *blk_cnt = 0;  // every wave has read it before the barriers inside the selection
-    } else if constexpr (PAIRS) {
+    } else if constexpr (TSEL) {
       kp = rp_select_tile<NTHR>(src, n_cols, P.K, tsel);
     } else {
       kp = rp_select_topk<NTHR>(src, n_cols, P.K, sel, SEG);
@@ -523,7 +551,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
       };
       if constexpr (BYTES)
         rp_select_emit_bitmap<NTHR>(n_cols, sel, emit);
-      else if constexpr (PAIRS)
+      else if constexpr (TSEL)
         rp_select_tile_emit<NTHR>(n_cols, tsel, emit);
       else
         rp_select_emit<NTHR>(n_cols, sel, emit, SEG);
@@ -536,7 +564,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
       };
       if constexpr (BYTES) {
         if (!(RP_FIT_ABL & 8)) rp_select_emit_bitmap<NTHR>(n_cols, sel, emit);  // (8: diagnostic, no emission)
-      } else if constexpr (PAIRS)
+      } else if constexpr (TSEL)
         rp_select_tile_emit<NTHR>(n_cols, tsel, emit);
       else
         rp_select_emit<NTHR>(n_cols, sel, emit, SEG);
@@ -544,8 +572,8 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
     }
     // clear only what was touched: the candidates (every wave its own list segment) and the diagonal; without a list
     // the whole tile.  Byte tiles: the emit above still reads neighbouring bytes of a word, so clear after a barrier.
-    if (BYTES || PAIRS) __syncthreads();
-    if constexpr (PAIRS) {
+    if (BYTES || TSEL) __syncthreads();
+    if constexpr (TSEL) {
       for (int w = tid; w < acc_words; w += NTHR) acc[w] = 0u;
     } else {
       if (BYTES && (RP_FIT_ABL & 16)) {  // (16: diagnostic, dense clear instead of the list-driven one)
@@ -783,12 +811,27 @@ __global__ void k_plan_offsets(int32_t* __restrict__ bucket_cnt) {
   }
 }
 
+// (round 6: one returning global atomic per ROW on a few dozen bucket words - most rows share the buckets of the small degrees - took
+// 0.21 ms at 100 000 rows, two thirds of the whole plan; now the rank inside the block by LDS atomics and one global atomic per
+// (block, bucket))
 __global__ void k_plan_scatter(const int32_t* __restrict__ deg, int row_begin, int n_rows, int32_t* __restrict__ bucket_off,
                                int32_t* __restrict__ order) {
-  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += gridDim.x * blockDim.x) {
-    const int row = row_begin + r;
-    const int pos = atomicAdd(&bucket_off[rp_deg_bucket(deg[row])], 1);
-    order[pos] = row;
+  __shared__ int h[PLAN_BUCKETS];
+  for (int r0 = blockIdx.x * blockDim.x; r0 < n_rows; r0 += gridDim.x * blockDim.x) {
+    for (int i = threadIdx.x; i < PLAN_BUCKETS; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const int r = r0 + threadIdx.x;
+    int b = 0, rk = 0;
+    if (r < n_rows) {
+      b = rp_deg_bucket(deg[row_begin + r]);
+      rk = atomicAdd(&h[b], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PLAN_BUCKETS; i += blockDim.x)
+      if (h[i]) h[i] = atomicAdd(&bucket_off[i], h[i]);
+    __syncthreads();
+    if (r < n_rows) order[h[b] + rk] = row_begin + r;
+    __syncthreads();
   }
 }
 
@@ -951,7 +994,9 @@ extern "C" int rphip_model_info(const rphip_model* m, int32_t* kind, int64_t* n_
   return RPHIP_OK;
 }
 
-static size_t rp_fit_lds_bytes(int tile_w) { return (size_t)tile_w * 4 + rp_select_smem_bytes(tile_w); }
+// (the u32 instances: the list-driven selection of the dense-capable instance, or the tile selection of the finalize launch, whose
+// fixed parts - histogram and collected list - are the larger ones on small tiles)
+static size_t rp_fit_lds_bytes(int tile_w) { return (size_t)tile_w * 4 + std::max(rp_select_smem_bytes(tile_w), rp_tsel_smem_bytes(tile_w) + 16); }
 
 // rows [row_begin, row_begin + n_rows) in descending degree order (coarse buckets): `bucket` = PLAN_BUCKETS ints of scratch
 int rp_plan_row_order(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int n_rows, int32_t* bucket, int32_t* order) {

@@ -15,69 +15,7 @@ for sampled columns the float64 answer is available without the inverse:
 import numpy as np
 
 
-class _Ops:
-    """X v and X^T w for a binary CSR held as torch tensors, float64.  Preferred: two sparse-CSR x dense products (X and an
-    explicitly built X^T, hipSPARSE on the GPU box); fallback where the sparse product is unavailable: gathers + index_add
-    over chunks of ~2^24 entries."""
-
-    def __init__(self, indptr_t, indices_t, shape, chunk_nnz=1 << 24, use_sparse=True):
-        import torch
-
-        self.torch = torch
-        self.ip = indptr_t.to(torch.int64)
-        self.ix = indices_t.to(torch.int64)
-        self.U, self.I = shape
-        dev = self.ix.device
-        cnt = self.ip[1:] - self.ip[:-1]
-        self.deg = torch.bincount(self.ix, minlength=self.I).to(torch.float64)
-        self.A = self.At = None
-        if use_sparse:
-            try:
-                ones = torch.ones(self.ix.numel(), dtype=torch.float64, device=dev)
-                rows = torch.repeat_interleave(torch.arange(self.U, device=dev), cnt)
-                perm = torch.argsort(self.ix, stable=True)
-                tptr = torch.zeros(self.I + 1, dtype=torch.int64, device=dev)
-                tptr[1:] = torch.cumsum(self.deg.to(torch.int64), 0)
-                A = torch.sparse_csr_tensor(self.ip, self.ix, ones, size=(self.U, self.I))
-                At = torch.sparse_csr_tensor(tptr, rows[perm], ones, size=(self.I, self.U))
-                probe = torch.ones((self.I, 2), dtype=torch.float64, device=dev)
-                got = At @ (A @ probe)
-                assert torch.isfinite(got).all()
-                self.A, self.At = A, At
-                del rows, perm, probe, got
-            except Exception as e:  # noqa: BLE001 - any failure of the sparse path: use the plain one
-                print(f"ease_cg: sparse CSR products unavailable ({type(e).__name__}: {e}); using gathers + index_add")
-                self.A = self.At = None
-        if self.A is None:
-            ipc = self.ip.cpu().numpy()
-            cuts = [0]
-            while cuts[-1] < self.U:
-                nxt = int(np.searchsorted(ipc, ipc[cuts[-1]] + chunk_nnz, side="right")) - 1
-                cuts.append(min(self.U, max(nxt, cuts[-1] + 1)))
-            self.cuts = cuts
-            self.ipc = ipc
-
-    def rows_of(self, u0, u1):
-        torch = self.torch
-        cnt = (self.ip[u0 + 1:u1 + 1] - self.ip[u0:u1])
-        return torch.repeat_interleave(torch.arange(u1 - u0, device=self.ix.device), cnt)
-
-    def gram_apply(self, V):
-        """(X^T X) V in float64, V [I, k]."""
-        torch = self.torch
-        if self.A is not None:
-            return self.At @ (self.A @ V)
-        out = torch.zeros_like(V)
-        for u0, u1 in zip(self.cuts[:-1], self.cuts[1:]):
-            a, b = int(self.ipc[u0]), int(self.ipc[u1])
-            if a == b:
-                continue
-            cols = self.ix[a:b]
-            rows = self.rows_of(u0, u1)
-            W = torch.zeros((u1 - u0, V.shape[1]), dtype=V.dtype, device=V.device)
-            W.index_add_(0, rows, V[cols])  # X v on this user chunk
-            out.index_add_(0, cols, W[rows])  # X^T (.)
-        return out
+from oracle.ease_probe import GramOps as _Ops  # noqa: E402  (X v and X^T w in float64: shared with the whole-matrix probe)
 
 
 def solve_columns(indptr_t, indices_t, shape, l2, cols, tol=1e-13, max_iter=3000, log=None):

@@ -187,6 +187,18 @@ def ease_full_size(hip, cfg, n_cols, n_users, l2=200.0, alpha=0.0, n_route_users
         np.testing.assert_allclose(pv[r_, :n], sc[got], rtol=2e-5, atol=2e-6 * np.abs(sc).max())
         t = np.sort(sc[sc != 0])[::-1][n - 1]
         assert (sc[got] >= t - 2e-6 * np.abs(sc).max()).all()
+    # the WHOLE matrix: A (I - B W^-1) is diagonal, so two random probes must give the same 1 / P_jj for
+    # every item - every entry of B takes part (oracle/ease_probe.py); the sampled columns above cannot see a wrong tile elsewhere
+    from oracle.ease_probe import ease_probe
+    from recpack_amd.synth import config_csr
+
+    ip, ix = config_csr(cfg, device=B.device)
+    pr = ease_probe(ip, ix, (U, I), B, l2, alpha)
+    print("EASE whole-matrix probe", cfg, l2, alpha, pr)
+    del ip, ix
+    assert pr["diag_max"] == 0.0 and pr["bounds_violation"] <= 1e-6, pr
+    assert pr["probe_rel"] <= EASE_TOL, pr
+    assert pr["items_checked"] >= 0.99 * I, pr
     del B
     if n_route_users:
         routes_agree_for_all_users(hip, m, dX, n_route_users, Kp)

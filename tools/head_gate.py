@@ -25,14 +25,27 @@ lens = (ip[1:] - ip[:-1]).long()
 rows = torch.repeat_interleave(torch.arange(U, device=dev), lens)
 deg = torch.bincount(ix.long(), minlength=I)
 order = torch.argsort(-deg, stable=True)
-rank = torch.empty_like(order)
-rank[order] = torch.arange(I, device=dev)
-ixr = rank[ix.long()]
-key = rows * I + ixr
-key, _ = torch.sort(key)
-ixr = (key % I).to(torch.int32)
-del key
 P = float((lens * lens).sum())
+
+
+def relabel(H):
+    """H = 0: ids = popularity rank (every tile sorted by popularity: tile 0 holds 85 % of the entries - the heavy kernel's atomics then
+    meet in one tile and it slows down by 40 %, a confound).  H > 0: only the H most popular items move (to ids [0, H), by popularity);
+    the others keep their original relative order behind them, so the tiles stay the random mix they are in the product path."""
+    rank = torch.empty_like(order)
+    if H == 0:
+        rank[order] = torch.arange(I, device=dev)
+    else:
+        is_head = torch.zeros(I, dtype=torch.bool, device=dev)
+        is_head[order[:H]] = True
+        rank[order[:H]] = torch.arange(H, device=dev)
+        tail_ids = torch.nonzero(~is_head).flatten()  # ascending original ids
+        rank[tail_ids] = H + torch.arange(I - H, device=dev)
+    ixr_ = rank[ix.long()]
+    key = rows * I + ixr_
+    key, _ = torch.sort(key)
+    return (key % I).to(torch.int32)
+
 
 
 def run(tag, ip_, ix_, fit_rows=None):
@@ -40,7 +53,7 @@ def run(tag, ip_, ix_, fit_rows=None):
     for it in range(3):
         ctx.reset_timings()
         dX = _lib.DeviceCSR.from_device(ctx, ip_, ix_, (U, I), fit_rows=fit_rows)
-        m = _lib.itemknn_fit(ctx, dX, 200)
+        m = _lib.itemknn_fit(ctx, dX, 200) if fit_rows is None else _lib.itemknn_fit(ctx, dX, 200, fit_rows[0], fit_rows[1])
         ctx.sync()
         tm = ctx.timings()
         cur = [tm[k]["ms"] for k in ("gram_topk", "gram_topk_wave", "topk_merge", "gram_finalize")]
@@ -53,8 +66,10 @@ def run(tag, ip_, ix_, fit_rows=None):
 
 
 run("full (original labels)", ip, ix)
-run("full (popularity labels)", ip, ixr)
-for H in (256, 1024, 4096):
+run("full (popularity labels)", ip, relabel(0))
+for H in (256, 1024, 2048, 4096, 8192):
+    ixr = relabel(H)
+    run(f"  full (head of {H} moved to the front)", ip, ixr)
     hl = torch.zeros(U, dtype=torch.int64, device=dev).scatter_add_(0, rows, (ixr < H).long())
     print(f"H = {H}: head entries {float(hl.sum()) / ix.numel():.3f} of nnz; head x head products {float((hl * hl).sum()) / P:.3f} P, head x tail "
           f"{float((hl * (lens - hl)).sum()) / P:.3f} P (each way), tail x tail {float(((lens - hl) ** 2).sum()) / P:.3f} P", flush=True)

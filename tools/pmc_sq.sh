@@ -2,7 +2,7 @@
 # SQ counters of one kernel family: tools/pmc_sq.sh <kernel-substring> [config]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 K=${1:-k_predict_wave}; C=${2:-C4}
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS --output-format csv -d gpurun_out/pmc_sq -- python3 bench.py --config $C --steps 1 --warmup 1 --cpu-baseline-seconds 0 --no-ease-in-step --ease-config none > gpurun_out/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS --output-format csv -d gpurun_out/pmc_sq -- python3 bench.py --config $C --steps 1 --warmup 1 --cpu-baseline-seconds 0 --no-ease-in-step --ease-config none --tars-config none --itemknn-config none --no-parity-check > gpurun_out/pmc_sq.log 2>&1
 python3 - "$K" <<'PY'
 import csv, glob, collections, sys
 k = sys.argv[1]

@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 C=${1:-C4}
 pass() {
-  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_ta -- python3 bench.py --config $C --steps 1 --warmup 1 --cpu-baseline-seconds 0 --no-ease-in-step --ease-config none --tars-config none > gpurun_out/pmc_ta.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_ta -- python3 bench.py --config $C --steps 1 --warmup 1 --cpu-baseline-seconds 0 --no-ease-in-step --ease-config none --tars-config none --itemknn-config none --no-parity-check > gpurun_out/pmc_ta.log 2>&1
   python3 - <<'PY'
 import csv, glob, collections
 acc = collections.defaultdict(lambda: [0.0, 0])

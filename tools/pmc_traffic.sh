@@ -34,5 +34,5 @@ json.dump(out, open(f"gpurun_out/pmc_traffic_{tag}.json", "w"), indent=1)
 PY
   rm -rf gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE  # (raw CSVs: tens of MB; gpurun copies back <= 64 MiB)
 }
-run c4 python3 bench.py --config C4 --steps 2 --warmup 1 --cpu-baseline-seconds 0 --no-ease-in-step --ease-config none --tars-config none
-run ease_c3 python3 bench.py --config C3 --steps 1 --warmup 1 --cpu-baseline-seconds 0 --ease-config none --tars-config none
+run c4 python3 bench.py --config C4 --steps 2 --warmup 1 --cpu-baseline-seconds 0 --no-ease-in-step --ease-config none --tars-config none --itemknn-config none --no-parity-check
+run ease_c3 python3 bench.py --config C3 --steps 1 --warmup 1 --cpu-baseline-seconds 0 --ease-config none --tars-config none --itemknn-config none --no-parity-check
