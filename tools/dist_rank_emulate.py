@@ -41,7 +41,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--world", type=int, default=8)
-    ap.add_argument("--ranks", default="0,7")
+    ap.add_argument("--ranks", default="0,7", help="comma separated ranks to emulate ('' = none: the single-GPU step alone)")
     ap.add_argument("--config", default="C4")
     ap.add_argument("--gbps", type=float, default=100.0)
     ap.add_argument("--latency-us", type=float, default=10.0)
@@ -54,6 +54,10 @@ def main():
     ap.add_argument("--predict-route", choices=("owner", "gather"), default="owner",
                     help="EASE predict of a rank: owner = int8 rows gathered, exact sums by the columns' owners (rphip_predict_topk_owner); "
                          "gather = the full model gathered in two phases (round 5's first route)")
+    ap.add_argument("--owner-on-emulated", action="store_true",
+                    help="with --skip-single (sizes whose single-GPU B does not fit beside a rank, e.g. C5's 160 GB): run the owner route on the "
+                         "EMULATED fit's own panels and int8 rows - noise, on which no list can be proven, so EVERY user takes the exact pass: "
+                         "the route's worst case in memory and time (an upper bound of the rank's predict)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
 
@@ -70,9 +74,14 @@ def main():
     W = args.world
     Kp = min(args.Kp, I)
 
+    peak = {"used": 0}
+
     def sync():
         ctx.sync()
         torch.cuda.synchronize()
+        free_b, total_b = torch.cuda.mem_get_info(dev)  # (device-wide: the library's own allocations count)
+        peak["used"] = max(peak["used"], total_b - free_b)
+        peak["total"] = total_b
 
     # the static plan of bench.py: cost-balanced item-row ranges, user ranges
     dX0 = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
@@ -113,6 +122,7 @@ def main():
                 del em
             dX.close()
         out["single_gpu"] = {k: round(v, 5) for k, v in best.items()}
+        out["single_gpu"]["hbm_used_peak_gb"] = round(peak["used"] / 1e9, 2)
         del oi, ov, on
         ptr, n_it, ld = em.dense_device_ptr()
         Breal = torch.as_tensor(rdist._DevPtr(ptr, (n_it, ld), "<f4", em), device=dev)  # (the single-GPU model stays alive: its B is the emulated ranks' "gathered" B)
@@ -126,7 +136,7 @@ def main():
         sync()
 
     # ---- one rank at a time
-    for r in [int(x) for x in args.ranks.split(",")]:
+    for r in [int(x) for x in args.ranks.split(",") if x.strip() != ""]:
         comm = _lib.Comm.loopback(ctx, W, r, args.gbps, args.latency_us)
         rb, re_ = row_parts[r]
         ub, ue = user_parts[r]
@@ -174,7 +184,16 @@ def main():
             # matrix and ADOPTS the pending gather: its first pass runs beside the f32 strips, its rescoring waits for them - what the
             # rank's own predict on the gathered model does.
             standin_s = 0.0
-            if args.predict_route == "owner" and not args.skip_single:
+            if args.predict_route == "owner" and args.skip_single and args.owner_on_emulated:
+                efull = rdist.ease_gather_rows_i8(ctx, em_r, I, comm)
+                sync()
+                t_g = time.perf_counter()
+                bounds = [p[0] for p in user_parts] + [user_parts[-1][1]]
+                _lib.predict_topk_owner(ctx, comm, em_r, efull, dXe, bounds, Kp, oi, ov, on)
+                sync()
+                so = _lib.predict_owner_stats(ctx)
+                standin_s = 0.0
+            elif args.predict_route == "owner" and not args.skip_single:
                 # the owner route: the int8 rows of the emulated fit's panels are gathered (timed: quantisation, all-gathers, unpacking),
                 # then the route runs on the REAL matrix - its int8 rows (pm) for the first pass, the rank's share of the real columns
                 # (a contiguous eighth: the same number of columns as its block-cyclic panels) for the exact sums; the library's stand-in
@@ -209,6 +228,8 @@ def main():
             if so is not None:
                 cur["ease_predict_unproven_users"] = so["unproven_here"]
                 cur["ease_predict_standin_subtracted_s"] = standin_s
+            cur["hbm_used_peak_gb"] = round(peak["used"] / 1e9, 2)
+            cur["hbm_total_gb"] = round(peak.get("total", 0) / 1e9, 2)
             if best is None or cur["step_s"] < best["step_s"]:
                 best = cur
             del local, full
