@@ -6,18 +6,138 @@
 // item.  Pairs may come in any order and may repeat.
 //
 //   k_coo_keys      key = uid * n_items + iid (64 bit), range check
-//   radix sort      rocPRIM (a plain library sort; not part of the hot path), only the bits the keys can have
+//   radix sort      own LSD radix sort (round 6: the last library kernel of the tree is gone), 4-bit digits over the bits the keys can
+//                   have: per pass k_coo_radix<false> (per-block digit counts, digit-major), one exclusive scan, k_coo_radix<true>
+//                   (stable rank of every key inside its block from per-thread counter columns in LDS, the block's keys laid out
+//                   digit by digit in LDS and copied out in runs)
 //   k_coo_heads     flag the first occurrence of every key; exclusive scan of the flags = position in the CSR
 //   k_coo_emit      indices[pos] = key % n_items, row pointer entries of the users that start (gaps = empty users)
 // then K0 (rp_csr_prepare) as for any other input.
 #include <cstring>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 
 #include "rp_common.h"
+#include "rp_wave.h"
+
+// ---- LSD radix sort of 64-bit keys, one 4-bit digit per pass ---------------------------------------------------------------------
+// A block owns RS_TILE consecutive keys; thread t owns the RS_E consecutive keys [t * RS_E, (t + 1) * RS_E) of them, so "block,
+// thread, position in the thread's run" is the input order and a rank built in that order is STABLE (an LSD pass must be).
+//   SCATTER = false   counts[d * n_blocks + b] = keys of block b with digit d  (digit-major: ONE exclusive scan of this array gives
+//                     every (digit, block) group its place in the output)
+//   SCATTER = true    the keys come into LDS with coalesced loads; every thread walks its run and numbers each key among the keys of
+//                     the same digit it has seen (its own column of 16 counters: no atomics); a scan over the columns - digit-major,
+//                     thread-minor - turns the numbers into positions inside the block's sorted tile; the tile is laid out in LDS
+//                     and copied out: consecutive threads write consecutive keys of a digit's run
+constexpr int RS_T = 256, RS_E = 16, RS_TILE = RS_T * RS_E, RS_BITS = 4, RS_BINS = 1 << RS_BITS;
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(RS_T) k_coo_radix(const unsigned long long* __restrict__ in, unsigned long long* __restrict__ out, long long n, int shift,
+                                                    int32_t* __restrict__ counts, const int32_t* __restrict__ offsets, int n_blocks) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const long long k0 = (long long)b * RS_TILE;
+  const int n_here = (int)min((long long)RS_TILE, n - k0);
+  if constexpr (!SCATTER) {
+    __shared__ int hist[RS_BINS];
+    if (tid < RS_BINS) hist[tid] = 0;
+    __syncthreads();
+    int c[RS_BINS];
+#pragma unroll
+    for (int d = 0; d < RS_BINS; ++d) c[d] = 0;
+    for (int i = tid; i < n_here; i += RS_T) {
+      const int dg = (int)(in[k0 + i] >> shift) & (RS_BINS - 1);
+#pragma unroll
+      for (int d = 0; d < RS_BINS; ++d) c[d] += (dg == d) ? 1 : 0;
+    }
+#pragma unroll
+    for (int d = 0; d < RS_BINS; ++d) {
+      int v = c[d];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0 && v) atomicAdd(&hist[d], v);
+    }
+    __syncthreads();
+    if (tid < RS_BINS) counts[(long long)tid * n_blocks + b] = hist[tid];
+  } else {
+    constexpr int PAD = RS_TILE + RS_TILE / RS_E;  // (a thread's run starts 17 keys after its neighbour's: its LDS reads spread over the banks)
+    __shared__ unsigned long long stage[PAD];
+    __shared__ uint16_t cnt[RS_BINS * RS_T];       // [digit][thread]
+    __shared__ int dstart[RS_BINS + 1], gbase[RS_BINS], wsum[RS_T / 64];
+    for (int i = tid; i < n_here; i += RS_T) stage[i + i / RS_E] = in[k0 + i];
+#pragma unroll
+    for (int d = 0; d < RS_BINS; ++d) cnt[d * RS_T + tid] = 0;
+    if (tid < RS_BINS) gbase[tid] = offsets[(long long)tid * n_blocks + b];
+    __syncthreads();
+    unsigned long long key[RS_E];
+    int rk[RS_E];  // digit | number among the thread's earlier keys of that digit << 8
+#pragma unroll
+    for (int e = 0; e < RS_E; ++e) {
+      const int i = tid * RS_E + e;
+      rk[e] = -1;
+      key[e] = 0ull;
+      if (i < n_here) {
+        key[e] = stage[i + tid];
+        const int dg = (int)(key[e] >> shift) & (RS_BINS - 1);
+        const int c = cnt[dg * RS_T + tid];
+        cnt[dg * RS_T + tid] = (uint16_t)(c + 1);
+        rk[e] = dg | (c << 8);
+      }
+    }
+    __syncthreads();  // (every run has left the stage: it is reused for the sorted tile)
+    // exclusive scan of cnt in memory order: thread q takes the 16 consecutive entries [16 q, 16 q + 16)
+    {
+      int v[RS_E], sum = 0;
+#pragma unroll
+      for (int e = 0; e < RS_E; ++e) {
+        v[e] = cnt[tid * RS_E + e];
+        sum += v[e];
+      }
+      const int inc = rp_wave_incl_scan(sum, lane);
+      if (lane == 63) wsum[wave] = inc;
+      __syncthreads();
+      int run = inc - sum;
+      for (int w = 0; w < wave; ++w) run += wsum[w];
+      if ((tid & (RS_T / RS_BINS - 1)) == 0) dstart[tid / (RS_T / RS_BINS)] = run;  // (entry 16 q is (digit q / 16, thread 0) when q % 16 == 0)
+      if (tid == RS_T - 1) dstart[RS_BINS] = run + sum;
+#pragma unroll
+      for (int e = 0; e < RS_E; ++e) {
+        cnt[tid * RS_E + e] = (uint16_t)run;
+        run += v[e];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < RS_E; ++e)
+      if (rk[e] >= 0) stage[cnt[(rk[e] & 255) * RS_T + tid] + (rk[e] >> 8)] = key[e];
+    __syncthreads();
+    const int total = dstart[RS_BINS];
+    for (int i = tid; i < total; i += RS_T) {
+      const unsigned long long k = stage[i];
+      const int dg = (int)(k >> shift) & (RS_BINS - 1);
+      out[(long long)gbase[dg] + (i - dstart[dg])] = k;
+    }
+  }
+}
+
+// sorts `n` keys held in `a` (scratch `b`, both n keys); returns the buffer that holds the result.  counts / offsets: 16 * n_blocks + 1 ints each
+static int rp_coo_sort(rphip_ctx* ctx, unsigned long long* a, unsigned long long* b, int64_t n, int bits, int32_t* counts, int32_t* offsets,
+                       unsigned long long** sorted) {
+  hipStream_t st = ctx->stream;
+  const int n_blocks = (int)rp_cdiv(n, RS_TILE);
+  unsigned long long *src = a, *dst = b;
+  for (int shift = 0; shift < bits; shift += RS_BITS) {
+    hipLaunchKernelGGL(k_coo_radix<false>, dim3(n_blocks), dim3(RS_T), 0, st, src, dst, (long long)n, shift, counts, offsets, n_blocks);
+    RP_TRY(rp_exclusive_scan_i32(ctx, counts, offsets, (int64_t)RS_BINS * n_blocks));
+    hipLaunchKernelGGL(k_coo_radix<true>, dim3(n_blocks), dim3(RS_T), 0, st, src, dst, (long long)n, shift, counts, offsets, n_blocks);
+    RP_HIP(hipGetLastError());
+    std::swap(src, dst);
+  }
+  *sorted = src;
+  return RPHIP_OK;
+}
 
 __global__ void k_coo_keys(const int64_t* __restrict__ uid, const int64_t* __restrict__ iid, int64_t n, int64_t n_users, int64_t n_items,
                            unsigned long long* __restrict__ key, int32_t* __restrict__ err) {
@@ -84,25 +204,26 @@ static int rp_coo_build(rphip_ctx* ctx, int64_t n_users, int64_t n_items, int64_
     // bits the keys can have
     int bits = 1;
     while (bits < 64 && ((unsigned long long)n_users * (unsigned long long)n_items - 1ull) >> bits) ++bits;
-    size_t tmp_bytes = 0;
-    if (rocprim::radix_sort_keys(nullptr, tmp_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (size_t)n, 0, bits, st) != hipSuccess)
-      return fail(RPHIP_EHIP);
     char* sc = nullptr;
     const size_t kb = ((size_t)n * 8 + 255) & ~(size_t)255, hb = ((size_t)(n + 1) * 4 + 255) & ~(size_t)255;
-    int rc = rp_scratch(ctx, 0, 2 * kb + 2 * hb + tmp_bytes + 512, (void**)&sc);
+    const size_t cb = (((size_t)RS_BINS * (size_t)rp_cdiv(n, RS_TILE) + 1) * 4 + 255) & ~(size_t)255;  // digit counts per block, and their scan
+    int rc = rp_scratch(ctx, 0, 2 * kb + 2 * hb + 2 * cb + 512, (void**)&sc);
     if (rc != RPHIP_OK) return fail(rc);
     unsigned long long* key = (unsigned long long*)sc;
-    unsigned long long* sorted = (unsigned long long*)(sc + kb);
+    unsigned long long* other = (unsigned long long*)(sc + kb);
+    unsigned long long* sorted = nullptr;
     int32_t* head = (int32_t*)(sc + 2 * kb);
     int32_t* pos = (int32_t*)(sc + 2 * kb + hb);
     int32_t* err = (int32_t*)(sc + 2 * kb + 2 * hb);
-    void* tmp = sc + 2 * kb + 2 * hb + 256;
+    int32_t* counts = (int32_t*)(sc + 2 * kb + 2 * hb + 256);
+    int32_t* offsets = (int32_t*)(sc + 2 * kb + 2 * hb + 256 + cb);
     hipEvent_t ev;
     rp_time_begin(ctx, &ev);
     hipMemsetAsync(err, 0, 4, st);
     const int grid = (int)std::min<int64_t>((int64_t)ctx->n_cu * 16, rp_cdiv(n, 256));
     hipLaunchKernelGGL(k_coo_keys, dim3(grid), dim3(256), 0, st, uid_dev, iid_dev, n, n_users, n_items, key, err);
-    if (rocprim::radix_sort_keys(tmp, tmp_bytes, key, sorted, (size_t)n, 0, bits, st) != hipSuccess) return fail(RPHIP_EHIP);
+    rc = rp_coo_sort(ctx, key, other, n, bits, counts, offsets, &sorted);
+    if (rc != RPHIP_OK) return fail(rc);
     hipLaunchKernelGGL(k_coo_heads, dim3(grid), dim3(256), 0, st, sorted, n, head);
     rc = rp_exclusive_scan_i32(ctx, head, pos, n);
     if (rc != RPHIP_OK) return fail(rc);

@@ -554,7 +554,7 @@ def test_csr_from_coo(hip):
 
     _lib, ctx = hip
     rng = np.random.default_rng(4)
-    for (U, I, n) in [(50, 20, 300), (3000, 70000, 200000), (7, 5, 0), (1200, 900, 50000)]:
+    for (U, I, n) in [(50, 20, 300), (3000, 70000, 200000), (7, 5, 0), (1000000, 100000, 3000000), (5, 3, 4097), (1200, 900, 50000)]:
         uid = rng.integers(0, max(1, U - 3), n)  # the last users stay empty
         iid = (rng.zipf(1.3, n) - 1) % I if n else np.zeros(0, dtype=np.int64)
         if n:
