@@ -319,16 +319,16 @@ class ItemKNN(TopKItemSimilarityMatrixAlgorithm):
         self.normalize_sim = normalize_sim
 
     def _fit(self, X: sp.csr_matrix) -> None:
-        # ANY K on one column tile (<= RP_TILE_MAX items; normalize_X: RP_WTILE_MAX, its sums are float64) and K x tiles < 32 768 beyond
-        # (binary: K = 8 191 at 100 000 items, normalize_X: 3 640): the merge of the per-tile lists reads them where they lie
-        # (deviation 5)
+        # ANY K, as the reference (recpack/util.py:63-66, base.py:302-304): one column tile, or K x tiles < 32 768 (the merges that number
+        # their candidates in 16 bits), or - round 6 - anything beyond on the binary fits (per-tile lists merged where they lie by
+        # k_itemknn_merge_big, rows in chunks).  Only normalize_X (float64 sums, tiles of RP_WTILE_MAX items) keeps K x tiles < 32 768
+        # (K = 3 640 at 100 000 items): DESIGN.md section 4, deviation 5
         k_eff = min(int(self.K), max(1, X.shape[1] - 1))
-        tile = RP_WTILE_MAX if self.normalize_X else RP_TILE_MAX
-        n_tiles = -(-X.shape[1] // tile)
-        if n_tiles > 1 and k_eff * n_tiles >= RP_K_TILES_MAX:
-            raise ValueError(f"K={self.K} exceeds the supported maximum for {X.shape[1]} items"
-                             + (" with normalize_X" if self.normalize_X else "") + f": K x {n_tiles} column tiles must stay below {RP_K_TILES_MAX}"
-                             + f" (any K up to {tile} items)")
+        if self.normalize_X:
+            n_tiles = -(-X.shape[1] // RP_WTILE_MAX)
+            if n_tiles > 1 and k_eff * n_tiles >= RP_K_TILES_MAX:
+                raise ValueError(f"K={self.K} exceeds the supported maximum for {X.shape[1]} items with normalize_X: K x {n_tiles} column tiles "
+                                 f"must stay below {RP_K_TILES_MAX} (any K up to {RP_WTILE_MAX} items)")
         ctx, dX = self._upload(X)
         try:
             if self.similarity == "cosine":

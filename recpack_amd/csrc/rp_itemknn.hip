@@ -45,6 +45,7 @@ struct rp_fit_params {
   const double* inv_deg;   // column weight of the key: 1/c_j (cosine) or c_j^-alpha (conditional probability)
   const int32_t* tile_ptr;
   int n_items, n_tiles, tile_w, K, row_begin;
+  int cand_stride;         // n_tiles > 1: entries between two tiles' lists of a row (K; min(K, tile_w) on the large-K route)
   int nnz;
   int key_pow;             // 2 = cosine, 1 = conditional probability
   const rp_task* tasks;
@@ -557,7 +558,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
         rp_select_emit<NTHR>(n_cols, sel, emit, SEG);
       if (tid == 0) P.out_nnz[rl] = kp;
     } else {
-      const int64_t o = ((int64_t)rl * T + tile) * P.K;
+      const int64_t o = ((int64_t)rl * T + tile) * P.cand_stride;
       auto emit = [&](int pos, int w) {
         P.out_idx[o + pos] = t0 + w;
         P.out_cnt[o + pos] = src.count(w);
@@ -612,6 +613,7 @@ struct rp_merge_params {
   const int32_t* deg;
   const double* inv_deg;
   int n_tiles, K, row_begin, n_rows, key_pow;
+  int stride;  // k_itemknn_merge_big: entries between two tiles' lists of a row (the other merges: K)
   int32_t* out_idx;
   double* out_val;
   int32_t* out_nnz;
@@ -775,6 +777,136 @@ __global__ void __launch_bounds__(64) k_itemknn_merge_wave(rp_merge_params P) {
     }
     if (lane == 0) P.out_nnz[rl] = n_out;
     RP_WAVE_FENCE();
+  }
+}
+
+// ---- (round 6) the merge for ANY K: K x tiles >= 32 768 candidates per row (recpack takes any K: util.py:63-66, base.py:302-304;
+// ItemKNN(K=20000) at 100 000 items).  The selections above number their candidates in 16 bits with a flag (RPS_FLAG); here nothing
+// is numbered: one workgroup per row walks the row's per-tile lists where they lie - an MSD radix select over the 64-bit key (11-bit
+// digits, at most six passes, each a histogram of the candidates that share the decided prefix) finds the K-th key, a last pass in
+// position order (= column order: tiles are ascending column ranges, a tile's list is in column order) writes everything above it, and
+// of the candidates that TIE with it the first ones - ties to the smaller column, as everywhere.  A row with at most K candidates
+// (the common case at such K: the Gram row has fewer non-zeros) is copied out.  Rare route: simple, not tuned.
+constexpr int RP_MBIG_THREADS = 256;
+__global__ void __launch_bounds__(RP_MBIG_THREADS) k_itemknn_merge_big(rp_merge_params P) {
+  __shared__ uint32_t hist[2048];
+  __shared__ int s_off[17], s_res[4], s_w[2][RP_MBIG_THREADS / 64];
+  const int T = P.n_tiles, K = P.K, S = P.stride;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  for (int rl = blockIdx.x; rl < P.n_rows; rl += gridDim.x) {
+    __syncthreads();
+    if (tid == 0) {
+      int o = 0;
+      for (int t = 0; t < T; ++t) {
+        s_off[t] = o;
+        o += P.cand_nnz[(int64_t)rl * T + t];
+      }
+      s_off[T] = o;
+    }
+    __syncthreads();
+    const int n = s_off[T];
+    const int32_t* gi = P.cand_idx + (int64_t)rl * T * S;
+    const uint32_t* gc = P.cand_cnt + (int64_t)rl * T * S;
+    auto at = [&](int w) {
+      int t = 0;
+      while (t + 1 < T && w >= s_off[t + 1]) ++t;
+      return t * S + (w - s_off[t]);
+    };
+    const bool all = n <= K;
+    uint64_t prefix = 0;
+    int need = K, sh = 0;
+    bool fin_all = false;
+    if (!all) {
+      for (int level = 0; level < 6; ++level) {
+        const int hi = 64 - 11 * level, width = min(11, hi), shift = hi - width;
+        for (int i = tid; i < 2048; i += RP_MBIG_THREADS) hist[i] = 0u;
+        __syncthreads();
+        for (int w = tid; w < n; w += RP_MBIG_THREADS) {
+          const int a = at(w);
+          const uint64_t k = rp_fit_key(gc[a], P.inv_deg[gi[a]], P.key_pow);
+          if (level == 0 || (k >> hi) == (prefix >> hi)) atomicAdd(&hist[(uint32_t)(k >> shift) & ((1u << width) - 1u)], 1u);
+        }
+        __syncthreads();
+        if (wave == 0) {  // the bin where the count from the top reaches `need`: lane l owns the 32 bins below 2047 - 32 l
+          int h[32], sum = 0;
+#pragma unroll
+          for (int e = 0; e < 32; ++e) {
+            h[e] = (int)hist[2047 - 32 * lane - e];
+            sum += h[e];
+          }
+          int above = rp_wave_incl_scan(sum, lane) - sum;
+#pragma unroll
+          for (int e = 0; e < 32; ++e) {
+            if (above < need && need <= above + h[e]) {
+              s_res[0] = 2047 - 32 * lane - e;
+              s_res[1] = above;
+              s_res[2] = h[e];
+            }
+            above += h[e];
+          }
+        }
+        __syncthreads();
+        need -= s_res[1];
+        prefix |= (uint64_t)(uint32_t)s_res[0] << shift;
+        sh = shift;
+        if (s_res[2] == need) {  // the whole boundary bin is selected
+          fin_all = true;
+          break;
+        }
+        __syncthreads();
+      }
+    }
+    // ---- emission in position order; `need` of the members of the boundary group (all of them when fin_all)
+    int32_t* oi = P.out_idx + (int64_t)rl * K;
+    double* ov = P.out_val + (int64_t)rl * K;
+    const double ci = (double)P.deg[P.row_begin + rl];
+    int run_sel = 0, run_mem = 0;
+    for (int base = 0; base < n; base += RP_MBIG_THREADS) {
+      const int w = base + tid;
+      int a = 0, j = 0;
+      uint32_t c = 0;
+      bool above = false, member = false;
+      if (w < n) {
+        a = at(w);
+        j = gi[a];
+        c = gc[a];
+        if (all) {
+          above = true;
+        } else {
+          const uint64_t k = rp_fit_key(c, P.inv_deg[j], P.key_pow);
+          above = (k >> sh) > (prefix >> sh);
+          member = (k >> sh) == (prefix >> sh);
+        }
+      }
+      const uint64_t mm = __ballot(member);
+      if (lane == 0) s_w[0][wave] = __popcll(mm);
+      __syncthreads();
+      int mem_before = run_mem + __popcll(mm & lt_mask);
+      int mem_total = 0;
+      for (int q = 0; q < RP_MBIG_THREADS / 64; ++q) {
+        if (q < wave) mem_before += s_w[0][q];
+        mem_total += s_w[0][q];
+      }
+      const bool sel = above || (member && (fin_all || mem_before < need));
+      const uint64_t sm = __ballot(sel);
+      if (lane == 0) s_w[1][wave] = __popcll(sm);
+      __syncthreads();
+      int pos = run_sel + __popcll(sm & lt_mask);
+      int sel_total = 0;
+      for (int q = 0; q < RP_MBIG_THREADS / 64; ++q) {
+        if (q < wave) pos += s_w[1][q];
+        sel_total += s_w[1][q];
+      }
+      if (sel) {
+        oi[pos] = j;
+        ov[pos] = (P.key_pow == 2) ? (double)c / sqrt(ci * (double)P.deg[j]) : ((double)c * P.inv_deg[j]) / ci;
+      }
+      run_sel += sel_total;
+      run_mem += mem_total;
+      __syncthreads();
+    }
+    if (tid == 0) P.out_nnz[rl] = run_sel;
   }
 }
 
@@ -1010,60 +1142,16 @@ int rp_plan_row_order(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int
   return RPHIP_OK;
 }
 
-// Shared driver of K1-K3 (out != NULL: neighbour lists) and K4 (dense != NULL: dense f32 Gram rows + lambda).
-// Xc (dense only): take the USER ROWS from another matrix of the same shape - rows of X^T Xc instead of X^T X
-// (EASE_XY's Y^T X); NULL = X itself.
-static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K, rphip_model** out,
-                        float* dense, int64_t dense_ld, float diag_add, const double* colw = nullptr, int key_pow = 2,
-                        const rphip_csr* Xc = nullptr) {
-  if (!ctx || !X || (!out && !dense)) RP_FAIL(RPHIP_EINVAL, "NULL argument");
-  if (out) *out = nullptr;
-  if (!Xc) Xc = X;
-  if (Xc->n_users != X->n_users || Xc->n_items != X->n_items) RP_FAIL(RPHIP_EINVAL, "the two matrices must have the same shape");
-  if (row_begin < 0 || row_end > X->n_items || row_begin > row_end)
-    RP_FAIL(RPHIP_EINVAL, "row range [%lld,%lld) outside 0..%lld", (long long)row_begin, (long long)row_end, (long long)X->n_items);
-  if (K < 1) RP_FAIL(RPHIP_EINVAL, "K must be >= 1 (got %d)", K);
-  RP_NEED_DEGREES(X);
-  RP_NEED_DEGREES(Xc);
-  if (X->xt_row_end >= 0 && (row_begin < X->xt_row_begin || row_end > X->xt_row_end))
-    RP_FAIL(RPHIP_ESTATE, "the matrix was built for item rows [%lld,%lld) only (rphip_csr_from_device_rows)", (long long)X->xt_row_begin,
-            (long long)X->xt_row_end);
-  RP_TRY(rp_set_device(ctx));
-  // a row has at most n_items-1 neighbours
-  const int32_t Keff = (int32_t)std::min<int64_t>(K, std::max<int64_t>(1, X->n_items - 1));
-  const int n_rows = (int)(row_end - row_begin);
+// K1-K3 / K4 for the item rows [row_begin, row_begin + n_rows): plan, the three instances, the merge of the per-tile lists.  The
+// neighbour lists go to out_idx / out_val / out_nnz (the first row's place); `big`: the large-K route (per-tile lists of
+// min(K, tile) entries, k_itemknn_merge_big).
+static int rp_gram_rows(rphip_ctx* ctx, const rphip_csr* X, const rphip_csr* Xc, int64_t row_begin, int n_rows, int32_t K, float* dense,
+                        int64_t dense_ld, float diag_add, const double* colw, int key_pow, int32_t* out_idx, double* out_val, int32_t* out_nnz,
+                        bool big) {
   const int T = X->n_tiles, W = X->tile_w;
-  // (round 4) one column tile - up to RP_TILE_MAX items - takes ANY K, as the reference does (recpack/algorithms/base.py:302-304,
-  // recpack/util.py:63-66): the selection runs on the tile itself and writes the row.  With several tiles a row's per-tile
-  // candidate lists meet in the LDS of the merge: K <= RP_K_MAX there.
-  // (round 5) ... any K with K x tiles < 32 768 (the selection's list of slot numbers): the merge reads the per-tile lists where
-  // they lie when they do not fit the LDS (k_itemknn_merge<true>) - K = 8 191 at 100 000 items, 4 095 at 200 000
-  if (T > 1 && (int64_t)T * Keff >= RPS_FLAG)
-    RP_FAIL(RPHIP_ELIMIT, "effective K=%d with %d column tiles (%lld items): K x tiles must stay below %d (any K up to %d items)", Keff, T,
-            (long long)X->n_items, RPS_FLAG, RP_TILE_MAX);
-
-  K = Keff;  // the model's row stride; rphip_model_info reports it
-  if (T > 15) RP_FAIL(RPHIP_ELIMIT, "%d column tiles (n_items=%lld) exceed the supported 15", T, (long long)X->n_items);
-  rphip_model* m = nullptr;
+  const int32_t Keff = K;
+  const int32_t Ks = big ? std::min<int32_t>(Keff, W) : Keff;
   hipStream_t st = ctx->stream;
-  if (!dense) {
-    RP_TRY(rp_model_alloc_topk(ctx, X->n_items, row_begin, row_end, K, &m));
-    const size_t nk = (size_t)std::max<int64_t>(1, (int64_t)n_rows * K);
-    hipMemsetAsync(m->idx, 0xFF, nk * sizeof(int32_t), st);
-    hipMemsetAsync(m->val, 0, nk * sizeof(double), st);
-    hipMemsetAsync(m->nnz, 0, (size_t)std::max(1, n_rows) * sizeof(int32_t), st);
-  }
-  if (n_rows == 0 || X->nnz == 0 || Xc->nnz == 0) {
-    if (dense) return RPHIP_OK;  // rows without users keep what the caller initialised (zeros + lambda)
-    int r = rp_model_finalize_topk(ctx, m);
-    if (r != RPHIP_OK) {
-      rphip_model_destroy(m);
-      return r;
-    }
-    *out = m;
-    return RPHIP_OK;
-  }
-
   // ---- plan
   hipEvent_t ev;
   rp_time_begin(ctx, &ev);
@@ -1129,7 +1217,7 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   int32_t* cand_nnz = nullptr;
   if (T > 1 && !dense) {
     char* cb = nullptr;
-    const size_t n_c = (size_t)n_rows * T * Keff;
+    const size_t n_c = (size_t)n_rows * T * Ks;
     RP_TRY(rp_scratch(ctx, 2, n_c * 8 + (size_t)n_rows * T * 4 + 64, (void**)&cb));
     cand_idx = (int32_t*)cb;
     cand_cnt = (uint32_t*)(cb + n_c * 4);
@@ -1152,6 +1240,7 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
   P.n_tiles = T;
   P.tile_w = W;
   P.K = K;
+  P.cand_stride = Ks;
   P.row_begin = (int)row_begin;
   P.part = part;
   P.dense = dense;
@@ -1172,10 +1261,10 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
     P.out_cnt = nullptr;
     P.out_nnz = nullptr;
   } else if (T == 1) {
-    P.out_idx = m->idx;
-    P.out_val = m->val;
+    P.out_idx = out_idx;
+    P.out_val = out_val;
     P.out_cnt = nullptr;
-    P.out_nnz = m->nnz;
+    P.out_nnz = out_nnz;
   } else {
     P.out_idx = cand_idx;
     P.out_val = nullptr;
@@ -1268,10 +1357,15 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
     M.K = Keff;
     M.row_begin = (int)row_begin;
     M.n_rows = n_rows;
-    M.out_idx = m->idx;
-    M.out_val = m->val;
-    M.out_nnz = m->nnz;
-    if (Keff <= RP_MERGE_WAVE_KMAX) {
+    M.stride = Ks;
+    M.out_idx = out_idx;
+    M.out_val = out_val;
+    M.out_nnz = out_nnz;
+    if (big) {
+      hipLaunchKernelGGL(k_itemknn_merge_big, dim3((unsigned)std::min<int64_t>(n_rows, (int64_t)ctx->n_cu * 8)), dim3(RP_MBIG_THREADS), 0, st, M);
+      RP_HIP(hipGetLastError());
+      rp_time_end(ctx, ev, RPHIP_T_TOPK_MERGE, 16.0 * (double)n_rows * T * Ks);
+    } else if (Keff <= RP_MERGE_WAVE_KMAX) {
       const size_t wl = rp_merge_wave_bytes(Keff);
       RP_HIP(hipFuncSetAttribute((const void*)k_itemknn_merge_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl));
       const int wpc = std::max<int>(1, std::min<int>(24, (int)((160 * 1024) / wl)));
@@ -1283,7 +1377,6 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
     const bool in_lds = (size_t)T * Keff * 8 + sel_lds <= (size_t)160 * 1024;
     const size_t mlds = in_lds ? (size_t)T * Keff * 8 + sel_lds : sel_lds;
     if (mlds > 160 * 1024 || T * Keff >= RPS_FLAG) {
-      rphip_model_destroy(m);
       RP_FAIL(RPHIP_ELIMIT, "K=%d with %d column tiles needs %zu bytes of LDS for the merge", K, T, mlds);
     }
     const int mper = std::max<int>(1, std::min<int>(8, (int)((160 * 1024) / mlds)));
@@ -1298,6 +1391,82 @@ static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, i
     RP_HIP(hipGetLastError());
     rp_time_end(ctx, ev, RPHIP_T_TOPK_MERGE, 16.0 * (double)n_rows * T * Keff);
     }
+  }
+  return RPHIP_OK;
+}
+
+// Shared driver of K1-K3 (out != NULL: neighbour lists) and K4 (dense != NULL: dense f32 Gram rows + lambda).
+// Xc (dense only): take the USER ROWS from another matrix of the same shape - rows of X^T Xc instead of X^T X
+// (EASE_XY's Y^T X); NULL = X itself.
+static int rp_gram_core(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K, rphip_model** out,
+                        float* dense, int64_t dense_ld, float diag_add, const double* colw = nullptr, int key_pow = 2,
+                        const rphip_csr* Xc = nullptr) {
+  if (!ctx || !X || (!out && !dense)) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  if (out) *out = nullptr;
+  if (!Xc) Xc = X;
+  if (Xc->n_users != X->n_users || Xc->n_items != X->n_items) RP_FAIL(RPHIP_EINVAL, "the two matrices must have the same shape");
+  if (row_begin < 0 || row_end > X->n_items || row_begin > row_end)
+    RP_FAIL(RPHIP_EINVAL, "row range [%lld,%lld) outside 0..%lld", (long long)row_begin, (long long)row_end, (long long)X->n_items);
+  if (K < 1) RP_FAIL(RPHIP_EINVAL, "K must be >= 1 (got %d)", K);
+  RP_NEED_DEGREES(X);
+  RP_NEED_DEGREES(Xc);
+  if (X->xt_row_end >= 0 && (row_begin < X->xt_row_begin || row_end > X->xt_row_end))
+    RP_FAIL(RPHIP_ESTATE, "the matrix was built for item rows [%lld,%lld) only (rphip_csr_from_device_rows)", (long long)X->xt_row_begin,
+            (long long)X->xt_row_end);
+  RP_TRY(rp_set_device(ctx));
+  // a row has at most n_items-1 neighbours
+  const int32_t Keff = (int32_t)std::min<int64_t>(K, std::max<int64_t>(1, X->n_items - 1));
+  const int n_rows = (int)(row_end - row_begin);
+  const int T = X->n_tiles, W = X->tile_w;
+  // (round 4) one column tile - up to RP_TILE_MAX items - takes ANY K, as the reference does (recpack/algorithms/base.py:302-304,
+  // recpack/util.py:63-66): the selection runs on the tile itself and writes the row.  With several tiles a row's per-tile
+  // candidate lists meet in the LDS of the merge: K <= RP_K_MAX there.
+  // (round 5) ... any K with K x tiles < 32 768 (the selection's list of slot numbers): the merge reads the per-tile lists where
+  // they lie when they do not fit the LDS (k_itemknn_merge<true>) - K = 8 191 at 100 000 items, 4 095 at 200 000
+  // (round 6) ... and any K beyond that: per-tile lists of min(K, tile) entries merged where they lie by k_itemknn_merge_big, the rows
+  // taken in chunks that bound the lists' memory - ItemKNN(K=20000) at 100 000 items
+  const bool big_k = T > 1 && (int64_t)T * Keff >= RPS_FLAG;
+
+  K = Keff;  // the model's row stride; rphip_model_info reports it
+  if (T > 15) RP_FAIL(RPHIP_ELIMIT, "%d column tiles (n_items=%lld) exceed the supported 15", T, (long long)X->n_items);
+  rphip_model* m = nullptr;
+  hipStream_t st = ctx->stream;
+  if (!dense) {
+    RP_TRY(rp_model_alloc_topk(ctx, X->n_items, row_begin, row_end, K, &m));
+    const size_t nk = (size_t)std::max<int64_t>(1, (int64_t)n_rows * K);
+    hipMemsetAsync(m->idx, 0xFF, nk * sizeof(int32_t), st);
+    hipMemsetAsync(m->val, 0, nk * sizeof(double), st);
+    hipMemsetAsync(m->nnz, 0, (size_t)std::max(1, n_rows) * sizeof(int32_t), st);
+  }
+  if (n_rows == 0 || X->nnz == 0 || Xc->nnz == 0) {
+    if (dense) return RPHIP_OK;  // rows without users keep what the caller initialised (zeros + lambda)
+    int r = rp_model_finalize_topk(ctx, m);
+    if (r != RPHIP_OK) {
+      rphip_model_destroy(m);
+      return r;
+    }
+    *out = m;
+    return RPHIP_OK;
+  }
+
+  // ---- the rows, in chunks where the per-tile candidate lists of all rows at once would be too much memory (T x min(K, tile) x 8 bytes per
+  // row: 64 GB at K = 20 000 and 100 000 items)
+  int rc = RPHIP_OK;
+  if (dense) {
+    rc = rp_gram_rows(ctx, X, Xc, row_begin, n_rows, K, dense, dense_ld, diag_add, colw, key_pow, nullptr, nullptr, nullptr, false);
+    return rc;
+  }
+  {
+    const int64_t per_row = T > 1 ? (int64_t)T * (big_k ? std::min<int64_t>(K, W) : K) * 8 + (int64_t)T * 4 : 0;
+    const int64_t budget = (int64_t)6 << 30;
+    const int64_t R = (per_row > 0 && per_row * n_rows > budget) ? std::max<int64_t>(1, budget / per_row) : n_rows;
+    for (int64_t c0 = 0; c0 < n_rows && rc == RPHIP_OK; c0 += R)
+      rc = rp_gram_rows(ctx, X, Xc, row_begin + c0, (int)std::min<int64_t>(R, n_rows - c0), K, nullptr, 0, 0.0f, colw, key_pow, m->idx + c0 * K,
+                        m->val + c0 * K, m->nnz + c0, big_k);
+  }
+  if (rc != RPHIP_OK) {
+    rphip_model_destroy(m);
+    return rc;
   }
   {
     int r = rp_model_finalize_topk(ctx, m);

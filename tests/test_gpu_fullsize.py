@@ -109,6 +109,45 @@ def test_itemknn_c4_full_size(hip):
     itemknn_full(hip, "C4", n_rows=10000, n_users=10000)  # >= 10 000 sampled rows per run
 
 
+def test_itemknn_c4_any_k(hip):
+    """ItemKNN(K=20000) on the metric's matrix (1M x 100K; VERDICT round 5 item 7: recpack runs where round 5 raised): a 48 GB model,
+    the fit in row chunks (6 GB of per-tile lists at a time), sampled rows - read back from the device, the whole model is 24 GB of host
+    memory - identical to the oracle's."""
+    import torch
+
+    from recpack_amd import dist as rdist
+
+    _lib, ctx = hip
+    dX, X, keep = make("C4", hip)
+    U, I = X.shape
+    K = 20000
+    m = _lib.itemknn_fit(ctx, dX, K)
+    assert m.K == K
+    pi, pv, pn, n_rows, k_ = m.topk_device_ptrs()
+    dev = torch.device("cuda", 0)
+    ti = torch.as_tensor(rdist._DevPtr(pi, (n_rows, k_), "<i4", m), device=dev)
+    tv = torch.as_tensor(rdist._DevPtr(pv, (n_rows, k_), "<f8", m), device=dev)
+    tn = torch.as_tensor(rdist._DevPtr(pn, (n_rows,), "<i4", m), device=dev)
+    nnz_all = tn.cpu().numpy()
+    rng = np.random.default_rng(13)
+    deg = np.diff(X.tocsc().indptr)
+    rows = np.unique(np.r_[rng.choice(I, size=200, replace=False), np.argsort(-deg)[:40], np.nonzero(nnz_all == K)[0][:60]])
+    rt = torch.as_tensor(rows, device=dev)
+    idx, val, nnz = ti[rt].cpu().numpy(), tv[rt].cpu().numpy(), nnz_all[rows]
+    ref = onp.itemknn_fit(X, K, rows=rows)
+    key = np.where(ref["idx"] < 0, np.iinfo(np.int32).max, ref["idx"])
+    perm = np.argsort(key, axis=1, kind="stable")
+    np.testing.assert_array_equal(nnz, ref["nnz"])
+    np.testing.assert_array_equal(idx, np.take_along_axis(ref["idx"], perm, axis=1))
+    np.testing.assert_allclose(val, np.take_along_axis(ref["val"], perm, axis=1), rtol=1e-12)
+    assert (nnz_all == K).sum() > 0 and (nnz_all < K).sum() > 0  # both kinds of rows exist: cut at K, and copied whole
+    del ti, tv, tn
+    m.close()
+    dX.close()
+    ctx.trim()
+    torch.cuda.empty_cache()
+
+
 EASE_TOL = 1e-4  # BASELINE.json north_star: EASE scores within 1e-4 relative (the reference inverts in float64, ease.py:82)
 
 

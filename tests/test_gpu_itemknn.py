@@ -693,9 +693,12 @@ def test_fit_any_k_on_one_tile(hip):
     got = algo.predict(X[:300])
     want = onp.predict_full(X[:300], S)
     assert abs(got - want).max() <= 2e-7 * abs(want).max()
-    Xw = powerlaw_csr(200, 26000, 0.002, seed=42).to_scipy()  # two column tiles: K x tiles < 32 768 is what is left of the limit
-    with pytest.raises(ValueError):
-        recpack_amd.ItemKNN(K=17000).fit(Xw)
+    Xw = powerlaw_csr(200, 26000, 0.002, seed=42).to_scipy()  # two column tiles: K x tiles >= 32 768 takes the large-K merge (round 6) ...
+    Sw = recpack_amd.ItemKNN(K=17000).fit(Xw).similarity_matrix_
+    rw = onp.itemknn_fit(Xw, 17000)
+    assert (Sw != onp.topk_to_csr(rw["idx"], rw["val"], rw["nnz"], 26000)).nnz == 0
+    with pytest.raises(ValueError):  # ... and only normalize_X keeps the limit
+        recpack_amd.ItemKNN(K=17000, normalize_X=True).fit(Xw)
 
 
 def test_fit_any_k_over_several_tiles(hip):
@@ -716,6 +719,34 @@ def test_fit_any_k_over_several_tiles(hip):
 
     S = recpack_amd.ItemKNN(K=5000).fit(X).similarity_matrix_
     assert S.shape == (40000, 40000) and 2048 < S.getnnz(axis=1).max() <= 5000
+
+
+def test_fit_any_k_beyond_the_numbered_merges(hip):
+    """ItemKNN(K=20000) and K = n_items on 60 000 x 40 000: K x tiles >= 32 768, per-tile lists of min(K, tile)
+    entries merged by k_itemknn_merge_big - rows with fewer candidates than K copied out, the popular rows through the MSD radix select on
+    the 64-bit key with ties to the smaller column; a tie-heavy matrix (few distinct keys: whole bins tie at the K-th key) on two tiles."""
+    from recpack_amd.synth import powerlaw_csr
+
+    _lib, ctx = hip
+    X = powerlaw_csr(60000, 40000, 0.004, seed=44).to_scipy()
+    rows = np.unique(np.r_[np.sort(np.random.default_rng(5).choice(40000, size=1500, replace=False)), np.argsort(-np.diff(X.tocsc().indptr))[:300]])
+    for K in (20000, 17000, 40000):
+        _, m, idx, val, nnz = fit_arrays(hip, X, K)
+        assert m.K == min(K, 39999)
+        ref = onp.itemknn_fit(X, K, rows=rows)
+        assert_same_as_oracle(idx[rows], val[rows], nnz[rows], ref)
+        if K == 17000:
+            assert (nnz == 17000).sum() > 50  # (rows that really cut at K: the radix select ran)
+        del m, idx, val, nnz
+    # ties: 300 users, every item in one of 12 groups of identical columns -> a handful of distinct keys per row
+    rng = np.random.default_rng(9)
+    base = (rng.random((300, 12)) < 0.4)
+    grp = rng.integers(0, 12, size=27000)
+    Xt = sp.csr_matrix(base[:, grp].astype(np.float64))
+    for K in (17000, 20000):
+        _, m, idx, val, nnz = fit_arrays(hip, Xt, K)
+        rr = np.sort(rng.choice(27000, size=300, replace=False))
+        assert_same_as_oracle(idx[rr], val[rr], nnz[rr], onp.itemknn_fit(Xt, K, rows=rr))
 
 
 def test_fit_normalize_X_any_k(hip):
