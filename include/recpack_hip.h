@@ -140,7 +140,7 @@ int rphip_ctx_trim(rphip_ctx* ctx);
  *                       rphip_comm_selftest (the large broadcast) is the only one that fails.
  *   "gemm_mode"         2 (default) | 0: how the O(n^3) products of the EASE solve (and rphip_gemm_nt_f32) multiply their fp32 operands.
  *                       2: two fp16 planes per operand, both rounded to nearest (x = h1 + h2 to 2^-24 |x|), three plane products per
- *                          step on v_mfma_f32_32x32x16_f16; each operand is scaled by a power of two taken from its largest magnitude
+ *                          step on v_mfma_f32_16x16x32_f16; each operand is scaled by a power of two taken from its largest magnitude
  *                          over the rows and K range the launch reads (one extra pass over the operands), so fp16's range is never
  *                          left; fp32 accumulate.  Entries below 2^-18 of that magnitude are held to an absolute 2^-40 of it
  *                          instead of fp32's relative 2^-24 (rows of very different size: use mode 0).

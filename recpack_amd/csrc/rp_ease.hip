@@ -574,7 +574,6 @@ struct rp_hp_args {
   const unsigned* sc_tab;  // k_gemm_hp16w: A's scale changes with the K chunk (k >> sc_shift): rp_plane_cache::amax
   int sc_shift, sc_mask;
   int b_tab;            // ... and B's is the same chunk's (B read from the same cache)
-  unsigned* stamps;     // diagnostic build (-DRP_GEMM_STAMPS): per-step clock stamps of one workgroup of k_gemm_hp16w
   int xb;               // k_gemm_hp16w: tile rows of an XCD's block of 32 tiles (0: plain 2-D grid)
 };
 
@@ -725,12 +724,6 @@ __global__ void __launch_bounds__(256, 2) k_gemm_hp16(rp_hp_args q) {
 // two steps old - before the one barrier of the step (which also says that everybody has finished reading the stage about to be
 // refilled).  The two 128-row halves of a tile follow the 128-tile rules separately (tri, K clipping: a half that is excluded or
 // whose K range has not begun skips the MFMAs, wave-uniformly), so every caller's tile semantics are those of the 128 x 128 kernels.
-// Diagnostic builds only (make gemmablate; tools/gemm_ablate.py): RP_GEMM_ABL removes parts of k_gemm_hp16w to attribute its time -
-// 1: no LDS-DMA requests after the prologue, 2: the fragments are read once (no ds_read in the loop), 4: no barrier and no counted
-// wait, 8: no flush.  Results are wrong by construction.
-#ifndef RP_GEMM_ABL
-#define RP_GEMM_ABL 0
-#endif
 #ifndef RP_FLUSH_FAST
 #define RP_FLUSH_FAST 1  // 0: the six-operation two-sum of rounds 2 and 3
 #endif
@@ -738,19 +731,6 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
   // [stage][A: plane 2 x block 8 x K16 2 | B: plane 2 x block 4 x K16 2][1 KB]
   extern __shared__ __attribute__((aligned(1024))) unsigned char smw[];
   constexpr int STAGE = 48 * 1024, AOFF = 0, BOFF = 32 * 1024;
-#ifdef RP_GEMM_STAMPS
-  // [wave 8][step 48][slot 5] low 32 bits of s_memtime, kept in the 16 KB of LDS the stages leave, written out by the workgroup (5, 3)
-  unsigned* stl = reinterpret_cast<unsigned*>(smw + 3 * STAGE);
-  const bool stamping = blockIdx.x == 5 && blockIdx.y == 3 && q.stamps;
-  int st_step = 0;
-#define GST(slot)                                                                                   \
-  do {                                                                                              \
-    if (stamping && st_step < 48 && (threadIdx.x & 63) == 0)                                        \
-      stl[((threadIdx.x >> 6) * 48 + st_step) * 5 + (slot)] = (unsigned)__builtin_amdgcn_s_memtime(); \
-  } while (0)
-#else
-#define GST(slot)
-#endif
   const rp_gemm_args& g = q.g;
   // (the wave index as a SCALAR: with tid >> 6 in a vector register every address, K bound and branch derived from it was vector
   // arithmetic - and vector instructions share the SIMD's issue port with the MFMAs: attribution by removal put the requests, the
@@ -915,22 +895,12 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
     issue(1, min(kb + 32, k_last));
     const int foff = (lane >> 5) * 1024 + ((((lane >> 4) & 1) * 32) + (lane & 15)) * 16;
     int since = 0, stage = 0;
-    f16x8 abl_a[2][2], abl_b[2][4];  // (RP_GEMM_ABL & 2 only)
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) abl_b[p][t] = (f16x8)(_Float16)1.0f;
-      abl_a[p][0] = abl_a[p][1] = (f16x8)(_Float16)1.0f;
-    }
     for (int k = kb; k < ke; k += 32) {
-      GST(0);
-      if (!(RP_GEMM_ABL & 4)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // my pieces of this step have landed (those of the next step may be in flight)
-      GST(1);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // my pieces of this step have landed (those of the next step may be in flight)
       // everybody's have, and nobody still reads the stage refilled below (the fragment reads of the previous step were consumed by
       // its MFMAs).  The bare barrier: __syncthreads() carries a fence that the compiler turns into vmcnt(0) - the counted wait gone.
-      if (!(RP_GEMM_ABL & 4)) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      GST(2);
       int st2 = stage + 2;
       if (st2 >= 3) st2 -= 3;
       const int kn = min(k + 64, k_last);
@@ -943,18 +913,8 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
         // program in step and sat in their request phases together.  So the halves take turns: waves 0-3 request BEFORE their MFMAs,
         // waves 4-7 AFTER theirs - one partner's requests run beside the other's MFMAs.  (A row's A fragments are read while the row
         // before it multiplies.)
-        if (wave < 4 && !(RP_GEMM_ABL & 1)) issue(st2, kn);
-        GST(3);
+        if (wave < 4) issue(st2, kn);
         f16x8 a[2][2], b[2][4];
-        if ((RP_GEMM_ABL & 2) && k != kb) {  // (diagnostic: stale fragments)
-#pragma unroll
-          for (int p = 0; p < 2; ++p) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) b[p][t] = abl_b[p][t];
-            a[p][0] = abl_a[p][0];
-            a[p][1] = abl_a[p][1];
-          }
-        } else {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
 #pragma unroll
@@ -962,14 +922,13 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
             b[p][t] = *reinterpret_cast<const f16x8*>(B0 + p * 8 * 1024 + ((wc * 2 + (t >> 1)) * 2) * 1024 + foff + (t & 1) * 256);
           a[p][0] = *reinterpret_cast<const f16x8*>(A0 + p * 16 * 1024 + ((wr * 2) * 2) * 1024 + foff);
         }
-        }
         // `fresh` is decided ONCE per step, outside the rows: with the branch inside, every row was a basic block of its own and
         // the compiler's wait-count pass, merging the two ways in, put s_waitcnt lgkmcnt(0) in front of each row's MFMAs - the
         // fragment reads issued for the NEXT row were waited for before the current row multiplied (found in the ISA listing)
         auto rows = [&](auto is_fresh) __attribute__((always_inline)) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            if (i < 3 && !((RP_GEMM_ABL & 2) && k != kb)) {
+            if (i < 3) {
 #pragma unroll
               for (int p = 0; p < 2; ++p)
                 a[p][(i + 1) & 1] = *reinterpret_cast<const f16x8*>(A0 + p * 16 * 1024 + ((wr * 2 + ((i + 1) >> 1)) * 2) * 1024 + foff + ((i + 1) & 1) * 256);
@@ -990,14 +949,10 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
         else
           rows(std::false_type{});
         fresh = false;
-        GST(4);
-        if (wave >= 4 && !(RP_GEMM_ABL & 1)) issue(st2, kn);
-#ifdef RP_GEMM_STAMPS
-        ++st_step;
-#endif
+        if (wave >= 4) issue(st2, kn);
         since += 32;
         const bool edge = q.sc_tab && !((k + 32) & q.sc_mask);
-        if ((since >= g.kc || edge) && k + 32 < my_ke && !(RP_GEMM_ABL & 8)) {
+        if ((since >= g.kc || edge) && k + 32 < my_ke) {
           flush();
           since = 0;
           if (edge) unscale = chunk_unscale(k + 32);
@@ -1008,12 +963,6 @@ __global__ void __launch_bounds__(512, 1) k_gemm_hp16w(rp_hp_args q) {
       stage = stage == 2 ? 0 : stage + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the trailing re-reads)
-#ifdef RP_GEMM_STAMPS
-    if (stamping) {
-      __syncthreads();
-      for (int e = threadIdx.x; e < 8 * 48 * 5; e += 512) q.stamps[e] = stl[e];
-    }
-#endif
   }
   if (!mine) return;
   if (!fresh) flush();
@@ -1402,16 +1351,7 @@ static bool rp_gemm_wide_ok(const rphip_ctx* ctx, const rp_gemm_args& g) {
 }
 
 static int rp_launch_hp16w(rphip_ctx* ctx, rp_hp_args& q, hipStream_t st) {
-#ifdef RP_GEMM_STAMPS
-  constexpr int wide_lds = 3 * 48 * 1024 + 8 * 48 * 5 * 4;
-  if (!ctx->scratch[15].p) {
-    void* sp = nullptr;
-    RP_TRY(rp_scratch(ctx, 15, 8 * 48 * 5 * 4, &sp));
-  }
-  q.stamps = (unsigned*)ctx->scratch[15].p;
-#else
   constexpr int wide_lds = 3 * 48 * 1024;
-#endif
   static bool attr_set = false;
   if (!attr_set) {
     RP_HIP(hipFuncSetAttribute((const void*)k_gemm_hp16w, hipFuncAttributeMaxDynamicSharedMemorySize, wide_lds));
@@ -1612,13 +1552,6 @@ int rp_gemm_nt(rphip_ctx* ctx, const rp_gemm_args& g, hipStream_t st, float* par
   return RPHIP_OK;
 }
 
-#ifdef RP_GEMM_STAMPS
-extern "C" int rphip_debug_gemm_stamps(rphip_ctx* ctx, unsigned* out) {  // [8][48][5]
-  if (!ctx->scratch[15].p) return RPHIP_ESTATE;
-  hipStreamSynchronize(ctx->stream);
-  return hipMemcpy(out, ctx->scratch[15].p, 8 * 48 * 5 * 4, hipMemcpyDeviceToHost) == hipSuccess ? RPHIP_OK : RPHIP_EHIP;
-}
-#endif
 
 extern "C" int rphip_gemm_nt_f32(rphip_ctx* ctx, int64_t M, int64_t N, int64_t K, float alpha, const float* A_dev, int64_t lda,
                                  const float* B_dev, int64_t ldb, float beta, float* C_dev, int64_t ldc) {

@@ -62,28 +62,7 @@ struct rp_fit_params {
   float* dense;       // K4 (EASE): write the Gram row tile as f32 into dense[row*dense_ld + col] instead of selecting
   long long dense_ld;
   float diag_add;     // lambda, added on the diagonal of the dense Gram
-  unsigned long long* stamps;  // diagnostic build only (-DRP_STAMPS): cycles per phase, summed over tasks
 };
-
-#ifdef RP_STAMPS
-#define RP_STAMP(ph)                                                        \
-  do {                                                                      \
-    if (tid == 0) {                                                         \
-      unsigned long long _t = __builtin_amdgcn_s_memtime();                 \
-      atomicAdd(&P.stamps[ph], _t - t_last);                                \
-      t_last = _t;                                                          \
-    }                                                                       \
-  } while (0)
-#else
-#define RP_STAMP(ph) do { } while (0)
-#endif
-
-// Diagnostic builds only (make fitablate; tools/fit_ablate.py): RP_FIT_ABL removes parts of the fit kernels to attribute their time -
-// 1: no counter atomics, 2: no selection / emission (the tile is only cleared), 4: no index loads of the user rows, 8: no emission
-// of the light rows' selection, 16: their tile cleared densely, 64: static task assignment.  Results are wrong.
-#ifndef RP_FIT_ABL
-#define RP_FIT_ABL 0
-#endif
 
 // Selection key of entry (i, j), monotone in the similarity for a fixed row i:
 //   cosine (pw = 2):                 fl(c*c) * fl(1/c_j)        (nearest_neighbour.py:69-84)
@@ -160,10 +139,6 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
     sel = rp_select_carve(sel_base, W, NW, SEG, 1 << SBITS);
   }
   int* s_task = &sel.misc[RPS_USER];  // all LDS lives in the dynamic region (keeps its base 16-B aligned)
-#ifdef RP_STAMPS
-  sel.stamps = P.stamps;
-  tsel.stamps = P.stamps;
-#endif
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = P.n_tiles;
@@ -171,9 +146,6 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
   for (int w = tid; w < acc_words; w += NTHR) acc[w] = 0u;
   if (tid == 0) sel.misc[RPS_USER + 16] = 0;  // first-touch block counter (light rows)
   const int n_tasks = *P.n_tasks;
-#ifdef RP_STAMPS
-  unsigned long long t_last = __builtin_amdgcn_s_memtime();
-#endif
 
   // Tasks come from a ticket counter (heaviest first).  The NEXT task is fetched by one lane of the last
   // wave while the current one is processed (two LDS slots), so the ticket atomic and the descriptor load
@@ -181,7 +153,6 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
   // (tickets are drawn RP_TICKET_CHUNK at a time: one returning atomic on ONE word per task was the light kernel's bound - a word
   // takes a few tens of such atomics per microsecond, and 313 835 tasks at C4 spent 8 of the kernel's 10.3 ms queueing for it)
   int tk_next = 0, tk_end = 0, xq = 0;  // (live in the one thread that fetches)
-  int abl_iter = 0;
   auto fetch_task = [&](int q) {
     int* d = s_task + q * 8;
     constexpr int TCH = BYTES ? RP_TICKET_CHUNK : 1;  // (heavy tasks are long and sorted heaviest first: one at a time)
@@ -205,15 +176,11 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
         ++xq;
       }
     } else {
-      if (tk_next == tk_end && !(RP_FIT_ABL & 64)) {
+      if (tk_next == tk_end) {
         tk_next = atomicAdd(P.ticket, TCH);
         tk_end = tk_next + TCH;
       }
       ti = tk_next++;
-    }
-    if (RP_FIT_ABL & 64) {  // (diagnostic: static assignment, no ticket atomics)
-      ti = (int)blockIdx.x + abl_iter * (int)gridDim.x;
-      ++abl_iter;
     }
     if (ti < n_tasks) {
       const rp_task t = P.tasks[ti];
@@ -245,7 +212,6 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
     tk.mode = cur[5];
     par ^= 1;
     if (tid == NTHR - 64) fetch_task(par);
-    RP_STAMP(0);
     const int row = tk.row, tile = tk.tile;
     const int t0 = tile * W;
     const int n_cols = min(W, P.n_items - t0);
@@ -344,10 +310,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
           const uint16_t* src = P.x_rel + ((n > 0) ? pos : 0);  // (pos is even: a dword-aligned address)
 #pragma unroll
           for (int h = 0; h < CH / 8; ++h) {
-            if (RP_FIT_ABL & 4)
-              S.a[h] = (v4i_a4){(pos & 1023) | (((pos >> 3) & 1023) + 1024) << 16, (lane << 4) | ((lane << 5) + 7) << 16, 3 | 5 << 16, 9 | 11 << 16};
-            else
-              S.a[h] = *reinterpret_cast<const v4i_a4*>(src + 8 * h);
+            S.a[h] = *reinterpret_cast<const v4i_a4*>(src + 8 * h);
           }
         };
         auto unpack = [&](const step_t& S, int (&jv)[CH]) {  // columns inside the tile; -1 = no entry
@@ -376,11 +339,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
 #pragma unroll
             for (int e = 0; e < CH; ++e) {
               const int j = jv[e];
-              if (RP_FIT_ABL & 1) {
-                old[e] = 0xffffffffu;
-                asm volatile("" ::"v"(j));
-              } else
-                old[e] = (jv[e] >= 0) ? atomicAdd(&acc[j >> 2], 1u << (8 * (j & 3))) : 0xffffffffu;
+              old[e] = (jv[e] >= 0) ? atomicAdd(&acc[j >> 2], 1u << (8 * (j & 3))) : 0xffffffffu;
             }
             // the step's first touches are appended in ONE go: a lane counts its own (up to CH), a scan over the lanes gives it
             // its offset behind the current block's fill, new blocks are drawn with one LDS atomic for all of them (one ballot,
@@ -425,10 +384,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
             for (int e = 0; e < CH; ++e)
               if (jv[e] >= 0) {
                 const int j = jv[e];
-                if (RP_FIT_ABL & 1)
-                  asm volatile("" ::"v"(j));
-                else
-                  atomicAdd(&acc[j >> 1], 1u << (16 * (j & 1)));
+                atomicAdd(&acc[j >> 1], 1u << (16 * (j & 1)));
               }
           } else {
 #pragma unroll
@@ -449,7 +405,6 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
       if (BYTES && blk < NBLK && lane >= fill) ft_list[blk * 64 + lane] = (uint16_t)RPS_EMPTY;  // rest of the last block
       if (BYTES) n_prod_all += n_prod;  // products done by the light kernel (roofline split between the two kernels)
       __syncthreads();
-      RP_STAMP(1);
       if (!BYTES && tk.mode == 1) {
         uint32_t* dst = P.part + (int64_t)tk.slot * W;
         if constexpr (PAIRS) {
@@ -462,7 +417,6 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
             acc[w] = 0u;
           }
         }
-        RP_STAMP(2);
         continue;
       }
     } else if constexpr (CB == 32) {
@@ -507,13 +461,6 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
       }
       continue;
     }
-    if (RP_FIT_ABL & 2) {  // (diagnostic: clear and go on)
-      __syncthreads();
-      for (int w = tid; w < acc_words; w += NTHR) acc[w] = 0u;
-      if (BYTES && tid == 0) *(&sel.misc[RPS_USER + 16]) = 0;
-      __syncthreads();
-      continue;
-    }
     // ---- select
     rp_dense_src<CB> src{acc, P.inv_deg, t0, row, n_cols, P.key_pow};
     int kp;
@@ -526,7 +473,6 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
     } else {
       kp = rp_select_topk<NTHR>(src, n_cols, P.K, sel, SEG);
     }
-    RP_STAMP(3);
     if (BYTES && kp < 0) {
       // more candidates than the list holds: hand the task to the heavy kernel (it runs after this one)
       if (tid == 0) {
@@ -564,7 +510,7 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
         P.out_cnt[o + pos] = src.count(w);
       };
       if constexpr (BYTES) {
-        if (!(RP_FIT_ABL & 8)) rp_select_emit_bitmap<NTHR>(n_cols, sel, emit);  // (8: diagnostic, no emission)
+        rp_select_emit_bitmap<NTHR>(n_cols, sel, emit);
       } else if constexpr (TSEL)
         rp_select_tile_emit<NTHR>(n_cols, tsel, emit);
       else
@@ -577,15 +523,12 @@ __global__ void __launch_bounds__(NTHR, (CB == 16 ? 8 : 1)) k_itemknn_fit(rp_fit
     if constexpr (TSEL) {
       for (int w = tid; w < acc_words; w += NTHR) acc[w] = 0u;
     } else {
-      if (BYTES && (RP_FIT_ABL & 16)) {  // (16: diagnostic, dense clear instead of the list-driven one)
-        for (int w = tid; w < acc_words; w += NTHR) acc[w] = 0u;
-      } else if (BYTES)
+      if (BYTES)
         rp_select_foreach_pre<NTHR>(sel, [&](int w) { acc[w >> 2] = 0u; });
       else
         rp_select_foreach<NTHR>(n_cols, sel, [&](int w) { acc[w] = 0u; }, SEG);
       if (tid == 0 && (unsigned)(row - t0) < (unsigned)n_cols) acc[BYTES ? ((row - t0) >> 2) : (row - t0)] = 0u;
     }
-    RP_STAMP(4);
   }
   if (BYTES && P.n_products) {  // one atomic per wave and launch
     long long v = n_prod_all;
@@ -1246,15 +1189,6 @@ static int rp_gram_rows(rphip_ctx* ctx, const rphip_csr* X, const rphip_csr* Xc,
   P.dense = dense;
   P.dense_ld = dense_ld;
   P.diag_add = diag_add;
-  P.stamps = nullptr;
-#ifdef RP_STAMPS
-  {
-    void* sp = nullptr;
-    RP_TRY(rp_scratch(ctx, 6, 64 * 8, &sp));
-    P.stamps = (unsigned long long*)sp;
-    hipMemsetAsync(sp, 0, 64 * 8, st);
-  }
-#endif
   if (dense) {
     P.out_idx = nullptr;
     P.out_val = nullptr;
@@ -1299,16 +1233,6 @@ static int rp_gram_rows(rphip_ctx* ctx, const rphip_csr* X, const rphip_csr* Xc,
     hipLaunchKernelGGL((k_itemknn_fit<false, RP_LIGHT_THREADS, 8>), dim3(ctx->n_cu * per_cu), dim3(RP_LIGHT_THREADS), llds, st, L);
     RP_HIP(hipGetLastError());
     rp_time_end(ctx, ev, RPHIP_T_GRAM_TOPK_WAVE, 0.0);
-#ifdef RP_STAMPS
-    {
-      unsigned long long h[16];
-      hipMemcpyAsync(h, P.stamps, sizeof(h), hipMemcpyDeviceToHost, st);
-      hipStreamSynchronize(st);
-      fprintf(stderr, "[stamps light] cycles/1e6: ticket %.1f accumulate %.1f select %.1f emit+clear %.1f | sel: compact %.1f levels %.1f (of which histogram loops %.1f) sort %.1f classify loop %.1f rest %.1f | tasks %llu candidates %llu levels %llu\n",
-              h[0] / 1e6, h[1] / 1e6, h[3] / 1e6, h[4] / 1e6, h[8] / 1e6, (h[9] + h[14]) / 1e6, h[14] / 1e6, h[10] / 1e6, h[13] / 1e6, h[11] / 1e6, h[5], h[6], h[7]);
-      hipMemsetAsync(P.stamps, 0, 64 * 8, st);
-    }
-#endif
   }
 
   rp_time_begin(ctx, &ev);
@@ -1333,15 +1257,6 @@ static int rp_gram_rows(rphip_ctx* ctx, const rphip_csr* X, const rphip_csr* Xc,
   hipLaunchKernelGGL((k_itemknn_fit<true, RP_FIT_THREADS, 32>), dim3(grid), dim3(RP_FIT_THREADS), lds, st, P);
   RP_HIP(hipGetLastError());
   rp_time_end(ctx, ev, dense ? RPHIP_T_GRAM_DENSE : RPHIP_T_GRAM_FINALIZE, 0.0);
-#ifdef RP_STAMPS
-  {
-    unsigned long long h[16];
-    hipMemcpyAsync(h, P.stamps, sizeof(h), hipMemcpyDeviceToHost, st);
-    hipStreamSynchronize(st);
-    fprintf(stderr, "[stamps] cycles/1e6: ticket %.1f accumulate %.1f dump %.1f select %.1f emit+clear %.1f | sel: sample/compact %.1f collect/levels %.1f list/sort %.1f full/pred %.1f; full fallbacks %llu\n",
-            h[0] / 1e6, h[1] / 1e6, h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, h[8] / 1e6, h[9] / 1e6, h[10] / 1e6, h[11] / 1e6, h[12]);
-  }
-#endif
 
   if (dense) return RPHIP_OK;
   if (T > 1) {

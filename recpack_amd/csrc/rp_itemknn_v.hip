@@ -24,19 +24,6 @@
 #include "rp_select.h"
 #include "rp_wave.h"
 
-#ifdef RP_STAMPS
-#define RPV_STAMP(ph)                                                       \
-  do {                                                                      \
-    if (tid == 0) {                                                         \
-      unsigned long long _t = __builtin_amdgcn_s_memtime();                 \
-      atomicAdd(&P.stamps[ph], _t - t_last);                                \
-      t_last = _t;                                                          \
-    }                                                                       \
-  } while (0)
-#else
-#define RPV_STAMP(ph) do { } while (0)
-#endif
-
 constexpr int RP_VMERGE_THREADS = 256;
 constexpr int RP_VTILE_MAX = 12288;
 constexpr int RP_VTILE_HERMANN = 8192;  // 12 bytes per column: the sum and the number of users behind it
@@ -58,7 +45,6 @@ struct rp_vfit_params {
   double pair_decay, pair_max;
   int n_items, n_rows, n_tiles, tile_w, K, row_begin;
   const int32_t* n_rows_dev;  // when set: the number of rows in `order` (a list built on the device)
-  unsigned long long* stamps;  // diagnostic build only (-DRP_STAMPS): cycles per phase of the tiled kernel, summed over tasks
   int32_t* ticket;
   int32_t* out_idx;       // T == 1: model rows; T > 1: per-tile candidates
   double* out_val;
@@ -125,9 +111,6 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
     if (hermann) cntw[w] = 0u;
   }
   const long long n_tasks = (long long)(P.n_rows_dev ? *P.n_rows_dev : P.n_rows) * T;
-#ifdef RP_STAMPS
-  unsigned long long t_last = __builtin_amdgcn_s_memtime();
-#endif
   while (true) {
     __syncthreads();
     if (tid == 0) {
@@ -141,7 +124,6 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
     if (task >= n_tasks) break;
     const int row = P.order[task / T], tile = (int)(task % T);
     const int t0 = tile * W, n_cols = min(W, P.n_items - t0);
-    RPV_STAMP(0);
     // ---- accumulate
     // Four users per 16-lane group and round, the loads of one kind issued together: user id and left value, then the
     // slice bounds, then the first 16 entries of every slice.
@@ -187,7 +169,6 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
         for (int k = s[r] + gl + 16; k < e[r]; k += 16) add(P.x_idx[k] - t0, q[r], P.x_val[k]);
     }
     __syncthreads();
-    RPV_STAMP(1);
     // ---- with negative entries the diagonal's stored zero decides how many of them the reference keeps
     int kk = P.K;
     if (P.signed_vals) {
@@ -213,7 +194,6 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
     const int rl = row - P.row_begin;
     int kp = 0;
     if (kk > 0) kp = rp_select_topk<NTHR>(src, n_cols, kk, sel);
-    RPV_STAMP(2);
     if (T == 1) {
       const double ri = P.roww ? P.roww[row] : 1.0;
       if (kk > 0)
@@ -234,13 +214,11 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
       }
     }
     __syncthreads();
-    RPV_STAMP(3);
     for (int w = tid; w < W; w += NTHR) {  // (the diagonal is in no list)
       acc[w] = 0.0;
       if (hermann) cntw[w] = 0u;
     }
     __syncthreads();
-    RPV_STAMP(4);
   }
 }
 
@@ -696,28 +674,9 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
     const size_t lds = (size_t)W * (pair_kind == RPHIP_PAIR_HERMANN ? 12 : 8) + rp_select_smem_bytes(W);
     if (hipFuncSetAttribute((const void*)k_itemknn_fit_values, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return fail(RPHIP_EHIP);
-    P.stamps = nullptr;
-#ifdef RP_STAMPS
-    {
-      void* sp = nullptr;
-      rc = rp_scratch(ctx, 6, 64 * 8, &sp);
-      if (rc != RPHIP_OK) return fail(rc);
-      P.stamps = (unsigned long long*)sp;
-      hipMemsetAsync(sp, 0, 64 * 8, st);
-    }
-#endif
     rp_time_begin(ctx, &ev);
     hipLaunchKernelGGL(k_itemknn_fit_values, dim3(ctx->n_cu), dim3(RP_FIT_THREADS), lds, st, P);
     rp_time_end(ctx, ev, RPHIP_T_GRAM_TOPK, 0.0);
-#ifdef RP_STAMPS
-    {
-      unsigned long long h[8];
-      hipMemcpyAsync(h, P.stamps, sizeof(h), hipMemcpyDeviceToHost, st);
-      hipStreamSynchronize(st);
-      fprintf(stderr, "[stamps valued] cycles/1e6: ticket+row %.1f accumulate %.1f select %.1f emit %.1f clear %.1f (T=%d)\n", h[0] / 1e6, h[1] / 1e6,
-              h[2] / 1e6, h[3] / 1e6, h[4] / 1e6, T);
-    }
-#endif
     if (use_hash) {
       rp_vfit_params H = P;  // writes the model rows directly
       H.out_idx = m->idx;

@@ -28,9 +28,6 @@
 #include "rp_select.h"
 #include "rp_wave.h"
 
-#ifndef RP_PW_ABL
-#define RP_PW_ABL 0  // (diagnostic builds: see below)
-#endif
 constexpr int RP_PRED_THREADS = 1024;
 constexpr int RP_PRED_FIX_TILE = 15360;  // columns of an 8-byte tile + selection buffers in 160 KB of LDS
 constexpr unsigned long long RP_KEY_FLIP = 0x8000000000000000ull;  // two's complement sum -> order-preserving u64 key
@@ -421,11 +418,6 @@ __global__ void __launch_bounds__(RP_PRED_THREADS, HC8 == 2 ? 8 : 4) k_predict_t
           if ((unsigned)j < (unsigned)n_cols) clear(j);
         }
         __syncthreads();
-      }
-      if (DENSE && (RP_PW_ABL & 1024)) {  // (diagnostic: K9 without its selection)
-        for (int w = tid; w < n_cols; w += RP_PRED_THREADS) clear(w);
-        __syncthreads();
-        continue;
       }
       // ---- select (top-Kp: the scores of one user share their sign and most exponent bits - dropped first)
       rp_score_src<DENSE> src{smem, t0, P.mode == 0 ? P.keep : nullptr, 0, &P, -INFINITY};
@@ -1043,24 +1035,10 @@ struct rp_pw_params {
   int32_t* out_idx;
   float* out_val;
   int32_t* out_nnz;
-  unsigned long long* stamps;  // -DRP_STAMPS only
 };
 
-#ifndef RP_STAMPS
-#define PW_STAMP(ph) do { } while (0)
-#define PW_COUNT(ph, n) do { } while (0)
-#endif
 
 typedef int v4i_a4 __attribute__((ext_vector_type(4), aligned(4)));
-
-// Diagnostic builds only (make ablate; tools/k8_ablate.py): RP_PW_ABL removes parts of the wave kernel to attribute its time -
-// 1: no sum atomics, 2: no walk, 4: no dirty-map atomics, 8: no entry loads, 16: no owner search in the chunk assignment,
-// 32: no adds at all, 64: no final cut and no column ranking of the output row, 128: no chunk assignment (empty units), 256: no gathers of the tile offsets (uniform 8-entry slices), 512: the offsets of 64 hot rows,
-// 1024: the dense kernel (K9) without its selection (517.8 against 542.8 ms for 200K users at 100K items).  Results are
-// wrong by construction.
-#ifndef RP_PW_ABL
-#define RP_PW_ABL 0
-#endif
 
 template <typename AccT>
 struct rp_pw_state {
@@ -1072,15 +1050,8 @@ struct rp_pw_state {
   rp_fix_scale fix;  // 64-bit sums: the call's scale
   float fmul;        // 32-bit sums: 2^ushift, this user's scale
   int ushift;
-#ifdef RP_STAMPS
-  unsigned long long t_last, t_ph[8];
-#endif
 };
 
-#ifdef RP_STAMPS
-#define PW_STAMP(ph) do { unsigned long long _t = __builtin_amdgcn_s_memtime(); S.t_ph[ph] += _t - S.t_last; S.t_last = _t; } while (0)
-#define PW_COUNT(ph, n) do { S.t_ph[ph] += (n); } while (0)
-#endif
 
 template <typename AccT, bool WGT, bool MAP = true>
 __device__ __forceinline__ void rp_pw_add_chunk(rp_pw_state<AccT>& S, int n, const v4i_a4& a, const v4i_a4& b, int t0, double xw) {
@@ -1103,12 +1074,10 @@ __device__ __forceinline__ void rp_pw_add_chunk(rp_pw_state<AccT>& S, int n, con
       v = rp_f64_to_fix((double)__int_as_float(bits) * xw, S.fix);
     else
       v = rp_f32_to_fix(bits, S.fix);
-    if (!(RP_PW_ABL & 1)) atomicAdd((AccT*)&S.acc[j], v);
-    if (RP_PW_ABL & 1) asm volatile("" ::"v"(v));
+    atomicAdd((AccT*)&S.acc[j], v);
     if constexpr (MAP) {
       const uint32_t bit = on ? (1u << ((j >> 6) & 31)) : 0u;
-      if (!(RP_PW_ABL & 4)) atomicOr((uint32_t*)&S.dirty[(j & 63) + 64 * (j >> 11)], bit);  // word (j mod 64) of the tile's (j / 2048)-th map
-      if (RP_PW_ABL & 4) asm volatile("" ::"v"(bit));
+      atomicOr((uint32_t*)&S.dirty[(j & 63) + 64 * (j >> 11)], bit);  // word (j mod 64) of the tile's (j / 2048)-th map
     }
   }
 }
@@ -1234,14 +1203,9 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
     valid3 = (h < he) && (t < NT);
   };
   auto load_offs = [&](int it, int t) __attribute__((always_inline)) {
-    const uint16_t* to = P.toff + (long long)((RP_PW_ABL & 512) ? (max(it, 0) & 63) : max(it, 0)) * (NT + 1) + min(t, NT - 1);  // (512: diagnostic, 64 hot rows)
-    if (RP_PW_ABL & 256) {  // (diagnostic: no offset gathers - every slice is entries 8 t .. 8 t + 8 of its list)
-      raw_oa = 8 * min(t, NT - 1);
-      raw_ob = raw_oa + 8;
-    } else {
-      raw_oa = (int)to[0];
-      raw_ob = (int)to[1];
-    }
+    const uint16_t* to = P.toff + (long long)max(it, 0) * (NT + 1) + min(t, NT - 1);
+    raw_oa = (int)to[0];
+    raw_ob = (int)to[1];
   };
   // Entries of one unit.  Chunk c of the batch goes to lane c % 64 of step c / 64.  Owner of chunk c = the largest lane whose
   // first chunk is <= c: every owner writes its lane id at its first chunk's slot of a 64 ST-word LDS scratch (the cut's
@@ -1250,11 +1214,6 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
   // round trips per unit whatever ST is.  Steps beyond the unit's chunks issue nothing.
   auto fetch = [&](rp_pw_uset<ST>& D, int it, int oa, int ob, double wt) __attribute__((always_inline)) {
     RP_LDS uint32_t* sc = S.pool.hist;
-    if (RP_PW_ABL & 128) {  // (diagnostic: no chunk assignment at all - the unit stays empty)
-      D.nchunks = 0;
-      asm volatile("" ::"v"(it), "v"(oa), "v"(ob));
-      return;
-    }
     D.s = (it >= 0) ? it * K + oa : 0;
     D.len = (it >= 0) ? ob - oa : 0;
     const int nch = (D.len + PW_CH - 1) / PW_CH;
@@ -1275,17 +1234,12 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
       own[st] = rp_wave_incl_max(max(own[st], (lane == 0) ? carry : 0));
       carry = __builtin_amdgcn_readlane(own[st], 63);
     }
-    if (RP_PW_ABL & 16) {  // (diagnostic: no owner search)
-#pragma unroll
-      for (int st = 0; st < ST; ++st) own[st] = lane;
-    }
     int us[ST], ulen[ST], co[ST];
 #pragma unroll
     for (int st = 0; st < ST; ++st) {
       us[st] = __shfl(D.s, own[st]);
       ulen[st] = __shfl(D.len, own[st]);
       co[st] = __shfl(D.choff, own[st]);
-      if (RP_PW_ABL & 16) co[st] = 64 * st + lane;  // (diagnostic: every lane reads the head of its own slice)
       if (WGT) D.w[st] = __shfl(wt, own[st]);
     }
 #pragma unroll
@@ -1362,17 +1316,12 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
     fetch(N, it1, oa1, ob1, wt1);  // entries of unit k+1
     load_offs(it2, t2c);           // offsets of unit k+2
     load_ids(t3c, g3c);            // ids of unit k+3
-    PW_STAMP(4);
     // ---- unit k: adds
     const int t0 = t0c * WT;
     touched |= C.nchunks > 0;
 #pragma unroll
     for (int st = 0; st < ST; ++st)
-      if (64 * st < C.nchunks && !(RP_PW_ABL & 32)) rp_pw_add_chunk<AccT, WGT, !ONE>(S, C.n[st], C.a[st], C.b[st], t0, C.w[st]);
-    if (RP_PW_ABL & 32) {  // (diagnostic: the entries are still waited for)
-#pragma unroll
-      for (int st = 0; st < ST; ++st) asm volatile("" ::"v"(C.a[st]), "v"(C.b[st]));
-    }
+      if (64 * st < C.nchunks) rp_pw_add_chunk<AccT, WGT, !ONE>(S, C.n[st], C.a[st], C.b[st], t0, C.w[st]);
     if (C.nchunks > 64 * ST)  // (rare; sets map bits, which the ONE form never reads: it scans such a tile densely)
       rp_pw_extra_steps<AccT, WGT>(S.acc, S.dirty, S.pool.hist, S.pairs_i, S.fix, S.fmul, lane, C.s, C.len, C.choff, C.nchunks, t0, wt0,
                                    64 * ST);
@@ -1380,9 +1329,7 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
       const int j = it0 - t0;
       if ((unsigned)j < (unsigned)WT) atomicOr((uint32_t*)&excl[(j & 63) + 64 * (j >> 11)], 1u << ((j >> 6) & 31));
     }
-    PW_STAMP(1);
     if (g0c != G - 1) return;  // more batches of this tile to come
-    if (RP_PW_ABL & 2) return;
     // ---- end of tile t0c: offer the touched columns to the pool.  Lane l walks the set bits of dirty word l (word l
     // covers columns l, l+64, ..: the lanes' reads of one round fall into different LDS banks), four set bits per lane and
     // round so that the sums of a round are read with one wait
@@ -1409,7 +1356,6 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
 #pragma unroll
       for (int q = 0; q < 4; ++q) live |= __any(kq[q]) ? (1u << q) : 0u;
       if (!live) return;
-      PW_STAMP(2);
       // the round's survivors in one go when they fit the pool as it is (the common case: a few of them); slot by slot
       // with cuts in between otherwise
       const uint64_t m0 = __ballot(kq[0]), m1 = __ballot(kq[1]), m2 = __ballot(kq[2]), m3 = __ballot(kq[3]);
@@ -1441,7 +1387,6 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
           S.pool.pay[pos] = (uint32_t)(t0 + j[3]);
         }
         S.pool.n = base + c3n;
-        PW_STAMP(7);
         return;
       }
 #pragma unroll 1
@@ -1450,14 +1395,7 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
           const uint32_t col = (uint32_t)(t0 + j[0]);
           // the threshold may have moved since the vote (a cut inside an earlier push): ask again
           const bool keep = kq[0] && rp_wpool_admits<AccT, 0>(S.pool, v[0], col);
-#ifdef RP_STAMPS
-          const int n_before = S.pool.n;
-          const unsigned long long t_push = __builtin_amdgcn_s_memtime();
-#endif
           rp_wpool_push<AccT, 0>(S.pool, Kp, cap, keep, v[0], col, lane);
-#ifdef RP_STAMPS
-          if (S.pool.n < n_before) PW_COUNT(6, __builtin_amdgcn_s_memtime() - t_push);  // a cut happened: its cycles
-#endif
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -1466,7 +1404,6 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
           v[r] = v[r + 1];
         }
       }
-      PW_STAMP(7);
     };
     if constexpr (ONE) {
       RP_WAVE_FENCE();
@@ -1475,7 +1412,6 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
         if ((unsigned)jx < (unsigned)WT) S.acc[jx] = 0;
         RP_WAVE_FENCE();
       }
-      PW_STAMP(5);
       if (C.nchunks > 64 * ST) {
         // more chunks than the prefetched steps hold (rp_pw_extra_steps added the rest): every column of the tile is looked at
 #pragma unroll 1
@@ -1514,13 +1450,11 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
           }
         }
       }
-      PW_STAMP(2);
       return;
     }
     const bool was_touched = touched;
     touched = false;
     RP_WAVE_FENCE();
-    PW_STAMP(5);
     // the lane's map words as ONE 64-bit word (DW <= 2): bit b is column lane + 64 b of the tile.  Walking the two words one
     // after the other ran as many rounds as the fullest lane of EACH needed; together the lanes' loads even out
     static_assert(DW <= 2, "one 64-bit map word per lane");
@@ -1566,7 +1500,6 @@ __device__ __forceinline__ void rp_pw_user_units(const rp_pw_params& P, rp_pw_st
         }
       }
     }
-    PW_STAMP(2);
   };
   for (int k = 0; k < NU; k += 2) {
     unit(set0, set1);
@@ -1611,10 +1544,6 @@ __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
   for (int i = lane; i < WT; i += 64) S.acc[i] = 0;
 #pragma unroll
   for (int d = 0; d < 2 * DW; ++d) S.dirty[lane + 64 * d] = 0u;
-#ifdef RP_STAMPS
-  S.t_last = __builtin_amdgcn_s_memtime();
-  for (int _p = 0; _p < 8; ++_p) S.t_ph[_p] = 0;
-#endif
 
   while (true) {
     int ubase = 0;
@@ -1644,15 +1573,14 @@ __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
       S.pool.n = 0;
       S.pool.tau = 0;
       S.pool.tau_col = 0;
-      PW_STAMP(0);
       if (he - hs <= 64)
         rp_pw_user_units<AccT, WT, WGT, (WT > PW_WT ? 3 : 2), true>(P, S, hs, he);
       else
         rp_pw_user_units<AccT, WT, WGT, (WT > PW_WT ? 3 : 2), false>(P, S, hs, he);
       // ---- final: best Kp by (score desc, column asc), then column order for the output row
       RP_WAVE_FENCE();
-      if (S.pool.n > Kp && !(RP_PW_ABL & 64)) rp_wpool_cut<AccT, 0>(S.pool, Kp, lane);
-      const int n_out = (RP_PW_ABL & 64) ? min(S.pool.n, Kp) : S.pool.n;
+      if (S.pool.n > Kp) rp_wpool_cut<AccT, 0>(S.pool, Kp, lane);
+      const int n_out = S.pool.n;
       RP_LDS AccT* pk = S.pool.key;
       RP_LDS uint32_t* pp = S.pool.pay;
       if (lane < 4) pp[n_out + lane] = 0xffffffffu;  // pads the last group of four (n_out + 4 <= cap)
@@ -1660,8 +1588,7 @@ __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
       for (int e = lane; e < n_out; e += 64) {
         const uint32_t col = pp[e];
         int rank = 0;
-        if (RP_PW_ABL & 64) rank = e;
-        for (int o = 0; o < ((RP_PW_ABL & 64) ? 0 : n_out); o += 4) {
+        for (int o = 0; o < n_out; o += 4) {
           const v4u q = *reinterpret_cast<RP_LDS v4u*>(&pp[o]);
           rank += (q.x < col ? 1 : 0) + (q.y < col ? 1 : 0) + (q.z < col ? 1 : 0) + (q.w < col ? 1 : 0);
         }
@@ -1673,13 +1600,6 @@ __global__ void __launch_bounds__(64) k_predict_wave(rp_pw_params P) {
       }
       if (lane == 0) P.out_nnz[ul] = n_out;
       RP_WAVE_FENCE();
-      PW_STAMP(3);
-#ifdef RP_STAMPS
-      if (lane == 0) {
-        for (int _p = 0; _p < 8; ++_p) atomicAdd(&P.stamps[_p], S.t_ph[_p]);
-      }
-      for (int _p = 0; _p < 8; ++_p) S.t_ph[_p] = 0;
-#endif
     }
   }
 }
@@ -2045,15 +1965,6 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
     W.out_idx = idx_dev;
     W.out_val = val_dev;
     W.out_nnz = nnz_dev;
-    W.stamps = nullptr;
-#ifdef RP_STAMPS
-    {
-      void* sp = nullptr;
-      RP_TRY(rp_scratch(ctx, 6, 64 * 8, &sp));
-      W.stamps = (unsigned long long*)sp;
-      hipMemsetAsync(sp, 0, 64 * 8, st);
-    }
-#endif
     // waves per CU: 12 for the 2048-column tiles of the 32-bit sums (the kernel's registers allow three waves per SIMD), 8 else
     const int acc_b = x32 ? 4 : 8;
     int wpc = (x32 && wt == PW_WT) ? 12 : 8;
@@ -2079,16 +1990,6 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
     else
       launch(k_predict_wave<uint32_t, PW_WT, false>);
     RP_HIP(hipGetLastError());
-#ifdef RP_STAMPS
-    {
-      unsigned long long h[8];
-      hipMemcpyAsync(h, W.stamps, sizeof(h), hipMemcpyDeviceToHost, st);
-      hipStreamSynchronize(st);
-      fprintf(stderr, "[stamps predict_wave] cycles/1e6: setup %.1f | per tile: prepare %.1f adds %.1f exclusion+dirty %.1f walk %.1f | final %.1f "
-                      "(grid %d); of the walk: push loops %.1f, of which pushes with a pool cut %.1f\n",
-              h[0] / 1e6, h[4] / 1e6, h[1] / 1e6, h[5] / 1e6, (h[2] + h[7]) / 1e6, h[3] / 1e6, wg, h[7] / 1e6, h[6] / 1e6);
-    }
-#endif
     rp_time_end(ctx, ev, model->kind == RPHIP_MODEL_DENSE ? RPHIP_T_PREDICT_DENSE : RPHIP_T_PREDICT, rp_pred_work(Xpred, model, n, Kp));
     return RPHIP_OK;
   }

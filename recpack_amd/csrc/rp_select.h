@@ -31,23 +31,7 @@ struct rp_select_smem {
   uint32_t* scol;  // RP_SORT_CAP
   uint16_t* list;  // rp_list_cap(n_slots) entries: wave w owns [w*per_wave, (w+1)*per_wave)
   int* misc;       // RPS_MISC_INTS ints
-#ifdef RP_STAMPS
-  unsigned long long* stamps;  // diagnostic build: [8]=compaction [9]=radix levels [10]=sort [11]=predicate
-#endif
 };
-
-#ifdef RP_STAMPS
-#define RPS_STAMP(ph)                                         \
-  do {                                                        \
-    if (threadIdx.x == 0 && s.stamps) {                       \
-      unsigned long long _t = __builtin_amdgcn_s_memtime();   \
-      atomicAdd(&s.stamps[ph], _t - ts_last);                 \
-      ts_last = _t;                                           \
-    }                                                         \
-  } while (0)
-#else
-#define RPS_STAMP(ph) do { } while (0)
-#endif
 
 constexpr int RPS_MISC_INTS = 96;
 constexpr int RPS_FLAG = 0x8000;
@@ -83,9 +67,6 @@ __device__ __forceinline__ rp_select_smem rp_select_carve(char* base, int n_slot
   s.scol = reinterpret_cast<uint32_t*>(base + (size_t)(bins / 4) * 8);
   s.list = reinterpret_cast<uint16_t*>(base + (size_t)bins * 4);
   s.misc = reinterpret_cast<int*>(base + (size_t)bins * 4 + list_entries * 2);
-#ifdef RP_STAMPS
-  s.stamps = nullptr;
-#endif
   return s;
 }
 
@@ -152,9 +133,6 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
   const int seg = seg_cap ? seg_cap : per_wave;
   auto lpos = [&](int e) { return rp_list_pos<NW, PRE>(wave, seg, e); };
 
-#ifdef RP_STAMPS
-  unsigned long long ts_last = __builtin_amdgcn_s_memtime();
-#endif
   // ---- 1. compaction
   int cnt = 0;       // list entries this wave visits
   int n_mine = 0;    // candidates among them
@@ -197,13 +175,6 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
   }
   const int kprime = min(K, n_valid);
   __syncthreads();
-  RPS_STAMP(8);
-#ifdef RP_STAMPS
-  if (threadIdx.x == 0 && s.stamps) {
-    atomicAdd(&s.stamps[5], 1ull);
-    atomicAdd(&s.stamps[6], (unsigned long long)n_valid);
-  }
-#endif
 
   // outcome of the radix levels: the boundary bin (prefix fin_pkey/fin_pcol down to fin_shift) holds fin_group
   // candidates of which fin_need are selected
@@ -242,9 +213,6 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
       bool is_col;
       rp_level<BITS>(level, &shift, &width, &is_col);
       const int nb = 1 << width;
-#ifdef RP_STAMPS
-      if (threadIdx.x == 0 && s.stamps) atomicAdd(&s.stamps[7], 1ull);
-#endif
       for (int i = tid; i < BINS; i += NTHR) s.hist[i] = 0;
       if (tid == 0) {
         s.misc[RPS_BIN] = -1;
@@ -284,7 +252,6 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
         entries4(e0, sl, ok, kk, ic, true);
         hist4(ok, kk, ic);
       }
-      RPS_STAMP(14);
       __syncthreads();
       // find the bin where the count from the top reaches `need`: thread t owns BPT bins, descending
       {
@@ -345,7 +312,6 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
     }
   }
 
-  RPS_STAMP(9);
   // ---- 3. fused classification pass: one key evaluation per candidate.  Above the boundary bin -> flagged now;
   // members of the bin -> flagged (whole bin selected) or gathered with their list position for the exact step.
   int wc = 0;
@@ -396,10 +362,8 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
     entries4(e0, sl, ok, kk, ic, have_fin);
     classify4(e0, sl, ok, kk, ic);
   }
-  RPS_STAMP(13);
   if (lane == 0) s.misc[RPS_RED + wave] = wc;
   __syncthreads();
-  RPS_STAMP(11);
   if (have_fin && !fin_all) {
     // ---- 4. exact order of the boundary bin's members: the fin_need best of them are selected too
     const int group = fin_group, need = fin_need;
@@ -465,7 +429,6 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
       }
     }
     __syncthreads();
-    RPS_STAMP(10);
   }
   if (tid == 0) {
     int off = 0;
@@ -476,7 +439,6 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
     s.misc[RPS_NSEL] = off;
   }
   __syncthreads();
-  RPS_STAMP(11);
   return kprime;
 }
 
@@ -611,9 +573,6 @@ struct rp_tsel_smem {
   int* misc;         // RPS_MISC_INTS
   uint64_t* lkey;    // [RP_TSEL_LIST] keys of the collected candidates
   uint16_t* lslot;   // [RP_TSEL_LIST] their slots
-#ifdef RP_STAMPS
-  unsigned long long* stamps;  // diagnostic build: [8]=sample [9]=collect [10]=exact on the list [11]=full fallback, [12]=fallbacks
-#endif
 };
 
 __host__ __device__ constexpr size_t rp_tsel_smem_bytes(int n_slots) {
@@ -865,9 +824,6 @@ __device__ int rp_select_tile(const Src& src, int n_slots, int K, rp_tsel_smem s
   constexpr int BPT = RP_HIST_BINS / NTHR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   auto mark_tile = [&](int w) { atomicOr(&s.bitmap[w >> 5], 1u << (w & 31)); };
-#ifdef RP_STAMPS
-  unsigned long long ts_last = __builtin_amdgcn_s_memtime();
-#endif
   int shift0, width0;
   bool is_col0;
   rp_level(0, &shift0, &width0, &is_col0);
@@ -911,7 +867,6 @@ __device__ int rp_select_tile(const Src& src, int n_slots, int K, rp_tsel_smem s
     }
     __syncthreads();
   }
-  RPS_STAMP(8);
   const int dstar = s.misc[RPS_BIN];  // -1: the sample holds fewer than `want` candidates - collect everything
   // ---- collect
   int mine = 0;
@@ -935,7 +890,6 @@ __device__ int rp_select_tile(const Src& src, int n_slots, int K, rp_tsel_smem s
   for (int w2 = 0; w2 < NW; ++w2) n_valid += s.misc[RPS_RED + w2];
   const int n_list = s.misc[RPS_CNT];
   __syncthreads();
-  RPS_STAMP(9);
   if (n_valid <= K) {  // fewer candidates than K: all of them
     for (int w = tid; w < n_slots; w += NTHR)
       if (src.valid(w)) mark_tile(w);
@@ -946,14 +900,9 @@ __device__ int rp_select_tile(const Src& src, int n_slots, int K, rp_tsel_smem s
     rp_tlist_src<Src> ls{&src, s.lkey, s.lslot, n_list};
     const uint16_t* lslot = s.lslot;
     const int kp = rp_select_tile_full<NTHR>(ls, n_list, K, s, [&](int p) { mark_tile((int)lslot[p]); });
-    RPS_STAMP(10);
     return kp;
   }
   const int kp = rp_select_tile_full<NTHR>(src, n_slots, K, s, mark_tile);
-  RPS_STAMP(11);
-#ifdef RP_STAMPS
-  if (threadIdx.x == 0 && s.stamps) atomicAdd(&s.stamps[12], 1ull);
-#endif
   return kp;
 }
 

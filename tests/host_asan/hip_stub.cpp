@@ -1,6 +1,8 @@
-// Test infrastructure: a HOST stand-in for the few HIP runtime entry points rp_api.hip's host code calls, so that the library's
-// host logic (context, block cache, grow-only scratch, timing bookkeeping, option and argument validation) can run under
-// AddressSanitizer on a machine without a GPU (sanitizers belong on the CPU build).  "Device" memory is
+// Test infrastructure: a HOST stand-in for the HIP runtime entry points the library's host code calls, so that its host logic - context,
+// block cache, grow-only scratch, timing bookkeeping, option and argument validation (rp_api.hip) and, round 6, the whole host
+// orchestration of the fits and predicts (rp_csr / rp_itemknn* / rp_predict* / rp_ease / rp_ease_dist: plans, streams, events, plane and
+// block caches, collectives on a loop-back communicator, agreed allocations) - can run under AddressSanitizer and
+// UndefinedBehaviorSanitizer on a machine without a GPU (sanitizers belong on the CPU build).  "Device" memory is
 // malloc'ed host memory; streams and events are counters; kernels are never launched.
 #include <hip/hip_runtime_api.h>
 #include <stdlib.h>
@@ -29,7 +31,7 @@ hipError_t hipMalloc(void** p, size_t n) {
     *p = nullptr;
     return hipErrorOutOfMemory;
   }
-  *p = malloc(n ? n : 1);
+  *p = calloc(n ? n : 1, 1);  // (zeroed: the host reads counts and flags back that no kernel ever wrote)
   if (!*p) return hipErrorOutOfMemory;
   g_live.insert(*p);
   return hipSuccess;
@@ -54,6 +56,18 @@ hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 1.0f; return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
+hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) {
+  *total_b = (size_t)288 << 30;
+  *free_b = (size_t)200 << 30;
+  return hipSuccess;
+}
+hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t) {
+  for (size_t r = 0; r < h; ++r) memcpy((char*)d + r * dp, (const char*)s + r * sp, w);
+  return hipSuccess;
+}
 hipError_t hipGetLastError(void) { return hipSuccess; }
 const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "stub error"; }
 // what a host-only compile of a file with kernels still references
@@ -62,5 +76,7 @@ void __hipUnregisterFatBinary(void**) {}
 void __hipRegisterFunction(void**, const void*, char*, const char*, unsigned, void*, void*, void*, void*, int*) {}
 hipError_t __hipPushCallConfiguration(dim3, dim3, size_t, hipStream_t) { return hipSuccess; }
 hipError_t __hipPopCallConfiguration(dim3*, dim3*, size_t*, hipStream_t*) { return hipSuccess; }
-hipError_t hipLaunchKernel(const void*, dim3, dim3, void**, size_t, hipStream_t) { return hipSuccess; }
+static long g_launches = 0;
+hipError_t hipLaunchKernel(const void*, dim3, dim3, void**, size_t, hipStream_t) { ++g_launches; return hipSuccess; }
+long stub_launches() { return g_launches; }
 }

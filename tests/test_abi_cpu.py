@@ -124,8 +124,8 @@ def test_post_condition_warnings():
 
 def test_k_limit_raises_before_upload():
     """What is left of the K limit (a documented deviation: the reference takes any K) raises ValueError on the host: K x column tiles
-    >= 32 768 over several tiles (round 5; any K on one tile since round 4) - tiles of 25 600 items for the binary fit, of 12 288 with
-    normalize_X."""
+    >= 32 768 over several tiles of 12 288 items with normalize_X.  The binary fit takes any K at any item count since round 6 (the call
+    reaches the device: without one it fails there, not on a host-side limit)."""
     import scipy.sparse as sp
     import torch
 
@@ -135,8 +135,9 @@ def test_k_limit_raises_before_upload():
 
     X = sp.random(50, RP_TILE_MAX + 400, density=0.002, format="csr", random_state=0)
     X.data[:] = 1
-    with pytest.raises(ValueError, match="32768"):
-        recpack_amd.ItemKNN(K=16384).fit(X)  # two column tiles: 2 x 16 384 slots
+    if not torch.cuda.is_available():
+        with pytest.raises(RecpackHipError):
+            recpack_amd.ItemKNN(K=16384).fit(X)  # two column tiles, 2 x 16 384 candidates: the large-K merge, no host-side limit
     if not torch.cuda.is_available():  # below that no host-side limit: the call reaches the (absent) device
         with pytest.raises(RecpackHipError):
             recpack_amd.ItemKNN(K=RP_K_MAX + 1).fit(X)
@@ -198,10 +199,12 @@ def test_fitted_models_pickle_round_trip(tmp_path):
 
 
 def test_host_code_under_asan():
-    """sanitizers belong on the CPU build.  `make -C recpack_amd/csrc asan` compiles the HOST side of rp_api.hip
-    (context, block cache with event-carrying frees, grow-only scratch, options, timing bookkeeping, argument validation) with
-    -fsanitize=address against a stub HIP runtime (tests/host_asan/hip_stub.cpp: malloc'ed "device" memory, no kernels) and
-    tests/host_asan/driver.cpp exercises it: exit code 0 = every check held, ASan and LeakSanitizer silent."""
+    """sanitizers belong on the CPU build.  `make -C recpack_amd/csrc asan` compiles the HOST side of EVERY source
+    with -fsanitize=address,undefined against a stub HIP runtime (tests/host_asan/hip_stub.cpp: calloc'ed "device" memory, kernels are
+    no-ops) and tests/host_asan/driver.cpp exercises it: rp_api.hip's context, block cache, scratch, options and timing bookkeeping,
+    and (round 6) the host orchestration of the fits and predicts - K0, the ItemKNN plans (any K), rp_spd_inverse's streams / events /
+    plane cache, the distributed solve and its three predict routes on a loop-back communicator with two and three ranks, COO
+    ingestion.  Exit code 0 = every check held, ASan, UBSan and LeakSanitizer silent, no "device" block left behind."""
     import shutil
     import subprocess
 
