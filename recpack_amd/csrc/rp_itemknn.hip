@@ -89,6 +89,8 @@ struct rp_dense_src {
   }
   __device__ __forceinline__ bool valid(int w) const { return count(w) != 0u && (t0 + w) != row; }
   __device__ __forceinline__ uint64_t key(int w) const { return rp_fit_key(count(w), inv_deg[t0 + w], key_pow); }
+  __device__ __forceinline__ double colw(int w) const { return inv_deg[t0 + w]; }
+  __device__ __forceinline__ uint64_t key_w(int w, double cw) const { return rp_fit_key(count(w), cw, key_pow); }
   __device__ __forceinline__ uint32_t col(int w) const { return (uint32_t)(t0 + w); }
 };
 

@@ -22,6 +22,8 @@
 //      bitonic sort otherwise): the best of them are flagged too; a scan over the waves' counts orders the emit.
 // Every candidate is classified exactly - no sampling, no tolerance.
 #pragma once
+#include <type_traits>
+#include <utility>
 
 #include "rp_common.h"
 
@@ -115,6 +117,14 @@ enum {
 // rp_select_emit_sorted / rp_select_foreach with the same seg_cap.
 // NCACHE: the (slot, key, ~column) of a lane's first 4 * NCACHE list entries stay in registers from the first radix level on - a key
 // costs a global gather (the column weight), and the levels and the classification pass would each evaluate it again.
+// a selection source whose key is (slot-local data) x (a weight gathered from global memory) may expose the two halves apart:
+//   double colw(slot)            the gathered weight (any slot < n_slots is a valid address, wanted or not)
+//   uint64_t key_w(slot, colw)   the key from it
+template <class S, class = void>
+struct rp_src_has_colw : std::false_type {};
+template <class S>
+struct rp_src_has_colw<S, std::void_t<decltype(std::declval<const S&>().colw(0))>> : std::true_type {};
+
 template <int NTHR, class Src, bool PRE = false, int BITS = 11, int NCACHE = 0>
 __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem s, int seg_cap = 0, int pre_cnt = 0,
                               bool pre_over = false, int pre_blocks = 0) {
@@ -195,8 +205,20 @@ __device__ int rp_select_topk(const Src& src, int n_slots, int K, rp_select_smem
       sl[u] = (e < cnt) ? (int)s.list[lpos(e)] : RPS_EMPTY;
       ok[u] = PRE ? sl[u] != RPS_EMPTY : e < cnt;
     }
+    if constexpr (rp_src_has_colw<Src>::value) {
+      // (round 6) the key's global operand - the column weight - of all four entries is REQUESTED before the first key is formed, and
+      // unconditionally (a lane without an entry reads slot 0): with the load inside `ok ? key(slot) : 0` every gather sat behind its
+      // own branch and the compiler put s_waitcnt vmcnt(0) in front of each use - eight dependent L2 round trips per thread in the
+      // light rows' selection, a third of that kernel
+      double cw[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) kk[u] = (ok[u] && want_key) ? src.key(sl[u]) : 0ull;
+      for (int u = 0; u < 4; ++u) cw[u] = src.colw(ok[u] ? sl[u] : 0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kk[u] = (ok[u] && want_key) ? src.key_w(sl[u], cw[u]) : 0ull;
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kk[u] = (ok[u] && want_key) ? src.key(sl[u]) : 0ull;
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) ic[u] = ok[u] ? ~src.col(sl[u]) : 0u;
   };
