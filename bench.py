@@ -19,10 +19,17 @@ Prints one JSON line (rank 0).  `roofline` is the dominant kernel's: the EASE so
 plane products per fp32-equivalent product; `frac_n3_model` states the plain n^3 model beside it); `roofline_hbm` prices the HBM-bound
 ItemKNN kernel with the longest launch (K8) with its algorithmic byte model (4*P-model for the SpGEMM instances,
 8*K*nnz-model for predict) against 8 TB/s - its `legs` hold all three ItemKNN kernels, `spgemm_all_kernels` the whole K1-K3 group;
-`k9_predict` prices K9 by the bytes it streams; `cold_first_step_s` is the first step of the fresh context; `cpu_baseline` = the
+`k9_predict` prices K9 by the bytes it streams; `parity` = the parity gates of SURVEY.md §8(d), checked AFTER the timed steps on the models the
+last step left (384 random rows of the ItemKNN model bit-identical to the oracle's; the whole-matrix probe of the EASE model, oracle/ease_probe.py:
+two random float64 probes through (X^T X + l2 I)(I - B) must give the same 1 / P_jj for every item, bar 1e-4) - a failed gate changes `status`;
+`itemknn_c2` / `ease_c3` = BASELINE.json's configs[1] / [2] outside the timed step; `roofline_hbm.spgemm_all_kernels.{traffic,
+measured_fabric_GBps}` = the counter-side bytes of the K1-K3 kernels (committed PMC pass) over this run's time;
+`cold_first_step_s` is the first step of the fresh context; `cpu_baseline` = the
 reference-shaped route (sklearn cosine + per-row argpartition loop, float64 np.linalg.inv) timed on a bounded sample on the host's
 cores and scaled, with the oracle's own vectorised route under `port`.  `status` is "ok" or names what failed; a failed or
-timed-out run exits non-zero.
+timed-out run exits non-zero.  N > 1: every way out leaves a status line on rank 0 - a rank that fails writes a note beside the rendezvous
+that rank 0's watcher thread turns into the line (phase, rank, reason, the last collective entered); watchdogs cover the communicator set-up, the
+transport self-test and the timed region.
 """
 import argparse
 import json
