@@ -75,6 +75,9 @@ def parse():
                     help="N > 1: auto = the owner route (int8 rows gathered, exact sums by the columns' owners), then the gathered model, then "
                          "columns sharded; owner = that route or an error; gather = round 5's first route (the full model gathered)")
     ap.add_argument("--selftest", action="store_true", help="N = 1: run the transport self-test on a one-rank RCCL communicator too (N > 1: always)")
+    ap.add_argument("--inject-failure-rank", type=int, default=-1,
+                    help="test hook (tests/test_gpu_ease.py): this rank raises in its first warm-up step - the line rank 0 then prints is what is tested")
+    ap.add_argument("--inject-failure-hard", action="store_true", help="test hook: the injected failure is a silent os._exit(9), as a crash would be")
     ap.add_argument("--timeout", type=float, default=1500.0,
                     help="seconds the timed region (warm-up + steps) may take; past it every rank prints what it has with status "
                          "'timeout' and exits with code 3")
@@ -545,6 +548,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         args.gpus = world
+    # (rank notes of an earlier run that used the same rendezvous port must be gone BEFORE the process group comes up - its set-up is
+    # the barrier behind which rank 0 starts to watch for them)
+    note_base = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"recpack_bench_{os.environ.get('MASTER_PORT', '0')}")
+    if world > 1:
+        import glob
+
+        for fn in ((glob.glob(note_base + ".rank*") + [note_base + ".ack"]) if rank == 0 else [f"{note_base}.rank{rank}"]):
+            try:
+                os.remove(fn)
+            except OSError:
+                pass
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     # RECPACK_DIST_BACKEND=gloo lets N ranks share the GPUs that are there (functional test of the sharded path on a
@@ -603,18 +617,47 @@ def main():
     # polls for such notes from a thread and, when one appears while it is itself stuck in a collective the dead rank will never
     # join, prints the line - status, phase, the rank and its reason - and exits non-zero.  A watchdog covers the set-up and the
     # self-test too (the timed region has its own).
-    note_base = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"recpack_bench_{os.environ.get('MASTER_PORT', '0')}")
-    if world > 1:
-        try:
-            os.remove(f"{note_base}.rank{rank}")
-        except OSError:
-            pass
+    def read_notes():
+        import glob
+
+        others = []
+        for fn in sorted(glob.glob(note_base + ".rank*")):
+            try:
+                msg = open(fn).read().strip()
+            except OSError:
+                continue
+            if msg:
+                others.append(f"rank {fn.rsplit('rank', 1)[1]}: {msg}")
+        return others
+
+    printed = {"done": False}
+    die_lock = threading.Lock()  # (rank 0: the watcher, the SIGTERM thread, a watchdog and the main thread may all arrive; the first one prints)
 
     def die(code, status, extra=None):
+        if os.environ.get("RECPACK_BENCH_DEBUG"):
+            sys.stderr.write(f"[debug] rank {rank} die({code}): {status[:120]}\n")
         if rank == 0:
+            die_lock.acquire()  # (never released: whoever comes second waits here until the first has printed and left)
+            if printed["done"]:
+                os._exit(code)
+            printed["done"] = True
+            if world > 1 and "failed on rank" not in status:
+                # rank 0 failed itself - often BECAUSE another rank left (a transport that notices the dead peer): that rank's own words
+                # belong in the line (a moment for its note to land)
+                for _ in range(10):
+                    others = read_notes()
+                    if others:
+                        break
+                    time.sleep(0.1)
+                if others:
+                    status += " | other ranks: " + " | ".join(others)
             line = {"metric": METRIC, "n_gpus": world, "status": status, "phase": state["phase"], "transport": transport}
             line.update(extra or {})
             print(json.dumps(line), flush=True)
+            try:
+                open(note_base + ".ack", "w").write("printed")
+            except OSError:
+                pass
         else:
             sys.stderr.write(f"rank {rank}: {status}\n")
             try:
@@ -622,23 +665,44 @@ def main():
                     f.write(status)
             except OSError:
                 pass
+            # a launcher (torch.distributed.run) terminates the other ranks the moment one exits non-zero: rank 0 must have had the
+            # time to print its line first - wait for its acknowledgement (at most 20 s)
+            for _ in range(200):
+                if os.path.exists(note_base + ".ack"):
+                    break
+                time.sleep(0.1)
         os._exit(code)
 
     if world > 1 and rank == 0:
         def watch_notes():
-            import glob
-
             while True:
-                time.sleep(1.0)
-                for fn in glob.glob(note_base + ".rank*"):
-                    try:
-                        msg = open(fn).read().strip()
-                    except OSError:
-                        continue
-                    if msg:
-                        die(4, f"failed on rank {fn.rsplit('rank', 1)[1]} during the {state['phase']}: {msg}")
+                time.sleep(0.5)
+                others = read_notes()
+                if others:
+                    die(4, f"failed on {others[0].split(':', 1)[0]} during the {state['phase']}: " + " | ".join(o.split(": ", 1)[1] for o in others))
 
         threading.Thread(target=watch_notes, daemon=True).start()
+        # rank 0 must get its line out even when the launcher ends the job (SIGTERM after another rank crashed without a word) while
+        # the main thread sits inside a collective of the library, where no Python signal handler runs: CPython's C-level handler
+        # writes the signal's number to a wake-up socket at once, whichever thread the kernel picks, and a thread of its own reads it
+        import signal
+        import socket
+
+        term_r, term_w = socket.socketpair()
+        term_w.setblocking(False)
+        signal.set_wakeup_fd(term_w.fileno(), warn_on_full_buffer=False)
+        signal.signal(signal.SIGTERM, lambda signum, frame: None)
+
+        def wait_term():
+            signum = term_r.recv(1)[0]
+            if os.environ.get("RECPACK_BENCH_DEBUG"):
+                sys.stderr.write(f"[debug] rank 0 woke up for signal {signum}\n")
+            if signum != signal.SIGTERM:
+                return
+            die(7, f"terminated by the launcher (signal {signum}) during the {state['phase']}" +
+                (f"; last collective entered: {state.get('collective')}" if state.get("collective") else ""))
+
+        threading.Thread(target=wait_term, daemon=True).start()
     setup_dog = None
     if world > 1:
         setup_dog = threading.Timer(min(args.timeout, 600.0), lambda: die(3, f"timeout: the {state['phase']} did not finish within {min(args.timeout, 600.0):.0f} s"))
@@ -721,6 +785,10 @@ def main():
 
     def step():
         keep.clear()  # the step before's models and matrices go back to the context's block cache BEFORE the new ones are asked for
+        if rank == args.inject_failure_rank:
+            if args.inject_failure_hard:
+                os._exit(9)  # (no note, no word: a crash)
+            raise RuntimeError("injected failure (test hook --inject-failure-rank)")
         t0 = time.perf_counter()
         if world > 1:  # K0 with the degree pass sharded by item rows + one all-reduce of the degree vector
             state["collective"] = "all-reduce of the item degrees (K0, rphip_comm_all_reduce_sum_i32)"

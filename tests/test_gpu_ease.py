@@ -423,6 +423,40 @@ def test_bench_two_ranks_share_the_gpu(hip):
         assert k in d
 
 
+@pytest.mark.parametrize("hard", [False, True])
+def test_bench_rank_failure_reaches_rank_zero(hip, hard):
+    """a rank != 0 that dies first must not leave rank 0 waiting in a collective without a word.  Rank 1 raises in its
+    first warm-up step (test hook); rank 0 - by then inside the all-reduce of the item degrees - prints ONE line whose status names the
+    rank, its reason and the phase, and the run exits non-zero within seconds, not at the 1 500 s watchdog.  The failing rank waits for
+    rank 0's acknowledgement before it exits (torch.distributed.run terminates the other ranks the moment one exits non-zero); `hard`: the
+    rank dies silently (os._exit) - rank 0's line then comes from its SIGTERM thread (sigwait: the main thread sits in C) or from its own
+    failed collective, and names the collective it was in."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RECPACK_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", "C2", "--cpu-baseline-seconds", "0",
+           "--ease-config", "none", "--tars-config", "none", "--inject-failure-rank", "1"] + (["--inject-failure-hard"] if hard else [])
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert time.time() - t0 < 300
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:] + r.stderr[-3000:]
+    d = json.loads(lines[0])
+    # (either rank 0's watcher saw rank 1's note first, or - over gloo - its own collective noticed the dead peer: the line carries rank 1's
+    # reason both ways, and the collective rank 0 was in)
+    if hard:  # a rank that crashes without a word: the launcher ends the job with SIGTERM, or rank 0's own collective notices the dead peer - the line says which
+        assert d["n_gpus"] == 2 and (d["status"].startswith("terminated by the launcher") or d["status"].startswith("failed in the")) and "all-reduce of the item degrees" in d["status"], d
+    else:
+        assert d["status"].startswith("failed") and "rank 1" in d["status"] and "injected failure" in d["status"] and d["n_gpus"] == 2, d
+
+
 def test_ease_fit_sharded_one_rank(hip):
     import torch
 
