@@ -352,12 +352,11 @@ int rphip_predict_topk_filtered_dev(rphip_ctx* ctx, const rphip_model* model, co
 /* exact reference semantics (every non-zero score): two phases.  _count fills row_nnz_host
  * (int64[n]) and returns the total; _fill writes CSR indices/data (float64) given the caller's
  * indptr (exclusive scan of row_nnz). */
-/* LIMITS (the reference accepts any K: base.py:302-304, util.py:63-66).  rphip_itemknn_fit[_ex] WITHOUT normalize_X: any K at any item
- * count (round 6: K x column tiles >= 32 768 takes per-tile lists of min(K, tile) entries merged where they lie, the rows in chunks of
- * bounded scratch - ItemKNN(K=20000) at 100 000 items is a 48 GB model).  With normalize_X (float64 sums) and for the valued
- * (time-aware) fits: any K on one column tile of 12 288 items (8 192 for rphip_itemknn_fit_hermann), K x tiles < 32 768 beyond.  The Kp
- * of rphip_predict_topk* (min(Kp, n_items)): at most 2048 (the selection's LDS buffers); larger values return RPHIP_ELIMIT -
- * rphip_predict_full_*, the reference's own predict(), has no K. */
+/* LIMITS (the reference accepts any K: base.py:302-304, util.py:63-66).  Every fit - rphip_itemknn_fit[_ex] with and without normalize_X,
+ * rphip_itemknn_fit_values / _timedist / _hermann - takes any K at any item count (round 6: from K x column tiles = 32 768 the per-tile
+ * lists hold min(K, tile) entries and are merged where they lie, rp_merge_big.h, the rows in chunks of bounded scratch -
+ * ItemKNN(K=20000) at 100 000 items is a 48 GB model).  The Kp of rphip_predict_topk* (min(Kp, n_items)): at most 2048 (the selection's LDS
+ * buffers); larger values return RPHIP_ELIMIT - rphip_predict_full_*, the reference's own predict(), has no K. */
 int rphip_predict_full_count(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred,
                              int64_t user_begin, int64_t user_end, int64_t* row_nnz_host, int64_t* total_out);
 int rphip_predict_full_fill(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred,

@@ -21,11 +21,9 @@ warning texts and exception messages ARE the interface recpack's Pipeline, regis
 this module is original.  When recpack itself is importable, :class:`Algorithm` additionally derives from recpack's own
 ``Algorithm`` so that ``isinstance`` / ``issubclass`` checks in recpack (e.g. the algorithm registry) accept these classes.
 
-Limit (a deviation from the reference, which accepts any K): up to :data:`RP_TILE_MAX` = 25 600 items ``ItemKNN`` takes any ``K``
-(round 4); beyond, over T = ceil(items / 25 600) column tiles, any ``K`` with K x T < 32 768 (round 5: K = 8 191 at 100 000 items -
-the merge of a row's per-tile lists reads them where they lie when they do not fit the LDS); with ``normalize_X`` the same over tiles of
-12 288 items (K = 3 640 at 100 000 items), and the time-aware fits alike.  The ``K`` of ``predict_topk`` - an extension, not part of the
-reference - is at most 2048.  Larger values raise ``ValueError`` before anything is uploaded.
+K: every fit takes ANY ``K`` at any item count, as the reference does (round 6; beyond K x column tiles = 32 768 the rows' per-tile lists are
+merged where they lie and the rows are fitted in chunks of bounded scratch).  The ``K`` of ``predict_topk`` - an extension, not part of the
+reference - is at most 2048 and raises ``ValueError`` before anything is uploaded.
 """
 from __future__ import annotations
 
@@ -45,7 +43,7 @@ from recpack_amd import _lib
 logger = logging.getLogger("recpack")
 
 RP_WTILE_MAX = 12288  # rp_itemknn_w.hip: items per column tile of the normalize_X fit (float64 sums)
-RP_K_TILES_MAX = 32768  # rp_select.h (RPS_FLAG): K x column tiles of a binary fit over several tiles stays below this
+RP_K_TILES_MAX = 32768  # rp_select.h (RPS_FLAG): from K x column tiles = this the fits take the large-K merge (rp_merge_big.h)
 RP_K_MAX = 2048  # rp_common.h: largest effective K of a fit over several column tiles, and largest Kp of the fused top-Kp
 RP_TILE_MAX = 25600  # rp_common.h: items of one column tile - up to here ItemKNN takes any K (round 4)
 
@@ -319,16 +317,9 @@ class ItemKNN(TopKItemSimilarityMatrixAlgorithm):
         self.normalize_sim = normalize_sim
 
     def _fit(self, X: sp.csr_matrix) -> None:
-        # ANY K, as the reference (recpack/util.py:63-66, base.py:302-304): one column tile, or K x tiles < 32 768 (the merges that number
-        # their candidates in 16 bits), or - round 6 - anything beyond on the binary fits (per-tile lists merged where they lie by
-        # k_itemknn_merge_big, rows in chunks).  Only normalize_X (float64 sums, tiles of RP_WTILE_MAX items) keeps K x tiles < 32 768
-        # (K = 3 640 at 100 000 items): DESIGN.md section 4, deviation 5
-        k_eff = min(int(self.K), max(1, X.shape[1] - 1))
-        if self.normalize_X:
-            n_tiles = -(-X.shape[1] // RP_WTILE_MAX)
-            if n_tiles > 1 and k_eff * n_tiles >= RP_K_TILES_MAX:
-                raise ValueError(f"K={self.K} exceeds the supported maximum for {X.shape[1]} items with normalize_X: K x {n_tiles} column tiles "
-                                 f"must stay below {RP_K_TILES_MAX} (any K up to {RP_WTILE_MAX} items)")
+        # ANY K at any item count, as the reference (recpack/util.py:63-66, base.py:302-304) - binary fits, normalize_X and (time_aware.py) the
+        # valued fits alike since round 6: beyond K x column tiles = 32 768 the per-tile lists are merged where they lie (rp_merge_big.h)
+        # and the rows are fitted in chunks of bounded scratch
         ctx, dX = self._upload(X)
         try:
             if self.similarity == "cosine":

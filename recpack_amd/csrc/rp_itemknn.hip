@@ -23,6 +23,7 @@
 #include "rp_comm.h"
 #include "rp_common.h"
 #include "rp_gemm.h"
+#include "rp_merge_big.h"
 #include "rp_select.h"
 #include "rp_wave.h"
 
@@ -725,133 +726,26 @@ __global__ void __launch_bounds__(64) k_itemknn_merge_wave(rp_merge_params P) {
   }
 }
 
-// ---- (round 6) the merge for ANY K: K x tiles >= 32 768 candidates per row (recpack takes any K: util.py:63-66, base.py:302-304;
-// ItemKNN(K=20000) at 100 000 items).  The selections above number their candidates in 16 bits with a flag (RPS_FLAG); here nothing
-// is numbered: one workgroup per row walks the row's per-tile lists where they lie - an MSD radix select over the 64-bit key (11-bit
-// digits, at most six passes, each a histogram of the candidates that share the decided prefix) finds the K-th key, a last pass in
-// position order (= column order: tiles are ascending column ranges, a tile's list is in column order) writes everything above it, and
-// of the candidates that TIE with it the first ones - ties to the smaller column, as everywhere.  A row with at most K candidates
-// (the common case at such K: the Gram row has fewer non-zeros) is copied out.  Rare route: simple, not tuned.
-constexpr int RP_MBIG_THREADS = 256;
+// ---- (round 6) the merge for ANY K: K x tiles >= 32 768 candidates per row (ItemKNN(K=20000) at 100 000 items): rp_merge_big.h
 __global__ void __launch_bounds__(RP_MBIG_THREADS) k_itemknn_merge_big(rp_merge_params P) {
-  __shared__ uint32_t hist[2048];
-  __shared__ int s_off[17], s_res[4], s_w[2][RP_MBIG_THREADS / 64];
-  const int T = P.n_tiles, K = P.K, S = P.stride;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  __shared__ rp_mbig_smem S;
+  const int T = P.n_tiles, K = P.K, St = P.stride;
   for (int rl = blockIdx.x; rl < P.n_rows; rl += gridDim.x) {
-    __syncthreads();
-    if (tid == 0) {
-      int o = 0;
-      for (int t = 0; t < T; ++t) {
-        s_off[t] = o;
-        o += P.cand_nnz[(int64_t)rl * T + t];
-      }
-      s_off[T] = o;
-    }
-    __syncthreads();
-    const int n = s_off[T];
-    const int32_t* gi = P.cand_idx + (int64_t)rl * T * S;
-    const uint32_t* gc = P.cand_cnt + (int64_t)rl * T * S;
-    auto at = [&](int w) {
-      int t = 0;
-      while (t + 1 < T && w >= s_off[t + 1]) ++t;
-      return t * S + (w - s_off[t]);
-    };
-    const bool all = n <= K;
-    uint64_t prefix = 0;
-    int need = K, sh = 0;
-    bool fin_all = false;
-    if (!all) {
-      for (int level = 0; level < 6; ++level) {
-        const int hi = 64 - 11 * level, width = min(11, hi), shift = hi - width;
-        for (int i = tid; i < 2048; i += RP_MBIG_THREADS) hist[i] = 0u;
-        __syncthreads();
-        for (int w = tid; w < n; w += RP_MBIG_THREADS) {
-          const int a = at(w);
-          const uint64_t k = rp_fit_key(gc[a], P.inv_deg[gi[a]], P.key_pow);
-          if (level == 0 || (k >> hi) == (prefix >> hi)) atomicAdd(&hist[(uint32_t)(k >> shift) & ((1u << width) - 1u)], 1u);
-        }
-        __syncthreads();
-        if (wave == 0) {  // the bin where the count from the top reaches `need`: lane l owns the 32 bins below 2047 - 32 l
-          int h[32], sum = 0;
-#pragma unroll
-          for (int e = 0; e < 32; ++e) {
-            h[e] = (int)hist[2047 - 32 * lane - e];
-            sum += h[e];
-          }
-          int above = rp_wave_incl_scan(sum, lane) - sum;
-#pragma unroll
-          for (int e = 0; e < 32; ++e) {
-            if (above < need && need <= above + h[e]) {
-              s_res[0] = 2047 - 32 * lane - e;
-              s_res[1] = above;
-              s_res[2] = h[e];
-            }
-            above += h[e];
-          }
-        }
-        __syncthreads();
-        need -= s_res[1];
-        prefix |= (uint64_t)(uint32_t)s_res[0] << shift;
-        sh = shift;
-        if (s_res[2] == need) {  // the whole boundary bin is selected
-          fin_all = true;
-          break;
-        }
-        __syncthreads();
-      }
-    }
-    // ---- emission in position order; `need` of the members of the boundary group (all of them when fin_all)
+    const int32_t* gi = P.cand_idx + (int64_t)rl * T * St;
+    const uint32_t* gc = P.cand_cnt + (int64_t)rl * T * St;
+    const int32_t* cn = P.cand_nnz + (int64_t)rl * T;
     int32_t* oi = P.out_idx + (int64_t)rl * K;
     double* ov = P.out_val + (int64_t)rl * K;
     const double ci = (double)P.deg[P.row_begin + rl];
-    int run_sel = 0, run_mem = 0;
-    for (int base = 0; base < n; base += RP_MBIG_THREADS) {
-      const int w = base + tid;
-      int a = 0, j = 0;
-      uint32_t c = 0;
-      bool above = false, member = false;
-      if (w < n) {
-        a = at(w);
-        j = gi[a];
-        c = gc[a];
-        if (all) {
-          above = true;
-        } else {
-          const uint64_t k = rp_fit_key(c, P.inv_deg[j], P.key_pow);
-          above = (k >> sh) > (prefix >> sh);
-          member = (k >> sh) == (prefix >> sh);
-        }
-      }
-      const uint64_t mm = __ballot(member);
-      if (lane == 0) s_w[0][wave] = __popcll(mm);
-      __syncthreads();
-      int mem_before = run_mem + __popcll(mm & lt_mask);
-      int mem_total = 0;
-      for (int q = 0; q < RP_MBIG_THREADS / 64; ++q) {
-        if (q < wave) mem_before += s_w[0][q];
-        mem_total += s_w[0][q];
-      }
-      const bool sel = above || (member && (fin_all || mem_before < need));
-      const uint64_t sm = __ballot(sel);
-      if (lane == 0) s_w[1][wave] = __popcll(sm);
-      __syncthreads();
-      int pos = run_sel + __popcll(sm & lt_mask);
-      int sel_total = 0;
-      for (int q = 0; q < RP_MBIG_THREADS / 64; ++q) {
-        if (q < wave) pos += s_w[1][q];
-        sel_total += s_w[1][q];
-      }
-      if (sel) {
-        oi[pos] = j;
-        ov[pos] = (P.key_pow == 2) ? (double)c / sqrt(ci * (double)P.deg[j]) : ((double)c * P.inv_deg[j]) / ci;
-      }
-      run_sel += sel_total;
-      run_mem += mem_total;
-      __syncthreads();
-    }
-    if (tid == 0) P.out_nnz[rl] = run_sel;
+    const int n_out = rp_merge_big_row(
+        S, T, St, K, [&](int t) { return cn[t]; }, [&](int a) { return rp_fit_key(gc[a], P.inv_deg[gi[a]], P.key_pow); },
+        [&](int pos, int a) {
+          const int j = gi[a];
+          const uint32_t c = gc[a];
+          oi[pos] = j;
+          ov[pos] = (P.key_pow == 2) ? (double)c / sqrt(ci * (double)P.deg[j]) : ((double)c * P.inv_deg[j]) / ci;
+        });
+    if (threadIdx.x == 0) P.out_nnz[rl] = n_out;
   }
 }
 

@@ -21,6 +21,7 @@
 #include <algorithm>
 
 #include "rp_common.h"
+#include "rp_merge_big.h"
 #include "rp_select.h"
 #include "rp_wave.h"
 
@@ -44,6 +45,7 @@ struct rp_vfit_params {
   int pair_kind;          // 0: products L_ui * X_uj; > 0: a decay (RPHIP_DECAY_*) of |X_uj - X_ui|, equal values add nothing
   double pair_decay, pair_max;
   int n_items, n_rows, n_tiles, tile_w, K, row_begin;
+  int cand_stride;  // T > 1: entries between two tiles' lists of a row (K; min(K, tile) on the large-K route)
   const int32_t* n_rows_dev;  // when set: the number of rows in `order` (a list built on the device)
   int32_t* ticket;
   int32_t* out_idx;       // T == 1: model rows; T > 1: per-tile candidates
@@ -203,7 +205,7 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_values(rp_vfit_p
         });
       if (tid == 0) P.out_nnz[rl] = kp;
     } else {
-      const int64_t o = ((int64_t)rl * T + tile) * P.K;
+      const int64_t o = ((int64_t)rl * T + tile) * P.cand_stride;
       rp_select_emit<NTHR>(n_cols, sel, [&](int pos, int w) {
         P.out_idx[o + pos] = t0 + w;
         P.out_val[o + pos] = src.value(w);
@@ -557,6 +559,37 @@ __global__ void __launch_bounds__(RP_VMERGE_THREADS) k_itemknn_merge_values(cons
   }
 }
 
+// the same merge for K x tiles >= 32 768 (round 6: rp_merge_big.h; lists of `stride` entries per tile)
+__global__ void __launch_bounds__(RP_MBIG_THREADS) k_itemknn_merge_values_big(const int32_t* __restrict__ cand_idx, const double* __restrict__ cand_g,
+                                                                             const int32_t* __restrict__ cand_nnz, const int32_t* __restrict__ cand_cnt,
+                                                                             const double* __restrict__ roww, int signed_vals, int n_tiles, int stride, int K,
+                                                                             int n_rows, int row_begin, const int32_t* __restrict__ light,
+                                                                             int32_t* __restrict__ out_idx, double* __restrict__ out_val,
+                                                                             int32_t* __restrict__ out_nnz) {
+  __shared__ rp_mbig_smem S;
+  const int T = n_tiles;
+  for (int rl = blockIdx.x; rl < n_rows; rl += gridDim.x) {
+    if (light && light[rl]) continue;  // done by the hash kernel
+    const int32_t* gi = cand_idx + (int64_t)rl * T * stride;
+    const double* gg = cand_g + (int64_t)rl * T * stride;
+    const int32_t* cn = cand_nnz + (int64_t)rl * T;
+    int kk = K;
+    if (signed_vals) {  // negatives beyond a tile's K never matter: at most K - n_pos - 1 of them are kept in total (rp_keff)
+      int np = 0;
+      for (int t = 0; t < T; ++t) np += cand_cnt[(int64_t)rl * T + t];
+      kk = rp_keff(K, np, 0x3fffffff);
+    }
+    const double ri = roww ? roww[row_begin + rl] : 1.0;
+    const int n_out = rp_merge_big_row(
+        S, T, stride, kk, [&](int t) { return cn[t]; }, [&](int a) { return rp_ordered_f64(gg[a]); },
+        [&](int pos, int a) {
+          out_idx[(int64_t)rl * K + pos] = gi[a];
+          out_val[(int64_t)rl * K + pos] = gg[a] * ri;
+        });
+    if (threadIdx.x == 0) out_nnz[rl] = n_out;
+  }
+}
+
 static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int64_t row_end, int32_t K, int32_t left_binary,
                               const double* row_scale_host, int pair_kind, double pair_decay, double pair_max, rphip_model** out) {
   if (!ctx || !X || !out) RP_FAIL(RPHIP_EINVAL, "NULL argument");
@@ -574,9 +607,11 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
   const int64_t I = X->n_items;
   const int tile_max = (pair_kind == RPHIP_PAIR_HERMANN) ? RP_VTILE_HERMANN : RP_VTILE_MAX;
   const int T = (int)std::max<int64_t>(1, rp_cdiv(I, tile_max));
-  // (round 5) any K on one column tile; over several tiles the merge keeps a 15-bit slot number per candidate (rp_select.h)
-  if (T > 1 && (int64_t)T * Keff >= RPS_FLAG) RP_FAIL(RPHIP_ELIMIT, "K=%d over %d column tiles: K x tiles must stay below %d", Keff, T, RPS_FLAG);
+  // (round 5) any K on one column tile; over several tiles the merge keeps a 15-bit slot number per candidate (rp_select.h) ...
+  // (round 6) ... and K x tiles >= 32 768 takes per-tile lists of min(K, tile) entries merged by rp_merge_big.h, the rows in chunks
+  const bool big_k = T > 1 && (int64_t)T * Keff >= RPS_FLAG;
   const int W = (int)(rp_cdiv(rp_cdiv(std::max<int64_t>(I, 1), T), 64) * 64);
+  const int Ks = big_k ? std::min<int>(Keff, W) : Keff;  // entries of a tile's candidate list
   if (T > 15) RP_FAIL(RPHIP_ELIMIT, "%d valued column tiles (n_items=%lld) exceed the supported 15", T, (long long)I);
   if ((T > 1 || !left_binary) && !X->sorted_rows) RP_FAIL(RPHIP_EINVAL, "the valued fit needs column-sorted rows");
   hipStream_t st = ctx->stream;
@@ -590,14 +625,15 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
     rphip_model_destroy(m);
     return rc;
   };
-  if (n_rows > 0 && X->nnz > 0) {
+  // the rows [rb, rb + nr): plan, the tile (and hash) kernels, the merge of the per-tile lists; the lists go to oi / ov / on
+  auto run_rows = [&](int64_t rb, int nr, int32_t* oi, double* ov, int32_t* on) -> int {
     char* sc = nullptr;
-    const size_t cand_n = (T > 1) ? (size_t)n_rows * T * K : 0;
+    const size_t cand_n = (T > 1) ? (size_t)nr * T * Ks : 0;
     const bool use_hash = T > 1 && K <= RP_VHASH_KMAX;  // light rows: one task per row in a hash table instead of T tiles
     const size_t vt_n = (T > 1) ? (size_t)X->n_users * (T + 1) : 0;
     const size_t xtv_n = left_binary ? 0 : (size_t)X->nnz;
-    const size_t bytes = (size_t)I * 8 + RP_PLAN_BUCKETS * 4 + (size_t)n_rows * 4 + 64 + cand_n * 12 + (size_t)n_rows * T * 8 + vt_n * 4 +
-                         xtv_n * 8 + (size_t)n_rows * 12 + 2048;
+    const size_t bytes = (size_t)I * 8 + RP_PLAN_BUCKETS * 4 + (size_t)nr * 4 + 64 + cand_n * 12 + (size_t)nr * T * 8 + vt_n * 4 +
+                         xtv_n * 8 + (size_t)nr * 12 + 2048;
     int rc = rp_scratch(ctx, 0, bytes, (void**)&sc);
     if (rc != RPHIP_OK) return fail(rc);
     size_t o = 0;
@@ -608,15 +644,15 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
     };
     double* roww = (double*)carve((size_t)I * 8);
     int32_t* bucket = (int32_t*)carve(RP_PLAN_BUCKETS * 4);
-    int32_t* order = (int32_t*)carve((size_t)n_rows * 4);
+    int32_t* order = (int32_t*)carve((size_t)nr * 4);
     int32_t* ticket = (int32_t*)carve(64);
     double* cand_g = (double*)carve(cand_n * 8);
     int32_t* cand_idx = (int32_t*)carve(cand_n * 4);
-    int32_t* cand_nnz = (int32_t*)carve((size_t)n_rows * T * 4);
-    int32_t* cand_cnt = (int32_t*)carve((size_t)n_rows * T * 4);
-    int32_t* light_flag = (int32_t*)carve((size_t)n_rows * 4);
-    int32_t* heavy_list = (int32_t*)carve((size_t)n_rows * 4);
-    int32_t* light_list = (int32_t*)carve((size_t)n_rows * 4);
+    int32_t* cand_nnz = (int32_t*)carve((size_t)nr * T * 4);
+    int32_t* cand_cnt = (int32_t*)carve((size_t)nr * T * 4);
+    int32_t* light_flag = (int32_t*)carve((size_t)nr * 4);
+    int32_t* heavy_list = (int32_t*)carve((size_t)nr * 4);
+    int32_t* light_list = (int32_t*)carve((size_t)nr * 4);
     int32_t* list_counts = (int32_t*)carve(64);
     int32_t* vt_ptr = (int32_t*)carve(vt_n * 4);
     double* xt_val = (double*)carve(xtv_n * 8);
@@ -624,19 +660,19 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
     rp_time_begin(ctx, &ev);
     hipMemsetAsync(ticket, 0, 64, st);
     if (T > 1) {
-      hipMemsetAsync(cand_nnz, 0, (size_t)n_rows * T * 4, st);
-      hipMemsetAsync(cand_cnt, 0, (size_t)n_rows * T * 4, st);
+      hipMemsetAsync(cand_nnz, 0, (size_t)nr * T * 4, st);
+      hipMemsetAsync(cand_cnt, 0, (size_t)nr * T * 4, st);
     }
-    rc = rp_plan_row_order(ctx, X, row_begin, n_rows, bucket, order);
+    rc = rp_plan_row_order(ctx, X, rb, nr, bucket, order);
     if (rc != RPHIP_OK) return fail(rc);
     if (T > 1) {
       rc = rp_user_tile_ptr(ctx, X, T, W, vt_ptr);
       if (rc != RPHIP_OK) return fail(rc);
     }
     if (use_hash) {
-      hipLaunchKernelGGL(k_vrow_light, dim3((unsigned)std::min<int64_t>(4096, rp_cdiv(n_rows, 4))), dim3(256), 0, st, X->xt_ptr, X->xt_idx,
-                         X->x_ptr, (int)row_begin, n_rows, light_flag);
-      hipLaunchKernelGGL(k_vrow_split, dim3(1), dim3(1024), 0, st, order, light_flag, (int)row_begin, n_rows, heavy_list, light_list,
+      hipLaunchKernelGGL(k_vrow_light, dim3((unsigned)std::min<int64_t>(4096, rp_cdiv(nr, 4))), dim3(256), 0, st, X->xt_ptr, X->xt_idx,
+                         X->x_ptr, (int)rb, nr, light_flag);
+      hipLaunchKernelGGL(k_vrow_split, dim3(1), dim3(1024), 0, st, order, light_flag, (int)rb, nr, heavy_list, light_list,
                          list_counts);
     }
     if (!left_binary)
@@ -661,15 +697,16 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
     P.pair_decay = pair_decay;
     P.pair_max = pair_max;
     P.n_items = (int)I;
-    P.n_rows = n_rows;
+    P.n_rows = nr;
     P.n_tiles = T;
     P.tile_w = W;
     P.K = K;
-    P.row_begin = (int)row_begin;
+    P.cand_stride = Ks;
+    P.row_begin = (int)rb;
     P.ticket = ticket;
-    P.out_idx = (T == 1) ? m->idx : cand_idx;
-    P.out_val = (T == 1) ? m->val : cand_g;
-    P.out_nnz = (T == 1) ? m->nnz : cand_nnz;
+    P.out_idx = (T == 1) ? oi : cand_idx;
+    P.out_val = (T == 1) ? ov : cand_g;
+    P.out_nnz = (T == 1) ? on : cand_nnz;
     P.out_cnt = cand_cnt;
     const size_t lds = (size_t)W * (pair_kind == RPHIP_PAIR_HERMANN ? 12 : 8) + rp_select_smem_bytes(W);
     if (hipFuncSetAttribute((const void*)k_itemknn_fit_values, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -679,9 +716,9 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
     rp_time_end(ctx, ev, RPHIP_T_GRAM_TOPK, 0.0);
     if (use_hash) {
       rp_vfit_params H = P;  // writes the model rows directly
-      H.out_idx = m->idx;
-      H.out_val = m->val;
-      H.out_nnz = m->nnz;
+      H.out_idx = oi;
+      H.out_val = ov;
+      H.out_nnz = on;
       const size_t hlds = (size_t)RP_VHASH_SLOTS * (pair_kind == RPHIP_PAIR_HERMANN ? 16 : 12) + rp_select_smem_bytes(RP_VHASH_SLOTS);
       if (hipFuncSetAttribute((const void*)k_itemknn_fit_values_hash, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hlds) != hipSuccess)
         return fail(RPHIP_EHIP);
@@ -689,7 +726,12 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
       hipLaunchKernelGGL(k_itemknn_fit_values_hash, dim3(ctx->n_cu), dim3(RP_FIT_THREADS), hlds, st, H, light_list, list_counts + 1);
       rp_time_end(ctx, ev, RPHIP_T_GRAM_TOPK_WAVE, 0.0);
     }
-    if (T > 1) {
+    if (T > 1 && big_k) {
+      rp_time_begin(ctx, &ev);
+      hipLaunchKernelGGL(k_itemknn_merge_values_big, dim3((unsigned)std::min<int64_t>(nr, (int64_t)ctx->n_cu * 8)), dim3(RP_MBIG_THREADS), 0, st, cand_idx, cand_g,
+                         cand_nnz, cand_cnt, P.roww, P.signed_vals, T, Ks, K, nr, (int)rb, use_hash ? light_flag : nullptr, oi, ov, on);
+      rp_time_end(ctx, ev, RPHIP_T_TOPK_MERGE, 0.0);
+    } else if (T > 1) {
       size_t mlds = (size_t)T * K * 12 + 8 + rp_select_smem_bytes(T * K, RP_VMERGE_THREADS / 64);
       const bool glob = mlds > 160 * 1024;  // the lists of a row do not fit the LDS: they are read where they lie (slot numbers only in LDS)
       if (glob) mlds = rp_select_smem_bytes(T * K, RP_VMERGE_THREADS / 64);
@@ -700,17 +742,28 @@ static int rp_fit_values_impl(rphip_ctx* ctx, const rphip_csr* X, int64_t row_be
       const void* mk = glob ? (const void*)k_itemknn_merge_values<true> : (const void*)k_itemknn_merge_values<false>;
       if (hipFuncSetAttribute(mk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds) != hipSuccess) return fail(RPHIP_EHIP);
       const int mper = std::max<int>(1, std::min<int>(8, (int)((160 * 1024) / mlds)));
-      const dim3 mgrid((unsigned)std::min<int64_t>(n_rows, (int64_t)ctx->n_cu * mper));
+      const dim3 mgrid((unsigned)std::min<int64_t>(nr, (int64_t)ctx->n_cu * mper));
       rp_time_begin(ctx, &ev);
       if (glob)
         hipLaunchKernelGGL(k_itemknn_merge_values<true>, mgrid, dim3(RP_VMERGE_THREADS), mlds, st, cand_idx, cand_g, cand_nnz, cand_cnt, P.roww, P.signed_vals, T, K,
-                           n_rows, (int)row_begin, use_hash ? light_flag : nullptr, m->idx, m->val, m->nnz);
+                           nr, (int)rb, use_hash ? light_flag : nullptr, oi, ov, on);
       else
         hipLaunchKernelGGL(k_itemknn_merge_values<false>, mgrid, dim3(RP_VMERGE_THREADS), mlds, st, cand_idx, cand_g, cand_nnz, cand_cnt, P.roww, P.signed_vals, T, K,
-                           n_rows, (int)row_begin, use_hash ? light_flag : nullptr, m->idx, m->val, m->nnz);
+                           nr, (int)rb, use_hash ? light_flag : nullptr, oi, ov, on);
       rp_time_end(ctx, ev, RPHIP_T_TOPK_MERGE, 0.0);
     }
     if (hipGetLastError() != hipSuccess) return fail(RPHIP_EHIP);
+      return RPHIP_OK;
+  };
+  if (n_rows > 0 && X->nnz > 0) {
+    // in chunks where the per-tile lists of all rows at once would be too much memory (T x min(K, tile) x 12 bytes per row)
+    const int64_t per_row = T > 1 ? (int64_t)T * Ks * 12 + (int64_t)T * 8 : 0;
+    const int64_t budget = (int64_t)6 << 30;
+    const int64_t R = (per_row > 0 && per_row * n_rows > budget) ? std::max<int64_t>(1, budget / per_row) : n_rows;
+    for (int64_t c0 = 0; c0 < n_rows; c0 += R) {
+      const int rc = run_rows(row_begin + c0, (int)std::min<int64_t>(R, n_rows - c0), m->idx + c0 * K, m->val + c0 * K, m->nnz + c0);
+      if (rc != RPHIP_OK) return rc;  // (run_rows has released the model)
+    }
   }
   int r = rp_model_finalize_topk(ctx, m);
   if (r != RPHIP_OK) return fail(r);

@@ -2,6 +2,7 @@
 #include <algorithm>
 
 #include "rp_common.h"
+#include "rp_merge_big.h"
 #include "rp_select.h"
 #include "rp_wave.h"
 
@@ -27,6 +28,7 @@ struct rp_wfit_params {
   const double* colw;      // [I] key = G_ij * colw_j (monotone in S_ij for a fixed row)
   const double* roww;      // [I] S_ij = key * roww_i
   int n_items, n_rows, n_tiles, tile_w, K, row_begin;
+  int cand_stride;         // T > 1: entries between two tiles' lists of a row (K; min(K, tile) on the large-K route)
   int32_t* ticket;
   int32_t* out_idx;        // T == 1: model rows; T > 1: per-tile candidates
   double* out_val;         //         values        ;        G_ij of the candidates
@@ -121,7 +123,7 @@ __global__ void __launch_bounds__(RP_FIT_THREADS) k_itemknn_fit_weighted(rp_wfit
       });
       if (tid == 0) P.out_nnz[rl] = kp;
     } else {
-      const int64_t o = ((int64_t)rl * T + tile) * P.K;
+      const int64_t o = ((int64_t)rl * T + tile) * P.cand_stride;
       rp_select_emit<NTHR>(n_cols, sel, [&](int pos, int w) {
         P.out_idx[o + pos] = t0 + w;
         P.out_val[o + pos] = acc[w];
@@ -225,6 +227,30 @@ __global__ void __launch_bounds__(RP_MERGE_THREADS) k_itemknn_merge_weighted(con
   }
 }
 
+// the same merge for K x tiles >= 32 768 (round 6: rp_merge_big.h; lists of `stride` entries per tile)
+__global__ void __launch_bounds__(RP_MBIG_THREADS) k_itemknn_merge_weighted_big(const int32_t* __restrict__ cand_idx, const double* __restrict__ cand_g,
+                                                                               const int32_t* __restrict__ cand_nnz, const double* __restrict__ colw,
+                                                                               const double* __restrict__ roww, int n_tiles, int stride, int K, int n_rows,
+                                                                               int row_begin, int32_t* __restrict__ out_idx, double* __restrict__ out_val,
+                                                                               int32_t* __restrict__ out_nnz) {
+  __shared__ rp_mbig_smem S;
+  const int T = n_tiles;
+  for (int rl = blockIdx.x; rl < n_rows; rl += gridDim.x) {
+    const int32_t* gi = cand_idx + (int64_t)rl * T * stride;
+    const double* gg = cand_g + (int64_t)rl * T * stride;
+    const int32_t* cn = cand_nnz + (int64_t)rl * T;
+    const double ri = roww[row_begin + rl];
+    const int n_out = rp_merge_big_row(
+        S, T, stride, K, [&](int t) { return cn[t]; }, [&](int a) { return (uint64_t)__double_as_longlong(gg[a] * colw[gi[a]]); },
+        [&](int pos, int a) {
+          const int j = gi[a];
+          out_idx[(int64_t)rl * K + pos] = j;
+          out_val[(int64_t)rl * K + pos] = (gg[a] * colw[j]) * ri;
+        });
+    if (threadIdx.x == 0) out_nnz[rl] = n_out;
+  }
+}
+
 // q_u = w_u^2 (cosine) or w_u (conditional probability), w_u = fl(1 / d_u)
 __global__ void k_user_weights(const int32_t* __restrict__ x_ptr, int n_users, int squared, double* __restrict__ q) {
   for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n_users; u += gridDim.x * blockDim.x) {
@@ -260,10 +286,11 @@ int rp_gram_weighted(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int6
   const int n_rows = (int)(row_end - row_begin);
   const int64_t I = X->n_items, U = X->n_users;
   const int T = (int)std::max<int64_t>(1, rp_cdiv(I, RP_WTILE_MAX));
-  // (round 5) any K on one column tile; over several tiles the merge keeps a 15-bit slot number per candidate (rp_select.h)
-  if (T > 1 && (int64_t)T * Keff >= RPS_FLAG)
-    RP_FAIL(RPHIP_ELIMIT, "K=%d over %d column tiles: K x tiles must stay below %d", Keff, T, RPS_FLAG);
+  // (round 5) any K on one column tile; over several tiles the merge keeps a 15-bit slot number per candidate (rp_select.h) ...
+  // (round 6) ... and K x tiles >= 32 768 takes per-tile lists of min(K, tile) entries merged by rp_merge_big.h, the rows in chunks
+  const bool big_k = T > 1 && (int64_t)T * Keff >= RPS_FLAG;
   const int W = (int)(rp_cdiv(rp_cdiv(std::max<int64_t>(I, 1), T), 64) * 64);
+  const int Ks = big_k ? std::min<int>(Keff, W) : Keff;  // entries of a tile's candidate list
   if (T > 15) RP_FAIL(RPHIP_ELIMIT, "%d weighted column tiles (n_items=%lld) exceed the supported 15", T, (long long)I);
   if (T > 1 && !X->sorted_rows) RP_FAIL(RPHIP_EINVAL, "normalize_X with more than %d items needs column-sorted rows", RP_WTILE_MAX);
   hipStream_t st = ctx->stream;
@@ -277,11 +304,12 @@ int rp_gram_weighted(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int6
     rphip_model_destroy(m);
     return rc;
   };
-  if (n_rows > 0 && X->nnz > 0) {
+  // the rows [rb, rb + nr): plan, the tile kernel, the merge of the per-tile lists; the lists go to oi / ov / on (the first row's place)
+  auto run_rows = [&](int64_t rb, int nr, int32_t* oi, double* ov, int32_t* on) -> int {
     char* sc = nullptr;
-    const size_t cand_n = (T > 1) ? (size_t)n_rows * T * K : 0;
+    const size_t cand_n = (T > 1) ? (size_t)nr * T * Ks : 0;
     const size_t vt_n = (T > 1) ? (size_t)U * (T + 1) : 0;
-    const size_t bytes = (size_t)U * 8 + (size_t)I * 8 + RP_PLAN_BUCKETS * 4 + (size_t)n_rows * 4 + 64 + cand_n * 12 + (size_t)n_rows * T * 4 +
+    const size_t bytes = (size_t)U * 8 + (size_t)I * 8 + RP_PLAN_BUCKETS * 4 + (size_t)nr * 4 + 64 + cand_n * 12 + (size_t)nr * T * 4 +
                          vt_n * 4 + 512;
     int rc = rp_scratch(ctx, 0, bytes, (void**)&sc);
     if (rc != RPHIP_OK) return fail(rc);
@@ -294,17 +322,17 @@ int rp_gram_weighted(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int6
     double* user_q = (double*)carve((size_t)U * 8);
     double* colw = (double*)carve((size_t)I * 8);
     int32_t* bucket = (int32_t*)carve(RP_PLAN_BUCKETS * 4);
-    int32_t* order = (int32_t*)carve((size_t)n_rows * 4);
+    int32_t* order = (int32_t*)carve((size_t)nr * 4);
     int32_t* ticket = (int32_t*)carve(64);
     double* cand_g = (double*)carve(cand_n * 8);
     int32_t* cand_idx = (int32_t*)carve(cand_n * 4);
-    int32_t* cand_nnz = (int32_t*)carve((size_t)n_rows * T * 4);
+    int32_t* cand_nnz = (int32_t*)carve((size_t)nr * T * 4);
     int32_t* vt_ptr = (int32_t*)carve(vt_n * 4);
     hipEvent_t ev;
     rp_time_begin(ctx, &ev);
     hipMemsetAsync(ticket, 0, 64, st);
-    if (T > 1) hipMemsetAsync(cand_nnz, 0, (size_t)n_rows * T * 4, st);
-    rc = rp_plan_row_order(ctx, X, row_begin, n_rows, bucket, order);
+    if (T > 1) hipMemsetAsync(cand_nnz, 0, (size_t)nr * T * 4, st);
+    rc = rp_plan_row_order(ctx, X, rb, nr, bucket, order);
     if (rc != RPHIP_OK) return fail(rc);
     if (T > 1) {
       rc = rp_user_tile_ptr(ctx, X, T, W, vt_ptr);
@@ -333,22 +361,28 @@ int rp_gram_weighted(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int6
     P.colw = colw;
     P.roww = roww;
     P.n_items = (int)I;
-    P.n_rows = n_rows;
+    P.n_rows = nr;
     P.n_tiles = T;
     P.tile_w = W;
     P.K = K;
-    P.row_begin = (int)row_begin;
+    P.cand_stride = Ks;
+    P.row_begin = (int)rb;
     P.ticket = ticket;
-    P.out_idx = (T == 1) ? m->idx : cand_idx;
-    P.out_val = (T == 1) ? m->val : cand_g;
-    P.out_nnz = (T == 1) ? m->nnz : cand_nnz;
+    P.out_idx = (T == 1) ? oi : cand_idx;
+    P.out_val = (T == 1) ? ov : cand_g;
+    P.out_nnz = (T == 1) ? on : cand_nnz;
     const size_t lds = (size_t)W * 8 + rp_select_smem_bytes(W);
     if (hipFuncSetAttribute((const void*)k_itemknn_fit_weighted, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return fail(RPHIP_EHIP);
     rp_time_begin(ctx, &ev);
     hipLaunchKernelGGL(k_itemknn_fit_weighted, dim3(ctx->n_cu), dim3(RP_FIT_THREADS), lds, st, P);
     rp_time_end(ctx, ev, RPHIP_T_GRAM_TOPK, 0.0);
-    if (T > 1) {
+    if (T > 1 && big_k) {
+      rp_time_begin(ctx, &ev);
+      hipLaunchKernelGGL(k_itemknn_merge_weighted_big, dim3((unsigned)std::min<int64_t>(nr, (int64_t)ctx->n_cu * 8)), dim3(RP_MBIG_THREADS), 0, st, cand_idx, cand_g,
+                         cand_nnz, colw, roww, T, Ks, K, nr, (int)rb, oi, ov, on);
+      rp_time_end(ctx, ev, RPHIP_T_TOPK_MERGE, 0.0);
+    } else if (T > 1) {
       size_t mlds = (size_t)T * K * 12 + 8 + rp_select_smem_bytes(T * K, RP_MERGE_THREADS / 64);
       const bool glob = mlds > 160 * 1024;  // the lists of a row do not fit the LDS: they are read where they lie (slot numbers only in LDS)
       if (glob) mlds = rp_select_smem_bytes(T * K, RP_MERGE_THREADS / 64);
@@ -360,16 +394,27 @@ int rp_gram_weighted(rphip_ctx* ctx, const rphip_csr* X, int64_t row_begin, int6
       if (hipFuncSetAttribute(mk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds) != hipSuccess) return fail(RPHIP_EHIP);
       const int mper = std::max<int>(1, std::min<int>(8, (int)((160 * 1024) / mlds)));
       rp_time_begin(ctx, &ev);
-      const dim3 mgrid((unsigned)std::min<int64_t>(n_rows, (int64_t)ctx->n_cu * mper));
+      const dim3 mgrid((unsigned)std::min<int64_t>(nr, (int64_t)ctx->n_cu * mper));
       if (glob)
-        hipLaunchKernelGGL(k_itemknn_merge_weighted<true>, mgrid, dim3(RP_MERGE_THREADS), mlds, st, cand_idx, cand_g, cand_nnz, colw, roww, T, K, n_rows,
-                           (int)row_begin, m->idx, m->val, m->nnz);
+        hipLaunchKernelGGL(k_itemknn_merge_weighted<true>, mgrid, dim3(RP_MERGE_THREADS), mlds, st, cand_idx, cand_g, cand_nnz, colw, roww, T, K, nr,
+                           (int)rb, oi, ov, on);
       else
-        hipLaunchKernelGGL(k_itemknn_merge_weighted<false>, mgrid, dim3(RP_MERGE_THREADS), mlds, st, cand_idx, cand_g, cand_nnz, colw, roww, T, K, n_rows,
-                           (int)row_begin, m->idx, m->val, m->nnz);
+        hipLaunchKernelGGL(k_itemknn_merge_weighted<false>, mgrid, dim3(RP_MERGE_THREADS), mlds, st, cand_idx, cand_g, cand_nnz, colw, roww, T, K, nr,
+                           (int)rb, oi, ov, on);
       rp_time_end(ctx, ev, RPHIP_T_TOPK_MERGE, 0.0);
     }
     if (hipGetLastError() != hipSuccess) return fail(RPHIP_EHIP);
+      return RPHIP_OK;
+  };
+  if (n_rows > 0 && X->nnz > 0) {
+    // in chunks where the per-tile lists of all rows at once would be too much memory (T x min(K, tile) x 12 bytes per row)
+    const int64_t per_row = T > 1 ? (int64_t)T * Ks * 12 + (int64_t)T * 4 : 0;
+    const int64_t budget = (int64_t)6 << 30;
+    const int64_t R = (per_row > 0 && per_row * n_rows > budget) ? std::max<int64_t>(1, budget / per_row) : n_rows;
+    for (int64_t c0 = 0; c0 < n_rows; c0 += R) {
+      const int rc = run_rows(row_begin + c0, (int)std::min<int64_t>(R, n_rows - c0), m->idx + c0 * K, m->val + c0 * K, m->nnz + c0);
+      if (rc != RPHIP_OK) return rc;  // (run_rows has released the model)
+    }
   }
   int r = rp_model_finalize_topk(ctx, m);
   if (r != RPHIP_OK) return fail(r);

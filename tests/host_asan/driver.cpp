@@ -76,6 +76,15 @@ static int host_drivers(rphip_ctx* ctx) {
       CHECK(rphip_model_destroy(m) == RPHIP_OK);
       CHECK(rphip_itemknn_fit_ex(ctx, X, 0, I, 50, RPHIP_SIM_COSINE, 0.0, 1, &m) == RPHIP_OK);
       CHECK(rphip_model_destroy(m) == RPHIP_OK);
+      CHECK(rphip_itemknn_fit_ex(ctx, X, 0, I, 20000, RPHIP_SIM_COSINE, 0.0, 1, &m) == RPHIP_OK);  // (30 000 items: three tiles, the large-K merge in row chunks)
+      CHECK(rphip_model_destroy(m) == RPHIP_OK);
+      std::vector<double> vals(ix.size(), 0.5);
+      CHECK(rphip_csr_set_values(ctx, X, vals.data()) == RPHIP_OK);
+      for (int32_t K : {50, 20000}) {
+        CHECK(rphip_itemknn_fit_values(ctx, X, 0, I, K, 0, nullptr, &m) == RPHIP_OK);
+        CHECK(rphip_model_destroy(m) == RPHIP_OK);
+      }
+      CHECK(rphip_csr_set_values(ctx, X, nullptr) == RPHIP_OK);
       CHECK(rphip_itemknn_fit_ex(ctx, X, 0, I, 50, RPHIP_SIM_CONDITIONAL_PROBABILITY, 2.0, 0, &m) == RPHIP_EINVAL);
     }
     if (I <= 3000) {

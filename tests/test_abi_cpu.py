@@ -122,10 +122,9 @@ def test_post_condition_warnings():
         alg._check_prediction(X, X)
 
 
-def test_k_limit_raises_before_upload():
-    """What is left of the K limit (a documented deviation: the reference takes any K) raises ValueError on the host: K x column tiles
-    >= 32 768 over several tiles of 12 288 items with normalize_X.  The binary fit takes any K at any item count since round 6 (the call
-    reaches the device: without one it fails there, not on a host-side limit)."""
+def test_no_host_side_k_limit_on_the_fits():
+    """The reference takes any K (recpack/util.py:63-66, base.py:302-304); since round 6 so does every fit here - no host-side ValueError is
+    left: the calls reach the device (without one they fail there: RecpackHipError).  Only the `predict_topk` extension keeps its K."""
     import scipy.sparse as sp
     import torch
 
@@ -135,23 +134,12 @@ def test_k_limit_raises_before_upload():
 
     X = sp.random(50, RP_TILE_MAX + 400, density=0.002, format="csr", random_state=0)
     X.data[:] = 1
-    if not torch.cuda.is_available():
-        with pytest.raises(RecpackHipError):
-            recpack_amd.ItemKNN(K=16384).fit(X)  # two column tiles, 2 x 16 384 candidates: the large-K merge, no host-side limit
-    if not torch.cuda.is_available():  # below that no host-side limit: the call reaches the (absent) device
-        with pytest.raises(RecpackHipError):
-            recpack_amd.ItemKNN(K=RP_K_MAX + 1).fit(X)
-    Xs = sp.random(50, 3000, density=0.01, format="csr", random_state=0)
-    Xs.data[:] = 1
     Xw = sp.random(50, 2 * RP_WTILE_MAX + 400, density=0.002, format="csr", random_state=0)
     Xw.data[:] = 1
-    with pytest.raises(ValueError, match="normalize_X"):
-        recpack_amd.ItemKNN(K=16384, normalize_X=True).fit(Xw)  # three tiles of the float64 fit: 3 x 16 384 slots
-    if not torch.cuda.is_available():  # one tile: no host-side limit any more - the call reaches the (absent) device
-        with pytest.raises(RecpackHipError):
-            recpack_amd.ItemKNN(K=RP_K_MAX + 1).fit(Xs)
-        with pytest.raises(RecpackHipError):
-            recpack_amd.ItemKNN(K=RP_K_MAX + 1, normalize_X=True).fit(Xs)
+    if not torch.cuda.is_available():
+        for algo, M in ((recpack_amd.ItemKNN(K=16384), X), (recpack_amd.ItemKNN(K=RP_K_MAX + 1), X), (recpack_amd.ItemKNN(K=16384, normalize_X=True), Xw)):
+            with pytest.raises(RecpackHipError):
+                algo.fit(M)
 
 
 def test_fitted_models_pickle_round_trip(tmp_path):

@@ -273,7 +273,8 @@ def test_ease_c5_full_size(hip):
     ease_full_size(hip, "C5", n_cols=(8, 4, 4), n_users=32)
 
 
-@pytest.mark.parametrize("mode,K", [("cosine", 50), ("pearson", 50), ("time_distance", 50), ("cosine", 7000), ("pearson", 3000)])
+@pytest.mark.parametrize("mode,K", [("cosine", 50), ("pearson", 50), ("time_distance", 50), ("cosine", 7000), ("pearson", 3000), ("cosine", 19999),
+                                    ("pearson", 17000)])  # (the last two: K x 2 tiles >= 32 768 - the large-K merge of round 6, unsigned and signed)
 def test_time_aware_c2_sampled_rows(hip, mode, K):
     """The valued fits at C2 (100K x 20K, two column tiles, rows from 10 to 66K users: hash rows, tiled rows, merge) with
     seeded timestamps: 400 sampled rows tie-aware identical to the float64 oracle, values within 1e-11; weighted predict

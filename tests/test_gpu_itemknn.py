@@ -697,8 +697,9 @@ def test_fit_any_k_on_one_tile(hip):
     Sw = recpack_amd.ItemKNN(K=17000).fit(Xw).similarity_matrix_
     rw = onp.itemknn_fit(Xw, 17000)
     assert (Sw != onp.topk_to_csr(rw["idx"], rw["val"], rw["nnz"], 26000)).nnz == 0
-    with pytest.raises(ValueError):  # ... and only normalize_X keeps the limit
-        recpack_amd.ItemKNN(K=17000, normalize_X=True).fit(Xw)
+    # ... and so does normalize_X (three tiles of its float64 fit; checked tie-aware in test_fit_normalize_X_any_k): no ValueError left
+    Sn = recpack_amd.ItemKNN(K=17000, normalize_X=True).fit(Xw).similarity_matrix_
+    assert Sn.shape == (26000, 26000) and Sn.nnz == Sw.nnz
 
 
 def test_fit_any_k_over_several_tiles(hip):
@@ -757,14 +758,14 @@ def test_fit_normalize_X_any_k(hip):
     from recpack_amd.synth import powerlaw_csr
 
     _lib, ctx = hip
-    for (U, I, dens, Ks) in ((10000, 25000, 0.0015, (7000,)), (6000, 3000, 0.01, (2500,))):
+    for (U, I, dens, Ks) in ((10000, 25000, 0.0015, (7000, 12000)), (6000, 3000, 0.01, (2500,))):  # (12 000 x 3 tiles: the large-K merge, round 6)
         X = powerlaw_csr(U, I, dens, seed=47).to_scipy()
         dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
         cand = onp.itemknn_fit_normalized(X, None)  # every candidate of the similarity (CSR)
         for K in Ks:
             m = _lib.itemknn_fit(ctx, dX, K, normalize_X=True)
             idx, val, nnz = m.topk_download()
-            assert m.K == K and nnz.max() > 2048
+            assert m.K == K and nnz.max() > 2048 and (K < 12000 or nnz.max() > 7000)
             live = np.arange(idx.shape[1])[None, :] < nnz[:, None]
             assert ((idx[:, 1:] > idx[:, :-1]) | ~live[:, 1:]).all()  # canonical rows
             o = onp.itemknn_fit_normalized(X, m.K)
