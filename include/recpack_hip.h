@@ -355,8 +355,10 @@ int rphip_predict_topk_filtered_dev(rphip_ctx* ctx, const rphip_model* model, co
 /* LIMITS (the reference accepts any K: base.py:302-304, util.py:63-66).  Every fit - rphip_itemknn_fit[_ex] with and without normalize_X,
  * rphip_itemknn_fit_values / _timedist / _hermann - takes any K at any item count (round 6: from K x column tiles = 32 768 the per-tile
  * lists hold min(K, tile) entries and are merged where they lie, rp_merge_big.h, the rows in chunks of bounded scratch -
- * ItemKNN(K=20000) at 100 000 items is a 48 GB model).  The Kp of rphip_predict_topk* (min(Kp, n_items)): at most 2048 (the selection's LDS
- * buffers); larger values return RPHIP_ELIMIT - rphip_predict_full_*, the reference's own predict(), has no K. */
+ * ItemKNN(K=20000) at 100 000 items is a 48 GB model).  The Kp of rphip_predict_topk[_filtered][_dev]: any (round 6: beyond 2048, what the
+ * fused kernels' LDS buffers hold, the full scores of predict() are formed per chunk of users and cut to Kp on the device - float64 sums
+ * rounded to float32; models on a column slab return RPHIP_ELIMIT there); the caller's arrays hold n x Kp entries whatever the item count.
+ * The distributed routes (rphip_predict_topk_owner / _dist, rphip_predict_merge_topk) keep Kp <= 2048. */
 int rphip_predict_full_count(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred,
                              int64_t user_begin, int64_t user_end, int64_t* row_nnz_host, int64_t* total_out);
 int rphip_predict_full_fill(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred,

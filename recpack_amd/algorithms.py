@@ -22,8 +22,8 @@ this module is original.  When recpack itself is importable, :class:`Algorithm` 
 ``Algorithm`` so that ``isinstance`` / ``issubclass`` checks in recpack (e.g. the algorithm registry) accept these classes.
 
 K: every fit takes ANY ``K`` at any item count, as the reference does (round 6; beyond K x column tiles = 32 768 the rows' per-tile lists are
-merged where they lie and the rows are fitted in chunks of bounded scratch).  The ``K`` of ``predict_topk`` - an extension, not part of the
-reference - is at most 2048 and raises ``ValueError`` before anything is uploaded.
+merged where they lie and the rows are fitted in chunks of bounded scratch), and so does the ``K`` of ``predict_topk`` - an extension, not part
+of the reference: beyond 2048 it takes predict()'s full scores per chunk of users and cuts them on the device.
 """
 from __future__ import annotations
 
@@ -44,7 +44,7 @@ logger = logging.getLogger("recpack")
 
 RP_WTILE_MAX = 12288  # rp_itemknn_w.hip: items per column tile of the normalize_X fit (float64 sums)
 RP_K_TILES_MAX = 32768  # rp_select.h (RPS_FLAG): from K x column tiles = this the fits take the large-K merge (rp_merge_big.h)
-RP_K_MAX = 2048  # rp_common.h: largest effective K of a fit over several column tiles, and largest Kp of the fused top-Kp
+RP_K_MAX = 2048  # rp_common.h: largest Kp of the FUSED top-Kp kernels (beyond: full scores per user chunk + the large-K selection)
 RP_TILE_MAX = 25600  # rp_common.h: items of one column tile - up to here ItemKNN takes any K (round 4)
 
 try:  # recpack's own base class, when it is installed: registry / isinstance checks then accept the classes below
@@ -237,8 +237,6 @@ class ItemSimilarityMatrixAlgorithm(Algorithm):
         self._check_fit_complete()
         X = self._transform_predict_input(X)
         n_items = X.shape[1]
-        if min(int(K), max(1, n_items)) > RP_K_MAX:
-            raise ValueError(f"K={K} exceeds the supported maximum of {RP_K_MAX} scores per user")
         keep = None
         for items, select in ((exclude_items, False), (select_items, True)):
             if items is None:

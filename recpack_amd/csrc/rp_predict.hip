@@ -25,6 +25,7 @@
 #include "rp_comm.h"
 #include "rp_common.h"
 #include "rp_predict_i8.h"
+#include "rp_merge_big.h"
 #include "rp_select.h"
 #include "rp_wave.h"
 
@@ -1891,12 +1892,147 @@ static int rp_first_pass_i8(rphip_ctx* ctx, const rphip_model* mm, const rphip_c
   return rp_predict_user_i8(ctx, U8, n_fail + 1, leave_room);
 }
 
+// ---- (round 6) the fused top-Kp for ANY Kp ("lift Kp > 2048 the same way") ---------------------------------
+// Beyond RP_K_MAX the selection's LDS buffers do not hold a user's list.  Then the scores of a chunk of users are formed in full - the
+// kernels of predict() itself (modes 1 and 2 of k_predict_tile: count, then fill a CSR of every non-zero score, columns ascending,
+// float64 sums) - and every user's row is cut to its Kp best on the spot: a workgroup per user drops the history items and the filtered
+// columns in place, then runs the selection of rp_merge_big.h over the row (one list; ties to the smaller column; output in column
+// order).  Chunks of users bound the CSR to ~4 GB.  The values are predict()'s float64 sums rounded to float32 - not the fixed-point sums
+// of the fused kernels: the two routes may differ in the last bit of a score, and in which of two columns wins a tie that only the
+// rounding creates.  Dense models on all columns and neighbour-list models; a column slab keeps RPHIP_ELIMIT.
+__device__ __forceinline__ uint64_t rp_pred_ord64(double v) {
+  const uint64_t b = (uint64_t)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+__global__ void k_ll_to_i32(const long long* __restrict__ in, int32_t* __restrict__ out, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = (int32_t)in[i];
+}
+__global__ void k_i32_to_ll(const int32_t* __restrict__ in, long long* __restrict__ out, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = (long long)in[i];
+}
+
+__global__ void __launch_bounds__(RP_MBIG_THREADS) k_predict_topk_big(const int32_t* __restrict__ x_ptr, const int32_t* __restrict__ x_idx, int sorted_rows,
+                                                                     int user_begin, int n_users, const long long* __restrict__ indptr,
+                                                                     int32_t* __restrict__ full_idx, double* __restrict__ full_val, int Kp,
+                                                                     int exclude_history, const uint8_t* __restrict__ keep, int32_t* __restrict__ out_idx,
+                                                                     float* __restrict__ out_val, int32_t* __restrict__ out_nnz) {
+  __shared__ rp_mbig_smem S;
+  __shared__ int s_n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  for (int ul = blockIdx.x; ul < n_users; ul += gridDim.x) {
+    const int u = user_begin + ul;
+    const long long r0 = indptr[ul];
+    const int nr = (int)(indptr[ul + 1] - r0);
+    int32_t* ri = full_idx + r0;
+    double* rv = full_val + r0;
+    const int hs = x_ptr[u], he = x_ptr[u + 1];
+    // ---- in place: keep the entries that may be recommended (the write position never passes the read position)
+    int kept = 0;
+    for (int base = 0; base < nr; base += RP_MBIG_THREADS) {
+      const int e = base + tid;
+      int c = -1;
+      double v = 0.0;
+      bool ok = false;
+      if (e < nr) {
+        c = ri[e];
+        v = rv[e];
+        ok = v != 0.0 && (!keep || keep[c]);
+        if (ok && exclude_history) {
+          if (sorted_rows) {
+            int lo = hs, hi = he;
+            while (lo < hi) {
+              const int mid = (lo + hi) >> 1;
+              if (x_idx[mid] < c) lo = mid + 1; else hi = mid;
+            }
+            ok = !(lo < he && x_idx[lo] == c);
+          } else {
+            for (int k = hs; k < he && ok; ++k) ok = x_idx[k] != c;
+          }
+        }
+      }
+      const uint64_t m = __ballot(ok);
+      if (lane == 0) S.w[0][wave] = __popcll(m);
+      __syncthreads();  // (everybody has read its entry of this round)
+      int pos = kept + __popcll(m & lt_mask), tot = 0;
+      for (int q = 0; q < RP_MBIG_THREADS / 64; ++q) {
+        if (q < wave) pos += S.w[0][q];
+        tot += S.w[0][q];
+      }
+      if (ok) {
+        ri[pos] = c;
+        rv[pos] = v;
+      }
+      kept += tot;
+      __syncthreads();
+    }
+    if (tid == 0) s_n = kept;
+    __syncthreads();
+    const int n_valid = s_n;
+    const int n_out = rp_merge_big_row(
+        S, 1, 0, Kp, [&](int) { return n_valid; }, [&](int a) { return rp_pred_ord64(rv[a]); },
+        [&](int pos, int a) {
+          out_idx[(long long)ul * Kp + pos] = ri[a];
+          out_val[(long long)ul * Kp + pos] = (float)rv[a];
+        });
+    if (tid == 0) out_nnz[ul] = n_out;
+    __syncthreads();
+  }
+}
+
+static int rp_predict_topk_big(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin, int64_t user_end, int32_t Kp,
+                               int32_t exclude_history, const uint8_t* keep_dev, int32_t* idx_dev, float* val_dev, int32_t* nnz_dev) {
+  if (model->kind == RPHIP_MODEL_DENSE && (model->n_cols > 0 || model->cyc_nb))
+    RP_FAIL(RPHIP_ELIMIT, "Kp=%d beyond %d is served on models that hold all columns (not a column slab)", Kp, RP_K_MAX);
+  hipStream_t st = ctx->stream;
+  const int64_t n = user_end - user_begin, I = Xpred->n_items;
+  RP_TRY(rp_model_gather_wait(ctx, model, true));
+  // users per chunk: a row of the full result has at most I entries of 12 bytes
+  const int64_t UCH = std::max<int64_t>(1, std::min<int64_t>(n, ((int64_t)4 << 30) / (I * 12)));
+  char* sb = nullptr;
+  RP_TRY(rp_scratch(ctx, 14, (size_t)UCH * I * 12 + (size_t)(UCH + 1) * 24 + 256, (void**)&sb));
+  double* fv = (double*)sb;
+  long long* cnt64 = (long long*)(sb + (size_t)UCH * I * 8);
+  long long* ptr64 = cnt64 + (UCH + 1);
+  int32_t* cnt32 = (int32_t*)(ptr64 + (UCH + 1));
+  int32_t* ptr32 = cnt32 + (UCH + 1);
+  int32_t* fi = (int32_t*)(sb + (size_t)UCH * I * 8 + (size_t)(UCH + 1) * 24);
+  hipEvent_t ev;
+  rp_time_begin(ctx, &ev);
+  for (int64_t c0 = 0; c0 < n; c0 += UCH) {
+    const int64_t nch = std::min<int64_t>(UCH, n - c0);
+    rp_pred_params P;
+    rp_pred_fill(P, model, Xpred, user_begin + c0, user_begin + c0 + nch);
+    const int grid = (int)std::min<int64_t>(nch, (int64_t)ctx->n_cu * 8);
+    P.mode = 1;
+    P.row_nnz = cnt64;
+    RP_TRY(rp_pred_launch(ctx, P, grid));
+    const unsigned cg = (unsigned)std::min<int64_t>(1024, rp_cdiv(nch + 1, 256));
+    hipLaunchKernelGGL(k_ll_to_i32, dim3(cg), dim3(256), 0, st, cnt64, cnt32, (int)nch);
+    RP_TRY(rp_exclusive_scan_i32(ctx, cnt32, ptr32, nch));
+    hipLaunchKernelGGL(k_i32_to_ll, dim3(cg), dim3(256), 0, st, ptr32, ptr64, (int)nch + 1);
+    P.mode = 2;
+    P.row_nnz = nullptr;
+    P.indptr = ptr64;
+    P.full_idx = fi;
+    P.full_val = fv;
+    RP_TRY(rp_pred_launch(ctx, P, grid));
+    hipLaunchKernelGGL(k_predict_topk_big, dim3((unsigned)std::min<int64_t>(nch, (int64_t)ctx->n_cu * 8)), dim3(RP_MBIG_THREADS), 0, st, Xpred->x_ptr,
+                       Xpred->x_idx, Xpred->sorted_rows ? 1 : 0, (int)(user_begin + c0), (int)nch, ptr64, fi, fv, Kp, exclude_history, keep_dev,
+                       idx_dev + c0 * Kp, val_dev + c0 * Kp, nnz_dev + c0);
+    RP_HIP(hipGetLastError());
+  }
+  rp_time_end(ctx, ev, model->kind == RPHIP_MODEL_DENSE ? RPHIP_T_PREDICT_DENSE : RPHIP_T_PREDICT, rp_pred_work(Xpred, model, n, Kp));
+  return RPHIP_OK;
+}
+
 static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const rphip_csr* Xpred, int64_t user_begin,
                                 int64_t user_end, int32_t Kp, int32_t exclude_history, const uint8_t* keep_dev, int32_t* idx_dev,
                                 float* val_dev, int32_t* nnz_dev) {
   RP_TRY(rp_pred_check(ctx, model, Xpred, user_begin, user_end));
   if (!idx_dev || !val_dev || !nnz_dev) RP_FAIL(RPHIP_EINVAL, "NULL output");
-  if (Kp < 1 || Kp > RP_K_MAX) RP_FAIL(RPHIP_ELIMIT, "Kp=%d outside 1..%d", Kp, RP_K_MAX);
+  if (Kp < 1) RP_FAIL(RPHIP_EINVAL, "Kp=%d must be at least 1", Kp);
   RP_TRY(rp_set_device(ctx));
   const int64_t n = user_end - user_begin;
   if (n == 0) return RPHIP_OK;
@@ -1904,6 +2040,8 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
   hipMemsetAsync(idx_dev, 0xFF, (size_t)n * Kp * 4, st);
   hipMemsetAsync(val_dev, 0, (size_t)n * Kp * 4, st);
   hipMemsetAsync(nnz_dev, 0, (size_t)n * 4, st);
+  if (Kp > RP_K_MAX)  // (round 6) any Kp: full scores per chunk of users, cut to Kp on the spot
+    return rp_predict_topk_big(ctx, model, Xpred, user_begin, user_end, Kp, exclude_history, keep_dev, idx_dev, val_dev, nnz_dev);
   rp_pred_params P;
   rp_pred_fill(P, model, Xpred, user_begin, user_end);
   P.Kp = Kp;
@@ -2787,7 +2925,7 @@ extern "C" int rphip_predict_topk_filtered(rphip_ctx* ctx, const rphip_model* mo
   RP_TRY(rp_pred_check(ctx, model, Xpred, user_begin, user_end));
   RP_TRY(rp_model_gather_wait(ctx, model, true));
   if (!idx_host || !val_host || !nnz_host) RP_FAIL(RPHIP_EINVAL, "NULL output");
-  if (Kp < 1 || Kp > RP_K_MAX) RP_FAIL(RPHIP_ELIMIT, "Kp=%d outside 1..%d", Kp, RP_K_MAX);
+  if (Kp < 1) RP_FAIL(RPHIP_EINVAL, "Kp=%d must be at least 1", Kp);  // (beyond RP_K_MAX: rp_predict_topk_big)
   RP_TRY(rp_set_device(ctx));
   const int64_t n = user_end - user_begin;
   if (n == 0) return RPHIP_OK;

@@ -64,7 +64,11 @@ static int host_drivers(rphip_ctx* ctx) {
       std::vector<int32_t> pi((size_t)U * 10), pn((size_t)U);
       std::vector<float> pv((size_t)U * 10);
       CHECK(rphip_predict_topk(ctx, m, X, 0, U, 10, 1, pi.data(), pv.data(), pn.data()) == RPHIP_OK);
-      CHECK(rphip_predict_topk(ctx, m, X, 0, U, 4000, 1, pi.data(), pv.data(), pn.data()) == RPHIP_ELIMIT);
+      {  // Kp beyond the fused kernels: full scores per user chunk + the large-K selection
+        std::vector<int32_t> bi((size_t)U * 4000), bn((size_t)U);  // (the caller's arrays hold n x Kp entries whatever the item count)
+        std::vector<float> bv((size_t)U * 4000);
+        CHECK(rphip_predict_topk(ctx, m, X, 0, U, 4000, 1, bi.data(), bv.data(), bn.data()) == RPHIP_OK);
+      }
       std::vector<int64_t> rn((size_t)U);
       int64_t total = -1;
       CHECK(rphip_predict_full_count(ctx, m, X, 0, U, rn.data(), &total) == RPHIP_OK);

@@ -691,6 +691,40 @@ def test_predict_user_route_corner_cases(hip):
             ctx.set_option("predict_user_tasks", 1)
 
 
+def test_predict_topk_any_kp_dense(hip):
+    """predict_topk with Kp beyond 2048 on an EASE model (round 6): predict()'s full float64 sums per chunk of users cut on the device -
+    the top-Kp of X @ B (float64 from the downloaded f32 matrix), columns ascending, history removed, several chunks of users
+    (6 000 items x 12 bytes: the 4 GB chunk holds every user here, so a second call on a sub-range checks the offsets)."""
+    from recpack_amd.synth import powerlaw_csr
+
+    _lib, ctx = hip
+    X = powerlaw_csr(3000, 6000, 0.006, seed=97).to_scipy()
+    dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
+    m = _lib.ease_fit(ctx, dX, 30.0, 0.0)
+    B = m.dense_download().astype(np.float64)
+    S = np.asarray(X[:400] @ B)
+    for Kp, excl in ((2500, True), (5999, False), (6000, True)):
+        pi, pv, pn = _lib.predict_topk(ctx, m, dX, Kp, exclude_history=excl, user_begin=0, user_end=400)
+        sub = _lib.predict_topk(ctx, m, dX, Kp, exclude_history=excl, user_begin=150, user_end=170)
+        np.testing.assert_array_equal(sub[0], pi[150:170])
+        np.testing.assert_array_equal(sub[1].view(np.uint32), pv[150:170].view(np.uint32))
+        smax = np.abs(S).max()
+        for u in range(0, 400, 9):
+            sc = S[u].copy()
+            live = sc != 0.0
+            if excl:
+                live[X.indices[X.indptr[u]:X.indptr[u + 1]]] = False
+            k = min(Kp, int(live.sum()))
+            assert pn[u] == k
+            got = pi[u, :k]
+            assert (np.diff(got) > 0).all() and live[got].all()
+            np.testing.assert_allclose(pv[u, :k], sc[got], rtol=2e-6, atol=2e-7 * smax)
+            if k < int(live.sum()):  # nothing left out beats the worst one kept (up to the f32 rounding of the sums)
+                out = live.copy()
+                out[got] = False
+                assert sc[out].max() <= sc[got].min() + 2e-6 * smax
+
+
 def test_predict_two_pass_equals_one_pass(hip):
     """K9's two passes (fp16 or int8 rows for a candidate list, exact f32 scores of the candidates, a proof per user, the one-pass kernel
     for users without one - options predict_half, predict_int8) give the one-pass kernel's top-Kp bit for bit: fitted models, several Kp, history

@@ -670,8 +670,17 @@ def test_limits_and_dense_corners(hip):
         for Kp in (384, 385, 2048):  # wave kernel's largest pool, first value of the workgroup kernel, RP_K_MAX
             pi, pv, pn = _lib.predict_topk(ctx, m, dX, Kp, exclude_history=True, user_begin=0, user_end=100)
             check_topk_scores(scores, pi, pv, pn, Kp, exclude=X[:100], hist=X[:100] if Kp <= 384 else None, S=S)
-        with pytest.raises(_lib.RecpackHipError):
-            _lib.predict_topk(ctx, m, dX, 2049)
+        # (round 6) beyond RP_K_MAX: predict()'s full scores per chunk of users, cut to Kp on the device - exact float64 sums (hist=None),
+        # with and without history removal, with an item filter; Kp past the number of scores returns them all
+        for Kp in (2049, 2200, I):
+            for excl in (True, False):
+                pi, pv, pn = _lib.predict_topk(ctx, m, dX, Kp, exclude_history=excl, user_begin=0, user_end=100)
+                assert pi.shape == (100, min(Kp, I))
+                check_topk_scores(scores, pi, pv, pn, min(Kp, I), exclude=X[:100] if excl else None, S=S)
+        keep = (np.arange(I) % 3 != 0).astype(np.uint8)
+        pi, pv, pn = _lib.predict_topk(ctx, m, dX, 2100, exclude_history=True, item_keep=keep, user_begin=0, user_end=100)
+        check_topk_scores(onp.pipeline_scores(scores, item_keep=keep), pi, pv, pn, 2100, exclude=X[:100], S=S)
+        assert not np.isin(pi[pi >= 0] % 3, [0]).any()
 
 
 def test_fit_any_k_on_one_tile(hip):
