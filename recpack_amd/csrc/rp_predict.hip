@@ -606,9 +606,19 @@ __global__ void __launch_bounds__(256) k_dense_to_i8(const float* __restrict__ B
     const float* row = B + (long long)i * ld;
     int8_t* out = Q + (long long)i * ld;
     float m = 0.0f;
-    for (int j = threadIdx.x * 4; j < n16; j += 1024) {
-      const float4 v = *reinterpret_cast<const float4*>(row + j);
-      m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    {  // (round 6) eight 16-byte loads in flight per thread: with one per iteration the sweep ran at 2.5 TB/s
+      int j = threadIdx.x * 4;
+      for (; j + 7 * 1024 < n16; j += 8 * 1024) {
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4*>(row + j + q * 1024);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m = fmaxf(m, fmaxf(fmaxf(fabsf(v[q].x), fabsf(v[q].y)), fmaxf(fabsf(v[q].z), fabsf(v[q].w))));
+      }
+      for (; j < n16; j += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(row + j);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+      }
     }
     m = wg_max(m);
     const bool ok = m > 0.0f && m < 3.0e38f;
