@@ -7,6 +7,7 @@
  *   rphip_potrf_trtri_128        the 128 x 128 diagonal-block kernel alone (tools/potrf_check.py, tests/test_gpu_ease.py)
  *   rphip_model_adopt_gather     hand a pending panel gather to another model (tools/dist_rank_emulate.py)
  *   rphip_gemm_nt_f32_ex         the NT product with the triangular K clipping of the solve (tests/test_gpu_ease.py)
+ *   rphip_predict_stats          users the two-pass predict sent to the exact pass in the last call (tests/test_gpu_ease.py)
  * The environment switches RP_CHOL_TRACE, RP_INV_TRACE, RP_CHOL_MEASURE_SCALES, RP_N22_PLANES, RP_EASE_SCALE_ROWS, RP_K9_I8_KC
  * exist only in the diagnostic build (make -C recpack_amd/csrc diag -> librecpack_hip_diag.so, selected with RECPACK_HIP_LIB).
  */
@@ -48,6 +49,12 @@ int rphip_model_adopt_gather(rphip_model* dst, rphip_model* src);
  * rank's columns), [1] this rank's, [2] candidates per user, [3] on a loop-back communicator: microseconds of the stand-in that forms the other ranks'
  * parts from the f32 matrix passed with the int8 rows (tools/dist_rank_emulate.py subtracts it). */
 int rphip_predict_owner_stats(rphip_ctx* ctx, int64_t* out4);
+
+/* The last rphip_predict_topk* call of this context on one GPU: out4[0] users the two-pass predict could not prove from its candidate list
+ * (they were served by the exact one-pass kernel: same results, three times the traffic), [1] users of the call, [2] candidates per user,
+ * [3] 1 when the first pass was the one-task-per-user kernel (rp_predict_i8.hip).  [0] = [1] = -1: the call did not take the two-pass route.
+ * (tests/test_gpu_ease.py: a tiling whose last wave owns four threads must not send every user to the exact pass - round 6.) */
+int rphip_predict_stats(rphip_ctx* ctx, int64_t* out4);
 
 #ifdef __cplusplus
 }

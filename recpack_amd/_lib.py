@@ -134,6 +134,7 @@ DIAG_PROTOTYPES = {
     "rphip_comm_loopback_create": (C.c_int, [_p, _i32, _i32, C.c_double, C.c_double, _pp]),
     "rphip_ease_fit_dist_stats": (C.c_int, [_p, _p]),
     "rphip_predict_owner_stats": (C.c_int, [_p, _p]),
+    "rphip_predict_stats": (C.c_int, [_p, _p]),
 }
 
 _lock = threading.Lock()
@@ -811,6 +812,14 @@ def predict_owner_stats(ctx: Context) -> dict:
     out = np.zeros(4, dtype=np.int64)
     check(ctx.lib.rphip_predict_owner_stats(ctx.handle, _np_ptr(out)))
     return {"unproven_all_ranks": int(out[0]), "unproven_here": int(out[1]), "candidates_per_user": int(out[2]), "loopback_standin_us": int(out[3])}
+
+
+def predict_stats(ctx: Context) -> dict:
+    """The last single-GPU ``predict_topk*`` of this context (diagnostic): users the two-pass predict sent to the exact pass, users of the
+    call (both -1 when the call took another route), candidates per user, whether the first pass was the per-user int8 kernel."""
+    out = np.zeros(4, dtype=np.int64)
+    check(ctx.lib.rphip_predict_stats(ctx.handle, _np_ptr(out)))
+    return {"exact_pass_users": int(out[0]), "users": int(out[1]), "candidates_per_user": int(out[2]), "per_user_first_pass": bool(out[3])}
 
 
 def ease_fit_dist_stats(ctx: Context) -> dict:

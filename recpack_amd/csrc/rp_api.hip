@@ -139,6 +139,18 @@ int rp_scratch(rphip_ctx* ctx, int slot, size_t bytes, void** out) {
   return RPHIP_OK;
 }
 
+// the plane workspaces of the large GEMMs (slots 8 - 13: tens of GB after a solve) go back to the driver; the caller has synchronised
+// the stream.  rphip_ctx_trim, and a predict whose quantised copy of the model would not fit beside them (rp_model_half)
+int rp_scratch_release_planes(rphip_ctx* ctx) {
+  for (int slot = 8; slot < 14; ++slot) {
+    rp_buf& b = ctx->scratch[slot];
+    if (b.p) RP_HIP(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  return RPHIP_OK;
+}
+
 // ---- block cache -------------------------------------------------------------------------------------
 // A freed block carries an event recorded on the context's stream at the time of the free: whoever gets the block
 // next waits for it first, so kernels that were still reading the block when its owner was destroyed are done
@@ -291,13 +303,7 @@ extern "C" int rphip_ctx_trim(rphip_ctx* ctx) {
   RP_TRY(rp_set_device(ctx));
   RP_HIP(hipStreamSynchronize(ctx->stream));
   rp_dev_trim(ctx);
-  for (int slot = 8; slot < 14; ++slot) {  // the plane workspaces of the large GEMMs
-    rp_buf& b = ctx->scratch[slot];
-    if (b.p) RP_HIP(hipFree(b.p));
-    b.p = nullptr;
-    b.cap = 0;
-  }
-  return RPHIP_OK;
+  return rp_scratch_release_planes(ctx);
 }
 
 extern "C" int rphip_ctx_set_option(rphip_ctx* ctx, const char* name, int64_t value) {

@@ -110,6 +110,7 @@ struct rphip_ctx {
   int predict_half_w = 11200;  // columns per tile of that first pass (0: the model's own tiling, one workgroup per CU)
   int predict_int8 = 1;      // ... on int8 rows (one scale per row) instead of fp16 ones: half the bytes again, a longer candidate list
   int predict_user_tasks = 1;  // ... with one task per USER (rp_predict_i8.hip) instead of one per (user, column tile) + a merge kernel
+  int64_t predict_stats[4] = {-1, -1, 0, 0};  // the last single-GPU predict: users sent to the exact pass, users of the call (-1: not the two-pass route), Kc, 1 = per-user first pass
   int64_t owner_stats[4] = {0, 0, 0, 0};  // the last rphip_predict_topk_owner: users without a proof (all ranks / this rank), Kc, loop-back: us of the stand-in for the others' parts
   int comm_broadcast_split = 1;  // a broadcast of >= 8 MiB among more than two ranks travels as scatter + all-gather (rp_comm_broadcast)
   int pw_wt32 = 4096;        // tile width of the 32-bit sums: 2048 or 4096 (tuning)
@@ -214,6 +215,7 @@ int rp_model_gather_wait(rphip_ctx* ctx, const rphip_model* m, bool on_stream);
 
 // ---- helpers (rp_api.hip) ------------------------------------------------------------------------
 int rp_scratch(rphip_ctx* ctx, int slot, size_t bytes, void** out);
+int rp_scratch_release_planes(rphip_ctx* ctx);
 int rp_dev_alloc(rphip_ctx* ctx, size_t bytes, void** out);  // hipMalloc through the context's block cache
 void rp_dev_free(rphip_ctx* ctx, void* p);                   // NULL is fine; blocks not from rp_dev_alloc go to hipFree
 void rp_dev_trim(rphip_ctx* ctx);                            // release every cached block (whole regions; parts of a split region stay)

@@ -1806,6 +1806,13 @@ static int rp_model_half(rphip_ctx* ctx, const rphip_model* m, int kind) {
     hipMemGetInfo(&free_b, &total_b);
     const size_t need = (size_t)rows * m->ld * esz + std::min<size_t>((size_t)16 << 30, total_b / 10);
     if (free_b + ctx->cached_bytes < need) {
+      // (round 6) after a fit at 200 000 items the solve's plane workspaces hold most of what the model leaves: a predict needs none
+      // of them, the next fit allocates them again (the one-pass kernel it would take otherwise costs three times the first pass)
+      RP_HIP(hipStreamSynchronize(st));
+      RP_TRY(rp_scratch_release_planes(ctx));
+      hipMemGetInfo(&free_b, &total_b);
+    }
+    if (free_b + ctx->cached_bytes < need) {
       m->b16_failed = true;
       return RPHIP_OK;
     }
@@ -2047,6 +2054,8 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
   const int64_t n = user_end - user_begin;
   if (n == 0) return RPHIP_OK;
   hipStream_t st = ctx->stream;
+  ctx->predict_stats[0] = ctx->predict_stats[1] = -1;
+  ctx->predict_stats[2] = ctx->predict_stats[3] = 0;
   hipMemsetAsync(idx_dev, 0xFF, (size_t)n * Kp * 4, st);
   hipMemsetAsync(val_dev, 0, (size_t)n * Kp * 4, st);
   hipMemsetAsync(nnz_dev, 0, (size_t)n * 4, st);
@@ -2160,9 +2169,14 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
     }
   }
   // (a borrowed slab whose leading dimension is a multiple of 8 but not of 16 cannot be read as int8 rows: it keeps the fp16 copy)
-  const bool want_i8 = ctx->predict_int8 && fits2 && (model->ld % 16) == 0;
   int kc_i8 = ((Kp + 92 + 63) / 64) * 64;
   if (const char* e = rp_diag_env("RP_K9_I8_KC")) kc_i8 = std::max(64, atoi(e) / 64 * 64);
+  // (round 6) the per-user first pass (rp_predict_i8.hip) has its own tiling: it does not need the narrow tiles of the (user, tile) pass
+  // to exist - beyond 15 x predict_half_w items (168 000) `fits2` is false, and a 200 000-item model took the one-pass f32 kernel for
+  // every user (27 s at 5M x 200K where the int8 pass takes a third)
+  const bool user_pass_certain = model->kind == RPHIP_MODEL_DENSE && ctx->predict_half && ctx->predict_user_tasks && !keep_dev &&
+                                 (!exclude_history || Xpred->sorted_rows) && kc_i8 <= 256 && (int64_t)4 * kc_i8 <= (int64_t)P.n_items;
+  const bool want_i8 = ctx->predict_int8 && (fits2 || user_pass_certain) && (model->ld % 16) == 0;
   const int Kc = want_i8 && kc_i8 <= 512 && (int64_t)4 * kc_i8 <= (int64_t)P.n_items ? kc_i8 : ((Kp + 24 + 63) / 64) * 64;
   const bool two_pass = model->kind == RPHIP_MODEL_DENSE && ctx->predict_half && Kc <= 512 && (int64_t)4 * Kc <= (int64_t)P.n_items && T <= 15;
   // ONE predicate decides both who enters the per-user first pass and who may leave a gathered model's f32 rows in flight
@@ -2237,6 +2251,10 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
         int h_fail = 0;
         RP_HIP(hipMemcpyAsync(&h_fail, n_fail, 4, hipMemcpyDeviceToHost, st));
         RP_HIP(hipStreamSynchronize(st));
+        ctx->predict_stats[0] = h_fail;
+        ctx->predict_stats[1] = n;
+        ctx->predict_stats[2] = Kc;
+        ctx->predict_stats[3] = 1;
         for (int64_t f0 = 0; f0 < h_fail; f0 += FCH) {
           const int64_t nf = std::min<int64_t>(FCH, h_fail - f0);
           const int grid = (int)std::min<int64_t>(nf * T, (int64_t)ctx->n_cu * 8), mgrid = (int)std::min<int64_t>(nf, (int64_t)ctx->n_cu * 8);
@@ -2374,6 +2392,9 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
       int h_fail = 0;
       RP_HIP(hipMemcpyAsync(&h_fail, n_fail, 4, hipMemcpyDeviceToHost, st));
       RP_HIP(hipStreamSynchronize(st));
+      ctx->predict_stats[0] = h_fail;
+      ctx->predict_stats[1] = n;
+      ctx->predict_stats[2] = Kc;
       // list entries per launch: what the tile lists hold (one tile: no lists, the kernel writes the output rows themselves)
       const int64_t FCH = T == 1 ? std::max<int64_t>(1, h_fail) : std::max<int64_t>(1, std::min<int64_t>(nchm, (int64_t)(szT / ((size_t)T * Kp))));
       for (int64_t f0 = 0; f0 < h_fail; f0 += FCH) {
@@ -2904,6 +2925,14 @@ extern "C" int rphip_predict_owner_stats(rphip_ctx* ctx, int64_t* out4) {
   RP_ENTER(ctx);
   if (!ctx || !out4) RP_FAIL(RPHIP_EINVAL, "NULL argument");
   ::memcpy(out4, ctx->owner_stats, sizeof(ctx->owner_stats));
+  return RPHIP_OK;
+}
+
+// (diagnostic, include/recpack_hip_diag.h) the last single-GPU predict of this context
+extern "C" int rphip_predict_stats(rphip_ctx* ctx, int64_t* out4) {
+  RP_ENTER(ctx);
+  if (!ctx || !out4) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  ::memcpy(out4, ctx->predict_stats, sizeof(ctx->predict_stats));
   return RPHIP_OK;
 }
 

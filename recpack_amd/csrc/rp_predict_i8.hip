@@ -76,6 +76,7 @@ __global__ void __launch_bounds__(RPU_THREADS, 8) k_predict_user_i8(rp_i8_params
   RP_LDS int* s_cnt = (RP_LDS int*)&sel.misc[RPS_USER];                    // [0] list entries (the append position), [1] history items inside the tile, [2] next user,
                                                                            // [4], [5] entries appended by the even / odd tiles (see the count below)
   RP_LDS float* s_tau = (RP_LDS float*)&sel.misc[RPS_USER + 8];            // [16]
+  RP_LDS int* s_cw = (RP_LDS int*)&sel.misc[RPS_LCNT];                     // [16] (the selection's own between its calls: here only between barriers of the first tile)
   const int32_t* lcol_g = reinterpret_cast<const int32_t*>(smem);          // (the selection's source takes generic pointers)
   const float* lval_g = reinterpret_cast<const float*>(smem + (size_t)RPU_CAP * 4);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -192,29 +193,55 @@ __global__ void __launch_bounds__(RPU_THREADS, 8) k_predict_user_i8(rp_i8_params
           __syncthreads();
           n_hist = s_cnt[1];
         }
-        const int nwa = (w16 + 63) >> 6;  // waves that own columns of this tile
-        const int R = (Kc + n_hist + nwa - 1) / nwa;
+        // (round 6) which wave counts down how many of its threads' best scores?  cw = the wave's threads with a score.  The level L is
+        // the smallest number with L x (waves with cw >= L) >= need: the waves that reach it count L, the others nothing - a wave of
+        // four threads (or of a few sold columns) would count its worst one and drag the threshold to the floor.  Only a tile too
+        // thin for that fills up like water: sum of min(cw, L) >= need.  (Until round 5 all waves counted the same R: a tile
+        // whose last wave owns four threads - 200 000 items: 13 tiles of 15 424 columns, 964 threads - never got a threshold, handed
+        // on every column and sent ALL users to the exact pass.)
+        const int need = Kc + n_hist;
         float m = -INFINITY;
 #pragma unroll
         for (int e = 0; e < 16; ++e)
           if (r[e] != 0.0f) m = fmaxf(m, r[e]);
-        float rth = -INFINITY;
-        if (wave < nwa && R <= 64) {
-          for (int it = 0; it < R; ++it) {
-            float mx = m;
+        const int cw = __popcll(__ballot(m > -INFINITY));
+        if (lane == 0) s_cw[wave] = cw;
+        __syncthreads();
+        int R = 0;
+        bool level = false;
+        {
+          int S = 0, A = 0;
 #pragma unroll
-            for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
-            rth = mx;
-            const unsigned long long hit = __ballot(m == mx);
-            if (lane == __ffsll((long long)hit) - 1) m = -INFINITY;
+          for (int q = 0; q < NW; ++q) {
+            const int c = s_cw[q];
+            S += min(c, lane + 1);
+            A += c >= lane + 1 ? lane + 1 : 0;
           }
+          const unsigned long long ok_a = __ballot(A >= need), ok_s = __ballot(S >= need);
+          if (ok_a) {
+            const int L = __ffsll((long long)ok_a);
+            R = cw >= L ? L : 0;
+            level = true;
+          } else if (ok_s) {
+            R = min(cw, __ffsll((long long)ok_s));
+            level = true;
+          }  // (else: fewer than `need` threads of the tile have a score)
         }
-        if (lane == 0) s_tau[wave] = (wave < nwa) ? rth : INFINITY;
+        float rth = INFINITY;
+        for (int it = 0; it < R; ++it) {
+          float mx = m;
+#pragma unroll
+          for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+          rth = mx;
+          const unsigned long long hit = __ballot(m == mx);
+          if (lane == __ffsll((long long)hit) - 1) m = -INFINITY;
+        }
+        if (lane == 0) s_tau[wave] = level ? rth : -INFINITY;  // (a wave that counts nothing leaves the minimum alone: +inf)
         __syncthreads();
         float t = s_tau[0];
 #pragma unroll
         for (int q = 1; q < NW; ++q) t = fminf(t, s_tau[q]);
-        if (t > -INFINITY && t < INFINITY) {  // (fewer than R scores in some wave: this tile hands on everything, the next one tries again)
+        if (t > -INFINITY && t < INFINITY) {  // (fewer than `need` scores in the tile: it hands on everything, the next one tries again)
           tau = t;
           have_tau = true;
         }

@@ -691,6 +691,37 @@ def test_predict_user_route_corner_cases(hip):
             ctx.set_option("predict_user_tasks", 1)
 
 
+@pytest.mark.parametrize("n_items", [13344, 18560])
+def test_predict_user_route_keeps_its_users_on_ragged_tiles(hip, n_items):
+    """(round 6) The per-user first pass finds its first threshold from the best score of every thread.  Until round 5 every wave of the
+    tile had to count down the same number of them: a tile whose last wave owns a handful of threads (200 000 items: 13 tiles of
+    15 424 columns = 964 threads, four in the last wave) never got a threshold, handed on every column, overflowed its list - and ALL
+    users went to the exact one-pass kernel (same results, 29 s instead of 17 s at 5M x 200K).  The results cannot show that, the
+    counter of include/recpack_hip_diag.h does: catalogues whose tiles end in a wave of four threads (one tile of 836 threads, two
+    tiles of 580) keep their users on the two-pass route as a catalogue of whole waves does (2 % without a proof at 13 312 items), and
+    give the one-pass kernel's result bit for bit."""
+    from recpack_amd.synth import powerlaw_csr
+
+    _lib, ctx = hip
+    X = powerlaw_csr(40000, n_items, 40.0 / n_items, seed=95).to_scipy()
+    dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
+    m = _lib.ease_fit(ctx, dX, 100.0, 0.0)
+    try:
+        for excl in (True, False):
+            ctx.set_option("predict_half", 0)
+            want = _lib.predict_topk(ctx, m, dX, 100, exclude_history=excl)
+            assert _lib.predict_stats(ctx)["users"] == -1
+            ctx.set_option("predict_half", 1)
+            got = _lib.predict_topk(ctx, m, dX, 100, exclude_history=excl)
+            st = _lib.predict_stats(ctx)
+            assert st["per_user_first_pass"] and st["users"] == X.shape[0] and st["candidates_per_user"] == 192, st
+            assert 0 <= st["exact_pass_users"] <= 0.06 * X.shape[0], st
+            for a, b in zip(got, want):
+                np.testing.assert_array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+    finally:
+        ctx.set_option("predict_half", 1)
+
+
 def test_predict_topk_any_kp_dense(hip):
     """predict_topk with Kp beyond 2048 on an EASE model (round 6): predict()'s full float64 sums per chunk of users cut on the device -
     the top-Kp of X @ B (float64 from the downloaded f32 matrix), columns ascending, history removed, several chunks of users
