@@ -193,12 +193,12 @@ __global__ void __launch_bounds__(RPU_THREADS, 8) k_predict_user_i8(rp_i8_params
           __syncthreads();
           n_hist = s_cnt[1];
         }
-        // (round 6) which wave counts down how many of its threads' best scores?  cw = the wave's threads with a score.  The level L is
-        // the smallest number with L x (waves with cw >= L) >= need: the waves that reach it count L, the others nothing - a wave of
-        // four threads (or of a few sold columns) would count its worst one and drag the threshold to the floor.  Only a tile too
-        // thin for that fills up like water: sum of min(cw, L) >= need.  (Until round 5 all waves counted the same R: a tile
-        // whose last wave owns four threads - 200 000 items: 13 tiles of 15 424 columns, 964 threads - never got a threshold, handed
-        // on every column and sent ALL users to the exact pass.)
+        // (round 6) which wave counts down how many of its threads' best scores?  cw = the wave's threads with a score; every wave
+        // takes its share of `need` in proportion to it, R = ceil(need x cw / sum of cw): the same quantile everywhere, the shares add
+        // up to `need` or more, and no wave is asked for more than it has.  (Until round 5 all waves counted the same R.  A tile whose
+        // last wave owns four threads - 200 000 items: 13 tiles of 15 424 columns, 964 threads - never got a threshold, handed on every
+        // column and sent ALL users to the exact pass; at 50 000 items - 784 threads, sixteen in the last wave - that wave counted down
+        // to its 15th of 16 and the threshold fell to the floor: a quarter of the users overflowed their list.)
         const int need = Kc + n_hist;
         float m = -INFINITY;
 #pragma unroll
@@ -207,26 +207,11 @@ __global__ void __launch_bounds__(RPU_THREADS, 8) k_predict_user_i8(rp_i8_params
         const int cw = __popcll(__ballot(m > -INFINITY));
         if (lane == 0) s_cw[wave] = cw;
         __syncthreads();
-        int R = 0;
-        bool level = false;
-        {
-          int S = 0, A = 0;
+        int tot = 0;
 #pragma unroll
-          for (int q = 0; q < NW; ++q) {
-            const int c = s_cw[q];
-            S += min(c, lane + 1);
-            A += c >= lane + 1 ? lane + 1 : 0;
-          }
-          const unsigned long long ok_a = __ballot(A >= need), ok_s = __ballot(S >= need);
-          if (ok_a) {
-            const int L = __ffsll((long long)ok_a);
-            R = cw >= L ? L : 0;
-            level = true;
-          } else if (ok_s) {
-            R = min(cw, __ffsll((long long)ok_s));
-            level = true;
-          }  // (else: fewer than `need` threads of the tile have a score)
-        }
+        for (int q = 0; q < NW; ++q) tot += s_cw[q];
+        const bool level = tot >= need;  // (else: fewer than `need` threads of the tile have a score)
+        const int R = level ? (int)(((long long)need * cw + tot - 1) / tot) : 0;
         float rth = INFINITY;
         for (int it = 0; it < R; ++it) {
           float mx = m;
