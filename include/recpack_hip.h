@@ -132,8 +132,8 @@ int rphip_ctx_trim(rphip_ctx* ctx);
  *   "predict_user_tasks"  1 (default) | 0.  The int8 first pass with one task per USER (round 5): a workgroup walks all column tiles of a
  *                       user, keeps a tile's sums in registers, hands the columns above a running lower bound of the user's Kc-th best
  *                       score to ONE candidate list in LDS and cuts it to Kc entries itself - no per-tile lists, no merge kernel.  0: one
- *                       task per (user, column tile) and a merge (round 4; also taken with an item filter, when history removal meets
- *                       unsorted rows, and for candidate lists longer than 256).  The results are identical either way.
+ *                       task per (user, column tile) and a merge (round 4; also taken when history removal meets unsorted rows, and for
+ *                       candidate lists longer than 256; until round 6 also with an item filter).  The results are identical either way.
  *   "comm_broadcast_split"  1 (default) | 0.  Broadcasts of 8 MiB and more among MORE than two ranks travel as scatter + all-gather
  *                       (grouped point-to-point sends on RCCL: no link of a fully connected xGMI node carries more than 2 / W of the
  *                       message); 0: the transport's own broadcast for every size.  bench.py switches it off when operation 4 of

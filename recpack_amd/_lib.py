@@ -7,6 +7,7 @@ or ``make -C recpack_amd/csrc``.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import os
 import sys
 import threading
@@ -197,6 +198,24 @@ def check(code: int):
         raise RecpackHipError(code, msg.decode("utf-8", "replace") if msg else "")
 
 
+class _Child:
+    """A native object made on a context (matrix, model, communicator): it points into the context, so it is destroyed before it
+    - `Context.close` sees to that - and NOT after it: when the garbage collector finalises the context of an unreachable cycle first
+    (any order is allowed there, and the weak references are gone by then), the child finds the context closed and leaves its native
+    object alone.  Nothing here may depend on module globals: at interpreter exit they are None before the last objects die."""
+
+    _destroy = ""        # the library's destructor for this kind
+    _close_last = False  # communicators go after the models that may still hold operations on them
+
+    def close(self):
+        ctx = getattr(self, "ctx", None)
+        if getattr(self, "handle", None) and ctx is not None and getattr(ctx, "handle", None):
+            getattr(ctx.lib, self._destroy)(self.handle)
+        self.handle = None
+
+    __del__ = close
+
+
 def _np_ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -211,9 +230,16 @@ class Context:
         self.handle = h
         self.device = int(device)
         self.stream = int(stream) if stream else None  # the caller's HIP stream, if the context runs on one
+        self._children = weakref.WeakSet()  # matrices, models and communicators made on this context (they point into it)
 
     def close(self):
+        """Destroy the context - after everything that was made on it: a matrix, model or communicator that is still alive is closed
+        first (its native object holds a pointer to the context).  When the garbage collector finalises a context BEFORE its children
+        (objects of one unreachable cycle are finalised in any order, and the weak references to them are already gone), the children
+        find the context closed and leave their native objects alone: see `_Child`."""
         if getattr(self, "handle", None):
+            for child in sorted(list(getattr(self, "_children", ())), key=lambda c: c._close_last):  # (communicators last)
+                child.close()
             self.lib.rphip_ctx_destroy(self.handle)
             self.handle = None
 
@@ -250,11 +276,14 @@ class Context:
         return {"n_cu": ncu.value, "hbm_bytes": hbm.value, "arch": buf.value.decode()}
 
 
-class DeviceCSR:
+class DeviceCSR(_Child):
     """Device-resident binary interaction matrix (rphip_csr): X, X^T, item degrees."""
+
+    _destroy = "rphip_csr_destroy"
 
     def __init__(self, ctx: Context, handle, keepalive=None):
         self.ctx, self.handle, self._keep = ctx, handle, keepalive
+        ctx._children.add(self)
         nu, ni, nz = C.c_int64(), C.c_int64(), C.c_int64()
         check(ctx.lib.rphip_csr_shape(handle, C.byref(nu), C.byref(ni), C.byref(nz)))
         self.shape = (nu.value, ni.value)
@@ -367,19 +396,16 @@ class DeviceCSR:
         check(self.ctx.lib.rphip_csr_num_products(self.ctx.handle, self.handle, C.byref(p)))
         return p.value
 
-    def close(self):
-        if getattr(self, "handle", None):
-            self.ctx.lib.rphip_csr_destroy(self.handle)
-            self.handle = None
-
-    __del__ = close
 
 
-class Model:
+class Model(_Child):
     """Fitted similarity on the device (rphip_model)."""
+
+    _destroy = "rphip_model_destroy"
 
     def __init__(self, ctx: Context, handle):
         self.ctx, self.handle = ctx, handle
+        ctx._children.add(self)
         kind, K = C.c_int32(), C.c_int32()
         ni, r0, r1 = C.c_int64(), C.c_int64(), C.c_int64()
         check(ctx.lib.rphip_model_info(handle, C.byref(kind), C.byref(ni), C.byref(r0), C.byref(r1), C.byref(K)))
@@ -490,12 +516,6 @@ class Model:
         """(diagnostic: include/recpack_hip_diag.h) take over the pending panel gather of `other` - tools/dist_rank_emulate.py."""
         check(self.ctx.lib.rphip_model_adopt_gather(self.handle, other.handle))
 
-    def close(self):
-        if getattr(self, "handle", None):
-            self.ctx.lib.rphip_model_destroy(self.handle)
-            self.handle = None
-
-    __del__ = close
 
 
 # ---- communicator (include/recpack_hip.h: rphip_comm) --------------------------------------------------------------------
@@ -518,15 +538,19 @@ class _DevBytes:
         self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
 
 
-class Comm:
+class Comm(_Child):
     """A group of ranks, one GPU each, with stream-ordered collectives on device memory (rphip_comm).
 
     ``Comm.rccl`` is the library's own RCCL communicator (the product path on a multi-GPU node); ``Comm.torch`` hands the
     library a table of callbacks that run the same operations through a torch.distributed group - any backend, so the
     distributed solve can be driven over gloo with the ranks sharing a GPU (tests)."""
 
+    _destroy = "rphip_comm_destroy"
+    _close_last = True
+
     def __init__(self, ctx: Context, handle, keep=None):
         self.ctx, self.handle, self._keep = ctx, handle, keep
+        ctx._children.add(self)
         w, r, k = C.c_int32(), C.c_int32(), C.c_int32()
         check(ctx.lib.rphip_comm_info(handle, C.byref(w), C.byref(r), C.byref(k)))
         self.world, self.rank, self.is_rccl = w.value, r.value, bool(k.value)
@@ -693,12 +717,6 @@ class Comm:
             out["ok"] = out["ok"] and bad == 0
         return out
 
-    def close(self):
-        if getattr(self, "handle", None):
-            self.ctx.lib.rphip_comm_destroy(self.handle)
-            self.handle = None
-
-    __del__ = close
 
 
 def itemknn_gather(ctx: Context, comm: Comm, local: Model, row_bounds) -> Model:

@@ -1882,7 +1882,7 @@ static void rp_launch_rescore_kc(rphip_ctx* ctx, const rp_rescore_params& R) {  
 // by his local id).  n_fail: [0] the fail list's count, [1] the pass's ticket (both zeroed by the caller).
 static int rp_first_pass_i8(rphip_ctx* ctx, const rphip_model* mm, const rphip_csr* Xpred, const rp_pred_params& P, int64_t user_begin, int64_t n,
                             int Kc, int exclude_history, int32_t* a_idx, float* a_val, int32_t* a_nnz, int32_t* fail, int32_t* n_fail,
-                            bool leave_room) {
+                            bool leave_room, const uint8_t* keep_dev = nullptr) {
   rp_i8_params U8;
   U8.x_ptr = Xpred->x_ptr;
   U8.x_idx = Xpred->x_idx;
@@ -1896,6 +1896,7 @@ static int rp_first_pass_i8(rphip_ctx* ctx, const rphip_model* mm, const rphip_c
   U8.cyc_w = P.cyc_w;
   U8.cyc_r = P.cyc_r;
   U8.exclude_history = exclude_history;
+  U8.keep = keep_dev;
   U8.user_begin = (int)user_begin;
   U8.n_users = (int)n;
   U8.Kc = Kc;
@@ -2174,7 +2175,7 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
   // (round 6) the per-user first pass (rp_predict_i8.hip) has its own tiling: it does not need the narrow tiles of the (user, tile) pass
   // to exist - beyond 15 x predict_half_w items (168 000) `fits2` is false, and a 200 000-item model took the one-pass f32 kernel for
   // every user (27 s at 5M x 200K where the int8 pass takes a third)
-  const bool user_pass_certain = model->kind == RPHIP_MODEL_DENSE && ctx->predict_half && ctx->predict_user_tasks && !keep_dev &&
+  const bool user_pass_certain = model->kind == RPHIP_MODEL_DENSE && ctx->predict_half && ctx->predict_user_tasks &&
                                  (!exclude_history || Xpred->sorted_rows) && kc_i8 <= 256 && (int64_t)4 * kc_i8 <= (int64_t)P.n_items;
   const bool want_i8 = ctx->predict_int8 && (fits2 || user_pass_certain) && (model->ld % 16) == 0;
   const int Kc = want_i8 && kc_i8 <= 512 && (int64_t)4 * kc_i8 <= (int64_t)P.n_items ? kc_i8 : ((Kp + 24 + 63) / 64) * 64;
@@ -2183,14 +2184,14 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
   // (every other route - the (user, tile) first pass, its rescoring, the one-pass kernel, a rebuild of the
   // quantised copy from B - reads the f32 rows at once and waits for the gather here)
   const bool per_user_first_pass = two_pass && want_i8 && Kc == kc_i8 && model->B16 && model->b16_kind == 2 && !model->b16_failed &&
-                                   ctx->predict_user_tasks && !keep_dev && Kc <= 256 && (!exclude_history || Xpred->sorted_rows);
+                                   ctx->predict_user_tasks && Kc <= 256 && (!exclude_history || Xpred->sorted_rows);
   if (!per_user_first_pass) RP_TRY(rp_model_gather_wait(ctx, model, true));
   if (two_pass) {
     const rphip_model* mm = model;  // (the quantised copy is built on first use: mutable members, under the context's lock)
     RP_TRY(rp_model_half(ctx, mm, want_i8 && Kc == kc_i8 ? 2 : 1));
     if (mm->B16) {
       const bool i8 = mm->b16_kind == 2;
-      if (i8 && ctx->predict_user_tasks && !keep_dev && Kc <= 256 && (!exclude_history || Xpred->sorted_rows)) {
+      if (i8 && ctx->predict_user_tasks && Kc <= 256 && (!exclude_history || Xpred->sorted_rows)) {
         // ---- (round 5) first pass with ONE TASK PER USER (rp_predict_i8.hip): the sums of a column tile stay in registers, a running
         // threshold hands candidates to one list per user in LDS, the workgroup cuts it to Kc entries itself - no per-tile lists in
         // HBM, no merge kernel, one launch for all users of the call - then the rescoring and the fallback as before
@@ -2208,7 +2209,7 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
         int32_t* fail = a_nnz + n;
         int32_t* n_fail = fail + n;  // [0] count, [1] the first pass's ticket
         hipMemsetAsync(n_fail, 0, 8, st);
-        RP_TRY(rp_first_pass_i8(ctx, mm, Xpred, P, user_begin, n, Kc, exclude_history, a_idx, a_val, a_nnz, fail, n_fail, model->gather_ev != nullptr));
+        RP_TRY(rp_first_pass_i8(ctx, mm, Xpred, P, user_begin, n, Kc, exclude_history, a_idx, a_val, a_nnz, fail, n_fail, model->gather_ev != nullptr, keep_dev));
         RP_TRY(rp_model_gather_wait(ctx, model, true));  // (a gathered model: the f32 rows the rescoring reads arrive beside the first pass)
         rp_rescore_params R{};
         R.x_ptr = Xpred->x_ptr;

@@ -13,6 +13,7 @@ struct rp_i8_params {
   int col_begin;          // dense column slab: column 0 is item col_begin
   int cyc_nb, cyc_w, cyc_r;  // cyc_nb > 0: block-cyclic panels (rp_common.h)
   int exclude_history;
+  const uint8_t* keep;    // optional item filter [items of the whole model]: only items with keep[j] != 0 are candidates
   int user_begin, n_users;
   int Kc;                 // candidates per user for the rescoring (<= 256)
   int32_t* out_idx;       // [n_users][Kc] global column ids

@@ -210,6 +210,25 @@ __global__ void __launch_bounds__(RPU_THREADS, 8) k_predict_user_i8(rp_i8_params
         }
       }
 
+      // ---- an item filter (ExcludeItems / SelectItems of the reference's pipelines): the same way - sixteen bytes of the mask per thread
+      if (P.keep && active) {
+        const bool run16 = P.cyc_nb == 0 || (P.cyc_nb & 15) == 0;
+        const int g0 = rpu_l2g(P, t0 + 16 * tid);
+        if (run16 && (g0 & 3) == 0 && 16 * tid + 16 <= n_cols) {
+          const uint32_t* kw = reinterpret_cast<const uint32_t*>(P.keep + g0);
+          uint32_t k4[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) k4[q] = kw[q];
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if (((k4[e >> 2] >> (8 * (e & 3))) & 0xFFu) == 0) r[e] = 0.0f;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if (16 * tid + e < n_cols && P.keep[run16 ? g0 + e : rpu_l2g(P, t0 + 16 * tid + e)] == 0) r[e] = 0.0f;
+        }
+      }
+
       if (!have_tau) {
         // ---- a lower bound of the Kc-th best score: every thread's best, of those the R-th best of every wave that owns columns.
         // Where the history's columns could not be cleared above (a cyclic slab of odd panels) the best columns may be history items

@@ -204,3 +204,54 @@ def test_host_code_under_asan():
     assert b.returncode == 0, b.stdout[-2000:] + b.stderr[-2000:]
     r = subprocess.run([os.path.join(csrc, "rp_host_asan")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "host asan driver: ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_wrapper_teardown_in_any_order():
+    """The ctypes wrappers' native objects point into their context.  `Context.close()` closes live matrices, models and communicators
+    first (communicators last); and when the garbage collector finalises the context of an unreachable cycle BEFORE its children - it
+    may, and the weak references are gone by then - a child must not hand the library its dangling object (a core dump at interpreter
+    exit, seen after a failed GPU test whose traceback kept a model alive)."""
+    import weakref
+
+    from recpack_amd import _lib
+
+    calls = []
+
+    class FakeLib:
+        def __getattr__(self, name):
+            return lambda *a: calls.append(name) or 0
+
+    def make(cls, ctx):
+        o = object.__new__(cls)
+        o.ctx, o.handle, o._keep = ctx, object(), None
+        ctx._children.add(o)
+        return o
+
+    def context():
+        c = object.__new__(_lib.Context)
+        c.lib, c.handle, c._children = FakeLib(), object(), weakref.WeakSet()
+        return c
+
+    ctx = context()
+    comm, m, x = make(_lib.Comm, ctx), make(_lib.Model, ctx), make(_lib.DeviceCSR, ctx)
+    ctx.close()
+    assert sorted(calls[:2]) == ["rphip_csr_destroy", "rphip_model_destroy"] and calls[2:] == ["rphip_comm_destroy", "rphip_ctx_destroy"], calls
+    for o in (m, x, comm, ctx):
+        o.close()
+        assert o.handle is None
+    assert len(calls) == 4
+    # the collector's order: the context first, its weak set already empty
+    del calls[:]
+    ctx = context()
+    m = make(_lib.Model, ctx)
+    ctx._children = weakref.WeakSet()
+    ctx.close()
+    m.close()
+    assert calls == ["rphip_ctx_destroy"] and m.handle is None
+    # the usual order: children first
+    del calls[:]
+    ctx = context()
+    m = make(_lib.Model, ctx)
+    m.close()
+    ctx.close()
+    assert calls == ["rphip_model_destroy", "rphip_ctx_destroy"]

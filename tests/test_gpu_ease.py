@@ -686,6 +686,22 @@ def test_predict_user_route_corner_cases(hip):
                         np.testing.assert_array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b,
                                                       err_msg=f"{n_items} items, Kp {Kp}, exclude {excl}, route {route}")
                 assert want[2][3] == 0 and (want[2][[0, 1, 2, 5]] > 0).all()
+            # an item filter (round 6: the per-user pass clears the filtered columns in its registers; until then a filter meant the
+            # per-(user, tile) route): most items kept, a SelectItems of 150 and one of 30 items (fewer than Kp: short rows)
+            ctx.set_option("predict_user_tasks", 1)
+            for n_keep in (int(0.7 * n_items), 150, 30):
+                keep = np.zeros(n_items, dtype=np.uint8)
+                keep[rng.choice(n_items, size=n_keep, replace=False)] = 1
+                for excl in (True, False):
+                    ctx.set_option("predict_half", 0)
+                    want = _lib.predict_topk(ctx, m, dX, 100, exclude_history=excl, item_keep=keep)
+                    ctx.set_option("predict_half", 1)
+                    got = _lib.predict_topk(ctx, m, dX, 100, exclude_history=excl, item_keep=keep)
+                    assert _lib.predict_stats(ctx)["per_user_first_pass"]
+                    for a, b in zip(got, want):
+                        np.testing.assert_array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b,
+                                                      err_msg=f"{n_items} items, {n_keep} kept, exclude {excl}")
+                    assert keep[got[0][got[0] >= 0]].all() and got[2].max() <= min(100, n_keep)
         finally:
             ctx.set_option("predict_half", 1)
             ctx.set_option("predict_user_tasks", 1)
