@@ -428,7 +428,7 @@ def parity_verdict(args, ctx, device, indptr_t, indices_t, shape, knn_model, eas
     return out
 
 
-def roofline_ease(tm, I, world, steps, dist_stats, nnz, U, Kp):
+def roofline_ease(tm, I, world, steps, dist_stats, nnz, U, Kp, k9_stats=None):
     """The EASE solve against the MFMA peak.  One rank: K5 (Cholesky) + K6 (inverse) of rphip_ease_fit, n^3 flop by SURVEY.md
     section 8(d) (n padded to 128).  N > 1: the symmetric block sweeps of rphip_ease_fit_dist, the rank's own products as counted
     by the library (n^3 / world + the T products).  The products run on the 16-bit matrix pipe with each fp32 operand cut into two
@@ -460,18 +460,25 @@ def roofline_ease(tm, I, world, steps, dist_stats, nnz, U, Kp):
     if k9["launches"]:
         # K9 beside it.  Since round 4 the first pass streams the INT8 copy of B's rows (1 byte per column per interaction) for a
         # candidate list of Kc = 192 (Kp = 100) and the second pass gathers the candidates' f32 entries for the exact rescoring
-        # (4 bytes per candidate per interaction, a 64-byte line each at worst); the ~1.5 % of users whose list proves nothing
-        # take the one-pass kernel on the f32 rows (4*I bytes per interaction; priced at that share).  `bytes_streamed` / time
+        # (4 bytes per candidate per interaction, a 64-byte line each at worst); the users whose list proves nothing (1 %) read the
+        # int8 rows once more for a list of 256 (round 6), and who is still unproven (0.3 %) takes the one-pass kernel on the f32
+        # rows (4*I bytes per interaction).  Both are priced at their MEASURED share of the users (rphip_predict_stats of the last
+        # timed step; their histories are longer than the average, so this understates their bytes).  `bytes_streamed` / time
         # against the HBM peak is the roofline of what the kernels read; at half the bytes of the fp16 pass the first pass is no
         # longer bound by them alone.  The 4*I*nnz no-reuse model of SURVEY.md 8(d) prices f32 rows that the
         # kernel no longer reads - kept as `model_bytes_f32_rows` for reference only.
         ms = k9["ms"] / steps
         kc = ((Kp + 92 + 63) // 64) * 64
-        fail_share = 0.015
-        streamed = 1.0 * I * nnz / world + 4.0 * kc * nnz / world + fail_share * 4.0 * I * nnz / world + 8.0 * U * Kp
+        two_pass = bool(k9_stats) and k9_stats.get("users", -1) > 0
+        fail_share = round(k9_stats["exact_pass_users"] / k9_stats["users"], 5) if two_pass else 0.0
+        second_share = round(k9_stats["second_list_users"] / k9_stats["users"], 5) if two_pass else 0.0
+        streamed = (1.0 + second_share) * I * nnz / world + 4.0 * kc * nnz / world + fail_share * 4.0 * I * nnz / world + 8.0 * U * Kp
         out["k9_predict"] = {"ms_per_step": round(ms, 2), "bytes_streamed": streamed,
                              "bytes_streamed_what": f"1*I*nnz (int8 rows of B, first pass) + 4*Kc*nnz (candidates' f32 entries, Kc = {kc}) + "
-                                                    f"{fail_share}*4*I*nnz (users without a proof: the one-pass kernel) + 8*U*Kp (output)",
+                                                    f"{second_share}*1*I*nnz (users without a proof: a second list of 256) + "
+                                                    f"{fail_share}*4*I*nnz (still unproven: the one-pass kernel) + 8*U*Kp (output); "
+                                                    "the two shares are the measured shares of the USERS (not priced when unknown: N > 1)",
+                             "users": k9_stats if two_pass else None,
                              "GBps": round(streamed / (ms * 1e-3) / 1e9, 1),
                              "frac_of_hbm_peak": round(streamed / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              "model_bytes_f32_rows": 4.0 * I * nnz / world + 8.0 * U * Kp,
@@ -811,6 +818,7 @@ def main():
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             _lib.predict_topk_dev(ctx, em, dX, Kp, e_idx, e_val, e_nnz)  # K9
+            keep["k9_stats"] = _lib.predict_stats(ctx)  # (host fields of the context: which users took which pass, for `k9_predict`)
         else:
             dXe = _lib.DeviceCSR.from_device(ctx, indptr_t, indices_t, (U, I))  # (the ItemKNN shard holds its own rows of X^T only)
             state["collective"] = "distributed EASE solve (rphip_ease_fit_dist: pivot broadcasts, panel exchange)"
@@ -1042,7 +1050,7 @@ def main():
         if ease_on:
             # the headline roofline is the DOMINANT kernel's: the EASE solve (two thirds of the step) against the dense 16-bit MFMA peak;
             # the HBM-bound ItemKNN kernels (K8, the SpGEMM instances) follow under `roofline_hbm`
-            re_ = roofline_ease(tm, I, world, args.steps, _lib.ease_fit_dist_stats(ctx) if world > 1 else None, nnz, U, Kp)
+            re_ = roofline_ease(tm, I, world, args.steps, _lib.ease_fit_dist_stats(ctx) if world > 1 else None, nnz, U, Kp, keep.get("k9_stats"))
             hbm = result.pop("roofline")
             k9 = re_.pop("k9_predict", None)
             re_["share_of_step"] = round(re_["solve_ms_per_step"] / (sec_per_step * 1e3), 4)

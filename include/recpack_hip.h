@@ -134,6 +134,11 @@ int rphip_ctx_trim(rphip_ctx* ctx);
  *                       score to ONE candidate list in LDS and cuts it to Kc entries itself - no per-tile lists, no merge kernel.  0: one
  *                       task per (user, column tile) and a merge (round 4; also taken when history removal meets unsorted rows, and for
  *                       candidate lists longer than 256; until round 6 also with an item filter).  The results are identical either way.
+ *   "predict_second_list"  1 (default) | 0 | n > 1.  With "predict_user_tasks": the users whose candidate list proved nothing (1 - 3 %:
+ *                       history removal and item filters take the best columns away) go through both passes once more, alone, with a
+ *                       list of 256 candidates, before the exact one-pass kernel takes who is left (it reads four times the bytes per
+ *                       row).  Users with more than n history items (1: 1024) skip it: a workgroup walks a user alone, and among ten
+ *                       thousand users a long one would be the whole launch.  The results are identical either way.
  *   "comm_broadcast_split"  1 (default) | 0.  Broadcasts of 8 MiB and more among MORE than two ranks travel as scatter + all-gather
  *                       (grouped point-to-point sends on RCCL: no link of a fully connected xGMI node carries more than 2 / W of the
  *                       message); 0: the transport's own broadcast for every size.  bench.py switches it off when operation 4 of

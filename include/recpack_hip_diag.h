@@ -50,11 +50,12 @@ int rphip_model_adopt_gather(rphip_model* dst, rphip_model* src);
  * parts from the f32 matrix passed with the int8 rows (tools/dist_rank_emulate.py subtracts it). */
 int rphip_predict_owner_stats(rphip_ctx* ctx, int64_t* out4);
 
-/* The last rphip_predict_topk* call of this context on one GPU: out4[0] users the two-pass predict could not prove from its candidate list
- * (they were served by the exact one-pass kernel: same results, three times the traffic), [1] users of the call, [2] candidates per user,
- * [3] 1 when the first pass was the one-task-per-user kernel (rp_predict_i8.hip).  [0] = [1] = -1: the call did not take the two-pass route.
+/* The last rphip_predict_topk* call of this context on one GPU: out6[0] users the two-pass predict could not prove from its candidate
+ * lists (they were served by the exact one-pass kernel: same results, three times the traffic), [1] users of the call, [2] candidates per
+ * user, [3] 1 when the first pass was the one-task-per-user kernel (rp_predict_i8.hip), [4] users that were given a second list (256
+ * candidates), [5] those of them it proved.  [0] = [1] = -1: the call did not take the two-pass route.
  * (tests/test_gpu_ease.py: a tiling whose last wave owns four threads must not send every user to the exact pass - round 6.) */
-int rphip_predict_stats(rphip_ctx* ctx, int64_t* out4);
+int rphip_predict_stats(rphip_ctx* ctx, int64_t* out6);
 
 #ifdef __cplusplus
 }

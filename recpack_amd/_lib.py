@@ -834,10 +834,12 @@ def predict_owner_stats(ctx: Context) -> dict:
 
 def predict_stats(ctx: Context) -> dict:
     """The last single-GPU ``predict_topk*`` of this context (diagnostic): users the two-pass predict sent to the exact pass, users of the
-    call (both -1 when the call took another route), candidates per user, whether the first pass was the per-user int8 kernel."""
-    out = np.zeros(4, dtype=np.int64)
+    call (both -1 when the call took another route), candidates per user, whether the first pass was the per-user int8 kernel, how many
+    users were given a second, longer list and how many of them it proved."""
+    out = np.zeros(6, dtype=np.int64)
     check(ctx.lib.rphip_predict_stats(ctx.handle, _np_ptr(out)))
-    return {"exact_pass_users": int(out[0]), "users": int(out[1]), "candidates_per_user": int(out[2]), "per_user_first_pass": bool(out[3])}
+    return {"exact_pass_users": int(out[0]), "users": int(out[1]), "candidates_per_user": int(out[2]), "per_user_first_pass": bool(out[3]),
+            "second_list_users": int(out[4]), "second_list_proven": int(out[5])}
 
 
 def ease_fit_dist_stats(ctx: Context) -> dict:

@@ -317,6 +317,9 @@ extern "C" int rphip_ctx_set_option(rphip_ctx* ctx, const char* name, int64_t va
     ctx->predict_int8 = value ? 1 : 0;
   } else if (!strcmp(name, "predict_user_tasks")) {
     ctx->predict_user_tasks = value ? 1 : 0;
+  } else if (!strcmp(name, "predict_second_list")) {
+    ctx->predict_second_list = value ? 1 : 0;
+    ctx->predict_second_list_hist = value > 1 ? (int)std::min<int64_t>(value, 1 << 30) : 1024;
   } else if (!strcmp(name, "comm_broadcast_split")) {
     ctx->comm_broadcast_split = value ? 1 : 0;
   } else if (!strcmp(name, "predict_half_tile")) {

@@ -110,7 +110,9 @@ struct rphip_ctx {
   int predict_half_w = 11200;  // columns per tile of that first pass (0: the model's own tiling, one workgroup per CU)
   int predict_int8 = 1;      // ... on int8 rows (one scale per row) instead of fp16 ones: half the bytes again, a longer candidate list
   int predict_user_tasks = 1;  // ... with one task per USER (rp_predict_i8.hip) instead of one per (user, column tile) + a merge kernel
-  int64_t predict_stats[4] = {-1, -1, 0, 0};  // the last single-GPU predict: users sent to the exact pass, users of the call (-1: not the two-pass route), Kc, 1 = per-user first pass
+  int predict_second_list = 1;  // ... and users without a proof try once more with a list of 256 before the exact pass takes them
+  int predict_second_list_hist = 1024;  // ... if their history is no longer than this (one workgroup per user: a long user would be the whole launch)
+  int64_t predict_stats[6] = {-1, -1, 0, 0, 0, 0};  // the last single-GPU predict: users sent to the exact pass, users of the call (-1: not the two-pass route), Kc, 1 = per-user first pass, users given a second list, of them proven by it
   int64_t owner_stats[4] = {0, 0, 0, 0};  // the last rphip_predict_topk_owner: users without a proof (all ranks / this rank), Kc, loop-back: us of the stand-in for the others' parts
   int comm_broadcast_split = 1;  // a broadcast of >= 8 MiB among more than two ranks travels as scatter + all-gather (rp_comm_broadcast)
   int pw_wt32 = 4096;        // tile width of the 32-bit sums: 2048 or 4096 (tuning)

@@ -667,6 +667,7 @@ struct rp_rescore_params {
   int32_t* out_nnz;
   int32_t* fail_list;  // users whose list does not prove its top-Kp (ul + fail_base); count in *n_fail
   int fail_base;
+  const int32_t* user_list;  // optional (mode 0): row k of the candidate arrays belongs to user user_begin + user_list[k]; the outputs are the user's
   int32_t* n_fail;
   // (round 5) the rescoring split between the owners of the candidates' columns (rphip_predict_topk_owner), MODE of the kernel:
   //   1  B holds THIS rank's columns only (col_begin / n_own_cols or cyc_*): the exact sums of the candidates it owns go to
@@ -687,10 +688,11 @@ __global__ void __launch_bounds__(256) k_predict_rescore(rp_rescore_params P) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float* se = reinterpret_cast<float*>(smem) + (size_t)wv * 2 * 64 * NQ;  // exact scores, then columns
   int* sc = reinterpret_cast<int*>(se + 64 * NQ);
-  for (int ul = blockIdx.x * 4 + wv; ul < P.n_users; ul += gridDim.x * 4) {
+  for (int row = blockIdx.x * 4 + wv; row < P.n_users; row += gridDim.x * 4) {
+    const int ul = (MODE == 0 && P.user_list) ? P.user_list[row] : row;
     const int u = P.user_begin + ul;
     const int hs = P.x_ptr[u], he = P.x_ptr[u + 1];
-    const int nc = P.cand_nnz[ul];
+    const int nc = P.cand_nnz[row];
     if (nc < 0) continue;  // (the first pass per user gave this one to the fallback list itself: his candidate list overflowed)
     int col[NQ], loc[NQ];
     bool mine[NQ];  // (mode 1: the candidate's column is this rank's)
@@ -700,8 +702,8 @@ __global__ void __launch_bounds__(256) k_predict_rescore(rp_rescore_params P) {
     for (int q = 0; q < NQ; ++q) {
       const int k = lane + 64 * q;
       const bool on = k < nc;
-      col[q] = on ? P.cand_idx[(long long)ul * P.Kc + k] : -1;
-      av[q] = on ? P.cand_val[(long long)ul * P.Kc + k] : -3.0e38f;
+      col[q] = on ? P.cand_idx[(long long)row * P.Kc + k] : -1;
+      av[q] = on ? P.cand_val[(long long)row * P.Kc + k] : -3.0e38f;
       if (on) amin = fminf(amin, av[q]);
       int l = 0;
       bool own = true;
@@ -1862,6 +1864,8 @@ static int rp_model_half(rphip_ctx* ctx, const rphip_model* m, int kind) {
   return RPHIP_OK;
 }
 
+constexpr int RPHIP_KC2 = 256;  // candidates per user of the second list (the per-user pass holds no longer one)
+
 template <int NQ, int MODE = 0>
 static void rp_launch_rescore(rphip_ctx* ctx, const rp_rescore_params& R) {
   const int grid = (int)std::min<int64_t>(rp_cdiv(R.n_users, 4), (int64_t)ctx->n_cu * 8);
@@ -1879,10 +1883,11 @@ static void rp_launch_rescore_kc(rphip_ctx* ctx, const rp_rescore_params& R) {  
 
 // The first pass with one task per user (rp_predict_i8.hip) on the int8 rows of `mm`: approximate top-Kc of users
 // [user_begin, user_begin + n) into a_idx / a_val [n][Kc] and a_nnz [n] (-1: the user's list overflowed - he is appended to `fail`
-// by his local id).  n_fail: [0] the fail list's count, [1] the pass's ticket (both zeroed by the caller).
+// by his local id).  n_fail: [0] the fail list's count, [1] the pass's ticket (both zeroed by the caller).  user_list: the pass serves
+// the n users user_begin + user_list[k] instead, row k of the outputs is the k-th of them (the second list of the unproven users).
 static int rp_first_pass_i8(rphip_ctx* ctx, const rphip_model* mm, const rphip_csr* Xpred, const rp_pred_params& P, int64_t user_begin, int64_t n,
                             int Kc, int exclude_history, int32_t* a_idx, float* a_val, int32_t* a_nnz, int32_t* fail, int32_t* n_fail,
-                            bool leave_room, const uint8_t* keep_dev = nullptr) {
+                            bool leave_room, const uint8_t* keep_dev = nullptr, const int32_t* user_list = nullptr, int max_hist = 0) {
   rp_i8_params U8;
   U8.x_ptr = Xpred->x_ptr;
   U8.x_idx = Xpred->x_idx;
@@ -1899,6 +1904,8 @@ static int rp_first_pass_i8(rphip_ctx* ctx, const rphip_model* mm, const rphip_c
   U8.keep = keep_dev;
   U8.user_begin = (int)user_begin;
   U8.n_users = (int)n;
+  U8.user_list = user_list;
+  U8.max_hist = max_hist;
   U8.Kc = Kc;
   U8.out_idx = a_idx;
   U8.out_val = a_val;
@@ -2056,7 +2063,7 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
   if (n == 0) return RPHIP_OK;
   hipStream_t st = ctx->stream;
   ctx->predict_stats[0] = ctx->predict_stats[1] = -1;
-  ctx->predict_stats[2] = ctx->predict_stats[3] = 0;
+  ctx->predict_stats[2] = ctx->predict_stats[3] = ctx->predict_stats[4] = ctx->predict_stats[5] = 0;
   hipMemsetAsync(idx_dev, 0xFF, (size_t)n * Kp * 4, st);
   hipMemsetAsync(val_dev, 0, (size_t)n * Kp * 4, st);
   hipMemsetAsync(nnz_dev, 0, (size_t)n * 4, st);
@@ -2199,7 +2206,7 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
         const int64_t FCH = T == 1 ? n : std::min<int64_t>(n, 16384);  // users per launch of the fallback: bounds its per-tile lists
         const size_t szF = T > 1 ? (size_t)FCH * T * Kp : 0;
         char* sb = nullptr;
-        RP_TRY(rp_scratch(ctx, 14, (szA + szF) * 8 + (size_t)FCH * T * 4 + (size_t)n * 8 + 256, (void**)&sb));
+        RP_TRY(rp_scratch(ctx, 14, (szA + szF) * 8 + (size_t)FCH * T * 4 + (size_t)n * 12 + 256, (void**)&sb));
         int32_t* a_idx = (int32_t*)sb;
         float* a_val = (float*)(sb + szA * 4);
         int32_t* t_idx = (int32_t*)(sb + szA * 8);
@@ -2207,9 +2214,12 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
         int32_t* t_nnz = (int32_t*)(sb + (szA + szF) * 8);
         int32_t* a_nnz = t_nnz + FCH * T;
         int32_t* fail = a_nnz + n;
-        int32_t* n_fail = fail + n;  // [0] count, [1] the first pass's ticket
-        hipMemsetAsync(n_fail, 0, 8, st);
+        int32_t* n_fail = fail + n;  // [0] count, [1] the first pass's ticket, [2] the count after the first pass (the overflowed lists);
+        int32_t* n_fail2 = n_fail + 4;  // the same two words of the second list's passes
+        int32_t* fail2 = n_fail + 16;   // [n] the users the exact pass serves when a second list was tried
+        hipMemsetAsync(n_fail, 0, 64, st);
         RP_TRY(rp_first_pass_i8(ctx, mm, Xpred, P, user_begin, n, Kc, exclude_history, a_idx, a_val, a_nnz, fail, n_fail, model->gather_ev != nullptr, keep_dev));
+        RP_HIP(hipMemcpyAsync(n_fail + 2, n_fail, 4, hipMemcpyDeviceToDevice, st));
         RP_TRY(rp_model_gather_wait(ctx, model, true));  // (a gathered model: the f32 rows the rescoring reads arrive beside the first pass)
         rp_rescore_params R{};
         R.x_ptr = Xpred->x_ptr;
@@ -2249,13 +2259,47 @@ static int rp_predict_topk_impl(rphip_ctx* ctx, const rphip_model* model, const 
           if (mlds_p > 160 * 1024 || T * Kp >= RPS_FLAG) RP_FAIL(RPHIP_ELIMIT, "Kp=%d with %d column tiles needs %zu bytes of LDS for the merge", Kp, T, mlds_p);
           RP_HIP(hipFuncSetAttribute((const void*)k_predict_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds_p));
         }
-        int h_fail = 0;
-        RP_HIP(hipMemcpyAsync(&h_fail, n_fail, 4, hipMemcpyDeviceToHost, st));
+        int h3[3] = {0, 0, 0};
+        RP_HIP(hipMemcpyAsync(h3, n_fail, 12, hipMemcpyDeviceToHost, st));
         RP_HIP(hipStreamSynchronize(st));
-        ctx->predict_stats[0] = h_fail;
+        int h_fail = h3[0];
+        const int n_over = h3[2];
         ctx->predict_stats[1] = n;
         ctx->predict_stats[2] = Kc;
         ctx->predict_stats[3] = 1;
+        ctx->predict_stats[4] = ctx->predict_stats[5] = 0;
+        // ---- (round 6) a SECOND LIST for the users without a proof: the same two passes on them alone with the longest list the pass
+        // holds (256).  A proof fails when the Kp-th exact score does not clear the list's end by the user's error bound - long
+        // histories, history removal and item filters (the best columns gone) make that 1.5 - 3 % of the users, and the exact pass
+        // reads four times the bytes per row for them.  The users whose list overflowed gain nothing from it: they go straight on.
+        const int Kc2 = RPHIP_KC2;
+        const int64_t n2 = (int64_t)h_fail - n_over;
+        if (ctx->predict_second_list && Kc < Kc2 && n2 > 0 && (size_t)n2 * Kc2 <= szA && (int64_t)4 * Kc2 <= (int64_t)P.n_items) {
+          int32_t* b_idx = (int32_t*)sb;  // (the first lists are done with: their place)
+          float* b_val = (float*)(sb + (size_t)n2 * Kc2 * 4);
+          const int32_t* list2 = fail + n_over;
+          if (n_over > 0) RP_HIP(hipMemcpyAsync(fail2, fail, (size_t)n_over * 4, hipMemcpyDeviceToDevice, st));
+          RP_HIP(hipMemcpyAsync(n_fail2, n_fail + 2, 4, hipMemcpyDeviceToDevice, st));
+          RP_TRY(rp_first_pass_i8(ctx, mm, Xpred, P, user_begin, n2, Kc2, exclude_history, b_idx, b_val, a_nnz, fail2, n_fail2, false, keep_dev, list2, ctx->predict_second_list_hist));
+          rp_rescore_params R2 = R;
+          R2.cand_idx = b_idx;
+          R2.cand_val = b_val;
+          R2.n_users = (int)n2;
+          R2.Kc = Kc2;
+          R2.user_list = list2;
+          R2.fail_list = fail2;
+          R2.n_fail = n_fail2;
+          rp_launch_rescore<RPHIP_KC2 / 64>(ctx, R2);
+          RP_HIP(hipGetLastError());
+          int h2 = 0;
+          RP_HIP(hipMemcpyAsync(&h2, n_fail2, 4, hipMemcpyDeviceToHost, st));
+          RP_HIP(hipStreamSynchronize(st));
+          ctx->predict_stats[4] = n2;
+          ctx->predict_stats[5] = (int64_t)h_fail - h2;  // (proven by the second list)
+          h_fail = h2;
+          fail = fail2;
+        }
+        ctx->predict_stats[0] = h_fail;
         for (int64_t f0 = 0; f0 < h_fail; f0 += FCH) {
           const int64_t nf = std::min<int64_t>(FCH, h_fail - f0);
           const int grid = (int)std::min<int64_t>(nf * T, (int64_t)ctx->n_cu * 8), mgrid = (int)std::min<int64_t>(nf, (int64_t)ctx->n_cu * 8);
@@ -2930,10 +2974,10 @@ extern "C" int rphip_predict_owner_stats(rphip_ctx* ctx, int64_t* out4) {
 }
 
 // (diagnostic, include/recpack_hip_diag.h) the last single-GPU predict of this context
-extern "C" int rphip_predict_stats(rphip_ctx* ctx, int64_t* out4) {
+extern "C" int rphip_predict_stats(rphip_ctx* ctx, int64_t* out6) {
   RP_ENTER(ctx);
-  if (!ctx || !out4) RP_FAIL(RPHIP_EINVAL, "NULL argument");
-  ::memcpy(out4, ctx->predict_stats, sizeof(ctx->predict_stats));
+  if (!ctx || !out6) RP_FAIL(RPHIP_EINVAL, "NULL argument");
+  ::memcpy(out6, ctx->predict_stats, sizeof(ctx->predict_stats));
   return RPHIP_OK;
 }
 

@@ -15,8 +15,10 @@ struct rp_i8_params {
   int exclude_history;
   const uint8_t* keep;    // optional item filter [items of the whole model]: only items with keep[j] != 0 are candidates
   int user_begin, n_users;
+  const int32_t* user_list;  // optional: the pass serves users user_begin + user_list[k], k < n_users; outputs are indexed by k
+  int max_hist;           // > 0: a user with a longer history is not served (appended to the fail list): the second list leaves the long ones to the exact pass, whose tasks are (user, tile)
   int Kc;                 // candidates per user for the rescoring (<= 256)
-  int32_t* out_idx;       // [n_users][Kc] global column ids
+  int32_t* out_idx;       // [n_users][Kc] global column ids (row k: the k-th user of the pass)
   float* out_val;         // [n_users][Kc] approximate scores
   int32_t* out_nnz;       // [n_users]; -1 = the user's list overflowed (he is on the fail list)
   int32_t* fail_list;

@@ -109,12 +109,20 @@ __global__ void __launch_bounds__(RPU_THREADS, 8) k_predict_user_i8(rp_i8_params
       s_cnt[4] = s_cnt[5] = 0;
     }
     __syncthreads();
-    const int ul = s_cnt[2];
-    if (ul >= P.n_users) break;
+    const int slot = s_cnt[2];  // the user's place in this pass (the row of its outputs)
+    if (slot >= P.n_users) break;
+    const int ul = P.user_list ? P.user_list[slot] : slot;
     const int u = P.user_begin + ul;
     const int hs = P.x_ptr[u], he = P.x_ptr[u + 1];
     if (he <= hs) {  // no history: no score
-      if (tid == 0) P.out_nnz[ul] = 0;
+      if (tid == 0) P.out_nnz[slot] = 0;
+      continue;
+    }
+    if (P.max_hist > 0 && he - hs > P.max_hist) {  // (one workgroup walks all tiles of a user: among few users a long one is the whole launch)
+      if (tid == 0) {
+        P.out_nnz[slot] = -1;
+        P.fail_list[atomicAdd(P.n_fail, 1)] = P.fail_base + ul;
+      }
       continue;
     }
     float tau = -INFINITY;
@@ -334,12 +342,12 @@ __global__ void __launch_bounds__(RPU_THREADS, 8) k_predict_user_i8(rp_i8_params
         rpu_list_src src{lcol_g, lval_g, n};
         const int kp = rp_select_topk<RPU_THREADS>(src, n, Kc, sel);
         if (last) {
-          const long long o = (long long)ul * Kc;
+          const long long o = (long long)slot * Kc;
           rp_select_emit<RPU_THREADS>(n, sel, [&](int pos, int w) {
             P.out_idx[o + pos] = lcol[w];
             P.out_val[o + pos] = lval[w];
           });
-          if (tid == 0) P.out_nnz[ul] = kp;
+          if (tid == 0) P.out_nnz[slot] = kp;
         } else {
           rp_select_emit<RPU_THREADS>(n, sel, [&](int pos, int w) {
             tcol[pos] = lcol[w];
@@ -374,7 +382,7 @@ __global__ void __launch_bounds__(RPU_THREADS, 8) k_predict_user_i8(rp_i8_params
       }
     }
     if (failed && tid == 0) {
-      P.out_nnz[ul] = -1;  // (the rescoring skips this user)
+      P.out_nnz[slot] = -1;  // (the rescoring skips this user)
       P.fail_list[atomicAdd(P.n_fail, 1)] = P.fail_base + ul;
     }
   }

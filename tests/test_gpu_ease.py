@@ -734,8 +734,19 @@ def test_predict_user_route_keeps_its_users_on_ragged_tiles(hip, n_items):
             assert 0 <= st["exact_pass_users"] <= 0.06 * X.shape[0], st
             for a, b in zip(got, want):
                 np.testing.assert_array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+            # the second list (round 6): the unproven users once more with 256 candidates - it proves some of them, the exact pass takes
+            # the rest, the results do not move; switched off, everybody without a proof takes the exact pass at once
+            assert st["second_list_users"] > 0 and 0 < st["second_list_proven"] <= st["second_list_users"], st
+            ctx.set_option("predict_second_list", 0)
+            got0 = _lib.predict_topk(ctx, m, dX, 100, exclude_history=excl)
+            st0 = _lib.predict_stats(ctx)
+            ctx.set_option("predict_second_list", 1)
+            assert st0["second_list_users"] == 0 and st0["exact_pass_users"] == st["exact_pass_users"] + st["second_list_proven"], (st0, st)
+            for a, b in zip(got0, want):
+                np.testing.assert_array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
     finally:
         ctx.set_option("predict_half", 1)
+        ctx.set_option("predict_second_list", 1)
 
 
 def test_predict_topk_any_kp_dense(hip):
