@@ -173,3 +173,110 @@ def test_valued_fit_fuzz(seed, n_cases):
         assert abs(S.multiply(S_ref != 0) - S_ref.multiply(S != 0)).max() <= 1e-11 * max(1e-300, abs(S_ref).max()), what
         dX.close()
         m.close()
+
+
+@pytest.mark.parametrize("seed,n_cases", [(21, 14)])
+def test_dense_predict_routes_fuzz(seed, n_cases):
+    """K9 on random dense models: every two-pass route (per-user int8 first pass with its second list, the per-(user, tile) route, the
+    fp16 rows) against the one-pass kernel, bit for bit - catalogue widths around the first pass's tile and wave boundaries (ragged last
+    waves, one and several tiles), models of smooth, heavy-tailed and sparse rows, COLUMN SLABS at offsets that are no multiple of 4 or
+    16 (the filter's byte path, the history's lower bound with an offset), histories from empty to longer than the kernel's LDS copy
+    (2 048), history removal, item filters from 'nearly all' to a handful, Kp from 1 to the route's limit and past it."""
+    import torch
+
+    from recpack_amd import _lib, get_context
+    from recpack_amd import dist as rdist
+    from recpack_amd.synth import powerlaw_csr
+
+    ctx = get_context(0)
+    rng = np.random.default_rng(seed + SEED_OFFSET)
+    dev = torch.device("cuda", 0)
+
+    def same(a, b, what):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y, err_msg=what)
+
+    served = {"calls": 0, "per_user": 0, "users": 0, "by_lists": 0, "second": 0}
+    try:
+        for case in range(n_cases):
+            I = int(rng.choice([1040, 3136, 4100, 13344, 16400, 18560, 33000]))
+            U = int(rng.integers(50, 1200))
+            kind = str(rng.choice(["smooth", "heavy", "sparse", "ease", "ease"]))
+            g = torch.Generator(device=dev)
+            g.manual_seed(int(rng.integers(1 << 30)))
+            ld = (I + 63) // 64 * 64
+            fitted = None
+            if kind == "ease":  # a fitted model: lists that prove most users, a second list that proves some of the rest
+                Xf = powerlaw_csr(30000, I, 40.0 / I, seed=int(rng.integers(1 << 30))).to_scipy()
+                dXf = _lib.DeviceCSR.from_host(ctx, Xf.indptr, Xf.indices, Xf.shape)
+                fitted = _lib.ease_fit(ctx, dXf, 100.0, 0.0)
+                dXf.close()
+                B = rdist.model_dense_tensor(fitted, dev)
+            else:
+                B = torch.zeros((I, ld), dtype=torch.float32, device=dev)
+                B[:, :I] = torch.randn((I, I), generator=g, device=dev)
+            if kind == "heavy":
+                B[:, :I] = B[:, :I] ** 3 * torch.exp(2.0 * torch.randn((I, 1), generator=g, device=dev))
+            elif kind == "sparse":
+                B[:, :I] *= (torch.rand((I, I), generator=g, device=dev) < 0.05)
+            if fitted is None:
+                B[:, :I].fill_diagonal_(0.0)
+            d = np.minimum(rng.pareto(1.0, size=U) * 8, I // 2).astype(np.int64)
+            d[0] = 0
+            d[1] = min(I // 2, 2600)  # longer than the LDS copy of a history
+            rows = np.repeat(np.arange(U), d)
+            cols = rng.integers(0, I, size=rows.shape[0])
+            X = sp.csr_matrix((np.ones(rows.shape[0]), (rows, cols)), shape=(U, I))
+            X.sum_duplicates()
+            X.sort_indices()
+            dX = _lib.DeviceCSR.from_host(ctx, X.indptr, X.indices, X.shape)
+            slab = bool(rng.random() < 0.5)
+            if slab:
+                c0 = int(rng.choice([0, 3, 16, 37, 64])) if I > 2000 else 0
+                nc = int(min(I - c0, rng.choice([I - c0, 1024 + 13, 9000])))
+                nc = max(nc, 800)
+                nc = min(nc, I - c0)
+                model = _lib.Model.from_dense_cols(ctx, I, c0, nc, B[:, c0:])
+            else:
+                c0, nc = 0, I
+                model = _lib.Model.from_dense_cols(ctx, I, 0, I, B)
+            Kp = int(rng.choice([1, 10, 100, 160, 164, 165, 200]))
+            n_keep = int(rng.choice([I, int(0.8 * I), 300, 12]))
+            keep = np.zeros(I, dtype=np.uint8)
+            keep[rng.choice(I, size=n_keep, replace=False)] = 1
+            for excl in (False, True):
+                for flt in (None, keep):
+                    what = f"case {case}: U={U} I={I} {kind} slab=({c0},{nc}) Kp={Kp} excl={excl} keep={None if flt is None else n_keep}"
+                    ctx.set_option("predict_half", 0)
+                    want = _lib.predict_topk(ctx, model, dX, Kp, exclude_history=excl, item_keep=flt)
+                    ctx.set_option("predict_half", 1)
+                    for i8, user_tasks, second in ((1, 1, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1)):
+                        ctx.set_option("predict_int8", i8)
+                        ctx.set_option("predict_user_tasks", user_tasks)
+                        ctx.set_option("predict_second_list", second)
+                        got = _lib.predict_topk(ctx, model, dX, Kp, exclude_history=excl, item_keep=flt)
+                        same(got, want, what + f" i8={i8} user_tasks={user_tasks} second={second}")
+                        st = _lib.predict_stats(ctx)
+                        if (i8, user_tasks, second) == (1, 1, 1) and st["users"] > 0:
+                            served["calls"] += 1
+                            served["per_user"] += int(st["per_user_first_pass"])
+                            served["users"] += st["users"]
+                            served["by_lists"] += st["users"] - st["exact_pass_users"]
+                            served["second"] += st["second_list_proven"]
+                    assert want[2][0] == 0, what
+                    if flt is not None:
+                        assert keep[want[0][want[0] >= 0]].all(), what
+            model.close()
+            dX.close()
+            del B
+            if fitted is not None:
+                fitted.close()
+        # the routes must have SERVED users (a fuzz whose every user falls through to the exact pass would prove nothing)
+        print("dense predict fuzz:", served)
+        assert served["per_user"] >= served["calls"] // 3 and served["by_lists"] >= 0.2 * served["users"], served
+        assert served["second"] > 0 or SEED_OFFSET != 0, served  # (the committed seed reaches the second list; a soak seed may not)
+    finally:
+        ctx.set_option("predict_half", 1)
+        ctx.set_option("predict_int8", 1)
+        ctx.set_option("predict_user_tasks", 1)
+        ctx.set_option("predict_second_list", 1)
