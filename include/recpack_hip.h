@@ -167,6 +167,11 @@ int rphip_ctx_trim(rphip_ctx* ctx);
  *   "chol_panel"        0 (default: 32 tiles from 640 tiles = 81 920 items, 16 below) | 8 | 16 | 32 | 64: tiles per panel of that Cholesky
  *                       (tuning; the trailing update of a finished panel is one product with K = 128 x this).
  *   "inv_panel"         16 (default) | 8 | 32: tiles per column panel of N = L^-T in the inverse (tuning).
+ *   "inv_n22_early"     4 (default) | 0 | n.  The diagonal blocks of the inverse's first n panels - chains of small products that need
+ *                       only the factor's rows inside the panel - are issued during the factorisation, as soon as it has passed the
+ *                       panel, on a stream of their own: the inverse then starts with its products.  The other panels' chains run ahead
+ *                       of the inverse's products as before (all of them early: the factorisation loses more than the inverse gains).
+ *                       Same kernels, same results.
  *   "gemm_plane_cache"  1 (default) | 0 | bytes.  The inverse N = L^-T keeps the fp16 planes of the part of N it has finished
  *                       (4 bytes per element of an n x n square, from the context's block cache) instead of cutting it anew for
  *                       every panel: 1 = as much as the free memory holds (everything at 100 000 items; a prefix of the panels

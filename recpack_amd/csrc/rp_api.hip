@@ -342,6 +342,9 @@ extern "C" int rphip_ctx_set_option(rphip_ctx* ctx, const char* name, int64_t va
   } else if (!strcmp(name, "inv_panel")) {
     if (value != 8 && value != 16 && value != 32) RP_FAIL(RPHIP_EINVAL, "inv_panel must be 8, 16 or 32 tiles");
     ctx->inv_panel = (int)value;
+  } else if (!strcmp(name, "inv_n22_early")) {
+    if (value < 0 || value > 4096) RP_FAIL(RPHIP_EINVAL, "inv_n22_early must be 0 .. 4096 panels");
+    ctx->inv_n22_early = (int)value;
   } else if (!strcmp(name, "gemm_plane_cache")) {
     if (value < 0) RP_FAIL(RPHIP_EINVAL, "gemm_plane_cache must be >= 0");
     ctx->gemm_plane_cache = value;

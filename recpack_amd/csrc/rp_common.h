@@ -125,6 +125,7 @@ struct rphip_ctx {
   int chol_sub = 8;          // tiles per sub-panel of the blocked Cholesky (0: one level of panels)
   int chol_panel = 0;        // tiles per panel of the blocked Cholesky (0: 32 from 640 tiles, else 16)
   int inv_panel = 16;        // tiles per panel of N = L^-T
+  int inv_n22_early = 4;  // the diagonal-block chains of the inverse's first panels are issued during the factorisation, on a stream of their own (0: all ahead of the inverse's products, as until round 5)
   int64_t gemm_plane_cache = 1;  // the inverse keeps the planes of N = L^-T between its panels: 0 off, 1 as much as fits, > 1 at most that many bytes
   unsigned* gemm_amax_ring = nullptr;  // mode 2: [RP_AMAX_SLOTS][2] words, the operands' largest magnitudes per launch
   unsigned long long gemm_amax_seq = 0;

@@ -1619,11 +1619,14 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
   // ---- K5: left-looking blocked Cholesky.  The 128x128 diagonal block (its update and its float64 factorisation, one
   // workgroup for 0.26 ms) runs on a side stream while the rest of the panel is updated on the main stream.
   struct side_stream {  // released on every way out of this function
-    hipStream_t s = nullptr, t = nullptr;
-    hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr, f = nullptr;
+    hipStream_t s = nullptr, t = nullptr, u = nullptr;
+    hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr, f = nullptr, g = nullptr;
     ~side_stream() {
       if (s) hipStreamSynchronize(s);
       if (t) hipStreamSynchronize(t);
+      if (u) hipStreamSynchronize(u);
+      if (g) hipEventDestroy(g);
+      if (u) hipStreamDestroy(u);
       if (f) hipEventDestroy(f);
       if (a) hipEventDestroy(a);
       if (b) hipEventDestroy(b);
@@ -1641,6 +1644,10 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
   RP_HIP(hipEventCreateWithFlags(&side.d, hipEventDisableTiming));
   hipStream_t s2 = side.s, s3 = side.t;
   RP_HIP(hipEventCreateWithFlags(&side.f, hipEventDisableTiming));
+  RP_HIP(hipStreamCreateWithFlags(&side.u, hipStreamNonBlocking));
+  RP_HIP(hipEventCreateWithFlags(&side.g, hipEventDisableTiming));
+  hipStream_t s4 = side.u;
+  hipEvent_t e_rows = side.g;
   hipEvent_t e_panel = side.a, e_diag = side.b, e_fact = side.c, e_trail = side.d, e_cols = side.f;
   bool cols_pending = false;  // the later sub-panels' columns of the current panel are still being updated on s3
   bool trail_pending = false;  // a trailing update is in flight on s3
@@ -1657,6 +1664,71 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
   };
   tr_rec(st);
   float* part_diag = part_all + (size_t)8 * (n_pad - GT) * GT;  // the side stream's own split-K partials
+  // The diagonal blocks N22 of the inverse's panels (K6a below) are chains of ~30 small launches that depend on nothing but W and L
+  // inside the panel's own diagonal block.  They run AHEAD of the inverse's wide products on the side stream (issued in line they were
+  // 13 % of the inverse at 60 000 items with the chip idle) - except those of the first `inv_n22_early` panels (round 6), which the
+  // inverse's first products would wait for: they are issued during the factorisation, on a stream of their own, as soon as it has
+  // passed the panel's last block column (they write tiles above the diagonal, which the factorisation never touches).  At 100 000
+  // items: fit -6 ms with 4 panels; with ALL panels early the factorisation loses 40 ms and the inverse gains 16 (EXPERIMENTS e55).
+  struct ev_list {
+    std::vector<hipEvent_t> v;
+    ~ev_list() {
+      for (auto e : v) hipEventDestroy(e);
+    }
+  } n22_ev;
+  const int n_inv_panels = (int)rp_cdiv(nb, RP_INV_PANEL);
+  n22_ev.v.resize(n_inv_panels, nullptr);
+  for (auto& e : n22_ev.v) RP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  const int n22_f32 = rp_diag_env("RP_N22_PLANES") == nullptr ? 1 : 0;
+  const bool n22_early = n22_f32 == 1 && ctx->inv_n22_early > 0;  // (the plane path shares workspaces with the factorisation's products)
+  int n22_issued = 0;
+  auto n22 = [&](int P, hipStream_t sn) -> int {
+    const int pb = P * RP_INV_PANEL, pe = std::min(nb, pb + RP_INV_PANEL);
+    const int j = pb * GT;
+    for (int i = pb; i < pe; ++i) {
+      const int c0 = i * GT;
+      const float* Wi = W + (size_t)i * GT * GT;
+      // (N's diagonal block W_i^T is where the factorisation left it: k_potrf_trtri, wt)
+      if (i > pb) {
+        rp_gemm_args g{};
+        g.A = Nb + (long long)j * ld;
+        g.lda = ld;
+        g.B = A + (long long)c0 * ld;
+        g.ldb = ld;
+        g.C = T2;
+        g.ldc = GT;
+        g.M = c0 - j;
+        g.N = GT;
+        g.k0 = j;
+        g.k1 = c0;
+        g.kb_m = 1;  // row block r of N starts at column r
+        g.m_off = j;
+        g.alpha = 1.0f;
+        g.beta = 0.0f;
+        g.no_splitk = 1;
+        g.f32 = n22_f32;  // (round 4: these tiny products - at most 15 x 1 tiles - on the fp32 kernel: one launch each, no measuring pass, no memset)
+        RP_TRY(rp_gemm_nt(ctx, g, sn));
+        rp_gemm_args h{};
+        h.f32 = n22_f32;
+        h.A = T2;
+        h.lda = GT;
+        h.B = Wi;
+        h.ldb = GT;
+        h.C = Nb + (long long)j * ld + c0;
+        h.ldc = ld;
+        h.M = c0 - j;
+        h.N = GT;
+        h.k0 = 0;
+        h.k1 = GT;
+        h.alpha = -1.0f;
+        h.beta = 0.0f;
+        h.no_splitk = 1;
+        RP_TRY(rp_gemm_nt(ctx, h, sn));
+      }
+    }
+    RP_HIP(hipEventRecord(n22_ev.v[P], sn));
+    return RPHIP_OK;
+  };
   if (timed) rp_time_begin(ctx, &ev);
   int rc = RPHIP_OK;
   // Blocked in two levels: wide panels of 16 or 32 tiles are factored left-looking with K restricted to the panel
@@ -1812,6 +1884,13 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
     } else {
       RP_HIP(hipStreamWaitEvent(st, e_diag, 0));
     }
+    if (n22_early && k / RP_INV_PANEL < ctx->inv_n22_early && ((k + 1) % RP_INV_PANEL == 0 || k + 1 == nb)) {  // rows and W of the inverse's panel k / RP_INV_PANEL are final on `st`
+      RP_HIP(hipEventRecord(e_rows, st));
+      RP_HIP(hipStreamWaitEvent(s4, e_rows, 0));
+      rc = n22(k / RP_INV_PANEL, s4);
+      if (rc != RPHIP_OK) break;
+      ++n22_issued;
+    }
   }
   hipStreamSynchronize(s2);
   if (trace) {
@@ -1877,70 +1956,11 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
   }
   const int Kc = pc.K;
   if (timed) rp_time_begin(ctx, &ev);
-  // The panels' own diagonal blocks N22 - chains of ~50 small launches that depend on nothing but W and L inside the block - run
-  // AHEAD on the side stream (a few panels, so that the host gets to the main stream's products in time) beside the wide products
-  // of earlier panels: issued in line they were 13 % of the inverse at 60 000 items with the chip idle.
-  struct ev_list {
-    std::vector<hipEvent_t> v;
-    ~ev_list() {
-      for (auto e : v) hipEventDestroy(e);
-    }
-  } n22_ev;
-  const int n_inv_panels = (int)rp_cdiv(nb, RP_INV_PANEL);
-  n22_ev.v.resize(n_inv_panels, nullptr);
-  for (auto& e : n22_ev.v) RP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  RP_HIP(hipEventRecord(e_panel, st));  // (the factor is complete)
-  RP_HIP(hipStreamWaitEvent(s2, e_panel, 0));
-  const int n22_f32 = rp_diag_env("RP_N22_PLANES") == nullptr ? 1 : 0;
-  auto n22 = [&](int P) -> int {
-    const int pb = P * RP_INV_PANEL, pe = std::min(nb, pb + RP_INV_PANEL);
-    const int j = pb * GT;
-    for (int i = pb; i < pe; ++i) {
-      const int c0 = i * GT;
-      const float* Wi = W + (size_t)i * GT * GT;
-      // (N's diagonal block W_i^T is where the factorisation left it: k_potrf_trtri, wt)
-      if (i > pb) {
-        rp_gemm_args g{};
-        g.A = Nb + (long long)j * ld;
-        g.lda = ld;
-        g.B = A + (long long)c0 * ld;
-        g.ldb = ld;
-        g.C = T2;
-        g.ldc = GT;
-        g.M = c0 - j;
-        g.N = GT;
-        g.k0 = j;
-        g.k1 = c0;
-        g.kb_m = 1;  // row block r of N starts at column r
-        g.m_off = j;
-        g.alpha = 1.0f;
-        g.beta = 0.0f;
-        g.no_splitk = 1;
-        g.f32 = n22_f32;  // (round 4: these tiny products - at most 15 x 1 tiles - on the fp32 kernel: one launch each, no measuring pass, no memset)
-        RP_TRY(rp_gemm_nt(ctx, g, s2));
-        rp_gemm_args h{};
-        h.f32 = n22_f32;
-        h.A = T2;
-        h.lda = GT;
-        h.B = Wi;
-        h.ldb = GT;
-        h.C = Nb + (long long)j * ld + c0;
-        h.ldc = ld;
-        h.M = c0 - j;
-        h.N = GT;
-        h.k0 = 0;
-        h.k1 = GT;
-        h.alpha = -1.0f;
-        h.beta = 0.0f;
-        h.no_splitk = 1;
-        RP_TRY(rp_gemm_nt(ctx, h, s2));
-      }
-    }
-    RP_HIP(hipEventRecord(n22_ev.v[P], s2));
-    return RPHIP_OK;
-  };
-  constexpr int N22_AHEAD = 3;
-  int n22_issued = 0;
+  constexpr int N22_AHEAD = 3;  // (only when the chains were not issued during the factorisation: diagnostic plane path)
+  if (n22_issued < n_inv_panels) {
+    RP_HIP(hipEventRecord(e_panel, st));  // (the factor is complete)
+    RP_HIP(hipStreamWaitEvent(s2, e_panel, 0));
+  }
   // diagnostic (RP_INV_TRACE=1): where the inverse's main stream spends its time, summed over the panels
   std::vector<hipEvent_t> iv_ev;
   const bool itrace = rp_diag_env("RP_INV_TRACE") != nullptr;
@@ -1955,7 +1975,7 @@ int rp_spd_inverse(rphip_ctx* ctx, float* A, int n_pad, long long ld, int* info_
     const int pe = std::min(nb, pb + RP_INV_PANEL);
     const int j = pb * GT, w = (pe - pb) * GT;
     const int P = pb / RP_INV_PANEL;
-    for (; n22_issued < std::min(n_inv_panels, P + 1 + N22_AHEAD); ++n22_issued) RP_TRY(n22(n22_issued));
+    for (; n22_issued < std::min(n_inv_panels, P + 1 + N22_AHEAD); ++n22_issued) RP_TRY(n22(n22_issued, s2));
     RP_HIP(hipStreamWaitEvent(st, n22_ev.v[P], 0));
     iv_rec();  // 0: after the wait for N22
     if (j > 0) {

@@ -293,6 +293,15 @@ def test_ease_solve_driver_options(hip):
                 finally:
                     ctx.set_option(opt, back)
                 assert rel_max(B, ref) <= 2e-5, (opt, v, rel_max(B, ref))
+        # (round 6) WHEN the inverse's diagonal-block chains are issued - during the factorisation (the first 4 panels by default), all of
+        # them there, none of them - changes no bit: the same kernels on the same operands
+        for v in (0, 1000):
+            ctx.set_option("inv_n22_early", v)
+            try:
+                B = _lib.ease_fit(ctx, dX, 50.0, 0.0).dense_download()
+            finally:
+                ctx.set_option("inv_n22_early", 4)
+            np.testing.assert_array_equal(B.view(np.uint32), ref.view(np.uint32), err_msg=f"inv_n22_early={v}")
     finally:
         dX.close()
         ctx.trim()

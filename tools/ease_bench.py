@@ -22,7 +22,7 @@ if os.environ.get("RECPACK_GEMM_WIDE"):
     ctx.set_option("gemm_wide", int(os.environ["RECPACK_GEMM_WIDE"]))
 if os.environ.get("RECPACK_GEMM_SUPERTILE"):
     ctx.set_option("gemm_supertile", int(os.environ["RECPACK_GEMM_SUPERTILE"]))
-for name, opt in (("RECPACK_XCD_BLOCK", "gemm_xcd_block"), ("RECPACK_CHOL_PANEL", "chol_panel"), ("RECPACK_INV_PANEL", "inv_panel"), ("RECPACK_CHOL_SUB", "chol_sub_panel")):
+for name, opt in (("RECPACK_XCD_BLOCK", "gemm_xcd_block"), ("RECPACK_CHOL_PANEL", "chol_panel"), ("RECPACK_INV_PANEL", "inv_panel"), ("RECPACK_CHOL_SUB", "chol_sub_panel"), ("RECPACK_N22_EARLY", "inv_n22_early")):
     if os.environ.get(name):
         ctx.set_option(opt, int(os.environ[name]))
 dX = _lib.DeviceCSR.from_device(ctx, ip, ix, (U, I))
