@@ -1056,6 +1056,15 @@ constexpr int RP_POTRF_THREADS = 512;
 
 // wt != 0: the block of A receives W^T (upper triangular) instead of L: in the fused solve nothing reads a diagonal block of L again
 // (the column below it is solved with W), and W^T is what N = L^-T holds there - one k_transpose_128 launch per block less.
+// lane `src` of a wave's double, `src` a compile-time constant (the loops below are fully unrolled): two v_readlane_b32 instead of the two
+// ds_bpermute_b32 of __shfl - the 16 x 16 diagonal steps are one wave's serial chain of 304 such broadcasts, each a trip through the LDS
+// crossbar (round 6: the kernel is 60 % of the factorisation's chain where the chain is the bound, EXPERIMENTS e57)
+__device__ __forceinline__ double rp_bcast_f64(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)b, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), src);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __global__ void __launch_bounds__(RP_POTRF_THREADS) k_potrf_trtri(float* __restrict__ A, long long lda, float* __restrict__ W, int* __restrict__ info,
                                                                   int wt = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1079,14 +1088,14 @@ __global__ void __launch_bounds__(RP_POTRF_THREADS) k_potrf_trtri(float* __restr
       for (int c = 0; c < PB; ++c) x[c] = a[(c0 + r) * DS + c0 + c];  // (zero above the diagonal)
 #pragma unroll
       for (int j = 0; j < PB; ++j) {
-        const double d = __shfl(x[j], j);
+        const double d = rp_bcast_f64(x[j], j);
         if (lane == 0 && !(d > 0.0)) atomicExch(info, c0 + j + 1);
         const double djj = sqrt(d > 0.0 ? d : 1.0), rj = 1.0 / djj;
         if (lane == 0) rdg[j] = rj;
         x[j] = (r == j) ? djj : x[j] * rj;
 #pragma unroll
         for (int c = j + 1; c < PB; ++c) {
-          const double lcj = __shfl(x[j], c);
+          const double lcj = rp_bcast_f64(x[j], c);
           if (r >= c) x[c] -= x[j] * lcj;
         }
       }
@@ -1165,18 +1174,41 @@ __global__ void __launch_bounds__(RP_POTRF_THREADS) k_potrf_trtri(float* __restr
         double t = (r == c) ? 1.0 : 0.0;
 #pragma unroll
         for (int m = 0; m < r; ++m) t -= a[(r0 + r) * DS + r0 + m] * w[m];
-        w[r] = (r >= c) ? t * __shfl(rc, r) : 0.0;
+        w[r] = (r >= c) ? t * rp_bcast_f64(rc, r) : 0.0;
       }
       if (lane < PB) {
 #pragma unroll
         for (int r = 0; r < PB; ++r) wii[r * (PB + 1) + c] = w[r];
       }
     } else {  // T = L[I][0 : r0] W[0 : r0][0 : r0] (16 x r0), the other waves
-      for (int e = tid - 64; e < PB * r0; e += NT - 64) {
-        const int r = e / r0, col = e % r0;
-        double t = 0.0;
-        for (int m = col; m < r0; ++m) t += a[(r0 + r) * DS + m] * a[m * DS + col];
-        stg[r * PSTG + col] = t;
+      // (round 6) a thread owns ONE column of T and FOUR of its rows, and a wave walks m in step from the smallest column it holds: the
+      // entry of W is read once for four sums (consecutive columns over the lanes: no bank conflict), the four entries of L are the
+      // same address in every lane (a broadcast).  Until then a thread owned one entry and started at its own column: two strided
+      // reads per product, 46 of the kernel's 143 us (tools/potrf_phases.hip).  Every sum still adds its terms for m = col .. r0 - 1
+      // in that order (the steps before a lane's column add 0): the same bits.
+      for (int e0 = (wave - 1) * 64; e0 < 4 * r0; e0 += NT - 64) {
+        const int e = e0 + lane;
+        const bool on = e < 4 * r0;
+        const int rg = on ? e / r0 : 0, col = on ? e - rg * r0 : r0;
+        int m_lo = col;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) m_lo = min(m_lo, __shfl_xor(m_lo, d));
+        const double* lrow = a + (r0 + 4 * rg) * DS;
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll 8
+        for (int m = m_lo; m < r0; ++m) {  // (unrolled: the reads of eight steps are in flight before the first sum needs one)
+          const double w = (on && m >= col) ? a[m * DS + col] : 0.0;
+          t0 += lrow[m] * w;
+          t1 += lrow[DS + m] * w;
+          t2 += lrow[2 * DS + m] * w;
+          t3 += lrow[3 * DS + m] * w;
+        }
+        if (on) {
+          stg[(4 * rg + 0) * PSTG + col] = t0;
+          stg[(4 * rg + 1) * PSTG + col] = t1;
+          stg[(4 * rg + 2) * PSTG + col] = t2;
+          stg[(4 * rg + 3) * PSTG + col] = t3;
+        }
       }
     }
     __syncthreads();
