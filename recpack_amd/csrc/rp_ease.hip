@@ -1051,7 +1051,8 @@ constexpr int DS = GT + 1;  // LDS row stride in doubles
 // with 2 barriers each.  40 barriers of 8 waves.
 constexpr int PB = 16;                                    // block width inside the diagonal block
 constexpr int PSTG = GT + 1;                              // row stride of the staging rows
-constexpr size_t RP_POTRF_LDS = ((size_t)GT * DS + (size_t)PB * PSTG + (size_t)PB * (PB + 1) + PB) * sizeof(double);
+constexpr int PSTC = GT + 2;                              // ... when they hold the Cholesky's current block column transposed (16-byte rows)
+constexpr size_t RP_POTRF_LDS = ((size_t)GT * DS + (size_t)PB * PSTC + (size_t)PB * (PB + 1) + PB) * sizeof(double);
 constexpr int RP_POTRF_THREADS = 512;
 
 // wt != 0: the block of A receives W^T (upper triangular) instead of L: in the fused solve nothing reads a diagonal block of L again
@@ -1069,8 +1070,8 @@ __global__ void __launch_bounds__(RP_POTRF_THREADS) k_potrf_trtri(float* __restr
                                                                   int wt = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* a = reinterpret_cast<double*>(smem_raw);  // [128][DS]
-  double* stg = a + GT * DS;                         // [PB][PSTG]
-  double* wii = stg + PB * PSTG;                     // [PB][PB + 1]
+  double* stg = a + GT * DS;                         // [PB][PSTG] (the inverse) / [PB][PSTC] (the Cholesky's block column, k-major)
+  double* wii = stg + PB * PSTC;                     // [PB][PB + 1]
   double* rdg = wii + PB * (PB + 1);                 // [PB]: reciprocals of the current block's diagonal
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NT = RP_POTRF_THREADS;
@@ -1120,7 +1121,10 @@ __global__ void __launch_bounds__(RP_POTRF_THREADS) k_potrf_trtri(float* __restr
         x[k] = t * rdg[k];
       }
 #pragma unroll
-      for (int k = 0; k < PB; ++k) a[row * DS + c0 + k] = x[k];
+      for (int k = 0; k < PB; ++k) {
+        a[row * DS + c0 + k] = x[k];
+        stg[k * PSTC + tid] = x[k];  // (round 6) ... and k-major beside it: what the update below reads
+      }
     }
     __syncthreads();
     // the rest: a[i][j] -= sum_k a[i][c0 + k] a[j][c0 + k] for i >= j >= c0 + PB, in 4 x 4 blocks (bi >= bj)
@@ -1136,14 +1140,23 @@ __global__ void __launch_bounds__(RP_POTRF_THREADS) k_potrf_trtri(float* __restr
       for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+      // (round 6) the operands come from the k-major copy: a thread's four rows are 32 contiguous bytes there - two 16-byte reads -
+      // where the row-major block had them 4 x 129 doubles apart from the next thread's: eight 8-byte reads per step that met in
+      // the same banks eight ways (18 of the kernel's 113 us, tools/potrf_phases.hip).  Same products, same order: the same bits.
 #pragma unroll 4
       for (int k = 0; k < PB; ++k) {
         double li[4], lj[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          li[u] = a[(i0 + u) * DS + c0 + k];
-          lj[u] = a[(j0 + u) * DS + c0 + k];
-        }
+        const double2* pi = reinterpret_cast<const double2*>(stg + k * PSTC + 4 * bi);
+        const double2* pj = reinterpret_cast<const double2*>(stg + k * PSTC + 4 * bj);
+        const double2 i01 = pi[0], i23 = pi[1], j01 = pj[0], j23 = pj[1];
+        li[0] = i01.x;
+        li[1] = i01.y;
+        li[2] = i23.x;
+        li[3] = i23.y;
+        lj[0] = j01.x;
+        lj[1] = j01.y;
+        lj[2] = j23.x;
+        lj[3] = j23.y;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
